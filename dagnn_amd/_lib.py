@@ -1,0 +1,106 @@
+"""ctypes binding of libdagnn_hip.so (the C ABI declared in include/dagnn_hip.h).
+
+There is NO fallback: if the library cannot be loaded the product path raises.  Tensors are passed
+as raw device pointers; torch only owns the memory and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+from . import build as _build
+
+MAX_DIRS = 2
+MAX_GROUPS = 4
+
+DAGNN_OK = 0
+_ERRORS = {-22: "DAGNN_EINVAL (bad argument)", -28: "DAGNN_ENOSPC (workspace too small)"}
+
+
+class DagnnHipError(RuntimeError):
+    pass
+
+
+class Plan(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("bytes", C.c_size_t), ("N", C.c_int64), ("E", C.c_int64),
+                ("B", C.c_int64), ("num_edge_feats", C.c_int)]
+
+
+class GemmGroup(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("C", C.c_void_p)]
+
+
+class LayerArgs(C.Structure):
+    _fields_ = [("gi", C.c_void_p * MAX_DIRS), ("w_hh_t", C.c_void_p * MAX_DIRS), ("b_hh", C.c_void_p * MAX_DIRS),
+                ("w_key", C.c_void_p * MAX_DIRS), ("edge_gain", C.c_void_p * MAX_DIRS),
+                ("vid_bias", C.c_void_p * MAX_DIRS), ("h", C.c_void_p * MAX_DIRS), ("score", C.c_void_p * MAX_DIRS),
+                ("vid_mod", C.c_int), ("ld_h", C.c_int)]
+
+
+# every symbol include/dagnn_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "dagnn_version": (C.c_char_p, []),
+    "dagnn_plan_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int]),
+    "dagnn_plan_layout": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
+    "dagnn_plan_build": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    "dagnn_encode_ast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                   C.c_int, C.c_int64, C.c_int, C.c_void_p]),
+    "dagnn_gemm_nt_bias": (C.c_int, [C.POINTER(GemmGroup), C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p]),
+    "dagnn_pack_whh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "dagnn_recurrence_layer": (C.c_int, [C.POINTER(Plan), C.POINTER(LayerArgs), C.c_int, C.c_int, C.c_void_p]),
+    "dagnn_readout_max": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_int, C.c_void_p]),
+    "dagnn_gather_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_int, C.c_void_p]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load():
+    """Load (building first if the in-tree .so is missing or stale and hipcc is present)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = _build.LIB
+        if _build.is_stale():
+            try:
+                _build.build()
+            except Exception as exc:  # no hipcc and no prebuilt library: fail loudly
+                if not os.path.exists(path):
+                    raise DagnnHipError(
+                        "libdagnn_hip.so is missing and could not be built (%s). There is no CPU or "
+                        "PyTorch fallback for the DAGNN hot path." % exc) from exc
+        try:
+            lib = C.CDLL(path)
+        except OSError as exc:
+            raise DagnnHipError("cannot load %s: %s (no fallback path exists)" % (path, exc)) from exc
+        for name, (res, args) in SYMBOLS.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as exc:
+                raise DagnnHipError("%s does not export %s" % (path, name)) from exc
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+        return lib
+
+
+def check(code: int, what: str) -> None:
+    if code == DAGNN_OK:
+        return
+    if code <= -1000:
+        msg = "hipError_t %d" % (-code - 1000)
+    else:
+        msg = _ERRORS.get(code, "error %d" % code)
+    raise DagnnHipError("%s failed: %s" % (what, msg))

@@ -1,0 +1,132 @@
+"""Shared forward machinery of the three DAGNN modules (ogbg-code DAGNN, D-VAE NA and BN encoders).
+
+`run_stack` drives the HIP path for `L` stacked GRU layers in every requested direction:
+
+    for i in range(L):                      # stacked layers (loop 3 of dagnn.py:171)
+        gi[d] = u_i @ W_ih[d][i]^T + b_ih   # ONE batched fp32-MFMA GEMM per layer, all nodes
+        h[d][i] = recurrence(gi[d], ...)    # persistent per-(graph, direction) workgroups walk
+                                            # all topological layers (loops 1+2 of dagnn.py:145-157)
+
+which is the reference's loop nest `for d: for layer: for i:` re-ordered legally: layer i of the
+stack only needs layer i-1 at the SAME node (`dagnn.py:177,181`) and layer i at the predecessors,
+so finishing layer i-1 for all nodes first changes no value.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import engine
+from ._lib import DagnnHipError
+
+
+def round_up4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class DerivedCache(object):
+    """Caches tensors derived from parameters (packed / padded weights, folded edge gains) and
+    rebuilds them when any source parameter changed (in-place updates bump `_version`)."""
+
+    def __init__(self):
+        self._key = None
+        self._val = None
+
+    def get(self, params: Sequence[torch.Tensor], fn: Callable[[], object]):
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        if key != self._key:
+            with torch.no_grad():
+                self._val = fn()
+            self._key = key
+        return self._val
+
+
+def _pad_gate_rows(w: torch.Tensor, H: int, Hp: int) -> torch.Tensor:
+    """[3H, ...] -> [3Hp, ...] keeping the (r, z, n) blocks aligned; pad rows are zero."""
+    if Hp == H:
+        return w.contiguous()
+    out = w.new_zeros((3 * Hp,) + tuple(w.shape[1:]))
+    for g in range(3):
+        out[g * Hp:g * Hp + H] = w[g * H:(g + 1) * H]
+    return out
+
+
+def _pad_cols(w: torch.Tensor, cols: int) -> torch.Tensor:
+    if w.shape[-1] == cols:
+        return w.contiguous()
+    out = w.new_zeros(tuple(w.shape[:-1]) + (cols,))
+    out[..., :w.shape[-1]] = w
+    return out
+
+
+class CellParams(object):
+    """Device-side, kernel-ready parameters of one (direction, stacked layer) cell."""
+
+    __slots__ = ("w_ih", "b_ih", "w_hh_t", "b_hh", "w_key", "edge_gain", "vid_bias")
+
+
+def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: bool,
+                edge_w: Optional[torch.Tensor], vid_nodes: int) -> CellParams:
+    """Fold / pack one cell's parameters for the kernels.
+
+    attn_w is `attn_lin.weight` [1, dq + H (+ vid_nodes)]: the first dq entries multiply the query
+    (they cancel in the segment softmax, as does the bias), the next H the key h_j, and for the NA
+    variant the last `vid_nodes` the one-hot vertex id of the key (`dvae/dagnn.py:130-134`).
+    `edge_w` is `edge_encoder.weight` [H, R]; its bias is constant inside a segment and cancels.
+    """
+    Hp = round_up4(H)
+    c = CellParams()
+    wi = _pad_gate_rows(w_ih.detach().float(), H, Hp)
+    if in_is_hidden:
+        wi = _pad_cols(wi, Hp)
+    c.w_ih = wi
+    c.b_ih = _pad_gate_rows(b_ih.detach().float(), H, Hp)
+    whh = _pad_cols(_pad_gate_rows(w_hh.detach().float(), H, Hp), Hp)
+    c.w_hh_t = engine.pack_whh(whh)
+    c.b_hh = _pad_gate_rows(b_hh.detach().float(), H, Hp)
+    key = attn_w.detach().float()[0, dq:dq + H]
+    c.w_key = _pad_cols(key, Hp)
+    c.edge_gain = (edge_w.detach().float().t() @ key).contiguous() if edge_w is not None else None
+    c.vid_bias = attn_w.detach().float()[0, dq + H:dq + H + vid_nodes].contiguous() if vid_nodes else None
+    return c
+
+
+def run_stack(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tuple[int, int], CellParams],
+              dirs: Sequence[int], L: int, H: int, vid_nodes: int = 0) -> List[List[torch.Tensor]]:
+    """Hidden states h[d][i] ([N, H] each) of all stacked layers and directions."""
+    Hp = round_up4(H)
+    N = x.shape[0]
+    dev = x.device
+    h: List[List[Optional[torch.Tensor]]] = [[None] * L for _ in range(2)]
+    score = [torch.empty(N, dtype=torch.float32, device=dev) for _ in range(2)]
+    gi = [torch.empty(N, 3 * Hp, dtype=torch.float32, device=dev) if d in dirs else None for d in range(2)]
+    for i in range(L):
+        A = [x if i == 0 else h[d][i - 1] for d in dirs]
+        engine.gemm_nt_bias(A, [cells[(d, i)].w_ih for d in dirs], [cells[(d, i)].b_ih for d in dirs],
+                            out=[gi[d] for d in dirs])
+        pick = lambda name: [getattr(cells[(d, i)], name) if d in dirs else None for d in range(2)]  # noqa: E731
+        has_gain = all(cells[(d, i)].edge_gain is not None for d in dirs)
+        out = engine.recurrence_layer(plan, dirs, Hp, gi, pick("w_hh_t"), pick("b_hh"), pick("w_key"),
+                                      edge_gain=pick("edge_gain") if has_gain else None,
+                                      vid_bias=pick("vid_bias") if vid_nodes else None, vid_mod=vid_nodes,
+                                      score=score)
+        for d in dirs:
+            h[d][i] = out[d]
+    if Hp != H:
+        return [[h[d][i][:, :H] if h[d][i] is not None else None for i in range(L)] for d in range(2)]
+    return h  # type: ignore[return-value]
+
+
+def require_inference(module: torch.nn.Module) -> None:
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise NotImplementedError(
+            "the HIP recurrence has no backward pass yet: call the module under torch.no_grad() "
+            "(as the reference's eval loop does, ogbg-code/main_pyg.py:103) or freeze its parameters")
+
+
+def num_graphs_of(G) -> int:
+    ng = getattr(G, "num_graphs", None)
+    if isinstance(ng, int):
+        return ng
+    return int(G.batch[-1]) + 1 if G.batch.numel() else 0  # one D2H sync, like dagnn.py:137

@@ -1,0 +1,77 @@
+// Shared device/host helpers for libdagnn_hip (gfx950 / CDNA4 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dagnn_hip.h"
+
+#define DAGNN_WAVE 64
+
+#define DAGNN_CHECK_LAUNCH()                                   \
+    do {                                                       \
+        hipError_t e_ = hipGetLastError();                     \
+        if (e_ != hipSuccess) return DAGNN_EHIP(e_);           \
+    } while (0)
+
+// ------------------------------------------------------------------ plan layout (int32 words)
+// One allocation, offsets fixed by (N, E, B, R) so host and device agree without a header read.
+struct PlanLayout {
+    int64_t node_ptr, edge_ptr;      // [B+1] each
+    int64_t depth[2];                // [B]
+    int64_t order[2];                // [N]   node ids sorted by (graph, layer)
+    int64_t lstart[2];               // [N+B] per graph: depth_g+1 absolute positions into order
+    int64_t rowptr[2];               // [N+B] per graph: n_g+1 absolute offsets into col
+    int64_t col[2];                  // [E]   predecessor node id per CSR slot
+    int64_t eattr[2];                // [E*R] fp32 edge features in CSR order
+    int64_t items;                   // [2B]  (g*2+d) sorted by depth, deepest first
+    int64_t pos[2];                  // [N]   scratch: sorted position of each node
+    int64_t cursor[2];               // [N+B] scratch: fill cursors
+    int64_t eidx[2];                 // [E]   scratch: original edge id per CSR slot
+    int64_t tmp_col[2], tmp_eidx[2]; // [E]   scratch for the heavy-row rank sort
+    int64_t total;                   // words
+};
+
+__host__ __device__ inline int64_t dagnn_align4(int64_t w) { return (w + 3) & ~int64_t(3); }
+
+__host__ __device__ inline PlanLayout dagnn_plan_layout_words(int64_t N, int64_t E, int64_t B, int R) {
+    PlanLayout L;
+    int64_t o = 16;  // header words
+    auto take = [&](int64_t n) { int64_t r = o; o = dagnn_align4(o + n); return r; };
+    L.node_ptr = take(B + 1);
+    L.edge_ptr = take(B + 1);
+    for (int d = 0; d < 2; ++d) L.depth[d] = take(B);
+    for (int d = 0; d < 2; ++d) L.order[d] = take(N);
+    for (int d = 0; d < 2; ++d) L.lstart[d] = take(N + B);
+    for (int d = 0; d < 2; ++d) L.rowptr[d] = take(N + B);
+    for (int d = 0; d < 2; ++d) L.col[d] = take(E);
+    for (int d = 0; d < 2; ++d) L.eattr[d] = take(E * (int64_t)(R > 0 ? R : 0));
+    L.items = take(2 * B);
+    for (int d = 0; d < 2; ++d) L.pos[d] = take(N);
+    for (int d = 0; d < 2; ++d) L.cursor[d] = take(N + B);
+    for (int d = 0; d < 2; ++d) L.eidx[d] = take(E);
+    for (int d = 0; d < 2; ++d) L.tmp_col[d] = take(E);
+    for (int d = 0; d < 2; ++d) L.tmp_eidx[d] = take(E);
+    L.total = o;
+    return L;
+}
+
+// Plan header words
+enum { PH_N = 0, PH_E = 1, PH_B = 2, PH_R = 3, PH_MAGIC = 4 };
+#define DAGNN_PLAN_MAGIC 0x44414731  // "DAG1"
+
+// ------------------------------------------------------------------ wave-level reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,178 @@
+// gemm_f32.hip - C[M,Nc] = A[M,K] * W[Nc,K]^T + bias, fp32 in / fp32 MFMA accumulate.
+//
+// This is the input-side half of nn.GRUCell (W_ih u + b_ih, ogbg-code/model/dagnn.py:181) hoisted
+// out of the recurrence: u (the embedding x for the first stacked layer, the previous layer's
+// hidden states afterwards) is known for every node before that layer's recurrence starts, so it
+// is ONE batched GEMM per layer instead of one GEMV per frontier node.
+//
+// gfx950 design: v_mfma_f32_32x32x2_f32 (exact fp32, bit-equal to an fmaf chain - bf16/xf32 are
+// ruled out by the 1e-4 parity bound after hundreds of recurrent steps).  128x128x16 block tile,
+// 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles (64 accumulator registers).  Both operands
+// are K-contiguous in HBM ("NT"), loaded as float4 and stored k-major in LDS with a +4 pad so that
+// the per-MFMA fragment reads (lane&31 -> consecutive rows, lane>>5 -> k) are conflict-free
+// ds_read_b32.  Register prefetch + double-buffered LDS: one barrier per K tile.  Blocks are
+// remapped so that the Nc/128 column tiles of one row tile run on the same XCD and share A in L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 4;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmGroups {
+    const float* A[DAGNN_MAX_GROUPS];
+    const float* W[DAGNN_MAX_GROUPS];
+    const float* bias[DAGNN_MAX_GROUPS];
+    float* C[DAGNN_MAX_GROUPS];
+};
+
+// load one [128 x 16] K-contiguous tile slice owned by this thread: 2 float4 (rows r0, r0+64)
+template <bool VEC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t rows, int K, int ld, int64_t row0,
+                                          int k0, int tid, float4 (&v)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i;
+        const int64_t r = row0 + (idx >> 2);
+        const int k = k0 + (idx & 3) * 4;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows) {
+            const float* p = P + r * ld + k;
+            if (VEC && k + 3 < K) {
+                t = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (k < K) t.x = p[0];
+                if (k + 1 < K) t.y = p[1];
+                if (k + 2 < K) t.z = p[2];
+                if (k + 3 < K) t.w = p[3];
+            }
+        }
+        v[i] = t;
+    }
+}
+
+__device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const float4 (&v)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx >> 2, kq = (idx & 3) * 4;
+        S[(kq + 0) * LDT + r] = v[i].x;
+        S[(kq + 1) * LDT + r] = v[i].y;
+        S[(kq + 2) * LDT + r] = v[i].z;
+        S[(kq + 3) * LDT + r] = v[i].w;
+    }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) gemm_nt_bias_kernel(GemmGroups G, int64_t M, int Nc, int K, int lda, int ldw,
+                                                            int ldc, int tiles_m, int tiles_n) {
+    __shared__ float As[2][BK * LDT];
+    __shared__ float Bs[2][BK * LDT];
+    const int g = blockIdx.y;
+    const float* __restrict__ A = G.A[g];
+    const float* __restrict__ W = G.W[g];
+    const float* __restrict__ bias = G.bias[g];
+    float* __restrict__ C = G.C[g];
+
+    // XCD-aware, bijective remap: hardware puts block b on XCD b % 8; give each XCD a contiguous
+    // run of tiles so the tiles_n column tiles of a row tile hit the same L2.
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int tm = swz / tiles_n, tn = swz - tm * tiles_n;
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int fr = lane & 31, fk = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float4 ra[2], rb[2];
+    load_tile<VEC>(A, M, K, lda, m0, 0, tid, ra);
+    load_tile<VEC>(W, Nc, K, ldw, n0, 0, tid, rb);
+    store_tile(As[0], tid, ra);
+    store_tile(Bs[0], tid, rb);
+    __syncthreads();
+
+    const int nk = (K + BK - 1) / BK;
+    int cur = 0;
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) {
+            load_tile<VEC>(A, M, K, lda, m0, (t + 1) * BK, tid, ra);
+            load_tile<VEC>(W, Nc, K, ldw, n0, (t + 1) * BK, tid, rb);
+        }
+        const float* as = As[cur];
+        const float* bs = Bs[cur];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int krow = (2 * kk + fk) * LDT;
+            const float a0 = as[krow + wm + fr], a1 = as[krow + wm + 32 + fr];
+            const float b0 = bs[krow + wn + fr], b1 = bs[krow + wn + 32 + fr];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (t + 1 < nk) {
+            store_tile(As[cur ^ 1], tid, ra);
+            store_tile(Bs[cur ^ 1], tid, rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn + j * 32 + fr;
+        if (col >= Nc) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fk;
+                if (row < M) C[row * ldc + col] = acc[i][j][e] + bv;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dagnn_gemm_nt_bias(const dagnn_gemm_group* groups, int num_groups, int64_t M, int Nc, int K,
+                                  int lda, int ldw, int ldc, void* stream) {
+    if (!groups || num_groups <= 0 || num_groups > DAGNN_MAX_GROUPS) return DAGNN_EINVAL;
+    if (M < 0 || Nc <= 0 || K <= 0 || lda < K || ldw < K || ldc < Nc) return DAGNN_EINVAL;
+    if (M == 0) return DAGNN_OK;
+    GemmGroups G;
+    bool vec = (lda % 4 == 0) && (ldw % 4 == 0);
+    for (int g = 0; g < DAGNN_MAX_GROUPS; ++g) {
+        const dagnn_gemm_group& s = groups[g < num_groups ? g : 0];
+        if (!s.A || !s.W || !s.C) return DAGNN_EINVAL;
+        G.A[g] = s.A; G.W[g] = s.W; G.bias[g] = s.bias; G.C[g] = s.C;
+        vec = vec && (((uintptr_t)s.A & 15) == 0) && (((uintptr_t)s.W & 15) == 0);
+    }
+    const int64_t tiles_m64 = (M + BM - 1) / BM;
+    const int tiles_n = (Nc + BN - 1) / BN;
+    if (tiles_m64 * tiles_n >= (int64_t(1) << 31)) return DAGNN_EINVAL;
+    const int tiles_m = (int)tiles_m64;
+    dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)num_groups);
+    if (vec)
+        hipLaunchKernelGGL(gemm_nt_bias_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, G, M, Nc, K, lda, ldw,
+                           ldc, tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL(gemm_nt_bias_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, G, M, Nc, K, lda,
+                           ldw, ldc, tiles_m, tiles_n);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}

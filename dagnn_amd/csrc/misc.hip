@@ -1,0 +1,130 @@
+// misc.hip - HBM-bound row kernels around the recurrence: AST node encoder, weight packing,
+// output-node max read-out and the D-VAE fixed-stride row gather.  One wave (64 lanes) moves one
+// row; lanes read float4 so a 256-wide fp32 row is one coalesced 1 KiB access.
+#include "common.h"
+
+namespace {
+
+// out[v,:] = type_emb[x[v,0]] + attr_emb[x[v,1]] + depth_emb[min(depth[v], max_depth)]
+// (ogbg-code/utils.py:26-28).  depth is clamped in place like the reference does (:27).
+__global__ void __launch_bounds__(256) encode_ast_kernel(const int64_t* __restrict__ x, int64_t* depth,
+                                                          const float* __restrict__ type_emb,
+                                                          const float* __restrict__ attr_emb,
+                                                          const float* __restrict__ depth_emb, int max_depth,
+                                                          float* __restrict__ out, int ld_out, int64_t N, int H) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int H4 = H >> 2;
+    for (int64_t v = wave; v < N; v += nwaves) {
+        const int64_t t = x[2 * v], a = x[2 * v + 1];
+        int64_t dp = depth[v];
+        if (dp > max_depth) { dp = max_depth; if (lane == 0) depth[v] = dp; }
+        const float4* pt = reinterpret_cast<const float4*>(type_emb + t * H);
+        const float4* pa = reinterpret_cast<const float4*>(attr_emb + a * H);
+        const float4* pd = reinterpret_cast<const float4*>(depth_emb + dp * H);
+        float4* po = reinterpret_cast<float4*>(out + v * ld_out);
+        for (int c = lane; c < H4; c += 64) {
+            float4 u = pt[c], w = pa[c], z = pd[c], r;
+            // same association as the reference: (type + attr) + depth
+            r.x = (u.x + w.x) + z.x; r.y = (u.y + w.y) + z.y; r.z = (u.z + w.z) + z.z; r.w = (u.w + w.w) + z.w;
+            po[c] = r;
+        }
+    }
+}
+
+// Wt[k, c] = W[c, k]: [3H, H] -> [H, 3H], 32x32 LDS tile transpose.
+__global__ void __launch_bounds__(256) pack_whh_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                        int rows /*3H*/, int cols /*H*/) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        int r = by + j, c = bx + tx;
+        tile[j][tx] = (r < rows && c < cols) ? w[(int64_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        int c = bx + j, r = by + tx;  // output row = c (k), output col = r
+        if (c < cols && r < rows) wt[(int64_t)c * rows + r] = tile[tx][j];
+    }
+}
+
+// out[g, col_off + j] = max over output nodes v of graph g of h[v, j]  (dagnn.py:119-126,184-193).
+// Output nodes of direction `dir` are the layer-0 frontier of the OPPOSITE direction, which the
+// plan already holds as a contiguous range of order[1-dir].
+__global__ void __launch_bounds__(256) readout_max_kernel(const int32_t* __restrict__ plan, PlanLayout L, int dir,
+                                                           const float* __restrict__ h, int ld_h, int width,
+                                                           float* __restrict__ out, int ld_out, int col_off) {
+    const int g = blockIdx.x;
+    const int od = 1 - dir;
+    const int n0 = plan[L.node_ptr + g];
+    const int depth = plan[L.depth[od] + g];
+    const int32_t* ls = plan + L.lstart[od] + n0 + g;
+    const int32_t* order = plan + L.order[od];
+    const int p0 = depth > 0 ? ls[0] : 0, p1 = depth > 0 ? ls[1] : 0;
+    for (int j = threadIdx.x; j < width; j += blockDim.x) {
+        float m = 0.f;  // PyG scatter-max leaves rows nothing lands on at zero
+        for (int p = p0; p < p1; ++p) {
+            float v = h[(int64_t)order[p] * ld_h + j];
+            m = (p == p0) ? v : fmaxf(m, v);
+        }
+        out[(int64_t)g * ld_out + col_off + j] = m;
+    }
+}
+
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ h, int ld_h, int width,
+                                                           int stride, int node_off, float* __restrict__ out,
+                                                           int ld_out, int col_off) {
+    const int64_t g = blockIdx.x;
+    const float* src = h + (g * stride + node_off) * (int64_t)ld_h;
+    for (int j = threadIdx.x; j < width; j += blockDim.x) out[g * ld_out + col_off + j] = src[j];
+}
+
+}  // namespace
+
+extern "C" const char* dagnn_version(void) { return "dagnn_hip 0.1 gfx950"; }
+
+extern "C" int dagnn_encode_ast(const int64_t* x, int64_t* depth, const float* type_emb, const float* attr_emb,
+                                const float* depth_emb, int max_depth, float* out, int ld_out, int64_t N, int H,
+                                void* stream) {
+    if (N < 0 || H <= 0 || (H & 3) || (ld_out & 3) || ld_out < H) return DAGNN_EINVAL;
+    if (N == 0) return DAGNN_OK;
+    if (!x || !depth || !type_emb || !attr_emb || !depth_emb || !out) return DAGNN_EINVAL;
+    int64_t blocks = (N + 3) / 4;  // 4 waves per block, one row per wave
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(encode_ast_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, depth,
+                       type_emb, attr_emb, depth_emb, max_depth, out, ld_out, N, H);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
+extern "C" int dagnn_pack_whh(const float* w_hh, float* w_hh_t, int H, void* stream) {
+    if (!w_hh || !w_hh_t || H <= 0) return DAGNN_EINVAL;
+    dim3 grid((H + 31) / 32, (3 * H + 31) / 32);
+    hipLaunchKernelGGL(pack_whh_kernel, grid, dim3(256), 0, (hipStream_t)stream, w_hh, w_hh_t, 3 * H, H);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
+extern "C" int dagnn_readout_max(const dagnn_plan* pl, const float* h, int ld_h, int width, int dir, float* out,
+                                 int ld_out, int col_off, void* stream) {
+    if (!pl || !pl->data || !h || !out || width <= 0 || (dir != 0 && dir != 1)) return DAGNN_EINVAL;
+    if (pl->B == 0) return DAGNN_OK;
+    PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
+    hipLaunchKernelGGL(readout_max_kernel, dim3((unsigned)pl->B), dim3(256), 0, (hipStream_t)stream,
+                       (const int32_t*)pl->data, L, dir, h, ld_h, width, out, ld_out, col_off);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
+extern "C" int dagnn_gather_rows(const float* h, int ld_h, int width, int64_t num_graphs, int stride, int node_off,
+                                 float* out, int ld_out, int col_off, void* stream) {
+    if (!h || !out || width <= 0 || num_graphs < 0 || stride <= 0 || node_off < 0 || node_off >= stride)
+        return DAGNN_EINVAL;
+    if (num_graphs == 0) return DAGNN_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)num_graphs), dim3(256), 0, (hipStream_t)stream, h, ld_h,
+                       width, stride, node_off, out, ld_out, col_off);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}

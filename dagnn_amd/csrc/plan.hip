@@ -1,0 +1,258 @@
+// plan.hip - builds the layer-sorted per-graph CSR ("plan") the recurrence kernel walks.
+//
+// Replaces, per forward call, the reference's `layer = ids[layer_id == l_idx]`
+// (ogbg-code/model/dagnn.py:146-147), its per-frontier-node scan of the whole edge_index
+// (dagnn.py:151-157, O(N*E) per direction) and `_get_output_nodes` (dagnn.py:119-126).
+//
+// One workgroup per (graph, direction) - graphs are independent, a PyG batch stores each graph's
+// nodes and edges contiguously - does two stable counting sorts in its own slice of the plan:
+// nodes by layer (frontiers become contiguous ranges) and edges by the sorted position of the
+// node they feed (rows of the CSR, original edge order kept inside a row so that the softmax /
+// weighted sum adds in the same order as the reference's scan produces).  Everything is int32;
+// the int64 inputs are narrowed on the way in.
+#include "common.h"
+
+namespace {
+
+constexpr int PB = 256;  // threads per plan workgroup
+
+__device__ __forceinline__ int64_t lower_bound_i64(const int64_t* a, int64_t n, int64_t key) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// node_ptr / edge_ptr by binary search + contract checks.
+__global__ void plan_ptr_kernel(int32_t* plan, PlanLayout L, const int64_t* __restrict__ edge_index,
+                                const int64_t* __restrict__ batch, int64_t N, int64_t E, int64_t B, int R,
+                                int32_t* status) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        plan[PH_N] = (int32_t)N; plan[PH_E] = (int32_t)E; plan[PH_B] = (int32_t)B; plan[PH_R] = R;
+        plan[PH_MAGIC] = DAGNN_PLAN_MAGIC;
+    }
+    if (i <= B) {
+        plan[L.node_ptr + i] = (int32_t)lower_bound_i64(batch, N, i);
+        // first edge whose source node belongs to graph >= i
+        int64_t lo = 0, hi = E;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (batch[edge_index[mid]] < i) lo = mid + 1; else hi = mid;
+        }
+        plan[L.edge_ptr + i] = (int32_t)lo;
+    }
+    int bad = 0;
+    if (i > 0 && i < N && batch[i] < batch[i - 1]) bad |= 4;
+    if (i < N && (batch[i] < 0 || batch[i] >= B)) bad |= 4;
+    if (i < E) {
+        int64_t s = edge_index[i], t = edge_index[E + i];
+        if (s < 0 || s >= N || t < 0 || t >= N) bad |= 2;
+        else {
+            if (batch[s] != batch[t]) bad |= 2;
+            if (i > 0) { int64_t sp = edge_index[i - 1]; if (sp >= 0 && sp < N && batch[sp] > batch[s]) bad |= 1; }
+        }
+    }
+    if (bad && status) atomicOr(status, bad);
+}
+
+// Block-wide inclusive scan of a[0..n) in place (global memory owned by this workgroup), plus `base`.
+__device__ void block_scan_inplace(int32_t* a, int n, int base, int32_t* lds /* PB+1 */) {
+    const int tid = threadIdx.x;
+    int carry = base;
+    for (int c0 = 0; c0 < n; c0 += PB) {
+        int i = c0 + tid;
+        int v = (i < n) ? a[i] : 0;
+        // wave inclusive scan
+        int x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if ((tid & 63) >= o) x += y; }
+        if ((tid & 63) == 63) lds[tid >> 6] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < (tid >> 6); ++w) woff += lds[w];
+        int tot = 0;
+        for (int w = 0; w < PB / 64; ++w) tot += lds[w];
+        if (i < n) a[i] = carry + woff + x;
+        carry += tot;
+        __syncthreads();
+    }
+}
+
+// Stable placement of one chunk: thread `tid` holds `key` (or -1); returns its rank among the
+// chunk's earlier threads with the same key, and whether it is the last holder of that key.
+__device__ __forceinline__ void chunk_rank(int key, int32_t* lds_keys, int& rank, bool& last) {
+    const int tid = threadIdx.x;
+    lds_keys[tid] = key;
+    __syncthreads();
+    rank = 0; last = true;
+    if (key >= 0) {
+        for (int j = 0; j < PB; ++j) {
+            int kj = lds_keys[j];
+            if (kj == key) { if (j < tid) ++rank; else if (j > tid) last = false; }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(PB) plan_graph_kernel(int32_t* plan, PlanLayout L,
+                                                         const int64_t* __restrict__ edge_index,
+                                                         const int64_t* __restrict__ layer_fwd,
+                                                         const int64_t* __restrict__ layer_bwd,
+                                                         const float* __restrict__ edge_attr, int R,
+                                                         int64_t N, int64_t E, int32_t* status) {
+    __shared__ int32_t lds[PB + 8];
+    __shared__ int32_t s_depth;
+    const int g = blockIdx.x, d = blockIdx.y, tid = threadIdx.x;
+    const int n0 = plan[L.node_ptr + g], n1 = plan[L.node_ptr + g + 1];
+    const int e0 = plan[L.edge_ptr + g], e1 = plan[L.edge_ptr + g + 1];
+    const int n = n1 - n0;
+    const int64_t* layer = d == 0 ? layer_fwd : layer_bwd;
+    int32_t* ls = plan + L.lstart[d] + n0 + g;     // n+1 words
+    int32_t* rp = plan + L.rowptr[d] + n0 + g;     // n+1 words
+    int32_t* cur = plan + L.cursor[d] + n0 + g;    // n+1 words
+    int32_t* order = plan + L.order[d];
+    int32_t* pos = plan + L.pos[d];
+    int32_t* col = plan + L.col[d];
+    float* eattr = reinterpret_cast<float*>(plan + L.eattr[d]);
+
+    // ---- depth of this graph in this direction
+    int mx = -1, bad = 0;
+    for (int v = n0 + tid; v < n1; v += PB) {
+        int64_t l = layer[v];
+        if (l < 0 || l >= n) { bad = 8; l = l < 0 ? 0 : n - 1; }
+        mx = max(mx, (int)l);
+    }
+    mx = wave_max_i(mx);
+    if (tid == 0) s_depth = -1;
+    __syncthreads();
+    if ((tid & 63) == 0) atomicMax(&s_depth, mx);
+    if (bad && status) atomicOr(status, bad);
+    for (int i = tid; i <= n; i += PB) { ls[i] = 0; rp[i] = 0; }
+    __syncthreads();
+    const int depth = s_depth + 1;  // 0 for an empty graph
+    if (tid == 0) plan[L.depth[d] + g] = depth;
+
+    // ---- histogram of layers -> lstart (absolute positions into order[])
+    for (int v = n0 + tid; v < n1; v += PB) {
+        int l = (int)min((int64_t)max((int64_t)layer[v], (int64_t)0), (int64_t)(n - 1));
+        atomicAdd(&ls[l + 1], 1);
+    }
+    __syncthreads();
+    block_scan_inplace(ls, depth + 1, n0, lds);
+    __syncthreads();
+    for (int i = tid; i < depth; i += PB) cur[i] = ls[i];
+    __syncthreads();
+
+    // ---- stable placement of nodes: order[] sorted by (layer, node id)
+    for (int c0 = n0; c0 < n1; c0 += PB) {
+        int v = c0 + tid;
+        int key = -1;
+        if (v < n1) key = (int)min((int64_t)max((int64_t)layer[v], (int64_t)0), (int64_t)(n - 1));
+        const int base = key >= 0 ? cur[key] : 0;  // read before any holder advances the cursor
+        int rank; bool last;
+        chunk_rank(key, lds, rank, last);
+        if (key >= 0) {
+            int slot = base + rank;
+            order[slot] = v;
+            pos[v] = slot;
+            if (last) cur[key] = slot + 1;  // single writer per key per chunk
+        }
+        __syncthreads();
+    }
+
+    // ---- rows of the CSR: the node an edge feeds is its target (d=0) or its source (d=1)
+    const int64_t* feed = d == 0 ? edge_index + E : edge_index;
+    const int64_t* other = d == 0 ? edge_index : edge_index + E;
+    for (int e = e0 + tid; e < e1; e += PB) {
+        int64_t f = feed[e];
+        if (f >= n0 && f < n1) atomicAdd(&rp[pos[f] - n0 + 1], 1);
+    }
+    __syncthreads();
+    block_scan_inplace(rp, n + 1, e0, lds);
+    __syncthreads();
+    for (int i = tid; i < n; i += PB) cur[i] = rp[i];
+    __syncthreads();
+    for (int c0 = e0; c0 < e1; c0 += PB) {
+        int e = c0 + tid;
+        int key = -1;
+        if (e < e1) { int64_t f = feed[e]; if (f >= n0 && f < n1) key = pos[f] - n0; }
+        const int base = key >= 0 ? cur[key] : 0;
+        int rank; bool last;
+        chunk_rank(key, lds, rank, last);
+        if (key >= 0) {
+            int slot = base + rank;
+            int64_t o = other[e];
+            col[slot] = (int)((o >= n0 && o < n1) ? o : feed[e]);
+            for (int r = 0; r < R; ++r) eattr[(int64_t)slot * R + r] = edge_attr[(int64_t)e * R + r];
+            if (last) cur[key] = slot + 1;
+        }
+        __syncthreads();
+    }
+}
+
+// Work items (g*2+d) sorted by depth, deepest first, so that the hardware's in-order workgroup
+// dispatch starts the longest dependency chains first (LPT scheduling).
+__global__ void __launch_bounds__(1024) plan_items_kernel(int32_t* plan, PlanLayout L, int B) {
+    const int n = 2 * B;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        int ki = plan[L.depth[i & 1] + (i >> 1)];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            int kj = plan[L.depth[j & 1] + (j >> 1)];
+            rank += (kj > ki) || (kj == ki && j < i);
+        }
+        plan[L.items + rank] = i;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t dagnn_plan_bytes(int64_t N, int64_t E, int64_t B, int num_edge_feats) {
+    if (N < 0 || E < 0 || B < 0 || num_edge_feats < 0) return 0;
+    return (size_t)dagnn_plan_layout_words(N, E, B, num_edge_feats).total * sizeof(int32_t);
+}
+
+extern "C" int dagnn_plan_layout(int64_t N, int64_t E, int64_t B, int R, int64_t* o) {
+    if (!o) return DAGNN_EINVAL;
+    PlanLayout L = dagnn_plan_layout_words(N, E, B, R);
+    int64_t w[16] = {L.node_ptr, L.edge_ptr, L.depth[0], L.depth[1], L.order[0], L.order[1], L.lstart[0],
+                     L.lstart[1], L.rowptr[0], L.rowptr[1], L.col[0], L.col[1], L.eattr[0], L.eattr[1],
+                     L.items, L.total};
+    for (int i = 0; i < 16; ++i) o[i] = w[i] * 4;
+    return DAGNN_OK;
+}
+
+extern "C" int dagnn_plan_build(const dagnn_plan* pl, const int64_t* edge_index, const int64_t* layer_fwd,
+                                const int64_t* layer_bwd, const int64_t* batch, const float* edge_attr,
+                                int32_t* status, void* stream_) {
+    if (!pl || !pl->data) return DAGNN_EINVAL;
+    void* plan = pl->data;
+    const size_t plan_bytes = pl->bytes;
+    const int64_t N = pl->N, E = pl->E, B = pl->B;
+    const int R = pl->num_edge_feats;
+    if (N < 0 || E < 0 || B < 0 || R < 0) return DAGNN_EINVAL;
+    if (N > 0 && (!layer_fwd || !layer_bwd || !batch)) return DAGNN_EINVAL;
+    if (E > 0 && !edge_index) return DAGNN_EINVAL;
+    if (R > 0 && E > 0 && !edge_attr) return DAGNN_EINVAL;
+    if (N >= (int64_t(1) << 30) || E >= (int64_t(1) << 30)) return DAGNN_EINVAL;  // int32 plan
+    PlanLayout L = dagnn_plan_layout_words(N, E, B, R);
+    if ((size_t)L.total * 4 > plan_bytes) return DAGNN_ENOSPC;
+    hipStream_t stream = (hipStream_t)stream_;
+    int32_t* p = (int32_t*)plan;
+    int64_t work = N > E ? N : E;
+    if (work < B + 1) work = B + 1;
+    hipLaunchKernelGGL(plan_ptr_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, p, L,
+                       edge_index, batch, N, E, B, R, status);
+    DAGNN_CHECK_LAUNCH();
+    if (B > 0) {
+        hipLaunchKernelGGL(plan_graph_kernel, dim3((unsigned)B, 2), dim3(PB), 0, stream, p, L, edge_index,
+                           layer_fwd, layer_bwd, edge_attr, R, N, E, status);
+        DAGNN_CHECK_LAUNCH();
+        hipLaunchKernelGGL(plan_items_kernel, dim3(1), dim3(1024), 0, stream, p, L, (int)B);
+        DAGNN_CHECK_LAUNCH();
+    }
+    return DAGNN_OK;
+}

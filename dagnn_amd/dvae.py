@@ -1,0 +1,194 @@
+"""D-VAE encoder variants of the same hot path: `DAGNN_NA` (= `dvae/dagnn.py:18-184`, class `DAGNN`
+there) for ENAS neural-architecture DAGs and `DAGNN_BN` (`dvae/dagnn_bn.py:19-177`) for
+Bayesian-network DAGs.
+
+Constructor arguments, parameter names and shapes follow the reference (including the decoder-side
+parameters of `DVAE_PYG` / `DVAE_BN_PYG`, `dvae/models_pyg.py:18-85,539-560`, which this build
+does not use but keeps so that `state_dict`s are interchangeable).  `forward(G)` / `encode(list)`
+run the layer-by-layer message passing in HIP; the igraph teacher-forced decoder and loss are out
+of scope.
+"""
+from __future__ import annotations
+
+import copy
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import constants as K
+from . import engine
+from .core import DerivedCache, derive_cell, require_inference, run_stack
+from .data import GraphBatch
+from .model import _EdgeAttnParams
+
+
+class _DvaeBase(nn.Module):
+    """Parameters of `DVAE_PYG.__init__` (`dvae/models_pyg.py:18-85`), same names and order."""
+
+    def __init__(self, max_n, nvt, START_TYPE, END_TYPE, hs=501, nz=56, bidirectional=False, vid=True,
+                 num_layers=1):
+        super().__init__()
+        self.max_n, self.nvt, self.START_TYPE, self.END_TYPE = max_n, nvt, START_TYPE, END_TYPE
+        self.hs, self.nz, self.gs = hs, nz, hs
+        self.bidir, self.vid = bidirectional, vid
+        self.vs = hs + max_n if vid else hs
+        self.num_layers = num_layers
+        gru = lambda: nn.ModuleList([nn.GRUCell(nvt if l == 0 else hs, hs) for l in range(num_layers)])  # noqa: E731
+        self.grue_forward = gru()
+        self.grue_backward = gru()
+        self.fc1 = nn.Linear(self.gs, nz)
+        self.fc2 = nn.Linear(self.gs, nz)
+        self.grud = gru()
+        self.fc3 = nn.Linear(nz, hs)
+        self.add_vertex = nn.Sequential(nn.Linear(hs, hs * 2), nn.ReLU(), nn.Linear(hs * 2, nvt))
+        self.add_edge = nn.Sequential(nn.Linear(hs * 2, hs * 4), nn.ReLU(), nn.Linear(hs * 4, 1))
+        self.gate_forward = nn.ModuleList([nn.Sequential(nn.Linear(self.vs, hs), nn.Sigmoid())
+                                           for _ in range(num_layers)])
+        self.gate_backward = nn.ModuleList([nn.Sequential(nn.Linear(self.vs, hs), nn.Sigmoid())
+                                            for _ in range(num_layers)])
+        self.mapper_forward = nn.ModuleList([nn.Sequential(nn.Linear(self.vs, hs, bias=False))
+                                             for _ in range(num_layers)])
+        self.mapper_backward = nn.ModuleList([nn.Sequential(nn.Linear(self.vs, hs, bias=False))
+                                              for _ in range(num_layers)])
+        if self.bidir:
+            self.hv_unify = nn.Sequential(nn.Linear(hs * 2, hs))
+            self.hg_unify = nn.Sequential(nn.Linear(self.gs * 2 * num_layers, self.gs))
+        self.relu, self.sigmoid, self.tanh = nn.ReLU(), nn.Sigmoid(), nn.Tanh()
+        self.logsoftmax1 = nn.LogSoftmax(1)
+        self.device = None
+
+    def get_device(self):
+        if self.device is None:
+            self.device = next(self.parameters()).device
+        return self.device
+
+    def _collate_fn(self, G):
+        return [copy.deepcopy(g) for g in G]
+
+
+class _DvaeDagnn(_DvaeBase):
+    _use_vids = True
+
+    def _setup(self, emb_dim, hidden_dim, out_dim, num_layers, bidirectional, agg, out_wx, out_pool_all, out_pool,
+               dropout, num_nodes):
+        self.num_nodes = num_nodes
+        self.agg = agg
+        self.agg_attn = "attn" in agg
+        self.agg_attn_x = "_x" in agg
+        self.bidirectional = bidirectional
+        self.dirs = [0, 1] if bidirectional else [0]
+        self.out_wx = out_wx
+        self.output_all = out_pool_all
+        self.out_pool = out_pool
+        self.emb_dim = emb_dim
+        self.hidden_dim = hidden_dim
+        self.out_hidden_dim = emb_dim + hidden_dim * num_layers if out_wx else hidden_dim * num_layers
+        if agg != K.NA_ATTN_H:
+            raise NotImplementedError("only agg='attn_h' is implemented for the D-VAE encoders so far")
+        extra = num_nodes if self._use_vids else 0
+        pred_dim = hidden_dim + extra
+        attn_dim = hidden_dim + extra
+        self.node_aggr_0 = nn.ModuleList([
+            _EdgeAttnParams(emb_dim if l == 0 else attn_dim, pred_dim, num_relations=1, attn_dim=attn_dim)
+            for l in range(num_layers)])
+        self.node_aggr_1 = nn.ModuleList([
+            _EdgeAttnParams(emb_dim if l == 0 else attn_dim, pred_dim, num_relations=1, attn_dim=attn_dim,
+                            reverse=True) for l in range(num_layers)])
+        # the cells ARE the base class's encoder GRUs (aliased names, dvae/dagnn.py:73-75)
+        self.cells_0 = self.grue_forward
+        if bidirectional:
+            self.cells_1 = self.grue_backward
+        self.dropout = nn.Dropout(dropout)
+        self.out_linear = nn.Linear(self.out_hidden_dim, out_dim) if num_layers > 1 else None
+        self._derived = DerivedCache()
+
+    def _cells(self):
+        srcs: List[torch.Tensor] = []
+        for d in self.dirs:
+            for i in range(self.num_layers):
+                c = getattr(self, "cells_%d" % d)[i]
+                a = getattr(self, "node_aggr_%d" % d)[i]
+                srcs += [c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh, a.attn_lin.weight]
+        extra = self.num_nodes if self._use_vids else 0
+
+        def make():
+            out = {}
+            for d in self.dirs:
+                for i in range(self.num_layers):
+                    c = getattr(self, "cells_%d" % d)[i]
+                    a = getattr(self, "node_aggr_%d" % d)[i]
+                    dq = self.emb_dim if i == 0 else self.hidden_dim + extra
+                    out[(d, i)] = derive_cell(c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh, a.attn_lin.weight,
+                                              self.hidden_dim, dq, i > 0, None, extra)
+            return out
+
+        return self._derived.get(srcs, make)
+
+    def forward(self, G):
+        """`dvae/dagnn.py:99-175` / `dvae/dagnn_bn.py:98-168` with `out_pool_all=False`."""
+        if self.output_all:
+            raise NotImplementedError("out_pool_all=True read-out is not implemented for the D-VAE encoders")
+        require_inference(self)
+        device = self.get_device()
+        G = G.to(device)
+        x = G.x.float().contiguous()
+        N = x.shape[0]
+        L, H, nn_ = self.num_layers, self.hidden_dim, self.num_nodes
+        if N % nn_ != 0:
+            raise ValueError("every graph must have exactly num_nodes=%d nodes (dvae/dagnn.py:150-158)" % nn_)
+        B = N // nn_
+        bl = G.bi_layer_index
+        plan = engine.build_plan(G.edge_index, bl[0][0], bl[1][0], G.batch, B, None)
+        h = run_stack(plan, x, self._cells(), self.dirs, L, H, vid_nodes=nn_ if self._use_vids else 0)
+        nd = len(self.dirs)
+        hcat = torch.empty(B, nd * L * H, dtype=torch.float32, device=x.device)
+        for i in range(L):  # end vertex of every graph for d=0, start vertex for d=1
+            engine.gather_rows(h[0][i], B, nn_, nn_ - 1, hcat, i * H)
+            if self.bidirectional:
+                engine.gather_rows(h[1][i], B, nn_, 0, hcat, (L + i) * H)
+        G.h = hcat
+        G.batch = G.batch[0::nn_] if self.bidirectional else G.batch[nn_ - 1::nn_]
+        if self.bidirectional:
+            return self.hg_unify(G.h)
+        return self.out_linear(G.h) if L > 1 else G.h
+
+    def encode(self, G):
+        """(mu, logvar) of a list of graphs (`dvae/dagnn.py:177-184`)."""
+        if type(G) != list:
+            G = [G]
+        b = GraphBatch.from_data_list(G)
+        Hg = self(b)
+        return self.fc1(Hg), self.fc2(Hg)
+
+
+class DAGNN_NA(_DvaeDagnn):
+    """The reference's `dvae/dagnn.py::DAGNN` (keys carry a one-hot vertex id, `:130-134`)."""
+    _use_vids = True
+
+    def __init__(self, emb_dim, hidden_dim, out_dim, max_n, nvt, START_TYPE, END_TYPE, hs, nz,
+                 num_layers=2, bidirectional=False, agg=K.NA_ATTN_H, out_wx=False, out_pool_all=False,
+                 out_pool=K.P_MAX, dropout=0.0, num_nodes=8):
+        super().__init__(max_n, nvt, START_TYPE, END_TYPE, hs, nz, bidirectional=bidirectional, num_layers=num_layers)
+        self._setup(emb_dim, hidden_dim, out_dim, num_layers, bidirectional, agg, out_wx, out_pool_all, out_pool,
+                    dropout, num_nodes)
+
+
+class DAGNN_BN(_DvaeDagnn):
+    """The reference's `dvae/dagnn_bn.py::DAGNN_BN` on `DVAE_BN_PYG` (`models_pyg.py:539-560`)."""
+    _use_vids = False
+
+    def __init__(self, emb_dim, hidden_dim, out_dim, max_n, nvt, START_TYPE, END_TYPE, hs, nz, num_layers=2,
+                 bidirectional=True, agg=K.NA_ATTN_H, out_wx=False, out_pool_all=False, out_pool=K.P_MAX,
+                 dropout=0.0, num_nodes=8):
+        super().__init__(max_n, nvt, START_TYPE, END_TYPE, hs, nz, bidirectional=bidirectional, vid=False,
+                         num_layers=num_layers)
+        # DVAE_BN_PYG (aggx=0) re-creates these with the first layer reading node types
+        lin = lambda l, bias: nn.Linear(self.nvt if l == 0 else hs, hs, bias=bias)  # noqa: E731
+        self.mapper_forward = nn.ModuleList([nn.Sequential(lin(l, False)) for l in range(num_layers)])
+        self.mapper_backward = nn.ModuleList([nn.Sequential(lin(l, False)) for l in range(num_layers)])
+        self.gate_forward = nn.ModuleList([nn.Sequential(lin(l, True), nn.Sigmoid()) for l in range(num_layers)])
+        self.gate_backward = nn.ModuleList([nn.Sequential(lin(l, True), nn.Sigmoid()) for l in range(num_layers)])
+        self.add_edge = nn.Sequential(nn.Linear(hs * 3, hs), nn.ReLU(), nn.Linear(hs, 1))
+        self._setup(emb_dim, hidden_dim, out_dim, num_layers, bidirectional, agg, out_wx, out_pool_all, out_pool,
+                    dropout, num_nodes)

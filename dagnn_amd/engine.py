@@ -1,0 +1,165 @@
+"""Host-side driver of the HIP path: turns torch tensors into C-ABI calls (include/dagnn_hip.h).
+
+PyTorch is plumbing here - device memory, the current stream, and the dense head GEMMs; every
+step of the DAGNN hot path itself runs in libdagnn_hip.so.  Nothing in this module has a CPU
+implementation: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import DagnnHipError, GemmGroup, LayerArgs, Plan, check
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dev(t: torch.Tensor, what: str, dtype=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise DagnnHipError(
+            "%s must be a tensor on a ROCm GPU: the DAGNN hot path is hand-written HIP for gfx950 and has no "
+            "CPU fallback (got %s)" % (what, getattr(t, "device", type(t))))
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class PlanHandle(object):
+    """Device workspace holding the layer-sorted per-graph CSR of one batch (both directions)."""
+
+    def __init__(self, N: int, E: int, B: int, R: int, device):
+        lib = _lib.load()
+        self.N, self.E, self.B, self.R = int(N), int(E), int(B), int(R)
+        nbytes = lib.dagnn_plan_bytes(self.N, self.E, self.B, self.R)
+        self.ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device)
+        self.status = torch.zeros(4, dtype=torch.int32, device=device)
+        self.desc = Plan(self.ws.data_ptr(), nbytes, self.N, self.E, self.B, self.R)
+
+    def layout(self) -> dict:
+        off = (C.c_int64 * 16)()
+        check(_lib.load().dagnn_plan_layout(self.N, self.E, self.B, self.R, off), "dagnn_plan_layout")
+        names = ["node_ptr", "edge_ptr", "depth0", "depth1", "order0", "order1", "lstart0", "lstart1", "rowptr0",
+                 "rowptr1", "col0", "col1", "eattr0", "eattr1", "items", "total"]
+        return {k: int(v) // 4 for k, v in zip(names, off)}
+
+    def check_status(self) -> None:
+        """Debug helper (synchronises): raises if the batch violated the layout contract."""
+        s = int(self.status[0])
+        if s:
+            msgs = [m for b, m in ((1, "edges not grouped by graph"), (2, "edge crosses graphs / out of range"),
+                                   (4, "batch vector not sorted"), (8, "layer id >= nodes of its graph")) if s & b]
+            raise DagnnHipError("plan contract violated: " + ", ".join(msgs))
+
+
+def build_plan(edge_index: torch.Tensor, layer_fwd: torch.Tensor, layer_bwd: torch.Tensor, batch: torch.Tensor,
+               num_graphs: int, edge_attr: Optional[torch.Tensor] = None) -> PlanHandle:
+    edge_index = _dev(edge_index, "edge_index", torch.int64)
+    layer_fwd = _dev(layer_fwd, "layer ids", torch.int64)
+    layer_bwd = _dev(layer_bwd, "layer ids", torch.int64)
+    batch = _dev(batch, "batch", torch.int64)
+    N, E = layer_fwd.numel(), edge_index.shape[1]
+    R = 0
+    if edge_attr is not None:
+        edge_attr = _dev(edge_attr, "edge_attr", torch.float32).view(E, -1)
+        R = edge_attr.shape[1]
+    plan = PlanHandle(N, E, num_graphs, R, edge_index.device)
+    check(_lib.load().dagnn_plan_build(C.byref(plan.desc), edge_index.data_ptr(), layer_fwd.data_ptr(),
+                                       layer_bwd.data_ptr(), batch.data_ptr(), _ptr(edge_attr),
+                                       plan.status.data_ptr(), _stream(edge_index)), "dagnn_plan_build")
+    plan._keep = (edge_index, layer_fwd, layer_bwd, batch, edge_attr)
+    return plan
+
+
+def encode_ast(x: torch.Tensor, depth: torch.Tensor, type_w: torch.Tensor, attr_w: torch.Tensor,
+               depth_w: torch.Tensor, max_depth: int) -> torch.Tensor:
+    """out = type_emb[x0] + attr_emb[x1] + depth_emb[min(depth, max_depth)]; clamps `depth` in place."""
+    x = _dev(x, "x", torch.int64)
+    if not (depth.is_cuda and depth.dtype == torch.int64 and depth.is_contiguous()):
+        raise DagnnHipError("node_depth must be a contiguous int64 GPU tensor (it is clamped in place)")
+    N, H = x.shape[0], type_w.shape[1]
+    out = torch.empty(N, H, dtype=torch.float32, device=x.device)
+    check(_lib.load().dagnn_encode_ast(x.data_ptr(), depth.data_ptr(), _dev(type_w, "type table").data_ptr(),
+                                       _dev(attr_w, "attribute table").data_ptr(),
+                                       _dev(depth_w, "depth table").data_ptr(), int(max_depth), out.data_ptr(), H,
+                                       N, H, _stream(x)), "dagnn_encode_ast")
+    return out
+
+
+def gemm_nt_bias(A: Sequence[torch.Tensor], W: Sequence[torch.Tensor], bias: Sequence[Optional[torch.Tensor]],
+                 out: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
+    """C_g = A_g @ W_g^T + bias_g for up to 4 groups sharing M, K and Nc (one launch)."""
+    n = len(A)
+    A = [_dev(a, "A", torch.float32) for a in A]
+    W = [_dev(w, "W", torch.float32) for w in W]
+    M, K = A[0].shape
+    Nc = W[0].shape[0]
+    for a, w in zip(A, W):
+        if tuple(a.shape) != (M, K) or tuple(w.shape) != (Nc, K):
+            raise DagnnHipError("grouped GEMM needs identical shapes per group")
+    if out is None:
+        out = [torch.empty(M, Nc, dtype=torch.float32, device=A[0].device) for _ in range(n)]
+    groups = (GemmGroup * n)()
+    keep = []
+    for g in range(n):
+        b = None if bias[g] is None else _dev(bias[g], "bias", torch.float32)
+        keep.append(b)
+        groups[g] = GemmGroup(A[g].data_ptr(), W[g].data_ptr(), _ptr(b), out[g].data_ptr())
+    check(_lib.load().dagnn_gemm_nt_bias(groups, n, M, Nc, K, K, K, Nc, _stream(A[0])), "dagnn_gemm_nt_bias")
+    return list(out)
+
+
+def pack_whh(w_hh: torch.Tensor) -> torch.Tensor:
+    """[3H, H] (torch GRUCell layout) -> k-major [H, 3H]."""
+    w_hh = _dev(w_hh, "weight_hh", torch.float32)
+    H = w_hh.shape[1]
+    out = torch.empty(H, 3 * H, dtype=torch.float32, device=w_hh.device)
+    check(_lib.load().dagnn_pack_whh(w_hh.data_ptr(), out.data_ptr(), H, _stream(w_hh)), "dagnn_pack_whh")
+    return out
+
+
+def recurrence_layer(plan: PlanHandle, dirs: Sequence[int], H: int, gi, w_hh_t, b_hh, w_key, edge_gain=None,
+                     vid_bias=None, vid_mod: int = 0, out=None, score=None) -> List[Optional[torch.Tensor]]:
+    """One stacked GRU layer over all topological layers.  Per-direction lists indexed by d."""
+    dev = plan.ws.device
+    h = [None, None]
+    args = LayerArgs()
+    keep = []
+    mask = 0
+    for d in dirs:
+        mask |= 1 << d
+        h[d] = out[d] if out is not None else torch.empty(plan.N, H, dtype=torch.float32, device=dev)
+        sc = score[d] if score is not None else torch.empty(plan.N, dtype=torch.float32, device=dev)
+        ts = [_dev(gi[d], "gi", torch.float32), _dev(w_hh_t[d], "w_hh_t", torch.float32),
+              _dev(b_hh[d], "b_hh", torch.float32), _dev(w_key[d], "w_key", torch.float32)]
+        eg = _dev(edge_gain[d], "edge_gain", torch.float32) if (edge_gain is not None and plan.R > 0) else None
+        vb = _dev(vid_bias[d], "vid_bias", torch.float32) if (vid_bias is not None and vid_mod > 0) else None
+        keep += ts + [eg, vb, sc]
+        args.gi[d], args.w_hh_t[d], args.b_hh[d], args.w_key[d] = (t.data_ptr() for t in ts)
+        args.edge_gain[d], args.vid_bias[d] = _ptr(eg), _ptr(vb)
+        args.h[d], args.score[d] = h[d].data_ptr(), sc.data_ptr()
+    args.vid_mod, args.ld_h = int(vid_mod), H
+    check(_lib.load().dagnn_recurrence_layer(C.byref(plan.desc), C.byref(args), mask, H, _stream(plan.ws)),
+          "dagnn_recurrence_layer")
+    return h
+
+
+def readout_max(plan: PlanHandle, h: torch.Tensor, direction: int, out: torch.Tensor, col_off: int) -> None:
+    h = _dev(h, "h", torch.float32)
+    check(_lib.load().dagnn_readout_max(C.byref(plan.desc), h.data_ptr(), h.shape[1], h.shape[1], direction,
+                                        out.data_ptr(), out.shape[1], col_off, _stream(h)), "dagnn_readout_max")
+
+
+def gather_rows(h: torch.Tensor, num_graphs: int, stride: int, node_off: int, out: torch.Tensor,
+                col_off: int) -> None:
+    h = _dev(h, "h", torch.float32)
+    check(_lib.load().dagnn_gather_rows(h.data_ptr(), h.shape[1], h.shape[1], num_graphs, stride, node_off,
+                                        out.data_ptr(), out.shape[1], col_off, _stream(h)), "dagnn_gather_rows")

@@ -1,0 +1,282 @@
+"""`DAGNN` - drop-in for the reference's `ogbg-code/model/dagnn.py:16-215` on MI355X.
+
+Same constructor signature, same `state_dict` keys and shapes (checkpoints written by the
+reference's `utils2.create_checkpoint` load unchanged), same `forward(G)` contract on a PyG-style
+batch including its side effects on `G` (`G.bi_layer_index`, `G.x` replaced by the embedding,
+`G.node_depth` clamped, `G.h`).  The layer-by-layer gather -> attention-aggregate -> GRU path
+runs in hand-written HIP (libdagnn_hip.so); there is no CPU or eager-PyTorch fallback for it.
+
+Aggregators: `attn_h` (every BASELINE config) runs in HIP.  The reference's other aggregator
+strings (`self_attn_*`, `mattn_h`, `gated_sum`, `add`, `max`, `attn_x`, `agg_x`, `recurr=0`) keep
+their constructor / state_dict support but `forward` raises NotImplementedError for them (SURVEY.md
+§8(a) row a12, "next").
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import constants as K
+from . import engine
+from .core import DerivedCache, derive_cell, num_graphs_of, require_inference, run_stack
+
+
+class ASTNodeEncoder(nn.Module):
+    """Node embedding of `ogbg-code/utils.py:6-28` (same parameter names)."""
+
+    def __init__(self, emb_dim, num_nodetypes, num_nodeattributes, max_depth):
+        super().__init__()
+        self.max_depth = max_depth
+        self.type_encoder = nn.Embedding(num_nodetypes, emb_dim)
+        self.attribute_encoder = nn.Embedding(num_nodeattributes, emb_dim)
+        self.depth_encoder = nn.Embedding(self.max_depth + 1, emb_dim)
+
+    def forward(self, x, depth):
+        if x.is_cuda and self.type_encoder.weight.shape[1] % 4 == 0 and depth.dtype == torch.int64 \
+                and depth.is_contiguous() and not (torch.is_grad_enabled() and self.type_encoder.weight.requires_grad):
+            return engine.encode_ast(x, depth, self.type_encoder.weight, self.attribute_encoder.weight,
+                                     self.depth_encoder.weight, self.max_depth)
+        # generic torch path (training of the tables, odd widths): same math as utils.py:26-28
+        depth[depth > self.max_depth] = self.max_depth
+        return self.type_encoder(x[:, 0]) + self.attribute_encoder(x[:, 1]) + self.depth_encoder(depth)
+
+
+class _EdgeAttnParams(nn.Module):
+    """Parameter holder with the names of the reference's `AttnConv` (`dagnn.py:347-359`)."""
+
+    def __init__(self, attn_q_dim, emb_dim, attn_dim=0, num_relations=1, reverse=False):
+        super().__init__()
+        attn_dim = attn_dim if attn_dim > 0 else emb_dim
+        self.wea = num_relations > 1
+        if self.wea:
+            self.edge_encoder = nn.Linear(num_relations, attn_dim)
+        self.attn_lin = nn.Linear(attn_q_dim + attn_dim, 1)
+        self.reverse = reverse
+
+
+class _SelfAttnParams(nn.Module):  # dagnn.py:279-290
+    def __init__(self, emb_dim, attn_dim=0, num_relations=1, reverse=False):
+        super().__init__()
+        attn_dim = attn_dim if attn_dim > 0 else emb_dim
+        self.wea = num_relations > 1
+        if self.wea:
+            self.edge_encoder = nn.Linear(num_relations, attn_dim)
+        self.attn_lin = nn.Linear(attn_dim, 1)
+
+
+class _MultAttnParams(nn.Module):  # dagnn.py:379-392
+    def __init__(self, attn_q_dim, emb_dim, attn_dim=0, num_relations=1, reverse=False):
+        super().__init__()
+        attn_dim = attn_dim if attn_dim > 0 else emb_dim
+        self.wea = num_relations > 1
+        if self.wea:
+            self.edge_encoder = nn.Linear(num_relations, attn_dim)
+        self.attn_linl = nn.Linear(attn_q_dim, attn_q_dim)
+        self.attn_linr = nn.Linear(attn_dim, attn_q_dim)
+
+
+class _GatedSumParams(nn.Module):  # dagnn.py:254-265
+    def __init__(self, emb_dim, num_relations=1, mapper_bias=True, reverse=False):
+        super().__init__()
+        self.wea = num_relations > 1
+        if self.wea:
+            self.edge_encoder = nn.Linear(num_relations, emb_dim)
+        self.mapper = nn.Linear(emb_dim, emb_dim, bias=mapper_bias)
+        self.gate = nn.Sequential(nn.Linear(emb_dim, emb_dim), nn.Sigmoid())
+
+
+class _AggParams(nn.Module):  # dagnn.py:232-241
+    def __init__(self, agg, num_relations=1, emb_dim=0):
+        super().__init__()
+        self.wea = num_relations > 1
+        if self.wea:
+            self.edge_encoder = nn.Linear(num_relations, emb_dim)
+
+
+def _init_encoder(word_vectors, emb_dims):  # dagnn.py:218-223
+    if word_vectors is not None:
+        return nn.EmbeddingBag.from_pretrained(word_vectors, freeze=True, mode="sum")
+    if len(emb_dims) > 0:
+        return nn.EmbeddingBag(emb_dims[0], emb_dims[1], mode="sum")
+    return None
+
+
+class DAGNN(nn.Module):
+    """See module docstring.  Constructor mirrors `dagnn.py:18-112` argument for argument."""
+
+    def __init__(self, num_vocab, max_seq_len, emb_dim, hidden_dim, out_dim,
+                 num_rels=2, w_edge_attr=True, num_layers=2, bidirectional=True, mapper_bias=True,
+                 agg_x=False, agg=K.NA_ATTN_H, out_wx=True, out_pool_all=True, out_pool=K.P_MAX, encoder=None,
+                 dropout=0.0, word_vectors=None, emb_dims=[], activation=None, num_class=0, recurr=1):
+        super().__init__()
+        self.num_class = num_class
+        self.num_vocab = num_vocab
+        self.max_seq_len = max_seq_len
+        if agg_x and hidden_dim < emb_dim:
+            raise ValueError('Hidden dimension too small for input.')
+
+        self.agg = agg
+        self.agg_x = agg_x
+        self.agg_attn = "attn" in agg
+        self.agg_attn_x = "_x" in agg
+        self.bidirectional = bidirectional
+        self.dirs = [0, 1] if bidirectional else [0]
+        self.num_layers = num_layers
+        self.out_wx = out_wx
+        self.output_all = out_pool_all
+        self.out_pool = out_pool
+        self.recurr = recurr
+        self.emb_dim = emb_dim
+        self.hidden_dim = hidden_dim
+        nd = len(self.dirs)
+        self.out_hidden_dim = emb_dim * nd + hidden_dim * nd * num_layers if out_wx else hidden_dim * nd * num_layers
+
+        self.encoder = encoder if encoder is not None else _init_encoder(word_vectors, emb_dims)
+
+        # parameter creation order follows the reference so that seeded default inits coincide
+        num_rels = num_rels if w_edge_attr else 1
+        self.num_rels = num_rels
+        pred_dim = emb_dim if agg_x else hidden_dim
+        attn_dim = emb_dim if "_x" in agg else hidden_dim
+        if "self_attn" in agg:
+            self.node_aggr_0 = nn.ModuleList([_SelfAttnParams(attn_dim, num_relations=num_rels)
+                                              for _ in range(num_layers)])
+            self.node_aggr_1 = nn.ModuleList([_SelfAttnParams(attn_dim, num_relations=num_rels, reverse=True)
+                                              for _ in range(num_layers)])
+        elif "attn" in agg:
+            op = _MultAttnParams if "mattn" in agg else _EdgeAttnParams
+            self.node_aggr_0 = nn.ModuleList([
+                op(emb_dim if l == 0 else attn_dim, pred_dim, num_relations=num_rels, attn_dim=attn_dim)
+                for l in range(num_layers)])
+            self.node_aggr_1 = nn.ModuleList([
+                op(emb_dim if l == 0 else attn_dim, pred_dim, num_relations=num_rels, attn_dim=attn_dim, reverse=True)
+                for l in range(num_layers)])
+        elif agg == K.NA_GATED_SUM:
+            self.node_aggr_0 = nn.ModuleList([_GatedSumParams(pred_dim, num_rels, mapper_bias=mapper_bias)
+                                              for _ in range(num_layers)])
+            self.node_aggr_1 = nn.ModuleList([_GatedSumParams(pred_dim, num_rels, mapper_bias=mapper_bias,
+                                                              reverse=True) for _ in range(num_layers)])
+        else:
+            node_aggr = _AggParams(agg, num_rels, pred_dim)
+            self.node_aggr_0 = self.node_aggr_1 = nn.ModuleList([node_aggr for _ in range(num_layers)])
+
+        for d in self.dirs:
+            if recurr:
+                cells = [nn.GRUCell(emb_dim if l == 0 else hidden_dim, hidden_dim) for l in range(num_layers)]
+            else:
+                cells = [nn.Linear((emb_dim if l == 0 else hidden_dim) + hidden_dim, hidden_dim)
+                         for l in range(num_layers)]
+            setattr(self, "cells_{}".format(d), nn.ModuleList(cells))
+
+        if out_pool == K.P_ATTN:
+            dd = int(self.out_hidden_dim / 2) if self.bidirectional and not self.output_all else self.out_hidden_dim
+            self.self_attn_linear_out = nn.Linear(dd, 1)
+
+        self.dropout = nn.Dropout(dropout)
+        if self.num_class > 0:
+            self.graph_pred_linear = nn.Linear(self.out_hidden_dim, self.num_class)
+        else:
+            self.graph_pred_linear_list = nn.ModuleList()
+            if self.num_vocab == 1:
+                self.graph_pred_linear_list.append(nn.Sequential(nn.Linear(self.out_hidden_dim, self.num_vocab),
+                                                                 nn.ReLU()))
+            else:
+                for _ in range(max_seq_len):
+                    self.graph_pred_linear_list.append(nn.Linear(self.out_hidden_dim, self.num_vocab))
+
+        self._derived = DerivedCache()
+
+    # ------------------------------------------------------------------------------ helpers
+    def _hip_supported(self) -> bool:
+        return self.agg == K.NA_ATTN_H and not self.agg_x and bool(self.recurr)
+
+    def _cells(self):
+        srcs: List[torch.Tensor] = []
+        for d in self.dirs:
+            for i in range(self.num_layers):
+                c = getattr(self, "cells_%d" % d)[i]
+                a = getattr(self, "node_aggr_%d" % d)[i]
+                srcs += [c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh, a.attn_lin.weight]
+                if a.wea:
+                    srcs.append(a.edge_encoder.weight)
+
+        def make():
+            out = {}
+            for d in self.dirs:
+                for i in range(self.num_layers):
+                    c = getattr(self, "cells_%d" % d)[i]
+                    a = getattr(self, "node_aggr_%d" % d)[i]
+                    dq = self.emb_dim if i == 0 else self.hidden_dim
+                    out[(d, i)] = derive_cell(c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh, a.attn_lin.weight,
+                                              self.hidden_dim, dq, i > 0, a.edge_encoder.weight if a.wea else None, 0)
+            return out
+
+        return self._derived.get(srcs, make)
+
+    def _pool(self, h, batch, B):
+        """`global_{max,mean,add}_pool` / P_ATTN read-outs on torch (variants outside BASELINE)."""
+        how = self.out_pool
+        if how == K.P_ATTN:  # dagnn.py:114-117: softmax over a size-1 dim == 1 -> sum pooling
+            w = F.softmax(self.self_attn_linear_out(h), dim=-1)
+            h, how = w * h, K.P_ADD
+        idx = batch.view(-1, 1).expand_as(h)
+        out = h.new_zeros(B, h.shape[1])
+        if how == K.P_MAX:
+            return out.scatter_reduce_(0, idx, h, "amax", include_self=False)
+        out.scatter_add_(0, idx, h)
+        if how == K.P_MEAN:
+            cnt = torch.bincount(batch, minlength=B).clamp(min=1).to(h.dtype).view(-1, 1)
+            out = out / cnt
+        return out
+
+    # ------------------------------------------------------------------------------ forward
+    def forward(self, G):
+        if not self._hip_supported():
+            raise NotImplementedError(
+                "aggregator %r / agg_x=%r / recurr=%r: only agg='attn_h', agg_x=False, recurr=1 is implemented "
+                "in the HIP path so far" % (self.agg, self.agg_x, self.recurr))
+        require_inference(self)
+        L, H, dirs = self.num_layers, self.hidden_dim, self.dirs
+
+        # side effect 1 (dagnn.py:130-133)
+        G.bi_layer_index = torch.stack([torch.stack([G._bi_layer_idx0, G._bi_layer_index0], dim=0),
+                                        torch.stack([G._bi_layer_idx1, G._bi_layer_index1], dim=0)], dim=0)
+        B = num_graphs_of(G)
+        # side effects 2+3 (dagnn.py:139, utils.py:27): embedding replaces G.x, depth clamped in place
+        G.x = self.encoder(G.x, G.node_depth.view(-1, ))
+        x = G.x
+        has_edge_enc = getattr(self.node_aggr_0[0], "wea", False)
+        plan = engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B,
+                                 G.edge_attr if has_edge_enc else None)
+        h = run_stack(plan, x, self._cells(), dirs, L, H)
+        G.h = [[h[d][i] for i in range(L)] for d in dirs]  # side effect 4 (dagnn.py:141-142,182)
+
+        if self.bidirectional and not self.output_all:
+            if self.out_pool == K.P_MAX:
+                out = torch.empty(B, self.out_hidden_dim, dtype=torch.float32, device=x.device)
+                col = 0
+                for d in (0, 1):
+                    for t in ([x] if self.out_wx else []) + [h[d][i] for i in range(L)]:
+                        engine.readout_max(plan, t, d, out, col)
+                        col += t.shape[1]
+            else:
+                outs = []
+                for d in (0, 1):
+                    idx = G.bi_layer_index[1 - d][1][G.bi_layer_index[1 - d][0] == 0]
+                    hd = torch.cat(([x] if self.out_wx else []) + [h[d][i] for i in range(L)], dim=-1)
+                    outs.append(self._pool(hd[idx], G.batch[idx], B))
+                out = torch.cat(outs, dim=-1)
+        else:
+            G.h = torch.cat(([x] if self.out_wx else []) + [h[d][i] for d in dirs for i in range(L)], dim=-1)
+            if not self.output_all:
+                idx = G.bi_layer_index[1][1][G.bi_layer_index[1][0] == 0]  # dagnn.py:124-126
+                G.h, G.batch = G.h[idx], G.batch[idx]
+            out = self._pool(G.h, G.batch, B)
+
+        out = self.dropout(out)
+        if self.num_class > 0:
+            return self.graph_pred_linear(out)
+        return [self.graph_pred_linear_list[i](out) for i in range(self.max_seq_len)]

@@ -1,0 +1,170 @@
+/*
+ * dagnn_hip.h - C ABI of the MI355X (gfx950) DAGNN message-passing library (libdagnn_hip.so).
+ *
+ * The reference (vthost/DAGNN) is pure Python on PyTorch/PyG and has no FFI of its own; the
+ * drop-in boundary it exposes is the nn.Module `DAGNN.forward(G)`
+ * (ogbg-code/model/dagnn.py:128-215; dvae/dagnn.py:99-184; dvae/dagnn_bn.py:98-177).  The
+ * Python mirror of that module lives in dagnn_amd/{model,dvae}.py; every device-side step it
+ * takes goes through the entry points declared here, each of which replaces the reference lines
+ * cited next to it.  INTEGRATION.md shows the ctypes binding a maintainer of the reference
+ * would add.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a BORROWED DEVICE pointer (e.g. torch.Tensor.data_ptr()) unless marked
+ *     "host"; the library never allocates, frees or synchronises, so calls are stream-ordered
+ *     and hipGraph-capturable;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *   - return value: 0 on success, DAGNN_E* (<0) on bad arguments, -(1000+hipError_t) when a HIP
+ *     call fails; nothing throws across the boundary;
+ *   - no global mutable state: k threads / k ranks may call concurrently on different devices
+ *     (ogbg-code/tg/data_parallel.py:59-62 runs one Python thread per device);
+ *   - floats are IEEE fp32; hidden size H must be a multiple of 4 (the host pads otherwise).
+ */
+#ifndef DAGNN_HIP_H
+#define DAGNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DAGNN_OK 0
+#define DAGNN_EINVAL (-22)     /* bad argument (null pointer, H % 4 != 0, negative size ...) */
+#define DAGNN_ENOSPC (-28)     /* workspace too small */
+#define DAGNN_EHIP(e) (-(1000 + (int)(e)))
+
+#define DAGNN_MAX_DIRS 2
+#define DAGNN_MAX_GROUPS 4
+
+/* Library / ABI version string, e.g. "dagnn_hip 0.1 gfx950". Host pointer, static storage. */
+const char* dagnn_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Plan: the layer-sorted, per-graph CSR the recurrence walks.
+ * Replaces, per forward call, the reference's frontier selection (dagnn.py:146-147), its
+ * per-node scan of the whole edge_index (dagnn.py:151-157) and the output-node selection
+ * (dagnn.py:119-126).  Consumes the layer ids that src/utils_dag.py:39-52 attaches offline.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Host-side descriptor of a plan: a device workspace plus the sizes it was laid out for. */
+typedef struct dagnn_plan {
+    void* data;          /* device workspace, >= dagnn_plan_bytes(N, E, B, num_edge_feats) bytes */
+    size_t bytes;
+    int64_t N, E, B;     /* nodes, edges, graphs in the batch */
+    int num_edge_feats;  /* floats of edge_attr per edge carried into the plan (0 = none) */
+} dagnn_plan;
+
+/* Bytes of device workspace `dagnn_plan_build` needs for N nodes, E edges, B graphs and
+ * `num_edge_feats` floats of edge_attr per edge (0 if the model has no edge features). */
+size_t dagnn_plan_bytes(int64_t N, int64_t E, int64_t B, int num_edge_feats);
+
+/* Build the plan for both directions.
+ *   edge_index [2,E] int64 row-major: row 0 = source, row 1 = target (PyG layout)
+ *   layer_fwd  [N] int64: longest-path layer of each node        (G._bi_layer_idx0)
+ *   layer_bwd  [N] int64: same on the reversed graph             (G._bi_layer_idx1)
+ *   batch      [N] int64: graph id of each node, non-decreasing  (G.batch)
+ *   edge_attr  [E,num_edge_feats] fp32 or NULL
+ * Edges must be grouped by graph in the same order as nodes (what PyG collation produces).
+ * `status` [4] int32 device words, written by the kernels: status[0] != 0 flags a contract
+ * violation (bit 0: edges not grouped by graph, bit 1: edge crosses graphs, bit 2: batch not
+ * sorted, bit 3: layer id >= nodes of its graph).  Read it back only when debugging: the
+ * forward path itself never synchronises. */
+int dagnn_plan_build(const dagnn_plan* plan /* host */,
+                     const int64_t* edge_index, const int64_t* layer_fwd, const int64_t* layer_bwd,
+                     const int64_t* batch, const float* edge_attr, int32_t* status, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * AST node encoder (ogbg-code/utils.py:26-28, called at dagnn.py:139):
+ *   out[v,:] = type_emb[x[v,0]] + attr_emb[x[v,1]] + depth_emb[min(depth[v], max_depth)]
+ * and clamps depth[v] IN PLACE to max_depth, as the reference does (utils.py:27).
+ *   x [N,2] int64, depth [N] int64, tables [*,H] fp32, out [N,ld_out] fp32 (ld_out >= H).
+ * ---------------------------------------------------------------------------------------- */
+int dagnn_encode_ast(const int64_t* x, int64_t* depth, const float* type_emb, const float* attr_emb,
+                     const float* depth_emb, int max_depth, float* out, int ld_out,
+                     int64_t N, int H, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Input-side GRU GEMMs, batched over all nodes (the W_i* x + b_i* half of nn.GRUCell,
+ * dagnn.py:181; independent of the recurrence, so done once per layer on the MFMA units):
+ *   for g < num_groups:  C_g[M,Nc] = A_g[M,K] * W_g[Nc,K]^T + bias_g[Nc]
+ * A row-major with leading dim lda, W row-major (torch weight layout) with leading dim ldw,
+ * C row-major with leading dim ldc.  fp32 in, fp32 MFMA accumulate (bit-equal to an fmaf chain).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dagnn_gemm_group {
+    const float* A;
+    const float* W;
+    const float* bias; /* may be NULL */
+    float* C;
+} dagnn_gemm_group;
+
+int dagnn_gemm_nt_bias(const dagnn_gemm_group* groups /* host array */, int num_groups,
+                       int64_t M, int Nc, int K, int lda, int ldw, int ldc, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Recurrent weights are consumed k-major: Wt[k, c] = W_hh[c, k]  ([H, 3H] from torch's [3H, H]).
+ * ---------------------------------------------------------------------------------------- */
+int dagnn_pack_whh(const float* w_hh /* [3H,H] */, float* w_hh_t /* [H,3H] */, int H, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One stacked GRU layer of the recurrence, all topological layers, for the directions in
+ * `dir_mask` (bit d).  One workgroup walks one (graph, direction): for every topological layer
+ * t of that graph and every frontier node v
+ *     a_v  = sum_e softmax_e( score[u_e] + gain . edge_attr_e ) * h[u_e]     (t > 0, else 0)
+ *     h[v] = GRU gates( gi[v], W_hh a_v + b_hh, a_v )
+ *     score[v] = w_key . h[v] (+ vid_bias[v mod vid_mod])
+ * Replaces AttnConv.forward/message + PyG propagate/softmax/scatter (dagnn.py:362-373), the
+ * hidden half of nn.GRUCell (dagnn.py:181) and the state write (dagnn.py:182); the query half
+ * of attn_lin and its bias cancel inside the segment softmax.
+ * The dvae NA variant's `vids` one-hot on the keys (dvae/dagnn.py:130-139) is the vid_bias term.
+ *
+ * Per direction d (arrays indexed by d; entries for directions not in dir_mask are ignored):
+ *   gi[d]       [N,3H]  W_ih u + b_ih for every node (from dagnn_gemm_nt_bias)
+ *   w_hh_t[d]   [H,3H]  packed by dagnn_pack_whh
+ *   b_hh[d]     [3H]
+ *   w_key[d]    [H]     key half of attn_lin.weight (last H entries; dagnn.py:359,370)
+ *   edge_gain[d][num_edge_feats]  = W_e^T w_key (edge_encoder folded onto the key vector), or NULL
+ *   vid_bias[d] [vid_mod] or NULL
+ *   h[d]        [N,ld_h] out: this layer's hidden states (rows are written exactly once)
+ *   score[d]    [N]     scratch
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dagnn_layer_args {
+    const float* gi[DAGNN_MAX_DIRS];
+    const float* w_hh_t[DAGNN_MAX_DIRS];
+    const float* b_hh[DAGNN_MAX_DIRS];
+    const float* w_key[DAGNN_MAX_DIRS];
+    const float* edge_gain[DAGNN_MAX_DIRS];
+    const float* vid_bias[DAGNN_MAX_DIRS];
+    float* h[DAGNN_MAX_DIRS];
+    float* score[DAGNN_MAX_DIRS];
+    int vid_mod;
+    int ld_h;
+} dagnn_layer_args;
+
+int dagnn_recurrence_layer(const dagnn_plan* plan /* host */, const dagnn_layer_args* args /* host */, int dir_mask,
+                           int H, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Read-out over output nodes (dagnn.py:119-126,184-193 with out_pool='max', out_pool_all=0):
+ *   out[g, col_off[d] + j] = max over { v in graph g : layer_{1-d}(v) == 0 } of h[d][v, j]
+ * d = 0 pools the sinks, d = 1 the sources.  h[d] is [N,ld_h]; `width` columns are pooled
+ * (pass a [N, L*H] concatenation or call once per layer with a column offset).
+ * ---------------------------------------------------------------------------------------- */
+int dagnn_readout_max(const dagnn_plan* plan /* host */, const float* h, int ld_h, int width, int dir,
+                      float* out, int ld_out, int col_off, void* stream);
+
+/* D-VAE read-out (dvae/dagnn.py:147-161, dvae/dagnn_bn.py:138-152): every graph has exactly
+ * `stride` nodes; gather row g*stride + node_off of h [N,ld_h] into out[g, col_off : col_off+width]. */
+int dagnn_gather_rows(const float* h, int ld_h, int width, int64_t num_graphs, int stride, int node_off,
+                      float* out, int ld_out, int col_off, void* stream);
+
+/* Introspection used by tests: copies plan arrays' offsets (in bytes from `plan`) into a host
+ * array: [node_ptr, edge_ptr, depth0, depth1, order0, order1, lstart0, lstart1, rowptr0,
+ * rowptr1, col0, col1, eattr0, eattr1, items, total]. */
+int dagnn_plan_layout(int64_t N, int64_t E, int64_t B, int num_edge_feats, int64_t* offsets16 /* host */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAGNN_HIP_H */

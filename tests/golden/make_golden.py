@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in this directory from the REAL reference.
+
+Runs only in the build container (needs `/root/reference`).  It imports the reference's model
+files *unmodified* (`ogbg-code/model/dagnn.py`, `ogbg-code/utils.py`, `dvae/dagnn.py`,
+`dvae/dagnn_bn.py`, `dvae/util.py`, `dvae/batch.py`, `src/utils_dag.py`) on top of our PyG
+stand-in (`oracle/pyg_standin`, see its README), runs them on seeded inputs and writes inputs +
+expected outputs as small `.npz` files.  Weights are not stored: `oracle/seeding.seeded_fill`
+regenerates them from the seed on both sides.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+The fixtures are data (inputs and expected outputs); no reference source travels.
+"""
+from __future__ import annotations
+
+import copy
+import importlib
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = os.environ.get("DAGNN_REFERENCE", "/root/reference")
+
+sys.path.insert(0, REPO)
+from oracle.seeding import seeded_fill  # noqa: E402
+from dagnn_amd import synth  # noqa: E402
+
+
+def _load_file(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _setup_paths():
+    sys.argv = sys.argv[:1]  # dvae/util.py parses argv at import
+    for p in (os.path.join(REF, "dvae"), REF, os.path.join(REPO, "oracle", "pyg_standin")):
+        if p in sys.path:
+            sys.path.remove(p)
+        sys.path.insert(0, p)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _save(name, meta, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **arrays)
+    print("wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+# ------------------------------------------------------------------------------- ogbg-code
+def make_code2(ref_dagnn, ref_utils, ref_dagutils, name, *, data_seed, B, mean_n, H, L, bidir,
+               V, S, n_attr, w_seed, row_stride, max_n=1000, **ctor):
+    from types import SimpleNamespace
+    graphs = synth.code2_graphs(data_seed, B, mean_n, max_n)
+    # layer ids from the REFERENCE's top_sort (src/utils_dag.py:8-52), not ours
+    for g in graphs:
+        g.x[:, 1] %= n_attr
+        ns = SimpleNamespace(edge_index=g.edge_index, num_nodes=g.num_nodes)
+        ref_dagutils.add_order_info_01(ns)
+        for k in ("_bi_layer_idx0", "_bi_layer_index0", "_bi_layer_idx1", "_bi_layer_index1"):
+            setattr(g, k, getattr(ns, k))
+    b = synth.GraphBatch.from_data_list(graphs)
+    enc = ref_utils.ASTNodeEncoder(H, 98, n_attr, 20)
+    kw = dict(w_edge_attr=True, num_layers=L, bidirectional=bidir, agg="attn_h", out_wx=False,
+              out_pool_all=False, out_pool="max", dropout=0.0)
+    kw.update(ctor)
+    model = ref_dagnn.DAGNN(num_vocab=V, max_seq_len=S, emb_dim=H, hidden_dim=H, out_dim=None,
+                            encoder=enc, **kw).eval()
+    seeded_fill(model, w_seed)
+    G = SimpleNamespace(x=b.x.clone(), node_depth=b.node_depth.clone(), edge_index=b.edge_index.clone(),
+                        edge_attr=b.edge_attr.clone(), batch=b.batch.clone(),
+                        _bi_layer_idx0=b._bi_layer_idx0.clone(), _bi_layer_index0=b._bi_layer_index0.clone(),
+                        _bi_layer_idx1=b._bi_layer_idx1.clone(), _bi_layer_index1=b._bi_layer_index1.clone())
+    with torch.no_grad():
+        out = model(G)
+    out = out if isinstance(out, (list, tuple)) else [out]
+    N = b.x.shape[0]
+    rows = np.arange(0, N, row_stride)
+    arrays = dict(
+        x=_np(b.x), node_depth=_np(b.node_depth), edge_index=_np(b.edge_index), edge_attr=_np(b.edge_attr),
+        batch=_np(b.batch), layer0=_np(b._bi_layer_idx0), layer1=_np(b._bi_layer_idx1),
+        pred=np.stack([_np(o) for o in out]), rows=rows, x_emb=_np(G.x)[rows],
+        node_depth_after=_np(G.node_depth),
+    )
+    if isinstance(G.h, list):
+        for d, hd in enumerate(G.h):
+            for i, h in enumerate(hd):
+                arrays["h_%d_%d" % (d, i)] = _np(h)[rows]
+    else:
+        arrays["h_cat"] = _np(G.h)
+        arrays["batch_after"] = _np(G.batch)
+    meta = dict(kind="code2", data_seed=data_seed, B=B, mean_n=mean_n, max_n=max_n, H=H, L=L, bidir=bool(bidir),
+                V=V, S=S, n_attr=n_attr, w_seed=w_seed, ctor=kw, N=int(N), E=int(b.edge_index.shape[1]),
+                T=int(b._bi_layer_idx0.max()) + 1,
+                state_dict={k: list(v.shape) for k, v in model.state_dict().items()})
+    _save(name, meta, **arrays)
+
+
+# ------------------------------------------------------------------------------- dvae
+def _dvae_case(model, graphs, ref_batch_mod):
+    data = [copy.deepcopy(g) for g in graphs]  # models_pyg.py:114-115 (collation mutates)
+    b = ref_batch_mod.Batch.from_data_list(data)
+    b.batch_before = b.batch.clone()  # forward overwrites G.batch with the read-out rows' ids
+    with torch.no_grad():
+        Hg = model(b)
+        mu, logvar = model.fc1(Hg), model.fc2(Hg)
+        # encode() itself must agree (dvae/dagnn.py:177-184)
+        mu2, lv2 = model.encode([copy.deepcopy(g) for g in graphs])
+    assert torch.equal(mu, mu2) and torch.equal(logvar, lv2)
+    return b, Hg, mu, logvar
+
+
+def make_na(ref_na, ref_util, ref_batch_mod, name, *, hs, L, bidir, w_seed, nrows=64):
+    rows = []
+    with open(os.path.join(REF, "dvae", "data", "final_structures6.txt")) as f:
+        for i, line in enumerate(f):
+            if i < 1000:  # burn_in of load_ENAS_graphs (dvae/util.py:67)
+                continue
+            rows.append(eval(line)[0])
+            if len(rows) == nrows:
+                break
+    graphs = [ref_util.decode_ENAS_to_pygraph(r)[0] for r in rows]
+    model = ref_na.DAGNN(8, hs, hs, 8, 8, 0, 1, hs=hs, nz=56, num_nodes=8, agg="attn_h", num_layers=L,
+                         bidirectional=bidir, out_wx=False, out_pool_all=False, out_pool="max",
+                         dropout=0.0).eval()
+    seeded_fill(model, w_seed)
+    b, Hg, mu, logvar = _dvae_case(model, graphs, ref_batch_mod)
+    meta = dict(kind="na", hs=hs, L=L, bidir=bool(bidir), w_seed=w_seed, nrows=nrows,
+                state_dict={k: list(v.shape) for k, v in model.state_dict().items()})
+    _save(name, meta, rows=np.array([json.dumps(r) for r in rows]),
+          x=_np(b.x), edge_index=_np(b.edge_index), bi_layer_index=_np(b.bi_layer_index), batch=_np(b.batch_before), batch_after=_np(b.batch),
+          Hg=_np(Hg), mu=_np(mu), logvar=_np(logvar))
+
+
+def make_bn(ref_bn, ref_util, ref_batch_mod, name, *, hs, L, bidir, w_seed, data_seed, nrows):
+    rows = synth.bn_rows(data_seed, nrows)
+    graphs = [ref_util.decode_BN_to_pygraph(r)[0] for r in rows]
+    model = ref_bn.DAGNN_BN(10, hs, hs, 10, 10, 0, 1, hs=hs, nz=56, num_nodes=10, agg="attn_h", num_layers=L,
+                            bidirectional=bidir, out_wx=False, out_pool_all=False, out_pool="max",
+                            dropout=0.0).eval()
+    seeded_fill(model, w_seed)
+    b, Hg, mu, logvar = _dvae_case(model, graphs, ref_batch_mod)
+    meta = dict(kind="bn", hs=hs, L=L, bidir=bool(bidir), w_seed=w_seed, data_seed=data_seed, nrows=nrows,
+                state_dict={k: list(v.shape) for k, v in model.state_dict().items()})
+    _save(name, meta, rows=np.array([json.dumps(r) for r in rows]),
+          x=_np(b.x), edge_index=_np(b.edge_index), bi_layer_index=_np(b.bi_layer_index), batch=_np(b.batch_before), batch_after=_np(b.batch),
+          Hg=_np(Hg), mu=_np(mu), logvar=_np(logvar))
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference not found at %s - fixtures can only be regenerated in the build container" % REF)
+    _setup_paths()
+    torch.manual_seed(0)
+    ref_dagutils = importlib.import_module("src.utils_dag")
+    ref_dagnn = _load_file("ref_ogbg_dagnn", os.path.join(REF, "ogbg-code", "model", "dagnn.py"))
+    ref_utils = _load_file("ref_ogbg_utils", os.path.join(REF, "ogbg-code", "utils.py"))
+
+    common = dict(V=48, S=5, n_attr=300)
+    # tiny generic-H case, every hidden row stored
+    make_code2(ref_dagnn, ref_utils, ref_dagutils, "code2_h32_bidir", data_seed=11, B=6, mean_n=30, H=32, L=2,
+               bidir=1, w_seed=101, row_stride=1, **common)
+    # the headline shape (h=256, L=2, bidirectional) on a small batch
+    make_code2(ref_dagnn, ref_utils, ref_dagutils, "code2_h256_bidir", data_seed=12, B=8, mean_n=60, H=256, L=2,
+               bidir=1, w_seed=102, row_stride=5, **common)
+    # cfg-5 shaped (h=512, L=5), tiny
+    make_code2(ref_dagnn, ref_utils, ref_dagutils, "code2_h512_L5", data_seed=13, B=4, mean_n=25, H=512, L=5,
+               bidir=1, w_seed=103, row_stride=4, **common)
+    # emb 300 as in scripts/ogb_tok.sh (H not a power of two), 3 layers
+    make_code2(ref_dagnn, ref_utils, ref_dagutils, "code2_h300_L3", data_seed=14, B=5, mean_n=40,
+               H=300, L=3, bidir=1, w_seed=104, row_stride=3, **common)
+    # unidirectional + pooled over output nodes (dagnn.py:195-202 branch)
+    make_code2(ref_dagnn, ref_utils, ref_dagutils, "code2_h64_unidir", data_seed=15, B=7, mean_n=35, H=64, L=2,
+               bidir=0, w_seed=105, row_stride=1, **common)
+    # LP-style single classification head (num_class>0, dagnn.py:103-104,209-210)
+    make_code2(ref_dagnn, ref_utils, ref_dagutils, "code2_h64_numclass", data_seed=16, B=5, mean_n=30, H=64, L=2,
+               bidir=1, w_seed=106, row_stride=1, V=48, S=5, n_attr=300, num_class=17)
+    # deep chain stress: long graphs (depth ~ 200) to exercise many recurrent steps
+    make_code2(ref_dagnn, ref_utils, ref_dagutils, "code2_h128_deep", data_seed=17, B=3, mean_n=400, H=128, L=2,
+               bidir=1, w_seed=107, row_stride=7, **common)
+
+    ref_util = importlib.import_module("util")
+    ref_batch_mod = importlib.import_module("batch")
+    ref_na = importlib.import_module("dagnn")
+    ref_bn = importlib.import_module("dagnn_bn")
+    make_na(ref_na, ref_util, ref_batch_mod, "na_h128_unidir", hs=128, L=2, bidir=False, w_seed=201)
+    make_na(ref_na, ref_util, ref_batch_mod, "na_h64_bidir", hs=64, L=2, bidir=True, w_seed=202, nrows=16)
+    make_bn(ref_bn, ref_util, ref_batch_mod, "bn_h256_bidir", hs=256, L=2, bidir=True, w_seed=203, data_seed=5,
+            nrows=32)
+    make_bn(ref_bn, ref_util, ref_batch_mod, "bn_h64_unidir", hs=64, L=3, bidir=False, w_seed=204, data_seed=6,
+            nrows=12)
+
+
+if __name__ == "__main__":
+    main()

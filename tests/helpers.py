@@ -1,0 +1,65 @@
+"""Fixture loading and model construction shared by the CPU and GPU test tiers."""
+from __future__ import annotations
+
+import json
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+import dagnn_amd
+from dagnn_amd import DAGNN, DAGNN_BN, DAGNN_NA, ASTNodeEncoder
+from oracle.seeding import seeded_fill
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CODE2 = ["code2_h32_bidir", "code2_h256_bidir", "code2_h512_L5", "code2_h300_L3", "code2_h64_unidir",
+         "code2_h64_numclass", "code2_h128_deep"]
+DVAE = ["na_h128_unidir", "na_h64_bidir", "bn_h256_bidir", "bn_h64_unidir"]
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    meta = json.loads(bytes(z["meta"]).decode())
+    return meta, {k: z[k] for k in z.files if k != "meta"}
+
+
+def code2_model(meta):
+    H = meta["H"]
+    enc = ASTNodeEncoder(H, 98, meta["n_attr"], 20)
+    model = DAGNN(num_vocab=meta["V"], max_seq_len=meta["S"], emb_dim=H, hidden_dim=H, out_dim=None, encoder=enc,
+                  **meta["ctor"]).eval()
+    seeded_fill(model, meta["w_seed"])
+    return model
+
+
+def code2_batch(arr, device="cpu"):
+    t = lambda k, dt=None: torch.from_numpy(arr[k].copy()).to(device)  # noqa: E731
+    N = arr["x"].shape[0]
+    ids = torch.arange(N, device=device)
+    return SimpleNamespace(x=t("x"), node_depth=t("node_depth"), edge_index=t("edge_index"), edge_attr=t("edge_attr"),
+                           batch=t("batch"), _bi_layer_idx0=t("layer0"), _bi_layer_index0=ids,
+                           _bi_layer_idx1=t("layer1"), _bi_layer_index1=ids.clone(),
+                           num_graphs=int(arr["batch"].max()) + 1)
+
+
+def dvae_model(meta):
+    cls, nn_ = (DAGNN_NA, 8) if meta["kind"] == "na" else (DAGNN_BN, 10)
+    hs = meta["hs"]
+    model = cls(nn_, hs, hs, nn_, nn_, 0, 1, hs=hs, nz=56, num_nodes=nn_, agg="attn_h", num_layers=meta["L"],
+                bidirectional=meta["bidir"], out_wx=False, out_pool_all=False, out_pool="max", dropout=0.0).eval()
+    seeded_fill(model, meta["w_seed"])
+    return model, nn_
+
+
+def dvae_batch(arr, device="cpu"):
+    t = lambda k: torch.from_numpy(arr[k].copy()).to(device)  # noqa: E731
+    return dagnn_amd.GraphBatch(x=t("x"), edge_index=t("edge_index"), bi_layer_index=t("bi_layer_index"),
+                                batch=t("batch"))
+
+
+def maxdiff(a, b):
+    a = a.detach().cpu().double() if isinstance(a, torch.Tensor) else torch.as_tensor(a).double()
+    b = b.detach().cpu().double() if isinstance(b, torch.Tensor) else torch.as_tensor(b).double()
+    return float((a - b).abs().max()) if a.numel() else 0.0

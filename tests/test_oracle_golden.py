@@ -1,0 +1,62 @@
+"""Pins the oracle (oracle/dagnn_oracle.py) against outputs of the REAL reference
+(tests/golden/*.npz, written by tests/golden/make_golden.py in the build container)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dagnn_oracle as O
+from tests import helpers as Hh
+
+TOL = 2e-5  # fp32 restatement vs fp32 reference: different summation order only
+
+
+@pytest.mark.parametrize("name", Hh.CODE2)
+@pytest.mark.parametrize("mode", ["csr", "faithful"])
+def test_code2_oracle_matches_reference(name, mode):
+    meta, arr = Hh.load(name)
+    if mode == "faithful" and meta["N"] > 700:
+        pytest.skip("faithful mirror is O(N*E); covered by the smaller fixtures")
+    model = Hh.code2_model(meta)
+    G = Hh.code2_batch(arr)
+    kw = meta["ctor"]
+    out = O.code2_forward(model.state_dict(), G, num_layers=kw["num_layers"], bidirectional=bool(kw["bidirectional"]),
+                          out_wx=kw["out_wx"], out_pool_all=kw["out_pool_all"], out_pool=kw["out_pool"],
+                          max_seq_len=meta["S"], num_class=kw.get("num_class", 0), mode=mode)
+    out = out if isinstance(out, list) else [out]
+    assert len(out) == arr["pred"].shape[0]
+    for o, ref in zip(out, arr["pred"]):
+        assert o.shape == ref.shape
+        assert Hh.maxdiff(o, ref) < TOL
+    rows = arr["rows"]
+    assert Hh.maxdiff(G.x[rows], arr["x_emb"]) < 1e-6
+    assert np.array_equal(G.node_depth.numpy(), arr["node_depth_after"])
+    if isinstance(G.h, list):
+        for d, hd in enumerate(G.h):
+            for i, h in enumerate(hd):
+                assert Hh.maxdiff(h[rows], arr["h_%d_%d" % (d, i)]) < TOL
+    else:
+        assert Hh.maxdiff(G.h, arr["h_cat"]) < TOL
+        assert np.array_equal(G.batch.numpy(), arr["batch_after"])
+
+
+@pytest.mark.parametrize("name", Hh.DVAE)
+@pytest.mark.parametrize("mode", ["csr", "faithful"])
+def test_dvae_oracle_matches_reference(name, mode):
+    meta, arr = Hh.load(name)
+    model, nn_ = Hh.dvae_model(meta)
+    G = Hh.dvae_batch(arr)
+    mu, logvar = O.dvae_encode(model.state_dict(), G, num_layers=meta["L"], bidirectional=meta["bidir"],
+                               num_nodes=nn_, vids=meta["kind"] == "na", mode=mode)
+    assert Hh.maxdiff(mu, arr["mu"]) < TOL
+    assert Hh.maxdiff(logvar, arr["logvar"]) < TOL
+
+
+def test_fp64_oracle_brackets_reference():
+    """The fp64 oracle is the 'true' value: the fp32 reference must sit within fp32 round-off of it."""
+    meta, arr = Hh.load("code2_h256_bidir")
+    model = Hh.code2_model(meta)
+    G = Hh.code2_batch(arr)
+    kw = meta["ctor"]
+    out = O.code2_forward(model.state_dict(), G, num_layers=kw["num_layers"], bidirectional=True, out_wx=False,
+                          out_pool_all=False, out_pool="max", max_seq_len=meta["S"], dtype=torch.float64)
+    assert max(Hh.maxdiff(o, r) for o, r in zip(out, arr["pred"])) < TOL

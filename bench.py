@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Headline benchmark: graphs/sec + ms/batch of DAGNN.forward(G) on code2-like AST batches.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE end-to-end forward(G) over one batch (plan build + AST encoder + L x (input GEMM +
+recurrence) + read-out + 5 vocabulary heads), inputs already resident in HBM.  Workload = cfg 2
+of BASELINE.json: synthetic ogbg-code2-like ASTs (seed = rank), batch=128,
+h=256, L=2, bidirectional, vocab 5002 x 5 heads, fp32.  Graph-parallel weak scaling: every rank
+runs its own 128-graph batch, no data-path collective (graphs are independent).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the per-layer recurrence):
+duration from HIP events on the launching stream inside the timed region.  `cpu_baseline` is the
+oracle's op-for-op restatement of the reference (per-node edge scan, full [N,H] scatter) timed on
+this host - a reported baseline, never the thing measured.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA == fp32 vector peak
+HBM_PEAK_GBPS = 8000.0
+
+
+def build_model(H, L, V, S, device):
+    from dagnn_amd import DAGNN, ASTNodeEncoder
+    torch.manual_seed(0)  # random-init weights of the reference architecture (no checkpoints offline)
+    enc = ASTNodeEncoder(H, 98, 10030, 20)
+    model = DAGNN(num_vocab=V, max_seq_len=S, emb_dim=H, hidden_dim=H, out_dim=None, encoder=enc, w_edge_attr=True,
+                  num_layers=L, bidirectional=True, agg="attn_h", out_wx=False, out_pool_all=False, out_pool="max",
+                  dropout=0.0).eval()
+    return model.to(device)
+
+
+def fresh_inputs(master, n):
+    """forward() mutates G (G.x becomes the embedding, node_depth is clamped): one namespace per step,
+    cloned on the device BEFORE the timed region."""
+    out = []
+    for _ in range(n):
+        out.append(SimpleNamespace(
+            x=master.x.clone(), node_depth=master.node_depth.clone(), edge_index=master.edge_index,
+            edge_attr=master.edge_attr, batch=master.batch, _bi_layer_idx0=master._bi_layer_idx0,
+            _bi_layer_index0=master._bi_layer_index0, _bi_layer_idx1=master._bi_layer_idx1,
+            _bi_layer_index1=master._bi_layer_index1, num_graphs=master.num_graphs))
+    return out
+
+
+def cpu_baseline(model_cpu_sd, batch, L, S, passes):
+    """Oracle `faithful` mode = the reference's algorithm restated op for op, on this host's cores."""
+    import copy
+    from oracle import dagnn_oracle as O
+    t0 = time.perf_counter()
+    O.code2_forward(model_cpu_sd, copy.deepcopy(batch), num_layers=L, max_seq_len=S, mode="faithful")  # warm-up
+    warm = time.perf_counter() - t0
+    times = []
+    for _ in range(passes):
+        g = copy.deepcopy(batch)
+        t0 = time.perf_counter()
+        O.code2_forward(model_cpu_sd, g, num_layers=L, max_seq_len=S, mode="faithful")
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(batch.num_graphs / med, 2), "unit": "graphs/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "%d full forward passes (median) over the same %d-graph seed-0 batch, oracle faithful mode "
+                      "(per-node edge scan + full [N,H] scatter as ogbg-code/model/dagnn.py:144-182), torch %s CPU, "
+                      "%.2f s/batch, first pass %.1f s" % (passes, batch.num_graphs, torch.__version__, med, warm),
+            "ms_per_batch": round(med * 1e3, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--vocab", type=int, default=5002)
+    ap.add_argument("--cpu-passes", type=int, default=3, help="0 disables the CPU baseline leg")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path is HIP for gfx950 and has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # nccl == RCCL on ROCm
+
+    from dagnn_amd import engine
+    from dagnn_amd.synth import code2_batch
+
+    H, L, S, V, B = args.hidden, args.layers, 5, args.vocab, args.batch
+    model = build_model(H, L, V, S, device)
+    batch_cpu = code2_batch(seed=rank, num_graphs=B)  # weak scaling: one B-graph batch per rank
+    N, E = batch_cpu.x.shape[0], batch_cpu.edge_index.shape[1]
+    T = int(batch_cpu._bi_layer_idx0.max()) + 1
+    master = batch_cpu.clone().to(device)
+    inputs = fresh_inputs(master, args.warmup + args.steps)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            out = model(inputs[i])
+        torch.cuda.synchronize()
+        timer = None if args.no_kernel_timer else engine.KernelTimer()
+        engine.TIMER = timer
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, args.warmup + args.steps):
+            out = model(inputs[i])
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        engine.TIMER = None
+    assert all(torch.isfinite(o).all() for o in out)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    result = {
+        "metric": "graphs/sec", "value": round(value, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "ogbg-code2-like synthetic ASTs (SURVEY.md App. E, seed=rank), batch=%d h=%d L=%d "
+                               "bidirectional attn_h, max-pool over output nodes, %d heads x vocab %d, forward(G) "
+                               "end-to-end incl. plan build" % (B, H, L, S, V),
+                   "global_batch": world * B, "nodes_per_batch": N, "edges_per_batch": E, "topo_layers": T,
+                   "parallelism": "graph-parallel x%d, no data-path collective" % world},
+    }
+    if rank == 0:
+        D = 2
+        if timer is not None:
+            summ = timer.summary()
+            n_rec, ms_rec = summ.get("recurrence_layer", (0, 0.0))
+            n_gemm, ms_gemm = summ.get("gemm_nt_bias", (0, 0.0))
+            n_plan, ms_plan = summ.get("plan_build", (0, 0.0))
+            # algorithmic work of ONE recurrence launch (one stacked layer, both directions), SURVEY.md §8(d):
+            # hidden-side GEMV 2*H*3H per node-update + attention/gates (2NH + 2EH + 15NH)
+            flops = D * (N * 6.0 * H * H + 2.0 * N * H + 2.0 * E * H + 15.0 * N * H)
+            # compulsory HBM bytes: predecessor rows + own row write ((E+N)*4H), gi read (N*12H), CSR, scores
+            byts = D * ((E + N) * 4.0 * H + N * 12.0 * H + 8.0 * E + 12.0 * N)
+            if ms_rec > 0:
+                tf = flops / (ms_rec * 1e-3) / 1e12
+                result["roofline"] = {
+                    "kernel": "recurrence_kernel<KSL> (dagnn_recurrence_layer), one launch = one stacked GRU layer, "
+                              "both directions, all topological layers",
+                    "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 5), "traffic": None,
+                    "launches_timed": n_rec, "avg_launch_ms": round(ms_rec, 4),
+                    "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": byts,
+                    "hbm_frac_of_8TBps": round(byts / (ms_rec * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                    "us_per_dependent_step": round(ms_rec * 1e3 / max(T, 1), 3),
+                }
+                result["kernels_ms_per_step"] = {
+                    "recurrence_layer": round(ms_rec * n_rec / args.steps, 4),
+                    "gemm_nt_bias": round(ms_gemm * n_gemm / args.steps, 4),
+                    "plan_build": round(ms_plan * n_plan / args.steps, 4)}
+        if args.cpu_passes > 0:
+            cpu_sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            result["cpu_baseline"] = cpu_baseline(cpu_sd, batch_cpu, L, S, args.cpu_passes)
+        print(json.dumps(result))
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

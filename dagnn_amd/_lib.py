@@ -35,7 +35,7 @@ class LayerArgs(C.Structure):
     _fields_ = [("gi", C.c_void_p * MAX_DIRS), ("w_hh_t", C.c_void_p * MAX_DIRS), ("b_hh", C.c_void_p * MAX_DIRS),
                 ("w_key", C.c_void_p * MAX_DIRS), ("edge_gain", C.c_void_p * MAX_DIRS),
                 ("vid_bias", C.c_void_p * MAX_DIRS), ("h", C.c_void_p * MAX_DIRS), ("score", C.c_void_p * MAX_DIRS),
-                ("vid_mod", C.c_int), ("ld_h", C.c_int)]
+                ("vid_mod", C.c_int), ("ld_h", C.c_int), ("debug_timing", C.c_void_p)]
 
 
 # every symbol include/dagnn_hip.h declares: (restype, argtypes)

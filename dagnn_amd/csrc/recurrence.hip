@@ -36,6 +36,7 @@ struct RecArgs {
     float* h[2];
     float* score[2];
     int vid_mod, ld_h, H, R, dir_mask, kper, rmax;
+    unsigned long long* dbg;  // optional [8] phase timing of work item 0 (wall_clock64 ticks, 100 MHz)
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -220,6 +221,9 @@ __global__ void __launch_bounds__(MAX_WAVES * 64) recurrence_kernel(const int32_
     float* hbuf = P.h[d];      // read (predecessor rows) and written (frontier rows): no restrict
     float* score = P.score[d];
 
+    const bool prof = P.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+    unsigned long long tA = 0, tB = 0, tC = 0, nchunk = 0, t_start = 0, tq = 0;
+    if (prof) t_start = wall_clock64();
     for (int t = 0; t < depth; ++t) {
         const int p0 = ls[t], p1 = ls[t + 1];
         if (t == 0) {
@@ -232,6 +236,7 @@ __global__ void __launch_bounds__(MAX_WAVES * 64) recurrence_kernel(const int32_
         }
         for (int c0 = p0; c0 < p1; c0 += rmax) {
             const int nr = min(rmax, p1 - c0);
+            if (prof) tq = wall_clock64();
             // ---- A: aggregate predecessors (one wave per row)
             for (int r = wave; r < nr; r += nwaves) {
                 const int p = c0 + r;
@@ -239,18 +244,25 @@ __global__ void __launch_bounds__(MAX_WAVES * 64) recurrence_kernel(const int32_
                               a_s + r * a_ld, H, kper, lane);
             }
             __syncthreads();
+            if (prof) { unsigned long long n = wall_clock64(); tA += n - tq; tq = n; }
             // ---- B: gh = W_hh a for the chunk's rows
             if (nr == 1) gemv_tiles<KSL, 1>(wt, a_s, gh_s, H, kper, a_ld, wave, nwaves, lane);
             else if (nr == 2) gemv_tiles<KSL, 2>(wt, a_s, gh_s, H, kper, a_ld, wave, nwaves, lane);
             else if (nr <= 4) gemv_tiles<KSL, 4>(wt, a_s, gh_s, H, kper, a_ld, wave, nwaves, lane);
             else gemv_tiles<KSL, 8>(wt, a_s, gh_s, H, kper, a_ld, wave, nwaves, lane);
             __syncthreads();
+            if (prof) { unsigned long long n = wall_clock64(); tB += n - tq; tq = n; }
             // ---- C: gates + state write + score (one wave per row)
             for (int r = wave; r < nr; r += nwaves)
                 gates_row(order[c0 + r], gi, gh_s + r * H3, bhh, a_s + r * a_ld, true, hbuf, P.ld_h, score, wkey,
                           vid, P.vid_mod, H, kper, lane);
             __syncthreads();
+            if (prof) { unsigned long long n = wall_clock64(); tC += n - tq; ++nchunk; }
         }
+    }
+    if (prof) {
+        P.dbg[0] = tA; P.dbg[1] = tB; P.dbg[2] = tC; P.dbg[3] = nchunk;
+        P.dbg[4] = wall_clock64() - t_start; P.dbg[5] = (unsigned long long)depth;
     }
 }
 
@@ -270,6 +282,7 @@ extern "C" int dagnn_recurrence_layer(const dagnn_plan* pl, const dagnn_layer_ar
         if ((dir_mask >> d) & 1)
             if (!P.gi[d] || !P.wt[d] || !P.bhh[d] || !P.wkey[d] || !P.h[d] || !P.score[d]) return DAGNN_EINVAL;
     }
+    P.dbg = (unsigned long long*)a->debug_timing;
     P.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
     P.ld_h = a->ld_h; P.H = H; P.R = pl->num_edge_feats; P.dir_mask = dir_mask & 3;
     // K split: the largest KSL whose tile count fits the 12 waves of a workgroup

@@ -15,6 +15,52 @@ from . import _lib
 from ._lib import DagnnHipError, GemmGroup, LayerArgs, Plan, check
 
 
+class KernelTimer(object):
+    """Optional HIP-event timing of individual launches (bench.py): events are recorded on the
+    stream the kernel is launched on (torch's current stream), so they bracket exactly that kernel."""
+
+    def __init__(self):
+        self.spans = {}
+
+    def span(self, name, device):
+        return _Span(self, name, device)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1)) for k, v in self.spans.items()}
+
+
+class _Span(object):
+    def __init__(self, timer, name, device):
+        self.timer, self.name, self.device = timer, name, device
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record(torch.cuda.current_stream(self.device))
+
+    def __exit__(self, *exc):
+        self.b.record(torch.cuda.current_stream(self.device))
+        self.timer.spans.setdefault(self.name, []).append((self.a, self.b))
+
+
+class _NoSpan(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+TIMER: Optional[KernelTimer] = None  # set by bench.py around its timed region
+DEBUG_TIMING: Optional[torch.Tensor] = None  # int64[8] device tensor: phase ticks of the deepest work item
+_NOSPAN = _NoSpan()
+
+
+def _span(name, tensor):
+    return TIMER.span(name, tensor.device) if TIMER is not None else _NOSPAN
+
+
 def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
@@ -72,9 +118,10 @@ def build_plan(edge_index: torch.Tensor, layer_fwd: torch.Tensor, layer_bwd: tor
         edge_attr = _dev(edge_attr, "edge_attr", torch.float32).view(E, -1)
         R = edge_attr.shape[1]
     plan = PlanHandle(N, E, num_graphs, R, edge_index.device)
-    check(_lib.load().dagnn_plan_build(C.byref(plan.desc), edge_index.data_ptr(), layer_fwd.data_ptr(),
-                                       layer_bwd.data_ptr(), batch.data_ptr(), _ptr(edge_attr),
-                                       plan.status.data_ptr(), _stream(edge_index)), "dagnn_plan_build")
+    with _span("plan_build", edge_index):
+        check(_lib.load().dagnn_plan_build(C.byref(plan.desc), edge_index.data_ptr(), layer_fwd.data_ptr(),
+                                           layer_bwd.data_ptr(), batch.data_ptr(), _ptr(edge_attr),
+                                           plan.status.data_ptr(), _stream(edge_index)), "dagnn_plan_build")
     plan._keep = (edge_index, layer_fwd, layer_bwd, batch, edge_attr)
     return plan
 
@@ -113,7 +160,8 @@ def gemm_nt_bias(A: Sequence[torch.Tensor], W: Sequence[torch.Tensor], bias: Seq
         b = None if bias[g] is None else _dev(bias[g], "bias", torch.float32)
         keep.append(b)
         groups[g] = GemmGroup(A[g].data_ptr(), W[g].data_ptr(), _ptr(b), out[g].data_ptr())
-    check(_lib.load().dagnn_gemm_nt_bias(groups, n, M, Nc, K, K, K, Nc, _stream(A[0])), "dagnn_gemm_nt_bias")
+    with _span("gemm_nt_bias", A[0]):
+        check(_lib.load().dagnn_gemm_nt_bias(groups, n, M, Nc, K, K, K, Nc, _stream(A[0])), "dagnn_gemm_nt_bias")
     return list(out)
 
 
@@ -147,8 +195,10 @@ def recurrence_layer(plan: PlanHandle, dirs: Sequence[int], H: int, gi, w_hh_t, 
         args.edge_gain[d], args.vid_bias[d] = _ptr(eg), _ptr(vb)
         args.h[d], args.score[d] = h[d].data_ptr(), sc.data_ptr()
     args.vid_mod, args.ld_h = int(vid_mod), H
-    check(_lib.load().dagnn_recurrence_layer(C.byref(plan.desc), C.byref(args), mask, H, _stream(plan.ws)),
-          "dagnn_recurrence_layer")
+    args.debug_timing = DEBUG_TIMING.data_ptr() if DEBUG_TIMING is not None else None
+    with _span("recurrence_layer", plan.ws):
+        check(_lib.load().dagnn_recurrence_layer(C.byref(plan.desc), C.byref(args), mask, H, _stream(plan.ws)),
+              "dagnn_recurrence_layer")
     return h
 
 

@@ -140,6 +140,7 @@ typedef struct dagnn_layer_args {
     float* score[DAGNN_MAX_DIRS];
     int vid_mod;
     int ld_h;
+    void* debug_timing; /* NULL, or 8 uint64 device words: per-phase 100 MHz ticks of the deepest work item */
 } dagnn_layer_args;
 
 int dagnn_recurrence_layer(const dagnn_plan* plan /* host */, const dagnn_layer_args* args /* host */, int dir_mask,

@@ -1,0 +1,180 @@
+"""CPU tier (-m "not gpu"): host logic, the C-ABI library's exports, data plumbing, sharding."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import dagnn_amd
+from dagnn_amd import _lib, collate_sharded, dag_utils, shard_by_nodes, synth
+from tests import helpers as Hh
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+# ------------------------------------------------------------------ C ABI surface
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dagnn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dagnn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 10
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(declared) == set(_lib.SYMBOLS), set(declared) ^ set(_lib.SYMBOLS)
+    assert lib.dagnn_version().decode().startswith("dagnn_hip")
+
+
+def test_host_only_entry_points_without_gpu():
+    lib = _lib.load()
+    n = lib.dagnn_plan_bytes(16561, 25377, 128, 2)
+    assert n > 0 and n % 4 == 0
+    off = (ctypes.c_int64 * 16)()
+    assert lib.dagnn_plan_layout(16561, 25377, 128, 2, off) == 0
+    offs = list(off)
+    assert offs[-1] == n and all(a < b for a, b in zip(offs[:-1], offs[1:]))
+    assert lib.dagnn_plan_bytes(-1, 0, 0, 0) == 0
+    # argument validation happens before any HIP call
+    assert lib.dagnn_pack_whh(None, None, 8, None) == -22
+    assert lib.dagnn_encode_ast(None, None, None, None, None, 20, None, 6, 5, 6, None) == -22  # H % 4 != 0
+    assert lib.dagnn_gather_rows(None, 4, 4, 1, 8, 9, None, 4, 0, None) == -22
+
+
+def test_engine_refuses_cpu_tensors():
+    from dagnn_amd import engine
+    with pytest.raises(_lib.DagnnHipError):
+        engine.pack_whh(torch.randn(12, 4))
+    meta, arr = Hh.load("code2_h32_bidir")
+    model = Hh.code2_model(meta)
+    with pytest.raises(_lib.DagnnHipError), torch.no_grad():
+        model(Hh.code2_batch(arr))  # no CPU fallback for the hot path
+
+
+# ------------------------------------------------------------------ layering / decoders vs the reference
+@pytest.mark.parametrize("name", Hh.CODE2)
+def test_layering_matches_reference_top_sort(name):
+    meta, arr = Hh.load(name)
+    batch, ei = arr["batch"], arr["edge_index"]
+    for g in range(int(batch.max()) + 1):
+        nodes = np.flatnonzero(batch == g)
+        n0 = nodes[0]
+        em = batch[ei[0]] == g
+        sub = ei[:, em] - n0
+        assert np.array_equal(dag_utils.longest_path_layers(sub, len(nodes)), arr["layer0"][nodes])
+        assert np.array_equal(dag_utils.longest_path_layers(sub[::-1], len(nodes)), arr["layer1"][nodes])
+        assert dag_utils.check_layers(sub, arr["layer0"][nodes])
+
+
+def test_layering_rejects_cycles():
+    with pytest.raises(ValueError):
+        dag_utils.longest_path_layers(np.array([[0, 1, 2], [1, 2, 0]]), 3)
+
+
+@pytest.mark.parametrize("name", Hh.DVAE)
+def test_dvae_decoders_match_reference(name):
+    meta, arr = Hh.load(name)
+    rows = [json.loads(r) for r in arr["rows"]]
+    dec = synth.decode_enas_row if meta["kind"] == "na" else synth.decode_bn_row
+    b = synth.dvae_batch([dec(r) for r in rows])
+    assert np.array_equal(b.x.numpy(), arr["x"])
+    assert np.array_equal(b.edge_index.numpy(), arr["edge_index"])
+    assert np.array_equal(b.bi_layer_index.numpy(), arr["bi_layer_index"])
+    assert np.array_equal(b.batch.numpy(), arr["batch"])
+
+
+def test_headline_generator_reproduces_survey_numbers():
+    b = synth.code2_batch(0, 128)
+    assert (b.x.shape[0], b.edge_index.shape[1]) == (16561, 25377)
+    assert int(b._bi_layer_idx0.max()) + 1 == 374 and int(b._bi_layer_idx1.max()) + 1 == 374
+    assert b.num_graphs == 128 and int(b.batch[-1]) == 127
+    ea = b.edge_attr
+    assert set(map(tuple, ea.unique(dim=0).tolist())) == {(0.0, 0.0), (1.0, 0.0)}  # utils2.py:44,67
+
+
+# ------------------------------------------------------------------ collation / sharding
+def test_collation_offsets_index_keys_only():
+    gs = synth.code2_graphs(5, 3, 20)
+    b = dagnn_amd.GraphBatch.from_data_list(gs)
+    n = [g.num_nodes for g in gs]
+    assert b.edge_index.shape[0] == 2 and int(b.edge_index.max()) < sum(n)
+    # "_index" keys are shifted by the running node count, "_idx" keys are not (dagnn.py:129)
+    assert torch.equal(b._bi_layer_index0, torch.arange(sum(n)))
+    assert int(b._bi_layer_idx0.max()) < max(n)
+    assert torch.equal(b.batch, torch.repeat_interleave(torch.arange(3), torch.tensor(n)))
+    assert b.x.shape == (sum(n), 2) and b.edge_attr.shape[0] == b.edge_index.shape[1]
+
+
+def test_shard_rule_matches_reference_collater():
+    """`tg/dataloader.py:17-27` on the seed-0 headline batch: numbers measured from the reference
+    (SURVEY.md §8(e))."""
+    graphs = synth.code2_graphs(0, 128)
+    n = [g.num_nodes for g in graphs]
+    s2 = shard_by_nodes(n, 2)
+    assert [(b - a, sum(n[a:b])) for a, b in zip(s2[:-1], s2[1:])] == [(60, 8250), (68, 8311)]
+    s8 = shard_by_nodes(n, 8)
+    got = [(b - a, sum(n[a:b])) for a, b in zip(s8[:-1], s8[1:])]
+    assert got == [(12, 2095), (16, 2078), (16, 2012), (16, 2065), (15, 2099), (18, 2064), (17, 2052), (18, 2096)]
+    assert shard_by_nodes(n, 1) == [0, 128]
+    # more devices than graphs: empty devices are dropped
+    assert len(shard_by_nodes([5, 5], 8)) - 1 == 2
+    shards = collate_sharded(graphs, 8)
+    assert [s.num_graphs for s in shards] == [g for g, _ in got]
+
+
+# ------------------------------------------------------------------ module contract
+@pytest.mark.parametrize("name", Hh.CODE2)
+def test_state_dict_contract_code2(name):
+    meta, _ = Hh.load(name)
+    model = Hh.code2_model(meta)
+    sd = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert list(sd.items()) == list(meta["state_dict"].items())  # names, shapes AND order
+
+
+@pytest.mark.parametrize("name", Hh.DVAE)
+def test_state_dict_contract_dvae(name):
+    meta, _ = Hh.load(name)
+    model, _ = Hh.dvae_model(meta)
+    sd = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert list(sd.items()) == list(meta["state_dict"].items())
+    # cells_d alias the base class's encoder GRUs (dvae/dagnn.py:73-75)
+    assert model.cells_0[0].weight_hh is model.grue_forward[0].weight_hh
+
+
+def test_ctor_errors_and_defaults():
+    with pytest.raises(ValueError):
+        dagnn_amd.DAGNN(10, 5, emb_dim=64, hidden_dim=32, out_dim=None, agg_x=True)  # dagnn.py:27-28
+    m = dagnn_amd.DAGNN(10, 5, emb_dim=16, hidden_dim=16, out_dim=None, encoder=dagnn_amd.ASTNodeEncoder(16, 4, 4, 20))
+    assert m.out_wx and m.output_all and m.out_hidden_dim == 16 * 2 + 16 * 2 * 2  # reference defaults (:19-21,44)
+    m2 = dagnn_amd.DAGNN(10, 5, 16, 16, None, agg="gated_sum", encoder=None)
+    assert "node_aggr_0.0.mapper.weight" in m2.state_dict()
+    with pytest.raises(NotImplementedError):
+        m2(object())
+
+
+def test_checkpoint_roundtrip_with_module_prefix(tmp_path):
+    """Reference checkpoints carry a `module.` prefix (saved from DataParallel, utils2.py:85-102)."""
+    meta, _ = Hh.load("code2_h32_bidir")
+    model = Hh.code2_model(meta)
+    ckpt = {"epoch": 3, "model": {"module." + k: v for k, v in model.state_dict().items()}}
+    path = tmp_path / "ckpt.pt"
+    torch.save(ckpt, path)
+    fresh = Hh.code2_model({**meta, "w_seed": 1})
+    wrapped = torch.nn.DataParallel(fresh) if False else None  # DataParallel needs a GPU; strip the prefix instead
+    sd = {k[len("module."):]: v for k, v in torch.load(path)["model"].items()}
+    fresh.load_state_dict(sd, strict=True)
+    assert all(torch.equal(a, b) for a, b in zip(fresh.state_dict().values(), model.state_dict().values()))
+    assert wrapped is None
+
+
+def test_grad_mode_raises_instead_of_silently_detaching():
+    meta, arr = Hh.load("code2_h32_bidir")
+    model = Hh.code2_model(meta)
+    with pytest.raises(NotImplementedError):
+        model(Hh.code2_batch(arr))

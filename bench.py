@@ -59,10 +59,12 @@ def fresh_inputs(master, n):
     return out
 
 
-def cpu_baseline(model_cpu_sd, batch, L, S, passes):
+def cpu_baseline(model_cpu_sd, batch, L, S, passes, threads):
     """Oracle `faithful` mode = the reference's algorithm restated op for op, on this host's cores."""
     import copy
     from oracle import dagnn_oracle as O
+    if threads > 0:
+        torch.set_num_threads(threads)
     t0 = time.perf_counter()
     O.code2_forward(model_cpu_sd, copy.deepcopy(batch), num_layers=L, max_seq_len=S, mode="faithful")  # warm-up
     warm = time.perf_counter() - t0
@@ -92,6 +94,11 @@ def main():
     ap.add_argument("--vocab", type=int, default=5002)
     ap.add_argument("--cpu-passes", type=int, default=3, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--schedule", choices=["lockstep", "pergraph"], default=None,
+                    help="recurrence schedule (default: the library default, lock-step frontier launches)")
+    ap.add_argument("--cpu-threads", type=int, default=8,
+                    help="torch threads for the CPU baseline leg (8 = the thread count BASELINE.md was measured with; "
+                         "the op-by-op path is slower with every core of a big host)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,6 +118,8 @@ def main():
     from dagnn_amd.synth import code2_batch
 
     H, L, S, V, B = args.hidden, args.layers, 5, args.vocab, args.batch
+    if args.schedule:
+        os.environ["DAGNN_AMD_SCHEDULE"] = args.schedule
     model = build_model(H, L, V, S, device)
     batch_cpu = code2_batch(seed=rank, num_graphs=B)  # weak scaling: one B-graph batch per rank
     N, E = batch_cpu.x.shape[0], batch_cpu.edge_index.shape[1]
@@ -160,7 +169,10 @@ def main():
         D = 2
         if timer is not None:
             summ = timer.summary()
-            n_rec, ms_rec = summ.get("recurrence_layer", (0, 0.0))
+            lock = model.schedule == "lockstep"
+            n_rec, ms_rec = summ.get("frontier_run" if lock else "recurrence_layer", (0, 0.0))
+            launches_per_call = (T + L - 1) if lock else 1
+            calls_per_step = 1 if lock else L
             n_gemm, ms_gemm = summ.get("gemm_nt_bias", (0, 0.0))
             n_plan, ms_plan = summ.get("plan_build", (0, 0.0))
             # algorithmic work of ONE recurrence launch (one stacked layer, both directions), SURVEY.md §8(d):
@@ -168,25 +180,35 @@ def main():
             flops = D * (N * 6.0 * H * H + 2.0 * N * H + 2.0 * E * H + 15.0 * N * H)
             # compulsory HBM bytes: predecessor rows + own row write ((E+N)*4H), gi read (N*12H), CSR, scores
             byts = D * ((E + N) * 4.0 * H + N * 12.0 * H + 8.0 * E + 12.0 * N)
+            if lock:
+                # the lock-step launches cover all L stacked layers; layers > 0 also do the input-side GEMV
+                flops = flops * L + D * (L - 1) * N * 6.0 * H * H
+                byts = byts * L
+                # per LAUNCH (one batch-level topological layer, all cells)
+                flops, byts, ms_rec = flops / launches_per_call, byts / launches_per_call, ms_rec / launches_per_call
             if ms_rec > 0:
                 tf = flops / (ms_rec * 1e-3) / 1e12
                 result["roofline"] = {
-                    "kernel": "recurrence_kernel<KSL> (dagnn_recurrence_layer), one launch = one stacked GRU layer, "
-                              "both directions, all topological layers",
+                    "kernel": ("frontier_step_kernel (dagnn_frontier_run): one launch = one batch-level topological "
+                               "layer, all (direction, stacked layer) cells; %d launches per forward" %
+                               launches_per_call) if lock else
+                              ("recurrence_kernel<KSL> (dagnn_recurrence_layer): one launch = one stacked GRU layer, "
+                               "both directions, all topological layers"),
                     "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 5), "traffic": None,
-                    "launches_timed": n_rec, "avg_launch_ms": round(ms_rec, 4),
+                    "launches_timed": n_rec * launches_per_call, "avg_launch_ms": round(ms_rec, 6),
                     "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": byts,
                     "hbm_frac_of_8TBps": round(byts / (ms_rec * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-                    "us_per_dependent_step": round(ms_rec * 1e3 / max(T, 1), 3),
+                    "us_per_dependent_step": round(ms_rec * 1e3 if lock else ms_rec * 1e3 / max(T, 1), 3),
+                    "schedule": model.schedule,
                 }
                 result["kernels_ms_per_step"] = {
-                    "recurrence_layer": round(ms_rec * n_rec / args.steps, 4),
+                    "recurrence": round(ms_rec * launches_per_call * n_rec / args.steps, 4),
                     "gemm_nt_bias": round(ms_gemm * n_gemm / args.steps, 4),
                     "plan_build": round(ms_plan * n_plan / args.steps, 4)}
         if args.cpu_passes > 0:
             cpu_sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-            result["cpu_baseline"] = cpu_baseline(cpu_sd, batch_cpu, L, S, args.cpu_passes)
+            result["cpu_baseline"] = cpu_baseline(cpu_sd, batch_cpu, L, S, args.cpu_passes, args.cpu_threads)
         print(json.dumps(result))
     barrier()
     if world > 1:

@@ -25,6 +25,13 @@ def round_up4(n: int) -> int:
     return (n + 3) // 4 * 4
 
 
+def round_up(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+SCHEDULES = ("lockstep", "pergraph")
+
+
 class DerivedCache(object):
     """Caches tensors derived from parameters (packed / padded weights, folded edge gains) and
     rebuilds them when any source parameter changed (in-place updates bump `_version`)."""
@@ -63,11 +70,12 @@ def _pad_cols(w: torch.Tensor, cols: int) -> torch.Tensor:
 class CellParams(object):
     """Device-side, kernel-ready parameters of one (direction, stacked layer) cell."""
 
-    __slots__ = ("w_ih", "b_ih", "w_hh_t", "b_hh", "w_key", "edge_gain", "vid_bias")
+    __slots__ = ("w_ih", "b_ih", "w_hh_t", "b_hh", "w_key", "edge_gain", "vid_bias", "w_hh_pk", "w_ih_pk",
+                 "b_ih_dev", "Hp")
 
 
 def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: bool,
-                edge_w: Optional[torch.Tensor], vid_nodes: int) -> CellParams:
+                edge_w: Optional[torch.Tensor], vid_nodes: int, schedule: str = "pergraph") -> CellParams:
     """Fold / pack one cell's parameters for the kernels.
 
     attn_w is `attn_lin.weight` [1, dq + H (+ vid_nodes)]: the first dq entries multiply the query
@@ -75,15 +83,20 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
     variant the last `vid_nodes` the one-hot vertex id of the key (`dvae/dagnn.py:130-134`).
     `edge_w` is `edge_encoder.weight` [H, R]; its bias is constant inside a segment and cancels.
     """
-    Hp = round_up4(H)
+    lock = schedule == "lockstep"
+    Hp = round_up(H, 64) if lock else round_up4(H)
     c = CellParams()
+    c.Hp = Hp
     wi = _pad_gate_rows(w_ih.detach().float(), H, Hp)
     if in_is_hidden:
         wi = _pad_cols(wi, Hp)
     c.w_ih = wi
     c.b_ih = _pad_gate_rows(b_ih.detach().float(), H, Hp)
     whh = _pad_cols(_pad_gate_rows(w_hh.detach().float(), H, Hp), Hp)
-    c.w_hh_t = engine.pack_whh(whh)
+    c.w_hh_t = None if lock else engine.pack_whh(whh)
+    c.w_hh_pk = engine.pack_slices(whh, Hp) if lock else None
+    c.w_ih_pk = engine.pack_slices(wi, Hp) if (lock and in_is_hidden) else None
+    c.b_ih_dev = c.b_ih if (lock and in_is_hidden) else None
     c.b_hh = _pad_gate_rows(b_hh.detach().float(), H, Hp)
     key = attn_w.detach().float()[0, dq:dq + H]
     c.w_key = _pad_cols(key, Hp)
@@ -92,9 +105,32 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
     return c
 
 
+def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tuple[int, int], CellParams],
+                       dirs: Sequence[int], L: int, H: int, vid_nodes: int = 0) -> List[List[torch.Tensor]]:
+    """Lock-step schedule (default): one batched input GEMM for stacked layer 0 of every direction,
+    then T + L - 1 frontier launches covering all cells (csrc/frontier.hip)."""
+    Hp = cells[(dirs[0], 0)].Hp
+    N, dev = x.shape[0], x.device
+    gi0 = engine.gemm_nt_bias([x] * len(dirs), [cells[(d, 0)].w_ih for d in dirs], [cells[(d, 0)].b_ih for d in dirs])
+    gi = [None, None]
+    for q, d in enumerate(dirs):
+        gi[d] = gi0[q]
+    h = [[torch.empty(N, Hp, dtype=torch.float32, device=dev) if d in dirs else None for _ in range(L)]
+         for d in range(2)]
+    spart = [[torch.empty(N, Hp // 32, dtype=torch.float32, device=dev) if d in dirs else None for _ in range(L)]
+             for d in range(2)]
+    engine.frontier_run(plan, dirs, L, Hp, cells, gi, h, spart, vid_mod=vid_nodes)
+    if Hp != H:
+        return [[h[d][i][:, :H] if h[d][i] is not None else None for i in range(L)] for d in range(2)]
+    return h
+
+
 def run_stack(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tuple[int, int], CellParams],
-              dirs: Sequence[int], L: int, H: int, vid_nodes: int = 0) -> List[List[torch.Tensor]]:
+              dirs: Sequence[int], L: int, H: int, vid_nodes: int = 0,
+              schedule: str = "pergraph") -> List[List[torch.Tensor]]:
     """Hidden states h[d][i] ([N, H] each) of all stacked layers and directions."""
+    if schedule == "lockstep":
+        return run_stack_lockstep(plan, x, cells, dirs, L, H, vid_nodes)
     Hp = round_up4(H)
     N = x.shape[0]
     dev = x.device
@@ -123,6 +159,14 @@ def require_inference(module: torch.nn.Module) -> None:
         raise NotImplementedError(
             "the HIP recurrence has no backward pass yet: call the module under torch.no_grad() "
             "(as the reference's eval loop does, ogbg-code/main_pyg.py:103) or freeze its parameters")
+
+
+def default_schedule() -> str:
+    import os
+    s = os.environ.get("DAGNN_AMD_SCHEDULE", "lockstep")
+    if s not in SCHEDULES:
+        raise ValueError("DAGNN_AMD_SCHEDULE must be one of %s" % (SCHEDULES,))
+    return s
 
 
 def num_graphs_of(G) -> int:

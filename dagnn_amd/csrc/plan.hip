@@ -44,6 +44,7 @@ __global__ void plan_ptr_kernel(int32_t* plan, PlanLayout L, const int64_t* __re
         }
         plan[L.edge_ptr + i] = (int32_t)lo;
     }
+    if (i < N + 2) { plan[L.blptr[0] + i] = 0; plan[L.blptr[1] + i] = 0; }
     int bad = 0;
     if (i > 0 && i < N && batch[i] < batch[i - 1]) bad |= 4;
     if (i < N && (batch[i] < 0 || batch[i] >= B)) bad |= 4;
@@ -143,7 +144,10 @@ __global__ void __launch_bounds__(PB) plan_graph_kernel(int32_t* plan, PlanLayou
     __syncthreads();
     block_scan_inplace(ls, depth + 1, n0, lds);
     __syncthreads();
-    for (int i = tid; i < depth; i += PB) cur[i] = ls[i];
+    for (int i = tid; i < depth; i += PB) {
+        cur[i] = ls[i];
+        atomicAdd(&plan[L.blptr[d] + i + 1], ls[i + 1] - ls[i]);  // rows of batch-level layer i
+    }
     __syncthreads();
 
     // ---- stable placement of nodes: order[] sorted by (layer, node id)
@@ -208,6 +212,79 @@ __global__ void __launch_bounds__(1024) plan_items_kernel(int32_t* plan, PlanLay
     }
 }
 
+// Batch-level layers (the lock-step schedule): blptr[d][t] = first rowrec slot of layer t over the
+// whole batch; T_d is stored at blptr[d][N+1].  One workgroup per direction.
+__global__ void __launch_bounds__(1024) plan_blptr_kernel(int32_t* plan, PlanLayout L, int N, int B) {
+    __shared__ int32_t lds[1024 / 64 + 1];
+    __shared__ int32_t s_T;
+    const int d = blockIdx.x, tid = threadIdx.x;
+    int mx = 0;
+    for (int g = tid; g < B; g += 1024) mx = max(mx, plan[L.depth[d] + g]);
+    mx = wave_max_i(mx);
+    if (tid == 0) s_T = 0;
+    __syncthreads();
+    if ((tid & 63) == 0) atomicMax(&s_T, mx);
+    __syncthreads();
+    const int T = s_T;
+    int32_t* a = plan + L.blptr[d];
+    int carry = 0;
+    for (int c0 = 0; c0 <= T; c0 += 1024) {  // inclusive scan of a[0..T]
+        const int i = c0 + tid;
+        const int v = (i <= T) ? a[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if ((tid & 63) >= o) x += y; }
+        if ((tid & 63) == 63) lds[tid >> 6] = x;
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < (tid >> 6)) woff += lds[w]; tot += lds[w]; }
+        if (i <= T) a[i] = carry + woff + x;
+        carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) a[N + 1] = T;
+}
+
+// lbase[g][t] = blptr[t] + rows of layer t in graphs before g (deterministic slot assignment).
+__global__ void __launch_bounds__(256) plan_lbase_kernel(int32_t* plan, PlanLayout L, int N, int B) {
+    const int d = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int T = plan[L.blptr[d] + N + 1];
+    if (t >= T) return;
+    int acc = plan[L.blptr[d] + t];
+    const int32_t* __restrict__ node_ptr = plan + L.node_ptr;
+    const int32_t* __restrict__ depth = plan + L.depth[d];
+    const int32_t* __restrict__ ls = plan + L.lstart[d];
+    int32_t* lb = plan + L.lbase[d];
+    for (int g = 0; g < B; ++g) {
+        if (t < depth[g]) {
+            const int base = node_ptr[g] + g + t;
+            lb[base] = acc;
+            acc += ls[base + 1] - ls[base];
+        }
+    }
+}
+
+// rowrec[slot] = {node, edge begin, edge end, graph} for every node, slots ordered by batch-level layer.
+__global__ void __launch_bounds__(256) plan_rowrec_kernel(int32_t* plan, PlanLayout L, const int64_t* __restrict__ batch,
+                                                           const int64_t* __restrict__ layer_fwd,
+                                                           const int64_t* __restrict__ layer_bwd, int N) {
+    const int d = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;  // per-graph sorted position
+    if (p >= N) return;
+    const int v = plan[L.order[d] + p];
+    const int g = (int)batch[v];
+    const int n0 = plan[L.node_ptr + g];
+    const int n = plan[L.node_ptr + g + 1] - n0;
+    int t = (int)(d == 0 ? layer_fwd[v] : layer_bwd[v]);
+    t = min(max(t, 0), n - 1);
+    const int base = n0 + g + t;
+    const int slot = plan[L.lbase[d] + base] + (p - plan[L.lstart[d] + base]);
+    const int32_t* rp = plan + L.rowptr[d] + n0 + g + (p - n0);
+    int4 rec = make_int4(v, rp[0], rp[1], g);
+    *reinterpret_cast<int4*>(plan + L.rowrec[d] + 4 * (int64_t)slot) = rec;
+}
+
 }  // namespace
 
 extern "C" size_t dagnn_plan_bytes(int64_t N, int64_t E, int64_t B, int num_edge_feats) {
@@ -218,10 +295,10 @@ extern "C" size_t dagnn_plan_bytes(int64_t N, int64_t E, int64_t B, int num_edge
 extern "C" int dagnn_plan_layout(int64_t N, int64_t E, int64_t B, int R, int64_t* o) {
     if (!o) return DAGNN_EINVAL;
     PlanLayout L = dagnn_plan_layout_words(N, E, B, R);
-    int64_t w[16] = {L.node_ptr, L.edge_ptr, L.depth[0], L.depth[1], L.order[0], L.order[1], L.lstart[0],
+    int64_t w[20] = {L.node_ptr, L.edge_ptr, L.depth[0], L.depth[1], L.order[0], L.order[1], L.lstart[0],
                      L.lstart[1], L.rowptr[0], L.rowptr[1], L.col[0], L.col[1], L.eattr[0], L.eattr[1],
-                     L.items, L.total};
-    for (int i = 0; i < 16; ++i) o[i] = w[i] * 4;
+                     L.items, L.total, L.blptr[0], L.blptr[1], L.rowrec[0], L.rowrec[1]};
+    for (int i = 0; i < 20; ++i) o[i] = w[i] * 4;
     return DAGNN_OK;
 }
 
@@ -242,7 +319,7 @@ extern "C" int dagnn_plan_build(const dagnn_plan* pl, const int64_t* edge_index,
     if ((size_t)L.total * 4 > plan_bytes) return DAGNN_ENOSPC;
     hipStream_t stream = (hipStream_t)stream_;
     int32_t* p = (int32_t*)plan;
-    int64_t work = N > E ? N : E;
+    int64_t work = N + 2 > E ? N + 2 : E;
     if (work < B + 1) work = B + 1;
     hipLaunchKernelGGL(plan_ptr_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, p, L,
                        edge_index, batch, N, E, B, R, status);
@@ -253,6 +330,16 @@ extern "C" int dagnn_plan_build(const dagnn_plan* pl, const int64_t* edge_index,
         DAGNN_CHECK_LAUNCH();
         hipLaunchKernelGGL(plan_items_kernel, dim3(1), dim3(1024), 0, stream, p, L, (int)B);
         DAGNN_CHECK_LAUNCH();
+        hipLaunchKernelGGL(plan_blptr_kernel, dim3(2), dim3(1024), 0, stream, p, L, (int)N, (int)B);
+        DAGNN_CHECK_LAUNCH();
+        if (N > 0) {
+            hipLaunchKernelGGL(plan_lbase_kernel, dim3((unsigned)((N + 255) / 256), 2), dim3(256), 0, stream, p, L,
+                               (int)N, (int)B);
+            DAGNN_CHECK_LAUNCH();
+            hipLaunchKernelGGL(plan_rowrec_kernel, dim3((unsigned)((N + 255) / 256), 2), dim3(256), 0, stream, p, L,
+                               batch, layer_fwd, layer_bwd, (int)N);
+            DAGNN_CHECK_LAUNCH();
+        }
     }
     return DAGNN_OK;
 }

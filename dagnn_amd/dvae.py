@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import constants as K
 from . import engine
-from .core import DerivedCache, derive_cell, require_inference, run_stack
+from .core import DerivedCache, default_schedule, derive_cell, require_inference, run_stack
 from .data import GraphBatch
 from .model import _EdgeAttnParams
 
@@ -101,7 +101,8 @@ class _DvaeDagnn(_DvaeBase):
             self.cells_1 = self.grue_backward
         self.dropout = nn.Dropout(dropout)
         self.out_linear = nn.Linear(self.out_hidden_dim, out_dim) if num_layers > 1 else None
-        self._derived = DerivedCache()
+        self._derived = {}
+        self.schedule = default_schedule()  # 'lockstep' (frontier launches) or 'pergraph' (persistent workgroups)
 
     def _cells(self):
         srcs: List[torch.Tensor] = []
@@ -120,10 +121,10 @@ class _DvaeDagnn(_DvaeBase):
                     a = getattr(self, "node_aggr_%d" % d)[i]
                     dq = self.emb_dim if i == 0 else self.hidden_dim + extra
                     out[(d, i)] = derive_cell(c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh, a.attn_lin.weight,
-                                              self.hidden_dim, dq, i > 0, None, extra)
+                                              self.hidden_dim, dq, i > 0, None, extra, schedule=self.schedule)
             return out
 
-        return self._derived.get(srcs, make)
+        return self._derived.setdefault(self.schedule, DerivedCache()).get(srcs, make)
 
     def forward(self, G):
         """`dvae/dagnn.py:99-175` / `dvae/dagnn_bn.py:98-168` with `out_pool_all=False`."""
@@ -140,7 +141,8 @@ class _DvaeDagnn(_DvaeBase):
         B = N // nn_
         bl = G.bi_layer_index
         plan = engine.build_plan(G.edge_index, bl[0][0], bl[1][0], G.batch, B, None)
-        h = run_stack(plan, x, self._cells(), self.dirs, L, H, vid_nodes=nn_ if self._use_vids else 0)
+        h = run_stack(plan, x, self._cells(), self.dirs, L, H, vid_nodes=nn_ if self._use_vids else 0,
+                      schedule=self.schedule)
         nd = len(self.dirs)
         hcat = torch.empty(B, nd * L * H, dtype=torch.float32, device=x.device)
         for i in range(L):  # end vertex of every graph for d=0, start vertex for d=1

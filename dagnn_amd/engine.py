@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import DagnnHipError, GemmGroup, LayerArgs, Plan, check
+from ._lib import DagnnHipError, FrontierArgs, GemmGroup, LayerArgs, Plan, check
 
 
 class KernelTimer(object):
@@ -91,11 +91,27 @@ class PlanHandle(object):
         self.desc = Plan(self.ws.data_ptr(), nbytes, self.N, self.E, self.B, self.R)
 
     def layout(self) -> dict:
-        off = (C.c_int64 * 16)()
+        off = (C.c_int64 * 20)()
         check(_lib.load().dagnn_plan_layout(self.N, self.E, self.B, self.R, off), "dagnn_plan_layout")
         names = ["node_ptr", "edge_ptr", "depth0", "depth1", "order0", "order1", "lstart0", "lstart1", "rowptr0",
-                 "rowptr1", "col0", "col1", "eattr0", "eattr1", "items", "total"]
+                 "rowptr1", "col0", "col1", "eattr0", "eattr1", "items", "total", "blptr0", "blptr1", "rowrec0",
+                 "rowrec1"]
         return {k: int(v) // 4 for k, v in zip(names, off)}
+
+    def read_schedule(self):
+        """Batch-level layer offsets of both directions as host int32 arrays (ONE device->host read,
+        the counterpart of the reference's `.item()` at dagnn.py:137).  Returns [ptr_fwd, ptr_bwd],
+        ptr_d has T_d + 1 entries."""
+        if getattr(self, "_schedule", None) is None:
+            lay = self.layout()
+            a, b = lay["blptr0"], lay["blptr1"]
+            host = self.ws[a:b + self.N + 2].cpu().numpy()
+            out = []
+            for off in (0, b - a):
+                T = int(host[off + self.N + 1])
+                out.append(host[off:off + T + 1].copy())
+            self._schedule = out
+        return self._schedule
 
     def check_status(self) -> None:
         """Debug helper (synchronises): raises if the batch violated the layout contract."""
@@ -172,6 +188,43 @@ def pack_whh(w_hh: torch.Tensor) -> torch.Tensor:
     out = torch.empty(H, 3 * H, dtype=torch.float32, device=w_hh.device)
     check(_lib.load().dagnn_pack_whh(w_hh.data_ptr(), out.data_ptr(), H, _stream(w_hh)), "dagnn_pack_whh")
     return out
+
+
+def pack_slices(w: torch.Tensor, H: int) -> torch.Tensor:
+    """[3H, K] (torch layout) -> slice/lane order consumed by the lock-step kernel."""
+    w = _dev(w, "weight", torch.float32)
+    K = w.shape[1]
+    out = torch.empty(3 * H * K, dtype=torch.float32, device=w.device)
+    check(_lib.load().dagnn_pack_slices(w.data_ptr(), out.data_ptr(), H, K, _stream(w)), "dagnn_pack_slices")
+    return out
+
+
+def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0, h, spart,
+                 vid_mod: int = 0) -> None:
+    """Lock-step recurrence over all batch-level layers.  `cells[(d, i)]` are kernel-ready parameter
+    holders (core.FrontierCellParams); gi0[d] [N,3H]; h[d][i] [N,H] and spart[d][i] [N,H/32] outputs."""
+    sched = plan.read_schedule()
+    args = FrontierArgs()
+    mask = 0
+    for d in dirs:
+        mask |= 1 << d
+        for i in range(L):
+            c, fc = cells[(d, i)], args.cell[d][i]
+            fc.w_hh_pk, fc.w_ih_pk = c.w_hh_pk.data_ptr(), _ptr(c.w_ih_pk)
+            fc.b_hh, fc.b_ih, fc.w_key = c.b_hh.data_ptr(), _ptr(c.b_ih_dev), c.w_key.data_ptr()
+            fc.edge_gain = _ptr(c.edge_gain) if plan.R > 0 else None
+            fc.vid_bias = _ptr(c.vid_bias) if vid_mod > 0 else None
+            fc.gi0 = gi0[d].data_ptr() if i == 0 else None
+            fc.h_out, fc.score_parts = h[d][i].data_ptr(), spart[d][i].data_ptr()
+    args.num_stacked, args.dir_mask, args.H, args.ld_h, args.vid_mod = L, mask, H, H, int(vid_mod)
+    ptrs = (C.POINTER(C.c_int32) * 2)()
+    nl = (C.c_int32 * 2)()
+    for d in (0, 1):
+        ptrs[d] = sched[d].ctypes.data_as(C.POINTER(C.c_int32))
+        nl[d] = len(sched[d]) - 1
+    with _span("frontier_run", plan.ws):
+        check(_lib.load().dagnn_frontier_run(C.byref(plan.desc), C.byref(args), ptrs, nl, _stream(plan.ws)),
+              "dagnn_frontier_run")
 
 
 def recurrence_layer(plan: PlanHandle, dirs: Sequence[int], H: int, gi, w_hh_t, b_hh, w_key, edge_gain=None,

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import constants as K
 from . import engine
-from .core import DerivedCache, derive_cell, num_graphs_of, require_inference, run_stack
+from .core import DerivedCache, default_schedule, derive_cell, num_graphs_of, require_inference, run_stack
 
 
 class ASTNodeEncoder(nn.Module):
@@ -187,7 +187,8 @@ class DAGNN(nn.Module):
                 for _ in range(max_seq_len):
                     self.graph_pred_linear_list.append(nn.Linear(self.out_hidden_dim, self.num_vocab))
 
-        self._derived = DerivedCache()
+        self._derived = {}
+        self.schedule = default_schedule()  # 'lockstep' (frontier launches) or 'pergraph' (persistent workgroups)
 
     # ------------------------------------------------------------------------------ helpers
     def _hip_supported(self) -> bool:
@@ -211,10 +212,11 @@ class DAGNN(nn.Module):
                     a = getattr(self, "node_aggr_%d" % d)[i]
                     dq = self.emb_dim if i == 0 else self.hidden_dim
                     out[(d, i)] = derive_cell(c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh, a.attn_lin.weight,
-                                              self.hidden_dim, dq, i > 0, a.edge_encoder.weight if a.wea else None, 0)
+                                              self.hidden_dim, dq, i > 0, a.edge_encoder.weight if a.wea else None, 0,
+                                              schedule=self.schedule)
             return out
 
-        return self._derived.get(srcs, make)
+        return self._derived.setdefault(self.schedule, DerivedCache()).get(srcs, make)
 
     def _pool(self, h, batch, B):
         """`global_{max,mean,add}_pool` / P_ATTN read-outs on torch (variants outside BASELINE)."""
@@ -251,7 +253,7 @@ class DAGNN(nn.Module):
         has_edge_enc = getattr(self.node_aggr_0[0], "wea", False)
         plan = engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B,
                                  G.edge_attr if has_edge_enc else None)
-        h = run_stack(plan, x, self._cells(), dirs, L, H)
+        h = run_stack(plan, x, self._cells(), dirs, L, H, schedule=self.schedule)
         G.h = [[h[d][i] for i in range(L)] for d in dirs]  # side effect 4 (dagnn.py:141-142,182)
 
         if self.bidirectional and not self.output_all:

@@ -147,6 +147,46 @@ int dagnn_recurrence_layer(const dagnn_plan* plan /* host */, const dagnn_layer_
                            int H, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Lock-step schedule of the same recurrence (the default path): one launch per batch-level
+ * topological layer covering every (direction, stacked layer) cell; stacked layer i runs one
+ * launch behind layer i-1, so the whole loop nest of dagnn.py:144-182 becomes T + L - 1 dependent
+ * launches.  Each workgroup owns a 32-unit slice of one cell's GRU weights for a block of <= 8
+ * frontier rows (see dagnn_amd/csrc/frontier.hip).  Requires H % 64 == 0 (the host pads).
+ *
+ * Weights are consumed in slice/lane order: pack W [3H, K] (torch layout) with dagnn_pack_slices
+ * (K = H for weight_hh, and for weight_ih of stacked layers > 0).
+ * ---------------------------------------------------------------------------------------- */
+int dagnn_pack_slices(const float* w /* [3H,K] */, float* out /* 3H*K floats */, int H, int K, void* stream);
+
+typedef struct dagnn_frontier_cell {
+    const float* w_hh_pk;   /* packed weight_hh */
+    const float* w_ih_pk;   /* packed weight_ih (stacked layers > 0), else NULL */
+    const float* b_hh;      /* [3H] */
+    const float* b_ih;      /* [3H] (stacked layers > 0; layer 0 has it folded into gi0) */
+    const float* w_key;     /* [H] key half of attn_lin.weight */
+    const float* edge_gain; /* [num_edge_feats] or NULL */
+    const float* vid_bias;  /* [vid_mod] or NULL */
+    const float* gi0;       /* [N,3H] W_ih x + b_ih (stacked layer 0 only), from dagnn_gemm_nt_bias */
+    float* h_out;           /* [N,ld_h] hidden states of this cell (every row written exactly once) */
+    float* score_parts;     /* [N,H/32] scratch: per-slice partial attention scores of h_out */
+} dagnn_frontier_cell;
+
+#define DAGNN_MAX_STACKED 8
+typedef struct dagnn_frontier_args {
+    dagnn_frontier_cell cell[DAGNN_MAX_DIRS][DAGNN_MAX_STACKED];
+    int num_stacked; /* L */
+    int dir_mask;
+    int H, ld_h, vid_mod;
+} dagnn_frontier_args;
+
+/* layer_ptr[d] (HOST, num_layers[d] + 1 int32): row offsets of the batch-level layers of direction
+ * d, i.e. the first num_layers[d]+1 words of the plan's blptr_d array read back by the caller
+ * (the one device->host read of the forward pass; the reference reads T back at dagnn.py:137). */
+int dagnn_frontier_run(const dagnn_plan* plan /* host */, const dagnn_frontier_args* args /* host */,
+                       const int32_t* const* layer_ptr /* host */, const int32_t* num_layers /* host [2] */,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Read-out over output nodes (dagnn.py:119-126,184-193 with out_pool='max', out_pool_all=0):
  *   out[g, col_off[d] + j] = max over { v in graph g : layer_{1-d}(v) == 0 } of h[d][v, j]
  * d = 0 pools the sinks, d = 1 the sources.  h[d] is [N,ld_h]; `width` columns are pooled
@@ -160,10 +200,12 @@ int dagnn_readout_max(const dagnn_plan* plan /* host */, const float* h, int ld_
 int dagnn_gather_rows(const float* h, int ld_h, int width, int64_t num_graphs, int stride, int node_off,
                       float* out, int ld_out, int col_off, void* stream);
 
-/* Introspection used by tests: copies plan arrays' offsets (in bytes from `plan`) into a host
- * array: [node_ptr, edge_ptr, depth0, depth1, order0, order1, lstart0, lstart1, rowptr0,
- * rowptr1, col0, col1, eattr0, eattr1, items, total]. */
-int dagnn_plan_layout(int64_t N, int64_t E, int64_t B, int num_edge_feats, int64_t* offsets16 /* host */);
+/* Introspection (tests, and the host-side read-back of the lock-step schedule): byte offsets of the
+ * plan's arrays from `plan->data`, into a host array of 20 entries: [node_ptr, edge_ptr, depth0,
+ * depth1, order0, order1, lstart0, lstart1, rowptr0, rowptr1, col0, col1, eattr0, eattr1, items,
+ * total, blptr0, blptr1, rowrec0, rowrec1].  blptr_d holds N+2 int32: the offsets of the
+ * batch-level topological layers of direction d (entries 0..T_d) and T_d itself at index N+1. */
+int dagnn_plan_layout(int64_t N, int64_t E, int64_t B, int num_edge_feats, int64_t* offsets20 /* host */);
 
 #ifdef __cplusplus
 }

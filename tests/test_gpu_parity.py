@@ -17,6 +17,14 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4  # BASELINE.json north_star: "within 1e-4 fp32"
 
 
+@pytest.fixture(params=["lockstep", "pergraph"])
+def schedule(request, monkeypatch):
+    """Both HIP schedules of the recurrence: lock-step frontier launches (default) and persistent
+    per-(graph, direction) workgroups."""
+    monkeypatch.setenv("DAGNN_AMD_SCHEDULE", request.param)
+    return request.param
+
+
 # ----------------------------------------------------------------------------- unit: kernels
 def _plan_arrays(plan):
     ws = plan.ws.cpu().numpy()
@@ -61,8 +69,21 @@ def test_plan_matches_oracle_csr(device, seed, B, mean_n):
                 seg = slice(rp[p - n0], rp[p - n0 + 1])
                 assert np.array_equal(col[seg], other[e_ids])
                 assert np.array_equal(eattr[seg], b.edge_attr.numpy()[e_ids])
-        if B <= 17:
-            continue
+        # batch-level (lock-step) schedule: slots ordered by layer, every node exactly once
+        T = int(layer.max()) + 1
+        bl = ws[lay["blptr%d" % d]:lay["blptr%d" % d] + N + 2]
+        assert bl[N + 1] == T and bl[0] == 0 and bl[T] == N
+        rec = ws[lay["rowrec%d" % d]:lay["rowrec%d" % d] + 4 * N].reshape(N, 4)
+        assert sorted(rec[:, 0].tolist()) == list(range(N))
+        for t in range(T):
+            nodes = rec[bl[t]:bl[t + 1], 0]
+            assert np.array_equal(np.sort(nodes), np.flatnonzero(layer == t))
+        pos = np.empty(N, dtype=np.int64)
+        pos[order] = np.arange(N)
+        gid = b.batch.numpy()
+        rp_flat = lambda v: ws[lay["rowptr%d" % d] + pos[v] + gid[v]: lay["rowptr%d" % d] + pos[v] + gid[v] + 2]  # noqa
+        for v, eb, ee, g in rec[:: max(1, N // 200)]:
+            assert g == gid[v] and [eb, ee] == rp_flat(v).tolist()
     items = ws[lay["items"]:lay["items"] + 2 * B]
     dep = [ws[lay["depth%d" % (i & 1)] + (i >> 1)] for i in items]
     assert sorted(items.tolist()) == list(range(2 * B)) and dep == sorted(dep, reverse=True)
@@ -124,7 +145,7 @@ def test_cpu_tensors_fail_loudly():
 
 # ----------------------------------------------------------------------------- golden fixtures
 @pytest.mark.parametrize("name", Hh.CODE2)
-def test_code2_forward_matches_reference_golden(device, name):
+def test_code2_forward_matches_reference_golden(device, name, schedule):
     meta, arr = Hh.load(name)
     model = Hh.code2_model(meta).to(device)
     G = Hh.code2_batch(arr, device)
@@ -149,7 +170,7 @@ def test_code2_forward_matches_reference_golden(device, name):
 
 
 @pytest.mark.parametrize("name", Hh.DVAE)
-def test_dvae_encode_matches_reference_golden(device, name):
+def test_dvae_encode_matches_reference_golden(device, name, schedule):
     meta, arr = Hh.load(name)
     model, nn_ = Hh.dvae_model(meta)
     model = model.to(device)
@@ -180,7 +201,7 @@ def _headline_model(H=256, L=2, V=64, seed=0):
     return m
 
 
-def test_headline_batch_matches_oracle(device):
+def test_headline_batch_matches_oracle(device, schedule):
     """cfg 2 at full size (seed-0 batch: B=128, N=16 561, E=25 377, T=374; h=256, L=2, bidir)."""
     model = _headline_model()
     b = synth.code2_batch(0, 128)
@@ -193,7 +214,7 @@ def test_headline_batch_matches_oracle(device):
     assert max(Hh.maxdiff(o, r) for o, r in zip(out, ref)) < TOL
 
 
-def test_headline_properties(device):
+def test_headline_properties(device, schedule):
     """Size-independent properties at BASELINE size: run-to-run bitwise determinism, graph
     independence (any sharding of the batch gives the same rows), graph-order equivariance."""
     model = _headline_model().to(device)
@@ -217,7 +238,7 @@ def test_headline_properties(device):
     assert torch.equal(out_r.flip(1), out_a)
 
 
-def test_wide_deep_config_matches_oracle(device):
+def test_wide_deep_config_matches_oracle(device, schedule):
     """cfg 5 shape (h=512, L=5, bidir) on a 24-graph batch."""
     model = _headline_model(H=512, L=5, V=32, seed=5)
     b = synth.code2_batch(21, 24)
@@ -229,7 +250,7 @@ def test_wide_deep_config_matches_oracle(device):
     assert max(Hh.maxdiff(o, r) for o, r in zip(out, ref)) < TOL
 
 
-def test_edge_cases(device):
+def test_edge_cases(device, schedule):
     """Single-node graphs, a chain, a star with a 200-way fan-in, and a graph with no edges."""
     from dagnn_amd import GraphData
     from dagnn_amd.dag_utils import add_order_info_01
@@ -256,7 +277,7 @@ def test_edge_cases(device):
     assert max(Hh.maxdiff(o, r) for o, r in zip(out, ref)) < TOL
 
 
-def test_out_wx_and_other_pools(device):
+def test_out_wx_and_other_pools(device, schedule):
     from dagnn_amd import DAGNN, ASTNodeEncoder
     b = synth.code2_batch(31, 9, 30)
     for kw in (dict(out_wx=True, out_pool="max"), dict(out_wx=False, out_pool="mean"),

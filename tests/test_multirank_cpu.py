@@ -1,0 +1,64 @@
+"""world_size-2 `gloo` test of the N>1 path on CPU.
+
+Graph-parallel sharding needs no data-path collective (graphs are independent); the only
+exchanges are the optional gather of per-shard outputs to one rank (what DataParallel.gather does,
+ogbg-code/tg/data_parallel.py:62) and the max-over-ranks timing reduction of bench.py."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dagnn_amd import collate_sharded, synth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _graph_row(g):
+    return [float(g.num_nodes), float(g.edge_index.shape[1])]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        graphs = synth.code2_graphs(7, 24, 30)   # every rank sees the same loader batch ...
+        shards = collate_sharded(graphs, world)  # ... and takes its contiguous, node-balanced shard
+        first = sum(s.num_graphs for s in shards[:rank])
+        mine = shards[rank]
+        # stand-in for the per-shard forward: one output row per graph, a pure function of that graph
+        rows = torch.tensor([_graph_row(g) for g in graphs[first:first + mine.num_graphs]])
+        sizes = [torch.zeros(1, dtype=torch.long) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([rows.shape[0]]))
+        sizes = [int(s) for s in sizes]
+        m = max(sizes)
+        pad = torch.zeros(m, 2)
+        pad[:rows.shape[0]] = rows
+        bufs = [torch.zeros(m, 2) for _ in range(world)]
+        dist.all_gather(bufs, pad)               # ragged shards travel through padded buffers
+        full = torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
+        assert torch.equal(full, torch.tensor([_graph_row(g) for g in graphs]))  # == single-device order
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # bench.py's timing reduction
+        assert float(t) == float(world)
+        dist.barrier()
+        out[rank] = sum(sizes)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_sharding_and_gather_gloo():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: 24, 1: 24}

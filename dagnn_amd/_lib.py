@@ -42,14 +42,14 @@ MAX_STACKED = 8
 
 
 class FrontierCell(C.Structure):
-    _fields_ = [("w_hh_pk", C.c_void_p), ("w_ih_pk", C.c_void_p), ("b_hh", C.c_void_p), ("b_ih", C.c_void_p),
-                ("w_key", C.c_void_p), ("edge_gain", C.c_void_p), ("vid_bias", C.c_void_p), ("gi0", C.c_void_p),
-                ("h_out", C.c_void_p), ("score_parts", C.c_void_p)]
+    _fields_ = [("w_hh_pk16", C.c_void_p), ("w_hh_pk32", C.c_void_p), ("w_ih_pk16", C.c_void_p),
+                ("w_ih_pk32", C.c_void_p), ("b_hh", C.c_void_p), ("b_ih", C.c_void_p), ("w_key", C.c_void_p),
+                ("edge_gain", C.c_void_p), ("vid_bias", C.c_void_p), ("gi0", C.c_void_p), ("h_out", C.c_void_p)]
 
 
 class FrontierArgs(C.Structure):
     _fields_ = [("cell", (FrontierCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
-                ("H", C.c_int), ("ld_h", C.c_int), ("vid_mod", C.c_int)]
+                ("H", C.c_int), ("ld_h", C.c_int), ("vid_mod", C.c_int), ("debug_timing", C.c_void_p)]
 
 
 # every symbol include/dagnn_hip.h declares: (restype, argtypes)
@@ -65,7 +65,7 @@ SYMBOLS = {
                                      C.c_int, C.c_void_p]),
     "dagnn_pack_whh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_recurrence_layer": (C.c_int, [C.POINTER(Plan), C.POINTER(LayerArgs), C.c_int, C.c_int, C.c_void_p]),
-    "dagnn_pack_slices": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dagnn_pack_slices": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dagnn_frontier_run": (C.c_int, [C.POINTER(Plan), C.POINTER(FrontierArgs), C.POINTER(C.POINTER(C.c_int32)),
                                      C.POINTER(C.c_int32), C.c_void_p]),
     "dagnn_readout_max": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,

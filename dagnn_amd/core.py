@@ -94,8 +94,8 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
     c.b_ih = _pad_gate_rows(b_ih.detach().float(), H, Hp)
     whh = _pad_cols(_pad_gate_rows(w_hh.detach().float(), H, Hp), Hp)
     c.w_hh_t = None if lock else engine.pack_whh(whh)
-    c.w_hh_pk = engine.pack_slices(whh, Hp) if lock else None
-    c.w_ih_pk = engine.pack_slices(wi, Hp) if (lock and in_is_hidden) else None
+    c.w_hh_pk = {js: engine.pack_slices(whh, Hp, js) for js in (16, 32)} if lock else None
+    c.w_ih_pk = {js: engine.pack_slices(wi, Hp, js) for js in (16, 32)} if (lock and in_is_hidden) else None
     c.b_ih_dev = c.b_ih if (lock and in_is_hidden) else None
     c.b_hh = _pad_gate_rows(b_hh.detach().float(), H, Hp)
     key = attn_w.detach().float()[0, dq:dq + H]
@@ -115,14 +115,11 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
     gi = [None, None]
     for q, d in enumerate(dirs):
         gi[d] = gi0[q]
-    h = [[torch.empty(N, Hp, dtype=torch.float32, device=dev) if d in dirs else None for _ in range(L)]
+    ld = engine.frontier_ld(Hp)  # state rows carry their H/16 partial attention scores behind the states
+    h = [[torch.empty(N, ld, dtype=torch.float32, device=dev) if d in dirs else None for _ in range(L)]
          for d in range(2)]
-    spart = [[torch.empty(N, Hp // 32, dtype=torch.float32, device=dev) if d in dirs else None for _ in range(L)]
-             for d in range(2)]
-    engine.frontier_run(plan, dirs, L, Hp, cells, gi, h, spart, vid_mod=vid_nodes)
-    if Hp != H:
-        return [[h[d][i][:, :H] if h[d][i] is not None else None for i in range(L)] for d in range(2)]
-    return h
+    engine.frontier_run(plan, dirs, L, Hp, cells, gi, h, vid_mod=vid_nodes)
+    return [[h[d][i][:, :H] if h[d][i] is not None else None for i in range(L)] for d in range(2)]
 
 
 def run_stack(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tuple[int, int], CellParams],

@@ -10,22 +10,24 @@
 // launches - and h[d][i-1] of the same node, finished in launch s-1).  T + L - 1 dependent
 // launches replace D*L*T dependent micro-steps.
 //
-// gfx950 design.  The dependent chain is what bounds this path (a launch boundary costs ~1.5 us,
-// an HBM/L2 round trip ~0.4-0.9 us), so each launch keeps its own chain to three dependent loads:
-//   rowrec[slot] -> {col, edge feats, score parts} -> predecessor rows.
-// The GRU weights never sit on that chain: a workgroup owns a SLICE of 32 hidden units
-// (3 gates x 32 = 96 weight columns, K = H rows) of one cell for a block of <= 8 frontier rows,
-// and issues the loads of its whole slice - pre-packed in exactly the order its lanes consume it,
-// so every load instruction is one contiguous 1 KiB - BEFORE it starts the aggregate; they land in
-// registers while the chain is in flight.  H/32 slice-workgroups share a row block: the weight
-// matrix is read once per row block by the whole GPU instead of once per graph-step by one CU
-// (the per-graph persistent kernel in recurrence.hip streams 786 KB per step from L2, 6 us).
-//   A  one wave per row: segment softmax over in-edges (score = sum of the H/32 per-slice partial
-//      dots the producers stored, + edge-feature gain), alpha-weighted float4 gather of the
-//      predecessors' rows -> LDS; for stacked layers > 0 also the node's own lower-layer row;
-//   B  6 waves x (16 K-lanes x 4 column groups): fp32 FMA GEMV on the slice for hidden- and
-//      input-side, K reduced by xor-shuffles;
-//   C  256 threads = 8 rows x 32 units: gates, h' store (128 B per row), score partial store.
+// gfx950 design.  This path is bound by its dependent chain (T = 374 layers deep at a median
+// frontier of 4-7 nodes), so every launch is built to be SHORT:
+//  * its own chain is two memory round trips: 64-byte row record (scalar load; node id, edge
+//    range and the first four predecessors + their edge features inline) -> predecessor rows.
+//    The per-slice partial attention scores travel in 16 trailing floats of each state row, so
+//    the same round trip brings them;
+//  * the GRU weights never sit on that chain: a workgroup owns a slice of JS hidden units
+//    (3 gates x JS weight columns, K = H) of one cell for a block of <= RB frontier rows, and
+//    issues the loads of its whole slice - pre-packed in exactly the order its lanes consume it,
+//    every load instruction one contiguous 1 KiB - before it starts the aggregate.  A CU moves
+//    64 B/clk, so a slice is sized by what one CU can pull in ~1 us: thin launches use JS=16
+//    slices spread over more CUs, fat ones JS=32;
+//  * K is split over the 16 lanes of a DPP row, so the K reduction is 4 v_add_dpp per value
+//    instead of LDS-crossbar shuffles.
+//   A  one wave per row: softmax over the in-edges, alpha-weighted float4 gather -> LDS; for
+//      stacked layers > 0 also the node's own lower-layer row;
+//   B  fp32 FMA GEMV on the slice, hidden- and input-side, RB rows register-blocked;
+//   C  RB x JS threads: gates, h' store, partial score store.
 // fp32 VALU FMA: at <= 8 rows per weight pass the fp32 MFMA has the same per-row rate.
 #include "common.h"
 
@@ -33,10 +35,9 @@
 
 namespace {
 
-constexpr int FT = 384;   // threads per workgroup (6 waves)
-constexpr int JS = 32;    // hidden units per slice
-constexpr int RB = 8;     // frontier rows per block
-constexpr int KCH = 16;   // k values per lane per register chunk (K chunk of 256)
+constexpr int FT = 384;     // threads per workgroup (6 waves)
+constexpr int KCH = 16;     // k values per lane per register chunk
+constexpr int PU = 16;      // hidden units per stored score part
 
 struct Cell {
     const float4* whh;   // packed hidden-side slices
@@ -48,8 +49,7 @@ struct Cell {
     const float* vid;    // [vid_mod] or null
     const float* gi0;    // [N,3H] precomputed input side (stacked layer 0) or null
     const float* h_in;   // [N,ld_h] lower stacked layer (with wih) or null
-    float* h_out;        // [N,ld_h]
-    float* spart;        // [N,NS] per-slice score partials of h_out
+    float* h_out;        // [N,ld_h]: H state floats + H/16 partial scores per row
     int dir;             // direction (selects the plan arrays)
     int row_base;        // first rowrec slot of the layer processed in this launch
     int row_end;         // one past the last
@@ -59,149 +59,184 @@ struct Cell {
 struct StepArgs {
     Cell cell[DAGNN_MAX_CELLS];
     int blk_start[DAGNN_MAX_CELLS + 1];  // row-block prefix sums over the active cells
-    int ncell, H, ld_h, NS, R, vid_mod;
+    int ncell, H, ld_h, R, vid_mod, step;
+    unsigned long long* dbg;  // optional [steps][8] wall_clock64 stamps of workgroup 0
 };
 
-// LDS index of element k of an 8-row operand: one float of pad per K-lane segment so the 16
-// segments a wave reads concurrently start on different banks.
+// LDS index of element k of an operand row: 4 floats of pad per K-lane segment so the 16
+// segments a DPP row reads concurrently (ds_read_b128) fall on disjoint banks.
 __device__ __forceinline__ int apad(int k, int kpt) { return k + 4 * (k / kpt); }
 
-// One wave: aggregate the predecessors of one frontier row into a_row (LDS, padded layout).
+__device__ __forceinline__ float dpp_row_sum16(float v) {
+    // inclusive scan over the 16 lanes of a DPP row (row_shr 1,2,4,8; out-of-row lanes read 0):
+    // lane 15 of every row ends with the row total, always in the same order -> deterministic
+#define DAGNN_DPP_ADD(ctrl) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+    DAGNN_DPP_ADD(0x111); DAGNN_DPP_ADD(0x112); DAGNN_DPP_ADD(0x114); DAGNN_DPP_ADD(0x118);
+#undef DAGNN_DPP_ADD
+    return v;
+}
+
+__device__ __forceinline__ void fma4(float4& acc, float al, const float4& v) {
+    acc.x = fmaf(al, v.x, acc.x); acc.y = fmaf(al, v.y, acc.y); acc.z = fmaf(al, v.z, acc.z); acc.w = fmaf(al, v.w, acc.w);
+}
+
+// sum of the H/16 partial scores stored behind a state row, in index order (deterministic).
+__device__ __forceinline__ float score_of(const float* __restrict__ hrow_tail, int nparts) {
+    float s = 0.f;
+    for (int q = 0; q < nparts; q += 4) {
+        const float4 p = *reinterpret_cast<const float4*>(hrow_tail + q);
+        s += p.x; if (q + 1 < nparts) s += p.y; if (q + 2 < nparts) s += p.z; if (q + 3 < nparts) s += p.w;
+    }
+    return s;
+}
+
+// One wave: a_row[:] = sum_e alpha_e * h[pred_e, :] with alpha = softmax_e(score[pred_e] + gain . feat_e)
+// (PyG: exp(x - max) / (sum + 1e-16)).  rec1 = first four predecessors, rec2/rec3 = their edge features.
 __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restrict__ col,
-                                          const float* __restrict__ eattr, int eb, int ee, int H, int ld_h, int NS,
-                                          int R, int vid_mod, int kpt, float* a_row, int lane) {
+                                          const float* __restrict__ eattr, int eb, int ee, int4 rec1, int4 rec2,
+                                          int4 rec3, int H, int ld_h, int R, int vid_mod, int kpt, float* a_row,
+                                          int lane) {
     const int H4 = H >> 2;
+    const int nparts = H / PU;
     const float* hsrc = C.h_out;  // predecessors' states of THIS stacked layer (earlier launches)
     const int deg = ee - eb;
-    if (deg == 1) {  // softmax over one edge: alpha = exp(0) / (exp(0) + 1e-16) == 1.0f exactly
-        const float4* hr = reinterpret_cast<const float4*>(hsrc + (int64_t)col[eb] * ld_h);
-        for (int c = lane; c < H4; c += 64) *reinterpret_cast<float4*>(a_row + apad(4 * c, kpt)) = hr[c];
+    if (deg <= 4 && R <= 2) {
+        // ---- inline path: predecessor ids and edge features came with the row record
+        const int pj[4] = {rec1.x, rec1.y, rec1.z, rec1.w};
+        const float f0[4] = {__int_as_float(rec2.x), __int_as_float(rec2.z), __int_as_float(rec3.x), __int_as_float(rec3.z)};
+        const float f1[4] = {__int_as_float(rec2.y), __int_as_float(rec2.w), __int_as_float(rec3.y), __int_as_float(rec3.w)};
+        float al[4] = {1.f, 0.f, 0.f, 0.f};
+        if (deg > 1) {
+            float lg[4], mx = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lg[e] = -INFINITY;
+                if (e < deg) {
+                    float s = score_of(hsrc + (int64_t)pj[e] * ld_h + H, nparts);
+                    if (C.vid) s += C.vid[pj[e] % vid_mod];
+                    if (R >= 1) s = fmaf(C.gain[0], f0[e], s);
+                    if (R >= 2) s = fmaf(C.gain[1], f1[e], s);
+                    lg[e] = s;
+                    mx = fmaxf(mx, s);
+                }
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { al[e] = e < deg ? expf(lg[e] - mx) : 0.f; sum += al[e]; }
+            const float denom = sum + 1e-16f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) al[e] = al[e] / denom;
+        }
+        for (int c = lane; c < H4; c += 64) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < deg) fma4(acc, al[e], reinterpret_cast<const float4*>(hsrc + (int64_t)pj[e] * ld_h)[c]);
+            *reinterpret_cast<float4*>(a_row + apad(4 * c, kpt)) = acc;
+        }
         return;
     }
+    // ---- general path (fan-in > 4): lanes own edges, three passes over the edge list
     auto logit = [&](int e, int cj) {
-        const float* sp = C.spart + (int64_t)cj * NS;
-        float s = 0.f;
-        for (int q = 0; q < NS; ++q) s += sp[q];  // fixed order: deterministic
+        float s = score_of(hsrc + (int64_t)cj * ld_h + H, nparts);
         if (C.vid) s += C.vid[cj % vid_mod];
         for (int r = 0; r < R; ++r) s = fmaf(C.gain[r], eattr[(int64_t)e * R + r], s);
         return s;
     };
-    float mx = -INFINITY, sum = 0.f, my_lg = 0.f;
-    int my_col = 0;
-    if (deg <= 64) {
-        if (lane < deg) { my_col = col[eb + lane]; my_lg = logit(eb + lane, my_col); mx = my_lg; }
-        mx = wave_max(mx);
-        const float ex = lane < deg ? expf(my_lg - mx) : 0.f;
-        sum = wave_sum(ex);
-        const float denom = sum + 1e-16f;
-        const float my_alpha = ex / denom;
-        for (int c0 = 0; c0 < H4; c0 += 128) {
-            float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-            const int ca = c0 + lane, cb = c0 + 64 + lane;
-            for (int i = 0; i < deg; ++i) {
-                const float al = __shfl(my_alpha, i, 64);
-                const int cj = __shfl(my_col, i, 64);
-                const float4* hr = reinterpret_cast<const float4*>(hsrc + (int64_t)cj * ld_h);
-                if (ca < H4) { const float4 v = hr[ca]; acc0.x = fmaf(al, v.x, acc0.x); acc0.y = fmaf(al, v.y, acc0.y);
-                               acc0.z = fmaf(al, v.z, acc0.z); acc0.w = fmaf(al, v.w, acc0.w); }
-                if (cb < H4) { const float4 v = hr[cb]; acc1.x = fmaf(al, v.x, acc1.x); acc1.y = fmaf(al, v.y, acc1.y);
-                               acc1.z = fmaf(al, v.z, acc1.z); acc1.w = fmaf(al, v.w, acc1.w); }
-            }
-            if (ca < H4) *reinterpret_cast<float4*>(a_row + apad(4 * ca, kpt)) = acc0;
-            if (cb < H4) *reinterpret_cast<float4*>(a_row + apad(4 * cb, kpt)) = acc1;
-        }
-        return;
-    }
-    // heavy rows (fan-in > 64): three passes over the edge list
+    float mx = -INFINITY, sum = 0.f;
     for (int e = eb + lane; e < ee; e += 64) mx = fmaxf(mx, logit(e, col[e]));
     mx = wave_max(mx);
     for (int e = eb + lane; e < ee; e += 64) sum += expf(logit(e, col[e]) - mx);
     sum = wave_sum(sum);
     const float denom = sum + 1e-16f;
-    for (int c0 = 0; c0 < H4; c0 += 128) {
-        float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-        const int ca = c0 + lane, cb = c0 + 64 + lane;
+    for (int c0 = 0; c0 < H4; c0 += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = c0 + lane;
         for (int base = eb; base < ee; base += 64) {
             const int e = base + lane;
             float my_alpha = 0.f;
+            int my_col = 0;
             if (e < ee) { my_col = col[e]; my_alpha = expf(logit(e, my_col) - mx) / denom; }
             const int cnt = min(64, ee - base);
-            for (int i = 0; i < cnt; ++i) {
-                const float al = __shfl(my_alpha, i, 64);
+            int i = 0;
+            for (; i + 4 <= cnt; i += 4) {  // four row loads in flight per lane
+                float4 v[4]; float a4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a4[u] = __shfl(my_alpha, i + u, 64);
+                    const int cj = __shfl(my_col, i + u, 64);
+                    v[u] = c < H4 ? reinterpret_cast<const float4*>(hsrc + (int64_t)cj * ld_h)[c] : make_float4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) fma4(acc, a4[u], v[u]);
+            }
+            for (; i < cnt; ++i) {
+                const float a1 = __shfl(my_alpha, i, 64);
                 const int cj = __shfl(my_col, i, 64);
-                const float4* hr = reinterpret_cast<const float4*>(hsrc + (int64_t)cj * ld_h);
-                if (ca < H4) { const float4 v = hr[ca]; acc0.x = fmaf(al, v.x, acc0.x); acc0.y = fmaf(al, v.y, acc0.y);
-                               acc0.z = fmaf(al, v.z, acc0.z); acc0.w = fmaf(al, v.w, acc0.w); }
-                if (cb < H4) { const float4 v = hr[cb]; acc1.x = fmaf(al, v.x, acc1.x); acc1.y = fmaf(al, v.y, acc1.y);
-                               acc1.z = fmaf(al, v.z, acc1.z); acc1.w = fmaf(al, v.w, acc1.w); }
+                if (c < H4) fma4(acc, a1, reinterpret_cast<const float4*>(hsrc + (int64_t)cj * ld_h)[c]);
             }
         }
-        if (ca < H4) *reinterpret_cast<float4*>(a_row + apad(4 * ca, kpt)) = acc0;
-        if (cb < H4) *reinterpret_cast<float4*>(a_row + apad(4 * cb, kpt)) = acc1;
+        if (c < H4) *reinterpret_cast<float4*>(a_row + apad(4 * c, kpt)) = acc;
     }
 }
 
-__device__ __forceinline__ void fma_rows(float4 (&acc)[RB], const float4 (&w)[KCH], const float* op, int op_ld,
+template <int RBT>
+__device__ __forceinline__ void fma_rows(float4 (&acc)[RBT], const float4 (&w)[KCH], const float* op, int op_ld,
                                          int koff, int n) {
 #pragma unroll
     for (int q = 0; q < KCH / 4; ++q) {
         if (4 * q < n) {
 #pragma unroll
-            for (int r = 0; r < RB; ++r) {
+            for (int r = 0; r < RBT; ++r) {
                 const float4 a = *reinterpret_cast<const float4*>(op + r * op_ld + koff + 4 * q);
-                const float4 w0 = w[4 * q], w1 = w[4 * q + 1], w2 = w[4 * q + 2], w3 = w[4 * q + 3];
-                acc[r].x = fmaf(w0.x, a.x, acc[r].x); acc[r].y = fmaf(w0.y, a.x, acc[r].y);
-                acc[r].z = fmaf(w0.z, a.x, acc[r].z); acc[r].w = fmaf(w0.w, a.x, acc[r].w);
-                acc[r].x = fmaf(w1.x, a.y, acc[r].x); acc[r].y = fmaf(w1.y, a.y, acc[r].y);
-                acc[r].z = fmaf(w1.z, a.y, acc[r].z); acc[r].w = fmaf(w1.w, a.y, acc[r].w);
-                acc[r].x = fmaf(w2.x, a.z, acc[r].x); acc[r].y = fmaf(w2.y, a.z, acc[r].y);
-                acc[r].z = fmaf(w2.z, a.z, acc[r].z); acc[r].w = fmaf(w2.w, a.z, acc[r].w);
-                acc[r].x = fmaf(w3.x, a.w, acc[r].x); acc[r].y = fmaf(w3.y, a.w, acc[r].y);
-                acc[r].z = fmaf(w3.z, a.w, acc[r].z); acc[r].w = fmaf(w3.w, a.w, acc[r].w);
+                fma4(acc[r], a.x, w[4 * q]); fma4(acc[r], a.y, w[4 * q + 1]);
+                fma4(acc[r], a.z, w[4 * q + 2]); fma4(acc[r], a.w, w[4 * q + 3]);
             }
-        }
-    }
-}
-
-__device__ __forceinline__ void reduce_k_lanes(float4 (&acc)[RB]) {
-#pragma unroll
-    for (int off = 4; off < 64; off <<= 1) {
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            acc[r].x += __shfl_xor(acc[r].x, off, 64); acc[r].y += __shfl_xor(acc[r].y, off, 64);
-            acc[r].z += __shfl_xor(acc[r].z, off, 64); acc[r].w += __shfl_xor(acc[r].w, off, 64);
         }
     }
 }
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// JS hidden units per slice (3*JS weight columns = 3*JS/4 float4 column groups, 4 per wave),
+// RBT frontier rows per block.
+template <int JS, int RBT>
 __global__ void __launch_bounds__(FT) frontier_step_kernel(const int32_t* __restrict__ plan, PlanLayout L, StepArgs S) {
+    constexpr int NCW = 3 * JS / 16;   // waves that own weight columns (4 column groups each)
+    constexpr int SW = 3 * JS;         // slice width in columns
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int NS = S.NS, H = S.H, ld_h = S.ld_h;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool prof = S.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+    unsigned long long* stamp = prof ? S.dbg + 8 * (int64_t)S.step : nullptr;
+    if (prof) stamp[0] = wall_clock64();
+    const int H = S.H, ld_h = S.ld_h;
+    const int NS = H / JS;
     const int sl = blockIdx.x % NS;
     const int gb = blockIdx.x / NS;
     int c = 0;
     while (c + 1 < S.ncell && gb >= S.blk_start[c + 1]) ++c;
     const Cell& C = S.cell[c];
-    const int slot0 = C.row_base + (gb - S.blk_start[c]) * RB;
-    const int nr = min(RB, C.row_end - slot0);
+    const int slot0 = C.row_base + (gb - S.blk_start[c]) * RBT;
+    const int nr = min(RBT, C.row_end - slot0);
     const int d = C.dir;
     const bool has_in = C.wih != nullptr;
+    const bool has_pred = C.has_pred != 0;
 
     const int kpt = H >> 4;                 // k values per K-lane (H % 64 == 0)
     const int op_ld = H + 4 * 16;           // padded operand row
-    float* a_s = smem;                      // [RB][op_ld]   aggregates
-    float* u_s = a_s + RB * op_ld;          // [RB][op_ld]   own lower-layer rows (has_in)
-    float* gh_s = u_s + RB * op_ld;         // [RB][96]      hidden-side pre-activations of the slice
-    float* gi_s = gh_s + RB * 96;           // [RB][96]      input-side
-    int4* rec_s = reinterpret_cast<int4*>(gi_s + RB * 96);  // [RB]
+    float* a_s = smem;                      // [RBT][op_ld]  aggregates
+    float* u_s = a_s + RBT * op_ld;         // [RBT][op_ld]  own lower-layer rows (has_in)
+    float* gh_s = u_s + RBT * op_ld;        // [RBT][SW]     hidden-side pre-activations of the slice
+    float* gi_s = gh_s + RBT * SW;          // [RBT][SW]     input-side
+    int* v_s = reinterpret_cast<int*>(gi_s + RBT * SW);  // [RBT] node ids
 
     // ---- weights of this slice: issued first, consumed after the aggregate (phase B)
-    const int ksl = lane >> 2;              // K-lane 0..15
+    const int ksl = lane & 15;              // K-lane within the DPP row
     const int nchunk = (kpt + KCH - 1) / KCH;
-    const int64_t wstride = (int64_t)FT;    // float4 per (chunk, kk) plane: 6 waves x 64 lanes
+    const int64_t wstride = (int64_t)NCW * 64;  // float4 per kk plane of one slice
+    const bool owns_cols = wave < NCW;
     const float4* whh = C.whh + (int64_t)sl * kpt * wstride + tid;
     const float4* wih = has_in ? C.wih + (int64_t)sl * kpt * wstride + tid : nullptr;
     float4 wh[KCH], wi[KCH];
@@ -210,30 +245,32 @@ __global__ void __launch_bounds__(FT) frontier_step_kernel(const int32_t* __rest
     for (int kk = 0; kk < KCH; ++kk) {
         wh[kk] = make_float4(0.f, 0.f, 0.f, 0.f);
         wi[kk] = wh[kk];
-        if (kk < n0k) {
-            wh[kk] = whh[kk * wstride];
+        if (owns_cols && kk < n0k) {
+            if (has_pred) wh[kk] = whh[kk * wstride];
             if (has_in) wi[kk] = wih[kk * wstride];
         }
     }
+    if (prof) stamp[1] = wall_clock64();
 
-    // ---- phase A: row records, own lower-layer row, aggregate
-    if (tid < RB) rec_s[tid] = tid < nr ? *reinterpret_cast<const int4*>(plan + L.rowrec[d] + 4 * (int64_t)(slot0 + tid))
-                                        : make_int4(0, 0, 0, 0);
+    // ---- phase A: one wave per row (rows wave, wave+6)
     const int32_t* col = plan + L.col[d];
     const float* eattr = reinterpret_cast<const float*>(plan + L.eattr[d]);
+    const int4* __restrict__ recs = reinterpret_cast<const int4*>(plan + L.rowrec[d]);
     const int R = C.gain ? S.R : 0;
     const int H4 = H >> 2;
-    for (int r = wave; r < RB; r += FT / 64) {
+    for (int r = wave; r < RBT; r += FT / 64) {
         float* a_row = a_s + r * op_ld;
         float* u_row = u_s + r * op_ld;
         if (r < nr) {
-            const int4 rec = *reinterpret_cast<const int4*>(plan + L.rowrec[d] + 4 * (int64_t)(slot0 + r));
+            const int4* rp = recs + 4 * (int64_t)(slot0 + r);  // wave-uniform address: scalar loads
+            const int4 rec0 = rp[0];
+            if (lane == 0) v_s[r] = rec0.x;
             if (has_in) {
-                const float4* ur = reinterpret_cast<const float4*>(C.h_in + (int64_t)rec.x * ld_h);
+                const float4* ur = reinterpret_cast<const float4*>(C.h_in + (int64_t)rec0.x * ld_h);
                 for (int cc = lane; cc < H4; cc += 64) *reinterpret_cast<float4*>(u_row + apad(4 * cc, kpt)) = ur[cc];
             }
-            if (C.has_pred && rec.z > rec.y) {
-                aggregate(C, col, eattr, rec.y, rec.z, H, ld_h, NS, R, S.vid_mod, kpt, a_row, lane);
+            if (has_pred && rec0.z > rec0.y) {
+                aggregate(C, col, eattr, rec0.y, rec0.z, rp[1], rp[2], rp[3], H, ld_h, R, S.vid_mod, kpt, a_row, lane);
             } else {
                 for (int cc = lane; cc < H4; cc += 64)
                     *reinterpret_cast<float4*>(a_row + apad(4 * cc, kpt)) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -246,105 +283,132 @@ __global__ void __launch_bounds__(FT) frontier_step_kernel(const int32_t* __rest
         }
     }
     __syncthreads();
+    if (prof) stamp[2] = wall_clock64();
 
-    // ---- phase B: slice GEMV, K over the 16 K-lanes of each wave
-    float4 acc_h[RB], acc_i[RB];
+    // gate inputs that do not depend on the GEMV: issue now, consume in phase C
+    const int gr_ = tid / JS, gj_ = tid - gr_ * JS;   // gate thread -> (row, unit of the slice)
+    const bool gate_thread = tid < RBT * JS && gr_ < nr;
+    const int gv = gate_thread ? v_s[gr_] : 0;
+    const int j = sl * JS + gj_;
+    float pre_r = 0.f, pre_z = 0.f, pre_n = 0.f, bh_r = 0.f, bh_z = 0.f, bh_n = 0.f, wk = 0.f;
+    if (gate_thread) {
+        if (has_in) { pre_r = C.bih[j]; pre_z = C.bih[H + j]; pre_n = C.bih[2 * H + j]; }
+        else { const float* g0 = C.gi0 + (int64_t)gv * 3 * H; pre_r = g0[j]; pre_z = g0[H + j]; pre_n = g0[2 * H + j]; }
+        bh_r = C.bhh[j]; bh_z = C.bhh[H + j]; bh_n = C.bhh[2 * H + j];
+        wk = C.wkey[j];
+    }
+
+    // ---- phase B: slice GEMV, K over the 16 lanes of each DPP row
+    if (owns_cols) {
+        float4 acc_h[RBT], acc_i[RBT];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) { acc_h[r] = make_float4(0.f, 0.f, 0.f, 0.f); acc_i[r] = acc_h[r]; }
-    const int kbase = ksl * kpt + 4 * ksl;  // == apad(ksl * kpt, kpt)
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const int n = min(KCH, kpt - ch * KCH);
-        if (ch > 0) {
+        for (int r = 0; r < RBT; ++r) { acc_h[r] = make_float4(0.f, 0.f, 0.f, 0.f); acc_i[r] = acc_h[r]; }
+        const int kbase = ksl * kpt + 4 * ksl;  // == apad(ksl * kpt, kpt)
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int n = min(KCH, kpt - ch * KCH);
+            if (ch > 0) {
 #pragma unroll
-            for (int kk = 0; kk < KCH; ++kk) {
-                if (kk < n) {
-                    wh[kk] = whh[(int64_t)(ch * KCH + kk) * wstride];
-                    if (has_in) wi[kk] = wih[(int64_t)(ch * KCH + kk) * wstride];
+                for (int kk = 0; kk < KCH; ++kk) {
+                    if (kk < n) {
+                        if (has_pred) wh[kk] = whh[(int64_t)(ch * KCH + kk) * wstride];
+                        if (has_in) wi[kk] = wih[(int64_t)(ch * KCH + kk) * wstride];
+                    }
                 }
             }
+            if (has_pred) fma_rows<RBT>(acc_h, wh, a_s, op_ld, kbase + ch * KCH, n);
+            if (has_in) fma_rows<RBT>(acc_i, wi, u_s, op_ld, kbase + ch * KCH, n);
         }
-        if (C.has_pred) fma_rows(acc_h, wh, a_s, op_ld, kbase + ch * KCH, n);
-        if (has_in) fma_rows(acc_i, wi, u_s, op_ld, kbase + ch * KCH, n);
-    }
-    if (C.has_pred) reduce_k_lanes(acc_h);
-    if (has_in) reduce_k_lanes(acc_i);
-    if (lane < 4) {  // K-lane 0 holds the sums of column group 4*wave + lane
-        const int cg = 4 * wave + lane;
+        if (prof) stamp[3] = wall_clock64();
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            *reinterpret_cast<float4*>(gh_s + r * 96 + 4 * cg) = acc_h[r];
-            *reinterpret_cast<float4*>(gi_s + r * 96 + 4 * cg) = acc_i[r];
+        for (int r = 0; r < RBT; ++r) {
+            if (has_pred) { acc_h[r].x = dpp_row_sum16(acc_h[r].x); acc_h[r].y = dpp_row_sum16(acc_h[r].y);
+                            acc_h[r].z = dpp_row_sum16(acc_h[r].z); acc_h[r].w = dpp_row_sum16(acc_h[r].w); }
+            if (has_in) { acc_i[r].x = dpp_row_sum16(acc_i[r].x); acc_i[r].y = dpp_row_sum16(acc_i[r].y);
+                          acc_i[r].z = dpp_row_sum16(acc_i[r].z); acc_i[r].w = dpp_row_sum16(acc_i[r].w); }
+        }
+        if (ksl == 15) {  // last lane of each DPP row holds the totals of column group 4*wave + row
+            const int cg = 4 * wave + (lane >> 4);
+#pragma unroll
+            for (int r = 0; r < RBT; ++r) {
+                *reinterpret_cast<float4*>(gh_s + r * SW + 4 * cg) = acc_h[r];
+                *reinterpret_cast<float4*>(gi_s + r * SW + 4 * cg) = acc_i[r];
+            }
         }
     }
     __syncthreads();
+    if (prof) stamp[4] = wall_clock64();
 
-    // ---- phase C: gates for 8 rows x 32 units
-    if (tid < RB * JS) {
-        const int r = tid >> 5, jj = tid & 31;
-        if (r < nr) {
-            const int v = rec_s[r].x;
-            const int j = sl * JS + jj;
-            float gr, gz, gn;
-            if (has_in) {
-                gr = gi_s[r * 96 + jj] + C.bih[j];
-                gz = gi_s[r * 96 + 32 + jj] + C.bih[H + j];
-                gn = gi_s[r * 96 + 64 + jj] + C.bih[2 * H + j];
-            } else {
-                const float* g0 = C.gi0 + (int64_t)v * 3 * H;
-                gr = g0[j]; gz = g0[H + j]; gn = g0[2 * H + j];
-            }
-            const float hr = gh_s[r * 96 + jj] + C.bhh[j];
-            const float hz = gh_s[r * 96 + 32 + jj] + C.bhh[H + j];
-            const float hn = gh_s[r * 96 + 64 + jj] + C.bhh[2 * H + j];
-            const float a = a_s[r * op_ld + apad(j, kpt)];
+    // ---- phase C: gates for RBT rows x JS units
+    if (tid < RBT * JS) {
+        float sp = 0.f;
+        if (gate_thread) {
+            const float gr = pre_r + (has_in ? gi_s[gr_ * SW + gj_] : 0.f);
+            const float gz = pre_z + (has_in ? gi_s[gr_ * SW + JS + gj_] : 0.f);
+            const float gn = pre_n + (has_in ? gi_s[gr_ * SW + 2 * JS + gj_] : 0.f);
+            const float hr = gh_s[gr_ * SW + gj_] + bh_r;
+            const float hz = gh_s[gr_ * SW + JS + gj_] + bh_z;
+            const float hn = gh_s[gr_ * SW + 2 * JS + gj_] + bh_n;
+            const float a = a_s[gr_ * op_ld + apad(j, kpt)];
             const float rg = sigm(gr + hr);
             const float zg = sigm(gz + hz);
             const float ng = tanhf(fmaf(rg, hn, gn));
             const float hv = fmaf(zg, a - ng, ng);  // n + z * (a - n)
-            C.h_out[(int64_t)v * ld_h + j] = hv;
-            float sp = C.wkey[j] * hv;
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) sp += __shfl_xor(sp, off, 64);  // 32-lane half-wave
-            if (jj == 0) C.spart[(int64_t)v * NS + sl] = sp;
+            C.h_out[(int64_t)gv * ld_h + j] = hv;
+            sp = wk * hv;
         }
+        // partial score of every 16-unit group (16 = one DPP row): summed by the consumers
+        sp = dpp_row_sum16(sp);
+        if (gate_thread && (tid & 15) == 15) C.h_out[(int64_t)gv * ld_h + H + (j >> 4)] = sp;
     }
+    if (prof) { stamp[5] = wall_clock64(); stamp[6] = gridDim.x; }
 }
 
-// Pack W [3H, K] (torch GRUCell layout: row g*H + j, K contiguous) into slice / lane order:
-// out[((sl * kpt + kk) * 6 + w) * 64 + lane] (float4) = the 4 columns of column group cg = 4w + (lane & 3)
-// of slice sl at k = (lane >> 2) * kpt + kk, where local column lc = 4cg + q  ->  gate lc/32, unit sl*32 + lc%32.
+// Pack W [3H, K] (torch GRUCell layout: row g*H + j, K contiguous) into slice / lane order for
+// slices of JS units: out[((sl * kpt + kk) * NCW + w) * 64 + lane] (float4) = the 4 columns of column
+// group cg = 4w + (lane >> 4) of slice sl at k = (lane & 15) * kpt + kk; local column lc = 4cg + q
+// -> gate lc / JS, unit sl*JS + lc % JS.
 __global__ void __launch_bounds__(256) pack_slices_kernel(const float* __restrict__ W, float4* __restrict__ out, int H,
-                                                           int K, int64_t total) {
+                                                           int K, int JS, int64_t total) {
     const int kpt = K >> 4;
+    const int NCW = 3 * JS / 16;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
         int64_t rest = idx >> 6;
-        const int w = (int)(rest % 6); rest /= 6;
+        const int w = (int)(rest % NCW); rest /= NCW;
         const int kk = (int)(rest % kpt);
         const int sl = (int)(rest / kpt);
-        const int cg = 4 * w + (lane & 3);
-        const int k = (lane >> 2) * kpt + kk;
+        const int cg = 4 * w + (lane >> 4);
+        const int k = (lane & 15) * kpt + kk;
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int lc = 4 * cg + q;
-            const int row = (lc >> 5) * H + sl * JS + (lc & 31);
+            const int row = (lc / JS) * H + sl * JS + (lc % JS);
             v[q] = W[(int64_t)row * K + k];
         }
         out[idx] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
+template <int JS, int RBT>
+hipError_t launch_step(int blocks, int H, hipStream_t st, const int32_t* plan, const PlanLayout& L, const StepArgs& S) {
+    const int op_ld = H + 64;
+    const size_t lds = (size_t)(2 * RBT * op_ld + 2 * RBT * 3 * JS) * sizeof(float) + RBT * sizeof(int);
+    hipLaunchKernelGGL((frontier_step_kernel<JS, RBT>), dim3((unsigned)(blocks * (H / JS))), dim3(FT), lds, st, plan, L, S);
+    return hipGetLastError();
+}
+
 }  // namespace
 
-extern "C" int dagnn_pack_slices(const float* w, float* out, int H, int K, void* stream) {
-    if (!w || !out || H <= 0 || K <= 0 || (H % JS) || (K % 64)) return DAGNN_EINVAL;
-    const int64_t total = (int64_t)(H / JS) * (K / 16) * FT;  // float4 elements == 3H*K/4
+extern "C" int dagnn_pack_slices(const float* w, float* out, int H, int K, int slice_units, void* stream) {
+    if (!w || !out || H <= 0 || K <= 0 || (slice_units != 16 && slice_units != 32) || (H % 32) || (K % 64))
+        return DAGNN_EINVAL;
+    const int64_t total = (int64_t)3 * H * K / 4;  // float4 elements
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(pack_slices_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w,
-                       reinterpret_cast<float4*>(out), H, K, total);
+                       reinterpret_cast<float4*>(out), H, K, slice_units, total);
     DAGNN_CHECK_LAUNCH();
     return DAGNN_OK;
 }
@@ -353,10 +417,10 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
                                   const int32_t* num_layers, void* stream) {
     if (!pl || !pl->data || !a || !layer_ptr || !num_layers) return DAGNN_EINVAL;
     const int H = a->H, Ls = a->num_stacked, dir_mask = a->dir_mask & 3;
-    if (H <= 0 || (H % 64) || Ls <= 0 || !dir_mask || a->ld_h < H || (a->ld_h & 3)) return DAGNN_EINVAL;
+    if (H <= 0 || (H % 64) || Ls <= 0 || !dir_mask || a->ld_h < H + H / PU || (a->ld_h & 3)) return DAGNN_EINVAL;
     int ndir = 0, dirs[2];
     for (int d = 0; d < 2; ++d) if ((dir_mask >> d) & 1) dirs[ndir++] = d;
-    if (ndir * Ls > DAGNN_MAX_CELLS) return DAGNN_EINVAL;
+    if (ndir * Ls > DAGNN_MAX_CELLS || Ls > DAGNN_MAX_STACKED) return DAGNN_EINVAL;
     if (pl->B == 0 || pl->N == 0) return DAGNN_OK;
     int Tmax = 0;
     for (int q = 0; q < ndir; ++q) {
@@ -365,18 +429,32 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         if (num_layers[d] > Tmax) Tmax = num_layers[d];
         for (int i = 0; i < Ls; ++i) {
             const dagnn_frontier_cell& c = a->cell[d][i];
-            if (!c.w_hh_pk || !c.b_hh || !c.w_key || !c.h_out || !c.score_parts) return DAGNN_EINVAL;
-            if (i == 0 ? !c.gi0 : (!c.w_ih_pk || !c.b_ih)) return DAGNN_EINVAL;
+            if (!c.w_hh_pk16 || !c.w_hh_pk32 || !c.b_hh || !c.w_key || !c.h_out) return DAGNN_EINVAL;
+            if (i == 0 ? !c.gi0 : (!c.w_ih_pk16 || !c.w_ih_pk32 || !c.b_ih)) return DAGNN_EINVAL;
         }
     }
     PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
-    const int NS = H / JS;
-    const int op_ld = H + 64;
-    const size_t lds = (size_t)(2 * RB * op_ld + 2 * RB * 96) * sizeof(float) + RB * sizeof(int4);
     StepArgs S;
-    S.H = H; S.ld_h = a->ld_h; S.NS = NS; S.R = pl->num_edge_feats; S.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
+    S.H = H; S.ld_h = a->ld_h; S.R = pl->num_edge_feats; S.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
+    S.dbg = (unsigned long long*)a->debug_timing;
     hipStream_t st = (hipStream_t)stream;
+    const int32_t* plan = (const int32_t*)pl->data;
     for (int s = 0; s < Tmax + Ls - 1; ++s) {
+        // geometry of this launch: thin launches use 16-unit slices (and 4-row blocks when that
+        // still fits one wave of workgroups), fat ones 32-unit slices and 8-row blocks
+        int rows_total = 0, blocks8 = 0, blocks4 = 0;
+        for (int q = 0; q < ndir; ++q)
+            for (int i = 0; i < Ls; ++i) {
+                const int t = s - i, d = dirs[q];
+                if (t < 0 || t >= num_layers[d]) continue;
+                const int n = layer_ptr[d][t + 1] - layer_ptr[d][t];
+                rows_total += n; blocks8 += (n + 7) / 8; blocks4 += (n + 3) / 4;
+            }
+        if (rows_total == 0) continue;
+        int js, rb;
+        if (blocks8 * (H / 32) >= 256) { js = 32; rb = 8; }
+        else if (blocks4 * (H / 16) <= 256) { js = 16; rb = 4; }
+        else { js = 16; rb = 8; }
         int nc = 0, blocks = 0;
         S.blk_start[0] = 0;
         for (int q = 0; q < ndir; ++q) {
@@ -388,23 +466,25 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
                 if (r1 <= r0) continue;
                 const dagnn_frontier_cell& c = a->cell[d][i];
                 Cell& K = S.cell[nc];
-                K.whh = (const float4*)c.w_hh_pk; K.wih = i > 0 ? (const float4*)c.w_ih_pk : nullptr;
+                K.whh = (const float4*)(js == 16 ? c.w_hh_pk16 : c.w_hh_pk32);
+                K.wih = i > 0 ? (const float4*)(js == 16 ? c.w_ih_pk16 : c.w_ih_pk32) : nullptr;
                 K.bhh = c.b_hh; K.bih = c.b_ih; K.wkey = c.w_key;
                 K.gain = pl->num_edge_feats > 0 ? c.edge_gain : nullptr;
                 K.vid = a->vid_mod > 0 ? c.vid_bias : nullptr;
                 K.gi0 = i == 0 ? c.gi0 : nullptr;
                 K.h_in = i > 0 ? a->cell[d][i - 1].h_out : nullptr;
-                K.h_out = c.h_out; K.spart = c.score_parts;
+                K.h_out = c.h_out;
                 K.dir = d; K.row_base = r0; K.row_end = r1; K.has_pred = t > 0;
-                blocks += (r1 - r0 + RB - 1) / RB;
+                blocks += (r1 - r0 + rb - 1) / rb;
                 S.blk_start[++nc] = blocks;
             }
         }
-        if (nc == 0) continue;
         S.ncell = nc;
-        hipLaunchKernelGGL(frontier_step_kernel, dim3((unsigned)(blocks * NS)), dim3(FT), lds, st,
-                           (const int32_t*)pl->data, L, S);
-        hipError_t e = hipGetLastError();
+        S.step = s;
+        hipError_t e;
+        if (js == 32) e = launch_step<32, 8>(blocks, H, st, plan, L, S);
+        else if (rb == 4) e = launch_step<16, 4>(blocks, H, st, plan, L, S);
+        else e = launch_step<16, 8>(blocks, H, st, plan, L, S);
         if (e != hipSuccess) return DAGNN_EHIP(e);
     }
     return DAGNN_OK;

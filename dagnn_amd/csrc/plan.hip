@@ -265,10 +265,13 @@ __global__ void __launch_bounds__(256) plan_lbase_kernel(int32_t* plan, PlanLayo
     }
 }
 
-// rowrec[slot] = {node, edge begin, edge end, graph} for every node, slots ordered by batch-level layer.
+// rowrec[slot] (64 B) = {node, edge begin, edge end, graph, pred[0..3], edge feats of the first four
+// in-edges (2 floats each)} for every node, slots ordered by batch-level layer.  Rows with <= 4
+// in-edges (every node of an AST in the forward direction) need no second indirection in the
+// lock-step kernel: its dependent chain is record -> predecessor rows.
 __global__ void __launch_bounds__(256) plan_rowrec_kernel(int32_t* plan, PlanLayout L, const int64_t* __restrict__ batch,
                                                            const int64_t* __restrict__ layer_fwd,
-                                                           const int64_t* __restrict__ layer_bwd, int N) {
+                                                           const int64_t* __restrict__ layer_bwd, int N, int R) {
     const int d = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;  // per-graph sorted position
     if (p >= N) return;
@@ -281,8 +284,23 @@ __global__ void __launch_bounds__(256) plan_rowrec_kernel(int32_t* plan, PlanLay
     const int base = n0 + g + t;
     const int slot = plan[L.lbase[d] + base] + (p - plan[L.lstart[d] + base]);
     const int32_t* rp = plan + L.rowptr[d] + n0 + g + (p - n0);
-    int4 rec = make_int4(v, rp[0], rp[1], g);
-    *reinterpret_cast<int4*>(plan + L.rowrec[d] + 4 * (int64_t)slot) = rec;
+    const int eb = rp[0], ee = rp[1];
+    const int32_t* col = plan + L.col[d];
+    const int32_t* eattr = plan + L.eattr[d];  // float bits
+    int w[16];
+    w[0] = v; w[1] = eb; w[2] = ee; w[3] = g;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bool ok = eb + q < ee;
+        w[4 + q] = ok ? col[eb + q] : 0;
+        w[8 + 2 * q] = (ok && R >= 1) ? eattr[(int64_t)(eb + q) * R] : 0;
+        w[9 + 2 * q] = (ok && R >= 2) ? eattr[(int64_t)(eb + q) * R + 1] : 0;
+    }
+    int4* out = reinterpret_cast<int4*>(plan + L.rowrec[d] + 16 * (int64_t)slot);
+    out[0] = make_int4(w[0], w[1], w[2], w[3]);
+    out[1] = make_int4(w[4], w[5], w[6], w[7]);
+    out[2] = make_int4(w[8], w[9], w[10], w[11]);
+    out[3] = make_int4(w[12], w[13], w[14], w[15]);
 }
 
 }  // namespace
@@ -337,7 +355,7 @@ extern "C" int dagnn_plan_build(const dagnn_plan* pl, const int64_t* edge_index,
                                (int)N, (int)B);
             DAGNN_CHECK_LAUNCH();
             hipLaunchKernelGGL(plan_rowrec_kernel, dim3((unsigned)((N + 255) / 256), 2), dim3(256), 0, stream, p, L,
-                               batch, layer_fwd, layer_bwd, (int)N);
+                               batch, layer_fwd, layer_bwd, (int)N, R);
             DAGNN_CHECK_LAUNCH();
         }
     }

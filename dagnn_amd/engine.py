@@ -190,19 +190,24 @@ def pack_whh(w_hh: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def pack_slices(w: torch.Tensor, H: int) -> torch.Tensor:
+def pack_slices(w: torch.Tensor, H: int, slice_units: int) -> torch.Tensor:
     """[3H, K] (torch layout) -> slice/lane order consumed by the lock-step kernel."""
     w = _dev(w, "weight", torch.float32)
     K = w.shape[1]
     out = torch.empty(3 * H * K, dtype=torch.float32, device=w.device)
-    check(_lib.load().dagnn_pack_slices(w.data_ptr(), out.data_ptr(), H, K, _stream(w)), "dagnn_pack_slices")
+    check(_lib.load().dagnn_pack_slices(w.data_ptr(), out.data_ptr(), H, K, slice_units, _stream(w)),
+          "dagnn_pack_slices")
     return out
 
 
-def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0, h, spart,
-                 vid_mod: int = 0) -> None:
+def frontier_ld(H: int) -> int:
+    """Row pitch of the lock-step state buffers: H states + H/16 partial scores, 16-byte multiple."""
+    return H + (H // 16 + 3) // 4 * 4
+
+
+def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0, h, vid_mod: int = 0) -> None:
     """Lock-step recurrence over all batch-level layers.  `cells[(d, i)]` are kernel-ready parameter
-    holders (core.FrontierCellParams); gi0[d] [N,3H]; h[d][i] [N,H] and spart[d][i] [N,H/32] outputs."""
+    holders (core.CellParams); gi0[d] [N,3H]; h[d][i] [N, frontier_ld(H)] outputs."""
     sched = plan.read_schedule()
     args = FrontierArgs()
     mask = 0
@@ -210,13 +215,16 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
         mask |= 1 << d
         for i in range(L):
             c, fc = cells[(d, i)], args.cell[d][i]
-            fc.w_hh_pk, fc.w_ih_pk = c.w_hh_pk.data_ptr(), _ptr(c.w_ih_pk)
+            fc.w_hh_pk16, fc.w_hh_pk32 = c.w_hh_pk[16].data_ptr(), c.w_hh_pk[32].data_ptr()
+            if c.w_ih_pk is not None:
+                fc.w_ih_pk16, fc.w_ih_pk32 = c.w_ih_pk[16].data_ptr(), c.w_ih_pk[32].data_ptr()
             fc.b_hh, fc.b_ih, fc.w_key = c.b_hh.data_ptr(), _ptr(c.b_ih_dev), c.w_key.data_ptr()
             fc.edge_gain = _ptr(c.edge_gain) if plan.R > 0 else None
             fc.vid_bias = _ptr(c.vid_bias) if vid_mod > 0 else None
             fc.gi0 = gi0[d].data_ptr() if i == 0 else None
-            fc.h_out, fc.score_parts = h[d][i].data_ptr(), spart[d][i].data_ptr()
-    args.num_stacked, args.dir_mask, args.H, args.ld_h, args.vid_mod = L, mask, H, H, int(vid_mod)
+            fc.h_out = h[d][i].data_ptr()
+    args.num_stacked, args.dir_mask, args.H, args.ld_h, args.vid_mod = L, mask, H, h[dirs[0]][0].shape[1], int(vid_mod)
+    args.debug_timing = DEBUG_TIMING.data_ptr() if DEBUG_TIMING is not None else None
     ptrs = (C.POINTER(C.c_int32) * 2)()
     nl = (C.c_int32 * 2)()
     for d in (0, 1):

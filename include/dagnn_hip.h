@@ -153,22 +153,29 @@ int dagnn_recurrence_layer(const dagnn_plan* plan /* host */, const dagnn_layer_
  * launches.  Each workgroup owns a 32-unit slice of one cell's GRU weights for a block of <= 8
  * frontier rows (see dagnn_amd/csrc/frontier.hip).  Requires H % 64 == 0 (the host pads).
  *
- * Weights are consumed in slice/lane order: pack W [3H, K] (torch layout) with dagnn_pack_slices
- * (K = H for weight_hh, and for weight_ih of stacked layers > 0).
+ * Weights are consumed in slice/lane order: pack W [3H, K] (torch layout) with dagnn_pack_slices for
+ * both slice widths the launches use (16 hidden units for thin launches, 32 for fat ones); K = H for
+ * weight_hh and for weight_ih of stacked layers > 0.  H % 32 == 0, K % 64 == 0.
+ *
+ * State rows carry their attention scores: h_out is [N, ld_h] with ld_h >= H + H/16 (multiple of 4);
+ * floats [H, H + H/16) of row v are the partial dots w_key[16q:16q+16] . h[v, 16q:16q+16], written
+ * by the producing workgroups and summed in index order by the consumers (deterministic).
  * ---------------------------------------------------------------------------------------- */
-int dagnn_pack_slices(const float* w /* [3H,K] */, float* out /* 3H*K floats */, int H, int K, void* stream);
+int dagnn_pack_slices(const float* w /* [3H,K] */, float* out /* 3H*K floats */, int H, int K, int slice_units,
+                      void* stream);
 
 typedef struct dagnn_frontier_cell {
-    const float* w_hh_pk;   /* packed weight_hh */
-    const float* w_ih_pk;   /* packed weight_ih (stacked layers > 0), else NULL */
+    const float* w_hh_pk16; /* weight_hh packed for 16-unit slices */
+    const float* w_hh_pk32; /* ... and for 32-unit slices */
+    const float* w_ih_pk16; /* weight_ih (stacked layers > 0), else NULL */
+    const float* w_ih_pk32;
     const float* b_hh;      /* [3H] */
     const float* b_ih;      /* [3H] (stacked layers > 0; layer 0 has it folded into gi0) */
     const float* w_key;     /* [H] key half of attn_lin.weight */
     const float* edge_gain; /* [num_edge_feats] or NULL */
     const float* vid_bias;  /* [vid_mod] or NULL */
     const float* gi0;       /* [N,3H] W_ih x + b_ih (stacked layer 0 only), from dagnn_gemm_nt_bias */
-    float* h_out;           /* [N,ld_h] hidden states of this cell (every row written exactly once) */
-    float* score_parts;     /* [N,H/32] scratch: per-slice partial attention scores of h_out */
+    float* h_out;           /* [N,ld_h] hidden states + partial scores (every row written exactly once) */
 } dagnn_frontier_cell;
 
 #define DAGNN_MAX_STACKED 8
@@ -177,6 +184,7 @@ typedef struct dagnn_frontier_args {
     int num_stacked; /* L */
     int dir_mask;
     int H, ld_h, vid_mod;
+    void* debug_timing; /* NULL, or (T+L-1)*8 uint64 device words: 100 MHz stamps of workgroup 0 per launch */
 } dagnn_frontier_args;
 
 /* layer_ptr[d] (HOST, num_layers[d] + 1 int32): row offsets of the batch-level layers of direction

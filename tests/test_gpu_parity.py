@@ -73,7 +73,8 @@ def test_plan_matches_oracle_csr(device, seed, B, mean_n):
         T = int(layer.max()) + 1
         bl = ws[lay["blptr%d" % d]:lay["blptr%d" % d] + N + 2]
         assert bl[N + 1] == T and bl[0] == 0 and bl[T] == N
-        rec = ws[lay["rowrec%d" % d]:lay["rowrec%d" % d] + 4 * N].reshape(N, 4)
+        rec16 = ws[lay["rowrec%d" % d]:lay["rowrec%d" % d] + 16 * N].reshape(N, 16)
+        rec = rec16[:, :4]
         assert sorted(rec[:, 0].tolist()) == list(range(N))
         for t in range(T):
             nodes = rec[bl[t]:bl[t + 1], 0]
@@ -82,8 +83,12 @@ def test_plan_matches_oracle_csr(device, seed, B, mean_n):
         pos[order] = np.arange(N)
         gid = b.batch.numpy()
         rp_flat = lambda v: ws[lay["rowptr%d" % d] + pos[v] + gid[v]: lay["rowptr%d" % d] + pos[v] + gid[v] + 2]  # noqa
-        for v, eb, ee, g in rec[:: max(1, N // 200)]:
+        for row in rec16[:: max(1, N // 200)]:
+            v, eb, ee, g = row[:4]
             assert g == gid[v] and [eb, ee] == rp_flat(v).tolist()
+            k = min(4, ee - eb)
+            assert np.array_equal(row[4:4 + k], col[eb:eb + k])  # inline predecessors
+            assert np.array_equal(row[8:8 + 2 * k].view(np.float32), eattr[eb:eb + k].reshape(-1))
     items = ws[lay["items"]:lay["items"] + 2 * B]
     dep = [ws[lay["depth%d" % (i & 1)] + (i >> 1)] for i in items]
     assert sorted(items.tolist()) == list(range(2 * B)) and dep == sorted(dep, reverse=True)

@@ -36,7 +36,6 @@
 namespace {
 
 constexpr int FT = 384;     // threads per workgroup (6 waves)
-constexpr int KCH = 16;     // k values per lane per register chunk
 constexpr int PU = 16;      // hidden units per stored score part
 
 struct Cell {
@@ -107,6 +106,13 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
         const float f0[4] = {__int_as_float(rec2.x), __int_as_float(rec2.z), __int_as_float(rec3.x), __int_as_float(rec3.z)};
         const float f1[4] = {__int_as_float(rec2.y), __int_as_float(rec2.w), __int_as_float(rec3.y), __int_as_float(rec3.w)};
         float al[4] = {1.f, 0.f, 0.f, 0.f};
+        // first 64 float4 columns of every predecessor row: issued before the scores are touched so
+        // that rows and scores share one memory round trip
+        float4 row0[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            row0[e] = (e < deg && lane < H4) ? reinterpret_cast<const float4*>(hsrc + (int64_t)pj[e] * ld_h)[lane]
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
         if (deg > 1) {
             float lg[4], mx = -INFINITY;
 #pragma unroll
@@ -128,7 +134,13 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
 #pragma unroll
             for (int e = 0; e < 4; ++e) al[e] = al[e] / denom;
         }
-        for (int c = lane; c < H4; c += 64) {
+        if (lane < H4) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fma4(acc, al[e], row0[e]);  // al[e] == 0 and row0[e] == 0 beyond deg
+            *reinterpret_cast<float4*>(a_row + apad(4 * lane, kpt)) = acc;
+        }
+        for (int c = lane + 64; c < H4; c += 64) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -144,11 +156,19 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
         for (int r = 0; r < R; ++r) s = fmaf(C.gain[r], eattr[(int64_t)e * R + r], s);
         return s;
     };
-    float mx = -INFINITY, sum = 0.f;
-    for (int e = eb + lane; e < ee; e += 64) mx = fmaxf(mx, logit(e, col[e]));
-    mx = wave_max(mx);
-    for (int e = eb + lane; e < ee; e += 64) sum += expf(logit(e, col[e]) - mx);
-    sum = wave_sum(sum);
+    float mx = -INFINITY, sum = 0.f, lg0 = -INFINITY;
+    int col0 = 0;
+    const bool one_pass = deg <= 64;  // every lane owns at most one edge: its logit stays in a register
+    if (one_pass) {
+        if (lane < deg) { col0 = col[eb + lane]; lg0 = logit(eb + lane, col0); }
+        mx = wave_max(lg0);
+        sum = wave_sum(lane < deg ? expf(lg0 - mx) : 0.f);
+    } else {
+        for (int e = eb + lane; e < ee; e += 64) mx = fmaxf(mx, logit(e, col[e]));
+        mx = wave_max(mx);
+        for (int e = eb + lane; e < ee; e += 64) sum += expf(logit(e, col[e]) - mx);
+        sum = wave_sum(sum);
+    }
     const float denom = sum + 1e-16f;
     for (int c0 = 0; c0 < H4; c0 += 64) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -157,7 +177,10 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
             const int e = base + lane;
             float my_alpha = 0.f;
             int my_col = 0;
-            if (e < ee) { my_col = col[e]; my_alpha = expf(logit(e, my_col) - mx) / denom; }
+            if (e < ee) {
+                if (one_pass) { my_col = col0; my_alpha = expf(lg0 - mx) / denom; }
+                else { my_col = col[e]; my_alpha = expf(logit(e, my_col) - mx) / denom; }
+            }
             const int cnt = min(64, ee - base);
             int i = 0;
             for (; i + 4 <= cnt; i += 4) {  // four row loads in flight per lane
@@ -181,11 +204,11 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
     }
 }
 
-template <int RBT>
-__device__ __forceinline__ void fma_rows(float4 (&acc)[RBT], const float4 (&w)[KCH], const float* op, int op_ld,
+template <int RBT, int KW>
+__device__ __forceinline__ void fma_rows(float4 (&acc)[RBT], const float4 (&w)[KW], const float* op, int op_ld,
                                          int koff, int n) {
 #pragma unroll
-    for (int q = 0; q < KCH / 4; ++q) {
+    for (int q = 0; q < KW / 4; ++q) {
         if (4 * q < n) {
 #pragma unroll
             for (int r = 0; r < RBT; ++r) {
@@ -200,9 +223,12 @@ __device__ __forceinline__ void fma_rows(float4 (&acc)[RBT], const float4 (&w)[K
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // JS hidden units per slice (3*JS weight columns = 3*JS/4 float4 column groups, 4 per wave),
-// RBT frontier rows per block.
-template <int JS, int RBT>
-__global__ void __launch_bounds__(FT) frontier_step_kernel(const int32_t* __restrict__ plan, PlanLayout L, StepArgs S) {
+// RBT frontier rows per block, KW k values per lane held in registers at a time: KW = 16 prefetches a
+// whole K = 256 slice ahead of the dependent chain (thin, latency-bound launches, 1 workgroup per
+// CU); KW = 4 streams it in chunks so that two workgroups fit a CU and hide each other's latency
+// (fat launches: many more workgroups than CUs).
+template <int JS, int RBT, int KW, int MINW>
+__global__ void __launch_bounds__(FT, MINW) frontier_step_kernel(const int32_t* __restrict__ plan, PlanLayout L, StepArgs S) {
     constexpr int NCW = 3 * JS / 16;   // waves that own weight columns (4 column groups each)
     constexpr int SW = 3 * JS;         // slice width in columns
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -234,15 +260,15 @@ __global__ void __launch_bounds__(FT) frontier_step_kernel(const int32_t* __rest
 
     // ---- weights of this slice: issued first, consumed after the aggregate (phase B)
     const int ksl = lane & 15;              // K-lane within the DPP row
-    const int nchunk = (kpt + KCH - 1) / KCH;
+    const int nchunk = (kpt + KW - 1) / KW;
     const int64_t wstride = (int64_t)NCW * 64;  // float4 per kk plane of one slice
     const bool owns_cols = wave < NCW;
     const float4* whh = C.whh + (int64_t)sl * kpt * wstride + tid;
     const float4* wih = has_in ? C.wih + (int64_t)sl * kpt * wstride + tid : nullptr;
-    float4 wh[KCH], wi[KCH];
-    const int n0k = min(KCH, kpt);
+    float4 wh[KW], wi[KW];
+    const int n0k = min(KW, kpt);
 #pragma unroll
-    for (int kk = 0; kk < KCH; ++kk) {
+    for (int kk = 0; kk < KW; ++kk) {
         wh[kk] = make_float4(0.f, 0.f, 0.f, 0.f);
         wi[kk] = wh[kk];
         if (owns_cols && kk < n0k) {
@@ -305,18 +331,18 @@ __global__ void __launch_bounds__(FT) frontier_step_kernel(const int32_t* __rest
         for (int r = 0; r < RBT; ++r) { acc_h[r] = make_float4(0.f, 0.f, 0.f, 0.f); acc_i[r] = acc_h[r]; }
         const int kbase = ksl * kpt + 4 * ksl;  // == apad(ksl * kpt, kpt)
         for (int ch = 0; ch < nchunk; ++ch) {
-            const int n = min(KCH, kpt - ch * KCH);
+            const int n = min(KW, kpt - ch * KW);
             if (ch > 0) {
 #pragma unroll
-                for (int kk = 0; kk < KCH; ++kk) {
+                for (int kk = 0; kk < KW; ++kk) {
                     if (kk < n) {
-                        if (has_pred) wh[kk] = whh[(int64_t)(ch * KCH + kk) * wstride];
-                        if (has_in) wi[kk] = wih[(int64_t)(ch * KCH + kk) * wstride];
+                        if (has_pred) wh[kk] = whh[(int64_t)(ch * KW + kk) * wstride];
+                        if (has_in) wi[kk] = wih[(int64_t)(ch * KW + kk) * wstride];
                     }
                 }
             }
-            if (has_pred) fma_rows<RBT>(acc_h, wh, a_s, op_ld, kbase + ch * KCH, n);
-            if (has_in) fma_rows<RBT>(acc_i, wi, u_s, op_ld, kbase + ch * KCH, n);
+            if (has_pred) fma_rows<RBT, KW>(acc_h, wh, a_s, op_ld, kbase + ch * KW, n);
+            if (has_in) fma_rows<RBT, KW>(acc_i, wi, u_s, op_ld, kbase + ch * KW, n);
         }
         if (prof) stamp[3] = wall_clock64();
 #pragma unroll
@@ -391,11 +417,11 @@ __global__ void __launch_bounds__(256) pack_slices_kernel(const float* __restric
     }
 }
 
-template <int JS, int RBT>
+template <int JS, int RBT, int KW, int MINW>
 hipError_t launch_step(int blocks, int H, hipStream_t st, const int32_t* plan, const PlanLayout& L, const StepArgs& S) {
     const int op_ld = H + 64;
     const size_t lds = (size_t)(2 * RBT * op_ld + 2 * RBT * 3 * JS) * sizeof(float) + RBT * sizeof(int);
-    hipLaunchKernelGGL((frontier_step_kernel<JS, RBT>), dim3((unsigned)(blocks * (H / JS))), dim3(FT), lds, st, plan, L, S);
+    hipLaunchKernelGGL((frontier_step_kernel<JS, RBT, KW, MINW>), dim3((unsigned)(blocks * (H / JS))), dim3(FT), lds, st, plan, L, S);
     return hipGetLastError();
 }
 
@@ -417,7 +443,8 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
                                   const int32_t* num_layers, void* stream) {
     if (!pl || !pl->data || !a || !layer_ptr || !num_layers) return DAGNN_EINVAL;
     const int H = a->H, Ls = a->num_stacked, dir_mask = a->dir_mask & 3;
-    if (H <= 0 || (H % 64) || Ls <= 0 || !dir_mask || a->ld_h < H + H / PU || (a->ld_h & 3)) return DAGNN_EINVAL;
+    if (H <= 0 || (H % 64) || Ls <= 0 || !dir_mask || a->ld_h < H + H / PU || (a->ld_h & 3) || a->num_cus <= 0)
+        return DAGNN_EINVAL;
     int ndir = 0, dirs[2];
     for (int d = 0; d < 2; ++d) if ((dir_mask >> d) & 1) dirs[ndir++] = d;
     if (ndir * Ls > DAGNN_MAX_CELLS || Ls > DAGNN_MAX_STACKED) return DAGNN_EINVAL;
@@ -451,10 +478,11 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
                 rows_total += n; blocks8 += (n + 7) / 8; blocks4 += (n + 3) / 4;
             }
         if (rows_total == 0) continue;
+        // one workgroup per CU is resident (6 waves, ~230 VGPRs): never spill slightly over one round
         int js, rb;
-        if (blocks8 * (H / 32) >= 256) { js = 32; rb = 8; }
-        else if (blocks4 * (H / 16) <= 256) { js = 16; rb = 4; }
-        else { js = 16; rb = 8; }
+        if (blocks4 * (H / 16) <= a->num_cus) { js = 16; rb = 4; }
+        else if (blocks8 * (H / 16) <= a->num_cus) { js = 16; rb = 8; }
+        else { js = 32; rb = 8; }
         int nc = 0, blocks = 0;
         S.blk_start[0] = 0;
         for (int q = 0; q < ndir; ++q) {
@@ -482,9 +510,9 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         S.ncell = nc;
         S.step = s;
         hipError_t e;
-        if (js == 32) e = launch_step<32, 8>(blocks, H, st, plan, L, S);
-        else if (rb == 4) e = launch_step<16, 4>(blocks, H, st, plan, L, S);
-        else e = launch_step<16, 8>(blocks, H, st, plan, L, S);
+        if (js == 32) e = launch_step<32, 8, 4, 3>(blocks, H, st, plan, L, S);
+        else if (rb == 4) e = launch_step<16, 4, 16, 1>(blocks, H, st, plan, L, S);
+        else e = launch_step<16, 8, 16, 1>(blocks, H, st, plan, L, S);
         if (e != hipSuccess) return DAGNN_EHIP(e);
     }
     return DAGNN_OK;

@@ -225,6 +225,7 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
             fc.h_out = h[d][i].data_ptr()
     args.num_stacked, args.dir_mask, args.H, args.ld_h, args.vid_mod = L, mask, H, h[dirs[0]][0].shape[1], int(vid_mod)
     args.debug_timing = DEBUG_TIMING.data_ptr() if DEBUG_TIMING is not None else None
+    args.num_cus = torch.cuda.get_device_properties(plan.ws.device).multi_processor_count
     ptrs = (C.POINTER(C.c_int32) * 2)()
     nl = (C.c_int32 * 2)()
     for d in (0, 1):

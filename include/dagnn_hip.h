@@ -184,6 +184,7 @@ typedef struct dagnn_frontier_args {
     int num_stacked; /* L */
     int dir_mask;
     int H, ld_h, vid_mod;
+    int num_cus;     /* compute units of the device (launch geometry heuristic), e.g. 256 */
     void* debug_timing; /* NULL, or (T+L-1)*8 uint64 device words: 100 MHz stamps of workgroup 0 per launch */
 } dagnn_frontier_args;
 

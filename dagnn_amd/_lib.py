@@ -50,7 +50,8 @@ class FrontierCell(C.Structure):
 class FrontierArgs(C.Structure):
     _fields_ = [("cell", (FrontierCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
                 ("H", C.c_int), ("ld_h", C.c_int), ("vid_mod", C.c_int), ("num_cus", C.c_int),
-                ("debug_timing", C.c_void_p)]
+                ("tail_replicas", C.c_int), ("tail_max_blocks", C.c_int), ("tail_sync", C.c_void_p),
+                ("tail_sync_words", C.c_int), ("debug_timing", C.c_void_p)]
 
 
 # every symbol include/dagnn_hip.h declares: (restype, argtypes)

@@ -222,34 +222,26 @@ __device__ __forceinline__ void fma_rows(float4 (&acc)[RBT], const float4 (&w)[K
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// JS hidden units per slice (3*JS weight columns = 3*JS/4 float4 column groups, 4 per wave),
-// RBT frontier rows per block, KW k values per lane held in registers at a time: KW = 16 prefetches a
-// whole K = 256 slice ahead of the dependent chain (thin, latency-bound launches, 1 workgroup per
-// CU); KW = 4 streams it in chunks so that two workgroups fit a CU and hide each other's latency
-// (fat launches: many more workgroups than CUs).
-template <int JS, int RBT, int KW, int MINW>
-__global__ void __launch_bounds__(FT, MINW) frontier_step_kernel(const int32_t* __restrict__ plan, PlanLayout L, StepArgs S) {
+// -----------------------------------------------------------------------------------------------
+// One row block (<= RBT frontier rows of one cell) x one slice of JS hidden units.
+//   JS   hidden units per slice (3*JS weight columns = 3*JS/4 float4 column groups, 4 per wave)
+//   KW   k values per lane held in registers at a time.  KW = 16 keeps a whole K = 256 slice in
+//        registers (issued ahead of the dependent chain in the launch-per-layer kernel, resident
+//        across steps in the persistent tail kernel); KW = 4 streams it in chunks so that two
+//        workgroups fit a CU and hide each other's latency (fat launches).
+//   RESIDENT  the first weight chunk is already in wh/wi (persistent kernel); rows are published
+//        with write-through (sc1) stores for the other workgroups of the same launch.
+// -----------------------------------------------------------------------------------------------
+template <int JS, int RBT, int KW, bool RESIDENT>
+__device__ __forceinline__ void process_block(const int32_t* __restrict__ plan, int64_t rowrec_off, int64_t col_off,
+                                              int64_t eattr_off, const Cell& C, bool has_pred, int slot0, int nr,
+                                              int sl, int H, int ld_h, int Rfeat, int vid_mod, float* smem,
+                                              float4 (&wh)[KW], float4 (&wi)[KW], unsigned long long* stamp) {
     constexpr int NCW = 3 * JS / 16;   // waves that own weight columns (4 column groups each)
     constexpr int SW = 3 * JS;         // slice width in columns
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool prof = S.dbg != nullptr && blockIdx.x == 0 && tid == 0;
-    unsigned long long* stamp = prof ? S.dbg + 8 * (int64_t)S.step : nullptr;
-    if (prof) stamp[0] = wall_clock64();
-    const int H = S.H, ld_h = S.ld_h;
-    const int NS = H / JS;
-    const int sl = blockIdx.x % NS;
-    const int gb = blockIdx.x / NS;
-    int c = 0;
-    while (c + 1 < S.ncell && gb >= S.blk_start[c + 1]) ++c;
-    const Cell& C = S.cell[c];
-    const int slot0 = C.row_base + (gb - S.blk_start[c]) * RBT;
-    const int nr = min(RBT, C.row_end - slot0);
-    const int d = C.dir;
     const bool has_in = C.wih != nullptr;
-    const bool has_pred = C.has_pred != 0;
-
     const int kpt = H >> 4;                 // k values per K-lane (H % 64 == 0)
     const int op_ld = H + 4 * 16;           // padded operand row
     float* a_s = smem;                      // [RBT][op_ld]  aggregates
@@ -258,6 +250,11 @@ __global__ void __launch_bounds__(FT, MINW) frontier_step_kernel(const int32_t* 
     float* gi_s = gh_s + RBT * SW;          // [RBT][SW]     input-side
     int* v_s = reinterpret_cast<int*>(gi_s + RBT * SW);  // [RBT] node ids
 
+    // first row record of this wave: a scalar load (own counter), issued ahead of the weight loads
+    const int4* __restrict__ recs = reinterpret_cast<const int4*>(plan + rowrec_off);
+    int4 rec_first = make_int4(0, 0, 0, 0);
+    if (wave < nr) rec_first = recs[4 * (int64_t)(slot0 + wave)];
+
     // ---- weights of this slice: issued first, consumed after the aggregate (phase B)
     const int ksl = lane & 15;              // K-lane within the DPP row
     const int nchunk = (kpt + KW - 1) / KW;
@@ -265,38 +262,38 @@ __global__ void __launch_bounds__(FT, MINW) frontier_step_kernel(const int32_t* 
     const bool owns_cols = wave < NCW;
     const float4* whh = C.whh + (int64_t)sl * kpt * wstride + tid;
     const float4* wih = has_in ? C.wih + (int64_t)sl * kpt * wstride + tid : nullptr;
-    float4 wh[KW], wi[KW];
-    const int n0k = min(KW, kpt);
+    if (!RESIDENT) {
+        const int n0k = min(KW, kpt);
 #pragma unroll
-    for (int kk = 0; kk < KW; ++kk) {
-        wh[kk] = make_float4(0.f, 0.f, 0.f, 0.f);
-        wi[kk] = wh[kk];
-        if (owns_cols && kk < n0k) {
-            if (has_pred) wh[kk] = whh[kk * wstride];
-            if (has_in) wi[kk] = wih[kk * wstride];
+        for (int kk = 0; kk < KW; ++kk) {
+            wh[kk] = make_float4(0.f, 0.f, 0.f, 0.f);
+            wi[kk] = wh[kk];
+            if (owns_cols && kk < n0k) {
+                if (has_pred) wh[kk] = whh[kk * wstride];
+                if (has_in) wi[kk] = wih[kk * wstride];
+            }
         }
     }
-    if (prof) stamp[1] = wall_clock64();
+    if (stamp) stamp[1] = wall_clock64();
 
     // ---- phase A: one wave per row (rows wave, wave+6)
-    const int32_t* col = plan + L.col[d];
-    const float* eattr = reinterpret_cast<const float*>(plan + L.eattr[d]);
-    const int4* __restrict__ recs = reinterpret_cast<const int4*>(plan + L.rowrec[d]);
-    const int R = C.gain ? S.R : 0;
+    const int32_t* col = plan + col_off;
+    const float* eattr = reinterpret_cast<const float*>(plan + eattr_off);
+    const int R = C.gain ? Rfeat : 0;
     const int H4 = H >> 2;
     for (int r = wave; r < RBT; r += FT / 64) {
         float* a_row = a_s + r * op_ld;
         float* u_row = u_s + r * op_ld;
         if (r < nr) {
             const int4* rp = recs + 4 * (int64_t)(slot0 + r);  // wave-uniform address: scalar loads
-            const int4 rec0 = rp[0];
+            const int4 rec0 = r == wave ? rec_first : rp[0];
             if (lane == 0) v_s[r] = rec0.x;
             if (has_in) {
                 const float4* ur = reinterpret_cast<const float4*>(C.h_in + (int64_t)rec0.x * ld_h);
                 for (int cc = lane; cc < H4; cc += 64) *reinterpret_cast<float4*>(u_row + apad(4 * cc, kpt)) = ur[cc];
             }
             if (has_pred && rec0.z > rec0.y) {
-                aggregate(C, col, eattr, rec0.y, rec0.z, rp[1], rp[2], rp[3], H, ld_h, R, S.vid_mod, kpt, a_row, lane);
+                aggregate(C, col, eattr, rec0.y, rec0.z, rp[1], rp[2], rp[3], H, ld_h, R, vid_mod, kpt, a_row, lane);
             } else {
                 for (int cc = lane; cc < H4; cc += 64)
                     *reinterpret_cast<float4*>(a_row + apad(4 * cc, kpt)) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -309,7 +306,7 @@ __global__ void __launch_bounds__(FT, MINW) frontier_step_kernel(const int32_t* 
         }
     }
     __syncthreads();
-    if (prof) stamp[2] = wall_clock64();
+    if (stamp) stamp[2] = wall_clock64();
 
     // gate inputs that do not depend on the GEMV: issue now, consume in phase C
     const int gr_ = tid / JS, gj_ = tid - gr_ * JS;   // gate thread -> (row, unit of the slice)
@@ -332,7 +329,7 @@ __global__ void __launch_bounds__(FT, MINW) frontier_step_kernel(const int32_t* 
         const int kbase = ksl * kpt + 4 * ksl;  // == apad(ksl * kpt, kpt)
         for (int ch = 0; ch < nchunk; ++ch) {
             const int n = min(KW, kpt - ch * KW);
-            if (ch > 0) {
+            if (ch > 0) {  // never taken when RESIDENT (the host only uses it for kpt <= KW)
 #pragma unroll
                 for (int kk = 0; kk < KW; ++kk) {
                     if (kk < n) {
@@ -344,7 +341,7 @@ __global__ void __launch_bounds__(FT, MINW) frontier_step_kernel(const int32_t* 
             if (has_pred) fma_rows<RBT, KW>(acc_h, wh, a_s, op_ld, kbase + ch * KW, n);
             if (has_in) fma_rows<RBT, KW>(acc_i, wi, u_s, op_ld, kbase + ch * KW, n);
         }
-        if (prof) stamp[3] = wall_clock64();
+        if (stamp) stamp[3] = wall_clock64();
 #pragma unroll
         for (int r = 0; r < RBT; ++r) {
             if (has_pred) { acc_h[r].x = dpp_row_sum16(acc_h[r].x); acc_h[r].y = dpp_row_sum16(acc_h[r].y);
@@ -362,11 +359,11 @@ __global__ void __launch_bounds__(FT, MINW) frontier_step_kernel(const int32_t* 
         }
     }
     __syncthreads();
-    if (prof) stamp[4] = wall_clock64();
+    if (stamp) stamp[4] = wall_clock64();
 
     // ---- phase C: gates for RBT rows x JS units
     if (tid < RBT * JS) {
-        float sp = 0.f;
+        float sp = 0.f, hv = 0.f;
         if (gate_thread) {
             const float gr = pre_r + (has_in ? gi_s[gr_ * SW + gj_] : 0.f);
             const float gz = pre_z + (has_in ? gi_s[gr_ * SW + JS + gj_] : 0.f);
@@ -378,15 +375,137 @@ __global__ void __launch_bounds__(FT, MINW) frontier_step_kernel(const int32_t* 
             const float rg = sigm(gr + hr);
             const float zg = sigm(gz + hz);
             const float ng = tanhf(fmaf(rg, hn, gn));
-            const float hv = fmaf(zg, a - ng, ng);  // n + z * (a - n)
-            C.h_out[(int64_t)gv * ld_h + j] = hv;
+            hv = fmaf(zg, a - ng, ng);  // n + z * (a - n)
             sp = wk * hv;
         }
         // partial score of every 16-unit group (16 = one DPP row): summed by the consumers
         sp = dpp_row_sum16(sp);
-        if (gate_thread && (tid & 15) == 15) C.h_out[(int64_t)gv * ld_h + H + (j >> 4)] = sp;
+        if (gate_thread) {
+            float* po = C.h_out + (int64_t)gv * ld_h;
+            if (RESIDENT) {  // publish to the other workgroups of this launch: write-through (sc1) stores
+                __hip_atomic_store(po + j, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((tid & 15) == 15)
+                    __hip_atomic_store(po + H + (j >> 4), sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                po[j] = hv;
+                if ((tid & 15) == 15) po[H + (j >> 4)] = sp;
+            }
+        }
     }
-    if (prof) { stamp[5] = wall_clock64(); stamp[6] = gridDim.x; }
+    if (stamp) stamp[5] = wall_clock64();
+}
+
+// ---- launch-per-layer kernel: one launch = one batch-level topological layer, all cells
+template <int JS, int RBT, int KW, int MINW>
+__global__ void __launch_bounds__(FT, MINW) frontier_step_kernel(const int32_t* __restrict__ plan, PlanLayout L, StepArgs S) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const bool prof = S.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    unsigned long long* stamp = prof ? S.dbg + 8 * (int64_t)S.step : nullptr;
+    if (prof) stamp[0] = wall_clock64();
+    const int NS = S.H / JS;
+    const int sl = blockIdx.x % NS;
+    const int gb = blockIdx.x / NS;
+    int c = 0;
+    while (c + 1 < S.ncell && gb >= S.blk_start[c + 1]) ++c;
+    const Cell& C = S.cell[c];
+    const int slot0 = C.row_base + (gb - S.blk_start[c]) * RBT;
+    const int nr = min(RBT, C.row_end - slot0);
+    const int d = C.dir;
+    float4 wh[KW], wi[KW];
+    process_block<JS, RBT, KW, false>(plan, L.rowrec[d], L.col[d], L.eattr[d], C, C.has_pred != 0, slot0, nr, sl, S.H,
+                                      S.ld_h, S.R, S.vid_mod, smem, wh, wi, stamp);
+    if (prof) stamp[6] = gridDim.x;
+}
+
+// ---- persistent tail kernel: ONE launch walks all remaining layers.
+// The tail of the schedule is hundreds of dependent layers with a handful of rows each; a launch
+// boundary (~3 us) + kernarg fetch + weight reload per layer is most of their cost.  Here every
+// workgroup owns (cell, slice, replica) for the whole tail, keeps its weight slice in registers,
+// and the workgroups meet at one counter per layer.  Visibility of the rows they exchange:
+//   producer: write-through (sc1) stores -> every storing wave s_waitcnt vmcnt(0) -> workgroup
+//   barrier -> one relaxed agent-scope atomic add on the layer's counter;
+//   consumer: one lane polls that counter with relaxed agent-scope loads, then a workgroup barrier.
+//   State rows are padded to whole 128-byte lines and every row is written before it is first
+//   read by anyone in this launch, so no cache anywhere can hold a stale copy of its lines: the
+//   consumers use plain loads.  Nothing depends on where a workgroup runs.  The grid is far below
+//   the CU count (all workgroups co-resident); every spin is bounded and reports through err_flag.
+struct TailArgs {
+    Cell cell[DAGNN_MAX_CELLS];
+    int stacked_idx[DAGNN_MAX_CELLS];  // i of each cell (layer processed at step s is s - i)
+    int ncell, nrep, H, ld_h, R, vid_mod;
+    int s_begin, s_end;                // steps [s_begin, s_end)
+    int* counters;                     // [s_end] zeroed before the launch; counters[s_end] = error flag
+    unsigned long long* dbg;
+};
+
+template <int JS, int RBT, int KW>
+__global__ void __launch_bounds__(FT, 1) frontier_tail_kernel(const int32_t* __restrict__ plan, PlanLayout L, TailArgs S) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NCW = 3 * JS / 16;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NS = S.H / JS;
+    const int sl = blockIdx.x % NS;
+    const int rep = (blockIdx.x / NS) % S.nrep;
+    const int c = blockIdx.x / (NS * S.nrep);
+    const Cell& C = S.cell[c];
+    const int d = C.dir, si = S.stacked_idx[c];
+    const int N = plan[PH_N];
+    const int32_t* __restrict__ blptr = plan + L.blptr[d];
+    const int T = blptr[N + 1];
+    const bool has_in = C.wih != nullptr;
+    const int kpt = S.H >> 4;
+    const bool prof = S.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+
+    // resident weights: the whole slice (kpt <= KW, checked by the host)
+    float4 wh[KW], wi[KW];
+    {
+        const int64_t wstride = (int64_t)NCW * 64;
+        const float4* whh = C.whh + (int64_t)sl * kpt * wstride + tid;
+        const float4* wih = has_in ? C.wih + (int64_t)sl * kpt * wstride + tid : nullptr;
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk) {
+            wh[kk] = make_float4(0.f, 0.f, 0.f, 0.f);
+            wi[kk] = wh[kk];
+            if (wave < NCW && kk < kpt) {
+                wh[kk] = whh[kk * wstride];
+                if (has_in) wi[kk] = wih[kk * wstride];
+            }
+        }
+    }
+    const int nwg = gridDim.x;
+    for (int s = S.s_begin; s < S.s_end; ++s) {
+        unsigned long long* stamp = prof ? S.dbg + 8 * (int64_t)s : nullptr;
+        if (prof) stamp[0] = wall_clock64();
+        const int t = s - si;
+        if (t >= 0 && t < T) {
+            const int r0 = blptr[t], r1 = blptr[t + 1];
+            const int nblk = (r1 - r0 + RBT - 1) / RBT;
+            for (int rb = rep; rb < nblk; rb += S.nrep) {
+                const int slot0 = r0 + rb * RBT;
+                process_block<JS, RBT, KW, true>(plan, L.rowrec[d], L.col[d], L.eattr[d], C, t > 0, slot0,
+                                                 min(RBT, r1 - slot0), sl, S.H, S.ld_h, S.R, S.vid_mod, smem, wh, wi,
+                                                 stamp);
+                __syncthreads();  // LDS is reused by the next block
+            }
+        }
+        // ---- layer barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have left
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(S.counters + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(S.counters + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) {  // ~seconds: never hang the device
+                    __hip_atomic_store(S.counters + S.s_end, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (prof) { stamp[6] = wall_clock64(); stamp[7] = gridDim.x; }
+    }
 }
 
 // Pack W [3H, K] (torch GRUCell layout: row g*H + j, K contiguous) into slice / lane order for
@@ -421,7 +540,8 @@ template <int JS, int RBT, int KW, int MINW>
 hipError_t launch_step(int blocks, int H, hipStream_t st, const int32_t* plan, const PlanLayout& L, const StepArgs& S) {
     const int op_ld = H + 64;
     const size_t lds = (size_t)(2 * RBT * op_ld + 2 * RBT * 3 * JS) * sizeof(float) + RBT * sizeof(int);
-    hipLaunchKernelGGL((frontier_step_kernel<JS, RBT, KW, MINW>), dim3((unsigned)(blocks * (H / JS))), dim3(FT), lds, st, plan, L, S);
+    hipLaunchKernelGGL((frontier_step_kernel<JS, RBT, KW, MINW>), dim3((unsigned)(blocks * (H / JS))), dim3(FT), lds,
+                       st, plan, L, S);
     return hipGetLastError();
 }
 
@@ -437,6 +557,19 @@ extern "C" int dagnn_pack_slices(const float* w, float* out, int H, int K, int s
                        reinterpret_cast<float4*>(out), H, K, slice_units, total);
     DAGNN_CHECK_LAUNCH();
     return DAGNN_OK;
+}
+
+static void fill_cell(Cell& K, const dagnn_frontier_args* a, const dagnn_plan* pl, int d, int i, int js) {
+    const dagnn_frontier_cell& c = a->cell[d][i];
+    K.whh = (const float4*)(js == 16 ? c.w_hh_pk16 : c.w_hh_pk32);
+    K.wih = i > 0 ? (const float4*)(js == 16 ? c.w_ih_pk16 : c.w_ih_pk32) : nullptr;
+    K.bhh = c.b_hh; K.bih = c.b_ih; K.wkey = c.w_key;
+    K.gain = pl->num_edge_feats > 0 ? c.edge_gain : nullptr;
+    K.vid = a->vid_mod > 0 ? c.vid_bias : nullptr;
+    K.gi0 = i == 0 ? c.gi0 : nullptr;
+    K.h_in = i > 0 ? a->cell[d][i - 1].h_out : nullptr;
+    K.h_out = c.h_out;
+    K.dir = d; K.row_base = 0; K.row_end = 0; K.has_pred = 0;
 }
 
 extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_args* a, const int32_t* const* layer_ptr,
@@ -461,24 +594,49 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         }
     }
     PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t* plan = (const int32_t*)pl->data;
+    const int nsteps = Tmax + Ls - 1;
+
+    auto rows_of = [&](int d, int i, int s) {
+        const int t = s - i;
+        return (t < 0 || t >= num_layers[d]) ? 0 : layer_ptr[d][t + 1] - layer_ptr[d][t];
+    };
+
+    // ---- where the persistent tail starts: the first step after which no cell ever has more rows
+    // than its replicas cover in `tail_max_blocks` blocks of 8.  Needs the whole slice in registers
+    // (H <= 256), line-aligned state rows (ld_h % 32 == 0) and a sync workspace.
+    int s_tail = nsteps;
+    const int tail_js = 32, tail_rb = 8;
+    int nrep = a->tail_replicas > 0 ? a->tail_replicas : 0;
+    const int tail_wgs = ndir * Ls * (H / tail_js) * (nrep > 0 ? nrep : 1);
+    const bool tail_ok = nrep > 0 && a->tail_sync && H <= 256 && (a->ld_h % 32) == 0 && tail_wgs <= a->num_cus / 2 &&
+                         a->tail_sync_words >= nsteps + 1;
+    if (tail_ok) {
+        const int cap = tail_rb * nrep * (a->tail_max_blocks > 0 ? a->tail_max_blocks : 1);
+        s_tail = 0;
+        for (int s = nsteps - 1; s >= 0; --s) {
+            int mx = 0;
+            for (int q = 0; q < ndir; ++q)
+                for (int i = 0; i < Ls; ++i) mx = mx > rows_of(dirs[q], i, s) ? mx : rows_of(dirs[q], i, s);
+            if (mx > cap) { s_tail = s + 1; break; }
+        }
+        if (nsteps - s_tail < 8) s_tail = nsteps;  // not worth a second kernel
+    }
+
     StepArgs S;
     S.H = H; S.ld_h = a->ld_h; S.R = pl->num_edge_feats; S.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
     S.dbg = (unsigned long long*)a->debug_timing;
-    hipStream_t st = (hipStream_t)stream;
-    const int32_t* plan = (const int32_t*)pl->data;
-    for (int s = 0; s < Tmax + Ls - 1; ++s) {
+    for (int s = 0; s < s_tail; ++s) {
         // geometry of this launch: thin launches use 16-unit slices (and 4-row blocks when that
-        // still fits one wave of workgroups), fat ones 32-unit slices and 8-row blocks
+        // still fits one round of workgroups), fat ones 32-unit slices, 8-row blocks, 2 per CU
         int rows_total = 0, blocks8 = 0, blocks4 = 0;
         for (int q = 0; q < ndir; ++q)
             for (int i = 0; i < Ls; ++i) {
-                const int t = s - i, d = dirs[q];
-                if (t < 0 || t >= num_layers[d]) continue;
-                const int n = layer_ptr[d][t + 1] - layer_ptr[d][t];
+                const int n = rows_of(dirs[q], i, s);
                 rows_total += n; blocks8 += (n + 7) / 8; blocks4 += (n + 3) / 4;
             }
         if (rows_total == 0) continue;
-        // one workgroup per CU is resident (6 waves, ~230 VGPRs): never spill slightly over one round
         int js, rb;
         if (blocks4 * (H / 16) <= a->num_cus) { js = 16; rb = 4; }
         else if (blocks8 * (H / 16) <= a->num_cus) { js = 16; rb = 8; }
@@ -488,22 +646,12 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         for (int q = 0; q < ndir; ++q) {
             const int d = dirs[q];
             for (int i = 0; i < Ls; ++i) {
-                const int t = s - i;
-                if (t < 0 || t >= num_layers[d]) continue;
-                const int r0 = layer_ptr[d][t], r1 = layer_ptr[d][t + 1];
-                if (r1 <= r0) continue;
-                const dagnn_frontier_cell& c = a->cell[d][i];
+                const int n = rows_of(d, i, s);
+                if (n <= 0) continue;
                 Cell& K = S.cell[nc];
-                K.whh = (const float4*)(js == 16 ? c.w_hh_pk16 : c.w_hh_pk32);
-                K.wih = i > 0 ? (const float4*)(js == 16 ? c.w_ih_pk16 : c.w_ih_pk32) : nullptr;
-                K.bhh = c.b_hh; K.bih = c.b_ih; K.wkey = c.w_key;
-                K.gain = pl->num_edge_feats > 0 ? c.edge_gain : nullptr;
-                K.vid = a->vid_mod > 0 ? c.vid_bias : nullptr;
-                K.gi0 = i == 0 ? c.gi0 : nullptr;
-                K.h_in = i > 0 ? a->cell[d][i - 1].h_out : nullptr;
-                K.h_out = c.h_out;
-                K.dir = d; K.row_base = r0; K.row_end = r1; K.has_pred = t > 0;
-                blocks += (r1 - r0 + rb - 1) / rb;
+                fill_cell(K, a, pl, d, i, js);
+                K.row_base = layer_ptr[d][s - i]; K.row_end = K.row_base + n; K.has_pred = (s - i) > 0;
+                blocks += (n + rb - 1) / rb;
                 S.blk_start[++nc] = blocks;
             }
         }
@@ -513,6 +661,27 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         if (js == 32) e = launch_step<32, 8, 4, 3>(blocks, H, st, plan, L, S);
         else if (rb == 4) e = launch_step<16, 4, 16, 1>(blocks, H, st, plan, L, S);
         else e = launch_step<16, 8, 16, 1>(blocks, H, st, plan, L, S);
+        if (e != hipSuccess) return DAGNN_EHIP(e);
+    }
+    if (s_tail < nsteps) {
+        TailArgs T;
+        int nc = 0;
+        for (int q = 0; q < ndir; ++q)
+            for (int i = 0; i < Ls; ++i) {
+                fill_cell(T.cell[nc], a, pl, dirs[q], i, tail_js);
+                T.stacked_idx[nc++] = i;
+            }
+        T.ncell = nc; T.nrep = nrep; T.H = H; T.ld_h = a->ld_h; T.R = pl->num_edge_feats;
+        T.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
+        T.s_begin = s_tail; T.s_end = nsteps;
+        T.counters = (int*)a->tail_sync;
+        T.dbg = (unsigned long long*)a->debug_timing;
+        hipError_t e = hipMemsetAsync(a->tail_sync, 0, (size_t)(nsteps + 1) * sizeof(int), st);
+        if (e != hipSuccess) return DAGNN_EHIP(e);
+        const int op_ld = H + 64;
+        const size_t lds = (size_t)(2 * tail_rb * op_ld + 2 * tail_rb * 3 * tail_js) * sizeof(float) + tail_rb * sizeof(int);
+        hipLaunchKernelGGL((frontier_tail_kernel<32, 8, 16>), dim3((unsigned)tail_wgs), dim3(FT), lds, st, plan, L, T);
+        e = hipGetLastError();
         if (e != hipSuccess) return DAGNN_EHIP(e);
     }
     return DAGNN_OK;

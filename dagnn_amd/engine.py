@@ -53,6 +53,8 @@ class _NoSpan(object):
 
 
 TIMER: Optional[KernelTimer] = None  # set by bench.py around its timed region
+TAIL_REPLICAS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_REPLICAS", "2"))   # 0 = launch every layer
+TAIL_MAX_BLOCKS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_MAX_BLOCKS", "4"))
 DEBUG_TIMING: Optional[torch.Tensor] = None  # int64[8] device tensor: phase ticks of the deepest work item
 _NOSPAN = _NoSpan()
 
@@ -201,8 +203,9 @@ def pack_slices(w: torch.Tensor, H: int, slice_units: int) -> torch.Tensor:
 
 
 def frontier_ld(H: int) -> int:
-    """Row pitch of the lock-step state buffers: H states + H/16 partial scores, 16-byte multiple."""
-    return H + (H // 16 + 3) // 4 * 4
+    """Row pitch of the lock-step state buffers: H states + H/16 partial scores, padded to whole 128-byte
+    lines (no two rows share a cache line: the persistent tail kernel relies on it)."""
+    return (H + H // 16 + 31) // 32 * 32
 
 
 def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0, h, vid_mod: int = 0) -> None:
@@ -226,6 +229,10 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     args.num_stacked, args.dir_mask, args.H, args.ld_h, args.vid_mod = L, mask, H, h[dirs[0]][0].shape[1], int(vid_mod)
     args.debug_timing = DEBUG_TIMING.data_ptr() if DEBUG_TIMING is not None else None
     args.num_cus = torch.cuda.get_device_properties(plan.ws.device).multi_processor_count
+    nsteps = max(len(sched[0]), len(sched[1])) - 1 + L
+    plan.tail_sync = torch.empty(nsteps + 8, dtype=torch.int32, device=plan.ws.device)
+    args.tail_replicas, args.tail_max_blocks = TAIL_REPLICAS, TAIL_MAX_BLOCKS
+    args.tail_sync, args.tail_sync_words = plan.tail_sync.data_ptr(), nsteps + 8
     ptrs = (C.POINTER(C.c_int32) * 2)()
     nl = (C.c_int32 * 2)()
     for d in (0, 1):

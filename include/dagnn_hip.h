@@ -185,6 +185,11 @@ typedef struct dagnn_frontier_args {
     int dir_mask;
     int H, ld_h, vid_mod;
     int num_cus;     /* compute units of the device (launch geometry heuristic), e.g. 256 */
+    /* persistent tail (one launch for all layers after the fat head; needs H <= 256 and ld_h % 32 == 0): */
+    int tail_replicas;   /* workgroups per (cell, slice) in the tail kernel; 0 disables it */
+    int tail_max_blocks; /* a layer may have up to 8 * tail_replicas * tail_max_blocks rows per cell in the tail */
+    void* tail_sync;     /* device int32[tail_sync_words] scratch (layer counters; last used word = error flag) */
+    int tail_sync_words; /* >= T + L */
     void* debug_timing; /* NULL, or (T+L-1)*8 uint64 device words: 100 MHz stamps of workgroup 0 per launch */
 } dagnn_frontier_args;
 

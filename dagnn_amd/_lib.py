@@ -44,14 +44,15 @@ MAX_STACKED = 8
 class FrontierCell(C.Structure):
     _fields_ = [("w_hh_pk16", C.c_void_p), ("w_hh_pk32", C.c_void_p), ("w_ih_pk16", C.c_void_p),
                 ("w_ih_pk32", C.c_void_p), ("b_hh", C.c_void_p), ("b_ih", C.c_void_p), ("w_key", C.c_void_p),
-                ("edge_gain", C.c_void_p), ("vid_bias", C.c_void_p), ("gi0", C.c_void_p), ("h_out", C.c_void_p)]
+                ("edge_gain", C.c_void_p), ("vid_bias", C.c_void_p), ("gi0", C.c_void_p), ("h_out", C.c_void_p),
+                ("granules", C.c_void_p)]
 
 
 class FrontierArgs(C.Structure):
     _fields_ = [("cell", (FrontierCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
                 ("H", C.c_int), ("ld_h", C.c_int), ("vid_mod", C.c_int), ("num_cus", C.c_int),
-                ("tail_replicas", C.c_int), ("tail_max_blocks", C.c_int), ("tail_sync", C.c_void_p),
-                ("tail_sync_words", C.c_int), ("debug_timing", C.c_void_p)]
+                ("tail_replicas", C.c_int), ("tail_max_blocks", C.c_int), ("epoch", C.c_uint),
+                ("tail_err", C.c_void_p), ("debug_timing", C.c_void_p)]
 
 
 # every symbol include/dagnn_hip.h declares: (restype, argtypes)

@@ -106,7 +106,8 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
 
 
 def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tuple[int, int], CellParams],
-                       dirs: Sequence[int], L: int, H: int, vid_nodes: int = 0) -> List[List[torch.Tensor]]:
+                       dirs: Sequence[int], L: int, H: int, vid_nodes: int = 0,
+                       arena: Optional[engine.GranuleArena] = None) -> List[List[torch.Tensor]]:
     """Lock-step schedule (default): one batched input GEMM for stacked layer 0 of every direction,
     then T + L - 1 frontier launches covering all cells (csrc/frontier.hip)."""
     Hp = cells[(dirs[0], 0)].Hp
@@ -118,16 +119,16 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
     ld = engine.frontier_ld(Hp)  # state rows carry their H/16 partial attention scores behind the states
     h = [[torch.empty(N, ld, dtype=torch.float32, device=dev) if d in dirs else None for _ in range(L)]
          for d in range(2)]
-    engine.frontier_run(plan, dirs, L, Hp, cells, gi, h, vid_mod=vid_nodes)
+    engine.frontier_run(plan, dirs, L, Hp, cells, gi, h, vid_mod=vid_nodes, arena=arena)
     return [[h[d][i][:, :H] if h[d][i] is not None else None for i in range(L)] for d in range(2)]
 
 
 def run_stack(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tuple[int, int], CellParams],
               dirs: Sequence[int], L: int, H: int, vid_nodes: int = 0,
-              schedule: str = "pergraph") -> List[List[torch.Tensor]]:
+              schedule: str = "pergraph", arena: Optional[engine.GranuleArena] = None) -> List[List[torch.Tensor]]:
     """Hidden states h[d][i] ([N, H] each) of all stacked layers and directions."""
     if schedule == "lockstep":
-        return run_stack_lockstep(plan, x, cells, dirs, L, H, vid_nodes)
+        return run_stack_lockstep(plan, x, cells, dirs, L, H, vid_nodes, arena)
     Hp = round_up4(H)
     N = x.shape[0]
     dev = x.device

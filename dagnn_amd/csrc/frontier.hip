@@ -49,6 +49,8 @@ struct Cell {
     const float* gi0;    // [N,3H] precomputed input side (stacked layer 0) or null
     const float* h_in;   // [N,ld_h] lower stacked layer (with wih) or null
     float* h_out;        // [N,ld_h]: H state floats + H/16 partial scores per row
+    unsigned long long* g_out;        // [N,gld] {epoch tag, fp32 bits} granules of h_out rows + parts, or null
+    const unsigned long long* g_in;   // granules of h_in, or null
     int dir;             // direction (selects the plan arrays)
     int row_base;        // first rowrec slot of the layer processed in this launch
     int row_end;         // one past the last
@@ -59,6 +61,7 @@ struct StepArgs {
     Cell cell[DAGNN_MAX_CELLS];
     int blk_start[DAGNN_MAX_CELLS + 1];  // row-block prefix sums over the active cells
     int ncell, H, ld_h, R, vid_mod, step;
+    unsigned epoch;           // tag of this forward pass in the granule copies (never 0)
     unsigned long long* dbg;  // optional [steps][8] wall_clock64 stamps of workgroup 0
 };
 
@@ -90,15 +93,64 @@ __device__ __forceinline__ float score_of(const float* __restrict__ hrow_tail, i
     return s;
 }
 
+// ---- granules: the hand-off format inside the persistent tail kernel ---------------------------
+// Every state float (and partial score) also exists as an 8-byte {tag = epoch of this forward pass,
+// value} granule written by ONE aligned 8-byte store.  A consumer re-reads the granules it needs
+// with relaxed agent-scope loads (they bypass the non-coherent caches) until every tag matches:
+// the data is its own flag, there is no barrier, no fence and no dependence on placement
+// (cdna_hip_programming.md Guideline 16, form R2).  Old tags never equal the current epoch because
+// the buffers are zero-initialised once and the epoch only grows.
+typedef unsigned long long gran_t;
+__device__ __forceinline__ gran_t gran_pack(unsigned epoch, float v) {
+    return ((gran_t)epoch << 32) | (gran_t)__float_as_uint(v);
+}
+__device__ __forceinline__ gran_t gran_ld(const gran_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct GranCtx { unsigned epoch; int* err; };
+
+// bounded spin helper: returns false (and raises the error flag) when the budget is exhausted
+__device__ __forceinline__ bool gran_retry(unsigned& spins, const GranCtx& G) {
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > (1u << 22)) {
+        __hip_atomic_store(G.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    }
+    return true;
+}
+
+// One wave: float4 chunk `lane` of granule row `grow` (H <= 256: one chunk per lane), waiting for it.
+__device__ __forceinline__ float4 gran_row_chunk(const gran_t* grow, int lane, int H4, const GranCtx& G) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned spins = 0;
+    for (;;) {
+        bool ok = true;
+        if (lane < H4) {
+            const gran_t x0 = gran_ld(grow + 4 * lane), x1 = gran_ld(grow + 4 * lane + 1),
+                         x2 = gran_ld(grow + 4 * lane + 2), x3 = gran_ld(grow + 4 * lane + 3);
+            ok = (unsigned)(x0 >> 32) == G.epoch && (unsigned)(x1 >> 32) == G.epoch &&
+                 (unsigned)(x2 >> 32) == G.epoch && (unsigned)(x3 >> 32) == G.epoch;
+            v = make_float4(__uint_as_float((unsigned)x0), __uint_as_float((unsigned)x1),
+                            __uint_as_float((unsigned)x2), __uint_as_float((unsigned)x3));
+        }
+        if (__all(ok) || !gran_retry(spins, G)) break;
+    }
+    return v;
+}
+
 // One wave: a_row[:] = sum_e alpha_e * h[pred_e, :] with alpha = softmax_e(score[pred_e] + gain . feat_e)
 // (PyG: exp(x - max) / (sum + 1e-16)).  rec1 = first four predecessors, rec2/rec3 = their edge features.
+// GRAN: predecessor rows and scores are read (and waited for) through their granule copies.
+template <bool GRAN>
 __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restrict__ col,
                                           const float* __restrict__ eattr, int eb, int ee, int4 rec1, int4 rec2,
                                           int4 rec3, int H, int ld_h, int R, int vid_mod, int kpt, float* a_row,
-                                          int lane) {
+                                          int lane, const GranCtx& G) {
     const int H4 = H >> 2;
     const int nparts = H / PU;
+    const int gld = H + nparts;
     const float* hsrc = C.h_out;  // predecessors' states of THIS stacked layer (earlier launches)
+    const gran_t* gsrc = C.g_out;
     const int deg = ee - eb;
     if (deg <= 4 && R <= 2) {
         // ---- inline path: predecessor ids and edge features came with the row record
@@ -106,20 +158,61 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
         const float f0[4] = {__int_as_float(rec2.x), __int_as_float(rec2.z), __int_as_float(rec3.x), __int_as_float(rec3.z)};
         const float f1[4] = {__int_as_float(rec2.y), __int_as_float(rec2.w), __int_as_float(rec3.y), __int_as_float(rec3.w)};
         float al[4] = {1.f, 0.f, 0.f, 0.f};
-        // first 64 float4 columns of every predecessor row: issued before the scores are touched so
-        // that rows and scores share one memory round trip
         float4 row0[4];
+        float sc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (GRAN) {
+            // rows and score parts of all <= 4 predecessors in ONE polling loop (one round trip when ready)
+            float pv[4] = {0.f, 0.f, 0.f, 0.f};
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            row0[e] = (e < deg && lane < H4) ? reinterpret_cast<const float4*>(hsrc + (int64_t)pj[e] * ld_h)[lane]
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int e = 0; e < 4; ++e) {
+                    row0[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e < deg) {
+                        const gran_t* grow = gsrc + (int64_t)pj[e] * gld;
+                        if (lane < H4) {
+                            const gran_t x0 = gran_ld(grow + 4 * lane), x1 = gran_ld(grow + 4 * lane + 1),
+                                         x2 = gran_ld(grow + 4 * lane + 2), x3 = gran_ld(grow + 4 * lane + 3);
+                            ok = ok && (unsigned)(x0 >> 32) == G.epoch && (unsigned)(x1 >> 32) == G.epoch &&
+                                 (unsigned)(x2 >> 32) == G.epoch && (unsigned)(x3 >> 32) == G.epoch;
+                            row0[e] = make_float4(__uint_as_float((unsigned)x0), __uint_as_float((unsigned)x1),
+                                                  __uint_as_float((unsigned)x2), __uint_as_float((unsigned)x3));
+                        }
+                        if (deg > 1 && lane < nparts) {
+                            const gran_t x = gran_ld(grow + H + lane);
+                            ok = ok && (unsigned)(x >> 32) == G.epoch;
+                            pv[e] = __uint_as_float((unsigned)x);
+                        }
+                    }
+                }
+                if (__all(ok) || !gran_retry(spins, G)) break;
+            }
+            if (deg > 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < deg) for (int q = 0; q < nparts; ++q) sc[e] += __shfl(pv[e], q, 64);  // index order
+            }
+        } else {
+            // first 64 float4 columns of every predecessor row: issued before the scores are touched so
+            // that rows and scores share one memory round trip
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                row0[e] = (e < deg && lane < H4) ? reinterpret_cast<const float4*>(hsrc + (int64_t)pj[e] * ld_h)[lane]
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (deg > 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < deg) sc[e] = score_of(hsrc + (int64_t)pj[e] * ld_h + H, nparts);
+            }
+        }
         if (deg > 1) {
             float lg[4], mx = -INFINITY;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 lg[e] = -INFINITY;
                 if (e < deg) {
-                    float s = score_of(hsrc + (int64_t)pj[e] * ld_h + H, nparts);
+                    float s = sc[e];
                     if (C.vid) s += C.vid[pj[e] % vid_mod];
                     if (R >= 1) s = fmaf(C.gain[0], f0[e], s);
                     if (R >= 2) s = fmaf(C.gain[1], f1[e], s);
@@ -140,18 +233,35 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
             for (int e = 0; e < 4; ++e) fma4(acc, al[e], row0[e]);  // al[e] == 0 and row0[e] == 0 beyond deg
             *reinterpret_cast<float4*>(a_row + apad(4 * lane, kpt)) = acc;
         }
-        for (int c = lane + 64; c < H4; c += 64) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!GRAN) {
+            for (int c = lane + 64; c < H4; c += 64) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (e < deg) fma4(acc, al[e], reinterpret_cast<const float4*>(hsrc + (int64_t)pj[e] * ld_h)[c]);
-            *reinterpret_cast<float4*>(a_row + apad(4 * c, kpt)) = acc;
+                for (int e = 0; e < 4; ++e)
+                    if (e < deg) fma4(acc, al[e], reinterpret_cast<const float4*>(hsrc + (int64_t)pj[e] * ld_h)[c]);
+                *reinterpret_cast<float4*>(a_row + apad(4 * c, kpt)) = acc;
+            }
         }
         return;
     }
-    // ---- general path (fan-in > 4): lanes own edges, three passes over the edge list
+    // ---- general path (fan-in > 4): lanes own edges
     auto logit = [&](int e, int cj) {
-        float s = score_of(hsrc + (int64_t)cj * ld_h + H, nparts);
+        float s = 0.f;
+        if (GRAN) {  // this lane's predecessor: its H/16 part granules, summed in index order
+            const gran_t* gp = gsrc + (int64_t)cj * gld + H;
+            for (int q = 0; q < nparts; ++q) {
+                gran_t x = gran_ld(gp + q);
+                unsigned spins = 0;
+                while ((unsigned)(x >> 32) != G.epoch) {  // per-lane wait: producers never wait on us
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1u << 22)) { __hip_atomic_store(G.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    x = gran_ld(gp + q);
+                }
+                s += __uint_as_float((unsigned)x);
+            }
+        } else {
+            s = score_of(hsrc + (int64_t)cj * ld_h + H, nparts);
+        }
         if (C.vid) s += C.vid[cj % vid_mod];
         for (int r = 0; r < R; ++r) s = fmaf(C.gain[r], eattr[(int64_t)e * R + r], s);
         return s;
@@ -183,21 +293,24 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
             }
             const int cnt = min(64, ee - base);
             int i = 0;
-            for (; i + 4 <= cnt; i += 4) {  // four row loads in flight per lane
-                float4 v[4]; float a4[4];
+            if (!GRAN) {
+                for (; i + 4 <= cnt; i += 4) {  // four row loads in flight per lane
+                    float4 v[4]; float a4[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    a4[u] = __shfl(my_alpha, i + u, 64);
-                    const int cj = __shfl(my_col, i + u, 64);
-                    v[u] = c < H4 ? reinterpret_cast<const float4*>(hsrc + (int64_t)cj * ld_h)[c] : make_float4(0, 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) {
+                        a4[u] = __shfl(my_alpha, i + u, 64);
+                        const int cj = __shfl(my_col, i + u, 64);
+                        v[u] = c < H4 ? reinterpret_cast<const float4*>(hsrc + (int64_t)cj * ld_h)[c] : make_float4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) fma4(acc, a4[u], v[u]);
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) fma4(acc, a4[u], v[u]);
             }
             for (; i < cnt; ++i) {
                 const float a1 = __shfl(my_alpha, i, 64);
                 const int cj = __shfl(my_col, i, 64);
-                if (c < H4) fma4(acc, a1, reinterpret_cast<const float4*>(hsrc + (int64_t)cj * ld_h)[c]);
+                if (GRAN) fma4(acc, a1, gran_row_chunk(gsrc + (int64_t)cj * gld, lane, H4, G));
+                else if (c < H4) fma4(acc, a1, reinterpret_cast<const float4*>(hsrc + (int64_t)cj * ld_h)[c]);
             }
         }
         if (c < H4) *reinterpret_cast<float4*>(a_row + apad(4 * c, kpt)) = acc;
@@ -236,7 +349,8 @@ template <int JS, int RBT, int KW, bool RESIDENT>
 __device__ __forceinline__ void process_block(const int32_t* __restrict__ plan, int64_t rowrec_off, int64_t col_off,
                                               int64_t eattr_off, const Cell& C, bool has_pred, int slot0, int nr,
                                               int sl, int H, int ld_h, int Rfeat, int vid_mod, float* smem,
-                                              float4 (&wh)[KW], float4 (&wi)[KW], unsigned long long* stamp) {
+                                              float4 (&wh)[KW], float4 (&wi)[KW], unsigned long long* stamp,
+                                              const GranCtx& G) {
     constexpr int NCW = 3 * JS / 16;   // waves that own weight columns (4 column groups each)
     constexpr int SW = 3 * JS;         // slice width in columns
     const int tid = threadIdx.x, lane = tid & 63;
@@ -289,11 +403,18 @@ __device__ __forceinline__ void process_block(const int32_t* __restrict__ plan, 
             const int4 rec0 = r == wave ? rec_first : rp[0];
             if (lane == 0) v_s[r] = rec0.x;
             if (has_in) {
-                const float4* ur = reinterpret_cast<const float4*>(C.h_in + (int64_t)rec0.x * ld_h);
-                for (int cc = lane; cc < H4; cc += 64) *reinterpret_cast<float4*>(u_row + apad(4 * cc, kpt)) = ur[cc];
+                if (RESIDENT) {  // produced one step ago by another workgroup of this launch: wait on its granules
+                    const float4 uv = gran_row_chunk(C.g_in + (int64_t)rec0.x * (H + H / PU), lane, H4, G);
+                    if (lane < H4) *reinterpret_cast<float4*>(u_row + apad(4 * lane, kpt)) = uv;
+                } else {
+                    const float4* ur = reinterpret_cast<const float4*>(C.h_in + (int64_t)rec0.x * ld_h);
+                    for (int cc = lane; cc < H4; cc += 64)
+                        *reinterpret_cast<float4*>(u_row + apad(4 * cc, kpt)) = ur[cc];
+                }
             }
             if (has_pred && rec0.z > rec0.y) {
-                aggregate(C, col, eattr, rec0.y, rec0.z, rp[1], rp[2], rp[3], H, ld_h, R, vid_mod, kpt, a_row, lane);
+                aggregate<RESIDENT>(C, col, eattr, rec0.y, rec0.z, rp[1], rp[2], rp[3], H, ld_h, R, vid_mod, kpt, a_row,
+                                    lane, G);
             } else {
                 for (int cc = lane; cc < H4; cc += 64)
                     *reinterpret_cast<float4*>(a_row + apad(4 * cc, kpt)) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -382,13 +503,19 @@ __device__ __forceinline__ void process_block(const int32_t* __restrict__ plan, 
         sp = dpp_row_sum16(sp);
         if (gate_thread) {
             float* po = C.h_out + (int64_t)gv * ld_h;
-            if (RESIDENT) {  // publish to the other workgroups of this launch: write-through (sc1) stores
-                __hip_atomic_store(po + j, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((tid & 15) == 15)
-                    __hip_atomic_store(po + H + (j >> 4), sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                po[j] = hv;
-                if ((tid & 15) == 15) po[H + (j >> 4)] = sp;
+            po[j] = hv;
+            if ((tid & 15) == 15) po[H + (j >> 4)] = sp;
+            if (C.g_out) {  // granule copy: the hand-off format of the persistent tail kernel
+                gran_t* pg = C.g_out + (int64_t)gv * (H + H / PU);
+                if (RESIDENT) {  // consumers run in this very launch: one write-through 8-byte store each
+                    __hip_atomic_store(pg + j, gran_pack(G.epoch, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((tid & 15) == 15)
+                        __hip_atomic_store(pg + H + (j >> 4), gran_pack(G.epoch, sp), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                } else {         // consumers run in a later launch: the launch boundary publishes
+                    pg[j] = gran_pack(G.epoch, hv);
+                    if ((tid & 15) == 15) pg[H + (j >> 4)] = gran_pack(G.epoch, sp);
+                }
             }
         }
     }
@@ -412,29 +539,30 @@ __global__ void __launch_bounds__(FT, MINW) frontier_step_kernel(const int32_t* 
     const int nr = min(RBT, C.row_end - slot0);
     const int d = C.dir;
     float4 wh[KW], wi[KW];
+    GranCtx G;
+    G.epoch = S.epoch; G.err = nullptr;
     process_block<JS, RBT, KW, false>(plan, L.rowrec[d], L.col[d], L.eattr[d], C, C.has_pred != 0, slot0, nr, sl, S.H,
-                                      S.ld_h, S.R, S.vid_mod, smem, wh, wi, stamp);
+                                      S.ld_h, S.R, S.vid_mod, smem, wh, wi, stamp, G);
     if (prof) stamp[6] = gridDim.x;
 }
 
-// ---- persistent tail kernel: ONE launch walks all remaining layers.
+// ---- persistent tail kernel: ONE launch walks all remaining layers, as a dataflow.
 // The tail of the schedule is hundreds of dependent layers with a handful of rows each; a launch
-// boundary (~3 us) + kernarg fetch + weight reload per layer is most of their cost.  Here every
-// workgroup owns (cell, slice, replica) for the whole tail, keeps its weight slice in registers,
-// and the workgroups meet at one counter per layer.  Visibility of the rows they exchange:
-//   producer: write-through (sc1) stores -> every storing wave s_waitcnt vmcnt(0) -> workgroup
-//   barrier -> one relaxed agent-scope atomic add on the layer's counter;
-//   consumer: one lane polls that counter with relaxed agent-scope loads, then a workgroup barrier.
-//   State rows are padded to whole 128-byte lines and every row is written before it is first
-//   read by anyone in this launch, so no cache anywhere can hold a stale copy of its lines: the
-//   consumers use plain loads.  Nothing depends on where a workgroup runs.  The grid is far below
-//   the CU count (all workgroups co-resident); every spin is bounded and reports through err_flag.
+// boundary (~3 us) + kernarg fetch + weight reload + cross-die row fetch per layer is most of their
+// cost, and a grid barrier would cost as much (measured: 5.3 us per layer for 64 workgroups).
+// Here every workgroup owns (cell, slice, replica) for the whole tail, keeps its weight slice in
+// registers, and walks its row blocks in schedule order WITHOUT any barrier: a row block starts as
+// soon as the granules (tagged 8-byte copies, see above) of the rows it reads carry this pass's
+// epoch.  Dependencies only point to earlier layers / the lower stacked layer, producers never wait
+// on consumers and the grid is far below the CU count (all workgroups resident), so it cannot
+// deadlock; spins are bounded anyway and report through err_flag.  Nothing depends on placement.
 struct TailArgs {
     Cell cell[DAGNN_MAX_CELLS];
     int stacked_idx[DAGNN_MAX_CELLS];  // i of each cell (layer processed at step s is s - i)
     int ncell, nrep, H, ld_h, R, vid_mod;
     int s_begin, s_end;                // steps [s_begin, s_end)
-    int* counters;                     // [s_end] zeroed before the launch; counters[s_end] = error flag
+    unsigned epoch;
+    int* err_flag;
     unsigned long long* dbg;
 };
 
@@ -456,6 +584,8 @@ __global__ void __launch_bounds__(FT, 1) frontier_tail_kernel(const int32_t* __r
     const bool has_in = C.wih != nullptr;
     const int kpt = S.H >> 4;
     const bool prof = S.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+    GranCtx G;
+    G.epoch = S.epoch; G.err = S.err_flag;
 
     // resident weights: the whole slice (kpt <= KW, checked by the host)
     float4 wh[KW], wi[KW];
@@ -473,38 +603,20 @@ __global__ void __launch_bounds__(FT, 1) frontier_tail_kernel(const int32_t* __r
             }
         }
     }
-    const int nwg = gridDim.x;
     for (int s = S.s_begin; s < S.s_end; ++s) {
         unsigned long long* stamp = prof ? S.dbg + 8 * (int64_t)s : nullptr;
-        if (prof) stamp[0] = wall_clock64();
+        if (prof) { stamp[0] = wall_clock64(); stamp[6] = gridDim.x; }
         const int t = s - si;
-        if (t >= 0 && t < T) {
-            const int r0 = blptr[t], r1 = blptr[t + 1];
-            const int nblk = (r1 - r0 + RBT - 1) / RBT;
-            for (int rb = rep; rb < nblk; rb += S.nrep) {
-                const int slot0 = r0 + rb * RBT;
-                process_block<JS, RBT, KW, true>(plan, L.rowrec[d], L.col[d], L.eattr[d], C, t > 0, slot0,
-                                                 min(RBT, r1 - slot0), sl, S.H, S.ld_h, S.R, S.vid_mod, smem, wh, wi,
-                                                 stamp);
-                __syncthreads();  // LDS is reused by the next block
-            }
+        if (t < 0 || t >= T) continue;
+        const int r0 = blptr[t], r1 = blptr[t + 1];
+        const int nblk = (r1 - r0 + RBT - 1) / RBT;
+        for (int rb = rep; rb < nblk; rb += S.nrep) {
+            const int slot0 = r0 + rb * RBT;
+            process_block<JS, RBT, KW, true>(plan, L.rowrec[d], L.col[d], L.eattr[d], C, t > 0, slot0,
+                                             min(RBT, r1 - slot0), sl, S.H, S.ld_h, S.R, S.vid_mod, smem, wh, wi,
+                                             stamp, G);
+            __syncthreads();  // LDS is reused by the next block
         }
-        // ---- layer barrier
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have left
-        __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_fetch_add(S.counters + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            while (__hip_atomic_load(S.counters + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 24)) {  // ~seconds: never hang the device
-                    __hip_atomic_store(S.counters + S.s_end, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
-        __syncthreads();
-        if (prof) { stamp[6] = wall_clock64(); stamp[7] = gridDim.x; }
     }
 }
 
@@ -569,6 +681,8 @@ static void fill_cell(Cell& K, const dagnn_frontier_args* a, const dagnn_plan* p
     K.gi0 = i == 0 ? c.gi0 : nullptr;
     K.h_in = i > 0 ? a->cell[d][i - 1].h_out : nullptr;
     K.h_out = c.h_out;
+    K.g_out = (gran_t*)c.granules;
+    K.g_in = i > 0 ? (const gran_t*)a->cell[d][i - 1].granules : nullptr;
     K.dir = d; K.row_base = 0; K.row_end = 0; K.has_pred = 0;
 }
 
@@ -607,11 +721,12 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
     // than its replicas cover in `tail_max_blocks` blocks of 8.  Needs the whole slice in registers
     // (H <= 256), line-aligned state rows (ld_h % 32 == 0) and a sync workspace.
     int s_tail = nsteps;
-    const int tail_js = 32, tail_rb = 8;
+    const int tail_js = 32, tail_rb = 4;
     int nrep = a->tail_replicas > 0 ? a->tail_replicas : 0;
     const int tail_wgs = ndir * Ls * (H / tail_js) * (nrep > 0 ? nrep : 1);
-    const bool tail_ok = nrep > 0 && a->tail_sync && H <= 256 && (a->ld_h % 32) == 0 && tail_wgs <= a->num_cus / 2 &&
-                         a->tail_sync_words >= nsteps + 1;
+    bool tail_ok = nrep > 0 && a->tail_err && a->epoch != 0 && H <= 256 && tail_wgs <= a->num_cus / 2;
+    for (int q = 0; q < ndir && tail_ok; ++q)
+        for (int i = 0; i < Ls; ++i) tail_ok = tail_ok && a->cell[dirs[q]][i].granules != nullptr;
     if (tail_ok) {
         const int cap = tail_rb * nrep * (a->tail_max_blocks > 0 ? a->tail_max_blocks : 1);
         s_tail = 0;
@@ -627,6 +742,7 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
     StepArgs S;
     S.H = H; S.ld_h = a->ld_h; S.R = pl->num_edge_feats; S.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
     S.dbg = (unsigned long long*)a->debug_timing;
+    S.epoch = a->epoch;
     for (int s = 0; s < s_tail; ++s) {
         // geometry of this launch: thin launches use 16-unit slices (and 4-row blocks when that
         // still fits one round of workgroups), fat ones 32-unit slices, 8-row blocks, 2 per CU
@@ -674,14 +790,13 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         T.ncell = nc; T.nrep = nrep; T.H = H; T.ld_h = a->ld_h; T.R = pl->num_edge_feats;
         T.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
         T.s_begin = s_tail; T.s_end = nsteps;
-        T.counters = (int*)a->tail_sync;
+        T.epoch = a->epoch;
+        T.err_flag = (int*)a->tail_err;
         T.dbg = (unsigned long long*)a->debug_timing;
-        hipError_t e = hipMemsetAsync(a->tail_sync, 0, (size_t)(nsteps + 1) * sizeof(int), st);
-        if (e != hipSuccess) return DAGNN_EHIP(e);
         const int op_ld = H + 64;
         const size_t lds = (size_t)(2 * tail_rb * op_ld + 2 * tail_rb * 3 * tail_js) * sizeof(float) + tail_rb * sizeof(int);
-        hipLaunchKernelGGL((frontier_tail_kernel<32, 8, 16>), dim3((unsigned)tail_wgs), dim3(FT), lds, st, plan, L, T);
-        e = hipGetLastError();
+        hipLaunchKernelGGL((frontier_tail_kernel<32, 4, 16>), dim3((unsigned)tail_wgs), dim3(FT), lds, st, plan, L, T);
+        hipError_t e = hipGetLastError();
         if (e != hipSuccess) return DAGNN_EHIP(e);
     }
     return DAGNN_OK;

@@ -102,6 +102,7 @@ class _DvaeDagnn(_DvaeBase):
         self.dropout = nn.Dropout(dropout)
         self.out_linear = nn.Linear(self.out_hidden_dim, out_dim) if num_layers > 1 else None
         self._derived = {}
+        self._arenas = {}  # per device: granule buffers of the persistent tail kernel
         self.schedule = default_schedule()  # 'lockstep' (frontier launches) or 'pergraph' (persistent workgroups)
 
     def _cells(self):
@@ -142,7 +143,8 @@ class _DvaeDagnn(_DvaeBase):
         bl = G.bi_layer_index
         plan = engine.build_plan(G.edge_index, bl[0][0], bl[1][0], G.batch, B, None)
         h = run_stack(plan, x, self._cells(), self.dirs, L, H, vid_nodes=nn_ if self._use_vids else 0,
-                      schedule=self.schedule)
+                      schedule=self.schedule, arena=self._arenas.setdefault((x.device, torch.cuda.current_stream(x.device).cuda_stream),
+                                                   engine.GranuleArena()))
         nd = len(self.dirs)
         hcat = torch.empty(B, nd * L * H, dtype=torch.float32, device=x.device)
         for i in range(L):  # end vertex of every graph for d=0, start vertex for d=1

@@ -188,6 +188,7 @@ class DAGNN(nn.Module):
                     self.graph_pred_linear_list.append(nn.Linear(self.out_hidden_dim, self.num_vocab))
 
         self._derived = {}
+        self._arenas = {}  # per device: granule buffers of the persistent tail kernel
         self.schedule = default_schedule()  # 'lockstep' (frontier launches) or 'pergraph' (persistent workgroups)
 
     # ------------------------------------------------------------------------------ helpers
@@ -253,7 +254,9 @@ class DAGNN(nn.Module):
         has_edge_enc = getattr(self.node_aggr_0[0], "wea", False)
         plan = engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B,
                                  G.edge_attr if has_edge_enc else None)
-        h = run_stack(plan, x, self._cells(), dirs, L, H, schedule=self.schedule)
+        h = run_stack(plan, x, self._cells(), dirs, L, H, schedule=self.schedule,
+                      arena=self._arenas.setdefault((x.device, torch.cuda.current_stream(x.device).cuda_stream),
+                                                   engine.GranuleArena()))
         G.h = [[h[d][i] for i in range(L)] for d in dirs]  # side effect 4 (dagnn.py:141-142,182)
 
         if self.bidirectional and not self.output_all:

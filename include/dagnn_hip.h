@@ -176,6 +176,9 @@ typedef struct dagnn_frontier_cell {
     const float* vid_bias;  /* [vid_mod] or NULL */
     const float* gi0;       /* [N,3H] W_ih x + b_ih (stacked layer 0 only), from dagnn_gemm_nt_bias */
     float* h_out;           /* [N,ld_h] hidden states + partial scores (every row written exactly once) */
+    void* granules;         /* NULL, or uint64 [N, H + H/16]: tagged copies {epoch, fp32 bits} of the same row,
+                             * the hand-off format of the persistent tail kernel.  The buffer must have been
+                             * zero-initialised once and only ever used with strictly increasing epochs. */
 } dagnn_frontier_cell;
 
 #define DAGNN_MAX_STACKED 8
@@ -185,11 +188,12 @@ typedef struct dagnn_frontier_args {
     int dir_mask;
     int H, ld_h, vid_mod;
     int num_cus;     /* compute units of the device (launch geometry heuristic), e.g. 256 */
-    /* persistent tail (one launch for all layers after the fat head; needs H <= 256 and ld_h % 32 == 0): */
+    /* persistent tail: one dataflow launch for all layers after the fat head (needs every cell's
+     * `granules`, epoch != 0 and H <= 256): */
     int tail_replicas;   /* workgroups per (cell, slice) in the tail kernel; 0 disables it */
-    int tail_max_blocks; /* a layer may have up to 8 * tail_replicas * tail_max_blocks rows per cell in the tail */
-    void* tail_sync;     /* device int32[tail_sync_words] scratch (layer counters; last used word = error flag) */
-    int tail_sync_words; /* >= T + L */
+    int tail_max_blocks; /* a layer may have up to 4 * tail_replicas * tail_max_blocks rows per cell in the tail */
+    unsigned epoch;      /* tag of this forward pass in the granule buffers: nonzero, larger than any used before */
+    void* tail_err;      /* device int32: set to 1 if a bounded wait in the tail kernel ever expires */
     void* debug_timing; /* NULL, or (T+L-1)*8 uint64 device words: 100 MHz stamps of workgroup 0 per launch */
 } dagnn_frontier_args;
 

@@ -317,14 +317,16 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
     }
 }
 
-template <int RBT, int KW>
+// acc[r] += W-slice x operand row r for the first NRW rows of the block (NRW <= RBT is a compile-time
+// bound so that blocks with few live rows do not pay for the padding rows).
+template <int RBT, int KW, int NRW>
 __device__ __forceinline__ void fma_rows(float4 (&acc)[RBT], const float4 (&w)[KW], const float* op, int op_ld,
                                          int koff, int n) {
 #pragma unroll
     for (int q = 0; q < KW / 4; ++q) {
         if (4 * q < n) {
 #pragma unroll
-            for (int r = 0; r < RBT; ++r) {
+            for (int r = 0; r < NRW; ++r) {
                 const float4 a = *reinterpret_cast<const float4*>(op + r * op_ld + koff + 4 * q);
                 fma4(acc[r], a.x, w[4 * q]); fma4(acc[r], a.y, w[4 * q + 1]);
                 fma4(acc[r], a.z, w[4 * q + 2]); fma4(acc[r], a.w, w[4 * q + 3]);
@@ -448,6 +450,7 @@ __device__ __forceinline__ void process_block(const int32_t* __restrict__ plan, 
 #pragma unroll
         for (int r = 0; r < RBT; ++r) { acc_h[r] = make_float4(0.f, 0.f, 0.f, 0.f); acc_i[r] = acc_h[r]; }
         const int kbase = ksl * kpt + 4 * ksl;  // == apad(ksl * kpt, kpt)
+        const bool few = RBT > 2 && nr <= 2;    // wave-uniform: blocks with <= 2 live rows (the thin tail)
         for (int ch = 0; ch < nchunk; ++ch) {
             const int n = min(KW, kpt - ch * KW);
             if (ch > 0) {  // never taken when RESIDENT (the host only uses it for kpt <= KW)
@@ -459,12 +462,18 @@ __device__ __forceinline__ void process_block(const int32_t* __restrict__ plan, 
                     }
                 }
             }
-            if (has_pred) fma_rows<RBT, KW>(acc_h, wh, a_s, op_ld, kbase + ch * KW, n);
-            if (has_in) fma_rows<RBT, KW>(acc_i, wi, u_s, op_ld, kbase + ch * KW, n);
+            if (few) {
+                if (has_pred) fma_rows<RBT, KW, 2>(acc_h, wh, a_s, op_ld, kbase + ch * KW, n);
+                if (has_in) fma_rows<RBT, KW, 2>(acc_i, wi, u_s, op_ld, kbase + ch * KW, n);
+            } else {
+                if (has_pred) fma_rows<RBT, KW, RBT>(acc_h, wh, a_s, op_ld, kbase + ch * KW, n);
+                if (has_in) fma_rows<RBT, KW, RBT>(acc_i, wi, u_s, op_ld, kbase + ch * KW, n);
+            }
         }
         if (stamp) stamp[3] = wall_clock64();
 #pragma unroll
         for (int r = 0; r < RBT; ++r) {
+            if (few && r >= 2) continue;
             if (has_pred) { acc_h[r].x = dpp_row_sum16(acc_h[r].x); acc_h[r].y = dpp_row_sum16(acc_h[r].y);
                             acc_h[r].z = dpp_row_sum16(acc_h[r].z); acc_h[r].w = dpp_row_sum16(acc_h[r].w); }
             if (has_in) { acc_i[r].x = dpp_row_sum16(acc_i[r].x); acc_i[r].y = dpp_row_sum16(acc_i[r].y);
@@ -753,10 +762,20 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
                 rows_total += n; blocks8 += (n + 7) / 8; blocks4 += (n + 3) / 4;
             }
         if (rows_total == 0) continue;
-        int js, rb;
-        if (blocks4 * (H / 16) <= a->num_cus) { js = 16; rb = 4; }
-        else if (blocks8 * (H / 16) <= a->num_cus) { js = 16; rb = 8; }
-        else { js = 32; rb = 8; }
+        // Pick the launch shape with the smallest modelled time = rounds x per-workgroup latency.
+        // Shapes: {slice units, rows per block, weights (P)refetched / (S)treamed, workgroups per CU};
+        // latencies (us) measured on MI355X with scripts/probe_frontier.py.
+        struct Shape { int js, rb, wgs_per_cu; float lat; };
+        static const Shape shapes[4] = {{16, 4, 1, 7.0f}, {16, 8, 1, 11.0f}, {32, 4, 2, 9.0f}, {32, 8, 2, 12.5f}};
+        int best = 0;
+        float best_t = 1e30f;
+        for (int k = 0; k < 4; ++k) {
+            const int wgs = (shapes[k].rb == 4 ? blocks4 : blocks8) * (H / shapes[k].js);
+            const int slots = a->num_cus * shapes[k].wgs_per_cu;
+            const float t = (float)((wgs + slots - 1) / slots) * shapes[k].lat;
+            if (t < best_t) { best_t = t; best = k; }
+        }
+        const int js = shapes[best].js, rb = shapes[best].rb;
         int nc = 0, blocks = 0;
         S.blk_start[0] = 0;
         for (int q = 0; q < ndir; ++q) {
@@ -774,7 +793,8 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         S.ncell = nc;
         S.step = s;
         hipError_t e;
-        if (js == 32) e = launch_step<32, 8, 4, 3>(blocks, H, st, plan, L, S);
+        if (js == 32) e = rb == 8 ? launch_step<32, 8, 4, 3>(blocks, H, st, plan, L, S)
+                                  : launch_step<32, 4, 4, 3>(blocks, H, st, plan, L, S);
         else if (rb == 4) e = launch_step<16, 4, 16, 1>(blocks, H, st, plan, L, S);
         else e = launch_step<16, 8, 16, 1>(blocks, H, st, plan, L, S);
         if (e != hipSuccess) return DAGNN_EHIP(e);

@@ -762,20 +762,14 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
                 rows_total += n; blocks8 += (n + 7) / 8; blocks4 += (n + 3) / 4;
             }
         if (rows_total == 0) continue;
-        // Pick the launch shape with the smallest modelled time = rounds x per-workgroup latency.
-        // Shapes: {slice units, rows per block, weights (P)refetched / (S)treamed, workgroups per CU};
-        // latencies (us) measured on MI355X with scripts/probe_frontier.py.
-        struct Shape { int js, rb, wgs_per_cu; float lat; };
-        static const Shape shapes[4] = {{16, 4, 1, 7.0f}, {16, 8, 1, 11.0f}, {32, 4, 2, 9.0f}, {32, 8, 2, 12.5f}};
-        int best = 0;
-        float best_t = 1e30f;
-        for (int k = 0; k < 4; ++k) {
-            const int wgs = (shapes[k].rb == 4 ? blocks4 : blocks8) * (H / shapes[k].js);
-            const int slots = a->num_cus * shapes[k].wgs_per_cu;
-            const float t = (float)((wgs + slots - 1) / slots) * shapes[k].lat;
-            if (t < best_t) { best_t = t; best = k; }
-        }
-        const int js = shapes[best].js, rb = shapes[best].rb;
+        // Launch shape {slice units, rows per block}: thin launches prefetch a whole 16-unit slice per
+        // workgroup (1 workgroup per CU) and must fit ONE round of CUs; otherwise 32-unit slices with
+        // streamed weights, two workgroups per CU, 4-row blocks while they fit one round of slots.
+        int js, rb;
+        if (blocks4 * (H / 16) <= a->num_cus) { js = 16; rb = 4; }
+        else if (blocks4 * (H / 32) <= 2 * a->num_cus) { js = 32; rb = 4; }
+        else if (blocks8 * (H / 16) <= a->num_cus) { js = 16; rb = 8; }
+        else { js = 32; rb = 8; }
         int nc = 0, blocks = 0;
         S.blk_start[0] = 0;
         for (int q = 0; q < ndir; ++q) {

@@ -15,6 +15,7 @@
 namespace {
 
 constexpr int PB = 256;  // threads per plan workgroup
+constexpr int PLAN_NMAX = 2048;  // graphs up to this many nodes are planned in LDS
 
 __device__ __forceinline__ int64_t lower_bound_i64(const int64_t* a, int64_t n, int64_t key) {
     int64_t lo = 0, hi = n;
@@ -106,16 +107,23 @@ __global__ void __launch_bounds__(PB) plan_graph_kernel(int32_t* plan, PlanLayou
                                                          int64_t N, int64_t E, int32_t* status) {
     __shared__ int32_t lds[PB + 8];
     __shared__ int32_t s_depth;
+    // graphs of up to PLAN_NMAX nodes (all of ogbg-code2's typical ASTs) keep their counters, cursors
+    // and positions in LDS: the kernel is a chain of ~15 dependent passes, and every pass through
+    // global memory costs a round trip
+    __shared__ int32_t small_ws[4 * (PLAN_NMAX + 1)];
     const int g = blockIdx.x, d = blockIdx.y, tid = threadIdx.x;
     const int n0 = plan[L.node_ptr + g], n1 = plan[L.node_ptr + g + 1];
     const int e0 = plan[L.edge_ptr + g], e1 = plan[L.edge_ptr + g + 1];
     const int n = n1 - n0;
+    const bool small = n <= PLAN_NMAX;
     const int64_t* layer = d == 0 ? layer_fwd : layer_bwd;
-    int32_t* ls = plan + L.lstart[d] + n0 + g;     // n+1 words
-    int32_t* rp = plan + L.rowptr[d] + n0 + g;     // n+1 words
-    int32_t* cur = plan + L.cursor[d] + n0 + g;    // n+1 words
+    int32_t* ls_g = plan + L.lstart[d] + n0 + g;   // n+1 words (final home)
+    int32_t* rp_g = plan + L.rowptr[d] + n0 + g;   // n+1 words (final home)
+    int32_t* ls = small ? small_ws : ls_g;
+    int32_t* rp = small ? small_ws + (PLAN_NMAX + 1) : rp_g;
+    int32_t* cur = small ? small_ws + 2 * (PLAN_NMAX + 1) : plan + L.cursor[d] + n0 + g;  // n+1 words
+    int32_t* pos = (small ? small_ws + 3 * (PLAN_NMAX + 1) : plan + L.pos[d] + n0) - n0;  // indexed by node id
     int32_t* order = plan + L.order[d];
-    int32_t* pos = plan + L.pos[d];
     int32_t* col = plan + L.col[d];
     float* eattr = reinterpret_cast<float*>(plan + L.eattr[d]);
 
@@ -148,6 +156,7 @@ __global__ void __launch_bounds__(PB) plan_graph_kernel(int32_t* plan, PlanLayou
         cur[i] = ls[i];
         atomicAdd(&plan[L.blptr[d] + i + 1], ls[i + 1] - ls[i]);  // rows of batch-level layer i
     }
+    if (small) for (int i = tid; i <= depth; i += PB) ls_g[i] = ls[i];
     __syncthreads();
 
     // ---- stable placement of nodes: order[] sorted by (layer, node id)
@@ -178,6 +187,7 @@ __global__ void __launch_bounds__(PB) plan_graph_kernel(int32_t* plan, PlanLayou
     block_scan_inplace(rp, n + 1, e0, lds);
     __syncthreads();
     for (int i = tid; i < n; i += PB) cur[i] = rp[i];
+    if (small) for (int i = tid; i <= n; i += PB) rp_g[i] = rp[i];
     __syncthreads();
     for (int c0 = e0; c0 < e1; c0 += PB) {
         int e = c0 + tid;
@@ -200,16 +210,23 @@ __global__ void __launch_bounds__(PB) plan_graph_kernel(int32_t* plan, PlanLayou
 // Work items (g*2+d) sorted by depth, deepest first, so that the hardware's in-order workgroup
 // dispatch starts the longest dependency chains first (LPT scheduling).
 __global__ void __launch_bounds__(1024) plan_items_kernel(int32_t* plan, PlanLayout L, int B) {
+    __shared__ int32_t keys[4096];
     const int n = 2 * B;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        int ki = plan[L.depth[i & 1] + (i >> 1)];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            int kj = plan[L.depth[j & 1] + (j >> 1)];
-            rank += (kj > ki) || (kj == ki && j < i);
+    for (int c0 = 0; c0 < n; c0 += 4096) {  // candidates staged through LDS, 4096 at a time
+        __syncthreads();
+        for (int j = threadIdx.x; j < 4096 && c0 + j < n; j += blockDim.x)
+            keys[j] = plan[L.depth[(c0 + j) & 1] + ((c0 + j) >> 1)];
+        __syncthreads();
+        const int m = min(4096, n - c0);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int ki = plan[L.depth[i & 1] + (i >> 1)];
+            int rank = 0;
+            for (int j = 0; j < m; ++j) rank += (keys[j] > ki) || (keys[j] == ki && c0 + j < i);
+            if (c0 == 0) plan[L.cursor[0] + i] = rank; else plan[L.cursor[0] + i] += rank;  // scratch: B <= N/1
         }
-        plan[L.items + rank] = i;
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) plan[L.items + plan[L.cursor[0] + i]] = i;
 }
 
 // Batch-level layers (the lock-step schedule): blptr[d][t] = first rowrec slot of layer t over the
@@ -246,21 +263,37 @@ __global__ void __launch_bounds__(1024) plan_blptr_kernel(int32_t* plan, PlanLay
 }
 
 // lbase[g][t] = blptr[t] + rows of layer t in graphs before g (deterministic slot assignment).
+// One thread per layer walks the graphs; per-graph constants are staged in LDS and the layer sizes
+// are loaded 8 graphs ahead so the walk is not a chain of dependent round trips.
 __global__ void __launch_bounds__(256) plan_lbase_kernel(int32_t* plan, PlanLayout L, int N, int B) {
+    __shared__ int32_t s_base[1024], s_depth[1024];
     const int d = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int T = plan[L.blptr[d] + N + 1];
-    if (t >= T) return;
-    int acc = plan[L.blptr[d] + t];
-    const int32_t* __restrict__ node_ptr = plan + L.node_ptr;
-    const int32_t* __restrict__ depth = plan + L.depth[d];
+    if ((int)(blockIdx.x * blockDim.x) >= T) return;  // whole block idle
     const int32_t* __restrict__ ls = plan + L.lstart[d];
-    int32_t* lb = plan + L.lbase[d];
-    for (int g = 0; g < B; ++g) {
-        if (t < depth[g]) {
-            const int base = node_ptr[g] + g + t;
-            lb[base] = acc;
-            acc += ls[base + 1] - ls[base];
+    int32_t* __restrict__ lb = plan + L.lbase[d];
+    int acc = t < T ? plan[L.blptr[d] + t] : 0;
+    for (int g0 = 0; g0 < B; g0 += 1024) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < 1024 && g0 + j < B; j += blockDim.x) {
+            s_base[j] = plan[L.node_ptr + g0 + j] + g0 + j;
+            s_depth[j] = plan[L.depth[d] + g0 + j];
+        }
+        __syncthreads();
+        const int m = min(1024, B - g0);
+        if (t < T) {
+            for (int j0 = 0; j0 < m; j0 += 8) {
+                int cnt[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u;
+                    cnt[u] = (j < m && t < s_depth[j]) ? ls[s_base[j] + t + 1] - ls[s_base[j] + t] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (cnt[u] >= 0) { lb[s_base[j0 + u] + t] = acc; acc += cnt[u]; }
+            }
         }
     }
 }

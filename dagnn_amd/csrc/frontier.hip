@@ -49,6 +49,8 @@ struct Cell {
     const float* gi0;    // [N,3H] precomputed input side (stacked layer 0) or null
     const float* h_in;   // [N,ld_h] lower stacked layer (with wih) or null
     float* h_out;        // [N,ld_h]: H state floats + H/16 partial scores per row
+    const float* a_pre;  // fat launches: aggregates of this launch's rows [row_end - row_base, H], written by
+                         // aggregate_rows_kernel one launch earlier; null = aggregate inside the block
     unsigned long long* g_out;        // [N,gld] {epoch tag, fp32 bits} granules of h_out rows + parts, or null
     const unsigned long long* g_in;   // granules of h_in, or null
     int dir;             // direction (selects the plan arrays)
@@ -414,7 +416,11 @@ __device__ __forceinline__ void process_block(const int32_t* __restrict__ plan, 
                         *reinterpret_cast<float4*>(u_row + apad(4 * cc, kpt)) = ur[cc];
                 }
             }
-            if (has_pred && rec0.z > rec0.y) {
+            if (!RESIDENT && C.a_pre != nullptr) {
+                // fat launch: the aggregate was computed once per row by aggregate_rows_kernel
+                const float4* ap = reinterpret_cast<const float4*>(C.a_pre + (int64_t)(slot0 + r - C.row_base) * H);
+                for (int cc = lane; cc < H4; cc += 64) *reinterpret_cast<float4*>(a_row + apad(4 * cc, kpt)) = ap[cc];
+            } else if (has_pred && rec0.z > rec0.y) {
                 aggregate<RESIDENT>(C, col, eattr, rec0.y, rec0.z, rp[1], rp[2], rp[3], H, ld_h, R, vid_mod, kpt, a_row,
                                     lane, G);
             } else {
@@ -450,7 +456,9 @@ __device__ __forceinline__ void process_block(const int32_t* __restrict__ plan, 
 #pragma unroll
         for (int r = 0; r < RBT; ++r) { acc_h[r] = make_float4(0.f, 0.f, 0.f, 0.f); acc_i[r] = acc_h[r]; }
         const int kbase = ksl * kpt + 4 * ksl;  // == apad(ksl * kpt, kpt)
-        const bool few = RBT > 2 && nr <= 2;    // wave-uniform: blocks with <= 2 live rows (the thin tail)
+        // wave-uniform: blocks with <= 2 live rows (the thin tail); only in the latency-bound shapes - the
+        // second code copy costs the streamed shapes registers and instruction-cache room
+        const bool few = RBT == 4 && KW == 16 && nr <= 2;
         for (int ch = 0; ch < nchunk; ++ch) {
             const int n = min(KW, kpt - ch * KW);
             if (ch > 0) {  // never taken when RESIDENT (the host only uses it for kpt <= KW)
@@ -529,6 +537,32 @@ __device__ __forceinline__ void process_block(const int32_t* __restrict__ plan, 
         }
     }
     if (stamp) stamp[5] = wall_clock64();
+}
+
+// ---- fat launches, stage 1: the aggregate of every frontier row ONCE (one wave per row, 4 rows per
+// workgroup: a low-register, high-occupancy gather kernel) instead of once per weight slice.
+__global__ void __launch_bounds__(256) aggregate_rows_kernel(const int32_t* __restrict__ plan, PlanLayout L, StepArgs S) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + wave;          // row index over all cells of this launch
+    int c = 0;
+    while (c + 1 < S.ncell && row >= S.blk_start[c + 1]) ++c;   // blk_start = ROW prefix sums here
+    if (row >= S.blk_start[S.ncell]) return;
+    const Cell& C = S.cell[c];
+    const int local = row - S.blk_start[c];
+    const int d = C.dir, H = S.H, H4 = H >> 2;
+    const int4* rp = reinterpret_cast<const int4*>(plan + L.rowrec[d]) + 4 * (int64_t)(C.row_base + local);
+    const int4 rec0 = rp[0];
+    float* out = const_cast<float*>(C.a_pre) + (int64_t)local * H;
+    GranCtx G;
+    G.epoch = S.epoch; G.err = nullptr;
+    if (C.has_pred && rec0.z > rec0.y) {
+        // kpt = H (no padding): apad(k, H) == k for k < H, so the rows land contiguously
+        aggregate<false>(C, plan + L.col[d], reinterpret_cast<const float*>(plan + L.eattr[d]), rec0.y, rec0.z, rp[1],
+                         rp[2], rp[3], H, S.ld_h, C.gain ? S.R : 0, S.vid_mod, H, out, lane, G);
+    } else {
+        for (int cc = lane; cc < H4; cc += 64) reinterpret_cast<float4*>(out)[cc] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 // ---- launch-per-layer kernel: one launch = one batch-level topological layer, all cells
@@ -692,6 +726,7 @@ static void fill_cell(Cell& K, const dagnn_frontier_args* a, const dagnn_plan* p
     K.h_out = c.h_out;
     K.g_out = (gran_t*)c.granules;
     K.g_in = i > 0 ? (const gran_t*)a->cell[d][i - 1].granules : nullptr;
+    K.a_pre = nullptr;
     K.dir = d; K.row_base = 0; K.row_end = 0; K.has_pred = 0;
 }
 
@@ -787,6 +822,22 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         S.ncell = nc;
         S.step = s;
         hipError_t e;
+        const bool split = js == 32 && rb == 8 && a->agg_scratch != nullptr && rows_total <= a->agg_scratch_rows;
+        if (split) {
+            // fat launch: stage 1 aggregates every row once into the scratch, stage 2 does the slices
+            StepArgs A = S;
+            int off = 0;
+            for (int k = 0; k < nc; ++k) {
+                A.cell[k].a_pre = (const float*)a->agg_scratch + (int64_t)off * H;
+                S.cell[k].a_pre = A.cell[k].a_pre;
+                A.blk_start[k] = off;
+                off += A.cell[k].row_end - A.cell[k].row_base;
+            }
+            A.blk_start[nc] = off;
+            hipLaunchKernelGGL(aggregate_rows_kernel, dim3((unsigned)((off + 3) / 4)), dim3(256), 0, st, plan, L, A);
+            e = hipGetLastError();
+            if (e != hipSuccess) return DAGNN_EHIP(e);
+        }
         if (js == 32) e = rb == 8 ? launch_step<32, 8, 4, 3>(blocks, H, st, plan, L, S)
                                   : launch_step<32, 4, 4, 3>(blocks, H, st, plan, L, S);
         else if (rb == 4) e = launch_step<16, 4, 16, 1>(blocks, H, st, plan, L, S);

@@ -260,6 +260,18 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     args.num_stacked, args.dir_mask, args.H, args.ld_h, args.vid_mod = L, mask, H, h[dirs[0]][0].shape[1], int(vid_mod)
     args.debug_timing = DEBUG_TIMING.data_ptr() if DEBUG_TIMING is not None else None
     args.num_cus = torch.cuda.get_device_properties(plan.ws.device).multi_processor_count
+    # widest launch: layer t of stacked layer i runs in launch t + i
+    widest = 0
+    for s_ in range(max(len(sched[0]), len(sched[1])) - 1 + L):
+        w = 0
+        for d in dirs:
+            for i in range(L):
+                t = s_ - i
+                if 0 <= t < len(sched[d]) - 1:
+                    w += int(sched[d][t + 1] - sched[d][t])
+        widest = max(widest, w)
+    plan.agg_scratch = torch.empty(max(widest, 1) * H, dtype=torch.float32, device=plan.ws.device)
+    args.agg_scratch, args.agg_scratch_rows = plan.agg_scratch.data_ptr(), widest
     args.tail_replicas, args.tail_max_blocks = (TAIL_REPLICAS if use_tail else 0), TAIL_MAX_BLOCKS
     args.epoch, args.tail_err = epoch, _ptr(err)
     ptrs = (C.POINTER(C.c_int32) * 2)()

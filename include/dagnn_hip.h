@@ -188,6 +188,8 @@ typedef struct dagnn_frontier_args {
     int dir_mask;
     int H, ld_h, vid_mod;
     int num_cus;     /* compute units of the device (launch geometry heuristic), e.g. 256 */
+    void* agg_scratch;    /* NULL, or fp32 [agg_scratch_rows, H]: fat launches aggregate every row once into it */
+    int agg_scratch_rows; /* >= the largest number of rows (over all cells) of any single launch */
     /* persistent tail: one dataflow launch for all layers after the fat head (needs every cell's
      * `granules`, epoch != 0 and H <= 256): */
     int tail_replicas;   /* workgroups per (cell, slice) in the tail kernel; 0 disables it */

@@ -53,6 +53,7 @@ class _NoSpan(object):
 
 
 TIMER: Optional[KernelTimer] = None  # set by bench.py around its timed region
+AGG_SPLIT = int(__import__("os").environ.get("DAGNN_AMD_AGG_SPLIT", "0"))
 TAIL_REPLICAS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_REPLICAS", "4"))   # 0 = launch every layer
 TAIL_MAX_BLOCKS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_MAX_BLOCKS", "2"))
 DEBUG_TIMING: Optional[torch.Tensor] = None  # int64[8] device tensor: phase ticks of the deepest work item
@@ -238,7 +239,6 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
                  arena: Optional[GranuleArena] = None) -> None:
     """Lock-step recurrence over all batch-level layers.  `cells[(d, i)]` are kernel-ready parameter
     holders (core.CellParams); gi0[d] [N,3H]; h[d][i] [N, frontier_ld(H)] outputs."""
-    sched = plan.read_schedule()
     args = FrontierArgs()
     mask = 0
     use_tail = arena is not None and TAIL_REPLICAS > 0 and H <= 256
@@ -260,18 +260,20 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     args.num_stacked, args.dir_mask, args.H, args.ld_h, args.vid_mod = L, mask, H, h[dirs[0]][0].shape[1], int(vid_mod)
     args.debug_timing = DEBUG_TIMING.data_ptr() if DEBUG_TIMING is not None else None
     args.num_cus = torch.cuda.get_device_properties(plan.ws.device).multi_processor_count
-    # widest launch: layer t of stacked layer i runs in launch t + i
-    widest = 0
-    for s_ in range(max(len(sched[0]), len(sched[1])) - 1 + L):
-        w = 0
+    # everything above is independent of the schedule: the one device->host read of the forward pass comes
+    # last, so the host-side argument marshalling overlaps the plan / GEMM kernels still in flight
+    sched = plan.read_schedule()
+    if AGG_SPLIT:  # experimental: fat launches aggregate every row once in a separate gather kernel
+        import numpy as np
+        nst = max(len(sched[0]), len(sched[1])) - 1 + L
+        width = np.zeros(nst, dtype=np.int64)
         for d in dirs:
-            for i in range(L):
-                t = s_ - i
-                if 0 <= t < len(sched[d]) - 1:
-                    w += int(sched[d][t + 1] - sched[d][t])
-        widest = max(widest, w)
-    plan.agg_scratch = torch.empty(max(widest, 1) * H, dtype=torch.float32, device=plan.ws.device)
-    args.agg_scratch, args.agg_scratch_rows = plan.agg_scratch.data_ptr(), widest
+            w = np.diff(sched[d].astype(np.int64))
+            for i in range(L):  # layer t of stacked layer i runs in launch t + i
+                width[i:i + len(w)] += w
+        widest = int(width.max())
+        plan.agg_scratch = torch.empty(max(widest, 1) * H, dtype=torch.float32, device=plan.ws.device)
+        args.agg_scratch, args.agg_scratch_rows = plan.agg_scratch.data_ptr(), widest
     args.tail_replicas, args.tail_max_blocks = (TAIL_REPLICAS if use_tail else 0), TAIL_MAX_BLOCKS
     args.epoch, args.tail_err = epoch, _ptr(err)
     ptrs = (C.POINTER(C.c_int32) * 2)()

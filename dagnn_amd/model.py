@@ -188,6 +188,7 @@ class DAGNN(nn.Module):
                     self.graph_pred_linear_list.append(nn.Linear(self.out_hidden_dim, self.num_vocab))
 
         self._derived = {}
+        self._head_cache = DerivedCache()
         self._arenas = {}  # per device: granule buffers of the persistent tail kernel
         self.schedule = default_schedule()  # 'lockstep' (frontier launches) or 'pergraph' (persistent workgroups)
 
@@ -284,4 +285,13 @@ class DAGNN(nn.Module):
         out = self.dropout(out)
         if self.num_class > 0:
             return self.graph_pred_linear(out)
+        if self.num_vocab > 1 and self.max_seq_len > 1 and not torch.is_grad_enabled():
+            # the S vocabulary heads as ONE library GEMM over the concatenated weights (dagnn.py:212-215);
+            # the list entries are views of its output
+            heads = list(self.graph_pred_linear_list)
+            wcat, bcat = self._head_cache.get([p for hd in heads for p in (hd.weight, hd.bias)],
+                                              lambda: (torch.cat([hd.weight for hd in heads], 0),
+                                                       torch.cat([hd.bias for hd in heads], 0)))
+            logits = torch.addmm(bcat, out, wcat.t())
+            return list(logits.split(self.num_vocab, dim=1))
         return [self.graph_pred_linear_list[i](out) for i in range(self.max_seq_len)]

@@ -171,39 +171,40 @@ def main():
             summ = timer.summary()
             lock = model.schedule == "lockstep"
             n_rec, ms_rec = summ.get("frontier_run" if lock else "recurrence_layer", (0, 0.0))
-            launches_per_call = (T + L - 1) if lock else 1
-            calls_per_step = 1 if lock else L
             n_gemm, ms_gemm = summ.get("gemm_nt_bias", (0, 0.0))
             n_plan, ms_plan = summ.get("plan_build", (0, 0.0))
-            # algorithmic work of ONE recurrence launch (one stacked layer, both directions), SURVEY.md §8(d):
-            # hidden-side GEMV 2*H*3H per node-update + attention/gates (2NH + 2EH + 15NH)
-            flops = D * (N * 6.0 * H * H + 2.0 * N * H + 2.0 * E * H + 15.0 * N * H)
-            # compulsory HBM bytes: predecessor rows + own row write ((E+N)*4H), gi read (N*12H), CSR, scores
-            byts = D * ((E + N) * 4.0 * H + N * 12.0 * H + 8.0 * E + 12.0 * N)
+            calls_per_step = 1 if lock else L
+            # algorithmic work of the recurrence per forward(G), SURVEY.md §8(d): hidden-side GEMV 2*H*3H per
+            # node-update + attention/gates (2NH + 2EH + 15NH); with the lock-step schedule the launches also
+            # do the input-side GEMV of stacked layers > 0 (the per-graph schedule leaves it to the batched GEMM)
+            flops = D * L * (N * 6.0 * H * H + 2.0 * N * H + 2.0 * E * H + 15.0 * N * H)
             if lock:
-                # the lock-step launches cover all L stacked layers; layers > 0 also do the input-side GEMV
-                flops = flops * L + D * (L - 1) * N * 6.0 * H * H
-                byts = byts * L
-                # per LAUNCH (one batch-level topological layer, all cells)
-                flops, byts, ms_rec = flops / launches_per_call, byts / launches_per_call, ms_rec / launches_per_call
-            if ms_rec > 0:
-                tf = flops / (ms_rec * 1e-3) / 1e12
+                flops += D * (L - 1) * N * 6.0 * H * H
+            # compulsory HBM bytes: predecessor rows + own row write ((E+N)*4H), gi read (N*12H), CSR, scores
+            byts = D * L * ((E + N) * 4.0 * H + 8.0 * E + 12.0 * N) + D * N * 12.0 * H * (1 if lock else L)
+            ms_fwd = ms_rec * calls_per_step  # recurrence time per forward
+            if ms_fwd > 0:
+                tf = flops / (ms_fwd * 1e-3) / 1e12
+                traffic = None
+                tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+                if lock and os.path.exists(tpath):  # separate rocprofv3 --pmc passes, see profiles/README.md
+                    traffic = json.load(open(tpath)).get("recurrence_hbm_bytes_per_forward")
                 result["roofline"] = {
-                    "kernel": ("frontier_step_kernel (dagnn_frontier_run): one launch = one batch-level topological "
-                               "layer, all (direction, stacked layer) cells; %d launches per forward" %
-                               launches_per_call) if lock else
-                              ("recurrence_kernel<KSL> (dagnn_recurrence_layer): one launch = one stacked GRU layer, "
-                               "both directions, all topological layers"),
+                    "kernel": ("recurrence = frontier_step_kernel (one launch per fat/mid topological layer) + "
+                               "frontier_tail_kernel (one persistent dataflow launch for the thin tail), all "
+                               "(direction, stacked layer) cells; figures are per forward(G)") if lock else
+                              ("recurrence_kernel<KSL> (dagnn_recurrence_layer): %d launches per forward, one per "
+                               "stacked GRU layer, persistent per-(graph, direction) workgroups" % L),
                     "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 5), "traffic": None,
-                    "launches_timed": n_rec * launches_per_call, "avg_launch_ms": round(ms_rec, 6),
-                    "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": byts,
-                    "hbm_frac_of_8TBps": round(byts / (ms_rec * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-                    "us_per_dependent_step": round(ms_rec * 1e3 if lock else ms_rec * 1e3 / max(T, 1), 3),
+                    "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 5), "traffic": traffic,
+                    "forwards_timed": n_rec // calls_per_step, "recurrence_ms_per_forward": round(ms_fwd, 4),
+                    "algorithmic_flops_per_forward": flops, "algorithmic_bytes_per_forward": byts,
+                    "hbm_frac_of_8TBps": round(byts / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                    "us_per_topological_layer": round(ms_fwd * 1e3 / max(T + L - 1, 1), 3),
                     "schedule": model.schedule,
                 }
                 result["kernels_ms_per_step"] = {
-                    "recurrence": round(ms_rec * launches_per_call * n_rec / args.steps, 4),
+                    "recurrence": round(ms_fwd, 4),
                     "gemm_nt_bias": round(ms_gemm * n_gemm / args.steps, 4),
                     "plan_build": round(ms_plan * n_plan / args.steps, 4)}
         if args.cpu_passes > 0:

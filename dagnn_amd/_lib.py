@@ -35,7 +35,7 @@ class LayerArgs(C.Structure):
     _fields_ = [("gi", C.c_void_p * MAX_DIRS), ("w_hh_t", C.c_void_p * MAX_DIRS), ("b_hh", C.c_void_p * MAX_DIRS),
                 ("w_key", C.c_void_p * MAX_DIRS), ("edge_gain", C.c_void_p * MAX_DIRS),
                 ("vid_bias", C.c_void_p * MAX_DIRS), ("h", C.c_void_p * MAX_DIRS), ("score", C.c_void_p * MAX_DIRS),
-                ("vid_mod", C.c_int), ("ld_h", C.c_int), ("debug_timing", C.c_void_p)]
+                ("vid_mod", C.c_int), ("ld_h", C.c_int), ("static_score", C.c_int), ("debug_timing", C.c_void_p)]
 
 
 MAX_STACKED = 8
@@ -44,7 +44,7 @@ MAX_STACKED = 8
 class FrontierCell(C.Structure):
     _fields_ = [("w_hh_pk16", C.c_void_p), ("w_hh_pk32", C.c_void_p), ("w_ih_pk16", C.c_void_p),
                 ("w_ih_pk32", C.c_void_p), ("b_hh", C.c_void_p), ("b_ih", C.c_void_p), ("w_key", C.c_void_p),
-                ("edge_gain", C.c_void_p), ("vid_bias", C.c_void_p), ("gi0", C.c_void_p), ("h_out", C.c_void_p),
+                ("static_score", C.c_void_p), ("edge_gain", C.c_void_p), ("vid_bias", C.c_void_p), ("gi0", C.c_void_p), ("h_out", C.c_void_p),
                 ("granules", C.c_void_p)]
 
 

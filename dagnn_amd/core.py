@@ -71,11 +71,12 @@ class CellParams(object):
     """Device-side, kernel-ready parameters of one (direction, stacked layer) cell."""
 
     __slots__ = ("w_ih", "b_ih", "w_hh_t", "b_hh", "w_key", "edge_gain", "vid_bias", "w_hh_pk", "w_ih_pk",
-                 "b_ih_dev", "Hp")
+                 "b_ih_dev", "Hp", "key_raw")
 
 
 def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: bool,
-                edge_w: Optional[torch.Tensor], vid_nodes: int, schedule: str = "pergraph") -> CellParams:
+                edge_w: Optional[torch.Tensor], vid_nodes: int, schedule: str = "pergraph",
+                key_dim: Optional[int] = None) -> CellParams:
     """Fold / pack one cell's parameters for the kernels.
 
     attn_w is `attn_lin.weight` [1, dq + H (+ vid_nodes)]: the first dq entries multiply the query
@@ -98,16 +99,18 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
     c.w_ih_pk = {js: engine.pack_slices(wi, Hp, js) for js in (16, 32)} if (lock and in_is_hidden) else None
     c.b_ih_dev = c.b_ih if (lock and in_is_hidden) else None
     c.b_hh = _pad_gate_rows(b_hh.detach().float(), H, Hp)
-    key = attn_w.detach().float()[0, dq:dq + H]
-    c.w_key = _pad_cols(key, Hp)
+    kd = H if key_dim is None else key_dim  # keys are hidden states (H) or, for the `*_x` aggregators, inputs
+    key = attn_w.detach().float()[0, dq:dq + kd]
+    c.key_raw = key.contiguous()
+    c.w_key = _pad_cols(key, Hp) if kd == H else None
     c.edge_gain = (edge_w.detach().float().t() @ key).contiguous() if edge_w is not None else None
-    c.vid_bias = attn_w.detach().float()[0, dq + H:dq + H + vid_nodes].contiguous() if vid_nodes else None
+    c.vid_bias = attn_w.detach().float()[0, dq + kd:dq + kd + vid_nodes].contiguous() if vid_nodes else None
     return c
 
 
 def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tuple[int, int], CellParams],
                        dirs: Sequence[int], L: int, H: int, vid_nodes: int = 0,
-                       arena: Optional[engine.GranuleArena] = None) -> List[List[torch.Tensor]]:
+                       arena: Optional[engine.GranuleArena] = None, static_score=None) -> List[List[torch.Tensor]]:
     """Lock-step schedule (default): one batched input GEMM for stacked layer 0 of every direction,
     then T + L - 1 frontier launches covering all cells (csrc/frontier.hip)."""
     Hp = cells[(dirs[0], 0)].Hp
@@ -119,16 +122,18 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
     ld = engine.frontier_ld(Hp)  # state rows carry their H/16 partial attention scores behind the states
     h = [[torch.empty(N, ld, dtype=torch.float32, device=dev) if d in dirs else None for _ in range(L)]
          for d in range(2)]
-    engine.frontier_run(plan, dirs, L, Hp, cells, gi, h, vid_mod=vid_nodes, arena=arena)
+    engine.frontier_run(plan, dirs, L, Hp, cells, gi, h, vid_mod=vid_nodes, arena=arena, static_score=static_score)
     return [[h[d][i][:, :H] if h[d][i] is not None else None for i in range(L)] for d in range(2)]
 
 
 def run_stack(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tuple[int, int], CellParams],
               dirs: Sequence[int], L: int, H: int, vid_nodes: int = 0,
-              schedule: str = "pergraph", arena: Optional[engine.GranuleArena] = None) -> List[List[torch.Tensor]]:
-    """Hidden states h[d][i] ([N, H] each) of all stacked layers and directions."""
+              schedule: str = "pergraph", arena: Optional[engine.GranuleArena] = None,
+              static_score=None) -> List[List[torch.Tensor]]:
+    """Hidden states h[d][i] ([N, H] each) of all stacked layers and directions.  `static_score[(d, i)]`
+    ([N]) replaces the hidden-state attention scores for the aggregators whose keys are the inputs."""
     if schedule == "lockstep":
-        return run_stack_lockstep(plan, x, cells, dirs, L, H, vid_nodes, arena)
+        return run_stack_lockstep(plan, x, cells, dirs, L, H, vid_nodes, arena, static_score)
     Hp = round_up4(H)
     N = x.shape[0]
     dev = x.device
@@ -141,10 +146,11 @@ def run_stack(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tuple[int, i
                             out=[gi[d] for d in dirs])
         pick = lambda name: [getattr(cells[(d, i)], name) if d in dirs else None for d in range(2)]  # noqa: E731
         has_gain = all(cells[(d, i)].edge_gain is not None for d in dirs)
+        sc = score if static_score is None else [static_score[(d, i)] if d in dirs else None for d in range(2)]
         out = engine.recurrence_layer(plan, dirs, Hp, gi, pick("w_hh_t"), pick("b_hh"), pick("w_key"),
                                       edge_gain=pick("edge_gain") if has_gain else None,
                                       vid_bias=pick("vid_bias") if vid_nodes else None, vid_mod=vid_nodes,
-                                      score=score)
+                                      score=sc, static_score=static_score is not None)
         for d in dirs:
             h[d][i] = out[d]
     if Hp != H:

@@ -43,7 +43,8 @@ struct Cell {
     const float4* wih;   // packed input-side slices, or null (stacked layer 0: gi0 instead)
     const float* bhh;    // [3H]
     const float* bih;    // [3H] (only with wih)
-    const float* wkey;   // [H]
+    const float* wkey;   // [H], or null when the scores are static
+    const float* sscore; // [N] static attention score of every node (keys taken from the inputs x), or null
     const float* gain;   // [R] or null
     const float* vid;    // [vid_mod] or null
     const float* gi0;    // [N,3H] precomputed input side (stacked layer 0) or null
@@ -181,7 +182,7 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
                             row0[e] = make_float4(__uint_as_float((unsigned)x0), __uint_as_float((unsigned)x1),
                                                   __uint_as_float((unsigned)x2), __uint_as_float((unsigned)x3));
                         }
-                        if (deg > 1 && lane < nparts) {
+                        if (deg > 1 && !C.sscore && lane < nparts) {
                             const gran_t x = gran_ld(grow + H + lane);
                             ok = ok && (unsigned)(x >> 32) == G.epoch;
                             pv[e] = __uint_as_float((unsigned)x);
@@ -192,8 +193,11 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
             }
             if (deg > 1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (e < deg) for (int q = 0; q < nparts; ++q) sc[e] += __shfl(pv[e], q, 64);  // index order
+                for (int e = 0; e < 4; ++e) {
+                    if (e >= deg) continue;
+                    if (C.sscore) sc[e] = C.sscore[pj[e]];
+                    else for (int q = 0; q < nparts; ++q) sc[e] += __shfl(pv[e], q, 64);  // index order
+                }
             }
         } else {
             // first 64 float4 columns of every predecessor row: issued before the scores are touched so
@@ -205,7 +209,7 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
             if (deg > 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (e < deg) sc[e] = score_of(hsrc + (int64_t)pj[e] * ld_h + H, nparts);
+                    if (e < deg) sc[e] = C.sscore ? C.sscore[pj[e]] : score_of(hsrc + (int64_t)pj[e] * ld_h + H, nparts);
             }
         }
         if (deg > 1) {
@@ -249,7 +253,9 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
     // ---- general path (fan-in > 4): lanes own edges
     auto logit = [&](int e, int cj) {
         float s = 0.f;
-        if (GRAN) {  // this lane's predecessor: its H/16 part granules, summed in index order
+        if (C.sscore) {
+            s = C.sscore[cj];
+        } else if (GRAN) {  // this lane's predecessor: its H/16 part granules, summed in index order
             const gran_t* gp = gsrc + (int64_t)cj * gld + H;
             for (int q = 0; q < nparts; ++q) {
                 gran_t x = gran_ld(gp + q);
@@ -447,7 +453,7 @@ __device__ __forceinline__ void process_block(const int32_t* __restrict__ plan, 
         if (has_in) { pre_r = C.bih[j]; pre_z = C.bih[H + j]; pre_n = C.bih[2 * H + j]; }
         else { const float* g0 = C.gi0 + (int64_t)gv * 3 * H; pre_r = g0[j]; pre_z = g0[H + j]; pre_n = g0[2 * H + j]; }
         bh_r = C.bhh[j]; bh_z = C.bhh[H + j]; bh_n = C.bhh[2 * H + j];
-        wk = C.wkey[j];
+        wk = C.wkey ? C.wkey[j] : 0.f;
     }
 
     // ---- phase B: slice GEMV, K over the 16 lanes of each DPP row
@@ -718,7 +724,7 @@ static void fill_cell(Cell& K, const dagnn_frontier_args* a, const dagnn_plan* p
     const dagnn_frontier_cell& c = a->cell[d][i];
     K.whh = (const float4*)(js == 16 ? c.w_hh_pk16 : c.w_hh_pk32);
     K.wih = i > 0 ? (const float4*)(js == 16 ? c.w_ih_pk16 : c.w_ih_pk32) : nullptr;
-    K.bhh = c.b_hh; K.bih = c.b_ih; K.wkey = c.w_key;
+    K.bhh = c.b_hh; K.bih = c.b_ih; K.wkey = c.w_key; K.sscore = c.static_score;
     K.gain = pl->num_edge_feats > 0 ? c.edge_gain : nullptr;
     K.vid = a->vid_mod > 0 ? c.vid_bias : nullptr;
     K.gi0 = i == 0 ? c.gi0 : nullptr;
@@ -747,7 +753,7 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         if (num_layers[d] > Tmax) Tmax = num_layers[d];
         for (int i = 0; i < Ls; ++i) {
             const dagnn_frontier_cell& c = a->cell[d][i];
-            if (!c.w_hh_pk16 || !c.w_hh_pk32 || !c.b_hh || !c.w_key || !c.h_out) return DAGNN_EINVAL;
+            if (!c.w_hh_pk16 || !c.w_hh_pk32 || !c.b_hh || (!c.w_key && !c.static_score) || !c.h_out) return DAGNN_EINVAL;
             if (i == 0 ? !c.gi0 : (!c.w_ih_pk16 || !c.w_ih_pk32 || !c.b_ih)) return DAGNN_EINVAL;
         }
     }

@@ -35,7 +35,7 @@ struct RecArgs {
     const float* vid[2];
     float* h[2];
     float* score[2];
-    int vid_mod, ld_h, H, R, dir_mask, kper, rmax;
+    int vid_mod, ld_h, H, R, dir_mask, kper, rmax, static_score;
     unsigned long long* dbg;  // optional [8] phase timing of work item 0 (wall_clock64 ticks, 100 MHz)
 };
 
@@ -184,10 +184,12 @@ __device__ __forceinline__ void gates_row(int v, const float* __restrict__ gi, c
         const float n = tanhf(fmaf(r, hn, g[2 * H + j]));
         const float hv = fmaf(z, a - n, n);
         hbuf[(int64_t)v * ld_h + j] = hv;
-        sp = fmaf(wkey[j], hv, sp);
+        if (wkey) sp = fmaf(wkey[j], hv, sp);
     }
-    sp = wave_sum(sp);
-    if (lane == 0) score[v] = vid ? sp + vid[v % vid_mod] : sp;
+    if (wkey) {  // null: the scores are static (keys from the inputs) and were filled in by the caller
+        sp = wave_sum(sp);
+        if (lane == 0) score[v] = vid ? sp + vid[v % vid_mod] : sp;
+    }
 }
 
 template <int KSL>
@@ -214,7 +216,7 @@ __global__ void __launch_bounds__(MAX_WAVES * 64) recurrence_kernel(const int32_
     const float* __restrict__ gi = P.gi[d];
     const float* __restrict__ wt = P.wt[d];
     const float* __restrict__ bhh = P.bhh[d];
-    const float* __restrict__ wkey = P.wkey[d];
+    const float* __restrict__ wkey = P.static_score ? nullptr : P.wkey[d];
     const float* __restrict__ gain = P.gain[d];
     const float* __restrict__ vid = P.vid[d];
     const int R = gain ? P.R : 0;
@@ -280,9 +282,11 @@ extern "C" int dagnn_recurrence_layer(const dagnn_plan* pl, const dagnn_layer_ar
         P.vid[d] = a->vid_mod > 0 ? a->vid_bias[d] : nullptr;
         P.h[d] = a->h[d]; P.score[d] = a->score[d];
         if ((dir_mask >> d) & 1)
-            if (!P.gi[d] || !P.wt[d] || !P.bhh[d] || !P.wkey[d] || !P.h[d] || !P.score[d]) return DAGNN_EINVAL;
+            if (!P.gi[d] || !P.wt[d] || !P.bhh[d] || (!P.wkey[d] && !a->static_score) || !P.h[d] || !P.score[d])
+                return DAGNN_EINVAL;
     }
     P.dbg = (unsigned long long*)a->debug_timing;
+    P.static_score = a->static_score ? 1 : 0;
     P.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
     P.ld_h = a->ld_h; P.H = H; P.R = pl->num_edge_feats; P.dir_mask = dir_mask & 3;
     // K split: the largest KSL whose tile count fits the 12 waves of a workgroup

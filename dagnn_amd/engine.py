@@ -236,7 +236,7 @@ class GranuleArena(object):
 
 
 def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0, h, vid_mod: int = 0,
-                 arena: Optional[GranuleArena] = None) -> None:
+                 arena: Optional[GranuleArena] = None, static_score=None) -> None:
     """Lock-step recurrence over all batch-level layers.  `cells[(d, i)]` are kernel-ready parameter
     holders (core.CellParams); gi0[d] [N,3H]; h[d][i] [N, frontier_ld(H)] outputs."""
     args = FrontierArgs()
@@ -252,7 +252,11 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
             fc.w_hh_pk16, fc.w_hh_pk32 = c.w_hh_pk[16].data_ptr(), c.w_hh_pk[32].data_ptr()
             if c.w_ih_pk is not None:
                 fc.w_ih_pk16, fc.w_ih_pk32 = c.w_ih_pk[16].data_ptr(), c.w_ih_pk[32].data_ptr()
-            fc.b_hh, fc.b_ih, fc.w_key = c.b_hh.data_ptr(), _ptr(c.b_ih_dev), c.w_key.data_ptr()
+            fc.b_hh, fc.b_ih = c.b_hh.data_ptr(), _ptr(c.b_ih_dev)
+            if static_score is not None:
+                fc.static_score = _dev(static_score[(d, i)], "static score", torch.float32).data_ptr()
+            else:
+                fc.w_key = c.w_key.data_ptr()
             fc.edge_gain = _ptr(c.edge_gain) if plan.R > 0 else None
             fc.vid_bias = _ptr(c.vid_bias) if vid_mod > 0 else None
             fc.gi0 = gi0[d].data_ptr() if i == 0 else None
@@ -287,7 +291,8 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
 
 
 def recurrence_layer(plan: PlanHandle, dirs: Sequence[int], H: int, gi, w_hh_t, b_hh, w_key, edge_gain=None,
-                     vid_bias=None, vid_mod: int = 0, out=None, score=None) -> List[Optional[torch.Tensor]]:
+                     vid_bias=None, vid_mod: int = 0, out=None, score=None,
+                     static_score: bool = False) -> List[Optional[torch.Tensor]]:
     """One stacked GRU layer over all topological layers.  Per-direction lists indexed by d."""
     dev = plan.ws.device
     h = [None, None]
@@ -299,14 +304,15 @@ def recurrence_layer(plan: PlanHandle, dirs: Sequence[int], H: int, gi, w_hh_t, 
         h[d] = out[d] if out is not None else torch.empty(plan.N, H, dtype=torch.float32, device=dev)
         sc = score[d] if score is not None else torch.empty(plan.N, dtype=torch.float32, device=dev)
         ts = [_dev(gi[d], "gi", torch.float32), _dev(w_hh_t[d], "w_hh_t", torch.float32),
-              _dev(b_hh[d], "b_hh", torch.float32), _dev(w_key[d], "w_key", torch.float32)]
+              _dev(b_hh[d], "b_hh", torch.float32),
+              sc if static_score else _dev(w_key[d], "w_key", torch.float32)]
         eg = _dev(edge_gain[d], "edge_gain", torch.float32) if (edge_gain is not None and plan.R > 0) else None
         vb = _dev(vid_bias[d], "vid_bias", torch.float32) if (vid_bias is not None and vid_mod > 0) else None
         keep += ts + [eg, vb, sc]
         args.gi[d], args.w_hh_t[d], args.b_hh[d], args.w_key[d] = (t.data_ptr() for t in ts)
         args.edge_gain[d], args.vid_bias[d] = _ptr(eg), _ptr(vb)
         args.h[d], args.score[d] = h[d].data_ptr(), sc.data_ptr()
-    args.vid_mod, args.ld_h = int(vid_mod), H
+    args.vid_mod, args.ld_h, args.static_score = int(vid_mod), H, int(static_score)
     args.debug_timing = DEBUG_TIMING.data_ptr() if DEBUG_TIMING is not None else None
     with _span("recurrence_layer", plan.ws):
         check(_lib.load().dagnn_recurrence_layer(C.byref(plan.desc), C.byref(args), mask, H, _stream(plan.ws)),

@@ -193,8 +193,20 @@ class DAGNN(nn.Module):
         self.schedule = default_schedule()  # 'lockstep' (frontier launches) or 'pergraph' (persistent workgroups)
 
     # ------------------------------------------------------------------------------ helpers
+    # additive-attention aggregators: the logit is w . [query ; key (+ edge)] (+ b); query and bias cancel
+    # inside the segment softmax, so all four reduce to "score of the key + edge gain"
+    _HIP_AGGS = (K.NA_ATTN_H, K.NA_ATTN_X, K.NA_SELF_ATTN_H, K.NA_SELF_ATTN_X)
+
     def _hip_supported(self) -> bool:
-        return self.agg == K.NA_ATTN_H and not self.agg_x and bool(self.recurr)
+        return self.agg in self._HIP_AGGS and not self.agg_x and bool(self.recurr)
+
+    def _attn_geometry(self, i: int):
+        """(offset of the key weights inside attn_lin.weight, key width) for stacked layer i."""
+        key_dim = self.emb_dim if self.agg_attn_x else self.hidden_dim
+        if "self_attn" in self.agg:
+            return 0, key_dim                                   # SelfAttnConv: Linear(attn_dim, 1), no query
+        attn_dim = self.emb_dim if self.agg_attn_x else self.hidden_dim
+        return (self.emb_dim if i == 0 else attn_dim), key_dim  # AttnConv: Linear(attn_q_dim + attn_dim, 1)
 
     def _cells(self):
         srcs: List[torch.Tensor] = []
@@ -212,10 +224,10 @@ class DAGNN(nn.Module):
                 for i in range(self.num_layers):
                     c = getattr(self, "cells_%d" % d)[i]
                     a = getattr(self, "node_aggr_%d" % d)[i]
-                    dq = self.emb_dim if i == 0 else self.hidden_dim
+                    dq, kd = self._attn_geometry(i)
                     out[(d, i)] = derive_cell(c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh, a.attn_lin.weight,
                                               self.hidden_dim, dq, i > 0, a.edge_encoder.weight if a.wea else None, 0,
-                                              schedule=self.schedule)
+                                              schedule=self.schedule, key_dim=kd)
             return out
 
         return self._derived.setdefault(self.schedule, DerivedCache()).get(srcs, make)
@@ -240,8 +252,8 @@ class DAGNN(nn.Module):
     def forward(self, G):
         if not self._hip_supported():
             raise NotImplementedError(
-                "aggregator %r / agg_x=%r / recurr=%r: only agg='attn_h', agg_x=False, recurr=1 is implemented "
-                "in the HIP path so far" % (self.agg, self.agg_x, self.recurr))
+                "aggregator %r / agg_x=%r / recurr=%r: the HIP path implements the additive-attention aggregators "
+                "%s with agg_x=False, recurr=1" % (self.agg, self.agg_x, self.recurr, (self._HIP_AGGS,)))
         require_inference(self)
         L, H, dirs = self.num_layers, self.hidden_dim, self.dirs
 
@@ -255,7 +267,11 @@ class DAGNN(nn.Module):
         has_edge_enc = getattr(self.node_aggr_0[0], "wea", False)
         plan = engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B,
                                  G.edge_attr if has_edge_enc else None)
-        h = run_stack(plan, x, self._cells(), dirs, L, H, schedule=self.schedule,
+        cells = self._cells()
+        sscore = None
+        if self.agg_attn_x:  # keys are the node inputs: one static score per node and cell (dagnn.py:175-177)
+            sscore = {k: torch.mv(x, c.key_raw) for k, c in cells.items()}
+        h = run_stack(plan, x, cells, dirs, L, H, schedule=self.schedule, static_score=sscore,
                       arena=self._arenas.setdefault((x.device, torch.cuda.current_stream(x.device).cuda_stream),
                                                    engine.GranuleArena()))
         G.h = [[h[d][i] for i in range(L)] for d in dirs]  # side effect 4 (dagnn.py:141-142,182)

@@ -140,6 +140,8 @@ typedef struct dagnn_layer_args {
     float* score[DAGNN_MAX_DIRS];
     int vid_mod;
     int ld_h;
+    int static_score;   /* 1: score[d] is an INPUT (w_key . x_v for the `*_x` aggregators whose keys are the node
+                         * inputs, dagnn.py:175-177) and is not rewritten; w_key may then be NULL */
     void* debug_timing; /* NULL, or 8 uint64 device words: per-phase 100 MHz ticks of the deepest work item */
 } dagnn_layer_args;
 
@@ -171,7 +173,9 @@ typedef struct dagnn_frontier_cell {
     const float* w_ih_pk32;
     const float* b_hh;      /* [3H] */
     const float* b_ih;      /* [3H] (stacked layers > 0; layer 0 has it folded into gi0) */
-    const float* w_key;     /* [H] key half of attn_lin.weight */
+    const float* w_key;     /* [H] key half of attn_lin.weight (NULL when static_score is given) */
+    const float* static_score; /* NULL, or [N]: attention score of every node when the keys are the node inputs
+                             * (`attn_x`, `self_attn_x`: w_key . x_v, constant over the recurrence) */
     const float* edge_gain; /* [num_edge_feats] or NULL */
     const float* vid_bias;  /* [vid_mod] or NULL */
     const float* gi0;       /* [N,3H] W_ih x + b_ih (stacked layer 0 only), from dagnn_gemm_nt_bias */

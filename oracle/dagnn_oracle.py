@@ -64,14 +64,16 @@ def segment_softmax(logit: Tensor, seg: Tensor, num_seg: int) -> Tensor:
     return ex / (sm[seg] + 1e-16)
 
 
-def attn_aggregate(h_val: Tensor, key: Tensor, query: Tensor, tgt: Tensor, src: Tensor,
+def attn_aggregate(h_val: Tensor, key: Tensor, query: Optional[Tensor], tgt: Tensor, src: Tensor,
                    attn_w: Tensor, attn_b: Tensor, edge_emb: Optional[Tensor], num_rows: int) -> Tensor:
     """`AttnConv.message` (`dagnn.py:366-373`): logit = attn_lin([q_tgt ; key_src (+ e)]),
-    alpha = softmax over edges sharing a target, out[tgt] += alpha * h_val[src]."""
+    alpha = softmax over edges sharing a target, out[tgt] += alpha * h_val[src].
+    `query=None` is `SelfAttnConv.message` (`dagnn.py:297-310`): logit = attn_lin(key_src (+ e))."""
     k = key[src]
     if edge_emb is not None:
         k = k + edge_emb
-    logit = (torch.cat([query[tgt], k], dim=-1) @ attn_w.t() + attn_b).squeeze(-1)
+    feat = k if query is None else torch.cat([query[tgt], k], dim=-1)
+    logit = (feat @ attn_w.t() + attn_b).squeeze(-1)
     alpha = segment_softmax(logit, tgt, num_rows)
     out = h_val.new_zeros(num_rows, h_val.shape[1])
     return out.index_add_(0, tgt, h_val[src] * alpha.unsqueeze(-1))
@@ -85,9 +87,12 @@ def _vids(n: int, num_nodes: int, like: Tensor) -> Tensor:
 
 
 class _Cfg:
-    def __init__(self, sd, dirs, L, H, cell_prefix, has_edge_enc, vid_nodes):
+    def __init__(self, sd, dirs, L, H, cell_prefix, has_edge_enc, vid_nodes, agg="attn_h"):
         self.sd, self.dirs, self.L, self.H = sd, dirs, L, H
         self.cell_prefix, self.has_edge_enc, self.vid_nodes = cell_prefix, has_edge_enc, vid_nodes
+        # aggregator strings of src/constants.py:12-27 handled here: attn_h, attn_x, self_attn_h, self_attn_x
+        self.keys_from_x = "_x" in agg        # dagnn.py:175-177: h_attn = G.x
+        self.use_query = "self_attn" not in agg
 
     def cell(self, d, i):
         p = "%s%d.%d." % (self.cell_prefix, d, i)
@@ -127,9 +132,12 @@ def recurrence_faithful(cfg: _Cfg, x: Tensor, edge_index: Tensor, edge_attr: Opt
                         vid = _vids(N, cfg.vid_nodes, x)
                         key = torch.cat([hv, vid], -1)
                         q = torch.cat([h[d][i - 1], vid], -1) if i > 0 else x
+                    elif cfg.keys_from_x:
+                        key, q = x, x
                     else:
                         key, q = hv, (h[d][i - 1] if i > 0 else x)
-                    ps = attn_aggregate(hv, key, q, lp[tgt_row], lp[src_row], aw, ab, emb, N)[layer]
+                    ps = attn_aggregate(hv, key, q if cfg.use_query else None, lp[tgt_row], lp[src_row], aw, ab, emb,
+                                        N)[layer]
                 inp = gru_cell(inp, ps, *cfg.cell(d, i))
                 h[d][i][layer] += inp
     return h
@@ -179,15 +187,16 @@ def recurrence_csr(cfg: _Cfg, x: Tensor, edge_index: Tensor, edge_attr: Optional
                 else:
                     aw, ab, ee = cfg.aggr(d, i)
                     hv = h[d][i]
-                    key = hv[src]
-                    qn = (h[d][i - 1] if i > 0 else x)[rows]
+                    key = (x if cfg.keys_from_x else hv)[src]
+                    qn = (x if cfg.keys_from_x else (h[d][i - 1] if i > 0 else x))[rows]
                     if vid is not None:
                         key = torch.cat([key, vid[src]], -1)
                         if i > 0:
                             qn = torch.cat([qn, vid[rows]], -1)
                     if ee is not None:
                         key = key + (ea @ ee[0].t() + ee[1])
-                    logit = (torch.cat([qn[seg], key], -1) @ aw.t() + ab).squeeze(-1)
+                    feat = torch.cat([qn[seg], key], -1) if cfg.use_query else key
+                    logit = (feat @ aw.t() + ab).squeeze(-1)
                     alpha = segment_softmax(logit, seg, p1 - p0)
                     ps = x.new_zeros(p1 - p0, H).index_add_(0, seg, hv[src] * alpha.unsqueeze(-1))
                 inp = gru_cell(inp, ps, *cfg.cell(d, i))
@@ -217,9 +226,9 @@ def _cast(sd, dtype):
 def code2_forward(sd: Dict[str, Tensor], G, *, num_layers: int = 2, bidirectional: bool = True,
                   out_wx: bool = False, out_pool_all: bool = False, out_pool: str = "max",
                   max_seq_len: int = 5, num_class: int = 0, mode: str = "csr",
-                  dtype: torch.dtype = torch.float32):
-    """`DAGNN.forward` of `ogbg-code/model/dagnn.py:128-215` for `agg='attn_h'`, `recurr=1`,
-    `agg_x=False`.  Reproduces the side effects on G (`G.x`, `G.h`, `G.bi_layer_index`, clamped
+                  dtype: torch.dtype = torch.float32, agg: str = "attn_h"):
+    """`DAGNN.forward` of `ogbg-code/model/dagnn.py:128-215` for the additive-attention aggregators
+    (`agg` in attn_h, attn_x, self_attn_h, self_attn_x), `recurr=1`, `agg_x=False`.  Reproduces the side effects on G (`G.x`, `G.h`, `G.bi_layer_index`, clamped
     `G.node_depth`, and `G.batch` on the unidirectional branch).  Returns a list of logits per
     head, or one tensor when `num_class > 0`."""
     sd = _cast(sd, dtype)
@@ -229,7 +238,7 @@ def code2_forward(sd: Dict[str, Tensor], G, *, num_layers: int = 2, bidirectiona
                                     torch.stack([G._bi_layer_idx1, G._bi_layer_index1], 0)], 0)
     G.x = ast_node_encoder(sd, G.x, G.node_depth.view(-1))
     layers = [G.bi_layer_index[0][0], G.bi_layer_index[1][0]]
-    cfg = _Cfg(sd, dirs, num_layers, H, "cells_", "node_aggr_0.0.edge_encoder.weight" in sd, 0)
+    cfg = _Cfg(sd, dirs, num_layers, H, "cells_", "node_aggr_0.0.edge_encoder.weight" in sd, 0, agg)
     ea = G.edge_attr.to(dtype) if getattr(G, "edge_attr", None) is not None else None
     rec = recurrence_faithful if mode == "faithful" else recurrence_csr
     G.h = rec(cfg, G.x, G.edge_index, ea, layers)

@@ -187,6 +187,10 @@ def main():
     # LP-style single classification head (num_class>0, dagnn.py:103-104,209-210)
     make_code2(ref_dagnn, ref_utils, ref_dagutils, "code2_h64_numclass", data_seed=16, B=5, mean_n=30, H=64, L=2,
                bidir=1, w_seed=106, row_stride=1, V=48, S=5, n_attr=300, num_class=17)
+    # the other additive-attention aggregators (src/constants.py:91-94; keys from x / no query)
+    for agg, seed in (("attn_x", 18), ("self_attn_h", 19), ("self_attn_x", 20)):
+        make_code2(ref_dagnn, ref_utils, ref_dagutils, "code2_h64_" + agg, data_seed=seed, B=5, mean_n=30, H=64,
+                   L=2, bidir=1, w_seed=100 + seed, row_stride=1, agg=agg, **common)
     # deep chain stress: long graphs (depth ~ 200) to exercise many recurrent steps
     make_code2(ref_dagnn, ref_utils, ref_dagutils, "code2_h128_deep", data_seed=17, B=3, mean_n=400, H=128, L=2,
                bidir=1, w_seed=107, row_stride=7, **common)

@@ -21,7 +21,8 @@ def test_code2_oracle_matches_reference(name, mode):
     kw = meta["ctor"]
     out = O.code2_forward(model.state_dict(), G, num_layers=kw["num_layers"], bidirectional=bool(kw["bidirectional"]),
                           out_wx=kw["out_wx"], out_pool_all=kw["out_pool_all"], out_pool=kw["out_pool"],
-                          max_seq_len=meta["S"], num_class=kw.get("num_class", 0), mode=mode)
+                          max_seq_len=meta["S"], num_class=kw.get("num_class", 0), mode=mode,
+                          agg=kw.get("agg", "attn_h"))
     out = out if isinstance(out, list) else [out]
     assert len(out) == arr["pred"].shape[0]
     for o, ref in zip(out, arr["pred"]):

@@ -355,6 +355,10 @@ __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x))
 //   RESIDENT  the first weight chunk is already in wh/wi (persistent kernel); rows are published
 //        with write-through (sc1) stores for the other workgroups of the same launch.
 // -----------------------------------------------------------------------------------------------
+// Threads per workgroup: 6 waves own the weight columns of a 32-unit slice; 8-row blocks get 8 waves so that
+// phase A is one row per wave (a second row per wave is a second dependent memory chain).
+template <int RBT> struct WgShape { static constexpr int threads = RBT > 6 ? 512 : FT; };
+
 template <int JS, int RBT, int KW, bool RESIDENT>
 __device__ __forceinline__ void process_block(const int32_t* __restrict__ plan, int64_t rowrec_off, int64_t col_off,
                                               int64_t eattr_off, const Cell& C, bool has_pred, int slot0, int nr,
@@ -405,7 +409,7 @@ __device__ __forceinline__ void process_block(const int32_t* __restrict__ plan, 
     const float* eattr = reinterpret_cast<const float*>(plan + eattr_off);
     const int R = C.gain ? Rfeat : 0;
     const int H4 = H >> 2;
-    for (int r = wave; r < RBT; r += FT / 64) {
+    for (int r = wave; r < RBT; r += WgShape<RBT>::threads / 64) {
         float* a_row = a_s + r * op_ld;
         float* u_row = u_s + r * op_ld;
         if (r < nr) {
@@ -573,7 +577,7 @@ __global__ void __launch_bounds__(256) aggregate_rows_kernel(const int32_t* __re
 
 // ---- launch-per-layer kernel: one launch = one batch-level topological layer, all cells
 template <int JS, int RBT, int KW, int MINW>
-__global__ void __launch_bounds__(FT, MINW) frontier_step_kernel(const int32_t* __restrict__ plan, PlanLayout L, StepArgs S) {
+__global__ void __launch_bounds__(WgShape<RBT>::threads, MINW) frontier_step_kernel(const int32_t* __restrict__ plan, PlanLayout L, StepArgs S) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const bool prof = S.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     unsigned long long* stamp = prof ? S.dbg + 8 * (int64_t)S.step : nullptr;
@@ -701,8 +705,8 @@ template <int JS, int RBT, int KW, int MINW>
 hipError_t launch_step(int blocks, int H, hipStream_t st, const int32_t* plan, const PlanLayout& L, const StepArgs& S) {
     const int op_ld = H + 64;
     const size_t lds = (size_t)(2 * RBT * op_ld + 2 * RBT * 3 * JS) * sizeof(float) + RBT * sizeof(int);
-    hipLaunchKernelGGL((frontier_step_kernel<JS, RBT, KW, MINW>), dim3((unsigned)(blocks * (H / JS))), dim3(FT), lds,
-                       st, plan, L, S);
+    hipLaunchKernelGGL((frontier_step_kernel<JS, RBT, KW, MINW>), dim3((unsigned)(blocks * (H / JS))),
+                       dim3(WgShape<RBT>::threads), lds, st, plan, L, S);
     return hipGetLastError();
 }
 
@@ -805,10 +809,11 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         if (rows_total == 0) continue;
         // Launch shape {slice units, rows per block}: thin launches prefetch a whole 16-unit slice per
         // workgroup (1 workgroup per CU) and must fit ONE round of CUs; otherwise 32-unit slices with
-        // streamed weights, two workgroups per CU, 4-row blocks while they fit one round of slots.
+        // streamed weights: 4-row blocks (96 VGPRs: three 6-wave workgroups per CU) while they fit one
+        // round of slots, else 8-row blocks (125 VGPRs, two per CU).
         int js, rb;
         if (blocks4 * (H / 16) <= a->num_cus) { js = 16; rb = 4; }
-        else if (blocks4 * (H / 32) <= 2 * a->num_cus) { js = 32; rb = 4; }
+        else if (blocks4 * (H / 32) <= 3 * a->num_cus * (a->rb4_rounds > 0 ? a->rb4_rounds : 1)) { js = 32; rb = 4; }
         else if (blocks8 * (H / 16) <= a->num_cus) { js = 16; rb = 8; }
         else { js = 32; rb = 8; }
         int nc = 0, blocks = 0;
@@ -844,7 +849,7 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
             e = hipGetLastError();
             if (e != hipSuccess) return DAGNN_EHIP(e);
         }
-        if (js == 32) e = rb == 8 ? launch_step<32, 8, 4, 3>(blocks, H, st, plan, L, S)
+        if (js == 32) e = rb == 8 ? launch_step<32, 8, 4, 4>(blocks, H, st, plan, L, S)
                                   : launch_step<32, 4, 4, 3>(blocks, H, st, plan, L, S);
         else if (rb == 4) e = launch_step<16, 4, 16, 1>(blocks, H, st, plan, L, S);
         else e = launch_step<16, 8, 16, 1>(blocks, H, st, plan, L, S);

@@ -53,6 +53,7 @@ class _NoSpan(object):
 
 
 TIMER: Optional[KernelTimer] = None  # set by bench.py around its timed region
+RB4_ROUNDS = int(__import__("os").environ.get("DAGNN_AMD_RB4_ROUNDS", "1"))
 AGG_SPLIT = int(__import__("os").environ.get("DAGNN_AMD_AGG_SPLIT", "0"))
 TAIL_REPLICAS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_REPLICAS", "4"))   # 0 = launch every layer
 TAIL_MAX_BLOCKS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_MAX_BLOCKS", "2"))
@@ -264,6 +265,7 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     args.num_stacked, args.dir_mask, args.H, args.ld_h, args.vid_mod = L, mask, H, h[dirs[0]][0].shape[1], int(vid_mod)
     args.debug_timing = DEBUG_TIMING.data_ptr() if DEBUG_TIMING is not None else None
     args.num_cus = torch.cuda.get_device_properties(plan.ws.device).multi_processor_count
+    args.rb4_rounds = RB4_ROUNDS
     # everything above is independent of the schedule: the one device->host read of the forward pass comes
     # last, so the host-side argument marshalling overlaps the plan / GEMM kernels still in flight
     sched = plan.read_schedule()

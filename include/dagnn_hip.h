@@ -192,6 +192,7 @@ typedef struct dagnn_frontier_args {
     int dir_mask;
     int H, ld_h, vid_mod;
     int num_cus;     /* compute units of the device (launch geometry heuristic), e.g. 256 */
+    int rb4_rounds;  /* launches of up to this many rounds of 4-row-block workgroups (3 per CU) use 4-row blocks */
     void* agg_scratch;    /* NULL, or fp32 [agg_scratch_rows, H]: fat launches aggregate every row once into it */
     int agg_scratch_rows; /* >= the largest number of rows (over all cells) of any single launch */
     /* persistent tail: one dataflow launch for all layers after the fat head (needs every cell's

@@ -96,6 +96,10 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--schedule", choices=["lockstep", "pergraph"], default=None,
                     help="recurrence schedule (default: the library default, lock-step frontier launches)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="issue the timed forward passes round-robin on this many HIP streams (independent "
+                         "batches overlap, as in an evaluation loop with a prefetching loader); 1 = strictly "
+                         "one batch after the other (the headline number)")
     ap.add_argument("--cpu-threads", type=int, default=8,
                     help="torch threads for the CPU baseline leg (8 = the thread count BASELINE.md was measured with; "
                          "the op-by-op path is slower with every core of a big host)")
@@ -120,6 +124,9 @@ def main():
     H, L, S, V, B = args.hidden, args.layers, 5, args.vocab, args.batch
     if args.schedule:
         os.environ["DAGNN_AMD_SCHEDULE"] = args.schedule
+    if args.streams > 1:
+        # concurrent persistent tail kernels must all stay co-resident: shrink each one's grid
+        os.environ.setdefault("DAGNN_AMD_TAIL_REPLICAS", str(max(1, 4 // args.streams)))
     model = build_model(H, L, V, S, device)
     batch_cpu = code2_batch(seed=rank, num_graphs=B)  # weak scaling: one B-graph batch per rank
     N, E = batch_cpu.x.shape[0], batch_cpu.edge_index.shape[1]
@@ -131,9 +138,17 @@ def main():
         if world > 1:
             dist.barrier()
 
+    streams = [torch.cuda.Stream(device) for _ in range(args.streams)] if args.streams > 1 else None
+
+    def step(i):
+        if streams is None:
+            return model(inputs[i])
+        with torch.cuda.stream(streams[i % args.streams]):
+            return model(inputs[i])
+
     with torch.no_grad():
         for i in range(args.warmup):
-            out = model(inputs[i])
+            out = step(i)
         torch.cuda.synchronize()
         timer = None if args.no_kernel_timer else engine.KernelTimer()
         engine.TIMER = timer
@@ -141,7 +156,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.warmup, args.warmup + args.steps):
-            out = model(inputs[i])
+            out = step(i)
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
@@ -163,7 +178,8 @@ def main():
                                "bidirectional attn_h, max-pool over output nodes, %d heads x vocab %d, forward(G) "
                                "end-to-end incl. plan build" % (B, H, L, S, V),
                    "global_batch": world * B, "nodes_per_batch": N, "edges_per_batch": E, "topo_layers": T,
-                   "parallelism": "graph-parallel x%d, no data-path collective" % world},
+                   "parallelism": "graph-parallel x%d, no data-path collective" % world,
+                   "streams_per_gpu": args.streams},
     }
     if rank == 0:
         D = 2

@@ -83,20 +83,38 @@ __device__ void block_scan_inplace(int32_t* a, int n, int base, int32_t* lds /* 
     }
 }
 
-// Stable placement of one chunk: thread `tid` holds `key` (or -1); returns its rank among the
-// chunk's earlier threads with the same key, and whether it is the last holder of that key.
-__device__ __forceinline__ void chunk_rank(int key, int32_t* lds_keys, int& rank, bool& last) {
-    const int tid = threadIdx.x;
-    lds_keys[tid] = key;
-    __syncthreads();
-    rank = 0; last = true;
-    if (key >= 0) {
-        for (int j = 0; j < PB; ++j) {
-            int kj = lds_keys[j];
-            if (kj == key) { if (j < tid) ++rank; else if (j > tid) last = false; }
+// Stable placement of one chunk of PB elements: thread `tid` holds `key` (a cursor index, or -1) and
+// gets slot = cur[key] + (number of earlier threads of the chunk with the same key); cur[] advances
+// by the chunk's count per key.  Inside a wave the rank comes from ballots over the wave's distinct
+// keys (AMD has no match-any instruction: one ballot per distinct key, a few dozen at most); the four
+// waves take turns on the cursors so that the order across waves is the thread order.
+__device__ __forceinline__ int chunk_place(int key, int32_t* cur) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int rank = 0, count = 0;
+    bool last = false;
+    unsigned long long todo = __ballot(key >= 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader, 64);
+        const unsigned long long m = __ballot(key == k);
+        if (key == k) {
+            rank = __popcll(m & lt);
+            count = __popcll(m);
+            last = (m >> lane) == 1ull;  // highest lane holding this key
         }
+        todo &= ~m;
     }
-    __syncthreads();
+    int slot = -1;
+    for (int w = 0; w < PB / 64; ++w) {
+        if (wave == w && key >= 0) {
+            const int base = cur[key];  // every lane of the wave reads before the single writer below stores
+            slot = base + rank;
+            if (last) cur[key] = base + count;
+        }
+        __syncthreads();
+    }
+    return slot;
 }
 
 __global__ void __launch_bounds__(PB) plan_graph_kernel(int32_t* plan, PlanLayout L,
@@ -164,16 +182,11 @@ __global__ void __launch_bounds__(PB) plan_graph_kernel(int32_t* plan, PlanLayou
         int v = c0 + tid;
         int key = -1;
         if (v < n1) key = (int)min((int64_t)max((int64_t)layer[v], (int64_t)0), (int64_t)(n - 1));
-        const int base = key >= 0 ? cur[key] : 0;  // read before any holder advances the cursor
-        int rank; bool last;
-        chunk_rank(key, lds, rank, last);
+        const int slot = chunk_place(key, cur);
         if (key >= 0) {
-            int slot = base + rank;
             order[slot] = v;
             pos[v] = slot;
-            if (last) cur[key] = slot + 1;  // single writer per key per chunk
         }
-        __syncthreads();
     }
 
     // ---- rows of the CSR: the node an edge feeds is its target (d=0) or its source (d=1)
@@ -193,17 +206,12 @@ __global__ void __launch_bounds__(PB) plan_graph_kernel(int32_t* plan, PlanLayou
         int e = c0 + tid;
         int key = -1;
         if (e < e1) { int64_t f = feed[e]; if (f >= n0 && f < n1) key = pos[f] - n0; }
-        const int base = key >= 0 ? cur[key] : 0;
-        int rank; bool last;
-        chunk_rank(key, lds, rank, last);
+        const int slot = chunk_place(key, cur);
         if (key >= 0) {
-            int slot = base + rank;
             int64_t o = other[e];
             col[slot] = (int)((o >= n0 && o < n1) ? o : feed[e]);
             for (int r = 0; r < R; ++r) eattr[(int64_t)slot * R + r] = edge_attr[(int64_t)e * R + r];
-            if (last) cur[key] = slot + 1;
         }
-        __syncthreads();
     }
 }
 
@@ -263,38 +271,33 @@ __global__ void __launch_bounds__(1024) plan_blptr_kernel(int32_t* plan, PlanLay
 }
 
 // lbase[g][t] = blptr[t] + rows of layer t in graphs before g (deterministic slot assignment).
-// One thread per layer walks the graphs; per-graph constants are staged in LDS and the layer sizes
-// are loaded 8 graphs ahead so the walk is not a chain of dependent round trips.
+// One WAVE per batch-level layer: lane l takes graphs l, l+64, ...; an exclusive wave scan over the
+// per-graph row counts gives every graph its first slot (two memory round trips per 64 graphs).
 __global__ void __launch_bounds__(256) plan_lbase_kernel(int32_t* plan, PlanLayout L, int N, int B) {
-    __shared__ int32_t s_base[1024], s_depth[1024];
     const int d = blockIdx.y;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int T = plan[L.blptr[d] + N + 1];
-    if ((int)(blockIdx.x * blockDim.x) >= T) return;  // whole block idle
+    if (t >= T) return;
     const int32_t* __restrict__ ls = plan + L.lstart[d];
+    const int32_t* __restrict__ node_ptr = plan + L.node_ptr;
+    const int32_t* __restrict__ depth = plan + L.depth[d];
     int32_t* __restrict__ lb = plan + L.lbase[d];
-    int acc = t < T ? plan[L.blptr[d] + t] : 0;
-    for (int g0 = 0; g0 < B; g0 += 1024) {
-        __syncthreads();
-        for (int j = threadIdx.x; j < 1024 && g0 + j < B; j += blockDim.x) {
-            s_base[j] = plan[L.node_ptr + g0 + j] + g0 + j;
-            s_depth[j] = plan[L.depth[d] + g0 + j];
+    int carry = plan[L.blptr[d] + t];
+    for (int g0 = 0; g0 < B; g0 += 64) {
+        const int g = g0 + lane;
+        int cnt = 0, base = 0;
+        bool has = false;
+        if (g < B && t < depth[g]) {
+            base = node_ptr[g] + g + t;
+            cnt = ls[base + 1] - ls[base];
+            has = true;
         }
-        __syncthreads();
-        const int m = min(1024, B - g0);
-        if (t < T) {
-            for (int j0 = 0; j0 < m; j0 += 8) {
-                int cnt[8];
+        int x = cnt;  // inclusive wave scan
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int j = j0 + u;
-                    cnt[u] = (j < m && t < s_depth[j]) ? ls[s_base[j] + t + 1] - ls[s_base[j] + t] : -1;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (cnt[u] >= 0) { lb[s_base[j0 + u] + t] = acc; acc += cnt[u]; }
-            }
-        }
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (has) lb[base] = carry + x - cnt;
+        carry += __shfl(x, 63, 64);
     }
 }
 
@@ -384,7 +387,7 @@ extern "C" int dagnn_plan_build(const dagnn_plan* pl, const int64_t* edge_index,
         hipLaunchKernelGGL(plan_blptr_kernel, dim3(2), dim3(1024), 0, stream, p, L, (int)N, (int)B);
         DAGNN_CHECK_LAUNCH();
         if (N > 0) {
-            hipLaunchKernelGGL(plan_lbase_kernel, dim3((unsigned)((N + 255) / 256), 2), dim3(256), 0, stream, p, L,
+            hipLaunchKernelGGL(plan_lbase_kernel, dim3((unsigned)((N + 3) / 4), 2), dim3(256), 0, stream, p, L,
                                (int)N, (int)B);
             DAGNN_CHECK_LAUNCH();
             hipLaunchKernelGGL(plan_rowrec_kernel, dim3((unsigned)((N + 255) / 256), 2), dim3(256), 0, stream, p, L,

@@ -43,14 +43,14 @@ MAX_STACKED = 8
 
 class FrontierCell(C.Structure):
     _fields_ = [("w_hh_pk16", C.c_void_p), ("w_hh_pk32", C.c_void_p), ("w_ih_pk16", C.c_void_p),
-                ("w_ih_pk32", C.c_void_p), ("b_hh", C.c_void_p), ("b_ih", C.c_void_p), ("w_key", C.c_void_p),
+                ("w_ih_pk32", C.c_void_p), ("w_hh_mfma", C.c_void_p), ("w_ih_mfma", C.c_void_p), ("b_hh", C.c_void_p), ("b_ih", C.c_void_p), ("w_key", C.c_void_p),
                 ("static_score", C.c_void_p), ("edge_gain", C.c_void_p), ("vid_bias", C.c_void_p), ("gi0", C.c_void_p), ("h_out", C.c_void_p),
                 ("granules", C.c_void_p)]
 
 
 class FrontierArgs(C.Structure):
     _fields_ = [("cell", (FrontierCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
-                ("H", C.c_int), ("ld_h", C.c_int), ("vid_mod", C.c_int), ("num_cus", C.c_int), ("rb4_rounds", C.c_int),
+                ("H", C.c_int), ("ld_h", C.c_int), ("vid_mod", C.c_int), ("num_cus", C.c_int), ("rb4_rounds", C.c_int), ("mfma_min_rows", C.c_int),
                 ("agg_scratch", C.c_void_p), ("agg_scratch_rows", C.c_int),
                 ("tail_replicas", C.c_int), ("tail_max_blocks", C.c_int), ("epoch", C.c_uint),
                 ("tail_err", C.c_void_p), ("debug_timing", C.c_void_p)]
@@ -70,6 +70,7 @@ SYMBOLS = {
     "dagnn_pack_whh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_recurrence_layer": (C.c_int, [C.POINTER(Plan), C.POINTER(LayerArgs), C.c_int, C.c_int, C.c_void_p]),
     "dagnn_pack_slices": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dagnn_pack_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dagnn_frontier_run": (C.c_int, [C.POINTER(Plan), C.POINTER(FrontierArgs), C.POINTER(C.POINTER(C.c_int32)),
                                      C.POINTER(C.c_int32), C.c_void_p]),
     "dagnn_readout_max": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,

@@ -97,6 +97,10 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
     c.w_hh_t = None if lock else engine.pack_whh(whh)
     c.w_hh_pk = {js: engine.pack_slices(whh, Hp, js) for js in (16, 32)} if lock else None
     c.w_ih_pk = {js: engine.pack_slices(wi, Hp, js) for js in (16, 32)} if (lock and in_is_hidden) else None
+    if lock:
+        c.w_hh_pk["mfma"] = engine.pack_mfma(whh, Hp)
+        if in_is_hidden:
+            c.w_ih_pk["mfma"] = engine.pack_mfma(wi, Hp)
     c.b_ih_dev = c.b_ih if (lock and in_is_hidden) else None
     c.b_hh = _pad_gate_rows(b_hh.detach().float(), H, Hp)
     kd = H if key_dim is None else key_dim  # keys are hidden states (H) or, for the `*_x` aggregators, inputs

@@ -41,6 +41,8 @@ constexpr int PU = 16;      // hidden units per stored score part
 struct Cell {
     const float4* whh;   // packed hidden-side slices
     const float4* wih;   // packed input-side slices, or null (stacked layer 0: gi0 instead)
+    const float4* whh_m; // the same matrices in MFMA fragment order (fat launches), or null
+    const float4* wih_m;
     const float* bhh;    // [3H]
     const float* bih;    // [3H] (only with wih)
     const float* wkey;   // [H], or null when the scores are static
@@ -575,6 +577,155 @@ __global__ void __launch_bounds__(256) aggregate_rows_kernel(const int32_t* __re
     }
 }
 
+
+// ---- fat launches, stage 2 on the matrix cores: 32 frontier rows x one 32-unit slice per workgroup.
+// The widest topological layers hold thousands of rows; with 8-row blocks every block re-reads its
+// 98-196 KB weight slice (528 MB of L2->CU traffic for one 2 700-row layer).  Here the aggregates
+// (stage 1, aggregate_rows_kernel) and the nodes' lower-layer rows of 32 rows are staged k-major in
+// LDS and the slice GEMMs [32 x K] x [K x 96] run as v_mfma_f32_32x32x2_f32 chains (exact fp32, the
+// fmaf order is k ascending), one (matrix, gate) chain per wave: 4x fewer weight bytes per row and 4x
+// fewer workgroups.  The B fragments are pre-packed in lane order (dagnn_pack_mfma), 16 B per lane.
+typedef float mf32x16 __attribute__((ext_vector_type(16)));
+constexpr int MT = 32;          // rows per tile
+constexpr int MLD = MT + 1;     // k-major LDS pitch (conflict-free lane == row reads)
+
+__global__ void __launch_bounds__(512, 2) frontier_mfma_kernel(const int32_t* __restrict__ plan, PlanLayout L, StepArgs S) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = S.H, ld_h = S.ld_h, NS = H / 32;
+    const int sl = blockIdx.x % NS;
+    const int gb = blockIdx.x / NS;
+    int c = 0;
+    while (c + 1 < S.ncell && gb >= S.blk_start[c + 1]) ++c;   // blk_start = 32-row tile prefix sums
+    const Cell& C = S.cell[c];
+    const int slot0 = C.row_base + (gb - S.blk_start[c]) * MT;
+    const int nr = min(MT, C.row_end - slot0);
+    const int d = C.dir;
+    const bool has_in = C.wih_m != nullptr;
+    const bool has_pred = C.has_pred != 0;
+
+    float* a_t = smem;                    // [H][MLD]  aggregates, k-major
+    float* u_t = a_t + H * MLD;           // [H][MLD]  own lower-layer rows, k-major; later the GEMM outputs
+    int* v_s = reinterpret_cast<int*>(u_t + H * MLD);  // [MT] node ids
+    float* g_s = u_t;                     // [2][MT][96] after the MFMA phase (u_t is dead by then)
+
+    const int4* __restrict__ recs = reinterpret_cast<const int4*>(plan + L.rowrec[d]);
+    if (tid < MT) v_s[tid] = tid < nr ? recs[4 * (int64_t)(slot0 + tid)].x : 0;
+    __syncthreads();
+
+    // ---- stage the operands k-major: wave w copies rows w, w+8, ... (coalesced float4 row reads)
+    const int H4 = H >> 2;
+    for (int r = wave; r < MT; r += 8) {
+        const bool live = r < nr;
+        const float4* ap = reinterpret_cast<const float4*>(C.a_pre + (int64_t)(slot0 + r - C.row_base) * H);
+        const float4* up = has_in ? reinterpret_cast<const float4*>(C.h_in + (int64_t)v_s[r] * ld_h) : nullptr;
+        for (int cc = lane; cc < H4; cc += 64) {
+            const float4 av = live ? ap[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
+            a_t[(4 * cc + 0) * MLD + r] = av.x; a_t[(4 * cc + 1) * MLD + r] = av.y;
+            a_t[(4 * cc + 2) * MLD + r] = av.z; a_t[(4 * cc + 3) * MLD + r] = av.w;
+            if (has_in) {
+                const float4 uv = live ? up[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
+                u_t[(4 * cc + 0) * MLD + r] = uv.x; u_t[(4 * cc + 1) * MLD + r] = uv.y;
+                u_t[(4 * cc + 2) * MLD + r] = uv.z; u_t[(4 * cc + 3) * MLD + r] = uv.w;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- MFMA chains: wave = matrix * 3 + gate (waves 6, 7 only help staging and the gates)
+    mf32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int mat = wave / 3, gate = wave - mat * 3;
+    const bool chain = wave < 6 && (mat == 0 ? has_pred : has_in);
+    if (chain) {
+        const float* op = mat == 0 ? a_t : u_t;
+        const float4* wp = (mat == 0 ? C.whh_m : C.wih_m) + ((int64_t)(sl * 3 + gate) * (H / 8)) * 64 + lane;
+        const int arow = lane & 31, ak = lane >> 5;
+        for (int k8 = 0; k8 < H / 8; k8 += 4) {   // 4 x 16 B of B fragments in flight per lane
+            float4 w4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w4[q] = wp[(int64_t)(k8 + q) * 64];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kb = 8 * (k8 + q) + ak;   // this lane's k for the first of the 4 MFMAs of this fragment
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[(kb + 0) * MLD + arow], w4[q].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[(kb + 2) * MLD + arow], w4[q].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[(kb + 4) * MLD + arow], w4[q].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[(kb + 6) * MLD + arow], w4[q].w, acc, 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();   // every chain has read u_t: it can now hold the outputs
+    if (wave < 6) {
+        // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+        float* out = g_s + mat * (MT * 96) + gate * 32 + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * 96] = acc[e];
+    }
+    __syncthreads();
+
+    // ---- gates: 32 rows x 32 units, two elements per thread; 16 consecutive lanes = 16 units of a row
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int id = p * 512 + tid;
+        const int r = id >> 5, jj = id & 31;
+        const bool live = r < nr;
+        float sp = 0.f, hv = 0.f;
+        const int gv = live ? v_s[r] : 0;
+        const int j = sl * 32 + jj;
+        if (live) {
+            float gr, gz, gn;
+            if (has_in) {
+                const float* gi = g_s + MT * 96 + r * 96;
+                gr = gi[jj] + C.bih[j]; gz = gi[32 + jj] + C.bih[H + j]; gn = gi[64 + jj] + C.bih[2 * H + j];
+            } else {
+                const float* g0 = C.gi0 + (int64_t)gv * 3 * H;
+                gr = g0[j]; gz = g0[H + j]; gn = g0[2 * H + j];
+            }
+            const float* gh = g_s + r * 96;
+            const float hr = gh[jj] + C.bhh[j], hz = gh[32 + jj] + C.bhh[H + j], hn = gh[64 + jj] + C.bhh[2 * H + j];
+            const float a = a_t[j * MLD + r];
+            const float rg = sigm(gr + hr);
+            const float zg = sigm(gz + hz);
+            const float ng = tanhf(fmaf(rg, hn, gn));
+            hv = fmaf(zg, a - ng, ng);
+            sp = (C.wkey ? C.wkey[j] : 0.f) * hv;
+        }
+        sp = dpp_row_sum16(sp);
+        if (live) {
+            float* po = C.h_out + (int64_t)gv * ld_h;
+            po[j] = hv;
+            if ((tid & 15) == 15) po[H + (j >> 4)] = sp;
+            if (C.g_out) {
+                gran_t* pg = C.g_out + (int64_t)gv * (H + H / PU);
+                pg[j] = gran_pack(S.epoch, hv);
+                if ((tid & 15) == 15) pg[H + (j >> 4)] = gran_pack(S.epoch, sp);
+            }
+        }
+    }
+}
+
+// Pack W [3H, K] (torch layout) into MFMA B-fragment order for 32-unit slices:
+// out[((sl * 3 + g) * (K/8) + k8) * 64 + lane] (float4): element q = W[g*H + sl*32 + (lane & 31)][8*k8 + 2*q + (lane >> 5)],
+// i.e. the B operand of the q-th of four consecutive v_mfma_f32_32x32x2_f32 (k pair 2*(4*k8+q)).
+__global__ void __launch_bounds__(256) pack_mfma_kernel(const float* __restrict__ W, float4* __restrict__ out, int H,
+                                                         int K, int64_t total) {
+    const int k8n = K >> 3;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        int64_t rest = idx >> 6;
+        const int k8 = (int)(rest % k8n); rest /= k8n;
+        const int g = (int)(rest % 3);
+        const int sl = (int)(rest / 3);
+        const int64_t row = (int64_t)g * H + sl * 32 + (lane & 31);
+        const int k = 8 * k8 + (lane >> 5);
+        out[idx] = make_float4(W[row * K + k], W[row * K + k + 2], W[row * K + k + 4], W[row * K + k + 6]);
+    }
+}
+
 // ---- launch-per-layer kernel: one launch = one batch-level topological layer, all cells
 template <int JS, int RBT, int KW, int MINW>
 __global__ void __launch_bounds__(WgShape<RBT>::threads, MINW) frontier_step_kernel(const int32_t* __restrict__ plan, PlanLayout L, StepArgs S) {
@@ -728,6 +879,8 @@ static void fill_cell(Cell& K, const dagnn_frontier_args* a, const dagnn_plan* p
     const dagnn_frontier_cell& c = a->cell[d][i];
     K.whh = (const float4*)(js == 16 ? c.w_hh_pk16 : c.w_hh_pk32);
     K.wih = i > 0 ? (const float4*)(js == 16 ? c.w_ih_pk16 : c.w_ih_pk32) : nullptr;
+    K.whh_m = (const float4*)c.w_hh_mfma;
+    K.wih_m = i > 0 ? (const float4*)c.w_ih_mfma : nullptr;
     K.bhh = c.b_hh; K.bih = c.b_ih; K.wkey = c.w_key; K.sscore = c.static_score;
     K.gain = pl->num_edge_feats > 0 ? c.edge_gain : nullptr;
     K.vid = a->vid_mod > 0 ? c.vid_bias : nullptr;
@@ -738,6 +891,17 @@ static void fill_cell(Cell& K, const dagnn_frontier_args* a, const dagnn_plan* p
     K.g_in = i > 0 ? (const gran_t*)a->cell[d][i - 1].granules : nullptr;
     K.a_pre = nullptr;
     K.dir = d; K.row_base = 0; K.row_end = 0; K.has_pred = 0;
+}
+
+extern "C" int dagnn_pack_mfma(const float* w, float* out, int H, int K, void* stream) {
+    if (!w || !out || H <= 0 || K <= 0 || (H % 32) || (K % 8)) return DAGNN_EINVAL;
+    const int64_t total = (int64_t)3 * H * K / 4;  // float4 elements
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pack_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<float4*>(out), H, K, total);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
 }
 
 extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_args* a, const int32_t* const* layer_ptr,
@@ -833,21 +997,33 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         S.ncell = nc;
         S.step = s;
         hipError_t e;
-        const bool split = js == 32 && rb == 8 && a->agg_scratch != nullptr && rows_total <= a->agg_scratch_rows;
-        if (split) {
-            // fat launch: stage 1 aggregates every row once into the scratch, stage 2 does the slices
+        // the fattest launches: aggregate every row once (stage 1), then 32-row MFMA tiles (stage 2)
+        bool mfma_ok = a->agg_scratch != nullptr && rows_total <= a->agg_scratch_rows && H <= 256 &&
+                       a->mfma_min_rows > 0 && rows_total >= a->mfma_min_rows;
+        for (int k = 0; k < nc && mfma_ok; ++k)
+            mfma_ok = S.cell[k].whh_m != nullptr && (S.cell[k].wih == nullptr || S.cell[k].wih_m != nullptr);
+        if (mfma_ok) {
             StepArgs A = S;
-            int off = 0;
+            int off = 0, tiles = 0;
             for (int k = 0; k < nc; ++k) {
+                const int n = S.cell[k].row_end - S.cell[k].row_base;
                 A.cell[k].a_pre = (const float*)a->agg_scratch + (int64_t)off * H;
                 S.cell[k].a_pre = A.cell[k].a_pre;
                 A.blk_start[k] = off;
-                off += A.cell[k].row_end - A.cell[k].row_base;
+                S.blk_start[k] = tiles;
+                off += n;
+                tiles += (n + MT - 1) / MT;
             }
             A.blk_start[nc] = off;
+            S.blk_start[nc] = tiles;
             hipLaunchKernelGGL(aggregate_rows_kernel, dim3((unsigned)((off + 3) / 4)), dim3(256), 0, st, plan, L, A);
             e = hipGetLastError();
             if (e != hipSuccess) return DAGNN_EHIP(e);
+            const size_t lds = (size_t)(2 * H * MLD) * sizeof(float) + MT * sizeof(int);
+            hipLaunchKernelGGL(frontier_mfma_kernel, dim3((unsigned)(tiles * (H / 32))), dim3(512), lds, st, plan, L, S);
+            e = hipGetLastError();
+            if (e != hipSuccess) return DAGNN_EHIP(e);
+            continue;
         }
         if (js == 32) e = rb == 8 ? launch_step<32, 8, 4, 4>(blocks, H, st, plan, L, S)
                                   : launch_step<32, 4, 4, 3>(blocks, H, st, plan, L, S);

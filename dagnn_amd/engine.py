@@ -54,6 +54,7 @@ class _NoSpan(object):
 
 TIMER: Optional[KernelTimer] = None  # set by bench.py around its timed region
 RB4_ROUNDS = int(__import__("os").environ.get("DAGNN_AMD_RB4_ROUNDS", "1"))
+MFMA_MIN_ROWS = int(__import__("os").environ.get("DAGNN_AMD_MFMA_MIN_ROWS", "800"))  # 0 = never use MFMA tiles
 AGG_SPLIT = int(__import__("os").environ.get("DAGNN_AMD_AGG_SPLIT", "0"))
 TAIL_REPLICAS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_REPLICAS", "4"))   # 0 = launch every layer
 TAIL_MAX_BLOCKS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_MAX_BLOCKS", "2"))
@@ -204,6 +205,14 @@ def pack_slices(w: torch.Tensor, H: int, slice_units: int) -> torch.Tensor:
     return out
 
 
+def pack_mfma(w: torch.Tensor, H: int) -> torch.Tensor:
+    """[3H, K] (torch layout) -> MFMA B-fragment order of the 32-row tile kernel."""
+    w = _dev(w, "weight", torch.float32)
+    out = torch.empty(3 * H * w.shape[1], dtype=torch.float32, device=w.device)
+    check(_lib.load().dagnn_pack_mfma(w.data_ptr(), out.data_ptr(), H, w.shape[1], _stream(w)), "dagnn_pack_mfma")
+    return out
+
+
 def frontier_ld(H: int) -> int:
     """Row pitch of the lock-step state buffers: H states + H/16 partial scores, 16-byte multiple."""
     return H + (H // 16 + 3) // 4 * 4
@@ -251,8 +260,10 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
             c, fc = cells[(d, i)], args.cell[d][i]
             fc.granules = gran[(d, i)].data_ptr() if use_tail else None
             fc.w_hh_pk16, fc.w_hh_pk32 = c.w_hh_pk[16].data_ptr(), c.w_hh_pk[32].data_ptr()
+            fc.w_hh_mfma = c.w_hh_pk["mfma"].data_ptr()
             if c.w_ih_pk is not None:
                 fc.w_ih_pk16, fc.w_ih_pk32 = c.w_ih_pk[16].data_ptr(), c.w_ih_pk[32].data_ptr()
+                fc.w_ih_mfma = c.w_ih_pk["mfma"].data_ptr()
             fc.b_hh, fc.b_ih = c.b_hh.data_ptr(), _ptr(c.b_ih_dev)
             if static_score is not None:
                 fc.static_score = _dev(static_score[(d, i)], "static score", torch.float32).data_ptr()
@@ -269,7 +280,8 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     # everything above is independent of the schedule: the one device->host read of the forward pass comes
     # last, so the host-side argument marshalling overlaps the plan / GEMM kernels still in flight
     sched = plan.read_schedule()
-    if AGG_SPLIT:  # experimental: fat launches aggregate every row once in a separate gather kernel
+    args.mfma_min_rows = MFMA_MIN_ROWS
+    if AGG_SPLIT or MFMA_MIN_ROWS > 0:  # fat launches aggregate every row once in a separate gather kernel
         import numpy as np
         nst = max(len(sched[0]), len(sched[1])) - 1 + L
         width = np.zeros(nst, dtype=np.int64)

@@ -166,11 +166,17 @@ int dagnn_recurrence_layer(const dagnn_plan* plan /* host */, const dagnn_layer_
 int dagnn_pack_slices(const float* w /* [3H,K] */, float* out /* 3H*K floats */, int H, int K, int slice_units,
                       void* stream);
 
+/* W [3H,K] -> B-fragment order of v_mfma_f32_32x32x2_f32 for 32-unit slices (3H*K floats out); used by
+ * the 32-row tiles of the fattest launches. */
+int dagnn_pack_mfma(const float* w /* [3H,K] */, float* out, int H, int K, void* stream);
+
 typedef struct dagnn_frontier_cell {
     const float* w_hh_pk16; /* weight_hh packed for 16-unit slices */
     const float* w_hh_pk32; /* ... and for 32-unit slices */
     const float* w_ih_pk16; /* weight_ih (stacked layers > 0), else NULL */
     const float* w_ih_pk32;
+    const float* w_hh_mfma; /* weight_hh in MFMA fragment order (dagnn_pack_mfma), or NULL: no MFMA tiles */
+    const float* w_ih_mfma; /* weight_ih likewise (stacked layers > 0) */
     const float* b_hh;      /* [3H] */
     const float* b_ih;      /* [3H] (stacked layers > 0; layer 0 has it folded into gi0) */
     const float* w_key;     /* [H] key half of attn_lin.weight (NULL when static_score is given) */
@@ -193,6 +199,7 @@ typedef struct dagnn_frontier_args {
     int H, ld_h, vid_mod;
     int num_cus;     /* compute units of the device (launch geometry heuristic), e.g. 256 */
     int rb4_rounds;  /* launches of up to this many rounds of 4-row-block workgroups (3 per CU) use 4-row blocks */
+    int mfma_min_rows;    /* launches with at least this many rows (all cells) run as 32-row MFMA tiles; 0 = never */
     void* agg_scratch;    /* NULL, or fp32 [agg_scratch_rows, H]: fat launches aggregate every row once into it */
     int agg_scratch_rows; /* >= the largest number of rows (over all cells) of any single launch */
     /* persistent tail: one dataflow launch for all layers after the fat head (needs every cell's

@@ -195,6 +195,31 @@ def test_dvae_encode_matches_reference_golden(device, name, schedule):
     assert Hh.maxdiff(mu2, arr["mu"]) < TOL and Hh.maxdiff(lv2, arr["logvar"]) < TOL
 
 
+@pytest.mark.parametrize("name", ["code2_h256_bidir", "code2_h64_unidir", "code2_h128_deep", "code2_h64_attn_x"])
+@pytest.mark.parametrize("knob", ["mfma_tiles", "no_tail", "agg_split"])
+def test_launch_shape_variants_match_reference_golden(device, name, knob, monkeypatch):
+    """Force the code paths the small fixtures would not reach on their own: 32-row MFMA tiles for
+    every launch, every layer as its own launch (no persistent tail), the separate gather kernel."""
+    monkeypatch.setenv("DAGNN_AMD_SCHEDULE", "lockstep")
+    if knob == "mfma_tiles":
+        monkeypatch.setattr(engine, "MFMA_MIN_ROWS", 1)
+        monkeypatch.setattr(engine, "TAIL_REPLICAS", 0)
+    elif knob == "no_tail":
+        monkeypatch.setattr(engine, "TAIL_REPLICAS", 0)
+        monkeypatch.setattr(engine, "MFMA_MIN_ROWS", 0)
+    else:
+        monkeypatch.setattr(engine, "AGG_SPLIT", 1)
+        monkeypatch.setattr(engine, "MFMA_MIN_ROWS", 0)
+    meta, arr = Hh.load(name)
+    model = Hh.code2_model(meta).to(device)
+    G = Hh.code2_batch(arr, device)
+    with torch.no_grad():
+        out = model(G)
+    out = out if isinstance(out, list) else [out]
+    for o, ref in zip(out, arr["pred"]):
+        assert Hh.maxdiff(o, ref) < TOL
+
+
 # ----------------------------------------------------------------------------- oracle at scale
 def _headline_model(H=256, L=2, V=64, seed=0):
     from dagnn_amd import DAGNN, ASTNodeEncoder

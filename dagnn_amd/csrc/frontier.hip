@@ -607,8 +607,8 @@ __global__ void __launch_bounds__(512, 2) frontier_mfma_kernel(const int32_t* __
 
     float* a_t = smem;                    // [H][MLD]  aggregates, k-major
     float* u_t = a_t + H * MLD;           // [H][MLD]  own lower-layer rows, k-major; later the GEMM outputs
-    int* v_s = reinterpret_cast<int*>(u_t + H * MLD);  // [MT] node ids
     float* g_s = u_t;                     // [2][MT][96] after the MFMA phase (u_t is dead by then)
+    int* v_s = reinterpret_cast<int*>(u_t + max(H * MLD, 2 * MT * 96));  // [MT] node ids
 
     const int4* __restrict__ recs = reinterpret_cast<const int4*>(plan + L.rowrec[d]);
     if (tid < MT) v_s[tid] = tid < nr ? recs[4 * (int64_t)(slot0 + tid)].x : 0;
@@ -1019,7 +1019,8 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
             hipLaunchKernelGGL(aggregate_rows_kernel, dim3((unsigned)((off + 3) / 4)), dim3(256), 0, st, plan, L, A);
             e = hipGetLastError();
             if (e != hipSuccess) return DAGNN_EHIP(e);
-            const size_t lds = (size_t)(2 * H * MLD) * sizeof(float) + MT * sizeof(int);
+            const size_t lds = (size_t)(H * MLD + (H * MLD > 2 * MT * 96 ? H * MLD : 2 * MT * 96)) * sizeof(float) +
+                               MT * sizeof(int);
             hipLaunchKernelGGL(frontier_mfma_kernel, dim3((unsigned)(tiles * (H / 32))), dim3(512), lds, st, plan, L, S);
             e = hipGetLastError();
             if (e != hipSuccess) return DAGNN_EHIP(e);

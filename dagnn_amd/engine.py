@@ -54,7 +54,7 @@ class _NoSpan(object):
 
 TIMER: Optional[KernelTimer] = None  # set by bench.py around its timed region
 RB4_ROUNDS = int(__import__("os").environ.get("DAGNN_AMD_RB4_ROUNDS", "1"))
-MFMA_MIN_ROWS = int(__import__("os").environ.get("DAGNN_AMD_MFMA_MIN_ROWS", "800"))  # 0 = never use MFMA tiles
+MFMA_MIN_ROWS = int(__import__("os").environ.get("DAGNN_AMD_MFMA_MIN_ROWS", "400"))  # 0 = never use MFMA tiles
 AGG_SPLIT = int(__import__("os").environ.get("DAGNN_AMD_AGG_SPLIT", "0"))
 TAIL_REPLICAS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_REPLICAS", "4"))   # 0 = launch every layer
 TAIL_MAX_BLOCKS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_MAX_BLOCKS", "2"))

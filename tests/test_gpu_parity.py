@@ -260,7 +260,10 @@ def test_headline_properties(device, schedule):
     assert len(shards) == 8 and sum(s.num_graphs for s in shards) == 128
     with torch.no_grad():
         parts = [torch.stack(model(s.to(device))) for s in shards]
-    assert torch.equal(torch.cat(parts, dim=1), out_a)
+    # a shard is narrower than the full batch, so some of its layers take a different launch shape (fp32
+    # FMA slices instead of fp32 MFMA tiles: same products, different summation order) - equal to
+    # rounding, not bitwise
+    assert Hh.maxdiff(torch.cat(parts, dim=1), out_a) < 2e-5
     # reversing the graph order permutes the rows and nothing else
     rev = synth.GraphBatch.from_data_list(graphs[::-1])
     with torch.no_grad():

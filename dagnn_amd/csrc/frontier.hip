@@ -939,7 +939,7 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
     // than its replicas cover in `tail_max_blocks` blocks of 8.  Needs the whole slice in registers
     // (H <= 256), line-aligned state rows (ld_h % 32 == 0) and a sync workspace.
     int s_tail = nsteps;
-    const int tail_js = 32, tail_rb = 4;
+    const int tail_js = a->tail_slice_units == 16 ? 16 : 32, tail_rb = 4;
     int nrep = a->tail_replicas > 0 ? a->tail_replicas : 0;
     const int tail_wgs = ndir * Ls * (H / tail_js) * (nrep > 0 ? nrep : 1);
     bool tail_ok = nrep > 0 && a->tail_err && a->epoch != 0 && H <= 256 && tail_wgs <= a->num_cus / 2;
@@ -1048,7 +1048,10 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         T.dbg = (unsigned long long*)a->debug_timing;
         const int op_ld = H + 64;
         const size_t lds = (size_t)(2 * tail_rb * op_ld + 2 * tail_rb * 3 * tail_js) * sizeof(float) + tail_rb * sizeof(int);
-        hipLaunchKernelGGL((frontier_tail_kernel<32, 4, 16>), dim3((unsigned)tail_wgs), dim3(FT), lds, st, plan, L, T);
+        if (tail_js == 16)
+            hipLaunchKernelGGL((frontier_tail_kernel<16, 4, 16>), dim3((unsigned)tail_wgs), dim3(FT), lds, st, plan, L, T);
+        else
+            hipLaunchKernelGGL((frontier_tail_kernel<32, 4, 16>), dim3((unsigned)tail_wgs), dim3(FT), lds, st, plan, L, T);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return DAGNN_EHIP(e);
     }

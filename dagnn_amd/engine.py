@@ -56,6 +56,7 @@ TIMER: Optional[KernelTimer] = None  # set by bench.py around its timed region
 RB4_ROUNDS = int(__import__("os").environ.get("DAGNN_AMD_RB4_ROUNDS", "1"))
 MFMA_MIN_ROWS = int(__import__("os").environ.get("DAGNN_AMD_MFMA_MIN_ROWS", "400"))  # 0 = never use MFMA tiles
 AGG_SPLIT = int(__import__("os").environ.get("DAGNN_AMD_AGG_SPLIT", "0"))
+TAIL_SLICE = int(__import__("os").environ.get("DAGNN_AMD_TAIL_SLICE", "32"))
 TAIL_REPLICAS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_REPLICAS", "4"))   # 0 = launch every layer
 TAIL_MAX_BLOCKS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_MAX_BLOCKS", "2"))
 DEBUG_TIMING: Optional[torch.Tensor] = None  # int64[8] device tensor: phase ticks of the deepest work item
@@ -293,6 +294,7 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
         plan.agg_scratch = torch.empty(max(widest, 1) * H, dtype=torch.float32, device=plan.ws.device)
         args.agg_scratch, args.agg_scratch_rows = plan.agg_scratch.data_ptr(), widest
     args.tail_replicas, args.tail_max_blocks = (TAIL_REPLICAS if use_tail else 0), TAIL_MAX_BLOCKS
+    args.tail_slice_units = TAIL_SLICE
     args.epoch, args.tail_err = epoch, _ptr(err)
     ptrs = (C.POINTER(C.c_int32) * 2)()
     nl = (C.c_int32 * 2)()

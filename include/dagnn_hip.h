@@ -205,6 +205,7 @@ typedef struct dagnn_frontier_args {
     /* persistent tail: one dataflow launch for all layers after the fat head (needs every cell's
      * `granules`, epoch != 0 and H <= 256): */
     int tail_replicas;   /* workgroups per (cell, slice) in the tail kernel; 0 disables it */
+    int tail_slice_units; /* 16 or 32 hidden units per tail workgroup (32 if anything else) */
     int tail_max_blocks; /* a layer may have up to 4 * tail_replicas * tail_max_blocks rows per cell in the tail */
     unsigned epoch;      /* tag of this forward pass in the granule buffers: nonzero, larger than any used before */
     void* tail_err;      /* device int32: set to 1 if a bounded wait in the tail kernel ever expires */

@@ -588,6 +588,7 @@ __global__ void __launch_bounds__(256) aggregate_rows_kernel(const int32_t* __re
 typedef float mf32x16 __attribute__((ext_vector_type(16)));
 constexpr int MT = 32;          // rows per tile
 constexpr int MLD = MT + 1;     // k-major LDS pitch (conflict-free lane == row reads)
+constexpr int MKC = 256;        // K chunk staged in LDS at a time
 
 __global__ void __launch_bounds__(512, 2) frontier_mfma_kernel(const int32_t* __restrict__ plan, PlanLayout L, StepArgs S) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -605,55 +606,59 @@ __global__ void __launch_bounds__(512, 2) frontier_mfma_kernel(const int32_t* __
     const bool has_in = C.wih_m != nullptr;
     const bool has_pred = C.has_pred != 0;
 
-    float* a_t = smem;                    // [H][MLD]  aggregates, k-major
-    float* u_t = a_t + H * MLD;           // [H][MLD]  own lower-layer rows, k-major; later the GEMM outputs
+    const int KC = min(H, MKC);           // K is staged through LDS in chunks of <= MKC
+    float* a_t = smem;                    // [KC][MLD]  aggregates, k-major
+    float* u_t = a_t + KC * MLD;          // [KC][MLD]  own lower-layer rows, k-major; later the GEMM outputs
     float* g_s = u_t;                     // [2][MT][96] after the MFMA phase (u_t is dead by then)
-    int* v_s = reinterpret_cast<int*>(u_t + max(H * MLD, 2 * MT * 96));  // [MT] node ids
+    int* v_s = reinterpret_cast<int*>(u_t + max(KC * MLD, 2 * MT * 96));  // [MT] node ids
 
     const int4* __restrict__ recs = reinterpret_cast<const int4*>(plan + L.rowrec[d]);
     if (tid < MT) v_s[tid] = tid < nr ? recs[4 * (int64_t)(slot0 + tid)].x : 0;
     __syncthreads();
 
-    // ---- stage the operands k-major: wave w copies rows w, w+8, ... (coalesced float4 row reads)
-    const int H4 = H >> 2;
-    for (int r = wave; r < MT; r += 8) {
-        const bool live = r < nr;
-        const float4* ap = reinterpret_cast<const float4*>(C.a_pre + (int64_t)(slot0 + r - C.row_base) * H);
-        const float4* up = has_in ? reinterpret_cast<const float4*>(C.h_in + (int64_t)v_s[r] * ld_h) : nullptr;
-        for (int cc = lane; cc < H4; cc += 64) {
-            const float4 av = live ? ap[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
-            a_t[(4 * cc + 0) * MLD + r] = av.x; a_t[(4 * cc + 1) * MLD + r] = av.y;
-            a_t[(4 * cc + 2) * MLD + r] = av.z; a_t[(4 * cc + 3) * MLD + r] = av.w;
-            if (has_in) {
-                const float4 uv = live ? up[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
-                u_t[(4 * cc + 0) * MLD + r] = uv.x; u_t[(4 * cc + 1) * MLD + r] = uv.y;
-                u_t[(4 * cc + 2) * MLD + r] = uv.z; u_t[(4 * cc + 3) * MLD + r] = uv.w;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- MFMA chains: wave = matrix * 3 + gate (waves 6, 7 only help staging and the gates)
     mf32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const int mat = wave / 3, gate = wave - mat * 3;
+    const int mat = wave / 3, gate = wave - mat * 3;   // wave = matrix * 3 + gate (waves 6, 7: staging + gates)
     const bool chain = wave < 6 && (mat == 0 ? has_pred : has_in);
-    if (chain) {
-        const float* op = mat == 0 ? a_t : u_t;
-        const float4* wp = (mat == 0 ? C.whh_m : C.wih_m) + ((int64_t)(sl * 3 + gate) * (H / 8)) * 64 + lane;
-        const int arow = lane & 31, ak = lane >> 5;
-        for (int k8 = 0; k8 < H / 8; k8 += 4) {   // 4 x 16 B of B fragments in flight per lane
-            float4 w4[4];
+    const float* op = mat == 0 ? a_t : u_t;
+    const float4* wp = chain ? (mat == 0 ? C.whh_m : C.wih_m) + ((int64_t)(sl * 3 + gate) * (H / 8)) * 64 + lane : nullptr;
+    const int arow = lane & 31, ak = lane >> 5;
+
+    for (int k0 = 0; k0 < H; k0 += KC) {
+        const int kc = min(KC, H - k0);
+        if (k0 > 0) __syncthreads();   // the previous chunk's MFMAs are done with a_t / u_t
+        // ---- stage the operand chunk k-major: wave w copies rows w, w+8, ... (coalesced float4 row reads)
+        for (int r = wave; r < MT; r += 8) {
+            const bool live = r < nr;
+            const float4* ap = reinterpret_cast<const float4*>(C.a_pre + (int64_t)(slot0 + r - C.row_base) * H + k0);
+            const float4* up = has_in ? reinterpret_cast<const float4*>(C.h_in + (int64_t)v_s[r] * ld_h + k0) : nullptr;
+            for (int cc = lane; cc < (kc >> 2); cc += 64) {
+                const float4 av = live ? ap[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
+                a_t[(4 * cc + 0) * MLD + r] = av.x; a_t[(4 * cc + 1) * MLD + r] = av.y;
+                a_t[(4 * cc + 2) * MLD + r] = av.z; a_t[(4 * cc + 3) * MLD + r] = av.w;
+                if (has_in) {
+                    const float4 uv = live ? up[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    u_t[(4 * cc + 0) * MLD + r] = uv.x; u_t[(4 * cc + 1) * MLD + r] = uv.y;
+                    u_t[(4 * cc + 2) * MLD + r] = uv.z; u_t[(4 * cc + 3) * MLD + r] = uv.w;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- MFMA chains over this K chunk
+        if (chain) {
+            for (int k8 = 0; k8 < (kc >> 3); k8 += 4) {   // 4 x 16 B of B fragments in flight per lane
+                float4 w4[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) w4[q] = wp[(int64_t)(k8 + q) * 64];
+                for (int q = 0; q < 4; ++q) w4[q] = wp[(int64_t)((k0 >> 3) + k8 + q) * 64];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int kb = 8 * (k8 + q) + ak;   // this lane's k for the first of the 4 MFMAs of this fragment
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[(kb + 0) * MLD + arow], w4[q].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[(kb + 2) * MLD + arow], w4[q].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[(kb + 4) * MLD + arow], w4[q].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[(kb + 6) * MLD + arow], w4[q].w, acc, 0, 0, 0);
+                for (int q = 0; q < 4; ++q) {
+                    const int kb = 8 * (k8 + q) + ak;   // this lane's k (within the chunk) for the first MFMA of the fragment
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[(kb + 0) * MLD + arow], w4[q].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[(kb + 2) * MLD + arow], w4[q].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[(kb + 4) * MLD + arow], w4[q].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[(kb + 6) * MLD + arow], w4[q].w, acc, 0, 0, 0);
+                }
             }
         }
     }
@@ -686,7 +691,7 @@ __global__ void __launch_bounds__(512, 2) frontier_mfma_kernel(const int32_t* __
             }
             const float* gh = g_s + r * 96;
             const float hr = gh[jj] + C.bhh[j], hz = gh[32 + jj] + C.bhh[H + j], hn = gh[64 + jj] + C.bhh[2 * H + j];
-            const float a = a_t[j * MLD + r];
+            const float a = C.a_pre[(int64_t)(slot0 + r - C.row_base) * H + j];
             const float rg = sigm(gr + hr);
             const float zg = sigm(gz + hz);
             const float ng = tanhf(fmaf(rg, hn, gn));
@@ -998,7 +1003,7 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         S.step = s;
         hipError_t e;
         // the fattest launches: aggregate every row once (stage 1), then 32-row MFMA tiles (stage 2)
-        bool mfma_ok = a->agg_scratch != nullptr && rows_total <= a->agg_scratch_rows && H <= 256 &&
+        bool mfma_ok = a->agg_scratch != nullptr && rows_total <= a->agg_scratch_rows && (H <= MKC || H % MKC == 0) &&
                        a->mfma_min_rows > 0 && rows_total >= a->mfma_min_rows;
         for (int k = 0; k < nc && mfma_ok; ++k)
             mfma_ok = S.cell[k].whh_m != nullptr && (S.cell[k].wih == nullptr || S.cell[k].wih_m != nullptr);
@@ -1019,7 +1024,8 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
             hipLaunchKernelGGL(aggregate_rows_kernel, dim3((unsigned)((off + 3) / 4)), dim3(256), 0, st, plan, L, A);
             e = hipGetLastError();
             if (e != hipSuccess) return DAGNN_EHIP(e);
-            const size_t lds = (size_t)(H * MLD + (H * MLD > 2 * MT * 96 ? H * MLD : 2 * MT * 96)) * sizeof(float) +
+            const int kcl = H < MKC ? H : MKC;
+            const size_t lds = (size_t)(kcl * MLD + (kcl * MLD > 2 * MT * 96 ? kcl * MLD : 2 * MT * 96)) * sizeof(float) +
                                MT * sizeof(int);
             hipLaunchKernelGGL(frontier_mfma_kernel, dim3((unsigned)(tiles * (H / 32))), dim3(512), lds, st, plan, L, S);
             e = hipGetLastError();

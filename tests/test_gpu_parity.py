@@ -195,7 +195,8 @@ def test_dvae_encode_matches_reference_golden(device, name, schedule):
     assert Hh.maxdiff(mu2, arr["mu"]) < TOL and Hh.maxdiff(lv2, arr["logvar"]) < TOL
 
 
-@pytest.mark.parametrize("name", ["code2_h256_bidir", "code2_h64_unidir", "code2_h128_deep", "code2_h64_attn_x"])
+@pytest.mark.parametrize("name", ["code2_h256_bidir", "code2_h64_unidir", "code2_h128_deep", "code2_h64_attn_x",
+                                  "code2_h512_L5"])
 @pytest.mark.parametrize("knob", ["mfma_tiles", "no_tail", "agg_split"])
 def test_launch_shape_variants_match_reference_golden(device, name, knob, monkeypatch):
     """Force the code paths the small fixtures would not reach on their own: 32-row MFMA tiles for

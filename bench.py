@@ -206,7 +206,8 @@ def main():
                 if lock and os.path.exists(tpath):  # separate rocprofv3 --pmc passes, see profiles/README.md
                     traffic = json.load(open(tpath)).get("recurrence_hbm_bytes_per_forward")
                 result["roofline"] = {
-                    "kernel": ("recurrence = frontier_step_kernel (one launch per fat/mid topological layer) + "
+                    "kernel": ("recurrence = aggregate_rows_kernel + frontier_mfma_kernel (fat topological layers, "
+                               "32-row MFMA tiles) + frontier_step_kernel (one launch per mid layer) + "
                                "frontier_tail_kernel (one persistent dataflow launch for the thin tail), all "
                                "(direction, stacked layer) cells; figures are per forward(G)") if lock else
                               ("recurrence_kernel<KSL> (dagnn_recurrence_layer): %d launches per forward, one per "

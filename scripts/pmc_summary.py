@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Fold two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE) into profiles/pmc_traffic.json.
+
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python bench.py --steps 2 --warmup 1 --cpu-passes 0 --no-kernel-timer
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python bench.py --steps 2 --warmup 1 --cpu-passes 0 --no-kernel-timer
+  python scripts/pmc_summary.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv 3
+
+Counter unit is KiB. FETCH_SIZE is doubled before use (MI355X_MICROARCH.md, HBM section: gfx950 reports
+wide coalesced reads at half size); WRITE_SIZE is used as reported.
+"""
+import csv
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+RECURRENCE = ("frontier_step_kernel", "frontier_tail_kernel", "frontier_mfma_kernel", "aggregate_rows_kernel")
+
+
+def short(name):
+    m = re.search(r"(\w+_kernel(?:<[^>]*>)?)", name)
+    return m.group(1) if m else name[:60]
+
+
+def fold(path):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            k = short(r["Kernel_Name"])
+            tot[k] += float(r["Counter_Value"])
+            cnt[k] += 1
+    return tot, cnt
+
+
+def main():
+    fetch_csv, write_csv, forwards = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    ft, fc = fold(fetch_csv)
+    wt, _ = fold(write_csv)
+    per = {}
+    rec_bytes = 0.0
+    for k in sorted(ft, key=lambda k: -ft[k]):
+        if not k.endswith("_kernel") and "_kernel<" not in k:
+            continue
+        f_kib, w_kib = ft[k] / forwards, wt.get(k, 0.0) / forwards
+        per[k] = {"launches_per_forward": round(fc[k] / forwards, 2), "FETCH_SIZE_KiB": round(f_kib, 1),
+                  "WRITE_SIZE_KiB": round(w_kib, 1), "hbm_bytes_corrected": int((2 * f_kib + w_kib) * 1024)}
+        if k.startswith(RECURRENCE):
+            rec_bytes += (2 * f_kib + w_kib) * 1024
+    out = {
+        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over `python bench.py "
+                "--steps 2 --warmup 1 --cpu-passes 0 --no-kernel-timer` (%d forwards), lock-step schedule. Counter "
+                "unit is KiB (calibrated: encode_ast_kernel WRITE_SIZE = N*H*4 bytes per launch). FETCH_SIZE is "
+                "doubled before use, as MI355X_MICROARCH.md (HBM section) prescribes for wide coalesced reads on "
+                "gfx950; WRITE_SIZE is used as reported. Produced by scripts/pmc_summary.py." % forwards,
+        "per_forward": per,
+        "recurrence_kernels": list(RECURRENCE),
+        "recurrence_hbm_bytes_per_forward": int(rec_bytes),
+    }
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "pmc_traffic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

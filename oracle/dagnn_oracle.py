@@ -20,6 +20,7 @@ each function follows:
                             the whole `edge_index` (:153-155), aggregation into all N rows (:179)
 * `recurrence_csr`        - same math on a layer-sorted CSR (what the HIP path implements)
 * `code2_forward`         - `DAGNN.forward` `dagnn.py:128-215` (read-outs :184-202, heads :209-215)
+* `code2_grads`           - one training step's loss + gradients, `ogbg-code/main_pyg.py:55-62`
 * `dvae_forward/encode`   - `dvae/dagnn.py:99-184` (NA, `vids` key bias :130-139) and
                             `dvae/dagnn_bn.py:98-177` (BN)
 """
@@ -219,19 +220,21 @@ def _pool(x: Tensor, batch: Tensor, how: str) -> Tensor:
     raise ValueError(how)
 
 
-def _cast(sd, dtype):
+def _cast(sd, dtype, keep_graph=False):
+    if keep_graph:  # code2_grads: the parameters are autograd leaves
+        return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     return {k: (v.detach().to(dtype) if v.is_floating_point() else v.detach()) for k, v in sd.items()}
 
 
 def code2_forward(sd: Dict[str, Tensor], G, *, num_layers: int = 2, bidirectional: bool = True,
                   out_wx: bool = False, out_pool_all: bool = False, out_pool: str = "max",
                   max_seq_len: int = 5, num_class: int = 0, mode: str = "csr",
-                  dtype: torch.dtype = torch.float32, agg: str = "attn_h"):
+                  dtype: torch.dtype = torch.float32, agg: str = "attn_h", keep_graph: bool = False):
     """`DAGNN.forward` of `ogbg-code/model/dagnn.py:128-215` for the additive-attention aggregators
     (`agg` in attn_h, attn_x, self_attn_h, self_attn_x), `recurr=1`, `agg_x=False`.  Reproduces the side effects on G (`G.x`, `G.h`, `G.bi_layer_index`, clamped
     `G.node_depth`, and `G.batch` on the unidirectional branch).  Returns a list of logits per
     head, or one tensor when `num_class > 0`."""
-    sd = _cast(sd, dtype)
+    sd = _cast(sd, dtype, keep_graph)
     dirs = [0, 1] if bidirectional else [0]
     H = sd["cells_0.0.weight_hh"].shape[1]
     G.bi_layer_index = torch.stack([torch.stack([G._bi_layer_idx0, G._bi_layer_index0], 0),
@@ -264,6 +267,20 @@ def code2_forward(sd: Dict[str, Tensor], G, *, num_layers: int = 2, bidirectiona
         return out @ sd["graph_pred_linear.weight"].t() + sd["graph_pred_linear.bias"]
     return [out @ sd["graph_pred_linear_list.%d.weight" % s].t() + sd["graph_pred_linear_list.%d.bias" % s]
             for s in range(max_seq_len)]
+
+
+def code2_grads(sd: Dict[str, Tensor], G, y: Tensor, *, dtype: torch.dtype = torch.float32, **kw):
+    """Loss and parameter gradients of one training step as `ogbg-code/main_pyg.py:55-62` computes them:
+    `loss = mean_s CrossEntropy(pred_list[s], y_arr[:, s])`, `loss.backward()`.  Plain torch autograd
+    through `code2_forward`; returns `(loss, {parameter name: gradient})` (zeros for unused parameters)."""
+    leaves = {k: (v.detach().to(dtype).clone().requires_grad_(True) if v.is_floating_point() else v)
+              for k, v in sd.items()}
+    pred = code2_forward(leaves, G, dtype=dtype, keep_graph=True, **kw)
+    pred = pred if isinstance(pred, (list, tuple)) else [pred]
+    loss = sum(torch.nn.functional.cross_entropy(p, y[:, s]) for s, p in enumerate(pred)) / len(pred)
+    names = [k for k, v in leaves.items() if v.is_floating_point()]
+    gs = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
+    return loss.detach(), {k: (torch.zeros_like(leaves[k]) if g is None else g) for k, g in zip(names, gs)}
 
 
 def dvae_forward(sd: Dict[str, Tensor], G, *, num_layers: int = 2, bidirectional: bool = False,

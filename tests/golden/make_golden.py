@@ -108,6 +108,61 @@ def make_code2(ref_dagnn, ref_utils, ref_dagutils, name, *, data_seed, B, mean_n
     _save(name, meta, **arrays)
 
 
+def sample_grad(name, g):
+    """What a gradient fixture keeps of one parameter gradient: everything when it is small, else every
+    `stride`-th row (tests/helpers.grad_view applies the same rule) - plus float64 sum / abs-sum of the full array."""
+    g = np.asarray(g)
+    stride = 1 if g.size <= 30000 or g.ndim < 2 else -(-g.shape[0] // 48)
+    return g[::stride], stride, np.array([g.astype(np.float64).sum(), np.abs(g.astype(np.float64)).sum()])
+
+
+def make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, name, *, data_seed, B, mean_n, H, L, V, S, n_attr, w_seed,
+                    y_seed, max_n=1000, **ctor):
+    """One training step's gradients from the reference: `DAGNN.forward` under autograd, the loss of
+    ogbg-code/main_pyg.py:55-62 (mean over the S heads of CrossEntropy against y_arr[:, s]), `.backward()`."""
+    from types import SimpleNamespace
+    graphs = synth.code2_graphs(data_seed, B, mean_n, max_n)
+    for g in graphs:
+        g.x[:, 1] %= n_attr
+        ns = SimpleNamespace(edge_index=g.edge_index, num_nodes=g.num_nodes)
+        ref_dagutils.add_order_info_01(ns)
+        for k in ("_bi_layer_idx0", "_bi_layer_index0", "_bi_layer_idx1", "_bi_layer_index1"):
+            setattr(g, k, getattr(ns, k))
+    b = synth.GraphBatch.from_data_list(graphs)
+    enc = ref_utils.ASTNodeEncoder(H, 98, n_attr, 20)
+    kw = dict(w_edge_attr=True, num_layers=L, bidirectional=True, agg="attn_h", out_wx=False,
+              out_pool_all=False, out_pool="max", dropout=0.0)
+    kw.update(ctor)
+    model = ref_dagnn.DAGNN(num_vocab=V, max_seq_len=S, emb_dim=H, hidden_dim=H, out_dim=None,
+                            encoder=enc, **kw).train()
+    seeded_fill(model, w_seed)
+    y = torch.from_numpy(np.random.default_rng(y_seed).integers(0, V, size=(B, S)))
+    G = SimpleNamespace(x=b.x.clone(), node_depth=b.node_depth.clone(), edge_index=b.edge_index.clone(),
+                        edge_attr=b.edge_attr.clone(), batch=b.batch.clone(),
+                        _bi_layer_idx0=b._bi_layer_idx0.clone(), _bi_layer_index0=b._bi_layer_index0.clone(),
+                        _bi_layer_idx1=b._bi_layer_idx1.clone(), _bi_layer_index1=b._bi_layer_index1.clone())
+    pred = model(G)
+    ce = torch.nn.CrossEntropyLoss()
+    loss = 0
+    for s_ in range(len(pred)):
+        loss = loss + ce(pred[s_].to(torch.float32), y[:, s_])
+    loss = loss / len(pred)
+    loss.backward()
+    arrays = dict(
+        x=_np(b.x), node_depth=_np(b.node_depth), edge_index=_np(b.edge_index), edge_attr=_np(b.edge_attr),
+        batch=_np(b.batch), layer0=_np(b._bi_layer_idx0), layer1=_np(b._bi_layer_idx1), y=_np(y),
+        loss=np.array(float(loss.detach())), pred=np.stack([_np(o) for o in pred]))
+    strides = {}
+    for k, p_ in model.named_parameters():
+        g = np.zeros(tuple(p_.shape), np.float32) if p_.grad is None else _np(p_.grad)
+        arrays["g::" + k], strides[k], arrays["gsum::" + k] = sample_grad(k, g)
+    meta = dict(kind="code2_grad", data_seed=data_seed, B=B, mean_n=mean_n, max_n=max_n, H=H, L=L, bidir=True,
+                V=V, S=S, n_attr=n_attr, w_seed=w_seed, y_seed=y_seed, ctor=kw, N=int(b.x.shape[0]),
+                E=int(b.edge_index.shape[1]), T=int(b._bi_layer_idx0.max()) + 1, grad_stride=strides,
+                state_dict={k: list(v.shape) for k, v in model.state_dict().items()})
+    _save(name, meta, **arrays)
+
+
 # ------------------------------------------------------------------------------- dvae
 def _dvae_case(model, graphs, ref_batch_mod):
     data = [copy.deepcopy(g) for g in graphs]  # models_pyg.py:114-115 (collation mutates)
@@ -169,6 +224,20 @@ def main():
     ref_utils = _load_file("ref_ogbg_utils", os.path.join(REF, "ogbg-code", "utils.py"))
 
     common = dict(V=48, S=5, n_attr=300)
+    only = os.environ.get("GOLDEN_ONLY")  # "grad": rewrite only the gradient fixtures
+    # training-step gradients: loss and parameter gradients of one step
+    if True:
+        make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, "grad_h32_bidir", data_seed=11, B=6, mean_n=30, H=32,
+                        L=2, w_seed=101, y_seed=301, **common)
+        make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, "grad_h256_bidir", data_seed=12, B=8, mean_n=60, H=256,
+                        L=2, w_seed=102, y_seed=302, **common)
+        make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, "grad_h128_deep", data_seed=17, B=3, mean_n=400, H=128,
+                        L=2, w_seed=107, y_seed=303, **common)
+        make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, "grad_h64_L3_wx", data_seed=21, B=5, mean_n=40, H=64,
+                        L=3, w_seed=121, y_seed=304, out_wx=True, **common)
+    if only == "grad":
+        return
+
     # tiny generic-H case, every hidden row stored
     make_code2(ref_dagnn, ref_utils, ref_dagutils, "code2_h32_bidir", data_seed=11, B=6, mean_n=30, H=32, L=2,
                bidir=1, w_seed=101, row_stride=1, **common)

@@ -17,6 +17,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CODE2 = ["code2_h32_bidir", "code2_h256_bidir", "code2_h512_L5", "code2_h300_L3", "code2_h64_unidir",
          "code2_h64_numclass", "code2_h128_deep", "code2_h64_attn_x", "code2_h64_self_attn_h",
          "code2_h64_self_attn_x"]
+GRAD = ["grad_h32_bidir", "grad_h256_bidir", "grad_h128_deep", "grad_h64_L3_wx"]
 DVAE = ["na_h128_unidir", "na_h64_bidir", "bn_h256_bidir", "bn_h64_unidir"]
 
 
@@ -64,3 +65,33 @@ def maxdiff(a, b):
     a = a.detach().cpu().double() if isinstance(a, torch.Tensor) else torch.as_tensor(a).double()
     b = b.detach().cpu().double() if isinstance(b, torch.Tensor) else torch.as_tensor(b).double()
     return float((a - b).abs().max()) if a.numel() else 0.0
+
+
+def grad_view(meta, name, g):
+    """The rows of a full gradient that a gradient fixture stores (tests/golden/make_golden.sample_grad)."""
+    return g[::meta["grad_stride"][name]]
+
+
+def check_grads(meta, arr, grads, rtol=2e-4, atol=2e-7, verbose=False):
+    """Compare {name: gradient} with a gradient fixture: stored rows and the float64 sum of every parameter,
+    relative to the largest entry of that gradient (+ `atol`: the gradients of the attention query weights,
+    attention bias and edge-encoder bias are mathematically zero - they cancel inside the segment softmax - and
+    come out of the reference's autograd as ~1e-9 rounding noise).  Returns the worst relative error."""
+    worst = 0.0
+    for key in arr:
+        if not key.startswith("g::"):
+            continue
+        name = key[3:]
+        ref = torch.from_numpy(arr[key]).double()
+        got = grad_view(meta, name, grads[name].detach().cpu()).double()
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        scale = float(ref.abs().max())
+        aerr = float((got - ref).abs().max())
+        abs_sum = float(arr["gsum::" + name][1])
+        serr = abs(float(grads[name].detach().cpu().double().sum()) - float(arr["gsum::" + name][0]))
+        if verbose:
+            print("%-44s max|g| %.3e  err %.3e  sum err %.3e / %.3e" % (name, scale, aerr, serr, abs_sum))
+        assert aerr <= rtol * scale + atol, "%s: max abs err %.3g at scale %.3g" % (name, aerr, scale)
+        assert serr <= rtol * abs_sum + atol * got.numel() ** 0.5 * 10, "%s: sum err %.3g of %.3g" % (name, serr, abs_sum)
+        worst = max(worst, aerr / max(scale, 1e-30) if scale > 100 * atol else 0.0)
+    return worst

@@ -61,3 +61,17 @@ def test_fp64_oracle_brackets_reference():
     out = O.code2_forward(model.state_dict(), G, num_layers=kw["num_layers"], bidirectional=True, out_wx=False,
                           out_pool_all=False, out_pool="max", max_seq_len=meta["S"], dtype=torch.float64)
     assert max(Hh.maxdiff(o, r) for o, r in zip(out, arr["pred"])) < TOL
+
+
+@pytest.mark.parametrize("name", Hh.GRAD)
+def test_oracle_training_step_gradients_match_reference(name):
+    """`code2_grads` (autograd through the restatement) against the reference's own `loss.backward()` on the
+    same seeded step (ogbg-code/main_pyg.py:55-62)."""
+    meta, arr = Hh.load(name)
+    model = Hh.code2_model(meta)
+    G = Hh.code2_batch(arr)
+    kw = meta["ctor"]
+    loss, grads = O.code2_grads(model.state_dict(), G, torch.from_numpy(arr["y"]), num_layers=kw["num_layers"],
+                                bidirectional=True, out_wx=kw["out_wx"], max_seq_len=meta["S"])
+    assert abs(float(loss) - float(arr["loss"])) < 1e-5
+    assert Hh.check_grads(meta, arr, grads, rtol=5e-5) < 5e-5

@@ -56,6 +56,16 @@ class FrontierArgs(C.Structure):
                 ("tail_err", C.c_void_p), ("debug_timing", C.c_void_p)]
 
 
+class BackwardCell(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("w_hh", "w_ih", "w_key", "edge_gain", "h", "a", "alpha", "gi", "gh", "g_ext",
+                                          "da", "dgi", "dgh", "sigma", "edge_feat_grad")]
+
+
+class BackwardArgs(C.Structure):
+    _fields_ = [("cell", (BackwardCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
+                ("H", C.c_int), ("ld_h", C.c_int), ("num_cus", C.c_int)]
+
+
 # every symbol include/dagnn_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     "dagnn_version": (C.c_char_p, []),
@@ -75,6 +85,11 @@ SYMBOLS = {
                                      C.POINTER(C.c_int32), C.c_void_p]),
     "dagnn_readout_max": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int, C.c_void_p]),
+    "dagnn_backward_prepare": (C.c_int, [C.POINTER(Plan), C.POINTER(BackwardArgs), C.c_void_p]),
+    "dagnn_backward_run": (C.c_int, [C.POINTER(Plan), C.POINTER(BackwardArgs), C.POINTER(C.POINTER(C.c_int32)),
+                                     C.POINTER(C.c_int32), C.c_void_p]),
+    "dagnn_readout_max_backward": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_gather_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int, C.c_void_p]),
 }

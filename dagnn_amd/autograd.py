@@ -1,0 +1,119 @@
+"""Training path: `torch.autograd.Function`s around the HIP kernels.
+
+The reference trains through torch autograd over its Python loops (`loss.backward()`,
+ogbg-code/main_pyg.py:62): one autograd node per (direction, topological layer, stacked layer)
+micro-step.  Here the forward pass is the same HIP path as inference and keeps only the states
+h[d][i]; `Recurrence.backward` recomputes aggregates / pre-activations in parallel, walks the dependent
+chain once in reverse lock-step (csrc/backward.hip) and finishes with library GEMMs for the weight
+gradients.  Everything around it (dropout, the vocabulary heads, the loss, the optimizer) stays
+ordinary torch autograd, as in the reference.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import engine
+from .core import run_stack_lockstep
+
+
+class EncodeAST(torch.autograd.Function):
+    """`ASTNodeEncoder.forward` (ogbg-code/utils.py:26-28) on the HIP kernel; backward = the three
+    embedding-table gradients (row sums of the incoming gradient by index)."""
+
+    @staticmethod
+    def forward(ctx, x, depth, type_w, attr_w, depth_w, max_depth):
+        out = engine.encode_ast(x, depth, type_w, attr_w, depth_w, max_depth)  # clamps `depth` in place
+        ctx.save_for_backward(x, depth.clone())
+        ctx.rows = (type_w.shape[0], attr_w.shape[0], depth_w.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, depth = ctx.saved_tensors
+        g = g.contiguous()
+        grads = []
+        for rows, idx in zip(ctx.rows, (x[:, 0], x[:, 1], depth)):
+            grads.append(torch.zeros(rows, g.shape[1], dtype=g.dtype, device=g.device).index_add_(0, idx, g))
+        return (None, None, grads[0], grads[1], grads[2], None)
+
+
+class Recurrence(torch.autograd.Function):
+    """Plan + embedding -> pooled read-out [B, D*L*H (+ D*emb)] of the bidirectional max-pool configuration
+    (dagnn.py:144-193).  Inputs after `x` are the cells' parameters, 8 per (direction, stacked layer):
+    weight_ih, weight_hh, bias_ih, bias_hh, attn_lin.weight, attn_lin.bias, edge_encoder.weight,
+    edge_encoder.bias (the last two None without edge features)."""
+
+    PER_CELL = 8
+
+    @staticmethod
+    def forward(ctx, mod, plan, B, x, *params):
+        L, H, dirs = mod.num_layers, mod.hidden_dim, mod.dirs
+        cells = mod._cells()
+        keep = {}
+        h = run_stack_lockstep(plan, x, cells, dirs, L, H, arena=mod._arena_for(x), keep=keep)
+        out = torch.empty(B, mod.out_hidden_dim, dtype=torch.float32, device=x.device)
+        col = 0
+        for d in (0, 1):
+            for t in ([x] if mod.out_wx else []) + [h[d][i] for i in range(L)]:
+                engine.readout_max(plan, t, d, out, col)
+                col += t.shape[1]
+        ctx.mod, ctx.plan, ctx.cells, ctx.keep, ctx.h = mod, plan, cells, keep, h
+        ctx.save_for_backward(x, *[p for p in params if p is not None])
+        ctx.present = [p is not None for p in params]
+        flat = [h[d][i] for d in dirs for i in range(L)]
+        ctx.mark_non_differentiable(*flat)
+        return (out,) + tuple(flat)
+
+    @staticmethod
+    def backward(ctx, gout, *_unused):
+        mod, plan, cells, keep, h = ctx.mod, ctx.plan, ctx.cells, ctx.keep, ctx.h
+        saved = list(ctx.saved_tensors)
+        x, it = saved[0], iter(saved[1:])
+        params = [next(it) if present else None for present in ctx.present]
+        L, H, dirs, Hp = mod.num_layers, mod.hidden_dim, mod.dirs, keep["Hp"]
+        N, dev = x.shape[0], x.device
+        gout = gout.contiguous().float()
+        g_ext = [[torch.zeros(N, Hp, dtype=torch.float32, device=dev) for _ in range(L)] for _ in range(2)]
+        dx = torch.zeros_like(x)
+        col = 0
+        for d in (0, 1):  # read-out gradient: to the arg-max output node of every (graph, column)
+            if mod.out_wx:
+                engine.readout_max_backward(plan, x, d, gout, col, dx)
+                col += x.shape[1]
+            for i in range(L):
+                engine.readout_max_backward(plan, h[d][i], d, gout, col, g_ext[d][i])
+                col += H
+        res = engine.backward_sweep(plan, dirs, L, Hp, cells, keep["h_buf"], keep["gi0"], g_ext)
+
+        def gates(t):  # [N, 3Hp] in gate blocks of Hp -> [N, 3H]
+            return t if Hp == H else t.view(N, 3, Hp)[:, :, :H].reshape(N, 3 * H)
+
+        grads = []
+        k = 0
+        for d in dirs:
+            for i in range(L):
+                w_ih, w_hh, b_ih, b_hh, attn_w, attn_b, edge_w, edge_b = params[k:k + Recurrence.PER_CELL]
+                k += Recurrence.PER_CELL
+                r = res[(d, i)]
+                dgi, dgh = gates(r["dgi"]), gates(r["dgh"])
+                u = x if i == 0 else h[d][i - 1]
+                g_wih, g_bih = dgi.t() @ u, dgi.sum(0)
+                g_whh, g_bhh = dgh.t() @ r["a"][:, :H], dgh.sum(0)
+                if i == 0:
+                    dx = dx + dgi @ w_ih
+                # attention logit s_e = w_key . (h_p + W_e feat_e + b_e) (+ query and bias terms that cancel in
+                # the segment softmax: their gradients are exact zeros)
+                dq = attn_w.shape[1] - H
+                sigma = r["sigma"]
+                g_key = h[d][i].t() @ sigma
+                g_edge_w = g_edge_b = None
+                if edge_w is not None:
+                    m, ssum = r["edge_feat_grad"].sum(0), sigma.sum()
+                    w_key = attn_w[0, dq:]
+                    g_key = g_key + edge_w @ m + edge_b * ssum
+                    g_edge_w, g_edge_b = torch.outer(w_key, m), w_key * ssum
+                g_attn = torch.zeros_like(attn_w)
+                g_attn[0, dq:] = g_key
+                grads += [g_wih, g_whh, g_bih, g_bhh, g_attn, None if attn_b is None else torch.zeros_like(attn_b),
+                          g_edge_w, g_edge_b]
+        return (None, None, None, dx) + tuple(grads)

@@ -71,7 +71,7 @@ class CellParams(object):
     """Device-side, kernel-ready parameters of one (direction, stacked layer) cell."""
 
     __slots__ = ("w_ih", "b_ih", "w_hh_t", "b_hh", "w_key", "edge_gain", "vid_bias", "w_hh_pk", "w_ih_pk",
-                 "b_ih_dev", "Hp", "key_raw")
+                 "b_ih_dev", "Hp", "key_raw", "w_hh_raw")
 
 
 def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: bool,
@@ -94,6 +94,7 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
     c.w_ih = wi
     c.b_ih = _pad_gate_rows(b_ih.detach().float(), H, Hp)
     whh = _pad_cols(_pad_gate_rows(w_hh.detach().float(), H, Hp), Hp)
+    c.w_hh_raw = whh  # torch layout, padded: the backward sweep reads it as is
     c.w_hh_t = None if lock else engine.pack_whh(whh)
     c.w_hh_pk = {js: engine.pack_slices(whh, Hp, js) for js in (16, 32)} if lock else None
     c.w_ih_pk = {js: engine.pack_slices(wi, Hp, js) for js in (16, 32)} if (lock and in_is_hidden) else None
@@ -114,9 +115,11 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
 
 def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tuple[int, int], CellParams],
                        dirs: Sequence[int], L: int, H: int, vid_nodes: int = 0,
-                       arena: Optional[engine.GranuleArena] = None, static_score=None) -> List[List[torch.Tensor]]:
+                       arena: Optional[engine.GranuleArena] = None, static_score=None,
+                       keep: Optional[dict] = None) -> List[List[torch.Tensor]]:
     """Lock-step schedule (default): one batched input GEMM for stacked layer 0 of every direction,
-    then T + L - 1 frontier launches covering all cells (csrc/frontier.hip)."""
+    then T + L - 1 frontier launches covering all cells (csrc/frontier.hip).  `keep` (training) receives
+    what the backward pass needs: the raw state buffers (`h_buf`) and `gi0`."""
     Hp = cells[(dirs[0], 0)].Hp
     N, dev = x.shape[0], x.device
     gi0 = engine.gemm_nt_bias([x] * len(dirs), [cells[(d, 0)].w_ih for d in dirs], [cells[(d, 0)].b_ih for d in dirs])
@@ -127,6 +130,8 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
     h = [[torch.empty(N, ld, dtype=torch.float32, device=dev) if d in dirs else None for _ in range(L)]
          for d in range(2)]
     engine.frontier_run(plan, dirs, L, Hp, cells, gi, h, vid_mod=vid_nodes, arena=arena, static_score=static_score)
+    if keep is not None:
+        keep["h_buf"], keep["gi0"], keep["Hp"] = h, gi, Hp
     return [[h[d][i][:, :H] if h[d][i] is not None else None for i in range(L)] for d in range(2)]
 
 

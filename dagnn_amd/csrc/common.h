@@ -24,9 +24,9 @@ struct PlanLayout {
     int64_t col[2];                  // [E]   predecessor node id per CSR slot
     int64_t eattr[2];                // [E*R] fp32 edge features in CSR order
     int64_t items;                   // [2B]  (g*2+d) sorted by depth, deepest first
-    int64_t pos[2];                  // [N]   scratch: sorted position of each node
+    int64_t pos[2];                  // [N]   during the build: sorted position of each node; final: its rowrec slot
     int64_t cursor[2];               // [N+B] scratch: fill cursors
-    int64_t eidx[2];                 // [E]   scratch: original edge id per CSR slot
+    int64_t eidx[2];                 // [E]   original edge id per CSR slot
     int64_t blptr[2];                // [N+2] batch-level layer offsets (counts, then scanned); [N+1] = T_d
     int64_t lbase[2];                // [N+B] per (graph, layer): first slot of its rows in rowrec
     int64_t rowrec[2];               // [16N] per batch-level slot, 64 B: {node, e_begin, e_end, graph,

@@ -143,6 +143,7 @@ __global__ void __launch_bounds__(PB) plan_graph_kernel(int32_t* plan, PlanLayou
     int32_t* pos = (small ? small_ws + 3 * (PLAN_NMAX + 1) : plan + L.pos[d] + n0) - n0;  // indexed by node id
     int32_t* order = plan + L.order[d];
     int32_t* col = plan + L.col[d];
+    int32_t* eidx = plan + L.eidx[d];
     float* eattr = reinterpret_cast<float*>(plan + L.eattr[d]);
 
     // ---- depth of this graph in this direction
@@ -210,6 +211,7 @@ __global__ void __launch_bounds__(PB) plan_graph_kernel(int32_t* plan, PlanLayou
         if (key >= 0) {
             int64_t o = other[e];
             col[slot] = (int)((o >= n0 && o < n1) ? o : feed[e]);
+            eidx[slot] = e;  // original edge id: per-edge quantities of the backward pass are stored by it
             for (int r = 0; r < R; ++r) eattr[(int64_t)slot * R + r] = edge_attr[(int64_t)e * R + r];
         }
     }
@@ -332,6 +334,7 @@ __global__ void __launch_bounds__(256) plan_rowrec_kernel(int32_t* plan, PlanLay
         w[8 + 2 * q] = (ok && R >= 1) ? eattr[(int64_t)(eb + q) * R] : 0;
         w[9 + 2 * q] = (ok && R >= 2) ? eattr[(int64_t)(eb + q) * R + 1] : 0;
     }
+    plan[L.pos[d] + v] = slot;  // final meaning of pos[]: batch-level slot of every node (backward: node -> record)
     int4* out = reinterpret_cast<int4*>(plan + L.rowrec[d] + 16 * (int64_t)slot);
     out[0] = make_int4(w[0], w[1], w[2], w[3]);
     out[1] = make_int4(w[4], w[5], w[6], w[7]);
@@ -349,10 +352,11 @@ extern "C" size_t dagnn_plan_bytes(int64_t N, int64_t E, int64_t B, int num_edge
 extern "C" int dagnn_plan_layout(int64_t N, int64_t E, int64_t B, int R, int64_t* o) {
     if (!o) return DAGNN_EINVAL;
     PlanLayout L = dagnn_plan_layout_words(N, E, B, R);
-    int64_t w[20] = {L.node_ptr, L.edge_ptr, L.depth[0], L.depth[1], L.order[0], L.order[1], L.lstart[0],
+    int64_t w[24] = {L.node_ptr, L.edge_ptr, L.depth[0], L.depth[1], L.order[0], L.order[1], L.lstart[0],
                      L.lstart[1], L.rowptr[0], L.rowptr[1], L.col[0], L.col[1], L.eattr[0], L.eattr[1],
-                     L.items, L.total, L.blptr[0], L.blptr[1], L.rowrec[0], L.rowrec[1]};
-    for (int i = 0; i < 20; ++i) o[i] = w[i] * 4;
+                     L.items, L.total, L.blptr[0], L.blptr[1], L.rowrec[0], L.rowrec[1],
+                     L.pos[0], L.pos[1], L.eidx[0], L.eidx[1]};
+    for (int i = 0; i < 24; ++i) o[i] = w[i] * 4;
     return DAGNN_OK;
 }
 

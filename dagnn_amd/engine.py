@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import DagnnHipError, FrontierArgs, GemmGroup, LayerArgs, Plan, check
+from ._lib import BackwardArgs, DagnnHipError, FrontierArgs, GemmGroup, LayerArgs, Plan, check
 
 
 class KernelTimer(object):
@@ -81,6 +81,17 @@ def _dev(t: torch.Tensor, what: str, dtype=None) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _rows(t: torch.Tensor, what: str) -> torch.Tensor:
+    """fp32 GPU matrix whose rows are contiguous; a row pitch larger than the width is kept (views of the
+    lock-step state buffers, [:, :H] of [N, H + H/16]) instead of being copied."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        return _dev(t, what, torch.float32)
+    if t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1] \
+            and t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0:
+        return t
+    return _dev(t, what, torch.float32)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -97,11 +108,11 @@ class PlanHandle(object):
         self.desc = Plan(self.ws.data_ptr(), nbytes, self.N, self.E, self.B, self.R)
 
     def layout(self) -> dict:
-        off = (C.c_int64 * 20)()
+        off = (C.c_int64 * 24)()
         check(_lib.load().dagnn_plan_layout(self.N, self.E, self.B, self.R, off), "dagnn_plan_layout")
         names = ["node_ptr", "edge_ptr", "depth0", "depth1", "order0", "order1", "lstart0", "lstart1", "rowptr0",
                  "rowptr1", "col0", "col1", "eattr0", "eattr1", "items", "total", "blptr0", "blptr1", "rowrec0",
-                 "rowrec1"]
+                 "rowrec1", "slot0", "slot1", "eidx0", "eidx1"]
         return {k: int(v) // 4 for k, v in zip(names, off)}
 
     def read_schedule(self):
@@ -167,7 +178,10 @@ def gemm_nt_bias(A: Sequence[torch.Tensor], W: Sequence[torch.Tensor], bias: Seq
                  out: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
     """C_g = A_g @ W_g^T + bias_g for up to 4 groups sharing M, K and Nc (one launch)."""
     n = len(A)
-    A = [_dev(a, "A", torch.float32) for a in A]
+    A = [_rows(a, "A") for a in A]
+    if len({a.stride(0) for a in A}) > 1:
+        A = [a.contiguous() for a in A]
+    lda = A[0].stride(0)
     W = [_dev(w, "W", torch.float32) for w in W]
     M, K = A[0].shape
     Nc = W[0].shape[0]
@@ -183,7 +197,7 @@ def gemm_nt_bias(A: Sequence[torch.Tensor], W: Sequence[torch.Tensor], bias: Seq
         keep.append(b)
         groups[g] = GemmGroup(A[g].data_ptr(), W[g].data_ptr(), _ptr(b), out[g].data_ptr())
     with _span("gemm_nt_bias", A[0]):
-        check(_lib.load().dagnn_gemm_nt_bias(groups, n, M, Nc, K, K, K, Nc, _stream(A[0])), "dagnn_gemm_nt_bias")
+        check(_lib.load().dagnn_gemm_nt_bias(groups, n, M, Nc, K, lda, K, Nc, _stream(A[0])), "dagnn_gemm_nt_bias")
     return list(out)
 
 
@@ -337,9 +351,77 @@ def recurrence_layer(plan: PlanHandle, dirs: Sequence[int], H: int, gi, w_hh_t, 
 
 
 def readout_max(plan: PlanHandle, h: torch.Tensor, direction: int, out: torch.Tensor, col_off: int) -> None:
-    h = _dev(h, "h", torch.float32)
-    check(_lib.load().dagnn_readout_max(C.byref(plan.desc), h.data_ptr(), h.shape[1], h.shape[1], direction,
+    h = _rows(h, "h")
+    check(_lib.load().dagnn_readout_max(C.byref(plan.desc), h.data_ptr(), h.stride(0), h.shape[1], direction,
                                         out.data_ptr(), out.shape[1], col_off, _stream(h)), "dagnn_readout_max")
+
+
+def readout_max_backward(plan: PlanHandle, h: torch.Tensor, direction: int, grad_out: torch.Tensor, col_off: int,
+                         grad_h: torch.Tensor) -> None:
+    """grad_h[v, :] += grad_out[g, col_off : col_off + width] at the arg-max output node of every graph/column."""
+    h = _rows(h, "h")
+    grad_out = _dev(grad_out, "grad_out", torch.float32)
+    check(_lib.load().dagnn_readout_max_backward(C.byref(plan.desc), h.data_ptr(), h.stride(0), h.shape[1], direction,
+                                                 grad_out.data_ptr(), grad_out.shape[1], col_off, grad_h.data_ptr(),
+                                                 grad_h.stride(0), _stream(h)), "dagnn_readout_max_backward")
+
+
+def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, h, gi0, g_ext):
+    """Reverse pass of the lock-step recurrence (csrc/backward.hip).  `h[d][i]` [N, frontier_ld(H)] are the
+    forward state buffers, `gi0[d]` [N,3H] the input-side pre-activations of stacked layer 0, `g_ext[d][i]`
+    [N,H] the gradients reaching the states from outside (modified: stacked layers below the top receive the
+    upper layer's input gradient).  Returns per cell (d, i) a dict with a, dgi, dgh, sigma, edge_feat_grad."""
+    dev = plan.ws.device
+    N, E, R = plan.N, plan.E, plan.R
+    args = BackwardArgs()
+    out = {}
+    mask = 0
+    f32 = dict(dtype=torch.float32, device=dev)
+    for d in dirs:
+        mask |= 1 << d
+        for i in range(L):
+            c, bc = cells[(d, i)], args.cell[d][i]
+            o = dict(a=torch.empty(N, H, **f32), alpha=torch.empty(max(E, 1), **f32), da=torch.empty(N, H, **f32),
+                     dgi=torch.empty(N, 3 * H, **f32), dgh=torch.empty(N, 3 * H, **f32), sigma=torch.empty(N, **f32),
+                     edge_feat_grad=torch.empty(N, R, **f32) if R > 0 else None)
+            out[(d, i)] = o
+            bc.w_hh, bc.w_ih = c.w_hh_raw.data_ptr(), (c.w_ih.data_ptr() if i > 0 else None)
+            bc.w_key, bc.edge_gain = c.w_key.data_ptr(), (_ptr(c.edge_gain) if R > 0 else None)
+            bc.h, bc.a, bc.alpha = h[d][i].data_ptr(), o["a"].data_ptr(), o["alpha"].data_ptr()
+            bc.g_ext, bc.da, bc.dgi, bc.dgh = g_ext[d][i].data_ptr(), o["da"].data_ptr(), o["dgi"].data_ptr(), o["dgh"].data_ptr()
+            bc.sigma, bc.edge_feat_grad = o["sigma"].data_ptr(), _ptr(o["edge_feat_grad"])
+    args.num_stacked, args.dir_mask, args.H, args.ld_h = L, mask, H, h[dirs[0]][0].shape[1]
+    args.num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    lib = _lib.load()
+    with _span("backward_prepare", plan.ws):
+        check(lib.dagnn_backward_prepare(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_backward_prepare")
+    # pre-activations of every cell, recomputed by batched MFMA GEMMs (all rows at once: every h is known)
+    keys = [(d, i) for d in dirs for i in range(L)]
+    gh = {}
+    for k0 in range(0, len(keys), 4):
+        grp = keys[k0:k0 + 4]
+        res = gemm_nt_bias([out[k]["a"] for k in grp], [cells[k].w_hh_raw for k in grp], [cells[k].b_hh for k in grp])
+        gh.update(dict(zip(grp, res)))
+    gi = {(d, 0): gi0[d] for d in dirs}
+    up = [(d, i) for d in dirs for i in range(1, L)]
+    for k0 in range(0, len(up), 4):
+        grp = up[k0:k0 + 4]
+        res = gemm_nt_bias([h[d][i - 1][:, :H] for d, i in grp], [cells[k].w_ih for k in grp],
+                           [cells[k].b_ih for k in grp])
+        gi.update(dict(zip(grp, res)))
+    for k in keys:
+        args.cell[k[0]][k[1]].gi, args.cell[k[0]][k[1]].gh = gi[k].data_ptr(), gh[k].data_ptr()
+        out[k]["gi"], out[k]["gh"] = gi[k], gh[k]
+    sched = plan.read_schedule()
+    ptrs = (C.POINTER(C.c_int32) * 2)()
+    nl = (C.c_int32 * 2)()
+    for d in (0, 1):
+        ptrs[d] = sched[d].ctypes.data_as(C.POINTER(C.c_int32))
+        nl[d] = len(sched[d]) - 1
+    with _span("backward_run", plan.ws):
+        check(lib.dagnn_backward_run(C.byref(plan.desc), C.byref(args), ptrs, nl, _stream(plan.ws)),
+              "dagnn_backward_run")
+    return out
 
 
 def gather_rows(h: torch.Tensor, num_graphs: int, stride: int, node_off: int, out: torch.Tensor,

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import constants as K
 from . import engine
-from .core import DerivedCache, default_schedule, derive_cell, num_graphs_of, require_inference, run_stack
+from .core import DerivedCache, default_schedule, derive_cell, num_graphs_of, run_stack
 
 
 class ASTNodeEncoder(nn.Module):
@@ -36,10 +36,13 @@ class ASTNodeEncoder(nn.Module):
 
     def forward(self, x, depth):
         if x.is_cuda and self.type_encoder.weight.shape[1] % 4 == 0 and depth.dtype == torch.int64 \
-                and depth.is_contiguous() and not (torch.is_grad_enabled() and self.type_encoder.weight.requires_grad):
-            return engine.encode_ast(x, depth, self.type_encoder.weight, self.attribute_encoder.weight,
-                                     self.depth_encoder.weight, self.max_depth)
-        # generic torch path (training of the tables, odd widths): same math as utils.py:26-28
+                and depth.is_contiguous():
+            tables = (self.type_encoder.weight, self.attribute_encoder.weight, self.depth_encoder.weight)
+            if torch.is_grad_enabled() and any(t.requires_grad for t in tables):
+                from .autograd import EncodeAST
+                return EncodeAST.apply(x, depth, *tables, self.max_depth)
+            return engine.encode_ast(x, depth, *tables, self.max_depth)
+        # generic torch path (odd widths): same math as utils.py:26-28
         depth[depth > self.max_depth] = self.max_depth
         return self.type_encoder(x[:, 0]) + self.attribute_encoder(x[:, 1]) + self.depth_encoder(depth)
 
@@ -232,6 +235,35 @@ class DAGNN(nn.Module):
 
         return self._derived.setdefault(self.schedule, DerivedCache()).get(srcs, make)
 
+    def _arena_for(self, x):
+        return self._arenas.setdefault((x.device, torch.cuda.current_stream(x.device).cuda_stream),
+                                       engine.GranuleArena())
+
+    def _training_pass(self) -> bool:
+        """True when this call must be differentiable.  The HIP backward (csrc/backward.hip) covers what the
+        reference's training scripts run (scripts/ogb_tok.sh: attn_h, bidirectional, max-pool over the output
+        nodes); other combinations raise instead of silently detaching."""
+        if not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            return False
+        ok = (self.agg == K.NA_ATTN_H and self.bidirectional and not self.output_all and self.out_pool == K.P_MAX
+              and self.schedule == "lockstep" and self.emb_dim % 4 == 0)
+        if not ok:
+            raise NotImplementedError(
+                "the HIP backward pass covers agg='attn_h', bidirectional=True, out_pool_all=False, out_pool='max' "
+                "with the lock-step schedule; call this configuration under torch.no_grad() (evaluation) or "
+                "freeze its parameters")
+        return True
+
+    def _train_params(self):
+        flat = []
+        for d in self.dirs:
+            for i in range(self.num_layers):
+                c = getattr(self, "cells_%d" % d)[i]
+                a = getattr(self, "node_aggr_%d" % d)[i]
+                flat += [c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh, a.attn_lin.weight, a.attn_lin.bias,
+                         a.edge_encoder.weight if a.wea else None, a.edge_encoder.bias if a.wea else None]
+        return flat
+
     def _pool(self, h, batch, B):
         """`global_{max,mean,add}_pool` / P_ATTN read-outs on torch (variants outside BASELINE)."""
         how = self.out_pool
@@ -254,7 +286,7 @@ class DAGNN(nn.Module):
             raise NotImplementedError(
                 "aggregator %r / agg_x=%r / recurr=%r: the HIP path implements the additive-attention aggregators "
                 "%s with agg_x=False, recurr=1" % (self.agg, self.agg_x, self.recurr, (self._HIP_AGGS,)))
-        require_inference(self)
+        train = self._training_pass()
         L, H, dirs = self.num_layers, self.hidden_dim, self.dirs
 
         # side effect 1 (dagnn.py:130-133)
@@ -267,13 +299,21 @@ class DAGNN(nn.Module):
         has_edge_enc = getattr(self.node_aggr_0[0], "wea", False)
         plan = engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B,
                                  G.edge_attr if has_edge_enc else None)
+        if train:
+            from .autograd import Recurrence
+            res = Recurrence.apply(self, plan, B, x, *self._train_params())
+            out, flat = res[0], res[1:]
+            G.h = [[flat[q * L + i] for i in range(L)] for q in range(len(dirs))]
+            out = self.dropout(out)
+            if self.num_class > 0:
+                return self.graph_pred_linear(out)
+            return [self.graph_pred_linear_list[i](out) for i in range(self.max_seq_len)]
         cells = self._cells()
         sscore = None
         if self.agg_attn_x:  # keys are the node inputs: one static score per node and cell (dagnn.py:175-177)
             sscore = {k: torch.mv(x, c.key_raw) for k, c in cells.items()}
         h = run_stack(plan, x, cells, dirs, L, H, schedule=self.schedule, static_score=sscore,
-                      arena=self._arenas.setdefault((x.device, torch.cuda.current_stream(x.device).cuda_stream),
-                                                   engine.GranuleArena()))
+                      arena=self._arena_for(x))
         G.h = [[h[d][i] for i in range(L)] for d in dirs]  # side effect 4 (dagnn.py:141-142,182)
 
         if self.bidirectional and not self.output_all:

@@ -228,17 +228,70 @@ int dagnn_frontier_run(const dagnn_plan* plan /* host */, const dagnn_frontier_a
 int dagnn_readout_max(const dagnn_plan* plan /* host */, const float* h, int ld_h, int width, int dir,
                       float* out, int ld_out, int col_off, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Backward pass of the recurrence (training: what `loss.backward()`, ogbg-code/main_pyg.py:62, does to
+ * dagnn.py:144-182).  Additive attention with keys from the hidden states (`attn_h`), GRU cells.
+ * The forward pass keeps only the lock-step state buffers h[d][i] ([N,ld_h], scores behind the rows).
+ *
+ *   1. dagnn_backward_prepare: a[c] [N,H] (attention aggregates) and alpha[c] [E] (attention weights,
+ *      indexed by ORIGINAL edge id) of every cell, one parallel launch;
+ *   2. caller: gh[c] = a[c] W_hh^T + b_hh and gi[c] = u W_ih^T + b_ih (dagnn_gemm_nt_bias), g_ext[c] [N,H]
+ *      = gradient reaching h[c] from outside the recurrence (read-out; dagnn_readout_max_backward);
+ *   3. dagnn_backward_run: T + L - 1 reverse lock-step launches.  Adds W_ih^T dgi of stacked layer i into
+ *      g_ext of layer i-1 and writes, per cell: da [N,H], dgi, dgh [N,3H] (gradients of the GRU
+ *      pre-activations, gate blocks r,z,n), sigma [N] (sum over a node's out-edges of the attention-logit
+ *      gradients) and edge_feat_grad [N,R] (the same sum weighted by the edge features);
+ *   4. caller (plain library GEMMs / reductions): dW_ih = dgi^T u, db_ih = colsum(dgi), dW_hh = dgh^T a,
+ *      db_hh = colsum(dgh), dx = sum_d dgi[d][0] W_ih, d w_key = h^T sigma + W_e colsum(edge_feat_grad),
+ *      dW_e = w_key (x) colsum(edge_feat_grad).  The attention query weights and biases get exact zeros
+ *      (they cancel inside the segment softmax).
+ * Deterministic: gradients are pulled (no atomics), sums run in a fixed order.  H % 64 == 0, H <= 1024.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dagnn_backward_cell {
+    const float* w_hh;      /* [3H,H] torch layout (padded to H) */
+    const float* w_ih;      /* [3H,H] (stacked layers > 0), else NULL */
+    const float* w_key;     /* [H] */
+    const float* edge_gain; /* [num_edge_feats] or NULL */
+    const float* h;         /* [N,ld_h] forward states + partial scores */
+    float* a;               /* [N,H]  written by prepare, read by run */
+    float* alpha;           /* [E]    written by prepare, read by run */
+    const float* gi;        /* [N,3H] */
+    const float* gh;        /* [N,3H] */
+    float* g_ext;           /* [N,H] in; stacked layers below the top also receive the upper layer's du */
+    float* da;              /* [N,H] out */
+    float* dgi;             /* [N,3H] out */
+    float* dgh;             /* [N,3H] out */
+    float* sigma;           /* [N] out */
+    float* edge_feat_grad;  /* [N,num_edge_feats] out, or NULL without edge features */
+} dagnn_backward_cell;
+
+typedef struct dagnn_backward_args {
+    dagnn_backward_cell cell[DAGNN_MAX_DIRS][DAGNN_MAX_STACKED];
+    int num_stacked, dir_mask, H, ld_h;
+    int num_cus;
+} dagnn_backward_args;
+
+int dagnn_backward_prepare(const dagnn_plan* plan /* host */, const dagnn_backward_args* args /* host */, void* stream);
+int dagnn_backward_run(const dagnn_plan* plan /* host */, const dagnn_backward_args* args /* host */,
+                       const int32_t* const* layer_ptr /* host */, const int32_t* num_layers /* host */, void* stream);
+
+/* grad_h[v, j] += grad_out[g, col_off + j] for the first output node v of graph g attaining the maximum
+ * of column j (the single winner of scatter-max); grad_h must be initialised by the caller. */
+int dagnn_readout_max_backward(const dagnn_plan* plan /* host */, const float* h, int ld_h, int width, int dir,
+                               const float* grad_out, int ld_out, int col_off, float* grad_h, int ld_g, void* stream);
+
 /* D-VAE read-out (dvae/dagnn.py:147-161, dvae/dagnn_bn.py:138-152): every graph has exactly
  * `stride` nodes; gather row g*stride + node_off of h [N,ld_h] into out[g, col_off : col_off+width]. */
 int dagnn_gather_rows(const float* h, int ld_h, int width, int64_t num_graphs, int stride, int node_off,
                       float* out, int ld_out, int col_off, void* stream);
 
 /* Introspection (tests, and the host-side read-back of the lock-step schedule): byte offsets of the
- * plan's arrays from `plan->data`, into a host array of 20 entries: [node_ptr, edge_ptr, depth0,
+ * plan's arrays from `plan->data`, into a host array of 24 entries: [node_ptr, edge_ptr, depth0,
  * depth1, order0, order1, lstart0, lstart1, rowptr0, rowptr1, col0, col1, eattr0, eattr1, items,
- * total, blptr0, blptr1, rowrec0, rowrec1].  blptr_d holds N+2 int32: the offsets of the
+ * total, blptr0, blptr1, rowrec0, rowrec1, slot0, slot1, eidx0, eidx1].  slot_d [N]: rowrec slot of
+ * every node; eidx_d [E]: original edge id (column of edge_index) of every CSR slot.  blptr_d holds N+2 int32: the offsets of the
  * batch-level topological layers of direction d (entries 0..T_d) and T_d itself at index N+1. */
-int dagnn_plan_layout(int64_t N, int64_t E, int64_t B, int num_edge_feats, int64_t* offsets20 /* host */);
+int dagnn_plan_layout(int64_t N, int64_t E, int64_t B, int num_edge_feats, int64_t* offsets24 /* host */);
 
 #ifdef __cplusplus
 }

@@ -36,7 +36,7 @@ def test_host_only_entry_points_without_gpu():
     lib = _lib.load()
     n = lib.dagnn_plan_bytes(16561, 25377, 128, 2)
     assert n > 0 and n % 4 == 0
-    off = (ctypes.c_int64 * 20)()
+    off = (ctypes.c_int64 * 24)()
     assert lib.dagnn_plan_layout(16561, 25377, 128, 2, off) == 0
     offs = list(off)
     assert offs[15] == n and all(a < b for a, b in zip(offs[:14], offs[1:15])) and all(o < n for o in offs[16:])
@@ -174,7 +174,18 @@ def test_checkpoint_roundtrip_with_module_prefix(tmp_path):
 
 
 def test_grad_mode_raises_instead_of_silently_detaching():
-    meta, arr = Hh.load("code2_h32_bidir")
+    """Configurations the HIP backward does not cover refuse a differentiable call; the covered one goes to
+    the HIP path (and, on CPU tensors, fails loudly there - there is no fallback)."""
+    meta, arr = Hh.load("code2_h64_unidir")
     model = Hh.code2_model(meta)
     with pytest.raises(NotImplementedError):
         model(Hh.code2_batch(arr))
+    meta, arr = Hh.load("code2_h64_attn_x")
+    with pytest.raises(NotImplementedError):
+        Hh.code2_model(meta)(Hh.code2_batch(arr))
+    meta, arr = Hh.load("code2_h32_bidir")
+    with pytest.raises(_lib.DagnnHipError):
+        Hh.code2_model(meta)(Hh.code2_batch(arr))
+    model, _ = Hh.dvae_model(Hh.load("na_h64_bidir")[0])
+    with pytest.raises(NotImplementedError):
+        model(Hh.dvae_batch(Hh.load("na_h64_bidir")[1]))

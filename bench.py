@@ -83,6 +83,61 @@ def cpu_baseline(model_cpu_sd, batch, L, S, passes, threads):
             "ms_per_batch": round(med * 1e3, 1)}
 
 
+def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
+    """One training step as ogbg-code/main_pyg.py:39-65 runs it: zero_grad, forward, mean-over-heads
+    cross-entropy, backward, (N>1: ONE all-reduce of the flat gradient bucket over RCCL), Adam step.
+    Reported next to the headline forward metric, never as `value`."""
+    from dagnn_amd import engine
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=device)
+    off = 0
+    for p in params:  # gradients live in one bucket: autograd accumulates in place, one collective per step
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    opt = torch.optim.Adam(params, lr=1e-3)
+    y = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(1)).to(device)
+    ce = torch.nn.CrossEntropyLoss()
+
+    def step(G):
+        flat.zero_()
+        pred = model(G)
+        loss = sum(ce(pred[s], y[:, s]) for s in range(S)) / S
+        loss.backward()
+        if world > 1:
+            dist.all_reduce(flat)
+            flat.div_(world)
+        opt.step()
+        return loss
+
+    for i in range(warmup):
+        step(inputs[i])
+    torch.cuda.synchronize()
+    timer = engine.KernelTimer()
+    engine.TIMER = timer
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        loss = step(inputs[i])
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    engine.TIMER = None
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    summ = timer.summary()
+    model.eval()
+    return {"what": "zero_grad + forward + mean-CE over %d heads + backward%s + Adam step (main_pyg.py:39-65)"
+                    % (S, " + one RCCL all-reduce of the %.1f M-float gradient bucket" % (flat.numel() / 1e6)
+                       if world > 1 else ""),
+            "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "graphs_per_s": round(world * B * steps / elapsed, 1), "final_loss": round(float(loss), 4),
+            "kernels_ms_per_step": {k: round(n * ms / steps, 4) for k, (n, ms) in summ.items()}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +149,9 @@ def main():
     ap.add_argument("--vocab", type=int, default=5002)
     ap.add_argument("--cpu-passes", type=int, default=3, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=10,
+                    help="also time this many full training steps (fwd + bwd + optimizer) after the headline "
+                         "forward measurement and report them as `training_step`; 0 disables the leg")
     ap.add_argument("--schedule", choices=["lockstep", "pergraph"], default=None,
                     help="recurrence schedule (default: the library default, lock-step frontier launches)")
     ap.add_argument("--streams", type=int, default=1,
@@ -167,6 +225,12 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    cpu_sd = {k: v.detach().cpu() for k, v in model.state_dict().items()} if (rank == 0 and args.cpu_passes > 0) else None
+    train_res = None
+    if args.train_steps > 0 and args.streams == 1 and model.schedule == "lockstep":
+        tw = 3
+        train_res = training_leg(model, fresh_inputs(master, tw + args.train_steps), B, S, V, args.train_steps, tw,
+                                 world, device, barrier)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
@@ -224,8 +288,9 @@ def main():
                     "recurrence": round(ms_fwd, 4),
                     "gemm_nt_bias": round(ms_gemm * n_gemm / args.steps, 4),
                     "plan_build": round(ms_plan * n_plan / args.steps, 4)}
+        if train_res is not None:
+            result["training_step"] = train_res
         if args.cpu_passes > 0:
-            cpu_sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             result["cpu_baseline"] = cpu_baseline(cpu_sd, batch_cpu, L, S, args.cpu_passes, args.cpu_threads)
         print(json.dumps(result))
     barrier()

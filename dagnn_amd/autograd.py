@@ -37,6 +37,21 @@ class EncodeAST(torch.autograd.Function):
         return (None, None, grads[0], grads[1], grads[2], None)
 
 
+def _wgrad(dg: torch.Tensor, u: torch.Tensor, splits: int = 32) -> torch.Tensor:
+    """dg^T @ u for [N, J] x [N, K] with N >> J, K (a weight gradient): the reduction dimension is the long one,
+    so it is split into `splits` batches (one library bmm fills the GPU; a plain GEMM here has J*K/128^2 = 12
+    output tiles for 256 CUs) and the partial products are summed in a fixed order."""
+    N = dg.shape[0]
+    n = N // splits * splits
+    if n == 0:
+        return dg.t() @ u
+    out = torch.bmm(dg[:n].view(splits, n // splits, dg.shape[1]).transpose(1, 2),
+                    u[:n].reshape(splits, n // splits, u.shape[1])).sum(0)
+    if n < N:
+        out = out + dg[n:].t() @ u[n:]
+    return out
+
+
 class Recurrence(torch.autograd.Function):
     """Plan + embedding -> pooled read-out [B, D*L*H (+ D*emb)] of the bidirectional max-pool configuration
     (dagnn.py:144-193).  Inputs after `x` are the cells' parameters, 8 per (direction, stacked layer):
@@ -97,15 +112,15 @@ class Recurrence(torch.autograd.Function):
                 r = res[(d, i)]
                 dgi, dgh = gates(r["dgi"]), gates(r["dgh"])
                 u = x if i == 0 else h[d][i - 1]
-                g_wih, g_bih = dgi.t() @ u, dgi.sum(0)
-                g_whh, g_bhh = dgh.t() @ r["a"][:, :H], dgh.sum(0)
+                g_wih, g_bih = _wgrad(dgi, u), dgi.sum(0)
+                g_whh, g_bhh = _wgrad(dgh, r["a"][:, :H]), dgh.sum(0)
                 if i == 0:
                     dx = dx + dgi @ w_ih
                 # attention logit s_e = w_key . (h_p + W_e feat_e + b_e) (+ query and bias terms that cancel in
                 # the segment softmax: their gradients are exact zeros)
                 dq = attn_w.shape[1] - H
                 sigma = r["sigma"]
-                g_key = h[d][i].t() @ sigma
+                g_key = (h[d][i] * sigma[:, None]).sum(0)
                 g_edge_w = g_edge_b = None
                 if edge_w is not None:
                     m, ssum = r["edge_feat_grad"].sum(0), sigma.sum()

@@ -25,19 +25,22 @@
 //   bias gradients are dgi^T u, dgh^T a and column sums), sigma_v = sum_e ds_e [N] and
 //   sum_e ds_e feat_e [N,R] (attention-key and edge-encoder gradients).
 //
-// Work split of a launch: workgroup = (cell, block of RB rows, slice of 64 hidden units).  Wave w pulls
-// row w (+4, ...), all threads do the gate algebra of the full rows (cheap, recomputed per slice), then
-// wave w multiplies k-range w of the [3H x 64] weight slice - lanes own output units, so every weight
-// load is one contiguous 256 B read of the torch-layout matrix (no packed copy), the gradients are LDS
-// broadcasts - and the four partial sums meet in LDS in wave order.
+// Work split of a launch: workgroup = (cell, block of RB rows, slice of 16 hidden units), 8 waves.  Wave w
+// pulls row w, all threads do the gate algebra of the full rows (cheap, recomputed per slice), then every
+// lane multiplies its k-group of the [3H x 16] weight slices (torch layout, no packed copy; for H <= 256 the
+// slice sits in registers, loaded before anything else) against LDS broadcasts of the gradients, and the 32
+// partial sums meet in LDS in k-group order.
 #include "common.h"
 
 #define DAGNN_BWD_MAX_CELLS 16
 
 namespace {
 
-constexpr int BT = 256;   // threads per workgroup
-constexpr int BJS = 64;   // hidden units per slice
+constexpr int BT = 256;   // threads per workgroup (prepare kernel)
+constexpr int ST = 512;   // threads per workgroup of the sweep kernel (8 waves)
+constexpr int SW = ST / 64;
+constexpr int KREG = 24;  // k values per lane and matrix held in registers (3H/32 for H = 256)
+constexpr int BJS = 16;   // hidden units per slice (a wave = 16 units x 4 k-groups)
 constexpr int BPU = 16;   // hidden units per stored score part (frontier.hip PU)
 
 struct BCell {
@@ -131,43 +134,83 @@ __global__ void __launch_bounds__(BT) bwd_prepare_kernel(const int32_t* __restri
     }
 }
 
-// ---- one reverse lock-step launch -----------------------------------------------------------------
-// LDS (floats): g_s[RB][H] | dgh_t[3H][RB] | dgi_t[3H][RB] | red[2][4][RB][64] | node[RB] (ints)
-template <int RB>
-__global__ void __launch_bounds__(BT) bwd_step_kernel(const int32_t* __restrict__ plan, PlanLayout L, BArgs S) {
-    extern __shared__ float lds[];
-    const int H = S.H, H3 = 3 * H, H4 = H >> 2, ld_h = S.ld_h;
-    float* g_s = lds;
-    float* dgh_t = g_s + RB * H;
-    float* dgi_t = dgh_t + H3 * RB;
-    float* red = dgi_t + H3 * RB;
-    int* node_s = reinterpret_cast<int*>(red + 2 * 4 * RB * BJS);
+// ---- successor records: brec[d][slot] (64 B) = {node, first/last CSR slot of its row in direction 1-d,
+// 0, first four successors, their original edge ids, 4 spare words}.  The dependent chain of a sweep
+// launch becomes record -> successor rows (the forward kernels' rowrec trick, built once per batch).
+__global__ void __launch_bounds__(256) bwd_succrec_kernel(int32_t* plan, PlanLayout L, int N) {
+    const int d = blockIdx.y, od = 1 - d;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= N) return;
+    const int v = plan[L.rowrec[d] + 16 * (int64_t)slot];
+    const int4* orec = reinterpret_cast<const int4*>(plan + L.rowrec[od]) + 4 * (int64_t)plan[L.pos[od] + v];
+    const int4 r0 = orec[0], r1 = orec[1];
+    const int eb = r0.y, ee = r0.z;
+    const int32_t* eidx = plan + L.eidx[od];
+    int4* out = reinterpret_cast<int4*>(plan + L.brec[d] + 16 * (int64_t)slot);
+    out[0] = make_int4(v, eb, ee, 0);
+    out[1] = r1;
+    out[2] = make_int4(eb < ee ? eidx[eb] : 0, eb + 1 < ee ? eidx[eb + 1] : 0, eb + 2 < ee ? eidx[eb + 2] : 0,
+                       eb + 3 < ee ? eidx[eb + 3] : 0);
+    out[3] = make_int4(0, 0, 0, 0);
+}
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NS = H / BJS;
-    const int slice = blockIdx.x % NS, gblk = blockIdx.x / NS;
-    int c = 0;
-    while (c + 1 < S.ncell && gblk >= S.blk_start[c + 1]) ++c;
-    const BCell& C = S.cell[c];
-    const int d = C.dir, od = 1 - d, R = C.mrel ? S.R : 0;
-    const int row0 = C.row_base + (gblk - S.blk_start[c]) * RB;
-    const int nrows = min(RB, C.row_end - row0);
-
-    // ---- 1. pull: G_v = Gext_v + sum over successors, one wave per row
-    for (int r = wave; r < nrows; r += 4) {
-        const int v = plan[L.rowrec[d] + 16 * (int64_t)(row0 + r)];
-        if (lane == 0) node_s[r] = v;
-        const int4 srec = reinterpret_cast<const int4*>(plan + L.rowrec[od])[4 * (int64_t)plan[L.pos[od] + v]];
-        const int eb = srec.y, ee = srec.z;
+// One wave: grow[0..H) (LDS) = Gext_v + sum over the successors of the node of record `rec` (see file header);
+// `publish`: also store sigma_v and the edge-feature sums.
+__device__ __forceinline__ void pull_row(const int32_t* __restrict__ plan, const PlanLayout& L, const BCell& C,
+                                         const int4* __restrict__ rec, int R, int H, int ld_h, float* grow, int lane,
+                                         bool publish) {
+    const int H4 = H >> 2, od = 1 - C.dir;
+    const int4 b0 = rec[0];
+    const int v = b0.x, eb = b0.y, ee = b0.z, deg = ee - eb;
+    const float* eattr = reinterpret_cast<const float*>(plan + L.eattr[od]);
+    const float* hv = C.h + (int64_t)v * ld_h;
+    float sig = 0.f, m0 = 0.f, m1 = 0.f;
+    if (deg <= 4 && H4 <= 64) {
+        // inline path: successor ids and edge ids came with the record; all rows in one round trip
+        const int4 b1 = rec[1], b2 = rec[2];
+        auto pick = [](const int4& b, int e) { return e == 0 ? b.x : e == 1 ? b.y : e == 2 ? b.z : b.w; };
+        const bool on = lane < H4;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 g = zero, y = zero, wk = zero;
+        if (on) {
+            g = reinterpret_cast<const float4*>(C.gext + (int64_t)v * H)[lane];
+            y = reinterpret_cast<const float4*>(hv)[lane];
+            wk = reinterpret_cast<const float4*>(C.wkey)[lane];
+        }
+        float4 x[4], z[4];
+        float al[4], f0[4], f1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x[e] = zero; z[e] = zero; al[e] = 0.f; f0[e] = 0.f; f1[e] = 0.f;
+            if (e < deg) {
+                al[e] = C.alpha[pick(b2, e)];
+                if (on) {
+                    x[e] = reinterpret_cast<const float4*>(C.da + (int64_t)pick(b1, e) * H)[lane];
+                    z[e] = reinterpret_cast<const float4*>(C.a + (int64_t)pick(b1, e) * H)[lane];
+                }
+                if (R >= 1) f0[e] = eattr[(int64_t)(eb + e) * R];
+                if (R >= 2) f1[e] = eattr[(int64_t)(eb + e) * R + 1];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (e >= deg) continue;
+            float dot = x[e].x * (y.x - z[e].x);
+            dot = fmaf(x[e].y, y.y - z[e].y, dot); dot = fmaf(x[e].z, y.z - z[e].z, dot);
+            dot = fmaf(x[e].w, y.w - z[e].w, dot);
+            const float ds = al[e] * wave_sum(dot);
+            sig += ds;
+            m0 = fmaf(ds, f0[e], m0); m1 = fmaf(ds, f1[e], m1);
+            g.x = fmaf(al[e], x[e].x, g.x); g.y = fmaf(al[e], x[e].y, g.y);
+            g.z = fmaf(al[e], x[e].z, g.z); g.w = fmaf(al[e], x[e].w, g.w);
+        }
+        g.x = fmaf(sig, wk.x, g.x); g.y = fmaf(sig, wk.y, g.y); g.z = fmaf(sig, wk.z, g.z); g.w = fmaf(sig, wk.w, g.w);
+        if (on) reinterpret_cast<float4*>(grow)[lane] = g;
+    } else {
         const int32_t* col = plan + L.col[od];
         const int32_t* eidx = plan + L.eidx[od];
-        const float* eattr = reinterpret_cast<const float*>(plan + L.eattr[od]);
-        const float* hv = C.h + (int64_t)v * ld_h;
-        float* grow = g_s + r * H;
         for (int cc = lane; cc < H4; cc += 64)
             reinterpret_cast<float4*>(grow)[cc] = reinterpret_cast<const float4*>(C.gext + (int64_t)v * H)[cc];
-        float sig = 0.f, m0 = 0.f, m1 = 0.f;
         for (int e = eb; e < ee; ++e) {
             const int w = col[e];
             const float al = C.alpha[eidx[e]];
@@ -195,34 +238,96 @@ __global__ void __launch_bounds__(BT) bwd_step_kernel(const int32_t* __restrict_
             g.x = fmaf(sig, k.x, g.x); g.y = fmaf(sig, k.y, g.y); g.z = fmaf(sig, k.z, g.z); g.w = fmaf(sig, k.w, g.w);
             reinterpret_cast<float4*>(grow)[cc] = g;
         }
-        if (slice == 0 && lane == 0) {
-            C.sig[v] = sig;
-            if (R >= 1) C.mrel[(int64_t)v * R] = m0;
-            if (R >= 2) C.mrel[(int64_t)v * R + 1] = m1;
+    }
+    if (publish && lane == 0) {
+        C.sig[v] = sig;
+        if (R >= 1) C.mrel[(int64_t)v * R] = m0;
+        if (R >= 2) C.mrel[(int64_t)v * R + 1] = m1;
+    }
+}
+
+// ---- one reverse lock-step launch -----------------------------------------------------------------
+// Workgroup = (cell, block of RB rows, slice of 16 hidden units), 8 waves.  Lane = (unit, k-group): the 32
+// k-groups of a workgroup each own 3H/32 rows of the [3H x 16] weight slices.
+// LDS (floats): g_s[RB][H] | dgh_t[3H][RB] | dgi_t[3H][RB] | red[2][32][RB][16]
+// PRE (H <= 256): every lane issues the loads of its whole k-range of both weight slices into registers
+// first, then the operands of the gate algebra (they depend only on the node ids of the records), and only
+// then walks record -> successor rows; the products are pure LDS-broadcast + FMA.  The dependent chain of a
+// thin launch - which is what bounds the sweep - is two memory round trips plus three barriers.
+template <int RB, bool PRE>
+__global__ void __launch_bounds__(ST) bwd_step_kernel(const int32_t* __restrict__ plan, PlanLayout L, BArgs S) {
+    extern __shared__ float lds[];
+    const int H = S.H, H3 = 3 * H, H4 = H >> 2, ld_h = S.ld_h;
+    float* g_s = lds;
+    float* dgh_t = g_s + RB * H;
+    float* dgi_t = dgh_t + H3 * RB;
+    float* red = dgi_t + H3 * RB;
+    constexpr int KG = ST / BJS;               // k-groups per workgroup (32)
+    constexpr int NI = PRE ? RB * 256 / ST : 1;  // gate-algebra elements per thread (H <= 256)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NS = H / BJS;
+    const int slice = blockIdx.x % NS, gblk = blockIdx.x / NS;
+    int c = 0;
+    while (c + 1 < S.ncell && gblk >= S.blk_start[c + 1]) ++c;
+    const BCell& C = S.cell[c];
+    const int d = C.dir, od = 1 - d, R = C.mrel ? S.R : 0;
+    const int row0 = C.row_base + (gblk - S.blk_start[c]) * RB;
+    const int nrows = min(RB, C.row_end - row0);
+    const int ul = lane & (BJS - 1);
+    const int unit = slice * BJS + ul;
+    const int kg = wave * (64 / BJS) + (lane / BJS);
+    const int KQ = H3 / KG, k0 = kg * KQ;
+    const int4* brec = reinterpret_cast<const int4*>(plan + L.brec[d]) + 4 * (int64_t)row0;
+
+    float wr[PRE ? KREG : 1], wr2[PRE ? KREG : 1];
+    float pf[NI][7];
+    if (PRE) {
+        const float* wp = C.whh + (int64_t)k0 * H + unit;
+#pragma unroll
+        for (int k = 0; k < KREG; ++k) wr[k] = k < KQ ? wp[(int64_t)k * H] : 0.f;
+        if (C.wih) {
+            const float* wq = C.wih + (int64_t)k0 * H + unit;
+#pragma unroll
+            for (int k = 0; k < KREG; ++k) wr2[k] = k < KQ ? wq[(int64_t)k * H] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int idx = tid + j * ST, r = idx / H, u = idx - r * H;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) pf[j][q] = 0.f;
+            if (r < nrows) {
+                const int v = brec[4 * r].x;
+                const float* gi = C.gi + (int64_t)v * H3;
+                const float* gh = C.gh + (int64_t)v * H3;
+                pf[j][0] = gi[u]; pf[j][1] = gi[H + u]; pf[j][2] = gi[2 * H + u];
+                pf[j][3] = gh[u]; pf[j][4] = gh[H + u]; pf[j][5] = gh[2 * H + u];
+                pf[j][6] = C.a[(int64_t)v * H + u];
+            }
         }
     }
+
+    // ---- 1. pull: G_v = Gext_v + sum over successors, one wave per row
+    for (int r = wave; r < nrows; r += SW) pull_row(plan, L, C, brec + 4 * r, R, H, ld_h, g_s + r * H, lane, slice == 0);
     __syncthreads();
 
     // ---- 2. GRU backward of the full rows (gates recomputed); operands of the products go to LDS k-major
-    for (int idx = tid; idx < RB * H; idx += BT) {
+    auto gate_algebra = [&](int idx, float gir, float giz, float gin, float ghr, float ghz, float ghn, float av) {
         const int r = idx / H, u = idx - r * H;
         float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, zg = 0.f;
         if (r < nrows) {
-            const int v = node_s[r];
-            const float* gi = C.gi + (int64_t)v * H3;
-            const float* gh = C.gh + (int64_t)v * H3;
-            const float ghn = gh[2 * H + u];
-            const float rr = bsigm(gi[u] + gh[u]);
-            const float zz = bsigm(gi[H + u] + gh[H + u]);
-            const float nn = tanhf(gi[2 * H + u] + rr * ghn);
+            const float rr = bsigm(gir + ghr);
+            const float zz = bsigm(giz + ghz);
+            const float nn = tanhf(gin + rr * ghn);
             const float G = g_s[idx];
-            const float av = C.a[(int64_t)v * H + u];
             dn = G * (1.0f - zz) * (1.0f - nn * nn);          // d pre-activation of n
             dz = G * (av - nn) * zz * (1.0f - zz);            // d pre-activation of z
             dr = dn * ghn * rr * (1.0f - rr);                 // d pre-activation of r
             dnr = dn * rr;                                    // hidden-side n input sits behind r
             zg = G * zz;                                      // direct path h' = n + z (a - n)
             if (u / BJS == slice) {
+                const int v = brec[4 * r].x;
                 float* og = C.dgi + (int64_t)v * H3;
                 float* oh = C.dgh + (int64_t)v * H3;
                 og[u] = dr; og[H + u] = dz; og[2 * H + u] = dn;
@@ -232,64 +337,240 @@ __global__ void __launch_bounds__(BT) bwd_step_kernel(const int32_t* __restrict_
         g_s[idx] = zg;
         dgh_t[u * RB + r] = dr; dgh_t[(H + u) * RB + r] = dz; dgh_t[(2 * H + u) * RB + r] = dnr;
         dgi_t[u * RB + r] = dr; dgi_t[(H + u) * RB + r] = dz; dgi_t[(2 * H + u) * RB + r] = dn;
+    };
+    if (PRE) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int idx = tid + j * ST;
+            if (idx < RB * H) gate_algebra(idx, pf[j][0], pf[j][1], pf[j][2], pf[j][3], pf[j][4], pf[j][5], pf[j][6]);
+        }
+    } else {
+        for (int idx = tid; idx < RB * H; idx += ST) {
+            const int r = idx / H, u = idx - r * H;
+            float q[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (r < nrows) {
+                const int v = brec[4 * r].x;
+                const float* gi = C.gi + (int64_t)v * H3;
+                const float* gh = C.gh + (int64_t)v * H3;
+                q[0] = gi[u]; q[1] = gi[H + u]; q[2] = gi[2 * H + u];
+                q[3] = gh[u]; q[4] = gh[H + u]; q[5] = gh[2 * H + u];
+                q[6] = C.a[(int64_t)v * H + u];
+            }
+            gate_algebra(idx, q[0], q[1], q[2], q[3], q[4], q[5], q[6]);
+        }
     }
     __syncthreads();
 
-    // ---- 3. da[slice] = W_hh^T dgh, du[slice] = W_ih^T dgi: wave w owns k in [w*3H/4, (w+1)*3H/4)
-    const int unit = slice * BJS + lane;
-    const int KQ = H3 / 4, k0 = wave * KQ;
+    // ---- 3. da[slice] = W_hh^T dgh, du[slice] = W_ih^T dgi: k-group q owns k in [q*3H/32, (q+1)*3H/32)
     float acc[RB], acc2[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
-    {
-        const float* wp = C.whh + (int64_t)k0 * H + unit;
-#pragma unroll 8
-        for (int k = 0; k < KQ; ++k) {
-            const float wv = wp[(int64_t)k * H];
-            const float* dp = dgh_t + (k0 + k) * RB;
+    auto fma_rows = [&](float (&a)[RB], float wv, const float* dp) {
 #pragma unroll
-            for (int r4 = 0; r4 < RB; r4 += 4) {
-                const float4 d4 = *reinterpret_cast<const float4*>(dp + r4);
-                acc[r4] = fmaf(wv, d4.x, acc[r4]); acc[r4 + 1] = fmaf(wv, d4.y, acc[r4 + 1]);
-                acc[r4 + 2] = fmaf(wv, d4.z, acc[r4 + 2]); acc[r4 + 3] = fmaf(wv, d4.w, acc[r4 + 3]);
-            }
+        for (int r4 = 0; r4 < RB; r4 += 4) {
+            const float4 d4 = *reinterpret_cast<const float4*>(dp + r4);
+            a[r4] = fmaf(wv, d4.x, a[r4]); a[r4 + 1] = fmaf(wv, d4.y, a[r4 + 1]);
+            a[r4 + 2] = fmaf(wv, d4.z, a[r4 + 2]); a[r4 + 3] = fmaf(wv, d4.w, a[r4 + 3]);
         }
-    }
-    if (C.wih) {
-        const float* wp = C.wih + (int64_t)k0 * H + unit;
-#pragma unroll 8
-        for (int k = 0; k < KQ; ++k) {
-            const float wv = wp[(int64_t)k * H];
-            const float* dp = dgi_t + (k0 + k) * RB;
+    };
+    if (PRE) {
 #pragma unroll
-            for (int r4 = 0; r4 < RB; r4 += 4) {
-                const float4 d4 = *reinterpret_cast<const float4*>(dp + r4);
-                acc2[r4] = fmaf(wv, d4.x, acc2[r4]); acc2[r4 + 1] = fmaf(wv, d4.y, acc2[r4 + 1]);
-                acc2[r4 + 2] = fmaf(wv, d4.z, acc2[r4 + 2]); acc2[r4 + 3] = fmaf(wv, d4.w, acc2[r4 + 3]);
-            }
+        for (int k = 0; k < KREG; ++k)
+            if (k < KQ) fma_rows(acc, wr[k], dgh_t + (k0 + k) * RB);
+        if (C.wih) {
+#pragma unroll
+            for (int k = 0; k < KREG; ++k)
+                if (k < KQ) fma_rows(acc2, wr2[k], dgi_t + (k0 + k) * RB);
+        }
+    } else {
+        const float* wp = C.whh + (int64_t)k0 * H + unit;
+#pragma unroll 16
+        for (int k = 0; k < KQ; ++k) fma_rows(acc, wp[(int64_t)k * H], dgh_t + (k0 + k) * RB);
+        if (C.wih) {
+            const float* wq = C.wih + (int64_t)k0 * H + unit;
+#pragma unroll 16
+            for (int k = 0; k < KQ; ++k) fma_rows(acc2, wq[(int64_t)k * H], dgi_t + (k0 + k) * RB);
         }
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-        red[(wave * RB + r) * BJS + lane] = acc[r];
-        red[((4 + wave) * RB + r) * BJS + lane] = acc2[r];
+        red[(kg * RB + r) * BJS + ul] = acc[r];
+        red[((KG + kg) * RB + r) * BJS + ul] = acc2[r];
     }
     __syncthreads();
 
-    // ---- 4. partial sums in wave order, stores
-    for (int idx = tid; idx < nrows * BJS; idx += BT) {
-        const int r = idx / BJS, l = idx - r * BJS, u = slice * BJS + l;
-        const int v = node_s[r];
-        float s = red[(0 * RB + r) * BJS + l];
-        s += red[(1 * RB + r) * BJS + l]; s += red[(2 * RB + r) * BJS + l]; s += red[(3 * RB + r) * BJS + l];
-        C.da[(int64_t)v * H + u] = g_s[r * H + u] + s;
-        if (C.gext_lo) {
-            float t = red[((4 + 0) * RB + r) * BJS + l];
-            t += red[((4 + 1) * RB + r) * BJS + l]; t += red[((4 + 2) * RB + r) * BJS + l];
-            t += red[((4 + 3) * RB + r) * BJS + l];
-            C.gext_lo[(int64_t)v * H + u] += t;   // this workgroup is the only writer of these 64 floats
+    // ---- 4. partial sums in k-group order, stores
+    for (int idx = tid; idx < 2 * nrows * BJS; idx += ST) {
+        const int m = idx / (nrows * BJS), rem = idx - m * nrows * BJS;
+        const int r = rem / BJS, l = rem - r * BJS, u = slice * BJS + l;
+        if (m == 1 && !C.gext_lo) continue;
+        const int v = brec[4 * r].x;
+        float s = 0.f;
+#pragma unroll 8
+        for (int w = 0; w < KG; ++w) s += red[((m * KG + w) * RB + r) * BJS + l];
+        if (m == 0) C.da[(int64_t)v * H + u] = g_s[r * H + u] + s;
+        else C.gext_lo[(int64_t)v * H + u] += s;   // this workgroup is the only writer of these 16 floats
+    }
+}
+
+// ---- fat launches, stage 1: one wave per row of the launch (all cells): pull + GRU backward of the full row,
+// once (the slice workgroups of the thin kernel each redo it).  Writes dgi, dgh, sigma / edge-feature sums
+// and da = z (.) G; stage 2 adds the matrix products.  blk_start = ROW prefix sums here.
+__global__ void __launch_bounds__(256) bwd_rows_kernel(const int32_t* __restrict__ plan, PlanLayout L, BArgs S) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= S.blk_start[S.ncell]) return;
+    int c = 0;
+    while (c + 1 < S.ncell && row >= S.blk_start[c + 1]) ++c;
+    const BCell& C = S.cell[c];
+    const int H = S.H, H3 = 3 * H, H4 = H >> 2, R = C.mrel ? S.R : 0;
+    const int4* rec = reinterpret_cast<const int4*>(plan + L.brec[C.dir]) + 4 * (int64_t)(C.row_base + row - S.blk_start[c]);
+    float* grow = lds + wave * H;
+    const int v = rec[0].x;
+    pull_row(plan, L, C, rec, R, H, S.ld_h, grow, lane, true);
+    const float4* gi = reinterpret_cast<const float4*>(C.gi + (int64_t)v * H3);
+    const float4* gh = reinterpret_cast<const float4*>(C.gh + (int64_t)v * H3);
+    float4* og = reinterpret_cast<float4*>(C.dgi + (int64_t)v * H3);
+    float4* oh = reinterpret_cast<float4*>(C.dgh + (int64_t)v * H3);
+    for (int cc = lane; cc < H4; cc += 64) {
+        const float4 ir = gi[cc], iz = gi[H4 + cc], in = gi[2 * H4 + cc];
+        const float4 hr = gh[cc], hz = gh[H4 + cc], hn = gh[2 * H4 + cc];
+        const float4 av = reinterpret_cast<const float4*>(C.a + (int64_t)v * H)[cc];
+        const float4 G = reinterpret_cast<const float4*>(grow)[cc];   // written by this wave's own lanes (same lane, same cc)
+        float4 dr, dz, dn, dnr, zg;
+#define DAGNN_GATE_BWD(f)                                                                    \
+        {                                                                                    \
+            const float rr = bsigm(ir.f + hr.f), zz = bsigm(iz.f + hz.f);                    \
+            const float nn = tanhf(in.f + rr * hn.f);                                        \
+            dn.f = G.f * (1.0f - zz) * (1.0f - nn * nn);                                     \
+            dz.f = G.f * (av.f - nn) * zz * (1.0f - zz);                                     \
+            dr.f = dn.f * hn.f * rr * (1.0f - rr);                                           \
+            dnr.f = dn.f * rr;                                                               \
+            zg.f = G.f * zz;                                                                 \
+        }
+        DAGNN_GATE_BWD(x) DAGNN_GATE_BWD(y) DAGNN_GATE_BWD(z) DAGNN_GATE_BWD(w)
+#undef DAGNN_GATE_BWD
+        og[cc] = dr; og[H4 + cc] = dz; og[2 * H4 + cc] = dn;
+        oh[cc] = dr; oh[H4 + cc] = dz; oh[2 * H4 + cc] = dnr;
+        reinterpret_cast<float4*>(C.da + (int64_t)v * H)[cc] = zg;
+    }
+}
+
+// ---- fat launches, stage 2 on the matrix cores: 32 rows x one 32-unit slice per workgroup, 8 waves.
+//   da[rows, slice] += dgh[rows, 3H] W_hh[3H, slice],   Gext_lower[rows, slice] += dgi[rows, 3H] W_ih[3H, slice]
+// as v_mfma_f32_32x32x2_f32 chains (exact fp32).  K = 3H is walked gate block by gate block in chunks of <= 256:
+// the chunk of the 32 gradient rows is staged k-major in LDS (dgi == dgh for the r and z blocks, so one copy
+// serves both products), every wave owns 1/8 of the chunk's k range for both products and reads its B
+// fragments straight from the torch-layout weights (128 B per half-wave), and the eight partial tiles meet in
+// LDS in wave order.  Weight bytes per row: 1/4 of the 8-row blocks; pull and gate algebra are not redone.
+typedef float bmf32x16 __attribute__((ext_vector_type(16)));
+constexpr int BMT = 32;        // rows per tile
+constexpr int BMLD = BMT + 1;  // k-major LDS pitch
+constexpr int BKC = 256;       // K chunk
+
+__global__ void __launch_bounds__(512, 2) bwd_mfma_kernel(const int32_t* __restrict__ plan, PlanLayout L, BArgs S) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = S.H, H3 = 3 * H, NS = H / 32;
+    const int sl = blockIdx.x % NS, gb = blockIdx.x / NS;
+    int c = 0;
+    while (c + 1 < S.ncell && gb >= S.blk_start[c + 1]) ++c;   // blk_start = 32-row tile prefix sums
+    const BCell& C = S.cell[c];
+    const int slot0 = C.row_base + (gb - S.blk_start[c]) * BMT;
+    const int nr = min(BMT, C.row_end - slot0);
+    const bool has_in = C.wih != nullptr;
+    const int KC = min(H, BKC);
+    float* d_h = smem;                 // [KC][BMLD] chunk of dgh, k-major
+    float* d_i = d_h + KC * BMLD;      // [KC][BMLD] chunk of dgi (n block only)
+    float* red = smem;                 // [2][8][32][BMLD] partial tiles after the chains
+    int* v_s = reinterpret_cast<int*>(smem + max(2 * KC * BMLD, 2 * 8 * BMT * BMLD));
+
+    const int4* __restrict__ recs = reinterpret_cast<const int4*>(plan + L.brec[C.dir]);
+    if (tid < BMT) v_s[tid] = tid < nr ? recs[4 * (int64_t)(slot0 + tid)].x : 0;
+    __syncthreads();
+
+    bmf32x16 acc_h, acc_i;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc_h[e] = 0.f; acc_i[e] = 0.f; }
+    const int arow = lane & 31, ak = lane >> 5;
+    const int kw = KC / 8, kb = wave * kw, nm = kw / 2;   // this wave's k range inside a chunk, MFMAs per product
+    const int colw = sl * 32 + arow;
+
+    for (int g = 0; g < 3; ++g) {
+        for (int k0 = 0; k0 < H; k0 += KC) {
+            const int kg = g * H + k0;   // global k of the chunk
+            // B fragments of this wave for the chunk: issued before the staging so they are in flight during it
+            float bh[16], bi[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                bh[j] = 0.f; bi[j] = 0.f;
+                if (j < nm) {
+                    const int64_t off = (int64_t)(kg + kb + 2 * j + ak) * H + colw;
+                    bh[j] = C.whh[off];
+                    if (has_in) bi[j] = C.wih[off];
+                }
+            }
+            __syncthreads();   // the previous chunk's MFMAs are done with d_h / d_i
+            const bool two = has_in && g == 2;
+            for (int r = wave; r < BMT; r += 8) {
+                const bool live = r < nr;
+                const float4* hp = reinterpret_cast<const float4*>(C.dgh + (int64_t)v_s[r] * H3 + kg);
+                const float4* ip = reinterpret_cast<const float4*>(C.dgi + (int64_t)v_s[r] * H3 + kg);
+                for (int cc = lane; cc < (KC >> 2); cc += 64) {
+                    const float4 x = live ? hp[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    d_h[(4 * cc + 0) * BMLD + r] = x.x; d_h[(4 * cc + 1) * BMLD + r] = x.y;
+                    d_h[(4 * cc + 2) * BMLD + r] = x.z; d_h[(4 * cc + 3) * BMLD + r] = x.w;
+                    if (two) {
+                        const float4 y = live ? ip[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        d_i[(4 * cc + 0) * BMLD + r] = y.x; d_i[(4 * cc + 1) * BMLD + r] = y.y;
+                        d_i[(4 * cc + 2) * BMLD + r] = y.z; d_i[(4 * cc + 3) * BMLD + r] = y.w;
+                    }
+                }
+            }
+            __syncthreads();
+            const float* opi = two ? d_i : d_h;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j < nm) {
+                    const int kk = (kb + 2 * j + ak) * BMLD + arow;
+                    acc_h = __builtin_amdgcn_mfma_f32_32x32x2f32(d_h[kk], bh[j], acc_h, 0, 0, 0);
+                    if (has_in) acc_i = __builtin_amdgcn_mfma_f32_32x32x2f32(opi[kk], bi[j], acc_i, 0, 0, 0);
+                }
+            }
         }
     }
+    __syncthreads();   // every chain has read the staging buffers: they can now hold the partial tiles
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        red[((0 * 8 + wave) * BMT + row) * BMLD + arow] = acc_h[e];
+        if (has_in) red[((1 * 8 + wave) * BMT + row) * BMLD + arow] = acc_i[e];
+    }
+    __syncthreads();
+    for (int id = tid; id < BMT * 32; id += 512) {
+        const int r = id >> 5, col = id & 31;
+        if (r >= nr) continue;
+        const int v = v_s[r];
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s0 += red[((0 * 8 + w) * BMT + r) * BMLD + col];
+        C.da[(int64_t)v * H + sl * 32 + col] += s0;   // da holds z (.) G from stage 1; one writer per element
+        if (has_in) {
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s1 += red[((1 * 8 + w) * BMT + r) * BMLD + col];
+            C.gext_lo[(int64_t)v * H + sl * 32 + col] += s1;
+        }
+    }
+}
+
+inline size_t mfma_lds_bytes(int H) {
+    const int KC = H < BKC ? H : BKC;
+    const int a = 2 * KC * BMLD, b = 2 * 8 * BMT * BMLD;
+    return (size_t)((a > b ? a : b) + BMT) * sizeof(float);
 }
 
 // Gradient of the max read-out (dagnn.py:184-193): the gradient of out[g, col_off + j] goes to the FIRST
@@ -318,8 +599,10 @@ __global__ void __launch_bounds__(256) readout_max_bwd_kernel(const int32_t* __r
     }
 }
 
+inline bool H3_fits_registers(int H) { return 3 * H / (ST / BJS) <= KREG; }
+
 template <int RB>
-size_t step_lds_bytes(int H) { return (size_t)(RB * H + 2 * 3 * H * RB + 2 * 4 * RB * BJS + RB) * sizeof(float); }
+size_t step_lds_bytes(int H) { return (size_t)(RB * H + 2 * 3 * H * RB + 2 * ST * RB) * sizeof(float); }
 
 void fill_cells(BArgs& S, const dagnn_backward_args* a, const int* dirs, int ndir) {
     S.ncell = 0;
@@ -357,6 +640,9 @@ extern "C" int dagnn_backward_prepare(const dagnn_plan* pl, const dagnn_backward
     S.H = H; S.ld_h = a->ld_h; S.R = pl->num_edge_feats;
     fill_cells(S, a, dirs, ndir);
     PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
+    hipLaunchKernelGGL(bwd_succrec_kernel, dim3((unsigned)((pl->N + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream,
+                       (int32_t*)pl->data, L, (int)pl->N);
+    DAGNN_CHECK_LAUNCH();
     dim3 grid((unsigned)((pl->N + 3) / 4), (unsigned)S.ncell);
     hipLaunchKernelGGL(bwd_prepare_kernel, grid, dim3(BT), 0, (hipStream_t)stream, (const int32_t*)pl->data, L, S,
                        (int)pl->N);
@@ -393,19 +679,21 @@ extern "C" int dagnn_backward_run(const dagnn_plan* pl, const dagnn_backward_arg
     S.H = H; S.ld_h = a->ld_h; S.R = pl->num_edge_feats;
     fill_cells(S, a, dirs, ndir);
     const int NS = H / BJS;
-    const int rb_fat = H <= 512 ? 8 : 4;
+    const bool pre = H3_fits_registers(H);
+    const bool mfma = H <= BKC || H % BKC == 0;   // fat launches: rows kernel + 32-row MFMA tiles
+    const int rb_fat = H <= 512 ? 8 : 4;          // ... or bigger row blocks of the slice kernel when H does not fit
     // dynamic LDS beyond 64 KB must be granted per kernel; idempotent, so no library-global state is kept
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_step_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)step_lds_bytes<4>(H)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_step_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)step_lds_bytes<8>(H <= 512 ? H : 512)) != hipSuccess)
+    const void* k4 = pre ? reinterpret_cast<const void*>(bwd_step_kernel<4, true>) : reinterpret_cast<const void*>(bwd_step_kernel<4, false>);
+    const void* k8 = pre ? reinterpret_cast<const void*>(bwd_step_kernel<8, true>) : reinterpret_cast<const void*>(bwd_step_kernel<8, false>);
+    if (hipFuncSetAttribute(k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds_bytes<4>(H)) != hipSuccess ||
+        hipFuncSetAttribute(k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds_bytes<8>(H <= 512 ? H : 512)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)mfma_lds_bytes(H)) != hipSuccess)
         return DAGNN_EHIP(hipGetLastError());
     const int nsteps = Tmax + Ls - 1;
     for (int s = 0; s < nsteps; ++s) {
         // stacked layer i handles layer t = T_d - 1 - (s - (Ls-1-i)): the top layer leads, every lower one is a launch behind
-        int total4 = 0, total_fat = 0;
-        for (int pass = 0; pass < 2; ++pass) {
-            const int rb = pass == 0 ? 4 : rb_fat;
+        auto layout = [&](int unit) {   // row ranges of the active cells; blk_start in blocks of `unit` rows
             int k = 0, tot = 0;
             for (int q = 0; q < ndir; ++q)
                 for (int i = 0; i < Ls; ++i, ++k) {
@@ -415,22 +703,30 @@ extern "C" int dagnn_backward_run(const dagnn_plan* pl, const dagnn_backward_arg
                     S.cell[k].row_base = on ? layer_ptr[d][t] : 0;
                     S.cell[k].row_end = on ? layer_ptr[d][t + 1] : 0;
                     S.blk_start[k] = tot;
-                    tot += (S.cell[k].row_end - S.cell[k].row_base + rb - 1) / rb;
+                    tot += (S.cell[k].row_end - S.cell[k].row_base + unit - 1) / unit;
                 }
             S.blk_start[k] = tot;
-            if (pass == 0) {
-                total4 = tot;
-                if (rb_fat == 4 || total4 * NS <= 2 * a->num_cus) break;   // thin launch: keep 4-row blocks
-            } else {
-                total_fat = tot;
-            }
+            return tot;
+        };
+        const int rows = layout(1);
+        if (rows == 0) continue;
+        const int blocks4 = layout(4);
+        const bool thin = blocks4 * NS <= 2 * a->num_cus;
+        if (thin || (!mfma && rb_fat == 4)) {
+            const dim3 grid((unsigned)(blocks4 * NS));
+            if (pre) hipLaunchKernelGGL((bwd_step_kernel<4, true>), grid, dim3(ST), step_lds_bytes<4>(H), st, plan, L, S);
+            else hipLaunchKernelGGL((bwd_step_kernel<4, false>), grid, dim3(ST), step_lds_bytes<4>(H), st, plan, L, S);
+        } else if (!mfma) {
+            const dim3 grid((unsigned)(layout(8) * NS));
+            if (pre) hipLaunchKernelGGL((bwd_step_kernel<8, true>), grid, dim3(ST), step_lds_bytes<8>(H), st, plan, L, S);
+            else hipLaunchKernelGGL((bwd_step_kernel<8, false>), grid, dim3(ST), step_lds_bytes<8>(H), st, plan, L, S);
+        } else {
+            layout(1);
+            hipLaunchKernelGGL(bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 4 * H * sizeof(float), st, plan, L, S);
+            DAGNN_CHECK_LAUNCH();
+            const int tiles = layout(BMT);
+            hipLaunchKernelGGL(bwd_mfma_kernel, dim3((unsigned)(tiles * (H / 32))), dim3(512), mfma_lds_bytes(H), st, plan, L, S);
         }
-        const int blocks = total_fat ? total_fat : total4;
-        if (blocks == 0) continue;
-        if (total_fat && rb_fat == 8)
-            hipLaunchKernelGGL(bwd_step_kernel<8>, dim3((unsigned)(blocks * NS)), dim3(BT), step_lds_bytes<8>(H), st, plan, L, S);
-        else
-            hipLaunchKernelGGL(bwd_step_kernel<4>, dim3((unsigned)(blocks * NS)), dim3(BT), step_lds_bytes<4>(H), st, plan, L, S);
         DAGNN_CHECK_LAUNCH();
     }
     return DAGNN_OK;

@@ -31,6 +31,8 @@ struct PlanLayout {
     int64_t lbase[2];                // [N+B] per (graph, layer): first slot of its rows in rowrec
     int64_t rowrec[2];               // [16N] per batch-level slot, 64 B: {node, e_begin, e_end, graph,
                                      //        pred[0..3], edge feats of the first 4 edges (2 floats each)}
+    int64_t brec[2];                 // [16N] backward pass: per slot {node, succ CSR range, first 4 successors, their
+                                     //        edge ids} (written by dagnn_backward_prepare)
     int64_t total;                   // words
 };
 
@@ -55,6 +57,7 @@ __host__ __device__ inline PlanLayout dagnn_plan_layout_words(int64_t N, int64_t
     for (int d = 0; d < 2; ++d) L.blptr[d] = take(N + 2);
     for (int d = 0; d < 2; ++d) L.lbase[d] = take(N + B);
     for (int d = 0; d < 2; ++d) L.rowrec[d] = take(16 * N);
+    for (int d = 0; d < 2; ++d) L.brec[d] = take(16 * N);
     L.total = o;
     return L;
 }

@@ -198,7 +198,9 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
                 for (int e = 0; e < 4; ++e) {
                     if (e >= deg) continue;
                     if (C.sscore) sc[e] = C.sscore[pj[e]];
-                    else for (int q = 0; q < nparts; ++q) sc[e] += __shfl(pv[e], q, 64);  // index order
+                    else  // the <= 16 parts sit in lanes 0..15 (0 beyond nparts): one DPP row scan, fixed order
+                        sc[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                                    __builtin_bit_cast(int, dpp_row_sum16(pv[e])), 15));
                 }
             }
         } else {
@@ -257,17 +259,24 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
         float s = 0.f;
         if (C.sscore) {
             s = C.sscore[cj];
-        } else if (GRAN) {  // this lane's predecessor: its H/16 part granules, summed in index order
+        } else if (GRAN) {  // this lane's predecessor: its H/16 part granules (H <= 256: at most 16), all loads in
+                            // flight together, re-polled as a group, summed in index order
             const gran_t* gp = gsrc + (int64_t)cj * gld + H;
-            for (int q = 0; q < nparts; ++q) {
-                gran_t x = gran_ld(gp + q);
-                unsigned spins = 0;
-                while ((unsigned)(x >> 32) != G.epoch) {  // per-lane wait: producers never wait on us
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 22)) { __hip_atomic_store(G.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                    x = gran_ld(gp + q);
+            unsigned spins = 0;
+            for (;;) {
+                gran_t x[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) x[q] = q < nparts ? gran_ld(gp + q) : ((gran_t)G.epoch << 32);
+                bool ok = true;
+                s = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    ok = ok && (unsigned)(x[q] >> 32) == G.epoch;
+                    if (q < nparts) s += __uint_as_float((unsigned)x[q]);
                 }
-                s += __uint_as_float((unsigned)x);
+                if (ok) break;   // per-lane wait: producers never wait on us
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 22)) { __hip_atomic_store(G.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
         } else {
             s = score_of(hsrc + (int64_t)cj * ld_h + H, nparts);
@@ -311,6 +320,36 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
                         a4[u] = __shfl(my_alpha, i + u, 64);
                         const int cj = __shfl(my_col, i + u, 64);
                         v[u] = c < H4 ? reinterpret_cast<const float4*>(hsrc + (int64_t)cj * ld_h)[c] : make_float4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) fma4(acc, a4[u], v[u]);
+                }
+            }
+            if (GRAN) {
+                for (; i + 4 <= cnt; i += 4) {  // four granule rows polled together: one round trip when they are ready
+                    float a4[4]; const gran_t* gr[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        a4[u] = __shfl(my_alpha, i + u, 64);
+                        gr[u] = gsrc + (int64_t)__shfl(my_col, i + u, 64) * gld;
+                    }
+                    float4 v[4];
+                    unsigned spins = 0;
+                    for (;;) {
+                        bool ok = true;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (lane < H4) {
+                                const gran_t x0 = gran_ld(gr[u] + 4 * lane), x1 = gran_ld(gr[u] + 4 * lane + 1),
+                                             x2 = gran_ld(gr[u] + 4 * lane + 2), x3 = gran_ld(gr[u] + 4 * lane + 3);
+                                ok = ok && (unsigned)(x0 >> 32) == G.epoch && (unsigned)(x1 >> 32) == G.epoch &&
+                                     (unsigned)(x2 >> 32) == G.epoch && (unsigned)(x3 >> 32) == G.epoch;
+                                v[u] = make_float4(__uint_as_float((unsigned)x0), __uint_as_float((unsigned)x1),
+                                                   __uint_as_float((unsigned)x2), __uint_as_float((unsigned)x3));
+                            }
+                        }
+                        if (__all(ok) || !gran_retry(spins, G)) break;
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) fma4(acc, a4[u], v[u]);
@@ -818,11 +857,14 @@ __global__ void __launch_bounds__(FT, 1) frontier_tail_kernel(const int32_t* __r
         const int t = s - si;
         if (t < 0 || t >= T) continue;
         const int r0 = blptr[t], r1 = blptr[t + 1];
-        const int nblk = (r1 - r0 + RBT - 1) / RBT;
+        // rows of a thin layer are spread over the replicas (blocks of ceil(rows / nrep) <= RBT rows): a block's
+        // latency grows with its live rows, and the layer is as slow as its slowest replica
+        const int rbs = min(max((r1 - r0 + S.nrep - 1) / S.nrep, 1), RBT);
+        const int nblk = (r1 - r0 + rbs - 1) / rbs;
         for (int rb = rep; rb < nblk; rb += S.nrep) {
-            const int slot0 = r0 + rb * RBT;
+            const int slot0 = r0 + rb * rbs;
             process_block<JS, RBT, KW, true>(plan, L.rowrec[d], L.col[d], L.eattr[d], C, t > 0, slot0,
-                                             min(RBT, r1 - slot0), sl, S.H, S.ld_h, S.R, S.vid_mod, smem, wh, wi,
+                                             min(rbs, r1 - slot0), sl, S.H, S.ld_h, S.R, S.vid_mod, smem, wh, wi,
                                              stamp, G);
             __syncthreads();  // LDS is reused by the next block
         }

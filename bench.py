@@ -89,24 +89,19 @@ def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
     Reported next to the headline forward metric, never as `value`."""
     from dagnn_amd import engine
     model.train()
-    params = [p for p in model.parameters() if p.requires_grad]
-    flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=device)
-    off = 0
-    for p in params:  # gradients live in one bucket: autograd accumulates in place, one collective per step
-        p.grad = flat[off:off + p.numel()].view_as(p)
-        off += p.numel()
+    from dagnn_amd.train import GradBucket
+    bucket = GradBucket(model.parameters())  # gradients live in one buffer: one collective per step
+    params, flat = bucket.params, bucket.flat
     opt = torch.optim.Adam(params, lr=1e-3)
     y = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(1)).to(device)
     ce = torch.nn.CrossEntropyLoss()
 
     def step(G):
-        flat.zero_()
+        bucket.zero()
         pred = model(G)
         loss = sum(ce(pred[s], y[:, s]) for s in range(S)) / S
         loss.backward()
-        if world > 1:
-            dist.all_reduce(flat)
-            flat.div_(world)
+        bucket.all_reduce_mean()
         opt.step()
         return loss
 

@@ -12,5 +12,6 @@ from .constants import *  # noqa: F401,F403
 from .data import GraphBatch, GraphData, collate_sharded, shard_by_nodes  # noqa: F401
 from .dvae import DAGNN_BN, DAGNN_NA  # noqa: F401
 from .model import DAGNN, ASTNodeEncoder  # noqa: F401
+from .train import GradBucket  # noqa: F401
 
 __version__ = "0.1.0"

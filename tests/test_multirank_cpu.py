@@ -62,3 +62,44 @@ def test_two_rank_sharding_and_gather_gloo():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert dict(out) == {0: 24, 1: 24}
+
+
+def _train_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dagnn_amd.train import GradBucket
+        torch.manual_seed(0)  # identical replicas
+        net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+        bucket = GradBucket(net.parameters())
+        opt = torch.optim.Adam(bucket.params, lr=1e-2)
+        g = torch.Generator().manual_seed(100 + rank)  # every rank its own shard
+        x, y = torch.randn(8, 6, generator=g), torch.randint(0, 3, (8,), generator=g)
+        for _ in range(3):
+            bucket.zero()
+            loss = torch.nn.functional.cross_entropy(net(x), y)
+            loss.backward()
+            local = bucket.flat.clone()
+            bucket.all_reduce_mean()
+            gathered = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local)
+            assert torch.allclose(bucket.flat, sum(gathered) / world, atol=1e-7)
+            assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in bucket.params)  # still views
+            opt.step()
+        w = torch.cat([p.detach().flatten() for p in net.parameters()])
+        ws = [torch.zeros_like(w) for _ in range(world)]
+        dist.all_gather(ws, w)
+        assert torch.equal(ws[0], ws[1])  # replicas stay in lock-step
+        out[rank] = float(loss)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gradient_bucket_all_reduce_gloo():
+    """The training exchange of the N>1 path (one flat-bucket all-reduce, bench.py's training leg) on gloo."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_train_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert len(out) == 2

@@ -9,7 +9,9 @@ The hot path runs in libdagnn_hip.so (hand-written HIP, C ABI in include/dagnn_h
 this package does not need a GPU, calling `forward` does.
 """
 from .constants import *  # noqa: F401,F403
-from .data import GraphBatch, GraphData, collate_sharded, shard_by_nodes  # noqa: F401
+from .data import (GraphBatch, GraphData, augment_edge2, collate_sharded, collate_with_plan,  # noqa: F401
+                   shard_by_nodes)
+from .host_plan import attach_plan, build_plan_host  # noqa: F401
 from .dvae import DAGNN_BN, DAGNN_NA  # noqa: F401
 from .model import DAGNN, ASTNodeEncoder  # noqa: F401
 from .train import GradBucket  # noqa: F401

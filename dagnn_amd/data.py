@@ -148,3 +148,26 @@ def collate_sharded(data_list: Sequence[GraphData], ndevices: int) -> List[Graph
     """`Collater.collate` (`tg/dataloader.py:13-35`): one `GraphBatch` per non-empty device."""
     split = shard_by_nodes([d.num_nodes for d in data_list], ndevices)
     return [GraphBatch.from_data_list(data_list[split[i]:split[i + 1]]) for i in range(len(split) - 1)]
+
+
+def augment_edge2(data):
+    """Edge augmentation of the ogbg-code2 transform (`ogbg-code/utils2.py:30-78`): keep the AST edges with
+    `edge_attr = [0, 0]` and append one next-token edge `[1, 0]` between consecutive attributed nodes (the
+    nodes are already in DFS order, so consecutive means consecutive indices of `node_is_attributed == 1`).
+    No inverse edges (the reference has them commented out).  Modifies and returns `data`."""
+    ast = data.edge_index
+    tok = torch.where(data.node_is_attributed.view(-1) == 1)[0]
+    nxt = torch.stack([tok[:-1], tok[1:]], dim=0)
+    attr_ast = torch.zeros((ast.size(1), 2))
+    attr_nxt = torch.cat([torch.ones(nxt.size(1), 1), torch.zeros(nxt.size(1), 1)], dim=1)
+    data.edge_index = torch.cat([ast, nxt], dim=1)
+    data.edge_attr = torch.cat([attr_ast, attr_nxt], dim=0)
+    return data
+
+
+def collate_with_plan(data_list: Sequence[GraphData]) -> "GraphBatch":
+    """Collate (PyG rule, as `ogbg-code/tg/dataloader.py:13-35` does per device chunk) and build the batch's
+    plan on the host, in the loader worker: `forward` then launches no plan kernels and
+    needs no device->host read."""
+    from .host_plan import attach_plan
+    return attach_plan(GraphBatch.from_data_list(data_list))

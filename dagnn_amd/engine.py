@@ -107,6 +107,26 @@ class PlanHandle(object):
         self.status = torch.zeros(4, dtype=torch.int32, device=device)
         self.desc = Plan(self.ws.data_ptr(), nbytes, self.N, self.E, self.B, self.R)
 
+    @classmethod
+    def from_words(cls, ws: torch.Tensor, meta: dict) -> "PlanHandle":
+        """Wrap a plan built on the host (`dagnn_amd.host_plan.build_plan_host`, e.g. in a loader worker) and
+        already moved to the GPU: no plan kernels and - the schedule being known on the host - no device->host
+        read in `forward`."""
+        lib = _lib.load()
+        if not (isinstance(ws, torch.Tensor) and ws.is_cuda and ws.dtype == torch.int32 and ws.is_contiguous()):
+            raise DagnnHipError("a host-built plan must be a contiguous int32 tensor on the GPU (move the batch "
+                                "with .to(device) first)")
+        self = cls.__new__(cls)
+        self.N, self.E, self.B, self.R = (int(meta[k]) for k in ("N", "E", "B", "R"))
+        nbytes = lib.dagnn_plan_bytes(self.N, self.E, self.B, self.R)
+        if ws.numel() * 4 < nbytes:
+            raise DagnnHipError("host-built plan has %d bytes, the layout needs %d" % (ws.numel() * 4, nbytes))
+        self.ws = ws
+        self.status = torch.zeros(4, dtype=torch.int32, device=ws.device)
+        self.desc = Plan(ws.data_ptr(), nbytes, self.N, self.E, self.B, self.R)
+        self._schedule = [a for a in meta["schedule"]]
+        return self
+
     def layout(self) -> dict:
         off = (C.c_int64 * 24)()
         check(_lib.load().dagnn_plan_layout(self.N, self.E, self.B, self.R, off), "dagnn_plan_layout")

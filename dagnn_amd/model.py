@@ -297,8 +297,11 @@ class DAGNN(nn.Module):
         G.x = self.encoder(G.x, G.node_depth.view(-1, ))
         x = G.x
         has_edge_enc = getattr(self.node_aggr_0[0], "wea", False)
-        plan = engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B,
-                                 G.edge_attr if has_edge_enc else None)
+        if getattr(G, "_dagnn_plan", None) is not None:  # built by the loader (dagnn_amd.host_plan.attach_plan)
+            plan = engine.PlanHandle.from_words(G._dagnn_plan, G._dagnn_plan_meta)
+        else:
+            plan = engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B,
+                                     G.edge_attr if has_edge_enc else None)
         if train:
             from .autograd import Recurrence
             res = Recurrence.apply(self, plan, B, x, *self._train_params())

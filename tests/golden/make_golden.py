@@ -214,6 +214,27 @@ def make_bn(ref_bn, ref_util, ref_batch_mod, name, *, hs, L, bidir, w_seed, data
           Hg=_np(Hg), mu=_np(mu), logvar=_np(logvar))
 
 
+def make_augment(name):
+    """`augment_edge2` of the reference (ogbg-code/utils2.py:30-78) on seeded ASTs: inputs and outputs."""
+    from types import SimpleNamespace
+    ref_utils2 = _load_file("ref_ogbg_utils2", os.path.join(REF, "ogbg-code", "utils2.py"))
+    rng = np.random.default_rng(41)
+    arrays = {}
+    for k, n in enumerate((12, 40, 3, 90)):
+        g = synth.gen_ast(rng, n)
+        parent_edges = g["ei"][:, g["ea"][:, 0] == 0]          # the AST edges only
+        attributed = np.zeros(n, dtype=np.int64)
+        attributed[np.setdiff1d(np.arange(n), parent_edges[0])] = 1   # leaves carry the tokens
+        d = SimpleNamespace(edge_index=torch.from_numpy(parent_edges).long(),
+                            node_is_attributed=torch.from_numpy(attributed).view(-1, 1))
+        out = ref_utils2.augment_edge2(d)
+        arrays["in_edge_index_%d" % k] = parent_edges
+        arrays["in_attributed_%d" % k] = attributed
+        arrays["out_edge_index_%d" % k] = _np(out.edge_index)
+        arrays["out_edge_attr_%d" % k] = _np(out.edge_attr)
+    _save(name, dict(kind="augment_edge2", cases=4), **arrays)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("reference not found at %s - fixtures can only be regenerated in the build container" % REF)
@@ -224,7 +245,11 @@ def main():
     ref_utils = _load_file("ref_ogbg_utils", os.path.join(REF, "ogbg-code", "utils.py"))
 
     common = dict(V=48, S=5, n_attr=300)
-    only = os.environ.get("GOLDEN_ONLY")  # "grad": rewrite only the gradient fixtures
+    only = os.environ.get("GOLDEN_ONLY")  # "grad" / "augment": rewrite only those fixtures
+    if only in (None, "augment"):
+        make_augment("augment_edge2")
+    if only == "augment":
+        return
     # training-step gradients: loss and parameter gradients of one step
     if True:
         make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, "grad_h32_bidir", data_seed=11, B=6, mean_n=30, H=32,

@@ -189,3 +189,63 @@ def test_grad_mode_raises_instead_of_silently_detaching():
     model, _ = Hh.dvae_model(Hh.load("na_h64_bidir")[0])
     with pytest.raises(NotImplementedError):
         model(Hh.dvae_batch(Hh.load("na_h64_bidir")[1]))
+
+
+# ------------------------------------------------------------------ loader-side plan
+def test_host_plan_layout_matches_library():
+    from dagnn_amd import host_plan
+    lib = _lib.load()
+    names = ["node_ptr", "edge_ptr", "depth0", "depth1", "order0", "order1", "lstart0", "lstart1", "rowptr0",
+             "rowptr1", "col0", "col1", "eattr0", "eattr1", "items", "total", "blptr0", "blptr1", "rowrec0",
+             "rowrec1", "slot0", "slot1", "eidx0", "eidx1"]
+    for N, E, B, R in ((16561, 25377, 128, 2), (7, 0, 3, 0), (512, 723, 64, 1), (0, 0, 0, 2)):
+        off = (ctypes.c_int64 * 24)()
+        assert lib.dagnn_plan_layout(N, E, B, R, off) == 0
+        lay = host_plan.plan_layout(N, E, B, R)
+        assert {k: lay[k] for k in names} == {k: int(v) // 4 for k, v in zip(names, off)}
+        assert lay["total"] * 4 == lib.dagnn_plan_bytes(N, E, B, R)
+
+
+def test_host_plan_against_brute_force():
+    from dagnn_amd import host_plan, synth
+    b = synth.code2_batch(3, 9, 25)
+    B, N, E = 9, b.x.shape[0], b.edge_index.shape[1]
+    ws, sched = host_plan.build_plan_host(b.edge_index, b._bi_layer_idx0, b._bi_layer_idx1, b.batch, B, b.edge_attr)
+    lay = host_plan.plan_layout(N, E, B, 2)
+    ei, gid = b.edge_index.numpy(), b.batch.numpy()
+    for d in (0, 1):
+        layer = (b._bi_layer_idx0 if d == 0 else b._bi_layer_idx1).numpy()
+        T = int(layer.max()) + 1
+        bl = ws[lay["blptr%d" % d]:lay["blptr%d" % d] + N + 2]
+        assert bl[N + 1] == T and np.array_equal(bl[:T + 1], sched[d]) and bl[T] == N
+        rec = ws[lay["rowrec%d" % d]:lay["rowrec%d" % d] + 16 * N].reshape(N, 16)
+        col = ws[lay["col%d" % d]:lay["col%d" % d] + E]
+        eidx = ws[lay["eidx%d" % d]:lay["eidx%d" % d] + E]
+        eattr = ws[lay["eattr%d" % d]:lay["eattr%d" % d] + 2 * E].view(np.float32).reshape(E, 2)
+        feed, other = ei[1 - d], ei[d]
+        for t in range(T):
+            nodes = rec[bl[t]:bl[t + 1], 0]
+            assert np.array_equal(nodes, np.flatnonzero(layer == t))   # (graph, id) order inside a layer
+        for v, eb, ee, g in rec[:, :4]:
+            e_ids = np.flatnonzero(feed == v)
+            assert g == gid[v] and np.array_equal(eidx[eb:ee], e_ids) and np.array_equal(col[eb:ee], other[e_ids])
+            assert np.array_equal(eattr[eb:ee], b.edge_attr.numpy()[e_ids])
+        slot = ws[lay["slot%d" % d]:lay["slot%d" % d] + N]
+        assert np.array_equal(rec[slot, 0], np.arange(N))
+    bad = b.batch.clone()
+    bad[2] = 5
+    with pytest.raises(ValueError):
+        host_plan.build_plan_host(b.edge_index, b._bi_layer_idx0, b._bi_layer_idx1, bad, B, b.edge_attr)
+
+
+def test_augment_edge2_matches_reference_fixture():
+    from types import SimpleNamespace
+    from dagnn_amd import augment_edge2
+    meta, arr = Hh.load("augment_edge2")
+    for k in range(meta["cases"]):
+        d = SimpleNamespace(edge_index=torch.from_numpy(arr["in_edge_index_%d" % k]).long(),
+                            node_is_attributed=torch.from_numpy(arr["in_attributed_%d" % k]).view(-1, 1))
+        out = augment_edge2(d)
+        assert np.array_equal(out.edge_index.numpy(), arr["out_edge_index_%d" % k])
+        assert np.array_equal(out.edge_attr.numpy(), arr["out_edge_attr_%d" % k])
+        assert out.edge_attr.dtype == torch.float32

@@ -401,3 +401,53 @@ def test_training_and_inference_forward_agree(device):
     out = model.train()(Hh.code2_batch(arr, device))
     assert all(torch.equal(a, b) or Hh.maxdiff(a, b) < 1e-6 for a, b in zip(ref, out))
     assert out[0].requires_grad
+
+
+# ----------------------------------------------------------------------------- loader-side plan
+@pytest.mark.parametrize("seed,B,mean_n", [(2, 17, 60), (0, 128, 125)])
+def test_host_plan_equals_device_plan_word_for_word(device, seed, B, mean_n):
+    from dagnn_amd import host_plan
+    b = synth.code2_batch(seed, B, mean_n)
+    plan = engine.build_plan(b.edge_index.to(device), b._bi_layer_idx0.to(device), b._bi_layer_idx1.to(device),
+                             b.batch.to(device), B, b.edge_attr.to(device))
+    torch.cuda.synchronize()
+    dev_words = plan.ws.cpu().numpy()
+    ws, sched, written = host_plan.build_plan_host(b.edge_index, b._bi_layer_idx0, b._bi_layer_idx1, b.batch, B,
+                                                   b.edge_attr, return_written=True)
+    assert ws.shape == dev_words.shape
+    assert written.sum() > 0.5 * ws.shape[0] - 32 * b.x.shape[0]
+    assert np.array_equal(ws[written], dev_words[written])
+    for d in (0, 1):
+        assert np.array_equal(sched[d], plan.read_schedule()[d])
+
+
+def test_forward_and_training_with_loader_side_plan(device):
+    """`collate_with_plan` batches: no plan kernels, no device->host read, bitwise the same results."""
+    from dagnn_amd import collate_with_plan
+    meta = dict(H=64, n_attr=300, V=40, S=3, w_seed=78,
+                ctor=dict(w_edge_attr=True, num_layers=2, bidirectional=True, agg="attn_h", out_wx=False,
+                          out_pool_all=False, out_pool="max", dropout=0.0))
+    model = Hh.code2_model(meta).to(device)
+    graphs = synth.code2_graphs(33, 20, 60)
+    for g in graphs:
+        g.x[:, 1] %= 300
+    plain = synth.GraphBatch.from_data_list(graphs).to(device)
+    planned = collate_with_plan(graphs).to(device)
+    assert planned._dagnn_plan.is_cuda and planned._dagnn_plan.dtype == torch.int32
+    with torch.no_grad():
+        a = model(plain.clone())
+        calls = []
+        orig = engine.build_plan
+        engine.build_plan = lambda *x, **k: calls.append(1) or orig(*x, **k)
+        try:
+            bb = model(planned.clone())
+        finally:
+            engine.build_plan = orig
+    assert not calls
+    assert all(torch.equal(x, y) for x, y in zip(a, bb))
+    y = torch.randint(0, 40, (20, 3), generator=torch.Generator().manual_seed(2)).to(device)
+    _, g1 = _train_step(model, plain.clone(), y)
+    _, g2 = _train_step(model, planned.clone(), y)
+    for k in g1:
+        if "encoder." not in k:
+            assert torch.equal(g1[k], g2[k]), k

@@ -90,6 +90,8 @@ SYMBOLS = {
                                      C.POINTER(C.c_int32), C.c_void_p]),
     "dagnn_readout_max_backward": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                              C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "dagnn_topo_layers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
     "dagnn_gather_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int, C.c_void_p]),
 }

@@ -79,3 +79,18 @@ def add_order_info(graph) -> None:
     l0 = torch.from_numpy(longest_path_layers(ei, n))
     l1 = torch.from_numpy(longest_path_layers(ei[::-1], n))
     graph.bi_layer_index = torch.stack([torch.stack([l0, ns]), torch.stack([l1, ns])], dim=0)
+
+
+def add_order_info_batch(batch, num_graphs=None, check: bool = False):
+    """`add_order_info_01` (src/utils_dag.py:39-52) for a whole collated batch that is already on the GPU:
+    sets `_bi_layer_idx0/1` (HIP kernel, csrc/toposort.hip) and `_bi_layer_index0/1` (= arange(N), which is what
+    PyG collation turns the per-graph aranges into).  `check=True` synchronises and raises on a cyclic graph."""
+    from . import engine
+    B = int(num_graphs if num_graphs is not None else getattr(batch, "num_graphs", None) or int(batch.batch[-1]) + 1)
+    lf, lb, status = engine.topo_layers(batch.edge_index, batch.batch, B)
+    if check and int(status):
+        raise ValueError("a graph of the batch has a cycle")
+    ids = torch.arange(batch.batch.numel(), device=batch.batch.device)
+    batch._bi_layer_idx0, batch._bi_layer_index0 = lf, ids
+    batch._bi_layer_idx1, batch._bi_layer_index1 = lb, ids.clone()
+    return batch

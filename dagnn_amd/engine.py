@@ -449,3 +449,18 @@ def gather_rows(h: torch.Tensor, num_graphs: int, stride: int, node_off: int, ou
     h = _dev(h, "h", torch.float32)
     check(_lib.load().dagnn_gather_rows(h.data_ptr(), h.shape[1], h.shape[1], num_graphs, stride, node_off,
                                         out.data_ptr(), out.shape[1], col_off, _stream(h)), "dagnn_gather_rows")
+
+
+def topo_layers(edge_index: torch.Tensor, batch: torch.Tensor, num_graphs: int):
+    """(layer_fwd, layer_bwd, status): longest-path layer ids of both orientations for a collated batch, on the
+    device (`src/utils_dag.py:8-52` without the per-graph numpy pass).  `status` is a device int32[1]: bit 16 =
+    some graph has a cycle (check it with `int(status)` when the input is not trusted - that synchronises)."""
+    edge_index = _dev(edge_index, "edge_index", torch.int64)
+    batch = _dev(batch, "batch", torch.int64)
+    N, E = batch.numel(), edge_index.shape[1]
+    lf = torch.empty(N, dtype=torch.int64, device=batch.device)
+    lb = torch.empty(N, dtype=torch.int64, device=batch.device)
+    status = torch.zeros(1, dtype=torch.int32, device=batch.device)
+    check(_lib.load().dagnn_topo_layers(edge_index.data_ptr(), batch.data_ptr(), N, E, int(num_graphs), lf.data_ptr(),
+                                        lb.data_ptr(), status.data_ptr(), _stream(batch)), "dagnn_topo_layers")
+    return lf, lb, status

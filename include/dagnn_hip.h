@@ -285,6 +285,16 @@ int dagnn_readout_max_backward(const dagnn_plan* plan /* host */, const float* h
 int dagnn_gather_rows(const float* h, int ld_h, int width, int64_t num_graphs, int stride, int node_off,
                       float* out, int ld_out, int col_off, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Topological layering on the device: replaces `top_sort` / `add_order_info_01` (src/utils_dag.py:8-52) for a
+ * whole collated batch.  layer_fwd[v] = longest-path distance of v from any source, layer_bwd[v] = the same on
+ * the flipped edges; both int64 [N], i.e. `_bi_layer_idx0/1` (`_bi_layer_index0/1` is arange(N)).  `batch`
+ * sorted, edges grouped by graph (the collation guarantees both).  A cyclic graph raises bit 16 of *status.
+ * ---------------------------------------------------------------------------------------- */
+int dagnn_topo_layers(const int64_t* edge_index /* [2,E] */, const int64_t* batch /* [N] */, int64_t N, int64_t E,
+                      int64_t B, int64_t* layer_fwd, int64_t* layer_bwd, int32_t* status /* device int32 or NULL */,
+                      void* stream);
+
 /* Introspection (tests, and the host-side read-back of the lock-step schedule): byte offsets of the
  * plan's arrays from `plan->data`, into a host array of 24 entries: [node_ptr, edge_ptr, depth0,
  * depth1, order0, order1, lstart0, lstart1, rowptr0, rowptr1, col0, col1, eattr0, eattr1, items,

@@ -451,3 +451,35 @@ def test_forward_and_training_with_loader_side_plan(device):
     for k in g1:
         if "encoder." not in k:
             assert torch.equal(g1[k], g2[k]), k
+
+
+# ----------------------------------------------------------------------------- device top_sort
+@pytest.mark.parametrize("name", ["code2_h32_bidir", "code2_h128_deep", "code2_h256_bidir"])
+def test_device_layering_matches_reference_top_sort(device, name):
+    """csrc/toposort.hip against the layer ids the REFERENCE's top_sort produced for the fixtures."""
+    from dagnn_amd import dag_utils
+    meta, arr = Hh.load(name)
+    G = Hh.code2_batch(arr, device)
+    G._bi_layer_idx0 = G._bi_layer_idx1 = None
+    dag_utils.add_order_info_batch(G, check=True)
+    assert np.array_equal(G._bi_layer_idx0.cpu().numpy(), arr["layer0"])
+    assert np.array_equal(G._bi_layer_idx1.cpu().numpy(), arr["layer1"])
+    assert torch.equal(G._bi_layer_index0, torch.arange(arr["x"].shape[0], device=device))
+
+
+def test_device_layering_full_batch_big_graph_and_cycle(device):
+    from dagnn_amd import dag_utils
+    b = synth.code2_batch(0, 128).to(device)
+    lf, lb, status = engine.topo_layers(b.edge_index, b.batch, 128)
+    assert torch.equal(lf, b._bi_layer_idx0) and torch.equal(lb, b._bi_layer_idx1) and int(status) == 0
+    # one graph beyond the LDS capacity (global-memory path): a 9000-node path with skip edges
+    n = 9000
+    ei = torch.cat([torch.stack([torch.arange(n - 1), torch.arange(1, n)]),
+                    torch.stack([torch.arange(0, n - 7, 5), torch.arange(7, n, 5)])], 1)
+    ref0 = dag_utils.longest_path_layers(ei.numpy(), n)
+    ref1 = dag_utils.longest_path_layers(ei.numpy()[::-1], n)
+    lf, lb, status = engine.topo_layers(ei.to(device), torch.zeros(n, dtype=torch.long, device=device), 1)
+    assert np.array_equal(lf.cpu().numpy(), ref0) and np.array_equal(lb.cpu().numpy(), ref1) and int(status) == 0
+    cyc = torch.tensor([[0, 1, 2], [1, 2, 0]], device=device)
+    _, _, status = engine.topo_layers(cyc, torch.zeros(3, dtype=torch.long, device=device), 1)
+    assert int(status) & 16

@@ -515,18 +515,26 @@ __global__ void __launch_bounds__(512, 2) bwd_mfma_kernel(const int32_t* __restr
             }
             __syncthreads();   // the previous chunk's MFMAs are done with d_h / d_i
             const bool two = has_in && g == 2;
-            for (int r = wave; r < BMT; r += 8) {
-                const bool live = r < nr;
-                const float4* hp = reinterpret_cast<const float4*>(C.dgh + (int64_t)v_s[r] * H3 + kg);
-                const float4* ip = reinterpret_cast<const float4*>(C.dgi + (int64_t)v_s[r] * H3 + kg);
-                for (int cc = lane; cc < (KC >> 2); cc += 64) {
-                    const float4 x = live ? hp[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    d_h[(4 * cc + 0) * BMLD + r] = x.x; d_h[(4 * cc + 1) * BMLD + r] = x.y;
-                    d_h[(4 * cc + 2) * BMLD + r] = x.z; d_h[(4 * cc + 3) * BMLD + r] = x.w;
+            for (int cc = lane; cc < (KC >> 2); cc += 64) {   // all four rows of this wave in flight together
+                float4 x[BMT / 8], y[BMT / 8];
+#pragma unroll
+                for (int q = 0; q < BMT / 8; ++q) {
+                    const int r = wave + 8 * q;
+                    x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    y[q] = x[q];
+                    if (r < nr) {
+                        x[q] = reinterpret_cast<const float4*>(C.dgh + (int64_t)v_s[r] * H3 + kg)[cc];
+                        if (two) y[q] = reinterpret_cast<const float4*>(C.dgi + (int64_t)v_s[r] * H3 + kg)[cc];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < BMT / 8; ++q) {
+                    const int r = wave + 8 * q;
+                    d_h[(4 * cc + 0) * BMLD + r] = x[q].x; d_h[(4 * cc + 1) * BMLD + r] = x[q].y;
+                    d_h[(4 * cc + 2) * BMLD + r] = x[q].z; d_h[(4 * cc + 3) * BMLD + r] = x[q].w;
                     if (two) {
-                        const float4 y = live ? ip[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
-                        d_i[(4 * cc + 0) * BMLD + r] = y.x; d_i[(4 * cc + 1) * BMLD + r] = y.y;
-                        d_i[(4 * cc + 2) * BMLD + r] = y.z; d_i[(4 * cc + 3) * BMLD + r] = y.w;
+                        d_i[(4 * cc + 0) * BMLD + r] = y[q].x; d_i[(4 * cc + 1) * BMLD + r] = y[q].y;
+                        d_i[(4 * cc + 2) * BMLD + r] = y[q].z; d_i[(4 * cc + 3) * BMLD + r] = y[q].w;
                     }
                 }
             }

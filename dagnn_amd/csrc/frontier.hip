@@ -644,22 +644,50 @@ __global__ void __launch_bounds__(512, 2) frontier_mfma_kernel(const int32_t* __
     const int d = C.dir;
     const bool has_in = C.wih_m != nullptr;
     const bool has_pred = C.has_pred != 0;
+    unsigned long long* stamp = (S.dbg != nullptr && blockIdx.x == 0 && tid == 0) ? S.dbg + 8 * (int64_t)S.step : nullptr;
+    if (stamp) { stamp[0] = wall_clock64(); stamp[6] = gridDim.x; }
 
     const int KC = min(H, MKC);           // K is staged through LDS in chunks of <= MKC
     float* a_t = smem;                    // [KC][MLD]  aggregates, k-major
     float* u_t = a_t + KC * MLD;          // [KC][MLD]  own lower-layer rows, k-major; later the GEMM outputs
-    float* g_s = u_t;                     // [2][MT][96] after the MFMA phase (u_t is dead by then)
-    int* v_s = reinterpret_cast<int*>(u_t + max(KC * MLD, 2 * MT * 96));  // [MT] node ids
+    float* g_s = u_t;                     // [2][MT][96] + [MT][64] after the MFMA phase (u_t is dead by then)
+    int* v_s = reinterpret_cast<int*>(u_t + max(KC * MLD, 2 * MT * 96 + MT * 64));  // [MT] node ids
 
     const int4* __restrict__ recs = reinterpret_cast<const int4*>(plan + L.rowrec[d]);
     if (tid < MT) v_s[tid] = tid < nr ? recs[4 * (int64_t)(slot0 + tid)].x : 0;
     __syncthreads();
 
+    // operands of the gate epilogue that do not depend on the products: issued now, consumed after the chains
+    // {input-side pre-activations or biases (r, z, n), hidden-side biases (r, z, n), aggregate, key weight}
+    float pre[2][8];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int id = p * 512 + tid;
+        const int r = id >> 5, j = sl * 32 + (id & 31);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pre[p][q] = 0.f;
+        if (r < nr) {
+            if (has_in) { pre[p][0] = C.bih[j]; pre[p][1] = C.bih[H + j]; pre[p][2] = C.bih[2 * H + j]; }
+            else {
+                const float* g0 = C.gi0 + (int64_t)v_s[r] * 3 * H;
+                pre[p][0] = g0[j]; pre[p][1] = g0[H + j]; pre[p][2] = g0[2 * H + j];
+            }
+            pre[p][3] = C.bhh[j]; pre[p][4] = C.bhh[H + j]; pre[p][5] = C.bhh[2 * H + j];
+            pre[p][6] = C.a_pre[(int64_t)(slot0 + r - C.row_base) * H + j];
+            pre[p][7] = C.wkey ? C.wkey[j] : 0.f;
+        }
+    }
+
     mf32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const int mat = wave / 3, gate = wave - mat * 3;   // wave = matrix * 3 + gate (waves 6, 7: staging + gates)
-    const bool chain = wave < 6 && (mat == 0 ? has_pred : has_in);
+    // chain c = matrix * 3 + gate.  With both products (6 chains on 4 SIMDs, two waves per SIMD) waves 0-3 run
+    // chains 0-3 over the whole K and waves 4|5, 6|7 the two K halves of chains 4, 5: 1.5 chains per SIMD
+    // instead of 2 on two of them; the second halves land in their own LDS tile and are added in the epilogue.
+    const int cid = has_in ? (wave < 4 ? wave : 4 + ((wave - 4) >> 1)) : wave;
+    const int khalf = (has_in && wave >= 4) ? ((wave - 4) & 1) : -1;   // -1: whole K
+    const int mat = cid / 3, gate = cid - mat * 3;
+    const bool chain = cid < 6 && (mat == 0 ? has_pred : has_in);
     const float* op = mat == 0 ? a_t : u_t;
     const float4* wp = chain ? (mat == 0 ? C.whh_m : C.wih_m) + ((int64_t)(sl * 3 + gate) * (H / 8)) * 64 + lane : nullptr;
     const int arow = lane & 31, ak = lane >> 5;
@@ -667,29 +695,50 @@ __global__ void __launch_bounds__(512, 2) frontier_mfma_kernel(const int32_t* __
     for (int k0 = 0; k0 < H; k0 += KC) {
         const int kc = min(KC, H - k0);
         if (k0 > 0) __syncthreads();   // the previous chunk's MFMAs are done with a_t / u_t
-        // ---- stage the operand chunk k-major: wave w copies rows w, w+8, ... (coalesced float4 row reads)
-        for (int r = wave; r < MT; r += 8) {
-            const bool live = r < nr;
-            const float4* ap = reinterpret_cast<const float4*>(C.a_pre + (int64_t)(slot0 + r - C.row_base) * H + k0);
-            const float4* up = has_in ? reinterpret_cast<const float4*>(C.h_in + (int64_t)v_s[r] * ld_h + k0) : nullptr;
-            for (int cc = lane; cc < (kc >> 2); cc += 64) {
-                const float4 av = live ? ap[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
-                a_t[(4 * cc + 0) * MLD + r] = av.x; a_t[(4 * cc + 1) * MLD + r] = av.y;
-                a_t[(4 * cc + 2) * MLD + r] = av.z; a_t[(4 * cc + 3) * MLD + r] = av.w;
+        // this wave's k range of the chunk and its first group of B fragments: in flight during the staging
+        const int k8n = kc >> 3, k8b = khalf < 0 ? 0 : khalf * (k8n >> 1), k8e = khalf < 0 ? k8n : k8b + (k8n >> 1);
+        float4 wn[4];
+        if (chain) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wn[q] = wp[(int64_t)((k0 >> 3) + k8b + q) * 64];
+        }
+        // ---- stage the operand chunk k-major: wave w copies rows w, w+8, w+16, w+24 (coalesced float4 row
+        // reads); the loads of all four rows are issued before the first LDS store - one round trip, not four
+        for (int cc = lane; cc < (kc >> 2); cc += 64) {
+            float4 av[MT / 8], uv[MT / 8];
+#pragma unroll
+            for (int q = 0; q < MT / 8; ++q) {
+                const int r = wave + 8 * q;
+                av[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                uv[q] = av[q];
+                if (r < nr) {
+                    av[q] = reinterpret_cast<const float4*>(C.a_pre + (int64_t)(slot0 + r - C.row_base) * H + k0)[cc];
+                    if (has_in) uv[q] = reinterpret_cast<const float4*>(C.h_in + (int64_t)v_s[r] * ld_h + k0)[cc];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < MT / 8; ++q) {
+                const int r = wave + 8 * q;
+                a_t[(4 * cc + 0) * MLD + r] = av[q].x; a_t[(4 * cc + 1) * MLD + r] = av[q].y;
+                a_t[(4 * cc + 2) * MLD + r] = av[q].z; a_t[(4 * cc + 3) * MLD + r] = av[q].w;
                 if (has_in) {
-                    const float4 uv = live ? up[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    u_t[(4 * cc + 0) * MLD + r] = uv.x; u_t[(4 * cc + 1) * MLD + r] = uv.y;
-                    u_t[(4 * cc + 2) * MLD + r] = uv.z; u_t[(4 * cc + 3) * MLD + r] = uv.w;
+                    u_t[(4 * cc + 0) * MLD + r] = uv[q].x; u_t[(4 * cc + 1) * MLD + r] = uv[q].y;
+                    u_t[(4 * cc + 2) * MLD + r] = uv[q].z; u_t[(4 * cc + 3) * MLD + r] = uv[q].w;
                 }
             }
         }
         __syncthreads();
+        if (stamp) stamp[1] = wall_clock64();
         // ---- MFMA chains over this K chunk
         if (chain) {
-            for (int k8 = 0; k8 < (kc >> 3); k8 += 4) {   // 4 x 16 B of B fragments in flight per lane
+            for (int k8 = k8b; k8 < k8e; k8 += 4) {   // 4 x 16 B of B fragments per group, the next group in flight
                 float4 w4[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) w4[q] = wp[(int64_t)((k0 >> 3) + k8 + q) * 64];
+                for (int q = 0; q < 4; ++q) w4[q] = wn[q];
+                if (k8 + 4 < k8e) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) wn[q] = wp[(int64_t)((k0 >> 3) + k8 + 4 + q) * 64];
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int kb = 8 * (k8 + q) + ak;   // this lane's k (within the chunk) for the first MFMA of the fragment
@@ -701,15 +750,20 @@ __global__ void __launch_bounds__(512, 2) frontier_mfma_kernel(const int32_t* __
             }
         }
     }
+    if (stamp) stamp[2] = wall_clock64();
     __syncthreads();   // every chain has read u_t: it can now hold the outputs
-    if (wave < 6) {
+    if (stamp) stamp[3] = wall_clock64();
+    if (cid < 6) {
         // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-        float* out = g_s + mat * (MT * 96) + gate * 32 + (lane & 31);
+        const bool second = khalf == 1;   // second K half of chain 4 / 5: its own [MT][64] tile behind g_s
+        float* out = second ? g_s + 2 * MT * 96 + (gate - 1) * 32 + (lane & 31) : g_s + mat * (MT * 96) + gate * 32 + (lane & 31);
+        const int pitch = second ? 64 : 96;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) out[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * 96] = acc[e];
+        for (int e = 0; e < 16; ++e) out[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * pitch] = acc[e];
     }
     __syncthreads();
 
+    if (stamp) stamp[4] = wall_clock64();
     // ---- gates: 32 rows x 32 units, two elements per thread; 16 consecutive lanes = 16 units of a row
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -720,22 +774,20 @@ __global__ void __launch_bounds__(512, 2) frontier_mfma_kernel(const int32_t* __
         const int gv = live ? v_s[r] : 0;
         const int j = sl * 32 + jj;
         if (live) {
-            float gr, gz, gn;
+            float gr = pre[p][0], gz = pre[p][1], gn = pre[p][2];
             if (has_in) {
                 const float* gi = g_s + MT * 96 + r * 96;
-                gr = gi[jj] + C.bih[j]; gz = gi[32 + jj] + C.bih[H + j]; gn = gi[64 + jj] + C.bih[2 * H + j];
-            } else {
-                const float* g0 = C.gi0 + (int64_t)gv * 3 * H;
-                gr = g0[j]; gz = g0[H + j]; gn = g0[2 * H + j];
+                const float* g2 = g_s + 2 * MT * 96 + r * 64;
+                gr += gi[jj]; gz += gi[32 + jj] + g2[jj]; gn += gi[64 + jj] + g2[32 + jj];
             }
             const float* gh = g_s + r * 96;
-            const float hr = gh[jj] + C.bhh[j], hz = gh[32 + jj] + C.bhh[H + j], hn = gh[64 + jj] + C.bhh[2 * H + j];
-            const float a = C.a_pre[(int64_t)(slot0 + r - C.row_base) * H + j];
+            const float hr = gh[jj] + pre[p][3], hz = gh[32 + jj] + pre[p][4], hn = gh[64 + jj] + pre[p][5];
+            const float a = pre[p][6];
             const float rg = sigm(gr + hr);
             const float zg = sigm(gz + hz);
             const float ng = tanhf(fmaf(rg, hn, gn));
             hv = fmaf(zg, a - ng, ng);
-            sp = (C.wkey ? C.wkey[j] : 0.f) * hv;
+            sp = pre[p][7] * hv;
         }
         sp = dpp_row_sum16(sp);
         if (live) {
@@ -749,6 +801,7 @@ __global__ void __launch_bounds__(512, 2) frontier_mfma_kernel(const int32_t* __
             }
         }
     }
+    if (stamp) stamp[5] = wall_clock64();
 }
 
 // Pack W [3H, K] (torch layout) into MFMA B-fragment order for 32-unit slices:
@@ -1067,7 +1120,8 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
             e = hipGetLastError();
             if (e != hipSuccess) return DAGNN_EHIP(e);
             const int kcl = H < MKC ? H : MKC;
-            const size_t lds = (size_t)(kcl * MLD + (kcl * MLD > 2 * MT * 96 ? kcl * MLD : 2 * MT * 96)) * sizeof(float) +
+            const int outw = 2 * MT * 96 + MT * 64;
+            const size_t lds = (size_t)(kcl * MLD + (kcl * MLD > outw ? kcl * MLD : outw)) * sizeof(float) +
                                MT * sizeof(int);
             hipLaunchKernelGGL(frontier_mfma_kernel, dim3((unsigned)(tiles * (H / 32))), dim3(512), lds, st, plan, L, S);
             e = hipGetLastError();

@@ -129,7 +129,7 @@ def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
                     % (S, " + one RCCL all-reduce of the %.1f M-float gradient bucket" % (flat.numel() / 1e6)
                        if world > 1 else ""),
             "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
-            "graphs_per_s": round(world * B * steps / elapsed, 1), "final_loss": round(float(loss), 4),
+            "graphs_per_s": round(world * B * steps / elapsed, 1), "final_loss": round(float(loss.detach()), 4),
             "kernels_ms_per_step": {k: round(n * ms / steps, 4) for k, (n, ms) in summ.items()}}
 
 
@@ -165,11 +165,18 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path is HIP for gfx950 and has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("DAGNN_BENCH_BACKEND", "nccl")  # "gloo": functional check of the N>1 path on fewer GPUs
+    if local_rank >= ndev and backend == "nccl":
+        raise SystemExit("rank %d has no GPU (%d visible): one process per GPU" % (local_rank, ndev))
+    torch.cuda.set_device(local_rank % ndev)
+    device = torch.device("cuda", local_rank % ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from dagnn_amd import engine
     from dagnn_amd.synth import code2_batch

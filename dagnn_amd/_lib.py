@@ -50,7 +50,7 @@ class FrontierCell(C.Structure):
 
 class FrontierArgs(C.Structure):
     _fields_ = [("cell", (FrontierCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
-                ("H", C.c_int), ("ld_h", C.c_int), ("vid_mod", C.c_int), ("num_cus", C.c_int), ("rb4_rounds", C.c_int), ("mfma_min_rows", C.c_int),
+                ("H", C.c_int), ("ld_h", C.c_int), ("vid_mod", C.c_int), ("num_cus", C.c_int), ("rb4_max_wgs", C.c_int), ("mfma_min_rows", C.c_int),
                 ("agg_scratch", C.c_void_p), ("agg_scratch_rows", C.c_int),
                 ("tail_replicas", C.c_int), ("tail_slice_units", C.c_int), ("tail_max_blocks", C.c_int), ("epoch", C.c_uint),
                 ("tail_err", C.c_void_p), ("debug_timing", C.c_void_p)]
@@ -63,7 +63,7 @@ class BackwardCell(C.Structure):
 
 class BackwardArgs(C.Structure):
     _fields_ = [("cell", (BackwardCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
-                ("H", C.c_int), ("ld_h", C.c_int), ("num_cus", C.c_int)]
+                ("H", C.c_int), ("ld_h", C.c_int), ("num_cus", C.c_int), ("thin_wgs", C.c_int)]
 
 
 # every symbol include/dagnn_hip.h declares: (restype, argtypes)

@@ -719,7 +719,7 @@ extern "C" int dagnn_backward_run(const dagnn_plan* pl, const dagnn_backward_arg
         const int rows = layout(1);
         if (rows == 0) continue;
         const int blocks4 = layout(4);
-        const bool thin = blocks4 * NS <= 2 * a->num_cus;
+        const bool thin = blocks4 * NS <= (a->thin_wgs > 0 ? a->thin_wgs : 2 * a->num_cus);
         if (thin || (!mfma && rb_fat == 4)) {
             const dim3 grid((unsigned)(blocks4 * NS));
             if (pre) hipLaunchKernelGGL((bwd_step_kernel<4, true>), grid, dim3(ST), step_lds_bytes<4>(H), st, plan, L, S);

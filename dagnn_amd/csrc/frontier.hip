@@ -169,27 +169,29 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
             // rows and score parts of all <= 4 predecessors in ONE polling loop (one round trip when ready)
             float pv[4] = {0.f, 0.f, 0.f, 0.f};
             unsigned spins = 0;
+            const gran_t ready = (gran_t)G.epoch << 32;   // stands in for granules that are not read
+            const bool want_parts = deg > 1 && !C.sscore && lane < nparts;
             for (;;) {
+                // every load of the iteration is issued before the first tag is looked at: the loads are atomics,
+                // which the compiler keeps in program order - a compare between two groups would serialise them
+                gran_t x[4][4], xp[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const gran_t* grow = gsrc + (int64_t)pj[e] * gld;
+                    const bool on = e < deg && lane < H4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[e][q] = on ? gran_ld(grow + 4 * lane + q) : ready;
+                    xp[e] = (e < deg && want_parts) ? gran_ld(grow + H + lane) : ready;
+                }
                 bool ok = true;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    row0[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (e < deg) {
-                        const gran_t* grow = gsrc + (int64_t)pj[e] * gld;
-                        if (lane < H4) {
-                            const gran_t x0 = gran_ld(grow + 4 * lane), x1 = gran_ld(grow + 4 * lane + 1),
-                                         x2 = gran_ld(grow + 4 * lane + 2), x3 = gran_ld(grow + 4 * lane + 3);
-                            ok = ok && (unsigned)(x0 >> 32) == G.epoch && (unsigned)(x1 >> 32) == G.epoch &&
-                                 (unsigned)(x2 >> 32) == G.epoch && (unsigned)(x3 >> 32) == G.epoch;
-                            row0[e] = make_float4(__uint_as_float((unsigned)x0), __uint_as_float((unsigned)x1),
-                                                  __uint_as_float((unsigned)x2), __uint_as_float((unsigned)x3));
-                        }
-                        if (deg > 1 && !C.sscore && lane < nparts) {
-                            const gran_t x = gran_ld(grow + H + lane);
-                            ok = ok && (unsigned)(x >> 32) == G.epoch;
-                            pv[e] = __uint_as_float((unsigned)x);
-                        }
-                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(x[e][q] >> 32) == G.epoch;
+                    ok = ok && (unsigned)(xp[e] >> 32) == G.epoch;
+                    row0[e] = make_float4(__uint_as_float((unsigned)x[e][0]), __uint_as_float((unsigned)x[e][1]),
+                                          __uint_as_float((unsigned)x[e][2]), __uint_as_float((unsigned)x[e][3]));
+                    pv[e] = __uint_as_float((unsigned)xp[e]);
                 }
                 if (__all(ok) || !gran_retry(spins, G)) break;
             }
@@ -336,18 +338,19 @@ __device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restri
                     float4 v[4];
                     unsigned spins = 0;
                     for (;;) {
+                        gran_t x[4][4];   // all 16 loads first, then the tags (see the inline path)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                x[u][q] = lane < H4 ? gran_ld(gr[u] + 4 * lane + q) : ((gran_t)G.epoch << 32);
                         bool ok = true;
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (lane < H4) {
-                                const gran_t x0 = gran_ld(gr[u] + 4 * lane), x1 = gran_ld(gr[u] + 4 * lane + 1),
-                                             x2 = gran_ld(gr[u] + 4 * lane + 2), x3 = gran_ld(gr[u] + 4 * lane + 3);
-                                ok = ok && (unsigned)(x0 >> 32) == G.epoch && (unsigned)(x1 >> 32) == G.epoch &&
-                                     (unsigned)(x2 >> 32) == G.epoch && (unsigned)(x3 >> 32) == G.epoch;
-                                v[u] = make_float4(__uint_as_float((unsigned)x0), __uint_as_float((unsigned)x1),
-                                                   __uint_as_float((unsigned)x2), __uint_as_float((unsigned)x3));
-                            }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(x[u][q] >> 32) == G.epoch;
+                            v[u] = make_float4(__uint_as_float((unsigned)x[u][0]), __uint_as_float((unsigned)x[u][1]),
+                                               __uint_as_float((unsigned)x[u][2]), __uint_as_float((unsigned)x[u][3]));
                         }
                         if (__all(ok) || !gran_retry(spins, G)) break;
                     }
@@ -1077,7 +1080,7 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         // round of slots, else 8-row blocks (125 VGPRs, two per CU).
         int js, rb;
         if (blocks4 * (H / 16) <= a->num_cus) { js = 16; rb = 4; }
-        else if (blocks4 * (H / 32) <= 3 * a->num_cus * (a->rb4_rounds > 0 ? a->rb4_rounds : 1)) { js = 32; rb = 4; }
+        else if (blocks4 * (H / 32) <= (a->rb4_max_wgs > 0 ? a->rb4_max_wgs : 3 * a->num_cus / 2)) { js = 32; rb = 4; }
         else if (blocks8 * (H / 16) <= a->num_cus) { js = 16; rb = 8; }
         else { js = 32; rb = 8; }
         int nc = 0, blocks = 0;

@@ -53,12 +53,13 @@ class _NoSpan(object):
 
 
 TIMER: Optional[KernelTimer] = None  # set by bench.py around its timed region
-RB4_ROUNDS = int(__import__("os").environ.get("DAGNN_AMD_RB4_ROUNDS", "1"))
+RB4_MAX_WGS = int(__import__("os").environ.get("DAGNN_AMD_RB4_MAX_WGS", "0"))  # 0 = library default (1.5 per CU)
 MFMA_MIN_ROWS = int(__import__("os").environ.get("DAGNN_AMD_MFMA_MIN_ROWS", "400"))  # 0 = never use MFMA tiles
 AGG_SPLIT = int(__import__("os").environ.get("DAGNN_AMD_AGG_SPLIT", "0"))
 TAIL_SLICE = int(__import__("os").environ.get("DAGNN_AMD_TAIL_SLICE", "32"))
 TAIL_REPLICAS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_REPLICAS", "4"))   # 0 = launch every layer
 TAIL_MAX_BLOCKS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_MAX_BLOCKS", "2"))
+BWD_THIN_WGS = int(__import__("os").environ.get("DAGNN_AMD_BWD_THIN_WGS", "0"))  # 0 = library default
 DEBUG_TIMING: Optional[torch.Tensor] = None  # int64[8] device tensor: phase ticks of the deepest work item
 _NOSPAN = _NoSpan()
 
@@ -311,7 +312,7 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     args.num_stacked, args.dir_mask, args.H, args.ld_h, args.vid_mod = L, mask, H, h[dirs[0]][0].shape[1], int(vid_mod)
     args.debug_timing = DEBUG_TIMING.data_ptr() if DEBUG_TIMING is not None else None
     args.num_cus = torch.cuda.get_device_properties(plan.ws.device).multi_processor_count
-    args.rb4_rounds = RB4_ROUNDS
+    args.rb4_max_wgs = RB4_MAX_WGS
     # everything above is independent of the schedule: the one device->host read of the forward pass comes
     # last, so the host-side argument marshalling overlaps the plan / GEMM kernels still in flight
     sched = plan.read_schedule()
@@ -412,6 +413,7 @@ def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells,
             bc.sigma, bc.edge_feat_grad = o["sigma"].data_ptr(), _ptr(o["edge_feat_grad"])
     args.num_stacked, args.dir_mask, args.H, args.ld_h = L, mask, H, h[dirs[0]][0].shape[1]
     args.num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    args.thin_wgs = BWD_THIN_WGS
     lib = _lib.load()
     with _span("backward_prepare", plan.ws):
         check(lib.dagnn_backward_prepare(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_backward_prepare")

@@ -198,7 +198,8 @@ typedef struct dagnn_frontier_args {
     int dir_mask;
     int H, ld_h, vid_mod;
     int num_cus;     /* compute units of the device (launch geometry heuristic), e.g. 256 */
-    int rb4_rounds;  /* launches of up to this many rounds of 4-row-block workgroups (3 per CU) use 4-row blocks */
+    int rb4_max_wgs; /* streamed 32-unit slices: launches of up to this many 4-row-block workgroups use 4-row blocks,
+                      * bigger ones 8-row blocks; 0 = default (1.5 per CU) */
     int mfma_min_rows;    /* launches with at least this many rows (all cells) run as 32-row MFMA tiles; 0 = never */
     void* agg_scratch;    /* NULL, or fp32 [agg_scratch_rows, H]: fat launches aggregate every row once into it */
     int agg_scratch_rows; /* >= the largest number of rows (over all cells) of any single launch */
@@ -269,6 +270,8 @@ typedef struct dagnn_backward_args {
     dagnn_backward_cell cell[DAGNN_MAX_DIRS][DAGNN_MAX_STACKED];
     int num_stacked, dir_mask, H, ld_h;
     int num_cus;
+    int thin_wgs;   /* launches of up to this many slice workgroups use the register-resident slice kernel, bigger ones
+                     * the rows + MFMA-tile kernels; 0 = default (2 * num_cus) */
 } dagnn_backward_args;
 
 int dagnn_backward_prepare(const dagnn_plan* plan /* host */, const dagnn_backward_args* args /* host */, void* stream);

@@ -8,13 +8,15 @@ from dagnn_amd import DAGNN, ASTNodeEncoder, GraphBatch, GraphData, engine
 from dagnn_amd.dag_utils import add_order_info_01
 
 
-def chain_batch(B, n, seed=0, leaves=0):
+def chain_batch(B, n, seed=0, leaves=0, skip=0):
     """B path graphs of n spine nodes; `leaves` > 0 hangs that many leaf children on every spine node, so the
     reverse direction sees a fan-in of leaves + 1 on the dependent chain."""
     rng = np.random.default_rng(seed)
     gs = []
     for _ in range(B):
         ei = np.stack([np.arange(n - 1), np.arange(1, n)])
+        if skip:  # ladder: i -> i + 2 as well, fan-in 2 with one row per layer
+            ei = np.concatenate([ei, np.stack([np.arange(n - 2), np.arange(2, n)])], 1)
         if leaves:
             src = np.repeat(np.arange(n), leaves)
             ei = np.concatenate([ei, np.stack([src, n + np.arange(n * leaves)])], 1)
@@ -28,13 +30,13 @@ def chain_batch(B, n, seed=0, leaves=0):
     return GraphBatch.from_data_list(gs)
 
 
-def run(B, n, L, bidir, H=256, reps=5, leaves=0):
+def run(B, n, L, bidir, H=256, reps=5, leaves=0, skip=0):
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     model = DAGNN(num_vocab=50, max_seq_len=2, emb_dim=H, hidden_dim=H, out_dim=None,
                   encoder=ASTNodeEncoder(H, 98, 10030, 20), num_layers=L, bidirectional=bidir, out_wx=False,
                   out_pool_all=False, out_pool="max").eval().to(dev)
-    master = chain_batch(B, n, leaves=leaves).to(dev)
+    master = chain_batch(B, n, leaves=leaves, skip=skip).to(dev)
     best = 1e9
     with torch.no_grad():
         for _ in range(reps):
@@ -80,5 +82,8 @@ def stamps(n=600, L=1, bidir=False, leaves=0):
 
 
 if __name__ == "__main__":
+    run(1, 1000, 1, False)
+    run(1, 1000, 1, False, skip=1)
+    run(1, 1000, 2, False, skip=1)
     stamps()
     stamps(leaves=1, L=1, bidir=True)

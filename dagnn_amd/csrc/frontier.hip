@@ -513,6 +513,7 @@ __device__ __forceinline__ void process_block(const int32_t* __restrict__ plan, 
         // wave-uniform: blocks with <= 2 live rows (the thin tail); only in the latency-bound shapes - the
         // second code copy costs the streamed shapes registers and instruction-cache room
         const bool few = RBT == 4 && KW == 16 && nr <= 2;
+        const bool one = RESIDENT && few && nr == 1;   // the persistent tail spreads thin layers: one row per block is the common case
         for (int ch = 0; ch < nchunk; ++ch) {
             const int n = min(KW, kpt - ch * KW);
             if (ch > 0) {  // never taken when RESIDENT (the host only uses it for kpt <= KW)
@@ -524,7 +525,10 @@ __device__ __forceinline__ void process_block(const int32_t* __restrict__ plan, 
                     }
                 }
             }
-            if (few) {
+            if (one) {
+                if (has_pred) fma_rows<RBT, KW, 1>(acc_h, wh, a_s, op_ld, kbase + ch * KW, n);
+                if (has_in) fma_rows<RBT, KW, 1>(acc_i, wi, u_s, op_ld, kbase + ch * KW, n);
+            } else if (few) {
                 if (has_pred) fma_rows<RBT, KW, 2>(acc_h, wh, a_s, op_ld, kbase + ch * KW, n);
                 if (has_in) fma_rows<RBT, KW, 2>(acc_i, wi, u_s, op_ld, kbase + ch * KW, n);
             } else {
@@ -535,7 +539,7 @@ __device__ __forceinline__ void process_block(const int32_t* __restrict__ plan, 
         if (stamp) stamp[3] = wall_clock64();
 #pragma unroll
         for (int r = 0; r < RBT; ++r) {
-            if (few && r >= 2) continue;
+            if ((few && r >= 2) || (one && r >= 1)) continue;
             if (has_pred) { acc_h[r].x = dpp_row_sum16(acc_h[r].x); acc_h[r].y = dpp_row_sum16(acc_h[r].y);
                             acc_h[r].z = dpp_row_sum16(acc_h[r].z); acc_h[r].w = dpp_row_sum16(acc_h[r].w); }
             if (has_in) { acc_i[r].x = dpp_row_sum16(acc_i[r].x); acc_i[r].y = dpp_row_sum16(acc_i[r].y);

@@ -393,6 +393,40 @@ def test_training_step_matches_oracle_autograd_and_is_deterministic(device):
             assert torch.equal(grads[k], again[k]), k
 
 
+def test_training_step_edge_cases_match_oracle_autograd(device):
+    """Gradients on the degenerate graphs of `test_edge_cases` (single nodes, no edges, a chain, 200-way fan-in
+    and fan-out, duplicate edges; attention ties in the max read-out) and with a w_edge_attr=False model."""
+    from dagnn_amd import GraphData
+    from dagnn_amd.dag_utils import add_order_info_01
+
+    def g(n, edges, attr=None):
+        ei = torch.tensor(edges, dtype=torch.long).t().reshape(2, -1)
+        ea = torch.zeros(ei.shape[1], 2) if attr is None else torch.tensor(attr, dtype=torch.float32)
+        d = GraphData(x=torch.stack([torch.arange(n) % 98, (7 * torch.arange(n)) % 300], 1),
+                      node_depth=(torch.arange(n) % 30).view(-1, 1), edge_index=ei, edge_attr=ea)
+        add_order_info_01(d)
+        return d
+
+    graphs = [g(1, []), g(5, []), g(40, [(i, i + 1) for i in range(39)]),
+              g(201, [(i, 200) for i in range(200)], [[i % 2, 0] for i in range(200)]),
+              g(201, [(0, i) for i in range(1, 201)], [[(i // 3) % 2, 0] for i in range(200)]),
+              g(3, [(0, 1), (0, 1), (1, 2)], [[0, 0], [1, 0], [0, 0]])]
+    b = synth.GraphBatch.from_data_list(graphs)
+    y = torch.from_numpy(np.random.default_rng(8).integers(0, 16, size=(len(graphs), 5)))
+    for wea in (True, False):
+        meta = dict(H=64, n_attr=300, V=16, S=5, w_seed=91 + wea,
+                    ctor=dict(w_edge_attr=wea, num_layers=2, bidirectional=True, agg="attn_h", out_wx=False,
+                              out_pool_all=False, out_pool="max", dropout=0.0))
+        model = Hh.code2_model(meta)
+        loss_ref, ref = O.code2_grads(model.state_dict(), b.clone(), y, num_layers=2, bidirectional=True, max_seq_len=5)
+        model = model.to(device)
+        loss, grads = _train_step(model, b.clone().to(device), y.to(device))
+        assert abs(float(loss) - float(loss_ref)) < 1e-5
+        for k, gk in grads.items():
+            scale = float(ref[k].abs().max())
+            assert Hh.maxdiff(gk, ref[k]) <= 1e-4 * scale + 2e-7, (wea, k)
+
+
 def test_training_and_inference_forward_agree(device):
     meta, arr = Hh.load("grad_h32_bidir")
     model = Hh.code2_model(meta).to(device)

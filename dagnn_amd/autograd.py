@@ -98,7 +98,8 @@ class Recurrence(torch.autograd.Function):
             for i in range(L):
                 engine.readout_max_backward(plan, h[d][i], d, gout, col, g_ext[d][i])
                 col += H
-        res = engine.backward_sweep(plan, dirs, L, Hp, cells, keep["h_buf"], keep["gi0"], g_ext)
+        res = engine.backward_sweep(plan, dirs, L, Hp, cells, keep["h_buf"], keep["gi0"], g_ext,
+                                    arena=mod._arena_for(x, "backward"))
 
         def gates(t):  # [N, 3Hp] in gate blocks of Hp -> [N, 3H]
             return t if Hp == H else t.view(N, 3, Hp)[:, :, :H].reshape(N, 3 * H)

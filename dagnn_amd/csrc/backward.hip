@@ -61,7 +61,13 @@ struct BCell {
     float* dgh;          // [N,3H]
     float* sig;          // [N]
     float* mrel;         // [N,R] or null
+    // persistent sweep only: tagged 8-byte copies (see common.h) of the rows other workgroups of the SAME launch wait for
+    gran_t* da_g;        // [N,H] granules of da
+    const gran_t* du_in; // [N,H] granules of the upper stacked layer's du for this cell's rows, or null (top layer)
+    gran_t* du_out;      // [N,H] granules of this cell's du (== du_in of stacked layer i-1), or null
+    const float* gext0;  // [N,H] gext as it was before the sweep (du arrives through du_in), or null (top layer)
     int dir, row_base, row_end;
+    int stacked, T;      // persistent sweep: stacked layer index i, number of topological layers of this direction
 };
 
 struct BArgs {
@@ -156,9 +162,30 @@ __global__ void __launch_bounds__(256) bwd_succrec_kernel(int32_t* plan, PlanLay
 
 // One wave: grow[0..H) (LDS) = Gext_v + sum over the successors of the node of record `rec` (see file header);
 // `publish`: also store sigma_v and the edge-feature sums.
+// GRAN (persistent sweep, H <= 256): successor rows da_w and the upper layer's du_v were written by other
+// workgroups of this very launch - they are read, and waited for, through their granule copies.
+// One wave: float4 chunk `lane` of a granule row, waiting for it.
+__device__ __forceinline__ float4 bgran_chunk(const gran_t* grow, int lane, int H4, const GranCtx& G) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned spins = 0;
+    for (;;) {
+        gran_t x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = lane < H4 ? gran_ld(grow + 4 * lane + q) : ((gran_t)G.epoch << 32);
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(x[q] >> 32) == G.epoch;
+        v = make_float4(__uint_as_float((unsigned)x[0]), __uint_as_float((unsigned)x[1]),
+                        __uint_as_float((unsigned)x[2]), __uint_as_float((unsigned)x[3]));
+        if (__all(ok) || !gran_retry(spins, G)) break;
+    }
+    return v;
+}
+
+template <bool GRAN>
 __device__ __forceinline__ void pull_row(const int32_t* __restrict__ plan, const PlanLayout& L, const BCell& C,
                                          const int4* __restrict__ rec, int R, int H, int ld_h, float* grow, int lane,
-                                         bool publish) {
+                                         bool publish, const GranCtx& G) {
     const int H4 = H >> 2, od = 1 - C.dir;
     const int4 b0 = rec[0];
     const int v = b0.x, eb = b0.y, ee = b0.z, deg = ee - eb;
@@ -172,8 +199,9 @@ __device__ __forceinline__ void pull_row(const int32_t* __restrict__ plan, const
         const bool on = lane < H4;
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 g = zero, y = zero, wk = zero;
+        const bool via_du = GRAN && C.du_in != nullptr;
         if (on) {
-            g = reinterpret_cast<const float4*>(C.gext + (int64_t)v * H)[lane];
+            g = reinterpret_cast<const float4*>((via_du ? C.gext0 : C.gext) + (int64_t)v * H)[lane];
             y = reinterpret_cast<const float4*>(hv)[lane];
             wk = reinterpret_cast<const float4*>(C.wkey)[lane];
         }
@@ -185,12 +213,44 @@ __device__ __forceinline__ void pull_row(const int32_t* __restrict__ plan, const
             if (e < deg) {
                 al[e] = C.alpha[pick(b2, e)];
                 if (on) {
-                    x[e] = reinterpret_cast<const float4*>(C.da + (int64_t)pick(b1, e) * H)[lane];
+                    if (!GRAN) x[e] = reinterpret_cast<const float4*>(C.da + (int64_t)pick(b1, e) * H)[lane];
                     z[e] = reinterpret_cast<const float4*>(C.a + (int64_t)pick(b1, e) * H)[lane];
                 }
                 if (R >= 1) f0[e] = eattr[(int64_t)(eb + e) * R];
                 if (R >= 2) f1[e] = eattr[(int64_t)(eb + e) * R + 1];
             }
+        }
+        if (GRAN) {
+            // one polling loop for the du row and all (<= 4) successor rows; every load of an iteration is issued
+            // before the first tag is looked at (atomic loads keep program order: a compare between two groups
+            // would serialise them)
+            const gran_t ready = (gran_t)G.epoch << 32;
+            unsigned spins = 0;
+            float4 du = zero;
+            for (;;) {
+                gran_t xu[4], xs[4][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xu[q] = (via_du && on) ? gran_ld(C.du_in + (int64_t)v * H + 4 * lane + q) : ready;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        xs[e][q] = (e < deg && on) ? gran_ld(C.da_g + (int64_t)pick(b1, e) * H + 4 * lane + q) : ready;
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(xu[q] >> 32) == G.epoch;
+                du = make_float4(__uint_as_float((unsigned)xu[0]), __uint_as_float((unsigned)xu[1]),
+                                 __uint_as_float((unsigned)xu[2]), __uint_as_float((unsigned)xu[3]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(xs[e][q] >> 32) == G.epoch;
+                    x[e] = make_float4(__uint_as_float((unsigned)xs[e][0]), __uint_as_float((unsigned)xs[e][1]),
+                                       __uint_as_float((unsigned)xs[e][2]), __uint_as_float((unsigned)xs[e][3]));
+                }
+                if (__all(ok) || !gran_retry(spins, G)) break;
+            }
+            if (via_du) { g.x += du.x; g.y += du.y; g.z += du.z; g.w += du.w; }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -206,7 +266,80 @@ __device__ __forceinline__ void pull_row(const int32_t* __restrict__ plan, const
         }
         g.x = fmaf(sig, wk.x, g.x); g.y = fmaf(sig, wk.y, g.y); g.z = fmaf(sig, wk.z, g.z); g.w = fmaf(sig, wk.w, g.w);
         if (on) reinterpret_cast<float4*>(grow)[lane] = g;
+    } else if (H4 <= 64) {
+        // fan-out > 4, one chunk per lane: successors in groups of four, every load of a group in flight together
+        const int32_t* col = plan + L.col[od];
+        const int32_t* eidx = plan + L.eidx[od];
+        const bool on = lane < H4;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 g = zero, y = zero, wk = zero;
+        const bool via_du = GRAN && C.du_in != nullptr;
+        if (on) {
+            g = reinterpret_cast<const float4*>((via_du ? C.gext0 : C.gext) + (int64_t)v * H)[lane];
+            y = reinterpret_cast<const float4*>(hv)[lane];
+            wk = reinterpret_cast<const float4*>(C.wkey)[lane];
+        }
+        if (via_du) {
+            const float4 du = bgran_chunk(C.du_in + (int64_t)v * H, lane, H4, G);
+            g.x += du.x; g.y += du.y; g.z += du.z; g.w += du.w;
+        }
+        for (int base = eb; base < ee; base += 4) {
+            const int n = min(4, ee - base);
+            int w[4];
+            float al[4];
+            float4 x[4], z[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                w[u] = u < n ? col[base + u] : 0;
+                al[u] = u < n ? C.alpha[eidx[base + u]] : 0.f;
+                x[u] = zero; z[u] = zero;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u < n && on) {
+                    if (!GRAN) x[u] = reinterpret_cast<const float4*>(C.da + (int64_t)w[u] * H)[lane];
+                    z[u] = reinterpret_cast<const float4*>(C.a + (int64_t)w[u] * H)[lane];
+                }
+            }
+            if (GRAN) {
+                const gran_t ready = (gran_t)G.epoch << 32;
+                unsigned spins = 0;
+                for (;;) {
+                    gran_t xs[4][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            xs[u][q] = (u < n && on) ? gran_ld(C.da_g + (int64_t)w[u] * H + 4 * lane + q) : ready;
+                    bool ok = true;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(xs[u][q] >> 32) == G.epoch;
+                        x[u] = make_float4(__uint_as_float((unsigned)xs[u][0]), __uint_as_float((unsigned)xs[u][1]),
+                                           __uint_as_float((unsigned)xs[u][2]), __uint_as_float((unsigned)xs[u][3]));
+                    }
+                    if (__all(ok) || !gran_retry(spins, G)) break;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u >= n) continue;
+                float dot = x[u].x * (y.x - z[u].x);
+                dot = fmaf(x[u].y, y.y - z[u].y, dot); dot = fmaf(x[u].z, y.z - z[u].z, dot);
+                dot = fmaf(x[u].w, y.w - z[u].w, dot);
+                const float ds = al[u] * wave_sum(dot);
+                sig += ds;
+                if (R >= 1) m0 = fmaf(ds, eattr[(int64_t)(base + u) * R], m0);
+                if (R >= 2) m1 = fmaf(ds, eattr[(int64_t)(base + u) * R + 1], m1);
+                g.x = fmaf(al[u], x[u].x, g.x); g.y = fmaf(al[u], x[u].y, g.y);
+                g.z = fmaf(al[u], x[u].z, g.z); g.w = fmaf(al[u], x[u].w, g.w);
+            }
+        }
+        g.x = fmaf(sig, wk.x, g.x); g.y = fmaf(sig, wk.y, g.y); g.z = fmaf(sig, wk.z, g.z); g.w = fmaf(sig, wk.w, g.w);
+        if (on) reinterpret_cast<float4*>(grow)[lane] = g;
     } else {
+        // wide rows (H > 256; never in the persistent sweep): successors one at a time, G accumulated in LDS
         const int32_t* col = plan + L.col[od];
         const int32_t* eidx = plan + L.eidx[od];
         for (int cc = lane; cc < H4; cc += 64)
@@ -254,10 +387,15 @@ __device__ __forceinline__ void pull_row(const int32_t* __restrict__ plan, const
 // first, then the operands of the gate algebra (they depend only on the node ids of the records), and only
 // then walks record -> successor rows; the products are pure LDS-broadcast + FMA.  The dependent chain of a
 // thin launch - which is what bounds the sweep - is two memory round trips plus three barriers.
-template <int RB, bool PRE>
-__global__ void __launch_bounds__(ST) bwd_step_kernel(const int32_t* __restrict__ plan, PlanLayout L, BArgs S) {
-    extern __shared__ float lds[];
-    const int H = S.H, H3 = 3 * H, H4 = H >> 2, ld_h = S.ld_h;
+// One row block of one cell x one 16-unit slice.  PERSIST: called from the persistent sweep - the weight slices are
+// already in wr / wr2, rows other workgroups wait for are also published as granules.
+template <int RB, bool PRE, bool PERSIST>
+__device__ __forceinline__ void bwd_block(const int32_t* __restrict__ plan, const PlanLayout& L, const BCell& C, int H,
+                                          int ld_h, int Rfeat, int row0, int nrows, int slice, float* lds,
+                                          float (&wr)[(PRE && !PERSIST) ? KREG : 1],
+                                          float (&wr2)[(PRE && !PERSIST) ? KREG : 1], const float* w_lds,
+                                          const GranCtx& G) {
+    const int H3 = 3 * H;
     float* g_s = lds;
     float* dgh_t = g_s + RB * H;
     float* dgi_t = dgh_t + H3 * RB;
@@ -267,30 +405,24 @@ __global__ void __launch_bounds__(ST) bwd_step_kernel(const int32_t* __restrict_
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NS = H / BJS;
-    const int slice = blockIdx.x % NS, gblk = blockIdx.x / NS;
-    int c = 0;
-    while (c + 1 < S.ncell && gblk >= S.blk_start[c + 1]) ++c;
-    const BCell& C = S.cell[c];
-    const int d = C.dir, od = 1 - d, R = C.mrel ? S.R : 0;
-    const int row0 = C.row_base + (gblk - S.blk_start[c]) * RB;
-    const int nrows = min(RB, C.row_end - row0);
+    const int d = C.dir, R = C.mrel ? Rfeat : 0;
     const int ul = lane & (BJS - 1);
     const int unit = slice * BJS + ul;
     const int kg = wave * (64 / BJS) + (lane / BJS);
     const int KQ = H3 / KG, k0 = kg * KQ;
     const int4* brec = reinterpret_cast<const int4*>(plan + L.brec[d]) + 4 * (int64_t)row0;
 
-    float wr[PRE ? KREG : 1], wr2[PRE ? KREG : 1];
     float pf[NI][7];
     if (PRE) {
-        const float* wp = C.whh + (int64_t)k0 * H + unit;
+        if (!PERSIST) {
+            const float* wp = C.whh + (int64_t)k0 * H + unit;
 #pragma unroll
-        for (int k = 0; k < KREG; ++k) wr[k] = k < KQ ? wp[(int64_t)k * H] : 0.f;
-        if (C.wih) {
-            const float* wq = C.wih + (int64_t)k0 * H + unit;
+            for (int k = 0; k < KREG; ++k) wr[k] = k < KQ ? wp[(int64_t)k * H] : 0.f;
+            if (C.wih) {
+                const float* wq = C.wih + (int64_t)k0 * H + unit;
 #pragma unroll
-            for (int k = 0; k < KREG; ++k) wr2[k] = k < KQ ? wq[(int64_t)k * H] : 0.f;
+                for (int k = 0; k < KREG; ++k) wr2[k] = k < KQ ? wq[(int64_t)k * H] : 0.f;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -309,7 +441,8 @@ __global__ void __launch_bounds__(ST) bwd_step_kernel(const int32_t* __restrict_
     }
 
     // ---- 1. pull: G_v = Gext_v + sum over successors, one wave per row
-    for (int r = wave; r < nrows; r += SW) pull_row(plan, L, C, brec + 4 * r, R, H, ld_h, g_s + r * H, lane, slice == 0);
+    for (int r = wave; r < nrows; r += SW)
+        pull_row<PERSIST>(plan, L, C, brec + 4 * r, R, H, ld_h, g_s + r * H, lane, slice == 0, G);
     __syncthreads();
 
     // ---- 2. GRU backward of the full rows (gates recomputed); operands of the products go to LDS k-major
@@ -320,12 +453,12 @@ __global__ void __launch_bounds__(ST) bwd_step_kernel(const int32_t* __restrict_
             const float rr = bsigm(gir + ghr);
             const float zz = bsigm(giz + ghz);
             const float nn = tanhf(gin + rr * ghn);
-            const float G = g_s[idx];
-            dn = G * (1.0f - zz) * (1.0f - nn * nn);          // d pre-activation of n
-            dz = G * (av - nn) * zz * (1.0f - zz);            // d pre-activation of z
+            const float Gv = g_s[idx];
+            dn = Gv * (1.0f - zz) * (1.0f - nn * nn);         // d pre-activation of n
+            dz = Gv * (av - nn) * zz * (1.0f - zz);           // d pre-activation of z
             dr = dn * ghn * rr * (1.0f - rr);                 // d pre-activation of r
             dnr = dn * rr;                                    // hidden-side n input sits behind r
-            zg = G * zz;                                      // direct path h' = n + z (a - n)
+            zg = Gv * zz;                                     // direct path h' = n + z (a - n)
             if (u / BJS == slice) {
                 const int v = brec[4 * r].x;
                 float* og = C.dgi + (int64_t)v * H3;
@@ -373,7 +506,16 @@ __global__ void __launch_bounds__(ST) bwd_step_kernel(const int32_t* __restrict_
             a[r4 + 2] = fmaf(wv, d4.z, a[r4 + 2]); a[r4 + 3] = fmaf(wv, d4.w, a[r4 + 3]);
         }
     };
-    if (PRE) {
+    if (PERSIST) {   // resident slices in LDS: [3H][16] per matrix (registers are needed by the polling loops)
+        const float* wl = w_lds + k0 * BJS + ul;
+#pragma unroll 8
+        for (int k = 0; k < KQ; ++k) fma_rows(acc, wl[k * BJS], dgh_t + (k0 + k) * RB);
+        if (C.wih) {
+            const float* wl2 = wl + H3 * BJS;
+#pragma unroll 8
+            for (int k = 0; k < KQ; ++k) fma_rows(acc2, wl2[k * BJS], dgi_t + (k0 + k) * RB);
+        }
+    } else if (PRE) {
 #pragma unroll
         for (int k = 0; k < KREG; ++k)
             if (k < KQ) fma_rows(acc, wr[k], dgh_t + (k0 + k) * RB);
@@ -408,8 +550,77 @@ __global__ void __launch_bounds__(ST) bwd_step_kernel(const int32_t* __restrict_
         float s = 0.f;
 #pragma unroll 8
         for (int w = 0; w < KG; ++w) s += red[((m * KG + w) * RB + r) * BJS + l];
-        if (m == 0) C.da[(int64_t)v * H + u] = g_s[r * H + u] + s;
-        else C.gext_lo[(int64_t)v * H + u] += s;   // this workgroup is the only writer of these 16 floats
+        if (m == 0) {
+            const float val = g_s[r * H + u] + s;
+            C.da[(int64_t)v * H + u] = val;
+            if (PERSIST) __hip_atomic_store(C.da_g + (int64_t)v * H + u, gran_pack(G.epoch, val), __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            C.gext_lo[(int64_t)v * H + u] += s;   // this workgroup is the only writer of these 16 floats
+            if (PERSIST) __hip_atomic_store(C.du_out + (int64_t)v * H + u, gran_pack(G.epoch, s), __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <int RB, bool PRE>
+__global__ void __launch_bounds__(ST) bwd_step_kernel(const int32_t* __restrict__ plan, PlanLayout L, BArgs S) {
+    extern __shared__ float lds[];
+    const int NS = S.H / BJS;
+    const int slice = blockIdx.x % NS, gblk = blockIdx.x / NS;
+    int c = 0;
+    while (c + 1 < S.ncell && gblk >= S.blk_start[c + 1]) ++c;
+    const BCell& C = S.cell[c];
+    const int row0 = C.row_base + (gblk - S.blk_start[c]) * RB;
+    float wr[PRE ? KREG : 1], wr2[PRE ? KREG : 1];
+    GranCtx G;
+    G.epoch = 0; G.err = nullptr;
+    bwd_block<RB, PRE, false>(plan, L, C, S.H, S.ld_h, S.R, row0, min(RB, C.row_end - row0), slice, lds, wr, wr2, nullptr, G);
+}
+
+// ---- persistent sweep over the thin head of the reverse order (the deepest layers come first): ONE launch walks
+// steps [s_begin, s_end).  Workgroup = (cell, 16-unit slice, replica) with its two [3H x 16] weight slices resident
+// in registers; the rows of a layer are spread over the replicas.  A row block starts as soon as the rows it pulls
+// are there: da rows and the upper stacked layer's du rows travel as {epoch, value} granules (common.h) - no
+// barrier between layers, bounded spins, nothing placement-dependent; the grid stays far below the CU count so
+// every workgroup is resident.  Same arithmetic, same order as the per-layer launches: bitwise the same result.
+struct BTailArgs {
+    BArgs S;
+    int nrep, s_begin, s_end, num_stacked;
+    unsigned epoch;
+    int* err;
+};
+
+__global__ void __launch_bounds__(ST) bwd_tail_kernel(const int32_t* __restrict__ plan, PlanLayout L, BTailArgs A) {
+    extern __shared__ float lds[];
+    constexpr int RB = 4;
+    const BArgs& S = A.S;
+    const int H = S.H, H3 = 3 * H, NS = H / BJS;
+    const int slice = blockIdx.x % NS;
+    const int rep = (blockIdx.x / NS) % A.nrep;
+    const BCell& C = S.cell[blockIdx.x / (NS * A.nrep)];
+    const int tid = threadIdx.x;
+    GranCtx G;
+    G.epoch = A.epoch; G.err = A.err;
+    // resident weight slices: [3H][16] of W_hh, then of W_ih, behind the operand buffers
+    float* w_lds = lds + (RB * H + 2 * H3 * RB + 2 * ST * RB);
+    for (int i = tid; i < H3 * BJS; i += ST) {
+        const int k = i / BJS, u = i - k * BJS;
+        w_lds[i] = C.whh[(int64_t)k * H + slice * BJS + u];
+        w_lds[H3 * BJS + i] = C.wih ? C.wih[(int64_t)k * H + slice * BJS + u] : 0.f;
+    }
+    __syncthreads();
+    float wr[1], wr2[1];
+    const int32_t* __restrict__ blptr = plan + L.blptr[C.dir];
+    for (int s = A.s_begin; s < A.s_end; ++s) {
+        const int t = C.T - 1 - (s - (A.num_stacked - 1 - C.stacked));   // the top stacked layer leads
+        if (t < 0 || t >= C.T) continue;
+        const int r0 = blptr[t], r1 = blptr[t + 1];
+        const int rbs = min(max((r1 - r0 + A.nrep - 1) / A.nrep, 1), RB);
+        for (int slot0 = r0 + rep * rbs; slot0 < r1; slot0 += A.nrep * rbs) {
+            bwd_block<RB, true, true>(plan, L, C, H, S.ld_h, S.R, slot0, min(rbs, r1 - slot0), slice, lds, wr, wr2, w_lds, G);
+            __syncthreads();   // LDS is reused by the next block
+        }
     }
 }
 
@@ -429,7 +640,9 @@ __global__ void __launch_bounds__(256) bwd_rows_kernel(const int32_t* __restrict
     const int4* rec = reinterpret_cast<const int4*>(plan + L.brec[C.dir]) + 4 * (int64_t)(C.row_base + row - S.blk_start[c]);
     float* grow = lds + wave * H;
     const int v = rec[0].x;
-    pull_row(plan, L, C, rec, R, H, S.ld_h, grow, lane, true);
+    GranCtx G;
+    G.epoch = 0; G.err = nullptr;
+    pull_row<false>(plan, L, C, rec, R, H, S.ld_h, grow, lane, true, G);
     const float4* gi = reinterpret_cast<const float4*>(C.gi + (int64_t)v * H3);
     const float4* gh = reinterpret_cast<const float4*>(C.gh + (int64_t)v * H3);
     float4* og = reinterpret_cast<float4*>(C.dgi + (int64_t)v * H3);
@@ -625,6 +838,11 @@ void fill_cells(BArgs& S, const dagnn_backward_args* a, const int* dirs, int ndi
             K.gext_lo = i > 0 ? (float*)a->cell[dirs[q]][i - 1].g_ext : nullptr;
             K.da = (float*)c.da; K.dgi = (float*)c.dgi; K.dgh = (float*)c.dgh; K.sig = (float*)c.sigma;
             K.mrel = (float*)c.edge_feat_grad;
+            K.da_g = (gran_t*)c.da_granules;
+            K.du_in = i + 1 < a->num_stacked ? (const gran_t*)c.du_granules : nullptr;
+            K.du_out = i > 0 ? (gran_t*)a->cell[dirs[q]][i - 1].du_granules : nullptr;
+            K.gext0 = i + 1 < a->num_stacked ? (const float*)c.g_ext_static : nullptr;
+            K.stacked = i; K.T = 0;
             K.dir = dirs[q]; K.row_base = 0; K.row_end = 0;
         }
 }
@@ -699,7 +917,43 @@ extern "C" int dagnn_backward_run(const dagnn_plan* pl, const dagnn_backward_arg
                             (int)mfma_lds_bytes(H)) != hipSuccess)
         return DAGNN_EHIP(hipGetLastError());
     const int nsteps = Tmax + Ls - 1;
-    for (int s = 0; s < nsteps; ++s) {
+    // ---- the thin head of the reverse order (deepest layers first) in ONE persistent launch: the prefix of steps in
+    // which no cell has more rows than its replicas cover in `tail_max_blocks` 4-row blocks
+    int s_first = 0;
+    {
+        const int nrep = a->tail_replicas;
+        bool ok = pre && nrep > 0 && a->epoch != 0 && a->tail_err && S.ncell * NS * nrep <= a->num_cus / 2;
+        for (int k = 0; k < S.ncell && ok; ++k)
+            ok = S.cell[k].da_g && (S.cell[k].stacked + 1 == Ls || (S.cell[k].du_in && S.cell[k].gext0));
+        if (ok) {
+            const int cap = 4 * nrep * (a->tail_max_blocks > 0 ? a->tail_max_blocks : 1);
+            int s_end = 0;
+            for (; s_end < nsteps; ++s_end) {
+                int mx = 0;
+                for (int q = 0; q < ndir; ++q)
+                    for (int i = 0; i < Ls; ++i) {
+                        const int d = dirs[q], t = num_layers[d] - 1 - (s_end - (Ls - 1 - i));
+                        if (t >= 0 && t < num_layers[d]) mx = mx > layer_ptr[d][t + 1] - layer_ptr[d][t] ? mx : layer_ptr[d][t + 1] - layer_ptr[d][t];
+                    }
+                if (mx > cap) break;
+            }
+            if (s_end >= 8) {   // worth a persistent launch
+                BTailArgs A;
+                A.S = S;
+                for (int k = 0; k < S.ncell; ++k) A.S.cell[k].T = num_layers[A.S.cell[k].dir];
+                A.nrep = nrep; A.s_begin = 0; A.s_end = s_end; A.num_stacked = Ls;
+                A.epoch = a->epoch; A.err = (int*)a->tail_err;
+                const size_t tail_lds = step_lds_bytes<4>(H) + (size_t)2 * 3 * H * BJS * sizeof(float);
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)tail_lds) != hipSuccess)
+                    return DAGNN_EHIP(hipGetLastError());
+                hipLaunchKernelGGL(bwd_tail_kernel, dim3((unsigned)(S.ncell * NS * nrep)), dim3(ST), tail_lds, st, plan, L, A);
+                DAGNN_CHECK_LAUNCH();
+                s_first = s_end;
+            }
+        }
+    }
+    for (int s = s_first; s < nsteps; ++s) {
         // stacked layer i handles layer t = T_d - 1 - (s - (Ls-1-i)): the top layer leads, every lower one is a launch behind
         auto layout = [&](int unit) {   // row ranges of the active cells; blk_start in blocks of `unit` rows
             int k = 0, tot = 0;

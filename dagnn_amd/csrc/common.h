@@ -82,3 +82,30 @@ __device__ __forceinline__ int wave_max_i(int v) {
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// ---- granules: the hand-off format inside the persistent tail kernel ---------------------------
+// Every state float (and partial score) also exists as an 8-byte {tag = epoch of this forward pass,
+// value} granule written by ONE aligned 8-byte store.  A consumer re-reads the granules it needs
+// with relaxed agent-scope loads (they bypass the non-coherent caches) until every tag matches:
+// the data is its own flag, there is no barrier, no fence and no dependence on placement
+// (cdna_hip_programming.md Guideline 16, form R2).  Old tags never equal the current epoch because
+// the buffers are zero-initialised once and the epoch only grows.
+typedef unsigned long long gran_t;
+static __device__ __forceinline__ gran_t gran_pack(unsigned epoch, float v) {
+    return ((gran_t)epoch << 32) | (gran_t)__float_as_uint(v);
+}
+static __device__ __forceinline__ gran_t gran_ld(const gran_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct GranCtx { unsigned epoch; int* err; };
+
+// bounded spin helper: returns false (and raises the error flag) when the budget is exhausted
+static __device__ __forceinline__ bool gran_retry(unsigned& spins, const GranCtx& G) {
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > (1u << 22)) {
+        __hip_atomic_store(G.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    }
+    return true;
+}
+

@@ -98,32 +98,6 @@ __device__ __forceinline__ float score_of(const float* __restrict__ hrow_tail, i
     return s;
 }
 
-// ---- granules: the hand-off format inside the persistent tail kernel ---------------------------
-// Every state float (and partial score) also exists as an 8-byte {tag = epoch of this forward pass,
-// value} granule written by ONE aligned 8-byte store.  A consumer re-reads the granules it needs
-// with relaxed agent-scope loads (they bypass the non-coherent caches) until every tag matches:
-// the data is its own flag, there is no barrier, no fence and no dependence on placement
-// (cdna_hip_programming.md Guideline 16, form R2).  Old tags never equal the current epoch because
-// the buffers are zero-initialised once and the epoch only grows.
-typedef unsigned long long gran_t;
-__device__ __forceinline__ gran_t gran_pack(unsigned epoch, float v) {
-    return ((gran_t)epoch << 32) | (gran_t)__float_as_uint(v);
-}
-__device__ __forceinline__ gran_t gran_ld(const gran_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-struct GranCtx { unsigned epoch; int* err; };
-
-// bounded spin helper: returns false (and raises the error flag) when the budget is exhausted
-__device__ __forceinline__ bool gran_retry(unsigned& spins, const GranCtx& G) {
-    __builtin_amdgcn_s_sleep(2);
-    if (++spins > (1u << 22)) {
-        __hip_atomic_store(G.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return false;
-    }
-    return true;
-}
-
 // One wave: float4 chunk `lane` of granule row `grow` (H <= 256: one chunk per lane), waiting for it.
 __device__ __forceinline__ float4 gran_row_chunk(const gran_t* grow, int lane, int H4, const GranCtx& G) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -60,6 +60,8 @@ TAIL_SLICE = int(__import__("os").environ.get("DAGNN_AMD_TAIL_SLICE", "32"))
 TAIL_REPLICAS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_REPLICAS", "4"))   # 0 = launch every layer
 TAIL_MAX_BLOCKS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_MAX_BLOCKS", "2"))
 BWD_THIN_WGS = int(__import__("os").environ.get("DAGNN_AMD_BWD_THIN_WGS", "0"))  # 0 = library default
+BWD_TAIL_REPLICAS = int(__import__("os").environ.get("DAGNN_AMD_BWD_TAIL_REPLICAS", "2"))  # 0 = launch every layer
+BWD_TAIL_MAX_BLOCKS = int(__import__("os").environ.get("DAGNN_AMD_BWD_TAIL_MAX_BLOCKS", "2"))
 DEBUG_TIMING: Optional[torch.Tensor] = None  # int64[8] device tensor: phase ticks of the deepest work item
 _NOSPAN = _NoSpan()
 
@@ -387,7 +389,8 @@ def readout_max_backward(plan: PlanHandle, h: torch.Tensor, direction: int, grad
                                                  grad_h.stride(0), _stream(h)), "dagnn_readout_max_backward")
 
 
-def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, h, gi0, g_ext):
+def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, h, gi0, g_ext,
+                   arena: Optional[GranuleArena] = None):
     """Reverse pass of the lock-step recurrence (csrc/backward.hip).  `h[d][i]` [N, frontier_ld(H)] are the
     forward state buffers, `gi0[d]` [N,3H] the input-side pre-activations of stacked layer 0, `g_ext[d][i]`
     [N,H] the gradients reaching the states from outside (modified: stacked layers below the top receive the
@@ -398,10 +401,20 @@ def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells,
     out = {}
     mask = 0
     f32 = dict(dtype=torch.float32, device=dev)
+    use_tail = arena is not None and BWD_TAIL_REPLICAS > 0 and H <= 256
+    gkeys = [("da", d, i) for d in dirs for i in range(L)] + [("du", d, i) for d in dirs for i in range(L - 1)]
+    gran, epoch, err = arena.get(gkeys, N, H, dev) if use_tail else ({}, 0, None)
+    keep = []
     for d in dirs:
         mask |= 1 << d
         for i in range(L):
             c, bc = cells[(d, i)], args.cell[d][i]
+            if use_tail:
+                bc.da_granules = gran[("da", d, i)].data_ptr()
+                if i + 1 < L:   # the sweep adds the upper layer's du into g_ext: keep what it was before
+                    static = g_ext[d][i].clone()
+                    keep.append(static)
+                    bc.du_granules, bc.g_ext_static = gran[("du", d, i)].data_ptr(), static.data_ptr()
             o = dict(a=torch.empty(N, H, **f32), alpha=torch.empty(max(E, 1), **f32), da=torch.empty(N, H, **f32),
                      dgi=torch.empty(N, 3 * H, **f32), dgh=torch.empty(N, 3 * H, **f32), sigma=torch.empty(N, **f32),
                      edge_feat_grad=torch.empty(N, R, **f32) if R > 0 else None)
@@ -414,6 +427,8 @@ def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells,
     args.num_stacked, args.dir_mask, args.H, args.ld_h = L, mask, H, h[dirs[0]][0].shape[1]
     args.num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
     args.thin_wgs = BWD_THIN_WGS
+    args.tail_replicas, args.tail_max_blocks = (BWD_TAIL_REPLICAS if use_tail else 0), BWD_TAIL_MAX_BLOCKS
+    args.epoch, args.tail_err = epoch, _ptr(err)
     lib = _lib.load()
     with _span("backward_prepare", plan.ws):
         check(lib.dagnn_backward_prepare(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_backward_prepare")

@@ -235,8 +235,8 @@ class DAGNN(nn.Module):
 
         return self._derived.setdefault(self.schedule, DerivedCache()).get(srcs, make)
 
-    def _arena_for(self, x):
-        return self._arenas.setdefault((x.device, torch.cuda.current_stream(x.device).cuda_stream),
+    def _arena_for(self, x, role="forward"):
+        return self._arenas.setdefault((role, x.device, torch.cuda.current_stream(x.device).cuda_stream),
                                        engine.GranuleArena())
 
     def _training_pass(self) -> bool:

@@ -264,6 +264,13 @@ typedef struct dagnn_backward_cell {
     float* dgh;             /* [N,3H] out */
     float* sigma;           /* [N] out */
     float* edge_feat_grad;  /* [N,num_edge_feats] out, or NULL without edge features */
+    /* persistent sweep (optional; all NULL = one launch per layer throughout): */
+    void* da_granules;      /* uint64 [N,H]: tagged copies {epoch, fp32 bits} of da rows (zero-initialised once,
+                             * strictly increasing epochs - the same contract as dagnn_frontier_cell.granules) */
+    void* du_granules;      /* uint64 [N,H]: the upper stacked layer's du for THIS cell's rows (stacked layers below
+                             * the top) */
+    const float* g_ext_static; /* [N,H] copy of g_ext taken before the sweep (stacked layers below the top): inside
+                             * the persistent launch a row's gradient is g_ext_static + its du granules */
 } dagnn_backward_cell;
 
 typedef struct dagnn_backward_args {
@@ -272,6 +279,11 @@ typedef struct dagnn_backward_args {
     int num_cus;
     int thin_wgs;   /* launches of up to this many slice workgroups use the register-resident slice kernel, bigger ones
                      * the rows + MFMA-tile kernels; 0 = default (2 * num_cus) */
+    /* persistent sweep over the thin head of the reverse order (needs the cells' granule buffers, H <= 256): */
+    int tail_replicas;   /* workgroups per (cell, 16-unit slice); 0 disables it */
+    int tail_max_blocks; /* a layer may have up to 4 * tail_replicas * tail_max_blocks rows per cell in it */
+    unsigned epoch;      /* tag of this backward pass in the granule buffers: nonzero, larger than any used before */
+    void* tail_err;      /* device int32: set to 1 if a bounded wait ever expires (results are then invalid) */
 } dagnn_backward_args;
 
 int dagnn_backward_prepare(const dagnn_plan* plan /* host */, const dagnn_backward_args* args /* host */, void* stream);

@@ -49,7 +49,7 @@ def main():
             rec_bytes += (2 * f_kib + w_kib) * 1024
     out = {
         "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over `python bench.py "
-                "--steps 2 --warmup 1 --cpu-passes 0 --no-kernel-timer` (%d forwards), lock-step schedule. Counter "
+                "--steps 2 --warmup 1 --cpu-passes 0 --no-kernel-timer` (%d forwards: the headline leg and the loader-side-plan leg), lock-step schedule. Counter "
                 "unit is KiB (calibrated: encode_ast_kernel WRITE_SIZE = N*H*4 bytes per launch). FETCH_SIZE is "
                 "doubled before use, as MI355X_MICROARCH.md (HBM section) prescribes for wide coalesced reads on "
                 "gfx950; WRITE_SIZE is used as reported. Produced by scripts/pmc_summary.py." % forwards,

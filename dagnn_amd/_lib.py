@@ -53,7 +53,8 @@ class FrontierArgs(C.Structure):
                 ("H", C.c_int), ("ld_h", C.c_int), ("vid_mod", C.c_int), ("num_cus", C.c_int), ("rb4_max_wgs", C.c_int), ("mfma_min_rows", C.c_int),
                 ("agg_scratch", C.c_void_p), ("agg_scratch_rows", C.c_int),
                 ("tail_replicas", C.c_int), ("tail_slice_units", C.c_int), ("tail_max_blocks", C.c_int), ("epoch", C.c_uint),
-                ("tail_err", C.c_void_p), ("debug_timing", C.c_void_p)]
+                ("tail_err", C.c_void_p), ("debug_timing", C.c_void_p), ("side_stream", C.c_void_p),
+                ("layer_split", C.POINTER(C.c_int32) * MAX_DIRS)]
 
 
 class BackwardCell(C.Structure):

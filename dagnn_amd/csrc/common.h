@@ -33,6 +33,10 @@ struct PlanLayout {
                                      //        pred[0..3], edge feats of the first 4 edges (2 floats each)}
     int64_t brec[2];                 // [16N] backward pass: per slot {node, succ CSR range, first 4 successors, their
                                      //        edge ids} (written by dagnn_backward_prepare)
+    int64_t blsplit[2];              // [N+2] per batch-level layer: first slot of the rows of DEEP graphs (depth > thr_d,
+                                     //        header word PH_THR0 + d); inside a layer the slots of the shallow graphs
+                                     //        come first.  Lets the dataflow kernel walk the deep graphs from layer 0
+                                     //        while the per-layer launches handle the shallow ones.
     int64_t total;                   // words
 };
 
@@ -55,6 +59,7 @@ __host__ __device__ inline PlanLayout dagnn_plan_layout_words(int64_t N, int64_t
     for (int d = 0; d < 2; ++d) L.cursor[d] = take(N + B);
     for (int d = 0; d < 2; ++d) L.eidx[d] = take(E);
     for (int d = 0; d < 2; ++d) L.blptr[d] = take(N + 2);
+    for (int d = 0; d < 2; ++d) L.blsplit[d] = take(N + 2);   // right behind blptr: one device->host read gets both
     for (int d = 0; d < 2; ++d) L.lbase[d] = take(N + B);
     for (int d = 0; d < 2; ++d) L.rowrec[d] = take(16 * N);
     for (int d = 0; d < 2; ++d) L.brec[d] = take(16 * N);
@@ -63,7 +68,12 @@ __host__ __device__ inline PlanLayout dagnn_plan_layout_words(int64_t N, int64_t
 }
 
 // Plan header words
-enum { PH_N = 0, PH_E = 1, PH_B = 2, PH_R = 3, PH_MAGIC = 4 };
+enum { PH_N = 0, PH_E = 1, PH_B = 2, PH_R = 3, PH_MAGIC = 4, PH_THR0 = 5, PH_THR1 = 6 };
+// A batch-level layer with more rows than this is "fat"; thr_d = 1 + the last fat layer of direction d
+// (0 if none): graphs deeper than thr_d are the DEEP graphs of direction d.  16 = the rows one pass of the
+// persistent kernel's replicas covers (4 replicas x 4-row blocks); measured best on the headline batch
+// (recurrence per forward with 8: 3.49 ms, 10: 3.34, 12: 3.17, 14: 3.12, 16: 3.12, 24: 3.99, 32: 4.29).
+#define DAGNN_PLAN_THIN_ROWS 16
 #define DAGNN_PLAN_MAGIC 0x44414731  // "DAG1"
 
 // ------------------------------------------------------------------ wave-level reductions

@@ -843,6 +843,7 @@ struct TailArgs {
     int stacked_idx[DAGNN_MAX_CELLS];  // i of each cell (layer processed at step s is s - i)
     int ncell, nrep, H, ld_h, R, vid_mod;
     int s_begin, s_end;                // steps [s_begin, s_end)
+    int use_split;                     // rows of a layer start at blsplit[t] (the deep graphs only) instead of blptr[t]
     unsigned epoch;
     int* err_flag;
     unsigned long long* dbg;
@@ -890,7 +891,7 @@ __global__ void __launch_bounds__(FT, 1) frontier_tail_kernel(const int32_t* __r
         if (prof) { stamp[0] = wall_clock64(); stamp[6] = gridDim.x; }
         const int t = s - si;
         if (t < 0 || t >= T) continue;
-        const int r0 = blptr[t], r1 = blptr[t + 1];
+        const int r0 = S.use_split ? plan[L.blsplit[d] + t] : blptr[t], r1 = blptr[t + 1];
         // rows of a thin layer are spread over the replicas (blocks of ceil(rows / nrep) <= RBT rows): a block's
         // latency grows with its live rows, and the layer is as slow as its slowest replica
         const int rbs = min(max((r1 - r0 + S.nrep - 1) / S.nrep, 1), RBT);
@@ -1011,7 +1012,12 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
     const int32_t* plan = (const int32_t*)pl->data;
     const int nsteps = Tmax + Ls - 1;
 
-    auto rows_of = [&](int d, int i, int s) {
+    // split mode (side stream + per-layer split pointers): the persistent kernel walks the DEEP graphs from layer 0
+    // on the side stream while the launches below handle the shallow graphs' rows [ptr[t], split[t]) - the two
+    // sets of graphs share nothing, so the deepest chains no longer wait behind the fat layers
+    bool split = a->side_stream != nullptr && a->debug_timing == nullptr;
+    for (int q = 0; q < ndir && split; ++q) split = a->layer_split[dirs[q]] != nullptr;
+    auto rows_all = [&](int d, int i, int s) {
         const int t = s - i;
         return (t < 0 || t >= num_layers[d]) ? 0 : layer_ptr[d][t + 1] - layer_ptr[d][t];
     };
@@ -1032,17 +1038,63 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         for (int s = nsteps - 1; s >= 0; --s) {
             int mx = 0;
             for (int q = 0; q < ndir; ++q)
-                for (int i = 0; i < Ls; ++i) mx = mx > rows_of(dirs[q], i, s) ? mx : rows_of(dirs[q], i, s);
+                for (int i = 0; i < Ls; ++i) mx = mx > rows_all(dirs[q], i, s) ? mx : rows_all(dirs[q], i, s);
             if (mx > cap) { s_tail = s + 1; break; }
         }
         if (nsteps - s_tail < 8) s_tail = nsteps;  // not worth a second kernel
+    }
+    split = split && tail_ok && s_tail < nsteps;
+    auto row_lo = [&](int d, int t) { return layer_ptr[d][t]; };
+    auto row_hi = [&](int d, int t) { return split ? a->layer_split[d][t] : layer_ptr[d][t + 1]; };
+    auto rows_of = [&](int d, int i, int s) {
+        const int t = s - i;
+        return (t < 0 || t >= num_layers[d]) ? 0 : row_hi(d, t) - row_lo(d, t);
+    };
+    const int s_eager = split ? nsteps : s_tail;   // split mode: every step that still has shallow rows
+
+    // ---- the persistent dataflow kernel (launched first in split mode, after the per-layer launches otherwise)
+    auto launch_tail = [&](hipStream_t ts, int s_begin) -> int {
+        TailArgs T;
+        int nc = 0;
+        for (int q = 0; q < ndir; ++q)
+            for (int i = 0; i < Ls; ++i) {
+                fill_cell(T.cell[nc], a, pl, dirs[q], i, tail_js);
+                T.stacked_idx[nc++] = i;
+            }
+        T.ncell = nc; T.nrep = nrep; T.H = H; T.ld_h = a->ld_h; T.R = pl->num_edge_feats;
+        T.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
+        T.s_begin = s_begin; T.s_end = nsteps;
+        T.use_split = split ? 1 : 0;
+        T.epoch = a->epoch;
+        T.err_flag = (int*)a->tail_err;
+        T.dbg = (unsigned long long*)a->debug_timing;
+        const int op_ld = H + 64;
+        const size_t lds = (size_t)(2 * tail_rb * op_ld + 2 * tail_rb * 3 * tail_js) * sizeof(float) + tail_rb * sizeof(int);
+        if (tail_js == 16)
+            hipLaunchKernelGGL((frontier_tail_kernel<16, 4, 16>), dim3((unsigned)tail_wgs), dim3(FT), lds, ts, plan, L, T);
+        else
+            hipLaunchKernelGGL((frontier_tail_kernel<32, 4, 16>), dim3((unsigned)tail_wgs), dim3(FT), lds, ts, plan, L, T);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? DAGNN_OK : DAGNN_EHIP(e);
+    };
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (split) {
+        hipStream_t side = (hipStream_t)a->side_stream;
+        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
+            return DAGNN_EHIP(hipGetLastError());
+        hipEventRecord(ev_fork, st);
+        hipStreamWaitEvent(side, ev_fork, 0);
+        const int rc = launch_tail(side, 0);
+        hipEventRecord(ev_join, side);
+        if (rc != DAGNN_OK) { hipEventDestroy(ev_fork); hipEventDestroy(ev_join); return rc; }
     }
 
     StepArgs S;
     S.H = H; S.ld_h = a->ld_h; S.R = pl->num_edge_feats; S.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
     S.dbg = (unsigned long long*)a->debug_timing;
     S.epoch = a->epoch;
-    for (int s = 0; s < s_tail; ++s) {
+    for (int s = 0; s < s_eager; ++s) {
         // geometry of this launch: thin launches use 16-unit slices (and 4-row blocks when that
         // still fits one round of workgroups), fat ones 32-unit slices, 8-row blocks, 2 per CU
         int rows_total = 0, blocks8 = 0, blocks4 = 0;
@@ -1070,7 +1122,8 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
                 if (n <= 0) continue;
                 Cell& K = S.cell[nc];
                 fill_cell(K, a, pl, d, i, js);
-                K.row_base = layer_ptr[d][s - i]; K.row_end = K.row_base + n; K.has_pred = (s - i) > 0;
+                K.row_base = row_lo(d, s - i); K.row_end = K.row_base + n; K.has_pred = (s - i) > 0;
+                if (split) K.g_out = nullptr;   // nothing of the shallow graphs is read through granules
                 blocks += (n + rb - 1) / rb;
                 S.blk_start[++nc] = blocks;
             }
@@ -1115,28 +1168,13 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         else e = launch_step<16, 8, 16, 1>(blocks, H, st, plan, L, S);
         if (e != hipSuccess) return DAGNN_EHIP(e);
     }
-    if (s_tail < nsteps) {
-        TailArgs T;
-        int nc = 0;
-        for (int q = 0; q < ndir; ++q)
-            for (int i = 0; i < Ls; ++i) {
-                fill_cell(T.cell[nc], a, pl, dirs[q], i, tail_js);
-                T.stacked_idx[nc++] = i;
-            }
-        T.ncell = nc; T.nrep = nrep; T.H = H; T.ld_h = a->ld_h; T.R = pl->num_edge_feats;
-        T.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
-        T.s_begin = s_tail; T.s_end = nsteps;
-        T.epoch = a->epoch;
-        T.err_flag = (int*)a->tail_err;
-        T.dbg = (unsigned long long*)a->debug_timing;
-        const int op_ld = H + 64;
-        const size_t lds = (size_t)(2 * tail_rb * op_ld + 2 * tail_rb * 3 * tail_js) * sizeof(float) + tail_rb * sizeof(int);
-        if (tail_js == 16)
-            hipLaunchKernelGGL((frontier_tail_kernel<16, 4, 16>), dim3((unsigned)tail_wgs), dim3(FT), lds, st, plan, L, T);
-        else
-            hipLaunchKernelGGL((frontier_tail_kernel<32, 4, 16>), dim3((unsigned)tail_wgs), dim3(FT), lds, st, plan, L, T);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return DAGNN_EHIP(e);
+    if (split) {   // join: the caller's stream continues only when the deep graphs are finished too
+        hipStreamWaitEvent(st, ev_join, 0);
+        hipEventDestroy(ev_fork);   // destruction is deferred by the runtime until the recorded work has completed
+        hipEventDestroy(ev_join);
+    } else if (s_tail < nsteps) {
+        const int rc = launch_tail(st, s_tail);
+        if (rc != DAGNN_OK) return rc;
     }
     return DAGNN_OK;
 }

@@ -45,7 +45,7 @@ __global__ void plan_ptr_kernel(int32_t* plan, PlanLayout L, const int64_t* __re
         }
         plan[L.edge_ptr + i] = (int32_t)lo;
     }
-    if (i < N + 2) { plan[L.blptr[0] + i] = 0; plan[L.blptr[1] + i] = 0; }
+    if (i < N + 2) { plan[L.blptr[0] + i] = 0; plan[L.blptr[1] + i] = 0; plan[L.blsplit[0] + i] = 0; plan[L.blsplit[1] + i] = 0; }
     int bad = 0;
     if (i > 0 && i < N && batch[i] < batch[i - 1]) bad |= 4;
     if (i < N && (batch[i] < 0 || batch[i] >= B)) bad |= 4;
@@ -270,9 +270,21 @@ __global__ void __launch_bounds__(1024) plan_blptr_kernel(int32_t* plan, PlanLay
         __syncthreads();
     }
     if (tid == 0) a[N + 1] = T;
+    // thr_d = 1 + last layer with more than DAGNN_PLAN_THIN_ROWS rows (the scan above is complete: width = a[t+1] - a[t])
+    __shared__ int32_t s_thr;
+    if (tid == 0) s_thr = 0;
+    __syncthreads();
+    int thr = 0;
+    for (int t = tid; t < T; t += 1024)
+        if (a[t + 1] - a[t] > DAGNN_PLAN_THIN_ROWS) thr = t + 1;
+    thr = wave_max_i(thr);
+    if ((tid & 63) == 0) atomicMax(&s_thr, thr);
+    __syncthreads();
+    if (tid == 0) plan[PH_THR0 + d] = s_thr;
 }
 
-// lbase[g][t] = blptr[t] + rows of layer t in graphs before g (deterministic slot assignment).
+// lbase[g][t] = blptr[t] + rows of layer t in graphs ordered before g - shallow graphs first, then deep ones, each
+// group in graph order (deterministic slot assignment); blsplit[t] = first slot of the deep group.
 // One WAVE per batch-level layer: lane l takes graphs l, l+64, ...; an exclusive wave scan over the
 // per-graph row counts gives every graph its first slot (two memory round trips per 64 graphs).
 __global__ void __launch_bounds__(256) plan_lbase_kernel(int32_t* plan, PlanLayout L, int N, int B) {
@@ -285,21 +297,25 @@ __global__ void __launch_bounds__(256) plan_lbase_kernel(int32_t* plan, PlanLayo
     const int32_t* __restrict__ node_ptr = plan + L.node_ptr;
     const int32_t* __restrict__ depth = plan + L.depth[d];
     int32_t* __restrict__ lb = plan + L.lbase[d];
+    const int thr = plan[PH_THR0 + d];
     int carry = plan[L.blptr[d] + t];
-    for (int g0 = 0; g0 < B; g0 += 64) {
-        const int g = g0 + lane;
-        int cnt = 0, base = 0;
-        bool has = false;
-        if (g < B && t < depth[g]) {
-            base = node_ptr[g] + g + t;
-            cnt = ls[base + 1] - ls[base];
-            has = true;
-        }
-        int x = cnt;  // inclusive wave scan
+    for (int pass = 0; pass < 2; ++pass) {   // shallow graphs first, then the deep ones (depth > thr)
+        if (pass == 1 && lane == 0) plan[L.blsplit[d] + t] = carry;
+        for (int g0 = 0; g0 < B; g0 += 64) {
+            const int g = g0 + lane;
+            int cnt = 0, base = 0;
+            bool has = false;
+            if (g < B && t < depth[g] && (depth[g] > thr) == (pass == 1)) {
+                base = node_ptr[g] + g + t;
+                cnt = ls[base + 1] - ls[base];
+                has = true;
+            }
+            int x = cnt;  // inclusive wave scan
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-        if (has) lb[base] = carry + x - cnt;
-        carry += __shfl(x, 63, 64);
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+            if (has) lb[base] = carry + x - cnt;
+            carry += __shfl(x, 63, 64);
+        }
     }
 }
 
@@ -352,11 +368,11 @@ extern "C" size_t dagnn_plan_bytes(int64_t N, int64_t E, int64_t B, int num_edge
 extern "C" int dagnn_plan_layout(int64_t N, int64_t E, int64_t B, int R, int64_t* o) {
     if (!o) return DAGNN_EINVAL;
     PlanLayout L = dagnn_plan_layout_words(N, E, B, R);
-    int64_t w[24] = {L.node_ptr, L.edge_ptr, L.depth[0], L.depth[1], L.order[0], L.order[1], L.lstart[0],
+    int64_t w[26] = {L.node_ptr, L.edge_ptr, L.depth[0], L.depth[1], L.order[0], L.order[1], L.lstart[0],
                      L.lstart[1], L.rowptr[0], L.rowptr[1], L.col[0], L.col[1], L.eattr[0], L.eattr[1],
                      L.items, L.total, L.blptr[0], L.blptr[1], L.rowrec[0], L.rowrec[1],
-                     L.pos[0], L.pos[1], L.eidx[0], L.eidx[1]};
-    for (int i = 0; i < 24; ++i) o[i] = w[i] * 4;
+                     L.pos[0], L.pos[1], L.eidx[0], L.eidx[1], L.blsplit[0], L.blsplit[1]};
+    for (int i = 0; i < 26; ++i) o[i] = w[i] * 4;
     return DAGNN_OK;
 }
 

@@ -59,6 +59,7 @@ AGG_SPLIT = int(__import__("os").environ.get("DAGNN_AMD_AGG_SPLIT", "0"))
 TAIL_SLICE = int(__import__("os").environ.get("DAGNN_AMD_TAIL_SLICE", "32"))
 TAIL_REPLICAS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_REPLICAS", "4"))   # 0 = launch every layer
 TAIL_MAX_BLOCKS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_MAX_BLOCKS", "2"))
+SPLIT_DEEP = int(__import__("os").environ.get("DAGNN_AMD_SPLIT_DEEP", "1"))  # 1: deep graphs on a side stream from layer 0
 BWD_THIN_WGS = int(__import__("os").environ.get("DAGNN_AMD_BWD_THIN_WGS", "0"))  # 0 = library default
 BWD_TAIL_REPLICAS = int(__import__("os").environ.get("DAGNN_AMD_BWD_TAIL_REPLICAS", "2"))  # 0 = launch every layer
 BWD_TAIL_MAX_BLOCKS = int(__import__("os").environ.get("DAGNN_AMD_BWD_TAIL_MAX_BLOCKS", "2"))
@@ -128,14 +129,15 @@ class PlanHandle(object):
         self.status = torch.zeros(4, dtype=torch.int32, device=ws.device)
         self.desc = Plan(ws.data_ptr(), nbytes, self.N, self.E, self.B, self.R)
         self._schedule = [a for a in meta["schedule"]]
+        self._splits = [a for a in meta["splits"]]
         return self
 
     def layout(self) -> dict:
-        off = (C.c_int64 * 24)()
+        off = (C.c_int64 * 26)()
         check(_lib.load().dagnn_plan_layout(self.N, self.E, self.B, self.R, off), "dagnn_plan_layout")
         names = ["node_ptr", "edge_ptr", "depth0", "depth1", "order0", "order1", "lstart0", "lstart1", "rowptr0",
                  "rowptr1", "col0", "col1", "eattr0", "eattr1", "items", "total", "blptr0", "blptr1", "rowrec0",
-                 "rowrec1", "slot0", "slot1", "eidx0", "eidx1"]
+                 "rowrec1", "slot0", "slot1", "eidx0", "eidx1", "blsplit0", "blsplit1"]
         return {k: int(v) // 4 for k, v in zip(names, off)}
 
     def read_schedule(self):
@@ -144,14 +146,21 @@ class PlanHandle(object):
         ptr_d has T_d + 1 entries."""
         if getattr(self, "_schedule", None) is None:
             lay = self.layout()
-            a, b = lay["blptr0"], lay["blptr1"]
-            host = self.ws[a:b + self.N + 2].cpu().numpy()
-            out = []
-            for off in (0, b - a):
+            a, b, c, e = lay["blptr0"], lay["blptr1"], lay["blsplit0"], lay["blsplit1"]
+            host = self.ws[a:e + self.N + 2].cpu().numpy()   # blptr0 .. blsplit1 in one copy
+            out, spl = [], []
+            for off, soff in ((0, c - a), (b - a, e - a)):
                 T = int(host[off + self.N + 1])
                 out.append(host[off:off + T + 1].copy())
-            self._schedule = out
+                spl.append(host[soff:soff + T].copy())
+            self._schedule, self._splits = out, spl
         return self._schedule
+
+    def read_splits(self):
+        """Per direction, per batch-level layer: first slot of the deep graphs' rows (see include/dagnn_hip.h);
+        comes with the same device->host read as the schedule."""
+        self.read_schedule()
+        return self._splits
 
     def check_status(self) -> None:
         """Debug helper (synchronises): raises if the batch violated the layout contract."""
@@ -267,6 +276,7 @@ class GranuleArena(object):
         self.gld = 0
         self.epoch = 0
         self.err = None
+        self.side = None   # second stream: the persistent kernel runs next to the per-layer launches (split mode)
 
     def get(self, keys, N: int, gld: int, device):
         if N > self.cap or gld != self.gld or self.err is None or self.err.device != device or \
@@ -276,6 +286,13 @@ class GranuleArena(object):
             self.err = torch.zeros(1, dtype=torch.int32, device=device)
         self.epoch += 1
         return self.bufs, self.epoch, self.err
+
+    def side_stream(self, device):
+        """Second stream for the split mode (created once): the persistent kernel runs on it next to the per-layer
+        launches of the caller's stream."""
+        if self.side is None or self.side.device != device:
+            self.side = torch.cuda.Stream(device)
+        return self.side
 
     def check(self) -> None:
         """Debug helper (synchronises): raises if a bounded wait in the tail kernel expired."""
@@ -338,6 +355,11 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     for d in (0, 1):
         ptrs[d] = sched[d].ctypes.data_as(C.POINTER(C.c_int32))
         nl[d] = len(sched[d]) - 1
+    if use_tail and SPLIT_DEEP and DEBUG_TIMING is None:
+        splits = plan.read_splits()
+        args.side_stream = arena.side_stream(plan.ws.device).cuda_stream
+        for d in dirs:
+            args.layer_split[d] = splits[d].ctypes.data_as(C.POINTER(C.c_int32))
     with _span("frontier_run", plan.ws):
         check(_lib.load().dagnn_frontier_run(C.byref(plan.desc), C.byref(args), ptrs, nl, _stream(plan.ws)),
               "dagnn_frontier_run")

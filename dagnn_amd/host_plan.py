@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 PLAN_MAGIC = 0x44414731  # "DAG1", csrc/common.h
+THIN_ROWS = 16            # DAGNN_PLAN_THIN_ROWS, csrc/common.h
 
 
 def _align4(w: int) -> int:
@@ -44,8 +45,8 @@ def plan_layout(N: int, E: int, B: int, R: int) -> Dict[str, int]:
         for d in (0, 1):
             take("%s%d" % (name, d), n)
     take("items", 2 * B)
-    for name, n in (("slot", N), ("cursor", N + B), ("eidx", E), ("blptr", N + 2), ("lbase", N + B),
-                    ("rowrec", 16 * N), ("brec", 16 * N)):
+    for name, n in (("slot", N), ("cursor", N + B), ("eidx", E), ("blptr", N + 2), ("blsplit", N + 2),
+                    ("lbase", N + B), ("rowrec", 16 * N), ("brec", 16 * N)):
         for d in (0, 1):
             take("%s%d" % (name, d), n)
     L["total"] = o
@@ -58,11 +59,12 @@ def _np(t) -> np.ndarray:
 
 def build_plan_host(edge_index, layer_fwd, layer_bwd, batch, num_graphs: int, edge_attr=None,
                     return_written: bool = False):
-    """-> (plan words int32 [total], [layer offsets of direction 0, of direction 1] as int32 arrays).
+    """-> (plan words int32 [total], [layer offsets of direction 0, of direction 1], [first deep slot of every
+    layer of direction 0, of direction 1]) - the last two as int32 arrays, what `PlanHandle.read_schedule` reads back.
 
     Raises ValueError where the device build would flag `status` (unsorted batch vector, edges not grouped
     by graph or crossing graphs).  With `return_written` a bool mask of the words this function defines is
-    returned as a third value (the device leaves the others uninitialised)."""
+    returned as a fourth value (the device leaves the others uninitialised)."""
     ei = _np(edge_index).astype(np.int64).reshape(2, -1)
     batch = _np(batch).astype(np.int64).reshape(-1)
     layers = [_np(layer_fwd).astype(np.int64).reshape(-1), _np(layer_bwd).astype(np.int64).reshape(-1)]
@@ -102,6 +104,7 @@ def build_plan_host(edge_index, layer_fwd, layer_bwd, batch, num_graphs: int, ed
     n_of = np.diff(node_ptr)
     ids = np.arange(N)
     sched: List[np.ndarray] = []
+    splits: List[np.ndarray] = []
     depths = []
     for d in (0, 1):
         layer = np.clip(layers[d], 0, np.maximum(n_of[batch] - 1, 0)) if N else layers[d]
@@ -147,18 +150,30 @@ def build_plan_host(edge_index, layer_fwd, layer_bwd, batch, num_graphs: int, ed
         bl[N + 1] = T
         put("blptr%d" % d, bl)
         sched.append(bl[:T + 1].astype(np.int32))
-        # slots: nodes ordered by (layer, graph, id); lbase = first slot of every (graph, layer)
-        by_layer = np.argsort(layer, kind="stable")
+        # deep graphs of this direction: deeper than thr = 1 + the last layer with more than THIN_ROWS rows
+        fat = np.flatnonzero(width[:T] > THIN_ROWS)
+        thr = int(fat[-1]) + 1 if fat.size else 0
+        ws[5 + d] = thr
+        if written is not None:
+            written[5 + d] = True
+        deep = depth > thr
+        # slots: nodes ordered by (layer, shallow before deep, graph, id); lbase = first slot of every (graph, layer)
+        by_layer = np.lexsort((ids, deep[batch], layer)) if N else ids
         slot = np.empty(N, dtype=np.int64)
         slot[by_layer] = ids
         put("slot%d" % d, slot)
+        split = np.zeros(N + 2, dtype=np.int64)
+        if N:
+            split[:T] = bl[:T] + np.bincount(layer[~deep[batch]], minlength=T)[:T]
+        put("blsplit%d" % d, split)
+        splits.append(split[:T].astype(np.int32))
         g2 = np.repeat(np.arange(B), depth)
         t2 = np.arange(g2.shape[0]) - np.repeat(np.cumsum(depth) - depth, depth)
         base2 = node_ptr[g2] + g2 + t2
         ls_full = np.zeros(N + B + 1, dtype=np.int64)
         ls_full[ls_idx] = ls_val
         cnt2 = ls_full[base2 + 1] - ls_full[base2]
-        by_tg = np.lexsort((g2, t2))
+        by_tg = np.lexsort((g2, deep[g2], t2))
         c = cnt2[by_tg]
         lb = np.empty(g2.shape[0], dtype=np.int64)
         lb[by_tg] = np.cumsum(c) - c
@@ -187,8 +202,8 @@ def build_plan_host(edge_index, layer_fwd, layer_bwd, batch, num_graphs: int, ed
     key = np.stack(depths, 1).reshape(-1) if B else np.zeros(0, dtype=np.int64)
     put("items", np.argsort(-key, kind="stable"))
     if return_written:
-        return ws, sched, written
-    return ws, sched
+        return ws, sched, splits, written
+    return ws, sched, splits
 
 
 def attach_plan(batch, num_graphs: Optional[int] = None):
@@ -196,9 +211,9 @@ def attach_plan(batch, num_graphs: Optional[int] = None):
     `batch.to(device)`; `_dagnn_plan_meta`: sizes + the host schedule).  `DAGNN.forward` uses it when present."""
     B = int(num_graphs if num_graphs is not None else getattr(batch, "num_graphs", int(batch.batch[-1]) + 1))
     ea = getattr(batch, "edge_attr", None)
-    ws, sched = build_plan_host(batch.edge_index, batch._bi_layer_idx0, batch._bi_layer_idx1, batch.batch, B, ea)
+    ws, sched, splits = build_plan_host(batch.edge_index, batch._bi_layer_idx0, batch._bi_layer_idx1, batch.batch, B, ea)
     batch._dagnn_plan = torch.from_numpy(ws)
     batch._dagnn_plan_meta = dict(N=int(batch.batch.shape[0]), E=int(batch.edge_index.shape[1]), B=B,
                                   R=0 if ea is None else int(ea.reshape(batch.edge_index.shape[1], -1).shape[1]),
-                                  schedule=sched)
+                                  schedule=sched, splits=splits)
     return batch

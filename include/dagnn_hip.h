@@ -211,6 +211,13 @@ typedef struct dagnn_frontier_args {
     unsigned epoch;      /* tag of this forward pass in the granule buffers: nonzero, larger than any used before */
     void* tail_err;      /* device int32: set to 1 if a bounded wait in the tail kernel ever expires */
     void* debug_timing; /* NULL, or (T+L-1)*8 uint64 device words: 100 MHz stamps of workgroup 0 per launch */
+    /* split mode (optional): with a second stream and the plan's per-layer split pointers (blsplit_d, read back with
+     * the schedule) the persistent kernel walks the DEEP graphs (depth > thr_d) from layer 0 on `side_stream`,
+     * concurrently with the per-layer launches, which then only cover the shallow graphs.  The call forks from and
+     * joins back into `stream` with events (capturable); results are identical.  (CU-masked streams for the two
+     * halves were measured and dropped: masked queues slowed every other launch of the process.) */
+    void* side_stream;                              /* hipStream_t or NULL: runs the persistent kernel */
+    const int32_t* layer_split[DAGNN_MAX_DIRS];     /* HOST, num_layers[d] int32: first deep slot of every layer, or NULL */
 } dagnn_frontier_args;
 
 /* layer_ptr[d] (HOST, num_layers[d] + 1 int32): row offsets of the batch-level layers of direction
@@ -311,12 +318,15 @@ int dagnn_topo_layers(const int64_t* edge_index /* [2,E] */, const int64_t* batc
                       void* stream);
 
 /* Introspection (tests, and the host-side read-back of the lock-step schedule): byte offsets of the
- * plan's arrays from `plan->data`, into a host array of 24 entries: [node_ptr, edge_ptr, depth0,
+ * plan's arrays from `plan->data`, into a host array of 26 entries: [node_ptr, edge_ptr, depth0,
  * depth1, order0, order1, lstart0, lstart1, rowptr0, rowptr1, col0, col1, eattr0, eattr1, items,
- * total, blptr0, blptr1, rowrec0, rowrec1, slot0, slot1, eidx0, eidx1].  slot_d [N]: rowrec slot of
- * every node; eidx_d [E]: original edge id (column of edge_index) of every CSR slot.  blptr_d holds N+2 int32: the offsets of the
+ * total, blptr0, blptr1, rowrec0, rowrec1, slot0, slot1, eidx0, eidx1, blsplit0, blsplit1].  slot_d [N]: rowrec
+ * slot of every node; eidx_d [E]: original edge id (column of edge_index) of every CSR slot; blsplit_d [N+2]: per
+ * batch-level layer the first slot of the rows of the DEEP graphs of direction d (depth > thr_d, int32 header word
+ * 5 + d of the plan; thr_d = 1 + the last layer with more than 32 rows) - inside a layer the shallow graphs' rows
+ * come first.  blptr_d holds N+2 int32: the offsets of the
  * batch-level topological layers of direction d (entries 0..T_d) and T_d itself at index N+1. */
-int dagnn_plan_layout(int64_t N, int64_t E, int64_t B, int num_edge_feats, int64_t* offsets24 /* host */);
+int dagnn_plan_layout(int64_t N, int64_t E, int64_t B, int num_edge_feats, int64_t* offsets26 /* host */);
 
 #ifdef __cplusplus
 }

@@ -36,7 +36,7 @@ def test_host_only_entry_points_without_gpu():
     lib = _lib.load()
     n = lib.dagnn_plan_bytes(16561, 25377, 128, 2)
     assert n > 0 and n % 4 == 0
-    off = (ctypes.c_int64 * 24)()
+    off = (ctypes.c_int64 * 26)()
     assert lib.dagnn_plan_layout(16561, 25377, 128, 2, off) == 0
     offs = list(off)
     assert offs[15] == n and all(a < b for a, b in zip(offs[:14], offs[1:15])) and all(o < n for o in offs[16:])
@@ -199,7 +199,7 @@ def test_host_plan_layout_matches_library():
              "rowptr1", "col0", "col1", "eattr0", "eattr1", "items", "total", "blptr0", "blptr1", "rowrec0",
              "rowrec1", "slot0", "slot1", "eidx0", "eidx1"]
     for N, E, B, R in ((16561, 25377, 128, 2), (7, 0, 3, 0), (512, 723, 64, 1), (0, 0, 0, 2)):
-        off = (ctypes.c_int64 * 24)()
+        off = (ctypes.c_int64 * 26)()
         assert lib.dagnn_plan_layout(N, E, B, R, off) == 0
         lay = host_plan.plan_layout(N, E, B, R)
         assert {k: lay[k] for k in names} == {k: int(v) // 4 for k, v in zip(names, off)}
@@ -208,9 +208,9 @@ def test_host_plan_layout_matches_library():
 
 def test_host_plan_against_brute_force():
     from dagnn_amd import host_plan, synth
-    b = synth.code2_batch(3, 9, 25)
-    B, N, E = 9, b.x.shape[0], b.edge_index.shape[1]
-    ws, sched = host_plan.build_plan_host(b.edge_index, b._bi_layer_idx0, b._bi_layer_idx1, b.batch, B, b.edge_attr)
+    b = synth.code2_batch(3, 40, 40)   # wide enough for fat layers: shallow and deep graphs both exist
+    B, N, E = 40, b.x.shape[0], b.edge_index.shape[1]
+    ws, sched, splits = host_plan.build_plan_host(b.edge_index, b._bi_layer_idx0, b._bi_layer_idx1, b.batch, B, b.edge_attr)
     lay = host_plan.plan_layout(N, E, B, 2)
     ei, gid = b.edge_index.numpy(), b.batch.numpy()
     for d in (0, 1):
@@ -223,9 +223,20 @@ def test_host_plan_against_brute_force():
         eidx = ws[lay["eidx%d" % d]:lay["eidx%d" % d] + E]
         eattr = ws[lay["eattr%d" % d]:lay["eattr%d" % d] + 2 * E].view(np.float32).reshape(E, 2)
         feed, other = ei[1 - d], ei[d]
+        thr = int(ws[5 + d])
+        width = np.bincount(layer, minlength=T)
+        fat = width > host_plan.THIN_ROWS
+        assert thr == (np.flatnonzero(fat).max() + 1 if fat.any() else 0)
+        depth_g = np.array([layer[gid == g].max() + 1 for g in range(B)])
+        sp = ws[lay["blsplit%d" % d]:lay["blsplit%d" % d] + T]
+        assert np.array_equal(sp, splits[d])
         for t in range(T):
             nodes = rec[bl[t]:bl[t + 1], 0]
-            assert np.array_equal(nodes, np.flatnonzero(layer == t))   # (graph, id) order inside a layer
+            members = np.flatnonzero(layer == t)
+            deep = depth_g[gid[members]] > thr
+            # inside a layer: the shallow graphs' rows, then the deep graphs' rows, each in (graph, id) order
+            assert np.array_equal(nodes, np.concatenate([members[~deep], members[deep]]))
+            assert sp[t] == bl[t] + (~deep).sum()
         for v, eb, ee, g in rec[:, :4]:
             e_ids = np.flatnonzero(feed == v)
             assert g == gid[v] and np.array_equal(eidx[eb:ee], e_ids) and np.array_equal(col[eb:ee], other[e_ids])

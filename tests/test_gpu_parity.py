@@ -446,7 +446,7 @@ def test_host_plan_equals_device_plan_word_for_word(device, seed, B, mean_n):
                              b.batch.to(device), B, b.edge_attr.to(device))
     torch.cuda.synchronize()
     dev_words = plan.ws.cpu().numpy()
-    ws, sched, written = host_plan.build_plan_host(b.edge_index, b._bi_layer_idx0, b._bi_layer_idx1, b.batch, B,
+    ws, sched, splits, written = host_plan.build_plan_host(b.edge_index, b._bi_layer_idx0, b._bi_layer_idx1, b.batch, B,
                                                    b.edge_attr, return_written=True)
     assert ws.shape == dev_words.shape
     assert written.sum() > 0.5 * ws.shape[0] - 32 * b.x.shape[0]

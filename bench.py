@@ -298,9 +298,10 @@ def main():
                     traffic = json.load(open(tpath)).get("recurrence_hbm_bytes_per_forward")
                 result["roofline"] = {
                     "kernel": ("recurrence = aggregate_rows_kernel + frontier_mfma_kernel (fat topological layers, "
-                               "32-row MFMA tiles) + frontier_step_kernel (one launch per mid layer) + "
-                               "frontier_tail_kernel (one persistent dataflow launch for the thin tail), all "
-                               "(direction, stacked layer) cells; figures are per forward(G)") if lock else
+                               "32-row MFMA tiles) + frontier_step_kernel (one launch per mid / thin layer) for the "
+                               "shallow graphs, overlapped with frontier_tail_kernel (one persistent dataflow launch "
+                               "walking the deep graphs through all layers on a side stream), all (direction, stacked "
+                               "layer) cells; figures are per forward(G)") if lock else
                               ("recurrence_kernel<KSL> (dagnn_recurrence_layer): %d launches per forward, one per "
                                "stacked GRU layer, persistent per-(graph, direction) workgroups" % L),
                     "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",

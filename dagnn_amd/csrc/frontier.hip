@@ -1078,7 +1078,18 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         return e == hipSuccess ? DAGNN_OK : DAGNN_EHIP(e);
     };
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    if (split) {
+    bool forked = false;
+    if (split) {   // no shallow rows at all (small batches: every graph is "deep"): nothing to overlap, no fork
+        int64_t shallow = 0;
+        for (int q = 0; q < ndir; ++q)
+            for (int t = 0; t < num_layers[dirs[q]]; ++t) shallow += a->layer_split[dirs[q]][t] - layer_ptr[dirs[q]][t];
+        forked = shallow > 0;
+        if (!forked) {
+            const int rc = launch_tail(st, 0);
+            if (rc != DAGNN_OK) return rc;
+        }
+    }
+    if (forked) {
         hipStream_t side = (hipStream_t)a->side_stream;
         if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
@@ -1168,11 +1179,11 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         else e = launch_step<16, 8, 16, 1>(blocks, H, st, plan, L, S);
         if (e != hipSuccess) return DAGNN_EHIP(e);
     }
-    if (split) {   // join: the caller's stream continues only when the deep graphs are finished too
+    if (forked) {   // join: the caller's stream continues only when the deep graphs are finished too
         hipStreamWaitEvent(st, ev_join, 0);
         hipEventDestroy(ev_fork);   // destruction is deferred by the runtime until the recorded work has completed
         hipEventDestroy(ev_join);
-    } else if (s_tail < nsteps) {
+    } else if (!split && s_tail < nsteps) {
         const int rc = launch_tail(st, s_tail);
         if (rc != DAGNN_OK) return rc;
     }

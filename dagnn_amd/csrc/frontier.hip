@@ -1080,14 +1080,17 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool forked = false;
     if (split) {   // no shallow rows at all (small batches: every graph is "deep"): nothing to overlap, no fork
-        int64_t shallow = 0;
+        int64_t shallow = 0, deep = 0;
         for (int q = 0; q < ndir; ++q)
-            for (int t = 0; t < num_layers[dirs[q]]; ++t) shallow += a->layer_split[dirs[q]][t] - layer_ptr[dirs[q]][t];
-        forked = shallow > 0;
-        if (!forked) {
+            for (int t = 0; t < num_layers[dirs[q]]; ++t) {
+                shallow += a->layer_split[dirs[q]][t] - layer_ptr[dirs[q]][t];
+                deep += layer_ptr[dirs[q]][t + 1] - a->layer_split[dirs[q]][t];
+            }
+        forked = shallow > 0 && deep > 0;
+        if (!forked && deep > 0) {   // only deep graphs: the persistent kernel alone, on the caller's stream
             const int rc = launch_tail(st, 0);
             if (rc != DAGNN_OK) return rc;
-        }
+        }                            // only shallow graphs: the per-layer launches alone
     }
     if (forked) {
         hipStream_t side = (hipStream_t)a->side_stream;

@@ -66,7 +66,8 @@ class BackwardCell(C.Structure):
 class BackwardArgs(C.Structure):
     _fields_ = [("cell", (BackwardCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
                 ("H", C.c_int), ("ld_h", C.c_int), ("num_cus", C.c_int), ("thin_wgs", C.c_int),
-                ("tail_replicas", C.c_int), ("tail_max_blocks", C.c_int), ("epoch", C.c_uint), ("tail_err", C.c_void_p)]
+                ("tail_replicas", C.c_int), ("tail_max_blocks", C.c_int), ("epoch", C.c_uint), ("tail_err", C.c_void_p),
+                ("side_stream", C.c_void_p), ("layer_split", C.POINTER(C.c_int32) * MAX_DIRS)]
 
 
 # every symbol include/dagnn_hip.h declares: (restype, argtypes)

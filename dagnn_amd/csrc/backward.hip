@@ -587,6 +587,7 @@ __global__ void __launch_bounds__(ST) bwd_step_kernel(const int32_t* __restrict_
 struct BTailArgs {
     BArgs S;
     int nrep, s_begin, s_end, num_stacked;
+    int use_split;   // rows of a layer start at blsplit[t] (the deep graphs only) instead of blptr[t]
     unsigned epoch;
     int* err;
 };
@@ -615,7 +616,7 @@ __global__ void __launch_bounds__(ST) bwd_tail_kernel(const int32_t* __restrict_
     for (int s = A.s_begin; s < A.s_end; ++s) {
         const int t = C.T - 1 - (s - (A.num_stacked - 1 - C.stacked));   // the top stacked layer leads
         if (t < 0 || t >= C.T) continue;
-        const int r0 = blptr[t], r1 = blptr[t + 1];
+        const int r0 = A.use_split ? plan[L.blsplit[C.dir] + t] : blptr[t], r1 = blptr[t + 1];
         const int rbs = min(max((r1 - r0 + A.nrep - 1) / A.nrep, 1), RB);
         for (int slot0 = r0 + rep * rbs; slot0 < r1; slot0 += A.nrep * rbs) {
             bwd_block<RB, true, true>(plan, L, C, H, S.ld_h, S.R, slot0, min(rbs, r1 - slot0), slice, lds, wr, wr2, w_lds, G);
@@ -917,6 +918,83 @@ extern "C" int dagnn_backward_run(const dagnn_plan* pl, const dagnn_backward_arg
                             (int)mfma_lds_bytes(H)) != hipSuccess)
         return DAGNN_EHIP(hipGetLastError());
     const int nsteps = Tmax + Ls - 1;
+    // Row range of layer t that a chain covers: everything, or - split mode - the shallow graphs' rows [ptr, split) /
+    // the deep graphs' rows [split, ptr').  The two sets of graphs share nothing, so in split mode the sweep runs as
+    // two independent chains: the shallow graphs' per-layer launches on the side stream, and on the caller's stream
+    // the deep graphs - persistent kernel over the thin head of the reverse order, then per-layer launches.
+    bool split = a->side_stream != nullptr;
+    for (int q = 0; q < ndir && split; ++q) split = a->layer_split[dirs[q]] != nullptr;
+    enum { ALL = 0, SHALLOW = 1, DEEP = 2 };
+    auto row_lo = [&](int part, int d, int t) { return part == DEEP ? a->layer_split[d][t] : layer_ptr[d][t]; };
+    auto row_hi = [&](int part, int d, int t) { return part == SHALLOW ? a->layer_split[d][t] : layer_ptr[d][t + 1]; };
+    if (split) {   // nothing to overlap unless both kinds of graphs exist
+        int64_t shallow = 0, deep = 0;
+        for (int q = 0; q < ndir; ++q)
+            for (int t = 0; t < num_layers[dirs[q]]; ++t) {
+                shallow += row_hi(SHALLOW, dirs[q], t) - row_lo(SHALLOW, dirs[q], t);
+                deep += row_hi(DEEP, dirs[q], t) - row_lo(DEEP, dirs[q], t);
+            }
+        split = shallow > 0 && deep > 0;
+    }
+
+    // per-layer launches of steps [s_from, nsteps) for one part of the rows, on stream `ss`
+    auto run_steps = [&](hipStream_t ss, int s_from, int part) -> int {
+        BArgs P = S;
+        for (int s = s_from; s < nsteps; ++s) {
+            // stacked layer i handles layer t = T_d - 1 - (s - (Ls-1-i)): the top layer leads, every lower one is a launch behind
+            auto layout = [&](int unit) {   // row ranges of the active cells; blk_start in blocks of `unit` rows
+                int k = 0, tot = 0;
+                for (int q = 0; q < ndir; ++q)
+                    for (int i = 0; i < Ls; ++i, ++k) {
+                        const int d = dirs[q];
+                        const int t = num_layers[d] - 1 - (s - (Ls - 1 - i));
+                        const bool on = t >= 0 && t < num_layers[d];
+                        P.cell[k].row_base = on ? row_lo(part, d, t) : 0;
+                        P.cell[k].row_end = on ? row_hi(part, d, t) : 0;
+                        P.blk_start[k] = tot;
+                        tot += (P.cell[k].row_end - P.cell[k].row_base + unit - 1) / unit;
+                    }
+                P.blk_start[k] = tot;
+                return tot;
+            };
+            const int rows = layout(1);
+            if (rows == 0) continue;
+            const int blocks4 = layout(4);
+            const bool thin = blocks4 * NS <= (a->thin_wgs > 0 ? a->thin_wgs : 2 * a->num_cus);
+            if (thin || (!mfma && rb_fat == 4)) {
+                const dim3 grid((unsigned)(blocks4 * NS));
+                if (pre) hipLaunchKernelGGL((bwd_step_kernel<4, true>), grid, dim3(ST), step_lds_bytes<4>(H), ss, plan, L, P);
+                else hipLaunchKernelGGL((bwd_step_kernel<4, false>), grid, dim3(ST), step_lds_bytes<4>(H), ss, plan, L, P);
+            } else if (!mfma) {
+                const dim3 grid((unsigned)(layout(8) * NS));
+                if (pre) hipLaunchKernelGGL((bwd_step_kernel<8, true>), grid, dim3(ST), step_lds_bytes<8>(H), ss, plan, L, P);
+                else hipLaunchKernelGGL((bwd_step_kernel<8, false>), grid, dim3(ST), step_lds_bytes<8>(H), ss, plan, L, P);
+            } else {
+                layout(1);
+                hipLaunchKernelGGL(bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 4 * H * sizeof(float), ss, plan, L, P);
+                DAGNN_CHECK_LAUNCH();
+                const int tiles = layout(BMT);
+                hipLaunchKernelGGL(bwd_mfma_kernel, dim3((unsigned)(tiles * (H / 32))), dim3(512), mfma_lds_bytes(H), ss, plan, L, P);
+            }
+            DAGNN_CHECK_LAUNCH();
+        }
+        return DAGNN_OK;
+    };
+
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (split) {   // fork: the shallow graphs' chain on the side stream
+        hipStream_t side = (hipStream_t)a->side_stream;
+        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
+            return DAGNN_EHIP(hipGetLastError());
+        hipEventRecord(ev_fork, st);
+        hipStreamWaitEvent(side, ev_fork, 0);
+        const int rc = run_steps(side, 0, SHALLOW);
+        hipEventRecord(ev_join, side);
+        if (rc != DAGNN_OK) { hipEventDestroy(ev_fork); hipEventDestroy(ev_join); return rc; }
+    }
+    const int part = split ? DEEP : ALL;
+
     // ---- the thin head of the reverse order (deepest layers first) in ONE persistent launch: the prefix of steps in
     // which no cell has more rows than its replicas cover in `tail_max_blocks` 4-row blocks
     int s_first = 0;
@@ -933,7 +1011,7 @@ extern "C" int dagnn_backward_run(const dagnn_plan* pl, const dagnn_backward_arg
                 for (int q = 0; q < ndir; ++q)
                     for (int i = 0; i < Ls; ++i) {
                         const int d = dirs[q], t = num_layers[d] - 1 - (s_end - (Ls - 1 - i));
-                        if (t >= 0 && t < num_layers[d]) mx = mx > layer_ptr[d][t + 1] - layer_ptr[d][t] ? mx : layer_ptr[d][t + 1] - layer_ptr[d][t];
+                        if (t >= 0 && t < num_layers[d]) mx = mx > row_hi(part, d, t) - row_lo(part, d, t) ? mx : row_hi(part, d, t) - row_lo(part, d, t);
                     }
                 if (mx > cap) break;
             }
@@ -942,6 +1020,7 @@ extern "C" int dagnn_backward_run(const dagnn_plan* pl, const dagnn_backward_arg
                 A.S = S;
                 for (int k = 0; k < S.ncell; ++k) A.S.cell[k].T = num_layers[A.S.cell[k].dir];
                 A.nrep = nrep; A.s_begin = 0; A.s_end = s_end; A.num_stacked = Ls;
+                A.use_split = split ? 1 : 0;
                 A.epoch = a->epoch; A.err = (int*)a->tail_err;
                 const size_t tail_lds = step_lds_bytes<4>(H) + (size_t)2 * 3 * H * BJS * sizeof(float);
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -953,45 +1032,13 @@ extern "C" int dagnn_backward_run(const dagnn_plan* pl, const dagnn_backward_arg
             }
         }
     }
-    for (int s = s_first; s < nsteps; ++s) {
-        // stacked layer i handles layer t = T_d - 1 - (s - (Ls-1-i)): the top layer leads, every lower one is a launch behind
-        auto layout = [&](int unit) {   // row ranges of the active cells; blk_start in blocks of `unit` rows
-            int k = 0, tot = 0;
-            for (int q = 0; q < ndir; ++q)
-                for (int i = 0; i < Ls; ++i, ++k) {
-                    const int d = dirs[q];
-                    const int t = num_layers[d] - 1 - (s - (Ls - 1 - i));
-                    const bool on = t >= 0 && t < num_layers[d];
-                    S.cell[k].row_base = on ? layer_ptr[d][t] : 0;
-                    S.cell[k].row_end = on ? layer_ptr[d][t + 1] : 0;
-                    S.blk_start[k] = tot;
-                    tot += (S.cell[k].row_end - S.cell[k].row_base + unit - 1) / unit;
-                }
-            S.blk_start[k] = tot;
-            return tot;
-        };
-        const int rows = layout(1);
-        if (rows == 0) continue;
-        const int blocks4 = layout(4);
-        const bool thin = blocks4 * NS <= (a->thin_wgs > 0 ? a->thin_wgs : 2 * a->num_cus);
-        if (thin || (!mfma && rb_fat == 4)) {
-            const dim3 grid((unsigned)(blocks4 * NS));
-            if (pre) hipLaunchKernelGGL((bwd_step_kernel<4, true>), grid, dim3(ST), step_lds_bytes<4>(H), st, plan, L, S);
-            else hipLaunchKernelGGL((bwd_step_kernel<4, false>), grid, dim3(ST), step_lds_bytes<4>(H), st, plan, L, S);
-        } else if (!mfma) {
-            const dim3 grid((unsigned)(layout(8) * NS));
-            if (pre) hipLaunchKernelGGL((bwd_step_kernel<8, true>), grid, dim3(ST), step_lds_bytes<8>(H), st, plan, L, S);
-            else hipLaunchKernelGGL((bwd_step_kernel<8, false>), grid, dim3(ST), step_lds_bytes<8>(H), st, plan, L, S);
-        } else {
-            layout(1);
-            hipLaunchKernelGGL(bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 4 * H * sizeof(float), st, plan, L, S);
-            DAGNN_CHECK_LAUNCH();
-            const int tiles = layout(BMT);
-            hipLaunchKernelGGL(bwd_mfma_kernel, dim3((unsigned)(tiles * (H / 32))), dim3(512), mfma_lds_bytes(H), st, plan, L, S);
-        }
-        DAGNN_CHECK_LAUNCH();
+    const int rc = run_steps(st, s_first, part);
+    if (split) {   // join: the caller's stream continues only when the shallow graphs are finished too
+        hipStreamWaitEvent(st, ev_join, 0);
+        hipEventDestroy(ev_fork);   // destruction is deferred by the runtime until the recorded work has completed
+        hipEventDestroy(ev_join);
     }
-    return DAGNN_OK;
+    return rc;
 }
 
 extern "C" int dagnn_readout_max_backward(const dagnn_plan* pl, const float* h, int ld_h, int width, int dir,

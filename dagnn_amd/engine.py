@@ -477,6 +477,11 @@ def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells,
     for d in (0, 1):
         ptrs[d] = sched[d].ctypes.data_as(C.POINTER(C.c_int32))
         nl[d] = len(sched[d]) - 1
+    if use_tail and SPLIT_DEEP:
+        splits = plan.read_splits()
+        args.side_stream = arena.side_stream(dev).cuda_stream
+        for d in dirs:
+            args.layer_split[d] = splits[d].ctypes.data_as(C.POINTER(C.c_int32))
     with _span("backward_run", plan.ws):
         check(lib.dagnn_backward_run(C.byref(plan.desc), C.byref(args), ptrs, nl, _stream(plan.ws)),
               "dagnn_backward_run")

@@ -291,6 +291,11 @@ typedef struct dagnn_backward_args {
     int tail_max_blocks; /* a layer may have up to 4 * tail_replicas * tail_max_blocks rows per cell in it */
     unsigned epoch;      /* tag of this backward pass in the granule buffers: nonzero, larger than any used before */
     void* tail_err;      /* device int32: set to 1 if a bounded wait ever expires (results are then invalid) */
+    /* split mode (optional): with a second stream and the plan's per-layer split pointers the sweep runs as two
+     * independent chains - the shallow graphs' per-layer launches on `side_stream`, the deep graphs (persistent head,
+     * then per-layer launches) on `stream`; forks from and joins back into `stream` with events */
+    void* side_stream;
+    const int32_t* layer_split[DAGNN_MAX_DIRS];   /* HOST, num_layers[d] int32, or NULL */
 } dagnn_backward_args;
 
 int dagnn_backward_prepare(const dagnn_plan* plan /* host */, const dagnn_backward_args* args /* host */, void* stream);

@@ -62,7 +62,7 @@ TAIL_MAX_BLOCKS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_MAX_BLOCKS", 
 SPLIT_DEEP = int(__import__("os").environ.get("DAGNN_AMD_SPLIT_DEEP", "1"))  # 1: deep graphs on a side stream from layer 0
 BWD_THIN_WGS = int(__import__("os").environ.get("DAGNN_AMD_BWD_THIN_WGS", "0"))  # 0 = library default
 BWD_TAIL_REPLICAS = int(__import__("os").environ.get("DAGNN_AMD_BWD_TAIL_REPLICAS", "2"))  # 0 = launch every layer
-BWD_TAIL_MAX_BLOCKS = int(__import__("os").environ.get("DAGNN_AMD_BWD_TAIL_MAX_BLOCKS", "2"))
+BWD_TAIL_MAX_BLOCKS = int(__import__("os").environ.get("DAGNN_AMD_BWD_TAIL_MAX_BLOCKS", "4"))
 DEBUG_TIMING: Optional[torch.Tensor] = None  # int64[8] device tensor: phase ticks of the deepest work item
 _NOSPAN = _NoSpan()
 

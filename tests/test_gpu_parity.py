@@ -517,3 +517,34 @@ def test_device_layering_full_batch_big_graph_and_cycle(device):
     cyc = torch.tensor([[0, 1, 2], [1, 2, 0]], device=device)
     _, _, status = engine.topo_layers(cyc, torch.zeros(3, dtype=torch.long, device=device), 1)
     assert int(status) & 16
+
+
+# ----------------------------------------------------------------------------- concurrency stress
+def test_back_to_back_forwards_and_steps_are_race_free(device):
+    """Split mode runs the persistent kernel on a side stream next to the per-layer launches, and nothing in
+    `forward` synchronises except the schedule read-back: 150 forwards and 20 training steps issued back to back
+    (buffers recycled by the caching allocator every iteration) must reproduce the first result bit for bit, and no
+    bounded wait may have expired."""
+    from bench import build_model, fresh_inputs
+    model = build_model(64, 2, 48, 3, device)
+    master = synth.code2_batch(5, 96, 110).to(device)
+    ins = fresh_inputs(master, 150)
+    with torch.no_grad():
+        first = [o.clone() for o in model(ins[0])]
+        for g in ins[1:]:
+            out = model(g)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(first, out))
+    for arena in model._arenas.values():
+        arena.check()
+    y = torch.randint(0, 48, (96, 3), generator=torch.Generator().manual_seed(4)).to(device)
+    ref = None
+    for g in fresh_inputs(master, 20):
+        _, grads = _train_step(model, g, y)
+        cell = {k: v.clone() for k, v in grads.items() if "encoder." not in k}
+        if ref is None:
+            ref = cell
+    torch.cuda.synchronize()
+    assert all(torch.equal(ref[k], cell[k]) for k in ref)
+    for arena in model._arenas.values():
+        arena.check()

@@ -7,6 +7,7 @@ implementation: CPU tensors raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -53,16 +54,23 @@ class _NoSpan(object):
 
 
 TIMER: Optional[KernelTimer] = None  # set by bench.py around its timed region
-RB4_MAX_WGS = int(__import__("os").environ.get("DAGNN_AMD_RB4_MAX_WGS", "0"))  # 0 = library default (1.5 per CU)
-MFMA_MIN_ROWS = int(__import__("os").environ.get("DAGNN_AMD_MFMA_MIN_ROWS", "400"))  # 0 = never use MFMA tiles
-AGG_SPLIT = int(__import__("os").environ.get("DAGNN_AMD_AGG_SPLIT", "0"))
-TAIL_SLICE = int(__import__("os").environ.get("DAGNN_AMD_TAIL_SLICE", "32"))
-TAIL_REPLICAS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_REPLICAS", "4"))   # 0 = launch every layer
-TAIL_MAX_BLOCKS = int(__import__("os").environ.get("DAGNN_AMD_TAIL_MAX_BLOCKS", "2"))
-SPLIT_DEEP = int(__import__("os").environ.get("DAGNN_AMD_SPLIT_DEEP", "1"))  # 1: deep graphs on a side stream from layer 0
-BWD_THIN_WGS = int(__import__("os").environ.get("DAGNN_AMD_BWD_THIN_WGS", "0"))  # 0 = library default
-BWD_TAIL_REPLICAS = int(__import__("os").environ.get("DAGNN_AMD_BWD_TAIL_REPLICAS", "2"))  # 0 = launch every layer
-BWD_TAIL_MAX_BLOCKS = int(__import__("os").environ.get("DAGNN_AMD_BWD_TAIL_MAX_BLOCKS", "4"))
+
+def _env_int(name: str, default: int) -> int:
+    return int(os.environ.get(name, default))
+
+
+# Launch-geometry knobs (read once at import; the defaults are the measured optima on MI355X).
+# Tests flip some of them to force the less common code paths.
+RB4_MAX_WGS = _env_int("DAGNN_AMD_RB4_MAX_WGS", 0)          # 4-row vs 8-row blocks of the streamed kernel; 0 = library default
+MFMA_MIN_ROWS = _env_int("DAGNN_AMD_MFMA_MIN_ROWS", 400)    # launches with at least this many rows use MFMA tiles; 0 = never
+AGG_SPLIT = _env_int("DAGNN_AMD_AGG_SPLIT", 0)              # allocate the gather scratch even without MFMA tiles (tests)
+TAIL_SLICE = _env_int("DAGNN_AMD_TAIL_SLICE", 32)           # hidden units per workgroup of the persistent kernel (16 | 32)
+TAIL_REPLICAS = _env_int("DAGNN_AMD_TAIL_REPLICAS", 4)      # workgroups per (cell, slice); 0 = one launch per layer throughout
+TAIL_MAX_BLOCKS = _env_int("DAGNN_AMD_TAIL_MAX_BLOCKS", 2)  # without split mode: layers of <= 4 * replicas * this rows go to it
+SPLIT_DEEP = _env_int("DAGNN_AMD_SPLIT_DEEP", 1)            # 1: deep graphs on a side stream from layer 0 (forward and backward)
+BWD_THIN_WGS = _env_int("DAGNN_AMD_BWD_THIN_WGS", 0)        # backward: slice kernel vs rows + MFMA kernels; 0 = library default
+BWD_TAIL_REPLICAS = _env_int("DAGNN_AMD_BWD_TAIL_REPLICAS", 2)    # backward persistent kernel; 0 = one launch per layer
+BWD_TAIL_MAX_BLOCKS = _env_int("DAGNN_AMD_BWD_TAIL_MAX_BLOCKS", 4)
 DEBUG_TIMING: Optional[torch.Tensor] = None  # int64[8] device tensor: phase ticks of the deepest work item
 _NOSPAN = _NoSpan()
 

@@ -58,14 +58,14 @@ class FrontierArgs(C.Structure):
 
 
 class BackwardCell(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("w_hh", "w_ih", "w_key", "edge_gain", "h", "a", "alpha", "gi", "gh", "g_ext",
+    _fields_ = [(k, C.c_void_p) for k in ("w_hh", "w_ih", "w_key", "edge_gain", "vid_bias", "h", "a", "alpha", "gi", "gh", "g_ext",
                                           "da", "dgi", "dgh", "sigma", "edge_feat_grad", "da_granules", "du_granules",
                                           "g_ext_static")]
 
 
 class BackwardArgs(C.Structure):
     _fields_ = [("cell", (BackwardCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
-                ("H", C.c_int), ("ld_h", C.c_int), ("num_cus", C.c_int), ("thin_wgs", C.c_int),
+                ("H", C.c_int), ("ld_h", C.c_int), ("vid_mod", C.c_int), ("num_cus", C.c_int), ("thin_wgs", C.c_int),
                 ("tail_replicas", C.c_int), ("tail_max_blocks", C.c_int), ("epoch", C.c_uint), ("tail_err", C.c_void_p),
                 ("side_stream", C.c_void_p), ("layer_split", C.POINTER(C.c_int32) * MAX_DIRS)]
 

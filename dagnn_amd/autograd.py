@@ -53,10 +53,15 @@ def _wgrad(dg: torch.Tensor, u: torch.Tensor, splits: int = 32) -> torch.Tensor:
 
 
 class Recurrence(torch.autograd.Function):
-    """Plan + embedding -> pooled read-out [B, D*L*H (+ D*emb)] of the bidirectional max-pool configuration
-    (dagnn.py:144-193).  Inputs after `x` are the cells' parameters, 8 per (direction, stacked layer):
-    weight_ih, weight_hh, bias_ih, bias_hh, attn_lin.weight, attn_lin.bias, edge_encoder.weight,
-    edge_encoder.bias (the last two None without edge features)."""
+    """Plan + node inputs -> graph read-out, differentiable (dagnn.py:144-193; dvae/dagnn.py:99-175).
+
+    `mod` is the calling module; it supplies `num_layers`, `hidden_dim`, `dirs`, `_cells()`, `_arena_for(x, role)`,
+    `_vid_nodes` (node count per graph when the keys carry a vertex-id one-hot, else 0), `_key_offset(i)` (position of
+    the key weights inside attn_lin.weight of stacked layer i) and the two read-out hooks
+    `_readout(plan, B, x, h) -> out`, `_readout_backward(plan, x, h, grad_out, g_ext, dx)`.
+    Inputs after `x` are the cells' parameters, 8 per (direction, stacked layer): weight_ih, weight_hh, bias_ih,
+    bias_hh, attn_lin.weight, attn_lin.bias, edge_encoder.weight, edge_encoder.bias (the last two None without edge
+    features)."""
 
     PER_CELL = 8
 
@@ -65,13 +70,8 @@ class Recurrence(torch.autograd.Function):
         L, H, dirs = mod.num_layers, mod.hidden_dim, mod.dirs
         cells = mod._cells()
         keep = {}
-        h = run_stack_lockstep(plan, x, cells, dirs, L, H, arena=mod._arena_for(x), keep=keep)
-        out = torch.empty(B, mod.out_hidden_dim, dtype=torch.float32, device=x.device)
-        col = 0
-        for d in (0, 1):
-            for t in ([x] if mod.out_wx else []) + [h[d][i] for i in range(L)]:
-                engine.readout_max(plan, t, d, out, col)
-                col += t.shape[1]
+        h = run_stack_lockstep(plan, x, cells, dirs, L, H, vid_nodes=mod._vid_nodes, arena=mod._arena_for(x), keep=keep)
+        out = mod._readout(plan, B, x, h)
         ctx.mod, ctx.plan, ctx.cells, ctx.keep, ctx.h = mod, plan, cells, keep, h
         ctx.save_for_backward(x, *[p for p in params if p is not None])
         ctx.present = [p is not None for p in params]
@@ -88,18 +88,12 @@ class Recurrence(torch.autograd.Function):
         L, H, dirs, Hp = mod.num_layers, mod.hidden_dim, mod.dirs, keep["Hp"]
         N, dev = x.shape[0], x.device
         gout = gout.contiguous().float()
-        g_ext = [[torch.zeros(N, Hp, dtype=torch.float32, device=dev) for _ in range(L)] for _ in range(2)]
+        g_ext = [[torch.zeros(N, Hp, dtype=torch.float32, device=dev) if d in dirs else None for _ in range(L)]
+                 for d in range(2)]
         dx = torch.zeros_like(x)
-        col = 0
-        for d in (0, 1):  # read-out gradient: to the arg-max output node of every (graph, column)
-            if mod.out_wx:
-                engine.readout_max_backward(plan, x, d, gout, col, dx)
-                col += x.shape[1]
-            for i in range(L):
-                engine.readout_max_backward(plan, h[d][i], d, gout, col, g_ext[d][i])
-                col += H
+        mod._readout_backward(plan, x, h, gout, g_ext, dx)
         res = engine.backward_sweep(plan, dirs, L, Hp, cells, keep["h_buf"], keep["gi0"], g_ext,
-                                    arena=mod._arena_for(x, "backward"))
+                                    arena=mod._arena_for(x, "backward"), vid_mod=mod._vid_nodes)
 
         def gates(t):  # [N, 3Hp] in gate blocks of Hp -> [N, 3H]
             return t if Hp == H else t.view(N, 3, Hp)[:, :, :H].reshape(N, 3 * H)
@@ -115,21 +109,23 @@ class Recurrence(torch.autograd.Function):
                 u = x if i == 0 else h[d][i - 1]
                 g_wih, g_bih = _wgrad(dgi, u), dgi.sum(0)
                 g_whh, g_bhh = _wgrad(dgh, r["a"][:, :H]), dgh.sum(0)
-                if i == 0:
+                if i == 0 and x.requires_grad:
                     dx = dx + dgi @ w_ih
-                # attention logit s_e = w_key . (h_p + W_e feat_e + b_e) (+ query and bias terms that cancel in
-                # the segment softmax: their gradients are exact zeros)
-                dq = attn_w.shape[1] - H
+                # attention logit s_e = w_key . (h_p + W_e feat_e + b_e) [+ w_vid[p mod n]] (+ query and bias terms
+                # that cancel in the segment softmax: their gradients are exact zeros)
+                dq = mod._key_offset(i)
                 sigma = r["sigma"]
                 g_key = (h[d][i] * sigma[:, None]).sum(0)
                 g_edge_w = g_edge_b = None
                 if edge_w is not None:
                     m, ssum = r["edge_feat_grad"].sum(0), sigma.sum()
-                    w_key = attn_w[0, dq:]
+                    w_key = attn_w[0, dq:dq + H]
                     g_key = g_key + edge_w @ m + edge_b * ssum
                     g_edge_w, g_edge_b = torch.outer(w_key, m), w_key * ssum
                 g_attn = torch.zeros_like(attn_w)
-                g_attn[0, dq:] = g_key
+                g_attn[0, dq:dq + H] = g_key
+                if mod._vid_nodes:   # node v carries the one-hot of (v mod n): d w_vid[j] = sum of sigma over those nodes
+                    g_attn[0, dq + H:dq + H + mod._vid_nodes] = sigma.view(-1, mod._vid_nodes).sum(0)
                 grads += [g_wih, g_whh, g_bih, g_bhh, g_attn, None if attn_b is None else torch.zeros_like(attn_b),
                           g_edge_w, g_edge_b]
-        return (None, None, None, dx) + tuple(grads)
+        return (None, None, None, dx if x.requires_grad else None) + tuple(grads)

@@ -167,13 +167,6 @@ def run_stack(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tuple[int, i
     return h  # type: ignore[return-value]
 
 
-def require_inference(module: torch.nn.Module) -> None:
-    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
-        raise NotImplementedError(
-            "the HIP recurrence has no backward pass yet: call the module under torch.no_grad() "
-            "(as the reference's eval loop does, ogbg-code/main_pyg.py:103) or freeze its parameters")
-
-
 def default_schedule() -> str:
     import os
     s = os.environ.get("DAGNN_AMD_SCHEDULE", "lockstep")

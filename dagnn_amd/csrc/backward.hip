@@ -48,6 +48,7 @@ struct BCell {
     const float* wih;    // [3H,H] or null (stacked layer 0)
     const float* wkey;   // [H]
     const float* gain;   // [R] or null
+    const float* vid;    // [vid_mod] per-vertex-id score bias of the NA variant (dvae/dagnn.py:130-134) or null
     const float* h;      // [N,ld_h] states + partial scores of this cell (forward output)
     const float* a;      // [N,H]
     float* a_w;          // same buffer, written by the prepare kernel
@@ -73,7 +74,7 @@ struct BCell {
 struct BArgs {
     BCell cell[DAGNN_BWD_MAX_CELLS];
     int blk_start[DAGNN_BWD_MAX_CELLS + 1];
-    int ncell, H, ld_h, R;
+    int ncell, H, ld_h, R, vid_mod;
 };
 
 __device__ __forceinline__ float bsigm(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -104,6 +105,7 @@ __global__ void __launch_bounds__(BT) bwd_prepare_kernel(const int32_t* __restri
     }
     auto logit = [&](int e) {
         float s = bscore(C.h + (int64_t)col[e] * ld_h + H, nparts);
+        if (C.vid) s += C.vid[col[e] % S.vid_mod];
         for (int r = 0; r < R; ++r) s = fmaf(C.gain[r], eattr[(int64_t)e * R + r], s);
         return s;
     };
@@ -834,6 +836,7 @@ void fill_cells(BArgs& S, const dagnn_backward_args* a, const int* dirs, int ndi
             BCell& K = S.cell[S.ncell++];
             K.whh = (const float*)c.w_hh; K.wih = i > 0 ? (const float*)c.w_ih : nullptr;
             K.wkey = (const float*)c.w_key; K.gain = (const float*)c.edge_gain;
+            K.vid = a->vid_mod > 0 ? (const float*)c.vid_bias : nullptr;
             K.h = (const float*)c.h; K.a = (const float*)c.a; K.a_w = (float*)c.a; K.alpha = (float*)c.alpha;
             K.gi = (const float*)c.gi; K.gh = (const float*)c.gh; K.gext = (const float*)c.g_ext;
             K.gext_lo = i > 0 ? (float*)a->cell[dirs[q]][i - 1].g_ext : nullptr;
@@ -864,7 +867,7 @@ extern "C" int dagnn_backward_prepare(const dagnn_plan* pl, const dagnn_backward
             if (!c.h || !c.a || !c.alpha || (pl->num_edge_feats > 0 && !c.edge_gain)) return DAGNN_EINVAL;
         }
     BArgs S;
-    S.H = H; S.ld_h = a->ld_h; S.R = pl->num_edge_feats;
+    S.H = H; S.ld_h = a->ld_h; S.R = pl->num_edge_feats; S.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
     fill_cells(S, a, dirs, ndir);
     PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
     hipLaunchKernelGGL(bwd_succrec_kernel, dim3((unsigned)((pl->N + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream,
@@ -903,7 +906,7 @@ extern "C" int dagnn_backward_run(const dagnn_plan* pl, const dagnn_backward_arg
     hipStream_t st = (hipStream_t)stream;
     const int32_t* plan = (const int32_t*)pl->data;
     BArgs S;
-    S.H = H; S.ld_h = a->ld_h; S.R = pl->num_edge_feats;
+    S.H = H; S.ld_h = a->ld_h; S.R = pl->num_edge_feats; S.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
     fill_cells(S, a, dirs, ndir);
     const int NS = H / BJS;
     const bool pre = H3_fits_registers(H);

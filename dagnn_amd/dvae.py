@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import constants as K
 from . import engine
-from .core import DerivedCache, default_schedule, derive_cell, require_inference, run_stack
+from .core import DerivedCache, default_schedule, derive_cell, run_stack
 from .data import GraphBatch
 from .model import _EdgeAttnParams
 
@@ -127,11 +127,56 @@ class _DvaeDagnn(_DvaeBase):
 
         return self._derived.setdefault(self.schedule, DerivedCache()).get(srcs, make)
 
+    # ---- hooks of autograd.Recurrence
+    @property
+    def _vid_nodes(self) -> int:
+        return self.num_nodes if self._use_vids else 0
+
+    def _key_offset(self, i: int) -> int:
+        return self.emb_dim if i == 0 else self.hidden_dim + self._vid_nodes
+
+    def _arena_for(self, x, role="forward"):
+        return self._arenas.setdefault((role, x.device, torch.cuda.current_stream(x.device).cuda_stream),
+                                       engine.GranuleArena())
+
+    def _readout(self, plan, B, x, h):
+        """End vertex of every graph for d = 0, start vertex for d = 1 (dvae/dagnn.py:147-161, dagnn_bn.py:138-152)."""
+        L, H, nn_ = self.num_layers, self.hidden_dim, self.num_nodes
+        hcat = torch.empty(B, len(self.dirs) * L * H, dtype=torch.float32, device=x.device)
+        for i in range(L):
+            engine.gather_rows(h[0][i], B, nn_, nn_ - 1, hcat, i * H)
+            if self.bidirectional:
+                engine.gather_rows(h[1][i], B, nn_, 0, hcat, (L + i) * H)
+        return hcat
+
+    def _readout_backward(self, plan, x, h, gout, g_ext, dx):
+        L, H, nn_ = self.num_layers, self.hidden_dim, self.num_nodes
+        for i in range(L):
+            g_ext[0][i][nn_ - 1::nn_, :H] = gout[:, i * H:(i + 1) * H]
+            if self.bidirectional:
+                g_ext[1][i][0::nn_, :H] = gout[:, (L + i) * H:(L + i + 1) * H]
+
+    def _train_params(self):
+        flat = []
+        for d in self.dirs:
+            for i in range(self.num_layers):
+                c = getattr(self, "cells_%d" % d)[i]
+                a = getattr(self, "node_aggr_%d" % d)[i]
+                flat += [c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh, a.attn_lin.weight, a.attn_lin.bias, None, None]
+        return flat
+
+    def _training_pass(self) -> bool:
+        if not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            return False
+        if self.schedule != "lockstep":
+            raise NotImplementedError("the HIP backward pass needs the lock-step schedule")
+        return True
+
     def forward(self, G):
         """`dvae/dagnn.py:99-175` / `dvae/dagnn_bn.py:98-168` with `out_pool_all=False`."""
         if self.output_all:
             raise NotImplementedError("out_pool_all=True read-out is not implemented for the D-VAE encoders")
-        require_inference(self)
+        train = self._training_pass()
         device = self.get_device()
         G = G.to(device)
         x = G.x.float().contiguous()
@@ -142,15 +187,13 @@ class _DvaeDagnn(_DvaeBase):
         B = N // nn_
         bl = G.bi_layer_index
         plan = engine.build_plan(G.edge_index, bl[0][0], bl[1][0], G.batch, B, None)
-        h = run_stack(plan, x, self._cells(), self.dirs, L, H, vid_nodes=nn_ if self._use_vids else 0,
-                      schedule=self.schedule, arena=self._arenas.setdefault((x.device, torch.cuda.current_stream(x.device).cuda_stream),
-                                                   engine.GranuleArena()))
-        nd = len(self.dirs)
-        hcat = torch.empty(B, nd * L * H, dtype=torch.float32, device=x.device)
-        for i in range(L):  # end vertex of every graph for d=0, start vertex for d=1
-            engine.gather_rows(h[0][i], B, nn_, nn_ - 1, hcat, i * H)
-            if self.bidirectional:
-                engine.gather_rows(h[1][i], B, nn_, 0, hcat, (L + i) * H)
+        if train:
+            from .autograd import Recurrence
+            hcat = Recurrence.apply(self, plan, B, x, *self._train_params())[0]
+        else:
+            h = run_stack(plan, x, self._cells(), self.dirs, L, H, vid_nodes=self._vid_nodes,
+                          schedule=self.schedule, arena=self._arena_for(x))
+            hcat = self._readout(plan, B, x, h)
         G.h = hcat
         G.batch = G.batch[0::nn_] if self.bidirectional else G.batch[nn_ - 1::nn_]
         if self.bidirectional:

@@ -420,7 +420,7 @@ def readout_max_backward(plan: PlanHandle, h: torch.Tensor, direction: int, grad
 
 
 def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, h, gi0, g_ext,
-                   arena: Optional[GranuleArena] = None):
+                   arena: Optional[GranuleArena] = None, vid_mod: int = 0):
     """Reverse pass of the lock-step recurrence (csrc/backward.hip).  `h[d][i]` [N, frontier_ld(H)] are the
     forward state buffers, `gi0[d]` [N,3H] the input-side pre-activations of stacked layer 0, `g_ext[d][i]`
     [N,H] the gradients reaching the states from outside (modified: stacked layers below the top receive the
@@ -451,10 +451,12 @@ def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells,
             out[(d, i)] = o
             bc.w_hh, bc.w_ih = c.w_hh_raw.data_ptr(), (c.w_ih.data_ptr() if i > 0 else None)
             bc.w_key, bc.edge_gain = c.w_key.data_ptr(), (_ptr(c.edge_gain) if R > 0 else None)
+            bc.vid_bias = _ptr(c.vid_bias) if vid_mod > 0 else None
             bc.h, bc.a, bc.alpha = h[d][i].data_ptr(), o["a"].data_ptr(), o["alpha"].data_ptr()
             bc.g_ext, bc.da, bc.dgi, bc.dgh = g_ext[d][i].data_ptr(), o["da"].data_ptr(), o["dgi"].data_ptr(), o["dgh"].data_ptr()
             bc.sigma, bc.edge_feat_grad = o["sigma"].data_ptr(), _ptr(o["edge_feat_grad"])
     args.num_stacked, args.dir_mask, args.H, args.ld_h = L, mask, H, h[dirs[0]][0].shape[1]
+    args.vid_mod = int(vid_mod)
     args.num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
     args.thin_wgs = BWD_THIN_WGS
     args.tail_replicas, args.tail_max_blocks = (BWD_TAIL_REPLICAS if use_tail else 0), BWD_TAIL_MAX_BLOCKS

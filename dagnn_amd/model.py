@@ -254,6 +254,32 @@ class DAGNN(nn.Module):
                 "freeze its parameters")
         return True
 
+    # hooks of autograd.Recurrence
+    _vid_nodes = 0
+
+    def _key_offset(self, i: int) -> int:
+        return self._attn_geometry(i)[0]
+
+    def _readout(self, plan, B, x, h):
+        """Max-pool over the output nodes of both directions (dagnn.py:184-193), columns [d][x?, layer 0.. L-1]."""
+        out = torch.empty(B, self.out_hidden_dim, dtype=torch.float32, device=x.device)
+        col = 0
+        for d in (0, 1):
+            for t in ([x] if self.out_wx else []) + [h[d][i] for i in range(self.num_layers)]:
+                engine.readout_max(plan, t, d, out, col)
+                col += t.shape[1]
+        return out
+
+    def _readout_backward(self, plan, x, h, gout, g_ext, dx):
+        col = 0
+        for d in (0, 1):  # to the arg-max output node of every (graph, column)
+            if self.out_wx:
+                engine.readout_max_backward(plan, x, d, gout, col, dx)
+                col += x.shape[1]
+            for i in range(self.num_layers):
+                engine.readout_max_backward(plan, h[d][i], d, gout, col, g_ext[d][i])
+                col += self.hidden_dim
+
     def _train_params(self):
         flat = []
         for d in self.dirs:

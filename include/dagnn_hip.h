@@ -260,6 +260,7 @@ typedef struct dagnn_backward_cell {
     const float* w_ih;      /* [3H,H] (stacked layers > 0), else NULL */
     const float* w_key;     /* [H] */
     const float* edge_gain; /* [num_edge_feats] or NULL */
+    const float* vid_bias;  /* [vid_mod] or NULL: score bias by vertex id (NA variant), as in dagnn_frontier_cell */
     const float* h;         /* [N,ld_h] forward states + partial scores */
     float* a;               /* [N,H]  written by prepare, read by run */
     float* alpha;           /* [E]    written by prepare, read by run */
@@ -283,6 +284,7 @@ typedef struct dagnn_backward_cell {
 typedef struct dagnn_backward_args {
     dagnn_backward_cell cell[DAGNN_MAX_DIRS][DAGNN_MAX_STACKED];
     int num_stacked, dir_mask, H, ld_h;
+    int vid_mod;    /* 0, or the node count per graph of the NA variant (node id % vid_mod selects vid_bias) */
     int num_cus;
     int thin_wgs;   /* launches of up to this many slice workgroups use the register-resident slice kernel, bigger ones
                      * the rows + MFMA-tile kernels; 0 = default (2 * num_cus) */

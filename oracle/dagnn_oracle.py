@@ -22,7 +22,7 @@ each function follows:
 * `code2_forward`         - `DAGNN.forward` `dagnn.py:128-215` (read-outs :184-202, heads :209-215)
 * `code2_grads`           - one training step's loss + gradients, `ogbg-code/main_pyg.py:55-62`
 * `dvae_forward/encode`   - `dvae/dagnn.py:99-184` (NA, `vids` key bias :130-139) and
-                            `dvae/dagnn_bn.py:98-177` (BN)
+                            `dvae/dagnn_bn.py:98-177` (BN); `dvae_grads`: gradients of the encoder
 """
 from __future__ import annotations
 
@@ -285,11 +285,11 @@ def code2_grads(sd: Dict[str, Tensor], G, y: Tensor, *, dtype: torch.dtype = tor
 
 def dvae_forward(sd: Dict[str, Tensor], G, *, num_layers: int = 2, bidirectional: bool = False,
                  num_nodes: int = 8, vids: bool = True, mode: str = "csr",
-                 dtype: torch.dtype = torch.float32) -> Tensor:
+                 dtype: torch.dtype = torch.float32, keep_graph: bool = False) -> Tensor:
     """`DAGNN.forward` of `dvae/dagnn.py:99-175` (`vids=True`, NA) or `DAGNN_BN.forward` of
     `dvae/dagnn_bn.py:98-168` (`vids=False`), `out_pool_all=False`: read-out = the end vertex of
     every graph for d=0 and the start vertex for d=1 (fixed stride `num_nodes`)."""
-    sd = _cast(sd, dtype)
+    sd = _cast(sd, dtype, keep_graph)
     dirs = [0, 1] if bidirectional else [0]
     H = sd["cells_0.0.weight_hh"].shape[1]
     x = G.x.to(dtype)
@@ -317,5 +317,30 @@ def dvae_encode(sd, G, **kw):
     """`encode` (`dvae/dagnn.py:177-184`): (mu, logvar) = fc1(Hg), fc2(Hg)."""
     dtype = kw.get("dtype", torch.float32)
     Hg = dvae_forward(sd, G, **kw)
-    sdc = _cast({k: sd[k] for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")}, dtype)
+    sdc = _cast({k: sd[k] for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")}, dtype,
+                kw.get("keep_graph", False))
     return Hg @ sdc["fc1.weight"].t() + sdc["fc1.bias"], Hg @ sdc["fc2.weight"].t() + sdc["fc2.bias"]
+
+
+def dvae_grads(sd: Dict[str, Tensor], G, r1: Tensor, r2: Tensor, *, dtype: torch.dtype = torch.float32, **kw):
+    """Gradients of `loss = <mu, r1> + <logvar, r2>` through `dvae_encode` (plain torch autograd): the checker of the
+    encoder's backward pass (the VAE loss itself needs the decoder, which is outside the path).  Returns
+    `(loss, {parameter name: gradient})` for the parameters that take part."""
+    leaves = {k: (v.detach().to(dtype).clone().requires_grad_(True) if v.is_floating_point() else v)
+              for k, v in sd.items()}
+    mu, logvar = dvae_encode(leaves, G, dtype=dtype, keep_graph=True, **kw)
+    loss = (mu * r1.to(dtype)).sum() + (logvar * r2.to(dtype)).sum()
+    names = [k for k, v in leaves.items() if v.is_floating_point()]
+    gs = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
+    out = {k: g for k, g in zip(names, gs) if g is not None}
+    # the D-VAE modules register their encoder GRUs under two names (cells_d == grue_forward / grue_backward,
+    # dvae/dagnn.py:73-75): report a gradient under every name of the same storage
+    by_ptr = {}
+    for k, v in sd.items():
+        by_ptr.setdefault(v.data_ptr(), []).append(k)
+    for ks in by_ptr.values():
+        have = [k for k in ks if k in out]
+        for k in ks:
+            if have and k not in out:
+                out[k] = out[have[0]]
+    return loss.detach(), out

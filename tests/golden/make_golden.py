@@ -235,6 +235,64 @@ def make_augment(name):
     _save(name, dict(kind="augment_edge2", cases=4), **arrays)
 
 
+def _dvae_grad_case(model, graphs, name, meta, seed):
+    """Gradients of the reference encoder: `(mu, logvar) = model.encode(graphs)` (dvae/dagnn.py:177-184) under
+    autograd, loss = <mu, R1> + <logvar, R2> with seeded weights R (a stand-in for the VAE loss of dvae/train.py, whose
+    decoder is outside the path), `.backward()`.  Only parameters that received a gradient are stored."""
+    model.train()
+    mu, logvar = model.encode([copy.deepcopy(g) for g in graphs])
+    rng = np.random.default_rng(seed)
+    r1 = torch.from_numpy(rng.standard_normal(tuple(mu.shape)).astype(np.float32))
+    r2 = torch.from_numpy(rng.standard_normal(tuple(mu.shape)).astype(np.float32))
+    loss = (mu * r1).sum() + (logvar * r2).sum()
+    loss.backward()
+    arrays = dict(r1=_np(r1), r2=_np(r2), loss=np.array(float(loss.detach())), mu=_np(mu), logvar=_np(logvar))
+    strides = {}
+    for k, p_ in model.named_parameters():
+        if p_.grad is None:
+            continue
+        arrays["g::" + k], strides[k], arrays["gsum::" + k] = sample_grad(k, _np(p_.grad))
+    meta = dict(meta, grad_stride=strides, loss_seed=seed)
+    return meta, arrays
+
+
+def make_na_grad(ref_na, ref_util, name, *, hs, L, bidir, w_seed, nrows):
+    rows = []
+    with open(os.path.join(REF, "dvae", "data", "final_structures6.txt")) as f:
+        for i, line in enumerate(f):
+            if i < 1000:
+                continue
+            rows.append(eval(line)[0])
+            if len(rows) == nrows:
+                break
+    graphs = [ref_util.decode_ENAS_to_pygraph(r)[0] for r in rows]
+    model = ref_na.DAGNN(8, hs, hs, 8, 8, 0, 1, hs=hs, nz=56, num_nodes=8, agg="attn_h", num_layers=L,
+                         bidirectional=bidir, out_wx=False, out_pool_all=False, out_pool="max", dropout=0.0)
+    seeded_fill(model, w_seed)
+    meta, arrays = _dvae_grad_case(model, graphs, name, dict(kind="na", hs=hs, L=L, bidir=bool(bidir), w_seed=w_seed,
+                                                                nrows=nrows), 401)
+    _save(name, meta, rows=np.array([json.dumps(r) for r in rows]), **arrays)
+
+
+def make_bn_grad(ref_bn, ref_util, name, *, hs, L, bidir, w_seed, data_seed, nrows):
+    rows = synth.bn_rows(data_seed, nrows)
+    graphs = [ref_util.decode_BN_to_pygraph(r)[0] for r in rows]
+    model = ref_bn.DAGNN_BN(10, hs, hs, 10, 10, 0, 1, hs=hs, nz=56, num_nodes=10, agg="attn_h", num_layers=L,
+                            bidirectional=bidir, out_wx=False, out_pool_all=False, out_pool="max", dropout=0.0)
+    seeded_fill(model, w_seed)
+    meta, arrays = _dvae_grad_case(model, graphs, name, dict(kind="bn", hs=hs, L=L, bidir=bool(bidir), w_seed=w_seed,
+                                                                data_seed=data_seed, nrows=nrows), 402)
+    _save(name, meta, rows=np.array([json.dumps(r) for r in rows]), **arrays)
+
+
+def _dvae_only():
+    ref_util = importlib.import_module("util")
+    ref_na = importlib.import_module("dagnn")
+    ref_bn = importlib.import_module("dagnn_bn")
+    make_na_grad(ref_na, ref_util, "grad_na_h64_unidir", hs=64, L=2, bidir=False, w_seed=211, nrows=24)
+    make_bn_grad(ref_bn, ref_util, "grad_bn_h64_bidir", hs=64, L=2, bidir=True, w_seed=212, data_seed=7, nrows=20)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("reference not found at %s - fixtures can only be regenerated in the build container" % REF)
@@ -250,6 +308,8 @@ def main():
         make_augment("augment_edge2")
     if only == "augment":
         return
+    if only == "dvae_grad":
+        return _dvae_only()
     # training-step gradients: loss and parameter gradients of one step
     if True:
         make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, "grad_h32_bidir", data_seed=11, B=6, mean_n=30, H=32,
@@ -293,6 +353,11 @@ def main():
     ref_batch_mod = importlib.import_module("batch")
     ref_na = importlib.import_module("dagnn")
     ref_bn = importlib.import_module("dagnn_bn")
+    if only in (None, "dvae_grad"):
+        make_na_grad(ref_na, ref_util, "grad_na_h64_unidir", hs=64, L=2, bidir=False, w_seed=211, nrows=24)
+        make_bn_grad(ref_bn, ref_util, "grad_bn_h64_bidir", hs=64, L=2, bidir=True, w_seed=212, data_seed=7, nrows=20)
+    if only == "dvae_grad":
+        return
     make_na(ref_na, ref_util, ref_batch_mod, "na_h128_unidir", hs=128, L=2, bidir=False, w_seed=201)
     make_na(ref_na, ref_util, ref_batch_mod, "na_h64_bidir", hs=64, L=2, bidir=True, w_seed=202, nrows=16)
     make_bn(ref_bn, ref_util, ref_batch_mod, "bn_h256_bidir", hs=256, L=2, bidir=True, w_seed=203, data_seed=5,

@@ -18,6 +18,7 @@ CODE2 = ["code2_h32_bidir", "code2_h256_bidir", "code2_h512_L5", "code2_h300_L3"
          "code2_h64_numclass", "code2_h128_deep", "code2_h64_attn_x", "code2_h64_self_attn_h",
          "code2_h64_self_attn_x"]
 GRAD = ["grad_h32_bidir", "grad_h256_bidir", "grad_h128_deep", "grad_h64_L3_wx"]
+DVAE_GRAD = ["grad_na_h64_unidir", "grad_bn_h64_bidir"]
 DVAE = ["na_h128_unidir", "na_h64_bidir", "bn_h256_bidir", "bn_h64_unidir"]
 
 
@@ -44,6 +45,14 @@ def code2_batch(arr, device="cpu"):
                            batch=t("batch"), _bi_layer_idx0=t("layer0"), _bi_layer_index0=ids,
                            _bi_layer_idx1=t("layer1"), _bi_layer_index1=ids.clone(),
                            num_graphs=int(arr["batch"].max()) + 1)
+
+
+def dvae_graphs(meta, arr):
+    """The fixture's graphs, decoded from its stored rows (ENAS / BN encodings) by our own decoders."""
+    import json as _json
+    from dagnn_amd import synth
+    rows = [_json.loads(r) for r in arr["rows"]]
+    return [(synth.decode_enas_row if meta["kind"] == "na" else synth.decode_bn_row)(r) for r in rows]
 
 
 def dvae_model(meta):

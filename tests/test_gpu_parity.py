@@ -548,3 +548,27 @@ def test_back_to_back_forwards_and_steps_are_race_free(device):
     assert all(torch.equal(ref[k], cell[k]) for k in ref)
     for arena in model._arenas.values():
         arena.check()
+
+
+# ----------------------------------------------------------------------------- D-VAE encoders under autograd
+@pytest.mark.parametrize("name", Hh.DVAE_GRAD)
+def test_dvae_encoder_gradients_match_reference_golden(device, name):
+    """`encode(list_of_graphs)` of DAGNN_NA / DAGNN_BN under autograd (dvae/dagnn.py:177-184): loss and the gradients
+    of every encoder parameter against the reference's own `.backward()`."""
+    meta, arr = Hh.load(name)
+    model, nn_ = Hh.dvae_model(meta)
+    model = model.to(device).train()
+    graphs = Hh.dvae_graphs(meta, arr)
+    mu, logvar = model.encode([g.clone() for g in graphs])
+    assert Hh.maxdiff(mu, arr["mu"]) < TOL and Hh.maxdiff(logvar, arr["logvar"]) < TOL
+    loss = (mu * torch.from_numpy(arr["r1"]).to(device)).sum() + (logvar * torch.from_numpy(arr["r2"]).to(device)).sum()
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(arr["loss"])) < 1e-4 * max(1.0, abs(float(arr["loss"])))
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    sd = model.state_dict()
+    for k in list(grads):   # aliased encoder GRUs (cells_d == grue_forward / grue_backward)
+        for k2, v2 in sd.items():
+            if k2 not in grads and v2.data_ptr() == sd[k].data_ptr():
+                grads[k2] = grads[k]
+    assert Hh.check_grads(meta, arr, grads, rtol=1e-4) < 1e-4

@@ -75,3 +75,17 @@ def test_oracle_training_step_gradients_match_reference(name):
                                 bidirectional=True, out_wx=kw["out_wx"], max_seq_len=meta["S"])
     assert abs(float(loss) - float(arr["loss"])) < 1e-5
     assert Hh.check_grads(meta, arr, grads, rtol=5e-5) < 5e-5
+
+
+@pytest.mark.parametrize("name", Hh.DVAE_GRAD)
+def test_oracle_dvae_encoder_gradients_match_reference(name):
+    """`dvae_grads` against the reference encoder's own `.backward()` (dvae/dagnn.py:177-184 under autograd)."""
+    import dagnn_amd
+    meta, arr = Hh.load(name)
+    model, nn_ = Hh.dvae_model(meta)
+    G = dagnn_amd.GraphBatch.from_data_list(Hh.dvae_graphs(meta, arr))
+    loss, grads = O.dvae_grads(model.state_dict(), G, torch.from_numpy(arr["r1"]), torch.from_numpy(arr["r2"]),
+                               num_layers=meta["L"], bidirectional=meta["bidir"], num_nodes=nn_,
+                               vids=meta["kind"] == "na")
+    assert abs(float(loss) - float(arr["loss"])) < 1e-4 * max(1.0, abs(float(arr["loss"])))
+    assert Hh.check_grads(meta, arr, grads, rtol=5e-5) < 5e-5

@@ -66,32 +66,42 @@ class Recurrence(torch.autograd.Function):
     PER_CELL = 8
 
     @staticmethod
-    def forward(ctx, mod, plan, B, x, *params):
+    def forward(ctx, mod, plan, B, fused, x, *params):
+        """fused: returns (read-out [B, .], states...) with the read-out done by the module's HIP hooks and the states
+        not differentiable; otherwise returns the states h[d][i] ([N, H] each, d over `dirs`, i over layers) as
+        differentiable outputs - any torch read-out can follow (other pools, all nodes, unidirectional)."""
         L, H, dirs = mod.num_layers, mod.hidden_dim, mod.dirs
         cells = mod._cells()
         keep = {}
         h = run_stack_lockstep(plan, x, cells, dirs, L, H, vid_nodes=mod._vid_nodes, arena=mod._arena_for(x), keep=keep)
-        out = mod._readout(plan, B, x, h)
-        ctx.mod, ctx.plan, ctx.cells, ctx.keep, ctx.h = mod, plan, cells, keep, h
+        ctx.mod, ctx.plan, ctx.cells, ctx.keep, ctx.h, ctx.fused = mod, plan, cells, keep, h, bool(fused)
         ctx.save_for_backward(x, *[p for p in params if p is not None])
         ctx.present = [p is not None for p in params]
         flat = [h[d][i] for d in dirs for i in range(L)]
+        if not fused:
+            return tuple(flat)
+        out = mod._readout(plan, B, x, h)
         ctx.mark_non_differentiable(*flat)
         return (out,) + tuple(flat)
 
     @staticmethod
-    def backward(ctx, gout, *_unused):
+    def backward(ctx, *gouts):
         mod, plan, cells, keep, h = ctx.mod, ctx.plan, ctx.cells, ctx.keep, ctx.h
         saved = list(ctx.saved_tensors)
         x, it = saved[0], iter(saved[1:])
         params = [next(it) if present else None for present in ctx.present]
         L, H, dirs, Hp = mod.num_layers, mod.hidden_dim, mod.dirs, keep["Hp"]
         N, dev = x.shape[0], x.device
-        gout = gout.contiguous().float()
         g_ext = [[torch.zeros(N, Hp, dtype=torch.float32, device=dev) if d in dirs else None for _ in range(L)]
                  for d in range(2)]
         dx = torch.zeros_like(x)
-        mod._readout_backward(plan, x, h, gout, g_ext, dx)
+        if ctx.fused:
+            mod._readout_backward(plan, x, h, gouts[0].contiguous().float(), g_ext, dx)
+        else:   # gradients of the states themselves, from whatever torch read-out followed
+            for q, d in enumerate(dirs):
+                for i in range(L):
+                    if gouts[q * L + i] is not None:
+                        g_ext[d][i][:, :H] = gouts[q * L + i]
         res = engine.backward_sweep(plan, dirs, L, Hp, cells, keep["h_buf"], keep["gi0"], g_ext,
                                     arena=mod._arena_for(x, "backward"), vid_mod=mod._vid_nodes)
 
@@ -128,4 +138,4 @@ class Recurrence(torch.autograd.Function):
                     g_attn[0, dq + H:dq + H + mod._vid_nodes] = sigma.view(-1, mod._vid_nodes).sum(0)
                 grads += [g_wih, g_whh, g_bih, g_bhh, g_attn, None if attn_b is None else torch.zeros_like(attn_b),
                           g_edge_w, g_edge_b]
-        return (None, None, None, dx if x.requires_grad else None) + tuple(grads)
+        return (None, None, None, None, dx if x.requires_grad else None) + tuple(grads)

@@ -189,7 +189,7 @@ class _DvaeDagnn(_DvaeBase):
         plan = engine.build_plan(G.edge_index, bl[0][0], bl[1][0], G.batch, B, None)
         if train:
             from .autograd import Recurrence
-            hcat = Recurrence.apply(self, plan, B, x, *self._train_params())[0]
+            hcat = Recurrence.apply(self, plan, B, True, x, *self._train_params())[0]
         else:
             h = run_stack(plan, x, self._cells(), self.dirs, L, H, vid_nodes=self._vid_nodes,
                           schedule=self.schedule, arena=self._arena_for(x))

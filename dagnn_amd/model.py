@@ -245,13 +245,11 @@ class DAGNN(nn.Module):
         nodes); other combinations raise instead of silently detaching."""
         if not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
             return False
-        ok = (self.agg == K.NA_ATTN_H and self.bidirectional and not self.output_all and self.out_pool == K.P_MAX
-              and self.schedule == "lockstep" and self.emb_dim % 4 == 0)
+        ok = self.agg == K.NA_ATTN_H and self.schedule == "lockstep" and self.emb_dim % 4 == 0
         if not ok:
             raise NotImplementedError(
-                "the HIP backward pass covers agg='attn_h', bidirectional=True, out_pool_all=False, out_pool='max' "
-                "with the lock-step schedule; call this configuration under torch.no_grad() (evaluation) or "
-                "freeze its parameters")
+                "the HIP backward pass covers agg='attn_h' (any read-out) with the lock-step schedule; call this "
+                "configuration under torch.no_grad() (evaluation) or freeze its parameters")
         return True
 
     # hooks of autograd.Recurrence
@@ -328,31 +326,40 @@ class DAGNN(nn.Module):
         else:
             plan = engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B,
                                      G.edge_attr if has_edge_enc else None)
+        fused_readout = self.bidirectional and not self.output_all and self.out_pool == K.P_MAX
         if train:
+            # differentiable call: HIP read-out + its backward for the configuration the reference trains
+            # (scripts/ogb_tok.sh), otherwise differentiable states and the torch read-outs below
             from .autograd import Recurrence
-            res = Recurrence.apply(self, plan, B, x, *self._train_params())
-            out, flat = res[0], res[1:]
-            G.h = [[flat[q * L + i] for i in range(L)] for q in range(len(dirs))]
-            out = self.dropout(out)
-            if self.num_class > 0:
-                return self.graph_pred_linear(out)
-            return [self.graph_pred_linear_list[i](out) for i in range(self.max_seq_len)]
+            res = Recurrence.apply(self, plan, B, fused_readout, x, *self._train_params())
+            flat = res[1:] if fused_readout else res
+            h = [[None] * L for _ in range(2)]
+            for q, d in enumerate(dirs):
+                for i in range(L):
+                    h[d][i] = flat[q * L + i]
+            if fused_readout:
+                G.h = [[h[d][i] for i in range(L)] for d in dirs]
+                out = self.dropout(res[0])
+                if self.num_class > 0:
+                    return self.graph_pred_linear(out)
+                return [self.graph_pred_linear_list[i](out) for i in range(self.max_seq_len)]
+            return self._finish(G, plan, x, h, B)
         cells = self._cells()
         sscore = None
         if self.agg_attn_x:  # keys are the node inputs: one static score per node and cell (dagnn.py:175-177)
             sscore = {k: torch.mv(x, c.key_raw) for k, c in cells.items()}
         h = run_stack(plan, x, cells, dirs, L, H, schedule=self.schedule, static_score=sscore,
                       arena=self._arena_for(x))
+        return self._finish(G, plan, x, h, B)
+
+    def _finish(self, G, plan, x, h, B):
+        """Read-out + heads (dagnn.py:184-215) on the states h[d][i]."""
+        L, dirs = self.num_layers, self.dirs
         G.h = [[h[d][i] for i in range(L)] for d in dirs]  # side effect 4 (dagnn.py:141-142,182)
 
         if self.bidirectional and not self.output_all:
             if self.out_pool == K.P_MAX:
-                out = torch.empty(B, self.out_hidden_dim, dtype=torch.float32, device=x.device)
-                col = 0
-                for d in (0, 1):
-                    for t in ([x] if self.out_wx else []) + [h[d][i] for i in range(L)]:
-                        engine.readout_max(plan, t, d, out, col)
-                        col += t.shape[1]
+                out = self._readout(plan, B, x, h)
             else:
                 outs = []
                 for d in (0, 1):

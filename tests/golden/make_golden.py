@@ -156,7 +156,8 @@ def make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, name, *, data_seed, B, m
     for k, p_ in model.named_parameters():
         g = np.zeros(tuple(p_.shape), np.float32) if p_.grad is None else _np(p_.grad)
         arrays["g::" + k], strides[k], arrays["gsum::" + k] = sample_grad(k, g)
-    meta = dict(kind="code2_grad", data_seed=data_seed, B=B, mean_n=mean_n, max_n=max_n, H=H, L=L, bidir=True,
+    meta = dict(kind="code2_grad", data_seed=data_seed, B=B, mean_n=mean_n, max_n=max_n, H=H, L=L,
+                bidir=bool(kw["bidirectional"]),
                 V=V, S=S, n_attr=n_attr, w_seed=w_seed, y_seed=y_seed, ctor=kw, N=int(b.x.shape[0]),
                 E=int(b.edge_index.shape[1]), T=int(b._bi_layer_idx0.max()) + 1, grad_stride=strides,
                 state_dict={k: list(v.shape) for k, v in model.state_dict().items()})
@@ -320,6 +321,12 @@ def main():
                         L=2, w_seed=107, y_seed=303, **common)
         make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, "grad_h64_L3_wx", data_seed=21, B=5, mean_n=40, H=64,
                         L=3, w_seed=121, y_seed=304, out_wx=True, **common)
+        # read-outs that go through torch ops on differentiable states: unidirectional (dagnn.py:195-202 branch),
+        # mean pooling over all nodes of both directions
+        make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, "grad_h64_unidir", data_seed=22, B=6, mean_n=35, H=64,
+                        L=2, w_seed=122, y_seed=305, bidirectional=False, **common)
+        make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, "grad_h64_mean_all", data_seed=23, B=6, mean_n=35, H=64,
+                        L=2, w_seed=123, y_seed=306, out_pool_all=True, out_pool="mean", **common)
     if only == "grad":
         return
 

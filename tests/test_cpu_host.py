@@ -178,7 +178,7 @@ def test_grad_mode_raises_instead_of_silently_detaching():
     the HIP path (and, on CPU tensors, fails loudly there - there is no fallback)."""
     meta, arr = Hh.load("code2_h64_unidir")
     model = Hh.code2_model(meta)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(_lib.DagnnHipError):   # every attn_h read-out is differentiable through the HIP path
         model(Hh.code2_batch(arr))
     meta, arr = Hh.load("code2_h64_attn_x")
     with pytest.raises(NotImplementedError):

@@ -72,7 +72,8 @@ def test_oracle_training_step_gradients_match_reference(name):
     G = Hh.code2_batch(arr)
     kw = meta["ctor"]
     loss, grads = O.code2_grads(model.state_dict(), G, torch.from_numpy(arr["y"]), num_layers=kw["num_layers"],
-                                bidirectional=True, out_wx=kw["out_wx"], max_seq_len=meta["S"])
+                                bidirectional=bool(kw["bidirectional"]), out_wx=kw["out_wx"],
+                                out_pool_all=kw["out_pool_all"], out_pool=kw["out_pool"], max_seq_len=meta["S"])
     assert abs(float(loss) - float(arr["loss"])) < 1e-5
     assert Hh.check_grads(meta, arr, grads, rtol=5e-5) < 5e-5
 

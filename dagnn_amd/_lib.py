@@ -58,7 +58,7 @@ class FrontierArgs(C.Structure):
 
 
 class BackwardCell(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("w_hh", "w_ih", "w_key", "edge_gain", "vid_bias", "h", "a", "alpha", "gi", "gh", "g_ext",
+    _fields_ = [(k, C.c_void_p) for k in ("w_hh", "w_ih", "w_key", "edge_gain", "vid_bias", "static_score", "h", "a", "alpha", "gi", "gh", "g_ext",
                                           "da", "dgi", "dgh", "sigma", "edge_feat_grad", "da_granules", "du_granules",
                                           "g_ext_static")]
 

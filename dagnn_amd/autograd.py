@@ -73,8 +73,11 @@ class Recurrence(torch.autograd.Function):
         L, H, dirs = mod.num_layers, mod.hidden_dim, mod.dirs
         cells = mod._cells()
         keep = {}
-        h = run_stack_lockstep(plan, x, cells, dirs, L, H, vid_nodes=mod._vid_nodes, arena=mod._arena_for(x), keep=keep)
+        sscore = mod._static_scores(x, cells)   # keys from the inputs (`*_x` aggregators): one score per node and cell
+        h = run_stack_lockstep(plan, x, cells, dirs, L, H, vid_nodes=mod._vid_nodes, arena=mod._arena_for(x), keep=keep,
+                               static_score=sscore)
         ctx.mod, ctx.plan, ctx.cells, ctx.keep, ctx.h, ctx.fused = mod, plan, cells, keep, h, bool(fused)
+        ctx.sscore = sscore
         ctx.save_for_backward(x, *[p for p in params if p is not None])
         ctx.present = [p is not None for p in params]
         flat = [h[d][i] for d in dirs for i in range(L)]
@@ -103,7 +106,8 @@ class Recurrence(torch.autograd.Function):
                     if gouts[q * L + i] is not None:
                         g_ext[d][i][:, :H] = gouts[q * L + i]
         res = engine.backward_sweep(plan, dirs, L, Hp, cells, keep["h_buf"], keep["gi0"], g_ext,
-                                    arena=mod._arena_for(x, "backward"), vid_mod=mod._vid_nodes)
+                                    arena=mod._arena_for(x, "backward"), vid_mod=mod._vid_nodes,
+                                    static_score=ctx.sscore)
 
         def gates(t):  # [N, 3Hp] in gate blocks of Hp -> [N, 3H]
             return t if Hp == H else t.view(N, 3, Hp)[:, :, :H].reshape(N, 3 * H)
@@ -125,17 +129,21 @@ class Recurrence(torch.autograd.Function):
                 # that cancel in the segment softmax: their gradients are exact zeros)
                 dq = mod._key_offset(i)
                 sigma = r["sigma"]
-                g_key = (h[d][i] * sigma[:, None]).sum(0)
+                kd = attn_w.shape[1] - dq - mod._vid_nodes     # key width: H, or the input width for the `*_x` aggregators
+                keys = x if ctx.sscore is not None else h[d][i]
+                g_key = (keys * sigma[:, None]).sum(0)
+                if ctx.sscore is not None and x.requires_grad:   # the score of node v is w_key . x_v
+                    dx = dx + sigma[:, None] * attn_w[0, dq:dq + kd][None, :]
                 g_edge_w = g_edge_b = None
                 if edge_w is not None:
                     m, ssum = r["edge_feat_grad"].sum(0), sigma.sum()
-                    w_key = attn_w[0, dq:dq + H]
+                    w_key = attn_w[0, dq:dq + kd]
                     g_key = g_key + edge_w @ m + edge_b * ssum
                     g_edge_w, g_edge_b = torch.outer(w_key, m), w_key * ssum
                 g_attn = torch.zeros_like(attn_w)
-                g_attn[0, dq:dq + H] = g_key
+                g_attn[0, dq:dq + kd] = g_key
                 if mod._vid_nodes:   # node v carries the one-hot of (v mod n): d w_vid[j] = sum of sigma over those nodes
-                    g_attn[0, dq + H:dq + H + mod._vid_nodes] = sigma.view(-1, mod._vid_nodes).sum(0)
+                    g_attn[0, dq + kd:dq + kd + mod._vid_nodes] = sigma.view(-1, mod._vid_nodes).sum(0)
                 grads += [g_wih, g_whh, g_bih, g_bhh, g_attn, None if attn_b is None else torch.zeros_like(attn_b),
                           g_edge_w, g_edge_b]
         return (None, None, None, None, dx if x.requires_grad else None) + tuple(grads)

@@ -49,6 +49,7 @@ struct BCell {
     const float* wkey;   // [H]
     const float* gain;   // [R] or null
     const float* vid;    // [vid_mod] per-vertex-id score bias of the NA variant (dvae/dagnn.py:130-134) or null
+    const float* sscore; // [N] static attention score of every node (keys taken from the inputs x), or null
     const float* h;      // [N,ld_h] states + partial scores of this cell (forward output)
     const float* a;      // [N,H]
     float* a_w;          // same buffer, written by the prepare kernel
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(BT) bwd_prepare_kernel(const int32_t* __restri
         return;
     }
     auto logit = [&](int e) {
-        float s = bscore(C.h + (int64_t)col[e] * ld_h + H, nparts);
+        float s = C.sscore ? C.sscore[col[e]] : bscore(C.h + (int64_t)col[e] * ld_h + H, nparts);
         if (C.vid) s += C.vid[col[e] % S.vid_mod];
         for (int r = 0; r < R; ++r) s = fmaf(C.gain[r], eattr[(int64_t)e * R + r], s);
         return s;
@@ -837,6 +838,7 @@ void fill_cells(BArgs& S, const dagnn_backward_args* a, const int* dirs, int ndi
             K.whh = (const float*)c.w_hh; K.wih = i > 0 ? (const float*)c.w_ih : nullptr;
             K.wkey = (const float*)c.w_key; K.gain = (const float*)c.edge_gain;
             K.vid = a->vid_mod > 0 ? (const float*)c.vid_bias : nullptr;
+            K.sscore = (const float*)c.static_score;
             K.h = (const float*)c.h; K.a = (const float*)c.a; K.a_w = (float*)c.a; K.alpha = (float*)c.alpha;
             K.gi = (const float*)c.gi; K.gh = (const float*)c.gh; K.gext = (const float*)c.g_ext;
             K.gext_lo = i > 0 ? (float*)a->cell[dirs[q]][i - 1].g_ext : nullptr;

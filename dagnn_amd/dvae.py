@@ -135,6 +135,9 @@ class _DvaeDagnn(_DvaeBase):
     def _key_offset(self, i: int) -> int:
         return self.emb_dim if i == 0 else self.hidden_dim + self._vid_nodes
 
+    def _static_scores(self, x, cells):
+        return None
+
     def _arena_for(self, x, role="forward"):
         return self._arenas.setdefault((role, x.device, torch.cuda.current_stream(x.device).cuda_stream),
                                        engine.GranuleArena())

@@ -420,7 +420,7 @@ def readout_max_backward(plan: PlanHandle, h: torch.Tensor, direction: int, grad
 
 
 def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, h, gi0, g_ext,
-                   arena: Optional[GranuleArena] = None, vid_mod: int = 0):
+                   arena: Optional[GranuleArena] = None, vid_mod: int = 0, static_score=None):
     """Reverse pass of the lock-step recurrence (csrc/backward.hip).  `h[d][i]` [N, frontier_ld(H)] are the
     forward state buffers, `gi0[d]` [N,3H] the input-side pre-activations of stacked layer 0, `g_ext[d][i]`
     [N,H] the gradients reaching the states from outside (modified: stacked layers below the top receive the
@@ -435,6 +435,7 @@ def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells,
     gkeys = [("da", d, i) for d in dirs for i in range(L)] + [("du", d, i) for d in dirs for i in range(L - 1)]
     gran, epoch, err = arena.get(gkeys, N, H, dev) if use_tail else ({}, 0, None)
     keep = []
+    keep_alive = keep
     for d in dirs:
         mask |= 1 << d
         for i in range(L):
@@ -450,7 +451,13 @@ def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells,
                      edge_feat_grad=torch.empty(N, R, **f32) if R > 0 else None)
             out[(d, i)] = o
             bc.w_hh, bc.w_ih = c.w_hh_raw.data_ptr(), (c.w_ih.data_ptr() if i > 0 else None)
-            bc.w_key, bc.edge_gain = c.w_key.data_ptr(), (_ptr(c.edge_gain) if R > 0 else None)
+            if static_score is not None:   # keys from the inputs: scores are given, the states' gradient gets no key term
+                zero_key = torch.zeros(H, **f32)
+                keep_alive.append(zero_key)
+                bc.w_key, bc.static_score = zero_key.data_ptr(), _dev(static_score[(d, i)], "static score", torch.float32).data_ptr()
+            else:
+                bc.w_key = c.w_key.data_ptr()
+            bc.edge_gain = _ptr(c.edge_gain) if R > 0 else None
             bc.vid_bias = _ptr(c.vid_bias) if vid_mod > 0 else None
             bc.h, bc.a, bc.alpha = h[d][i].data_ptr(), o["a"].data_ptr(), o["alpha"].data_ptr()
             bc.g_ext, bc.da, bc.dgi, bc.dgh = g_ext[d][i].data_ptr(), o["da"].data_ptr(), o["dgi"].data_ptr(), o["dgh"].data_ptr()

@@ -245,11 +245,11 @@ class DAGNN(nn.Module):
         nodes); other combinations raise instead of silently detaching."""
         if not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
             return False
-        ok = self.agg == K.NA_ATTN_H and self.schedule == "lockstep" and self.emb_dim % 4 == 0
+        ok = self._hip_supported() and self.schedule == "lockstep" and self.emb_dim % 4 == 0
         if not ok:
             raise NotImplementedError(
-                "the HIP backward pass covers agg='attn_h' (any read-out) with the lock-step schedule; call this "
-                "configuration under torch.no_grad() (evaluation) or freeze its parameters")
+                "the HIP backward pass covers the aggregators %s (any read-out) with the lock-step schedule; call "
+                "this configuration under torch.no_grad() (evaluation) or freeze its parameters" % (self._HIP_AGGS,))
         return True
 
     # hooks of autograd.Recurrence
@@ -257,6 +257,12 @@ class DAGNN(nn.Module):
 
     def _key_offset(self, i: int) -> int:
         return self._attn_geometry(i)[0]
+
+    def _static_scores(self, x, cells):
+        """`*_x` aggregators: the keys are the node inputs, one score per node and cell (dagnn.py:175-177)."""
+        if not self.agg_attn_x:
+            return None
+        return {k: torch.mv(x.detach(), c.key_raw) for k, c in cells.items()}
 
     def _readout(self, plan, B, x, h):
         """Max-pool over the output nodes of both directions (dagnn.py:184-193), columns [d][x?, layer 0.. L-1]."""
@@ -345,9 +351,7 @@ class DAGNN(nn.Module):
                 return [self.graph_pred_linear_list[i](out) for i in range(self.max_seq_len)]
             return self._finish(G, plan, x, h, B)
         cells = self._cells()
-        sscore = None
-        if self.agg_attn_x:  # keys are the node inputs: one static score per node and cell (dagnn.py:175-177)
-            sscore = {k: torch.mv(x, c.key_raw) for k, c in cells.items()}
+        sscore = self._static_scores(x, cells)
         h = run_stack(plan, x, cells, dirs, L, H, schedule=self.schedule, static_score=sscore,
                       arena=self._arena_for(x))
         return self._finish(G, plan, x, h, B)

@@ -261,6 +261,8 @@ typedef struct dagnn_backward_cell {
     const float* w_key;     /* [H] */
     const float* edge_gain; /* [num_edge_feats] or NULL */
     const float* vid_bias;  /* [vid_mod] or NULL: score bias by vertex id (NA variant), as in dagnn_frontier_cell */
+    const float* static_score; /* NULL, or [N]: the nodes' attention scores when the keys are the inputs (`attn_x`,
+                             * `self_attn_x`); pass an all-zero w_key then (the scores do not depend on the states) */
     const float* h;         /* [N,ld_h] forward states + partial scores */
     float* a;               /* [N,H]  written by prepare, read by run */
     float* alpha;           /* [E]    written by prepare, read by run */

@@ -181,8 +181,12 @@ def test_grad_mode_raises_instead_of_silently_detaching():
     with pytest.raises(_lib.DagnnHipError):   # every attn_h read-out is differentiable through the HIP path
         model(Hh.code2_batch(arr))
     meta, arr = Hh.load("code2_h64_attn_x")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(_lib.DagnnHipError):
         Hh.code2_model(meta)(Hh.code2_batch(arr))
+    model = Hh.code2_model(meta)
+    model.schedule = "pergraph"   # the backward sweep exists for the lock-step schedule only
+    with pytest.raises(NotImplementedError):
+        model(Hh.code2_batch(arr))
     meta, arr = Hh.load("code2_h32_bidir")
     with pytest.raises(_lib.DagnnHipError):
         Hh.code2_model(meta)(Hh.code2_batch(arr))

@@ -572,3 +572,21 @@ def test_dvae_encoder_gradients_match_reference_golden(device, name):
             if k2 not in grads and v2.data_ptr() == sd[k].data_ptr():
                 grads[k2] = grads[k]
     assert Hh.check_grads(meta, arr, grads, rtol=1e-4) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["code2_h64_attn_x", "code2_h64_self_attn_h", "code2_h64_self_attn_x"])
+def test_training_step_other_additive_aggregators_match_oracle_autograd(device, name):
+    """The other additive-attention aggregators (keys from the inputs: static scores; no query) under autograd,
+    against autograd through the oracle (itself pinned against the reference's forward for these aggregators)."""
+    meta, arr = Hh.load(name)
+    kw = meta["ctor"]
+    model = Hh.code2_model(meta)
+    y = torch.from_numpy(np.random.default_rng(3).integers(0, meta["V"], size=(int(arr["batch"].max()) + 1, meta["S"])))
+    loss_ref, ref = O.code2_grads(model.state_dict(), Hh.code2_batch(arr), y, num_layers=kw["num_layers"],
+                                  bidirectional=True, out_wx=kw["out_wx"], max_seq_len=meta["S"], agg=kw["agg"])
+    model = model.to(device)
+    loss, grads = _train_step(model, Hh.code2_batch(arr, device), y.to(device))
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    for k, g in grads.items():
+        scale = float(ref[k].abs().max())
+        assert Hh.maxdiff(g, ref[k]) <= 1e-4 * scale + 2e-7, k

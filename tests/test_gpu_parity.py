@@ -590,3 +590,23 @@ def test_training_step_other_additive_aggregators_match_oracle_autograd(device, 
     for k, g in grads.items():
         scale = float(ref[k].abs().max())
         assert Hh.maxdiff(g, ref[k]) <= 1e-4 * scale + 2e-7, k
+
+
+@pytest.mark.parametrize("H,L", [(512, 3), (320, 2)])
+def test_training_step_wide_hidden_matches_oracle_autograd(device, H, L):
+    """Hidden sizes beyond the register-resident path: H = 512 (streamed slice kernel, K-chunked MFMA tiles, no
+    persistent kernels) and H = 320 (padded to 384, not MFMA-eligible: 8-row blocks), with fat layers present."""
+    meta = dict(H=H, n_attr=300, V=24, S=2, w_seed=55,
+                ctor=dict(w_edge_attr=True, num_layers=L, bidirectional=True, agg="attn_h", out_wx=False,
+                          out_pool_all=False, out_pool="max", dropout=0.0))
+    model = Hh.code2_model(meta)
+    b = synth.code2_batch(41, 40, 60)
+    b.x[:, 1] %= 300
+    y = torch.from_numpy(np.random.default_rng(6).integers(0, 24, size=(40, 2)))
+    loss_ref, ref = O.code2_grads(model.state_dict(), b.clone(), y, num_layers=L, bidirectional=True, max_seq_len=2)
+    model = model.to(device)
+    loss, grads = _train_step(model, b.clone().to(device), y.to(device))
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    for k, g in grads.items():
+        scale = float(ref[k].abs().max())
+        assert Hh.maxdiff(g, ref[k]) <= 1e-4 * scale + 2e-7, k

@@ -6,10 +6,10 @@ batch including its side effects on `G` (`G.bi_layer_index`, `G.x` replaced by t
 `G.node_depth` clamped, `G.h`).  The layer-by-layer gather -> attention-aggregate -> GRU path
 runs in hand-written HIP (libdagnn_hip.so); there is no CPU or eager-PyTorch fallback for it.
 
-Aggregators: `attn_h` (every BASELINE config) runs in HIP.  The reference's other aggregator
-strings (`self_attn_*`, `mattn_h`, `gated_sum`, `add`, `max`, `attn_x`, `agg_x`, `recurr=0`) keep
-their constructor / state_dict support but `forward` raises NotImplementedError for them (SURVEY.md
-§8(a) row a12, "next").
+Aggregators: the additive-attention family (`attn_h` - every BASELINE config - `attn_x`, `self_attn_h`,
+`self_attn_x`) runs in HIP, forward and backward.  The reference's other constructor strings (`mattn_h`,
+`gated_sum`, `add`, `max`, `agg_x=True`, `recurr=0`; SURVEY.md §8(a) row a12: exercised by no BASELINE
+configuration) keep the same contract and run on torch-ROCm ops (`dagnn_amd/variants.py`).
 """
 from __future__ import annotations
 
@@ -312,12 +312,18 @@ class DAGNN(nn.Module):
 
     # ------------------------------------------------------------------------------ forward
     def forward(self, G):
-        if not self._hip_supported():
-            raise NotImplementedError(
-                "aggregator %r / agg_x=%r / recurr=%r: the HIP path implements the additive-attention aggregators "
-                "%s with agg_x=False, recurr=1" % (self.agg, self.agg_x, self.recurr, (self._HIP_AGGS,)))
-        train = self._training_pass()
         L, H, dirs = self.num_layers, self.hidden_dim, self.dirs
+        if not self._hip_supported():
+            # constructor strings outside every BASELINE configuration: same contract, torch-ROCm ops
+            if not G.x.is_cuda:
+                raise engine.DagnnHipError("DAGNN.forward needs its batch on a ROCm GPU (there is no CPU path)")
+            from . import variants
+            G.bi_layer_index = torch.stack([torch.stack([G._bi_layer_idx0, G._bi_layer_index0], dim=0),
+                                            torch.stack([G._bi_layer_idx1, G._bi_layer_index1], dim=0)], dim=0)
+            B = num_graphs_of(G)
+            G.x = self.encoder(G.x, G.node_depth.view(-1, ))
+            return self._finish(G, None, G.x, variants.run(self, G, G.x), B)
+        train = self._training_pass()
 
         # side effect 1 (dagnn.py:130-133)
         G.bi_layer_index = torch.stack([torch.stack([G._bi_layer_idx0, G._bi_layer_index0], dim=0),
@@ -362,8 +368,9 @@ class DAGNN(nn.Module):
         G.h = [[h[d][i] for i in range(L)] for d in dirs]  # side effect 4 (dagnn.py:141-142,182)
 
         if self.bidirectional and not self.output_all:
-            if self.out_pool == K.P_MAX:
-                out = self._readout(plan, B, x, h)
+            differentiable = torch.is_grad_enabled() and any(h[d][i].requires_grad for d in dirs for i in range(L))
+            if self.out_pool == K.P_MAX and plan is not None and not differentiable:
+                out = self._readout(plan, B, x, h)   # HIP max-pool over the output nodes
             else:
                 outs = []
                 for d in (0, 1):

@@ -19,6 +19,7 @@ each function follows:
 * `recurrence_faithful`   - the three nested loops `dagnn.py:144-182` op for op: per-node scan of
                             the whole `edge_index` (:153-155), aggregation into all N rows (:179)
 * `recurrence_csr`        - same math on a layer-sorted CSR (what the HIP path implements)
+* `conv_variant`, `recurrence_variants` - the other aggregators / `agg_x` / `recurr=0` (`dagnn.py:159-169,232-313,379-409`)
 * `code2_forward`         - `DAGNN.forward` `dagnn.py:128-215` (read-outs :184-202, heads :209-215)
 * `code2_grads`           - one training step's loss + gradients, `ogbg-code/main_pyg.py:55-62`
 * `dvae_forward/encode`   - `dvae/dagnn.py:99-184` (NA, `vids` key bias :130-139) and
@@ -31,6 +32,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 Tensor = torch.Tensor
+ADDITIVE_ATTN = ("attn_h", "attn_x", "self_attn_h", "self_attn_x")
 
 
 # ------------------------------------------------------------------------------ building blocks
@@ -205,6 +207,96 @@ def recurrence_csr(cfg: _Cfg, x: Tensor, edge_index: Tensor, edge_attr: Optional
     return h
 
 
+# ------------------------------------------------------------------------------ variants (row a12)
+def _propagate(msg: Tensor, index: Tensor, num_nodes: int, reduce: str) -> Tensor:
+    """PyG-1.6 `propagate` tail: scatter the messages onto `index`; rows nothing lands on are zero."""
+    out = msg.new_zeros(num_nodes, msg.shape[1])
+    if reduce == "add":
+        return out.index_add_(0, index, msg)
+    return out.scatter_reduce_(0, index.view(-1, 1).expand_as(msg), msg, "amax", include_self=False)
+
+
+def conv_variant(sd: Dict[str, Tensor], prefix: str, agg: str, vals: Tensor, lp: Tensor, reverse: bool,
+                 edge_attr: Optional[Tensor], h_attn: Optional[Tensor], h_attn_q: Optional[Tensor]) -> Tensor:
+    """One call of the reference's conv modules on the step's edge list `lp` [2, E_f], result for ALL N nodes:
+    `AggConv` add|max (`dagnn.py:232-251`), `GatedSumConv` (:254-276), `SelfAttnConv` (:279-313), `AttnConv`
+    (:347-376), `MultAttnConv` (:379-409).  `reverse` = the module was built with flow target_to_source (messages go
+    from lp[1] to lp[0]); the shared `AggConv` never is (`dagnn.py:74-75`)."""
+    N = vals.shape[0]
+    i_row, j_row = (0, 1) if reverse else (1, 0)
+    e = None
+    if prefix + "edge_encoder.weight" in sd and edge_attr is not None:
+        e = edge_attr @ sd[prefix + "edge_encoder.weight"].t() + sd[prefix + "edge_encoder.bias"]
+    hj = vals[lp[j_row]]
+    if agg in ("add", "max"):
+        return _propagate(hj + e if e is not None else hj, lp[i_row], N, agg)
+    if agg == "gated_sum":
+        m = hj + e if e is not None else hj
+        gate = torch.sigmoid(m @ sd[prefix + "gate.0.weight"].t() + sd[prefix + "gate.0.bias"])
+        mapped = m @ sd[prefix + "mapper.weight"].t()
+        if prefix + "mapper.bias" in sd:
+            mapped = mapped + sd[prefix + "mapper.bias"]
+        return _propagate(gate * mapped, lp[i_row], N, "add")
+    k = (h_attn if h_attn is not None else vals)[lp[j_row]]
+    if e is not None:
+        k = k + e
+    if "mattn" in agg:
+        ql = h_attn_q[lp[i_row]] @ sd[prefix + "attn_linl.weight"].t() + sd[prefix + "attn_linl.bias"]
+        kr = k @ sd[prefix + "attn_linr.weight"].t() + sd[prefix + "attn_linr.bias"]
+        logit = (ql * kr).sum(1)
+    elif "self_attn" in agg:
+        logit = (k @ sd[prefix + "attn_lin.weight"].t() + sd[prefix + "attn_lin.bias"]).squeeze(-1)
+    else:
+        logit = (torch.cat([h_attn_q[lp[i_row]], k], -1) @ sd[prefix + "attn_lin.weight"].t()
+                 + sd[prefix + "attn_lin.bias"]).squeeze(-1)
+    alpha = segment_softmax(logit, lp[i_row], N)
+    return _propagate(hj * alpha.unsqueeze(-1), lp[i_row], N, "add")
+
+
+def recurrence_variants(sd: Dict[str, Tensor], x: Tensor, edge_index: Tensor, edge_attr: Optional[Tensor],
+                        layers: Sequence[Tensor], *, dirs: Sequence[int], L: int, H: int, agg: str, agg_x: bool,
+                        recurr: int) -> List[List[Tensor]]:
+    """Op-for-op mirror of `dagnn.py:144-182` for every constructor string (aggregator, `agg_x`, `recurr=0`): per-node
+    edge scan, convs evaluated for all N nodes, frontier rows taken afterwards."""
+    N = x.shape[0]
+    ids = torch.arange(N)
+    agg_attn, agg_attn_x = "attn" in agg, "_x" in agg
+    shared = agg in ("add", "max")   # one AggConv module for both directions: never reversed
+    h = [[x.new_zeros(N, H) for _ in range(L)] for _ in dirs]
+    T = int(layers[0].max()) + 1
+    for d in dirs:
+        for t in range(T):
+            layer = ids[layers[d] == t]
+            inp = x[layer]
+            if t > 0:
+                le = torch.cat([(edge_index[1 - d] == n).nonzero().squeeze(-1) for n in layer], dim=-1)
+                lp, ea = edge_index[:, le], (edge_attr[le] if edge_attr is not None else None)
+                if agg_x:
+                    ps_x = conv_variant(sd, "node_aggr_%d.0." % d, agg, x, lp, d == 1 and not shared, ea,
+                                        x if agg_attn else None, x if agg_attn else None)[layer]
+                    if ps_x.shape[1] < H:
+                        ps_x = torch.cat([ps_x, ps_x.new_zeros(ps_x.shape[0], H - ps_x.shape[1])], -1)
+            for i in range(L):
+                if t == 0:
+                    ps = None if recurr else x.new_zeros(inp.shape[0], H)
+                elif agg_x:
+                    ps = ps_x
+                else:
+                    h_attn = h_attn_q = None
+                    if agg_attn:
+                        h_attn = x if agg_attn_x else h[d][i]
+                        h_attn_q = x if agg_attn_x else (h[d][i - 1] if i > 0 else x)
+                    ps = conv_variant(sd, "node_aggr_%d.%d." % (d, i), agg, h[d][i], lp, d == 1 and not shared, ea,
+                                      h_attn, h_attn_q)[layer]
+                p = "cells_%d.%d." % (d, i)
+                if recurr:
+                    inp = gru_cell(inp, ps, sd[p + "weight_ih"], sd[p + "weight_hh"], sd[p + "bias_ih"], sd[p + "bias_hh"])
+                else:
+                    inp = torch.cat([inp, ps], 1) @ sd[p + "weight"].t() + sd[p + "bias"]
+                h[d][i][layer] += inp
+    return h
+
+
 # ------------------------------------------------------------------------------ read-outs
 def _pool(x: Tensor, batch: Tensor, how: str) -> Tensor:
     B = int(batch.max()) + 1
@@ -229,22 +321,27 @@ def _cast(sd, dtype, keep_graph=False):
 def code2_forward(sd: Dict[str, Tensor], G, *, num_layers: int = 2, bidirectional: bool = True,
                   out_wx: bool = False, out_pool_all: bool = False, out_pool: str = "max",
                   max_seq_len: int = 5, num_class: int = 0, mode: str = "csr",
-                  dtype: torch.dtype = torch.float32, agg: str = "attn_h", keep_graph: bool = False):
+                  dtype: torch.dtype = torch.float32, agg: str = "attn_h", keep_graph: bool = False,
+                  agg_x: bool = False, recurr: int = 1):
     """`DAGNN.forward` of `ogbg-code/model/dagnn.py:128-215` for the additive-attention aggregators
     (`agg` in attn_h, attn_x, self_attn_h, self_attn_x), `recurr=1`, `agg_x=False`.  Reproduces the side effects on G (`G.x`, `G.h`, `G.bi_layer_index`, clamped
     `G.node_depth`, and `G.batch` on the unidirectional branch).  Returns a list of logits per
     head, or one tensor when `num_class > 0`."""
     sd = _cast(sd, dtype, keep_graph)
     dirs = [0, 1] if bidirectional else [0]
-    H = sd["cells_0.0.weight_hh"].shape[1]
+    H = sd["cells_0.0.weight_hh"].shape[1] if recurr else sd["cells_0.0.weight"].shape[0]
     G.bi_layer_index = torch.stack([torch.stack([G._bi_layer_idx0, G._bi_layer_index0], 0),
                                     torch.stack([G._bi_layer_idx1, G._bi_layer_index1], 0)], 0)
     G.x = ast_node_encoder(sd, G.x, G.node_depth.view(-1))
     layers = [G.bi_layer_index[0][0], G.bi_layer_index[1][0]]
-    cfg = _Cfg(sd, dirs, num_layers, H, "cells_", "node_aggr_0.0.edge_encoder.weight" in sd, 0, agg)
     ea = G.edge_attr.to(dtype) if getattr(G, "edge_attr", None) is not None else None
-    rec = recurrence_faithful if mode == "faithful" else recurrence_csr
-    G.h = rec(cfg, G.x, G.edge_index, ea, layers)
+    if agg in ADDITIVE_ATTN and not agg_x and recurr:
+        cfg = _Cfg(sd, dirs, num_layers, H, "cells_", "node_aggr_0.0.edge_encoder.weight" in sd, 0, agg)
+        rec = recurrence_faithful if mode == "faithful" else recurrence_csr
+        G.h = rec(cfg, G.x, G.edge_index, ea, layers)
+    else:   # the other constructor strings (row a12): one faithful mirror
+        G.h = recurrence_variants(sd, G.x, G.edge_index, ea, layers, dirs=dirs, L=num_layers, H=H, agg=agg,
+                                  agg_x=agg_x, recurr=recurr)
 
     def out_nodes(reverse):  # dagnn.py:119-126
         return G.bi_layer_index[0][1][G.bi_layer_index[0][0] == 0] if reverse else \

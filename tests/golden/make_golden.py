@@ -286,6 +286,18 @@ def make_bn_grad(ref_bn, ref_util, name, *, hs, L, bidir, w_seed, data_seed, nro
     _save(name, meta, rows=np.array([json.dumps(r) for r in rows]), **arrays)
 
 
+VARIANTS = (("gated_sum", 31, dict(agg="gated_sum")), ("gated_nobias", 32, dict(agg="gated_sum", mapper_bias=False)),
+            ("mattn_h", 33, dict(agg="mattn_h")), ("add", 34, dict(agg="add")), ("max", 35, dict(agg="max")),
+            ("aggx_attn_h", 36, dict(agg="attn_h", agg_x=True)), ("aggx_add", 37, dict(agg="add", agg_x=True)),
+            ("recurr0", 38, dict(agg="attn_h", recurr=0)), ("recurr0_gated", 39, dict(agg="gated_sum", recurr=0)))
+
+
+def _variants_only(ref_dagnn, ref_utils, ref_dagutils, common):
+    for tag, seed, extra in VARIANTS:
+        make_code2(ref_dagnn, ref_utils, ref_dagutils, "var_h64_" + tag, data_seed=seed, B=4, mean_n=25, H=64, L=2,
+                   bidir=1, w_seed=100 + seed, row_stride=2, **extra, **common)
+
+
 def _dvae_only():
     ref_util = importlib.import_module("util")
     ref_na = importlib.import_module("dagnn")
@@ -330,6 +342,8 @@ def main():
     if only == "grad":
         return
 
+    if only == "variants":
+        return _variants_only(ref_dagnn, ref_utils, ref_dagutils, common)
     # tiny generic-H case, every hidden row stored
     make_code2(ref_dagnn, ref_utils, ref_dagutils, "code2_h32_bidir", data_seed=11, B=6, mean_n=30, H=32, L=2,
                bidir=1, w_seed=101, row_stride=1, **common)
@@ -352,6 +366,8 @@ def main():
     for agg, seed in (("attn_x", 18), ("self_attn_h", 19), ("self_attn_x", 20)):
         make_code2(ref_dagnn, ref_utils, ref_dagutils, "code2_h64_" + agg, data_seed=seed, B=5, mean_n=30, H=64,
                    L=2, bidir=1, w_seed=100 + seed, row_stride=1, agg=agg, **common)
+    # the constructor strings outside every BASELINE configuration: other aggregators, agg_x, recurr=0
+    _variants_only(ref_dagnn, ref_utils, ref_dagutils, common)
     # deep chain stress: long graphs (depth ~ 200) to exercise many recurrent steps
     make_code2(ref_dagnn, ref_utils, ref_dagutils, "code2_h128_deep", data_seed=17, B=3, mean_n=400, H=128, L=2,
                bidir=1, w_seed=107, row_stride=7, **common)

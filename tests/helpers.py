@@ -17,6 +17,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CODE2 = ["code2_h32_bidir", "code2_h256_bidir", "code2_h512_L5", "code2_h300_L3", "code2_h64_unidir",
          "code2_h64_numclass", "code2_h128_deep", "code2_h64_attn_x", "code2_h64_self_attn_h",
          "code2_h64_self_attn_x"]
+VARIANTS = ["var_h64_" + t for t in ("gated_sum", "gated_nobias", "mattn_h", "add", "max", "aggx_attn_h", "aggx_add",
+                                        "recurr0", "recurr0_gated")]
 GRAD = ["grad_h32_bidir", "grad_h256_bidir", "grad_h128_deep", "grad_h64_L3_wx", "grad_h64_unidir",
         "grad_h64_mean_all"]
 DVAE_GRAD = ["grad_na_h64_unidir", "grad_bn_h64_bidir"]

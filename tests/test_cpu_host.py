@@ -154,8 +154,9 @@ def test_ctor_errors_and_defaults():
     assert m.out_wx and m.output_all and m.out_hidden_dim == 16 * 2 + 16 * 2 * 2  # reference defaults (:19-21,44)
     m2 = dagnn_amd.DAGNN(10, 5, 16, 16, None, agg="gated_sum", encoder=None)
     assert "node_aggr_0.0.mapper.weight" in m2.state_dict()
-    with pytest.raises(NotImplementedError):
-        m2(object())
+    meta, arr = Hh.load("var_h64_gated_sum")
+    with pytest.raises(_lib.DagnnHipError):   # the variants run on torch-ROCm ops: a CPU batch is refused, not computed
+        Hh.code2_model(meta)(Hh.code2_batch(arr))
 
 
 def test_checkpoint_roundtrip_with_module_prefix(tmp_path):

@@ -610,3 +610,39 @@ def test_training_step_wide_hidden_matches_oracle_autograd(device, H, L):
     for k, g in grads.items():
         scale = float(ref[k].abs().max())
         assert Hh.maxdiff(g, ref[k]) <= 1e-4 * scale + 2e-7, k
+
+
+# ----------------------------------------------------------------------------- constructor-string variants (row a12)
+@pytest.mark.parametrize("name", Hh.VARIANTS)
+def test_variant_forward_matches_reference_golden(device, name):
+    """`mattn_h`, `gated_sum` (with and without mapper bias), `add`, `max` (incl. the reference's shared-module flow in
+    the reverse direction), `agg_x`, `recurr=0`: outputs and hidden rows against the reference's own forward."""
+    meta, arr = Hh.load(name)
+    model = Hh.code2_model(meta).to(device)
+    G = Hh.code2_batch(arr, device)
+    with torch.no_grad():
+        out = model(G)
+    assert len(out) == arr["pred"].shape[0]
+    for o, ref in zip(out, arr["pred"]):
+        assert Hh.maxdiff(o, ref) < TOL
+    rows = arr["rows"]
+    for d, hd in enumerate(G.h):
+        for i, h in enumerate(hd):
+            assert Hh.maxdiff(h[rows], arr["h_%d_%d" % (d, i)]) < TOL
+
+
+@pytest.mark.parametrize("name", ["var_h64_mattn_h", "var_h64_gated_sum", "var_h64_recurr0"])
+def test_variant_training_step_matches_oracle_autograd(device, name):
+    meta, arr = Hh.load(name)
+    kw = meta["ctor"]
+    model = Hh.code2_model(meta)
+    y = torch.from_numpy(np.random.default_rng(2).integers(0, meta["V"], size=(int(arr["batch"].max()) + 1, meta["S"])))
+    loss_ref, ref = O.code2_grads(model.state_dict(), Hh.code2_batch(arr), y, num_layers=kw["num_layers"],
+                                  bidirectional=True, out_wx=kw["out_wx"], max_seq_len=meta["S"], agg=kw["agg"],
+                                  agg_x=kw.get("agg_x", False), recurr=kw.get("recurr", 1))
+    model = model.to(device)
+    loss, grads = _train_step(model, Hh.code2_batch(arr, device), y.to(device))
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    for k, g in grads.items():
+        scale = float(ref[k].abs().max())
+        assert Hh.maxdiff(g, ref[k]) <= 1e-4 * scale + 2e-7, k

@@ -10,19 +10,21 @@ from tests import helpers as Hh
 TOL = 2e-5  # fp32 restatement vs fp32 reference: different summation order only
 
 
-@pytest.mark.parametrize("name", Hh.CODE2)
+@pytest.mark.parametrize("name", Hh.CODE2 + Hh.VARIANTS)
 @pytest.mark.parametrize("mode", ["csr", "faithful"])
 def test_code2_oracle_matches_reference(name, mode):
     meta, arr = Hh.load(name)
     if mode == "faithful" and meta["N"] > 700:
         pytest.skip("faithful mirror is O(N*E); covered by the smaller fixtures")
+    if mode == "csr" and name in Hh.VARIANTS:
+        pytest.skip("the row-a12 variants have one (faithful) restatement")
     model = Hh.code2_model(meta)
     G = Hh.code2_batch(arr)
     kw = meta["ctor"]
     out = O.code2_forward(model.state_dict(), G, num_layers=kw["num_layers"], bidirectional=bool(kw["bidirectional"]),
                           out_wx=kw["out_wx"], out_pool_all=kw["out_pool_all"], out_pool=kw["out_pool"],
                           max_seq_len=meta["S"], num_class=kw.get("num_class", 0), mode=mode,
-                          agg=kw.get("agg", "attn_h"))
+                          agg=kw.get("agg", "attn_h"), agg_x=kw.get("agg_x", False), recurr=kw.get("recurr", 1))
     out = out if isinstance(out, list) else [out]
     assert len(out) == arr["pred"].shape[0]
     for o, ref in zip(out, arr["pred"]):

@@ -176,9 +176,10 @@ class _DvaeDagnn(_DvaeBase):
         return True
 
     def forward(self, G):
-        """`dvae/dagnn.py:99-175` / `dvae/dagnn_bn.py:98-168` with `out_pool_all=False`."""
-        if self.output_all:
-            raise NotImplementedError("out_pool_all=True read-out is not implemented for the D-VAE encoders")
+        """`dvae/dagnn.py:99-175` / `dvae/dagnn_bn.py:98-168`."""
+        if self.output_all and self.out_pool not in (K.P_MAX, K.P_MEAN, K.P_ADD):
+            raise NotImplementedError("out_pool=%r over all nodes: the reference's own self-attention pooling of the "
+                                      "D-VAE models references an undefined layer (dvae/dagnn.py:85-88)" % self.out_pool)
         train = self._training_pass()
         device = self.get_device()
         G = G.to(device)
@@ -190,6 +191,25 @@ class _DvaeDagnn(_DvaeBase):
         B = N // nn_
         bl = G.bi_layer_index
         plan = engine.build_plan(G.edge_index, bl[0][0], bl[1][0], G.batch, B, None)
+        if self.output_all:   # pool over ALL nodes (dvae/dagnn.py:163-172): states, per-node projection, torch pooling
+            if train:
+                from .autograd import Recurrence
+                flat = Recurrence.apply(self, plan, B, False, x, *self._train_params())
+            else:
+                hh = run_stack(plan, x, self._cells(), self.dirs, L, H, vid_nodes=self._vid_nodes,
+                               schedule=self.schedule, arena=self._arena_for(x))
+                flat = [hh[d][i] for d in self.dirs for i in range(L)]
+            G.h = torch.cat(([x] if self.out_wx else []) + list(flat), dim=-1)
+            if self.bidirectional:
+                G.h = self.hg_unify(G.h)
+            elif L > 1:
+                G.h = self.out_linear(G.h)
+            idx = G.batch.view(-1, 1).expand_as(G.h)
+            out = G.h.new_zeros(B, G.h.shape[1])
+            if self.out_pool == K.P_MAX:
+                return out.scatter_reduce(0, idx, G.h, "amax", include_self=False)
+            out = out.scatter_add(0, idx, G.h)
+            return out / nn_ if self.out_pool == K.P_MEAN else out
         if train:
             from .autograd import Recurrence
             hcat = Recurrence.apply(self, plan, B, True, x, *self._train_params())[0]

@@ -382,7 +382,8 @@ def code2_grads(sd: Dict[str, Tensor], G, y: Tensor, *, dtype: torch.dtype = tor
 
 def dvae_forward(sd: Dict[str, Tensor], G, *, num_layers: int = 2, bidirectional: bool = False,
                  num_nodes: int = 8, vids: bool = True, mode: str = "csr",
-                 dtype: torch.dtype = torch.float32, keep_graph: bool = False) -> Tensor:
+                 dtype: torch.dtype = torch.float32, keep_graph: bool = False, out_pool_all: bool = False,
+                 out_pool: str = "max") -> Tensor:
     """`DAGNN.forward` of `dvae/dagnn.py:99-175` (`vids=True`, NA) or `DAGNN_BN.forward` of
     `dvae/dagnn_bn.py:98-168` (`vids=False`), `out_pool_all=False`: read-out = the end vertex of
     every graph for d=0 and the start vertex for d=1 (fixed stride `num_nodes`)."""
@@ -395,6 +396,13 @@ def dvae_forward(sd: Dict[str, Tensor], G, *, num_layers: int = 2, bidirectional
     rec = recurrence_faithful if mode == "faithful" else recurrence_csr
     h = rec(cfg, x, G.edge_index, None, layers)
     N = x.shape[0]
+    if out_pool_all:   # dvae/dagnn.py:163-172: per-node projection, then pooling over all nodes of a graph
+        G.h = torch.cat([h[q][l] for q in range(len(dirs)) for l in range(num_layers)], -1)
+        if bidirectional:
+            G.h = G.h @ sd["hg_unify.0.weight"].t() + sd["hg_unify.0.bias"]
+        elif num_layers > 1:
+            G.h = G.h @ sd["out_linear.weight"].t() + sd["out_linear.bias"]
+        return _pool(G.h, G.batch, out_pool)
     first = torch.arange(0, N, num_nodes)
     last = first + (num_nodes - 1)
     if bidirectional:

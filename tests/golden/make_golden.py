@@ -178,7 +178,8 @@ def _dvae_case(model, graphs, ref_batch_mod):
     return b, Hg, mu, logvar
 
 
-def make_na(ref_na, ref_util, ref_batch_mod, name, *, hs, L, bidir, w_seed, nrows=64):
+def make_na(ref_na, ref_util, ref_batch_mod, name, *, hs, L, bidir, w_seed, nrows=64, out_pool_all=False,
+            out_pool="max"):
     rows = []
     with open(os.path.join(REF, "dvae", "data", "final_structures6.txt")) as f:
         for i, line in enumerate(f):
@@ -189,26 +190,29 @@ def make_na(ref_na, ref_util, ref_batch_mod, name, *, hs, L, bidir, w_seed, nrow
                 break
     graphs = [ref_util.decode_ENAS_to_pygraph(r)[0] for r in rows]
     model = ref_na.DAGNN(8, hs, hs, 8, 8, 0, 1, hs=hs, nz=56, num_nodes=8, agg="attn_h", num_layers=L,
-                         bidirectional=bidir, out_wx=False, out_pool_all=False, out_pool="max",
+                         bidirectional=bidir, out_wx=False, out_pool_all=out_pool_all, out_pool=out_pool,
                          dropout=0.0).eval()
     seeded_fill(model, w_seed)
     b, Hg, mu, logvar = _dvae_case(model, graphs, ref_batch_mod)
-    meta = dict(kind="na", hs=hs, L=L, bidir=bool(bidir), w_seed=w_seed, nrows=nrows,
+    meta = dict(kind="na", hs=hs, L=L, bidir=bool(bidir), w_seed=w_seed, nrows=nrows, out_pool_all=out_pool_all,
+                out_pool=out_pool,
                 state_dict={k: list(v.shape) for k, v in model.state_dict().items()})
     _save(name, meta, rows=np.array([json.dumps(r) for r in rows]),
           x=_np(b.x), edge_index=_np(b.edge_index), bi_layer_index=_np(b.bi_layer_index), batch=_np(b.batch_before), batch_after=_np(b.batch),
           Hg=_np(Hg), mu=_np(mu), logvar=_np(logvar))
 
 
-def make_bn(ref_bn, ref_util, ref_batch_mod, name, *, hs, L, bidir, w_seed, data_seed, nrows):
+def make_bn(ref_bn, ref_util, ref_batch_mod, name, *, hs, L, bidir, w_seed, data_seed, nrows, out_pool_all=False,
+            out_pool="max"):
     rows = synth.bn_rows(data_seed, nrows)
     graphs = [ref_util.decode_BN_to_pygraph(r)[0] for r in rows]
     model = ref_bn.DAGNN_BN(10, hs, hs, 10, 10, 0, 1, hs=hs, nz=56, num_nodes=10, agg="attn_h", num_layers=L,
-                            bidirectional=bidir, out_wx=False, out_pool_all=False, out_pool="max",
+                            bidirectional=bidir, out_wx=False, out_pool_all=out_pool_all, out_pool=out_pool,
                             dropout=0.0).eval()
     seeded_fill(model, w_seed)
     b, Hg, mu, logvar = _dvae_case(model, graphs, ref_batch_mod)
     meta = dict(kind="bn", hs=hs, L=L, bidir=bool(bidir), w_seed=w_seed, data_seed=data_seed, nrows=nrows,
+                out_pool_all=out_pool_all, out_pool=out_pool,
                 state_dict={k: list(v.shape) for k, v in model.state_dict().items()})
     _save(name, meta, rows=np.array([json.dumps(r) for r in rows]),
           x=_np(b.x), edge_index=_np(b.edge_index), bi_layer_index=_np(b.bi_layer_index), batch=_np(b.batch_before), batch_after=_np(b.batch),
@@ -387,6 +391,11 @@ def main():
             nrows=32)
     make_bn(ref_bn, ref_util, ref_batch_mod, "bn_h64_unidir", hs=64, L=3, bidir=False, w_seed=204, data_seed=6,
             nrows=12)
+    # pooling over all nodes (dvae/dagnn.py:163-172)
+    make_na(ref_na, ref_util, ref_batch_mod, "na_h64_poolall_max", hs=64, L=2, bidir=False, w_seed=205, nrows=16,
+            out_pool_all=True, out_pool="max")
+    make_bn(ref_bn, ref_util, ref_batch_mod, "bn_h64_poolall_mean", hs=64, L=2, bidir=True, w_seed=206, data_seed=8,
+            nrows=12, out_pool_all=True, out_pool="mean")
 
 
 if __name__ == "__main__":

@@ -22,7 +22,7 @@ VARIANTS = ["var_h64_" + t for t in ("gated_sum", "gated_nobias", "mattn_h", "ad
 GRAD = ["grad_h32_bidir", "grad_h256_bidir", "grad_h128_deep", "grad_h64_L3_wx", "grad_h64_unidir",
         "grad_h64_mean_all"]
 DVAE_GRAD = ["grad_na_h64_unidir", "grad_bn_h64_bidir"]
-DVAE = ["na_h128_unidir", "na_h64_bidir", "bn_h256_bidir", "bn_h64_unidir"]
+DVAE = ["na_h128_unidir", "na_h64_bidir", "bn_h256_bidir", "bn_h64_unidir", "na_h64_poolall_max", "bn_h64_poolall_mean"]
 
 
 def load(name):
@@ -62,7 +62,8 @@ def dvae_model(meta):
     cls, nn_ = (DAGNN_NA, 8) if meta["kind"] == "na" else (DAGNN_BN, 10)
     hs = meta["hs"]
     model = cls(nn_, hs, hs, nn_, nn_, 0, 1, hs=hs, nz=56, num_nodes=nn_, agg="attn_h", num_layers=meta["L"],
-                bidirectional=meta["bidir"], out_wx=False, out_pool_all=False, out_pool="max", dropout=0.0).eval()
+                bidirectional=meta["bidir"], out_wx=False, out_pool_all=meta.get("out_pool_all", False),
+                out_pool=meta.get("out_pool", "max"), dropout=0.0).eval()
     seeded_fill(model, meta["w_seed"])
     return model, nn_
 

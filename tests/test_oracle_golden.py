@@ -49,7 +49,8 @@ def test_dvae_oracle_matches_reference(name, mode):
     model, nn_ = Hh.dvae_model(meta)
     G = Hh.dvae_batch(arr)
     mu, logvar = O.dvae_encode(model.state_dict(), G, num_layers=meta["L"], bidirectional=meta["bidir"],
-                               num_nodes=nn_, vids=meta["kind"] == "na", mode=mode)
+                               num_nodes=nn_, vids=meta["kind"] == "na", mode=mode,
+                               out_pool_all=meta.get("out_pool_all", False), out_pool=meta.get("out_pool", "max"))
     assert Hh.maxdiff(mu, arr["mu"]) < TOL
     assert Hh.maxdiff(logvar, arr["logvar"]) < TOL
 

@@ -214,7 +214,8 @@ typedef struct dagnn_frontier_args {
     /* split mode (optional): with a second stream and the plan's per-layer split pointers (blsplit_d, read back with
      * the schedule) the persistent kernel walks the DEEP graphs (depth > thr_d) from layer 0 on `side_stream`,
      * concurrently with the per-layer launches, which then only cover the shallow graphs.  The call forks from and
-     * joins back into `stream` with events (capturable); results are identical.  (CU-masked streams for the two
+     * joins back into `stream` with events (capturable); results agree with the unsplit mode to rounding (a row may be
+     * handled by a different kernel), each mode by itself is deterministic.  (CU-masked streams for the two
      * halves were measured and dropped: masked queues slowed every other launch of the process.) */
     void* side_stream;                              /* hipStream_t or NULL: runs the persistent kernel */
     const int32_t* layer_split[DAGNN_MAX_DIRS];     /* HOST, num_layers[d] int32: first deep slot of every layer, or NULL */

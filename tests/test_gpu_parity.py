@@ -242,6 +242,29 @@ def _headline_model(H=256, L=2, V=64, seed=0):
     return m
 
 
+@pytest.mark.parametrize("split", [0, 1])
+def test_headline_batch_split_modes_agree(device, split, monkeypatch):
+    """The headline batch with and without the split mode (deep graphs on a side stream).  A row may be handled by a
+    different kernel in the two modes (MFMA tile vs slice FMA: another summation order), so the results agree to
+    rounding, not bit for bit; each mode by itself is deterministic (test_headline_properties, stress test)."""
+    from bench import build_model
+    b = synth.code2_batch(0, 128)
+    b.x[:, 1] %= 10030
+    y = torch.randint(0, 48, (128, 3), generator=torch.Generator().manual_seed(9)).to(device)
+    res = {}
+    for mode in (1 - split, split):
+        monkeypatch.setattr(engine, "SPLIT_DEEP", mode)
+        model = build_model(128, 2, 48, 3, device)
+        with torch.no_grad():
+            out = [o.clone() for o in model(b.clone().to(device))]
+        _, grads = _train_step(model, b.clone().to(device), y)
+        res[mode] = (out, {k: v.clone() for k, v in grads.items() if "encoder." not in k})
+    assert max(Hh.maxdiff(a, c) for a, c in zip(res[0][0], res[1][0])) < 2e-5
+    for k in res[0][1]:
+        scale = float(res[0][1][k].abs().max())
+        assert Hh.maxdiff(res[0][1][k], res[1][1][k]) <= 2e-5 * scale + 1e-7, k
+
+
 def test_headline_batch_matches_oracle(device, schedule):
     """cfg 2 at full size (seed-0 batch: B=128, N=16 561, E=25 377, T=374; h=256, L=2, bidir)."""
     model = _headline_model()

@@ -70,6 +70,34 @@ class BackwardArgs(C.Structure):
                 ("side_stream", C.c_void_p), ("layer_split", C.POINTER(C.c_int32) * MAX_DIRS)]
 
 
+AGG_ATTN, AGG_MATTN, AGG_GATED, AGG_ADD, AGG_MAX, AGG_GIVEN = range(6)
+
+
+class VariantAggregator(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("lands", C.c_int32), ("val_dim", C.c_int32), ("aux_dim", C.c_int32),
+                ("out_dim", C.c_int32), ("reserved", C.c_int32), ("vals", C.c_void_p), ("ld_vals", C.c_int64),
+                ("node0", C.c_void_p), ("node1", C.c_void_p), ("ld_node", C.c_int64), ("edge_mat0", C.c_void_p),
+                ("edge_vec0", C.c_void_p), ("edge_mat1", C.c_void_p), ("edge_vec1", C.c_void_p), ("out", C.c_void_p),
+                ("ld_out", C.c_int64)]
+
+
+class VariantMap(C.Structure):
+    _fields_ = [("w_t", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("ld_out", C.c_int64),
+                ("out_dim", C.c_int32), ("reserved", C.c_int32)]
+
+
+class VariantCell(C.Structure):
+    _fields_ = [("agg", VariantAggregator), ("recurrent", C.c_int32), ("in_dim", C.c_int32), ("input", C.c_void_p),
+                ("ld_input", C.c_int64), ("w_in_t", C.c_void_p), ("w_agg_t", C.c_void_p), ("b_in", C.c_void_p),
+                ("b_agg", C.c_void_p), ("h", C.c_void_p), ("ld_h", C.c_int64), ("map", VariantMap * 3),
+                ("num_maps", C.c_int32), ("reserved", C.c_int32)]
+
+
+class VariantArgs(C.Structure):
+    _fields_ = [("cell", (VariantCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
+                ("H", C.c_int)]
+
+
 # every symbol include/dagnn_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     "dagnn_version": (C.c_char_p, []),
@@ -96,6 +124,10 @@ SYMBOLS = {
                                              C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_topo_layers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
+    "dagnn_variant_aggregate": (C.c_int, [C.POINTER(Plan), C.POINTER(VariantAggregator), C.c_int, C.c_int32, C.c_int32,
+                                          C.c_void_p]),
+    "dagnn_variant_run": (C.c_int, [C.POINTER(Plan), C.POINTER(VariantArgs), C.POINTER(C.POINTER(C.c_int32)),
+                                    C.POINTER(C.c_int32), C.c_void_p]),
     "dagnn_gather_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int, C.c_void_p]),
 }

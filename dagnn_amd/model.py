@@ -194,6 +194,8 @@ class DAGNN(nn.Module):
         self._head_cache = DerivedCache()
         self._arenas = {}  # per device: granule buffers of the persistent tail kernel
         self.schedule = default_schedule()  # 'lockstep' (frontier launches) or 'pergraph' (persistent workgroups)
+        self.variant_backend = "hip"       # constructor-string variants (a12): 'hip' kernels when no gradient is needed,
+                                            # 'torch' = always the differentiable torch-ROCm ops (the training path)
 
     # ------------------------------------------------------------------------------ helpers
     # additive-attention aggregators: the logit is w . [query ; key (+ edge)] (+ b); query and bias cancel
@@ -310,6 +312,13 @@ class DAGNN(nn.Module):
             out = out / cnt
         return out
 
+    def _plan_of(self, G, B):
+        if getattr(G, "_dagnn_plan", None) is not None:  # built by the loader (dagnn_amd.host_plan.attach_plan)
+            return engine.PlanHandle.from_words(G._dagnn_plan, G._dagnn_plan_meta)
+        has_edge_enc = getattr(self.node_aggr_0[0], "wea", False)
+        return engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B,
+                                 G.edge_attr if has_edge_enc else None)
+
     # ------------------------------------------------------------------------------ forward
     def forward(self, G):
         L, H, dirs = self.num_layers, self.hidden_dim, self.dirs
@@ -322,7 +331,11 @@ class DAGNN(nn.Module):
                                             torch.stack([G._bi_layer_idx1, G._bi_layer_index1], dim=0)], dim=0)
             B = num_graphs_of(G)
             G.x = self.encoder(G.x, G.node_depth.view(-1, ))
-            return self._finish(G, None, G.x, variants.run(self, G, G.x), B)
+            if self.variant_backend == "torch" or (torch.is_grad_enabled()
+                                                    and any(p.requires_grad for p in self.parameters())):
+                return self._finish(G, None, G.x, variants.run(self, G, G.x), B)   # training: differentiable torch ops
+            plan = self._plan_of(G, B)
+            return self._finish(G, plan, G.x, variants.run_hip(self, G, G.x, plan), B)
         train = self._training_pass()
 
         # side effect 1 (dagnn.py:130-133)
@@ -332,12 +345,7 @@ class DAGNN(nn.Module):
         # side effects 2+3 (dagnn.py:139, utils.py:27): embedding replaces G.x, depth clamped in place
         G.x = self.encoder(G.x, G.node_depth.view(-1, ))
         x = G.x
-        has_edge_enc = getattr(self.node_aggr_0[0], "wea", False)
-        if getattr(G, "_dagnn_plan", None) is not None:  # built by the loader (dagnn_amd.host_plan.attach_plan)
-            plan = engine.PlanHandle.from_words(G._dagnn_plan, G._dagnn_plan_meta)
-        else:
-            plan = engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B,
-                                     G.edge_attr if has_edge_enc else None)
+        plan = self._plan_of(G, B)
         fused_readout = self.bidirectional and not self.output_all and self.out_pool == K.P_MAX
         if train:
             # differentiable call: HIP read-out + its backward for the configuration the reference trains

@@ -1,11 +1,18 @@
-"""The aggregator / cell variants no BASELINE configuration exercises, on torch-ROCm ops.
+"""The aggregator / cell variants no BASELINE configuration exercises.
 
 `agg` in {`mattn_h`, `gated_sum`, `add`, `max`}, `agg_x=True`, `recurr=0` of `ogbg-code/model/dagnn.py`: the module
-keeps the reference's constructor and `state_dict` for them, and `forward` lands here instead of in the HIP
-recurrence.  This is the reference's own loop nest (`dagnn.py:144-182`) with its O(F*E) per-node edge scan replaced by
-one stable sort of the edges by the layer of the node they feed; every step is a handful of gather / segment-softmax /
-scatter ops on the GPU (a few thousand small launches per batch - fine for variants that are selected by a constructor
-string for ablations, not for throughput).  Nothing here touches the CPU or the test oracle.
+keeps the reference's constructor and `state_dict` for them, and `forward` lands here instead of in the tuned HIP
+recurrence.  Two paths, same values:
+
+* `run_hip` (evaluation / inference, i.e. whenever no gradient is requested): one lock-step pass of the generic HIP
+  kernels of `csrc/variants.hip` (`dagnn_variant_run`, `dagnn_variant_aggregate`): an aggregate launch, a cell launch
+  and - for `mattn_h` / `gated_sum` - a launch of per-node projections per step.  This module only derives the
+  kernel-ready weights (transposes, the `[dim, R]` products that fold the edge encoder into the projections; cached
+  per parameter version) and marshals pointers.
+* `run` (training): the reference's loop nest (`dagnn.py:144-182`) on differentiable torch-ROCm ops, with its
+  O(F*E) per-node edge scan replaced by one stable sort of the edges by the layer of the node they feed.
+
+Neither touches the CPU or the test oracle.
 
 Conv semantics restated from `dagnn.py:232-313,347-409` and PyG-1.6 `propagate` (messages flow j -> i; the result of a
 conv is a full [N, .] tensor that is zero where no edge lands, of which the caller reads the frontier rows):
@@ -20,9 +27,13 @@ conv is a full [N, .] tensor that is zero where no edge lands, of which the call
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import List, Optional
 
 import torch
+
+from . import _lib, engine
+from .core import DerivedCache
 
 
 def _segment_softmax(logit: torch.Tensor, seg: torch.Tensor, num_seg: int) -> torch.Tensor:
@@ -118,4 +129,180 @@ def run(mod, G, x: torch.Tensor) -> List[List[Optional[torch.Tensor]]]:
                 inp = cells[i](inp, ps) if mod.recurr else cells[i](torch.cat([inp, ps], dim=1))
                 hs[i].index_add_(0, rows, inp)   # `G.h[d][i][layer] += inp` (dagnn.py:182)
         h[d] = hs
+    return h
+
+
+# ---------------------------------------------------------------------------------------------- HIP path
+def _derive(mod):
+    """Kernel-ready weights of every cell: k-major cell weights, the aggregator's projections and the edge-encoder
+    products.  Cached on the module per parameter version."""
+    H, L, E = mod.hidden_dim, mod.num_layers, mod.emb_dim
+
+    def make():
+        out = {}
+        for d in mod.dirs:
+            for i in range(L):
+                c = getattr(mod, "cells_%d" % d)[i]
+                a = getattr(mod, "node_aggr_%d" % d)[0 if mod.agg_x else i]
+                in_dim = E if i == 0 else H
+                p = {}
+                if mod.recurr:
+                    p["w_in_t"], p["w_agg_t"] = c.weight_ih.t().contiguous(), c.weight_hh.t().contiguous()
+                    p["b_in"], p["b_agg"] = c.bias_ih.contiguous(), c.bias_hh.contiguous()
+                else:
+                    p["w_in_t"] = c.weight[:, :in_dim].t().contiguous()
+                    p["w_agg_t"] = c.weight[:, in_dim:].t().contiguous()
+                    p["b_in"], p["b_agg"] = c.bias.contiguous(), None
+                We = a.edge_encoder.weight if getattr(a, "wea", False) else None   # [dim, R]
+                be = a.edge_encoder.bias if We is not None else None
+                if mod.agg in ("add", "max"):
+                    p["edge_mat0"] = We.contiguous() if We is not None else None
+                    p["edge_vec0"] = be.contiguous() if We is not None else None
+                elif mod.agg == "gated_sum":
+                    Wg, bg, Wm, bm = a.gate[0].weight, a.gate[0].bias, a.mapper.weight, a.mapper.bias
+                    p["pq_w_t"] = torch.cat([Wg, Wm], 0).t().contiguous()
+                    p["pq_b"] = torch.cat([bg, bm if bm is not None else torch.zeros_like(bg)])
+                    if We is not None:
+                        p["edge_mat0"], p["edge_vec0"] = (Wg @ We).contiguous(), (Wg @ be).contiguous()
+                        p["edge_mat1"], p["edge_vec1"] = (Wm @ We).contiguous(), (Wm @ be).contiguous()
+                elif "mattn" in mod.agg:
+                    Wl, Wr = a.attn_linl.weight, a.attn_linr.weight
+                    p["ql_w"], p["ql_b"], p["kr_w"], p["kr_b"] = Wl, a.attn_linl.bias, Wr, a.attn_linr.bias
+                    p["ql_w_t"], p["kr_w_t"] = Wl.t().contiguous(), Wr.t().contiguous()
+                    if We is not None:
+                        p["edge_mat0"], p["edge_vec0"] = (Wr @ We).contiguous(), (Wr @ be).contiguous()
+                else:   # additive attention: only the key half of attn_lin matters inside a softmax segment
+                    off = 0 if "self_attn" in mod.agg else (E if (i == 0 or mod.agg_x) else
+                                                            (E if mod.agg_attn_x else H))
+                    kd = E if (mod.agg_x or mod.agg_attn_x) else H
+                    wk = a.attn_lin.weight[0, off:off + kd].contiguous()
+                    p["edge_vec0"] = wk
+                    p["edge_mat0"] = (We.t() @ wk).contiguous() if We is not None else None   # [R]
+                out[(d, i)] = p
+        return out
+
+    srcs = [q for q in mod.parameters()]
+    cache = mod.__dict__.setdefault("_variant_cache", DerivedCache())
+    return cache.get(srcs, make)
+
+
+_MODES = {"add": _lib.AGG_ADD, "max": _lib.AGG_MAX, "gated_sum": _lib.AGG_GATED}
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def run_hip(mod, G, x: torch.Tensor, plan) -> List[List[Optional[torch.Tensor]]]:
+    """h[d][i] ([N, hidden]) through `dagnn_variant_run` (csrc/variants.hip).  `plan`: engine.PlanHandle of the batch
+    (with the edge features when the model has an edge encoder)."""
+    N, H, L, E = x.shape[0], mod.hidden_dim, mod.num_layers, mod.emb_dim
+    x = engine._dev(x.detach(), "node inputs", torch.float32)
+    dev = x.device
+    lib = _lib.load()
+    prm = _derive(mod)
+    sched = plan.read_schedule()
+    stream = engine._stream(x)
+    mode = _MODES.get(mod.agg, _lib.AGG_MATTN if "mattn" in mod.agg else _lib.AGG_ATTN)
+    shared_flow = mod.agg in ("add", "max")
+    keep = []   # tensors the launches read: alive until the call returns (stream-ordered afterwards)
+    h: List[List[Optional[torch.Tensor]]] = [[None] * L for _ in range(2)]
+    args = _lib.VariantArgs()
+    args.num_stacked, args.H, args.dir_mask = L, H, sum(1 << d for d in mod.dirs)
+    with torch.no_grad():
+        for d in mod.dirs:
+            lands = 0 if (shared_flow and d == 1) else 1
+            for i in range(L):
+                h[d][i] = torch.empty(N, H, dtype=torch.float32, device=dev)
+            given = None
+            if mod.agg_x:
+                # the aggregator runs on the inputs (dagnn.py:159-169): all layers in one launch, reused by every cell
+                p = prm[(d, 0)]
+                given = torch.zeros(N, H, dtype=torch.float32, device=dev)
+                keep.append(given)
+                T = len(sched[d]) - 1
+                if lands and T > 1:
+                    a = _lib.VariantAggregator()
+                    a.mode, a.lands, a.val_dim, a.out_dim = mode, 1, E, H
+                    a.vals, a.ld_vals, a.out, a.ld_out = x.data_ptr(), x.shape[1], given.data_ptr(), H
+                    a.edge_mat0, a.edge_vec0 = _ptr(p.get("edge_mat0")), _ptr(p.get("edge_vec0"))
+                    a.edge_mat1, a.edge_vec1 = _ptr(p.get("edge_mat1")), _ptr(p.get("edge_vec1"))
+                    if mode == _lib.AGG_ATTN:
+                        a.node0, a.ld_node, a.aux_dim = x.data_ptr(), x.shape[1], E
+                    elif mode == _lib.AGG_MATTN:
+                        kr = torch.addmm(p["kr_b"], x, p["kr_w"].t())
+                        ql = torch.addmm(p["ql_b"], x, p["ql_w"].t())
+                        keep += [kr, ql]
+                        a.node0, a.node1, a.ld_node, a.aux_dim = kr.data_ptr(), ql.data_ptr(), kr.shape[1], kr.shape[1]
+                    elif mode == _lib.AGG_GATED:
+                        pq = torch.addmm(p["pq_b"], x, p["pq_w_t"])
+                        keep.append(pq)
+                        a.node0, a.node1, a.ld_node = pq.data_ptr(), pq.data_ptr() + 4 * E, 2 * E
+                    engine.check(lib.dagnn_variant_aggregate(C.byref(plan.desc), C.byref(a), d, int(sched[d][1]),
+                                                             int(sched[d][T]), stream), "dagnn_variant_aggregate")
+            for i in range(L):
+                p, vc = prm[(d, i)], args.cell[d][i]
+                inp = x if i == 0 else h[d][i - 1]
+                vc.recurrent, vc.in_dim = (1 if mod.recurr else 0), inp.shape[1]
+                vc.input, vc.ld_input = inp.data_ptr(), inp.shape[1]
+                vc.w_in_t, vc.w_agg_t = p["w_in_t"].data_ptr(), p["w_agg_t"].data_ptr()
+                vc.b_in, vc.b_agg = _ptr(p["b_in"]), _ptr(p["b_agg"])
+                vc.h, vc.ld_h = h[d][i].data_ptr(), H
+                a = vc.agg
+                a.out_dim, a.ld_out = H, H
+                if given is not None:
+                    a.mode, a.lands, a.out = _lib.AGG_GIVEN, 1, given.data_ptr()
+                    continue
+                scratch = torch.empty(N, H, dtype=torch.float32, device=dev)
+                keep.append(scratch)
+                a.mode, a.lands, a.val_dim, a.out = mode, lands, H, scratch.data_ptr()
+                a.vals, a.ld_vals = h[d][i].data_ptr(), H
+                a.edge_mat0, a.edge_vec0 = _ptr(p.get("edge_mat0")), _ptr(p.get("edge_vec0"))
+                a.edge_mat1, a.edge_vec1 = _ptr(p.get("edge_mat1")), _ptr(p.get("edge_vec1"))
+                nm = 0
+                if mode == _lib.AGG_ATTN:
+                    keys = x if mod.agg_attn_x else h[d][i]
+                    a.node0, a.ld_node, a.aux_dim = keys.data_ptr(), keys.shape[1], keys.shape[1]
+                elif mode == _lib.AGG_GATED:
+                    pq = torch.empty(N, 2 * H, dtype=torch.float32, device=dev)
+                    keep.append(pq)
+                    a.node0, a.node1, a.ld_node = pq.data_ptr(), pq.data_ptr() + 4 * H, 2 * H
+                    m = vc.map[nm]
+                    m.w_t, m.bias, m.out, m.ld_out, m.out_dim = p["pq_w_t"].data_ptr(), p["pq_b"].data_ptr(), \
+                        pq.data_ptr(), 2 * H, 2 * H
+                    nm += 1
+                elif mode == _lib.AGG_MATTN:
+                    qd = p["kr_w"].shape[0]
+                    if mod.agg_attn_x:     # keys are the inputs: one library GEMM
+                        kr = torch.addmm(p["kr_b"], x, p["kr_w"].t())
+                    else:                  # keys are this cell's states: projected as the rows are produced
+                        kr = torch.empty(N, qd, dtype=torch.float32, device=dev)
+                        m = vc.map[nm]
+                        m.w_t, m.bias, m.out, m.ld_out, m.out_dim = p["kr_w_t"].data_ptr(), p["kr_b"].data_ptr(), \
+                            kr.data_ptr(), qd, qd
+                        nm += 1
+                    if mod.agg_attn_x or i == 0:   # the query is the node input
+                        ql = torch.addmm(p["ql_b"], x, p["ql_w"].t())
+                    else:                          # the query is the state of the cell below: projected there
+                        ql = torch.empty(N, qd, dtype=torch.float32, device=dev)
+                        below = args.cell[d][i - 1]
+                        m = below.map[below.num_maps]
+                        m.w_t, m.bias, m.out, m.ld_out, m.out_dim = p["ql_w_t"].data_ptr(), p["ql_b"].data_ptr(), \
+                            ql.data_ptr(), qd, qd
+                        below.num_maps += 1
+                    keep += [kr, ql]
+                    a.node0, a.node1, a.ld_node, a.aux_dim = kr.data_ptr(), ql.data_ptr(), qd, qd
+                vc.num_maps += nm
+        ptrs = (C.POINTER(C.c_int32) * 2)()
+        nl = (C.c_int32 * 2)()
+        if mod.agg_x:   # the aggregate is an input: the layers are independent, every cell is one launch over all rows
+            import numpy as np
+            sched = [np.array([0, N], dtype=np.int32)] * 2
+        for d in (0, 1):
+            ptrs[d] = sched[d].ctypes.data_as(C.POINTER(C.c_int32))
+            nl[d] = len(sched[d]) - 1
+        with engine._span("variant_run", x):
+            engine.check(lib.dagnn_variant_run(C.byref(plan.desc), C.byref(args), ptrs, nl, stream),
+                         "dagnn_variant_run")
+    del keep
     return h

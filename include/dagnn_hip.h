@@ -312,6 +312,96 @@ int dagnn_backward_run(const dagnn_plan* plan /* host */, const dagnn_backward_a
 int dagnn_readout_max_backward(const dagnn_plan* plan /* host */, const float* h, int ld_h, int width, int dir,
                                const float* grad_out, int ld_out, int col_off, float* grad_h, int ld_g, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Constructor-string variants of the same loop (no BASELINE configuration selects
+ * them): the aggregators `MultAttnConv` (dagnn.py:379-409), `GatedSumConv` (:254-276), `AggConv` add / max
+ * (:232-251), the additive-attention convs when they meet `agg_x` (:159-169) or the Linear cell `recurr=0`
+ * (:83-85,181).  Forward only; one lock-step pass of generic kernels: per step an aggregate launch (one wave per
+ * frontier row), a cell launch (GRU or Linear over [input ; aggregate]) and - for the aggregators that project the
+ * states - a launch of per-node linear maps over the rows just produced.  All operands are indexed by node id.
+ *
+ * Aggregate of frontier row v over its in-edges e = (j -> v) in original edge order, attr_e = the plan's edge
+ * features (num_edge_feats = R floats; pointers marked "or NULL" drop their term):
+ *   ATTN   logit_e = edge_vec0 . node0[j] + edge_mat0 . attr_e        (key score; the query half and the biases are
+ *          out[v]  = sum_e softmax_e(logit) * vals[j]                   constant inside a softmax segment)
+ *   MATTN  logit_e = node1[v] . (node0[j] + edge_mat0 attr_e + edge_vec0);  out[v] as for ATTN
+ *          node1 = W_l q + b_l per node, node0 = W_r k + b_r per node, edge_mat0 = W_r W_e [aux_dim,R],
+ *          edge_vec0 = W_r b_e
+ *   GATED  out[v] = sum_e sigmoid(node0[j] + edge_mat0 attr_e + edge_vec0) * (node1[j] + edge_mat1 attr_e + edge_vec1)
+ *          node0 = W_g h + b_g, node1 = W_m h (+ b_m) per node; edge_mat0 = W_g W_e, edge_vec0 = W_g b_e, ..1 for W_m
+ *   ADD    out[v] = sum_e (vals[j] + edge_mat0 attr_e + edge_vec0)      edge_mat0 = W_e [val_dim,R], edge_vec0 = b_e
+ *   MAX    out[v] = max_e (...)                                          (as ADD)
+ *   GIVEN  out is an input: the aggregate of every node (zeros for the nodes of layer 0), computed beforehand
+ *          (`agg_x`: the aggregator runs on the node inputs, dagnn.py:159-169, so dagnn_variant_aggregate does all
+ *          layers in one launch; nothing then couples the layers, and the caller may pass the whole batch as ONE
+ *          layer: layer_ptr = {0, N})
+ * Segment softmax as PyG 1.6: exp(x - max) / (sum + 1e-16).  Columns val_dim..out_dim-1 of out[v] are zero-filled
+ * (the reference pads the aggregate of the inputs up to the hidden size, dagnn.py:166-168).
+ * ---------------------------------------------------------------------------------------- */
+enum { DAGNN_AGG_ATTN = 0, DAGNN_AGG_MATTN = 1, DAGNN_AGG_GATED = 2, DAGNN_AGG_ADD = 3, DAGNN_AGG_MAX = 4,
+       DAGNN_AGG_GIVEN = 5 };
+
+typedef struct dagnn_variant_aggregator {
+    int32_t mode;      /* DAGNN_AGG_* */
+    int32_t lands;     /* 0: the messages do not land on the frontier and every row reads zeros - the reference builds ONE
+                        * AggConv for both directions (dagnn.py:74-75), whose flow is source -> target in direction 1 too */
+    int32_t val_dim;   /* width of a message (<= 1024) */
+    int32_t aux_dim;   /* ATTN: key width; MATTN: width of the projected query / key */
+    int32_t out_dim;   /* columns of out written per row (>= val_dim) */
+    int32_t reserved;
+    const float* vals; /* [N,ld_vals] rows summed (ATTN, MATTN, ADD, MAX) */
+    int64_t ld_vals;
+    const float* node0; /* [N,ld_node], see above */
+    const float* node1;
+    int64_t ld_node;
+    const float* edge_mat0; /* row-major [dim,R], or NULL */
+    const float* edge_vec0; /* [dim], or NULL (ATTN: the key weights, required) */
+    const float* edge_mat1;
+    const float* edge_vec1;
+    float* out;        /* [N,ld_out] aggregate by node id */
+    int64_t ld_out;
+} dagnn_variant_aggregator;
+
+/* Aggregate the rowrec slots [slot_begin, slot_end) of direction `dir` (any range of whole layers >= 1). */
+int dagnn_variant_aggregate(const dagnn_plan* plan /* host */, const dagnn_variant_aggregator* agg /* host */, int dir,
+                            int32_t slot_begin, int32_t slot_end, void* stream);
+
+typedef struct dagnn_variant_map { /* out[v, 0:out_dim] = w_t^T h[v] + bias for every row v the cell just produced */
+    const float* w_t;  /* [H,out_dim]: the weight transposed (k-major) */
+    const float* bias; /* [out_dim] or NULL */
+    float* out;        /* [N,ld_out] */
+    int64_t ld_out;
+    int32_t out_dim;
+    int32_t reserved;
+} dagnn_variant_map;
+
+typedef struct dagnn_variant_cell {
+    dagnn_variant_aggregator agg; /* agg.out: scratch [N,ld_out] with out_dim = H (GIVEN: the input aggregate) */
+    int32_t recurrent; /* 1: GRUCell(input, aggregate) (gate order r,z,n); 0: Linear([input ; aggregate]) (dagnn.py:181) */
+    int32_t in_dim;    /* width of the input: emb_dim for stacked layer 0, H above */
+    const float* input; /* [N,ld_input]: node inputs (stacked layer 0) or the states of the cell below */
+    int64_t ld_input;
+    const float* w_in_t;  /* [in_dim, G*H] k-major (G = 3 gates, or 1): weight_ih^T, or weight[:, :in_dim]^T */
+    const float* w_agg_t; /* [H, G*H]: weight_hh^T, or weight[:, in_dim:]^T */
+    const float* b_in;    /* [G*H] bias_ih, or the Linear bias */
+    const float* b_agg;   /* [3H] bias_hh, or NULL */
+    float* h;          /* [N,ld_h] states, every row written exactly once */
+    int64_t ld_h;
+    dagnn_variant_map map[3];
+    int32_t num_maps;
+    int32_t reserved;
+} dagnn_variant_cell;
+
+typedef struct dagnn_variant_args {
+    dagnn_variant_cell cell[DAGNN_MAX_DIRS][DAGNN_MAX_STACKED];
+    int num_stacked, dir_mask, H;
+} dagnn_variant_args;
+
+/* layer_ptr / num_layers as for dagnn_frontier_run.  Layer t of stacked layer i runs in step t + i; at layer 0 the
+ * aggregate is zero (GRUCell(x, None), dagnn.py:172-174,181) unless it is GIVEN. */
+int dagnn_variant_run(const dagnn_plan* plan /* host */, const dagnn_variant_args* args /* host */,
+                      const int32_t* const* layer_ptr /* host */, const int32_t* num_layers /* host [2] */, void* stream);
+
 /* D-VAE read-out (dvae/dagnn.py:147-161, dvae/dagnn_bn.py:138-152): every graph has exactly
  * `stride` nodes; gather row g*stride + node_off of h [N,ld_h] into out[g, col_off : col_off+width]. */
 int dagnn_gather_rows(const float* h, int ld_h, int width, int64_t num_graphs, int stride, int node_off,
@@ -333,7 +423,7 @@ int dagnn_topo_layers(const int64_t* edge_index /* [2,E] */, const int64_t* batc
  * total, blptr0, blptr1, rowrec0, rowrec1, slot0, slot1, eidx0, eidx1, blsplit0, blsplit1].  slot_d [N]: rowrec
  * slot of every node; eidx_d [E]: original edge id (column of edge_index) of every CSR slot; blsplit_d [N+2]: per
  * batch-level layer the first slot of the rows of the DEEP graphs of direction d (depth > thr_d, int32 header word
- * 5 + d of the plan; thr_d = 1 + the last layer with more than 32 rows) - inside a layer the shallow graphs' rows
+ * 5 + d of the plan; thr_d = 1 + the last layer with more than 16 rows) - inside a layer the shallow graphs' rows
  * come first.  blptr_d holds N+2 int32: the offsets of the
  * batch-level topological layers of direction d (entries 0..T_d) and T_d itself at index N+1. */
 int dagnn_plan_layout(int64_t N, int64_t E, int64_t B, int num_edge_feats, int64_t* offsets26 /* host */);

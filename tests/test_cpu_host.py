@@ -45,6 +45,39 @@ def test_host_only_entry_points_without_gpu():
     assert lib.dagnn_pack_whh(None, None, 8, None) == -22
     assert lib.dagnn_encode_ast(None, None, None, None, None, 20, None, 6, 5, 6, None) == -22  # H % 4 != 0
     assert lib.dagnn_gather_rows(None, 4, 4, 1, 8, 9, None, 4, 0, None) == -22
+    # variant entry points: the ctypes mirrors and the C structs agree on the layout (a misplaced field would move
+    # the one bad value these cases plant)
+    plan = _lib.Plan(None, 0, 4, 3, 1, 0)
+    assert lib.dagnn_variant_run(None, None, None, None, None) == -22
+    agg = _lib.VariantAggregator()
+    agg.mode, agg.lands, agg.val_dim, agg.out_dim, agg.out, agg.ld_out = _lib.AGG_ADD, 1, 8, 8, 64, 8
+    agg.vals, agg.ld_vals = 64, 8
+    assert lib.dagnn_variant_aggregate(ctypes.byref(plan), ctypes.byref(agg), 0, 2, 2, None) == 0   # empty range
+    assert lib.dagnn_variant_aggregate(ctypes.byref(plan), ctypes.byref(agg), 2, 0, 2, None) == -22  # direction
+    assert lib.dagnn_variant_aggregate(ctypes.byref(plan), ctypes.byref(agg), 0, 0, 5, None) == -22  # beyond N
+    agg.ld_out = 7
+    assert lib.dagnn_variant_aggregate(ctypes.byref(plan), ctypes.byref(agg), 0, 2, 2, None) == -22  # pitch < width
+    agg.ld_out, agg.mode = 8, _lib.AGG_GIVEN
+    assert lib.dagnn_variant_aggregate(ctypes.byref(plan), ctypes.byref(agg), 0, 2, 2, None) == -22
+    agg.mode, agg.val_dim = _lib.AGG_MAX, 2000
+    assert lib.dagnn_variant_aggregate(ctypes.byref(plan), ctypes.byref(agg), 0, 2, 2, None) == -22  # > 1024 wide
+    va = _lib.VariantArgs()
+    va.num_stacked, va.dir_mask, va.H = 1, 1, 8
+    ptrs = (ctypes.POINTER(ctypes.c_int32) * 2)()
+    sched = (ctypes.c_int32 * 2)(0, 4)
+    ptrs[0] = ctypes.cast(sched, ctypes.POINTER(ctypes.c_int32))
+    nl = (ctypes.c_int32 * 2)(1, 0)
+    c = va.cell[0][0]
+    c.agg.mode, c.agg.lands, c.agg.val_dim, c.agg.out_dim, c.agg.out, c.agg.ld_out = _lib.AGG_ADD, 1, 8, 8, 64, 8
+    c.agg.vals, c.agg.ld_vals = 64, 8
+    c.recurrent, c.in_dim, c.input, c.ld_input, c.w_in_t, c.w_agg_t, c.h, c.ld_h = 0, 8, 64, 8, 64, 64, 64, 7
+    assert lib.dagnn_variant_run(ctypes.byref(plan), ctypes.byref(va), ptrs, nl, None) == -22   # ld_h < H
+    c.ld_h, c.num_maps = 8, 4
+    assert lib.dagnn_variant_run(ctypes.byref(plan), ctypes.byref(va), ptrs, nl, None) == -22   # too many maps
+    c.num_maps, c.recurrent = 0, 1
+    assert lib.dagnn_variant_run(ctypes.byref(plan), ctypes.byref(va), ptrs, nl, None) == -22   # GRU without biases
+    c.recurrent = 0
+    assert lib.dagnn_variant_run(ctypes.byref(plan), ctypes.byref(va), ptrs, nl, None) == -22   # plan without data
 
 
 def test_engine_refuses_cpu_tensors():

@@ -669,3 +669,57 @@ def test_variant_training_step_matches_oracle_autograd(device, name):
     for k, g in grads.items():
         scale = float(ref[k].abs().max())
         assert Hh.maxdiff(g, ref[k]) <= 1e-4 * scale + 2e-7, k
+
+
+_VARIANT_CTORS = [dict(agg="gated_sum"), dict(agg="gated_sum", mapper_bias=False), dict(agg="mattn_h"), dict(agg="add"),
+                  dict(agg="max"), dict(agg="attn_h", agg_x=True), dict(agg="self_attn_h", agg_x=True),
+                  dict(agg="add", agg_x=True), dict(agg="max", agg_x=True), dict(agg="gated_sum", agg_x=True),
+                  dict(agg="mattn_h", agg_x=True), dict(agg="attn_h", recurr=0), dict(agg="attn_x", recurr=0),
+                  dict(agg="self_attn_x", recurr=0), dict(agg="gated_sum", recurr=0), dict(agg="mattn_h", recurr=0),
+                  dict(agg="max", recurr=0, agg_x=True), dict(agg="max", w_edge_attr=False),
+                  dict(agg="gated_sum", w_edge_attr=False), dict(agg="mattn_h", w_edge_attr=False),
+                  dict(agg="mattn_h", bidirectional=False, out_pool_all=True), dict(agg="gated_sum", num_layers=3)]
+
+
+def test_variant_hip_kernels_wide_hidden(device):
+    """H = 512 and 1024: 8-row workgroups, more than 64 KB of LDS per workgroup at 1024, 16 message elements per lane."""
+    for H, kw in ((512, dict(agg="mattn_h")), (1024, dict(agg="gated_sum")), (1024, dict(agg="max", recurr=0))):
+        _variant_hip_vs_torch(device, kw, H, graphs=6)
+
+
+@pytest.mark.parametrize("H", [72, 256])
+@pytest.mark.parametrize("kw", _VARIANT_CTORS, ids=lambda kw: "-".join("%s=%s" % kv for kv in kw.items()))
+def test_variant_hip_kernels_match_torch_ops_path(device, kw, H):
+    """Every constructor-string variant through csrc/variants.hip (evaluation path) against the differentiable
+    torch-ops path the fixtures pin to the reference - on a batch wide and deep enough for every launch shape,
+    H = 72 (ragged last slice / lane tail) and 256."""
+    _variant_hip_vs_torch(device, kw, H, graphs=24)
+
+
+def _variant_hip_vs_torch(device, kw, H, graphs):
+    from dagnn_amd import DAGNN, ASTNodeEncoder
+    ctor = dict(num_layers=2, bidirectional=True, out_wx=True, out_pool_all=False, out_pool="max")
+    ctor.update(kw)
+    torch.manual_seed(11)
+    model = DAGNN(num_vocab=37, max_seq_len=3, emb_dim=H, hidden_dim=H, out_dim=None,
+                  encoder=ASTNodeEncoder(H, 98, 300, 20), **ctor).eval().to(device)
+    b = synth.code2_batch(77, graphs, 70)
+    b.x[:, 1] %= 300
+    outs, hs = [], []
+    for backend in ("hip", "torch"):
+        model.variant_backend = backend
+        G = b.clone().to(device)
+        with torch.no_grad():
+            outs.append(model(G))
+        hs.append(G.h)
+    def close(a, r):   # sum aggregators grow with fan-in and depth: tolerance relative to the largest entry
+        return Hh.maxdiff(a, r) <= TOL * max(1.0, float(r.abs().max()))
+
+    for a, r in zip(outs[0], outs[1]):
+        assert close(a, r)
+    if isinstance(hs[0], list):
+        for ha, hr in zip(hs[0], hs[1]):
+            for a, r in zip(ha, hr):
+                assert close(a, r)
+    else:
+        assert close(hs[0], hs[1])

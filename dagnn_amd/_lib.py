@@ -71,6 +71,7 @@ class BackwardArgs(C.Structure):
 
 
 AGG_ATTN, AGG_MATTN, AGG_GATED, AGG_ADD, AGG_MAX, AGG_GIVEN = range(6)
+POOL_MAX, POOL_ADD, POOL_MEAN = range(3)
 
 
 class VariantAggregator(C.Structure):
@@ -117,6 +118,8 @@ SYMBOLS = {
                                      C.POINTER(C.c_int32), C.c_void_p]),
     "dagnn_readout_max": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int, C.c_void_p]),
+    "dagnn_readout_pool": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_int, C.c_int, C.c_void_p]),
     "dagnn_backward_prepare": (C.c_int, [C.POINTER(Plan), C.POINTER(BackwardArgs), C.c_void_p]),
     "dagnn_backward_run": (C.c_int, [C.POINTER(Plan), C.POINTER(BackwardArgs), C.POINTER(C.POINTER(C.c_int32)),
                                      C.POINTER(C.c_int32), C.c_void_p]),

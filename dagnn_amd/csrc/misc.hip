@@ -73,6 +73,36 @@ __global__ void __launch_bounds__(256) readout_max_kernel(const int32_t* __restr
     }
 }
 
+// Generic read-out (dagnn.py:194-202 `global_{max,mean,add}_pool`; P_ATTN is a softmax over a size-1 dimension, i.e.
+// add): scope 0 / 1 = the output nodes of direction 0 / 1, scope 2 = every node of the graph (`out_pool_all`).
+// One workgroup per graph, a thread per column, nodes in id order (a fixed summation order).
+__global__ void __launch_bounds__(256) readout_pool_kernel(const int32_t* __restrict__ plan, PlanLayout L, int scope,
+                                                            int mode, const float* __restrict__ h, int ld_h, int width,
+                                                            float* __restrict__ out, int ld_out, int col_off) {
+    const int g = blockIdx.x;
+    const int n0 = plan[L.node_ptr + g];
+    int p0, p1;
+    const int32_t* order = nullptr;
+    if (scope == 2) {
+        p0 = n0; p1 = plan[L.node_ptr + g + 1];
+    } else {
+        const int od = 1 - scope;
+        const int depth = plan[L.depth[od] + g];
+        const int32_t* ls = plan + L.lstart[od] + n0 + g;
+        order = plan + L.order[od];
+        p0 = depth > 0 ? ls[0] : 0; p1 = depth > 0 ? ls[1] : 0;
+    }
+    const float inv = mode == DAGNN_POOL_MEAN ? 1.f / (float)max(p1 - p0, 1) : 1.f;
+    for (int j = threadIdx.x; j < width; j += blockDim.x) {
+        float m = 0.f;  // graphs nothing lands on stay at zero
+        for (int p = p0; p < p1; ++p) {
+            const float v = h[(int64_t)(order ? order[p] : p) * ld_h + j];
+            m = mode == DAGNN_POOL_MAX ? ((p == p0) ? v : fmaxf(m, v)) : m + v;
+        }
+        out[(int64_t)g * ld_out + col_off + j] = m * inv;
+    }
+}
+
 __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ h, int ld_h, int width,
                                                            int stride, int node_off, float* __restrict__ out,
                                                            int ld_out, int col_off) {
@@ -114,6 +144,19 @@ extern "C" int dagnn_readout_max(const dagnn_plan* pl, const float* h, int ld_h,
     PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
     hipLaunchKernelGGL(readout_max_kernel, dim3((unsigned)pl->B), dim3(256), 0, (hipStream_t)stream,
                        (const int32_t*)pl->data, L, dir, h, ld_h, width, out, ld_out, col_off);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
+extern "C" int dagnn_readout_pool(const dagnn_plan* pl, const float* h, int ld_h, int width, int scope, int mode,
+                                  float* out, int ld_out, int col_off, void* stream) {
+    if (!pl || !pl->data || !h || !out || width <= 0 || scope < 0 || scope > 2 || mode < DAGNN_POOL_MAX ||
+        mode > DAGNN_POOL_MEAN || ld_h < width || col_off < 0 || ld_out < col_off + width)
+        return DAGNN_EINVAL;
+    if (pl->B == 0) return DAGNN_OK;
+    PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
+    hipLaunchKernelGGL(readout_pool_kernel, dim3((unsigned)pl->B), dim3(256), 0, (hipStream_t)stream,
+                       (const int32_t*)pl->data, L, scope, mode, h, ld_h, width, out, ld_out, col_off);
     DAGNN_CHECK_LAUNCH();
     return DAGNN_OK;
 }

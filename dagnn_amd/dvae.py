@@ -204,6 +204,10 @@ class _DvaeDagnn(_DvaeBase):
                 G.h = self.hg_unify(G.h)
             elif L > 1:
                 G.h = self.out_linear(G.h)
+            if not (torch.is_grad_enabled() and G.h.requires_grad):   # HIP pooling over the nodes of every graph
+                out = torch.empty(B, G.h.shape[1], dtype=torch.float32, device=G.h.device)
+                engine.readout_pool(plan, G.h, 2, self.out_pool, out, 0)
+                return out
             idx = G.batch.view(-1, 1).expand_as(G.h)
             out = G.h.new_zeros(B, G.h.shape[1])
             if self.out_pool == K.P_MAX:

@@ -409,6 +409,15 @@ def readout_max(plan: PlanHandle, h: torch.Tensor, direction: int, out: torch.Te
                                         out.data_ptr(), out.shape[1], col_off, _stream(h)), "dagnn_readout_max")
 
 
+def readout_pool(plan: PlanHandle, h: torch.Tensor, scope: int, how: str, out: torch.Tensor, col_off: int) -> None:
+    """out[:, col_off : col_off + width] = max / add / mean pool of h over scope 0 / 1 (output nodes of that direction)
+    or 2 (all nodes of the graph)."""
+    h = _rows(h, "hidden states")
+    mode = {"max": _lib.POOL_MAX, "add": _lib.POOL_ADD, "sum": _lib.POOL_ADD, "mean": _lib.POOL_MEAN}[how]
+    check(_lib.load().dagnn_readout_pool(C.byref(plan.desc), h.data_ptr(), h.stride(0), h.shape[1], int(scope), mode,
+                                         out.data_ptr(), out.stride(0), int(col_off), _stream(h)), "dagnn_readout_pool")
+
+
 def readout_max_backward(plan: PlanHandle, h: torch.Tensor, direction: int, grad_out: torch.Tensor, col_off: int,
                          grad_h: torch.Tensor) -> None:
     """grad_h[v, :] += grad_out[g, col_off : col_off + width] at the arg-max output node of every graph/column."""

@@ -375,10 +375,21 @@ class DAGNN(nn.Module):
         L, dirs = self.num_layers, self.dirs
         G.h = [[h[d][i] for i in range(L)] for d in dirs]  # side effect 4 (dagnn.py:141-142,182)
 
+        differentiable = torch.is_grad_enabled() and (x.requires_grad or any(h[d][i].requires_grad
+                                                                             for d in dirs for i in range(L)))
+        hip_pool = plan is not None and not differentiable
+        # P_ATTN (dagnn.py:114-117) is a softmax over a size-1 dimension: weights of exactly 1, i.e. add-pooling
+        how = K.P_ADD if self.out_pool in (K.P_ATTN, K.P_SUM) else self.out_pool
         if self.bidirectional and not self.output_all:
-            differentiable = torch.is_grad_enabled() and any(h[d][i].requires_grad for d in dirs for i in range(L))
-            if self.out_pool == K.P_MAX and plan is not None and not differentiable:
+            if hip_pool and how == K.P_MAX:
                 out = self._readout(plan, B, x, h)   # HIP max-pool over the output nodes
+            elif hip_pool:
+                out = torch.empty(B, self.out_hidden_dim, dtype=torch.float32, device=x.device)
+                col = 0
+                for d in (0, 1):
+                    for t in ([x] if self.out_wx else []) + [h[d][i] for i in range(L)]:
+                        engine.readout_pool(plan, t, d, how, out, col)
+                        col += t.shape[1]
             else:
                 outs = []
                 for d in (0, 1):
@@ -388,10 +399,14 @@ class DAGNN(nn.Module):
                 out = torch.cat(outs, dim=-1)
         else:
             G.h = torch.cat(([x] if self.out_wx else []) + [h[d][i] for d in dirs for i in range(L)], dim=-1)
+            if hip_pool:   # over all nodes, or over the output nodes of direction 0 (dagnn.py:124-126,194-202)
+                out = torch.empty(B, G.h.shape[1], dtype=torch.float32, device=x.device)
+                engine.readout_pool(plan, G.h, 2 if self.output_all else 0, how, out, 0)
             if not self.output_all:
                 idx = G.bi_layer_index[1][1][G.bi_layer_index[1][0] == 0]  # dagnn.py:124-126
                 G.h, G.batch = G.h[idx], G.batch[idx]
-            out = self._pool(G.h, G.batch, B)
+            if not hip_pool:
+                out = self._pool(G.h, G.batch, B)
 
         out = self.dropout(out)
         if self.num_class > 0:

@@ -237,6 +237,15 @@ int dagnn_frontier_run(const dagnn_plan* plan /* host */, const dagnn_frontier_a
 int dagnn_readout_max(const dagnn_plan* plan /* host */, const float* h, int ld_h, int width, int dir,
                       float* out, int ld_out, int col_off, void* stream);
 
+/* The other read-outs of dagnn.py:194-202 (`global_max_pool` / `global_mean_pool` / `global_add_pool`; `P_ATTN`,
+ * dagnn.py:114-117, is a softmax over a size-1 dimension and therefore add-pooling): pool `width` columns of
+ * h [N,ld_h] per graph over scope 0 / 1 = the output nodes of direction 0 / 1 (as dagnn_readout_max) or scope 2 = all
+ * nodes of the graph (`out_pool_all=1`).  Nodes are visited in id order (a fixed summation order); a graph without
+ * nodes in scope reads 0, the mean divides by max(count, 1). */
+enum { DAGNN_POOL_MAX = 0, DAGNN_POOL_ADD = 1, DAGNN_POOL_MEAN = 2 };
+int dagnn_readout_pool(const dagnn_plan* plan /* host */, const float* h, int ld_h, int width, int scope, int mode,
+                       float* out, int ld_out, int col_off, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Backward pass of the recurrence (training: what `loss.backward()`, ogbg-code/main_pyg.py:62, does to
  * dagnn.py:144-182).  Additive attention with keys from the hidden states (`attn_h`), GRU cells.

@@ -348,20 +348,29 @@ def test_out_wx_and_other_pools(device, schedule):
     from dagnn_amd import DAGNN, ASTNodeEncoder
     b = synth.code2_batch(31, 9, 30)
     for kw in (dict(out_wx=True, out_pool="max"), dict(out_wx=False, out_pool="mean"),
-               dict(out_wx=False, out_pool="add", out_pool_all=True), dict(out_wx=False, out_pool="attn")):
+               dict(out_wx=False, out_pool="add", out_pool_all=True), dict(out_wx=False, out_pool="attn"),
+               dict(out_wx=False, out_pool="mean", out_pool_all=True), dict(out_pool="attn", out_pool_all=True),
+               dict(bidirectional=False, out_pool="mean"), dict(bidirectional=False, out_pool="add", out_wx=True),
+               dict(bidirectional=False, out_pool="max", out_pool_all=True)):
         enc = ASTNodeEncoder(32, 98, 10030, 20)
         args = dict(w_edge_attr=True, num_layers=2, bidirectional=True, agg="attn_h", out_wx=False,
                     out_pool_all=False, out_pool="max", dropout=0.0)
         args.update(kw)
         m = DAGNN(num_vocab=12, max_seq_len=3, emb_dim=32, hidden_dim=32, out_dim=None, encoder=enc, **args).eval()
         seeded_fill(m, 77)
-        ref = O.code2_forward(m.state_dict(), copy.deepcopy(b), num_layers=2, bidirectional=True,
+        ref = O.code2_forward(m.state_dict(), copy.deepcopy(b), num_layers=2, bidirectional=args["bidirectional"],
                               out_wx=args["out_wx"], out_pool_all=args["out_pool_all"], out_pool=args["out_pool"],
                               max_seq_len=3)
         m = m.to(device)
+        G = copy.deepcopy(b).to(device)
         with torch.no_grad():
-            out = m(copy.deepcopy(b).to(device))
+            out = m(G)
         assert max(Hh.maxdiff(o, r) for o, r in zip(out, ref)) < TOL, kw
+        if not (args["bidirectional"] and not args["out_pool_all"]):
+            # side effects of dagnn.py:194-202: G.h is the concatenation (of the output nodes only without
+            # out_pool_all, and then G.batch is narrowed with it)
+            rows = b.x.shape[0] if args["out_pool_all"] else int((b._bi_layer_idx1 == 0).sum())
+            assert G.h.shape == (rows, m.out_hidden_dim) and G.batch.shape[0] == rows
 
 
 def test_smoke_entry(device):

@@ -1,0 +1,68 @@
+"""The driver's bench.py contract: one JSON line with the agreed keys (checked on the committed round line here,
+and on a live run in the GPU tier)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _check_line(j, n_gpus, steps, warmup, with_cpu=True):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert j["metric"] == "graphs/sec" and j["unit"] == "graphs/s" and j["higher_is_better"] is True
+    assert j["n_gpus"] == n_gpus and j["steps"] == steps and j["warmup"] == warmup
+    assert j["scaling"] == "weak" and j["data"] == "synthetic" and j["dtype"] == "f32" and j["vs_baseline"] is None
+    assert "workload" in j["config"] and "model" not in j["config"]
+    # value = graphs of all ranks / max-over-ranks time of the timed steps
+    assert abs(j["value"] - j["config"]["global_batch"] / j["ms_per_step"] * 1e3) <= 1e-3 * j["value"]
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0 < r["frac"] < 1
+    if with_cpu:
+        c = j["cpu_baseline"]
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in c, k
+        assert c["kind"] in ("port", "reference") and c["unit"] == j["unit"] and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_committed_round_line_keeps_the_contract():
+    path = os.path.join(ROOT, "profiles", "r01_final_bench.json.log")
+    lines = [l for l in open(path).read().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    _check_line(json.loads(lines[0]), 1, 30, 5)
+
+
+def _run_bench(args, env_extra=None, launcher=()):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    cmd = [sys.executable] + list(launcher) + [os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]   # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line():
+    j = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-passes", "0", "--train-steps", "0"])
+    _check_line(j, 1, 3, 1, with_cpu=False)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_under_torchrun():
+    """The driver's N > 1 launch line (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`);
+    here two ranks share the one visible GPU and rendezvous over gloo (RCCL refuses two ranks on one device)."""
+    launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29517"]
+    j = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-passes", "0", "--train-steps", "2"],
+                   env_extra={"DAGNN_BENCH_BACKEND": "gloo"}, launcher=launcher)
+    _check_line(j, 2, 3, 1, with_cpu=False)
+    assert j["config"]["global_batch"] == 256   # weak scaling: 128 graphs per rank

@@ -87,6 +87,24 @@ def run(mod, G, x: torch.Tensor) -> List[List[Optional[torch.Tensor]]]:
     h: List[List[Optional[torch.Tensor]]] = [[None] * L for _ in range(2)]
     shared_flow = mod.agg in ("add", "max")   # one AggConv for both directions: flow is always source -> target
     for d in mod.dirs:
+        aggr = getattr(mod, "node_aggr_%d" % d)
+        cells = getattr(mod, "cells_%d" % d)
+        if mod.agg_x:
+            # the aggregator reads the node inputs only (dagnn.py:159-169): nothing couples the layers, so the whole
+            # direction is ONE conv over all edges and one cell call per stacked layer over all nodes (a node of
+            # layer 0 has no in-edge: its aggregate row is zero, which is GRUCell(x, None) / the zero block of the
+            # Linear cell)
+            lands = not (shared_flow and d == 1)
+            ps_x = _conv(mod.agg, aggr[0], x, x if mod.agg_attn else None, x if mod.agg_attn else None, ei[d],
+                         ei[1 - d], ids, edge_attr, lands)
+            if ps_x.shape[1] < H:
+                ps_x = torch.cat([ps_x, ps_x.new_zeros(N, H - ps_x.shape[1])], dim=-1)
+            inp, hs = x, []
+            for i in range(L):
+                inp = cells[i](inp, ps_x) if mod.recurr else cells[i](torch.cat([inp, ps_x], dim=1))
+                hs.append(inp)
+            h[d] = hs
+            continue
         layer_of = G.bi_layer_index[d][0]
         T = int(layer_of.max()) + 1 if N else 0
         hs = [x.new_zeros(N, H) for _ in range(L)]
@@ -97,12 +115,9 @@ def run(mod, G, x: torch.Tensor) -> List[List[Optional[torch.Tensor]]]:
         e_ptr = torch.zeros(T + 1, dtype=torch.long)
         e_ptr[1:] = torch.bincount(layer_of[feed], minlength=T).cumsum(0).cpu()
         local = torch.empty(N, dtype=torch.long, device=dev)
-        aggr = getattr(mod, "node_aggr_%d" % d)
-        cells = getattr(mod, "cells_%d" % d)
         for t in range(T):
             rows = ids[layer_of == t]
             inp = x[rows]
-            ps_x = None
             if t > 0:
                 eids = order[int(e_ptr[t]):int(e_ptr[t + 1])]
                 src = other[eids]
@@ -110,16 +125,9 @@ def run(mod, G, x: torch.Tensor) -> List[List[Optional[torch.Tensor]]]:
                 seg = local[feed[eids]]
                 ea = edge_attr[eids] if edge_attr is not None else None
                 lands = not (shared_flow and d == 1)
-                if mod.agg_x:   # one aggregation of the inputs per step, reused by every stacked cell (dagnn.py:159-169)
-                    ps_x = _conv(mod.agg, aggr[0], x, x if mod.agg_attn else None, x if mod.agg_attn else None, src,
-                                 seg, rows, ea, lands)
-                    if ps_x.shape[1] < H:
-                        ps_x = torch.cat([ps_x, ps_x.new_zeros(ps_x.shape[0], H - ps_x.shape[1])], dim=-1)
             for i in range(L):
                 if t == 0:
                     ps = None if mod.recurr else x.new_zeros(rows.shape[0], H)
-                elif mod.agg_x:
-                    ps = ps_x
                 else:
                     keys = query = None
                     if mod.agg_attn:

@@ -663,7 +663,8 @@ def test_variant_forward_matches_reference_golden(device, name):
             assert Hh.maxdiff(h[rows], arr["h_%d_%d" % (d, i)]) < TOL
 
 
-@pytest.mark.parametrize("name", ["var_h64_mattn_h", "var_h64_gated_sum", "var_h64_recurr0"])
+@pytest.mark.parametrize("name", ["var_h64_mattn_h", "var_h64_gated_sum", "var_h64_recurr0", "var_h64_aggx_attn_h",
+                                  "var_h64_aggx_add"])
 def test_variant_training_step_matches_oracle_autograd(device, name):
     meta, arr = Hh.load(name)
     kw = meta["ctor"]

@@ -317,8 +317,8 @@ def test_wide_deep_config_matches_oracle(device, schedule):
     assert max(Hh.maxdiff(o, r) for o, r in zip(out, ref)) < TOL
 
 
-def test_edge_cases(device, schedule):
-    """Single-node graphs, a chain, a star with a 200-way fan-in, and a graph with no edges."""
+def _degenerate_batch():
+    """Single-node graphs, a chain, stars with a 200-way fan-in / fan-out, a graph with no edges, a duplicate edge."""
     from dagnn_amd import GraphData
     from dagnn_amd.dag_utils import add_order_info_01
 
@@ -333,7 +333,12 @@ def test_edge_cases(device, schedule):
     graphs = [g(1, []), g(5, []), g(40, [(i, i + 1) for i in range(39)]),
               g(201, [(i, 200) for i in range(200)], [[i % 2, 0] for i in range(200)]),
               g(201, [(0, i) for i in range(1, 201)]), g(2, [(0, 1), (0, 1)])]
-    b = synth.GraphBatch.from_data_list(graphs)
+    return synth.GraphBatch.from_data_list(graphs)
+
+
+def test_edge_cases(device, schedule):
+    """Single-node graphs, a chain, a star with a 200-way fan-in, and a graph with no edges."""
+    b = _degenerate_batch()
     model = _headline_model(H=64, L=2, V=16, seed=9)
     # shrink the attribute table use: x[:,1] < 300 already
     ref = O.code2_forward(model.state_dict(), copy.deepcopy(b), num_layers=2, bidirectional=True, out_wx=False,
@@ -706,14 +711,23 @@ def test_variant_hip_kernels_match_torch_ops_path(device, kw, H):
     _variant_hip_vs_torch(device, kw, H, graphs=24)
 
 
-def _variant_hip_vs_torch(device, kw, H, graphs):
+@pytest.mark.parametrize("kw", [dict(agg="mattn_h"), dict(agg="gated_sum"), dict(agg="max"), dict(agg="add", agg_x=True),
+                                dict(agg="self_attn_h", recurr=0)],
+                         ids=lambda kw: "-".join("%s=%s" % kv for kv in kw.items()))
+def test_variant_hip_kernels_on_degenerate_graphs(device, kw):
+    """The variant kernels on single-node graphs, graphs without edges, a chain, 200-way fan-in (50 four-edge trips
+    of the aggregate, online softmax) and fan-out, a duplicate edge."""
+    _variant_hip_vs_torch(device, kw, 64, batch=_degenerate_batch())
+
+
+def _variant_hip_vs_torch(device, kw, H, graphs=24, batch=None):
     from dagnn_amd import DAGNN, ASTNodeEncoder
     ctor = dict(num_layers=2, bidirectional=True, out_wx=True, out_pool_all=False, out_pool="max")
     ctor.update(kw)
     torch.manual_seed(11)
     model = DAGNN(num_vocab=37, max_seq_len=3, emb_dim=H, hidden_dim=H, out_dim=None,
                   encoder=ASTNodeEncoder(H, 98, 300, 20), **ctor).eval().to(device)
-    b = synth.code2_batch(77, graphs, 70)
+    b = batch if batch is not None else synth.code2_batch(77, graphs, 70)
     b.x[:, 1] %= 300
     outs, hs = [], []
     for backend in ("hip", "torch"):

@@ -71,7 +71,7 @@ class Recurrence(torch.autograd.Function):
         not differentiable; otherwise returns the states h[d][i] ([N, H] each, d over `dirs`, i over layers) as
         differentiable outputs - any torch read-out can follow (other pools, all nodes, unidirectional)."""
         L, H, dirs = mod.num_layers, mod.hidden_dim, mod.dirs
-        cells = mod._cells()
+        cells = mod._cells(fresh=True)   # a differentiable pass: the optimizer changes the parameters every step
         keep = {}
         sscore = mod._static_scores(x, cells)   # keys from the inputs (`*_x` aggregators): one score per node and cell
         h = run_stack_lockstep(plan, x, cells, dirs, L, H, vid_nodes=mod._vid_nodes, arena=mod._arena_for(x), keep=keep,

@@ -34,15 +34,25 @@ SCHEDULES = ("lockstep", "pergraph")
 
 class DerivedCache(object):
     """Caches tensors derived from parameters (packed / padded weights, folded edge gains) and
-    rebuilds them when any source parameter changed (in-place updates bump `_version`)."""
+    rebuilds them when any source parameter changed (in-place updates bump `_version`).
+
+    The version counter does not see every update: fused optimizers (`torch.optim.Adam(fused=True)`) and writes
+    through `.data` change a parameter without bumping it.  The modules therefore ask for `fresh=True` while they are
+    in training mode (derived tensors are rebuilt on every forward - parameters change every step there anyway) and
+    drop their caches whenever `train()` / `eval()` is called; the cache serves evaluation, where parameters only
+    change through `load_state_dict` / `copy_` (which do bump the counter).  `invalidate()` is the manual override."""
 
     def __init__(self):
         self._key = None
         self._val = None
 
-    def get(self, params: Sequence[torch.Tensor], fn: Callable[[], object]):
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
-        if key != self._key:
+    def invalidate(self) -> None:
+        self._key = None
+        self._val = None
+
+    def get(self, params: Sequence[torch.Tensor], fn: Callable[[], object], fresh: bool = False):
+        key = None if fresh else tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        if fresh or key != self._key:
             with torch.no_grad():
                 self._val = fn()
             self._key = key

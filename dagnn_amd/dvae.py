@@ -105,7 +105,7 @@ class _DvaeDagnn(_DvaeBase):
         self._arenas = {}  # per device: granule buffers of the persistent tail kernel
         self.schedule = default_schedule()  # 'lockstep' (frontier launches) or 'pergraph' (persistent workgroups)
 
-    def _cells(self):
+    def _cells(self, fresh: bool = False):
         srcs: List[torch.Tensor] = []
         for d in self.dirs:
             for i in range(self.num_layers):
@@ -125,7 +125,13 @@ class _DvaeDagnn(_DvaeBase):
                                               self.hidden_dim, dq, i > 0, None, extra, schedule=self.schedule)
             return out
 
-        return self._derived.setdefault(self.schedule, DerivedCache()).get(srcs, make)
+        return self._derived.setdefault(self.schedule, DerivedCache()).get(srcs, make, fresh=fresh or self.training)
+
+    def train(self, mode: bool = True):
+        """Mode switches drop the derived-weight caches (see core.DerivedCache)."""
+        for c in self.__dict__.get("_derived", {}).values():
+            c.invalidate()
+        return super().train(mode)
 
     # ---- hooks of autograd.Recurrence
     @property

@@ -213,7 +213,7 @@ class DAGNN(nn.Module):
         attn_dim = self.emb_dim if self.agg_attn_x else self.hidden_dim
         return (self.emb_dim if i == 0 else attn_dim), key_dim  # AttnConv: Linear(attn_q_dim + attn_dim, 1)
 
-    def _cells(self):
+    def _cells(self, fresh: bool = False):
         srcs: List[torch.Tensor] = []
         for d in self.dirs:
             for i in range(self.num_layers):
@@ -235,7 +235,7 @@ class DAGNN(nn.Module):
                                               schedule=self.schedule, key_dim=kd)
             return out
 
-        return self._derived.setdefault(self.schedule, DerivedCache()).get(srcs, make)
+        return self._derived.setdefault(self.schedule, DerivedCache()).get(srcs, make, fresh=fresh or self.training)
 
     def _arena_for(self, x, role="forward"):
         return self._arenas.setdefault((role, x.device, torch.cuda.current_stream(x.device).cuda_stream),
@@ -312,6 +312,15 @@ class DAGNN(nn.Module):
             out = out / cnt
         return out
 
+    def train(self, mode: bool = True):
+        """Mode switches drop the derived-weight caches (core.DerivedCache: an optimizer may have updated the
+        parameters without bumping their version counters)."""
+        for c in list(self.__dict__.get("_derived", {}).values()) + [self.__dict__.get("_head_cache"),
+                                                                      self.__dict__.get("_variant_cache")]:
+            if c is not None:
+                c.invalidate()
+        return super().train(mode)
+
     def _plan_of(self, G, B):
         if getattr(G, "_dagnn_plan", None) is not None:  # built by the loader (dagnn_amd.host_plan.attach_plan)
             return engine.PlanHandle.from_words(G._dagnn_plan, G._dagnn_plan_meta)
@@ -333,6 +342,9 @@ class DAGNN(nn.Module):
             G.x = self.encoder(G.x, G.node_depth.view(-1, ))
             if self.variant_backend == "torch" or (torch.is_grad_enabled()
                                                     and any(p.requires_grad for p in self.parameters())):
+                for c in (self._head_cache, self.__dict__.get("_variant_cache")):
+                    if c is not None:
+                        c.invalidate()
                 return self._finish(G, None, G.x, variants.run(self, G, G.x), B)   # training: differentiable torch ops
             plan = self._plan_of(G, B)
             return self._finish(G, plan, G.x, variants.run_hip(self, G, G.x, plan), B)
@@ -348,6 +360,7 @@ class DAGNN(nn.Module):
         plan = self._plan_of(G, B)
         fused_readout = self.bidirectional and not self.output_all and self.out_pool == K.P_MAX
         if train:
+            self._head_cache.invalidate()   # the optimizer step that follows may not bump version counters
             # differentiable call: HIP read-out + its backward for the configuration the reference trains
             # (scripts/ogb_tok.sh), otherwise differentiable states and the torch read-outs below
             from .autograd import Recurrence
@@ -417,7 +430,7 @@ class DAGNN(nn.Module):
             heads = list(self.graph_pred_linear_list)
             wcat, bcat = self._head_cache.get([p for hd in heads for p in (hd.weight, hd.bias)],
                                               lambda: (torch.cat([hd.weight for hd in heads], 0),
-                                                       torch.cat([hd.bias for hd in heads], 0)))
+                                                       torch.cat([hd.bias for hd in heads], 0)), fresh=self.training)
             logits = torch.addmm(bcat, out, wcat.t())
             return list(logits.split(self.num_vocab, dim=1))
         return [self.graph_pred_linear_list[i](out) for i in range(self.max_seq_len)]

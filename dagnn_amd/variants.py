@@ -191,7 +191,7 @@ def _derive(mod):
 
     srcs = [q for q in mod.parameters()]
     cache = mod.__dict__.setdefault("_variant_cache", DerivedCache())
-    return cache.get(srcs, make)
+    return cache.get(srcs, make, fresh=mod.training)
 
 
 _MODES = {"add": _lib.AGG_ADD, "max": _lib.AGG_MAX, "gated_sum": _lib.AGG_GATED}

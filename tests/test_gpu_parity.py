@@ -747,3 +747,35 @@ def _variant_hip_vs_torch(device, kw, H, graphs=24, batch=None):
                 assert close(a, r)
     else:
         assert close(hs[0], hs[1])
+
+
+def test_fused_optimizer_updates_reach_the_kernels(device):
+    """`torch.optim.Adam(fused=True)` changes the parameters WITHOUT bumping their version counters; the packed
+    weights the kernels read must follow anyway (core.DerivedCache): two models trained with the foreach and the
+    fused optimizer stay together, in train mode and with the module left in eval mode, and the evaluation forward
+    after the steps sees the new weights."""
+    meta, arr = Hh.load("grad_h32_bidir")
+    y = torch.from_numpy(arr["y"]).to(device) if "y" in arr else None
+    outs = {}
+    for fused in (False, True):
+        for mode in ("train", "eval"):
+            model = Hh.code2_model(meta).to(device)
+            getattr(model, mode)()
+            opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-2, fused=fused)
+            with torch.no_grad():
+                before = torch.stack(model(Hh.code2_batch(arr, device)))   # fills the evaluation caches
+            for _ in range(3):
+                opt.zero_grad()
+                pred = model(Hh.code2_batch(arr, device))
+                tgt = y if y is not None else torch.zeros(pred[0].shape[0], len(pred), dtype=torch.long, device=device)
+                loss = sum(torch.nn.functional.cross_entropy(p, tgt[:, s]) for s, p in enumerate(pred)) / len(pred)
+                loss.backward()
+                opt.step()
+            with torch.no_grad():
+                after = torch.stack(model(Hh.code2_batch(arr, device)))
+            assert Hh.maxdiff(after, before) > 1e-3   # the steps did something
+            outs[(fused, mode)] = (float(loss.detach()), after)
+    for mode in ("train", "eval"):
+        (l0, a0), (l1, a1) = outs[(False, mode)], outs[(True, mode)]
+        assert abs(l0 - l1) < 1e-4 * max(1.0, abs(l0)), (mode, l0, l1)
+        assert Hh.maxdiff(a0, a1) < 1e-3, mode

@@ -41,6 +41,14 @@ class LayerArgs(C.Structure):
 MAX_STACKED = 8
 
 
+class PackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("out_slices16", C.c_void_p), ("out_slices32", C.c_void_p), ("out_mfma", C.c_void_p),
+                ("H", C.c_int32), ("K", C.c_int32)]
+
+
+MAX_PACK_JOBS = 16
+
+
 class FrontierCell(C.Structure):
     _fields_ = [("w_hh_pk16", C.c_void_p), ("w_hh_pk32", C.c_void_p), ("w_ih_pk16", C.c_void_p),
                 ("w_ih_pk32", C.c_void_p), ("w_hh_mfma", C.c_void_p), ("w_ih_mfma", C.c_void_p), ("b_hh", C.c_void_p), ("b_ih", C.c_void_p), ("w_key", C.c_void_p),
@@ -113,6 +121,7 @@ SYMBOLS = {
     "dagnn_pack_whh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_recurrence_layer": (C.c_int, [C.POINTER(Plan), C.POINTER(LayerArgs), C.c_int, C.c_int, C.c_void_p]),
     "dagnn_pack_slices": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dagnn_pack_batch": (C.c_int, [C.POINTER(PackJob), C.c_int, C.c_void_p]),
     "dagnn_pack_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dagnn_frontier_run": (C.c_int, [C.POINTER(Plan), C.POINTER(FrontierArgs), C.POINTER(C.POINTER(C.c_int32)),
                                      C.POINTER(C.c_int32), C.c_void_p]),

@@ -84,9 +84,23 @@ class CellParams(object):
                  "b_ih_dev", "Hp", "key_raw", "w_hh_raw")
 
 
+def pack_lockstep(cells) -> None:
+    """The lock-step kernels' weight layouts of every cell derived with `pack=False`: one `dagnn_pack_batch` launch
+    for all matrices instead of three launches per matrix."""
+    todo = []
+    for c in cells:
+        todo.append((c, "w_hh_pk", c.w_hh_raw))
+        if c.b_ih_dev is not None:
+            todo.append((c, "w_ih_pk", c.w_ih))
+    if not todo:
+        return
+    for (c, name, _), packed in zip(todo, engine.pack_batch([w for _, _, w in todo], todo[0][0].Hp)):
+        setattr(c, name, packed)
+
+
 def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: bool,
                 edge_w: Optional[torch.Tensor], vid_nodes: int, schedule: str = "pergraph",
-                key_dim: Optional[int] = None) -> CellParams:
+                key_dim: Optional[int] = None, pack: bool = True) -> CellParams:
     """Fold / pack one cell's parameters for the kernels.
 
     attn_w is `attn_lin.weight` [1, dq + H (+ vid_nodes)]: the first dq entries multiply the query
@@ -106,11 +120,12 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
     whh = _pad_cols(_pad_gate_rows(w_hh.detach().float(), H, Hp), Hp)
     c.w_hh_raw = whh  # torch layout, padded: the backward sweep reads it as is
     c.w_hh_t = None if lock else engine.pack_whh(whh)
-    c.w_hh_pk = {js: engine.pack_slices(whh, Hp, js) for js in (16, 32)} if lock else None
-    c.w_ih_pk = {js: engine.pack_slices(wi, Hp, js) for js in (16, 32)} if (lock and in_is_hidden) else None
-    if lock:
+    c.w_hh_pk = c.w_ih_pk = None
+    if lock and pack:   # pack=False: the caller batches the packing of all its cells (pack_lockstep)
+        c.w_hh_pk = {js: engine.pack_slices(whh, Hp, js) for js in (16, 32)}
         c.w_hh_pk["mfma"] = engine.pack_mfma(whh, Hp)
         if in_is_hidden:
+            c.w_ih_pk = {js: engine.pack_slices(wi, Hp, js) for js in (16, 32)}
             c.w_ih_pk["mfma"] = engine.pack_mfma(wi, Hp)
     c.b_ih_dev = c.b_ih if (lock and in_is_hidden) else None
     c.b_hh = _pad_gate_rows(b_hh.detach().float(), H, Hp)

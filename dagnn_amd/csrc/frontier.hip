@@ -788,11 +788,10 @@ __global__ void __launch_bounds__(512, 2) frontier_mfma_kernel(const int32_t* __
 // Pack W [3H, K] (torch layout) into MFMA B-fragment order for 32-unit slices:
 // out[((sl * 3 + g) * (K/8) + k8) * 64 + lane] (float4): element q = W[g*H + sl*32 + (lane & 31)][8*k8 + 2*q + (lane >> 5)],
 // i.e. the B operand of the q-th of four consecutive v_mfma_f32_32x32x2_f32 (k pair 2*(4*k8+q)).
-__global__ void __launch_bounds__(256) pack_mfma_kernel(const float* __restrict__ W, float4* __restrict__ out, int H,
-                                                         int K, int64_t total) {
+__device__ __forceinline__ void pack_mfma_range(const float* __restrict__ W, float4* __restrict__ out, int H, int K,
+                                                int64_t total, int64_t first, int64_t stride) {
     const int k8n = K >> 3;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = first; idx < total; idx += stride) {
         const int lane = (int)(idx & 63);
         int64_t rest = idx >> 6;
         const int k8 = (int)(rest % k8n); rest /= k8n;
@@ -802,6 +801,11 @@ __global__ void __launch_bounds__(256) pack_mfma_kernel(const float* __restrict_
         const int k = 8 * k8 + (lane >> 5);
         out[idx] = make_float4(W[row * K + k], W[row * K + k + 2], W[row * K + k + 4], W[row * K + k + 6]);
     }
+}
+
+__global__ void __launch_bounds__(256) pack_mfma_kernel(const float* __restrict__ W, float4* __restrict__ out, int H,
+                                                         int K, int64_t total) {
+    pack_mfma_range(W, out, H, K, total, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
 // ---- launch-per-layer kernel: one launch = one batch-level topological layer, all cells
@@ -910,12 +914,11 @@ __global__ void __launch_bounds__(FT, 1) frontier_tail_kernel(const int32_t* __r
 // slices of JS units: out[((sl * kpt + kk) * NCW + w) * 64 + lane] (float4) = the 4 columns of column
 // group cg = 4w + (lane >> 4) of slice sl at k = (lane & 15) * kpt + kk; local column lc = 4cg + q
 // -> gate lc / JS, unit sl*JS + lc % JS.
-__global__ void __launch_bounds__(256) pack_slices_kernel(const float* __restrict__ W, float4* __restrict__ out, int H,
-                                                           int K, int JS, int64_t total) {
+__device__ __forceinline__ void pack_slices_range(const float* __restrict__ W, float4* __restrict__ out, int H, int K,
+                                                  int JS, int64_t total, int64_t first, int64_t stride) {
     const int kpt = K >> 4;
     const int NCW = 3 * JS / 16;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = first; idx < total; idx += stride) {
         const int lane = (int)(idx & 63);
         int64_t rest = idx >> 6;
         const int w = (int)(rest % NCW); rest /= NCW;
@@ -932,6 +935,24 @@ __global__ void __launch_bounds__(256) pack_slices_kernel(const float* __restric
         }
         out[idx] = make_float4(v[0], v[1], v[2], v[3]);
     }
+}
+
+__global__ void __launch_bounds__(256) pack_slices_kernel(const float* __restrict__ W, float4* __restrict__ out, int H,
+                                                           int K, int JS, int64_t total) {
+    pack_slices_range(W, out, H, K, JS, total, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
+                      (int64_t)gridDim.x * blockDim.x);
+}
+
+// All three layouts of up to DAGNN_MAX_PACK_JOBS matrices in ONE launch (training re-packs every cell every step:
+// 18 small launches otherwise).  blockIdx.y = layout (16-unit slices, 32-unit slices, MFMA fragments), blockIdx.z = job.
+struct PackJobs { dagnn_pack_job j[DAGNN_MAX_PACK_JOBS]; };
+__global__ void __launch_bounds__(256) pack_batch_kernel(PackJobs P) {
+    const dagnn_pack_job& J = P.j[blockIdx.z];
+    const int64_t total = (int64_t)3 * J.H * J.K / 4;
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    if (blockIdx.y == 0) { if (J.out_slices16) pack_slices_range(J.w, reinterpret_cast<float4*>(J.out_slices16), J.H, J.K, 16, total, first, stride); }
+    else if (blockIdx.y == 1) { if (J.out_slices32) pack_slices_range(J.w, reinterpret_cast<float4*>(J.out_slices32), J.H, J.K, 32, total, first, stride); }
+    else if (J.out_mfma) pack_mfma_range(J.w, reinterpret_cast<float4*>(J.out_mfma), J.H, J.K, total, first, stride);
 }
 
 template <int JS, int RBT, int KW, int MINW>
@@ -953,6 +974,25 @@ extern "C" int dagnn_pack_slices(const float* w, float* out, int H, int K, int s
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(pack_slices_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w,
                        reinterpret_cast<float4*>(out), H, K, slice_units, total);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
+extern "C" int dagnn_pack_batch(const dagnn_pack_job* jobs, int num_jobs, void* stream) {
+    if (!jobs || num_jobs < 0 || num_jobs > DAGNN_MAX_PACK_JOBS) return DAGNN_EINVAL;
+    if (num_jobs == 0) return DAGNN_OK;
+    PackJobs P;
+    int64_t most = 0;
+    for (int i = 0; i < num_jobs; ++i) {
+        const dagnn_pack_job& J = jobs[i];
+        if (!J.w || J.H <= 0 || J.K <= 0 || (J.H % 32) || (J.K % 64)) return DAGNN_EINVAL;
+        P.j[i] = J;
+        const int64_t total = (int64_t)3 * J.H * J.K / 4;
+        most = total > most ? total : most;
+    }
+    int64_t blocks = (most + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)blocks, 3, (unsigned)num_jobs), dim3(256), 0, (hipStream_t)stream, P);
     DAGNN_CHECK_LAUNCH();
     return DAGNN_OK;
 }

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import constants as K
 from . import engine
-from .core import DerivedCache, default_schedule, derive_cell, run_stack
+from .core import DerivedCache, default_schedule, derive_cell, pack_lockstep, run_stack
 from .data import GraphBatch
 from .model import _EdgeAttnParams
 
@@ -122,7 +122,10 @@ class _DvaeDagnn(_DvaeBase):
                     a = getattr(self, "node_aggr_%d" % d)[i]
                     dq = self.emb_dim if i == 0 else self.hidden_dim + extra
                     out[(d, i)] = derive_cell(c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh, a.attn_lin.weight,
-                                              self.hidden_dim, dq, i > 0, None, extra, schedule=self.schedule)
+                                              self.hidden_dim, dq, i > 0, None, extra, schedule=self.schedule,
+                                              pack=False)
+            if self.schedule == "lockstep":
+                pack_lockstep(out.values())
             return out
 
         return self._derived.setdefault(self.schedule, DerivedCache()).get(srcs, make, fresh=fresh or self.training)

@@ -268,6 +268,24 @@ def pack_mfma(w: torch.Tensor, H: int) -> torch.Tensor:
     return out
 
 
+def pack_batch(mats: Sequence[torch.Tensor], H: int):
+    """All three lock-step layouts ({16: .., 32: .., "mfma": ..}) of every [3H, K] matrix in `mats`, one launch per 16
+    matrices (`dagnn_pack_batch`)."""
+    mats = [_dev(w, "weight", torch.float32) for w in mats]
+    outs = []
+    for base in range(0, len(mats), _lib.MAX_PACK_JOBS):
+        chunk = mats[base:base + _lib.MAX_PACK_JOBS]
+        jobs = (_lib.PackJob * len(chunk))()
+        for j, w in zip(jobs, chunk):
+            o = {k: torch.empty(3 * H * w.shape[1], dtype=torch.float32, device=w.device) for k in (16, 32, "mfma")}
+            outs.append(o)
+            j.w, j.out_slices16, j.out_slices32, j.out_mfma = w.data_ptr(), o[16].data_ptr(), o[32].data_ptr(), \
+                o["mfma"].data_ptr()
+            j.H, j.K = H, w.shape[1]
+        check(_lib.load().dagnn_pack_batch(jobs, len(chunk), _stream(chunk[0])), "dagnn_pack_batch")
+    return outs
+
+
 def frontier_ld(H: int) -> int:
     """Row pitch of the lock-step state buffers: H states + H/16 partial scores, 16-byte multiple."""
     return H + (H // 16 + 3) // 4 * 4

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import constants as K
 from . import engine
-from .core import DerivedCache, default_schedule, derive_cell, num_graphs_of, run_stack
+from .core import DerivedCache, default_schedule, derive_cell, num_graphs_of, pack_lockstep, run_stack
 
 
 class ASTNodeEncoder(nn.Module):
@@ -232,7 +232,9 @@ class DAGNN(nn.Module):
                     dq, kd = self._attn_geometry(i)
                     out[(d, i)] = derive_cell(c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh, a.attn_lin.weight,
                                               self.hidden_dim, dq, i > 0, a.edge_encoder.weight if a.wea else None, 0,
-                                              schedule=self.schedule, key_dim=kd)
+                                              schedule=self.schedule, key_dim=kd, pack=False)
+            if self.schedule == "lockstep":
+                pack_lockstep(out.values())
             return out
 
         return self._derived.setdefault(self.schedule, DerivedCache()).get(srcs, make, fresh=fresh or self.training)

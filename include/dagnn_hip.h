@@ -170,6 +170,18 @@ int dagnn_pack_slices(const float* w /* [3H,K] */, float* out /* 3H*K floats */,
  * the 32-row tiles of the fattest launches. */
 int dagnn_pack_mfma(const float* w /* [3H,K] */, float* out, int H, int K, void* stream);
 
+/* Both slice layouts and the MFMA layout of several matrices in ONE launch (a training step re-packs every cell's
+ * weights: 18 launches at L = 2 otherwise).  Outputs that are NULL are skipped. */
+#define DAGNN_MAX_PACK_JOBS 16
+typedef struct dagnn_pack_job {
+    const float* w;      /* [3H,K] torch layout */
+    float* out_slices16; /* 3H*K floats each, as dagnn_pack_slices(.., 16) / (.., 32) / dagnn_pack_mfma would write them */
+    float* out_slices32;
+    float* out_mfma;
+    int32_t H, K;
+} dagnn_pack_job;
+int dagnn_pack_batch(const dagnn_pack_job* jobs /* host */, int num_jobs, void* stream);
+
 typedef struct dagnn_frontier_cell {
     const float* w_hh_pk16; /* weight_hh packed for 16-unit slices */
     const float* w_hh_pk32; /* ... and for 32-unit slices */

@@ -46,6 +46,10 @@ def test_host_only_entry_points_without_gpu():
     assert lib.dagnn_encode_ast(None, None, None, None, None, 20, None, 6, 5, 6, None) == -22  # H % 4 != 0
     assert lib.dagnn_gather_rows(None, 4, 4, 1, 8, 9, None, 4, 0, None) == -22
     assert lib.dagnn_readout_pool(None, None, 4, 4, 0, 0, None, 4, 0, None) == -22
+    assert lib.dagnn_pack_batch(None, 1, None) == -22
+    job = (_lib.PackJob * 1)()
+    job[0].w, job[0].H, job[0].K = 64, 48, 64   # H % 32 != 0
+    assert lib.dagnn_pack_batch(job, 1, None) == -22 and lib.dagnn_pack_batch(job, 0, None) == 0
     # variant entry points: the ctypes mirrors and the C structs agree on the layout (a misplaced field would move
     # the one bad value these cases plant)
     plan = _lib.Plan(None, 0, 4, 3, 1, 0)

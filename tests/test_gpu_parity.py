@@ -779,3 +779,15 @@ def test_fused_optimizer_updates_reach_the_kernels(device):
         (l0, a0), (l1, a1) = outs[(False, mode)], outs[(True, mode)]
         assert abs(l0 - l1) < 1e-4 * max(1.0, abs(l0)), (mode, l0, l1)
         assert Hh.maxdiff(a0, a1) < 1e-3, mode
+
+
+def test_batched_weight_packing_equals_single_packs(device):
+    """`dagnn_pack_batch` (one launch for all matrices and layouts) writes exactly what `dagnn_pack_slices` /
+    `dagnn_pack_mfma` write one matrix and one layout at a time; more matrices than one launch takes."""
+    g = torch.Generator().manual_seed(4)
+    for H, n in ((64, 3), (256, 18)):
+        mats = [torch.randn(3 * H, H, generator=g).to(device) for _ in range(n)]
+        for w, packed in zip(mats, engine.pack_batch(mats, H)):
+            assert torch.equal(packed[16], engine.pack_slices(w, H, 16))
+            assert torch.equal(packed[32], engine.pack_slices(w, H, 32))
+            assert torch.equal(packed["mfma"], engine.pack_mfma(w, H))

@@ -305,6 +305,24 @@ def test_headline_properties(device, schedule):
     assert torch.equal(out_r.flip(1), out_a)
 
 
+def test_wide_deep_config_full_size_properties(device):
+    """cfg 5 at BASELINE.json's full size (B=256, h=512, L=5, bidirectional; the oracle needs minutes there): bitwise
+    run-to-run determinism, graph-order equivariance, and the 64 deepest / widest graphs alone give the rows they
+    give inside the full batch (to rounding: another batch takes other launch shapes)."""
+    model = _headline_model(H=512, L=5, V=32, seed=5).to(device)
+    graphs = synth.code2_graphs(3, 256)
+    full = synth.GraphBatch.from_data_list(graphs)
+    with torch.no_grad():
+        a = torch.stack(model(full.clone().to(device)))
+        b = torch.stack(model(full.clone().to(device)))
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+        rev = torch.stack(model(synth.GraphBatch.from_data_list(graphs[::-1]).to(device)))
+        assert Hh.maxdiff(rev.flip(1), a) < 2e-5
+        order = sorted(range(256), key=lambda g: -graphs[g].x.shape[0])[:64]
+        sub = torch.stack(model(synth.GraphBatch.from_data_list([graphs[g] for g in order]).to(device)))
+        assert Hh.maxdiff(sub, a[:, order]) < 2e-5
+
+
 def test_wide_deep_config_matches_oracle(device, schedule):
     """cfg 5 shape (h=512, L=5, bidir) on a 24-graph batch."""
     model = _headline_model(H=512, L=5, V=32, seed=5)

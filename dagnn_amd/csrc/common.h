@@ -70,10 +70,10 @@ __host__ __device__ inline PlanLayout dagnn_plan_layout_words(int64_t N, int64_t
 // Plan header words
 enum { PH_N = 0, PH_E = 1, PH_B = 2, PH_R = 3, PH_MAGIC = 4, PH_THR0 = 5, PH_THR1 = 6 };
 // A batch-level layer with more rows than this is "fat"; thr_d = 1 + the last fat layer of direction d
-// (0 if none): graphs deeper than thr_d are the DEEP graphs of direction d.  16 = the rows one pass of the
-// persistent kernel's replicas covers (4 replicas x 4-row blocks); measured best on the headline batch
-// (recurrence per forward with 8: 3.49 ms, 10: 3.34, 12: 3.17, 14: 3.12, 16: 3.12, 24: 3.99, 32: 4.29).
-#define DAGNN_PLAN_THIN_ROWS 16
+// (0 if none): graphs deeper than thr_d are the DEEP graphs of direction d.  About one pass of the persistent
+// kernel's replicas (4 replicas x 4-row blocks = 16 rows); measured on the headline batch (recurrence per forward,
+// MFMA tiles from 300 rows: 10: 3.30 ms, 12: 3.09, 13: 3.02, 14: 3.02, 15: 3.05, 16: 3.11, 24: 3.99, 32: 4.29).
+#define DAGNN_PLAN_THIN_ROWS 14
 #define DAGNN_PLAN_MAGIC 0x44414731  // "DAG1"
 
 // ------------------------------------------------------------------ wave-level reductions

@@ -62,7 +62,7 @@ def _env_int(name: str, default: int) -> int:
 # Launch-geometry knobs (read once at import; the defaults are the measured optima on MI355X).
 # Tests flip some of them to force the less common code paths.
 RB4_MAX_WGS = _env_int("DAGNN_AMD_RB4_MAX_WGS", 0)          # 4-row vs 8-row blocks of the streamed kernel; 0 = library default
-MFMA_MIN_ROWS = _env_int("DAGNN_AMD_MFMA_MIN_ROWS", 400)    # launches with at least this many rows use MFMA tiles; 0 = never
+MFMA_MIN_ROWS = _env_int("DAGNN_AMD_MFMA_MIN_ROWS", 300)    # launches with at least this many rows use MFMA tiles; 0 = never
 AGG_SPLIT = _env_int("DAGNN_AMD_AGG_SPLIT", 0)              # allocate the gather scratch even without MFMA tiles (tests)
 TAIL_SLICE = _env_int("DAGNN_AMD_TAIL_SLICE", 32)           # hidden units per workgroup of the persistent kernel (16 | 32)
 TAIL_REPLICAS = _env_int("DAGNN_AMD_TAIL_REPLICAS", 4)      # workgroups per (cell, slice); 0 = one launch per layer throughout

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 PLAN_MAGIC = 0x44414731  # "DAG1", csrc/common.h
-THIN_ROWS = 16            # DAGNN_PLAN_THIN_ROWS, csrc/common.h
+THIN_ROWS = 14            # DAGNN_PLAN_THIN_ROWS, csrc/common.h
 
 
 def _align4(w: int) -> int:

@@ -444,7 +444,7 @@ int dagnn_topo_layers(const int64_t* edge_index /* [2,E] */, const int64_t* batc
  * total, blptr0, blptr1, rowrec0, rowrec1, slot0, slot1, eidx0, eidx1, blsplit0, blsplit1].  slot_d [N]: rowrec
  * slot of every node; eidx_d [E]: original edge id (column of edge_index) of every CSR slot; blsplit_d [N+2]: per
  * batch-level layer the first slot of the rows of the DEEP graphs of direction d (depth > thr_d, int32 header word
- * 5 + d of the plan; thr_d = 1 + the last layer with more than 16 rows) - inside a layer the shallow graphs' rows
+ * 5 + d of the plan; thr_d = 1 + the last layer with more than 14 rows) - inside a layer the shallow graphs' rows
  * come first.  blptr_d holds N+2 int32: the offsets of the
  * batch-level topological layers of direction d (entries 0..T_d) and T_d itself at index N+1. */
 int dagnn_plan_layout(int64_t N, int64_t E, int64_t B, int num_edge_feats, int64_t* offsets26 /* host */);

@@ -7,9 +7,12 @@
 
 A "step" is ONE end-to-end forward(G) over one batch (plan build + AST encoder + L x (input GEMM +
 recurrence) + read-out + 5 vocabulary heads), inputs already resident in HBM.  Workload = cfg 2
-of BASELINE.json: synthetic ogbg-code2-like ASTs (seed = rank), batch=128,
-h=256, L=2, bidirectional, vocab 5002 x 5 heads, fp32.  Graph-parallel weak scaling: every rank
-runs its own 128-graph batch, no data-path collective (graphs are independent).
+of BASELINE.json: synthetic ogbg-code2-like ASTs, batch=128, h=256, L=2,
+bidirectional, vocab 5002 x 5 heads, fp32.  Graph-parallel weak scaling: every rank runs its own copy
+of the 128-graph headline batch (seed 0) - per-GPU work is literally fixed as N grows, so the N > 1
+values measure the system, not the depth spread of the synthetic shards (seeds 0..7 have 195..439
+topological layers; `--rank-seeds` draws batch `rank` on rank `rank` instead and the slowest shard
+then sets the time).  No data-path collective (graphs are independent).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the per-layer recurrence):
 duration from HIP events on the launching stream inside the timed region.  `cpu_baseline` is the
@@ -146,6 +149,8 @@ def main():
     ap.add_argument("--vocab", type=int, default=5002)
     ap.add_argument("--cpu-passes", type=int, default=3, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--rank-seeds", action="store_true",
+                    help="rank r draws batch r (different depths per rank) instead of the headline batch everywhere")
     ap.add_argument("--train-steps", type=int, default=10,
                     help="also time this many full training steps (fwd + bwd + optimizer) after the headline "
                          "forward measurement and report them as `training_step`; 0 disables the leg")
@@ -190,7 +195,8 @@ def main():
         # concurrent persistent tail kernels must all stay co-resident: shrink each one's grid
         os.environ.setdefault("DAGNN_AMD_TAIL_REPLICAS", str(max(1, 4 // args.streams)))
     model = build_model(H, L, V, S, device)
-    batch_cpu = code2_batch(seed=rank, num_graphs=B)  # weak scaling: one B-graph batch per rank
+    # weak scaling: one B-graph batch per rank, by default the same headline batch everywhere (module docstring)
+    batch_cpu = code2_batch(seed=rank if args.rank_seeds else 0, num_graphs=B)
     N, E = batch_cpu.x.shape[0], batch_cpu.edge_index.shape[1]
     T = int(batch_cpu._bi_layer_idx0.max()) + 1
     master = batch_cpu.clone().to(device)
@@ -267,9 +273,10 @@ def main():
         "metric": "graphs/sec", "value": round(value, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "ogbg-code2-like synthetic ASTs (SURVEY.md App. E, seed=rank), batch=%d h=%d L=%d "
+        "config": {"workload": "ogbg-code2-like synthetic ASTs (SURVEY.md App. E, %s), batch=%d h=%d L=%d "
                                "bidirectional attn_h, max-pool over output nodes, %d heads x vocab %d, forward(G) "
-                               "end-to-end incl. plan build" % (B, H, L, S, V),
+                               "end-to-end incl. plan build" % ("seed=rank" if args.rank_seeds else
+                                                                "seed 0: the headline batch on every rank", B, H, L, S, V),
                    "global_batch": world * B, "nodes_per_batch": N, "edges_per_batch": E, "topo_layers": T,
                    "parallelism": "graph-parallel x%d, no data-path collective" % world,
                    "streams_per_gpu": args.streams},

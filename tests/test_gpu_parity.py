@@ -809,3 +809,66 @@ def test_batched_weight_packing_equals_single_packs(device):
             assert torch.equal(packed[16], engine.pack_slices(w, H, 16))
             assert torch.equal(packed[32], engine.pack_slices(w, H, 32))
             assert torch.equal(packed["mfma"], engine.pack_mfma(w, H))
+
+
+def _random_ctor(rng):
+    agg = str(rng.choice(["attn_h", "attn_h", "attn_x", "self_attn_h", "self_attn_x"]))
+    bidir = bool(rng.integers(0, 2))
+    out_pool_all = bool(rng.integers(0, 2))
+    out_wx = bool(rng.integers(0, 2)) and not (bidir and out_pool_all)   # the reference's head width is wrong there
+    return dict(agg=agg, bidirectional=bidir, num_layers=int(rng.integers(1, 4)), w_edge_attr=bool(rng.integers(0, 2)),
+                out_wx=out_wx, out_pool_all=out_pool_all, out_pool=str(rng.choice(["max", "mean", "add", "attn"])),
+                num_class=int(rng.choice([0, 0, 7])))
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_configurations_match_oracle(device, case):
+    """Seeded random walk over the constructor space of the HIP recurrence (aggregator, directions, 1-3 stacked
+    layers, edge encoder on/off, every read-out, classification head) x hidden sizes that are not multiples of 64
+    x batch shapes, forward against the oracle."""
+    from dagnn_amd import DAGNN, ASTNodeEncoder
+    rng = np.random.default_rng(1000 + case)
+    H = int(rng.choice([20, 32, 48, 64, 100, 128, 192, 256, 300]))
+    kw = _random_ctor(rng)
+    B, mean_n = int(rng.integers(1, 40)), int(rng.choice([12, 30, 80]))
+    b = synth.code2_batch(int(rng.integers(0, 10 ** 6)), B, mean_n)
+    b.x[:, 1] %= 300
+    model = DAGNN(num_vocab=11, max_seq_len=3, emb_dim=H, hidden_dim=H, out_dim=None, encoder=ASTNodeEncoder(H, 98, 300, 20),
+                  dropout=0.0, **kw).eval()
+    seeded_fill(model, 5000 + case)
+    ref = O.code2_forward(model.state_dict(), copy.deepcopy(b), num_layers=kw["num_layers"], bidirectional=kw["bidirectional"],
+                          out_wx=kw["out_wx"], out_pool_all=kw["out_pool_all"], out_pool=kw["out_pool"], max_seq_len=3,
+                          num_class=kw["num_class"], agg=kw["agg"])
+    model = model.to(device)
+    with torch.no_grad():
+        out = model(b.to(device))
+    out, ref = (out if isinstance(out, (list, tuple)) else [out]), (ref if isinstance(ref, (list, tuple)) else [ref])
+    scale = max(1.0, max(float(r.abs().max()) for r in ref))
+    assert max(Hh.maxdiff(o, r) for o, r in zip(out, ref)) < TOL * scale, (H, kw, B, mean_n)
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_random_configurations_gradients_match_oracle(device, case):
+    """The same random walk for one training step: loss and every parameter gradient against autograd through the
+    oracle (multi-head models; hidden sizes that are multiples of 4)."""
+    from dagnn_amd import DAGNN, ASTNodeEncoder
+    rng = np.random.default_rng(2000 + case)
+    H = int(rng.choice([20, 32, 64, 100, 128, 192]))
+    kw = _random_ctor(rng)
+    kw["num_class"] = 0
+    B, mean_n = int(rng.integers(2, 24)), int(rng.choice([12, 30, 60]))
+    b = synth.code2_batch(int(rng.integers(0, 10 ** 6)), B, mean_n)
+    b.x[:, 1] %= 300
+    model = DAGNN(num_vocab=11, max_seq_len=3, emb_dim=H, hidden_dim=H, out_dim=None, encoder=ASTNodeEncoder(H, 98, 300, 20),
+                  dropout=0.0, **kw).eval()
+    seeded_fill(model, 6000 + case)
+    y = torch.from_numpy(rng.integers(0, 11, size=(B, 3)))
+    loss_ref, ref = O.code2_grads(model.state_dict(), copy.deepcopy(b), y, num_layers=kw["num_layers"],
+                                  bidirectional=kw["bidirectional"], out_wx=kw["out_wx"], out_pool_all=kw["out_pool_all"],
+                                  out_pool=kw["out_pool"], max_seq_len=3, agg=kw["agg"])
+    model = model.to(device)
+    loss, grads = _train_step(model, b.to(device), y.to(device))
+    assert abs(float(loss) - float(loss_ref)) < 1e-5 * max(1.0, abs(float(loss_ref))), (H, kw)
+    for k, g in grads.items():
+        scale = float(ref[k].abs().max())
+        assert Hh.maxdiff(g, ref[k]) <= 1e-4 * scale + 2e-7, (k, H, kw)

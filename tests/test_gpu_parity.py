@@ -872,3 +872,30 @@ def test_random_configurations_gradients_match_oracle(device, case):
     for k, g in grads.items():
         scale = float(ref[k].abs().max())
         assert Hh.maxdiff(g, ref[k]) <= 1e-4 * scale + 2e-7, (k, H, kw)
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_random_dvae_encoders_match_oracle(device, case):
+    """Seeded random D-VAE encoder configurations (NA with vertex-id keys / BN, 1-3 stacked layers, uni- and
+    bidirectional, end-vertex read-out or pooling over all nodes, hidden sizes off the 64 grid) against the oracle."""
+    from dagnn_amd import DAGNN_NA, DAGNN_BN
+    rng = np.random.default_rng(3000 + case)
+    na = bool(rng.integers(0, 2))
+    hs = int(rng.choice([24, 56, 64, 100, 128, 200, 256]))
+    L, bidir = int(rng.integers(1, 4)), bool(rng.integers(0, 2))
+    pool_all = bool(rng.integers(0, 2))
+    pool = str(rng.choice(["max", "mean", "add"]))
+    B = int(rng.integers(1, 70))
+    cls, nn_ = (DAGNN_NA, 8) if na else (DAGNN_BN, 10)
+    model = cls(nn_, hs, hs, nn_, nn_, 0, 1, hs=hs, nz=56, num_nodes=nn_, agg="attn_h", num_layers=L, bidirectional=bidir,
+                out_wx=False, out_pool_all=pool_all, out_pool=pool, dropout=0.0).eval()
+    seeded_fill(model, 7000 + case)
+    rows = (synth.enas_rows if na else synth.bn_rows)(int(rng.integers(0, 10 ** 6)), B)
+    graphs = [(synth.decode_enas_row if na else synth.decode_bn_row)(r) for r in rows]
+    G = synth.dvae_batch(graphs)
+    ref = O.dvae_forward(model.state_dict(), copy.deepcopy(G), num_layers=L, bidirectional=bidir, num_nodes=nn_, vids=na,
+                         out_pool_all=pool_all, out_pool=pool)
+    model = model.to(device)
+    with torch.no_grad():
+        out = model(G.to(device))
+    assert Hh.maxdiff(out, ref) < TOL * max(1.0, float(ref.abs().max())), (na, hs, L, bidir, pool_all, pool, B)

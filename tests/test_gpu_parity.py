@@ -900,3 +900,19 @@ def test_random_dvae_encoders_match_oracle(device, case):
     with torch.no_grad():
         out = model(G.to(device))
     assert Hh.maxdiff(out, ref) < TOL * max(1.0, float(ref.abs().max())), (na, hs, L, bidir, pool_all, pool, B)
+
+
+def test_large_batch_properties(device):
+    """B = 1024 graphs (N ~ 130 k nodes, 8x the headline batch): bitwise run-to-run determinism, and the four
+    256-graph quarters give the rows they give inside the big batch (to rounding)."""
+    model = _headline_model(H=256, L=2, V=32, seed=3).to(device)
+    graphs = synth.code2_graphs(11, 1024)
+    full = synth.GraphBatch.from_data_list(graphs)
+    assert full.x.shape[0] > 100000
+    with torch.no_grad():
+        a = torch.stack(model(full.clone().to(device)))
+        b = torch.stack(model(full.clone().to(device)))
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+        parts = [torch.stack(model(synth.GraphBatch.from_data_list(graphs[q:q + 256]).to(device)))
+                 for q in range(0, 1024, 256)]
+    assert Hh.maxdiff(torch.cat(parts, dim=1), a) < 2e-5

@@ -12,7 +12,9 @@
  * Conventions (all entry points):
  *   - every pointer is a BORROWED DEVICE pointer (e.g. torch.Tensor.data_ptr()) unless marked
  *     "host"; the library never allocates, frees or synchronises, so calls are stream-ordered
- *     and hipGraph-capturable;
+ *     and hipGraph-capturable (one caveat: a replayed graph repeats the `epoch` it was captured with, so a graph
+ *     that contains dagnn_frontier_run / dagnn_backward_run with granule buffers must also contain the memset that
+ *     re-zeroes those buffers - see dagnn_frontier_cell.granules);
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
  *   - return value: 0 on success, DAGNN_E* (<0) on bad arguments, -(1000+hipError_t) when a HIP
  *     call fails; nothing throws across the boundary;

@@ -12,7 +12,7 @@ recurrence.  Two paths, same values:
 * `run` (training): the reference's loop nest (`dagnn.py:144-182`) on differentiable torch-ROCm ops, with its
   O(F*E) per-node edge scan replaced by one stable sort of the edges by the layer of the node they feed.
 
-Neither touches the CPU or the test oracle.
+Neither runs anything on the CPU.
 
 Conv semantics restated from `dagnn.py:232-313,347-409` and PyG-1.6 `propagate` (messages flow j -> i; the result of a
 conv is a full [N, .] tensor that is zero where no edge lands, of which the caller reads the frontier rows):

@@ -65,6 +65,18 @@ class FrontierArgs(C.Structure):
                 ("layer_split", C.POINTER(C.c_int32) * MAX_DIRS)]
 
 
+class DataflowCell(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("w_hh", "w_ih", "b_hh", "b_ih", "w_key", "static_score", "edge_gain",
+                                          "vid_bias", "gi0", "h_out", "granules")]
+
+
+class DataflowArgs(C.Structure):
+    _fields_ = [("cell", (DataflowCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
+                ("H", C.c_int), ("ld_h", C.c_int), ("gld", C.c_int), ("vid_mod", C.c_int), ("groups", C.c_int),
+                ("epoch", C.c_uint), ("schedule", C.c_void_p), ("err", C.c_void_p), ("debug_timing", C.c_void_p),
+                ("spin_limit", C.c_uint), ("debug_wg", C.c_int)]
+
+
 class BackwardCell(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("w_hh", "w_ih", "w_key", "edge_gain", "vid_bias", "static_score", "h", "a", "alpha", "gi", "gh", "g_ext",
                                           "da", "dgi", "dgh", "sigma", "edge_feat_grad", "da_granules", "du_granules",
@@ -125,6 +137,14 @@ SYMBOLS = {
     "dagnn_pack_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dagnn_frontier_run": (C.c_int, [C.POINTER(Plan), C.POINTER(FrontierArgs), C.POINTER(C.POINTER(C.c_int32)),
                                      C.POINTER(C.c_int32), C.c_void_p]),
+    "dagnn_dataflow_groups": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64]),
+    "dagnn_dataflow_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),
+    "dagnn_dataflow_layout": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
+    "dagnn_dataflow_schedule": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p]),
+    "dagnn_dataflow_run": (C.c_int, [C.POINTER(Plan), C.POINTER(DataflowArgs), C.c_void_p]),
+    "dagnn_pack_dataflow": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "dagnn_score_parts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "dagnn_readout_max": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int, C.c_void_p]),
     "dagnn_readout_pool": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,

@@ -42,17 +42,40 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or put /opt/rocm/bin on PATH)")
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
-        return LIB
-    os.makedirs(LIB_DIR, exist_ok=True)
-    tmp = LIB + ".tmp.%d" % os.getpid()
-    cmd = [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + sources()
+def _compile(src: str, obj: str, verbose: bool) -> None:
+    cmd = [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-c", "-o", obj, src]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("hipcc failed on %s:\n%s%s" % (src, res.stdout, res.stderr))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """One object per source (compiled in parallel, re-used while neither the source nor a header changed), then one
+    link step; the objects live next to the library and are git-ignored like it."""
+    if not force and not is_stale():
+        return LIB
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    hdr_time = max([os.path.getmtime(h) for h in _deps() if h.endswith(".h")] + [0.0])
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append((src, obj))
+    with ThreadPoolExecutor(max_workers=min(8, max(len(jobs), 1))) as pool:
+        for f in [pool.submit(_compile, s_, o_, verbose) for s_, o_ in jobs]:
+            f.result()
+    tmp = LIB + ".tmp.%d" % os.getpid()
+    cmd = [hipcc_path(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(tmp, LIB)
     return LIB
 

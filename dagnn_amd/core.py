@@ -81,12 +81,26 @@ class CellParams(object):
     """Device-side, kernel-ready parameters of one (direction, stacked layer) cell."""
 
     __slots__ = ("w_ih", "b_ih", "w_hh_t", "b_hh", "w_key", "edge_gain", "vid_bias", "w_hh_pk", "w_ih_pk",
-                 "b_ih_dev", "Hp", "key_raw", "w_hh_raw")
+                 "b_ih_dev", "Hp", "key_raw", "w_hh_raw", "w_hh_df", "w_ih_df")
 
 
-def pack_lockstep(cells) -> None:
+def pack_dataflow(cells) -> None:
+    """The dataflow kernel's weight layout of every cell (Hp <= 256)."""
+    for c in cells:
+        if c.w_hh_df is None:
+            c.w_hh_df = engine.pack_dataflow(c.w_hh_raw, c.Hp)
+            c.w_ih_df = engine.pack_dataflow(c.w_ih, c.Hp) if c.b_ih_dev is not None else None
+
+
+def pack_lockstep(cells, force: bool = False) -> None:
     """The lock-step kernels' weight layouts of every cell derived with `pack=False`: one `dagnn_pack_batch` launch
-    for all matrices instead of three launches per matrix."""
+    for all matrices instead of three launches per matrix.  Cells the dataflow kernel serves (Hp <= 256) get its
+    layout instead; `force` (the fallback inside `run_stack_lockstep`) packs the per-layer launches' layouts too."""
+    cells = list(cells)
+    if cells and engine.DATAFLOW and cells[0].Hp <= 256 and not force:
+        pack_dataflow(cells)
+        return
+    cells = [c for c in cells if c.w_hh_pk is None]
     todo = []
     for c in cells:
         todo.append((c, "w_hh_pk", c.w_hh_raw))
@@ -121,13 +135,17 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
     c.w_hh_raw = whh  # torch layout, padded: the backward sweep reads it as is
     c.w_hh_t = None if lock else engine.pack_whh(whh)
     c.w_hh_pk = c.w_ih_pk = None
-    if lock and pack:   # pack=False: the caller batches the packing of all its cells (pack_lockstep)
+    c.w_hh_df = c.w_ih_df = None
+    use_df = engine.DATAFLOW and Hp <= 256   # the dataflow kernel's layout instead (packed below)
+    if lock and pack and not use_df:   # pack=False: the caller batches the packing of all its cells (pack_lockstep)
         c.w_hh_pk = {js: engine.pack_slices(whh, Hp, js) for js in (16, 32)}
         c.w_hh_pk["mfma"] = engine.pack_mfma(whh, Hp)
         if in_is_hidden:
             c.w_ih_pk = {js: engine.pack_slices(wi, Hp, js) for js in (16, 32)}
             c.w_ih_pk["mfma"] = engine.pack_mfma(wi, Hp)
     c.b_ih_dev = c.b_ih if (lock and in_is_hidden) else None
+    if lock and pack and use_df:
+        pack_dataflow([c])
     c.b_hh = _pad_gate_rows(b_hh.detach().float(), H, Hp)
     kd = H if key_dim is None else key_dim  # keys are hidden states (H) or, for the `*_x` aggregators, inputs
     key = attn_w.detach().float()[0, dq:dq + kd]
@@ -154,7 +172,15 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
     ld = engine.frontier_ld(Hp)  # state rows carry their H/16 partial attention scores behind the states
     h = [[torch.empty(N, ld, dtype=torch.float32, device=dev) if d in dirs else None for _ in range(L)]
          for d in range(2)]
-    engine.frontier_run(plan, dirs, L, Hp, cells, gi, h, vid_mod=vid_nodes, arena=arena, static_score=static_score)
+    groups = engine.dataflow_groups(dev, len(dirs) * L, Hp, plan.B) if (arena is not None and N > 0) else 0
+    if groups > 0:
+        arena.poll()   # a failure an earlier pass reported (no synchronisation)
+        pack_dataflow(cells.values())
+        engine.dataflow_run(plan, dirs, L, Hp, cells, gi, h, groups, vid_mod=vid_nodes, arena=arena,
+                            static_score=static_score, score_parts=keep is not None)
+    else:
+        pack_lockstep(cells.values(), force=True)
+        engine.frontier_run(plan, dirs, L, Hp, cells, gi, h, vid_mod=vid_nodes, arena=arena, static_score=static_score)
     if keep is not None:
         keep["h_buf"], keep["gi0"], keep["Hp"] = h, gi, Hp
     return [[h[d][i][:, :H] if h[d][i] is not None else None for i in range(L)] for d in range(2)]

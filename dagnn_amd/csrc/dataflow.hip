@@ -1,0 +1,926 @@
+// dataflow.hip - the recurrence as ONE persistent, graph-affine dataflow launch (H <= 256).
+//
+// Reference path replaced: the three nested loops of ogbg-code/model/dagnn.py:144-182 (frontier selection :146-149,
+// per-node edge scan :151-157, AttnConv :362-373, GRUCell :181, state write :182) and their D-VAE twins
+// (dvae/dagnn.py:112-146, dvae/dagnn_bn.py:110-137), for every (direction, stacked layer) cell at once.
+//
+// Why this shape.  The batch is hundreds of topological layers deep with a handful of rows per layer: the time of
+// the recurrence is (dependent hops) x (latency of one hop) for the deepest graph and (rows) x (cost of a row) for
+// everything else.  Graphs share nothing, so the schedule is cut along GRAPHS, not along layers:
+//   * the graphs are dealt to G independent groups (longest-processing-time first on cost = c_layer * depth +
+//     c_row * nodes, csrc: df_assign_kernel; the deepest graph ends up almost alone in its group);
+//   * a group is a set of ncell x H/32 workgroups, one per (cell, 32-unit slice of the hidden dimension), each on its
+//     own CU for the whole pass with its W_hh slice in registers and its W_ih slice in LDS;
+//   * a group walks ITS graphs layer by layer in blocks of <= 4 rows (records re-sorted by (group, layer, graph),
+//     every group-layer padded to whole blocks, so block b of a group is records [4b, 4b + 4) - no indirection on
+//     the dependent chain);
+//   * rows travel between the workgroups of a group as 8-byte {epoch, fp32} granules (one write-through store each,
+//     polled with relaxed agent-scope loads: cdna_hip_programming.md Guideline 16, form R2) - no barrier, no fence,
+//     nothing placement-dependent.  Groups never exchange anything, and workgroup ids are group-major: with in-order
+//     dispatch a partially resident grid still makes progress group by group.
+// Inside a workgroup the waves are specialised (4 loader + 4 compute waves, coupled only through LDS flags):
+//   loader wave w   row w of every block: row record (scalar loads from a fixed address - prefetchable), poll the
+//                   predecessor rows (and the node's own lower-layer row / its gi0 slice), attention softmax over the
+//                   in-edges (scores = w_key . h_j computed HERE from the polled row: a DPP wave reduction, so the
+//                   producers publish no score parts), aggregate -> LDS ring slot, ready flag;
+//   compute wave c  its 8 hidden units of the slice: K split over the 16 lanes of a DPP row, v_pk_fma_f32 on the
+//                   resident W_hh registers / the LDS-resident W_ih, DPP row reduction, gates in the same wave (no
+//                   workgroup barrier anywhere), h' -> plain row store + granule store.
+// The loader runs up to NSLOT blocks ahead, so wide layers stream at the FMA rate while a thin dependent chain costs
+// one hand-off + ~0.5 us of compute per hop.
+#include "common.h"
+
+namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr int DF_JS = 32;      // hidden units per slice
+constexpr int DF_RB = 4;       // rows per block = loader waves
+constexpr int DF_NCW = 4;      // compute waves
+constexpr int DF_NSLOT = 3;    // LDS ring depth (blocks the loaders may run ahead)
+constexpr int DF_THREADS = 64 * (DF_NCW + DF_RB);
+constexpr int DF_MAX_GROUPS = 64;
+constexpr int DF_MAGIC = 0x44463031;   // "DF01"
+
+// ---------------------------------------------------------------- schedule workspace (int32 words)
+struct DfLayout {
+    int64_t grp_of;        // [B]     group of every graph
+    int64_t gdepth;        // [G]     deepest graph of every group (layers)
+    int64_t gload;         // [G]     LPT load of every group (cost units; diagnostics)
+    int64_t loff;          // [G+1]   offset of group k's per-layer table in lcnt (both directions: depths are equal)
+    int64_t gtab[2];       // [2G]    per group {first record, number of blocks}
+    int64_t lcnt[2];       // [N+G+1] per (group, layer): rows, then the padded exclusive prefix (records)
+    int64_t glbase[2];     // [N+B]   per (graph, layer) (indexed like lstart): first record inside its group
+    int64_t grec[2];       // [16 * (4N + 4)] records in (group, layer, graph, node) order, group-layers padded to
+                           //         whole blocks; padding records have node = -1
+    int64_t total;
+};
+
+__host__ __device__ inline DfLayout df_layout_words(int64_t N, int64_t B, int G) {
+    DfLayout L;
+    int64_t o = 16;
+    auto take = [&](int64_t n) { int64_t r = o; o = dagnn_align4(o + n); return r; };
+    L.grp_of = take(B);
+    L.gdepth = take(G);
+    L.gload = take(G);
+    L.loff = take(G + 1);
+    for (int d = 0; d < 2; ++d) L.gtab[d] = take(2 * (int64_t)G);
+    for (int d = 0; d < 2; ++d) L.lcnt[d] = take(N + G + 1);
+    for (int d = 0; d < 2; ++d) L.glbase[d] = take(N + B);
+    for (int d = 0; d < 2; ++d) L.grec[d] = take(16 * (4 * N + 4));
+    L.total = o;
+    return L;
+}
+
+// ---- LPT assignment: graphs in order of decreasing depth (plan items), each to the group whose load it raises the
+// least; load_k = c_layer * (depth of the first = deepest graph of k) + c_row * (nodes of k).  One wave, lane = group.
+__global__ void __launch_bounds__(64) df_assign_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws,
+                                                       DfLayout S, int B, int G, int c_layer, int c_row) {
+    const int lane = threadIdx.x;
+    long long load = 0;
+    int depth = 0;
+    bool empty = true;
+    const int32_t* items = plan + L.items;
+    for (int j = 0; j < 2 * B; ++j) {
+        const int it = items[j];
+        if (it & 1) continue;   // direction-1 entry of the same graph (longest paths have the same length both ways)
+        const int g = it >> 1;
+        const int dg = max(plan[L.depth[0] + g], plan[L.depth[1] + g]);
+        const int ng = plan[L.node_ptr + g + 1] - plan[L.node_ptr + g];
+        long long cand = load + (long long)c_row * ng + (empty ? (long long)c_layer * dg : 0);
+        if (lane >= G) cand = 0x7fffffffffffffffLL;
+        long long best = cand;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long other = __shfl_xor(best, o, 64);
+            best = other < best ? other : best;
+        }
+        const unsigned long long m = __ballot(cand == best);
+        const int k = __ffsll((long long)m) - 1;
+        if (lane == k) {
+            load = cand;
+            if (empty) { depth = dg; empty = false; }
+        }
+        if (lane == 0) ws[S.grp_of + g] = k;
+    }
+    if (lane < G) { ws[S.gdepth + lane] = depth; ws[S.gload + lane] = (int)(load > 0x7fffffff ? 0x7fffffff : load); }
+    // loff = exclusive prefix of (depth_k + 1)
+    int x = lane < G ? depth + 1 : 0;
+    const int own = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (lane < G) ws[S.loff + lane] = x - own;
+    if (lane == G - 1) ws[S.loff + G] = x;
+    if (lane == 0) { ws[0] = G; ws[1] = DF_MAGIC; ws[2] = DF_RB; }
+}
+
+// rows per (group, layer): one workgroup per (graph, direction) adds its layer widths
+__global__ void __launch_bounds__(256) df_count_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws,
+                                                        DfLayout S) {
+    const int g = blockIdx.x, d = blockIdx.y;
+    const int n0 = plan[L.node_ptr + g];
+    const int depth = plan[L.depth[d] + g];
+    const int k = ws[S.grp_of + g];
+    const int32_t* ls = plan + L.lstart[d] + n0 + g;
+    int32_t* cnt = ws + S.lcnt[d] + ws[S.loff + k];
+    for (int t = threadIdx.x; t < depth; t += blockDim.x) atomicAdd(&cnt[t], ls[t + 1] - ls[t]);
+}
+
+// per (group, direction): counts -> exclusive prefix of the block-padded counts; gtab = {.., blocks}
+__global__ void __launch_bounds__(256) df_prefix_kernel(int32_t* ws, DfLayout S, int G) {
+    __shared__ int32_t wsum[4];
+    __shared__ int32_t carry_s;
+    const int k = blockIdx.x, d = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int depth = ws[S.gdepth + k];
+    int32_t* cnt = ws + S.lcnt[d] + ws[S.loff + k];
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 <= depth; c0 += 256) {
+        const int t = c0 + tid;
+        const int c = t < depth ? cnt[t] : 0;
+        const int padded = (c + DF_RB - 1) / DF_RB * DF_RB;
+        int x = padded;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63) wsum[tid >> 6] = x;
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 4; ++w) { if (w < (tid >> 6)) woff += wsum[w]; tot += wsum[w]; }
+        const int carry = carry_s;
+        if (t <= depth) cnt[t] = carry + woff + x - padded;
+        __syncthreads();
+        if (tid == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (tid == 0) ws[S.gtab[d] + 2 * k + 1] = carry_s / DF_RB;
+}
+
+// first record of every group (exclusive prefix over the groups' record counts); one wave per direction
+__global__ void __launch_bounds__(64) df_base_kernel(int32_t* ws, DfLayout S, int G) {
+    const int d = blockIdx.x, lane = threadIdx.x;
+    int x = lane < G ? ws[S.gtab[d] + 2 * lane + 1] * DF_RB : 0;
+    const int own = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (lane < G) ws[S.gtab[d] + 2 * lane] = x - own;
+}
+
+// glbase[(g, t)] = padded prefix of (group, t) + rows of layer t in the group's graphs ordered before g.
+// One wave per (group, layer) pair, lanes over graphs.
+__global__ void __launch_bounds__(256) df_lbase_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws,
+                                                        DfLayout S, int B, int G) {
+    const int d = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int nw = gridDim.x * 4;
+    const int total = ws[S.loff + G];
+    const int32_t* __restrict__ ls = plan + L.lstart[d];
+    const int32_t* __restrict__ node_ptr = plan + L.node_ptr;
+    const int32_t* __restrict__ depth = plan + L.depth[d];
+    for (int pair = blockIdx.x * 4 + (threadIdx.x >> 6); pair < total; pair += nw) {
+        int k = 0;
+        while (k + 1 < G && pair >= ws[S.loff + k + 1]) ++k;
+        const int t = pair - ws[S.loff + k];
+        if (t >= ws[S.gdepth + k]) continue;   // the table has depth + 1 entries per group
+        int carry = ws[S.lcnt[d] + pair];
+        for (int g0 = 0; g0 < B; g0 += 64) {
+            const int g = g0 + lane;
+            int cnt = 0, base = 0;
+            bool has = false;
+            if (g < B && ws[S.grp_of + g] == k && t < depth[g]) {
+                base = node_ptr[g] + g + t;
+                cnt = ls[base + 1] - ls[base];
+                has = true;
+            }
+            int x = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+            if (has) ws[S.glbase[d] + base] = carry + x - cnt;
+            carry += __shfl(x, 63, 64);
+        }
+    }
+}
+
+// copy every row record to its place in the group order (padding records were preset to -1)
+__global__ void __launch_bounds__(256) df_records_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws,
+                                                          DfLayout S, int N) {
+    const int d = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;   // per-graph sorted position
+    if (p >= N) return;
+    const int v = plan[L.order[d] + p];
+    const int slot = plan[L.pos[d] + v];
+    const int4* src = reinterpret_cast<const int4*>(plan + L.rowrec[d]) + 4 * (int64_t)slot;
+    const int4 r0 = src[0];
+    const int g = r0.w;
+    const int n0 = plan[L.node_ptr + g];
+    const int depth = plan[L.depth[d] + g];
+    const int32_t* ls = plan + L.lstart[d] + n0 + g;   // depth + 1 absolute positions
+    int lo = 0, hi = depth;                            // largest t with ls[t] <= p
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ls[mid] <= p) lo = mid; else hi = mid; }
+    const int t = lo;
+    const int k = ws[S.grp_of + g];
+    const int rec = ws[S.gtab[d] + 2 * k] + ws[S.glbase[d] + n0 + g + t] + (p - ls[t]);
+    int4* dst = reinterpret_cast<int4*>(ws + S.grec[d]) + 4 * (int64_t)rec;
+    dst[0] = r0; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+}
+
+// ---------------------------------------------------------------- the persistent kernel
+struct DfCell {
+    const float4* whh;    // packed slices (dagnn_pack_dataflow)
+    const float4* wih;    // stacked layers > 0, else null
+    const float* bhh;     // [3H]
+    const float* bih;     // [3H] (with wih)
+    const float* wkey;    // [H] or null (static scores)
+    const float* sscore;  // [N] or null
+    const float* gain;    // [R] or null
+    const float* vid;     // [vid_mod] or null
+    const float* gi0;     // [N,3H] (stacked layer 0) or null
+    float* h_out;         // [N,ld_h]
+    gran_t* g_out;        // [N,gld] granules of h_out
+    const gran_t* g_in;   // granules of the lower stacked layer, or null
+    int dir;
+    int stacked;
+};
+
+struct DfArgs {
+    DfCell cell[DAGNN_MAX_DIRS * DAGNN_MAX_STACKED];
+    const int32_t* sched;   // schedule workspace (dagnn_dataflow_schedule)
+    int64_t gtab[2], grec[2];   // word offsets into sched
+    int64_t col[2], eattr[2];   // word offsets into the plan
+    int ncell, H, ld_h, gld, R, vid_mod, groups;
+    unsigned epoch, spin_limit;
+    int dbg_wg;                 // workgroup whose blocks are stamped
+    int* err;
+    unsigned long long* dbg;    // optional: [grid][2] start / end stamps, then [blocks][8] stamps of workgroup 0 (100 MHz)
+};
+
+__device__ __forceinline__ float df_dpp_row_sum16(float v) {
+#define DF_DPP_ADD(ctrl) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+    DF_DPP_ADD(0x111); DF_DPP_ADD(0x112); DF_DPP_ADD(0x114); DF_DPP_ADD(0x118);
+#undef DF_DPP_ADD
+    return v;
+}
+
+// sum over the 64 lanes, broadcast as a wave-uniform value (row scans, then row_bcast15 / row_bcast31)
+__device__ __forceinline__ float df_wave_sum(float v) {
+    v = df_dpp_row_sum16(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// gate non-linearities on the hardware exp / rcp (both ~1 ulp): sigma(x) = 1 / (1 + e^-x), tanh(x) = 1 - 2 / (1 + e^2x)
+// (saturates correctly: e^2x = inf -> 1, e^2x = 0 -> -1)
+__device__ __forceinline__ float df_sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float df_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+// operand rows in LDS: the K dimension is split over 8 lanes (KP8 = H / 8 = 2 KPT values each); K-lane segment s
+// starts at s * (KP8 + 4): the 8 segments a half DPP row reads concurrently (ds_read_b128) fall on disjoint banks
+template <int KPT> struct DfPad { static constexpr int kp8 = 2 * KPT; static constexpr int seg = kp8 + 4; static constexpr int row = 8 * seg; };
+
+struct DfLds {
+    float4* wih;     // [3*KPT/2][256]
+    float* ring;     // NSLOT x slot
+    int* rdy;        // [RB]   per loader wave: blocks it has finished (relaxed workgroup-scope atomics: plain ds_ accesses;
+    int* dn;         // [NCW]  per compute wave likewise        a volatile access here compiles to a FLAT load + vmcnt(0))
+};
+
+template <int KPT> struct DfSlot {
+    static constexpr int AP = DfPad<KPT>::row;
+    static constexpr int a_off = 0;                       // [RB][AP]
+    static constexpr int u_off = DF_RB * AP;              // [RB][AP]
+    static constexpr int gi_off = 2 * DF_RB * AP;         // [RB][96]
+    static constexpr int v_off = gi_off + DF_RB * 3 * DF_JS;   // [RB] ints (16 B)
+    static constexpr int words = v_off + 4;
+};
+
+__device__ __forceinline__ int df_flag_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void df_flag_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__device__ __forceinline__ bool df_wait4(const int* f, int target, int* err, unsigned limit) {
+    unsigned spins = 0;
+    for (;;) {
+        const int a = df_flag_ld(f), b = df_flag_ld(f + 1), c = df_flag_ld(f + 2), d = df_flag_ld(f + 3);
+        if (min(min(a, b), min(c, d)) >= target) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > 4 * limit) { __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+        // once any wait of the launch has failed, nobody waits long again (the pass is lost; it must still end)
+        if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    }
+}
+
+// bounded global poll: false (and error bit 0) once the budget is spent
+__device__ __forceinline__ bool df_retry(unsigned& spins, int* err, unsigned limit) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > limit) { __hip_atomic_fetch_or(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+    if ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    return true;
+}
+
+// ---- loader wave: row `lw` of every block of this group
+template <int KPT>
+__device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, const DfArgs& S,
+                                          const DfCell& C, int sl, int group, const DfLds& lds, int lw) {
+    constexpr int H = 16 * KPT;
+    constexpr int SEG = DfPad<KPT>::seg, KP8 = DfPad<KPT>::kp8;
+    typedef DfSlot<KPT> Slot;
+    const int lane = threadIdx.x & 63;
+    const int d = C.dir;
+    const int32_t* tab = S.sched + S.gtab[d] + 2 * group;
+    const int rec_base = tab[0], nblk = tab[1];
+    const int4* __restrict__ recs = reinterpret_cast<const int4*>(S.sched + S.grec[d]) + 4 * ((int64_t)rec_base + lw);
+    const int32_t* __restrict__ col = plan + S.col[d];
+    const float* __restrict__ eattr = reinterpret_cast<const float*>(plan + S.eattr[d]);
+    const int R = C.gain ? S.R : 0;
+    const bool has_in = C.wih != nullptr;
+    const int gld = S.gld;
+    // everything the loop needs from the argument structs, read ONCE: a field access inside the loop is a scalar load
+    // from the kernel-argument segment plus an lgkmcnt(0) wait on the dependent chain
+    const unsigned epoch = S.epoch, spin_limit = S.spin_limit;
+    int* const err = S.err;
+    gran_t* const g_out = C.g_out;
+    const gran_t* const g_in = C.g_in;
+    const float* const gi0 = C.gi0;
+    const float* const sscore = C.sscore;
+    const float* const vid = C.vid;
+    const float* const gainp = C.gain;
+    const int vid_mod = S.vid_mod;
+    const float gain0 = R >= 1 ? C.gain[0] : 0.f, gain1 = R >= 2 ? C.gain[1] : 0.f;
+    unsigned long long* const dbg = S.dbg ? S.dbg + 2 * gridDim.x : nullptr;
+    const gran_t ready = (gran_t)epoch << 32;
+    // a lane holds columns {lane, 64 + lane, 128 + lane, 192 + lane} of a row (the first NQ4 = H / 64 of them): load
+    // instruction q of a sweep then covers 512 contiguous bytes of the row (granules [64q, 64q + 64)) - a quarter of
+    // the cache lines a lane-owns-4-consecutive-granules sweep asks for
+    constexpr int NQ4 = H / 64;
+    float wk[4] = {0.f, 0.f, 0.f, 0.f};
+    int cpos[4];   // LDS position of the lane's columns in an operand row
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = 64 * q + lane;
+        cpos[q] = c + (SEG - KP8) * (c / KP8);
+        if (C.wkey && q < NQ4) wk[q] = C.wkey[c];
+    }
+    const bool prof = dbg != nullptr && (int)blockIdx.x == S.dbg_wg && lw == 0 && lane == 0;
+
+    // records are static plan data, prefetched two blocks ahead: lanes 0..15 load one word each of this wave's record
+    // (one 64-byte request, ONE register per record in flight) and the words become wave-uniform scalars
+    // (v_readlane) only when their block starts.  A scalar load here would be waited for together with every LDS
+    // access of the block (they share lgkmcnt); a uniform vector load would be waited for right where it is issued.
+    // The prefetch is issued right before the block's polls: their wait covers it (the same trip to memory), and by
+    // the time the words are read they have been in the register for a whole block.
+    const int32_t* rec_w = reinterpret_cast<const int32_t*>(recs) + (lane & 15);
+    const int64_t wstride = 16 * DF_RB;   // words per block
+    int pf0 = nblk > 0 ? rec_w[0] : -1;
+    int pf1 = nblk > 1 ? rec_w[wstride] : -1;
+    float4 giv_next = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int gi_lane_off = (lane >> 3) * H + sl * DF_JS + 4 * (lane & 7);
+    {
+        const int v0 = __builtin_amdgcn_readlane(pf0, 0);
+        if (gi0 && lane < 24 && v0 >= 0) giv_next = *reinterpret_cast<const float4*>(gi0 + (int64_t)v0 * 3 * H + gi_lane_off);
+    }
+
+    for (int b = 0; b < nblk; ++b) {
+        const int cur = pf0;
+        pf0 = pf1;
+#define DF_W(i) __builtin_amdgcn_readlane(cur, i)
+        const int4 r0 = make_int4(DF_W(0), DF_W(1), DF_W(2), DF_W(3));
+        const int4 r1 = make_int4(DF_W(4), DF_W(5), DF_W(6), DF_W(7));
+        const int4 r2 = make_int4(DF_W(8), DF_W(9), DF_W(10), DF_W(11));
+        const int4 r3 = make_int4(DF_W(12), DF_W(13), DF_W(14), DF_W(15));
+#undef DF_W
+        float4 giv = giv_next;
+        asm volatile("" : "+v"(giv.x), "+v"(giv.y), "+v"(giv.z), "+v"(giv.w));   // its own registers, before the reload below
+        const int vn = __builtin_amdgcn_readlane(pf0, 0);   // node of block b + 1: its gi0 slice, one block early
+        __builtin_amdgcn_sched_barrier(0);   // the loads below stay below the reads of what arrived a block ago
+        pf1 = b + 2 < nblk ? rec_w[(int64_t)(b + 2) * wstride] : -1;
+        if (gi0 && lane < 24 && b + 1 < nblk && vn >= 0)
+            giv_next = *reinterpret_cast<const float4*>(gi0 + (int64_t)vn * 3 * H + gi_lane_off);
+        const int slot = b % DF_NSLOT;
+        float* sbase = lds.ring + slot * Slot::words;
+        if (b >= DF_NSLOT) df_wait4(lds.dn, b - DF_NSLOT + 1, err, spin_limit);
+        int* v_s = reinterpret_cast<int*>(sbase + Slot::v_off);
+        const int v = r0.x;
+        if (prof) dbg[8 * (int64_t)b + 4] = wall_clock64();
+        unsigned polls = 0;
+        if (v >= 0) {
+            const int eb = r0.y, deg = r0.z - r0.y;
+            float* a_row = sbase + Slot::a_off + lw * Slot::AP;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            float m = -INFINITY, l = 0.f;
+            bool u_pending = has_in;
+            float urow[4] = {0.f, 0.f, 0.f, 0.f};
+            const gran_t* gu = has_in ? g_in + (int64_t)v * gld : nullptr;
+            int c0 = 0;
+            do {   // chunks of <= 4 in-edges (one pass for deg <= 4, where ids and features came with the record)
+                const int nn = min(4, deg - c0);
+                int pj[4] = {0, 0, 0, 0};
+                float fe[4] = {0.f, 0.f, 0.f, 0.f};   // gain . edge features of the chunk's edges
+                if (c0 == 0) {
+                    pj[0] = r1.x; pj[1] = r1.y; pj[2] = r1.z; pj[3] = r1.w;
+                    if (R >= 1 && R <= 2) {
+                        fe[0] = gain0 * __int_as_float(r2.x) + gain1 * __int_as_float(r2.y);
+                        fe[1] = gain0 * __int_as_float(r2.z) + gain1 * __int_as_float(r2.w);
+                        fe[2] = gain0 * __int_as_float(r3.x) + gain1 * __int_as_float(r3.y);
+                        fe[3] = gain0 * __int_as_float(r3.z) + gain1 * __int_as_float(r3.w);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (e < nn) pj[e] = col[eb + c0 + e];
+                }
+                if (R > 2 || (R > 0 && c0 > 0)) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        fe[e] = 0.f;
+                        if (e < nn) for (int r = 0; r < R; ++r) fe[e] = fmaf(gainp[r], eattr[(int64_t)(eb + c0 + e) * R + r], fe[e]);
+                    }
+                }
+                // ---- poll: every load of a pass is issued before the first tag is looked at (atomic loads keep
+                // program order; a compare between two groups would serialise the round trips); rows that have
+                // arrived are not asked for again
+                float row[4][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) row[e][q] = 0.f;
+                unsigned pend = (1u << nn) - 1u;   // wave-uniform: predecessor rows still missing
+                unsigned spins = 0;
+                for (;;) {
+                    gran_t x[4][4], xu[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const gran_t* gp = g_out + (int64_t)pj[e] * gld;
+                        const bool on = (pend >> e) & 1u;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) x[e][q] = (on && q < NQ4) ? gran_ld(gp + 64 * q + lane) : ready;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xu[q] = (u_pending && q < NQ4) ? gran_ld(gu + 64 * q + lane) : ready;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if ((pend >> e) & 1u) {
+                            bool ok = true;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(x[e][q] >> 32) == epoch;
+                            if (__all(ok)) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) row[e][q] = __uint_as_float((unsigned)x[e][q]);
+                                pend &= ~(1u << e);
+                            }
+                        }
+                    }
+                    if (u_pending) {
+                        bool oku = true;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) oku = oku && (unsigned)(xu[q] >> 32) == epoch;
+                        if (__all(oku)) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) urow[q] = __uint_as_float((unsigned)xu[q]);
+                            u_pending = false;
+                        }
+                    }
+                    ++polls;
+                    if ((pend == 0 && !u_pending) || !df_retry(spins, err, spin_limit)) break;
+                }
+                if (prof && c0 == 0) { dbg[8 * (int64_t)b + 5] = wall_clock64(); dbg[8 * (int64_t)b + 6] = polls; }
+                if (deg == 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = row[0][q];
+                    l = 1.f;
+                } else if (nn > 0) {
+                    float s[4];
+                    float mc = m;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s[e] = -INFINITY;
+                        if (e < nn) {
+                            float sv;
+                            if (sscore) sv = sscore[pj[e]];
+                            else sv = df_wave_sum(row[e][0] * wk[0] + row[e][1] * wk[1] + row[e][2] * wk[2] + row[e][3] * wk[3]);
+                            if (vid) sv += vid[pj[e] % vid_mod];
+                            sv += fe[e];
+                            s[e] = sv;
+                            mc = fmaxf(mc, sv);
+                        }
+                    }
+                    const float sc = __expf(m - mc);   // 0 on the first chunk (m = -inf)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] *= sc;
+                    l *= sc;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (e < nn) {
+                            const float p = __expf(s[e] - mc);
+                            l += p;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[q] = fmaf(p, row[e][q], acc[q]);
+                        }
+                    }
+                    m = mc;
+                }
+                c0 += 4;
+            } while (c0 < deg);
+            if (deg > 1) {   // PyG softmax: exp(x - max) / (sum + 1e-16)
+                const float inv = 1.0f / (l + 1e-16f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] *= inv;
+            }
+#pragma unroll
+            for (int q = 0; q < NQ4; ++q) {
+                a_row[cpos[q]] = acc[q];
+                if (has_in) sbase[Slot::u_off + lw * Slot::AP + cpos[q]] = urow[q];
+            }
+            if (gi0 && lane < 24)
+                *reinterpret_cast<float4*>(sbase + Slot::gi_off + lw * (3 * DF_JS) + (lane >> 3) * DF_JS + 4 * (lane & 7)) = giv;
+        }
+        if (lane == 0) v_s[lw] = v;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) df_flag_st(lds.rdy + lw, b + 1);
+        if (prof) dbg[8 * (int64_t)b + 3] = wall_clock64();
+    }
+}
+
+// acc[r][0..3] (sums for r / z gates, hidden-side n, input-side n; the two halves of a v2f take even / odd k) +=
+// products of this lane's K range for rows 0..NR-1: hidden side from registers, input side from LDS weights
+template <int KPT, int NR>
+__device__ __forceinline__ void df_fma(v2f (&acc)[2][4], const v2f (&wr)[KPT], const v2f (&wz)[KPT],
+                                       const v2f (&wn)[KPT], const float* a_seg, const float* u_seg,
+                                       const float4* wih_s, bool has_in, int tc) {
+    constexpr int AP = DfPad<KPT>::row;
+    constexpr int NK4 = DfPad<KPT>::kp8 / 4;   // float4 steps over the lane's K range
+#pragma unroll
+    for (int q = 0; q < NK4; ++q) {
+        float4 av[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) av[r] = *reinterpret_cast<const float4*>(a_seg + r * AP + 4 * q);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const v2f lo = {av[r].x, av[r].y}, hi = {av[r].z, av[r].w};
+            acc[r][0] = __builtin_elementwise_fma(lo, wr[2 * q], acc[r][0]);
+            acc[r][1] = __builtin_elementwise_fma(lo, wz[2 * q], acc[r][1]);
+            acc[r][2] = __builtin_elementwise_fma(lo, wn[2 * q], acc[r][2]);
+            acc[r][0] = __builtin_elementwise_fma(hi, wr[2 * q + 1], acc[r][0]);
+            acc[r][1] = __builtin_elementwise_fma(hi, wz[2 * q + 1], acc[r][1]);
+            acc[r][2] = __builtin_elementwise_fma(hi, wn[2 * q + 1], acc[r][2]);
+        }
+    }
+    if (has_in) {
+#pragma unroll
+        for (int q = 0; q < NK4; ++q) {
+            float4 uv[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) uv[r] = *reinterpret_cast<const float4*>(u_seg + r * AP + 4 * q);
+            const float4 w0 = wih_s[(0 * NK4 + q) * 256 + tc];
+            const float4 w1 = wih_s[(1 * NK4 + q) * 256 + tc];
+            const float4 w2 = wih_s[(2 * NK4 + q) * 256 + tc];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const v2f lo = {uv[r].x, uv[r].y}, hi = {uv[r].z, uv[r].w};
+                acc[r][0] = __builtin_elementwise_fma(lo, (v2f){w0.x, w0.y}, acc[r][0]);
+                acc[r][1] = __builtin_elementwise_fma(lo, (v2f){w1.x, w1.y}, acc[r][1]);
+                acc[r][3] = __builtin_elementwise_fma(lo, (v2f){w2.x, w2.y}, acc[r][3]);
+                acc[r][0] = __builtin_elementwise_fma(hi, (v2f){w0.z, w0.w}, acc[r][0]);
+                acc[r][1] = __builtin_elementwise_fma(hi, (v2f){w1.z, w1.w}, acc[r][1]);
+                acc[r][3] = __builtin_elementwise_fma(hi, (v2f){w2.z, w2.w}, acc[r][3]);
+            }
+        }
+    }
+}
+
+// inclusive scan over each group of 8 lanes (row_shr 1, 2, 4; lanes shifted in from outside the row read 0): lanes 7
+// and 15 of every DPP row end with the totals of their half, always in the same order -> deterministic
+__device__ __forceinline__ float df_dpp_sum8(float v) {
+#define DF_DPP_ADD(ctrl) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+    DF_DPP_ADD(0x111); DF_DPP_ADD(0x112); DF_DPP_ADD(0x114);
+#undef DF_DPP_ADD
+    return v;
+}
+// lane i reads lane i + n of its DPP row (row_shl:n)
+template <int N> __device__ __forceinline__ float df_dpp_shl(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
+}
+
+// ---- compute wave `cw`: hidden units [8 cw, 8 cw + 8) of the slice, every block of this group.
+// Lane = (unit g8 = lane >> 3 of the wave's 8, K-lane ks = lane & 7): it holds the r / z / n rows of W_hh for ITS unit
+// over k in [ks * H/8, (ks + 1) * H/8) (96 registers at H = 256), products accumulate as even / odd k pairs
+// (v_pk_fma_f32 straight on the LDS operand pairs), the K reduction is three DPP row shifts, and the lane the totals
+// end in (ks = 7) already holds all four sums of its unit: it evaluates the gates and stores h' itself (rows 1..3 of
+// a block are handed to lanes ks = 6, 5, 4 with one more DPP shift) - no LDS exchange, no barrier.
+template <int KPT>
+__device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int sl, int group, const DfLds& lds, int cw) {
+    constexpr int H = 16 * KPT;
+    constexpr int SEG = DfPad<KPT>::seg, KP8 = DfPad<KPT>::kp8, NK4 = KP8 / 4;
+    typedef DfSlot<KPT> Slot;
+    const int tc = threadIdx.x;   // 0..255
+    const int lane = tc & 63;
+    const int g8 = lane >> 3, ks = lane & 7;
+    const bool has_in = C.wih != nullptr;
+    const int d = C.dir;
+    const int nblk = S.sched[S.gtab[d] + 2 * group + 1];
+    v2f wr[KPT], wz[KPT], wn[KPT];   // KP8 / 2 k pairs per gate
+    {
+        const float4* wp = C.whh + (int64_t)sl * (3 * NK4) * 256 + tc;
+#pragma unroll
+        for (int q = 0; q < NK4; ++q) {
+            const float4 x0 = wp[(0 * NK4 + q) * 256], x1 = wp[(1 * NK4 + q) * 256], x2 = wp[(2 * NK4 + q) * 256];
+            wr[2 * q] = (v2f){x0.x, x0.y}; wr[2 * q + 1] = (v2f){x0.z, x0.w};
+            wz[2 * q] = (v2f){x1.x, x1.y}; wz[2 * q + 1] = (v2f){x1.z, x1.w};
+            wn[2 * q] = (v2f){x2.x, x2.y}; wn[2 * q + 1] = (v2f){x2.z, x2.w};
+        }
+    }
+    const int unit_l = 8 * cw + g8, unit = sl * DF_JS + unit_l;
+    float b_r = C.bhh[unit], b_z = C.bhh[H + unit];
+    const float b_hn = C.bhh[2 * H + unit];
+    float b_in = 0.f;
+    if (has_in) { b_r += C.bih[unit]; b_z += C.bih[H + unit]; b_in = C.bih[2 * H + unit]; }
+    const int gr = 7 - ks;   // row of the block this lane evaluates the gates of (K-lanes 7, 6, 5, 4 -> rows 0..3)
+    const int apos = unit + (SEG - KP8) * (unit / KP8);   // LDS position of column `unit` of an operand row
+    const unsigned epoch = S.epoch, spin_limit = S.spin_limit;
+    int* const err = S.err;
+    float* const h_out = C.h_out;
+    gran_t* const g_out = C.g_out;
+    const int ld_h = S.ld_h, gld = S.gld;
+    unsigned long long* const dbg = S.dbg ? S.dbg + 2 * gridDim.x : nullptr;
+    const bool prof = dbg != nullptr && (int)blockIdx.x == S.dbg_wg && cw == 0 && lane == 0;
+
+    for (int b = 0; b < nblk; ++b) {
+        const int slot = b % DF_NSLOT;
+        const float* sbase = lds.ring + slot * Slot::words;
+        df_wait4(lds.rdy, b + 1, err, spin_limit);
+        if (prof) dbg[8 * (int64_t)b + 0] = wall_clock64();
+        const int4 ids = *reinterpret_cast<const int4*>(sbase + Slot::v_off);
+        const int nr = (ids.x >= 0) + (ids.y >= 0) + (ids.z >= 0) + (ids.w >= 0);   // live records come first
+        const float* a_seg = sbase + Slot::a_off + ks * SEG;
+        const float* u_seg = sbase + Slot::u_off + ks * SEG;
+        // two rows per pass (the accumulators and in-flight operands of four rows do not fit the register budget next
+        // to the resident weights); K reduction; row r's totals move from K-lane 7 to K-lane 7 - r, which evaluates
+        // that row's gates
+        float g4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rb = 0; rb < DF_RB; rb += 2) {
+            if (rb < nr) {
+                v2f acc[2][4];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[r][a] = (v2f){0.f, 0.f};
+                const bool two = nr - rb >= 2;
+                if (two) df_fma<KPT, 2>(acc, wr, wz, wn, a_seg + rb * Slot::AP, u_seg + rb * Slot::AP, lds.wih, has_in, tc);
+                else df_fma<KPT, 1>(acc, wr, wz, wn, a_seg + rb * Slot::AP, u_seg + rb * Slot::AP, lds.wih, has_in, tc);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (j == 0 || two) {
+                        float t[4];
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) t[a] = df_dpp_sum8(acc[j][a].x + acc[j][a].y);
+                        if (rb + j == 1) {
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) t[a] = df_dpp_shl<1>(t[a]);
+                        } else if (rb + j == 2) {
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) t[a] = df_dpp_shl<2>(t[a]);
+                        } else if (rb + j == 3) {
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) t[a] = df_dpp_shl<3>(t[a]);
+                        }
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) g4[a] = gr == rb + j ? t[a] : g4[a];
+                    }
+                }
+            }
+        }
+        if (prof) dbg[8 * (int64_t)b + 1] = wall_clock64();
+        const bool live = gr < nr;
+        float hv = 0.f;
+        int gv = 0;
+        if (live) {
+            gv = gr == 0 ? ids.x : (gr == 1 ? ids.y : (gr == 2 ? ids.z : ids.w));
+            float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f;
+            if (!has_in) {
+                const float* gp = sbase + Slot::gi_off + gr * (3 * DF_JS) + unit_l;
+                gi_r = gp[0]; gi_z = gp[DF_JS]; gi_n = gp[2 * DF_JS];
+            }
+            const float aval = sbase[Slot::a_off + gr * Slot::AP + apos];
+            const float rg = df_sigm(g4[0] + b_r + gi_r);
+            const float zg = df_sigm(g4[1] + b_z + gi_z);
+            const float ng = df_tanh(fmaf(rg, g4[2] + b_hn, g4[3] + b_in + gi_n));
+            hv = fmaf(zg, aval - ng, ng);   // n + z * (a - n)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) df_flag_st(lds.dn + cw, b + 1);   // this wave is done with the slot (LDS executes a wave's accesses in order)
+        if (live) {
+            h_out[(int64_t)gv * ld_h + unit] = hv;
+            __hip_atomic_store(g_out + (int64_t)gv * gld + unit, gran_pack(epoch, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (prof) dbg[8 * (int64_t)b + 2] = wall_clock64();
+    }
+}
+
+template <int KPT>
+__global__ void __launch_bounds__(DF_THREADS, 2) dataflow_kernel(const int32_t* __restrict__ plan, DfArgs S) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef DfSlot<KPT> Slot;
+    constexpr int NQ = 3 * KPT / 2;
+    constexpr int NS = 16 * KPT / DF_JS;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int per_group = S.ncell * NS;
+    const int group = blockIdx.x / per_group;
+    const int rem = blockIdx.x - group * per_group;
+    const int c = rem / NS, sl = rem - c * NS;
+    const DfCell& C = S.cell[c];
+    DfLds lds;
+    lds.wih = reinterpret_cast<float4*>(smem);
+    lds.ring = smem + NQ * 256 * 4;
+    int* flags = reinterpret_cast<int*>(lds.ring + DF_NSLOT * Slot::words);
+    lds.rdy = flags;
+    lds.dn = flags + 4;
+    if (C.wih) {
+        const float4* src = C.wih + (int64_t)sl * NQ * 256;
+        for (int i = tid; i < NQ * 256; i += DF_THREADS) lds.wih[i] = src[i];
+    }
+    if (tid < 8) flags[tid] = 0;
+    if (S.dbg && tid == 0) S.dbg[2 * blockIdx.x] = wall_clock64();
+    __syncthreads();
+    if (wave < DF_NCW) df_compute<KPT>(S, C, sl, group, lds, wave);
+    else df_loader<KPT>(plan, S, C, sl, group, lds, wave - DF_NCW);
+    if (S.dbg && tid == 0) S.dbg[2 * blockIdx.x + 1] = wall_clock64();   // compute wave 0 is done
+}
+
+template <int KPT> size_t df_lds_bytes() {
+    return (size_t)(3 * KPT / 2) * 256 * 16 + (size_t)(DF_NSLOT * DfSlot<KPT>::words) * 4 + 32;
+}
+
+// Pack W [3H, K = H] (torch GRUCell layout) for the dataflow kernel: out[(sl * NQ + q) * 256 + tc] (float4), NQ = 3 H/32,
+// q = gate * (H/32) + k4, thread tc = (compute wave w = tc >> 6, unit g8 = (tc >> 3) & 7, K-lane ks = tc & 7):
+// W[gate * H + 32 sl + 8 w + g8][ks * H/8 + 4 k4 .. + 3].
+__global__ void __launch_bounds__(256) df_pack_kernel(const float* __restrict__ W, float4* __restrict__ out, int H, int64_t total) {
+    const int kp8 = H >> 3, nk4 = kp8 >> 2, nq = 3 * nk4;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int tc = (int)(idx & 255);
+        int64_t rest = idx >> 8;
+        const int q = (int)(rest % nq);
+        const int sl = (int)(rest / nq);
+        const int g = q / nk4, k4 = q - g * nk4;
+        const int unit = sl * DF_JS + 8 * (tc >> 6) + ((tc >> 3) & 7), ks = tc & 7;
+        out[idx] = *reinterpret_cast<const float4*>(W + (int64_t)(g * H + unit) * H + ks * kp8 + 4 * k4);
+    }
+}
+
+// partial attention scores behind the state rows (the format the backward pass reads): part q of row v =
+// w_key[16q : 16q + 16] . h[v, 16q : 16q + 16].  One wave per row.
+__global__ void __launch_bounds__(256) df_score_parts_kernel(float* __restrict__ h, int ld_h, int H,
+                                                              const float* __restrict__ wkey, int64_t N) {
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= N) return;
+    float* row = h + v * ld_h;
+    float s = 0.f;
+    if (4 * lane < H) {
+        const float4 x = reinterpret_cast<const float4*>(row)[lane];
+        const float4 w = reinterpret_cast<const float4*>(wkey)[lane];
+        s = x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w;
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if ((lane & 3) == 0 && 4 * lane < H) row[H + (lane >> 2)] = s;
+}
+
+}  // namespace
+
+extern "C" size_t dagnn_dataflow_bytes(int64_t N, int64_t B, int groups) {
+    if (N < 0 || B < 0 || groups < 1 || groups > DF_MAX_GROUPS) return 0;
+    return (size_t)df_layout_words(N, B, groups).total * sizeof(int32_t);
+}
+
+extern "C" int dagnn_dataflow_layout(int64_t N, int64_t B, int groups, int64_t* o) {
+    if (!o || groups < 1 || groups > DF_MAX_GROUPS) return DAGNN_EINVAL;
+    DfLayout S = df_layout_words(N, B, groups);
+    const int64_t w[13] = {S.grp_of, S.gdepth, S.gload, S.loff, S.gtab[0], S.gtab[1], S.lcnt[0], S.lcnt[1],
+                           S.glbase[0], S.glbase[1], S.grec[0], S.grec[1], S.total};
+    for (int i = 0; i < 13; ++i) o[i] = w[i] * 4;
+    return DAGNN_OK;
+}
+
+extern "C" int dagnn_dataflow_groups(int num_cus, int num_cells, int H, int64_t B) {
+    if (num_cus <= 0 || num_cells <= 0 || num_cells > DAGNN_MAX_DIRS * DAGNN_MAX_STACKED || H <= 0 || (H % 64) || H > 256 || B <= 0)
+        return 0;
+    int64_t g = num_cus / (num_cells * (H / DF_JS));
+    if (g > DF_MAX_GROUPS) g = DF_MAX_GROUPS;
+    if (g > B) g = B;
+    return (int)g;
+}
+
+extern "C" int dagnn_dataflow_schedule(const dagnn_plan* pl, void* ws_, size_t ws_bytes, int groups, int cost_layer,
+                                       int cost_row, void* stream_) {
+    if (!pl || !pl->data || !ws_ || groups < 1 || groups > DF_MAX_GROUPS || cost_layer < 0 || cost_row < 0)
+        return DAGNN_EINVAL;
+    const int64_t N = pl->N, B = pl->B;
+    DfLayout S = df_layout_words(N, B, groups);
+    if ((size_t)S.total * 4 > ws_bytes) return DAGNN_ENOSPC;
+    PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
+    hipStream_t st = (hipStream_t)stream_;
+    int32_t* ws = (int32_t*)ws_;
+    const int32_t* plan = (const int32_t*)pl->data;
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)S.grec[0] * 4, st);   // header, tables, counters
+    if (e != hipSuccess) return DAGNN_EHIP(e);
+    e = hipMemsetAsync(ws + S.grec[0], 0xff, (size_t)(S.total - S.grec[0]) * 4, st);   // padding records: node = -1
+    if (e != hipSuccess) return DAGNN_EHIP(e);
+    if (B == 0 || N == 0) return DAGNN_OK;
+    hipLaunchKernelGGL(df_assign_kernel, dim3(1), dim3(64), 0, st, plan, L, ws, S, (int)B, groups, cost_layer, cost_row);
+    DAGNN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(df_count_kernel, dim3((unsigned)B, 2), dim3(256), 0, st, plan, L, ws, S);
+    DAGNN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(df_prefix_kernel, dim3((unsigned)groups, 2), dim3(256), 0, st, ws, S, groups);
+    DAGNN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(df_base_kernel, dim3(2), dim3(64), 0, st, ws, S, groups);
+    DAGNN_CHECK_LAUNCH();
+    int64_t lb = (N + groups + 3) / 4;
+    if (lb > 2048) lb = 2048;
+    hipLaunchKernelGGL(df_lbase_kernel, dim3((unsigned)lb, 2), dim3(256), 0, st, plan, L, ws, S, (int)B, groups);
+    DAGNN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(df_records_kernel, dim3((unsigned)((N + 255) / 256), 2), dim3(256), 0, st, plan, L, ws, S, (int)N);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
+extern "C" int dagnn_pack_dataflow(const float* w, float* out, int H, void* stream) {
+    if (!w || !out || H <= 0 || (H % 64) || H > 256) return DAGNN_EINVAL;
+    const int64_t total = (int64_t)3 * H * H / 4;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(df_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<float4*>(out), H, total);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
+extern "C" int dagnn_score_parts(float* h, int ld_h, int H, const float* w_key, int64_t N, void* stream) {
+    if (!h || !w_key || H <= 0 || (H % 16) || ld_h < H + H / 16 || N < 0) return DAGNN_EINVAL;
+    if (N == 0) return DAGNN_OK;
+    hipLaunchKernelGGL(df_score_parts_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, ld_h, H,
+                       w_key, N);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
+extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_args* a, void* stream) {
+    if (!pl || !pl->data || !a || !a->schedule) return DAGNN_EINVAL;
+    const int H = a->H, Ls = a->num_stacked, dir_mask = a->dir_mask & 3, G = a->groups;
+    if (H <= 0 || (H % 64) || H > 256 || Ls <= 0 || Ls > DAGNN_MAX_STACKED || !dir_mask || a->ld_h < H || a->gld < H ||
+        G < 1 || G > DF_MAX_GROUPS || a->epoch == 0 || !a->err)
+        return DAGNN_EINVAL;
+    if (pl->B == 0 || pl->N == 0) return DAGNN_OK;
+    DfArgs S;
+    int nc = 0;
+    for (int d = 0; d < 2; ++d) {
+        if (!((dir_mask >> d) & 1)) continue;
+        for (int i = 0; i < Ls; ++i) {
+            const dagnn_dataflow_cell& c = a->cell[d][i];
+            if (!c.w_hh || !c.b_hh || (!c.w_key && !c.static_score) || !c.h_out || !c.granules) return DAGNN_EINVAL;
+            if (i == 0 ? !c.gi0 : (!c.w_ih || !c.b_ih)) return DAGNN_EINVAL;
+            DfCell& K = S.cell[nc++];
+            K.whh = (const float4*)c.w_hh;
+            K.wih = i > 0 ? (const float4*)c.w_ih : nullptr;
+            K.bhh = c.b_hh; K.bih = i > 0 ? c.b_ih : nullptr;
+            K.wkey = c.static_score ? nullptr : c.w_key;
+            K.sscore = c.static_score;
+            K.gain = pl->num_edge_feats > 0 ? c.edge_gain : nullptr;
+            K.vid = a->vid_mod > 0 ? c.vid_bias : nullptr;
+            K.gi0 = i == 0 ? c.gi0 : nullptr;
+            K.h_out = c.h_out;
+            K.g_out = (gran_t*)c.granules;
+            K.g_in = i > 0 ? (const gran_t*)a->cell[d][i - 1].granules : nullptr;
+            K.dir = d; K.stacked = i;
+        }
+    }
+    const DfLayout SL = df_layout_words(pl->N, pl->B, G);
+    S.sched = (const int32_t*)a->schedule;
+    PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
+    for (int d = 0; d < 2; ++d) { S.gtab[d] = SL.gtab[d]; S.grec[d] = SL.grec[d]; S.col[d] = L.col[d]; S.eattr[d] = L.eattr[d]; }
+    S.spin_limit = a->spin_limit ? a->spin_limit : (1u << 22);
+    S.ncell = nc; S.H = H; S.ld_h = a->ld_h; S.gld = a->gld; S.R = pl->num_edge_feats;
+    S.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
+    S.groups = G; S.epoch = a->epoch; S.err = (int*)a->err;
+    S.dbg = (unsigned long long*)a->debug_timing;
+    S.dbg_wg = a->debug_wg;
+    const int32_t* plan = (const int32_t*)pl->data;
+    const unsigned grid = (unsigned)(G * nc * (H / DF_JS));
+    hipStream_t st = (hipStream_t)stream;
+#define DF_LAUNCH(KPT)                                                                                                   \
+    do {                                                                                                                 \
+        const void* fn = reinterpret_cast<const void*>(dataflow_kernel<KPT>);                                            \
+        const hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)df_lds_bytes<KPT>()); \
+        if (ea != hipSuccess) return DAGNN_EHIP(ea);                                                                     \
+        hipLaunchKernelGGL((dataflow_kernel<KPT>), dim3(grid), dim3(DF_THREADS), df_lds_bytes<KPT>(), st, plan, S);      \
+    } while (0)
+    switch (H / 16) {
+        case 4: DF_LAUNCH(4); break;
+        case 8: DF_LAUNCH(8); break;
+        case 12: DF_LAUNCH(12); break;
+        default: DF_LAUNCH(16); break;
+    }
+#undef DF_LAUNCH
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}

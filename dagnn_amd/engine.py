@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import BackwardArgs, DagnnHipError, FrontierArgs, GemmGroup, LayerArgs, Plan, check
+from ._lib import BackwardArgs, DagnnHipError, DataflowArgs, FrontierArgs, GemmGroup, LayerArgs, Plan, check
 
 
 class KernelTimer(object):
@@ -71,6 +71,11 @@ SPLIT_DEEP = _env_int("DAGNN_AMD_SPLIT_DEEP", 1)            # 1: deep graphs on 
 BWD_THIN_WGS = _env_int("DAGNN_AMD_BWD_THIN_WGS", 0)        # backward: slice kernel vs rows + MFMA kernels; 0 = library default
 BWD_TAIL_REPLICAS = _env_int("DAGNN_AMD_BWD_TAIL_REPLICAS", 2)    # backward persistent kernel; 0 = one launch per layer
 BWD_TAIL_MAX_BLOCKS = _env_int("DAGNN_AMD_BWD_TAIL_MAX_BLOCKS", 4)
+DATAFLOW = _env_int("DAGNN_AMD_DATAFLOW", 1)                # 1: the persistent graph-affine dataflow kernel where it applies (H <= 256)
+DF_COST_LAYER = _env_int("DAGNN_AMD_DF_COST_LAYER", 8)      # schedule cost of one dependent layer, in rows (hop latency / row cost)
+DF_COST_ROW = _env_int("DAGNN_AMD_DF_COST_ROW", 1)
+DF_GROUPS = _env_int("DAGNN_AMD_DF_GROUPS", 0)              # 0 = as many groups as the device hosts
+SPIN_LIMIT = _env_int("DAGNN_AMD_SPIN_LIMIT", 0)            # polls before a device-side wait gives up; 0 = library default
 DEBUG_TIMING: Optional[torch.Tensor] = None  # int64[8] device tensor: phase ticks of the deepest work item
 _NOSPAN = _NoSpan()
 
@@ -169,6 +174,31 @@ class PlanHandle(object):
         comes with the same device->host read as the schedule."""
         self.read_schedule()
         return self._splits
+
+    def dataflow_schedule(self, groups: int) -> torch.Tensor:
+        """The plan's rows dealt to `groups` independent groups (`dagnn_dataflow_schedule`), built once per plan."""
+        cache = self.__dict__.setdefault("_df", {})
+        key = (int(groups), DF_COST_LAYER, DF_COST_ROW)
+        if key not in cache:
+            meta = getattr(self, "_df_host", None)
+            if meta is not None and meta.get("key") == key:   # built by the loader (host_plan.attach_plan)
+                cache[key] = meta["words"]
+            else:
+                lib = _lib.load()
+                nbytes = lib.dagnn_dataflow_bytes(self.N, self.B, key[0])
+                ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=self.ws.device)
+                with _span("dataflow_schedule", self.ws):
+                    check(lib.dagnn_dataflow_schedule(C.byref(self.desc), ws.data_ptr(), nbytes, key[0], key[1], key[2],
+                                                      _stream(self.ws)), "dagnn_dataflow_schedule")
+                cache[key] = ws
+        return cache[key]
+
+    def dataflow_layout(self, groups: int) -> dict:
+        off = (C.c_int64 * 13)()
+        check(_lib.load().dagnn_dataflow_layout(self.N, self.B, int(groups), off), "dagnn_dataflow_layout")
+        names = ["grp_of", "gdepth", "gload", "loff", "gtab0", "gtab1", "lcnt0", "lcnt1", "glbase0", "glbase1", "grec0",
+                 "grec1", "total"]
+        return {k: int(v) // 4 for k, v in zip(names, off)}
 
     def check_status(self) -> None:
         """Debug helper (synchronises): raises if the batch violated the layout contract."""
@@ -286,6 +316,69 @@ def pack_batch(mats: Sequence[torch.Tensor], H: int):
     return outs
 
 
+def pack_dataflow(w: torch.Tensor, H: int) -> torch.Tensor:
+    """[3H, H] (torch layout) -> slice / lane order of the dataflow kernel."""
+    w = _dev(w, "weight", torch.float32)
+    if tuple(w.shape) != (3 * H, H):
+        raise DagnnHipError("pack_dataflow needs a [3H, H] matrix, got %s" % (tuple(w.shape),))
+    out = torch.empty(3 * H * H, dtype=torch.float32, device=w.device)
+    check(_lib.load().dagnn_pack_dataflow(w.data_ptr(), out.data_ptr(), H, _stream(w)), "dagnn_pack_dataflow")
+    return out
+
+
+def dataflow_groups(device, num_cells: int, H: int, B: int) -> int:
+    """Groups the dataflow kernel runs on this device for this model shape; 0 = not applicable."""
+    if not DATAFLOW:
+        return 0
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    g = _lib.load().dagnn_dataflow_groups(cus, int(num_cells), int(H), int(B))
+    return min(g, DF_GROUPS) if DF_GROUPS > 0 else g
+
+
+def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0, h, groups: int, vid_mod: int = 0,
+                 arena: Optional["GranuleArena"] = None, static_score=None, score_parts: bool = False) -> None:
+    """The whole recurrence as one persistent launch (csrc/dataflow.hip).  Same operands as `frontier_run`;
+    `score_parts` adds the partial attention scores behind the state rows (what the backward pass reads)."""
+    if arena is None:
+        raise DagnnHipError("the dataflow kernel needs a GranuleArena (persistent, zero-initialised granule buffers)")
+    lib = _lib.load()
+    args = DataflowArgs()
+    gld = H + H // 16
+    gran, epoch, err = arena.get([(d, i) for d in dirs for i in range(L)], plan.N, gld, plan.ws.device)
+    mask = 0
+    for d in dirs:
+        mask |= 1 << d
+        for i in range(L):
+            c, fc = cells[(d, i)], args.cell[d][i]
+            fc.w_hh = c.w_hh_df.data_ptr()
+            fc.w_ih = c.w_ih_df.data_ptr() if c.w_ih_df is not None else None
+            fc.b_hh, fc.b_ih = c.b_hh.data_ptr(), _ptr(c.b_ih_dev)
+            if static_score is not None:
+                fc.static_score = _dev(static_score[(d, i)], "static score", torch.float32).data_ptr()
+            else:
+                fc.w_key = c.w_key.data_ptr()
+            fc.edge_gain = _ptr(c.edge_gain) if plan.R > 0 else None
+            fc.vid_bias = _ptr(c.vid_bias) if vid_mod > 0 else None
+            fc.gi0 = gi0[d].data_ptr() if i == 0 else None
+            fc.h_out = h[d][i].data_ptr()
+            fc.granules = gran[(d, i)].data_ptr()
+    args.num_stacked, args.dir_mask, args.H, args.ld_h, args.gld = L, mask, H, h[dirs[0]][0].shape[1], gld
+    args.vid_mod, args.groups, args.epoch = int(vid_mod), int(groups), epoch
+    sched = plan.dataflow_schedule(groups)
+    args.schedule, args.err = sched.data_ptr(), err.data_ptr()
+    args.debug_timing = DEBUG_TIMING.data_ptr() if DEBUG_TIMING is not None else None
+    args.spin_limit = SPIN_LIMIT
+    args.debug_wg = _env_int("DAGNN_AMD_DEBUG_WG", 0)
+    with _span("dataflow_run", plan.ws):
+        check(lib.dagnn_dataflow_run(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_dataflow_run")
+    if score_parts and static_score is None:
+        for d in dirs:
+            for i in range(L):
+                check(lib.dagnn_score_parts(h[d][i].data_ptr(), h[d][i].shape[1], H, cells[(d, i)].w_key.data_ptr(),
+                                            plan.N, _stream(plan.ws)), "dagnn_score_parts")
+    arena.watch(plan)
+
+
 def frontier_ld(H: int) -> int:
     """Row pitch of the lock-step state buffers: H states + H/16 partial scores, 16-byte multiple."""
     return H + (H // 16 + 3) // 4 * 4
@@ -320,10 +413,48 @@ class GranuleArena(object):
             self.side = torch.cuda.Stream(device)
         return self.side
 
+    def watch(self, plan=None) -> None:
+        """Queue an asynchronous read-back of the device-side error words (the kernels' bounded-wait flag and the
+        plan's contract status) behind the work just launched; `poll()` looks at it without synchronising."""
+        dev = self.err.device
+        if getattr(self, "_host", None) is None:
+            self._host = torch.zeros(2, dtype=torch.int32).pin_memory()
+        st = torch.cuda.current_stream(dev)
+        self._host[0:1].copy_(self.err, non_blocking=True)
+        if plan is not None:
+            self._host[1:2].copy_(plan.status[0:1], non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record(st)
+
+    def poll(self, block: bool = False) -> None:
+        """Raise `DagnnHipError` if a finished earlier pass reported a device-side failure.  Without `block` this only
+        looks at read-backs that have already completed (no synchronisation)."""
+        ev = getattr(self, "_event", None)
+        if ev is None:
+            return
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        self._event = None
+        e, s = int(self._host[0]), int(self._host[1])
+        if e or s:
+            self._host.zero_()
+            if self.err is not None:
+                self.err.zero_()
+            msgs = []
+            if e:
+                msgs.append("a bounded device-side wait expired (code %d): the persistent kernel's workgroups were not "
+                            "co-resident, or a producer failed" % e)
+            if s:
+                msgs.append("the batch violates the plan contract (status %d: 1 edges not grouped by graph, 2 edge "
+                            "crosses graphs / out of range, 4 batch vector not sorted, 8 layer id out of range)" % s)
+            raise DagnnHipError("results of an earlier DAGNN pass are invalid: " + "; ".join(msgs))
+
     def check(self) -> None:
-        """Debug helper (synchronises): raises if a bounded wait in the tail kernel expired."""
+        """Synchronising check: raises if a bounded wait in a persistent kernel expired."""
         if self.err is not None and int(self.err[0]):
-            raise DagnnHipError("persistent tail kernel: a bounded wait expired (results are invalid)")
+            raise DagnnHipError("persistent kernel: a bounded wait expired (results are invalid)")
 
 
 def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0, h, vid_mod: int = 0,

@@ -243,6 +243,66 @@ int dagnn_frontier_run(const dagnn_plan* plan /* host */, const dagnn_frontier_a
                        void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Dataflow schedule of the same recurrence (the default path for H <= 256): ONE persistent launch for the whole loop
+ * nest of dagnn.py:144-182, cut along graphs instead of layers (dagnn_amd/csrc/dataflow.hip).
+ *
+ *   1. dagnn_dataflow_groups: how many independent groups G the device hosts (one workgroup per (cell, 32-unit slice)
+ *      per group, one workgroup per CU): floor(num_cus / (num_cells * H/32)), capped at 64 and at B; 0 = this shape
+ *      is not supported (H > 256, H % 64 != 0, or one group does not fit the device) - use dagnn_frontier_run.
+ *   2. dagnn_dataflow_schedule: deals the graphs of a plan to the G groups - longest-processing-time first on
+ *      cost_layer * depth + cost_row * nodes, integer arithmetic, ties to the lowest group - and re-sorts the plan's
+ *      64-byte row records by (group, topological layer, graph, node), every group-layer padded to whole blocks of 4
+ *      records (padding records: node = -1).  The result depends on the plan and on (G, costs) only: build it once per
+ *      batch (it also serves the backward pass).  Workspace: dagnn_dataflow_bytes(N, B, G), any contents.
+ *   3. dagnn_dataflow_run: the launch.  Every (direction, stacked layer) cell needs `granules`: uint64 [N, gld]
+ *      (gld >= H) tagged copies {epoch, fp32 bits} of its state rows - the hand-off format between workgroups.  The
+ *      buffers must have been zero-initialised once and only ever used with strictly increasing `epoch`s (a replayed
+ *      hipGraph must contain the memset).  `err` (device int32, zeroed by the caller) is set when a bounded wait
+ *      expires (results are then invalid): bit 0 a granule poll, bit 1 an LDS flag.
+ *      State rows h_out [N, ld_h] receive the H states only; dagnn_score_parts adds the H/16 partial attention scores
+ *      behind them (the format dagnn_backward_prepare reads) when a backward pass follows.
+ * Weights: dagnn_pack_dataflow(W [3H,H] torch layout) -> 3*H*H floats in slice / lane order.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dagnn_dataflow_cell {
+    const float* w_hh;      /* weight_hh packed by dagnn_pack_dataflow */
+    const float* w_ih;      /* weight_ih packed likewise (stacked layers > 0), else NULL */
+    const float* b_hh;      /* [3H] */
+    const float* b_ih;      /* [3H] (stacked layers > 0; layer 0 has it folded into gi0) */
+    const float* w_key;     /* [H] key half of attn_lin.weight (ignored when static_score is given) */
+    const float* static_score; /* NULL, or [N]: see dagnn_frontier_cell */
+    const float* edge_gain; /* [num_edge_feats] or NULL */
+    const float* vid_bias;  /* [vid_mod] or NULL */
+    const float* gi0;       /* [N,3H] W_ih x + b_ih (stacked layer 0 only) */
+    float* h_out;           /* [N,ld_h] */
+    void* granules;         /* uint64 [N,gld] */
+} dagnn_dataflow_cell;
+
+typedef struct dagnn_dataflow_args {
+    dagnn_dataflow_cell cell[DAGNN_MAX_DIRS][DAGNN_MAX_STACKED];
+    int num_stacked, dir_mask;
+    int H, ld_h, gld, vid_mod;
+    int groups;            /* G the schedule was built for */
+    unsigned epoch;
+    const void* schedule;  /* device workspace written by dagnn_dataflow_schedule */
+    void* err;             /* device int32 */
+    void* debug_timing;    /* NULL, or uint64 device words (100 MHz stamps): [workgroups][2] start / end of every
+                            * workgroup, then [blocks][8] phase stamps of workgroup `debug_wg` */
+    unsigned spin_limit;   /* polls before a wait gives up and raises `err`; 0 = default (1 << 22, seconds) */
+    int debug_wg;          /* workgroup whose blocks are stamped (debug_timing) */
+} dagnn_dataflow_args;
+
+int dagnn_dataflow_groups(int num_cus, int num_cells, int H, int64_t B);
+size_t dagnn_dataflow_bytes(int64_t N, int64_t B, int groups);
+int dagnn_dataflow_schedule(const dagnn_plan* plan /* host */, void* workspace, size_t workspace_bytes, int groups,
+                            int cost_layer, int cost_row, void* stream);
+int dagnn_dataflow_run(const dagnn_plan* plan /* host */, const dagnn_dataflow_args* args /* host */, void* stream);
+int dagnn_pack_dataflow(const float* w /* [3H,H] */, float* out /* 3H*H floats */, int H, void* stream);
+int dagnn_score_parts(float* h /* [N,ld_h] */, int ld_h, int H, const float* w_key /* [H] */, int64_t N, void* stream);
+/* Introspection (tests, host-side mirror): byte offsets of the schedule workspace's arrays, 13 entries: [grp_of,
+ * gdepth, gload, loff, gtab0, gtab1, lcnt0, lcnt1, glbase0, glbase1, grec0, grec1, total]. */
+int dagnn_dataflow_layout(int64_t N, int64_t B, int groups, int64_t* offsets13 /* host */);
+
+/* ------------------------------------------------------------------------------------------
  * Read-out over output nodes (dagnn.py:119-126,184-193 with out_pool='max', out_pool_all=0):
  *   out[g, col_off[d] + j] = max over { v in graph g : layer_{1-d}(v) == 0 } of h[d][v, j]
  * d = 0 pools the sinks, d = 1 the sources.  h[d] is [N,ld_h]; `width` columns are pooled

@@ -17,11 +17,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4  # BASELINE.json north_star: "within 1e-4 fp32"
 
 
-@pytest.fixture(params=["lockstep", "pergraph"])
+@pytest.fixture(params=["dataflow", "lockstep", "pergraph"])
 def schedule(request, monkeypatch):
-    """Both HIP schedules of the recurrence: lock-step frontier launches (default) and persistent
-    per-(graph, direction) workgroups."""
-    monkeypatch.setenv("DAGNN_AMD_SCHEDULE", request.param)
+    """The three HIP schedules of the recurrence: the persistent graph-affine dataflow launch (default for H <= 256),
+    lock-step frontier launches (its fallback; the default for wider models) and persistent per-(graph, direction)
+    workgroups."""
+    monkeypatch.setenv("DAGNN_AMD_SCHEDULE", "pergraph" if request.param == "pergraph" else "lockstep")
+    monkeypatch.setattr(engine, "DATAFLOW", 1 if request.param == "dataflow" else 0)
     return request.param
 
 
@@ -212,6 +214,7 @@ def test_launch_shape_variants_match_reference_golden(device, name, knob, monkey
     """Force the code paths the small fixtures would not reach on their own: 32-row MFMA tiles for
     every launch, every layer as its own launch (no persistent tail), the separate gather kernel."""
     monkeypatch.setenv("DAGNN_AMD_SCHEDULE", "lockstep")
+    monkeypatch.setattr(engine, "DATAFLOW", 0)
     if knob == "mfma_tiles":
         monkeypatch.setattr(engine, "MFMA_MIN_ROWS", 1)
         monkeypatch.setattr(engine, "TAIL_REPLICAS", 0)
@@ -252,6 +255,7 @@ def test_headline_batch_split_modes_agree(device, split, monkeypatch):
     b.x[:, 1] %= 10030
     y = torch.randint(0, 48, (128, 3), generator=torch.Generator().manual_seed(9)).to(device)
     res = {}
+    monkeypatch.setattr(engine, "DATAFLOW", 0)
     for mode in (1 - split, split):
         monkeypatch.setattr(engine, "SPLIT_DEEP", mode)
         model = build_model(128, 2, 48, 3, device)

@@ -67,12 +67,12 @@ class FrontierArgs(C.Structure):
 
 class DataflowCell(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("w_hh", "w_ih", "b_hh", "b_ih", "w_key", "static_score", "edge_gain",
-                                          "vid_bias", "gi0", "h_out", "granules")]
+                                          "vid_bias", "gi0", "h_out", "granules", "proj_granules")]
 
 
 class DataflowArgs(C.Structure):
     _fields_ = [("cell", (DataflowCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
-                ("H", C.c_int), ("ld_h", C.c_int), ("gld", C.c_int), ("vid_mod", C.c_int), ("groups", C.c_int),
+                ("H", C.c_int), ("ld_h", C.c_int), ("gld", C.c_int), ("pld", C.c_int), ("vid_mod", C.c_int), ("groups", C.c_int),
                 ("epoch", C.c_uint), ("schedule", C.c_void_p), ("err", C.c_void_p), ("debug_timing", C.c_void_p),
                 ("spin_limit", C.c_uint), ("debug_wg", C.c_int)]
 
@@ -137,7 +137,7 @@ SYMBOLS = {
     "dagnn_pack_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dagnn_frontier_run": (C.c_int, [C.POINTER(Plan), C.POINTER(FrontierArgs), C.POINTER(C.POINTER(C.c_int32)),
                                      C.POINTER(C.c_int32), C.c_void_p]),
-    "dagnn_dataflow_groups": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64]),
+    "dagnn_dataflow_groups": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64]),
     "dagnn_dataflow_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),
     "dagnn_dataflow_layout": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
     "dagnn_dataflow_schedule": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,

@@ -16,7 +16,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
-LIB = os.path.join(LIB_DIR, "libdagnn_hip.so")
+LIB = os.environ.get("DAGNN_AMD_LIB") or os.path.join(LIB_DIR, "libdagnn_hip.so")   # override: experiment builds
 ARCH = "gfx950"
 
 
@@ -29,6 +29,8 @@ def _deps():
 
 
 def is_stale() -> bool:
+    if os.environ.get("DAGNN_AMD_LIB"):
+        return False
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
@@ -43,7 +45,8 @@ def hipcc_path() -> str:
 
 
 def _compile(src: str, obj: str, verbose: bool) -> None:
-    cmd = [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-c", "-o", obj, src]
+    cmd = [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-c", "-o", obj, src] + \
+        os.environ.get("DAGNN_AMD_HIPCC_FLAGS", "").split()
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)

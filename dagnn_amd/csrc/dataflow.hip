@@ -30,6 +30,10 @@
 // one hand-off + ~0.5 us of compute per hop.
 #include "common.h"
 
+#ifndef DF_EXPERIMENT
+#define DF_EXPERIMENT 0
+#endif
+
 namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -224,33 +228,43 @@ __global__ void __launch_bounds__(256) df_records_kernel(const int32_t* __restri
 }
 
 // ---------------------------------------------------------------- the persistent kernel
+// Kernel cells.  A GRU cell of stacked layer i > 0 has two matrix products per node: W_hh x (aggregate of the
+// predecessors' states) - on the dependent chain - and W_ih x (the node's own state one layer down), which is known
+// one hop earlier.  They run as two kinds of kernel cell with the SAME compute path (one [3H x H] slice resident in
+// registers, no weight stream):
+//   RECURRENT  aggregate -> W_hh product -> gates -> h' (states + granules); its input-side pre-activations come
+//              from gi0 (stacked layer 0: the batched GEMM) or from the granules of its PROJECTION cell;
+//   PROJECTION lower-layer row -> W_ih product + b_ih -> [N, 3H] granules, off the dependent chain.
+enum { DF_RECURRENT = 0, DF_PROJECTION = 1 };
+
 struct DfCell {
-    const float4* whh;    // packed slices (dagnn_pack_dataflow)
-    const float4* wih;    // stacked layers > 0, else null
-    const float* bhh;     // [3H]
-    const float* bih;     // [3H] (with wih)
+    const float4* w;      // packed slices (dagnn_pack_dataflow): W_hh (recurrent) or W_ih (projection)
+    const float* bias;    // [3H] b_hh (recurrent; + b_ih folded by the projection) or b_ih (projection)
     const float* wkey;    // [H] or null (static scores)
     const float* sscore;  // [N] or null
     const float* gain;    // [R] or null
     const float* vid;     // [vid_mod] or null
-    const float* gi0;     // [N,3H] (stacked layer 0) or null
-    float* h_out;         // [N,ld_h]
-    gran_t* g_out;        // [N,gld] granules of h_out
-    const gran_t* g_in;   // granules of the lower stacked layer, or null
+    const float* gi0;     // recurrent, stacked layer 0: [N,3H] input-side pre-activations, else null
+    const gran_t* p_in;   // recurrent, stacked layers > 0: [N,pld] granules of its projection cell, else null
+    float* h_out;         // recurrent: [N,ld_h]
+    gran_t* g_out;        // recurrent: [N,gld] granules of h_out; projection: [N,pld] granules of the pre-activations
+    const gran_t* g_in;   // projection: granules of the lower stacked layer's states
     int dir;
-    int stacked;
+    int kind;
 };
 
+#define DF_MAX_KCELLS 16
+
 struct DfArgs {
-    DfCell cell[DAGNN_MAX_DIRS * DAGNN_MAX_STACKED];
+    DfCell cell[DF_MAX_KCELLS];
     const int32_t* sched;   // schedule workspace (dagnn_dataflow_schedule)
     int64_t gtab[2], grec[2];   // word offsets into sched
     int64_t col[2], eattr[2];   // word offsets into the plan
-    int ncell, H, ld_h, gld, R, vid_mod, groups;
+    int ncell, H, ld_h, gld, pld, R, vid_mod, groups;
     unsigned epoch, spin_limit;
     int dbg_wg;                 // workgroup whose blocks are stamped
     int* err;
-    unsigned long long* dbg;    // optional: [grid][2] start / end stamps, then [blocks][8] stamps of workgroup 0 (100 MHz)
+    unsigned long long* dbg;    // optional: [grid][2] start / end stamps, then [blocks][8] stamps of workgroup dbg_wg (100 MHz)
 };
 
 __device__ __forceinline__ float df_dpp_row_sum16(float v) {
@@ -278,18 +292,22 @@ __device__ __forceinline__ float df_tanh(float x) { return 1.0f - 2.0f * __built
 // starts at s * (KP8 + 4): the 8 segments a half DPP row reads concurrently (ds_read_b128) fall on disjoint banks
 template <int KPT> struct DfPad { static constexpr int kp8 = 2 * KPT; static constexpr int seg = kp8 + 4; static constexpr int row = 8 * seg; };
 
+constexpr int DF_RD = 7;       // a row record is requested this many blocks ahead (record ring: 8 entries)
+constexpr int DF_GD = 4;       // a gi0 slice this many (its node id must have landed: DF_RD >= DF_GD + 2)
+constexpr int DF_GIRING = DF_NSLOT + DF_GD + 1;   // blocks in the gi0 ring: ring slots in use + the prefetch distance + 1
+
 struct DfLds {
-    float4* wih;     // [3*KPT/2][256]
     float* ring;     // NSLOT x slot
+    float* giring;   // [DF_GIRING][RB][96]: gi0 slices of the slice's rows, landed by LDS-DMA two blocks ahead
+    int* rec;        // [RB][8][16]: row records of the loader waves, landed by LDS-DMA four blocks ahead
     int* rdy;        // [RB]   per loader wave: blocks it has finished (relaxed workgroup-scope atomics: plain ds_ accesses;
     int* dn;         // [NCW]  per compute wave likewise        a volatile access here compiles to a FLAT load + vmcnt(0))
 };
 
 template <int KPT> struct DfSlot {
     static constexpr int AP = DfPad<KPT>::row;
-    static constexpr int a_off = 0;                       // [RB][AP]
-    static constexpr int u_off = DF_RB * AP;              // [RB][AP]
-    static constexpr int gi_off = 2 * DF_RB * AP;         // [RB][96]
+    static constexpr int a_off = 0;                       // [RB][AP]  operand rows (aggregates / lower-layer rows)
+    static constexpr int gi_off = DF_RB * AP;             // [RB][96]  input-side pre-activations of the slice
     static constexpr int v_off = gi_off + DF_RB * 3 * DF_JS;   // [RB] ints (16 B)
     static constexpr int words = v_off + 4;
 };
@@ -331,15 +349,15 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
     const int4* __restrict__ recs = reinterpret_cast<const int4*>(S.sched + S.grec[d]) + 4 * ((int64_t)rec_base + lw);
     const int32_t* __restrict__ col = plan + S.col[d];
     const float* __restrict__ eattr = reinterpret_cast<const float*>(plan + S.eattr[d]);
-    const int R = C.gain ? S.R : 0;
-    const bool has_in = C.wih != nullptr;
-    const int gld = S.gld;
+    const bool proj = C.kind == DF_PROJECTION;
+    const int R = (C.gain && !proj) ? S.R : 0;
     // everything the loop needs from the argument structs, read ONCE: a field access inside the loop is a scalar load
     // from the kernel-argument segment plus an lgkmcnt(0) wait on the dependent chain
     const unsigned epoch = S.epoch, spin_limit = S.spin_limit;
     int* const err = S.err;
-    gran_t* const g_out = C.g_out;
-    const gran_t* const g_in = C.g_in;
+    const gran_t* const g_src = proj ? C.g_in : C.g_out;   // rows this cell reads: the lower layer's / its own states
+    const int gld = S.gld, pld = S.pld;
+    const gran_t* const p_in = C.p_in;
     const float* const gi0 = C.gi0;
     const float* const sscore = C.sscore;
     const float* const vid = C.vid;
@@ -358,64 +376,136 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
     for (int q = 0; q < 4; ++q) {
         const int c = 64 * q + lane;
         cpos[q] = c + (SEG - KP8) * (c / KP8);
-        if (C.wkey && q < NQ4) wk[q] = C.wkey[c];
+        if (C.wkey && !proj && q < NQ4) wk[q] = C.wkey[c];
     }
     const bool prof = dbg != nullptr && (int)blockIdx.x == S.dbg_wg && lw == 0 && lane == 0;
 
-    // records are static plan data, prefetched two blocks ahead: lanes 0..15 load one word each of this wave's record
-    // (one 64-byte request, ONE register per record in flight) and the words become wave-uniform scalars
-    // (v_readlane) only when their block starts.  A scalar load here would be waited for together with every LDS
-    // access of the block (they share lgkmcnt); a uniform vector load would be waited for right where it is issued.
-    // The prefetch is issued right before the block's polls: their wait covers it (the same trip to memory), and by
-    // the time the words are read they have been in the register for a whole block.
+    // ---- memory traffic of this wave, by hand.  Three streams share the wave's in-order vmcnt counter: the granule
+    // sweeps (on the dependent chain), the static row records and the gi0 slices (cold lines: HBM latency).  Left to
+    // the compiler every wait inside this loop is a vmcnt(0), i.e. each sweep would also wait for the prefetches
+    // issued next to it (measured: 1.3 us per block instead of 0.2).  So:
+    //  * records and gi0 slices travel by LDS-DMA (global_load_lds: no destination register that the compiler could
+    //    copy or spill while the load is in flight) into small LDS rings, DF_RD resp. DF_GD blocks ahead;
+    //  * the sweeps are inline-asm register loads, consumed right behind their wait;
+    //  * the order is fixed - sweep of block b, then the prefetch group P(b) = {record of block b + RD, gi0 slice of
+    //    block b + GD} - and the waits are counted: vmcnt(|P|) after P(b) completes the sweep and everything older
+    //    (P(b - 1) included) while P(b) stays in flight.
+    // wave-uniform row pointer (scalar registers) + one per-lane byte offset shared by all loads + an immediate
+#define DF_LD_GRAN(dst, voff, sbase, imm) \
+    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3 sc1" : "+v"(dst) : "v"(voff), "s"(sbase), "n"(imm) : "memory")
+    auto glds4 = [&](const void* gsrc, unsigned lds_dst) {   // lane l: 4 bytes from gsrc -> LDS lds_dst + 4 l
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    };
+    auto glds16 = [&](const void* gsrc, unsigned lds_dst) {   // lane l: 16 bytes from gsrc -> LDS lds_dst + 16 l
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    };
+    struct Sweep { gran_t x[4][4]; gran_t xp[3]; };
+    const unsigned lane8 = 8u * lane, lane31x8 = 8u * (lane & 31);
+    auto issue = [&](Sweep& W, const int (&pj)[4], unsigned pend, bool pp, const gran_t* gp_in) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const gran_t* gp = g_src + (int64_t)pj[e] * gld;   // wave-uniform
+            const bool on = (pend >> e) & 1u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) W.x[e][q] = ready;   // (read-write operands: no merge of a loaded and a constant value)
+            if (on) {
+                DF_LD_GRAN(W.x[e][0], lane8, gp, 0);
+                if (NQ4 > 1) DF_LD_GRAN(W.x[e][1], lane8, gp, 512);
+                if (NQ4 > 2) DF_LD_GRAN(W.x[e][2], lane8, gp, 1024);
+                if (NQ4 > 3) DF_LD_GRAN(W.x[e][3], lane8, gp, 1536);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g) W.xp[g] = ready;
+        if (pp) {   // all lanes (lanes 32.. repeat lanes 0..31): one instruction per gate
+            DF_LD_GRAN(W.xp[0], lane31x8, gp_in, 0);
+            DF_LD_GRAN(W.xp[1], lane31x8, gp_in + H, 0);
+            DF_LD_GRAN(W.xp[2], lane31x8, gp_in + 2 * H, 0);
+        }
+    };
+#define DF_TOUCH(W)                                                                                                       \
+    asm volatile("" : "+v"(W.x[0][0]), "+v"(W.x[0][1]), "+v"(W.x[0][2]), "+v"(W.x[0][3]), "+v"(W.x[1][0]), "+v"(W.x[1][1]), \
+                      "+v"(W.x[1][2]), "+v"(W.x[1][3]), "+v"(W.x[2][0]), "+v"(W.x[2][1]), "+v"(W.x[2][2]), "+v"(W.x[2][3]), \
+                      "+v"(W.x[3][0]), "+v"(W.x[3][1]), "+v"(W.x[3][2]), "+v"(W.x[3][3]), "+v"(W.xp[0]), "+v"(W.xp[1]),     \
+                      "+v"(W.xp[2]))
+    const bool has_gi0 = gi0 != nullptr;
+    // everything issued before the newest |P| loads has landed; the sweep's registers may be read from here on
+    auto landed = [&](Sweep& W) {
+        if (has_gi0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        DF_TOUCH(W);
+    };
+    auto landed_all = [&](Sweep& W) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DF_TOUCH(W);
+    };
+
+    // LDS rings of this wave: records (8 entries x 64 B) and, shared with the compute waves, the gi0 slices
+    // (DF_GIRING blocks x RB rows x 384 B: compute reads entry b % DF_GIRING)
+    int* const rec_ring = lds.rec + lw * (8 * 16);
+    const unsigned rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
+    const unsigned gi_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds.giring + lw * (3 * DF_JS)));
     const int32_t* rec_w = reinterpret_cast<const int32_t*>(recs) + (lane & 15);
     const int64_t wstride = 16 * DF_RB;   // words per block
-    int pf0 = nblk > 0 ? rec_w[0] : -1;
-    int pf1 = nblk > 1 ? rec_w[wstride] : -1;
-    float4 giv_next = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int gi_lane_off = (lane >> 3) * H + sl * DF_JS + 4 * (lane & 7);
-    {
-        const int v0 = __builtin_amdgcn_readlane(pf0, 0);
-        if (gi0 && lane < 24 && v0 >= 0) giv_next = *reinterpret_cast<const float4*>(gi0 + (int64_t)v0 * 3 * H + gi_lane_off);
+    const int gi_lane_off = ((lane % 24) >> 3) * H + sl * DF_JS + 4 * (lane & 7);
+    auto rec_dma = [&](int blk) {   // record of block `blk` (past the end: the last one again) -> ring entry blk & 7
+        if (lane < 16) glds4(rec_w + (int64_t)min(blk, nblk - 1) * wstride, rec_ring_a + (blk & 7) * 64);
+    };
+    auto gi_dma = [&](int blk, int node) {   // gi0 slice of `node` -> gi ring entry blk % DF_GIRING, row lw
+        if (lane < 24) glds16(gi0 + (int64_t)max(node, 0) * 3 * H + gi_lane_off, gi_ring_a + (blk % DF_GIRING) * (DF_RB * 3 * DF_JS * 4));
+    };
+    if (nblk > 0) {   // prologue: records 0..RD-1, gi0 slices of blocks 0..GD-1
+#pragma unroll
+        for (int j = 0; j < DF_RD; ++j) rec_dma(j);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (has_gi0) {
+#pragma unroll
+            for (int j = 0; j < DF_GD; ++j) gi_dma(j, __builtin_amdgcn_readfirstlane(rec_ring[j * 16]));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
 
+    Sweep A;
     for (int b = 0; b < nblk; ++b) {
-        const int cur = pf0;
-        pf0 = pf1;
+        const int cur = rec_ring[(b & 7) * 16 + (lane & 15)];
 #define DF_W(i) __builtin_amdgcn_readlane(cur, i)
         const int4 r0 = make_int4(DF_W(0), DF_W(1), DF_W(2), DF_W(3));
         const int4 r1 = make_int4(DF_W(4), DF_W(5), DF_W(6), DF_W(7));
         const int4 r2 = make_int4(DF_W(8), DF_W(9), DF_W(10), DF_W(11));
         const int4 r3 = make_int4(DF_W(12), DF_W(13), DF_W(14), DF_W(15));
 #undef DF_W
-        float4 giv = giv_next;
-        asm volatile("" : "+v"(giv.x), "+v"(giv.y), "+v"(giv.z), "+v"(giv.w));   // its own registers, before the reload below
-        const int vn = __builtin_amdgcn_readlane(pf0, 0);   // node of block b + 1: its gi0 slice, one block early
-        __builtin_amdgcn_sched_barrier(0);   // the loads below stay below the reads of what arrived a block ago
-        pf1 = b + 2 < nblk ? rec_w[(int64_t)(b + 2) * wstride] : -1;
-        if (gi0 && lane < 24 && b + 1 < nblk && vn >= 0)
-            giv_next = *reinterpret_cast<const float4*>(gi0 + (int64_t)vn * 3 * H + gi_lane_off);
+        const int v2 = __builtin_amdgcn_readfirstlane(rec_ring[((b + DF_GD) & 7) * 16]);   // node of block b + GD (landed with P(b + GD - RD))
         const int slot = b % DF_NSLOT;
         float* sbase = lds.ring + slot * Slot::words;
-        if (b >= DF_NSLOT) df_wait4(lds.dn, b - DF_NSLOT + 1, err, spin_limit);
         int* v_s = reinterpret_cast<int*>(sbase + Slot::v_off);
         const int v = r0.x;
         if (prof) dbg[8 * (int64_t)b + 4] = wall_clock64();
         unsigned polls = 0;
+        auto prefetch = [&]() {   // P(b): exactly 1 (+1 with gi0) loads, whatever the block looks like
+            rec_dma(b + DF_RD);
+            if (has_gi0) gi_dma(b + DF_GD, v2);
+        };
         if (v >= 0) {
-            const int eb = r0.y, deg = r0.z - r0.y;
-            float* a_row = sbase + Slot::a_off + lw * Slot::AP;
+            const int eb = r0.y;
+            const int deg = proj ? 1 : r0.z - r0.y;   // a projection reads ONE row: the node's own state one layer down
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             float m = -INFINITY, l = 0.f;
-            bool u_pending = has_in;
-            float urow[4] = {0.f, 0.f, 0.f, 0.f};
-            const gran_t* gu = has_in ? g_in + (int64_t)v * gld : nullptr;
+            // input-side pre-activations of the slice from the projection cell: 3 gates x 32 units, lanes 0..31
+            bool p_pending = p_in != nullptr;
+            float pv[3] = {0.f, 0.f, 0.f};
+            const gran_t* gp_in = p_pending ? p_in + (int64_t)v * pld + sl * DF_JS : nullptr;   // wave-uniform
             int c0 = 0;
             do {   // chunks of <= 4 in-edges (one pass for deg <= 4, where ids and features came with the record)
                 const int nn = min(4, deg - c0);
                 int pj[4] = {0, 0, 0, 0};
                 float fe[4] = {0.f, 0.f, 0.f, 0.f};   // gain . edge features of the chunk's edges
-                if (c0 == 0) {
+                if (proj) {
+                    pj[0] = v;
+                } else if (c0 == 0) {
                     pj[0] = r1.x; pj[1] = r1.y; pj[2] = r1.z; pj[3] = r1.w;
                     if (R >= 1 && R <= 2) {
                         fe[0] = gain0 * __int_as_float(r2.x) + gain1 * __int_as_float(r2.y);
@@ -434,72 +524,81 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                         if (e < nn) for (int r = 0; r < R; ++r) fe[e] = fmaf(gainp[r], eattr[(int64_t)(eb + c0 + e) * R + r], fe[e]);
                     }
                 }
-                // ---- poll: every load of a pass is issued before the first tag is looked at (atomic loads keep
-                // program order; a compare between two groups would serialise the round trips); rows that have
-                // arrived are not asked for again
+                // ---- poll; rows that have arrived are not asked for again
                 float row[4][4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) row[e][q] = 0.f;
-                unsigned pend = (1u << nn) - 1u;   // wave-uniform: predecessor rows still missing
+                unsigned pend = (1u << nn) - 1u;   // wave-uniform: rows still missing
                 unsigned spins = 0;
+#if DF_EXPERIMENT == 8
+                if (prof && c0 == 0) dbg[8 * (int64_t)b + 4] = wall_clock64();
+#endif
+                issue(A, pj, pend, p_pending, gp_in);
+                if (c0 == 0) { prefetch(); landed(A); }
+                else landed_all(A);
+#if DF_EXPERIMENT == 8
+                if (prof && c0 == 0) dbg[8 * (int64_t)b + 5] = wall_clock64();
+#endif
                 for (;;) {
-                    gran_t x[4][4], xu[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const gran_t* gp = g_out + (int64_t)pj[e] * gld;
-                        const bool on = (pend >> e) & 1u;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) x[e][q] = (on && q < NQ4) ? gran_ld(gp + 64 * q + lane) : ready;
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) xu[q] = (u_pending && q < NQ4) ? gran_ld(gu + 64 * q + lane) : ready;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if ((pend >> e) & 1u) {
                             bool ok = true;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(x[e][q] >> 32) == epoch;
+                            for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(A.x[e][q] >> 32) == epoch;
                             if (__all(ok)) {
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) row[e][q] = __uint_as_float((unsigned)x[e][q]);
+                                for (int q = 0; q < 4; ++q) row[e][q] = __uint_as_float((unsigned)A.x[e][q]);
                                 pend &= ~(1u << e);
                             }
                         }
                     }
-                    if (u_pending) {
-                        bool oku = true;
+                    if (p_pending) {
+                        bool okp = true;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) oku = oku && (unsigned)(xu[q] >> 32) == epoch;
-                        if (__all(oku)) {
+                        for (int g = 0; g < 3; ++g) okp = okp && (unsigned)(A.xp[g] >> 32) == epoch;
+                        if (__all(okp)) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) urow[q] = __uint_as_float((unsigned)xu[q]);
-                            u_pending = false;
+                            for (int g = 0; g < 3; ++g) pv[g] = __uint_as_float((unsigned)A.xp[g]);
+                            p_pending = false;
                         }
                     }
                     ++polls;
-                    if ((pend == 0 && !u_pending) || !df_retry(spins, err, spin_limit)) break;
+                    if ((pend == 0 && !p_pending) || !df_retry(spins, err, spin_limit)) break;
+                    issue(A, pj, pend, p_pending, gp_in);
+                    landed_all(A);
                 }
+#if DF_EXPERIMENT != 8
                 if (prof && c0 == 0) { dbg[8 * (int64_t)b + 5] = wall_clock64(); dbg[8 * (int64_t)b + 6] = polls; }
+#else
+                if (prof && c0 == 0) dbg[8 * (int64_t)b + 6] = polls;
+#endif
                 if (deg == 1) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[q] = row[0][q];
                     l = 1.f;
                 } else if (nn > 0) {
+                    // all four scores at once (rows not in the chunk are zeros): four independent reductions interleave
                     float s[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[e] = row[e][0] * wk[0] + row[e][1] * wk[1] + row[e][2] * wk[2] + row[e][3] * wk[3];
+                    if (!sscore) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s[e] = df_wave_sum(s[e]);
+                    }
                     float mc = m;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        s[e] = -INFINITY;
                         if (e < nn) {
-                            float sv;
-                            if (sscore) sv = sscore[pj[e]];
-                            else sv = df_wave_sum(row[e][0] * wk[0] + row[e][1] * wk[1] + row[e][2] * wk[2] + row[e][3] * wk[3]);
+                            float sv = sscore ? sscore[pj[e]] : s[e];
                             if (vid) sv += vid[pj[e] % vid_mod];
                             sv += fe[e];
                             s[e] = sv;
                             mc = fmaxf(mc, sv);
+                        } else {
+                            s[e] = -INFINITY;
                         }
                     }
                     const float sc = __expf(m - mc);   // 0 on the first chunk (m = -inf)
@@ -508,53 +607,68 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                     l *= sc;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (e < nn) {
-                            const float p = __expf(s[e] - mc);
-                            l += p;
+                        const float p = __expf(s[e] - mc);   // 0 for the slots beyond the chunk (s = -inf)
+                        l += p;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[q] = fmaf(p, row[e][q], acc[q]);
-                        }
+                        for (int q = 0; q < 4; ++q) acc[q] = fmaf(p, row[e][q], acc[q]);
                     }
                     m = mc;
                 }
                 c0 += 4;
             } while (c0 < deg);
             if (deg > 1) {   // PyG softmax: exp(x - max) / (sum + 1e-16)
-                const float inv = 1.0f / (l + 1e-16f);
+                const float inv = __builtin_amdgcn_rcpf(l + 1e-16f);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] *= inv;
             }
+            if (b >= DF_NSLOT) df_wait4(lds.dn, b - DF_NSLOT + 1, err, spin_limit);   // the ring slot is free again
+            float* a_row = sbase + Slot::a_off + lw * Slot::AP;
 #pragma unroll
-            for (int q = 0; q < NQ4; ++q) {
-                a_row[cpos[q]] = acc[q];
-                if (has_in) sbase[Slot::u_off + lw * Slot::AP + cpos[q]] = urow[q];
+            for (int q = 0; q < NQ4; ++q) a_row[cpos[q]] = acc[q];
+            if (p_in && lane < 32) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) sbase[Slot::gi_off + lw * (3 * DF_JS) + g * DF_JS + lane] = pv[g];
             }
-            if (gi0 && lane < 24)
-                *reinterpret_cast<float4*>(sbase + Slot::gi_off + lw * (3 * DF_JS) + (lane >> 3) * DF_JS + 4 * (lane & 7)) = giv;
+        } else {
+            prefetch();   // an idle row keeps the cadence: P(b) out, P(b - 1) landed
+            if (has_gi0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            if (b >= DF_NSLOT) df_wait4(lds.dn, b - DF_NSLOT + 1, err, spin_limit);
         }
         if (lane == 0) v_s[lw] = v;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) df_flag_st(lds.rdy + lw, b + 1);
         if (prof) dbg[8 * (int64_t)b + 3] = wall_clock64();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of ours is in flight when the wave ends
+#undef DF_LD_GRAN
+#undef DF_TOUCH
 }
 
-// acc[r][0..3] (sums for r / z gates, hidden-side n, input-side n; the two halves of a v2f take even / odd k) +=
-// products of this lane's K range for rows 0..NR-1: hidden side from registers, input side from LDS weights
+// Products of this lane's K range for rows 0..NR-1 (NR <= 2): acc[r][0..2] += (r, z, n) rows of the resident matrix
+// slice x the operand row in LDS; the two halves of a v2f take even / odd k.  The operand loads run PF steps ahead of
+// the products.
 template <int KPT, int NR>
-__device__ __forceinline__ void df_fma(v2f (&acc)[2][4], const v2f (&wr)[KPT], const v2f (&wz)[KPT],
-                                       const v2f (&wn)[KPT], const float* a_seg, const float* u_seg,
-                                       const float4* wih_s, bool has_in, int tc) {
+__device__ __forceinline__ void df_mac(v2f (&acc)[2][3], const v2f (&wr)[KPT], const v2f (&wz)[KPT],
+                                       const v2f (&wn)[KPT], const float* a_seg) {
     constexpr int AP = DfPad<KPT>::row;
     constexpr int NK4 = DfPad<KPT>::kp8 / 4;   // float4 steps over the lane's K range
+    constexpr int PF = NK4 < 4 ? NK4 : 4;
+    float4 av[NK4][NR];
+#pragma unroll
+    for (int q = 0; q < PF; ++q)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) av[q][r] = *reinterpret_cast<const float4*>(a_seg + r * AP + 4 * q);
 #pragma unroll
     for (int q = 0; q < NK4; ++q) {
-        float4 av[NR];
+        if (q + PF < NK4) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) av[r] = *reinterpret_cast<const float4*>(a_seg + r * AP + 4 * q);
+            for (int r = 0; r < NR; ++r) av[q + PF][r] = *reinterpret_cast<const float4*>(a_seg + r * AP + 4 * (q + PF));
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads this far ahead of their use
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const v2f lo = {av[r].x, av[r].y}, hi = {av[r].z, av[r].w};
+            const v2f lo = {av[q][r].x, av[q][r].y}, hi = {av[q][r].z, av[q][r].w};
             acc[r][0] = __builtin_elementwise_fma(lo, wr[2 * q], acc[r][0]);
             acc[r][1] = __builtin_elementwise_fma(lo, wz[2 * q], acc[r][1]);
             acc[r][2] = __builtin_elementwise_fma(lo, wn[2 * q], acc[r][2]);
@@ -562,27 +676,7 @@ __device__ __forceinline__ void df_fma(v2f (&acc)[2][4], const v2f (&wr)[KPT], c
             acc[r][1] = __builtin_elementwise_fma(hi, wz[2 * q + 1], acc[r][1]);
             acc[r][2] = __builtin_elementwise_fma(hi, wn[2 * q + 1], acc[r][2]);
         }
-    }
-    if (has_in) {
-#pragma unroll
-        for (int q = 0; q < NK4; ++q) {
-            float4 uv[NR];
-#pragma unroll
-            for (int r = 0; r < NR; ++r) uv[r] = *reinterpret_cast<const float4*>(u_seg + r * AP + 4 * q);
-            const float4 w0 = wih_s[(0 * NK4 + q) * 256 + tc];
-            const float4 w1 = wih_s[(1 * NK4 + q) * 256 + tc];
-            const float4 w2 = wih_s[(2 * NK4 + q) * 256 + tc];
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const v2f lo = {uv[r].x, uv[r].y}, hi = {uv[r].z, uv[r].w};
-                acc[r][0] = __builtin_elementwise_fma(lo, (v2f){w0.x, w0.y}, acc[r][0]);
-                acc[r][1] = __builtin_elementwise_fma(lo, (v2f){w1.x, w1.y}, acc[r][1]);
-                acc[r][3] = __builtin_elementwise_fma(lo, (v2f){w2.x, w2.y}, acc[r][3]);
-                acc[r][0] = __builtin_elementwise_fma(hi, (v2f){w0.z, w0.w}, acc[r][0]);
-                acc[r][1] = __builtin_elementwise_fma(hi, (v2f){w1.z, w1.w}, acc[r][1]);
-                acc[r][3] = __builtin_elementwise_fma(hi, (v2f){w2.z, w2.w}, acc[r][3]);
-            }
-        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -601,11 +695,11 @@ template <int N> __device__ __forceinline__ float df_dpp_shl(float v) {
 }
 
 // ---- compute wave `cw`: hidden units [8 cw, 8 cw + 8) of the slice, every block of this group.
-// Lane = (unit g8 = lane >> 3 of the wave's 8, K-lane ks = lane & 7): it holds the r / z / n rows of W_hh for ITS unit
-// over k in [ks * H/8, (ks + 1) * H/8) (96 registers at H = 256), products accumulate as even / odd k pairs
-// (v_pk_fma_f32 straight on the LDS operand pairs), the K reduction is three DPP row shifts, and the lane the totals
-// end in (ks = 7) already holds all four sums of its unit: it evaluates the gates and stores h' itself (rows 1..3 of
-// a block are handed to lanes ks = 6, 5, 4 with one more DPP shift) - no LDS exchange, no barrier.
+// Lane = (unit g8 = lane >> 3 of the wave's 8, K-lane ks = lane & 7): it holds the r / z / n rows of the cell's matrix
+// for ITS unit over k in [ks * H/8, (ks + 1) * H/8) (96 registers at H = 256), products accumulate as even / odd k
+// pairs (v_pk_fma_f32 straight on the LDS operand pairs), the K reduction is three DPP row shifts, and the lane the
+// totals end in (ks = 7) already holds all three sums of its unit: it evaluates the gates and stores h' itself (rows
+// 1..3 of a block are handed to lanes ks = 6, 5, 4 with one more DPP shift) - no LDS exchange, no barrier.
 template <int KPT>
 __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int sl, int group, const DfLds& lds, int cw) {
     constexpr int H = 16 * KPT;
@@ -614,12 +708,13 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     const int tc = threadIdx.x;   // 0..255
     const int lane = tc & 63;
     const int g8 = lane >> 3, ks = lane & 7;
-    const bool has_in = C.wih != nullptr;
+    const bool proj = C.kind == DF_PROJECTION;
+    const bool has_gi = C.gi0 != nullptr || C.p_in != nullptr;
     const int d = C.dir;
     const int nblk = S.sched[S.gtab[d] + 2 * group + 1];
     v2f wr[KPT], wz[KPT], wn[KPT];   // KP8 / 2 k pairs per gate
     {
-        const float4* wp = C.whh + (int64_t)sl * (3 * NK4) * 256 + tc;
+        const float4* wp = C.w + (int64_t)sl * (3 * NK4) * 256 + tc;
 #pragma unroll
         for (int q = 0; q < NK4; ++q) {
             const float4 x0 = wp[(0 * NK4 + q) * 256], x1 = wp[(1 * NK4 + q) * 256], x2 = wp[(2 * NK4 + q) * 256];
@@ -627,19 +722,21 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
             wz[2 * q] = (v2f){x1.x, x1.y}; wz[2 * q + 1] = (v2f){x1.z, x1.w};
             wn[2 * q] = (v2f){x2.x, x2.y}; wn[2 * q + 1] = (v2f){x2.z, x2.w};
         }
+        // the weights have landed before the block loop starts: otherwise the first use inside the loop carries a
+        // vmcnt(0), which - every block - also waits for the acknowledgement of the previous block's state stores
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) asm volatile("" : "+v"(wr[k]), "+v"(wz[k]), "+v"(wn[k]));
     }
     const int unit_l = 8 * cw + g8, unit = sl * DF_JS + unit_l;
-    float b_r = C.bhh[unit], b_z = C.bhh[H + unit];
-    const float b_hn = C.bhh[2 * H + unit];
-    float b_in = 0.f;
-    if (has_in) { b_r += C.bih[unit]; b_z += C.bih[H + unit]; b_in = C.bih[2 * H + unit]; }
+    float b_r = C.bias[unit], b_z = C.bias[H + unit], b_n = C.bias[2 * H + unit];
+    asm volatile("" : "+v"(b_r), "+v"(b_z), "+v"(b_n));   // landed before the loop (see the weights above)
     const int gr = 7 - ks;   // row of the block this lane evaluates the gates of (K-lanes 7, 6, 5, 4 -> rows 0..3)
     const int apos = unit + (SEG - KP8) * (unit / KP8);   // LDS position of column `unit` of an operand row
     const unsigned epoch = S.epoch, spin_limit = S.spin_limit;
     int* const err = S.err;
     float* const h_out = C.h_out;
     gran_t* const g_out = C.g_out;
-    const int ld_h = S.ld_h, gld = S.gld;
+    const int ld_h = S.ld_h, gld = S.gld, pld = S.pld;
     unsigned long long* const dbg = S.dbg ? S.dbg + 2 * gridDim.x : nullptr;
     const bool prof = dbg != nullptr && (int)blockIdx.x == S.dbg_wg && cw == 0 && lane == 0;
 
@@ -651,40 +748,47 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
         const int4 ids = *reinterpret_cast<const int4*>(sbase + Slot::v_off);
         const int nr = (ids.x >= 0) + (ids.y >= 0) + (ids.z >= 0) + (ids.w >= 0);   // live records come first
         const float* a_seg = sbase + Slot::a_off + ks * SEG;
-        const float* u_seg = sbase + Slot::u_off + ks * SEG;
-        // two rows per pass (the accumulators and in-flight operands of four rows do not fit the register budget next
-        // to the resident weights); K reduction; row r's totals move from K-lane 7 to K-lane 7 - r, which evaluates
-        // that row's gates
-        float g4[4] = {0.f, 0.f, 0.f, 0.f};
+        // operands of the gate algebra: requested now, used after the products
+        float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, aval = 0.f;
+        if (!proj && gr < nr) {
+            if (has_gi) {   // from the gi0 ring (stacked layer 0) or from the slot (projection granules)
+                const float* gp = (C.gi0 ? lds.giring + (b % DF_GIRING) * (DF_RB * 3 * DF_JS) : sbase + Slot::gi_off) + gr * (3 * DF_JS) + unit_l;
+                gi_r = gp[0]; gi_z = gp[DF_JS]; gi_n = gp[2 * DF_JS];
+            }
+            aval = sbase[Slot::a_off + gr * Slot::AP + apos];
+        }
+        // two rows per pass (resident weights + accumulators + operands in flight fill the register budget); K
+        // reduction; row r's totals move from K-lane 7 to K-lane 7 - r, which finishes that row
+        float g3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int rb = 0; rb < DF_RB; rb += 2) {
             if (rb < nr) {
-                v2f acc[2][4];
+                v2f acc[2][3];
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) acc[r][a] = (v2f){0.f, 0.f};
+                    for (int a = 0; a < 3; ++a) acc[r][a] = (v2f){0.f, 0.f};
                 const bool two = nr - rb >= 2;
-                if (two) df_fma<KPT, 2>(acc, wr, wz, wn, a_seg + rb * Slot::AP, u_seg + rb * Slot::AP, lds.wih, has_in, tc);
-                else df_fma<KPT, 1>(acc, wr, wz, wn, a_seg + rb * Slot::AP, u_seg + rb * Slot::AP, lds.wih, has_in, tc);
+                if (two) df_mac<KPT, 2>(acc, wr, wz, wn, a_seg + rb * Slot::AP);
+                else df_mac<KPT, 1>(acc, wr, wz, wn, a_seg + rb * Slot::AP);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (j == 0 || two) {
-                        float t[4];
+                        float t[3];
 #pragma unroll
-                        for (int a = 0; a < 4; ++a) t[a] = df_dpp_sum8(acc[j][a].x + acc[j][a].y);
+                        for (int a = 0; a < 3; ++a) t[a] = df_dpp_sum8(acc[j][a].x + acc[j][a].y);
                         if (rb + j == 1) {
 #pragma unroll
-                            for (int a = 0; a < 4; ++a) t[a] = df_dpp_shl<1>(t[a]);
+                            for (int a = 0; a < 3; ++a) t[a] = df_dpp_shl<1>(t[a]);
                         } else if (rb + j == 2) {
 #pragma unroll
-                            for (int a = 0; a < 4; ++a) t[a] = df_dpp_shl<2>(t[a]);
+                            for (int a = 0; a < 3; ++a) t[a] = df_dpp_shl<2>(t[a]);
                         } else if (rb + j == 3) {
 #pragma unroll
-                            for (int a = 0; a < 4; ++a) t[a] = df_dpp_shl<3>(t[a]);
+                            for (int a = 0; a < 3; ++a) t[a] = df_dpp_shl<3>(t[a]);
                         }
 #pragma unroll
-                        for (int a = 0; a < 4; ++a) g4[a] = gr == rb + j ? t[a] : g4[a];
+                        for (int a = 0; a < 3; ++a) g3[a] = gr == rb + j ? t[a] : g3[a];
                     }
                 }
             }
@@ -695,22 +799,25 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
         int gv = 0;
         if (live) {
             gv = gr == 0 ? ids.x : (gr == 1 ? ids.y : (gr == 2 ? ids.z : ids.w));
-            float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f;
-            if (!has_in) {
-                const float* gp = sbase + Slot::gi_off + gr * (3 * DF_JS) + unit_l;
-                gi_r = gp[0]; gi_z = gp[DF_JS]; gi_n = gp[2 * DF_JS];
+            if (!proj) {
+                const float rg = df_sigm(g3[0] + b_r + gi_r);
+                const float zg = df_sigm(g3[1] + b_z + gi_z);
+                const float ng = df_tanh(fmaf(rg, g3[2] + b_n, gi_n));
+                hv = fmaf(zg, aval - ng, ng);   // n + z * (a - n)
             }
-            const float aval = sbase[Slot::a_off + gr * Slot::AP + apos];
-            const float rg = df_sigm(g4[0] + b_r + gi_r);
-            const float zg = df_sigm(g4[1] + b_z + gi_z);
-            const float ng = df_tanh(fmaf(rg, g4[2] + b_hn, g4[3] + b_in + gi_n));
-            hv = fmaf(zg, aval - ng, ng);   // n + z * (a - n)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) df_flag_st(lds.dn + cw, b + 1);   // this wave is done with the slot (LDS executes a wave's accesses in order)
         if (live) {
-            h_out[(int64_t)gv * ld_h + unit] = hv;
-            __hip_atomic_store(g_out + (int64_t)gv * gld + unit, gran_pack(epoch, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (proj) {   // input-side pre-activations of the upper cell: W_ih u + b_ih, gate-major
+                gran_t* po = g_out + (int64_t)gv * pld + unit;
+                __hip_atomic_store(po, gran_pack(epoch, g3[0] + b_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(po + H, gran_pack(epoch, g3[1] + b_z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(po + 2 * H, gran_pack(epoch, g3[2] + b_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                h_out[(int64_t)gv * ld_h + unit] = hv;
+                __hip_atomic_store(g_out + (int64_t)gv * gld + unit, gran_pack(epoch, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         if (prof) dbg[8 * (int64_t)b + 2] = wall_clock64();
     }
@@ -720,7 +827,6 @@ template <int KPT>
 __global__ void __launch_bounds__(DF_THREADS, 2) dataflow_kernel(const int32_t* __restrict__ plan, DfArgs S) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef DfSlot<KPT> Slot;
-    constexpr int NQ = 3 * KPT / 2;
     constexpr int NS = 16 * KPT / DF_JS;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -730,17 +836,16 @@ __global__ void __launch_bounds__(DF_THREADS, 2) dataflow_kernel(const int32_t* 
     const int c = rem / NS, sl = rem - c * NS;
     const DfCell& C = S.cell[c];
     DfLds lds;
-    lds.wih = reinterpret_cast<float4*>(smem);
-    lds.ring = smem + NQ * 256 * 4;
-    int* flags = reinterpret_cast<int*>(lds.ring + DF_NSLOT * Slot::words);
+    lds.ring = smem;
+    lds.giring = lds.ring + DF_NSLOT * Slot::words;
+    lds.rec = reinterpret_cast<int*>(lds.giring + DF_GIRING * DF_RB * 3 * DF_JS);
+    int* flags = lds.rec + DF_RB * 8 * 16;
     lds.rdy = flags;
     lds.dn = flags + 4;
-    if (C.wih) {
-        const float4* src = C.wih + (int64_t)sl * NQ * 256;
-        for (int i = tid; i < NQ * 256; i += DF_THREADS) lds.wih[i] = src[i];
-    }
     if (tid < 8) flags[tid] = 0;
     if (S.dbg && tid == 0) S.dbg[2 * blockIdx.x] = wall_clock64();
+    if (S.dbg && (int)blockIdx.x == S.dbg_wg && (tid & 63) == 0)   // where the waves of the stamped workgroup run (HW_REG_HW_ID)
+        S.dbg[2 * gridDim.x + 8 * (int64_t)wave + 7] = 0x100000000ull | __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
     __syncthreads();
     if (wave < DF_NCW) df_compute<KPT>(S, C, sl, group, lds, wave);
     else df_loader<KPT>(plan, S, C, sl, group, lds, wave - DF_NCW);
@@ -748,7 +853,7 @@ __global__ void __launch_bounds__(DF_THREADS, 2) dataflow_kernel(const int32_t* 
 }
 
 template <int KPT> size_t df_lds_bytes() {
-    return (size_t)(3 * KPT / 2) * 256 * 16 + (size_t)(DF_NSLOT * DfSlot<KPT>::words) * 4 + 32;
+    return (size_t)(DF_NSLOT * DfSlot<KPT>::words + DF_GIRING * DF_RB * 3 * DF_JS + DF_RB * 8 * 16) * 4 + 32;
 }
 
 // Pack W [3H, K = H] (torch GRUCell layout) for the dataflow kernel: out[(sl * NQ + q) * 256 + tc] (float4), NQ = 3 H/32,
@@ -802,10 +907,12 @@ extern "C" int dagnn_dataflow_layout(int64_t N, int64_t B, int groups, int64_t* 
     return DAGNN_OK;
 }
 
-extern "C" int dagnn_dataflow_groups(int num_cus, int num_cells, int H, int64_t B) {
-    if (num_cus <= 0 || num_cells <= 0 || num_cells > DAGNN_MAX_DIRS * DAGNN_MAX_STACKED || H <= 0 || (H % 64) || H > 256 || B <= 0)
+extern "C" int dagnn_dataflow_groups(int num_cus, int num_dirs, int num_stacked, int H, int64_t B) {
+    if (num_cus <= 0 || num_dirs < 1 || num_dirs > DAGNN_MAX_DIRS || num_stacked < 1 || H <= 0 || (H % 64) || H > 256 || B <= 0)
         return 0;
-    int64_t g = num_cus / (num_cells * (H / DF_JS));
+    const int kcells = num_dirs * (2 * num_stacked - 1);   // one projection cell per stacked layer above the first
+    if (kcells > DF_MAX_KCELLS) return 0;
+    int64_t g = num_cus / (kcells * (H / DF_JS));
     if (g > DF_MAX_GROUPS) g = DF_MAX_GROUPS;
     if (g > B) g = B;
     return (int)g;
@@ -868,7 +975,7 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
     if (!pl || !pl->data || !a || !a->schedule) return DAGNN_EINVAL;
     const int H = a->H, Ls = a->num_stacked, dir_mask = a->dir_mask & 3, G = a->groups;
     if (H <= 0 || (H % 64) || H > 256 || Ls <= 0 || Ls > DAGNN_MAX_STACKED || !dir_mask || a->ld_h < H || a->gld < H ||
-        G < 1 || G > DF_MAX_GROUPS || a->epoch == 0 || !a->err)
+        (Ls > 1 && a->pld < 3 * H) || G < 1 || G > DF_MAX_GROUPS || a->epoch == 0 || !a->err)
         return DAGNN_EINVAL;
     if (pl->B == 0 || pl->N == 0) return DAGNN_OK;
     DfArgs S;
@@ -878,20 +985,29 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
         for (int i = 0; i < Ls; ++i) {
             const dagnn_dataflow_cell& c = a->cell[d][i];
             if (!c.w_hh || !c.b_hh || (!c.w_key && !c.static_score) || !c.h_out || !c.granules) return DAGNN_EINVAL;
-            if (i == 0 ? !c.gi0 : (!c.w_ih || !c.b_ih)) return DAGNN_EINVAL;
+            if (i == 0 ? !c.gi0 : (!c.w_ih || !c.b_ih || !c.proj_granules)) return DAGNN_EINVAL;
+            if (nc + (i > 0 ? 2 : 1) > DF_MAX_KCELLS) return DAGNN_EINVAL;
+            if (i > 0) {   // projection cell: W_ih x (states of layer i - 1) + b_ih
+                DfCell& P = S.cell[nc++];
+                P.w = (const float4*)c.w_ih; P.bias = c.b_ih;
+                P.wkey = nullptr; P.sscore = nullptr; P.gain = nullptr; P.vid = nullptr; P.gi0 = nullptr; P.p_in = nullptr;
+                P.h_out = nullptr;
+                P.g_out = (gran_t*)c.proj_granules;
+                P.g_in = (const gran_t*)a->cell[d][i - 1].granules;
+                P.dir = d; P.kind = DF_PROJECTION;
+            }
             DfCell& K = S.cell[nc++];
-            K.whh = (const float4*)c.w_hh;
-            K.wih = i > 0 ? (const float4*)c.w_ih : nullptr;
-            K.bhh = c.b_hh; K.bih = i > 0 ? c.b_ih : nullptr;
+            K.w = (const float4*)c.w_hh; K.bias = c.b_hh;
             K.wkey = c.static_score ? nullptr : c.w_key;
             K.sscore = c.static_score;
             K.gain = pl->num_edge_feats > 0 ? c.edge_gain : nullptr;
             K.vid = a->vid_mod > 0 ? c.vid_bias : nullptr;
             K.gi0 = i == 0 ? c.gi0 : nullptr;
+            K.p_in = i > 0 ? (const gran_t*)c.proj_granules : nullptr;
             K.h_out = c.h_out;
             K.g_out = (gran_t*)c.granules;
-            K.g_in = i > 0 ? (const gran_t*)a->cell[d][i - 1].granules : nullptr;
-            K.dir = d; K.stacked = i;
+            K.g_in = nullptr;
+            K.dir = d; K.kind = DF_RECURRENT;
         }
     }
     const DfLayout SL = df_layout_words(pl->N, pl->B, G);
@@ -899,7 +1015,7 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
     PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
     for (int d = 0; d < 2; ++d) { S.gtab[d] = SL.gtab[d]; S.grec[d] = SL.grec[d]; S.col[d] = L.col[d]; S.eattr[d] = L.eattr[d]; }
     S.spin_limit = a->spin_limit ? a->spin_limit : (1u << 22);
-    S.ncell = nc; S.H = H; S.ld_h = a->ld_h; S.gld = a->gld; S.R = pl->num_edge_feats;
+    S.ncell = nc; S.H = H; S.ld_h = a->ld_h; S.gld = a->gld; S.pld = a->pld; S.R = pl->num_edge_feats;
     S.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
     S.groups = G; S.epoch = a->epoch; S.err = (int*)a->err;
     S.dbg = (unsigned long long*)a->debug_timing;

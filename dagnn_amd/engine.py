@@ -326,12 +326,12 @@ def pack_dataflow(w: torch.Tensor, H: int) -> torch.Tensor:
     return out
 
 
-def dataflow_groups(device, num_cells: int, H: int, B: int) -> int:
+def dataflow_groups(device, num_dirs: int, num_stacked: int, H: int, B: int) -> int:
     """Groups the dataflow kernel runs on this device for this model shape; 0 = not applicable."""
     if not DATAFLOW:
         return 0
     cus = torch.cuda.get_device_properties(device).multi_processor_count
-    g = _lib.load().dagnn_dataflow_groups(cus, int(num_cells), int(H), int(B))
+    g = _lib.load().dagnn_dataflow_groups(cus, int(num_dirs), int(num_stacked), int(H), int(B))
     return min(g, DF_GROUPS) if DF_GROUPS > 0 else g
 
 
@@ -344,7 +344,8 @@ def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     lib = _lib.load()
     args = DataflowArgs()
     gld = H + H // 16
-    gran, epoch, err = arena.get([(d, i) for d in dirs for i in range(L)], plan.N, gld, plan.ws.device)
+    keys = [(d, i) for d in dirs for i in range(L)] + [("p", d, i) for d in dirs for i in range(1, L)]
+    gran, epoch, err = arena.get(keys, plan.N, gld, plan.ws.device, widths={k: 3 * H for k in keys if k[0] == "p"})
     mask = 0
     for d in dirs:
         mask |= 1 << d
@@ -362,7 +363,9 @@ def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
             fc.gi0 = gi0[d].data_ptr() if i == 0 else None
             fc.h_out = h[d][i].data_ptr()
             fc.granules = gran[(d, i)].data_ptr()
+            fc.proj_granules = gran[("p", d, i)].data_ptr() if i > 0 else None
     args.num_stacked, args.dir_mask, args.H, args.ld_h, args.gld = L, mask, H, h[dirs[0]][0].shape[1], gld
+    args.pld = 3 * H
     args.vid_mod, args.groups, args.epoch = int(vid_mod), int(groups), epoch
     sched = plan.dataflow_schedule(groups)
     args.schedule, args.err = sched.data_ptr(), err.data_ptr()
@@ -397,11 +400,13 @@ class GranuleArena(object):
         self.err = None
         self.side = None   # second stream: the persistent kernel runs next to the per-layer launches (split mode)
 
-    def get(self, keys, N: int, gld: int, device):
+    def get(self, keys, N: int, gld: int, device, widths=None):
+        """`widths`: row pitch (granules) of the buffers that differ from `gld`."""
+        widths = widths or {}
         if N > self.cap or gld != self.gld or self.err is None or self.err.device != device or \
                 set(keys) != set(self.bufs) or self.epoch >= 0x7FFFFFF0:
             self.cap, self.gld, self.epoch = max(N, int(self.cap * 1.5)), gld, 0
-            self.bufs = {k: torch.zeros(self.cap * gld, dtype=torch.int64, device=device) for k in keys}
+            self.bufs = {k: torch.zeros(self.cap * widths.get(k, gld), dtype=torch.int64, device=device) for k in keys}
             self.err = torch.zeros(1, dtype=torch.int32, device=device)
         self.epoch += 1
         return self.bufs, self.epoch, self.err

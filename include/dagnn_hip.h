@@ -246,9 +246,12 @@ int dagnn_frontier_run(const dagnn_plan* plan /* host */, const dagnn_frontier_a
  * Dataflow schedule of the same recurrence (the default path for H <= 256): ONE persistent launch for the whole loop
  * nest of dagnn.py:144-182, cut along graphs instead of layers (dagnn_amd/csrc/dataflow.hip).
  *
- *   1. dagnn_dataflow_groups: how many independent groups G the device hosts (one workgroup per (cell, 32-unit slice)
- *      per group, one workgroup per CU): floor(num_cus / (num_cells * H/32)), capped at 64 and at B; 0 = this shape
- *      is not supported (H > 256, H % 64 != 0, or one group does not fit the device) - use dagnn_frontier_run.
+ *   1. dagnn_dataflow_groups: how many independent groups G the device hosts.  A group has one workgroup (one CU) per
+ *      (kernel cell, 32-unit slice); the kernel cells of a direction are its L GRU cells plus, for every stacked
+ *      layer above the first, one PROJECTION cell (the input-side product W_ih u + b_ih, which leaves the dependent
+ *      chain that way): G = floor(num_cus / (num_dirs * (2L - 1) * H/32)), capped at 64 and at B; 0 = this shape is
+ *      not supported (H > 256, H % 64 != 0, more than 16 kernel cells, or one group does not fit the device) - use
+ *      dagnn_frontier_run.
  *   2. dagnn_dataflow_schedule: deals the graphs of a plan to the G groups - longest-processing-time first on
  *      cost_layer * depth + cost_row * nodes, integer arithmetic, ties to the lowest group - and re-sorts the plan's
  *      64-byte row records by (group, topological layer, graph, node), every group-layer padded to whole blocks of 4
@@ -275,12 +278,14 @@ typedef struct dagnn_dataflow_cell {
     const float* gi0;       /* [N,3H] W_ih x + b_ih (stacked layer 0 only) */
     float* h_out;           /* [N,ld_h] */
     void* granules;         /* uint64 [N,gld] */
+    void* proj_granules;    /* stacked layers > 0: uint64 [N,pld] (pld >= 3H), the hand-off buffer of the cell's input-side
+                             * pre-activations W_ih u + b_ih (same zero-init / epoch contract as `granules`); else NULL */
 } dagnn_dataflow_cell;
 
 typedef struct dagnn_dataflow_args {
     dagnn_dataflow_cell cell[DAGNN_MAX_DIRS][DAGNN_MAX_STACKED];
     int num_stacked, dir_mask;
-    int H, ld_h, gld, vid_mod;
+    int H, ld_h, gld, pld, vid_mod;
     int groups;            /* G the schedule was built for */
     unsigned epoch;
     const void* schedule;  /* device workspace written by dagnn_dataflow_schedule */
@@ -291,7 +296,7 @@ typedef struct dagnn_dataflow_args {
     int debug_wg;          /* workgroup whose blocks are stamped (debug_timing) */
 } dagnn_dataflow_args;
 
-int dagnn_dataflow_groups(int num_cus, int num_cells, int H, int64_t B);
+int dagnn_dataflow_groups(int num_cus, int num_dirs, int num_stacked, int H, int64_t B);
 size_t dagnn_dataflow_bytes(int64_t N, int64_t B, int groups);
 int dagnn_dataflow_schedule(const dagnn_plan* plan /* host */, void* workspace, size_t workspace_bytes, int groups,
                             int cost_layer, int cost_row, void* stream);

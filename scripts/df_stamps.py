@@ -21,7 +21,7 @@ torch.cuda.synchronize()
 st = engine.DEBUG_TIMING.cpu().numpy()
 engine.DEBUG_TIMING = None
 cus = torch.cuda.get_device_properties(dev).multi_processor_count
-ncell, NS = 2 * L, H // 32
+ncell, NS = 2 * (2 * L - 1), H // 32
 G = min(cus // (ncell * NS), B)
 grid = G * ncell * NS
 wg = st[:2 * grid].reshape(grid, 2).astype(np.float64) / 100.0   # us
@@ -32,6 +32,8 @@ for k in range(G):
     ends = [sel[c * NS:(c + 1) * NS, 1].max() - t0 for c in range(ncell)]
     print("  group %d: cell ends (us) %s" % (k, " ".join("%.0f" % e for e in ends)))
 blk = st[2 * grid:]
+hw = [int(blk[8 * w + 7]) & 0xffffffff for w in range(8)]
+print("waves 0..7 (compute 0-3, loaders 4-7): simd %s cu %s" % ([(h >> 4) & 3 for h in hw], [(h >> 8) & 15 for h in hw]))
 nb = int((blk[:len(blk) // 8 * 8].reshape(-1, 8)[:, 0] != 0).sum())
 polls = blk[:8 * nb].reshape(nb, 8)[:, 6].copy()
 blk = blk[:8 * nb].reshape(nb, 8).astype(np.float64) / 100.0

@@ -41,8 +41,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int DF_JS = 32;      // hidden units per slice
 constexpr int DF_RB = 4;       // rows per block = loader waves
 constexpr int DF_NCW = 4;      // compute waves
-constexpr int DF_NSLOT = 3;    // LDS ring depth (blocks the loaders may run ahead)
-constexpr int DF_THREADS = 64 * (DF_NCW + DF_RB);
+constexpr int DF_NLS = 2;      // loader sets: set s takes the blocks b = s (mod NLS) - a block costs a loader wave one trip to
+                               // memory plus ~1 us of scalar work, twice what the compute waves need for it
+constexpr int DF_NSLOT = 4;    // LDS ring depth (blocks the loaders may run ahead)
+constexpr bool DF_TWO_CHUNKS = false;   // rows with > 4 in-edges: two chunks per trip to memory.  Measured: the second sweep's
+                               // 32 registers spill the loader at 3 waves per SIMD; such rows cost ~75 us per group
+constexpr int DF_THREADS = 64 * (DF_NCW + DF_NLS * DF_RB);
 constexpr int DF_MAX_GROUPS = 64;
 constexpr int DF_MAGIC = 0x44463031;   // "DF01"
 
@@ -292,15 +296,15 @@ __device__ __forceinline__ float df_tanh(float x) { return 1.0f - 2.0f * __built
 // starts at s * (KP8 + 4): the 8 segments a half DPP row reads concurrently (ds_read_b128) fall on disjoint banks
 template <int KPT> struct DfPad { static constexpr int kp8 = 2 * KPT; static constexpr int seg = kp8 + 4; static constexpr int row = 8 * seg; };
 
-constexpr int DF_RD = 7;       // a row record is requested this many blocks ahead (record ring: 8 entries)
-constexpr int DF_GD = 4;       // a gi0 slice this many (its node id must have landed: DF_RD >= DF_GD + 2)
-constexpr int DF_GIRING = DF_NSLOT + DF_GD + 1;   // blocks in the gi0 ring: ring slots in use + the prefetch distance + 1
+constexpr int DF_RD = 6;       // a loader wave requests a row record this many of ITS blocks ahead (record ring: 8 entries)
+constexpr int DF_GD = 2;       // a gi0 slice this many (its node id must have landed: DF_RD >= DF_GD + 2)
+constexpr int DF_GIRING = DF_NSLOT + DF_NLS * DF_GD + 2;   // blocks in the gi0 ring: slots in use + prefetch distance + slack
 
 struct DfLds {
     float* ring;     // NSLOT x slot
     float* giring;   // [DF_GIRING][RB][96]: gi0 slices of the slice's rows, landed by LDS-DMA two blocks ahead
-    int* rec;        // [RB][8][16]: row records of the loader waves, landed by LDS-DMA four blocks ahead
-    int* rdy;        // [RB]   per loader wave: blocks it has finished (relaxed workgroup-scope atomics: plain ds_ accesses;
+    int* rec;        // [NLS * RB][8][16]: row records of the loader waves, landed by LDS-DMA DF_RD of their blocks ahead
+    int* rdy;        // [NLS * RB]   per loader wave: blocks it has finished (relaxed workgroup-scope atomics: plain ds_ accesses;
     int* dn;         // [NCW]  per compute wave likewise        a volatile access here compiles to a FLAT load + vmcnt(0))
 };
 
@@ -338,7 +342,7 @@ __device__ __forceinline__ bool df_retry(unsigned& spins, int* err, unsigned lim
 // ---- loader wave: row `lw` of every block of this group
 template <int KPT>
 __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, const DfArgs& S,
-                                          const DfCell& C, int sl, int group, const DfLds& lds, int lw) {
+                                          const DfCell& C, int sl, int group, const DfLds& lds, int lw, int set) {
     constexpr int H = 16 * KPT;
     constexpr int SEG = DfPad<KPT>::seg, KP8 = DfPad<KPT>::kp8;
     typedef DfSlot<KPT> Slot;
@@ -378,7 +382,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
         cpos[q] = c + (SEG - KP8) * (c / KP8);
         if (C.wkey && !proj && q < NQ4) wk[q] = C.wkey[c];
     }
-    const bool prof = dbg != nullptr && (int)blockIdx.x == S.dbg_wg && lw == 0 && lane == 0;
+    const bool prof = dbg != nullptr && (int)blockIdx.x == S.dbg_wg && lw == 0 && set == 0 && lane == 0;
 
     // ---- memory traffic of this wave, by hand.  Three streams share the wave's in-order vmcnt counter: the granule
     // sweeps (on the dependent chain), the static row records and the gi0 slices (cold lines: HBM latency).  Left to
@@ -409,9 +413,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const gran_t* gp = g_src + (int64_t)pj[e] * gld;   // wave-uniform
-            const bool on = (pend >> e) & 1u;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) W.x[e][q] = ready;   // (read-write operands: no merge of a loaded and a constant value)
+            const bool on = (pend >> e) & 1u;   // rows that have arrived keep their registers
             if (on) {
                 DF_LD_GRAN(W.x[e][0], lane8, gp, 0);
                 if (NQ4 > 1) DF_LD_GRAN(W.x[e][1], lane8, gp, 512);
@@ -419,8 +421,6 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                 if (NQ4 > 3) DF_LD_GRAN(W.x[e][3], lane8, gp, 1536);
             }
         }
-#pragma unroll
-        for (int g = 0; g < 3; ++g) W.xp[g] = ready;
         if (pp) {   // all lanes (lanes 32.. repeat lanes 0..31): one instruction per gate
             DF_LD_GRAN(W.xp[0], lane31x8, gp_in, 0);
             DF_LD_GRAN(W.xp[1], lane31x8, gp_in + H, 0);
@@ -443,42 +443,47 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         DF_TOUCH(W);
     };
+    auto landed_rows = [&](Sweep& W) {   // a sweep without the projection slice (second chunk of a trip)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(W.x[0][0]), "+v"(W.x[0][1]), "+v"(W.x[0][2]), "+v"(W.x[0][3]), "+v"(W.x[1][0]),
+                     "+v"(W.x[1][1]), "+v"(W.x[1][2]), "+v"(W.x[1][3]), "+v"(W.x[2][0]), "+v"(W.x[2][1]), "+v"(W.x[2][2]),
+                     "+v"(W.x[2][3]), "+v"(W.x[3][0]), "+v"(W.x[3][1]), "+v"(W.x[3][2]), "+v"(W.x[3][3]) :: "memory");
+    };
 
     // LDS rings of this wave: records (8 entries x 64 B) and, shared with the compute waves, the gi0 slices
     // (DF_GIRING blocks x RB rows x 384 B: compute reads entry b % DF_GIRING)
-    int* const rec_ring = lds.rec + lw * (8 * 16);
+    int* const rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
     const unsigned rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
     const unsigned gi_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds.giring + lw * (3 * DF_JS)));
     const int32_t* rec_w = reinterpret_cast<const int32_t*>(recs) + (lane & 15);
     const int64_t wstride = 16 * DF_RB;   // words per block
     const int gi_lane_off = ((lane % 24) >> 3) * H + sl * DF_JS + 4 * (lane & 7);
-    auto rec_dma = [&](int blk) {   // record of block `blk` (past the end: the last one again) -> ring entry blk & 7
-        if (lane < 16) glds4(rec_w + (int64_t)min(blk, nblk - 1) * wstride, rec_ring_a + (blk & 7) * 64);
+    auto rec_dma = [&](int j) {   // record of this wave's j-th block (past the end: the last block's again) -> ring entry j & 7
+        if (lane < 16) glds4(rec_w + (int64_t)min(DF_NLS * j + set, nblk - 1) * wstride, rec_ring_a + (j & 7) * 64);
     };
     auto gi_dma = [&](int blk, int node) {   // gi0 slice of `node` -> gi ring entry blk % DF_GIRING, row lw
         if (lane < 24) glds16(gi0 + (int64_t)max(node, 0) * 3 * H + gi_lane_off, gi_ring_a + (blk % DF_GIRING) * (DF_RB * 3 * DF_JS * 4));
     };
-    if (nblk > 0) {   // prologue: records 0..RD-1, gi0 slices of blocks 0..GD-1
+    if (nblk > set) {   // prologue: records of this wave's blocks 0..RD-1, gi0 slices of its blocks 0..GD-1
 #pragma unroll
         for (int j = 0; j < DF_RD; ++j) rec_dma(j);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (has_gi0) {
 #pragma unroll
-            for (int j = 0; j < DF_GD; ++j) gi_dma(j, __builtin_amdgcn_readfirstlane(rec_ring[j * 16]));
+            for (int j = 0; j < DF_GD; ++j) gi_dma(DF_NLS * j + set, __builtin_amdgcn_readfirstlane(rec_ring[j * 16]));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
 
-    Sweep A;
-    for (int b = 0; b < nblk; ++b) {
-        const int cur = rec_ring[(b & 7) * 16 + (lane & 15)];
+    Sweep A, A2;
+    for (int b = set, j = 0; b < nblk; b += DF_NLS, ++j) {
+        const int cur = rec_ring[(j & 7) * 16 + (lane & 15)];
 #define DF_W(i) __builtin_amdgcn_readlane(cur, i)
         const int4 r0 = make_int4(DF_W(0), DF_W(1), DF_W(2), DF_W(3));
         const int4 r1 = make_int4(DF_W(4), DF_W(5), DF_W(6), DF_W(7));
         const int4 r2 = make_int4(DF_W(8), DF_W(9), DF_W(10), DF_W(11));
         const int4 r3 = make_int4(DF_W(12), DF_W(13), DF_W(14), DF_W(15));
 #undef DF_W
-        const int v2 = __builtin_amdgcn_readfirstlane(rec_ring[((b + DF_GD) & 7) * 16]);   // node of block b + GD (landed with P(b + GD - RD))
+        const int v2 = __builtin_amdgcn_readfirstlane(rec_ring[((j + DF_GD) & 7) * 16]);   // node of this wave's block j + GD (landed long ago)
         const int slot = b % DF_NSLOT;
         float* sbase = lds.ring + slot * Slot::words;
         int* v_s = reinterpret_cast<int*>(sbase + Slot::v_off);
@@ -486,9 +491,16 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
         if (prof) dbg[8 * (int64_t)b + 4] = wall_clock64();
         unsigned polls = 0;
         auto prefetch = [&]() {   // P(b): exactly 1 (+1 with gi0) loads, whatever the block looks like
-            rec_dma(b + DF_RD);
-            if (has_gi0) gi_dma(b + DF_GD, v2);
+            rec_dma(j + DF_RD);
+            if (has_gi0) gi_dma(b + DF_NLS * DF_GD, v2);
         };
+#if DF_EXPERIMENT == 9
+        if (v >= -1) {
+            prefetch();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (b >= DF_NSLOT) df_wait4(lds.dn, b - DF_NSLOT + 1, err, spin_limit);
+        } else
+#endif
         if (v >= 0) {
             const int eb = r0.y;
             const int deg = proj ? 1 : r0.z - r0.y;   // a projection reads ONE row: the node's own state one layer down
@@ -498,11 +510,13 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
             bool p_pending = p_in != nullptr;
             float pv[3] = {0.f, 0.f, 0.f};
             const gran_t* gp_in = p_pending ? p_in + (int64_t)v * pld + sl * DF_JS : nullptr;   // wave-uniform
-            int c0 = 0;
-            do {   // chunks of <= 4 in-edges (one pass for deg <= 4, where ids and features came with the record)
-                const int nn = min(4, deg - c0);
-                int pj[4] = {0, 0, 0, 0};
-                float fe[4] = {0.f, 0.f, 0.f, 0.f};   // gain . edge features of the chunk's edges
+            // in-edges in chunks of <= 4 (ids and features of the first chunk came with the record).  A node with more
+            // than 4 in-edges takes two chunks per trip to memory (all of them finished long ago: the trips, not the
+            // data, are what such a row waits for)
+            auto chunk_ids = [&](int c0, int (&pj)[4], float (&fe)[4]) -> int {
+                const int nn = max(0, min(4, deg - c0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pj[e] = 0; fe[e] = 0.f; }
                 if (proj) {
                     pj[0] = v;
                 } else if (c0 == 0) {
@@ -524,37 +538,98 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                         if (e < nn) for (int r = 0; r < R; ++r) fe[e] = fmaf(gainp[r], eattr[(int64_t)(eb + c0 + e) * R + r], fe[e]);
                     }
                 }
-                // ---- poll; rows that have arrived are not asked for again
-                float row[4][4];
+                return nn;
+            };
+            // rows of a sweep that carry this pass's tag are cleared from `pend` (their values stay in the sweep's registers)
+            auto harvest = [&](Sweep& W, unsigned& pend) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if ((pend >> e) & 1u) {
+                        bool ok = true;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(W.x[e][q] >> 32) == epoch;
+                        if (__all(ok)) pend &= ~(1u << e);
+                    }
+                }
+            };
+            auto clear = [&](Sweep& W) {   // every slot reads as an arrived all-zero row
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) row[e][q] = 0.f;
-                unsigned pend = (1u << nn) - 1u;   // wave-uniform: rows still missing
+                    for (int q = 0; q < 4; ++q) W.x[e][q] = ready;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) W.xp[g] = ready;
+            };
+            // online softmax over one chunk (rows beyond nn are zeros with score -inf)
+            auto fold = [&](const int (&pj)[4], const float (&fe)[4], int nn, const Sweep& W) {
+#define DF_ROW(e, q) __uint_as_float((unsigned)W.x[e][q])
+                float s[4];   // all four scores at once: four independent reductions interleave
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] = DF_ROW(e, 0) * wk[0] + DF_ROW(e, 1) * wk[1] + DF_ROW(e, 2) * wk[2] + DF_ROW(e, 3) * wk[3];
+                if (!sscore) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[e] = df_wave_sum(s[e]);
+                }
+                float mc = m;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (e < nn) {
+                        float sv = sscore ? sscore[pj[e]] : s[e];
+                        if (vid) sv += vid[pj[e] % vid_mod];
+                        sv += fe[e];
+                        s[e] = sv;
+                        mc = fmaxf(mc, sv);
+                    } else {
+                        s[e] = -INFINITY;
+                    }
+                }
+                const float sc = __expf(m - mc);   // 0 on the first chunk (m = -inf)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] *= sc;
+                l *= sc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p = __expf(s[e] - mc);   // 0 for the slots beyond the chunk (s = -inf)
+                    l += p;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = fmaf(p, DF_ROW(e, q), acc[q]);
+                }
+                m = mc;
+#undef DF_ROW
+            };
+            int c0 = 0;
+            do {
+                int pj[4], pj2[4];
+                float fe[4], fe2[4];
+                const int nn = chunk_ids(c0, pj, fe);
+                const bool two = DF_TWO_CHUNKS && deg > 4;   // wave-uniform: this row takes two chunks per trip
+                const int nn2 = two ? chunk_ids(c0 + 4, pj2, fe2) : 0;
+                clear(A);
+                if (two) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) A2.x[e][q] = ready;
+                }
+                unsigned pend = (1u << nn) - 1u, pend2 = (1u << nn2) - 1u;   // wave-uniform: rows still missing
                 unsigned spins = 0;
 #if DF_EXPERIMENT == 8
                 if (prof && c0 == 0) dbg[8 * (int64_t)b + 4] = wall_clock64();
 #endif
                 issue(A, pj, pend, p_pending, gp_in);
-                if (c0 == 0) { prefetch(); landed(A); }
-                else landed_all(A);
+                if (two) issue(A2, pj2, pend2, false, nullptr);
+                if (c0 == 0 && !two) { prefetch(); landed(A); }
+                else {
+                    if (c0 == 0) prefetch();
+                    landed_all(A);
+                    if (two) landed_rows(A2);
+                }
 #if DF_EXPERIMENT == 8
                 if (prof && c0 == 0) dbg[8 * (int64_t)b + 5] = wall_clock64();
 #endif
                 for (;;) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if ((pend >> e) & 1u) {
-                            bool ok = true;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(A.x[e][q] >> 32) == epoch;
-                            if (__all(ok)) {
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) row[e][q] = __uint_as_float((unsigned)A.x[e][q]);
-                                pend &= ~(1u << e);
-                            }
-                        }
-                    }
+                    harvest(A, pend);
+                    if (two) harvest(A2, pend2);
                     if (p_pending) {
                         bool okp = true;
 #pragma unroll
@@ -566,9 +641,11 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                         }
                     }
                     ++polls;
-                    if ((pend == 0 && !p_pending) || !df_retry(spins, err, spin_limit)) break;
+                    if ((pend == 0 && pend2 == 0 && !p_pending) || !df_retry(spins, err, spin_limit)) break;
                     issue(A, pj, pend, p_pending, gp_in);
+                    if (two) issue(A2, pj2, pend2, false, nullptr);
                     landed_all(A);
+                    if (two) landed_rows(A2);
                 }
 #if DF_EXPERIMENT != 8
                 if (prof && c0 == 0) { dbg[8 * (int64_t)b + 5] = wall_clock64(); dbg[8 * (int64_t)b + 6] = polls; }
@@ -577,44 +654,13 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
 #endif
                 if (deg == 1) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] = row[0][q];
+                    for (int q = 0; q < 4; ++q) acc[q] = __uint_as_float((unsigned)A.x[0][q]);
                     l = 1.f;
                 } else if (nn > 0) {
-                    // all four scores at once (rows not in the chunk are zeros): four independent reductions interleave
-                    float s[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) s[e] = row[e][0] * wk[0] + row[e][1] * wk[1] + row[e][2] * wk[2] + row[e][3] * wk[3];
-                    if (!sscore) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) s[e] = df_wave_sum(s[e]);
-                    }
-                    float mc = m;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (e < nn) {
-                            float sv = sscore ? sscore[pj[e]] : s[e];
-                            if (vid) sv += vid[pj[e] % vid_mod];
-                            sv += fe[e];
-                            s[e] = sv;
-                            mc = fmaxf(mc, sv);
-                        } else {
-                            s[e] = -INFINITY;
-                        }
-                    }
-                    const float sc = __expf(m - mc);   // 0 on the first chunk (m = -inf)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] *= sc;
-                    l *= sc;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float p = __expf(s[e] - mc);   // 0 for the slots beyond the chunk (s = -inf)
-                        l += p;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[q] = fmaf(p, row[e][q], acc[q]);
-                    }
-                    m = mc;
+                    fold(pj, fe, nn, A);
+                    if (nn2 > 0) fold(pj2, fe2, nn2, A2);
                 }
-                c0 += 4;
+                c0 += two ? 8 : 4;
             } while (c0 < deg);
             if (deg > 1) {   // PyG softmax: exp(x - max) / (sum + 1e-16)
                 const float inv = __builtin_amdgcn_rcpf(l + 1e-16f);
@@ -637,7 +683,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
         }
         if (lane == 0) v_s[lw] = v;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) df_flag_st(lds.rdy + lw, b + 1);
+        if (lane == 0) df_flag_st(lds.rdy + set * DF_RB + lw, b + 1);
         if (prof) dbg[8 * (int64_t)b + 3] = wall_clock64();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of ours is in flight when the wave ends
@@ -653,7 +699,7 @@ __device__ __forceinline__ void df_mac(v2f (&acc)[2][3], const v2f (&wr)[KPT], c
                                        const v2f (&wn)[KPT], const float* a_seg) {
     constexpr int AP = DfPad<KPT>::row;
     constexpr int NK4 = DfPad<KPT>::kp8 / 4;   // float4 steps over the lane's K range
-    constexpr int PF = NK4 < 4 ? NK4 : 4;
+    constexpr int PF = NK4 < 2 ? NK4 : 2;
     float4 av[NK4][NR];
 #pragma unroll
     for (int q = 0; q < PF; ++q)
@@ -710,6 +756,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     const int g8 = lane >> 3, ks = lane & 7;
     const bool proj = C.kind == DF_PROJECTION;
     const bool has_gi = C.gi0 != nullptr || C.p_in != nullptr;
+    const bool gi_ring = C.gi0 != nullptr;   // (read once: a field access in the loop is a scalar load + lgkmcnt(0) per block)
     const int d = C.dir;
     const int nblk = S.sched[S.gtab[d] + 2 * group + 1];
     v2f wr[KPT], wz[KPT], wn[KPT];   // KP8 / 2 k pairs per gate
@@ -743,7 +790,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     for (int b = 0; b < nblk; ++b) {
         const int slot = b % DF_NSLOT;
         const float* sbase = lds.ring + slot * Slot::words;
-        df_wait4(lds.rdy, b + 1, err, spin_limit);
+        df_wait4(lds.rdy + (b % DF_NLS) * DF_RB, b + 1, err, spin_limit);   // the loader set that owns block b
         if (prof) dbg[8 * (int64_t)b + 0] = wall_clock64();
         const int4 ids = *reinterpret_cast<const int4*>(sbase + Slot::v_off);
         const int nr = (ids.x >= 0) + (ids.y >= 0) + (ids.z >= 0) + (ids.w >= 0);   // live records come first
@@ -752,7 +799,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
         float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, aval = 0.f;
         if (!proj && gr < nr) {
             if (has_gi) {   // from the gi0 ring (stacked layer 0) or from the slot (projection granules)
-                const float* gp = (C.gi0 ? lds.giring + (b % DF_GIRING) * (DF_RB * 3 * DF_JS) : sbase + Slot::gi_off) + gr * (3 * DF_JS) + unit_l;
+                const float* gp = (gi_ring ? lds.giring + (b % DF_GIRING) * (DF_RB * 3 * DF_JS) : sbase + Slot::gi_off) + gr * (3 * DF_JS) + unit_l;
                 gi_r = gp[0]; gi_z = gp[DF_JS]; gi_n = gp[2 * DF_JS];
             }
             aval = sbase[Slot::a_off + gr * Slot::AP + apos];
@@ -824,7 +871,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
 }
 
 template <int KPT>
-__global__ void __launch_bounds__(DF_THREADS, 2) dataflow_kernel(const int32_t* __restrict__ plan, DfArgs S) {
+__global__ void __launch_bounds__(DF_THREADS, 3) dataflow_kernel(const int32_t* __restrict__ plan, DfArgs S) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef DfSlot<KPT> Slot;
     constexpr int NS = 16 * KPT / DF_JS;
@@ -839,21 +886,21 @@ __global__ void __launch_bounds__(DF_THREADS, 2) dataflow_kernel(const int32_t* 
     lds.ring = smem;
     lds.giring = lds.ring + DF_NSLOT * Slot::words;
     lds.rec = reinterpret_cast<int*>(lds.giring + DF_GIRING * DF_RB * 3 * DF_JS);
-    int* flags = lds.rec + DF_RB * 8 * 16;
+    int* flags = lds.rec + DF_NLS * DF_RB * 8 * 16;
     lds.rdy = flags;
-    lds.dn = flags + 4;
-    if (tid < 8) flags[tid] = 0;
+    lds.dn = flags + DF_NLS * DF_RB;
+    if (tid < DF_NLS * DF_RB + DF_NCW) flags[tid] = 0;
     if (S.dbg && tid == 0) S.dbg[2 * blockIdx.x] = wall_clock64();
     if (S.dbg && (int)blockIdx.x == S.dbg_wg && (tid & 63) == 0)   // where the waves of the stamped workgroup run (HW_REG_HW_ID)
-        S.dbg[2 * gridDim.x + 8 * (int64_t)wave + 7] = 0x100000000ull | __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+        if (wave < 8) S.dbg[2 * gridDim.x + 8 * (int64_t)wave + 7] = 0x100000000ull | __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
     __syncthreads();
     if (wave < DF_NCW) df_compute<KPT>(S, C, sl, group, lds, wave);
-    else df_loader<KPT>(plan, S, C, sl, group, lds, wave - DF_NCW);
+    else df_loader<KPT>(plan, S, C, sl, group, lds, (wave - DF_NCW) % DF_RB, (wave - DF_NCW) / DF_RB);
     if (S.dbg && tid == 0) S.dbg[2 * blockIdx.x + 1] = wall_clock64();   // compute wave 0 is done
 }
 
 template <int KPT> size_t df_lds_bytes() {
-    return (size_t)(DF_NSLOT * DfSlot<KPT>::words + DF_GIRING * DF_RB * 3 * DF_JS + DF_RB * 8 * 16) * 4 + 32;
+    return (size_t)(DF_NSLOT * DfSlot<KPT>::words + DF_GIRING * DF_RB * 3 * DF_JS + DF_NLS * DF_RB * 8 * 16) * 4 + 64;
 }
 
 // Pack W [3H, K = H] (torch GRUCell layout) for the dataflow kernel: out[(sl * NQ + q) * 256 + tc] (float4), NQ = 3 H/32,

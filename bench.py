@@ -14,8 +14,8 @@ values measure the system, not the depth spread of the synthetic shards (seeds 0
 topological layers; `--rank-seeds` draws batch `rank` on rank `rank` instead and the slowest shard
 then sets the time).  No data-path collective (graphs are independent).
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the per-layer recurrence):
-duration from HIP events on the launching stream inside the timed region.  `cpu_baseline` is the
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the recurrence: one persistent dataflow
+launch per forward): duration from HIP events on the launching stream inside the timed region.  `cpu_baseline` is the
 oracle's op-for-op restatement of the reference (per-node edge scan, full [N,H] scatter) timed on
 this host - a reported baseline, never the thing measured.
 """
@@ -62,28 +62,47 @@ def fresh_inputs(master, n):
     return out
 
 
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(model_cpu_sd, batch, L, S, passes, threads):
-    """Oracle `faithful` mode = the reference's algorithm restated op for op, on this host's cores."""
+    """The oracle on this host's cores: `faithful` = the reference's algorithm restated op
+    for op (per-node edge scan, full [N,H] scatter: its cost profile), `vectorised` = the same arithmetic over a CSR."""
     import copy
     from oracle import dagnn_oracle as O
     if threads > 0:
         torch.set_num_threads(threads)
-    t0 = time.perf_counter()
-    O.code2_forward(model_cpu_sd, copy.deepcopy(batch), num_layers=L, max_seq_len=S, mode="faithful")  # warm-up
-    warm = time.perf_counter() - t0
-    times = []
-    for _ in range(passes):
-        g = copy.deepcopy(batch)
+
+    def leg(mode, n):
         t0 = time.perf_counter()
-        O.code2_forward(model_cpu_sd, g, num_layers=L, max_seq_len=S, mode="faithful")
-        times.append(time.perf_counter() - t0)
-    med = sorted(times)[len(times) // 2]
+        O.code2_forward(model_cpu_sd, copy.deepcopy(batch), num_layers=L, max_seq_len=S, mode=mode)  # warm-up
+        warm = time.perf_counter() - t0
+        times = []
+        for _ in range(n):
+            g = copy.deepcopy(batch)
+            t0 = time.perf_counter()
+            O.code2_forward(model_cpu_sd, g, num_layers=L, max_seq_len=S, mode=mode)
+            times.append(time.perf_counter() - t0)
+        return sorted(times)[len(times) // 2], warm
+
+    med, warm = leg("faithful", passes)
+    vmed, _ = leg("csr", max(passes, 4))
     return {"value": round(batch.num_graphs / med, 2), "unit": "graphs/s", "cores": torch.get_num_threads(),
-            "kind": "port",
+            "kind": "port", "cpu": _cpu_model(),
             "sample": "%d full forward passes (median) over the same %d-graph seed-0 batch, oracle faithful mode "
                       "(per-node edge scan + full [N,H] scatter as ogbg-code/model/dagnn.py:144-182), torch %s CPU, "
                       "%.2f s/batch, first pass %.1f s" % (passes, batch.num_graphs, torch.__version__, med, warm),
-            "ms_per_batch": round(med * 1e3, 1)}
+            "ms_per_batch": round(med * 1e3, 1),
+            "vectorised": {"value": round(batch.num_graphs / vmed, 2), "unit": "graphs/s", "ms_per_batch": round(vmed * 1e3, 1),
+                           "what": "the oracle's CSR form of the same arithmetic (one gather / segment softmax per "
+                                   "micro-step instead of the per-node edge scan), same threads"}}
 
 
 def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
@@ -117,13 +136,17 @@ def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
     engine.TIMER = timer
     barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(warmup, warmup + steps):
         loss = step(inputs[i])
+        marks[i - warmup + 1].record()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     engine.TIMER = None
+    per_step = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -134,8 +157,58 @@ def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
                     % (S, " + one RCCL all-reduce of the %.1f M-float gradient bucket" % (flat.numel() / 1e6)
                        if world > 1 else ""),
             "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "ms_per_step_median": round(per_step[len(per_step) // 2], 4),
+            "ms_per_step_p90": round(per_step[min(len(per_step) - 1, int(0.9 * len(per_step)))], 4),
             "graphs_per_s": round(world * B * steps / elapsed, 1), "final_loss": round(float(loss.detach()), 4),
             "kernels_ms_per_step": {k: round(n * ms / steps, 4) for k, (n, ms) in summ.items()}}
+
+
+def other_configs(device):
+    """BASELINE.json's other configurations, briefly (same code, forward only, inputs resident; medians of HIP-event
+    times): cfg 1 (NA: 64 ENAS-shaped DAGs, h=128, L=2, unidirectional), cfg 4 (BN: 128 ten-node DAGs, h=256, L=2,
+    bidirectional), cfg 5 (code2-like, B=256, h=512, L=5, bidirectional)."""
+    from dagnn_amd import DAGNN_NA, DAGNN_BN, synth
+
+    def timed(fn, n, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(n):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            ts.append((a, b))
+        torch.cuda.synchronize()
+        ms = sorted(x.elapsed_time(y) for x, y in ts)
+        return ms[len(ms) // 2]
+
+    out = {}
+    with torch.no_grad():
+        torch.manual_seed(0)
+        na = DAGNN_NA(8, 128, 128, 8, 8, 0, 1, hs=128, nz=56, num_nodes=8, num_layers=2, bidirectional=False).eval().to(device)
+        b = synth.dvae_batch([synth.decode_enas_row(r) for r in synth.enas_rows(0, 64)]).to(device)
+        ms = timed(lambda: na(b.clone()), 30, 5)
+        out["cfg1_NA_B64_h128_L2_unidir"] = {"ms_per_batch": round(ms, 4), "graphs_per_s": round(64 / ms * 1e3, 1)}
+        bn = DAGNN_BN(10, 256, 256, 10, 10, 0, 1, hs=256, nz=56, num_nodes=10, num_layers=2, bidirectional=True).eval().to(device)
+        b = synth.dvae_batch([synth.decode_bn_row(r) for r in synth.bn_rows(0, 128)]).to(device)
+        ms = timed(lambda: bn(b.clone()), 30, 5)
+        out["cfg4_BN_B128_h256_L2_bidir"] = {"ms_per_batch": round(ms, 4), "graphs_per_s": round(128 / ms * 1e3, 1)}
+        m5 = build_model(512, 5, 5002, 5, device)
+        b5 = synth.code2_batch(seed=0, num_graphs=256)
+        N5, E5 = b5.x.shape[0], b5.edge_index.shape[1]
+        b5 = b5.to(device)
+        ins = fresh_inputs(b5, 9)
+        it = iter(ins)
+        ms = timed(lambda: m5(next(it)), 6, 3)
+        gf = 2 * (2 * N5 * (512 + 512) * 3 * 512 + 4 * 12.0 * N5 * 512 * 512) / 1e9
+        out["cfg5_code2_B256_h512_L5_bidir"] = {"ms_per_batch": round(ms, 4), "graphs_per_s": round(256 / ms * 1e3, 1),
+                                                "gru_gflop_per_batch": round(gf, 1),
+                                                "frac_of_fp32_peak": round(gf / ms / FP32_MATRIX_PEAK_TFLOPS, 4),
+                                                "path": "lock-step launches (the dataflow kernel covers h <= 256)"}
+        del m5
+    return out
 
 
 def main():
@@ -151,6 +224,9 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--rank-seeds", action="store_true",
                     help="rank r draws batch r (different depths per rank) instead of the headline batch everywhere")
+    ap.add_argument("--other-configs", type=int, default=1,
+                    help="1: also time BASELINE.json's other configurations briefly (cfg 1 NA, cfg 4 BN, cfg 5 wide/deep) "
+                         "and report them under `other_configs` (never as `value`); 0 disables")
     ap.add_argument("--train-steps", type=int, default=10,
                     help="also time this many full training steps (fwd + bwd + optimizer) after the headline "
                          "forward measurement and report them as `training_step`; 0 disables the leg")
@@ -222,14 +298,22 @@ def main():
         engine.TIMER = timer
         barrier()
         torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if streams is None else None
         t0 = time.perf_counter()
+        if marks:
+            marks[0].record()
         for i in range(args.warmup, args.warmup + args.steps):
             out = step(i)
+            if marks:
+                marks[i - args.warmup + 1].record()
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
         engine.TIMER = None
     assert all(torch.isfinite(o).all() for o in out)
+    for a in model._arenas.values():
+        a.poll(block=True)   # a device-side failure (expired wait, plan contract) invalidates the run
+    per_step = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])) if marks else None
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -241,10 +325,13 @@ def main():
     planned_res = None
     if args.streams == 1 and model.schedule == "lockstep":
         from dagnn_amd import attach_plan
-        pm = attach_plan(batch_cpu.clone()).to(device)
+        groups = engine.dataflow_groups(device, 2, L, (H + 63) // 64 * 64, B)
+        pm = attach_plan(batch_cpu.clone(), dataflow_groups=groups, cost_layer=engine.DF_COST_LAYER,
+                         cost_row=engine.DF_COST_ROW).to(device)
         pin = fresh_inputs(pm, args.warmup + args.steps)
         for g in pin:
             g._dagnn_plan, g._dagnn_plan_meta = pm._dagnn_plan, pm._dagnn_plan_meta
+            g._dagnn_df = getattr(pm, "_dagnn_df", None)
         with torch.no_grad():
             for i in range(args.warmup):
                 model(pin[i])
@@ -258,14 +345,18 @@ def main():
             tp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
         if world > 1:
             dist.all_reduce(tp, op=dist.ReduceOp.MAX)
-        planned_res = {"what": "forward(G) with the plan built on the host by the loader (collate_with_plan)",
+        planned_res = {"what": "forward(G) with the plan and the dataflow schedule built on the host by the loader "
+                               "(attach_plan): no plan / schedule kernels inside the step",
                        "ms_per_step": round(float(tp) / args.steps * 1e3, 4),
                        "graphs_per_s": round(world * B * args.steps / float(tp), 1)}
     train_res = None
     if args.train_steps > 0 and args.streams == 1 and model.schedule == "lockstep":
-        tw = 3
+        tw = 5
         train_res = training_leg(model, fresh_inputs(master, tw + args.train_steps), B, S, V, args.train_steps, tw,
                                  world, device, barrier)
+    other_res = None
+    if args.other_configs and rank == 0 and args.streams == 1:
+        other_res = other_configs(device)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
@@ -286,13 +377,15 @@ def main():
         if timer is not None:
             summ = timer.summary()
             lock = model.schedule == "lockstep"
-            n_rec, ms_rec = summ.get("frontier_run" if lock else "recurrence_layer", (0, 0.0))
+            df = lock and "dataflow_run" in summ
+            n_rec, ms_rec = summ.get("dataflow_run" if df else ("frontier_run" if lock else "recurrence_layer"), (0, 0.0))
             n_gemm, ms_gemm = summ.get("gemm_nt_bias", (0, 0.0))
             n_plan, ms_plan = summ.get("plan_build", (0, 0.0))
+            n_sch, ms_sch = summ.get("dataflow_schedule", (0, 0.0))
             calls_per_step = 1 if lock else L
-            # algorithmic work of the recurrence per forward(G), SURVEY.md §8(d): hidden-side GEMV 2*H*3H per
-            # node-update + attention/gates (2NH + 2EH + 15NH); with the lock-step schedule the launches also
-            # do the input-side GEMV of stacked layers > 0 (the per-graph schedule leaves it to the batched GEMM)
+            # algorithmic work of the recurrence per forward(G), SURVEY.md section 8(d): hidden-side GEMV 2*H*3H per
+            # node-update + attention/gates (2NH + 2EH + 15NH); the dataflow / lock-step launches also do the
+            # input-side GEMV of stacked layers > 0 (the per-graph schedule leaves it to the batched GEMM)
             flops = D * L * (N * 6.0 * H * H + 2.0 * N * H + 2.0 * E * H + 15.0 * N * H)
             if lock:
                 flops += D * (L - 1) * N * 6.0 * H * H
@@ -301,34 +394,52 @@ def main():
             ms_fwd = ms_rec * calls_per_step  # recurrence time per forward
             if ms_fwd > 0:
                 tf = flops / (ms_fwd * 1e-3) / 1e12
-                traffic = None
-                tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-                if lock and os.path.exists(tpath):  # separate rocprofv3 --pmc passes, see profiles/README.md
+                traffic, traffic_source = None, None
+                tname = "r02_pmc_traffic.json" if df else "pmc_traffic.json"
+                tpath = os.path.join(ROOT, "profiles", tname)
+                if lock and os.path.exists(tpath):  # separate rocprofv3 --pmc passes of this command, see profiles/README.md
                     traffic = json.load(open(tpath)).get("recurrence_hbm_bytes_per_forward")
+                    traffic_source = "profiles/" + tname + " (separate rocprofv3 --pmc passes, not measured in this run)"
+                if df:
+                    kname = ("dataflow_kernel<H/16> (dagnn_dataflow_run): ONE persistent launch per forward(G) for the "
+                             "whole recurrence - every (direction, stacked layer) cell plus the input-side projection "
+                             "cells, graphs dealt to independent groups, rows handed between workgroups as tagged "
+                             "granules")
+                elif lock:
+                    kname = ("recurrence = aggregate_rows_kernel + frontier_mfma_kernel + frontier_step_kernel (one launch "
+                             "per topological layer) overlapped with frontier_tail_kernel (persistent, deep graphs); "
+                             "figures are per forward(G)")
+                else:
+                    kname = ("recurrence_kernel<KSL> (dagnn_recurrence_layer): %d launches per forward, one per stacked "
+                             "GRU layer, persistent per-(graph, direction) workgroups" % L)
                 result["roofline"] = {
-                    "kernel": ("recurrence = aggregate_rows_kernel + frontier_mfma_kernel (fat topological layers, "
-                               "32-row MFMA tiles) + frontier_step_kernel (one launch per mid / thin layer) for the "
-                               "shallow graphs, overlapped with frontier_tail_kernel (one persistent dataflow launch "
-                               "walking the deep graphs through all layers on a side stream), all (direction, stacked "
-                               "layer) cells; figures are per forward(G)") if lock else
-                              ("recurrence_kernel<KSL> (dagnn_recurrence_layer): %d launches per forward, one per "
-                               "stacked GRU layer, persistent per-(graph, direction) workgroups" % L),
+                    "kernel": kname,
                     "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 5), "traffic": traffic,
+                    "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_source,
                     "forwards_timed": n_rec // calls_per_step, "recurrence_ms_per_forward": round(ms_fwd, 4),
                     "algorithmic_flops_per_forward": flops, "algorithmic_bytes_per_forward": byts,
                     "hbm_frac_of_8TBps": round(byts / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                     "us_per_topological_layer": round(ms_fwd * 1e3 / max(T + L - 1, 1), 3),
-                    "schedule": model.schedule,
+                    "schedule": "dataflow" if df else model.schedule,
+                    "note": "fp32 matrix / vector peak (the path computes in fp32: 1e-4 after ~375 dependent steps); the "
+                            "kernel is bound by dependent-chain latency and per-row VALU work, not by HBM (hbm_frac)",
                 }
                 result["kernels_ms_per_step"] = {
                     "recurrence": round(ms_fwd, 4),
                     "gemm_nt_bias": round(ms_gemm * n_gemm / args.steps, 4),
-                    "plan_build": round(ms_plan * n_plan / args.steps, 4)}
+                    "plan_build": round(ms_plan * n_plan / args.steps, 4),
+                    "dataflow_schedule": round(ms_sch * n_sch / args.steps, 4)}
+        if per_step:
+            result["ms_per_step_median"] = round(per_step[len(per_step) // 2], 4)
+            result["ms_per_step_p90"] = round(per_step[min(len(per_step) - 1, int(0.9 * len(per_step)))], 4)
+            result["timing"] = "value / ms_per_step: wall clock over the K steps between two synchronisations (max over " \
+                               "ranks); median / p90: HIP events around every step on the launching stream"
         if planned_res is not None:
             result["loader_side_plan"] = planned_res
         if train_res is not None:
             result["training_step"] = train_res
+        if other_res is not None:
+            result["other_configs"] = other_res
         if args.cpu_passes > 0:
             result["cpu_baseline"] = cpu_baseline(cpu_sd, batch_cpu, L, S, args.cpu_passes, args.cpu_threads)
         print(json.dumps(result))

@@ -74,7 +74,7 @@ class DataflowArgs(C.Structure):
     _fields_ = [("cell", (DataflowCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
                 ("H", C.c_int), ("ld_h", C.c_int), ("gld", C.c_int), ("pld", C.c_int), ("vid_mod", C.c_int), ("groups", C.c_int),
                 ("epoch", C.c_uint), ("schedule", C.c_void_p), ("err", C.c_void_p), ("debug_timing", C.c_void_p),
-                ("spin_limit", C.c_uint), ("debug_wg", C.c_int)]
+                ("spin_limit", C.c_uint), ("debug_wg", C.c_int), ("plan_status", C.c_void_p)]
 
 
 class BackwardCell(C.Structure):
@@ -141,7 +141,7 @@ SYMBOLS = {
     "dagnn_dataflow_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),
     "dagnn_dataflow_layout": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
     "dagnn_dataflow_schedule": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
-                                          C.c_void_p]),
+                                          C.c_void_p, C.c_void_p]),
     "dagnn_dataflow_run": (C.c_int, [C.POINTER(Plan), C.POINTER(DataflowArgs), C.c_void_p]),
     "dagnn_pack_dataflow": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_score_parts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -83,7 +83,8 @@ __host__ __device__ inline DfLayout df_layout_words(int64_t N, int64_t B, int G)
 // ---- LPT assignment: graphs in order of decreasing depth (plan items), each to the group whose load it raises the
 // least; load_k = c_layer * (depth of the first = deepest graph of k) + c_row * (nodes of k).  One wave, lane = group.
 __global__ void __launch_bounds__(64) df_assign_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws,
-                                                       DfLayout S, int B, int G, int c_layer, int c_row) {
+                                                       DfLayout S, int B, int G, int c_layer, int c_row, const int32_t* __restrict__ status) {
+    if (status && status[0] != 0) return;   // the batch violates the plan contract: nothing here can be trusted
     const int lane = threadIdx.x;
     long long load = 0;
     int depth = 0;
@@ -124,7 +125,8 @@ __global__ void __launch_bounds__(64) df_assign_kernel(const int32_t* __restrict
 
 // rows per (group, layer): one workgroup per (graph, direction) adds its layer widths
 __global__ void __launch_bounds__(256) df_count_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws,
-                                                        DfLayout S) {
+                                                        DfLayout S, const int32_t* __restrict__ status) {
+    if (status && status[0] != 0) return;   // the batch violates the plan contract: nothing here can be trusted
     const int g = blockIdx.x, d = blockIdx.y;
     const int n0 = plan[L.node_ptr + g];
     const int depth = plan[L.depth[d] + g];
@@ -135,7 +137,8 @@ __global__ void __launch_bounds__(256) df_count_kernel(const int32_t* __restrict
 }
 
 // per (group, direction): counts -> exclusive prefix of the block-padded counts; gtab = {.., blocks}
-__global__ void __launch_bounds__(256) df_prefix_kernel(int32_t* ws, DfLayout S, int G) {
+__global__ void __launch_bounds__(256) df_prefix_kernel(int32_t* ws, DfLayout S, int G, const int32_t* __restrict__ status) {
+    if (status && status[0] != 0) return;   // the batch violates the plan contract: nothing here can be trusted
     __shared__ int32_t wsum[4];
     __shared__ int32_t carry_s;
     const int k = blockIdx.x, d = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
@@ -164,7 +167,8 @@ __global__ void __launch_bounds__(256) df_prefix_kernel(int32_t* ws, DfLayout S,
 }
 
 // first record of every group (exclusive prefix over the groups' record counts); one wave per direction
-__global__ void __launch_bounds__(64) df_base_kernel(int32_t* ws, DfLayout S, int G) {
+__global__ void __launch_bounds__(64) df_base_kernel(int32_t* ws, DfLayout S, int G, const int32_t* __restrict__ status) {
+    if (status && status[0] != 0) return;   // the batch violates the plan contract: nothing here can be trusted
     const int d = blockIdx.x, lane = threadIdx.x;
     int x = lane < G ? ws[S.gtab[d] + 2 * lane + 1] * DF_RB : 0;
     const int own = x;
@@ -176,7 +180,8 @@ __global__ void __launch_bounds__(64) df_base_kernel(int32_t* ws, DfLayout S, in
 // glbase[(g, t)] = padded prefix of (group, t) + rows of layer t in the group's graphs ordered before g.
 // One wave per (group, layer) pair, lanes over graphs.
 __global__ void __launch_bounds__(256) df_lbase_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws,
-                                                        DfLayout S, int B, int G) {
+                                                        DfLayout S, int B, int G, const int32_t* __restrict__ status) {
+    if (status && status[0] != 0) return;   // the batch violates the plan contract: nothing here can be trusted
     const int d = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int nw = gridDim.x * 4;
@@ -210,7 +215,8 @@ __global__ void __launch_bounds__(256) df_lbase_kernel(const int32_t* __restrict
 
 // copy every row record to its place in the group order (padding records were preset to -1)
 __global__ void __launch_bounds__(256) df_records_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws,
-                                                          DfLayout S, int N) {
+                                                          DfLayout S, int N, const int32_t* __restrict__ status) {
+    if (status && status[0] != 0) return;   // the batch violates the plan contract: nothing here can be trusted
     const int d = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;   // per-graph sorted position
     if (p >= N) return;
@@ -264,9 +270,10 @@ struct DfArgs {
     const int32_t* sched;   // schedule workspace (dagnn_dataflow_schedule)
     int64_t gtab[2], grec[2];   // word offsets into sched
     int64_t col[2], eattr[2];   // word offsets into the plan
-    int ncell, H, ld_h, gld, pld, R, vid_mod, groups;
+    int ncell, H, ld_h, gld, pld, R, vid_mod, groups, N;
     unsigned epoch, spin_limit;
     int dbg_wg;                 // workgroup whose blocks are stamped
+    const int32_t* status;      // plan status word (dagnn_plan_build), or null
     int* err;
     unsigned long long* dbg;    // optional: [grid][2] start / end stamps, then [blocks][8] stamps of workgroup dbg_wg (100 MHz)
 };
@@ -783,7 +790,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     int* const err = S.err;
     float* const h_out = C.h_out;
     gran_t* const g_out = C.g_out;
-    const int ld_h = S.ld_h, gld = S.gld, pld = S.pld;
+    const int ld_h = S.ld_h, gld = S.gld, pld = S.pld, num_nodes = S.N;
     unsigned long long* const dbg = S.dbg ? S.dbg + 2 * gridDim.x : nullptr;
     const bool prof = dbg != nullptr && (int)blockIdx.x == S.dbg_wg && cw == 0 && lane == 0;
 
@@ -841,11 +848,12 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
             }
         }
         if (prof) dbg[8 * (int64_t)b + 1] = wall_clock64();
-        const bool live = gr < nr;
+        // (the bound on the node id only matters once a wait has expired and the slot may hold anything: the pass is
+        // lost then, but it must not write outside its buffers)
+        int gv = gr == 0 ? ids.x : (gr == 1 ? ids.y : (gr == 2 ? ids.z : ids.w));
+        const bool live = gr < nr && (unsigned)gv < (unsigned)num_nodes;
         float hv = 0.f;
-        int gv = 0;
         if (live) {
-            gv = gr == 0 ? ids.x : (gr == 1 ? ids.y : (gr == 2 ? ids.z : ids.w));
             if (!proj) {
                 const float rg = df_sigm(g3[0] + b_r + gi_r);
                 const float zg = df_sigm(g3[1] + b_z + gi_z);
@@ -876,6 +884,10 @@ __global__ void __launch_bounds__(DF_THREADS, 3) dataflow_kernel(const int32_t* 
     typedef DfSlot<KPT> Slot;
     constexpr int NS = 16 * KPT / DF_JS;
     const int tid = threadIdx.x;
+    if (S.status && S.status[0] != 0) {   // the batch violates the plan contract: the schedule is garbage - do not walk it
+        if (tid == 0) __hip_atomic_fetch_or(S.err, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int per_group = S.ncell * NS;
     const int group = blockIdx.x / per_group;
@@ -966,7 +978,7 @@ extern "C" int dagnn_dataflow_groups(int num_cus, int num_dirs, int num_stacked,
 }
 
 extern "C" int dagnn_dataflow_schedule(const dagnn_plan* pl, void* ws_, size_t ws_bytes, int groups, int cost_layer,
-                                       int cost_row, void* stream_) {
+                                       int cost_row, const int32_t* status, void* stream_) {
     if (!pl || !pl->data || !ws_ || groups < 1 || groups > DF_MAX_GROUPS || cost_layer < 0 || cost_row < 0)
         return DAGNN_EINVAL;
     const int64_t N = pl->N, B = pl->B;
@@ -981,19 +993,19 @@ extern "C" int dagnn_dataflow_schedule(const dagnn_plan* pl, void* ws_, size_t w
     e = hipMemsetAsync(ws + S.grec[0], 0xff, (size_t)(S.total - S.grec[0]) * 4, st);   // padding records: node = -1
     if (e != hipSuccess) return DAGNN_EHIP(e);
     if (B == 0 || N == 0) return DAGNN_OK;
-    hipLaunchKernelGGL(df_assign_kernel, dim3(1), dim3(64), 0, st, plan, L, ws, S, (int)B, groups, cost_layer, cost_row);
+    hipLaunchKernelGGL(df_assign_kernel, dim3(1), dim3(64), 0, st, plan, L, ws, S, (int)B, groups, cost_layer, cost_row, status);
     DAGNN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(df_count_kernel, dim3((unsigned)B, 2), dim3(256), 0, st, plan, L, ws, S);
+    hipLaunchKernelGGL(df_count_kernel, dim3((unsigned)B, 2), dim3(256), 0, st, plan, L, ws, S, status);
     DAGNN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(df_prefix_kernel, dim3((unsigned)groups, 2), dim3(256), 0, st, ws, S, groups);
+    hipLaunchKernelGGL(df_prefix_kernel, dim3((unsigned)groups, 2), dim3(256), 0, st, ws, S, groups, status);
     DAGNN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(df_base_kernel, dim3(2), dim3(64), 0, st, ws, S, groups);
+    hipLaunchKernelGGL(df_base_kernel, dim3(2), dim3(64), 0, st, ws, S, groups, status);
     DAGNN_CHECK_LAUNCH();
     int64_t lb = (N + groups + 3) / 4;
     if (lb > 2048) lb = 2048;
-    hipLaunchKernelGGL(df_lbase_kernel, dim3((unsigned)lb, 2), dim3(256), 0, st, plan, L, ws, S, (int)B, groups);
+    hipLaunchKernelGGL(df_lbase_kernel, dim3((unsigned)lb, 2), dim3(256), 0, st, plan, L, ws, S, (int)B, groups, status);
     DAGNN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(df_records_kernel, dim3((unsigned)((N + 255) / 256), 2), dim3(256), 0, st, plan, L, ws, S, (int)N);
+    hipLaunchKernelGGL(df_records_kernel, dim3((unsigned)((N + 255) / 256), 2), dim3(256), 0, st, plan, L, ws, S, (int)N, status);
     DAGNN_CHECK_LAUNCH();
     return DAGNN_OK;
 }
@@ -1062,11 +1074,13 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
     PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
     for (int d = 0; d < 2; ++d) { S.gtab[d] = SL.gtab[d]; S.grec[d] = SL.grec[d]; S.col[d] = L.col[d]; S.eattr[d] = L.eattr[d]; }
     S.spin_limit = a->spin_limit ? a->spin_limit : (1u << 22);
+    S.N = (int)pl->N;
     S.ncell = nc; S.H = H; S.ld_h = a->ld_h; S.gld = a->gld; S.pld = a->pld; S.R = pl->num_edge_feats;
     S.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
     S.groups = G; S.epoch = a->epoch; S.err = (int*)a->err;
     S.dbg = (unsigned long long*)a->debug_timing;
     S.dbg_wg = a->debug_wg;
+    S.status = (const int32_t*)a->plan_status;
     const int32_t* plan = (const int32_t*)pl->data;
     const unsigned grid = (unsigned)(G * nc * (H / DF_JS));
     hipStream_t st = (hipStream_t)stream;

@@ -125,7 +125,7 @@ class PlanHandle(object):
         self.desc = Plan(self.ws.data_ptr(), nbytes, self.N, self.E, self.B, self.R)
 
     @classmethod
-    def from_words(cls, ws: torch.Tensor, meta: dict) -> "PlanHandle":
+    def from_words(cls, ws: torch.Tensor, meta: dict, dataflow_words: Optional[torch.Tensor] = None) -> "PlanHandle":
         """Wrap a plan built on the host (`dagnn_amd.host_plan.build_plan_host`, e.g. in a loader worker) and
         already moved to the GPU: no plan kernels and - the schedule being known on the host - no device->host
         read in `forward`."""
@@ -143,6 +143,8 @@ class PlanHandle(object):
         self.desc = Plan(ws.data_ptr(), nbytes, self.N, self.E, self.B, self.R)
         self._schedule = [a for a in meta["schedule"]]
         self._splits = [a for a in meta["splits"]]
+        if dataflow_words is not None and meta.get("dataflow_key") is not None and dataflow_words.is_cuda:
+            self._df_host = {"key": tuple(meta["dataflow_key"]), "words": dataflow_words}
         return self
 
     def layout(self) -> dict:
@@ -189,7 +191,7 @@ class PlanHandle(object):
                 ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=self.ws.device)
                 with _span("dataflow_schedule", self.ws):
                     check(lib.dagnn_dataflow_schedule(C.byref(self.desc), ws.data_ptr(), nbytes, key[0], key[1], key[2],
-                                                      _stream(self.ws)), "dagnn_dataflow_schedule")
+                                                      self.status.data_ptr(), _stream(self.ws)), "dagnn_dataflow_schedule")
                 cache[key] = ws
         return cache[key]
 
@@ -372,6 +374,7 @@ def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     args.debug_timing = DEBUG_TIMING.data_ptr() if DEBUG_TIMING is not None else None
     args.spin_limit = SPIN_LIMIT
     args.debug_wg = _env_int("DAGNN_AMD_DEBUG_WG", 0)
+    args.plan_status = plan.status.data_ptr()
     with _span("dataflow_run", plan.ws):
         check(lib.dagnn_dataflow_run(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_dataflow_run")
     if score_parts and static_score is None:
@@ -448,7 +451,7 @@ class GranuleArena(object):
             if self.err is not None:
                 self.err.zero_()
             msgs = []
-            if e:
+            if e & 3:
                 msgs.append("a bounded device-side wait expired (code %d): the persistent kernel's workgroups were not "
                             "co-resident, or a producer failed" % e)
             if s:

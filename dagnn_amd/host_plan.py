@@ -206,14 +206,147 @@ def build_plan_host(edge_index, layer_fwd, layer_bwd, batch, num_graphs: int, ed
     return ws, sched, splits
 
 
-def attach_plan(batch, num_graphs: Optional[int] = None):
+DF_MAGIC = 0x44463031   # "DF01", csrc/dataflow.hip
+DF_RB = 4               # rows per block
+
+
+def dataflow_layout(N: int, B: int, G: int) -> Dict[str, int]:
+    """Word offsets of the dataflow schedule workspace: mirror of `df_layout_words` (csrc/dataflow.hip)."""
+    o = 16
+    L: Dict[str, int] = {}
+
+    def take(name: str, n: int) -> None:
+        nonlocal o
+        L[name] = o
+        o = _align4(o + n)
+
+    take("grp_of", B)
+    take("gdepth", G)
+    take("gload", G)
+    take("loff", G + 1)
+    for name, n in (("gtab", 2 * G), ("lcnt", N + G + 1), ("glbase", N + B), ("grec", 16 * (4 * N + 4))):
+        for d in (0, 1):
+            take("%s%d" % (name, d), n)
+    L["total"] = o
+    return L
+
+
+def build_dataflow_schedule_host(plan_words, N: int, E: int, B: int, R: int, groups: int, cost_layer: int = 8,
+                                 cost_row: int = 1) -> np.ndarray:
+    """The dataflow kernel's schedule (`dagnn_dataflow_schedule`, csrc/dataflow.hip) from a plan, on the host: graphs
+    dealt to `groups` groups longest-processing-time first (integer costs, ties to the lowest group), row records
+    re-sorted by (group, layer, graph, node) with every group-layer padded to whole blocks of 4.  Word for word what
+    the device kernels write (the GPU test compares them)."""
+    ws = _np(plan_words).astype(np.int32, copy=False)
+    P = plan_layout(N, E, B, R)
+    S = dataflow_layout(N, B, groups)
+    out = np.zeros(S["total"], dtype=np.int32)
+    out[S["grec0"]:] = -1
+    if B == 0 or N == 0:
+        return out
+    G = int(groups)
+    node_ptr = ws[P["node_ptr"]:P["node_ptr"] + B + 1].astype(np.int64)
+    n_of = np.diff(node_ptr)
+    depth = [ws[P["depth%d" % d]:P["depth%d" % d] + B].astype(np.int64) for d in (0, 1)]
+    items = ws[P["items"]:P["items"] + 2 * B]
+    # ---- LPT assignment (df_assign_kernel)
+    load = np.zeros(G, dtype=np.int64)
+    gdepth = np.zeros(G, dtype=np.int64)
+    empty = np.ones(G, dtype=bool)
+    grp = np.zeros(B, dtype=np.int64)
+    for it in items:
+        if it & 1:
+            continue
+        g = int(it) >> 1
+        dg = int(max(depth[0][g], depth[1][g]))
+        cand = load + cost_row * int(n_of[g]) + np.where(empty, cost_layer * dg, 0)
+        k = int(np.argmin(cand))   # first minimum = lowest group
+        load[k] = cand[k]
+        if empty[k]:
+            gdepth[k], empty[k] = dg, False
+        grp[g] = k
+    out[0:3] = (G, DF_MAGIC, DF_RB)
+    out[S["grp_of"]:S["grp_of"] + B] = grp
+    out[S["gdepth"]:S["gdepth"] + G] = gdepth
+    out[S["gload"]:S["gload"] + G] = np.minimum(load, 0x7fffffff)
+    loff = np.concatenate([[0], np.cumsum(gdepth + 1)])
+    out[S["loff"]:S["loff"] + G + 1] = loff
+    for d in (0, 1):
+        # per (graph, layer) row counts from lstart
+        g2 = np.repeat(np.arange(B), depth[d])
+        t2 = np.arange(g2.shape[0]) - np.repeat(np.cumsum(depth[d]) - depth[d], depth[d])
+        base2 = node_ptr[g2] + g2 + t2
+        ls = ws[P["lstart%d" % d]:P["lstart%d" % d] + N + B].astype(np.int64)
+        cnt2 = ls[base2 + 1] - ls[base2]
+        k2 = grp[g2]
+        # rows per (group, layer), padded exclusive prefix (df_count_kernel, df_prefix_kernel)
+        cnt = np.zeros(int(loff[G]), dtype=np.int64)
+        np.add.at(cnt, loff[k2] + t2, cnt2)
+        padded = (cnt + DF_RB - 1) // DF_RB * DF_RB
+        pref = np.zeros_like(cnt)
+        nblk = np.zeros(G, dtype=np.int64)
+        for k in range(G):
+            a, b = int(loff[k]), int(loff[k + 1])
+            seg = padded[a:b].copy()
+            seg[-1] = 0                      # the table has depth + 1 entries; the last holds the total
+            c = np.cumsum(seg) - seg
+            c[-1] = seg[:-1].sum()
+            pref[a:b] = c
+            nblk[k] = c[-1] // DF_RB
+        out[S["lcnt%d" % d]:S["lcnt%d" % d] + int(loff[G])] = pref
+        base = np.cumsum(nblk * DF_RB) - nblk * DF_RB
+        gt = np.empty(2 * G, dtype=np.int64)
+        gt[0::2], gt[1::2] = base, nblk
+        out[S["gtab%d" % d]:S["gtab%d" % d] + 2 * G] = gt
+        # first record of every (graph, layer) inside its group (df_lbase_kernel): graphs of a group in id order
+        order2 = np.lexsort((g2, t2, k2))
+        c = cnt2[order2]
+        run_key = k2[order2] * (int(gdepth.max()) + 2) + t2[order2]
+        start = np.concatenate([[True], run_key[1:] != run_key[:-1]])
+        csum = np.cumsum(c) - c
+        run_base = np.maximum.accumulate(np.where(start, csum, 0))
+        within = csum - run_base
+        glb = np.empty(g2.shape[0], dtype=np.int64)
+        glb[order2] = pref[loff[k2[order2]] + t2[order2]] + within
+        out[S["glbase%d" % d] + base2] = glb
+        # records (df_records_kernel)
+        order = ws[P["order%d" % d]:P["order%d" % d] + N].astype(np.int64)
+        slot = ws[P["slot%d" % d]:P["slot%d" % d] + N].astype(np.int64)
+        rowrec = ws[P["rowrec%d" % d]:P["rowrec%d" % d] + 16 * N].reshape(N, 16)
+        p = np.arange(N)
+        v = order[p]
+        recs = rowrec[slot[v]]
+        g = recs[:, 3].astype(np.int64)
+        # layer of sorted position p inside its graph: ls[t] <= p < ls[t + 1]
+        glb_full = np.zeros(N + B + 1, dtype=np.int64)
+        glb_full[base2] = glb
+        # expand per (graph, layer) -> per position
+        reps = cnt2
+        t_of_p = np.empty(N, dtype=np.int64)
+        b_of_p = np.empty(N, dtype=np.int64)
+        lsv = ls[base2]
+        idx = np.repeat(np.arange(base2.shape[0]), reps)
+        pos_sorted = np.repeat(lsv, reps) + (np.arange(idx.shape[0]) - np.repeat(np.cumsum(reps) - reps, reps))
+        t_of_p[pos_sorted] = t2[idx]
+        b_of_p[pos_sorted] = base2[idx]
+        rec_idx = base[grp[g]] + glb_full[b_of_p] + (p - ls[b_of_p])
+        dst = out[S["grec%d" % d]:S["grec%d" % d] + 16 * (4 * N + 4)].reshape(-1, 16)
+        dst[rec_idx] = recs
+    return out
+
+
+def attach_plan(batch, num_graphs: Optional[int] = None, dataflow_groups: int = 0, cost_layer: int = 8, cost_row: int = 1):
     """Build the host plan of a collated batch and attach it (`_dagnn_plan`: int32 tensor that moves with
-    `batch.to(device)`; `_dagnn_plan_meta`: sizes + the host schedule).  `DAGNN.forward` uses it when present."""
+    `batch.to(device)`; `_dagnn_plan_meta`: sizes + the host schedule).  `DAGNN.forward` uses it when present.  With
+    `dataflow_groups` the schedule of the persistent dataflow kernel is built here as well (`_dagnn_df`)."""
     B = int(num_graphs if num_graphs is not None else getattr(batch, "num_graphs", int(batch.batch[-1]) + 1))
     ea = getattr(batch, "edge_attr", None)
     ws, sched, splits = build_plan_host(batch.edge_index, batch._bi_layer_idx0, batch._bi_layer_idx1, batch.batch, B, ea)
     batch._dagnn_plan = torch.from_numpy(ws)
-    batch._dagnn_plan_meta = dict(N=int(batch.batch.shape[0]), E=int(batch.edge_index.shape[1]), B=B,
-                                  R=0 if ea is None else int(ea.reshape(batch.edge_index.shape[1], -1).shape[1]),
-                                  schedule=sched, splits=splits)
+    N, E = int(batch.batch.shape[0]), int(batch.edge_index.shape[1])
+    R = 0 if ea is None else int(ea.reshape(E, -1).shape[1])
+    batch._dagnn_plan_meta = dict(N=N, E=E, B=B, R=R, schedule=sched, splits=splits)
+    if dataflow_groups > 0:   # the dataflow kernel's schedule too (what `engine.dataflow_groups` gives for the model)
+        batch._dagnn_df = torch.from_numpy(build_dataflow_schedule_host(ws, N, E, B, R, dataflow_groups, cost_layer, cost_row))
+        batch._dagnn_plan_meta["dataflow_key"] = (int(dataflow_groups), int(cost_layer), int(cost_row))
     return batch

@@ -325,7 +325,7 @@ class DAGNN(nn.Module):
 
     def _plan_of(self, G, B):
         if getattr(G, "_dagnn_plan", None) is not None:  # built by the loader (dagnn_amd.host_plan.attach_plan)
-            return engine.PlanHandle.from_words(G._dagnn_plan, G._dagnn_plan_meta)
+            return engine.PlanHandle.from_words(G._dagnn_plan, G._dagnn_plan_meta, getattr(G, "_dagnn_df", None))
         has_edge_enc = getattr(self.node_aggr_0[0], "wea", False)
         return engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B,
                                  G.edge_attr if has_edge_enc else None)

@@ -261,7 +261,8 @@ int dagnn_frontier_run(const dagnn_plan* plan /* host */, const dagnn_frontier_a
  *      (gld >= H) tagged copies {epoch, fp32 bits} of its state rows - the hand-off format between workgroups.  The
  *      buffers must have been zero-initialised once and only ever used with strictly increasing `epoch`s (a replayed
  *      hipGraph must contain the memset).  `err` (device int32, zeroed by the caller) is set when a bounded wait
- *      expires (results are then invalid): bit 0 a granule poll, bit 1 an LDS flag.
+ *      expires (results are then invalid): bit 0 a granule poll, bit 1 an LDS flag; bit 2: the plan's status word
+ *      (`plan_status`) was nonzero, nothing was computed.
  *      State rows h_out [N, ld_h] receive the H states only; dagnn_score_parts adds the H/16 partial attention scores
  *      behind them (the format dagnn_backward_prepare reads) when a backward pass follows.
  * Weights: dagnn_pack_dataflow(W [3H,H] torch layout) -> 3*H*H floats in slice / lane order.
@@ -294,12 +295,14 @@ typedef struct dagnn_dataflow_args {
                             * workgroup, then [blocks][8] phase stamps of workgroup `debug_wg` */
     unsigned spin_limit;   /* polls before a wait gives up and raises `err`; 0 = default (1 << 22, seconds) */
     int debug_wg;          /* workgroup whose blocks are stamped (debug_timing) */
+    const void* plan_status; /* NULL, or the device status word of dagnn_plan_build: if it is nonzero (the batch violates
+                            * the layout contract) the launch walks nothing and raises bit 2 of `err` */
 } dagnn_dataflow_args;
 
 int dagnn_dataflow_groups(int num_cus, int num_dirs, int num_stacked, int H, int64_t B);
 size_t dagnn_dataflow_bytes(int64_t N, int64_t B, int groups);
 int dagnn_dataflow_schedule(const dagnn_plan* plan /* host */, void* workspace, size_t workspace_bytes, int groups,
-                            int cost_layer, int cost_row, void* stream);
+                            int cost_layer, int cost_row, const int32_t* plan_status /* device, or NULL */, void* stream);
 int dagnn_dataflow_run(const dagnn_plan* plan /* host */, const dagnn_dataflow_args* args /* host */, void* stream);
 int dagnn_pack_dataflow(const float* w /* [3H,H] */, float* out /* 3H*H floats */, int H, void* stream);
 int dagnn_score_parts(float* h /* [N,ld_h] */, int ld_h, int H, const float* w_key /* [H] */, int64_t N, void* stream);

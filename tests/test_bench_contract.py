@@ -52,7 +52,7 @@ def _run_bench(args, env_extra=None, launcher=()):
 
 @pytest.mark.gpu
 def test_bench_single_gpu_line():
-    j = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-passes", "0", "--train-steps", "0"])
+    j = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-passes", "0", "--train-steps", "0", "--other-configs", "0"])
     _check_line(j, 1, 3, 1, with_cpu=False)
 
 
@@ -62,7 +62,7 @@ def test_bench_two_ranks_under_torchrun():
     here two ranks share the one visible GPU and rendezvous over gloo (RCCL refuses two ranks on one device)."""
     launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                 "--master-port", "29517"]
-    j = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-passes", "0", "--train-steps", "2"],
+    j = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-passes", "0", "--train-steps", "2", "--other-configs", "0"],
                    env_extra={"DAGNN_BENCH_BACKEND": "gloo"}, launcher=launcher)
     _check_line(j, 2, 3, 1, with_cpu=False)
     assert j["config"]["global_batch"] == 256   # weak scaling: 128 graphs per rank

@@ -249,6 +249,79 @@ def test_host_plan_layout_matches_library():
         assert lay["total"] * 4 == lib.dagnn_plan_bytes(N, E, B, R)
 
 
+def test_dataflow_layout_matches_library():
+    from dagnn_amd import host_plan
+    lib = _lib.load()
+    names = ["grp_of", "gdepth", "gload", "loff", "gtab0", "gtab1", "lcnt0", "lcnt1", "glbase0", "glbase1", "grec0",
+             "grec1", "total"]
+    for N, B, G in ((16561, 128, 5), (7, 3, 2), (512, 64, 32), (1, 1, 1)):
+        off = (ctypes.c_int64 * 13)()
+        assert lib.dagnn_dataflow_layout(N, B, G, off) == 0
+        lay = host_plan.dataflow_layout(N, B, G)
+        assert {k: lay[k] for k in names} == {k: int(v) // 4 for k, v in zip(names, off)}
+        assert lay["total"] * 4 == lib.dagnn_dataflow_bytes(N, B, G)
+    # groups the device hosts: floor(CUs / (dirs * (2L - 1) * H / 32)), capped by the graphs; 0 = not applicable
+    assert lib.dagnn_dataflow_groups(256, 2, 2, 256, 128) == 5
+    assert lib.dagnn_dataflow_groups(256, 1, 2, 128, 64) == 21
+    assert lib.dagnn_dataflow_groups(256, 2, 2, 256, 3) == 3
+    assert lib.dagnn_dataflow_groups(256, 2, 5, 512, 256) == 0 and lib.dagnn_dataflow_groups(256, 2, 2, 300, 8) == 0
+    assert lib.dagnn_dataflow_groups(16, 2, 2, 256, 8) == 0
+
+
+@pytest.mark.parametrize("seed,B,mean_n,G", [(1, 17, 60, 5), (0, 128, 125, 5), (3, 4, 30, 8), (4, 40, 15, 3)])
+def test_dataflow_schedule_host_properties(seed, B, mean_n, G):
+    """The schedule the persistent kernel walks (host mirror of csrc/dataflow.hip): every node exactly once per
+    direction, blocks of 4 records that never mix topological layers or groups, live records first, every
+    predecessor in an earlier block of the same group (the kernel's deadlock-freedom argument), LPT assignment."""
+    from dagnn_amd import host_plan, synth
+    b = synth.code2_batch(seed, B, mean_n)
+    N, E = b.x.shape[0], b.edge_index.shape[1]
+    G = min(G, B)
+    ws, _, _ = host_plan.build_plan_host(b.edge_index, b._bi_layer_idx0, b._bi_layer_idx1, b.batch, B, b.edge_attr)
+    out = host_plan.build_dataflow_schedule_host(ws, N, E, B, 2, G, 8, 1)
+    S = host_plan.dataflow_layout(N, B, G)
+    assert tuple(out[:3]) == (G, host_plan.DF_MAGIC, 4)
+    grp = out[S["grp_of"]:S["grp_of"] + B]
+    assert grp.min() >= 0 and grp.max() < G
+    n_of = np.diff(b.ptr.numpy())
+    depth = np.array([int(b._bi_layer_idx0[b.ptr[g]:b.ptr[g + 1]].max()) + 1 for g in range(B)])
+    # the deepest graph opens group 0; loads are what the rule says
+    assert grp[int(np.argmax(depth))] == 0
+    gload = out[S["gload"]:S["gload"] + G]
+    for k in range(G):
+        members = np.flatnonzero(grp == k)
+        if members.size:
+            assert gload[k] == 8 * depth[members].max() + n_of[members].sum()
+            assert out[S["gdepth"] + k] == depth[members].max()
+    ei = b.edge_index.numpy()
+    for d in (0, 1):
+        layer = (b._bi_layer_idx0 if d == 0 else b._bi_layer_idx1).numpy()
+        gt = out[S["gtab%d" % d]:S["gtab%d" % d] + 2 * G].reshape(G, 2)
+        rec = out[S["grec%d" % d]:S["grec%d" % d] + 16 * (4 * N + 4)].reshape(-1, 16)
+        live = rec[:, 0] >= 0
+        assert sorted(rec[live, 0].tolist()) == list(range(N))
+        assert gt[:, 0].tolist() == (np.cumsum(gt[:, 1] * 4) - gt[:, 1] * 4).tolist()
+        assert not live[int(gt[-1, 0] + 4 * gt[-1, 1]):].any()
+        block_of = np.full(N, -1)
+        feed, other = (ei[1], ei[0]) if d == 0 else (ei[0], ei[1])
+        for k in range(G):
+            last_layer = -1
+            for blk in range(gt[k, 1]):
+                r = rec[gt[k, 0] + 4 * blk: gt[k, 0] + 4 * blk + 4]
+                lv = r[:, 0] >= 0
+                assert lv[0] and not (np.diff(lv.astype(int)) > 0).any()      # at least one record, live ones first
+                nodes = r[lv, 0]
+                assert (grp[b.batch.numpy()[nodes]] == k).all()
+                assert len(set(layer[nodes].tolist())) == 1 and layer[nodes[0]] >= last_layer
+                last_layer = layer[nodes[0]]
+                block_of[nodes] = blk
+                for row in r[lv]:
+                    preds = other[feed == row[0]]
+                    assert row[2] - row[1] == preds.size
+                    assert (block_of[preds] >= 0).all() and (block_of[preds] < blk).all()
+                    assert row[4:4 + min(4, preds.size)].tolist() == preds[:4].tolist()
+
+
 def test_host_plan_against_brute_force():
     from dagnn_amd import host_plan, synth
     b = synth.code2_batch(3, 40, 40)   # wide enough for fat layers: shallow and deep graphs both exist

@@ -515,6 +515,82 @@ def test_host_plan_equals_device_plan_word_for_word(device, seed, B, mean_n):
         assert np.array_equal(sched[d], plan.read_schedule()[d])
 
 
+@pytest.mark.parametrize("seed,B,mean_n,G", [(2, 17, 60, 5), (0, 128, 125, 5), (5, 1, 12, 1), (7, 64, 14, 21), (8, 300, 20, 8),
+                                             (-1, 6, 0, 3)])
+def test_dataflow_schedule_host_equals_device_word_for_word(device, seed, B, mean_n, G):
+    """`dagnn_dataflow_schedule` (LPT groups, group-ordered padded records) against its numpy mirror."""
+    from dagnn_amd import host_plan
+    b = _degenerate_batch() if seed < 0 else synth.code2_batch(seed, B, mean_n)
+    plan = engine.build_plan(b.edge_index.to(device), b._bi_layer_idx0.to(device), b._bi_layer_idx1.to(device),
+                             b.batch.to(device), B, b.edge_attr.to(device))
+    dev = plan.dataflow_schedule(G).cpu().numpy()
+    ws = host_plan.build_plan_host(b.edge_index, b._bi_layer_idx0, b._bi_layer_idx1, b.batch, B, b.edge_attr)[0]
+    N, E = b.x.shape[0], b.edge_index.shape[1]
+    host = host_plan.build_dataflow_schedule_host(ws, N, E, B, 2, G, engine.DF_COST_LAYER, engine.DF_COST_ROW)
+    assert host.shape == dev.shape
+    assert plan.dataflow_layout(G) == host_plan.dataflow_layout(N, B, G)
+    assert np.array_equal(host, dev)
+
+
+def test_dataflow_with_loader_side_schedule(device, monkeypatch):
+    """`attach_plan(..., dataflow_groups=G)`: plan AND dataflow schedule from the loader - the forward pass launches
+    neither the plan nor the schedule kernels and gives bitwise the same logits."""
+    from dagnn_amd.host_plan import attach_plan
+    monkeypatch.setattr(engine, "DATAFLOW", 1)
+    model = _headline_model(H=128, L=2, V=32, seed=5).to(device)
+    graphs = synth.code2_graphs(21, 40, 50)
+    plain = synth.GraphBatch.from_data_list(graphs).to(device)
+    G = engine.dataflow_groups(device, 2, 2, 128, 40)
+    assert G > 0
+    planned = attach_plan(synth.GraphBatch.from_data_list(graphs), dataflow_groups=G, cost_layer=engine.DF_COST_LAYER,
+                          cost_row=engine.DF_COST_ROW).to(device)
+    lib = engine._lib.load()
+    with torch.no_grad():
+        a = model(plain.clone())
+        calls = []
+        orig = lib.dagnn_dataflow_schedule
+
+        def spy(*args):
+            calls.append(1)
+            return orig(*args)
+        monkeypatch.setattr(lib, "dagnn_dataflow_schedule", spy, raising=False)
+        bb = model(planned.clone())
+    assert not calls
+    assert all(torch.equal(x, y) for x, y in zip(a, bb))
+
+
+def test_device_side_failures_raise(device, monkeypatch):
+    """A bounded device-side wait that expires (here: a spin budget of one poll) and a batch that violates the plan
+    contract (unsorted `batch` vector) both surface as DagnnHipError - at the latest at the next forward pass, with
+    no synchronisation on the healthy path."""
+    monkeypatch.setattr(engine, "DATAFLOW", 1)
+    model = _headline_model(H=64, L=2, V=16, seed=3).to(device)
+    b = synth.code2_batch(4, 24, 60)
+    with torch.no_grad():
+        model(b.clone().to(device))
+        monkeypatch.setattr(engine, "SPIN_LIMIT", 1)
+        model(b.clone().to(device))          # every dependent poll gives up at once: garbage, flagged
+        torch.cuda.synchronize()
+        monkeypatch.setattr(engine, "SPIN_LIMIT", 0)
+        with pytest.raises(DagnnHipError, match="bounded device-side wait"):
+            model(b.clone().to(device))
+            torch.cuda.synchronize()
+            model(b.clone().to(device))
+        torch.cuda.synchronize()
+        out = model(b.clone().to(device))     # the flag was consumed: healthy again
+        ref = model(b.clone().to(device))
+        assert all(torch.equal(x, y) for x, y in zip(out, ref))
+        bad = b.clone().to(device)
+        bad.batch = bad.batch.flip(0).contiguous()
+        with pytest.raises(DagnnHipError, match="plan contract"):
+            try:
+                model(bad)
+            except DagnnHipError:
+                raise
+            torch.cuda.synchronize()
+            model(b.clone().to(device))
+
+
 def test_forward_and_training_with_loader_side_plan(device):
     """`collate_with_plan` batches: no plan kernels, no device->host read, bitwise the same results."""
     from dagnn_amd import collate_with_plan

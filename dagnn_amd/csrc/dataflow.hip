@@ -83,19 +83,50 @@ __host__ __device__ inline DfLayout df_layout_words(int64_t N, int64_t B, int G)
 // ---- LPT assignment: graphs in order of decreasing depth (plan items), each to the group whose load it raises the
 // least; load_k = c_layer * (depth of the first = deepest graph of k) + c_row * (nodes of k).  One wave, lane = group.
 __global__ void __launch_bounds__(64) df_assign_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws,
-                                                       DfLayout S, int B, int G, int c_layer, int c_row, const int32_t* __restrict__ status) {
+                                                        DfLayout S, int B, int G, int c_layer, int c_row, const int32_t* __restrict__ status) {
     if (status && status[0] != 0) return;   // the batch violates the plan contract: nothing here can be trusted
+    // the sequential part below is B dependent steps: its operands (graph, depth, nodes, in schedule order) are
+    // staged in LDS first - from global memory every step is three dependent round trips (measured 76 us at B = 128)
+    constexpr int CAP = 4096;
+    __shared__ int32_t s_g[CAP], s_d[CAP], s_n[CAP];
+    const int32_t* items = plan + L.items;
+    const bool staged = B <= CAP;
     const int lane = threadIdx.x;
+    // compact the direction-0 entries in order (wave-level prefix over 64 entries at a time)
+    int count = 0;
+    if (staged) {
+        for (int j0 = 0; j0 < 2 * B; j0 += 64) {
+            const int j = j0 + lane;
+            const int it = j < 2 * B ? items[j] : 1;
+            const bool keep = !(it & 1);
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                const int g = it >> 1;
+                s_g[pos] = g;
+                s_d[pos] = max(plan[L.depth[0] + g], plan[L.depth[1] + g]);
+                s_n[pos] = plan[L.node_ptr + g + 1] - plan[L.node_ptr + g];
+            }
+            count += __popcll(m);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     long long load = 0;
     int depth = 0;
     bool empty = true;
-    const int32_t* items = plan + L.items;
-    for (int j = 0; j < 2 * B; ++j) {
-        const int it = items[j];
-        if (it & 1) continue;   // direction-1 entry of the same graph (longest paths have the same length both ways)
-        const int g = it >> 1;
-        const int dg = max(plan[L.depth[0] + g], plan[L.depth[1] + g]);
-        const int ng = plan[L.node_ptr + g + 1] - plan[L.node_ptr + g];
+    const int steps = staged ? count : 2 * B;
+    for (int j = 0; j < steps; ++j) {
+        int g, dg, ng;
+        if (staged) {
+            g = s_g[j]; dg = s_d[j]; ng = s_n[j];
+        } else {
+            const int it = items[j];
+            if (it & 1) continue;
+            g = it >> 1;
+            dg = max(plan[L.depth[0] + g], plan[L.depth[1] + g]);
+            ng = plan[L.node_ptr + g + 1] - plan[L.node_ptr + g];
+        }
         long long cand = load + (long long)c_row * ng + (empty ? (long long)c_layer * dg : 0);
         if (lane >= G) cand = 0x7fffffffffffffffLL;
         long long best = cand;

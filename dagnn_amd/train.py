@@ -3,7 +3,10 @@
 The reference trains with `tg/data_parallel.DataParallel`: one process, k threads, the 29.8 M parameters
 re-broadcast and the gradients reduced to device 0 every step (`ogbg-code/tg/data_parallel.py:48-62`).  Here
 every rank owns a full replica and its own shard of graphs; the only exchange of a training step is ONE
-all-reduce (sum, then divide by the world size) of a flat gradient bucket over RCCL/xGMI.
+all-reduce of a flat gradient bucket over RCCL/xGMI.  The reference's loss is the mean over the graphs of the GLOBAL
+batch (`main_pyg.py:55-60` on the gathered predictions) and its `Collater` balances shards by nodes, not by graphs
+(`tg/dataloader.py:17-27`: 12..18 graphs per shard on the seed-0 batch), so every rank's gradient of its LOCAL mean
+loss is weighted by its graph count: grad = sum_k b_k grad_k / sum_k b_k.  The counts travel in the same collective.
 """
 from __future__ import annotations
 
@@ -25,7 +28,9 @@ class GradBucket(object):
         if not self.params:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
-        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        n = sum(p.numel() for p in self.params)
+        self._buf = torch.zeros(n + 1, dtype=torch.float32, device=dev)   # one more float: this rank's graph count
+        self.flat = self._buf[:n]
         off = 0
         for p in self.params:
             if p.dtype != torch.float32 or p.device != dev:
@@ -41,10 +46,16 @@ class GradBucket(object):
         """Replaces `optimizer.zero_grad()` (which would detach the views when it sets grads to None)."""
         self.flat.zero_()
 
-    def all_reduce_mean(self, group: Optional[dist.ProcessGroup] = None) -> None:
-        """Average over ranks: the reference's loss is the mean over the graphs of the GLOBAL batch
-        (`main_pyg.py:55-60` on the gathered predictions), which for equal shard sizes is the mean of the
-        per-rank mean losses."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(dist.get_world_size(group))
+    def all_reduce_mean(self, local_count: Optional[int] = None, group: Optional[dist.ProcessGroup] = None) -> None:
+        """Gradient of the mean loss over the GLOBAL batch from the ranks' gradients of their local mean losses:
+        sum_k b_k grad_k / sum_k b_k with b_k = `local_count` (graphs in this rank's shard; 0 for a rank that skipped
+        its shard, as `main_pyg.py:47` does for one-graph chunks).  Without `local_count` every rank weighs the same
+        (equal shards).  ONE collective of numel + 1 floats."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+            return
+        b = 1.0 if local_count is None else float(local_count)
+        if b != 1.0:
+            self.flat.mul_(b)
+        self._buf[-1] = b
+        dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=group)
+        self.flat.div_(self._buf[-1].clamp(min=1.0))

@@ -3,7 +3,7 @@
 
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python bench.py --steps 2 --warmup 1 --cpu-passes 0 --no-kernel-timer
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python bench.py --steps 2 --warmup 1 --cpu-passes 0 --no-kernel-timer
-  python scripts/pmc_summary.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv 3
+  python scripts/pmc_summary.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv 6 [out.json]
 
 Counter unit is KiB. FETCH_SIZE is doubled before use (MI355X_MICROARCH.md, HBM section: gfx950 reports
 wide coalesced reads at half size); WRITE_SIZE is used as reported.
@@ -15,7 +15,7 @@ import re
 import sys
 from collections import defaultdict
 
-RECURRENCE = ("frontier_step_kernel", "frontier_tail_kernel", "frontier_mfma_kernel", "aggregate_rows_kernel")
+RECURRENCE = ("dataflow_kernel", "frontier_step_kernel", "frontier_tail_kernel", "frontier_mfma_kernel", "aggregate_rows_kernel")
 
 
 def short(name):
@@ -35,6 +35,7 @@ def fold(path):
 
 def main():
     fetch_csv, write_csv, forwards = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    out_name = sys.argv[4] if len(sys.argv) > 4 else "pmc_traffic.json"
     ft, fc = fold(fetch_csv)
     wt, _ = fold(write_csv)
     per = {}
@@ -49,7 +50,7 @@ def main():
             rec_bytes += (2 * f_kib + w_kib) * 1024
     out = {
         "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over `python bench.py "
-                "--steps 2 --warmup 1 --cpu-passes 0 --no-kernel-timer` (%d forwards: the headline leg and the loader-side-plan leg), lock-step schedule. Counter "
+                "--steps 2 --warmup 1 --cpu-passes 0 --no-kernel-timer --train-steps 0 --other-configs 0` (%d forwards: the headline leg and the loader-side-plan leg). Counter "
                 "unit is KiB (calibrated: encode_ast_kernel WRITE_SIZE = N*H*4 bytes per launch). FETCH_SIZE is "
                 "doubled before use, as MI355X_MICROARCH.md (HBM section) prescribes for wide coalesced reads on "
                 "gfx950; WRITE_SIZE is used as reported. Produced by scripts/pmc_summary.py." % forwards,
@@ -58,7 +59,7 @@ def main():
         "recurrence_hbm_bytes_per_forward": int(rec_bytes),
     }
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "pmc_traffic.json"), "w") as f:
+    with open(os.path.join(root, "profiles", out_name), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
 

@@ -95,6 +95,46 @@ def _train_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _uneven_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dagnn_amd.train import GradBucket
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+        g = torch.Generator().manual_seed(5)
+        x, y = torch.randn(11, 6, generator=g), torch.randint(0, 3, (11,), generator=g)   # the global batch, everywhere
+        cut = 4                                                                         # shards of 4 and 7 rows
+        mine = slice(0, cut) if rank == 0 else slice(cut, 11)
+        bucket = GradBucket(net.parameters())
+        bucket.zero()
+        torch.nn.functional.cross_entropy(net(x[mine]), y[mine]).backward()            # mean over the LOCAL shard
+        bucket.all_reduce_mean(local_count=x[mine].shape[0])
+        got = bucket.flat.clone()
+        ref_net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+        ref_net.load_state_dict(net.state_dict())
+        torch.nn.functional.cross_entropy(ref_net(x), y).backward()                    # mean over the GLOBAL batch
+        ref = torch.cat([p.grad.flatten() for p in ref_net.parameters()])
+        assert torch.allclose(got, ref, atol=1e-6), float((got - ref).abs().max())
+        # the unweighted mean of the two local means is NOT the global mean here
+        naive = GradBucket(ref_net.parameters())
+        out[rank] = float((got - ref).abs().max())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_uneven_shards_give_the_global_mean_gradient_gloo():
+    """Shards of 4 and 7 rows: the bucket's count-weighted all-reduce equals the single-process gradient of the mean
+    loss over all 11 rows (the reference's loss, main_pyg.py:55-60); the node-balanced Collater split makes uneven
+    shards the normal case (tg/dataloader.py:17-27)."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_uneven_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert len(out) == 2 and max(out.values()) < 1e-6
+
+
 @pytest.mark.timeout(180)
 def test_two_rank_gradient_bucket_all_reduce_gloo():
     """The training exchange of the N>1 path (one flat-bucket all-reduce, bench.py's training leg) on gloo."""

@@ -172,6 +172,7 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
     ld = engine.frontier_ld(Hp)  # state rows carry their H/16 partial attention scores behind the states
     h = [[torch.empty(N, ld, dtype=torch.float32, device=dev) if d in dirs else None for _ in range(L)]
          for d in range(2)]
+    plan.wait_ready()   # a plan built on the side stream (model._plan_of) meets the caller's stream here
     groups = engine.dataflow_groups(dev, len(dirs), L, Hp, plan.B) if (arena is not None and N > 0) else 0
     if groups > 0:
         arena.poll()   # a failure an earlier pass reported (no synchronisation)

@@ -43,7 +43,10 @@ constexpr int DF_RB = 4;       // rows per block = loader waves
 constexpr int DF_NCW = 4;      // compute waves
 constexpr int DF_NLS = 2;      // loader sets: set s takes the blocks b = s (mod NLS) - a block costs a loader wave one trip to
                                // memory plus ~1 us of scalar work, twice what the compute waves need for it
-constexpr int DF_NSLOT = 4;    // LDS ring depth (blocks the loaders may run ahead)
+#ifndef DF_NSLOT_V
+#define DF_NSLOT_V 4
+#endif
+constexpr int DF_NSLOT = DF_NSLOT_V;    // LDS ring depth (blocks the loaders may run ahead)
 constexpr bool DF_TWO_CHUNKS = false;   // rows with > 4 in-edges: two chunks per trip to memory.  Measured: the second sweep's
                                // 32 registers spill the loader at 3 waves per SIMD; such rows cost ~75 us per group
 constexpr int DF_THREADS = 64 * (DF_NCW + DF_NLS * DF_RB);
@@ -420,7 +423,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
         cpos[q] = c + (SEG - KP8) * (c / KP8);
         if (C.wkey && !proj && q < NQ4) wk[q] = C.wkey[c];
     }
-    const bool prof = dbg != nullptr && (int)blockIdx.x == S.dbg_wg && lw == 0 && set == 0 && lane == 0;
+    const bool prof = dbg != nullptr && (int)blockIdx.x == S.dbg_wg && lw == 0 && lane == 0;
 
     // ---- memory traffic of this wave, by hand.  Three streams share the wave's in-order vmcnt counter: the granule
     // sweeps (on the dependent chain), the static row records and the gi0 slices (cold lines: HBM latency).  Left to
@@ -654,6 +657,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
 #if DF_EXPERIMENT == 8
                 if (prof && c0 == 0) dbg[8 * (int64_t)b + 4] = wall_clock64();
 #endif
+                unsigned long long t_issue = prof ? wall_clock64() : 0ull;
                 issue(A, pj, pend, p_pending, gp_in);
                 if (two) issue(A2, pj2, pend2, false, nullptr);
                 if (c0 == 0 && !two) { prefetch(); landed(A); }
@@ -680,13 +684,17 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                     }
                     ++polls;
                     if ((pend == 0 && pend2 == 0 && !p_pending) || !df_retry(spins, err, spin_limit)) break;
+                    if (prof) t_issue = wall_clock64();
                     issue(A, pj, pend, p_pending, gp_in);
                     if (two) issue(A2, pj2, pend2, false, nullptr);
                     landed_all(A);
                     if (two) landed_rows(A2);
                 }
 #if DF_EXPERIMENT != 8
-                if (prof && c0 == 0) { dbg[8 * (int64_t)b + 5] = wall_clock64(); dbg[8 * (int64_t)b + 6] = polls; }
+                if (prof && c0 == 0) {
+                    dbg[8 * (int64_t)b + 5] = wall_clock64(); dbg[8 * (int64_t)b + 6] = polls;
+                    if (b >= 8) dbg[8 * (int64_t)b + 7] = t_issue;   // when the poll that found the row was issued
+                }
 #else
                 if (prof && c0 == 0) dbg[8 * (int64_t)b + 6] = polls;
 #endif

@@ -189,6 +189,7 @@ __global__ void __launch_bounds__(PB) plan_graph_kernel(int32_t* plan, PlanLayou
             pos[v] = slot;
         }
     }
+    __syncthreads();  // pos[] is read across waves below: an unwritten LDS word is an arbitrary index into rp[]
 
     // ---- rows of the CSR: the node an edge feeds is its target (d=0) or its source (d=1)
     const int64_t* feed = d == 0 ? edge_index + E : edge_index;

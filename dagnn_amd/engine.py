@@ -71,6 +71,10 @@ SPLIT_DEEP = _env_int("DAGNN_AMD_SPLIT_DEEP", 1)            # 1: deep graphs on 
 BWD_THIN_WGS = _env_int("DAGNN_AMD_BWD_THIN_WGS", 0)        # backward: slice kernel vs rows + MFMA kernels; 0 = library default
 BWD_TAIL_REPLICAS = _env_int("DAGNN_AMD_BWD_TAIL_REPLICAS", 2)    # backward persistent kernel; 0 = one launch per layer
 BWD_TAIL_MAX_BLOCKS = _env_int("DAGNN_AMD_BWD_TAIL_MAX_BLOCKS", 4)
+# 1: plan / schedule kernels on a side stream next to the encoder + input GEMM.  Off by default - measured on MI355X: no
+# gain (2.405 vs 2.413 ms per forward); the GEMM's workgroups hold the CUs' LDS, so the 33-KB-LDS plan kernels only get
+# their turn as it drains (rocprofv3 timeline: plan_graph_kernel 101 us next to the GEMM, 60 us alone).
+PLAN_OVERLAP = _env_int("DAGNN_AMD_PLAN_OVERLAP", 0)
 DATAFLOW = _env_int("DAGNN_AMD_DATAFLOW", 1)                # 1: the persistent graph-affine dataflow kernel where it applies (H <= 256)
 DF_COST_LAYER = _env_int("DAGNN_AMD_DF_COST_LAYER", 8)      # schedule cost of one dependent layer, in rows (hop latency / row cost)
 DF_COST_ROW = _env_int("DAGNN_AMD_DF_COST_ROW", 1)
@@ -123,6 +127,14 @@ class PlanHandle(object):
         self.ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device)
         self.status = torch.zeros(4, dtype=torch.int32, device=device)
         self.desc = Plan(self.ws.data_ptr(), nbytes, self.N, self.E, self.B, self.R)
+        self.ready = None   # event to wait for when the plan was built on another stream
+
+    def wait_ready(self) -> None:
+        """Order the caller's stream behind the plan's construction (no-op for a plan built on this stream)."""
+        ev = getattr(self, "ready", None)
+        if ev is not None:
+            torch.cuda.current_stream(self.ws.device).wait_event(ev)
+            self.ready = None
 
     @classmethod
     def from_words(cls, ws: torch.Tensor, meta: dict, dataflow_words: Optional[torch.Tensor] = None) -> "PlanHandle":

@@ -323,12 +323,30 @@ class DAGNN(nn.Module):
                 c.invalidate()
         return super().train(mode)
 
-    def _plan_of(self, G, B):
+    def _plan_of(self, G, B, overlap: bool = False):
+        """The batch's plan.  With `overlap` the plan kernels (and the dataflow schedule's) run on a side stream next
+        to the encoder and the batched input GEMM, which do not depend on them; the recurrence waits for `plan.ready`."""
         if getattr(G, "_dagnn_plan", None) is not None:  # built by the loader (dagnn_amd.host_plan.attach_plan)
             return engine.PlanHandle.from_words(G._dagnn_plan, G._dagnn_plan_meta, getattr(G, "_dagnn_df", None))
         has_edge_enc = getattr(self.node_aggr_0[0], "wea", False)
-        return engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B,
-                                 G.edge_attr if has_edge_enc else None)
+        ea = G.edge_attr if has_edge_enc else None
+        if not (overlap and engine.PLAN_OVERLAP and G.edge_index.is_cuda):
+            return engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B, ea)
+        dev = G.edge_index.device
+        cur = torch.cuda.current_stream(dev)
+        side = self._arena_for(G.edge_index).side_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            plan = engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B, ea)
+            Hp = (self.hidden_dim + 63) // 64 * 64
+            groups = engine.dataflow_groups(dev, len(self.dirs), self.num_layers, Hp, B) if self.schedule == "lockstep" else 0
+            if groups > 0:
+                plan.dataflow_schedule(groups)
+            plan.ready = torch.cuda.Event()
+            plan.ready.record(side)
+        for t in (plan.ws, plan.status) + tuple(plan.__dict__.get("_df", {}).values()):
+            t.record_stream(cur)   # allocated on the side stream, used on the caller's from here on
+        return plan
 
     # ------------------------------------------------------------------------------ forward
     def forward(self, G):
@@ -356,10 +374,10 @@ class DAGNN(nn.Module):
         G.bi_layer_index = torch.stack([torch.stack([G._bi_layer_idx0, G._bi_layer_index0], dim=0),
                                         torch.stack([G._bi_layer_idx1, G._bi_layer_index1], dim=0)], dim=0)
         B = num_graphs_of(G)
+        plan = self._plan_of(G, B, overlap=True)   # (optionally on a side stream, next to the encoder and the input GEMM)
         # side effects 2+3 (dagnn.py:139, utils.py:27): embedding replaces G.x, depth clamped in place
         G.x = self.encoder(G.x, G.node_depth.view(-1, ))
         x = G.x
-        plan = self._plan_of(G, B)
         fused_readout = self.bidirectional and not self.output_all and self.out_pool == K.P_MAX
         if train:
             self._head_cache.invalidate()   # the optimizer step that follows may not bump version counters

@@ -20,6 +20,8 @@ with torch.no_grad():
 torch.cuda.synchronize()
 st = engine.DEBUG_TIMING.cpu().numpy()
 engine.DEBUG_TIMING = None
+if os.environ.get("DUMP"):   # raw stamps for offline analysis (scripts/df_stamp_layers.py)
+    np.save(os.environ["DUMP"], st[:2 * 1024 + 8 * 4096])
 cus = torch.cuda.get_device_properties(dev).multi_processor_count
 ncell, NS = 2 * (2 * L - 1), H // 32
 G = min(cus // (ncell * NS), B)

@@ -41,7 +41,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int DF_JS = 32;      // hidden units per slice
 constexpr int DF_RB = 4;       // rows per block = loader waves
 constexpr int DF_NCW = 4;      // compute waves
-constexpr int DF_NLS = 2;      // loader sets: set s takes the blocks b = s (mod NLS) - a block costs a loader wave one trip to
+constexpr int DF_NLS = 2;      // streams per workgroup = loader sets: set s serves group NLS * pair + s - a block costs a loader wave one trip to
                                // memory plus ~1 us of scalar work, twice what the compute waves need for it
 #ifndef DF_NSLOT_V
 #define DF_NSLOT_V 4
@@ -335,18 +335,18 @@ __device__ __forceinline__ float df_tanh(float x) { return 1.0f - 2.0f * __built
 
 // operand rows in LDS: the K dimension is split over 8 lanes (KP8 = H / 8 = 2 KPT values each); K-lane segment s
 // starts at s * (KP8 + 4): the 8 segments a half DPP row reads concurrently (ds_read_b128) fall on disjoint banks
-template <int KPT> struct DfPad { static constexpr int kp8 = 2 * KPT; static constexpr int seg = kp8 + 4; static constexpr int row = 8 * seg; };
+template <int KPT> struct DfPad { static constexpr int kp8 = 2 * KPT; static constexpr int seg = kp8 + 4; static constexpr int row = 8 * seg + 8; };
 
 constexpr int DF_RD = 6;       // a loader wave requests a row record this many of ITS blocks ahead (record ring: 8 entries)
 constexpr int DF_GD = 2;       // a gi0 slice this many (its node id must have landed: DF_RD >= DF_GD + 2)
-constexpr int DF_GIRING = DF_NSLOT + DF_NLS * DF_GD + 2;   // blocks in the gi0 ring: slots in use + prefetch distance + slack
+constexpr int DF_GIRING = DF_NSLOT + DF_GD + 2;   // blocks in a stream's gi0 ring: slots in use + prefetch distance + slack
 
 struct DfLds {
-    float* ring;     // NSLOT x slot
-    float* giring;   // [DF_GIRING][RB][96]: gi0 slices of the slice's rows, landed by LDS-DMA two blocks ahead
+    float* ring;     // [NLS][NSLOT] slots: a ring per stream
+    float* giring;   // [NLS][DF_GIRING][RB][96]: gi0 slices of the slice's rows, landed by LDS-DMA two blocks ahead
     int* rec;        // [NLS * RB][8][16]: row records of the loader waves, landed by LDS-DMA DF_RD of their blocks ahead
     int* rdy;        // [NLS * RB]   per loader wave: blocks it has finished (relaxed workgroup-scope atomics: plain ds_ accesses;
-    int* dn;         // [NCW]  per compute wave likewise        a volatile access here compiles to a FLAT load + vmcnt(0))
+    int* dn;         // [NLS][NCW]  per stream and compute wave likewise   a volatile access here compiles to a FLAT load + vmcnt(0))
 };
 
 template <int KPT> struct DfSlot {
@@ -411,6 +411,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
     const float gain0 = R >= 1 ? C.gain[0] : 0.f, gain1 = R >= 2 ? C.gain[1] : 0.f;
     unsigned long long* const dbg = S.dbg ? S.dbg + 2 * gridDim.x : nullptr;
     const gran_t ready = (gran_t)epoch << 32;
+    int* const dn = lds.dn + set * DF_NCW;   // this stream's slots
     // a lane holds columns {lane, 64 + lane, 128 + lane, 192 + lane} of a row (the first NQ4 = H / 64 of them): load
     // instruction q of a sweep then covers 512 contiguous bytes of the row (granules [64q, 64q + 64)) - a quarter of
     // the cache lines a lane-owns-4-consecutive-granules sweep asks for
@@ -494,29 +495,30 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
     // (DF_GIRING blocks x RB rows x 384 B: compute reads entry b % DF_GIRING)
     int* const rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
     const unsigned rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
-    const unsigned gi_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds.giring + lw * (3 * DF_JS)));
+    const unsigned gi_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds.giring + (set * DF_GIRING * DF_RB + lw) * (3 * DF_JS)));
     const int32_t* rec_w = reinterpret_cast<const int32_t*>(recs) + (lane & 15);
     const int64_t wstride = 16 * DF_RB;   // words per block
     const int gi_lane_off = ((lane % 24) >> 3) * H + sl * DF_JS + 4 * (lane & 7);
     auto rec_dma = [&](int j) {   // record of this wave's j-th block (past the end: the last block's again) -> ring entry j & 7
-        if (lane < 16) glds4(rec_w + (int64_t)min(DF_NLS * j + set, nblk - 1) * wstride, rec_ring_a + (j & 7) * 64);
+        if (lane < 16) glds4(rec_w + (int64_t)min(j, nblk - 1) * wstride, rec_ring_a + (j & 7) * 64);
     };
     auto gi_dma = [&](int blk, int node) {   // gi0 slice of `node` -> gi ring entry blk % DF_GIRING, row lw
         if (lane < 24) glds16(gi0 + (int64_t)max(node, 0) * 3 * H + gi_lane_off, gi_ring_a + (blk % DF_GIRING) * (DF_RB * 3 * DF_JS * 4));
     };
-    if (nblk > set) {   // prologue: records of this wave's blocks 0..RD-1, gi0 slices of its blocks 0..GD-1
+    if (nblk > 0) {   // prologue: records of this wave's blocks 0..RD-1, gi0 slices of its blocks 0..GD-1
 #pragma unroll
         for (int j = 0; j < DF_RD; ++j) rec_dma(j);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (has_gi0) {
 #pragma unroll
-            for (int j = 0; j < DF_GD; ++j) gi_dma(DF_NLS * j + set, __builtin_amdgcn_readfirstlane(rec_ring[j * 16]));
+            for (int j = 0; j < DF_GD; ++j) gi_dma(j, __builtin_amdgcn_readfirstlane(rec_ring[j * 16]));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
 
     Sweep A, A2;
-    for (int b = set, j = 0; b < nblk; b += DF_NLS, ++j) {
+    for (int b = 0; b < nblk; ++b) {
+        const int j = b;
         const int cur = rec_ring[(j & 7) * 16 + (lane & 15)];
 #define DF_W(i) __builtin_amdgcn_readlane(cur, i)
         const int4 r0 = make_int4(DF_W(0), DF_W(1), DF_W(2), DF_W(3));
@@ -526,20 +528,20 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
 #undef DF_W
         const int v2 = __builtin_amdgcn_readfirstlane(rec_ring[((j + DF_GD) & 7) * 16]);   // node of this wave's block j + GD (landed long ago)
         const int slot = b % DF_NSLOT;
-        float* sbase = lds.ring + slot * Slot::words;
+        float* sbase = lds.ring + (set * DF_NSLOT + slot) * Slot::words;
         int* v_s = reinterpret_cast<int*>(sbase + Slot::v_off);
         const int v = r0.x;
-        if (prof) dbg[8 * (int64_t)b + 4] = wall_clock64();
+        if (prof) dbg[8 * (int64_t)(DF_NLS * b + set) + 4] = wall_clock64();
         unsigned polls = 0;
         auto prefetch = [&]() {   // P(b): exactly 1 (+1 with gi0) loads, whatever the block looks like
             rec_dma(j + DF_RD);
-            if (has_gi0) gi_dma(b + DF_NLS * DF_GD, v2);
+            if (has_gi0) gi_dma(b + DF_GD, v2);
         };
 #if DF_EXPERIMENT == 9
         if (v >= -1) {
             prefetch();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (b >= DF_NSLOT) df_wait4(lds.dn, b - DF_NSLOT + 1, err, spin_limit);
+            if (b >= DF_NSLOT) df_wait4(dn, b - DF_NSLOT + 1, err, spin_limit);
         } else
 #endif
         if (v >= 0) {
@@ -655,7 +657,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                 unsigned pend = (1u << nn) - 1u, pend2 = (1u << nn2) - 1u;   // wave-uniform: rows still missing
                 unsigned spins = 0;
 #if DF_EXPERIMENT == 8
-                if (prof && c0 == 0) dbg[8 * (int64_t)b + 4] = wall_clock64();
+                if (prof && c0 == 0) dbg[8 * (int64_t)(DF_NLS * b + set) + 4] = wall_clock64();
 #endif
                 unsigned long long t_issue = prof ? wall_clock64() : 0ull;
                 issue(A, pj, pend, p_pending, gp_in);
@@ -667,7 +669,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                     if (two) landed_rows(A2);
                 }
 #if DF_EXPERIMENT == 8
-                if (prof && c0 == 0) dbg[8 * (int64_t)b + 5] = wall_clock64();
+                if (prof && c0 == 0) dbg[8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64();
 #endif
                 for (;;) {
                     harvest(A, pend);
@@ -692,11 +694,11 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                 }
 #if DF_EXPERIMENT != 8
                 if (prof && c0 == 0) {
-                    dbg[8 * (int64_t)b + 5] = wall_clock64(); dbg[8 * (int64_t)b + 6] = polls;
-                    if (b >= 8) dbg[8 * (int64_t)b + 7] = t_issue;   // when the poll that found the row was issued
+                    dbg[8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64(); dbg[8 * (int64_t)(DF_NLS * b + set) + 6] = polls;
+                    if (DF_NLS * b + set >= 8) dbg[8 * (int64_t)(DF_NLS * b + set) + 7] = t_issue;   // when the poll that found the row was issued
                 }
 #else
-                if (prof && c0 == 0) dbg[8 * (int64_t)b + 6] = polls;
+                if (prof && c0 == 0) dbg[8 * (int64_t)(DF_NLS * b + set) + 6] = polls;
 #endif
                 if (deg == 1) {
 #pragma unroll
@@ -713,7 +715,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] *= inv;
             }
-            if (b >= DF_NSLOT) df_wait4(lds.dn, b - DF_NSLOT + 1, err, spin_limit);   // the ring slot is free again
+            if (b >= DF_NSLOT) df_wait4(dn, b - DF_NSLOT + 1, err, spin_limit);   // the ring slot is free again
             float* a_row = sbase + Slot::a_off + lw * Slot::AP;
 #pragma unroll
             for (int q = 0; q < NQ4; ++q) a_row[cpos[q]] = acc[q];
@@ -725,105 +727,79 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
             prefetch();   // an idle row keeps the cadence: P(b) out, P(b - 1) landed
             if (has_gi0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            if (b >= DF_NSLOT) df_wait4(lds.dn, b - DF_NSLOT + 1, err, spin_limit);
+            if (b >= DF_NSLOT) df_wait4(dn, b - DF_NSLOT + 1, err, spin_limit);
         }
         if (lane == 0) v_s[lw] = v;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) df_flag_st(lds.rdy + set * DF_RB + lw, b + 1);
-        if (prof) dbg[8 * (int64_t)b + 3] = wall_clock64();
+        if (prof) dbg[8 * (int64_t)(DF_NLS * b + set) + 3] = wall_clock64();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of ours is in flight when the wave ends
 #undef DF_LD_GRAN
 #undef DF_TOUCH
 }
 
-// Products of this lane's K range for rows 0..NR-1 (NR <= 2): acc[r][0..2] += (r, z, n) rows of the resident matrix
-// slice x the operand row in LDS; the two halves of a v2f take even / odd k.  The operand loads run PF steps ahead of
-// the products.
-template <int KPT, int NR>
-__device__ __forceinline__ void df_mac(v2f (&acc)[2][3], const v2f (&wr)[KPT], const v2f (&wz)[KPT],
-                                       const v2f (&wn)[KPT], const float* a_seg) {
-    constexpr int AP = DfPad<KPT>::row;
-    constexpr int NK4 = DfPad<KPT>::kp8 / 4;   // float4 steps over the lane's K range
-    constexpr int PF = NK4 < 2 ? NK4 : 2;
-    float4 av[NK4][NR];
-#pragma unroll
-    for (int q = 0; q < PF; ++q)
-#pragma unroll
-        for (int r = 0; r < NR; ++r) av[q][r] = *reinterpret_cast<const float4*>(a_seg + r * AP + 4 * q);
-#pragma unroll
-    for (int q = 0; q < NK4; ++q) {
-        if (q + PF < NK4) {
-#pragma unroll
-            for (int r = 0; r < NR; ++r) av[q + PF][r] = *reinterpret_cast<const float4*>(a_seg + r * AP + 4 * (q + PF));
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep the loads this far ahead of their use
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const v2f lo = {av[q][r].x, av[q][r].y}, hi = {av[q][r].z, av[q][r].w};
-            acc[r][0] = __builtin_elementwise_fma(lo, wr[2 * q], acc[r][0]);
-            acc[r][1] = __builtin_elementwise_fma(lo, wz[2 * q], acc[r][1]);
-            acc[r][2] = __builtin_elementwise_fma(lo, wn[2 * q], acc[r][2]);
-            acc[r][0] = __builtin_elementwise_fma(hi, wr[2 * q + 1], acc[r][0]);
-            acc[r][1] = __builtin_elementwise_fma(hi, wz[2 * q + 1], acc[r][1]);
-            acc[r][2] = __builtin_elementwise_fma(hi, wn[2 * q + 1], acc[r][2]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int CTRL> __device__ __forceinline__ float df_dpp(float v) {   // 0 where the source lane is outside the DPP row
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// x + (x of the lane 16 away, i.e. the neighbouring DPP row of the pair): v_permlane16_swap on two copies of x leaves
+// rows (0, 0, 2, 2) in one and (1, 1, 3, 3) in the other
+__device__ __forceinline__ float df_row_pair_sum(float x) {
+    // (inline asm: with both operands holding the same value hipcc 7.2 folds the builtin's two results into one and
+    // emits v1 + v1 behind the swap; volatile also keeps it out of the divergent branch that uses the sum)
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
 }
 
-// inclusive scan over each group of 8 lanes (row_shr 1, 2, 4; lanes shifted in from outside the row read 0): lanes 7
-// and 15 of every DPP row end with the totals of their half, always in the same order -> deterministic
-__device__ __forceinline__ float df_dpp_sum8(float v) {
-#define DF_DPP_ADD(ctrl) \
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
-    DF_DPP_ADD(0x111); DF_DPP_ADD(0x112); DF_DPP_ADD(0x114);
-#undef DF_DPP_ADD
-    return v;
-}
-// lane i reads lane i + n of its DPP row (row_shl:n)
-template <int N> __device__ __forceinline__ float df_dpp_shl(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
-}
-
-// ---- compute wave `cw`: hidden units [8 cw, 8 cw + 8) of the slice, every block of this group.
-// Lane = (unit g8 = lane >> 3 of the wave's 8, K-lane ks = lane & 7): it holds the r / z / n rows of the cell's matrix
-// for ITS unit over k in [ks * H/8, (ks + 1) * H/8) (96 registers at H = 256), products accumulate as even / odd k
-// pairs (v_pk_fma_f32 straight on the LDS operand pairs), the K reduction is three DPP row shifts, and the lane the
-// totals end in (ks = 7) already holds all three sums of its unit: it evaluates the gates and stores h' itself (rows
-// 1..3 of a block are handed to lanes ks = 6, 5, 4 with one more DPP shift) - no LDS exchange, no barrier.
+// ---- compute wave `cw`: hidden units [8 cw, 8 cw + 8) of the slice, every block of the workgroup's streams.
+// The products run on the matrix cores as v_mfma_f32_4x4x1 (16 independent 4 x 4 x 1 outer products per instruction:
+// the only MFMA shape a 4-row block fills).  Lane = (unit quad = lane >> 5, K slice ks = (lane >> 2) & 7, x = lane & 3):
+//   A operand  W[unit 4 quad + x][k]   - this lane's 3 x H/8 resident weights (k in [ks H/8, (ks + 1) H/8))
+//   B operand  a[row x][k]             - the block's operand rows from LDS: H/8 floats per lane and block (the whole
+//                                        4 x H block is read ONCE per wave; the FMA layout read it 8 times)
+//   D[i][x] (register i) += W[unit 4 quad + i][k] a[row x][k]   for the lane's K slice,
+// 3 H/8 instructions per block whatever the number of live rows.  The 8 K slices are then summed by a reduce-scatter
+// over the lanes (ks bit 0: DPP row_shl/shr 4 keeps units {0,1} / {2,3}; bit 1: row_shl/shr 8 keeps one unit; bit 2:
+// v_permlane16_swap adds the neighbouring row): lane (quad, ks, x) ends with all three gate sums of unit
+// 4 quad + 2 (ks & 1) + ((ks >> 1) & 1) for row x, evaluates the gates and stores h' itself - no LDS exchange, no
+// barrier.  Always the same order of additions -> deterministic.
 template <int KPT>
-__device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int sl, int group, const DfLds& lds, int cw) {
+__device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int sl, int pair, const DfLds& lds, int cw) {
     constexpr int H = 16 * KPT;
     constexpr int SEG = DfPad<KPT>::seg, KP8 = DfPad<KPT>::kp8, NK4 = KP8 / 4;
     typedef DfSlot<KPT> Slot;
     const int tc = threadIdx.x;   // 0..255
     const int lane = tc & 63;
-    const int g8 = lane >> 3, ks = lane & 7;
+    const int quad = lane >> 5, ks = (lane >> 2) & 7, x = lane & 3;
+    const bool s0 = (ks & 1) != 0, s1 = (ks & 2) != 0;
     const bool proj = C.kind == DF_PROJECTION;
     const bool has_gi = C.gi0 != nullptr || C.p_in != nullptr;
     const bool gi_ring = C.gi0 != nullptr;   // (read once: a field access in the loop is a scalar load + lgkmcnt(0) per block)
     const int d = C.dir;
-    const int nblk = S.sched[S.gtab[d] + 2 * group + 1];
-    v2f wr[KPT], wz[KPT], wn[KPT];   // KP8 / 2 k pairs per gate
+    // the two streams of this workgroup: groups NLS * pair and NLS * pair + 1 (the second may not exist)
+    const int nb0 = S.sched[S.gtab[d] + 2 * (DF_NLS * pair) + 1];
+    const int nb1 = DF_NLS * pair + 1 < S.groups ? S.sched[S.gtab[d] + 2 * (DF_NLS * pair + 1) + 1] : 0;
+    float wr[KP8], wz[KP8], wn[KP8];   // the lane's K slice of the r / z / n rows of its unit
     {
         const float4* wp = C.w + (int64_t)sl * (3 * NK4) * 256 + tc;
 #pragma unroll
         for (int q = 0; q < NK4; ++q) {
             const float4 x0 = wp[(0 * NK4 + q) * 256], x1 = wp[(1 * NK4 + q) * 256], x2 = wp[(2 * NK4 + q) * 256];
-            wr[2 * q] = (v2f){x0.x, x0.y}; wr[2 * q + 1] = (v2f){x0.z, x0.w};
-            wz[2 * q] = (v2f){x1.x, x1.y}; wz[2 * q + 1] = (v2f){x1.z, x1.w};
-            wn[2 * q] = (v2f){x2.x, x2.y}; wn[2 * q + 1] = (v2f){x2.z, x2.w};
+            wr[4 * q] = x0.x; wr[4 * q + 1] = x0.y; wr[4 * q + 2] = x0.z; wr[4 * q + 3] = x0.w;
+            wz[4 * q] = x1.x; wz[4 * q + 1] = x1.y; wz[4 * q + 2] = x1.z; wz[4 * q + 3] = x1.w;
+            wn[4 * q] = x2.x; wn[4 * q + 1] = x2.y; wn[4 * q + 2] = x2.z; wn[4 * q + 3] = x2.w;
         }
         // the weights have landed before the block loop starts: otherwise the first use inside the loop carries a
         // vmcnt(0), which - every block - also waits for the acknowledgement of the previous block's state stores
 #pragma unroll
-        for (int k = 0; k < KPT; ++k) asm volatile("" : "+v"(wr[k]), "+v"(wz[k]), "+v"(wn[k]));
+        for (int k = 0; k < KP8; ++k) asm volatile("" : "+v"(wr[k]), "+v"(wz[k]), "+v"(wn[k]));
     }
-    const int unit_l = 8 * cw + g8, unit = sl * DF_JS + unit_l;
+    const int unit_l = 8 * cw + 4 * quad + 2 * (ks & 1) + ((ks >> 1) & 1), unit = sl * DF_JS + unit_l;   // after the reduction
     float b_r = C.bias[unit], b_z = C.bias[H + unit], b_n = C.bias[2 * H + unit];
     asm volatile("" : "+v"(b_r), "+v"(b_z), "+v"(b_n));   // landed before the loop (see the weights above)
-    const int gr = 7 - ks;   // row of the block this lane evaluates the gates of (K-lanes 7, 6, 5, 4 -> rows 0..3)
+    const int gr = x;   // row of the block this lane evaluates the gates of
     const int apos = unit + (SEG - KP8) * (unit / KP8);   // LDS position of column `unit` of an operand row
     const unsigned epoch = S.epoch, spin_limit = S.spin_limit;
     int* const err = S.err;
@@ -833,64 +809,90 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     unsigned long long* const dbg = S.dbg ? S.dbg + 2 * gridDim.x : nullptr;
     const bool prof = dbg != nullptr && (int)blockIdx.x == S.dbg_wg && cw == 0 && lane == 0;
 
-    for (int b = 0; b < nblk; ++b) {
+    // Blocks of the two streams in whatever order they become ready.  A stream inside a thin dependent chain is ready
+    // once per hop (~3 us, of which this wave works ~0.8): the other stream's blocks fill the gap.  When both have a
+    // block, the one whose loader is LESS far ahead goes first (it is the latency-bound one); ties alternate.
+    int done0 = 0, done1 = 0, pref = 0;
+    while (done0 < nb0 || done1 < nb1) {
+        int st;
+        {
+            unsigned spins = 0;
+            for (;;) {
+                int lead0 = 0, lead1 = 0;
+                if (done0 < nb0) {
+                    const int a = df_flag_ld(lds.rdy), b_ = df_flag_ld(lds.rdy + 1), c = df_flag_ld(lds.rdy + 2), e = df_flag_ld(lds.rdy + 3);
+                    lead0 = min(min(a, b_), min(c, e)) - done0;
+                }
+                if (done1 < nb1) {
+                    const int a = df_flag_ld(lds.rdy + DF_RB), b_ = df_flag_ld(lds.rdy + DF_RB + 1), c = df_flag_ld(lds.rdy + DF_RB + 2),
+                              e = df_flag_ld(lds.rdy + DF_RB + 3);
+                    lead1 = min(min(a, b_), min(c, e)) - done1;
+                }
+                if (lead0 > 0 || lead1 > 0) {
+                    st = lead1 <= 0 ? 0 : (lead0 <= 0 ? 1 : (lead0 < lead1 ? 0 : (lead1 < lead0 ? 1 : pref)));
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > 4 * spin_limit) {   // the pass is lost; it must still end (node ids are bounded below)
+                    __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    st = done0 < nb0 ? 0 : 1;
+                    break;
+                }
+                if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { st = done0 < nb0 ? 0 : 1; break; }
+            }
+        }
+        st = __builtin_amdgcn_readfirstlane(st);
+        pref = st ^ 1;
+        const int b = st ? done1 : done0;
+        if (st) ++done1; else ++done0;
         const int slot = b % DF_NSLOT;
-        const float* sbase = lds.ring + slot * Slot::words;
-        df_wait4(lds.rdy + (b % DF_NLS) * DF_RB, b + 1, err, spin_limit);   // the loader set that owns block b
-        if (prof) dbg[8 * (int64_t)b + 0] = wall_clock64();
+        const float* sbase = lds.ring + (st * DF_NSLOT + slot) * Slot::words;
+        if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 0] = wall_clock64();
         const int4 ids = *reinterpret_cast<const int4*>(sbase + Slot::v_off);
         const int nr = (ids.x >= 0) + (ids.y >= 0) + (ids.z >= 0) + (ids.w >= 0);   // live records come first
-        const float* a_seg = sbase + Slot::a_off + ks * SEG;
+        const float* a_seg = sbase + Slot::a_off + x * Slot::AP + ks * SEG;   // B operand: row x, K slice ks
         // operands of the gate algebra: requested now, used after the products
         float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, aval = 0.f;
         if (!proj && gr < nr) {
             if (has_gi) {   // from the gi0 ring (stacked layer 0) or from the slot (projection granules)
-                const float* gp = (gi_ring ? lds.giring + (b % DF_GIRING) * (DF_RB * 3 * DF_JS) : sbase + Slot::gi_off) + gr * (3 * DF_JS) + unit_l;
+                const float* gp = (gi_ring ? lds.giring + (st * DF_GIRING + b % DF_GIRING) * (DF_RB * 3 * DF_JS) : sbase + Slot::gi_off) + gr * (3 * DF_JS) + unit_l;
                 gi_r = gp[0]; gi_z = gp[DF_JS]; gi_n = gp[2 * DF_JS];
             }
             aval = sbase[Slot::a_off + gr * Slot::AP + apos];
         }
-        // two rows per pass (resident weights + accumulators + operands in flight fill the register budget); K
-        // reduction; row r's totals move from K-lane 7 to K-lane 7 - r, which finishes that row
-        float g3[3] = {0.f, 0.f, 0.f};
+        float g3[3];
+        {
+            float4 bv[NK4];
 #pragma unroll
-        for (int rb = 0; rb < DF_RB; rb += 2) {
-            if (rb < nr) {
-                v2f acc[2][3];
+            for (int q = 0; q < NK4; ++q) bv[q] = *reinterpret_cast<const float4*>(a_seg + 4 * q);
+            f4v acc[3] = {(f4v){0.f, 0.f, 0.f, 0.f}, (f4v){0.f, 0.f, 0.f, 0.f}, (f4v){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
+            for (int q = 0; q < NK4; ++q) {
+                const float bq[4] = {bv[q].x, bv[q].y, bv[q].z, bv[q].w};
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) acc[r][a] = (v2f){0.f, 0.f};
-                const bool two = nr - rb >= 2;
-                if (two) df_mac<KPT, 2>(acc, wr, wz, wn, a_seg + rb * Slot::AP);
-                else df_mac<KPT, 1>(acc, wr, wz, wn, a_seg + rb * Slot::AP);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (j == 0 || two) {
-                        float t[3];
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) t[a] = df_dpp_sum8(acc[j][a].x + acc[j][a].y);
-                        if (rb + j == 1) {
-#pragma unroll
-                            for (int a = 0; a < 3; ++a) t[a] = df_dpp_shl<1>(t[a]);
-                        } else if (rb + j == 2) {
-#pragma unroll
-                            for (int a = 0; a < 3; ++a) t[a] = df_dpp_shl<2>(t[a]);
-                        } else if (rb + j == 3) {
-#pragma unroll
-                            for (int a = 0; a < 3; ++a) t[a] = df_dpp_shl<3>(t[a]);
-                        }
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) g3[a] = gr == rb + j ? t[a] : g3[a];
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q + e], bq[e], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wz[4 * q + e], bq[e], acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(wn[4 * q + e], bq[e], acc[2], 0, 0, 0);
                 }
             }
+            // reduce-scatter over the 8 K slices
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                        // (every DPP op outside the selects: inside a divergent branch its source lanes would be switched off)
+                const float u0 = acc[a][0] + df_dpp<0x104>(acc[a][0]), u1 = acc[a][1] + df_dpp<0x104>(acc[a][1]);   // + the lane 4 up
+                const float u2 = acc[a][2] + df_dpp<0x114>(acc[a][2]), u3 = acc[a][3] + df_dpp<0x114>(acc[a][3]);   // + the lane 4 down
+                const float e0 = s0 ? u2 : u0, e1 = s0 ? u3 : u1;   // units (2, 3) | (0, 1) of the quad
+                const float f0 = e0 + df_dpp<0x108>(e0), f1 = e1 + df_dpp<0x118>(e1);
+                const float f = s1 ? f1 : f0;
+                g3[a] = df_row_pair_sum(f);
+            }
         }
-        if (prof) dbg[8 * (int64_t)b + 1] = wall_clock64();
+        if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 1] = wall_clock64();
         // (the bound on the node id only matters once a wait has expired and the slot may hold anything: the pass is
         // lost then, but it must not write outside its buffers)
         int gv = gr == 0 ? ids.x : (gr == 1 ? ids.y : (gr == 2 ? ids.z : ids.w));
-        const bool live = gr < nr && (unsigned)gv < (unsigned)num_nodes;
+        const bool live = gr < nr && (unsigned)gv < (unsigned)num_nodes && (lane & 16) == 0;   // (lanes 16 away hold the same sums)
         float hv = 0.f;
         if (live) {
             if (!proj) {
@@ -901,7 +903,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) df_flag_st(lds.dn + cw, b + 1);   // this wave is done with the slot (LDS executes a wave's accesses in order)
+        if (lane == 0) df_flag_st(lds.dn + st * DF_NCW + cw, b + 1);   // this wave is done with the slot (LDS executes a wave's accesses in order)
         if (live) {
             if (proj) {   // input-side pre-activations of the upper cell: W_ih u + b_ih, gate-major
                 gran_t* po = g_out + (int64_t)gv * pld + unit;
@@ -913,7 +915,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
                 __hip_atomic_store(g_out + (int64_t)gv * gld + unit, gran_pack(epoch, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if (prof) dbg[8 * (int64_t)b + 2] = wall_clock64();
+        if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 2] = wall_clock64();
     }
 }
 
@@ -928,35 +930,40 @@ __global__ void __launch_bounds__(DF_THREADS, 3) dataflow_kernel(const int32_t* 
         return;
     }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int per_group = S.ncell * NS;
-    const int group = blockIdx.x / per_group;
-    const int rem = blockIdx.x - group * per_group;
+    // a workgroup serves NLS groups ("streams"): workgroup ids are pair-major, then cell, then slice
+    const int per_pair = S.ncell * NS;
+    const int pair = blockIdx.x / per_pair;
+    const int rem = blockIdx.x - pair * per_pair;
     const int c = rem / NS, sl = rem - c * NS;
     const DfCell& C = S.cell[c];
     DfLds lds;
     lds.ring = smem;
-    lds.giring = lds.ring + DF_NSLOT * Slot::words;
-    lds.rec = reinterpret_cast<int*>(lds.giring + DF_GIRING * DF_RB * 3 * DF_JS);
+    lds.giring = lds.ring + DF_NLS * DF_NSLOT * Slot::words;
+    lds.rec = reinterpret_cast<int*>(lds.giring + DF_NLS * DF_GIRING * DF_RB * 3 * DF_JS);
     int* flags = lds.rec + DF_NLS * DF_RB * 8 * 16;
     lds.rdy = flags;
     lds.dn = flags + DF_NLS * DF_RB;
-    if (tid < DF_NLS * DF_RB + DF_NCW) flags[tid] = 0;
+    if (tid < DF_NLS * (DF_RB + DF_NCW)) flags[tid] = 0;
     if (S.dbg && tid == 0) S.dbg[2 * blockIdx.x] = wall_clock64();
     if (S.dbg && (int)blockIdx.x == S.dbg_wg && (tid & 63) == 0)   // where the waves of the stamped workgroup run (HW_REG_HW_ID)
         if (wave < 8) S.dbg[2 * gridDim.x + 8 * (int64_t)wave + 7] = 0x100000000ull | __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
     __syncthreads();
-    if (wave < DF_NCW) df_compute<KPT>(S, C, sl, group, lds, wave);
-    else df_loader<KPT>(plan, S, C, sl, group, lds, (wave - DF_NCW) % DF_RB, (wave - DF_NCW) / DF_RB);
+    if (wave < DF_NCW) {
+        df_compute<KPT>(S, C, sl, pair, lds, wave);
+    } else {
+        const int set = (wave - DF_NCW) / DF_RB;
+        if (DF_NLS * pair + set < S.groups) df_loader<KPT>(plan, S, C, sl, DF_NLS * pair + set, lds, (wave - DF_NCW) % DF_RB, set);
+    }
     if (S.dbg && tid == 0) S.dbg[2 * blockIdx.x + 1] = wall_clock64();   // compute wave 0 is done
 }
 
 template <int KPT> size_t df_lds_bytes() {
-    return (size_t)(DF_NSLOT * DfSlot<KPT>::words + DF_GIRING * DF_RB * 3 * DF_JS + DF_NLS * DF_RB * 8 * 16) * 4 + 64;
+    return (size_t)DF_NLS * (DF_NSLOT * DfSlot<KPT>::words + DF_GIRING * DF_RB * 3 * DF_JS + DF_RB * 8 * 16) * 4 + 64;
 }
 
 // Pack W [3H, K = H] (torch GRUCell layout) for the dataflow kernel: out[(sl * NQ + q) * 256 + tc] (float4), NQ = 3 H/32,
-// q = gate * (H/32) + k4, thread tc = (compute wave w = tc >> 6, unit g8 = (tc >> 3) & 7, K-lane ks = tc & 7):
-// W[gate * H + 32 sl + 8 w + g8][ks * H/8 + 4 k4 .. + 3].
+// q = gate * (H/32) + k4, thread tc = (compute wave w = tc >> 6, unit quad = (tc >> 5) & 1, K slice ks = (tc >> 2) & 7, unit of
+// the quad x = tc & 3):  W[gate * H + 32 sl + 8 w + 4 quad + x][ks * H/8 + 4 k4 .. + 3]  (the A operands of df_compute).
 __global__ void __launch_bounds__(256) df_pack_kernel(const float* __restrict__ W, float4* __restrict__ out, int H, int64_t total) {
     const int kp8 = H >> 3, nk4 = kp8 >> 2, nq = 3 * nk4;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -965,7 +972,7 @@ __global__ void __launch_bounds__(256) df_pack_kernel(const float* __restrict__ 
         const int q = (int)(rest % nq);
         const int sl = (int)(rest / nq);
         const int g = q / nk4, k4 = q - g * nk4;
-        const int unit = sl * DF_JS + 8 * (tc >> 6) + ((tc >> 3) & 7), ks = tc & 7;
+        const int unit = sl * DF_JS + 8 * (tc >> 6) + 4 * ((tc >> 5) & 1) + (tc & 3), ks = (tc >> 2) & 7;
         out[idx] = *reinterpret_cast<const float4*>(W + (int64_t)(g * H + unit) * H + ks * kp8 + 4 * k4);
     }
 }
@@ -1010,7 +1017,7 @@ extern "C" int dagnn_dataflow_groups(int num_cus, int num_dirs, int num_stacked,
         return 0;
     const int kcells = num_dirs * (2 * num_stacked - 1);   // one projection cell per stacked layer above the first
     if (kcells > DF_MAX_KCELLS) return 0;
-    int64_t g = num_cus / (kcells * (H / DF_JS));
+    int64_t g = (int64_t)DF_NLS * (num_cus / (kcells * (H / DF_JS)));   // NLS groups per workgroup set
     if (g > DF_MAX_GROUPS) g = DF_MAX_GROUPS;
     if (g > B) g = B;
     return (int)g;
@@ -1121,7 +1128,7 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
     S.dbg_wg = a->debug_wg;
     S.status = (const int32_t*)a->plan_status;
     const int32_t* plan = (const int32_t*)pl->data;
-    const unsigned grid = (unsigned)(G * nc * (H / DF_JS));
+    const unsigned grid = (unsigned)((G + DF_NLS - 1) / DF_NLS * nc * (H / DF_JS));
     hipStream_t st = (hipStream_t)stream;
 #define DF_LAUNCH(KPT)                                                                                                   \
     do {                                                                                                                 \

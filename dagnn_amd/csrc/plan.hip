@@ -123,6 +123,7 @@ __global__ void __launch_bounds__(PB) plan_graph_kernel(int32_t* plan, PlanLayou
                                                          const int64_t* __restrict__ layer_bwd,
                                                          const float* __restrict__ edge_attr, int R,
                                                          int64_t N, int64_t E, int32_t* status) {
+    if (status && status[0] & 7) return;   // contract violated (plan_ptr_kernel): the tables are garbage - do not walk them (plan_seal_kernel)
     __shared__ int32_t lds[PB + 8];
     __shared__ int32_t s_depth;
     // graphs of up to PLAN_NMAX nodes (all of ogbg-code2's typical ASTs) keep their counters, cursors
@@ -218,9 +219,22 @@ __global__ void __launch_bounds__(PB) plan_graph_kernel(int32_t* plan, PlanLayou
     }
 }
 
+// Last kernel of the build.  Once the status word is set (unsorted `batch`, edges across graphs, layers out of range)
+// the tables above hold whatever the violated assumptions produced; every consumer - read-outs, per-layer launches,
+// the dataflow schedule - takes its loop bounds from the depths and the layer offsets, so zero those: the batch reads
+// as one without layers, nothing walks the garbage, and the host raises on the status word at its next poll.
+__global__ void __launch_bounds__(256) plan_seal_kernel(int32_t* plan, PlanLayout L, int64_t N, int64_t B,
+                                                         const int32_t* __restrict__ status) {
+    if (status[0] == 0) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) { plan[L.depth[0] + i] = 0; plan[L.depth[1] + i] = 0; }
+    if (i < N + 2) { plan[L.blptr[0] + i] = 0; plan[L.blptr[1] + i] = 0; plan[L.blsplit[0] + i] = 0; plan[L.blsplit[1] + i] = 0; }
+}
+
 // Work items (g*2+d) sorted by depth, deepest first, so that the hardware's in-order workgroup
 // dispatch starts the longest dependency chains first (LPT scheduling).
-__global__ void __launch_bounds__(1024) plan_items_kernel(int32_t* plan, PlanLayout L, int B) {
+__global__ void __launch_bounds__(1024) plan_items_kernel(int32_t* plan, PlanLayout L, int B, const int32_t* __restrict__ status) {
+    if (status && status[0] & 7) return;   // contract violated (plan_ptr_kernel): the tables are garbage - do not walk them (plan_seal_kernel)
     __shared__ int32_t keys[4096];
     const int n = 2 * B;
     for (int c0 = 0; c0 < n; c0 += 4096) {  // candidates staged through LDS, 4096 at a time
@@ -242,7 +256,8 @@ __global__ void __launch_bounds__(1024) plan_items_kernel(int32_t* plan, PlanLay
 
 // Batch-level layers (the lock-step schedule): blptr[d][t] = first rowrec slot of layer t over the
 // whole batch; T_d is stored at blptr[d][N+1].  One workgroup per direction.
-__global__ void __launch_bounds__(1024) plan_blptr_kernel(int32_t* plan, PlanLayout L, int N, int B) {
+__global__ void __launch_bounds__(1024) plan_blptr_kernel(int32_t* plan, PlanLayout L, int N, int B, const int32_t* __restrict__ status) {
+    if (status && status[0] & 7) return;   // contract violated (plan_ptr_kernel): the tables are garbage - do not walk them (plan_seal_kernel)
     __shared__ int32_t lds[1024 / 64 + 1];
     __shared__ int32_t s_T;
     const int d = blockIdx.x, tid = threadIdx.x;
@@ -288,7 +303,8 @@ __global__ void __launch_bounds__(1024) plan_blptr_kernel(int32_t* plan, PlanLay
 // group in graph order (deterministic slot assignment); blsplit[t] = first slot of the deep group.
 // One WAVE per batch-level layer: lane l takes graphs l, l+64, ...; an exclusive wave scan over the
 // per-graph row counts gives every graph its first slot (two memory round trips per 64 graphs).
-__global__ void __launch_bounds__(256) plan_lbase_kernel(int32_t* plan, PlanLayout L, int N, int B) {
+__global__ void __launch_bounds__(256) plan_lbase_kernel(int32_t* plan, PlanLayout L, int N, int B, const int32_t* __restrict__ status) {
+    if (status && status[0] & 7) return;   // contract violated (plan_ptr_kernel): the tables are garbage - do not walk them (plan_seal_kernel)
     const int d = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -326,7 +342,9 @@ __global__ void __launch_bounds__(256) plan_lbase_kernel(int32_t* plan, PlanLayo
 // lock-step kernel: its dependent chain is record -> predecessor rows.
 __global__ void __launch_bounds__(256) plan_rowrec_kernel(int32_t* plan, PlanLayout L, const int64_t* __restrict__ batch,
                                                            const int64_t* __restrict__ layer_fwd,
-                                                           const int64_t* __restrict__ layer_bwd, int N, int R) {
+                                                           const int64_t* __restrict__ layer_bwd, int N, int R,
+                                                           const int32_t* __restrict__ status) {
+    if (status && status[0] & 7) return;   // contract violated (plan_ptr_kernel): the tables are garbage - do not walk them (plan_seal_kernel)
     const int d = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;  // per-graph sorted position
     if (p >= N) return;
@@ -403,18 +421,23 @@ extern "C" int dagnn_plan_build(const dagnn_plan* pl, const int64_t* edge_index,
         hipLaunchKernelGGL(plan_graph_kernel, dim3((unsigned)B, 2), dim3(PB), 0, stream, p, L, edge_index,
                            layer_fwd, layer_bwd, edge_attr, R, N, E, status);
         DAGNN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(plan_items_kernel, dim3(1), dim3(1024), 0, stream, p, L, (int)B);
+        hipLaunchKernelGGL(plan_items_kernel, dim3(1), dim3(1024), 0, stream, p, L, (int)B, status);
         DAGNN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(plan_blptr_kernel, dim3(2), dim3(1024), 0, stream, p, L, (int)N, (int)B);
+        hipLaunchKernelGGL(plan_blptr_kernel, dim3(2), dim3(1024), 0, stream, p, L, (int)N, (int)B, status);
         DAGNN_CHECK_LAUNCH();
         if (N > 0) {
             hipLaunchKernelGGL(plan_lbase_kernel, dim3((unsigned)((N + 3) / 4), 2), dim3(256), 0, stream, p, L,
-                               (int)N, (int)B);
+                               (int)N, (int)B, status);
             DAGNN_CHECK_LAUNCH();
             hipLaunchKernelGGL(plan_rowrec_kernel, dim3((unsigned)((N + 255) / 256), 2), dim3(256), 0, stream, p, L,
-                               batch, layer_fwd, layer_bwd, (int)N, R);
+                               batch, layer_fwd, layer_bwd, (int)N, R, status);
             DAGNN_CHECK_LAUNCH();
         }
+    }
+    if (status) {   // a batch that violates the contract leaves an EMPTY plan behind, whatever the kernels above made of it
+        int64_t w = N + 2 > B ? N + 2 : B;
+        hipLaunchKernelGGL(plan_seal_kernel, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, stream, p, L, N, B, status);
+        DAGNN_CHECK_LAUNCH();
     }
     return DAGNN_OK;
 }

@@ -20,10 +20,13 @@ class KernelTimer(object):
     """Optional HIP-event timing of individual launches (bench.py): events are recorded on the
     stream the kernel is launched on (torch's current stream), so they bracket exactly that kernel."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.spans = {}
+        self.only = set(only) if only else None   # every event pair costs the stream ~8 us: time only what is asked for
 
     def span(self, name, device):
+        if self.only is not None and name not in self.only:
+            return _NoSpan()
         return _Span(self, name, device)
 
     def summary(self):
@@ -76,7 +79,7 @@ BWD_TAIL_MAX_BLOCKS = _env_int("DAGNN_AMD_BWD_TAIL_MAX_BLOCKS", 4)
 # their turn as it drains (rocprofv3 timeline: plan_graph_kernel 101 us next to the GEMM, 60 us alone).
 PLAN_OVERLAP = _env_int("DAGNN_AMD_PLAN_OVERLAP", 0)
 DATAFLOW = _env_int("DAGNN_AMD_DATAFLOW", 1)                # 1: the persistent graph-affine dataflow kernel where it applies (H <= 256)
-DF_COST_LAYER = _env_int("DAGNN_AMD_DF_COST_LAYER", 8)      # schedule cost of one dependent layer, in rows (hop latency / row cost)
+DF_COST_LAYER = _env_int("DAGNN_AMD_DF_COST_LAYER", 4)      # schedule cost of one dependent layer, in rows (hop latency / row cost)
 DF_COST_ROW = _env_int("DAGNN_AMD_DF_COST_ROW", 1)
 DF_GROUPS = _env_int("DAGNN_AMD_DF_GROUPS", 0)              # 0 = as many groups as the device hosts
 SPIN_LIMIT = _env_int("DAGNN_AMD_SPIN_LIMIT", 0)            # polls before a device-side wait gives up; 0 = library default

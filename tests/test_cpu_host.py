@@ -260,9 +260,10 @@ def test_dataflow_layout_matches_library():
         lay = host_plan.dataflow_layout(N, B, G)
         assert {k: lay[k] for k in names} == {k: int(v) // 4 for k, v in zip(names, off)}
         assert lay["total"] * 4 == lib.dagnn_dataflow_bytes(N, B, G)
-    # groups the device hosts: floor(CUs / (dirs * (2L - 1) * H / 32)), capped by the graphs; 0 = not applicable
-    assert lib.dagnn_dataflow_groups(256, 2, 2, 256, 128) == 5
-    assert lib.dagnn_dataflow_groups(256, 1, 2, 128, 64) == 21
+    # groups the device hosts: 2 per workgroup set, floor(CUs / (dirs * (2L - 1) * H / 32)) sets, capped by the graphs
+    # (and by the 64 groups the assignment kernel handles); 0 = not applicable
+    assert lib.dagnn_dataflow_groups(256, 2, 2, 256, 128) == 10
+    assert lib.dagnn_dataflow_groups(256, 1, 2, 128, 64) == 42
     assert lib.dagnn_dataflow_groups(256, 2, 2, 256, 3) == 3
     assert lib.dagnn_dataflow_groups(256, 2, 5, 512, 256) == 0 and lib.dagnn_dataflow_groups(256, 2, 2, 300, 8) == 0
     assert lib.dagnn_dataflow_groups(16, 2, 2, 256, 8) == 0

@@ -4,6 +4,7 @@ Drop-in modules with the reference's constructor / state_dict / forward(G) contr
 
     from dagnn_amd import DAGNN, ASTNodeEncoder        # ogbg-code/model/dagnn.py, ogbg-code/utils.py
     from dagnn_amd import DAGNN_NA, DAGNN_BN           # dvae/dagnn.py (DAGNN), dvae/dagnn_bn.py
+    from dagnn_amd import DataParallel                 # ogbg-code/tg/data_parallel.py (list[Batch] caller)
 
 The hot path runs in libdagnn_hip.so (hand-written HIP, C ABI in include/dagnn_hip.h); importing
 this package does not need a GPU, calling `forward` does.
@@ -15,5 +16,6 @@ from .host_plan import attach_plan, build_plan_host  # noqa: F401
 from .dvae import DAGNN_BN, DAGNN_NA  # noqa: F401
 from .model import DAGNN, ASTNodeEncoder  # noqa: F401
 from .train import GradBucket  # noqa: F401
+from .data_parallel import DataParallel  # noqa: F401
 
 __version__ = "0.1.0"

@@ -143,3 +143,67 @@ def test_two_rank_gradient_bucket_all_reduce_gloo():
     out = mgr.dict()
     mp.spawn(_train_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert len(out) == 2
+
+
+# ---------------------------------------------------------------- the reference's caller: DataParallel(list[Batch])
+class _RowSum(torch.nn.Module):
+    """Stand-in module: one output row per graph, differentiable in its parameter."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.tensor([0.5, -0.25]))
+
+    def forward(self, G):
+        n = torch.bincount(G.batch, minlength=G.num_graphs).float()
+        e = torch.bincount(G.batch[G.edge_index[0]], minlength=G.num_graphs).float()
+        return torch.stack([n, e], dim=1) @ self.w
+
+
+def test_data_parallel_shim_single_process_semantics():
+    """`tg/data_parallel.py:41-50`: empty list -> warning and None; one device -> `module(data_list[0])` only;
+    `.module` and the `module.`-prefixed state dict of the reference's checkpoints."""
+    from dagnn_amd import DataParallel
+    graphs = synth.code2_graphs(3, 6, 20)
+    shards = collate_sharded(graphs, 2)
+    dp = DataParallel(_RowSum(), device_ids=[])
+    with pytest.warns(UserWarning):
+        assert dp([]) is None
+    assert torch.equal(dp(shards), dp.module(shards[0]))
+    assert list(dp.state_dict().keys()) == ["module.w"]
+    assert dp.src_device.type == "cpu"
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dagnn_amd import DataParallel
+        graphs = synth.code2_graphs(11, 9, 25)
+        shards = collate_sharded(graphs, world)            # every rank builds the same list, as the reference's one loader
+        dp = DataParallel(_RowSum(), device_ids=[])
+        y = dp(shards)                                      # this rank's element
+        assert y.shape[0] == shards[rank].num_graphs
+        y.mean().backward()                                 # local mean loss
+        dp.reduce_gradients(local_count=shards[rank].num_graphs)
+        full = _RowSum()
+        full(synth.GraphBatch.from_data_list(graphs)).mean().backward()   # mean over the global batch
+        assert torch.allclose(dp.module.w.grad, full.w.grad, atol=1e-6)
+        dp.zero_grad()
+        assert float(dp.module.w.grad.abs().max()) == 0.0 and dp.module.w.grad.data_ptr() == dp._bucket.flat.data_ptr()
+        with pytest.raises(ValueError):
+            dp(shards + shards)
+        assert dp(shards[:1]) is None if rank == 1 else dp(shards[:1]) is not None   # a list shorter than the world
+        out[rank] = shards[rank].num_graphs
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_data_parallel_shim_gloo():
+    """k processes, one `data_list` each: rank r runs element r, and `reduce_gradients` gives every rank the
+    gradient of the mean loss over the global batch although the node-balanced shards differ in size."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert len(out) == 2 and sum(out.values()) == 9

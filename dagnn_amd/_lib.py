@@ -189,6 +189,12 @@ def load():
                     raise DagnnHipError(
                         "libdagnn_hip.so is missing and could not be built (%s). There is no CPU or "
                         "PyTorch fallback for the DAGNN hot path." % exc) from exc
+                # an OLDER library next to NEWER sources: its argument structs and plan layout may no longer match
+                # the ctypes mirrors in this file - that is memory corruption, not an error message
+                if os.environ.get("DAGNN_AMD_ALLOW_STALE", "0") != "1":
+                    raise DagnnHipError(
+                        "%s is older than its sources and the rebuild failed (%s); refusing to load a library whose "
+                        "ABI may differ from this package (set DAGNN_AMD_ALLOW_STALE=1 to load it anyway)" % (path, exc)) from exc
         try:
             lib = C.CDLL(path)
         except OSError as exc:

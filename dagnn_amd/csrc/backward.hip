@@ -986,17 +986,14 @@ extern "C" int dagnn_backward_run(const dagnn_plan* pl, const dagnn_backward_arg
         return DAGNN_OK;
     };
 
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    DagnnForkJoin fj;   // joins and releases its events on every return path
     if (split) {   // fork: the shallow graphs' chain on the side stream
         hipStream_t side = (hipStream_t)a->side_stream;
-        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
-            return DAGNN_EHIP(hipGetLastError());
-        hipEventRecord(ev_fork, st);
-        hipStreamWaitEvent(side, ev_fork, 0);
+        const hipError_t ef = fj.begin(st, side);
+        if (ef != hipSuccess) return DAGNN_EHIP(ef);
         const int rc = run_steps(side, 0, SHALLOW);
-        hipEventRecord(ev_join, side);
-        if (rc != DAGNN_OK) { hipEventDestroy(ev_fork); hipEventDestroy(ev_join); return rc; }
+        fj.mark();
+        if (rc != DAGNN_OK) return rc;
     }
     const int part = split ? DEEP : ALL;
 
@@ -1037,13 +1034,7 @@ extern "C" int dagnn_backward_run(const dagnn_plan* pl, const dagnn_backward_arg
             }
         }
     }
-    const int rc = run_steps(st, s_first, part);
-    if (split) {   // join: the caller's stream continues only when the shallow graphs are finished too
-        hipStreamWaitEvent(st, ev_join, 0);
-        hipEventDestroy(ev_fork);   // destruction is deferred by the runtime until the recorded work has completed
-        hipEventDestroy(ev_join);
-    }
-    return rc;
+    return run_steps(st, s_first, part);   // join (fj's destructor): the caller's stream continues only when the shallow graphs are finished too
 }
 
 extern "C" int dagnn_readout_max_backward(const dagnn_plan* pl, const float* h, int ld_h, int width, int dir,

@@ -1117,7 +1117,7 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? DAGNN_OK : DAGNN_EHIP(e);
     };
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    DagnnForkJoin fj;   // joins and releases its events on every return path
     bool forked = false;
     if (split) {   // no shallow rows at all (small batches: every graph is "deep"): nothing to overlap, no fork
         int64_t shallow = 0, deep = 0;
@@ -1134,14 +1134,11 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
     }
     if (forked) {
         hipStream_t side = (hipStream_t)a->side_stream;
-        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
-            return DAGNN_EHIP(hipGetLastError());
-        hipEventRecord(ev_fork, st);
-        hipStreamWaitEvent(side, ev_fork, 0);
+        const hipError_t ef = fj.begin(st, side);
+        if (ef != hipSuccess) return DAGNN_EHIP(ef);
         const int rc = launch_tail(side, 0);
-        hipEventRecord(ev_join, side);
-        if (rc != DAGNN_OK) { hipEventDestroy(ev_fork); hipEventDestroy(ev_join); return rc; }
+        fj.mark();
+        if (rc != DAGNN_OK) return rc;
     }
 
     StepArgs S;
@@ -1222,10 +1219,7 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         else e = launch_step<16, 8, 16, 1>(blocks, H, st, plan, L, S);
         if (e != hipSuccess) return DAGNN_EHIP(e);
     }
-    if (forked) {   // join: the caller's stream continues only when the deep graphs are finished too
-        hipStreamWaitEvent(st, ev_join, 0);
-        hipEventDestroy(ev_fork);   // destruction is deferred by the runtime until the recorded work has completed
-        hipEventDestroy(ev_join);
+    if (forked) {   // join (fj's destructor): the caller's stream continues only when the deep graphs are finished too
     } else if (!split && s_tail < nsteps) {
         const int rc = launch_tail(st, s_tail);
         if (rc != DAGNN_OK) return rc;

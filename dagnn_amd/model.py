@@ -326,9 +326,12 @@ class DAGNN(nn.Module):
     def _plan_of(self, G, B, overlap: bool = False):
         """The batch's plan.  With `overlap` the plan kernels (and the dataflow schedule's) run on a side stream next
         to the encoder and the batched input GEMM, which do not depend on them; the recurrence waits for `plan.ready`."""
-        if getattr(G, "_dagnn_plan", None) is not None:  # built by the loader (dagnn_amd.host_plan.attach_plan)
-            return engine.PlanHandle.from_words(G._dagnn_plan, G._dagnn_plan_meta, getattr(G, "_dagnn_df", None))
         has_edge_enc = getattr(self.node_aggr_0[0], "wea", False)
+        if getattr(G, "_dagnn_plan", None) is not None:  # built by the loader (dagnn_amd.host_plan.attach_plan)
+            if has_edge_enc or int(G._dagnn_plan_meta.get("R", 0)) == 0:
+                return engine.PlanHandle.from_words(G._dagnn_plan, G._dagnn_plan_meta, getattr(G, "_dagnn_df", None))
+            # the loader packed edge features this model has no encoder for (w_edge_attr=False): the kernels would
+            # want an edge gain per feature - build the plan without them here instead
         ea = G.edge_attr if has_edge_enc else None
         if not (overlap and engine.PLAN_OVERLAP and G.edge_index.is_cuda):
             return engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B, ea)

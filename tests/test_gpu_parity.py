@@ -591,6 +591,34 @@ def test_device_side_failures_raise(device, monkeypatch):
             model(b.clone().to(device))
 
 
+def test_loader_side_plan_with_edge_features_the_model_does_not_use(device):
+    """`collate_with_plan` packs `edge_attr` into the plan; a model built with `w_edge_attr=False` has no gain for
+    them: forward and the training step then build the plan on the device without the features (same results as
+    the plain batch) instead of failing in `dagnn_backward_prepare`."""
+    from dagnn_amd import collate_with_plan
+    meta = dict(H=64, n_attr=300, V=40, S=3, w_seed=79,
+                ctor=dict(w_edge_attr=False, num_layers=2, bidirectional=True, agg="attn_h", out_wx=False,
+                          out_pool_all=False, out_pool="max", dropout=0.0))
+    model = Hh.code2_model(meta).to(device)
+    graphs = synth.code2_graphs(34, 12, 40)
+    for g in graphs:
+        g.x[:, 1] %= 300
+    plain = synth.GraphBatch.from_data_list(graphs).to(device)
+    planned = collate_with_plan(graphs).to(device)
+    assert planned._dagnn_plan_meta["R"] == 2
+    with torch.no_grad():
+        a, bb = model(plain.clone()), model(planned.clone())
+    assert all(torch.equal(x, y) for x, y in zip(a, bb))
+    y = torch.randint(0, 40, (12, 3), generator=torch.Generator().manual_seed(2)).to(device)
+    _, g1 = _train_step(model, plain.clone(), y)
+    _, g2 = _train_step(model, planned.clone(), y)
+    for k in g1:
+        if "encoder." not in k:   # (torch's embedding backward accumulates with atomics: not bitwise repeatable)
+            assert torch.equal(g1[k], g2[k]), k
+        else:
+            assert torch.allclose(g1[k], g2[k], atol=1e-6), k
+
+
 def test_forward_and_training_with_loader_side_plan(device):
     """`collate_with_plan` batches: no plan kernels, no device->host read, bitwise the same results."""
     from dagnn_amd import collate_with_plan

@@ -83,6 +83,18 @@ __host__ __device__ inline DfLayout df_layout_words(int64_t N, int64_t B, int G)
     return L;
 }
 
+// minimum over the 64 lanes as a wave-uniform value: inclusive row scans (row_shr 1, 2, 4, 8), then the last lane of a
+// row into the next row (row_bcast15) and of the first half into the second (row_bcast31); a lane without a source
+// keeps its own value (old operand = the value, bound_ctrl off)
+__device__ __forceinline__ unsigned df_wave_umin(unsigned v) {
+#define DF_DPP_MIN(ctrl, rmask) \
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false))
+    DF_DPP_MIN(0x111, 0xf); DF_DPP_MIN(0x112, 0xf); DF_DPP_MIN(0x114, 0xf); DF_DPP_MIN(0x118, 0xf);
+    DF_DPP_MIN(0x142, 0xa); DF_DPP_MIN(0x143, 0xc);
+#undef DF_DPP_MIN
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // ---- LPT assignment: graphs in order of decreasing depth (plan items), each to the group whose load it raises the
 // least; load_k = c_layer * (depth of the first = deepest graph of k) + c_row * (nodes of k).  One wave, lane = group.
 __global__ void __launch_bounds__(64) df_assign_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws,
@@ -132,13 +144,12 @@ __global__ void __launch_bounds__(64) df_assign_kernel(const int32_t* __restrict
         }
         long long cand = load + (long long)c_row * ng + (empty ? (long long)c_layer * dg : 0);
         if (lane >= G) cand = 0x7fffffffffffffffLL;
-        long long best = cand;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const long long other = __shfl_xor(best, o, 64);
-            best = other < best ? other : best;
-        }
-        const unsigned long long m = __ballot(cand == best);
+        // wave minimum of the 64-bit candidates, high words first (two DPP scans instead of six 64-bit shuffles through
+        // the LDS crossbar on the B-step dependent chain: 57 -> 20 us at B = 128)
+        const unsigned hi = (unsigned)((unsigned long long)cand >> 32), lo = (unsigned)cand;
+        const unsigned best_hi = df_wave_umin(hi);
+        const unsigned best_lo = df_wave_umin(hi == best_hi ? lo : 0xffffffffu);
+        const unsigned long long m = __ballot(hi == best_hi && lo == best_lo);
         const int k = __ffsll((long long)m) - 1;
         if (lane == k) {
             load = cand;
@@ -373,8 +384,11 @@ __device__ __forceinline__ bool df_wait4(const int* f, int target, int* err, uns
 }
 
 // bounded global poll: false (and error bit 0) once the budget is spent
+#ifndef DF_POLL_SLEEP
+#define DF_POLL_SLEEP 1
+#endif
 __device__ __forceinline__ bool df_retry(unsigned& spins, int* err, unsigned limit) {
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(DF_POLL_SLEEP);
     if (++spins > limit) { __hip_atomic_fetch_or(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
     if ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
     return true;

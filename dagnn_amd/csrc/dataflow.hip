@@ -9,25 +9,29 @@
 // everything else.  Graphs share nothing, so the schedule is cut along GRAPHS, not along layers:
 //   * the graphs are dealt to G independent groups (longest-processing-time first on cost = c_layer * depth +
 //     c_row * nodes, csrc: df_assign_kernel; the deepest graph ends up almost alone in its group);
-//   * a group is a set of ncell x H/32 workgroups, one per (cell, 32-unit slice of the hidden dimension), each on its
-//     own CU for the whole pass with its W_hh slice in registers and its W_ih slice in LDS;
+//   * a workgroup SET is ncell x H/32 workgroups, one per (kernel cell, 32-unit slice of the hidden dimension), each on
+//     its own CU for the whole pass with its matrix slice in registers.  Kernel cells of a direction: its L recurrent
+//     cells (W_hh) plus one PROJECTION cell per stacked layer above the first (W_ih u + b_ih, published as [N, 3H]
+//     granules: the input-side product leaves the dependent chain).  A set serves TWO groups ("streams"): a stream
+//     inside a thin dependent chain is ready once per hop (~3.5 us), the other stream's blocks fill the gap;
 //   * a group walks ITS graphs layer by layer in blocks of <= 4 rows (records re-sorted by (group, layer, graph),
 //     every group-layer padded to whole blocks, so block b of a group is records [4b, 4b + 4) - no indirection on
 //     the dependent chain);
-//   * rows travel between the workgroups of a group as 8-byte {epoch, fp32} granules (one write-through store each,
+//   * rows travel between the workgroups of a set as 8-byte {epoch, fp32} granules (one write-through store each,
 //     polled with relaxed agent-scope loads: cdna_hip_programming.md Guideline 16, form R2) - no barrier, no fence,
-//     nothing placement-dependent.  Groups never exchange anything, and workgroup ids are group-major: with in-order
-//     dispatch a partially resident grid still makes progress group by group.
-// Inside a workgroup the waves are specialised (4 loader + 4 compute waves, coupled only through LDS flags):
-//   loader wave w   row w of every block: row record (scalar loads from a fixed address - prefetchable), poll the
-//                   predecessor rows (and the node's own lower-layer row / its gi0 slice), attention softmax over the
+//     nothing placement-dependent.  Groups never exchange anything, and workgroup ids are set-major: with in-order
+//     dispatch a partially resident grid still makes progress set by set.
+// Inside a workgroup the waves are specialised (2 x 4 loader + 4 compute waves, coupled only through LDS flags):
+//   loader wave w of set s   row w of every block of stream s: row record and gi0 slice by LDS-DMA a few blocks
+//                   ahead, poll the predecessor rows (and the node's projection granules), attention softmax over the
 //                   in-edges (scores = w_key . h_j computed HERE from the polled row: a DPP wave reduction, so the
-//                   producers publish no score parts), aggregate -> LDS ring slot, ready flag;
-//   compute wave c  its 8 hidden units of the slice: K split over the 16 lanes of a DPP row, v_pk_fma_f32 on the
-//                   resident W_hh registers / the LDS-resident W_ih, DPP row reduction, gates in the same wave (no
-//                   workgroup barrier anywhere), h' -> plain row store + granule store.
-// The loader runs up to NSLOT blocks ahead, so wide layers stream at the FMA rate while a thin dependent chain costs
-// one hand-off + ~0.5 us of compute per hop.
+//                   producers publish no score parts), aggregate -> the stream's LDS ring slot, ready flag;
+//   compute wave c  its 8 hidden units of the slice, blocks of either stream as they become ready: products on
+//                   v_mfma_f32_4x4x1 (the resident weights are the A operands, the block's rows the B operands), K
+//                   slices summed by a DPP / v_permlane16_swap reduce-scatter, gates in the same lanes (no workgroup
+//                   barrier anywhere), h' -> plain row store + granule store.
+// The loaders run up to NSLOT blocks ahead, so wide layers stream while a thin dependent chain costs one hand-off +
+// ~1 us of compute per hop.  DESIGN.md section 4a has the measurements.
 #include "common.h"
 
 #ifndef DF_EXPERIMENT

@@ -246,12 +246,13 @@ int dagnn_frontier_run(const dagnn_plan* plan /* host */, const dagnn_frontier_a
  * Dataflow schedule of the same recurrence (the default path for H <= 256): ONE persistent launch for the whole loop
  * nest of dagnn.py:144-182, cut along graphs instead of layers (dagnn_amd/csrc/dataflow.hip).
  *
- *   1. dagnn_dataflow_groups: how many independent groups G the device hosts.  A group has one workgroup (one CU) per
- *      (kernel cell, 32-unit slice); the kernel cells of a direction are its L GRU cells plus, for every stacked
- *      layer above the first, one PROJECTION cell (the input-side product W_ih u + b_ih, which leaves the dependent
- *      chain that way): G = floor(num_cus / (num_dirs * (2L - 1) * H/32)), capped at 64 and at B; 0 = this shape is
- *      not supported (H > 256, H % 64 != 0, more than 16 kernel cells, or one group does not fit the device) - use
- *      dagnn_frontier_run.
+ *   1. dagnn_dataflow_groups: how many independent groups G the device hosts.  A workgroup SET has one workgroup
+ *      (one CU) per (kernel cell, 32-unit slice); the kernel cells of a direction are its L GRU cells plus, for every
+ *      stacked layer above the first, one PROJECTION cell (the input-side product W_ih u + b_ih, which leaves the
+ *      dependent chain that way).  A set serves TWO groups (their blocks interleave: one group's dependent hop hides
+ *      behind the other's work): G = 2 * floor(num_cus / (num_dirs * (2L - 1) * H/32)), capped at 64 and at B;
+ *      0 = this shape is not supported (H > 256, H % 64 != 0, more than 16 kernel cells, or one set does not fit the
+ *      device) - use dagnn_frontier_run.  Any 1 <= G <= 64 is valid for the calls below (ceil(G / 2) sets launch).
  *   2. dagnn_dataflow_schedule: deals the graphs of a plan to the G groups - longest-processing-time first on
  *      cost_layer * depth + cost_row * nodes, integer arithmetic, ties to the lowest group - and re-sorts the plan's
  *      64-byte row records by (group, topological layer, graph, node), every group-layer padded to whole blocks of 4
@@ -265,7 +266,8 @@ int dagnn_frontier_run(const dagnn_plan* plan /* host */, const dagnn_frontier_a
  *      (`plan_status`) was nonzero, nothing was computed.
  *      State rows h_out [N, ld_h] receive the H states only; dagnn_score_parts adds the H/16 partial attention scores
  *      behind them (the format dagnn_backward_prepare reads) when a backward pass follows.
- * Weights: dagnn_pack_dataflow(W [3H,H] torch layout) -> 3*H*H floats in slice / lane order.
+ * Weights: dagnn_pack_dataflow(W [3H,H] torch layout) -> 3*H*H floats in slice / lane order (the A operands of the
+ * kernel's v_mfma_f32_4x4x1 products: lane = (unit quad, K slice of H/8, unit of the quad)).
  * ---------------------------------------------------------------------------------------- */
 typedef struct dagnn_dataflow_cell {
     const float* w_hh;      /* weight_hh packed by dagnn_pack_dataflow */

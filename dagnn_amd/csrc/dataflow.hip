@@ -356,6 +356,15 @@ constexpr int DF_RD = 6;       // a loader wave requests a row record this many 
 constexpr int DF_GD = 2;       // a gi0 slice this many (its node id must have landed: DF_RD >= DF_GD + 2)
 constexpr int DF_GIRING = DF_NSLOT + DF_GD + 2;   // blocks in a stream's gi0 ring: slots in use + prefetch distance + slack
 
+// group served by stream `set` of workgroup set `pair` (-1: none).  (Measured and dropped: the first set serving the
+// deepest graph's group alone, 9 groups on 5 sets - 2.15 ms against 1.93: what binds the pass is the sets'
+// throughput, not that one chain.)
+__device__ __host__ __forceinline__ int df_stream_group(int pair, int set, int groups) {
+    const int g = DF_NLS * pair + set;
+    return g < groups ? g : -1;
+}
+__host__ inline int df_sets_for(int groups) { return (groups + DF_NLS - 1) / DF_NLS; }
+
 struct DfLds {
     float* ring;     // [NLS][NSLOT] slots: a ring per stream
     float* giring;   // [NLS][DF_GIRING][RB][96]: gi0 slices of the slice's rows, landed by LDS-DMA two blocks ahead
@@ -797,8 +806,9 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     const bool gi_ring = C.gi0 != nullptr;   // (read once: a field access in the loop is a scalar load + lgkmcnt(0) per block)
     const int d = C.dir;
     // the two streams of this workgroup: groups NLS * pair and NLS * pair + 1 (the second may not exist)
-    const int nb0 = S.sched[S.gtab[d] + 2 * (DF_NLS * pair) + 1];
-    const int nb1 = DF_NLS * pair + 1 < S.groups ? S.sched[S.gtab[d] + 2 * (DF_NLS * pair + 1) + 1] : 0;
+    const int grp0 = df_stream_group(pair, 0, S.groups), grp1 = df_stream_group(pair, 1, S.groups);
+    const int nb0 = grp0 >= 0 ? S.sched[S.gtab[d] + 2 * grp0 + 1] : 0;
+    const int nb1 = grp1 >= 0 ? S.sched[S.gtab[d] + 2 * grp1 + 1] : 0;
     float wr[KP8], wz[KP8], wn[KP8];   // the lane's K slice of the r / z / n rows of its unit
     {
         const float4* wp = C.w + (int64_t)sl * (3 * NK4) * 256 + tc;
@@ -970,7 +980,8 @@ __global__ void __launch_bounds__(DF_THREADS, 3) dataflow_kernel(const int32_t* 
         df_compute<KPT>(S, C, sl, pair, lds, wave);
     } else {
         const int set = (wave - DF_NCW) / DF_RB;
-        if (DF_NLS * pair + set < S.groups) df_loader<KPT>(plan, S, C, sl, DF_NLS * pair + set, lds, (wave - DF_NCW) % DF_RB, set);
+        const int grp = df_stream_group(pair, set, S.groups);
+        if (grp >= 0) df_loader<KPT>(plan, S, C, sl, grp, lds, (wave - DF_NCW) % DF_RB, set);
     }
     if (S.dbg && tid == 0) S.dbg[2 * blockIdx.x + 1] = wall_clock64();   // compute wave 0 is done
 }
@@ -1146,7 +1157,7 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
     S.dbg_wg = a->debug_wg;
     S.status = (const int32_t*)a->plan_status;
     const int32_t* plan = (const int32_t*)pl->data;
-    const unsigned grid = (unsigned)((G + DF_NLS - 1) / DF_NLS * nc * (H / DF_JS));
+    const unsigned grid = (unsigned)(df_sets_for(G) * nc * (H / DF_JS));
     hipStream_t st = (hipStream_t)stream;
 #define DF_LAUNCH(KPT)                                                                                                   \
     do {                                                                                                                 \

@@ -33,10 +33,8 @@
 // The loaders run up to NSLOT blocks ahead, so wide layers stream while a thin dependent chain costs one hand-off +
 // ~1 us of compute per hop.  DESIGN.md section 4a has the measurements.
 #include "common.h"
+#include <type_traits>
 
-#ifndef DF_EXPERIMENT
-#define DF_EXPERIMENT 0
-#endif
 
 namespace {
 
@@ -45,15 +43,28 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int DF_JS = 32;      // hidden units per slice
 constexpr int DF_RB = 4;       // rows per block = loader waves
 constexpr int DF_NCW = 4;      // compute waves
-constexpr int DF_NLS = 2;      // streams per workgroup = loader sets: set s serves group NLS * pair + s - a block costs a loader wave one trip to
+#ifndef DF_NLS_V
+#define DF_NLS_V 2
+#endif
+constexpr int DF_NLS = DF_NLS_V;   // streams per workgroup = loader sets: set s serves group NLS * pair + s - a block costs a loader wave one trip to
                                // memory plus ~1 us of scalar work, twice what the compute waves need for it
 #ifndef DF_NSLOT_V
-#define DF_NSLOT_V 4
+#define DF_NSLOT_V (DF_NLS_V <= 2 ? 4 : 2)
 #endif
 constexpr int DF_NSLOT = DF_NSLOT_V;    // LDS ring depth (blocks the loaders may run ahead)
-constexpr bool DF_TWO_CHUNKS = false;   // rows with > 4 in-edges: two chunks per trip to memory.  Measured: the second sweep's
-                               // 32 registers spill the loader at 3 waves per SIMD; such rows cost ~75 us per group
-constexpr int DF_THREADS = 64 * (DF_NCW + DF_NLS * DF_RB);
+// (Measured and removed: two chunks per trip for rows with > 4 in-edges - the second sweep's 32 registers spilled the
+// loader at 3 waves per SIMD.)
+#ifndef DF_TEAMS_V
+#define DF_TEAMS_V 1
+#endif
+constexpr int DF_TEAMS = DF_TEAMS_V;          // compute teams (of DF_NCW waves): 1 = one team takes the blocks of every stream
+                                              // as they become ready; DF_NLS = a team per stream (two waves per SIMD)
+static_assert(DF_TEAMS == 1 || DF_TEAMS == DF_NLS, "compute teams");
+constexpr int DF_NLW = 12 - DF_NCW * DF_TEAMS;   // loader waves per workgroup (12 waves = 3 per SIMD at <= 168 VGPRs)
+constexpr int DF_WPS = DF_NLW / DF_NLS;     // ... per stream
+constexpr int DF_RPW = DF_RB / DF_WPS;      // rows of a block per loader wave (one after the other)
+static_assert(DF_NLS == 2 || DF_NLS == 4 || DF_NLS == 8, "streams per workgroup");
+constexpr int DF_THREADS = 64 * (DF_NCW * DF_TEAMS + DF_NLW);
 constexpr int DF_MAX_GROUPS = 64;
 constexpr int DF_MAGIC = 0x44463031;   // "DF01"
 
@@ -369,7 +380,7 @@ struct DfLds {
     float* ring;     // [NLS][NSLOT] slots: a ring per stream
     float* giring;   // [NLS][DF_GIRING][RB][96]: gi0 slices of the slice's rows, landed by LDS-DMA two blocks ahead
     int* rec;        // [NLS * RB][8][16]: row records of the loader waves, landed by LDS-DMA DF_RD of their blocks ahead
-    int* rdy;        // [NLS * RB]   per loader wave: blocks it has finished (relaxed workgroup-scope atomics: plain ds_ accesses;
+    int* rdy;        // [NLS][WPS]  per loader wave: blocks it has finished (relaxed workgroup-scope atomics: plain ds_ accesses;
     int* dn;         // [NLS][NCW]  per stream and compute wave likewise   a volatile access here compiles to a FLAT load + vmcnt(0))
 };
 
@@ -410,7 +421,7 @@ __device__ __forceinline__ bool df_retry(unsigned& spins, int* err, unsigned lim
 // ---- loader wave: row `lw` of every block of this group
 template <int KPT>
 __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, const DfArgs& S,
-                                          const DfCell& C, int sl, int group, const DfLds& lds, int lw, int set) {
+                                          const DfCell& C, int sl, int group, const DfLds& lds, int w, int set) {
     constexpr int H = 16 * KPT;
     constexpr int SEG = DfPad<KPT>::seg, KP8 = DfPad<KPT>::kp8;
     typedef DfSlot<KPT> Slot;
@@ -418,7 +429,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
     const int d = C.dir;
     const int32_t* tab = S.sched + S.gtab[d] + 2 * group;
     const int rec_base = tab[0], nblk = tab[1];
-    const int4* __restrict__ recs = reinterpret_cast<const int4*>(S.sched + S.grec[d]) + 4 * ((int64_t)rec_base + lw);
+    const int32_t* __restrict__ recs = S.sched + S.grec[d] + 16 * (int64_t)rec_base;   // records of this stream (16 words each)
     const int32_t* __restrict__ col = plan + S.col[d];
     const float* __restrict__ eattr = reinterpret_cast<const float*>(plan + S.eattr[d]);
     const bool proj = C.kind == DF_PROJECTION;
@@ -451,21 +462,88 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
         cpos[q] = c + (SEG - KP8) * (c / KP8);
         if (C.wkey && !proj && q < NQ4) wk[q] = C.wkey[c];
     }
-    const bool prof = dbg != nullptr && (int)blockIdx.x == S.dbg_wg && lw == 0 && lane == 0;
+    const bool prof_wave = dbg != nullptr && (int)blockIdx.x == S.dbg_wg && w == 0 && lane == 0;
+    bool prof = prof_wave;
 
     // ---- memory traffic of this wave, by hand.  Three streams share the wave's in-order vmcnt counter: the granule
     // sweeps (on the dependent chain), the static row records and the gi0 slices (cold lines: HBM latency).  Left to
     // the compiler every wait inside this loop is a vmcnt(0), i.e. each sweep would also wait for the prefetches
     // issued next to it (measured: 1.3 us per block instead of 0.2).  So:
-    //  * records and gi0 slices travel by LDS-DMA (global_load_lds: no destination register that the compiler could
-    //    copy or spill while the load is in flight) into small LDS rings, DF_RD resp. DF_GD blocks ahead;
-    //  * the sweeps are inline-asm register loads, consumed right behind their wait;
-    //  * the order is fixed - sweep of block b, then the prefetch group P(b) = {record of block b + RD, gi0 slice of
-    //    block b + GD} - and the waits are counted: vmcnt(|P|) after P(b) completes the sweep and everything older
-    //    (P(b - 1) included) while P(b) stays in flight.
-    // wave-uniform row pointer (scalar registers) + one per-lane byte offset shared by all loads + an immediate
-#define DF_LD_GRAN(dst, voff, sbase, imm) \
-    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3 sc1" : "+v"(dst) : "v"(voff), "s"(sbase), "n"(imm) : "memory")
+    //  * records and gi0 slices travel by LDS-DMA (global_load_lds: no destination register) into small LDS rings,
+    //    DF_RD resp. DF_GD blocks ahead;
+    //  * ONE asm statement per trip to memory: the sweep's register loads (wave-uniform row pointer in SGPRs + one
+    //    per-lane byte offset + immediates), behind them the prefetch group P(b) = {record of block b + RD, gi0 slice
+    //    of block b + GD}, and the counted wait - vmcnt(|P|) completes the sweep and everything older (P(b - 1)
+    //    included) while P(b) stays in flight.  The loads and their wait sit in the SAME statement because a
+    //    destination register the compiler can see while its load is in flight gets copied sooner or later (a
+    //    loop-carried value, a phi behind a branch): the copy reads the stale register and the wait then protects the
+    //    wrong one - measured twice, a memory fault and a silent 0.5 error.
+    //    One statement per shape: NN rows x 4 loads (H < 256 repeats the last 512 bytes: same instruction count for
+    //    every H), the projection slice or not, no / record / record + gi0 prefetch.
+    struct Sweep { gran_t x[4][4]; gran_t xp[3]; };
+    const unsigned lane8 = 8u * lane, lane31x8 = 8u * (lane & 31);
+    const bool has_gi0 = gi0 != nullptr;
+#define DF_ROW_LD(e)                                                            \
+    "global_load_dwordx2 %[x" #e "0], %[vo], %[b" #e "] offset:0 sc1\n\t"        \
+    "global_load_dwordx2 %[x" #e "1], %[vo], %[b" #e "] offset:%[o1] sc1\n\t"    \
+    "global_load_dwordx2 %[x" #e "2], %[vo], %[b" #e "] offset:%[o2] sc1\n\t"    \
+    "global_load_dwordx2 %[x" #e "3], %[vo], %[b" #e "] offset:%[o3] sc1\n\t"
+#define DF_ROWS_0 ""
+#define DF_ROWS_1 DF_ROW_LD(0)
+#define DF_ROWS_2 DF_ROWS_1 DF_ROW_LD(1)
+#define DF_ROWS_3 DF_ROWS_2 DF_ROW_LD(2)
+#define DF_ROWS_4 DF_ROWS_3 DF_ROW_LD(3)
+#define DF_PROJ_0 ""
+#define DF_PROJ_1                                                   \
+    "global_load_dwordx2 %[p0], %[vp], %[c0] offset:0 sc1\n\t"       \
+    "global_load_dwordx2 %[p1], %[vp], %[c1] offset:0 sc1\n\t"       \
+    "global_load_dwordx2 %[p2], %[vp], %[c2] offset:0 sc1\n\t"
+    // LDS-DMA: lane l of the first 16 (24) lanes moves 4 (16) bytes to M0 + 4 l (16 l); all lanes are active here
+#define DF_DMA_0 "s_waitcnt vmcnt(0)"
+#define DF_DMA_1                                                                                   \
+    "s_mov_b32 %[km], m0\n\ts_mov_b64 %[ke], exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %[rl]\n\t" \
+    "s_nop 0\n\tglobal_load_lds_dword %[ra], off\n\t"                                              \
+    "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]\n\ts_waitcnt vmcnt(1)"
+#define DF_DMA_2                                                                                   \
+    "s_mov_b32 %[km], m0\n\ts_mov_b64 %[ke], exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %[rl]\n\t" \
+    "s_nop 0\n\tglobal_load_lds_dword %[ra], off\n\t"                                              \
+    "s_mov_b64 exec, 0xffffff\n\ts_mov_b32 m0, %[gl]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[ga], off\n\t" \
+    "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]\n\ts_waitcnt vmcnt(2)"
+#define DF_TRIP(n, p, d)                                                                                                   \
+    asm volatile(DF_ROWS_##n DF_PROJ_##p DF_DMA_##d                                                                        \
+                 : [x00] "=v"(W.x[0][0]), [x01] "=v"(W.x[0][1]), [x02] "=v"(W.x[0][2]), [x03] "=v"(W.x[0][3]),             \
+                   [x10] "=v"(W.x[1][0]), [x11] "=v"(W.x[1][1]), [x12] "=v"(W.x[1][2]), [x13] "=v"(W.x[1][3]),             \
+                   [x20] "=v"(W.x[2][0]), [x21] "=v"(W.x[2][1]), [x22] "=v"(W.x[2][2]), [x23] "=v"(W.x[2][3]),             \
+                   [x30] "=v"(W.x[3][0]), [x31] "=v"(W.x[3][1]), [x32] "=v"(W.x[3][2]), [x33] "=v"(W.x[3][3]),             \
+                   [p0] "=v"(W.xp[0]), [p1] "=v"(W.xp[1]), [p2] "=v"(W.xp[2]), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)  \
+                 : [vo] "v"(lane8), [vp] "v"(lane31x8), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),            \
+                   [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [ra] "v"(ra), [rl] "s"(rl), [ga] "v"(ga), [gl] "s"(gl),    \
+                   [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)                                                                \
+                 : "memory")
+#define DF_CASE(n, p, d) case (n) * 6 + (p) * 3 + (d): DF_TRIP(n, p, d); break;
+#define DF_CASES(n) DF_CASE(n, 0, 0) DF_CASE(n, 0, 1) DF_CASE(n, 0, 2) DF_CASE(n, 1, 0) DF_CASE(n, 1, 1) DF_CASE(n, 1, 2)
+
+    // (a wave serves DF_RPW rows of every block, one after the other: `lw` and the ring addresses below follow the row)
+    int lw = w * DF_RPW;
+    int* rec_ring;
+    unsigned rec_ring_a, gi_ring_a;
+    const int32_t* rec_w;
+    auto set_row = [&](int row) {
+        lw = row;
+        rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
+        rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
+        gi_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds.giring + (set * DF_GIRING * DF_RB + lw) * (3 * DF_JS)));
+        rec_w = recs + 16 * lw + (lane & 15);
+    };
+    set_row(lw);
+    const int64_t wstride = 16 * DF_RB;   // words per block
+    const int gi_lane_off = ((lane % 24) >> 3) * H + sl * DF_JS + 4 * (lane & 7);
+    // addresses of the prefetch group: record of this wave's j-th block (past the end: the last block's again) -> ring
+    // entry j & 7; gi0 slice of `node` -> gi ring entry blk % DF_GIRING, row lw
+    auto rec_src = [&](int j) -> const void* { return rec_w + (int64_t)min(j, nblk - 1) * wstride; };
+    auto rec_dst = [&](int j) -> unsigned { return rec_ring_a + (j & 7) * 64; };
+    auto gi_src = [&](int node) -> const void* { return gi0 + (int64_t)max(node, 0) * 3 * H + gi_lane_off; };
+    auto gi_dst = [&](int blk) -> unsigned { return gi_ring_a + (blk % DF_GIRING) * (DF_RB * 3 * DF_JS * 4); };
     auto glds4 = [&](const void* gsrc, unsigned lds_dst) {   // lane l: 4 bytes from gsrc -> LDS lds_dst + 4 l
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
@@ -476,76 +554,29 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
     };
-    struct Sweep { gran_t x[4][4]; gran_t xp[3]; };
-    const unsigned lane8 = 8u * lane, lane31x8 = 8u * (lane & 31);
-    auto issue = [&](Sweep& W, const int (&pj)[4], unsigned pend, bool pp, const gran_t* gp_in) {
+    auto rec_dma = [&](int j) { if (lane < 16) glds4(rec_src(j), rec_dst(j)); };
+    auto gi_dma = [&](int blk, int node) { if (lane < 24) glds16(gi_src(node), gi_dst(blk)); };
+    if (nblk > 0) {   // prologue: records of this wave's rows of blocks 0..RD-1, gi0 slices of blocks 0..GD-1
+        for (int rr = 0; rr < DF_RPW; ++rr) {
+            set_row(w * DF_RPW + rr);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const gran_t* gp = g_src + (int64_t)pj[e] * gld;   // wave-uniform
-            const bool on = (pend >> e) & 1u;   // rows that have arrived keep their registers
-            if (on) {
-                DF_LD_GRAN(W.x[e][0], lane8, gp, 0);
-                if (NQ4 > 1) DF_LD_GRAN(W.x[e][1], lane8, gp, 512);
-                if (NQ4 > 2) DF_LD_GRAN(W.x[e][2], lane8, gp, 1024);
-                if (NQ4 > 3) DF_LD_GRAN(W.x[e][3], lane8, gp, 1536);
-            }
-        }
-        if (pp) {   // all lanes (lanes 32.. repeat lanes 0..31): one instruction per gate
-            DF_LD_GRAN(W.xp[0], lane31x8, gp_in, 0);
-            DF_LD_GRAN(W.xp[1], lane31x8, gp_in + H, 0);
-            DF_LD_GRAN(W.xp[2], lane31x8, gp_in + 2 * H, 0);
-        }
-    };
-#define DF_TOUCH(W)                                                                                                       \
-    asm volatile("" : "+v"(W.x[0][0]), "+v"(W.x[0][1]), "+v"(W.x[0][2]), "+v"(W.x[0][3]), "+v"(W.x[1][0]), "+v"(W.x[1][1]), \
-                      "+v"(W.x[1][2]), "+v"(W.x[1][3]), "+v"(W.x[2][0]), "+v"(W.x[2][1]), "+v"(W.x[2][2]), "+v"(W.x[2][3]), \
-                      "+v"(W.x[3][0]), "+v"(W.x[3][1]), "+v"(W.x[3][2]), "+v"(W.x[3][3]), "+v"(W.xp[0]), "+v"(W.xp[1]),     \
-                      "+v"(W.xp[2]))
-    const bool has_gi0 = gi0 != nullptr;
-    // everything issued before the newest |P| loads has landed; the sweep's registers may be read from here on
-    auto landed = [&](Sweep& W) {
-        if (has_gi0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        DF_TOUCH(W);
-    };
-    auto landed_all = [&](Sweep& W) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        DF_TOUCH(W);
-    };
-    auto landed_rows = [&](Sweep& W) {   // a sweep without the projection slice (second chunk of a trip)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(W.x[0][0]), "+v"(W.x[0][1]), "+v"(W.x[0][2]), "+v"(W.x[0][3]), "+v"(W.x[1][0]),
-                     "+v"(W.x[1][1]), "+v"(W.x[1][2]), "+v"(W.x[1][3]), "+v"(W.x[2][0]), "+v"(W.x[2][1]), "+v"(W.x[2][2]),
-                     "+v"(W.x[2][3]), "+v"(W.x[3][0]), "+v"(W.x[3][1]), "+v"(W.x[3][2]), "+v"(W.x[3][3]) :: "memory");
-    };
-
-    // LDS rings of this wave: records (8 entries x 64 B) and, shared with the compute waves, the gi0 slices
-    // (DF_GIRING blocks x RB rows x 384 B: compute reads entry b % DF_GIRING)
-    int* const rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
-    const unsigned rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
-    const unsigned gi_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds.giring + (set * DF_GIRING * DF_RB + lw) * (3 * DF_JS)));
-    const int32_t* rec_w = reinterpret_cast<const int32_t*>(recs) + (lane & 15);
-    const int64_t wstride = 16 * DF_RB;   // words per block
-    const int gi_lane_off = ((lane % 24) >> 3) * H + sl * DF_JS + 4 * (lane & 7);
-    auto rec_dma = [&](int j) {   // record of this wave's j-th block (past the end: the last block's again) -> ring entry j & 7
-        if (lane < 16) glds4(rec_w + (int64_t)min(j, nblk - 1) * wstride, rec_ring_a + (j & 7) * 64);
-    };
-    auto gi_dma = [&](int blk, int node) {   // gi0 slice of `node` -> gi ring entry blk % DF_GIRING, row lw
-        if (lane < 24) glds16(gi0 + (int64_t)max(node, 0) * 3 * H + gi_lane_off, gi_ring_a + (blk % DF_GIRING) * (DF_RB * 3 * DF_JS * 4));
-    };
-    if (nblk > 0) {   // prologue: records of this wave's blocks 0..RD-1, gi0 slices of its blocks 0..GD-1
-#pragma unroll
-        for (int j = 0; j < DF_RD; ++j) rec_dma(j);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (has_gi0) {
-#pragma unroll
-            for (int j = 0; j < DF_GD; ++j) gi_dma(j, __builtin_amdgcn_readfirstlane(rec_ring[j * 16]));
+            for (int j = 0; j < DF_RD; ++j) rec_dma(j);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (has_gi0) {
+#pragma unroll
+                for (int j = 0; j < DF_GD; ++j) gi_dma(j, __builtin_amdgcn_readfirstlane(rec_ring[j * 16]));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
     }
 
-    Sweep A, A2;
+    Sweep A;
     for (int b = 0; b < nblk; ++b) {
-        const int j = b;
+      const int j = b;
+      bool slot_free = b < DF_NSLOT;   // the ring slot has been handed back (checked once per block, before the first write)
+#pragma unroll 1
+      for (int rr = 0; rr < DF_RPW; ++rr) {
+        if (DF_RPW > 1) { set_row(w * DF_RPW + rr); prof = prof_wave && rr == 0; }
         const int cur = rec_ring[(j & 7) * 16 + (lane & 15)];
 #define DF_W(i) __builtin_amdgcn_readlane(cur, i)
         const int4 r0 = make_int4(DF_W(0), DF_W(1), DF_W(2), DF_W(3));
@@ -560,17 +591,26 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
         const int v = r0.x;
         if (prof) dbg[8 * (int64_t)(DF_NLS * b + set) + 4] = wall_clock64();
         unsigned polls = 0;
-        auto prefetch = [&]() {   // P(b): exactly 1 (+1 with gi0) loads, whatever the block looks like
-            rec_dma(j + DF_RD);
-            if (has_gi0) gi_dma(b + DF_GD, v2);
+        constexpr int O1 = (NQ4 > 1 ? 1 : 0) * 512, O2 = (NQ4 > 2 ? 2 : NQ4 - 1) * 512, O3 = (NQ4 - 1) * 512;
+        // one trip to memory: the rows pj[0..nn), the projection slice if `pp`, the prefetch group P(b) if `dma`
+        // (1: record, 2: record + gi0 slice); returns with every register it loaded valid
+        auto trip = [&](Sweep& W, int nn, bool pp, int dma, const int (&pj)[4], const gran_t* gp_in) {
+            const gran_t* b0 = g_src + (int64_t)pj[0] * gld;   // wave-uniform (unused slots: row 0, not loaded)
+            const gran_t* b1 = g_src + (int64_t)pj[1] * gld;
+            const gran_t* b2 = g_src + (int64_t)pj[2] * gld;
+            const gran_t* b3 = g_src + (int64_t)pj[3] * gld;
+            const gran_t* c0p = gp_in, * c1p = gp_in + H, * c2p = gp_in + 2 * H;
+            const void* ra = rec_src(j + DF_RD);
+            const unsigned rl = rec_dst(j + DF_RD);
+            const void* ga = has_gi0 ? gi_src(v2) : ra;
+            const unsigned gl = gi_dst(b + DF_GD);
+            unsigned keep_m0;
+            unsigned long long keep_exec;
+            switch (nn * 6 + (pp ? 3 : 0) + dma) {
+                DF_CASES(0) DF_CASES(1) DF_CASES(2) DF_CASES(3)
+                default: DF_CASES(4)
+            }
         };
-#if DF_EXPERIMENT == 9
-        if (v >= -1) {
-            prefetch();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (b >= DF_NSLOT) df_wait4(dn, b - DF_NSLOT + 1, err, spin_limit);
-        } else
-#endif
         if (v >= 0) {
             const int eb = r0.y;
             const int deg = proj ? 1 : r0.z - r0.y;   // a projection reads ONE row: the node's own state one layer down
@@ -579,7 +619,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
             // input-side pre-activations of the slice from the projection cell: 3 gates x 32 units, lanes 0..31
             bool p_pending = p_in != nullptr;
             float pv[3] = {0.f, 0.f, 0.f};
-            const gran_t* gp_in = p_pending ? p_in + (int64_t)v * pld + sl * DF_JS : nullptr;   // wave-uniform
+            const gran_t* gp_in = p_pending ? p_in + (int64_t)v * pld + sl * DF_JS : g_src;   // wave-uniform (g_src: never loaded)
             // in-edges in chunks of <= 4 (ids and features of the first chunk came with the record).  A node with more
             // than 4 in-edges takes two chunks per trip to memory (all of them finished long ago: the trips, not the
             // data, are what such a row waits for)
@@ -610,56 +650,49 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                 }
                 return nn;
             };
-            // rows of a sweep that carry this pass's tag are cleared from `pend` (their values stay in the sweep's registers)
-            auto harvest = [&](Sweep& W, unsigned& pend) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if ((pend >> e) & 1u) {
-                        bool ok = true;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(W.x[e][q] >> 32) == epoch;
-                        if (__all(ok)) pend &= ~(1u << e);
-                    }
-                }
-            };
-            auto clear = [&](Sweep& W) {   // every slot reads as an arrived all-zero row
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) W.x[e][q] = ready;
-#pragma unroll
-                for (int g = 0; g < 3; ++g) W.xp[g] = ready;
-            };
-            // online softmax over one chunk (rows beyond nn are zeros with score -inf)
-            auto fold = [&](const int (&pj)[4], const float (&fe)[4], int nn, const Sweep& W) {
-#define DF_ROW(e, q) __uint_as_float((unsigned)W.x[e][q])
-                float s[4];   // all four scores at once: four independent reductions interleave
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s[e] = DF_ROW(e, 0) * wk[0] + DF_ROW(e, 1) * wk[1] + DF_ROW(e, 2) * wk[2] + DF_ROW(e, 3) * wk[3];
-                if (!sscore) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) s[e] = df_wave_sum(s[e]);
-                }
-                float mc = m;
+            // every row of the trip carries this pass's tag (nn is wave-uniform)
+            auto arrived = [&](const Sweep& W, int nn) -> bool {
+                bool all = true;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (e < nn) {
-                        float sv = sscore ? sscore[pj[e]] : s[e];
-                        if (vid) sv += vid[pj[e] % vid_mod];
-                        sv += fe[e];
-                        s[e] = sv;
-                        mc = fmaxf(mc, sv);
-                    } else {
-                        s[e] = -INFINITY;
+                        bool ok = true;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(W.x[e][q] >> 32) == epoch;
+                        all = all && __all(ok);
                     }
+                }
+                return all;
+            };
+            // online softmax over one chunk of NN in-edges (NN is wave-uniform: one straight-line variant per count, so
+            // the independent reductions of a chunk interleave and an absent slot costs nothing - the loader waves
+            // share their SIMD's issue slots with the compute wave, every instruction here is paid twice)
+            auto fold_n = [&](auto nn_c, const int (&pj)[4], const float (&fe)[4], const Sweep& W) {
+                constexpr int NN = decltype(nn_c)::value;
+#define DF_ROW(e, q) __uint_as_float((unsigned)W.x[e][q])
+                float s[NN];
+#pragma unroll
+                for (int e = 0; e < NN; ++e) s[e] = DF_ROW(e, 0) * wk[0] + DF_ROW(e, 1) * wk[1] + DF_ROW(e, 2) * wk[2] + DF_ROW(e, 3) * wk[3];
+                if (!sscore) {
+#pragma unroll
+                    for (int e = 0; e < NN; ++e) s[e] = df_wave_sum(s[e]);
+                }
+                float mc = m;
+#pragma unroll
+                for (int e = 0; e < NN; ++e) {
+                    float sv = sscore ? sscore[pj[e]] : s[e];
+                    if (vid) sv += vid[pj[e] % vid_mod];
+                    sv += fe[e];
+                    s[e] = sv;
+                    mc = fmaxf(mc, sv);
                 }
                 const float sc = __expf(m - mc);   // 0 on the first chunk (m = -inf)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] *= sc;
                 l *= sc;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float p = __expf(s[e] - mc);   // 0 for the slots beyond the chunk (s = -inf)
+                for (int e = 0; e < NN; ++e) {
+                    const float p = __expf(s[e] - mc);
                     l += p;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[q] = fmaf(p, DF_ROW(e, q), acc[q]);
@@ -667,40 +700,27 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                 m = mc;
 #undef DF_ROW
             };
+            auto fold = [&](const int (&pj)[4], const float (&fe)[4], int nn, const Sweep& W) {
+                switch (nn) {
+                    case 1: fold_n(std::integral_constant<int, 1>(), pj, fe, W); break;
+                    case 2: fold_n(std::integral_constant<int, 2>(), pj, fe, W); break;
+                    case 3: fold_n(std::integral_constant<int, 3>(), pj, fe, W); break;
+                    default: fold_n(std::integral_constant<int, 4>(), pj, fe, W); break;
+                }
+            };
             int c0 = 0;
             do {
-                int pj[4], pj2[4];
-                float fe[4], fe2[4];
+                int pj[4];
+                float fe[4];
                 const int nn = chunk_ids(c0, pj, fe);
-                const bool two = DF_TWO_CHUNKS && deg > 4;   // wave-uniform: this row takes two chunks per trip
-                const int nn2 = two ? chunk_ids(c0 + 4, pj2, fe2) : 0;
-                clear(A);
-                if (two) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) A2.x[e][q] = ready;
-                }
-                unsigned pend = (1u << nn) - 1u, pend2 = (1u << nn2) - 1u;   // wave-uniform: rows still missing
                 unsigned spins = 0;
-#if DF_EXPERIMENT == 8
-                if (prof && c0 == 0) dbg[8 * (int64_t)(DF_NLS * b + set) + 4] = wall_clock64();
-#endif
-                unsigned long long t_issue = prof ? wall_clock64() : 0ull;
-                issue(A, pj, pend, p_pending, gp_in);
-                if (two) issue(A2, pj2, pend2, false, nullptr);
-                if (c0 == 0 && !two) { prefetch(); landed(A); }
-                else {
-                    if (c0 == 0) prefetch();
-                    landed_all(A);
-                    if (two) landed_rows(A2);
-                }
-#if DF_EXPERIMENT == 8
-                if (prof && c0 == 0) dbg[8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64();
-#endif
+                unsigned long long t_issue = 0ull;
+                int dma = c0 == 0 ? (has_gi0 ? 2 : 1) : 0;   // P(b) rides behind the block's first sweep
                 for (;;) {
-                    harvest(A, pend);
-                    if (two) harvest(A2, pend2);
+                    if (prof) t_issue = wall_clock64();
+                    trip(A, nn, p_pending, dma, pj, gp_in);
+                    dma = 0;
+                    const bool rows_ok = arrived(A, nn);
                     if (p_pending) {
                         bool okp = true;
 #pragma unroll
@@ -712,37 +732,27 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                         }
                     }
                     ++polls;
-                    if ((pend == 0 && pend2 == 0 && !p_pending) || !df_retry(spins, err, spin_limit)) break;
-                    if (prof) t_issue = wall_clock64();
-                    issue(A, pj, pend, p_pending, gp_in);
-                    if (two) issue(A2, pj2, pend2, false, nullptr);
-                    landed_all(A);
-                    if (two) landed_rows(A2);
+                    if ((rows_ok && !p_pending) || !df_retry(spins, err, spin_limit)) break;
                 }
-#if DF_EXPERIMENT != 8
                 if (prof && c0 == 0) {
                     dbg[8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64(); dbg[8 * (int64_t)(DF_NLS * b + set) + 6] = polls;
                     if (DF_NLS * b + set >= 8) dbg[8 * (int64_t)(DF_NLS * b + set) + 7] = t_issue;   // when the poll that found the row was issued
                 }
-#else
-                if (prof && c0 == 0) dbg[8 * (int64_t)(DF_NLS * b + set) + 6] = polls;
-#endif
                 if (deg == 1) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[q] = __uint_as_float((unsigned)A.x[0][q]);
                     l = 1.f;
                 } else if (nn > 0) {
                     fold(pj, fe, nn, A);
-                    if (nn2 > 0) fold(pj2, fe2, nn2, A2);
                 }
-                c0 += two ? 8 : 4;
+                c0 += 4;
             } while (c0 < deg);
             if (deg > 1) {   // PyG softmax: exp(x - max) / (sum + 1e-16)
                 const float inv = __builtin_amdgcn_rcpf(l + 1e-16f);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] *= inv;
             }
-            if (b >= DF_NSLOT) df_wait4(dn, b - DF_NSLOT + 1, err, spin_limit);   // the ring slot is free again
+            if (!slot_free) { df_wait4(dn, b - DF_NSLOT + 1, err, spin_limit); slot_free = true; }   // the ring slot is free again
             float* a_row = sbase + Slot::a_off + lw * Slot::AP;
 #pragma unroll
             for (int q = 0; q < NQ4; ++q) a_row[cpos[q]] = acc[q];
@@ -751,19 +761,20 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                 for (int g = 0; g < 3; ++g) sbase[Slot::gi_off + lw * (3 * DF_JS) + g * DF_JS + lane] = pv[g];
             }
         } else {
-            prefetch();   // an idle row keeps the cadence: P(b) out, P(b - 1) landed
-            if (has_gi0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            if (b >= DF_NSLOT) df_wait4(dn, b - DF_NSLOT + 1, err, spin_limit);
+            const int none[4] = {0, 0, 0, 0};
+            trip(A, 0, false, has_gi0 ? 2 : 1, none, g_src);   // an idle row keeps the cadence: P(b) out, P(b - 1) landed
+            if (!slot_free) { df_wait4(dn, b - DF_NSLOT + 1, err, spin_limit); slot_free = true; }
         }
         if (lane == 0) v_s[lw] = v;
+      }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) df_flag_st(lds.rdy + set * DF_RB + lw, b + 1);
-        if (prof) dbg[8 * (int64_t)(DF_NLS * b + set) + 3] = wall_clock64();
+        if (lane == 0) df_flag_st(lds.rdy + set * DF_WPS + w, b + 1);
+        if (prof_wave) dbg[8 * (int64_t)(DF_NLS * b + set) + 3] = wall_clock64();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of ours is in flight when the wave ends
-#undef DF_LD_GRAN
-#undef DF_TOUCH
+#undef DF_TRIP
+#undef DF_CASE
+#undef DF_CASES
 }
 
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -793,11 +804,11 @@ __device__ __forceinline__ float df_row_pair_sum(float x) {
 // 4 quad + 2 (ks & 1) + ((ks >> 1) & 1) for row x, evaluates the gates and stores h' itself - no LDS exchange, no
 // barrier.  Always the same order of additions -> deterministic.
 template <int KPT>
-__device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int sl, int pair, const DfLds& lds, int cw) {
+__device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int sl, int pair, const DfLds& lds, int cw, int team) {
     constexpr int H = 16 * KPT;
     constexpr int SEG = DfPad<KPT>::seg, KP8 = DfPad<KPT>::kp8, NK4 = KP8 / 4;
     typedef DfSlot<KPT> Slot;
-    const int tc = threadIdx.x;   // 0..255
+    const int tc = threadIdx.x & 255;   // position inside the team
     const int lane = tc & 63;
     const int quad = lane >> 5, ks = (lane >> 2) & 7, x = lane & 3;
     const bool s0 = (ks & 1) != 0, s1 = (ks & 2) != 0;
@@ -806,9 +817,12 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     const bool gi_ring = C.gi0 != nullptr;   // (read once: a field access in the loop is a scalar load + lgkmcnt(0) per block)
     const int d = C.dir;
     // the two streams of this workgroup: groups NLS * pair and NLS * pair + 1 (the second may not exist)
-    const int grp0 = df_stream_group(pair, 0, S.groups), grp1 = df_stream_group(pair, 1, S.groups);
-    const int nb0 = grp0 >= 0 ? S.sched[S.gtab[d] + 2 * grp0 + 1] : 0;
-    const int nb1 = grp1 >= 0 ? S.sched[S.gtab[d] + 2 * grp1 + 1] : 0;
+    int nb[DF_NLS];   // blocks of the workgroup's streams (0: no such group)
+#pragma unroll
+    for (int q = 0; q < DF_NLS; ++q) {
+        const int grp = df_stream_group(pair, q, S.groups);
+        nb[q] = grp >= 0 ? S.sched[S.gtab[d] + 2 * grp + 1] : 0;
+    }
     float wr[KP8], wz[KP8], wn[KP8];   // the lane's K slice of the r / z / n rows of its unit
     {
         const float4* wp = C.w + (int64_t)sl * (3 * NK4) * 256 + tc;
@@ -840,39 +854,68 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     // Blocks of the two streams in whatever order they become ready.  A stream inside a thin dependent chain is ready
     // once per hop (~3 us, of which this wave works ~0.8): the other stream's blocks fill the gap.  When both have a
     // block, the one whose loader is LESS far ahead goes first (it is the latency-bound one); ties alternate.
-    int done0 = 0, done1 = 0, pref = 0;
-    while (done0 < nb0 || done1 < nb1) {
-        int st;
-        {
+    int done[DF_NLS];
+    int left = 0, pref = 0;
+#pragma unroll
+    for (int q = 0; q < DF_NLS; ++q) { done[q] = 0; left += nb[q]; }
+    if (DF_TEAMS > 1) {   // this team serves its own stream only
+        left = 0;
+#pragma unroll
+        for (int q = 0; q < DF_NLS; ++q) if (q == team) left = nb[q];
+    }
+    while (left > 0) {
+        int st = -1;
+        if (DF_TEAMS > 1) {
+            st = team;
+            int bnext = 0;
+#pragma unroll
+            for (int q = 0; q < DF_NLS; ++q) if (q == team) bnext = done[q];
             unsigned spins = 0;
             for (;;) {
-                int lead0 = 0, lead1 = 0;
-                if (done0 < nb0) {
-                    const int a = df_flag_ld(lds.rdy), b_ = df_flag_ld(lds.rdy + 1), c = df_flag_ld(lds.rdy + 2), e = df_flag_ld(lds.rdy + 3);
-                    lead0 = min(min(a, b_), min(c, e)) - done0;
-                }
-                if (done1 < nb1) {
-                    const int a = df_flag_ld(lds.rdy + DF_RB), b_ = df_flag_ld(lds.rdy + DF_RB + 1), c = df_flag_ld(lds.rdy + DF_RB + 2),
-                              e = df_flag_ld(lds.rdy + DF_RB + 3);
-                    lead1 = min(min(a, b_), min(c, e)) - done1;
-                }
-                if (lead0 > 0 || lead1 > 0) {
-                    st = lead1 <= 0 ? 0 : (lead0 <= 0 ? 1 : (lead0 < lead1 ? 0 : (lead1 < lead0 ? 1 : pref)));
-                    break;
-                }
+                int r = df_flag_ld(lds.rdy + team * DF_WPS);
+#pragma unroll
+                for (int x2 = 1; x2 < DF_WPS; ++x2) r = min(r, df_flag_ld(lds.rdy + team * DF_WPS + x2));
+                if (r > bnext) break;
                 __builtin_amdgcn_s_sleep(1);
+                if (++spins > 4 * spin_limit) { __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            }
+        } else {
+            unsigned spins = 0;
+            for (;;) {
+                // lead of a stream = blocks its loader has finished beyond what this wave has consumed; the smallest
+                // positive lead goes first, ties round-robin starting behind the last stream served
+                int best = 0x7fffffff;
+#pragma unroll
+                for (int e = 0; e < DF_NLS; ++e) {
+                    int r = df_flag_ld(lds.rdy + e * DF_WPS);
+#pragma unroll
+                    for (int x2 = 1; x2 < DF_WPS; ++x2) r = min(r, df_flag_ld(lds.rdy + e * DF_WPS + x2));
+                    const int lead = done[e] < nb[e] ? r - done[e] : 0;
+                    const int key = lead * DF_NLS + ((e - pref + DF_NLS) % DF_NLS);
+                    if (lead > 0 && key < best) { best = key; st = e; }
+                }
+                if (st >= 0) break;
+                __builtin_amdgcn_s_sleep(1);
+                bool give_up = false;
                 if (++spins > 4 * spin_limit) {   // the pass is lost; it must still end (node ids are bounded below)
                     __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    st = done0 < nb0 ? 0 : 1;
+                    give_up = true;
+                }
+                if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = true;
+                if (give_up) {
+#pragma unroll
+                    for (int e = DF_NLS - 1; e >= 0; --e) if (done[e] < nb[e]) st = e;
                     break;
                 }
-                if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { st = done0 < nb0 ? 0 : 1; break; }
             }
         }
         st = __builtin_amdgcn_readfirstlane(st);
-        pref = st ^ 1;
-        const int b = st ? done1 : done0;
-        if (st) ++done1; else ++done0;
+        pref = (st + 1) % DF_NLS;
+        int b = 0;
+#pragma unroll
+        for (int e = 0; e < DF_NLS; ++e) if (e == st) { b = done[e]; ++done[e]; }
+        --left;
         const int slot = b % DF_NSLOT;
         const float* sbase = lds.ring + (st * DF_NSLOT + slot) * Slot::words;
         if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 0] = wall_clock64();
@@ -970,24 +1013,24 @@ __global__ void __launch_bounds__(DF_THREADS, 3) dataflow_kernel(const int32_t* 
     lds.rec = reinterpret_cast<int*>(lds.giring + DF_NLS * DF_GIRING * DF_RB * 3 * DF_JS);
     int* flags = lds.rec + DF_NLS * DF_RB * 8 * 16;
     lds.rdy = flags;
-    lds.dn = flags + DF_NLS * DF_RB;
-    if (tid < DF_NLS * (DF_RB + DF_NCW)) flags[tid] = 0;
+    lds.dn = flags + DF_NLW;
+    if (tid < DF_NLW + DF_NLS * DF_NCW) flags[tid] = 0;
     if (S.dbg && tid == 0) S.dbg[2 * blockIdx.x] = wall_clock64();
     if (S.dbg && (int)blockIdx.x == S.dbg_wg && (tid & 63) == 0)   // where the waves of the stamped workgroup run (HW_REG_HW_ID)
         if (wave < 8) S.dbg[2 * gridDim.x + 8 * (int64_t)wave + 7] = 0x100000000ull | __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
     __syncthreads();
-    if (wave < DF_NCW) {
-        df_compute<KPT>(S, C, sl, pair, lds, wave);
+    if (wave < DF_NCW * DF_TEAMS) {
+        df_compute<KPT>(S, C, sl, pair, lds, wave % DF_NCW, wave / DF_NCW);
     } else {
-        const int set = (wave - DF_NCW) / DF_RB;
+        const int set = (wave - DF_NCW * DF_TEAMS) / DF_WPS;
         const int grp = df_stream_group(pair, set, S.groups);
-        if (grp >= 0) df_loader<KPT>(plan, S, C, sl, grp, lds, (wave - DF_NCW) % DF_RB, set);
+        if (grp >= 0) df_loader<KPT>(plan, S, C, sl, grp, lds, (wave - DF_NCW * DF_TEAMS) % DF_WPS, set);
     }
     if (S.dbg && tid == 0) S.dbg[2 * blockIdx.x + 1] = wall_clock64();   // compute wave 0 is done
 }
 
 template <int KPT> size_t df_lds_bytes() {
-    return (size_t)DF_NLS * (DF_NSLOT * DfSlot<KPT>::words + DF_GIRING * DF_RB * 3 * DF_JS + DF_RB * 8 * 16) * 4 + 64;
+    return (size_t)DF_NLS * (DF_NSLOT * DfSlot<KPT>::words + DF_GIRING * DF_RB * 3 * DF_JS + DF_RB * 8 * 16) * 4 + 256;
 }
 
 // Pack W [3H, K = H] (torch GRUCell layout) for the dataflow kernel: out[(sl * NQ + q) * 256 + tc] (float4), NQ = 3 H/32,

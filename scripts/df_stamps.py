@@ -36,8 +36,9 @@ for k in range(G):
 raw = st[2 * grid:]
 hw = [int(raw[8 * w + 7]) & 0xffffffff for w in range(8)]
 print("waves 0..7 (compute 0-3, loaders 4-7): simd %s cu %s" % ([(h >> 4) & 3 for h in hw], [(h >> 8) & 15 for h in hw]))
-ent = raw[:len(raw) // 16 * 16].reshape(-1, 2, 8)   # [block][stream][stamp]
-for sidx in (0, 1):
+NLS = int(os.environ.get("NLS", 2))
+ent = raw[:len(raw) // (8 * NLS) * (8 * NLS)].reshape(-1, NLS, 8)   # [block][stream][stamp]
+for sidx in range(NLS):
     e = ent[:, sidx, :]
     nb = int((e[:, 0] != 0).sum())
     if nb < 3:

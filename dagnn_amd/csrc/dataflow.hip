@@ -896,7 +896,9 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
                     if (lead > 0 && key < best) { best = key; st = e; }
                 }
                 if (st >= 0) break;
+#ifndef DF_NO_CSLEEP
                 __builtin_amdgcn_s_sleep(1);
+#endif
                 bool give_up = false;
                 if (++spins > 4 * spin_limit) {   // the pass is lost; it must still end (node ids are bounded below)
                     __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -32,11 +32,19 @@ def _check_line(j, n_gpus, steps, warmup, with_cpu=True):
         assert c["kind"] in ("port", "reference") and c["unit"] == j["unit"] and c["cores"] >= 1 and c["value"] > 0
 
 
-def test_committed_round_line_keeps_the_contract():
-    path = os.path.join(ROOT, "profiles", "r01_final_bench.json.log")
+@pytest.mark.parametrize("name", ["r01_final_bench.json.log", "r02_final_bench.json.log"])
+def test_committed_round_line_keeps_the_contract(name):
+    path = os.path.join(ROOT, "profiles", name)
     lines = [l for l in open(path).read().splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    _check_line(json.loads(lines[0]), 1, 30, 5)
+    j = json.loads(lines[0])
+    _check_line(j, 1, 30, 5)
+    if name.startswith("r02"):   # round 2: where the traffic figure comes from, both CPU legs, the other configurations
+        assert j["roofline"]["traffic_source"].startswith("profiles/r02_pmc_traffic.json")
+        assert j["roofline"]["schedule"] == "dataflow" and "ms_per_step_median" in j
+        assert j["cpu_baseline"]["vectorised"]["value"] > 0 and j["cpu_baseline"]["cpu"]
+        assert set(j["other_configs"]) >= {"cfg1_NA_B64_h128_L2_unidir", "cfg4_BN_B128_h256_L2_bidir"}
+        assert j["training_step"]["ms_per_step_median"] > 0
 
 
 def _run_bench(args, env_extra=None, launcher=()):

@@ -219,6 +219,63 @@ def make_bn(ref_bn, ref_util, ref_batch_mod, name, *, hs, L, bidir, w_seed, data
           Hg=_np(Hg), mu=_np(mu), logvar=_np(logvar))
 
 
+# ------------------------------------------------------------------------------- D-VAE decoder-side single-vertex step
+def make_ipropagate(ref_mod, cls_name, name, *, kind, hs, L, w_seed, data_seed, K, n):
+    """`_ipropagate_to(G, v, propagator)` of the reference (`dvae/dagnn.py:187-239`, `dvae/dagnn_bn.py:179-238`) on
+    K stand-in igraph graphs of up to n vertices: the new states at vertex v from the states of its predecessors
+    (dense padded attention over the predecessor lists), for two vertices, without and with a given H."""
+    import igraph
+    nvt = 8 if kind == "na" else 10
+    model = getattr(ref_mod, cls_name)(nvt, hs, hs, nvt, nvt, 0, 1, hs=hs, nz=56, num_nodes=nvt, agg="attn_h",
+                                       num_layers=L, bidirectional=False, out_wx=False, out_pool_all=False,
+                                       out_pool="max", dropout=0.0).eval()
+    seeded_fill(model, w_seed)
+    rng = np.random.default_rng(data_seed)
+    counts = rng.integers(max(3, n - 3), n + 1, size=K)
+    types = np.full((K, n), -1, dtype=np.int64)
+    adj = np.zeros((K, n, n), dtype=np.int64)      # adj[k, u, v] = 1: edge u -> v (u < v)
+    states = rng.standard_normal((K, n, L, hs)).astype(np.float32) * 0.5
+    for k in range(K):
+        types[k, :counts[k]] = rng.integers(0, nvt, size=counts[k])
+        for v in range(1, counts[k]):
+            for u in range(v):
+                adj[k, u, v] = int(rng.random() < (0.9 if u == v - 1 else 0.35))
+    adj[0, :, 2] = 0                               # a vertex without predecessors among the cases
+
+    def graphs():
+        gs = []
+        for k in range(K):
+            g = igraph.Graph(directed=True)
+            g.add_vertices(int(counts[k]))
+            for v in range(counts[k]):
+                g.vs[v]["type"] = int(types[k, v])
+                for l in range(L):
+                    g.vs[v]["H_forward%d" % l] = torch.from_numpy(states[k, v, l][None].copy())
+                for u in range(v):
+                    if adj[k, u, v]:
+                        g.add_edge(u, v)
+            gs.append(g)
+        return gs
+
+    out = {}
+    H_given = torch.from_numpy(rng.standard_normal((K, hs)).astype(np.float32) * 0.5)
+    with torch.no_grad():
+        for v in (2, n - 2):
+            G = graphs()
+            Hv = model._ipropagate_to(G, v, model.grud)
+            alive = [k for k in range(K) if counts[k] > v]
+            out["v%d_alive" % v] = np.array(alive)
+            out["v%d_Hv" % v] = _np(Hv)
+            out["v%d_states" % v] = np.stack([np.stack([_np(G[k].vs[v]["H_forward%d" % l])[0] for l in range(L)])
+                                              for k in alive])
+            G = graphs()
+            out["v%d_Hv_given" % v] = _np(model._ipropagate_to(G, v, model.grud, H=H_given.clone()))
+    meta = dict(kind=kind, hs=hs, L=L, w_seed=w_seed, K=K, n=n, vs=[2, n - 2],
+                state_dict={k: list(v.shape) for k, v in model.state_dict().items()})
+    _save(name, meta, counts=counts, types=types, adj=adj, states=states, H_given=_np(H_given), **out)
+
+
+
 def make_augment(name):
     """`augment_edge2` of the reference (ogbg-code/utils2.py:30-78) on seeded ASTs: inputs and outputs."""
     from types import SimpleNamespace
@@ -302,6 +359,14 @@ def _variants_only(ref_dagnn, ref_utils, ref_dagutils, common):
                    bidir=1, w_seed=100 + seed, row_stride=2, **extra, **common)
 
 
+def _ipropagate_only():
+    importlib.import_module("util")
+    ref_na = importlib.import_module("dagnn")
+    ref_bn = importlib.import_module("dagnn_bn")
+    make_ipropagate(ref_na, "DAGNN", "iprop_na_h64_L2", kind="na", hs=64, L=2, w_seed=221, data_seed=31, K=6, n=8)
+    make_ipropagate(ref_bn, "DAGNN_BN", "iprop_bn_h32_L3", kind="bn", hs=32, L=3, w_seed=222, data_seed=32, K=5, n=10)
+
+
 def _dvae_only():
     ref_util = importlib.import_module("util")
     ref_na = importlib.import_module("dagnn")
@@ -327,6 +392,8 @@ def main():
         return
     if only == "dvae_grad":
         return _dvae_only()
+    if only == "ipropagate":
+        return _ipropagate_only()
     # training-step gradients: loss and parameter gradients of one step
     if True:
         make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, "grad_h32_bidir", data_seed=11, B=6, mean_n=30, H=32,
@@ -396,6 +463,7 @@ def main():
             out_pool_all=True, out_pool="max")
     make_bn(ref_bn, ref_util, ref_batch_mod, "bn_h64_poolall_mean", hs=64, L=2, bidir=True, w_seed=206, data_seed=8,
             nrows=12, out_pool_all=True, out_pool="mean")
+    _ipropagate_only()   # decoder-side single-vertex step (needs the igraph stand-in)
 
 
 if __name__ == "__main__":

@@ -349,7 +349,10 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    cpu_sd = {k: v.detach().cpu() for k, v in model.state_dict().items()} if (rank == 0 and args.cpu_passes > 0) else None
+    # the CPU baseline and the other configurations are single-process legs: rank 0 at N = 1 only (the other ranks would
+    # sit in the final barrier for half a minute)
+    cpu_leg = rank == 0 and world == 1 and args.cpu_passes > 0
+    cpu_sd = {k: v.detach().cpu() for k, v in model.state_dict().items()} if cpu_leg else None
     # the same forward with the plan built by the loader (dagnn_amd.collate_with_plan): no plan
     # kernels and no device->host read inside the step.  Reported next to the headline, never as `value`.
     planned_res = None
@@ -416,7 +419,7 @@ def main():
         train_res = training_leg(model, fresh_inputs(master, tw + args.train_steps), B, S, V, args.train_steps, tw,
                                  world, device, barrier)
     other_res = None
-    if args.other_configs and rank == 0 and args.streams == 1:
+    if args.other_configs and rank == 0 and world == 1 and args.streams == 1:
         other_res = other_configs(device)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
@@ -503,7 +506,7 @@ def main():
             result["training_step"] = train_res
         if other_res is not None:
             result["other_configs"] = other_res
-        if args.cpu_passes > 0:
+        if cpu_leg:
             result["cpu_baseline"] = cpu_baseline(cpu_sd, batch_cpu, L, S, args.cpu_passes, args.cpu_threads)
         print(json.dumps(result))
     barrier()

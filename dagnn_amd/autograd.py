@@ -109,6 +109,9 @@ class Recurrence(torch.autograd.Function):
                                     arena=mod._arena_for(x, "backward"), vid_mod=mod._vid_nodes,
                                     static_score=ctx.sscore)
 
+        ep = engine._span("backward_epilogue", x)
+        ep.__enter__()
+
         def gates(t):  # [N, 3Hp] in gate blocks of Hp -> [N, 3H]
             return t if Hp == H else t.view(N, 3, Hp)[:, :, :H].reshape(N, 3 * H)
 
@@ -146,4 +149,5 @@ class Recurrence(torch.autograd.Function):
                     g_attn[0, dq + kd:dq + kd + mod._vid_nodes] = sigma.view(-1, mod._vid_nodes).sum(0)
                 grads += [g_wih, g_whh, g_bih, g_bhh, g_attn, None if attn_b is None else torch.zeros_like(attn_b),
                           g_edge_w, g_edge_b]
+        ep.__exit__(None, None, None)
         return (None, None, None, None, dx if x.requires_grad else None) + tuple(grads)

@@ -22,6 +22,10 @@ class DagnnHipError(RuntimeError):
     pass
 
 
+class ReadoutJob(C.Structure):
+    _fields_ = [("h", C.c_void_p), ("ld_h", C.c_int), ("width", C.c_int), ("dir", C.c_int), ("col_off", C.c_int)]
+
+
 class Plan(C.Structure):
     _fields_ = [("data", C.c_void_p), ("bytes", C.c_size_t), ("N", C.c_int64), ("E", C.c_int64),
                 ("B", C.c_int64), ("num_edge_feats", C.c_int)]
@@ -147,6 +151,7 @@ SYMBOLS = {
     "dagnn_score_parts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "dagnn_readout_max": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int, C.c_void_p]),
+    "dagnn_readout_max_batch": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_readout_pool": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_int, C.c_int, C.c_void_p]),
     "dagnn_backward_prepare": (C.c_int, [C.POINTER(Plan), C.POINTER(BackwardArgs), C.c_void_p]),

@@ -146,6 +146,25 @@ __global__ void __launch_bounds__(64) df_assign_kernel(const int32_t* __restrict
     int depth = 0;
     bool empty = true;
     const int steps = staged ? count : 2 * B;
+    // fast form of the B-step chain when (cost << 6 | group) fits 32 bits: ONE wave minimum per graph gives the least
+    // load and, through the low bits, the lowest group that has it (38 -> 17 us at B = 128)
+    const long long bound = (long long)c_row * plan[L.node_ptr + B] + (long long)c_layer * (staged && count > 0 ? s_d[0] : 0);
+    if (staged && bound < (1ll << 25)) {
+        unsigned load32 = 0;
+#pragma unroll 4
+        for (int j = 0; j < count; ++j) {
+            const int g = s_g[j], dg = s_d[j], ng = s_n[j];
+            const unsigned cand = load32 + (unsigned)(c_row * ng) + (empty ? (unsigned)(c_layer * dg) : 0u);
+            const unsigned best = df_wave_umin(lane < G ? (cand << 6) | (unsigned)lane : 0xffffffffu);
+            const int k = (int)(best & 63u);
+            if (lane == k) {
+                load32 = cand;
+                if (empty) { depth = dg; empty = false; }
+            }
+            if (lane == 0) ws[S.grp_of + g] = k;
+        }
+        load = load32;
+    } else
     for (int j = 0; j < steps; ++j) {
         int g, dg, ng;
         if (staged) {

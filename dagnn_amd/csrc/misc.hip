@@ -73,6 +73,28 @@ __global__ void __launch_bounds__(256) readout_max_kernel(const int32_t* __restr
     }
 }
 
+struct ReadoutJobs { const float* h[16]; int ld_h[16], width[16], dir[16], col_off[16]; };
+__global__ void __launch_bounds__(256) readout_max_batch_kernel(const int32_t* __restrict__ plan, PlanLayout L, ReadoutJobs J,
+                                                                 float* __restrict__ out, int ld_out) {
+    const int g = blockIdx.x, k = blockIdx.y;
+    const int od = 1 - J.dir[k];
+    const int n0 = plan[L.node_ptr + g];
+    const int depth = plan[L.depth[od] + g];
+    const int32_t* ls = plan + L.lstart[od] + n0 + g;
+    const int32_t* order = plan + L.order[od];
+    const int p0 = depth > 0 ? ls[0] : 0, p1 = depth > 0 ? ls[1] : 0;
+    const float* __restrict__ h = J.h[k];
+    const int ld_h = J.ld_h[k];
+    for (int j = threadIdx.x; j < J.width[k]; j += blockDim.x) {
+        float m = 0.f;  // PyG scatter-max leaves rows nothing lands on at zero
+        for (int p = p0; p < p1; ++p) {
+            float v = h[(int64_t)order[p] * ld_h + j];
+            m = (p == p0) ? v : fmaxf(m, v);
+        }
+        out[(int64_t)g * ld_out + J.col_off[k] + j] = m;
+    }
+}
+
 // Generic read-out (dagnn.py:194-202 `global_{max,mean,add}_pool`; P_ATTN is a softmax over a size-1 dimension, i.e.
 // add): scope 0 / 1 = the output nodes of direction 0 / 1, scope 2 = every node of the graph (`out_pool_all`).
 // One workgroup per graph, a thread per column, nodes in id order (a fixed summation order).
@@ -144,6 +166,24 @@ extern "C" int dagnn_readout_max(const dagnn_plan* pl, const float* h, int ld_h,
     PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
     hipLaunchKernelGGL(readout_max_kernel, dim3((unsigned)pl->B), dim3(256), 0, (hipStream_t)stream,
                        (const int32_t*)pl->data, L, dir, h, ld_h, width, out, ld_out, col_off);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
+extern "C" int dagnn_readout_max_batch(const dagnn_plan* pl, const dagnn_readout_job* jobs, int n, float* out, int ld_out,
+                                       void* stream) {
+    if (!pl || !pl->data || !jobs || !out || n < 0 || n > 16) return DAGNN_EINVAL;
+    if (pl->B == 0 || n == 0) return DAGNN_OK;
+    ReadoutJobs J;
+    for (int k = 0; k < n; ++k) {
+        const dagnn_readout_job& q = jobs[k];
+        if (!q.h || q.width <= 0 || (q.dir != 0 && q.dir != 1) || q.ld_h < q.width || q.col_off < 0 || ld_out < q.col_off + q.width)
+            return DAGNN_EINVAL;
+        J.h[k] = q.h; J.ld_h[k] = q.ld_h; J.width[k] = q.width; J.dir[k] = q.dir; J.col_off[k] = q.col_off;
+    }
+    PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
+    hipLaunchKernelGGL(readout_max_batch_kernel, dim3((unsigned)pl->B, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                       (const int32_t*)pl->data, L, J, out, ld_out);
     DAGNN_CHECK_LAUNCH();
     return DAGNN_OK;
 }

@@ -581,6 +581,18 @@ def readout_max(plan: PlanHandle, h: torch.Tensor, direction: int, out: torch.Te
                                         out.data_ptr(), out.shape[1], col_off, _stream(h)), "dagnn_readout_max")
 
 
+def readout_max_batch(plan: PlanHandle, jobs, out: torch.Tensor) -> None:
+    """`readout_max` for several (h, direction, col_off) in one launch."""
+    arr = (_lib.ReadoutJob * len(jobs))()
+    keep = []
+    for k, (h, direction, col_off) in enumerate(jobs):
+        h = _rows(h, "h")
+        keep.append(h)
+        arr[k].h, arr[k].ld_h, arr[k].width, arr[k].dir, arr[k].col_off = h.data_ptr(), h.stride(0), h.shape[1], int(direction), int(col_off)
+    check(_lib.load().dagnn_readout_max_batch(C.byref(plan.desc), arr, len(jobs), out.data_ptr(), out.shape[1], _stream(out)),
+          "dagnn_readout_max_batch")
+
+
 def readout_pool(plan: PlanHandle, h: torch.Tensor, scope: int, how: str, out: torch.Tensor, col_off: int) -> None:
     """out[:, col_off : col_off + width] = max / add / mean pool of h over scope 0 / 1 (output nodes of that direction)
     or 2 (all nodes of the graph)."""

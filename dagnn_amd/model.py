@@ -271,11 +271,16 @@ class DAGNN(nn.Module):
     def _readout(self, plan, B, x, h):
         """Max-pool over the output nodes of both directions (dagnn.py:184-193), columns [d][x?, layer 0.. L-1]."""
         out = torch.empty(B, self.out_hidden_dim, dtype=torch.float32, device=x.device)
-        col = 0
+        col, jobs = 0, []
         for d in (0, 1):
             for t in ([x] if self.out_wx else []) + [h[d][i] for i in range(self.num_layers)]:
-                engine.readout_max(plan, t, d, out, col)
+                jobs.append((t, d, col))
                 col += t.shape[1]
+        if len(jobs) <= 16:
+            engine.readout_max_batch(plan, jobs, out)   # one launch for all (direction, stacked layer) columns
+        else:
+            for t, d, c in jobs:
+                engine.readout_max(plan, t, d, out, c)
         return out
 
     def _readout_backward(self, plan, x, h, gout, g_ext, dx):

@@ -321,6 +321,15 @@ int dagnn_dataflow_layout(int64_t N, int64_t B, int groups, int64_t* offsets13 /
 int dagnn_readout_max(const dagnn_plan* plan /* host */, const float* h, int ld_h, int width, int dir,
                       float* out, int ld_out, int col_off, void* stream);
 
+/* The same for several state buffers in ONE launch (the bidirectional L-layer read-out of dagnn.py:184-193 is 2 L calls
+ * of the above: launch-bound).  jobs: host array, n <= 16. */
+typedef struct dagnn_readout_job {
+    const float* h;   /* [N, ld_h] */
+    int ld_h, width, dir, col_off;
+} dagnn_readout_job;
+int dagnn_readout_max_batch(const dagnn_plan* plan /* host */, const dagnn_readout_job* jobs /* host */, int n,
+                            float* out, int ld_out, void* stream);
+
 /* The other read-outs of dagnn.py:194-202 (`global_max_pool` / `global_mean_pool` / `global_add_pool`; `P_ATTN`,
  * dagnn.py:114-117, is a softmax over a size-1 dimension and therefore add-pooling): pool `width` columns of
  * h [N,ld_h] per graph over scope 0 / 1 = the output nodes of direction 0 / 1 (as dagnn_readout_max) or scope 2 = all

@@ -112,9 +112,22 @@ __device__ __forceinline__ unsigned df_wave_umin(unsigned v) {
 
 // ---- LPT assignment: graphs in order of decreasing depth (plan items), each to the group whose load it raises the
 // least; load_k = c_layer * (depth of the first = deepest graph of k) + c_row * (nodes of k).  One wave, lane = group.
-__global__ void __launch_bounds__(64) df_assign_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws,
-                                                        DfLayout S, int B, int G, int c_layer, int c_row, const int32_t* __restrict__ status) {
+// Workgroups 1.. of the launch initialise the rest of the workspace meanwhile (tables and counters = 0, records = -1:
+// two memsets less on a launch-bound path); workgroup 0 clears the head it writes into itself.
+__global__ void __launch_bounds__(256) df_assign_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws,
+                                                         DfLayout S, int B, int G, int c_layer, int c_row, const int32_t* __restrict__ status) {
     if (status && status[0] != 0) return;   // the batch violates the plan contract: nothing here can be trusted
+    if (blockIdx.x > 0) {
+        const int64_t nfill = (int64_t)(gridDim.x - 1) * blockDim.x, me = (int64_t)(blockIdx.x - 1) * blockDim.x + threadIdx.x;
+        int4* z = reinterpret_cast<int4*>(ws + S.gtab[0]);   // (every array of the layout starts on a multiple of 4 words)
+        const int64_t nz = (S.grec[0] - S.gtab[0]) / 4, nf = (S.total - S.grec[0]) / 4;
+        for (int64_t i = me; i < nz; i += nfill) z[i] = make_int4(0, 0, 0, 0);
+        int4* f = reinterpret_cast<int4*>(ws + S.grec[0]);
+        for (int64_t i = me; i < nf; i += nfill) f[i] = make_int4(-1, -1, -1, -1);
+        return;
+    }
+    if (threadIdx.x >= 64) return;
+    for (int64_t i = threadIdx.x; i < S.gtab[0]; i += 64) ws[i] = 0;   // header + grp_of / gdepth / gload / loff (+ padding)
     // the sequential part below is B dependent steps: its operands (graph, depth, nodes, in schedule order) are
     // staged in LDS first - from global memory every step is three dependent round trips (measured 76 us at B = 128)
     constexpr int CAP = 4096;
@@ -1127,12 +1140,14 @@ extern "C" int dagnn_dataflow_schedule(const dagnn_plan* pl, void* ws_, size_t w
     hipStream_t st = (hipStream_t)stream_;
     int32_t* ws = (int32_t*)ws_;
     const int32_t* plan = (const int32_t*)pl->data;
-    hipError_t e = hipMemsetAsync(ws, 0, (size_t)S.grec[0] * 4, st);   // header, tables, counters
-    if (e != hipSuccess) return DAGNN_EHIP(e);
-    e = hipMemsetAsync(ws + S.grec[0], 0xff, (size_t)(S.total - S.grec[0]) * 4, st);   // padding records: node = -1
-    if (e != hipSuccess) return DAGNN_EHIP(e);
-    if (B == 0 || N == 0) return DAGNN_OK;
-    hipLaunchKernelGGL(df_assign_kernel, dim3(1), dim3(64), 0, st, plan, L, ws, S, (int)B, groups, cost_layer, cost_row, status);
+    if (B == 0 || N == 0) {   // an empty batch: the initial state only (header, tables, counters = 0; records: node = -1)
+        hipError_t e = hipMemsetAsync(ws, 0, (size_t)S.grec[0] * 4, st);
+        if (e != hipSuccess) return DAGNN_EHIP(e);
+        e = hipMemsetAsync(ws + S.grec[0], 0xff, (size_t)(S.total - S.grec[0]) * 4, st);
+        return e == hipSuccess ? DAGNN_OK : DAGNN_EHIP(e);
+    }
+    // workgroup 0: the LPT assignment; the others initialise tables and records next to it
+    hipLaunchKernelGGL(df_assign_kernel, dim3(1 + 512), dim3(256), 0, st, plan, L, ws, S, (int)B, groups, cost_layer, cost_row, status);
     DAGNN_CHECK_LAUNCH();
     hipLaunchKernelGGL(df_count_kernel, dim3((unsigned)B, 2), dim3(256), 0, st, plan, L, ws, S, status);
     DAGNN_CHECK_LAUNCH();

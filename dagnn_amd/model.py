@@ -364,8 +364,8 @@ class DAGNN(nn.Module):
             if not G.x.is_cuda:
                 raise engine.DagnnHipError("DAGNN.forward needs its batch on a ROCm GPU (there is no CPU path)")
             from . import variants
-            G.bi_layer_index = torch.stack([torch.stack([G._bi_layer_idx0, G._bi_layer_index0], dim=0),
-                                            torch.stack([G._bi_layer_idx1, G._bi_layer_index1], dim=0)], dim=0)
+            G.bi_layer_index = torch.stack([G._bi_layer_idx0, G._bi_layer_index0, G._bi_layer_idx1, G._bi_layer_index1],
+                                        dim=0).view(2, 2, -1)   # (one copy kernel instead of three)
             B = num_graphs_of(G)
             G.x = self.encoder(G.x, G.node_depth.view(-1, ))
             if self.variant_backend == "torch" or (torch.is_grad_enabled()
@@ -379,8 +379,8 @@ class DAGNN(nn.Module):
         train = self._training_pass()
 
         # side effect 1 (dagnn.py:130-133)
-        G.bi_layer_index = torch.stack([torch.stack([G._bi_layer_idx0, G._bi_layer_index0], dim=0),
-                                        torch.stack([G._bi_layer_idx1, G._bi_layer_index1], dim=0)], dim=0)
+        G.bi_layer_index = torch.stack([G._bi_layer_idx0, G._bi_layer_index0, G._bi_layer_idx1, G._bi_layer_index1],
+                                        dim=0).view(2, 2, -1)   # (one copy kernel instead of three)
         B = num_graphs_of(G)
         plan = self._plan_of(G, B, overlap=True)   # (optionally on a side stream, next to the encoder and the input GEMM)
         # side effects 2+3 (dagnn.py:139, utils.py:27): embedding replaces G.x, depth clamped in place

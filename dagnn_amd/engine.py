@@ -77,6 +77,9 @@ BWD_TAIL_MAX_BLOCKS = _env_int("DAGNN_AMD_BWD_TAIL_MAX_BLOCKS", 4)
 # 1: plan / schedule kernels on a side stream next to the encoder + input GEMM.  Off by default - measured on MI355X: no
 # gain (2.405 vs 2.413 ms per forward); the GEMM's workgroups hold the CUs' LDS, so the 33-KB-LDS plan kernels only get
 # their turn as it drains (rocprofv3 timeline: plan_graph_kernel 101 us next to the GEMM, 60 us alone).
+# Tried again with the plan kernels' LDS cut to 17 / 12 KB so that they fit next to the GEMM's four workgroups per CU:
+# they then run concurrently but 2-4x slower (plan_ptr 61 us instead of 15, plan_graph 103 instead of 49), bench.py
+# 2.302-2.312 against 2.3085 ms - nothing - and two processes sharing one GPU (the two-rank bench test) failed.
 PLAN_OVERLAP = _env_int("DAGNN_AMD_PLAN_OVERLAP", 0)
 DATAFLOW = _env_int("DAGNN_AMD_DATAFLOW", 1)                # 1: the persistent graph-affine dataflow kernel where it applies (H <= 256)
 DF_COST_LAYER = _env_int("DAGNN_AMD_DF_COST_LAYER", 4)      # schedule cost of one dependent layer, in rows (hop latency / row cost)

@@ -47,6 +47,12 @@ def test_host_only_entry_points_without_gpu():
     assert lib.dagnn_gather_rows(None, 4, 4, 1, 8, 9, None, 4, 0, None) == -22
     assert lib.dagnn_readout_pool(None, None, 4, 4, 0, 0, None, 4, 0, None) == -22
     assert lib.dagnn_pack_batch(None, 1, None) == -22
+    assert lib.dagnn_readout_max_batch(None, None, 1, None, 4, None) == -22
+    rj = (_lib.ReadoutJob * 1)()
+    rj[0].h, rj[0].ld_h, rj[0].width, rj[0].dir, rj[0].col_off = 64, 4, 8, 0, 0   # pitch < width
+    plan0 = _lib.Plan(64, 0, 4, 3, 1, 0)
+    assert lib.dagnn_readout_max_batch(ctypes.byref(plan0), rj, 1, 64, 8, None) == -22
+    assert lib.dagnn_readout_max_batch(ctypes.byref(plan0), rj, 17, 64, 8, None) == -22 and lib.dagnn_readout_max_batch(ctypes.byref(plan0), rj, 0, 64, 8, None) == 0
     job = (_lib.PackJob * 1)()
     job[0].w, job[0].H, job[0].K = 64, 48, 64   # H % 32 != 0
     assert lib.dagnn_pack_batch(job, 1, None) == -22 and lib.dagnn_pack_batch(job, 0, None) == 0

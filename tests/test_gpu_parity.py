@@ -591,6 +591,33 @@ def test_device_side_failures_raise(device, monkeypatch):
             model(b.clone().to(device))
 
 
+def test_data_parallel_shim_runs_the_first_batch_on_the_gpu(device):
+    """`dagnn_amd.DataParallel(model)(list_of_batches)` on one device = `model(list[0].to(device))`
+    (`tg/data_parallel.py:48-50`), batches handed over on the host as the reference's loader does; and the batched
+    max read-out equals one launch per column block."""
+    from dagnn_amd import DataParallel, collate_sharded
+    model = _headline_model(H=64, L=2, V=16, seed=5).to(device)
+    graphs = synth.code2_graphs(9, 10, 40)
+    shards = collate_sharded(graphs, 2)
+    dp = DataParallel(model)
+    assert dp.src_device.type == "cuda"
+    with torch.no_grad():
+        a = dp([s.clone() for s in shards])
+        b = model(shards[0].clone().to(device))
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    G = shards[0].clone().to(device)
+    with torch.no_grad():
+        model(G)
+    plan = engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, shards[0].num_graphs, G.edge_attr)
+    hs = [G.h[d][i] for d in range(2) for i in range(2)]
+    one = torch.zeros(shards[0].num_graphs, 4 * 64, device=device)
+    many = torch.zeros_like(one)
+    engine.readout_max_batch(plan, [(h, k // 2, 64 * k) for k, h in enumerate(hs)], one)
+    for k, h in enumerate(hs):
+        engine.readout_max(plan, h, k // 2, many, 64 * k)
+    assert torch.equal(one, many)
+
+
 def test_loader_side_plan_with_edge_features_the_model_does_not_use(device):
     """`collate_with_plan` packs `edge_attr` into the plan; a model built with `w_edge_attr=False` has no gain for
     them: forward and the training step then build the plan on the device without the features (same results as

@@ -198,11 +198,23 @@ def other_configs(device):
         na = DAGNN_NA(8, 128, 128, 8, 8, 0, 1, hs=128, nz=56, num_nodes=8, num_layers=2, bidirectional=False).eval().to(device)
         b = synth.dvae_batch([synth.decode_enas_row(r) for r in synth.enas_rows(0, 64)]).to(device)
         ms = timed(lambda: na(b.clone()), 30, 5)
-        out["cfg1_NA_B64_h128_L2_unidir"] = {"ms_per_batch": round(ms, 4), "graphs_per_s": round(64 / ms * 1e3, 1)}
+        def small_roofline(ms, N, D, L, H, Din, T):
+            # GRU products of the recurrence: D [2 N (Din + H) 3 H + (L - 1) 12 N H^2]  
+            gf = D * (2.0 * N * (Din + H) * 3 * H + (L - 1) * 12.0 * N * H * H) / 1e9
+            tf = gf / ms
+            return {"bound": "mfma", "achieved": round(tf, 4), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 6), "gru_gflop_per_batch": round(gf, 3), "topo_layers": T,
+                    "note": "whole forward(G) over the GRU flops: a %d-node batch is launch- and latency-bound (about 25 "
+                            "launches around one persistent recurrence kernel of %d dependent layers)" % (N, T)}
+        T1 = int(b.bi_layer_index[0][0].max()) + 1
+        out["cfg1_NA_B64_h128_L2_unidir"] = {"ms_per_batch": round(ms, 4), "graphs_per_s": round(64 / ms * 1e3, 1),
+                                             "roofline": small_roofline(ms, int(b.x.shape[0]), 1, 2, 128, 8, T1)}
         bn = DAGNN_BN(10, 256, 256, 10, 10, 0, 1, hs=256, nz=56, num_nodes=10, num_layers=2, bidirectional=True).eval().to(device)
         b = synth.dvae_batch([synth.decode_bn_row(r) for r in synth.bn_rows(0, 128)]).to(device)
         ms = timed(lambda: bn(b.clone()), 30, 5)
-        out["cfg4_BN_B128_h256_L2_bidir"] = {"ms_per_batch": round(ms, 4), "graphs_per_s": round(128 / ms * 1e3, 1)}
+        T4 = int(b.bi_layer_index[0][0].max()) + 1
+        out["cfg4_BN_B128_h256_L2_bidir"] = {"ms_per_batch": round(ms, 4), "graphs_per_s": round(128 / ms * 1e3, 1),
+                                             "roofline": small_roofline(ms, int(b.x.shape[0]), 2, 2, 256, 10, T4)}
         m5 = build_model(512, 5, 5002, 5, device)
         b5 = synth.code2_batch(seed=0, num_graphs=256)
         N5, E5 = b5.x.shape[0], b5.edge_index.shape[1]
@@ -214,6 +226,8 @@ def other_configs(device):
         out["cfg5_code2_B256_h512_L5_bidir"] = {"ms_per_batch": round(ms, 4), "graphs_per_s": round(256 / ms * 1e3, 1),
                                                 "gru_gflop_per_batch": round(gf, 1),
                                                 "frac_of_fp32_peak": round(gf / ms / FP32_MATRIX_PEAK_TFLOPS, 4),
+                                                "roofline": {"bound": "mfma", "achieved": round(gf / ms, 3), "peak": FP32_MATRIX_PEAK_TFLOPS,
+                                                             "unit": "TFLOP/s", "frac": round(gf / ms / FP32_MATRIX_PEAK_TFLOPS, 5)},
                                                 "path": "lock-step launches (the dataflow kernel covers h <= 256)"}
         del m5
     return out

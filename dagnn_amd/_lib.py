@@ -66,7 +66,7 @@ class FrontierArgs(C.Structure):
                 ("agg_scratch", C.c_void_p), ("agg_scratch_rows", C.c_int),
                 ("tail_replicas", C.c_int), ("tail_slice_units", C.c_int), ("tail_max_blocks", C.c_int), ("epoch", C.c_uint),
                 ("tail_err", C.c_void_p), ("debug_timing", C.c_void_p), ("side_stream", C.c_void_p),
-                ("layer_split", C.POINTER(C.c_int32) * MAX_DIRS)]
+                ("layer_split", C.POINTER(C.c_int32) * MAX_DIRS), ("fork_event", C.c_void_p), ("join_event", C.c_void_p)]
 
 
 class DataflowCell(C.Structure):
@@ -91,7 +91,8 @@ class BackwardArgs(C.Structure):
     _fields_ = [("cell", (BackwardCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
                 ("H", C.c_int), ("ld_h", C.c_int), ("vid_mod", C.c_int), ("num_cus", C.c_int), ("thin_wgs", C.c_int),
                 ("tail_replicas", C.c_int), ("tail_max_blocks", C.c_int), ("epoch", C.c_uint), ("tail_err", C.c_void_p),
-                ("side_stream", C.c_void_p), ("layer_split", C.POINTER(C.c_int32) * MAX_DIRS)]
+                ("side_stream", C.c_void_p), ("layer_split", C.POINTER(C.c_int32) * MAX_DIRS),
+                ("fork_event", C.c_void_p), ("join_event", C.c_void_p)]
 
 
 AGG_ATTN, AGG_MATTN, AGG_GATED, AGG_ADD, AGG_MAX, AGG_GIVEN = range(6)
@@ -116,6 +117,10 @@ class VariantCell(C.Structure):
                 ("ld_input", C.c_int64), ("w_in_t", C.c_void_p), ("w_agg_t", C.c_void_p), ("b_in", C.c_void_p),
                 ("b_agg", C.c_void_p), ("h", C.c_void_p), ("ld_h", C.c_int64), ("map", VariantMap * 3),
                 ("num_maps", C.c_int32), ("reserved", C.c_int32)]
+
+
+class IpropLayer(C.Structure):
+    _fields_ = [("w_ih", C.c_void_p), ("w_hh", C.c_void_p), ("b_ih", C.c_void_p), ("b_hh", C.c_void_p), ("in_dim", C.c_int)]
 
 
 class VariantArgs(C.Structure):
@@ -165,6 +170,8 @@ SYMBOLS = {
                                           C.c_void_p]),
     "dagnn_variant_run": (C.c_int, [C.POINTER(Plan), C.POINTER(VariantArgs), C.POINTER(C.POINTER(C.c_int32)),
                                     C.POINTER(C.c_int32), C.c_void_p]),
+    "dagnn_iprop_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int, C.POINTER(IpropLayer), C.c_int, C.c_void_p, C.c_void_p]),
     "dagnn_gather_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int, C.c_void_p]),
 }

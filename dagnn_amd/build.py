@@ -45,13 +45,20 @@ def hipcc_path() -> str:
 
 
 def _compile(src: str, obj: str, verbose: bool) -> None:
-    cmd = [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-c", "-o", obj, src] + \
+    """One object, written next to its final name and renamed on success: two ranks / pytest workers that both find a
+    stale library never link each other's half-written object, and a compile killed mid-write leaves no object that
+    looks fresh."""
+    tmp = "%s.tmp.%d" % (obj, os.getpid())
+    cmd = [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-c", "-o", tmp, src] + \
         os.environ.get("DAGNN_AMD_HIPCC_FLAGS", "").split()
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed on %s:\n%s%s" % (src, res.stdout, res.stderr))
+    os.replace(tmp, obj)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -174,8 +174,9 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
          for d in range(2)]
     plan.wait_ready()   # a plan built on the side stream (model._plan_of) meets the caller's stream here
     groups = engine.dataflow_groups(dev, len(dirs), L, Hp, plan.B) if (arena is not None and N > 0) else 0
+    if arena is not None:
+        arena.poll()   # a failure an earlier pass reported (no synchronisation); either path below is watched
     if groups > 0:
-        arena.poll()   # a failure an earlier pass reported (no synchronisation)
         pack_dataflow(cells.values())
         engine.dataflow_run(plan, dirs, L, Hp, cells, gi, h, groups, vid_mod=vid_nodes, arena=arena,
                             static_score=static_score, score_parts=keep is not None)
@@ -217,6 +218,16 @@ def run_stack(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tuple[int, i
     if Hp != H:
         return [[h[d][i][:, :H] if h[d][i] is not None else None for i in range(L)] for d in range(2)]
     return h  # type: ignore[return-value]
+
+
+def check_arenas(mod) -> None:
+    """Blocking device-side error check of every pass `mod` has launched (all devices / streams it ran on): raises
+    `DagnnHipError` if a bounded wait of a persistent kernel expired or a batch violated the plan contract.  The
+    healthy path never synchronises - `forward` only looks at finished read-backs of EARLIER passes - so a caller that
+    consumes outputs without another forward behind them (the last batch of an evaluation loop,
+    `ogbg-code/main_pyg.py:91-124`) calls this once where it synchronises anyway."""
+    for a in list(mod._arenas.values()):
+        a.check()
 
 
 def default_schedule() -> str:

@@ -927,7 +927,7 @@ extern "C" int dagnn_backward_run(const dagnn_plan* pl, const dagnn_backward_arg
     // the deep graphs' rows [split, ptr').  The two sets of graphs share nothing, so in split mode the sweep runs as
     // two independent chains: the shallow graphs' per-layer launches on the side stream, and on the caller's stream
     // the deep graphs - persistent kernel over the thin head of the reverse order, then per-layer launches.
-    bool split = a->side_stream != nullptr;
+    bool split = a->side_stream != nullptr && a->fork_event != nullptr && a->join_event != nullptr;
     for (int q = 0; q < ndir && split; ++q) split = a->layer_split[dirs[q]] != nullptr;
     enum { ALL = 0, SHALLOW = 1, DEEP = 2 };
     auto row_lo = [&](int part, int d, int t) { return part == DEEP ? a->layer_split[d][t] : layer_ptr[d][t]; };
@@ -989,7 +989,7 @@ extern "C" int dagnn_backward_run(const dagnn_plan* pl, const dagnn_backward_arg
     DagnnForkJoin fj;   // joins and releases its events on every return path
     if (split) {   // fork: the shallow graphs' chain on the side stream
         hipStream_t side = (hipStream_t)a->side_stream;
-        const hipError_t ef = fj.begin(st, side);
+        const hipError_t ef = fj.begin(st, side, a->fork_event, a->join_event);
         if (ef != hipSuccess) return DAGNN_EHIP(ef);
         const int rc = run_steps(side, 0, SHALLOW);
         fj.mark();

@@ -7,28 +7,28 @@
 
 #define DAGNN_WAVE 64
 
-// Fork / join of a side stream around a host-side launch loop.  The destructor is the single exit path: whatever return
-// statement leaves the function, the caller's stream is ordered behind the work already queued on the side stream
-// (which still reads and writes buffers torch may recycle) and both events are released (the runtime defers the
-// destruction until the recorded work has completed).
+// Fork / join of a side stream around a host-side launch loop, on two events the CALLER owns (the library creates and
+// destroys nothing).  The destructor is the single exit path: whatever return statement leaves the function, the
+// caller's stream is ordered behind the work already queued on the side stream (which still reads and writes buffers
+// torch may recycle).
 struct DagnnForkJoin {
     hipStream_t main = nullptr, side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
-    bool joined = true;
-    hipError_t begin(hipStream_t main_, hipStream_t side_) {   // side waits for everything queued on main so far
-        main = main_; side = side_;
-        hipError_t e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&join, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventRecord(fork, main);
+    bool joined = true, marked = false;
+    hipError_t begin(hipStream_t main_, hipStream_t side_, void* fork_, void* join_) {   // side waits for everything queued on main so far
+        main = main_; side = side_; fork = (hipEvent_t)fork_; join = (hipEvent_t)join_;
+        if (!fork || !join) return hipErrorInvalidValue;
+        hipError_t e = hipEventRecord(fork, main);
         if (e == hipSuccess) e = hipStreamWaitEvent(side, fork, 0);
         if (e == hipSuccess) joined = false;
         return e;
     }
-    void mark() { if (join) hipEventRecord(join, side); }       // the side stream's work up to here is what main joins
+    void mark() { if (join && !joined) { hipEventRecord(join, side); marked = true; } }   // the side stream's work up to here is what main joins
     ~DagnnForkJoin() {
-        if (!joined && join) hipStreamWaitEvent(main, join, 0);
-        if (fork) hipEventDestroy(fork);
-        if (join) hipEventDestroy(join);
+        if (!joined && join) {
+            if (!marked) hipEventRecord(join, side);
+            hipStreamWaitEvent(main, join, 0);
+        }
     }
 };
 

@@ -221,8 +221,10 @@ __global__ void __launch_bounds__(256) df_count_kernel(const int32_t* __restrict
     if (status && status[0] != 0) return;   // the batch violates the plan contract: nothing here can be trusted
     const int g = blockIdx.x, d = blockIdx.y;
     const int n0 = plan[L.node_ptr + g];
-    const int depth = plan[L.depth[d] + g];
     const int k = ws[S.grp_of + g];
+    // (the group's table has gdepth_k + 1 entries, gdepth_k = max over its graphs of max(depth0, depth1): the bound
+    // below holds even if a batch's two layerings ever disagreed in depth)
+    const int depth = min(plan[L.depth[d] + g], ws[S.gdepth + k]);
     const int32_t* ls = plan + L.lstart[d] + n0 + g;
     int32_t* cnt = ws + S.lcnt[d] + ws[S.loff + k];
     for (int t = threadIdx.x; t < depth; t += blockDim.x) atomicAdd(&cnt[t], ls[t + 1] - ls[t]);
@@ -1033,6 +1035,10 @@ __global__ void __launch_bounds__(DF_THREADS, 3) dataflow_kernel(const int32_t* 
     if (S.status && S.status[0] != 0) {   // the batch violates the plan contract: the schedule is garbage - do not walk it
         if (tid == 0) __hip_atomic_fetch_or(S.err, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
+    }
+    if (S.sched[0] != S.groups || S.sched[1] != DF_MAGIC || S.sched[2] != DF_RB) {   // a schedule built for another group count
+        if (tid == 0) __hip_atomic_fetch_or(S.err, 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (or not built at all) would
+        return;                                                                                      // index gtab / grec out of bounds
     }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // a workgroup serves NLS groups ("streams"): workgroup ids are pair-major, then cell, then slice

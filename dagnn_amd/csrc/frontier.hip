@@ -1055,7 +1055,7 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
     // split mode (side stream + per-layer split pointers): the persistent kernel walks the DEEP graphs from layer 0
     // on the side stream while the launches below handle the shallow graphs' rows [ptr[t], split[t]) - the two
     // sets of graphs share nothing, so the deepest chains no longer wait behind the fat layers
-    bool split = a->side_stream != nullptr && a->debug_timing == nullptr;
+    bool split = a->side_stream != nullptr && a->debug_timing == nullptr && a->fork_event != nullptr && a->join_event != nullptr;
     for (int q = 0; q < ndir && split; ++q) split = a->layer_split[dirs[q]] != nullptr;
     auto rows_all = [&](int d, int i, int s) {
         const int t = s - i;
@@ -1134,7 +1134,7 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
     }
     if (forked) {
         hipStream_t side = (hipStream_t)a->side_stream;
-        const hipError_t ef = fj.begin(st, side);
+        const hipError_t ef = fj.begin(st, side, a->fork_event, a->join_event);
         if (ef != hipSuccess) return DAGNN_EHIP(ef);
         const int rc = launch_tail(side, 0);
         fj.mark();

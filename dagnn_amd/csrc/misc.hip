@@ -133,6 +133,86 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restric
     for (int j = threadIdx.x; j < width; j += blockDim.x) out[g * ld_out + col_off + j] = src[j];
 }
 
+// ---- decoder-side single-vertex step (dvae/dagnn.py:187-239, dvae/dagnn_bn.py:179-238): for every graph that has
+// vertex v, aggregate the states of v's predecessors with the reference's PADDED soft-max (the predecessor lists are
+// padded to the longest one with zero rows, and the soft-max runs over the padding as well: a padded key scores
+// w_q.q + b, a real one w_q.q + b + w_k.h_j [+ w_vid[j]] - the common term cancels, so padded slots score 0), then
+// run the L stacked GRU cells of the propagator on it - the aggregate is computed ONCE, from the layer-0 states, and
+// reused by every stacked layer (the reference's `H` is no longer None after the first iteration).  One workgroup per
+// graph, one launch per decoder step.
+struct IpropLayers {
+    const float* w_ih[DAGNN_MAX_STACKED];
+    const float* w_hh[DAGNN_MAX_STACKED];
+    const float* b_ih[DAGNN_MAX_STACKED];
+    const float* b_hh[DAGNN_MAX_STACKED];
+    int in_dim[DAGNN_MAX_STACKED];
+};
+
+__global__ void __launch_bounds__(256) iprop_step_kernel(const float* __restrict__ values, const int32_t* __restrict__ pred_vid,
+                                                          int P, int hs, const float* __restrict__ w_key,
+                                                          const float* __restrict__ vid_bias, const float* __restrict__ H_given,
+                                                          const float* __restrict__ x, int in0, IpropLayers W, int L,
+                                                          float* __restrict__ states, int64_t B) {
+    extern __shared__ float lds[];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int din = in0 > hs ? in0 : hs;
+    float* Hs = lds;              // [hs]   the aggregate
+    float* in = Hs + hs;          // [din]  input of the current stacked layer
+    float* gi = in + din;         // [3hs]
+    float* gh = gi + 3 * hs;      // [3hs]
+    float* sc = gh + 3 * hs;      // [P]
+    if (H_given) {
+        for (int k = tid; k < hs; k += 256) Hs[k] = H_given[(int64_t)g * hs + k];
+    } else {
+        const float* vg = values + (int64_t)g * P * hs;
+        for (int p = wave; p < P; p += 4) {
+            const int id = pred_vid[(int64_t)g * P + p];
+            float s = 0.f;
+            if (id >= 0) {
+                for (int k = lane; k < hs; k += 64) s = fmaf(w_key[k], vg[(int64_t)p * hs + k], s);
+                s = wave_sum(s);
+                if (vid_bias) s += vid_bias[id];
+            }
+            if (lane == 0) sc[p] = s;
+        }
+        __syncthreads();
+        float m = -INFINITY, den = 0.f;
+        for (int p = 0; p < P; ++p) m = fmaxf(m, sc[p]);
+        for (int p = 0; p < P; ++p) den += expf(sc[p] - m);
+        for (int k = tid; k < hs; k += 256) {
+            float a = 0.f;
+            for (int p = 0; p < P; ++p) a = fmaf(expf(sc[p] - m) / den, vg[(int64_t)p * hs + k], a);   // padded rows are zero
+            Hs[k] = a;
+        }
+    }
+    for (int k = tid; k < in0; k += 256) in[k] = x[(int64_t)g * in0 + k];
+    __syncthreads();
+    for (int l = 0; l < L; ++l) {
+        const int K = W.in_dim[l];
+        for (int j = wave; j < 6 * hs; j += 4) {   // one wave per row of [W_ih ; W_hh]
+            const bool hid = j >= 3 * hs;
+            const int r = hid ? j - 3 * hs : j, kk = hid ? hs : K;
+            const float* wrow = (hid ? W.w_hh[l] : W.w_ih[l]) + (int64_t)r * kk;
+            const float* v = hid ? Hs : in;
+            float s = 0.f;
+            for (int k = lane; k < kk; k += 64) s = fmaf(wrow[k], v[k], s);
+            s = wave_sum(s);
+            if (lane == 0) (hid ? gh : gi)[r] = s + (hid ? W.b_hh[l] : W.b_ih[l])[r];
+        }
+        __syncthreads();
+        for (int u = tid; u < hs; u += 256) {
+            const float r = 1.0f / (1.0f + expf(-(gi[u] + gh[u])));
+            const float z = 1.0f / (1.0f + expf(-(gi[hs + u] + gh[hs + u])));
+            const float n = tanhf(gi[2 * hs + u] + r * gh[2 * hs + u]);
+            const float hv = (1.0f - z) * n + z * Hs[u];
+            states[((int64_t)l * B + g) * hs + u] = hv;
+            in[u] = hv;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" const char* dagnn_version(void) { return "dagnn_hip 0.1 gfx950"; }
@@ -208,6 +288,31 @@ extern "C" int dagnn_gather_rows(const float* h, int ld_h, int width, int64_t nu
     if (num_graphs == 0) return DAGNN_OK;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)num_graphs), dim3(256), 0, (hipStream_t)stream, h, ld_h,
                        width, stride, node_off, out, ld_out, col_off);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
+extern "C" int dagnn_iprop_step(const float* values, const int32_t* pred_vid, int64_t B, int P, int hs, const float* w_key,
+                                const float* vid_bias, const float* H_given, const float* x, int in0,
+                                const dagnn_iprop_layer* layers, int L, float* states, void* stream) {
+    if (B < 0 || P < 0 || hs <= 0 || in0 <= 0 || L <= 0 || L > DAGNN_MAX_STACKED || !layers || !x || !states)
+        return DAGNN_EINVAL;
+    if (!H_given && P > 0 && (!values || !pred_vid || !w_key)) return DAGNN_EINVAL;
+    if (B == 0) return DAGNN_OK;
+    IpropLayers W;
+    for (int l = 0; l < L; ++l) {
+        const dagnn_iprop_layer& q = layers[l];
+        if (!q.w_ih || !q.w_hh || !q.b_ih || !q.b_hh || q.in_dim != (l == 0 ? in0 : hs)) return DAGNN_EINVAL;
+        W.w_ih[l] = q.w_ih; W.w_hh[l] = q.w_hh; W.b_ih[l] = q.b_ih; W.b_hh[l] = q.b_hh; W.in_dim[l] = q.in_dim;
+    }
+    const int din = in0 > hs ? in0 : hs;
+    const size_t lds = (size_t)(hs + din + 6 * hs + (P > 0 ? P : 1)) * sizeof(float);
+    if (lds > 160 * 1024) return DAGNN_EINVAL;
+    const void* fn = reinterpret_cast<const void*>(iprop_step_kernel);
+    if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DAGNN_EHIP(hipGetLastError());
+    hipLaunchKernelGGL(iprop_step_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, values, pred_vid, P, hs,
+                       w_key, vid_bias, H_given, x, in0, W, L, states, B);
     DAGNN_CHECK_LAUNCH();
     return DAGNN_OK;
 }

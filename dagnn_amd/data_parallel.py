@@ -39,31 +39,68 @@ class DataParallel(torch.nn.Module):
             return dist.get_rank(), dist.get_world_size()
         return 0, 1
 
+    def _device(self) -> torch.device:
+        """Where this process runs its shard: with one process per GPU that is the device the module's parameters
+        live on (NOT `device_ids[0]`: the reference-style `DataParallel(model, list(range(k)))` under k processes would
+        send every rank's data to cuda:0), else the reference's `src_device`."""
+        if self._world()[1] > 1:
+            for p in self.module.parameters():
+                return p.device
+        return self.src_device
+
     def shard_of(self, data_list):
-        """The element of `data_list` this process runs: the only one, or the one of its rank.  A list shorter than
-        the world (the reference's `Collater` drops empty devices, `tg/dataloader.py:29-33`) leaves the last ranks
+        """The element of `data_list` this process runs under `torch.distributed`: the one of its rank.  A list shorter
+        than the world (the reference's `Collater` drops empty devices, `tg/dataloader.py:29-33`) leaves the last ranks
         without work: None."""
         rank, world = self._world()
         if world == 1:
-            return data_list[0]   # the reference's one-device fallback runs the first element only (:48-50)
+            return data_list[0]
         if len(data_list) > world:
             raise ValueError("DataParallel got %d batches for %d processes: collate with collate_sharded(graphs, %d)"
                              % (len(data_list), world, world))
         return data_list[rank] if rank < len(data_list) else None
 
+    @staticmethod
+    def _gather(outs):
+        """`torch.nn.DataParallel.gather` for the shapes the DAGNN heads return: tensors are concatenated along dim 0,
+        lists / tuples element-wise (`tg/data_parallel.py:62`)."""
+        first = outs[0]
+        if isinstance(first, torch.Tensor):
+            return torch.cat(outs, dim=0)
+        if isinstance(first, (list, tuple)):
+            return type(first)(DataParallel._gather([o[k] for o in outs]) for k in range(len(first)))
+        raise TypeError("cannot gather outputs of type %s" % type(first).__name__)
+
     def forward(self, data_list):
         if len(data_list) == 0:
             warnings.warn("DataParallel received an empty data list, which may result in unexpected behaviour.")
             return None
-        data = self.shard_of(data_list)
-        if data is None:
-            return None
-        return self.module(data.to(self.src_device))
+        rank, world = self._world()
+        dev = self._device()
+        if world == 1 and len(self.device_ids) > 1 and len(data_list) > 1:
+            # the reference's k-device branch (`:52-62`: scatter the first min(k, len) elements, one replica each,
+            # gather on the output device) inside ONE process that owns one GPU: the same elements one after the other
+            # on that GPU, outputs concatenated in list order - nothing is dropped
+            outs = [self.module(d.to(dev)) for d in data_list[:len(self.device_ids)]]
+            out = self._gather(outs)
+        else:
+            data = self.shard_of(data_list)   # one device: the reference's fallback runs the first element only (:48-50)
+            if data is None:
+                return None
+            out = self.module(data.to(dev))
+        if not self.training:
+            # evaluation consumes the outputs right away (`main_pyg.py:91-124`): surface a device-side failure of THIS
+            # pass now instead of at the next forward (a loop's last batch has no next forward)
+            check = getattr(self.module, "check", None)
+            if callable(check):
+                check()
+        return out
 
-    def reduce_gradients(self, local_count: Optional[int] = None, group=None) -> None:
-        """Average the replicas' gradients of their local mean losses into the gradient of the mean over the global
-        batch (`main_pyg.py:55-60` computes the loss on the gathered predictions): ONE all-reduce, weighted by the
-        graphs each rank ran (0 for a rank without a shard).  The first call moves the gradients into a flat bucket."""
+    def _attach_bucket(self) -> None:
+        """(Re-)bind every parameter's `.grad` to its view of the flat bucket.  `optimizer.zero_grad()` (the
+        reference's loop, `main_pyg.py:50`) sets the gradients to None, so the next `backward()` allocates fresh
+        tensors outside the bucket: whatever `.grad` holds then is copied into the view and re-bound, so that the
+        collective below reduces THIS step's gradients and `optimizer.step()` reads the reduced ones."""
         if self._bucket is None:
             grads = {id(p): p.grad for p in self.module.parameters() if p.requires_grad and p.grad is not None}
             self._bucket = GradBucket(self.module.parameters())
@@ -71,9 +108,18 @@ class DataParallel(torch.nn.Module):
                 g = grads.get(id(p))
                 if g is not None:
                     p.grad.copy_(g)
+            return
+        self._bucket.rebind()
+
+    def reduce_gradients(self, local_count: Optional[int] = None, group=None) -> None:
+        """Average the replicas' gradients of their local mean losses into the gradient of the mean over the global
+        batch (`main_pyg.py:55-60` computes the loss on the gathered predictions): ONE all-reduce, weighted by the
+        graphs each rank ran (0 for a rank without a shard).  The first call moves the gradients into a flat bucket;
+        every call checks that they still live there (see `_attach_bucket`)."""
+        self._attach_bucket()
         self._bucket.all_reduce_mean(local_count, group)
 
-    def zero_grad(self, set_to_none: bool = False) -> None:   # the bucket's views must survive
+    def zero_grad(self, set_to_none: bool = False) -> None:   # keeps the bucket's views (no copy on the next step)
         if self._bucket is not None:
             self._bucket.zero()
         else:

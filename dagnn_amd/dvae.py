@@ -148,6 +148,13 @@ class _DvaeDagnn(_DvaeBase):
     def _static_scores(self, x, cells):
         return None
 
+    def check(self) -> None:
+        """Blocking check for device-side failures of every pass launched so far (`core.check_arenas`): call it where
+        the outputs of the LAST forward of a loop are consumed - the non-blocking poll inside `forward` only reports
+        earlier passes."""
+        from .core import check_arenas
+        check_arenas(self)
+
     def _arena_for(self, x, role="forward"):
         return self._arenas.setdefault((role, x.device, torch.cuda.current_stream(x.device).cuda_stream),
                                        engine.GranuleArena())
@@ -269,46 +276,44 @@ class _DvaeDagnn(_DvaeBase):
         `models_pyg.py:247-250`, with `propagator = self.grud`).  `G` holds igraph-style graphs: `g.vcount()`,
         `g.predecessors(v)`, `g.vs[x]['type']`, `g.vs[x]['H_forward<l>']` ([1, hs] tensors, written for `v`).
 
-        Reproduced as the reference computes it, quirks included: the predecessor lists are padded to the longest one
-        with zero rows and the attention soft-max runs over the padding as well (a zero key scores `w_q.q + b`, so
-        padded slots take weight away from the real predecessors) - which is why this is NOT the encoder's aggregate
-        and does not go through the HIP path; and the aggregate `H` is computed for stacked layer 0 only and then
-        reused by every layer above (`H` is no longer None in the later iterations of the reference's loop).
-        Dense torch ops on [graphs, predecessors, hs] tensors of a handful of rows: decoder bookkeeping, not the hot
-        path."""
+        ONE HIP launch per call (`dagnn_iprop_step`, csrc/misc.hip) for the padded soft-max aggregate and the L
+        stacked GRU cells of all graphs; there is no CPU path (the model must live on the GPU).  Reproduced as the
+        reference computes it, quirks included: the predecessor lists are padded to the longest one with zero rows and
+        the attention soft-max runs over the padding as well (a zero key scores `w_q.q + b`; that term is common to all
+        slots and cancels, so padded slots score 0 and take weight away from the real predecessors - which is why this
+        is NOT the encoder's aggregate); and the aggregate is computed from the layer-0 states only and reused by every
+        layer above (`H` is no longer None in the later iterations of the reference's loop).  The host side only
+        gathers the igraph-style inputs into dense tensors and writes the new states back into the vertices."""
         assert not reverse
         G = [g for g in G if g.vcount() > v]
         if len(G) == 0:
             return None
+        dev = self.get_device()
         if H is not None:
-            H = H[list(range(len(G)))]   # the reference indexes with the positions of the already filtered list
+            H = H[list(range(len(G)))].to(dev)   # the reference indexes with the positions of the already filtered list
         X = self._one_hot([g.vs[v]["type"] for g in G], self.nvt)
-        Hv = X
+        values = pred_vid = None
+        lin = self.node_aggr_0[0].attn_lin   # AttnConv.forward with edge_index=None (`dagnn.py:391-399`), stacked layer 0
+        dq = self._key_offset(0)
+        w = lin.weight.detach()[0]
+        if H is None:
+            preds = [g.predecessors(v) for g in G]
+            P = max(len(p) for p in preds)
+            if P > 0:
+                rows, ids = [], []
+                zero = self._get_zeros(1, self.hs)
+                for g, p in zip(G, preds):
+                    rows += [g.vs[x]["H_forward0"].to(dev) for x in p] + [zero] * (P - len(p))
+                    ids += list(p) + [-1] * (P - len(p))
+                values = torch.cat(rows, 0).view(len(G), P, self.hs)
+                pred_vid = torch.tensor(ids, dtype=torch.int32).view(len(G), P).to(dev)
+        states = engine.iprop_step(values, pred_vid, w[dq:dq + self.hs],
+                                   w[dq + self.hs:dq + self.hs + self.max_n] if self._use_vids else None, H, X,
+                                   list(propagator)[:self.num_layers])
         for l in range(self.num_layers):
-            name = "H_forward%d" % l
-            if H is None:
-                preds = [g.predecessors(v) for g in G]
-                P = max(len(p) for p in preds)
-                if P == 0:
-                    H = self._get_zero_hidden(len(G))
-                else:
-                    def padded(rows, width):   # [len(G), P, width], zero rows behind the real ones
-                        return torch.stack([torch.cat(r + [self._get_zeros(P - len(r), width)], 0) for r in rows], 0)
-                    states = [[g.vs[x][name] for x in p] for g, p in zip(G, preds)]
-                    values = padded(states, self.hs)
-                    if self._use_vids:     # keys = [state ; one-hot of the predecessor's vertex id] (`dagnn.py:208-214`)
-                        keys = padded([[torch.cat([h, self._one_hot(x, self.max_n)], 1) for h, x in zip(st, p)]
-                                       for st, p in zip(states, preds)], self.vs)
-                    else:
-                        keys = values
-                    query = X if l == 0 else torch.cat([g.vs[v]["H_forward%d" % (l - 1)] for g in G], 0)
-                    lin = self.node_aggr_0[l].attn_lin     # AttnConv.forward with edge_index=None (`dagnn.py:391-399`)
-                    scores = lin(torch.cat([query[:, None, :].expand(-1, P, -1), keys], -1)).view(len(G), P)
-                    H = torch.einsum("bi,bij->bj", F.softmax(scores, dim=-1), values)
-            Hv = propagator[l](Hv, H)
             for i, g in enumerate(G):
-                g.vs[v][name] = Hv[i:i + 1]
-        return Hv
+                g.vs[v]["H_forward%d" % l] = states[l, i:i + 1]
+        return states[self.num_layers - 1]
 
 
 class DAGNN_NA(_DvaeDagnn):

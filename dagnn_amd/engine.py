@@ -439,47 +439,89 @@ class GranuleArena(object):
             self.side = torch.cuda.Stream(device)
         return self.side
 
+    def fork_join_events(self, device):
+        """The two events a split-mode call forks and joins with (raw hipEvent_t handles).  They belong to the arena:
+        the library itself creates and destroys nothing (include/dagnn_hip.h, conventions)."""
+        evs = getattr(self, "_fj", None)
+        if evs is None or evs[2] != device:
+            a, b = torch.cuda.Event(), torch.cuda.Event()
+            st = torch.cuda.current_stream(device)
+            a.record(st)   # (torch creates the underlying event at the first record)
+            b.record(st)
+            evs = self._fj = (a, b, device)
+        return evs[0].cuda_event, evs[1].cuda_event
+
+    WATCH_SLOTS = 64   # read-backs in flight before the oldest one is waited for
+
     def watch(self, plan=None) -> None:
         """Queue an asynchronous read-back of the device-side error words (the kernels' bounded-wait flag and the
-        plan's contract status) behind the work just launched; `poll()` looks at it without synchronising."""
+        plan's contract status) behind the work just launched; `poll()` looks at the finished ones without
+        synchronising.  Every watch owns a slot of a pinned ring and an event: an async evaluation loop that issues
+        many passes before anything synchronises loses none of their reports (one shared buffer would let a later clean
+        pass overwrite a violation)."""
+        import collections
         dev = self.err.device
         if getattr(self, "_host", None) is None:
-            self._host = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self._host = torch.zeros(self.WATCH_SLOTS, 2, dtype=torch.int32).pin_memory()
+            self._pending = collections.deque()
+            self._seq = 0
+        if len(self._pending) >= self.WATCH_SLOTS:
+            self._drain(block_first=True)   # (raises if that oldest pass failed)
+        slot = self._seq % self.WATCH_SLOTS
+        self._seq += 1
         st = torch.cuda.current_stream(dev)
-        self._host[0:1].copy_(self.err, non_blocking=True)
+        self._host[slot, 1] = 0
+        self._host[slot, 0:1].copy_(self.err, non_blocking=True)
         if plan is not None:
-            self._host[1:2].copy_(plan.status[0:1], non_blocking=True)
-        self._event = torch.cuda.Event()
-        self._event.record(st)
+            self._host[slot, 1:2].copy_(plan.status[0:1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(st)
+        self._pending.append((ev, slot))
+
+    def _drain(self, block: bool = False, block_first: bool = False) -> None:
+        pend = getattr(self, "_pending", None)
+        failed = None
+        while pend:
+            ev, slot = pend[0]
+            if block or block_first:
+                ev.synchronize()
+                block_first = False
+            elif not ev.query():
+                break
+            pend.popleft()
+            e, s = int(self._host[slot, 0]), int(self._host[slot, 1])
+            if (e or s) and failed is None:
+                failed = (e, s)
+        if failed is None:
+            return
+        e, s = failed
+        if self.err is not None:
+            self.err.zero_()   # the flag is sticky on the device (a lost pass makes later ones give up early): consumed here
+        msgs = []
+        if e & 3:
+            msgs.append("a bounded device-side wait expired (code %d): the persistent kernel's workgroups were not "
+                        "co-resident, or a producer failed" % e)
+        if e & 8:
+            msgs.append("the dataflow schedule handed to the kernel was built for another group count (or not built)")
+        if (e & 4) and not s:
+            msgs.append("the persistent kernel found the plan's status word set (the batch violates the plan contract)")
+        if s:
+            msgs.append("the batch violates the plan contract (status %d: 1 edges not grouped by graph, 2 edge "
+                        "crosses graphs / out of range, 4 batch vector not sorted, 8 layer id out of range)" % s)
+        if not msgs:
+            msgs.append("device-side error word %d" % e)
+        raise DagnnHipError("results of an earlier DAGNN pass are invalid: " + "; ".join(msgs))
 
     def poll(self, block: bool = False) -> None:
         """Raise `DagnnHipError` if a finished earlier pass reported a device-side failure.  Without `block` this only
-        looks at read-backs that have already completed (no synchronisation)."""
-        ev = getattr(self, "_event", None)
-        if ev is None:
-            return
-        if block:
-            ev.synchronize()
-        elif not ev.query():
-            return
-        self._event = None
-        e, s = int(self._host[0]), int(self._host[1])
-        if e or s:
-            self._host.zero_()
-            if self.err is not None:
-                self.err.zero_()
-            msgs = []
-            if e & 3:
-                msgs.append("a bounded device-side wait expired (code %d): the persistent kernel's workgroups were not "
-                            "co-resident, or a producer failed" % e)
-            if s:
-                msgs.append("the batch violates the plan contract (status %d: 1 edges not grouped by graph, 2 edge "
-                            "crosses graphs / out of range, 4 batch vector not sorted, 8 layer id out of range)" % s)
-            raise DagnnHipError("results of an earlier DAGNN pass are invalid: " + "; ".join(msgs))
+        looks at read-backs that have already completed (no synchronisation); with it, at every pass launched so far."""
+        self._drain(block=block)
 
     def check(self) -> None:
-        """Synchronising check: raises if a bounded wait in a persistent kernel expired."""
+        """Synchronising check of every pass launched so far (bounded waits and plan contract)."""
+        self._drain(block=True)
         if self.err is not None and int(self.err[0]):
+            self.err.zero_()
             raise DagnnHipError("persistent kernel: a bounded wait expired (results are invalid)")
 
 
@@ -541,11 +583,14 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     if use_tail and SPLIT_DEEP and DEBUG_TIMING is None:
         splits = plan.read_splits()
         args.side_stream = arena.side_stream(plan.ws.device).cuda_stream
+        args.fork_event, args.join_event = arena.fork_join_events(plan.ws.device)
         for d in dirs:
             args.layer_split[d] = splits[d].ctypes.data_as(C.POINTER(C.c_int32))
     with _span("frontier_run", plan.ws):
         check(_lib.load().dagnn_frontier_run(C.byref(plan.desc), C.byref(args), ptrs, nl, _stream(plan.ws)),
               "dagnn_frontier_run")
+    if arena is not None and arena.err is not None:
+        arena.watch(plan)   # the persistent tail's bounded waits and the plan's status word, like the dataflow path
 
 
 def recurrence_layer(plan: PlanHandle, dirs: Sequence[int], H: int, gi, w_hh_t, b_hh, w_key, edge_gain=None,
@@ -632,6 +677,8 @@ def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells,
     gran, epoch, err = arena.get(gkeys, N, H, dev) if use_tail else ({}, 0, None)
     keep = []
     keep_alive = keep
+    if arena is not None:
+        arena.poll()
     for d in dirs:
         mask |= 1 << d
         for i in range(L):
@@ -693,11 +740,14 @@ def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells,
     if use_tail and SPLIT_DEEP:
         splits = plan.read_splits()
         args.side_stream = arena.side_stream(dev).cuda_stream
+        args.fork_event, args.join_event = arena.fork_join_events(dev)
         for d in dirs:
             args.layer_split[d] = splits[d].ctypes.data_as(C.POINTER(C.c_int32))
     with _span("backward_run", plan.ws):
         check(lib.dagnn_backward_run(C.byref(plan.desc), C.byref(args), ptrs, nl, _stream(plan.ws)),
               "dagnn_backward_run")
+    if use_tail:
+        arena.watch()
     return out
 
 
@@ -706,6 +756,38 @@ def gather_rows(h: torch.Tensor, num_graphs: int, stride: int, node_off: int, ou
     h = _dev(h, "h", torch.float32)
     check(_lib.load().dagnn_gather_rows(h.data_ptr(), h.shape[1], h.shape[1], num_graphs, stride, node_off,
                                         out.data_ptr(), out.shape[1], col_off, _stream(h)), "dagnn_gather_rows")
+
+
+def iprop_step(values: Optional[torch.Tensor], pred_vid: Optional[torch.Tensor], w_key: torch.Tensor,
+               vid_bias: Optional[torch.Tensor], H_given: Optional[torch.Tensor], x: torch.Tensor, cells) -> torch.Tensor:
+    """`_ipropagate_to` for all graphs of a decoder step in one launch (`dagnn_iprop_step`).  values [B,P,hs] /
+    pred_vid [B,P] int32 (or None with `H_given` [B,hs]); x [B,in0]; cells: the propagator's GRUCells.  Returns the
+    new states [L,B,hs]."""
+    x = _dev(x, "x", torch.float32)
+    B, in0 = x.shape
+    hs = cells[0].weight_hh.shape[1]
+    L = len(cells)
+    P = 0
+    if H_given is not None:
+        H_given = _dev(H_given, "H", torch.float32)
+    elif values is not None:
+        values = _dev(values, "predecessor states", torch.float32)
+        pred_vid = _dev(pred_vid, "predecessor ids", torch.int32)
+        P = values.shape[1]
+    layers = (_lib.IpropLayer * L)()
+    keep = []
+    for l, c in enumerate(cells):
+        ts = [_dev(t.detach(), "GRU parameter", torch.float32) for t in (c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh)]
+        keep.append(ts)
+        layers[l] = _lib.IpropLayer(ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), ts[0].shape[1])
+    states = torch.empty(L, B, hs, dtype=torch.float32, device=x.device)
+    if H_given is None and P == 0:   # no graph has a predecessor: the aggregate is zero (`_get_zero_hidden`)
+        H_given = torch.zeros(B, hs, dtype=torch.float32, device=x.device)
+    wk = _dev(w_key.detach(), "w_key", torch.float32)
+    vb = None if vid_bias is None else _dev(vid_bias.detach(), "vid_bias", torch.float32)
+    check(_lib.load().dagnn_iprop_step(_ptr(values), _ptr(pred_vid), B, P, hs, wk.data_ptr(), _ptr(vb), _ptr(H_given),
+                                       x.data_ptr(), in0, layers, L, states.data_ptr(), _stream(x)), "dagnn_iprop_step")
+    return states
 
 
 def topo_layers(edge_index: torch.Tensor, batch: torch.Tensor, num_graphs: int):

@@ -239,6 +239,13 @@ class DAGNN(nn.Module):
 
         return self._derived.setdefault(self.schedule, DerivedCache()).get(srcs, make, fresh=fresh or self.training)
 
+    def check(self) -> None:
+        """Blocking check for device-side failures of every pass launched so far (`core.check_arenas`): call it where
+        the outputs of the LAST forward of a loop are consumed - the non-blocking poll inside `forward` only reports
+        earlier passes."""
+        from .core import check_arenas
+        check_arenas(self)
+
     def _arena_for(self, x, role="forward"):
         return self._arenas.setdefault((role, x.device, torch.cuda.current_stream(x.device).cuda_stream),
                                        engine.GranuleArena())

@@ -42,6 +42,22 @@ class GradBucket(object):
     def numel(self) -> int:
         return self.flat.numel()
 
+    def rebind(self) -> None:
+        """Make every `p.grad` alias its view of the flat buffer again.  A gradient that lives elsewhere (the
+        optimizer's `zero_grad()` set it to None and `backward()` allocated a fresh one) is copied in first; a
+        parameter without a gradient this step contributes zeros."""
+        off = 0
+        for p in self.params:
+            view = self.flat[off:off + p.numel()].view_as(p)
+            g = p.grad
+            if g is None:
+                view.zero_()
+                p.grad = view
+            elif g.data_ptr() != view.data_ptr() or g.shape != view.shape:
+                view.copy_(g)
+                p.grad = view
+            off += p.numel()
+
     def zero(self) -> None:
         """Replaces `optimizer.zero_grad()` (which would detach the views when it sets grads to None)."""
         self.flat.zero_()

@@ -228,11 +228,13 @@ typedef struct dagnn_frontier_args {
     /* split mode (optional): with a second stream and the plan's per-layer split pointers (blsplit_d, read back with
      * the schedule) the persistent kernel walks the DEEP graphs (depth > thr_d) from layer 0 on `side_stream`,
      * concurrently with the per-layer launches, which then only cover the shallow graphs.  The call forks from and
-     * joins back into `stream` with events (capturable); results agree with the unsplit mode to rounding (a row may be
+     * joins back into `stream` with the caller's `fork_event` / `join_event` (capturable); results agree with the unsplit mode to rounding (a row may be
      * handled by a different kernel), each mode by itself is deterministic.  (CU-masked streams for the two
      * halves were measured and dropped: masked queues slowed every other launch of the process.) */
     void* side_stream;                              /* hipStream_t or NULL: runs the persistent kernel */
     const int32_t* layer_split[DAGNN_MAX_DIRS];     /* HOST, num_layers[d] int32: first deep slot of every layer, or NULL */
+    void* fork_event;                               /* hipEvent_t x 2, CALLER-OWNED (the library creates nothing): split */
+    void* join_event;                               /* mode needs both, otherwise it is off */
 } dagnn_frontier_args;
 
 /* layer_ptr[d] (HOST, num_layers[d] + 1 int32): row offsets of the batch-level layers of direction
@@ -263,7 +265,8 @@ int dagnn_frontier_run(const dagnn_plan* plan /* host */, const dagnn_frontier_a
  *      buffers must have been zero-initialised once and only ever used with strictly increasing `epoch`s (a replayed
  *      hipGraph must contain the memset).  `err` (device int32, zeroed by the caller) is set when a bounded wait
  *      expires (results are then invalid): bit 0 a granule poll, bit 1 an LDS flag; bit 2: the plan's status word
- *      (`plan_status`) was nonzero, nothing was computed.
+ *      (`plan_status`) was nonzero, nothing was computed; bit 3: `schedule` does not carry the header of a schedule
+ *      built for `groups` groups (dagnn_dataflow_schedule), nothing was computed.
  *      State rows h_out [N, ld_h] receive the H states only; dagnn_score_parts adds the H/16 partial attention scores
  *      behind them (the format dagnn_backward_prepare reads) when a backward pass follows.
  * Weights: dagnn_pack_dataflow(W [3H,H] torch layout) -> 3*H*H floats in slice / lane order (the A operands of the
@@ -400,9 +403,11 @@ typedef struct dagnn_backward_args {
     void* tail_err;      /* device int32: set to 1 if a bounded wait ever expires (results are then invalid) */
     /* split mode (optional): with a second stream and the plan's per-layer split pointers the sweep runs as two
      * independent chains - the shallow graphs' per-layer launches on `side_stream`, the deep graphs (persistent head,
-     * then per-layer launches) on `stream`; forks from and joins back into `stream` with events */
+     * then per-layer launches) on `stream`; forks from and joins back into `stream` with the caller's two events */
     void* side_stream;
     const int32_t* layer_split[DAGNN_MAX_DIRS];   /* HOST, num_layers[d] int32, or NULL */
+    void* fork_event;                             /* hipEvent_t x 2, CALLER-OWNED; split mode needs both */
+    void* join_event;
 } dagnn_backward_args;
 
 int dagnn_backward_prepare(const dagnn_plan* plan /* host */, const dagnn_backward_args* args /* host */, void* stream);
@@ -508,6 +513,25 @@ int dagnn_variant_run(const dagnn_plan* plan /* host */, const dagnn_variant_arg
  * `stride` nodes; gather row g*stride + node_off of h [N,ld_h] into out[g, col_off : col_off+width]. */
 int dagnn_gather_rows(const float* h, int ld_h, int width, int64_t num_graphs, int stride, int node_off,
                       float* out, int ld_out, int col_off, void* stream);
+
+/* Decoder-side single-vertex step of the D-VAE models: `_ipropagate_to(G, v, propagator, H)` (dvae/dagnn.py:187-239,
+ * dvae/dagnn_bn.py:179-238; called as `_update_iv` from models_pyg.py:247-250), for all B graphs that have vertex v, in
+ * ONE launch.  values [B,P,hs]: layer-0 states of v's predecessors, lists padded to P with zero rows; pred_vid [B,P]:
+ * vertex id of each predecessor, -1 for padding.  The reference's soft-max runs over the padding too (a padded key
+ * scores w_q.q + b; that common term cancels, so padded slots score 0 and real ones w_key.h_j + vid_bias[j]); the
+ * aggregate is computed once and feeds every stacked GRU cell; with `H_given` [B,hs] it replaces the aggregate.
+ * x [B,in0]: one-hot vertex types.  states [L,B,hs]: the new state of v per stacked layer (states[L-1] is the return
+ * value of the reference's function). */
+typedef struct dagnn_iprop_layer {
+    const float* w_ih;   /* [3hs, in_dim] torch GRUCell layout */
+    const float* w_hh;   /* [3hs, hs] */
+    const float* b_ih;   /* [3hs] */
+    const float* b_hh;   /* [3hs] */
+    int in_dim;          /* in0 for layer 0, hs above */
+} dagnn_iprop_layer;
+int dagnn_iprop_step(const float* values, const int32_t* pred_vid, int64_t B, int P, int hs, const float* w_key,
+                     const float* vid_bias /* [max_n] or NULL */, const float* H_given /* or NULL */, const float* x, int in0,
+                     const dagnn_iprop_layer* layers /* host [L] */, int L, float* states, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Topological layering on the device: replaces `top_sort` / `add_order_info_01` (src/utils_dag.py:8-52) for a

@@ -108,3 +108,52 @@ def check_grads(meta, arr, grads, rtol=2e-4, atol=2e-7, verbose=False):
         assert serr <= rtol * abs_sum + atol * got.numel() ** 0.5 * 10, "%s: sum err %.3g of %.3g" % (name, serr, abs_sum)
         worst = max(worst, aerr / max(scale, 1e-30) if scale > 100 * atol else 0.0)
     return worst
+
+
+# ------------------------------------------------------------------ decoder-side single-vertex step
+class VertexGraph(object):
+    """The igraph surface `_ipropagate_to` touches: `vcount()`, `predecessors(v)` (ascending), `vs[x][attr]`."""
+
+    def __init__(self, n):
+        self.vs = [dict() for _ in range(n)]
+        self._pred = [[] for _ in range(n)]
+
+    def vcount(self):
+        return len(self.vs)
+
+    def predecessors(self, v):
+        return sorted(self._pred[v])
+
+
+def iprop_graphs(meta, arr, device):
+    gs = []
+    for k in range(meta["K"]):
+        g = VertexGraph(int(arr["counts"][k]))
+        for v in range(g.vcount()):
+            g.vs[v]["type"] = int(arr["types"][k, v])
+            for l in range(meta["L"]):
+                g.vs[v]["H_forward%d" % l] = torch.from_numpy(arr["states"][k, v, l][None].copy()).to(device)
+            g._pred[v] = [u for u in range(v) if arr["adj"][k, u, v]]
+        gs.append(g)
+    return gs
+
+
+def check_ipropagate(name, step, device, tol):
+    """`step(model, G, v, H=None)` against the `iprop_*` fixture generated from the reference's `_ipropagate_to`."""
+    meta, arr = load(name)
+    meta = dict(meta, bidir=False)
+    model, nvt = dvae_model(meta)
+    model = model.to(device)
+    K, n, L = meta["K"], meta["n"], meta["L"]
+    with torch.no_grad():
+        for v in meta["vs"]:
+            G = iprop_graphs(meta, arr, device)
+            Hv = step(model, G, v)
+            alive = [k for k in range(K) if arr["counts"][k] > v]
+            assert alive == list(arr["v%d_alive" % v])
+            assert maxdiff(Hv, arr["v%d_Hv" % v]) < tol
+            got = np.stack([np.stack([G[k].vs[v]["H_forward%d" % l][0].cpu().numpy() for l in range(L)]) for k in alive])
+            assert np.abs(got - arr["v%d_states" % v]).max() < tol
+            Hg = step(model, iprop_graphs(meta, arr, device), v, H=torch.from_numpy(arr["H_given"].copy()).to(device))
+            assert maxdiff(Hg, arr["v%d_Hv_given" % v]) < tol
+        assert step(model, iprop_graphs(meta, arr, device), n + 3) is None   # no graph has that vertex

@@ -386,51 +386,21 @@ def test_augment_edge2_matches_reference_fixture():
 
 
 # ------------------------------------------------------------------ decoder-side single-vertex step
-class _VertexGraph(object):
-    """The igraph surface `_ipropagate_to` touches: `vcount()`, `predecessors(v)` (ascending), `vs[x][attr]`."""
-
-    def __init__(self, n):
-        self.vs = [dict() for _ in range(n)]
-        self._pred = [[] for _ in range(n)]
-
-    def vcount(self):
-        return len(self.vs)
-
-    def predecessors(self, v):
-        return sorted(self._pred[v])
-
-
 @pytest.mark.parametrize("name", ["iprop_na_h64_L2", "iprop_bn_h32_L3"])
-def test_ipropagate_to_matches_reference(name):
-    """`_ipropagate_to(G, v, self.grud)` against the reference's own (`dvae/dagnn.py:187-239`,
-    `dvae/dagnn_bn.py:179-238`) on the fixture's stand-in igraph graphs: returned states, the states it writes
-    into the vertices, a vertex without predecessors, graphs too short for `v`, and the `H`-given form."""
-    meta, arr = Hh.load(name)
-    meta = dict(meta, bidir=False)
-    model, nvt = Hh.dvae_model(meta)
-    K, n, L = meta["K"], meta["n"], meta["L"]
+def test_ipropagate_to_oracle_matches_reference(name):
+    """The CPU restatement of `_ipropagate_to` (oracle/iprop_oracle.py, the checker of the HIP step) against the
+    reference's own (`dvae/dagnn.py:187-239`, `dvae/dagnn_bn.py:179-238`) on the fixture's stand-in igraph graphs:
+    returned states, the states it writes into the vertices, a vertex without predecessors, graphs too short for `v`,
+    and the `H`-given form.  (The product's `_ipropagate_to` is one HIP launch: tests/test_gpu_parity.py.)"""
+    from oracle.iprop_oracle import ipropagate_to
+    Hh.check_ipropagate(name, lambda model, G, v, H=None: ipropagate_to(model, G, v, model.grud, H=H), "cpu", 2e-6)
 
-    def graphs():
-        gs = []
-        for k in range(K):
-            g = _VertexGraph(int(arr["counts"][k]))
-            for v in range(g.vcount()):
-                g.vs[v]["type"] = int(arr["types"][k, v])
-                for l in range(L):
-                    g.vs[v]["H_forward%d" % l] = torch.from_numpy(arr["states"][k, v, l][None].copy())
-                g._pred[v] = [u for u in range(v) if arr["adj"][k, u, v]]
-            gs.append(g)
-        return gs
 
-    with torch.no_grad():
-        for v in meta["vs"]:
-            G = graphs()
-            Hv = model._ipropagate_to(G, v, model.grud)
-            alive = [k for k in range(K) if arr["counts"][k] > v]
-            assert alive == list(arr["v%d_alive" % v])
-            assert Hh.maxdiff(Hv, arr["v%d_Hv" % v]) < 2e-6
-            got = np.stack([np.stack([G[k].vs[v]["H_forward%d" % l][0].numpy() for l in range(L)]) for k in alive])
-            assert np.abs(got - arr["v%d_states" % v]).max() < 2e-6
-            Hg = model._ipropagate_to(graphs(), v, model.grud, H=torch.from_numpy(arr["H_given"].copy()))
-            assert Hh.maxdiff(Hg, arr["v%d_Hv_given" % v]) < 2e-6
-        assert model._ipropagate_to(graphs(), n + 3, model.grud) is None   # no graph has that vertex
+def test_ipropagate_to_has_no_cpu_path():
+    """The product's single-vertex step is HIP only: a model on the CPU raises instead of falling back."""
+    from dagnn_amd._lib import DagnnHipError
+    meta, arr = Hh.load("iprop_bn_h32_L3")
+    model, _ = Hh.dvae_model(dict(meta, bidir=False))
+    G = Hh.iprop_graphs(meta, arr, "cpu")
+    with pytest.raises(DagnnHipError):
+        model._ipropagate_to(G, meta["vs"][0], model.grud)

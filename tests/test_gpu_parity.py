@@ -710,6 +710,54 @@ def test_device_layering_full_batch_big_graph_and_cycle(device):
     assert int(status) & 16
 
 
+# ----------------------------------------------------------------------------- decoder-side single-vertex step (f4)
+@pytest.mark.parametrize("name", ["iprop_na_h64_L2", "iprop_bn_h32_L3"])
+def test_ipropagate_to_matches_reference_on_the_gpu(device, name):
+    """`_ipropagate_to(G, v, self.grud)` of both D-VAE encoders as ONE HIP launch per decoder step
+    (`dagnn_iprop_step`) against the reference's own (`dvae/dagnn.py:187-239`, `dvae/dagnn_bn.py:179-238`): returned
+    states, the states written into the vertices, a vertex without predecessors, graphs too short for `v`, the
+    `H`-given form - and against the CPU restatement in oracle/."""
+    from oracle.iprop_oracle import ipropagate_to
+    Hh.check_ipropagate(name, lambda model, G, v, H=None: model._ipropagate_to(G, v, model.grud, H=H), device, 5e-6)
+    meta, arr = Hh.load(name)
+    model, _ = Hh.dvae_model(dict(meta, bidir=False))
+    v = meta["vs"][-1]
+    with torch.no_grad():
+        ref = ipropagate_to(model, Hh.iprop_graphs(meta, arr, "cpu"), v, model.grud)
+        got = model.to(device)._ipropagate_to(Hh.iprop_graphs(meta, arr, device), v, model.grud)
+    assert Hh.maxdiff(got, ref.numpy()) < 5e-6
+
+
+def test_check_raises_for_the_last_forward_of_a_loop(device, monkeypatch):
+    """A device-side failure of the LAST forward of a loop has no next forward to report it: `model.check()` (and the
+    `DataParallel` wrapper in eval mode, which calls it) raises; earlier healthy passes of the same async loop do not
+    mask it, and the flag is consumed."""
+    from dagnn_amd import DataParallel
+    monkeypatch.setattr(engine, "DATAFLOW", 1)
+    model = _headline_model(H=64, L=2, V=16, seed=3).to(device).eval()
+    b = synth.code2_batch(4, 24, 60)
+    with torch.no_grad():
+        for _ in range(3):
+            model(b.clone().to(device))
+        model.check()                         # healthy: returns
+        monkeypatch.setattr(engine, "SPIN_LIMIT", 1)
+        model(b.clone().to(device))           # every dependent poll gives up at once: garbage, flagged
+        monkeypatch.setattr(engine, "SPIN_LIMIT", 0)
+        with pytest.raises(DagnnHipError, match="bounded device-side wait"):
+            model.check()
+        model.check()                         # consumed
+        out = model(b.clone().to(device))
+        ref = model(b.clone().to(device))
+        model.check()
+        assert all(torch.equal(x, y) for x, y in zip(out, ref))
+        dp = DataParallel(model, device_ids=[torch.cuda.current_device()]).eval()
+        monkeypatch.setattr(engine, "SPIN_LIMIT", 1)
+        with pytest.raises(DagnnHipError, match="bounded device-side wait"):
+            dp([b.clone()])
+        monkeypatch.setattr(engine, "SPIN_LIMIT", 0)
+        dp([b.clone()])
+
+
 # ----------------------------------------------------------------------------- concurrency stress
 def test_back_to_back_forwards_and_steps_are_race_free(device):
     """Split mode runs the persistent kernel on a side stream next to the per-layer launches, and nothing in

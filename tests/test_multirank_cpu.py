@@ -171,6 +171,42 @@ def test_data_parallel_shim_single_process_semantics():
     assert torch.equal(dp(shards), dp.module(shards[0]))
     assert list(dp.state_dict().keys()) == ["module.w"]
     assert dp.src_device.type == "cpu"
+    # k device ids in ONE process (`:52-62`: scatter, one replica per element, gather): every element runs, the
+    # outputs come back concatenated in list order - nothing is silently dropped
+    dpk = DataParallel(_RowSum(), device_ids=[0, 1])
+    dpk.src_device = torch.device("cpu")
+    full = dpk.module(synth.GraphBatch.from_data_list(graphs))
+    assert torch.equal(dpk(shards), full)
+    lists = DataParallel._gather([[torch.ones(2, 3), torch.zeros(2, 1)], [torch.ones(1, 3), torch.zeros(1, 1)]])
+    assert [tuple(t.shape) for t in lists] == [(3, 3), (3, 1)]
+
+
+class _Checked(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.ones(1))
+        self.checks = 0
+
+    def forward(self, G):
+        return self.w * float(G.num_graphs)
+
+    def check(self):
+        self.checks += 1
+
+
+def test_data_parallel_eval_forward_checks_the_module():
+    """In eval mode the wrapper asks the module for a blocking device-side error check behind every forward
+    (`main_pyg.py:91-124` consumes the outputs right away; the last batch of a loop has no next forward)."""
+    from dagnn_amd import DataParallel
+    shards = collate_sharded(synth.code2_graphs(3, 4, 12), 1)
+    dp = DataParallel(_Checked(), device_ids=[])
+    dp.train()
+    dp(shards)
+    assert dp.module.checks == 0
+    dp.eval()
+    dp(shards)
+    dp(shards)
+    assert dp.module.checks == 2
 
 
 def _dp_worker(rank, world, port, out):
@@ -190,6 +226,24 @@ def _dp_worker(rank, world, port, out):
         assert torch.allclose(dp.module.w.grad, full.w.grad, atol=1e-6)
         dp.zero_grad()
         assert float(dp.module.w.grad.abs().max()) == 0.0 and dp.module.w.grad.data_ptr() == dp._bucket.flat.data_ptr()
+        # the reference's loop calls optimizer.zero_grad() (`main_pyg.py:50`), which sets the gradients to None: the
+        # next backward() allocates them OUTSIDE the bucket.  reduce_gradients must notice, or step 2 reduces a stale
+        # bucket and the replicas drift apart silently
+        opt = torch.optim.SGD(dp.parameters(), lr=0.1)
+        ref = _RowSum()
+        ref_opt = torch.optim.SGD(ref.parameters(), lr=0.1)
+        for _ in range(3):
+            opt.zero_grad()        # set_to_none=True is the default
+            assert dp.module.w.grad is None
+            dp(shards).mean().backward()
+            assert dp.module.w.grad.data_ptr() != dp._bucket.flat.data_ptr()
+            dp.reduce_gradients(local_count=shards[rank].num_graphs)
+            assert dp.module.w.grad.data_ptr() == dp._bucket.flat.data_ptr()
+            opt.step()
+            ref_opt.zero_grad()
+            ref(synth.GraphBatch.from_data_list(graphs)).mean().backward()
+            ref_opt.step()
+            assert torch.allclose(dp.module.w.detach(), ref.w.detach(), atol=1e-6)
         with pytest.raises(ValueError):
             dp(shards + shards)
         assert dp(shards[:1]) is None if rank == 1 else dp(shards[:1]) is not None   # a list shorter than the world

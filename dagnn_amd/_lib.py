@@ -95,6 +95,19 @@ class BackwardArgs(C.Structure):
                 ("fork_event", C.c_void_p), ("join_event", C.c_void_p)]
 
 
+class BwdDataflowCell(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("w_hh_t", "w_ih_t", "w_key", "alpha", "gi", "gh", "a", "b_hh", "h", "g_ext", "stat",
+                                          "da_granules", "q_granules", "dgi_granules", "du_granules", "dgi", "dgh", "sigma",
+                                          "edge_feat_grad")]
+
+
+class BwdDataflowArgs(C.Structure):
+    _fields_ = [("cell", (BwdDataflowCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
+                ("H", C.c_int), ("ld_h", C.c_int), ("ld_g", C.c_int), ("gld", C.c_int), ("groups", C.c_int),
+                ("epoch", C.c_uint), ("spin_limit", C.c_uint), ("schedule", C.c_void_p), ("records", C.c_void_p),
+                ("err", C.c_void_p), ("plan_status", C.c_void_p)]
+
+
 AGG_ATTN, AGG_MATTN, AGG_GATED, AGG_ADD, AGG_MAX, AGG_GIVEN = range(6)
 POOL_MAX, POOL_ADD, POOL_MEAN = range(3)
 
@@ -162,6 +175,11 @@ SYMBOLS = {
     "dagnn_backward_prepare": (C.c_int, [C.POINTER(Plan), C.POINTER(BackwardArgs), C.c_void_p]),
     "dagnn_backward_run": (C.c_int, [C.POINTER(Plan), C.POINTER(BackwardArgs), C.POINTER(C.POINTER(C.c_int32)),
                                      C.POINTER(C.c_int32), C.c_void_p]),
+    "dagnn_bwd_dataflow_record_bytes": (C.c_size_t, [C.c_int64]),
+    "dagnn_bwd_dataflow_static_bytes": (C.c_size_t, [C.c_int64]),
+    "dagnn_gatewise_transpose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "dagnn_bwd_dataflow_prepare": (C.c_int, [C.POINTER(Plan), C.POINTER(BwdDataflowArgs), C.c_void_p]),
+    "dagnn_bwd_dataflow_run": (C.c_int, [C.POINTER(Plan), C.POINTER(BwdDataflowArgs), C.c_void_p]),
     "dagnn_readout_max_backward": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                              C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_topo_layers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,

@@ -105,9 +105,15 @@ class Recurrence(torch.autograd.Function):
                 for i in range(L):
                     if gouts[q * L + i] is not None:
                         g_ext[d][i][:, :H] = gouts[q * L + i]
-        res = engine.backward_sweep(plan, dirs, L, Hp, cells, keep["h_buf"], keep["gi0"], g_ext,
-                                    arena=mod._arena_for(x, "backward"), vid_mod=mod._vid_nodes,
-                                    static_score=ctx.sscore)
+        groups = keep.get("groups", 0)
+        if groups > 0 and engine.bwd_dataflow_groups(dev, len(dirs), L, Hp, plan.B) == groups:
+            res = engine.bwd_dataflow_sweep(plan, dirs, L, Hp, cells, keep["h_buf"], keep["gi0"], g_ext, groups,
+                                            arena=mod._arena_for(x, "backward"), vid_mod=mod._vid_nodes,
+                                            static_score=ctx.sscore)
+        else:
+            res = engine.backward_sweep(plan, dirs, L, Hp, cells, keep["h_buf"], keep["gi0"], g_ext,
+                                        arena=mod._arena_for(x, "backward"), vid_mod=mod._vid_nodes,
+                                        static_score=ctx.sscore)
 
         ep = engine._span("backward_epilogue", x)
         ep.__enter__()

@@ -81,7 +81,7 @@ class CellParams(object):
     """Device-side, kernel-ready parameters of one (direction, stacked layer) cell."""
 
     __slots__ = ("w_ih", "b_ih", "w_hh_t", "b_hh", "w_key", "edge_gain", "vid_bias", "w_hh_pk", "w_ih_pk",
-                 "b_ih_dev", "Hp", "key_raw", "w_hh_raw", "w_hh_df", "w_ih_df")
+                 "b_ih_dev", "Hp", "key_raw", "w_hh_raw", "w_hh_df", "w_ih_df", "w_hh_bt", "w_ih_bt")
 
 
 def pack_dataflow(cells) -> None:
@@ -136,6 +136,7 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
     c.w_hh_t = None if lock else engine.pack_whh(whh)
     c.w_hh_pk = c.w_ih_pk = None
     c.w_hh_df = c.w_ih_df = None
+    c.w_hh_bt = c.w_ih_bt = None   # reverse sweep: packed gate-wise transposes (engine.bwd_dataflow_sweep)
     use_df = engine.DATAFLOW and Hp <= 256   # the dataflow kernel's layout instead (packed below)
     if lock and pack and not use_df:   # pack=False: the caller batches the packing of all its cells (pack_lockstep)
         c.w_hh_pk = {js: engine.pack_slices(whh, Hp, js) for js in (16, 32)}
@@ -184,7 +185,7 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
         pack_lockstep(cells.values(), force=True)
         engine.frontier_run(plan, dirs, L, Hp, cells, gi, h, vid_mod=vid_nodes, arena=arena, static_score=static_score)
     if keep is not None:
-        keep["h_buf"], keep["gi0"], keep["Hp"] = h, gi, Hp
+        keep["h_buf"], keep["gi0"], keep["Hp"], keep["groups"] = h, gi, Hp, groups
     return [[h[d][i][:, :H] if h[d][i] is not None else None for i in range(L)] for d in range(2)]
 
 

@@ -1,0 +1,920 @@
+// bwd_dataflow.hip - the reverse-mode sweep of the recurrence as ONE persistent, graph-affine dataflow launch (H <= 256).
+//
+// Reference path replaced: what `loss.backward()` (ogbg-code/main_pyg.py:62; dvae/train.py through `encode`) does to the
+// loops of ogbg-code/model/dagnn.py:144-182 (dvae/dagnn.py:112-146, dvae/dagnn_bn.py:110-137) through torch autograd: one
+// autograd node per (direction, topological layer, stacked layer) micro-step.  backward.hip (round 1) walks them as
+// T + L - 1 reverse lock-step launches plus a persistent head; here the whole sweep is the mirror image of dataflow.hip:
+// the SAME schedule (graphs dealt to independent groups, dagnn_dataflow_schedule), walked block by block from the deepest
+// layer of every group back to layer 0, one workgroup per (workgroup set, kernel cell, 32-unit slice) with its matrix
+// slice resident in registers, rows handed between workgroups as tagged granules.
+//
+// Math (per direction d, stacked layer i, node v; see backward.hip's header for the derivation):
+//   G_v   = Gext_v + du_v(i+1) + sum_{e = (v -> w)} [ alpha_e da_w + ds_e w_k ],   ds_e = alpha_e (da_w . h_v - q_w)
+//           with q_w = da_w . a_w.  q_w never needs the row a_w: da_w = z_w (.) G_w + W_hh^T dgh_w, hence
+//           q_w = G_w . c_q,w with c_q = z a + c_r (gh_r - b_r) + c_z (gh_z - b_z) + c_nr (gh_n - b_n)  (W_hh a = gh - b_hh):
+//           ONE scalar per node, published by the workgroup that computes G_w;
+//   GRU backward is linear in G_v with coefficients that depend on the forward pass only, so they are computed for all
+//   nodes beforehand (dagnn_bwd_dataflow_prepare, off the dependent chain):
+//           dgh_v = G_v (.) (c_r, c_z, c_nr),  dgi_v = G_v (.) (c_r, c_z, c_n),  zg_v = G_v (.) z
+//           c_n = (1 - z)(1 - n^2), c_z = (a - n) z (1 - z), c_r = c_n gh_n r (1 - r), c_nr = c_n r;
+//   da_v  = zg_v + W_hh^T dgh_v          (K = 3H: three gate blocks of K = H, i.e. the forward kernel's product shape
+//                                          on the gate-wise transposed matrix)
+//   du_v  = W_ih^T dgi_v  -> G of stacked layer i - 1 at the same node.
+// Kernel cells of a direction: L "state-gradient" cells (W_hh^T -> da granules) and L - 1 "input-gradient" cells (W_ih^T of
+// the stacked layers above the first -> du granules, off the dependent chain like the forward projection cells).
+//   loader wave (da cell)  row w of every block of its stream: static rows of the node (Gext, h, the coefficient rows: one
+//                   contiguous 8 KB record of dagnn_bwd_dataflow_prepare), poll the successors' da rows + q scalars (and
+//                   the node's du row), pull, coefficients -> dgh into the stream's LDS ring slot (3 operand rows), zg
+//                   slice; its slice of dgi / dgh to memory (the weight-gradient epilogue reads them), dgi also as
+//                   granules for the input-gradient cell; slice 0 publishes q_v, sigma_v and the edge-feature sums;
+//   loader wave (du cell)  polls the dgi granules of the node, no arithmetic;
+//   compute wave    v_mfma_f32_4x4x1 products exactly as in dataflow.hip (A = resident weights, B = the block's operand
+//                   rows), the three gate accumulators summed BEFORE the K reduce-scatter, + zg, granule store.
+// No atomics on values, a fixed order of additions: gradients are bitwise reproducible run to run.
+#include "df_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef float bf4 __attribute__((ext_vector_type(4)));
+
+constexpr int BD_NSLOT = 3;          // LDS ring depth per stream (a slot holds 3 operand rows per block row)
+constexpr int BD_WPS = 4;            // loader waves per stream = rows per block
+constexpr int BD_NLW = DF_NLS * BD_WPS;
+constexpr int BD_THREADS = 64 * (DF_NCW + BD_NLW);
+constexpr int BD_SP = 256;           // pitch of a static row (floats): lane l holds columns {l, 64 + l, 128 + l, 192 + l} at [4l, 4l + 4)
+constexpr int BD_NSTAT = 8;          // static rows per (cell, node): Gext, h, c_r, c_z, c_nr, c_n, z, c_q
+constexpr int BD_RD = 6;             // a loader wave requests a record this many of its blocks ahead (ring: 8 entries)
+enum { BD_DA = 0, BD_DU = 1 };
+enum { ST_GEXT = 0, ST_H = 1, ST_CR = 2, ST_CZ = 3, ST_CNR = 4, ST_CN = 5, ST_Z = 6, ST_CQ = 7 };
+
+struct BdCell {            // (104 bytes: 30 kernel cells - 8 stacked layers, both directions - fit the kernel-argument segment)
+    const float4* w;       // packed slices (dagnn_pack_dataflow of the gate-wise transposed matrix)
+    const float* wkey;     // da: [H] key weights (zeros when the scores are static)
+    const float* alpha;    // da: [E] attention weights by original edge id
+    const float* stat;     // da: [N, 8 * 256] static rows
+    const gran_t* du_in;   // da: [N, gld] du arriving from stacked layer i + 1, or null (top layer)
+    gran_t* out_g;         // da: [N, gld] granules of da (also read by this cell's own loaders); du: [N, gld] granules of du
+                           //     for stacked layer i - 1
+    gran_t* q_g;           // da: [N] granules of q
+    gran_t* dgi_g;         // da: [N, 3 gld] granules of dgi for the input-gradient cell, or null (stacked layer 0);
+                           // du: the same buffer (its input)
+    float* dgi;            // da: [N, 3H]
+    float* dgh;            // da: [N, 3H]
+    float* sig;            // da: [N]
+    float* mrel;           // da: [N, R] or null
+    int dir, kind;
+};
+
+#define BD_MAX_KCELLS 30
+
+struct BdArgs {
+    BdCell cell[BD_MAX_KCELLS];
+    const int32_t* sched;   // schedule workspace (dagnn_dataflow_schedule)
+    const int32_t* brecs;   // successor records in schedule order (dagnn_bwd_dataflow_prepare)
+    int64_t gtab[2], brec[2];   // word offsets into sched / brecs
+    int64_t col[2], eidx[2], eattr[2];   // word offsets into the plan
+    int ncell, H, gld, R, groups, N;
+    unsigned epoch, spin_limit;
+    const int32_t* status;
+    int* err;
+};
+
+template <int KPT> struct BdPad { static constexpr int kp8 = 2 * KPT; static constexpr int seg = kp8 + 4; static constexpr int row = 8 * seg + 8; };
+
+template <int KPT> struct BdSlot {
+    static constexpr int AP = BdPad<KPT>::row;
+    static constexpr int op_off = 0;                          // [3][RB][AP] operand rows: gate block g of row r at (g * RB + r) * AP
+    static constexpr int zg_off = 3 * DF_RB * AP;             // [RB][32]    z (.) G of the slice's units
+    static constexpr int v_off = zg_off + DF_RB * DF_JS;      // [RB] ints
+    static constexpr int words = v_off + 4;
+};
+
+struct BdLds {
+    float* ring;   // [NLS][NSLOT] slots
+    int* rec;      // [NLS * RB][8][16] row records, landed by LDS-DMA BD_RD blocks ahead
+    int* rdy;      // [NLS][WPS]
+    int* dn;       // [NLS][NCW]
+};
+
+__device__ __forceinline__ int bd_flag_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void bd_flag_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__device__ __forceinline__ bool bd_wait4(const int* f, int target, int* err, unsigned limit) {
+    unsigned spins = 0;
+    for (;;) {
+        const int a = bd_flag_ld(f), b = bd_flag_ld(f + 1), c = bd_flag_ld(f + 2), d = bd_flag_ld(f + 3);
+        if (min(min(a, b), min(c, d)) >= target) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > 4 * limit) { __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+        if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    }
+}
+
+__device__ __forceinline__ bool bd_retry(unsigned& spins, int* err, unsigned limit) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > limit) { __hip_atomic_fetch_or(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+    if ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    return true;
+}
+
+__device__ __forceinline__ float bd_dpp_row_sum16(float v) {
+#define BD_DPP_ADD(ctrl) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+    BD_DPP_ADD(0x111); BD_DPP_ADD(0x112); BD_DPP_ADD(0x114); BD_DPP_ADD(0x118);
+#undef BD_DPP_ADD
+    return v;
+}
+// sum over the 64 lanes, broadcast as a wave-uniform value (row scans, then row_bcast15 / row_bcast31)
+__device__ __forceinline__ float bd_wave_sum(float v) {
+    v = bd_dpp_row_sum16(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+template <int CTRL> __device__ __forceinline__ float bd_dpp(float v) {   // 0 where the source lane is outside the DPP row
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float bd_row_pair_sum(float x) {   // (see df_row_pair_sum in dataflow.hip: the swap must be inline asm)
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __host__ __forceinline__ int bd_stream_group(int pair, int set, int groups) {
+    const int g = DF_NLS * pair + set;
+    return g < groups ? g : -1;
+}
+
+// ---------------------------------------------------------------- preparation kernels
+// successor records in schedule order: for schedule record r of direction d (node v, or -1 = padding) the 64 bytes
+// {v, first / last CSR slot of v's row in direction 1 - d, 0, first four successors, their original edge ids, 0 x 4}
+__global__ void __launch_bounds__(256) bd_records_kernel(const int32_t* __restrict__ plan, PlanLayout L,
+                                                          const int32_t* __restrict__ sched, DfLayout S,
+                                                          int32_t* __restrict__ brecs, int64_t nrec,
+                                                          const int32_t* __restrict__ status) {
+    if (status && status[0] != 0) return;
+    const int d = blockIdx.y, od = 1 - d;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrec) return;
+    const int v = sched[S.grec[d] + 16 * r];
+    int4* out = reinterpret_cast<int4*>(brecs + (int64_t)d * 16 * nrec + 16 * r);
+    if (v < 0) {
+        out[0] = make_int4(-1, 0, 0, 0);
+        out[1] = make_int4(0, 0, 0, 0); out[2] = out[1]; out[3] = out[1];
+        return;
+    }
+    const int4* orec = reinterpret_cast<const int4*>(plan + L.rowrec[od]) + 4 * (int64_t)plan[L.pos[od] + v];
+    const int4 r0 = orec[0], r1 = orec[1];
+    const int eb = r0.y, ee = r0.z;
+    const int32_t* eidx = plan + L.eidx[od];
+    out[0] = make_int4(v, eb, ee, 0);
+    out[1] = r1;
+    out[2] = make_int4(eb < ee ? eidx[eb] : 0, eb + 1 < ee ? eidx[eb + 1] : 0, eb + 2 < ee ? eidx[eb + 2] : 0,
+                       eb + 3 < ee ? eidx[eb + 3] : 0);
+    out[3] = make_int4(0, 0, 0, 0);
+}
+
+struct BdStatCell {
+    const float* gi;     // [N,3H]
+    const float* gh;     // [N,3H]
+    const float* a;      // [N,H]
+    const float* b_hh;   // [3H]
+    const float* h;      // [N,ld_h]
+    const float* gext;   // [N,ld_g]
+    float* stat;         // [N, 8 * 256]
+};
+struct BdStatArgs { BdStatCell cell[DAGNN_MAX_DIRS * DAGNN_MAX_STACKED]; int ncell, H, ld_h, ld_g; };
+
+__device__ __forceinline__ float bd_sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// one wave per (cell, node): the eight static rows in the lane order the sweep's loader waves read them in
+__global__ void __launch_bounds__(256) bd_stat_kernel(BdStatArgs A, int64_t N) {
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= N) return;
+    const BdStatCell& C = A.cell[blockIdx.y];
+    const int H = A.H, H3 = 3 * H;
+    float o[BD_NSTAT][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = 64 * q + lane;
+#pragma unroll
+        for (int r = 0; r < BD_NSTAT; ++r) o[r][q] = 0.f;
+        if (c < H) {
+            const float* gi = C.gi + v * H3;
+            const float* gh = C.gh + v * H3;
+            const float ghr = gh[c], ghz = gh[H + c], ghn = gh[2 * H + c];
+            const float rr = bd_sigm(gi[c] + ghr), zz = bd_sigm(gi[H + c] + ghz);
+            const float nn = tanhf(gi[2 * H + c] + rr * ghn);
+            const float av = C.a[v * H + c];
+            const float cn = (1.0f - zz) * (1.0f - nn * nn);
+            const float cz = (av - nn) * zz * (1.0f - zz);
+            const float cr = cn * ghn * rr * (1.0f - rr);
+            const float cnr = cn * rr;
+            o[ST_GEXT][q] = C.gext[v * A.ld_g + c];
+            o[ST_H][q] = C.h[v * A.ld_h + c];
+            o[ST_CR][q] = cr; o[ST_CZ][q] = cz; o[ST_CNR][q] = cnr; o[ST_CN][q] = cn; o[ST_Z][q] = zz;
+            o[ST_CQ][q] = zz * av + cr * (ghr - C.b_hh[c]) + cz * (ghz - C.b_hh[H + c]) + cnr * (ghn - C.b_hh[2 * H + c]);
+        }
+    }
+    float4* dst = reinterpret_cast<float4*>(C.stat + v * (BD_NSTAT * BD_SP)) + lane;
+#pragma unroll
+    for (int r = 0; r < BD_NSTAT; ++r) dst[r * (BD_SP / 4)] = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
+}
+
+// ---------------------------------------------------------------- loader waves
+// Memory traffic by hand, as in dataflow.hip: ONE asm statement per trip to memory - the polls (granule rows with
+// `sc1`), on the first trip of a row also its static rows and the LDS-DMA of the record BD_RD blocks ahead, and the counted
+// wait (the DMA stays in flight).  A destination register the compiler can see while its load is in flight gets copied
+// sooner or later; loads and wait in the same statement leave it nothing to see.
+struct BdSweep {
+    gran_t x[4][4];   // da rows of up to four successors: columns {lane, 64 + lane, 128 + lane, 192 + lane}
+    gran_t q[4];      // their q scalars (every lane loads the same granule)
+    gran_t u[4];      // the node's du row
+    bf4 st[BD_NSTAT]; // the node's static rows
+};
+
+#define BD_ROW_LD(e)                                                            \
+    "global_load_dwordx2 %[x" #e "0], %[vo], %[b" #e "] offset:0 sc1\n\t"        \
+    "global_load_dwordx2 %[x" #e "1], %[vo], %[b" #e "] offset:%[o1] sc1\n\t"    \
+    "global_load_dwordx2 %[x" #e "2], %[vo], %[b" #e "] offset:%[o2] sc1\n\t"    \
+    "global_load_dwordx2 %[x" #e "3], %[vo], %[b" #e "] offset:%[o3] sc1\n\t"    \
+    "global_load_dwordx2 %[q" #e "], %[vz], %[c" #e "] offset:0 sc1\n\t"
+#define BD_ROWS_0 ""
+#define BD_ROWS_1 BD_ROW_LD(0)
+#define BD_ROWS_2 BD_ROWS_1 BD_ROW_LD(1)
+#define BD_ROWS_3 BD_ROWS_2 BD_ROW_LD(2)
+#define BD_ROWS_4 BD_ROWS_3 BD_ROW_LD(3)
+#define BD_DU_0 ""
+#define BD_DU_1                                                      \
+    "global_load_dwordx2 %[u0], %[vo], %[ub] offset:0 sc1\n\t"        \
+    "global_load_dwordx2 %[u1], %[vo], %[ub] offset:%[o1] sc1\n\t"    \
+    "global_load_dwordx2 %[u2], %[vo], %[ub] offset:%[o2] sc1\n\t"    \
+    "global_load_dwordx2 %[u3], %[vo], %[ub] offset:%[o3] sc1\n\t"
+#define BD_STAT_0 "s_waitcnt vmcnt(0)"
+#define BD_STAT_1                                                     \
+    "global_load_dwordx4 %[s0], %[vs], %[sa] offset:0\n\t"            \
+    "global_load_dwordx4 %[s1], %[vs], %[sa] offset:1024\n\t"         \
+    "global_load_dwordx4 %[s2], %[vs], %[sa] offset:2048\n\t"         \
+    "global_load_dwordx4 %[s3], %[vs], %[sa] offset:3072\n\t"         \
+    "global_load_dwordx4 %[s4], %[vs], %[sb] offset:0\n\t"            \
+    "global_load_dwordx4 %[s5], %[vs], %[sb] offset:1024\n\t"         \
+    "global_load_dwordx4 %[s6], %[vs], %[sb] offset:2048\n\t"         \
+    "global_load_dwordx4 %[s7], %[vs], %[sb] offset:3072\n\t"         \
+    "s_mov_b32 %[km], m0\n\ts_mov_b64 %[ke], exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %[rl]\n\t" \
+    "s_nop 0\n\tglobal_load_lds_dword %[ra], off\n\t"                 \
+    "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]\n\ts_waitcnt vmcnt(1)"
+#define BD_TRIP(n_, du_, st_)                                                                                                  \
+    asm volatile(BD_ROWS_##n_ BD_DU_##du_ BD_STAT_##st_                                                                        \
+                 : [x00] "=v"(W.x[0][0]), [x01] "=v"(W.x[0][1]), [x02] "=v"(W.x[0][2]), [x03] "=v"(W.x[0][3]),              \
+                   [x10] "=v"(W.x[1][0]), [x11] "=v"(W.x[1][1]), [x12] "=v"(W.x[1][2]), [x13] "=v"(W.x[1][3]),              \
+                   [x20] "=v"(W.x[2][0]), [x21] "=v"(W.x[2][1]), [x22] "=v"(W.x[2][2]), [x23] "=v"(W.x[2][3]),              \
+                   [x30] "=v"(W.x[3][0]), [x31] "=v"(W.x[3][1]), [x32] "=v"(W.x[3][2]), [x33] "=v"(W.x[3][3]),              \
+                   [q0] "=v"(W.q[0]), [q1] "=v"(W.q[1]), [q2] "=v"(W.q[2]), [q3] "=v"(W.q[3]),                              \
+                   [u0] "=v"(W.u[0]), [u1] "=v"(W.u[1]), [u2] "=v"(W.u[2]), [u3] "=v"(W.u[3]),                              \
+                   [s0] "=v"(W.st[0]), [s1] "=v"(W.st[1]), [s2] "=v"(W.st[2]), [s3] "=v"(W.st[3]),                          \
+                   [s4] "=v"(W.st[4]), [s5] "=v"(W.st[5]), [s6] "=v"(W.st[6]), [s7] "=v"(W.st[7]),                          \
+                   [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)                                                               \
+                 : [vo] "v"(lane8), [vz] "v"(vzero), [vs] "v"(lane16), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3), \
+                   [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [c3] "s"(c3p), [ub] "s"(ub), [sa] "s"(sa), [sb] "s"(sb),    \
+                   [ra] "v"(ra), [rl] "s"(rl), [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)                                     \
+                 : "memory")
+#define BD_CASE(n_, du_, st_) case (n_) * 4 + (du_) * 2 + (st_): BD_TRIP(n_, du_, st_); break;
+#define BD_CASES(n) BD_CASE(n, 0, 0) BD_CASE(n, 0, 1) BD_CASE(n, 1, 0) BD_CASE(n, 1, 1)
+
+template <int KPT, bool HAS_DU>
+__device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, const BdArgs& S, const BdCell& C, int sl,
+                                             int group, const BdLds& lds, int w, int set) {
+    constexpr int H = 16 * KPT;
+    constexpr int SEG = BdPad<KPT>::seg, KP8 = BdPad<KPT>::kp8;
+    constexpr int NQ4 = H / 64;
+    typedef BdSlot<KPT> Slot;
+    const int lane = threadIdx.x & 63;
+    const int d = C.dir, od = 1 - d;
+    const int32_t* tab = S.sched + S.gtab[d] + 2 * group;
+    const int rec_base = tab[0], nblk = tab[1];
+    const int32_t* __restrict__ recs = S.brecs + S.brec[d] + 16 * (int64_t)rec_base;
+    const int32_t* __restrict__ col = plan + S.col[od];
+    const int32_t* __restrict__ eidx = plan + S.eidx[od];
+    const float* __restrict__ eattr = reinterpret_cast<const float*>(plan + S.eattr[od]);
+    const int R = C.mrel ? S.R : 0;
+    const unsigned epoch = S.epoch, spin_limit = S.spin_limit;
+    int* const err = S.err;
+    const int gld = S.gld;
+    const gran_t* const da_g = C.out_g;
+    const gran_t* const q_in = C.q_g;
+    const gran_t* const du_in = C.du_in;
+    const float* const stat = C.stat;
+    const float* const alpha = C.alpha;
+    gran_t* const q_out = C.q_g;
+    gran_t* const dgi_g = C.dgi_g;
+    float* const dgi = C.dgi;
+    float* const dgh = C.dgh;
+    float* const sig_out = C.sig;
+    float* const mrel = C.mrel;
+    int* const dn = lds.dn + set * DF_NCW;
+    float wk[4] = {0.f, 0.f, 0.f, 0.f};
+    int cpos[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = 64 * q + lane;
+        cpos[q] = c + (SEG - KP8) * (c / KP8);
+        if (q < NQ4) wk[q] = C.wkey[c];
+    }
+    const unsigned lane8 = 8u * lane, lane16 = 16u * lane, vzero = 0u;
+    constexpr int O1 = (NQ4 > 1 ? 1 : 0) * 512, O2 = (NQ4 > 2 ? 2 : NQ4 - 1) * 512, O3 = (NQ4 - 1) * 512;
+    const int lw = w;   // this wave's row of every block
+    int* const rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
+    const unsigned rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
+    const int32_t* const rec_w = recs + 16 * lw + (lane & 15);
+    const int64_t wstride = 16 * DF_RB;
+    // block j of this wave (the j-th from the END of the stream's record list: the sweep runs the layers in reverse)
+    auto rec_src = [&](int j) -> const void* { return rec_w + (int64_t)(nblk - 1 - min(j, nblk - 1)) * wstride; };
+    auto rec_dst = [&](int j) -> unsigned { return rec_ring_a + (j & 7) * 64; };
+    auto glds4 = [&](const void* gsrc, unsigned lds_dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    };
+    if (nblk > 0) {
+#pragma unroll
+        for (int j = 0; j < BD_RD; ++j) if (lane < 16) glds4(rec_src(j), rec_dst(j));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // the slice's share of a full row in the loader's column layout: units [32 sl, 32 sl + 32) = column block q = sl / 2,
+    // lanes [32 (sl & 1), + 32)
+    const int myq = sl >> 1;
+    const bool mine = (lane >> 5) == (sl & 1);
+    auto pick = [&](const float (&a)[4]) -> float { return myq == 0 ? a[0] : (myq == 1 ? a[1] : (myq == 2 ? a[2] : a[3])); };
+
+    BdSweep A;
+    for (int b = 0; b < nblk; ++b) {
+        const int j = b;
+        const int cur = rec_ring[(j & 7) * 16 + (lane & 15)];
+#define BD_W(i) __builtin_amdgcn_readlane(cur, i)
+        const int v = BD_W(0), eb = BD_W(1), ee = BD_W(2);
+        const int s4[4] = {BD_W(4), BD_W(5), BD_W(6), BD_W(7)};
+        const int e4[4] = {BD_W(8), BD_W(9), BD_W(10), BD_W(11)};
+#undef BD_W
+        const int slot = b % BD_NSLOT;
+        float* sbase = lds.ring + (set * BD_NSLOT + slot) * Slot::words;
+        int* v_s = reinterpret_cast<int*>(sbase + Slot::v_off);
+        const void* ra = rec_src(j + BD_RD);
+        const unsigned rl = rec_dst(j + BD_RD);
+        if (v >= 0) {
+            const int deg = ee - eb;
+            const float* sa = stat + (int64_t)v * (BD_NSTAT * BD_SP);
+            const float* sb = sa + 4 * BD_SP;
+            const gran_t* ub = HAS_DU ? du_in + (int64_t)v * gld : da_g;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            float hv[4] = {0.f, 0.f, 0.f, 0.f};
+            float sig = 0.f, m0 = 0.f, m1 = 0.f;
+            bf4 st[BD_NSTAT];
+            float du[4] = {0.f, 0.f, 0.f, 0.f};
+            int c0 = 0;
+            do {
+                const int nn = max(0, min(4, deg - c0));
+                int pj[4] = {0, 0, 0, 0};
+                float al[4] = {0.f, 0.f, 0.f, 0.f}, f0[4] = {0.f, 0.f, 0.f, 0.f}, f1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (e < nn) {
+                        int eid;
+                        if (c0 == 0) { pj[e] = s4[e]; eid = e4[e]; }
+                        else { pj[e] = col[eb + c0 + e]; eid = eidx[eb + c0 + e]; }
+                        al[e] = alpha[eid];
+                        if (R >= 1) f0[e] = eattr[(int64_t)(eb + c0 + e) * R];
+                        if (R >= 2) f1[e] = eattr[(int64_t)(eb + c0 + e) * R + 1];
+                    }
+                }
+                const gran_t* b0 = da_g + (int64_t)pj[0] * gld;
+                const gran_t* b1 = da_g + (int64_t)pj[1] * gld;
+                const gran_t* b2 = da_g + (int64_t)pj[2] * gld;
+                const gran_t* b3 = da_g + (int64_t)pj[3] * gld;
+                const gran_t* c0p = q_in + pj[0], * c1p = q_in + pj[1], * c2p = q_in + pj[2], * c3p = q_in + pj[3];
+                const bool first = c0 == 0;
+                bool stat_pending = first;
+                bool du_pending = HAS_DU && first;
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned keep_m0;
+                    unsigned long long keep_exec;
+                    BdSweep& W = A;
+                    switch (nn * 4 + (du_pending ? 2 : 0) + (stat_pending ? 1 : 0)) {
+                        BD_CASES(0) BD_CASES(1) BD_CASES(2) BD_CASES(3)
+                        default: BD_CASES(4)
+                    }
+                    if (stat_pending) {
+#pragma unroll
+                        for (int r = 0; r < BD_NSTAT; ++r) st[r] = A.st[r];
+                        hv[0] = st[ST_H].x; hv[1] = st[ST_H].y; hv[2] = st[ST_H].z; hv[3] = st[ST_H].w;
+                        stat_pending = false;
+                    }
+                    bool ok = true;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (e < nn) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(A.x[e][q] >> 32) == epoch;
+                            ok = ok && (unsigned)(A.q[e] >> 32) == epoch;
+                        }
+                    }
+                    if (du_pending) {
+                        bool oku = true;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) oku = oku && (unsigned)(A.u[q] >> 32) == epoch;
+                        if (__all(oku)) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) du[q] = __uint_as_float((unsigned)A.u[q]);
+                            du_pending = false;
+                        }
+                    }
+                    if ((__all(ok) && !du_pending) || !bd_retry(spins, err, spin_limit)) break;
+                }
+                // pull: ds_e = alpha_e (da_w . h_v - q_w), G += alpha_e da_w (nn is wave-uniform)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (e < nn) {
+#define BD_X(q) __uint_as_float((unsigned)A.x[e][q])
+                        float dot = BD_X(0) * hv[0];
+                        if (NQ4 > 1) dot = fmaf(BD_X(1), hv[1], dot);
+                        if (NQ4 > 2) dot = fmaf(BD_X(2), hv[2], dot);
+                        if (NQ4 > 3) dot = fmaf(BD_X(3), hv[3], dot);
+                        const float ds = al[e] * (bd_wave_sum(dot) - __uint_as_float((unsigned)A.q[e]));
+                        sig += ds;
+                        m0 = fmaf(ds, f0[e], m0);
+                        m1 = fmaf(ds, f1[e], m1);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q] = fmaf(al[e], BD_X(q), acc[q]);
+#undef BD_X
+                    }
+                }
+                c0 += 4;
+            } while (c0 < deg);
+            // G_v, then everything that is linear in it
+            float G[4];
+            G[0] = st[ST_GEXT].x + du[0] + acc[0] + sig * wk[0];
+            G[1] = st[ST_GEXT].y + du[1] + acc[1] + sig * wk[1];
+            G[2] = st[ST_GEXT].z + du[2] + acc[2] + sig * wk[2];
+            G[3] = st[ST_GEXT].w + du[3] + acc[3] + sig * wk[3];
+            const float cr[4] = {st[ST_CR].x, st[ST_CR].y, st[ST_CR].z, st[ST_CR].w};
+            const float cz[4] = {st[ST_CZ].x, st[ST_CZ].y, st[ST_CZ].z, st[ST_CZ].w};
+            const float cnr[4] = {st[ST_CNR].x, st[ST_CNR].y, st[ST_CNR].z, st[ST_CNR].w};
+            const float cn[4] = {st[ST_CN].x, st[ST_CN].y, st[ST_CN].z, st[ST_CN].w};
+            const float zz[4] = {st[ST_Z].x, st[ST_Z].y, st[ST_Z].z, st[ST_Z].w};
+            float dr[4], dz[4], dnr[4], dnn[4], zg[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                dr[q] = G[q] * cr[q]; dz[q] = G[q] * cz[q]; dnr[q] = G[q] * cnr[q]; dnn[q] = G[q] * cn[q]; zg[q] = G[q] * zz[q];
+            }
+            if (b >= BD_NSLOT) bd_wait4(dn, b - BD_NSLOT + 1, err, spin_limit);   // the ring slot is free again
+            float* op = sbase + Slot::op_off + lw * Slot::AP;
+#pragma unroll
+            for (int q = 0; q < NQ4; ++q) {
+                op[cpos[q]] = dr[q];
+                op[DF_RB * Slot::AP + cpos[q]] = dz[q];
+                op[2 * DF_RB * Slot::AP + cpos[q]] = dnr[q];
+            }
+            if (mine) {
+                const int c = 64 * myq + lane;   // = 32 sl + (lane & 31)
+                sbase[Slot::zg_off + lw * DF_JS + (lane & 31)] = pick(zg);
+                const float mr = pick(dr), mz = pick(dz), mn = pick(dnn), mnr = pick(dnr);
+                float* og = dgi + (int64_t)v * (3 * H);
+                float* oh = dgh + (int64_t)v * (3 * H);
+                og[c] = mr; og[H + c] = mz; og[2 * H + c] = mn;
+                oh[c] = mr; oh[H + c] = mz; oh[2 * H + c] = mnr;
+                if (dgi_g) {
+                    gran_t* pg = dgi_g + (int64_t)v * (3 * gld) + c;
+                    __hip_atomic_store(pg, gran_pack(epoch, mr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(pg + gld, gran_pack(epoch, mz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(pg + 2 * gld, gran_pack(epoch, mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (sl == 0) {   // q_v = G_v . c_q,v; the row's scalar outputs
+                float qd = G[0] * st[ST_CQ].x;
+                if (NQ4 > 1) qd = fmaf(G[1], st[ST_CQ].y, qd);
+                if (NQ4 > 2) qd = fmaf(G[2], st[ST_CQ].z, qd);
+                if (NQ4 > 3) qd = fmaf(G[3], st[ST_CQ].w, qd);
+                qd = bd_wave_sum(qd);
+                if (lane == 0) {
+                    __hip_atomic_store(q_out + v, gran_pack(epoch, qd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sig_out[v] = sig;
+                    if (R >= 1) mrel[(int64_t)v * R] = m0;
+                    if (R >= 2) mrel[(int64_t)v * R + 1] = m1;
+                }
+            }
+        } else {
+            if (lane < 16) glds4(ra, rl);   // an idle row keeps the record ring moving
+            if (b >= BD_NSLOT) bd_wait4(dn, b - BD_NSLOT + 1, err, spin_limit);
+        }
+        if (lane == 0) v_s[lw] = v;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) bd_flag_st(lds.rdy + set * BD_WPS + w, b + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#undef BD_TRIP
+#undef BD_CASE
+#undef BD_CASES
+
+// ---- loader wave of an input-gradient cell: the node's dgi row (3 gate blocks of granules) -> the three operand rows
+#define BD_G_LD(g)                                                               \
+    "global_load_dwordx2 %[y" #g "0], %[vo], %[g" #g "] offset:0 sc1\n\t"        \
+    "global_load_dwordx2 %[y" #g "1], %[vo], %[g" #g "] offset:%[o1] sc1\n\t"    \
+    "global_load_dwordx2 %[y" #g "2], %[vo], %[g" #g "] offset:%[o2] sc1\n\t"    \
+    "global_load_dwordx2 %[y" #g "3], %[vo], %[g" #g "] offset:%[o3] sc1\n\t"
+#define BD_DMA_0 "s_waitcnt vmcnt(0)"
+#define BD_DMA_1                                                                                   \
+    "s_mov_b32 %[km], m0\n\ts_mov_b64 %[ke], exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %[rl]\n\t" \
+    "s_nop 0\n\tglobal_load_lds_dword %[ra], off\n\t"                                              \
+    "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]\n\ts_waitcnt vmcnt(1)"
+#define BD_GTRIP(dm)                                                                                                         \
+    asm volatile(BD_G_LD(0) BD_G_LD(1) BD_G_LD(2) BD_DMA_##dm                                                                \
+                 : [y00] "=v"(Y[0][0]), [y01] "=v"(Y[0][1]), [y02] "=v"(Y[0][2]), [y03] "=v"(Y[0][3]),                       \
+                   [y10] "=v"(Y[1][0]), [y11] "=v"(Y[1][1]), [y12] "=v"(Y[1][2]), [y13] "=v"(Y[1][3]),                       \
+                   [y20] "=v"(Y[2][0]), [y21] "=v"(Y[2][1]), [y22] "=v"(Y[2][2]), [y23] "=v"(Y[2][3]),                       \
+                   [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)                                                                \
+                 : [vo] "v"(lane8), [g0] "s"(g0), [g1] "s"(g1), [g2] "s"(g2), [ra] "v"(ra), [rl] "s"(rl),                    \
+                   [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)                                                                  \
+                 : "memory")
+
+template <int KPT>
+__device__ __forceinline__ void bd_loader_du(const BdArgs& S, const BdCell& C, int group, const BdLds& lds, int w, int set) {
+    constexpr int H = 16 * KPT;
+    constexpr int SEG = BdPad<KPT>::seg, KP8 = BdPad<KPT>::kp8;
+    constexpr int NQ4 = H / 64;
+    typedef BdSlot<KPT> Slot;
+    const int lane = threadIdx.x & 63;
+    const int d = C.dir;
+    const int32_t* tab = S.sched + S.gtab[d] + 2 * group;
+    const int rec_base = tab[0], nblk = tab[1];
+    const int32_t* __restrict__ recs = S.brecs + S.brec[d] + 16 * (int64_t)rec_base;
+    const unsigned epoch = S.epoch, spin_limit = S.spin_limit;
+    int* const err = S.err;
+    const int gld = S.gld;
+    const gran_t* const dgi_in = C.dgi_g;
+    int* const dn = lds.dn + set * DF_NCW;
+    int cpos[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = 64 * q + lane;
+        cpos[q] = c + (SEG - KP8) * (c / KP8);
+    }
+    const unsigned lane8 = 8u * lane;
+    constexpr int O1 = (NQ4 > 1 ? 1 : 0) * 512, O2 = (NQ4 > 2 ? 2 : NQ4 - 1) * 512, O3 = (NQ4 - 1) * 512;
+    const int lw = w;
+    int* const rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
+    const unsigned rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
+    const int32_t* const rec_w = recs + 16 * lw + (lane & 15);
+    const int64_t wstride = 16 * DF_RB;
+    auto rec_src = [&](int j) -> const void* { return rec_w + (int64_t)(nblk - 1 - min(j, nblk - 1)) * wstride; };
+    auto rec_dst = [&](int j) -> unsigned { return rec_ring_a + (j & 7) * 64; };
+    auto glds4 = [&](const void* gsrc, unsigned lds_dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    };
+    if (nblk > 0) {
+#pragma unroll
+        for (int j = 0; j < BD_RD; ++j) if (lane < 16) glds4(rec_src(j), rec_dst(j));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    gran_t Y[3][4];
+    for (int b = 0; b < nblk; ++b) {
+        const int j = b;
+        const int v = __builtin_amdgcn_readfirstlane(rec_ring[(j & 7) * 16]);
+        const int slot = b % BD_NSLOT;
+        float* sbase = lds.ring + (set * BD_NSLOT + slot) * Slot::words;
+        int* v_s = reinterpret_cast<int*>(sbase + Slot::v_off);
+        const void* ra = rec_src(j + BD_RD);
+        const unsigned rl = rec_dst(j + BD_RD);
+        if (v >= 0) {
+            const gran_t* g0 = dgi_in + (int64_t)v * (3 * gld);
+            const gran_t* g1 = g0 + gld, * g2 = g0 + 2 * gld;
+            unsigned spins = 0;
+            bool dma = true;
+            for (;;) {
+                unsigned keep_m0;
+                unsigned long long keep_exec;
+                if (dma) BD_GTRIP(1); else BD_GTRIP(0);
+                dma = false;
+                bool ok = true;
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(Y[g][q] >> 32) == epoch;
+                if (__all(ok) || !bd_retry(spins, err, spin_limit)) break;
+            }
+            if (b >= BD_NSLOT) bd_wait4(dn, b - BD_NSLOT + 1, err, spin_limit);
+            float* op = sbase + Slot::op_off + lw * Slot::AP;
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int q = 0; q < NQ4; ++q) op[g * DF_RB * Slot::AP + cpos[q]] = __uint_as_float((unsigned)Y[g][q]);
+        } else {
+            if (lane < 16) glds4(ra, rl);
+            if (b >= BD_NSLOT) bd_wait4(dn, b - BD_NSLOT + 1, err, spin_limit);
+        }
+        if (lane == 0) v_s[lw] = v;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) bd_flag_st(lds.rdy + set * BD_WPS + w, b + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#undef BD_GTRIP
+
+// ---- compute wave `cw`: output units [8 cw, 8 cw + 8) of the slice (lane layout and reduce-scatter of dataflow.hip's
+// df_compute; the A operands are the packed gate-wise transposed matrix, the B operands differ per gate block)
+template <int KPT>
+__device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int sl, int pair, const BdLds& lds, int cw) {
+    constexpr int H = 16 * KPT;
+    constexpr int SEG = BdPad<KPT>::seg, KP8 = BdPad<KPT>::kp8, NK4 = KP8 / 4;
+    typedef BdSlot<KPT> Slot;
+    const int tc = threadIdx.x & 255;
+    const int lane = tc & 63;
+    const int quad = lane >> 5, ks = (lane >> 2) & 7, x = lane & 3;
+    const bool s0 = (ks & 1) != 0, s1 = (ks & 2) != 0;
+    const bool is_da = C.kind == BD_DA;
+    const int d = C.dir;
+    int nb[DF_NLS];
+#pragma unroll
+    for (int q = 0; q < DF_NLS; ++q) {
+        const int grp = bd_stream_group(pair, q, S.groups);
+        nb[q] = grp >= 0 ? S.sched[S.gtab[d] + 2 * grp + 1] : 0;
+    }
+    float wr[KP8], wz[KP8], wn[KP8];
+    {
+        const float4* wp = C.w + (int64_t)sl * (3 * NK4) * 256 + tc;
+#pragma unroll
+        for (int q = 0; q < NK4; ++q) {
+            const float4 x0 = wp[(0 * NK4 + q) * 256], x1 = wp[(1 * NK4 + q) * 256], x2 = wp[(2 * NK4 + q) * 256];
+            wr[4 * q] = x0.x; wr[4 * q + 1] = x0.y; wr[4 * q + 2] = x0.z; wr[4 * q + 3] = x0.w;
+            wz[4 * q] = x1.x; wz[4 * q + 1] = x1.y; wz[4 * q + 2] = x1.z; wz[4 * q + 3] = x1.w;
+            wn[4 * q] = x2.x; wn[4 * q + 1] = x2.y; wn[4 * q + 2] = x2.z; wn[4 * q + 3] = x2.w;
+        }
+#pragma unroll
+        for (int k = 0; k < KP8; ++k) asm volatile("" : "+v"(wr[k]), "+v"(wz[k]), "+v"(wn[k]));
+    }
+    const int unit_l = 8 * cw + 4 * quad + 2 * (ks & 1) + ((ks >> 1) & 1), unit = sl * DF_JS + unit_l;
+    const int gr = x;
+    const unsigned epoch = S.epoch, spin_limit = S.spin_limit;
+    int* const err = S.err;
+    gran_t* const out_g = C.out_g;
+    const int gld = S.gld, num_nodes = S.N;
+
+    int done[DF_NLS];
+    int left = 0, pref = 0;
+#pragma unroll
+    for (int q = 0; q < DF_NLS; ++q) { done[q] = 0; left += nb[q]; }
+    while (left > 0) {
+        int st = -1;
+        unsigned spins = 0;
+        for (;;) {
+            int best = 0x7fffffff;
+#pragma unroll
+            for (int e = 0; e < DF_NLS; ++e) {
+                int r = bd_flag_ld(lds.rdy + e * BD_WPS);
+#pragma unroll
+                for (int x2 = 1; x2 < BD_WPS; ++x2) r = min(r, bd_flag_ld(lds.rdy + e * BD_WPS + x2));
+                const int lead = done[e] < nb[e] ? r - done[e] : 0;
+                const int key = lead * DF_NLS + ((e - pref + DF_NLS) % DF_NLS);
+                if (lead > 0 && key < best) { best = key; st = e; }
+            }
+            if (st >= 0) break;
+            __builtin_amdgcn_s_sleep(1);
+            bool give_up = false;
+            if (++spins > 4 * spin_limit) {
+                __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                give_up = true;
+            }
+            if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = true;
+            if (give_up) {
+#pragma unroll
+                for (int e = DF_NLS - 1; e >= 0; --e) if (done[e] < nb[e]) st = e;
+                break;
+            }
+        }
+        st = __builtin_amdgcn_readfirstlane(st);
+        pref = (st + 1) % DF_NLS;
+        int b = 0;
+#pragma unroll
+        for (int e = 0; e < DF_NLS; ++e) if (e == st) { b = done[e]; ++done[e]; }
+        --left;
+        const int slot = b % BD_NSLOT;
+        const float* sbase = lds.ring + (st * BD_NSLOT + slot) * Slot::words;
+        const int4 ids = *reinterpret_cast<const int4*>(sbase + Slot::v_off);
+        const int nr = (ids.x >= 0) + (ids.y >= 0) + (ids.z >= 0) + (ids.w >= 0);   // live records come first
+        const float* a_seg = sbase + Slot::op_off + x * Slot::AP + ks * SEG;   // gate block 0, row x, K slice ks
+        float zgv = 0.f;
+        if (is_da && gr < nr) zgv = sbase[Slot::zg_off + gr * DF_JS + unit_l];
+        float gsum;
+        {
+            bf4 acc[3] = {(bf4){0.f, 0.f, 0.f, 0.f}, (bf4){0.f, 0.f, 0.f, 0.f}, (bf4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int q = 0; q < NK4; ++q) {
+                const float4 b0 = *reinterpret_cast<const float4*>(a_seg + 4 * q);
+                const float4 b1 = *reinterpret_cast<const float4*>(a_seg + DF_RB * Slot::AP + 4 * q);
+                const float4 b2 = *reinterpret_cast<const float4*>(a_seg + 2 * DF_RB * Slot::AP + 4 * q);
+                const float q0[4] = {b0.x, b0.y, b0.z, b0.w}, q1[4] = {b1.x, b1.y, b1.z, b1.w}, q2[4] = {b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q + e], q0[e], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wz[4 * q + e], q1[e], acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(wn[4 * q + e], q2[e], acc[2], 0, 0, 0);
+                }
+            }
+            const bf4 t = acc[0] + acc[1] + acc[2];   // the three gate blocks of K: one reduce-scatter for their sum
+            const float u0 = t[0] + bd_dpp<0x104>(t[0]), u1 = t[1] + bd_dpp<0x104>(t[1]);
+            const float u2 = t[2] + bd_dpp<0x114>(t[2]), u3 = t[3] + bd_dpp<0x114>(t[3]);
+            const float e0 = s0 ? u2 : u0, e1 = s0 ? u3 : u1;
+            const float f0 = e0 + bd_dpp<0x108>(e0), f1 = e1 + bd_dpp<0x118>(e1);
+            const float f = s1 ? f1 : f0;
+            gsum = bd_row_pair_sum(f);
+        }
+        int gv = gr == 0 ? ids.x : (gr == 1 ? ids.y : (gr == 2 ? ids.z : ids.w));
+        const bool live = gr < nr && (unsigned)gv < (unsigned)num_nodes && (lane & 16) == 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) bd_flag_st(lds.dn + st * DF_NCW + cw, b + 1);
+        if (live)
+            __hip_atomic_store(out_g + (int64_t)gv * gld + unit, gran_pack(epoch, gsum + zgv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int KPT>
+__global__ void __launch_bounds__(BD_THREADS, 3) bwd_dataflow_kernel(const int32_t* __restrict__ plan, BdArgs S) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef BdSlot<KPT> Slot;
+    constexpr int NS = 16 * KPT / DF_JS;
+    const int tid = threadIdx.x;
+    if (S.status && S.status[0] != 0) {
+        if (tid == 0) __hip_atomic_fetch_or(S.err, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (S.sched[0] != S.groups || S.sched[1] != DF_MAGIC || S.sched[2] != DF_RB) {
+        if (tid == 0) __hip_atomic_fetch_or(S.err, 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int per_pair = S.ncell * NS;
+    const int pair = blockIdx.x / per_pair;
+    const int rem = blockIdx.x - pair * per_pair;
+    const int c = rem / NS, sl = rem - c * NS;
+    const BdCell& C = S.cell[c];
+    BdLds lds;
+    lds.ring = smem;
+    lds.rec = reinterpret_cast<int*>(lds.ring + DF_NLS * BD_NSLOT * Slot::words);
+    int* flags = lds.rec + DF_NLS * DF_RB * 8 * 16;
+    lds.rdy = flags;
+    lds.dn = flags + BD_NLW;
+    if (tid < BD_NLW + DF_NLS * DF_NCW) flags[tid] = 0;
+    __syncthreads();
+    if (wave < DF_NCW) {
+        bd_compute<KPT>(S, C, sl, pair, lds, wave);
+    } else {
+        const int set = (wave - DF_NCW) / BD_WPS, w = (wave - DF_NCW) % BD_WPS;
+        const int grp = bd_stream_group(pair, set, S.groups);
+        if (grp >= 0) {
+            if (C.kind == BD_DU) bd_loader_du<KPT>(S, C, grp, lds, w, set);
+            else if (C.du_in) bd_loader_da<KPT, true>(plan, S, C, sl, grp, lds, w, set);
+            else bd_loader_da<KPT, false>(plan, S, C, sl, grp, lds, w, set);
+        }
+    }
+}
+
+template <int KPT> size_t bd_lds_bytes() {
+    return (size_t)(DF_NLS * (BD_NSLOT * BdSlot<KPT>::words + DF_RB * 8 * 16) + BD_NLW + DF_NLS * DF_NCW) * 4 + 256;
+}
+
+// gate-wise transpose: out[g H + j][u] = W[g H + u][j] (the A operands of the reverse products are the columns of W)
+__global__ void __launch_bounds__(256) bd_transpose_kernel(const float* __restrict__ W, float* __restrict__ out, int H) {
+    __shared__ float tile[32][33];
+    const int g = blockIdx.z, bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (by + r < H && bx + tx < H) tile[r][tx] = W[(int64_t)(g * H + by + r) * H + bx + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (bx + r < H && by + tx < H) out[(int64_t)(g * H + bx + r) * H + by + tx] = tile[tx][r];
+}
+
+}  // namespace
+
+extern "C" size_t dagnn_bwd_dataflow_record_bytes(int64_t N) {
+    if (N < 0) return 0;
+    return (size_t)2 * 16 * (4 * N + 4) * sizeof(int32_t);
+}
+
+extern "C" size_t dagnn_bwd_dataflow_static_bytes(int64_t N) {
+    if (N < 0) return 0;
+    return (size_t)N * BD_NSTAT * BD_SP * sizeof(float);
+}
+
+extern "C" int dagnn_gatewise_transpose(const float* w, float* out, int H, void* stream) {
+    if (!w || !out || H <= 0) return DAGNN_EINVAL;
+    hipLaunchKernelGGL(bd_transpose_kernel, dim3((H + 31) / 32, (H + 31) / 32, 3), dim3(256), 0, (hipStream_t)stream, w, out, H);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
+extern "C" int dagnn_bwd_dataflow_prepare(const dagnn_plan* pl, const dagnn_bwd_dataflow_args* a, void* stream) {
+    if (!pl || !pl->data || !a || !a->schedule || !a->records) return DAGNN_EINVAL;
+    const int H = a->H, Ls = a->num_stacked, dir_mask = a->dir_mask & 3, G = a->groups;
+    if (H <= 0 || (H % 64) || H > 256 || Ls <= 0 || Ls > DAGNN_MAX_STACKED || !dir_mask || G < 1 || G > DF_MAX_GROUPS ||
+        a->ld_h < H || a->ld_g < H)
+        return DAGNN_EINVAL;
+    if (pl->B == 0 || pl->N == 0) return DAGNN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
+    const DfLayout SL = df_layout_words(pl->N, pl->B, G);
+    const int64_t nrec = 4 * pl->N + 4;
+    hipLaunchKernelGGL(bd_records_kernel, dim3((unsigned)((nrec + 255) / 256), 2), dim3(256), 0, st, (const int32_t*)pl->data, L,
+                       (const int32_t*)a->schedule, SL, (int32_t*)a->records, nrec, (const int32_t*)a->plan_status);
+    DAGNN_CHECK_LAUNCH();
+    BdStatArgs A;
+    A.ncell = 0; A.H = H; A.ld_h = a->ld_h; A.ld_g = a->ld_g;
+    for (int d = 0; d < 2; ++d) {
+        if (!((dir_mask >> d) & 1)) continue;
+        for (int i = 0; i < Ls; ++i) {
+            const dagnn_bwd_dataflow_cell& c = a->cell[d][i];
+            if (!c.gi || !c.gh || !c.a || !c.b_hh || !c.h || !c.g_ext || !c.stat) return DAGNN_EINVAL;
+            BdStatCell& K = A.cell[A.ncell++];
+            K.gi = c.gi; K.gh = c.gh; K.a = c.a; K.b_hh = c.b_hh; K.h = c.h; K.gext = c.g_ext; K.stat = c.stat;
+        }
+    }
+    hipLaunchKernelGGL(bd_stat_kernel, dim3((unsigned)((pl->N + 3) / 4), (unsigned)A.ncell), dim3(256), 0, st, A, pl->N);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
+extern "C" int dagnn_bwd_dataflow_run(const dagnn_plan* pl, const dagnn_bwd_dataflow_args* a, void* stream) {
+    if (!pl || !pl->data || !a || !a->schedule || !a->records) return DAGNN_EINVAL;
+    const int H = a->H, Ls = a->num_stacked, dir_mask = a->dir_mask & 3, G = a->groups;
+    if (H <= 0 || (H % 64) || H > 256 || Ls <= 0 || Ls > DAGNN_MAX_STACKED || !dir_mask || a->gld < H || G < 1 ||
+        G > DF_MAX_GROUPS || a->epoch == 0 || !a->err)
+        return DAGNN_EINVAL;
+    if (pl->B == 0 || pl->N == 0) return DAGNN_OK;
+    BdArgs S;
+    BdCell* cells = S.cell;
+    int nc = 0;
+    for (int d = 0; d < 2; ++d) {
+        if (!((dir_mask >> d) & 1)) continue;
+        for (int i = Ls - 1; i >= 0; --i) {   // the top stacked layer leads
+            const dagnn_bwd_dataflow_cell& c = a->cell[d][i];
+            if (!c.w_hh_t || !c.w_key || !c.alpha || !c.stat || !c.da_granules || !c.q_granules || !c.dgi || !c.dgh || !c.sigma ||
+                (pl->num_edge_feats > 0 && !c.edge_feat_grad) || (i > 0 && (!c.w_ih_t || !c.dgi_granules)) ||
+                (i + 1 < Ls && !c.du_granules))
+                return DAGNN_EINVAL;
+            if (nc + (i > 0 ? 2 : 1) > BD_MAX_KCELLS) return DAGNN_EINVAL;
+            BdCell K = {};
+            K.w = (const float4*)c.w_hh_t; K.wkey = c.w_key; K.alpha = c.alpha; K.stat = c.stat;
+            K.du_in = i + 1 < Ls ? (const gran_t*)c.du_granules : nullptr;
+            K.out_g = (gran_t*)c.da_granules; K.q_g = (gran_t*)c.q_granules;
+            K.dgi_g = i > 0 ? (gran_t*)c.dgi_granules : nullptr;
+            K.dgi = c.dgi; K.dgh = c.dgh; K.sig = c.sigma; K.mrel = pl->num_edge_feats > 0 ? c.edge_feat_grad : nullptr;
+            K.dir = d; K.kind = BD_DA;
+            cells[nc++] = K;
+            if (i > 0) {
+                BdCell U = {};
+                U.w = (const float4*)c.w_ih_t;
+                U.dgi_g = (gran_t*)c.dgi_granules;
+                U.out_g = (gran_t*)a->cell[d][i - 1].du_granules;
+                U.dir = d; U.kind = BD_DU;
+                cells[nc++] = U;
+            }
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int NS = H / DF_JS;
+    const int sets = (G + DF_NLS - 1) / DF_NLS;
+    S.sched = (const int32_t*)a->schedule;
+    S.brecs = (const int32_t*)a->records;
+    const DfLayout SL = df_layout_words(pl->N, pl->B, G);
+    PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
+    const int64_t nrec = 4 * pl->N + 4;
+    for (int d = 0; d < 2; ++d) {
+        S.gtab[d] = SL.gtab[d]; S.brec[d] = (int64_t)d * 16 * nrec;
+        S.col[d] = L.col[d]; S.eidx[d] = L.eidx[d]; S.eattr[d] = L.eattr[d];
+    }
+    S.ncell = nc; S.H = H; S.gld = a->gld; S.R = pl->num_edge_feats; S.groups = G; S.N = (int)pl->N;
+    S.epoch = a->epoch; S.spin_limit = a->spin_limit ? a->spin_limit : (1u << 22);
+    S.status = (const int32_t*)a->plan_status;
+    S.err = (int*)a->err;
+    const unsigned grid = (unsigned)(sets * nc * NS);
+    const int32_t* plan = (const int32_t*)pl->data;
+#define BD_LAUNCH(KPT)                                                                                                   \
+    do {                                                                                                                 \
+        const void* fn = reinterpret_cast<const void*>(bwd_dataflow_kernel<KPT>);                                        \
+        const hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bd_lds_bytes<KPT>()); \
+        if (ea != hipSuccess) return DAGNN_EHIP(ea);                                                                     \
+        hipLaunchKernelGGL((bwd_dataflow_kernel<KPT>), dim3(grid), dim3(BD_THREADS), bd_lds_bytes<KPT>(), st, plan, S);  \
+    } while (0)
+    switch (H / 16) {
+        case 4: BD_LAUNCH(4); break;
+        case 8: BD_LAUNCH(8); break;
+        case 12: BD_LAUNCH(12); break;
+        default: BD_LAUNCH(16); break;
+    }
+#undef BD_LAUNCH
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}

@@ -23,11 +23,11 @@ struct DagnnForkJoin {
         if (e == hipSuccess) joined = false;
         return e;
     }
-    void mark() { if (join && !joined) { hipEventRecord(join, side); marked = true; } }   // the side stream's work up to here is what main joins
+    void mark() { if (join && !joined) { (void)hipEventRecord(join, side); marked = true; } }   // the side stream's work up to here is what main joins
     ~DagnnForkJoin() {
         if (!joined && join) {
-            if (!marked) hipEventRecord(join, side);
-            hipStreamWaitEvent(main, join, 0);
+            if (!marked) (void)hipEventRecord(join, side);
+            (void)hipStreamWaitEvent(main, join, 0);
         }
     }
 };

@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import BackwardArgs, DagnnHipError, DataflowArgs, FrontierArgs, GemmGroup, LayerArgs, Plan, check
+from ._lib import BackwardArgs, BwdDataflowArgs, DagnnHipError, DataflowArgs, FrontierArgs, GemmGroup, LayerArgs, Plan, check
 
 
 class KernelTimer(object):
@@ -85,6 +85,7 @@ DATAFLOW = _env_int("DAGNN_AMD_DATAFLOW", 1)                # 1: the persistent 
 DF_COST_LAYER = _env_int("DAGNN_AMD_DF_COST_LAYER", 4)      # schedule cost of one dependent layer, in rows (hop latency / row cost)
 DF_COST_ROW = _env_int("DAGNN_AMD_DF_COST_ROW", 1)
 DF_GROUPS = _env_int("DAGNN_AMD_DF_GROUPS", 0)              # 0 = as many groups as the device hosts
+BWD_DATAFLOW = _env_int("DAGNN_AMD_BWD_DATAFLOW", 1)        # 1: the reverse sweep as one persistent dataflow launch (H <= 256)
 SPIN_LIMIT = _env_int("DAGNN_AMD_SPIN_LIMIT", 0)            # polls before a device-side wait gives up; 0 = library default
 DEBUG_TIMING: Optional[torch.Tensor] = None  # int64[8] device tensor: phase ticks of the deepest work item
 _NOSPAN = _NoSpan()
@@ -748,6 +749,115 @@ def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells,
               "dagnn_backward_run")
     if use_tail:
         arena.watch()
+    return out
+
+
+def pack_dataflow_transposed(w: torch.Tensor, H: int) -> torch.Tensor:
+    """[3H, H] (torch layout) -> the dataflow kernel's slice / lane order of the GATE-WISE TRANSPOSED matrix
+    (out[g H + j][u] = W[g H + u][j]): the A operands of the reverse products W^T dg."""
+    w = _dev(w, "weight", torch.float32)
+    if tuple(w.shape) != (3 * H, H):
+        raise DagnnHipError("pack_dataflow_transposed needs a [3H, H] matrix, got %s" % (tuple(w.shape),))
+    t = torch.empty_like(w)
+    check(_lib.load().dagnn_gatewise_transpose(w.data_ptr(), t.data_ptr(), H, _stream(w)), "dagnn_gatewise_transpose")
+    return pack_dataflow(t, H)
+
+
+def bwd_dataflow_groups(device, num_dirs: int, num_stacked: int, H: int, B: int) -> int:
+    """Groups the reverse dataflow launch runs with (same cell count and workgroup shape as the forward kernel, so the
+    forward pass's schedule workspace serves both); 0 = not applicable."""
+    if not BWD_DATAFLOW:
+        return 0
+    return dataflow_groups(device, num_dirs, num_stacked, H, B)
+
+
+def bwd_dataflow_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, h, gi0, g_ext, groups: int,
+                       arena: "GranuleArena", vid_mod: int = 0, static_score=None):
+    """Reverse pass of the recurrence as ONE persistent dataflow launch (csrc/bwd_dataflow.hip).  Same operands and
+    the same result dictionary as `backward_sweep`; `groups` must be the group count of the forward pass's schedule."""
+    dev = plan.ws.device
+    N, E, R = plan.N, plan.E, plan.R
+    lib = _lib.load()
+    f32 = dict(dtype=torch.float32, device=dev)
+    arena.poll()
+    out, keep = {}, []
+    pargs = BackwardArgs()
+    mask = 0
+    for d in dirs:
+        mask |= 1 << d
+        for i in range(L):
+            c, bc = cells[(d, i)], pargs.cell[d][i]
+            o = dict(a=torch.empty(N, H, **f32), alpha=torch.empty(max(E, 1), **f32),
+                     dgi=torch.empty(N, 3 * H, **f32), dgh=torch.empty(N, 3 * H, **f32), sigma=torch.empty(N, **f32),
+                     edge_feat_grad=torch.empty(N, R, **f32) if R > 0 else None)
+            out[(d, i)] = o
+            if static_score is not None:
+                zero_key = torch.zeros(H, **f32)
+                keep.append(zero_key)
+                bc.w_key, bc.static_score = zero_key.data_ptr(), _dev(static_score[(d, i)], "static score", torch.float32).data_ptr()
+                o["_wkey"] = zero_key
+            else:
+                bc.w_key = c.w_key.data_ptr()
+                o["_wkey"] = c.w_key
+            bc.edge_gain = _ptr(c.edge_gain) if R > 0 else None
+            bc.vid_bias = _ptr(c.vid_bias) if vid_mod > 0 else None
+            bc.h, bc.a, bc.alpha = h[d][i].data_ptr(), o["a"].data_ptr(), o["alpha"].data_ptr()
+    pargs.num_stacked, pargs.dir_mask, pargs.H, pargs.ld_h = L, mask, H, h[dirs[0]][0].shape[1]
+    pargs.vid_mod = int(vid_mod)
+    with _span("backward_prepare", plan.ws):
+        check(lib.dagnn_backward_prepare(C.byref(plan.desc), C.byref(pargs), _stream(plan.ws)), "dagnn_backward_prepare")
+        keys = [(d, i) for d in dirs for i in range(L)]
+        gh = {}
+        for k0 in range(0, len(keys), 4):
+            grp = keys[k0:k0 + 4]
+            res = gemm_nt_bias([out[k]["a"] for k in grp], [cells[k].w_hh_raw for k in grp], [cells[k].b_hh for k in grp])
+            gh.update(dict(zip(grp, res)))
+        gi = {(d, 0): gi0[d] for d in dirs}
+        up = [(d, i) for d in dirs for i in range(1, L)]
+        for k0 in range(0, len(up), 4):
+            grp = up[k0:k0 + 4]
+            res = gemm_nt_bias([h[d][i - 1][:, :H] for d, i in grp], [cells[k].w_ih for k in grp],
+                               [cells[k].b_ih for k in grp])
+            gi.update(dict(zip(grp, res)))
+        gkeys = [("da", d, i) for d in dirs for i in range(L)] + [("q", d, i) for d in dirs for i in range(L)] + \
+                [("dgi", d, i) for d in dirs for i in range(1, L)] + [("du", d, i) for d in dirs for i in range(L - 1)]
+        widths = {k: (1 if k[0] == "q" else 3 * H) for k in gkeys if k[0] in ("q", "dgi")}
+        gran, epoch, err = arena.get(gkeys, N, H, dev, widths=widths)
+        args = BwdDataflowArgs()
+        stat_bytes = lib.dagnn_bwd_dataflow_static_bytes(N)
+        for k in keys:
+            d, i = k
+            c, bc, o = cells[k], args.cell[d][i], out[k]
+            o["gi"], o["gh"] = gi[k], gh[k]
+            if getattr(c, "w_hh_bt", None) is None:
+                c.w_hh_bt = pack_dataflow_transposed(c.w_hh_raw, H)
+                c.w_ih_bt = pack_dataflow_transposed(c.w_ih, H) if i > 0 else None
+            stat = torch.empty(stat_bytes // 4, **f32)
+            keep.append(stat)
+            bc.w_hh_t, bc.w_ih_t = c.w_hh_bt.data_ptr(), _ptr(c.w_ih_bt)
+            bc.w_key, bc.alpha = o["_wkey"].data_ptr(), o["alpha"].data_ptr()
+            bc.gi, bc.gh, bc.a, bc.b_hh = gi[k].data_ptr(), gh[k].data_ptr(), o["a"].data_ptr(), c.b_hh.data_ptr()
+            bc.h, bc.g_ext, bc.stat = h[d][i].data_ptr(), g_ext[d][i].data_ptr(), stat.data_ptr()
+            bc.da_granules, bc.q_granules = gran[("da", d, i)].data_ptr(), gran[("q", d, i)].data_ptr()
+            bc.dgi_granules = gran[("dgi", d, i)].data_ptr() if i > 0 else None
+            bc.du_granules = gran[("du", d, i)].data_ptr() if i + 1 < L else None
+            bc.dgi, bc.dgh, bc.sigma = o["dgi"].data_ptr(), o["dgh"].data_ptr(), o["sigma"].data_ptr()
+            bc.edge_feat_grad = _ptr(o["edge_feat_grad"])
+        args.num_stacked, args.dir_mask, args.H = L, mask, H
+        args.ld_h, args.ld_g, args.gld, args.groups = h[dirs[0]][0].shape[1], g_ext[dirs[0]][0].shape[1], H, int(groups)
+        args.epoch, args.spin_limit = epoch, SPIN_LIMIT
+        sched = plan.dataflow_schedule(groups)
+        recs = torch.empty(lib.dagnn_bwd_dataflow_record_bytes(N) // 4, dtype=torch.int32, device=dev)
+        keep.append(recs)
+        args.schedule, args.records, args.err = sched.data_ptr(), recs.data_ptr(), err.data_ptr()
+        args.plan_status = plan.status.data_ptr()
+        check(lib.dagnn_bwd_dataflow_prepare(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_bwd_dataflow_prepare")
+    with _span("backward_run", plan.ws):
+        check(lib.dagnn_bwd_dataflow_run(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_bwd_dataflow_run")
+    arena.watch(plan)
+    for o in out.values():
+        o.pop("_wkey", None)
+    out["_keep"] = keep   # buffers the launch reads: alive until the caller drops the result
     return out
 
 

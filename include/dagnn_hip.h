@@ -414,6 +414,56 @@ int dagnn_backward_prepare(const dagnn_plan* plan /* host */, const dagnn_backwa
 int dagnn_backward_run(const dagnn_plan* plan /* host */, const dagnn_backward_args* args /* host */,
                        const int32_t* const* layer_ptr /* host */, const int32_t* num_layers /* host */, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The same reverse sweep as ONE persistent dataflow launch (csrc/bwd_dataflow.hip; H <= 256): the mirror image of
+ * dagnn_dataflow_run on the same schedule workspace, replacing dagnn_backward_run's T + L - 1 launches.
+ *   1. dagnn_backward_prepare (a, alpha) and the two pre-activation GEMMs (gi, gh) as before;
+ *   2. dagnn_bwd_dataflow_prepare: successor records in schedule order (`records`, dagnn_bwd_dataflow_record_bytes) and the
+ *      per-(cell, node) static rows `stat` (dagnn_bwd_dataflow_static_bytes each): Gext, h and the GRU-backward
+ *      coefficients - the gate algebra is linear in the incoming gradient, so it leaves the dependent chain;
+ *   3. dagnn_bwd_dataflow_run: the launch.  Hand-off buffers (uint64 granules {epoch, fp32 bits}, zero-initialised once,
+ *      strictly increasing epochs): da [N,gld], q [N], dgi [N,3 gld] (stacked layers > 0), du [N,gld] (stacked layers
+ *      below the top: the du arriving at THIS cell's rows).  Outputs for the weight-gradient epilogue: dgi, dgh [N,3H],
+ *      sigma [N], edge_feat_grad [N,R].  `err` as for dagnn_dataflow_run.
+ * Weights: dagnn_pack_dataflow(dagnn_gatewise_transpose(W)): out[g H + j][u] = W[g H + u][j]. */
+typedef struct dagnn_bwd_dataflow_cell {
+    const float* w_hh_t;    /* packed gate-wise transposed W_hh */
+    const float* w_ih_t;    /* ... W_ih (stacked layers > 0), else NULL */
+    const float* w_key;     /* [H] (zeros when the scores are static) */
+    const float* alpha;     /* [E] (dagnn_backward_prepare) */
+    const float* gi;        /* prepare: [N,3H] */
+    const float* gh;        /* prepare: [N,3H] */
+    const float* a;         /* prepare: [N,H] */
+    const float* b_hh;      /* prepare: [3H] */
+    const float* h;         /* prepare: [N,ld_h] forward states */
+    const float* g_ext;     /* prepare: [N,ld_g] gradient reaching h from outside the recurrence */
+    float* stat;            /* [N, 8 * 256] static rows: written by prepare, read by run */
+    void* da_granules;      /* uint64 [N,gld] */
+    void* q_granules;       /* uint64 [N] */
+    void* dgi_granules;     /* uint64 [N,3 gld] (stacked layers > 0) */
+    void* du_granules;      /* uint64 [N,gld] (stacked layers below the top) */
+    float* dgi;             /* out [N,3H] */
+    float* dgh;             /* out [N,3H] */
+    float* sigma;           /* out [N] */
+    float* edge_feat_grad;  /* out [N,R] or NULL */
+} dagnn_bwd_dataflow_cell;
+
+typedef struct dagnn_bwd_dataflow_args {
+    dagnn_bwd_dataflow_cell cell[DAGNN_MAX_DIRS][DAGNN_MAX_STACKED];
+    int num_stacked, dir_mask, H, ld_h, ld_g, gld, groups;
+    unsigned epoch, spin_limit;
+    const void* schedule;     /* dagnn_dataflow_schedule workspace for `groups` groups */
+    void* records;            /* dagnn_bwd_dataflow_record_bytes(N) */
+    void* err;                /* device int32 */
+    const void* plan_status;  /* or NULL */
+} dagnn_bwd_dataflow_args;
+
+size_t dagnn_bwd_dataflow_record_bytes(int64_t N);
+size_t dagnn_bwd_dataflow_static_bytes(int64_t N);
+int dagnn_gatewise_transpose(const float* w /* [3H,H] */, float* out /* [3H,H] */, int H, void* stream);
+int dagnn_bwd_dataflow_prepare(const dagnn_plan* plan /* host */, const dagnn_bwd_dataflow_args* args /* host */, void* stream);
+int dagnn_bwd_dataflow_run(const dagnn_plan* plan /* host */, const dagnn_bwd_dataflow_args* args /* host */, void* stream);
+
 /* grad_h[v, j] += grad_out[g, col_off + j] for the first output node v of graph g attaining the maximum
  * of column j (the single winner of scatter-max); grad_h must be initialised by the caller. */
 int dagnn_readout_max_backward(const dagnn_plan* plan /* host */, const float* h, int ld_h, int width, int dir,

@@ -71,7 +71,7 @@ class FrontierArgs(C.Structure):
 
 class DataflowCell(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("w_hh", "w_ih", "b_hh", "b_ih", "w_key", "static_score", "edge_gain",
-                                          "vid_bias", "gi0", "h_out", "granules", "proj_granules")]
+                                          "vid_bias", "gi0", "h_out", "granules", "proj_granules", "gh_out", "gi_out")]
 
 
 class DataflowArgs(C.Structure):
@@ -93,6 +93,15 @@ class BackwardArgs(C.Structure):
                 ("tail_replicas", C.c_int), ("tail_max_blocks", C.c_int), ("epoch", C.c_uint), ("tail_err", C.c_void_p),
                 ("side_stream", C.c_void_p), ("layer_split", C.POINTER(C.c_int32) * MAX_DIRS),
                 ("fork_event", C.c_void_p), ("join_event", C.c_void_p)]
+
+
+class WgradJob(C.Structure):
+    _fields_ = [("dg", C.c_void_p), ("inp", C.c_void_p), ("d_weight", C.c_void_p), ("d_bias", C.c_void_p),
+                ("ld_dg", C.c_int), ("ld_in", C.c_int), ("in_dim", C.c_int)]
+
+
+class ColsumJob(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("weight", C.c_void_p), ("out", C.c_void_p), ("ld_x", C.c_int), ("cols", C.c_int)]
 
 
 class BwdDataflowCell(C.Structure):
@@ -180,6 +189,12 @@ SYMBOLS = {
     "dagnn_gatewise_transpose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_bwd_dataflow_prepare": (C.c_int, [C.POINTER(Plan), C.POINTER(BwdDataflowArgs), C.c_void_p]),
     "dagnn_bwd_dataflow_run": (C.c_int, [C.POINTER(Plan), C.POINTER(BwdDataflowArgs), C.c_void_p]),
+    "dagnn_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "dagnn_colsum_run": (C.c_int, [C.POINTER(ColsumJob), C.c_int, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dagnn_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dagnn_wgrad_splits": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64]),
+    "dagnn_wgrad_run": (C.c_int, [C.POINTER(WgradJob), C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_size_t, C.c_void_p]),
     "dagnn_readout_max_backward": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                              C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_topo_layers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,

@@ -109,7 +109,7 @@ class Recurrence(torch.autograd.Function):
         if groups > 0 and engine.bwd_dataflow_groups(dev, len(dirs), L, Hp, plan.B) == groups:
             res = engine.bwd_dataflow_sweep(plan, dirs, L, Hp, cells, keep["h_buf"], keep["gi0"], g_ext, groups,
                                             arena=mod._arena_for(x, "backward"), vid_mod=mod._vid_nodes,
-                                            static_score=ctx.sscore)
+                                            static_score=ctx.sscore, preact=keep.get("preact"))
         else:
             res = engine.backward_sweep(plan, dirs, L, Hp, cells, keep["h_buf"], keep["gi0"], g_ext,
                                         arena=mod._arena_for(x, "backward"), vid_mod=mod._vid_nodes,
@@ -121,17 +121,39 @@ class Recurrence(torch.autograd.Function):
         def gates(t):  # [N, 3Hp] in gate blocks of Hp -> [N, 3H]
             return t if Hp == H else t.view(N, 3, Hp)[:, :, :H].reshape(N, 3 * H)
 
+        # weight / bias gradients of every cell: ONE batch of split transposed products in HIP (csrc/wgrad.hip)
+        jobs = []
+        for d in dirs:
+            for i in range(L):
+                r = res[(d, i)]
+                jobs.append((r["dgi"], x if i == 0 else h[d][i - 1], True))
+                jobs.append((r["dgh"], r["a"][:, :H], True))
+        wg = engine.wgrad(jobs, N, Hp, H) if N > 0 else None
+        # the small reductions of the attention / edge-encoder gradients, all cells in one batch (csrc/wgrad.hip):
+        # sum_v sigma_v keys_v, sum_v (edge-feature sums)_v, sum_v sigma_v
+        cs_jobs, cs_at = [], {}
+        if N > 0:
+            for d in dirs:
+                for i in range(L):
+                    r = res[(d, i)]
+                    keys = x if ctx.sscore is not None else h[d][i]
+                    cs_at[(d, i)] = len(cs_jobs)
+                    cs_jobs.append((keys, r["sigma"]))
+                    if r["edge_feat_grad"] is not None:
+                        cs_jobs += [(r["edge_feat_grad"], None), (r["sigma"], None)]
+        cs = engine.colsums(cs_jobs, N) if cs_jobs else None
         grads = []
         k = 0
         for d in dirs:
             for i in range(L):
                 w_ih, w_hh, b_ih, b_hh, attn_w, attn_b, edge_w, edge_b = params[k:k + Recurrence.PER_CELL]
-                k += Recurrence.PER_CELL
                 r = res[(d, i)]
-                dgi, dgh = gates(r["dgi"]), gates(r["dgh"])
-                u = x if i == 0 else h[d][i - 1]
-                g_wih, g_bih = _wgrad(dgi, u), dgi.sum(0)
-                g_whh, g_bhh = _wgrad(dgh, r["a"][:, :H]), dgh.sum(0)
+                dgi = gates(r["dgi"])
+                if wg is not None:
+                    (g_wih, g_bih), (g_whh, g_bhh) = wg[2 * (k // Recurrence.PER_CELL)], wg[2 * (k // Recurrence.PER_CELL) + 1]
+                else:
+                    g_wih, g_bih, g_whh, g_bhh = (torch.zeros_like(t) for t in (w_ih, b_ih, w_hh, b_hh))
+                k += Recurrence.PER_CELL
                 if i == 0 and x.requires_grad:
                     dx = dx + dgi @ w_ih
                 # attention logit s_e = w_key . (h_p + W_e feat_e + b_e) [+ w_vid[p mod n]] (+ query and bias terms
@@ -140,12 +162,15 @@ class Recurrence(torch.autograd.Function):
                 sigma = r["sigma"]
                 kd = attn_w.shape[1] - dq - mod._vid_nodes     # key width: H, or the input width for the `*_x` aggregators
                 keys = x if ctx.sscore is not None else h[d][i]
-                g_key = (keys * sigma[:, None]).sum(0)
+                g_key = cs[cs_at[(d, i)]] if cs is not None else torch.zeros(kd, dtype=torch.float32, device=dev)
                 if ctx.sscore is not None and x.requires_grad:   # the score of node v is w_key . x_v
                     dx = dx + sigma[:, None] * attn_w[0, dq:dq + kd][None, :]
                 g_edge_w = g_edge_b = None
                 if edge_w is not None:
-                    m, ssum = r["edge_feat_grad"].sum(0), sigma.sum()
+                    if cs is not None:
+                        m, ssum = cs[cs_at[(d, i)] + 1], cs[cs_at[(d, i)] + 2][0]
+                    else:
+                        m, ssum = r["edge_feat_grad"].sum(0), sigma.sum()
                     w_key = attn_w[0, dq:dq + kd]
                     g_key = g_key + edge_w @ m + edge_b * ssum
                     g_edge_w, g_edge_b = torch.outer(w_key, m), w_key * ssum

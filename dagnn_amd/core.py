@@ -179,8 +179,11 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
         arena.poll()   # a failure an earlier pass reported (no synchronisation); either path below is watched
     if groups > 0:
         pack_dataflow(cells.values())
+        preact = {} if (keep is not None and engine.BWD_DATAFLOW) else None
         engine.dataflow_run(plan, dirs, L, Hp, cells, gi, h, groups, vid_mod=vid_nodes, arena=arena,
-                            static_score=static_score, score_parts=keep is not None)
+                            static_score=static_score, score_parts=keep is not None, preact=preact)
+        if keep is not None:
+            keep["preact"] = preact
     else:
         pack_lockstep(cells.values(), force=True)
         engine.frontier_run(plan, dirs, L, Hp, cells, gi, h, vid_mod=vid_nodes, arena=arena, static_score=static_score)

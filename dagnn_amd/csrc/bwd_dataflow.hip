@@ -95,6 +95,7 @@ struct BdLds {
     int* rec;      // [NLS * RB][8][16] row records, landed by LDS-DMA BD_RD blocks ahead
     int* rdy;      // [NLS][WPS]
     int* dn;       // [NLS][NCW]
+    int* dump;     // [NLS * RB][64] landing area of the L2 warm-up DMAs (never read)
 };
 
 __device__ __forceinline__ int bd_flag_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -231,7 +232,6 @@ struct BdSweep {
     gran_t x[4][4];   // da rows of up to four successors: columns {lane, 64 + lane, 128 + lane, 192 + lane}
     gran_t q[4];      // their q scalars (every lane loads the same granule)
     gran_t u[4];      // the node's du row
-    bf4 st[BD_NSTAT]; // the node's static rows
 };
 
 #define BD_ROW_LD(e)                                                            \
@@ -251,7 +251,10 @@ struct BdSweep {
     "global_load_dwordx2 %[u1], %[vo], %[ub] offset:%[o1] sc1\n\t"    \
     "global_load_dwordx2 %[u2], %[vo], %[ub] offset:%[o2] sc1\n\t"    \
     "global_load_dwordx2 %[u3], %[vo], %[ub] offset:%[o3] sc1\n\t"
-#define BD_STAT_0 "s_waitcnt vmcnt(0)"
+// first trip of a row: its static rows, the LDS-DMA of the record BD_RD blocks ahead, and a one-instruction warm-up of the
+// NEXT block's static rows (lane l fetches one dword of cache line l of that 8 KB record into an LDS dump area nobody
+// reads: the lines are in this XCD's L2 when the next block's trip asks for them - a cold static row costs ~1.5 us, an L2
+// hit less than the polls next to it); both DMAs stay in flight behind the counted wait
 #define BD_STAT_1                                                     \
     "global_load_dwordx4 %[s0], %[vs], %[sa] offset:0\n\t"            \
     "global_load_dwordx4 %[s1], %[vs], %[sa] offset:1024\n\t"         \
@@ -261,26 +264,34 @@ struct BdSweep {
     "global_load_dwordx4 %[s5], %[vs], %[sb] offset:1024\n\t"         \
     "global_load_dwordx4 %[s6], %[vs], %[sb] offset:2048\n\t"         \
     "global_load_dwordx4 %[s7], %[vs], %[sb] offset:3072\n\t"         \
-    "s_mov_b32 %[km], m0\n\ts_mov_b64 %[ke], exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %[rl]\n\t" \
+    "s_mov_b32 %[km], m0\n\ts_mov_b32 m0, %[pl]\n\ts_nop 0\n\tglobal_load_lds_dword %[pa], off\n\t" \
+    "s_mov_b64 %[ke], exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %[rl]\n\t" \
     "s_nop 0\n\tglobal_load_lds_dword %[ra], off\n\t"                 \
-    "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]\n\ts_waitcnt vmcnt(1)"
-#define BD_TRIP(n_, du_, st_)                                                                                                  \
-    asm volatile(BD_ROWS_##n_ BD_DU_##du_ BD_STAT_##st_                                                                        \
-                 : [x00] "=v"(W.x[0][0]), [x01] "=v"(W.x[0][1]), [x02] "=v"(W.x[0][2]), [x03] "=v"(W.x[0][3]),              \
+    "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]\n\ts_waitcnt vmcnt(2)"
+#define BD_ROW_OUTS                                                                                                         \
+                   [x00] "=v"(W.x[0][0]), [x01] "=v"(W.x[0][1]), [x02] "=v"(W.x[0][2]), [x03] "=v"(W.x[0][3]),              \
                    [x10] "=v"(W.x[1][0]), [x11] "=v"(W.x[1][1]), [x12] "=v"(W.x[1][2]), [x13] "=v"(W.x[1][3]),              \
                    [x20] "=v"(W.x[2][0]), [x21] "=v"(W.x[2][1]), [x22] "=v"(W.x[2][2]), [x23] "=v"(W.x[2][3]),              \
                    [x30] "=v"(W.x[3][0]), [x31] "=v"(W.x[3][1]), [x32] "=v"(W.x[3][2]), [x33] "=v"(W.x[3][3]),              \
                    [q0] "=v"(W.q[0]), [q1] "=v"(W.q[1]), [q2] "=v"(W.q[2]), [q3] "=v"(W.q[3]),                              \
-                   [u0] "=v"(W.u[0]), [u1] "=v"(W.u[1]), [u2] "=v"(W.u[2]), [u3] "=v"(W.u[3]),                              \
-                   [s0] "=v"(W.st[0]), [s1] "=v"(W.st[1]), [s2] "=v"(W.st[2]), [s3] "=v"(W.st[3]),                          \
-                   [s4] "=v"(W.st[4]), [s5] "=v"(W.st[5]), [s6] "=v"(W.st[6]), [s7] "=v"(W.st[7]),                          \
+                   [u0] "=v"(W.u[0]), [u1] "=v"(W.u[1]), [u2] "=v"(W.u[2]), [u3] "=v"(W.u[3])
+#define BD_ROW_INS                                                                                                          \
+                   [vo] "v"(lane8), [vz] "v"(vzero), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),                \
+                   [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [c3] "s"(c3p), [ub] "s"(ub),                                \
+                   [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)
+#define BD_TRIP_FIRST(n_, du_)                                                                                              \
+    asm volatile(BD_ROWS_##n_ BD_DU_##du_ BD_STAT_1                                                                         \
+                 : BD_ROW_OUTS,                                                                                             \
+                   [s0] "=v"(ST[0]), [s1] "=v"(ST[1]), [s2] "=v"(ST[2]), [s3] "=v"(ST[3]),                                  \
+                   [s4] "=v"(ST[4]), [s5] "=v"(ST[5]), [s6] "=v"(ST[6]), [s7] "=v"(ST[7]),                                  \
                    [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)                                                               \
-                 : [vo] "v"(lane8), [vz] "v"(vzero), [vs] "v"(lane16), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3), \
-                   [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [c3] "s"(c3p), [ub] "s"(ub), [sa] "s"(sa), [sb] "s"(sb),    \
-                   [ra] "v"(ra), [rl] "s"(rl), [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)                                     \
+                 : BD_ROW_INS, [vs] "v"(lane16), [sa] "s"(sa), [sb] "s"(sb), [ra] "v"(ra), [rl] "s"(rl),                    \
+                   [pa] "v"(pa), [pl] "s"(pl)                                                                               \
                  : "memory")
-#define BD_CASE(n_, du_, st_) case (n_) * 4 + (du_) * 2 + (st_): BD_TRIP(n_, du_, st_); break;
-#define BD_CASES(n) BD_CASE(n, 0, 0) BD_CASE(n, 0, 1) BD_CASE(n, 1, 0) BD_CASE(n, 1, 1)
+#define BD_TRIP_POLL(n_, du_)                                                                                               \
+    asm volatile(BD_ROWS_##n_ BD_DU_##du_ "s_waitcnt vmcnt(0)" : BD_ROW_OUTS : BD_ROW_INS : "memory")
+#define BD_CASE(n_, du_) case (n_) * 2 + (du_): if (stat_pending) BD_TRIP_FIRST(n_, du_); else BD_TRIP_POLL(n_, du_); break;
+#define BD_CASES(n_) BD_CASE(n_, 0) BD_CASE(n_, 1)
 
 template <int KPT, bool HAS_DU>
 __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, const BdArgs& S, const BdCell& C, int sl,
@@ -343,6 +354,9 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
     }
     // the slice's share of a full row in the loader's column layout: units [32 sl, 32 sl + 32) = column block q = sl / 2,
     // lanes [32 (sl & 1), + 32)
+    // L2 warm-up (see BD_STAT_1): lane l asks for line l of the next block's static record; the dump area is this wave's
+    unsigned* const dump = reinterpret_cast<unsigned*>(lds.dump) + ((set * DF_RB + lw) * 64);
+    const unsigned pl = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)dump);
     const int myq = sl >> 1;
     const bool mine = (lane >> 5) == (sl & 1);
     auto pick = [&](const float (&a)[4]) -> float { return myq == 0 ? a[0] : (myq == 1 ? a[1] : (myq == 2 ? a[2] : a[3])); };
@@ -361,15 +375,16 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
         int* v_s = reinterpret_cast<int*>(sbase + Slot::v_off);
         const void* ra = rec_src(j + BD_RD);
         const unsigned rl = rec_dst(j + BD_RD);
+        const int vnext = __builtin_amdgcn_readfirstlane(rec_ring[((j + 1) & 7) * 16]);   // (past the end: the last block's again)
+        const void* pa = stat + (int64_t)max(vnext, 0) * (BD_NSTAT * BD_SP) + 32 * lane;
         if (v >= 0) {
             const int deg = ee - eb;
             const float* sa = stat + (int64_t)v * (BD_NSTAT * BD_SP);
             const float* sb = sa + 4 * BD_SP;
             const gran_t* ub = HAS_DU ? du_in + (int64_t)v * gld : da_g;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            float hv[4] = {0.f, 0.f, 0.f, 0.f};
             float sig = 0.f, m0 = 0.f, m1 = 0.f;
-            bf4 st[BD_NSTAT];
+            bf4 ST[BD_NSTAT];   // the node's static rows: outputs of the FIRST trip only, so they stay put across re-polls
             float du[4] = {0.f, 0.f, 0.f, 0.f};
             int c0 = 0;
             do {
@@ -400,16 +415,11 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                     unsigned keep_m0;
                     unsigned long long keep_exec;
                     BdSweep& W = A;
-                    switch (nn * 4 + (du_pending ? 2 : 0) + (stat_pending ? 1 : 0)) {
+                    switch (nn * 2 + (du_pending ? 1 : 0)) {
                         BD_CASES(0) BD_CASES(1) BD_CASES(2) BD_CASES(3)
                         default: BD_CASES(4)
                     }
-                    if (stat_pending) {
-#pragma unroll
-                        for (int r = 0; r < BD_NSTAT; ++r) st[r] = A.st[r];
-                        hv[0] = st[ST_H].x; hv[1] = st[ST_H].y; hv[2] = st[ST_H].z; hv[3] = st[ST_H].w;
-                        stat_pending = false;
-                    }
+                    stat_pending = false;
                     bool ok = true;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -436,10 +446,10 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                 for (int e = 0; e < 4; ++e) {
                     if (e < nn) {
 #define BD_X(q) __uint_as_float((unsigned)A.x[e][q])
-                        float dot = BD_X(0) * hv[0];
-                        if (NQ4 > 1) dot = fmaf(BD_X(1), hv[1], dot);
-                        if (NQ4 > 2) dot = fmaf(BD_X(2), hv[2], dot);
-                        if (NQ4 > 3) dot = fmaf(BD_X(3), hv[3], dot);
+                        float dot = BD_X(0) * ST[ST_H].x;
+                        if (NQ4 > 1) dot = fmaf(BD_X(1), ST[ST_H].y, dot);
+                        if (NQ4 > 2) dot = fmaf(BD_X(2), ST[ST_H].z, dot);
+                        if (NQ4 > 3) dot = fmaf(BD_X(3), ST[ST_H].w, dot);
                         const float ds = al[e] * (bd_wave_sum(dot) - __uint_as_float((unsigned)A.q[e]));
                         sig += ds;
                         m0 = fmaf(ds, f0[e], m0);
@@ -453,15 +463,15 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
             } while (c0 < deg);
             // G_v, then everything that is linear in it
             float G[4];
-            G[0] = st[ST_GEXT].x + du[0] + acc[0] + sig * wk[0];
-            G[1] = st[ST_GEXT].y + du[1] + acc[1] + sig * wk[1];
-            G[2] = st[ST_GEXT].z + du[2] + acc[2] + sig * wk[2];
-            G[3] = st[ST_GEXT].w + du[3] + acc[3] + sig * wk[3];
-            const float cr[4] = {st[ST_CR].x, st[ST_CR].y, st[ST_CR].z, st[ST_CR].w};
-            const float cz[4] = {st[ST_CZ].x, st[ST_CZ].y, st[ST_CZ].z, st[ST_CZ].w};
-            const float cnr[4] = {st[ST_CNR].x, st[ST_CNR].y, st[ST_CNR].z, st[ST_CNR].w};
-            const float cn[4] = {st[ST_CN].x, st[ST_CN].y, st[ST_CN].z, st[ST_CN].w};
-            const float zz[4] = {st[ST_Z].x, st[ST_Z].y, st[ST_Z].z, st[ST_Z].w};
+            G[0] = ST[ST_GEXT].x + du[0] + acc[0] + sig * wk[0];
+            G[1] = ST[ST_GEXT].y + du[1] + acc[1] + sig * wk[1];
+            G[2] = ST[ST_GEXT].z + du[2] + acc[2] + sig * wk[2];
+            G[3] = ST[ST_GEXT].w + du[3] + acc[3] + sig * wk[3];
+            const float cr[4] = {ST[ST_CR].x, ST[ST_CR].y, ST[ST_CR].z, ST[ST_CR].w};
+            const float cz[4] = {ST[ST_CZ].x, ST[ST_CZ].y, ST[ST_CZ].z, ST[ST_CZ].w};
+            const float cnr[4] = {ST[ST_CNR].x, ST[ST_CNR].y, ST[ST_CNR].z, ST[ST_CNR].w};
+            const float cn[4] = {ST[ST_CN].x, ST[ST_CN].y, ST[ST_CN].z, ST[ST_CN].w};
+            const float zz[4] = {ST[ST_Z].x, ST[ST_Z].y, ST[ST_Z].z, ST[ST_Z].w};
             float dr[4], dz[4], dnr[4], dnn[4], zg[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -491,10 +501,10 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                 }
             }
             if (sl == 0) {   // q_v = G_v . c_q,v; the row's scalar outputs
-                float qd = G[0] * st[ST_CQ].x;
-                if (NQ4 > 1) qd = fmaf(G[1], st[ST_CQ].y, qd);
-                if (NQ4 > 2) qd = fmaf(G[2], st[ST_CQ].z, qd);
-                if (NQ4 > 3) qd = fmaf(G[3], st[ST_CQ].w, qd);
+                float qd = G[0] * ST[ST_CQ].x;
+                if (NQ4 > 1) qd = fmaf(G[1], ST[ST_CQ].y, qd);
+                if (NQ4 > 2) qd = fmaf(G[2], ST[ST_CQ].z, qd);
+                if (NQ4 > 3) qd = fmaf(G[3], ST[ST_CQ].w, qd);
                 qd = bd_wave_sum(qd);
                 if (lane == 0) {
                     __hip_atomic_store(q_out + v, gran_pack(epoch, qd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -513,7 +523,8 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-#undef BD_TRIP
+#undef BD_TRIP_FIRST
+#undef BD_TRIP_POLL
 #undef BD_CASE
 #undef BD_CASES
 
@@ -766,6 +777,7 @@ __global__ void __launch_bounds__(BD_THREADS, 3) bwd_dataflow_kernel(const int32
     int* flags = lds.rec + DF_NLS * DF_RB * 8 * 16;
     lds.rdy = flags;
     lds.dn = flags + BD_NLW;
+    lds.dump = flags + BD_NLW + DF_NLS * DF_NCW;
     if (tid < BD_NLW + DF_NLS * DF_NCW) flags[tid] = 0;
     __syncthreads();
     if (wave < DF_NCW) {
@@ -782,7 +794,7 @@ __global__ void __launch_bounds__(BD_THREADS, 3) bwd_dataflow_kernel(const int32
 }
 
 template <int KPT> size_t bd_lds_bytes() {
-    return (size_t)(DF_NLS * (BD_NSLOT * BdSlot<KPT>::words + DF_RB * 8 * 16) + BD_NLW + DF_NLS * DF_NCW) * 4 + 256;
+    return (size_t)(DF_NLS * (BD_NSLOT * BdSlot<KPT>::words + DF_RB * 8 * 16) + BD_NLW + DF_NLS * DF_NCW + DF_NLS * DF_RB * 64) * 4 + 256;
 }
 
 // gate-wise transpose: out[g H + j][u] = W[g H + u][j] (the A operands of the reverse products are the columns of W)

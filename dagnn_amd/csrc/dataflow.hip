@@ -295,6 +295,8 @@ struct DfCell {
     float* h_out;         // recurrent: [N,ld_h]
     gran_t* g_out;        // recurrent: [N,gld] granules of h_out; projection: [N,pld] granules of the pre-activations
     const gran_t* g_in;   // projection: granules of the lower stacked layer's states
+    float* aux_out;       // training passes: [N,3H] plain copy of the pre-activations this cell computes (recurrent: W_hh a +
+                          // b_hh; projection: W_ih u + b_ih), or null
     int dir;
     int kind;
 };
@@ -822,6 +824,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     const unsigned epoch = S.epoch, spin_limit = S.spin_limit;
     int* const err = S.err;
     float* const h_out = C.h_out;
+    float* const aux_out = C.aux_out;
     gran_t* const g_out = C.g_out;
     const int ld_h = S.ld_h, gld = S.gld, pld = S.pld, num_nodes = S.N;
     unsigned long long* const dbg = S.dbg ? S.dbg + 2 * gridDim.x : nullptr;
@@ -962,6 +965,10 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
             } else {
                 h_out[(int64_t)gv * ld_h + unit] = hv;
                 __hip_atomic_store(g_out + (int64_t)gv * gld + unit, gran_pack(epoch, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (aux_out) {   // (behind the hand-off stores: nobody waits for these)
+                float* ao = aux_out + (int64_t)gv * (3 * H) + unit;
+                ao[0] = g3[0] + b_r; ao[H] = g3[1] + b_z; ao[2 * H] = g3[2] + b_n;
             }
         }
         if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 2] = wall_clock64();
@@ -1155,6 +1162,7 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
                 P.h_out = nullptr;
                 P.g_out = (gran_t*)c.proj_granules;
                 P.g_in = (const gran_t*)a->cell[d][i - 1].granules;
+                P.aux_out = c.gi_out;
                 P.dir = d; P.kind = DF_PROJECTION;
             }
             DfCell& K = S.cell[nc++];
@@ -1168,6 +1176,7 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
             K.h_out = c.h_out;
             K.g_out = (gran_t*)c.granules;
             K.g_in = nullptr;
+            K.aux_out = c.gh_out;
             K.dir = d; K.kind = DF_RECURRENT;
         }
     }

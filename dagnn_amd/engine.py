@@ -357,9 +357,12 @@ def dataflow_groups(device, num_dirs: int, num_stacked: int, H: int, B: int) -> 
 
 
 def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0, h, groups: int, vid_mod: int = 0,
-                 arena: Optional["GranuleArena"] = None, static_score=None, score_parts: bool = False) -> None:
+                 arena: Optional["GranuleArena"] = None, static_score=None, score_parts: bool = False,
+                 preact: Optional[dict] = None) -> None:
     """The whole recurrence as one persistent launch (csrc/dataflow.hip).  Same operands as `frontier_run`;
-    `score_parts` adds the partial attention scores behind the state rows (what the backward pass reads)."""
+    `score_parts` adds the partial attention scores behind the state rows (what the backward pass reads); `preact`
+    (a dict, training passes) receives the pre-activations the kernel computed anyway - `("gh", d, i)` [N,3H] for every
+    cell and `("gi", d, i)` for the stacked layers above the first - so the reverse sweep need not recompute them."""
     if arena is None:
         raise DagnnHipError("the dataflow kernel needs a GranuleArena (persistent, zero-initialised granule buffers)")
     lib = _lib.load()
@@ -385,6 +388,12 @@ def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
             fc.h_out = h[d][i].data_ptr()
             fc.granules = gran[(d, i)].data_ptr()
             fc.proj_granules = gran[("p", d, i)].data_ptr() if i > 0 else None
+            if preact is not None:
+                preact[("gh", d, i)] = torch.empty(plan.N, 3 * H, dtype=torch.float32, device=plan.ws.device)
+                fc.gh_out = preact[("gh", d, i)].data_ptr()
+                if i > 0:
+                    preact[("gi", d, i)] = torch.empty(plan.N, 3 * H, dtype=torch.float32, device=plan.ws.device)
+                    fc.gi_out = preact[("gi", d, i)].data_ptr()
     args.num_stacked, args.dir_mask, args.H, args.ld_h, args.gld = L, mask, H, h[dirs[0]][0].shape[1], gld
     args.pld = 3 * H
     args.vid_mod, args.groups, args.epoch = int(vid_mod), int(groups), epoch
@@ -772,7 +781,7 @@ def bwd_dataflow_groups(device, num_dirs: int, num_stacked: int, H: int, B: int)
 
 
 def bwd_dataflow_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, h, gi0, g_ext, groups: int,
-                       arena: "GranuleArena", vid_mod: int = 0, static_score=None):
+                       arena: "GranuleArena", vid_mod: int = 0, static_score=None, preact: Optional[dict] = None):
     """Reverse pass of the recurrence as ONE persistent dataflow launch (csrc/bwd_dataflow.hip).  Same operands and
     the same result dictionary as `backward_sweep`; `groups` must be the group count of the forward pass's schedule."""
     dev = plan.ws.device
@@ -808,17 +817,21 @@ def bwd_dataflow_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, ce
         check(lib.dagnn_backward_prepare(C.byref(plan.desc), C.byref(pargs), _stream(plan.ws)), "dagnn_backward_prepare")
         keys = [(d, i) for d in dirs for i in range(L)]
         gh = {}
-        for k0 in range(0, len(keys), 4):
-            grp = keys[k0:k0 + 4]
-            res = gemm_nt_bias([out[k]["a"] for k in grp], [cells[k].w_hh_raw for k in grp], [cells[k].b_hh for k in grp])
-            gh.update(dict(zip(grp, res)))
         gi = {(d, 0): gi0[d] for d in dirs}
         up = [(d, i) for d in dirs for i in range(1, L)]
-        for k0 in range(0, len(up), 4):
-            grp = up[k0:k0 + 4]
-            res = gemm_nt_bias([h[d][i - 1][:, :H] for d, i in grp], [cells[k].w_ih for k in grp],
-                               [cells[k].b_ih for k in grp])
-            gi.update(dict(zip(grp, res)))
+        if preact:   # the forward kernel kept the pre-activations of this pass (dataflow_run, `preact`)
+            gh = {k: preact[("gh",) + k] for k in keys}
+            gi.update({k: preact[("gi",) + k] for k in up})
+        else:
+            for k0 in range(0, len(keys), 4):
+                grp = keys[k0:k0 + 4]
+                res = gemm_nt_bias([out[k]["a"] for k in grp], [cells[k].w_hh_raw for k in grp], [cells[k].b_hh for k in grp])
+                gh.update(dict(zip(grp, res)))
+            for k0 in range(0, len(up), 4):
+                grp = up[k0:k0 + 4]
+                res = gemm_nt_bias([h[d][i - 1][:, :H] for d, i in grp], [cells[k].w_ih for k in grp],
+                                   [cells[k].b_ih for k in grp])
+                gi.update(dict(zip(grp, res)))
         gkeys = [("da", d, i) for d in dirs for i in range(L)] + [("q", d, i) for d in dirs for i in range(L)] + \
                 [("dgi", d, i) for d in dirs for i in range(1, L)] + [("du", d, i) for d in dirs for i in range(L - 1)]
         widths = {k: (1 if k[0] == "q" else 3 * H) for k in gkeys if k[0] in ("q", "dgi")}
@@ -859,6 +872,63 @@ def bwd_dataflow_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, ce
         o.pop("_wkey", None)
     out["_keep"] = keep   # buffers the launch reads: alive until the caller drops the result
     return out
+
+
+_WGRAD_WS = {}   # per device: the partial-tile workspace of `wgrad` (grown on demand, reused by every step)
+
+
+def wgrad(jobs, N: int, Hp: int, H: int):
+    """Weight / bias gradients of GRU cells in one batch (`dagnn_wgrad_run`).  `jobs`: list of (dg [N, >= 3 Hp], inp
+    [N, in_dim] (row pitch kept), want_bias); returns a list of (d_weight [3H, in_dim], d_bias [3H] or None)."""
+    lib = _lib.load()
+    dev = jobs[0][0].device
+    arr = (_lib.WgradJob * len(jobs))()
+    outs, keep = [], []
+    kmax = 0
+    for q, (dg, inp, want_bias) in enumerate(jobs):
+        dg, inp = _rows(dg, "dg"), _rows(inp, "wgrad input")
+        keep += [dg, inp]
+        K2 = inp.shape[1]
+        kmax = max(kmax, K2)
+        dW = torch.empty(3 * H, K2, dtype=torch.float32, device=dev)
+        db = torch.empty(3 * H, dtype=torch.float32, device=dev) if want_bias else None
+        outs.append((dW, db))
+        arr[q] = _lib.WgradJob(dg.data_ptr(), inp.data_ptr(), dW.data_ptr(), _ptr(db), dg.stride(0), inp.stride(0), K2)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    splits = max(lib.dagnn_wgrad_splits(cus, len(jobs), Hp, kmax, max(N, 1)), 1)
+    nbytes = lib.dagnn_wgrad_workspace_bytes(len(jobs), Hp, kmax, splits)
+    ws = _WGRAD_WS.get(dev)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _WGRAD_WS[dev] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+    check(lib.dagnn_wgrad_run(arr, len(jobs), N, Hp, H, splits, ws.data_ptr(), ws.numel() * 4, _stream(jobs[0][0])),
+          "dagnn_wgrad_run")
+    return outs
+
+
+def colsums(jobs, N: int):
+    """Weighted column sums in one batch (`dagnn_colsum_run`).  `jobs`: list of (x [N, cols] (row pitch kept; a 1-d
+    tensor counts as [N, 1]), weight [N] or None); returns the list of [cols] sums."""
+    lib = _lib.load()
+    dev = jobs[0][0].device
+    arr = (_lib.ColsumJob * len(jobs))()
+    outs, keep = [], []
+    kmax = 0
+    for q, (x, w) in enumerate(jobs):
+        x = x.view(-1, 1) if x.dim() == 1 else x
+        if not (x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1):
+            x = _dev(x, "colsum input", torch.float32)
+        w = None if w is None else _dev(w, "colsum weight", torch.float32)
+        keep += [x, w]
+        o = torch.empty(x.shape[1], dtype=torch.float32, device=dev)
+        outs.append(o)
+        kmax = max(kmax, x.shape[1])
+        arr[q] = _lib.ColsumJob(x.data_ptr(), _ptr(w), o.data_ptr(), x.stride(0) if x.shape[0] > 1 else x.shape[1], x.shape[1])
+    nbytes = lib.dagnn_colsum_workspace_bytes(len(jobs), kmax)
+    ws = _WGRAD_WS.get(("cs", dev))
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _WGRAD_WS[("cs", dev)] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+    check(lib.dagnn_colsum_run(arr, len(jobs), N, ws.data_ptr(), ws.numel() * 4, _stream(jobs[0][0])), "dagnn_colsum_run")
+    return outs
 
 
 def gather_rows(h: torch.Tensor, num_graphs: int, stride: int, node_off: int, out: torch.Tensor,

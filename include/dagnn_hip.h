@@ -286,6 +286,9 @@ typedef struct dagnn_dataflow_cell {
     void* granules;         /* uint64 [N,gld] */
     void* proj_granules;    /* stacked layers > 0: uint64 [N,pld] (pld >= 3H), the hand-off buffer of the cell's input-side
                              * pre-activations W_ih u + b_ih (same zero-init / epoch contract as `granules`); else NULL */
+    float* gh_out;          /* NULL, or [N,3H]: the hidden-side pre-activations W_hh a + b_hh of every node as the gates saw them */
+    float* gi_out;          /* NULL, or [N,3H] (stacked layers > 0): the input-side pre-activations as plain floats - what a
+                             * training pass keeps for its reverse sweep instead of recomputing both with GEMMs */
 } dagnn_dataflow_cell;
 
 typedef struct dagnn_dataflow_args {
@@ -463,6 +466,37 @@ size_t dagnn_bwd_dataflow_static_bytes(int64_t N);
 int dagnn_gatewise_transpose(const float* w /* [3H,H] */, float* out /* [3H,H] */, int H, void* stream);
 int dagnn_bwd_dataflow_prepare(const dagnn_plan* plan /* host */, const dagnn_bwd_dataflow_args* args /* host */, void* stream);
 int dagnn_bwd_dataflow_run(const dagnn_plan* plan /* host */, const dagnn_bwd_dataflow_args* args /* host */, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Parameter gradients of the GRU cells from the sweep's outputs (csrc/wgrad.hip): for every job
+ *     d_weight [3H, in_dim] = dg[:, real rows]^T in,      d_bias [3H] = column sums of dg          (both overwritten)
+ * with dg [N, ld_dg] = dgi or dgh (three gate blocks of Hp columns, Hp >= H: padding units are dropped) and `in` [N, ld_in]
+ * the product's input (u for W_ih, the aggregate a for W_hh).  The reduction over the nodes is split `splits` ways
+ * (dagnn_wgrad_splits) into partial tiles in `workspace` (dagnn_wgrad_workspace_bytes) that a second kernel adds in
+ * split order: deterministic, no atomics.  Replaces what autograd accumulates per `nn.GRUCell` call (dagnn.py:181). */
+typedef struct dagnn_wgrad_job {
+    const float* dg;     /* [N, ld_dg] */
+    const float* in;     /* [N, ld_in] */
+    float* d_weight;     /* [3H, in_dim] */
+    float* d_bias;       /* [3H] or NULL */
+    int ld_dg, ld_in, in_dim;   /* in_dim even; ld_dg % 4 == 0, ld_in % 2 == 0, rows 8-byte aligned */
+} dagnn_wgrad_job;
+/* Weighted column sums for the rest of the epilogue: out[k] = sum_n weight[n] x[n][k] (weight NULL: plain column sums) -
+ * the attention-key gradients sum_v sigma_v keys_v, the edge-feature sums, sum_v sigma_v.  Rows are summed in a fixed
+ * chunk order (deterministic). */
+typedef struct dagnn_colsum_job {
+    const float* x;        /* [N, ld_x] */
+    const float* weight;   /* [N] or NULL */
+    float* out;            /* [cols] */
+    int ld_x, cols;
+} dagnn_colsum_job;
+size_t dagnn_colsum_workspace_bytes(int njob, int max_cols);
+int dagnn_colsum_run(const dagnn_colsum_job* jobs /* host */, int njob, int64_t N, void* workspace, size_t workspace_bytes,
+                     void* stream);
+size_t dagnn_wgrad_workspace_bytes(int njob, int Hp, int max_in_dim, int splits);
+int dagnn_wgrad_splits(int num_cus, int njob, int Hp, int max_in_dim, int64_t N);
+int dagnn_wgrad_run(const dagnn_wgrad_job* jobs /* host */, int njob, int64_t N, int Hp, int H, int splits, void* workspace,
+                    size_t workspace_bytes, void* stream);
 
 /* grad_h[v, j] += grad_out[g, col_off + j] for the first output node v of graph g attaining the maximum
  * of column j (the single winner of scatter-max); grad_h must be initialised by the caller. */

@@ -175,6 +175,7 @@ SYMBOLS = {
                                           C.c_void_p, C.c_void_p]),
     "dagnn_dataflow_run": (C.c_int, [C.POINTER(Plan), C.POINTER(DataflowArgs), C.c_void_p]),
     "dagnn_pack_dataflow": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "dagnn_pack_dataflow_transposed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_score_parts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "dagnn_readout_max": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int, C.c_void_p]),
@@ -186,7 +187,6 @@ SYMBOLS = {
                                      C.POINTER(C.c_int32), C.c_void_p]),
     "dagnn_bwd_dataflow_record_bytes": (C.c_size_t, [C.c_int64]),
     "dagnn_bwd_dataflow_static_bytes": (C.c_size_t, [C.c_int64]),
-    "dagnn_gatewise_transpose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_bwd_dataflow_prepare": (C.c_int, [C.POINTER(Plan), C.POINTER(BwdDataflowArgs), C.c_void_p]),
     "dagnn_bwd_dataflow_run": (C.c_int, [C.POINTER(Plan), C.POINTER(BwdDataflowArgs), C.c_void_p]),
     "dagnn_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),

@@ -797,18 +797,6 @@ template <int KPT> size_t bd_lds_bytes() {
     return (size_t)(DF_NLS * (BD_NSLOT * BdSlot<KPT>::words + DF_RB * 8 * 16) + BD_NLW + DF_NLS * DF_NCW + DF_NLS * DF_RB * 64) * 4 + 256;
 }
 
-// gate-wise transpose: out[g H + j][u] = W[g H + u][j] (the A operands of the reverse products are the columns of W)
-__global__ void __launch_bounds__(256) bd_transpose_kernel(const float* __restrict__ W, float* __restrict__ out, int H) {
-    __shared__ float tile[32][33];
-    const int g = blockIdx.z, bx = blockIdx.x * 32, by = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int r = ty; r < 32; r += 8)
-        if (by + r < H && bx + tx < H) tile[r][tx] = W[(int64_t)(g * H + by + r) * H + bx + tx];
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8)
-        if (bx + r < H && by + tx < H) out[(int64_t)(g * H + bx + r) * H + by + tx] = tile[tx][r];
-}
-
 }  // namespace
 
 extern "C" size_t dagnn_bwd_dataflow_record_bytes(int64_t N) {
@@ -819,13 +807,6 @@ extern "C" size_t dagnn_bwd_dataflow_record_bytes(int64_t N) {
 extern "C" size_t dagnn_bwd_dataflow_static_bytes(int64_t N) {
     if (N < 0) return 0;
     return (size_t)N * BD_NSTAT * BD_SP * sizeof(float);
-}
-
-extern "C" int dagnn_gatewise_transpose(const float* w, float* out, int H, void* stream) {
-    if (!w || !out || H <= 0) return DAGNN_EINVAL;
-    hipLaunchKernelGGL(bd_transpose_kernel, dim3((H + 31) / 32, (H + 31) / 32, 3), dim3(256), 0, (hipStream_t)stream, w, out, H);
-    DAGNN_CHECK_LAUNCH();
-    return DAGNN_OK;
 }
 
 extern "C" int dagnn_bwd_dataflow_prepare(const dagnn_plan* pl, const dagnn_bwd_dataflow_args* a, void* stream) {

@@ -1025,7 +1025,10 @@ template <int KPT> size_t df_lds_bytes() {
 // Pack W [3H, K = H] (torch GRUCell layout) for the dataflow kernel: out[(sl * NQ + q) * 256 + tc] (float4), NQ = 3 H/32,
 // q = gate * (H/32) + k4, thread tc = (compute wave w = tc >> 6, unit quad = (tc >> 5) & 1, K slice ks = (tc >> 2) & 7, unit of
 // the quad x = tc & 3):  W[gate * H + 32 sl + 8 w + 4 quad + x][ks * H/8 + 4 k4 .. + 3]  (the A operands of df_compute).
-__global__ void __launch_bounds__(256) df_pack_kernel(const float* __restrict__ W, float4* __restrict__ out, int H, int64_t total) {
+// `transposed`: pack the GATE-WISE TRANSPOSED matrix W'[g H + j][u] = W[g H + u][j] instead (the A operands of the reverse
+// sweep's products W^T dg, bwd_dataflow.hip) - four strided reads per element instead of one float4.
+__global__ void __launch_bounds__(256) df_pack_kernel(const float* __restrict__ W, float4* __restrict__ out, int H, int64_t total,
+                                                       int transposed) {
     const int kp8 = H >> 3, nk4 = kp8 >> 2, nq = 3 * nk4;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int tc = (int)(idx & 255);
@@ -1034,7 +1037,12 @@ __global__ void __launch_bounds__(256) df_pack_kernel(const float* __restrict__ 
         const int sl = (int)(rest / nq);
         const int g = q / nk4, k4 = q - g * nk4;
         const int unit = sl * DF_JS + 8 * (tc >> 6) + 4 * ((tc >> 5) & 1) + (tc & 3), ks = (tc >> 2) & 7;
-        out[idx] = *reinterpret_cast<const float4*>(W + (int64_t)(g * H + unit) * H + ks * kp8 + 4 * k4);
+        if (!transposed) {
+            out[idx] = *reinterpret_cast<const float4*>(W + (int64_t)(g * H + unit) * H + ks * kp8 + 4 * k4);
+        } else {
+            const float* src = W + (int64_t)(g * H + ks * kp8 + 4 * k4) * H + unit;
+            out[idx] = make_float4(src[0], src[H], src[2 * (int64_t)H], src[3 * (int64_t)H]);
+        }
     }
 }
 
@@ -1119,16 +1127,20 @@ extern "C" int dagnn_dataflow_schedule(const dagnn_plan* pl, void* ws_, size_t w
     return DAGNN_OK;
 }
 
-extern "C" int dagnn_pack_dataflow(const float* w, float* out, int H, void* stream) {
+static int df_pack(const float* w, float* out, int H, int transposed, void* stream) {
     if (!w || !out || H <= 0 || (H % 64) || H > 256) return DAGNN_EINVAL;
     const int64_t total = (int64_t)3 * H * H / 4;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(df_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w,
-                       reinterpret_cast<float4*>(out), H, total);
+                       reinterpret_cast<float4*>(out), H, total, transposed);
     DAGNN_CHECK_LAUNCH();
     return DAGNN_OK;
 }
+
+extern "C" int dagnn_pack_dataflow(const float* w, float* out, int H, void* stream) { return df_pack(w, out, H, 0, stream); }
+
+extern "C" int dagnn_pack_dataflow_transposed(const float* w, float* out, int H, void* stream) { return df_pack(w, out, H, 1, stream); }
 
 extern "C" int dagnn_score_parts(float* h, int ld_h, int H, const float* w_key, int64_t N, void* stream) {
     if (!h || !w_key || H <= 0 || (H % 16) || ld_h < H + H / 16 || N < 0) return DAGNN_EINVAL;

@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgArgs S) {
 // the attention-key gradients sum_v sigma_v keys_v, the edge-feature sums and sum_v sigma_v of the epilogue.  Two
 // stages like the products above: every workgroup sums a chunk of rows, a second kernel adds the chunks in order.
 constexpr int CS_MAX_JOBS = 32;
-constexpr int CS_CHUNKS = 64;
+constexpr int CS_CHUNKS = 256;
 struct CsJob { const float* X; const float* w; float* out; int ld, K; };
 struct CsArgs { CsJob job[CS_MAX_JOBS]; int njob; int64_t N; float* part; int Kmax; };
 
@@ -177,8 +177,22 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(CsArgs S) {
         const int phases = 256 / cols;
         const int c = threadIdx.x % cols, ph = threadIdx.x / cols;
         float s = 0.f;
-        if (c < kw)
-            for (int64_t n = n0 + ph; n < n1; n += phases) s = fmaf(J.w ? J.w[n] : 1.0f, J.X[n * J.ld + k0 + c], s);
+        if (c < kw) {   // four rows in flight per thread (a chain of dependent loads would be latency-bound)
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+            int64_t n = n0 + ph;
+            for (; n + 3 * phases < n1; n += 4 * phases) {
+                float xv[4], wv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xv[e] = J.X[(n + e * phases) * J.ld + k0 + c];
+                    wv[e] = J.w ? J.w[n + e * phases] : 1.0f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s4[e] = fmaf(wv[e], xv[e], s4[e]);
+            }
+            for (; n < n1; n += phases) s4[0] = fmaf(J.w ? J.w[n] : 1.0f, J.X[n * J.ld + k0 + c], s4[0]);
+            s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        }
         red[threadIdx.x] = s;
         __syncthreads();
         if (ph == 0 && c < kw) {

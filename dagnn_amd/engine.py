@@ -767,9 +767,10 @@ def pack_dataflow_transposed(w: torch.Tensor, H: int) -> torch.Tensor:
     w = _dev(w, "weight", torch.float32)
     if tuple(w.shape) != (3 * H, H):
         raise DagnnHipError("pack_dataflow_transposed needs a [3H, H] matrix, got %s" % (tuple(w.shape),))
-    t = torch.empty_like(w)
-    check(_lib.load().dagnn_gatewise_transpose(w.data_ptr(), t.data_ptr(), H, _stream(w)), "dagnn_gatewise_transpose")
-    return pack_dataflow(t, H)
+    out = torch.empty(3 * H * H, dtype=torch.float32, device=w.device)
+    check(_lib.load().dagnn_pack_dataflow_transposed(w.data_ptr(), out.data_ptr(), H, _stream(w)),
+          "dagnn_pack_dataflow_transposed")
+    return out
 
 
 def bwd_dataflow_groups(device, num_dirs: int, num_stacked: int, H: int, B: int) -> int:

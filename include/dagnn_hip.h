@@ -313,6 +313,8 @@ int dagnn_dataflow_schedule(const dagnn_plan* plan /* host */, void* workspace, 
                             int cost_layer, int cost_row, const int32_t* plan_status /* device, or NULL */, void* stream);
 int dagnn_dataflow_run(const dagnn_plan* plan /* host */, const dagnn_dataflow_args* args /* host */, void* stream);
 int dagnn_pack_dataflow(const float* w /* [3H,H] */, float* out /* 3H*H floats */, int H, void* stream);
+/* the same order of the gate-wise transposed matrix W'[g H + j][u] = W[g H + u][j] (reverse sweep, dagnn_bwd_dataflow_run) */
+int dagnn_pack_dataflow_transposed(const float* w /* [3H,H] */, float* out /* 3H*H floats */, int H, void* stream);
 int dagnn_score_parts(float* h /* [N,ld_h] */, int ld_h, int H, const float* w_key /* [H] */, int64_t N, void* stream);
 /* Introspection (tests, host-side mirror): byte offsets of the schedule workspace's arrays, 13 entries: [grp_of,
  * gdepth, gload, loff, gtab0, gtab1, lcnt0, lcnt1, glbase0, glbase1, grec0, grec1, total]. */
@@ -428,7 +430,8 @@ int dagnn_backward_run(const dagnn_plan* plan /* host */, const dagnn_backward_a
  *      strictly increasing epochs): da [N,gld], q [N], dgi [N,3 gld] (stacked layers > 0), du [N,gld] (stacked layers
  *      below the top: the du arriving at THIS cell's rows).  Outputs for the weight-gradient epilogue: dgi, dgh [N,3H],
  *      sigma [N], edge_feat_grad [N,R].  `err` as for dagnn_dataflow_run.
- * Weights: dagnn_pack_dataflow(dagnn_gatewise_transpose(W)): out[g H + j][u] = W[g H + u][j]. */
+ * Weights: dagnn_pack_dataflow_transposed(W): the forward kernel's slice / lane order of the gate-wise transposed matrix
+ * W'[g H + j][u] = W[g H + u][j] (H x H blocks of the torch layout transposed in place). */
 typedef struct dagnn_bwd_dataflow_cell {
     const float* w_hh_t;    /* packed gate-wise transposed W_hh */
     const float* w_ih_t;    /* ... W_ih (stacked layers > 0), else NULL */
@@ -463,7 +466,6 @@ typedef struct dagnn_bwd_dataflow_args {
 
 size_t dagnn_bwd_dataflow_record_bytes(int64_t N);
 size_t dagnn_bwd_dataflow_static_bytes(int64_t N);
-int dagnn_gatewise_transpose(const float* w /* [3H,H] */, float* out /* [3H,H] */, int H, void* stream);
 int dagnn_bwd_dataflow_prepare(const dagnn_plan* plan /* host */, const dagnn_bwd_dataflow_args* args /* host */, void* stream);
 int dagnn_bwd_dataflow_run(const dagnn_plan* plan /* host */, const dagnn_bwd_dataflow_args* args /* host */, void* stream);
 

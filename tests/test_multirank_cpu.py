@@ -261,3 +261,67 @@ def test_two_rank_data_parallel_shim_gloo():
     out = mgr.dict()
     mp.spawn(_dp_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert len(out) == 2 and sum(out.values()) == 9
+
+
+# ---------------------------------------------------------------- two buckets: the heads' exchange leaves mid-backward
+class _TwoPart(torch.nn.Module):
+    """A 'core' whose output feeds two 'heads' (the shape of DAGNN + its vocabulary heads, dagnn.py:106-112)."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(5)
+        self.core = torch.nn.Linear(2, 3)
+        self.heads = torch.nn.ModuleList([torch.nn.Linear(3, 4), torch.nn.Linear(3, 4)])
+
+    def forward(self, G):
+        n = torch.bincount(G.batch, minlength=G.num_graphs).float()
+        e = torch.bincount(G.batch[G.edge_index[0]], minlength=G.num_graphs).float()
+        z = torch.tanh(self.core(torch.stack([n, e], dim=1) / 50.0))
+        return [h(z) for h in self.heads]
+
+
+def _overlap_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dagnn_amd.train import GradBucket, OverlappedGradReducer
+        graphs = synth.code2_graphs(13, 11, 25)
+        shards = collate_sharded(graphs, world)             # uneven, node-balanced shards
+        mine = shards[rank]
+        loss_of = lambda m, G: sum(p.pow(2).mean() for p in m(G)) / 2   # noqa: E731
+        a, b, full = _TwoPart(), _TwoPart(), _TwoPart()
+        red = OverlappedGradReducer(a.parameters(), early=a.heads.parameters())
+        single = GradBucket(b.parameters())
+        launched_mid_backward = []
+        orig = red.early.launch
+        red.early.launch = lambda *args, **kw: (launched_mid_backward.append(a.core.weight.grad.abs().sum().item() == 0.0),
+                                                orig(*args, **kw))[1]
+        for step in range(2):
+            red.zero(local_count=mine.num_graphs)
+            loss_of(a, mine).backward()
+            red.finish()
+            single.zero()
+            loss_of(b, mine).backward()
+            single.all_reduce_mean(local_count=mine.num_graphs)
+            full.zero_grad()
+            loss_of(full, synth.GraphBatch.from_data_list(graphs)).backward()
+            for (k, pa), pb, pf in zip(a.named_parameters(), b.parameters(), full.parameters()):
+                assert torch.equal(pa.grad, pb.grad), k                       # two buckets == one bucket, bit for bit
+                assert torch.allclose(pa.grad, pf.grad, atol=1e-6), k         # == the single-process global-mean gradient
+        # the heads' exchange left from the hook, before the core's gradients existed
+        assert launched_mid_backward and all(launched_mid_backward)
+        out[rank] = mine.num_graphs
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_overlapped_two_bucket_reduce_equals_single_bucket_gloo():
+    """`OverlappedGradReducer`: the heads' bucket is all-reduced asynchronously from a post-accumulate hook in the
+    middle of `backward()`, the core's bucket afterwards; on uneven shards the result equals the single-bucket
+    count-weighted exchange bit for bit and the single-process global-mean gradient to rounding."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_overlap_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert len(out) == 2 and sum(out.values()) == 11

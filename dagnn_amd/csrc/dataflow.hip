@@ -282,6 +282,20 @@ __global__ void __launch_bounds__(256) df_records_kernel(const int32_t* __restri
 //              from gi0 (stacked layer 0: the batched GEMM) or from the granules of its PROJECTION cell;
 //   PROJECTION lower-layer row -> W_ih product + b_ih -> [N, 3H] granules, off the dependent chain.
 enum { DF_RECURRENT = 0, DF_PROJECTION = 1 };
+// Code variants of a workgroup (template parameters of the loader / compute paths: the constructor-dependent branches,
+// their operands and the scalar registers that carried them leave the per-block path).
+//   KIND  0 recurrent cell of stacked layer 0 (input side from the gi0 ring), 1 recurrent cell above it (input side from
+//         its projection cell's granules), 2 projection cell;
+//   RR    2: exactly two edge features, gains folded inline (ogbg-code: `edge_attr` [E,2]); -1: any other count (run-time);
+//   EXTRA static scores or vertex-id key biases present (`*_x` aggregators, D-VAE NA).
+enum { DFK_REC0 = 0, DFK_RECP = 1, DFK_PROJ = 2 };
+// per-block stamps (scripts/df_stamps.py) only in a build with -DDF_STAMPS: the disabled form still costs a branch and
+// its scalar state in every block of every wave
+#ifdef DF_STAMPS
+constexpr bool DF_PROF = true;
+#else
+constexpr bool DF_PROF = false;
+#endif
 
 struct DfCell {
     const float4* w;      // packed slices (dagnn_pack_dataflow): W_hh (recurrent) or W_ih (projection)
@@ -299,6 +313,7 @@ struct DfCell {
                           // b_hh; projection: W_ih u + b_ih), or null
     int dir;
     int kind;
+    int variant;          // KIND * 4 + (RR == 2 ? 2 : 0) + EXTRA
 };
 
 #define DF_MAX_KCELLS 16
@@ -397,7 +412,7 @@ __device__ __forceinline__ bool df_retry(unsigned& spins, int* err, unsigned lim
 }
 
 // ---- loader wave: row `lw` of every block of this group
-template <int KPT>
+template <int KPT, int KIND, int RR, bool EXTRA>
 __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, const DfArgs& S,
                                           const DfCell& C, int sl, int group, const DfLds& lds, int w, int set) {
     constexpr int H = 16 * KPT;
@@ -410,22 +425,22 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
     const int32_t* __restrict__ recs = S.sched + S.grec[d] + 16 * (int64_t)rec_base;   // records of this stream (16 words each)
     const int32_t* __restrict__ col = plan + S.col[d];
     const float* __restrict__ eattr = reinterpret_cast<const float*>(plan + S.eattr[d]);
-    const bool proj = C.kind == DF_PROJECTION;
-    const int R = (C.gain && !proj) ? S.R : 0;
+    constexpr bool proj = KIND == DFK_PROJ;
+    const int R = proj ? 0 : (RR >= 0 ? RR : (C.gain ? S.R : 0));
     // everything the loop needs from the argument structs, read ONCE: a field access inside the loop is a scalar load
     // from the kernel-argument segment plus an lgkmcnt(0) wait on the dependent chain
     const unsigned epoch = S.epoch, spin_limit = S.spin_limit;
     int* const err = S.err;
     const gran_t* const g_src = proj ? C.g_in : C.g_out;   // rows this cell reads: the lower layer's / its own states
     const int gld = S.gld, pld = S.pld;
-    const gran_t* const p_in = C.p_in;
-    const float* const gi0 = C.gi0;
-    const float* const sscore = C.sscore;
-    const float* const vid = C.vid;
-    const float* const gainp = C.gain;
-    const int vid_mod = S.vid_mod;
+    const gran_t* const p_in = KIND == DFK_RECP ? C.p_in : nullptr;
+    const float* const gi0 = KIND == DFK_REC0 ? C.gi0 : nullptr;
+    const float* const sscore = EXTRA ? C.sscore : nullptr;
+    const float* const vid = EXTRA ? C.vid : nullptr;
+    const float* const gainp = proj ? nullptr : C.gain;
+    const int vid_mod = EXTRA ? S.vid_mod : 1;
     const float gain0 = R >= 1 ? C.gain[0] : 0.f, gain1 = R >= 2 ? C.gain[1] : 0.f;
-    unsigned long long* const dbg = S.dbg ? S.dbg + 2 * gridDim.x : nullptr;
+    unsigned long long* const dbg = (DF_PROF && S.dbg) ? S.dbg + 2 * gridDim.x : nullptr;
     const gran_t ready = (gran_t)epoch << 32;
     int* const dn = lds.dn + set * DF_NCW;   // this stream's slots
     // a lane holds columns {lane, 64 + lane, 128 + lane, 192 + lane} of a row (the first NQ4 = H / 64 of them): load
@@ -438,9 +453,9 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
     for (int q = 0; q < 4; ++q) {
         const int c = 64 * q + lane;
         cpos[q] = c + (SEG - KP8) * (c / KP8);
-        if (C.wkey && !proj && q < NQ4) wk[q] = C.wkey[c];
+        if (!proj && !(EXTRA && C.sscore) && q < NQ4) wk[q] = C.wkey[c];
     }
-    const bool prof_wave = dbg != nullptr && (int)blockIdx.x == S.dbg_wg && w == 0 && lane == 0;
+    const bool prof_wave = DF_PROF && dbg != nullptr && (int)blockIdx.x == S.dbg_wg && w == 0 && lane == 0;
     bool prof = prof_wave;
 
     // ---- memory traffic of this wave, by hand.  Three streams share the wave's in-order vmcnt counter: the granule
@@ -460,7 +475,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
     //    every H), the projection slice or not, no / record / record + gi0 prefetch.
     struct Sweep { gran_t x[4][4]; gran_t xp[3]; };
     const unsigned lane8 = 8u * lane, lane31x8 = 8u * (lane & 31);
-    const bool has_gi0 = gi0 != nullptr;
+    constexpr bool has_gi0 = KIND == DFK_REC0;
 #define DF_ROW_LD(e)                                                            \
     "global_load_dwordx2 %[x" #e "0], %[vo], %[b" #e "] offset:0 sc1\n\t"        \
     "global_load_dwordx2 %[x" #e "1], %[vo], %[b" #e "] offset:%[o1] sc1\n\t"    \
@@ -573,10 +588,12 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
         // one trip to memory: the rows pj[0..nn), the projection slice if `pp`, the prefetch group P(b) if `dma`
         // (1: record, 2: record + gi0 slice); returns with every register it loaded valid
         auto trip = [&](Sweep& W, int nn, bool pp, int dma, const int (&pj)[4], const gran_t* gp_in) {
-            const gran_t* b0 = g_src + (int64_t)pj[0] * gld;   // wave-uniform (unused slots: row 0, not loaded)
-            const gran_t* b1 = g_src + (int64_t)pj[1] * gld;
-            const gran_t* b2 = g_src + (int64_t)pj[2] * gld;
-            const gran_t* b3 = g_src + (int64_t)pj[3] * gld;
+            // wave-uniform row bases (unused slots: row 0, not loaded); N * gld granules fit 32 bits (host check): one
+            // 32-bit multiply + a 64-bit add per row instead of the five-instruction 64-bit product
+            const gran_t* b0 = g_src + (unsigned)pj[0] * (unsigned)gld;
+            const gran_t* b1 = g_src + (unsigned)pj[1] * (unsigned)gld;
+            const gran_t* b2 = g_src + (unsigned)pj[2] * (unsigned)gld;
+            const gran_t* b3 = g_src + (unsigned)pj[3] * (unsigned)gld;
             const gran_t* c0p = gp_in, * c1p = gp_in + H, * c2p = gp_in + 2 * H;
             const void* ra = rec_src(j + DF_RD);
             const unsigned rl = rec_dst(j + DF_RD);
@@ -595,9 +612,9 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             float m = -INFINITY, l = 0.f;
             // input-side pre-activations of the slice from the projection cell: 3 gates x 32 units, lanes 0..31
-            bool p_pending = p_in != nullptr;
+            bool p_pending = KIND == DFK_RECP;
             float pv[3] = {0.f, 0.f, 0.f};
-            const gran_t* gp_in = p_pending ? p_in + (int64_t)v * pld + sl * DF_JS : g_src;   // wave-uniform (g_src: never loaded)
+            const gran_t* gp_in = p_pending ? p_in + (unsigned)v * (unsigned)pld + sl * DF_JS : g_src;   // wave-uniform (g_src: never loaded)
             // in-edges in chunks of <= 4 (ids and features of the first chunk came with the record).  A node with more
             // than 4 in-edges takes two chunks per trip to memory (all of them finished long ago: the trips, not the
             // data, are what such a row waits for)
@@ -734,7 +751,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
             float* a_row = sbase + Slot::a_off + lw * Slot::AP;
 #pragma unroll
             for (int q = 0; q < NQ4; ++q) a_row[cpos[q]] = acc[q];
-            if (p_in && lane < 32) {
+            if (KIND == DFK_RECP && lane < 32) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) sbase[Slot::gi_off + lw * (3 * DF_JS) + g * DF_JS + lane] = pv[g];
             }
@@ -781,7 +798,7 @@ __device__ __forceinline__ float df_row_pair_sum(float x) {
 // v_permlane16_swap adds the neighbouring row): lane (quad, ks, x) ends with all three gate sums of unit
 // 4 quad + 2 (ks & 1) + ((ks >> 1) & 1) for row x, evaluates the gates and stores h' itself - no LDS exchange, no
 // barrier.  Always the same order of additions -> deterministic.
-template <int KPT>
+template <int KPT, int KIND>
 __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int sl, int pair, const DfLds& lds, int cw, int team) {
     constexpr int H = 16 * KPT;
     constexpr int SEG = DfPad<KPT>::seg, KP8 = DfPad<KPT>::kp8, NK4 = KP8 / 4;
@@ -790,9 +807,9 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     const int lane = tc & 63;
     const int quad = lane >> 5, ks = (lane >> 2) & 7, x = lane & 3;
     const bool s0 = (ks & 1) != 0, s1 = (ks & 2) != 0;
-    const bool proj = C.kind == DF_PROJECTION;
-    const bool has_gi = C.gi0 != nullptr || C.p_in != nullptr;
-    const bool gi_ring = C.gi0 != nullptr;   // (read once: a field access in the loop is a scalar load + lgkmcnt(0) per block)
+    constexpr bool proj = KIND == DFK_PROJ;
+    constexpr bool has_gi = !proj;
+    constexpr bool gi_ring = KIND == DFK_REC0;
     const int d = C.dir;
     // the two streams of this workgroup: groups NLS * pair and NLS * pair + 1 (the second may not exist)
     int nb[DF_NLS];   // blocks of the workgroup's streams (0: no such group)
@@ -827,8 +844,8 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     float* const aux_out = C.aux_out;
     gran_t* const g_out = C.g_out;
     const int ld_h = S.ld_h, gld = S.gld, pld = S.pld, num_nodes = S.N;
-    unsigned long long* const dbg = S.dbg ? S.dbg + 2 * gridDim.x : nullptr;
-    const bool prof = dbg != nullptr && (int)blockIdx.x == S.dbg_wg && cw == 0 && lane == 0;
+    unsigned long long* const dbg = (DF_PROF && S.dbg) ? S.dbg + 2 * gridDim.x : nullptr;
+    const bool prof = DF_PROF && dbg != nullptr && (int)blockIdx.x == S.dbg_wg && cw == 0 && lane == 0;
 
     // Blocks of the two streams in whatever order they become ready.  A stream inside a thin dependent chain is ready
     // once per hop (~3 us, of which this wave works ~0.8): the other stream's blocks fill the gap.  When both have a
@@ -1004,18 +1021,35 @@ __global__ void __launch_bounds__(DF_THREADS, 3) dataflow_kernel(const int32_t* 
     lds.rdy = flags;
     lds.dn = flags + DF_NLW;
     if (tid < DF_NLW + DF_NLS * DF_NCW) flags[tid] = 0;
-    if (S.dbg && tid == 0) S.dbg[2 * blockIdx.x] = wall_clock64();
-    if (S.dbg && (int)blockIdx.x == S.dbg_wg && (tid & 63) == 0)   // where the waves of the stamped workgroup run (HW_REG_HW_ID)
+    if (DF_PROF && S.dbg && tid == 0) S.dbg[2 * blockIdx.x] = wall_clock64();
+    if (DF_PROF && S.dbg && (int)blockIdx.x == S.dbg_wg && (tid & 63) == 0)   // where the waves of the stamped workgroup run (HW_REG_HW_ID)
         if (wave < 8) S.dbg[2 * gridDim.x + 8 * (int64_t)wave + 7] = 0x100000000ull | __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
     __syncthreads();
+    const int variant = C.variant;
     if (wave < DF_NCW * DF_TEAMS) {
-        df_compute<KPT>(S, C, sl, pair, lds, wave % DF_NCW, wave / DF_NCW);
+        const int cw = wave % DF_NCW, team = wave / DF_NCW;
+        switch (variant >> 2) {
+            case DFK_REC0: df_compute<KPT, DFK_REC0>(S, C, sl, pair, lds, cw, team); break;
+            case DFK_RECP: df_compute<KPT, DFK_RECP>(S, C, sl, pair, lds, cw, team); break;
+            default: df_compute<KPT, DFK_PROJ>(S, C, sl, pair, lds, cw, team); break;
+        }
     } else {
         const int set = (wave - DF_NCW * DF_TEAMS) / DF_WPS;
         const int grp = df_stream_group(pair, set, S.groups);
-        if (grp >= 0) df_loader<KPT>(plan, S, C, sl, grp, lds, (wave - DF_NCW * DF_TEAMS) % DF_WPS, set);
+        const int w = (wave - DF_NCW * DF_TEAMS) % DF_WPS;
+        if (grp >= 0) {
+#define DF_LOADER_CASE(K, RR, EX) case (K) * 4 + ((RR) == 2 ? 2 : 0) + ((EX) ? 1 : 0): df_loader<KPT, K, RR, EX>(plan, S, C, sl, grp, lds, w, set); break;
+            switch (variant) {
+                DF_LOADER_CASE(DFK_REC0, 2, false) DF_LOADER_CASE(DFK_REC0, 2, true)
+                DF_LOADER_CASE(DFK_REC0, -1, false) DF_LOADER_CASE(DFK_REC0, -1, true)
+                DF_LOADER_CASE(DFK_RECP, 2, false) DF_LOADER_CASE(DFK_RECP, 2, true)
+                DF_LOADER_CASE(DFK_RECP, -1, false) DF_LOADER_CASE(DFK_RECP, -1, true)
+                default: df_loader<KPT, DFK_PROJ, -1, false>(plan, S, C, sl, grp, lds, w, set); break;
+            }
+#undef DF_LOADER_CASE
+        }
     }
-    if (S.dbg && tid == 0) S.dbg[2 * blockIdx.x + 1] = wall_clock64();   // compute wave 0 is done
+    if (DF_PROF && S.dbg && tid == 0) S.dbg[2 * blockIdx.x + 1] = wall_clock64();   // compute wave 0 is done
 }
 
 template <int KPT> size_t df_lds_bytes() {
@@ -1158,6 +1192,8 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
         (Ls > 1 && a->pld < 3 * H) || G < 1 || G > DF_MAX_GROUPS || a->epoch == 0 || !a->err)
         return DAGNN_EINVAL;
     if (pl->B == 0 || pl->N == 0) return DAGNN_OK;
+    // row offsets inside the granule buffers are 32-bit in the kernel (granules: 8 bytes each)
+    if ((int64_t)pl->N * a->gld >= (1ll << 31) || (int64_t)pl->N * a->pld >= (1ll << 31)) return DAGNN_EINVAL;
     DfArgs S;
     int nc = 0;
     for (int d = 0; d < 2; ++d) {
@@ -1175,7 +1211,7 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
                 P.g_out = (gran_t*)c.proj_granules;
                 P.g_in = (const gran_t*)a->cell[d][i - 1].granules;
                 P.aux_out = c.gi_out;
-                P.dir = d; P.kind = DF_PROJECTION;
+                P.dir = d; P.kind = DF_PROJECTION; P.variant = DFK_PROJ * 4;
             }
             DfCell& K = S.cell[nc++];
             K.w = (const float4*)c.w_hh; K.bias = c.b_hh;
@@ -1190,6 +1226,7 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
             K.g_in = nullptr;
             K.aux_out = c.gh_out;
             K.dir = d; K.kind = DF_RECURRENT;
+            K.variant = (i == 0 ? DFK_REC0 : DFK_RECP) * 4 + ((K.gain && pl->num_edge_feats == 2) ? 2 : 0) + ((K.sscore || K.vid) ? 1 : 0);
         }
     }
     const DfLayout SL = df_layout_words(pl->N, pl->B, G);

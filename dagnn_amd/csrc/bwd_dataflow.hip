@@ -381,7 +381,7 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
             const int deg = ee - eb;
             const float* sa = stat + (int64_t)v * (BD_NSTAT * BD_SP);
             const float* sb = sa + 4 * BD_SP;
-            const gran_t* ub = HAS_DU ? du_in + (int64_t)v * gld : da_g;
+            const gran_t* ub = HAS_DU ? du_in + (unsigned)v * (unsigned)gld : da_g;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             float sig = 0.f, m0 = 0.f, m1 = 0.f;
             bf4 ST[BD_NSTAT];   // the node's static rows: outputs of the FIRST trip only, so they stay put across re-polls
@@ -402,10 +402,11 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                         if (R >= 2) f1[e] = eattr[(int64_t)(eb + c0 + e) * R + 1];
                     }
                 }
-                const gran_t* b0 = da_g + (int64_t)pj[0] * gld;
-                const gran_t* b1 = da_g + (int64_t)pj[1] * gld;
-                const gran_t* b2 = da_g + (int64_t)pj[2] * gld;
-                const gran_t* b3 = da_g + (int64_t)pj[3] * gld;
+                // (N * 3 gld granules fit 32 bits - host check: one 32-bit multiply per row base)
+                const gran_t* b0 = da_g + (unsigned)pj[0] * (unsigned)gld;
+                const gran_t* b1 = da_g + (unsigned)pj[1] * (unsigned)gld;
+                const gran_t* b2 = da_g + (unsigned)pj[2] * (unsigned)gld;
+                const gran_t* b3 = da_g + (unsigned)pj[3] * (unsigned)gld;
                 const gran_t* c0p = q_in + pj[0], * c1p = q_in + pj[1], * c2p = q_in + pj[2], * c3p = q_in + pj[3];
                 const bool first = c0 == 0;
                 bool stat_pending = first;
@@ -600,7 +601,7 @@ __device__ __forceinline__ void bd_loader_du(const BdArgs& S, const BdCell& C, i
         const void* ra = rec_src(j + BD_RD);
         const unsigned rl = rec_dst(j + BD_RD);
         if (v >= 0) {
-            const gran_t* g0 = dgi_in + (int64_t)v * (3 * gld);
+            const gran_t* g0 = dgi_in + (unsigned)v * (unsigned)(3 * gld);
             const gran_t* g1 = g0 + gld, * g2 = g0 + 2 * gld;
             unsigned spins = 0;
             bool dma = true;
@@ -846,6 +847,7 @@ extern "C" int dagnn_bwd_dataflow_run(const dagnn_plan* pl, const dagnn_bwd_data
         G > DF_MAX_GROUPS || a->epoch == 0 || !a->err)
         return DAGNN_EINVAL;
     if (pl->B == 0 || pl->N == 0) return DAGNN_OK;
+    if ((int64_t)pl->N * 3 * a->gld >= (1ll << 31)) return DAGNN_EINVAL;   // row offsets inside the granule buffers are 32-bit
     BdArgs S;
     BdCell* cells = S.cell;
     int nc = 0;

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p scripts/tmp
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -c -o scripts/tmp/dataflow_$name.o dagnn_amd/csrc/dataflow.hip "$@" -Rpass-analysis=kernel-resource-usage 2> scripts/tmp/build_$name.log || { tail -30 scripts/tmp/build_$name.log; exit 1; }
-objs=$(ls dagnn_amd/lib/obj/*.o | grep -v dataflow.o)
+objs=$(ls dagnn_amd/lib/obj/*.o | grep -v "/dataflow.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scripts/tmp/lib_$name.so $objs scripts/tmp/dataflow_$name.o
 grep -A12 "dataflow_kernelILi16" scripts/tmp/build_$name.log | grep -i "VGPRs:\|Spill\|LDS Size\|Occupancy" | head -8
 echo scripts/tmp/lib_$name.so

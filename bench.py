@@ -105,6 +105,16 @@ def cpu_baseline(model_cpu_sd, batch, L, S, passes, threads):
                                    "micro-step instead of the per-node edge scan), same threads"}}
 
 
+def kernel_sources_sha16():
+    """Fingerprint of the sources of the dominant kernel (what `roofline.traffic`'s PMC passes were collected with)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("dataflow.hip", "df_common.h", "common.h"):
+        with open(os.path.join(ROOT, "dagnn_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
     """One training step as ogbg-code/main_pyg.py:39-65 runs it: zero_grad, forward, mean-over-heads
     cross-entropy, backward, (N>1: the gradient all-reduce over RCCL in two buckets, the larger one overlapped), Adam step.
@@ -496,11 +506,18 @@ def main():
             if ms_fwd > 0:
                 tf = flops / (ms_fwd * 1e-3) / 1e12
                 traffic, traffic_source = None, None
-                tname = "r02_pmc_traffic.json" if df else "pmc_traffic.json"
+                tname = "r03_pmc_traffic.json" if df else "pmc_traffic.json"
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if lock and os.path.exists(tpath):  # separate rocprofv3 --pmc passes of this command, see profiles/README.md
-                    traffic = json.load(open(tpath)).get("recurrence_hbm_bytes_per_forward")
-                    traffic_source = "profiles/" + tname + " (separate rocprofv3 --pmc passes, not measured in this run)"
+                    rec = json.load(open(tpath))
+                    # the counters belong to the kernel sources they were collected with: a kernel change without a
+                    # new PMC run must not leave a stale number in this line
+                    if not df or rec.get("kernel_sources_sha16") == kernel_sources_sha16():
+                        traffic = rec.get("recurrence_hbm_bytes_per_forward")
+                        traffic_source = "profiles/" + tname + " (separate rocprofv3 --pmc passes, not measured in this run)"
+                    else:
+                        traffic_source = ("profiles/%s is older than the kernel sources (sha %s, now %s): re-run "
+                                          "scripts/pmc_traffic.sh" % (tname, rec.get("kernel_sources_sha16"), kernel_sources_sha16()))
                 if df:
                     kname = ("dataflow_kernel<H/16> (dagnn_dataflow_run): ONE persistent launch per forward(G) for the "
                              "whole recurrence - every (direction, stacked layer) cell plus the input-side projection "

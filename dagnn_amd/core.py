@@ -157,6 +157,31 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
     return c
 
 
+_OFF_DATAFLOW_SEEN = set()
+
+
+def _warn_off_dataflow(dev, ndirs: int, L: int, Hp: int) -> None:
+    """Say ONCE per model shape that it runs on the per-layer launches instead of the persistent dataflow kernel (which
+    is 1.5-2x faster where it applies): the applicability limits are otherwise a silent cliff."""
+    key = (str(dev), ndirs, L, Hp)
+    if key in _OFF_DATAFLOW_SEEN:
+        return
+    _OFF_DATAFLOW_SEEN.add(key)
+    import warnings
+    cells = ndirs * (2 * L - 1)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    if Hp > 256:
+        why = "hidden size %d > 256 (a 32-unit slice of the [3H, H] matrices no longer fits the register file)" % Hp
+    elif cells > 24:
+        why = "%d kernel cells (directions x (2 x stacked layers - 1)) > 24" % cells
+    elif cells * (Hp // 32) > cus:
+        why = "%d kernel cells x %d slices need more than the %d CUs of this device" % (cells, Hp // 32, cus)
+    else:
+        why = "the kernel does not apply to this shape"
+    warnings.warn("dagnn_amd: this model (hidden %d, %d stacked layers, %d direction(s)) runs on the per-layer launch path, "
+                  "not the persistent dataflow kernel: %s" % (Hp, L, ndirs, why), RuntimeWarning, stacklevel=3)
+
+
 def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tuple[int, int], CellParams],
                        dirs: Sequence[int], L: int, H: int, vid_nodes: int = 0,
                        arena: Optional[engine.GranuleArena] = None, static_score=None,
@@ -177,6 +202,8 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
     groups = engine.dataflow_groups(dev, len(dirs), L, Hp, plan.B) if (arena is not None and N > 0) else 0
     if arena is not None:
         arena.poll()   # a failure an earlier pass reported (no synchronisation); either path below is watched
+    if groups == 0 and arena is not None and N > 0 and engine.DATAFLOW:
+        _warn_off_dataflow(dev, len(dirs), L, Hp)
     if groups > 0:
         pack_dataflow(cells.values())
         preact = {} if (keep is not None and engine.BWD_DATAFLOW) else None

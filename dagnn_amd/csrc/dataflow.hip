@@ -316,7 +316,7 @@ struct DfCell {
     int variant;          // KIND * 4 + (RR == 2 ? 2 : 0) + EXTRA
 };
 
-#define DF_MAX_KCELLS 16
+#define DF_MAX_KCELLS 24   // (24 x 144 bytes of cell table + the rest stay inside the 4 KB kernel-argument segment)
 
 struct DfArgs {
     DfCell cell[DF_MAX_KCELLS];
@@ -330,6 +330,8 @@ struct DfArgs {
     int* err;
     unsigned long long* dbg;    // optional: [grid][2] start / end stamps, then [blocks][8] stamps of workgroup dbg_wg (100 MHz)
 };
+
+static_assert(sizeof(DfArgs) + 8 <= 4096, "the cell table must fit the kernel-argument segment");
 
 __device__ __forceinline__ float df_dpp_row_sum16(float v) {
 #define DF_DPP_ADD(ctrl) \

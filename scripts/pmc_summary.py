@@ -33,6 +33,17 @@ def fold(path):
     return tot, cnt
 
 
+def sources_sha16():
+    """Same fingerprint as bench.kernel_sources_sha16: the counters are only valid for these kernel sources."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for name in ("dataflow.hip", "df_common.h", "common.h"):
+        with open(os.path.join(root, "dagnn_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     fetch_csv, write_csv, forwards = sys.argv[1], sys.argv[2], int(sys.argv[3])
     out_name = sys.argv[4] if len(sys.argv) > 4 else "pmc_traffic.json"
@@ -56,6 +67,7 @@ def main():
                 "gfx950; WRITE_SIZE is used as reported. Produced by scripts/pmc_summary.py." % forwards,
         "per_forward": per,
         "recurrence_kernels": list(RECURRENCE),
+        "kernel_sources_sha16": sources_sha16(),
         "recurrence_hbm_bytes_per_forward": int(rec_bytes),
     }
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -339,6 +339,59 @@ def test_wide_deep_config_matches_oracle(device, schedule):
     assert max(Hh.maxdiff(o, r) for o, r in zip(out, ref)) < TOL
 
 
+def test_deep_stack_runs_on_the_dataflow_kernel(device, monkeypatch):
+    """L = 5 stacked layers, h = 256, bidirectional = 18 kernel cells (more than round 2's 16-cell cap): forward and
+    one training step on the persistent dataflow kernels, against the oracle; the same model with the dataflow path
+    switched off agrees; and a model the dataflow kernel does not cover says so once."""
+    import warnings
+    calls = []
+    lib = engine._lib.load()
+    orig = lib.dagnn_dataflow_run
+    monkeypatch.setattr(engine, "DATAFLOW", 1)
+    model = _headline_model(H=256, L=5, V=24, seed=9)
+    b = synth.code2_batch(17, 20, 40)
+    ref = O.code2_forward(model.state_dict(), copy.deepcopy(b), num_layers=5, bidirectional=True, out_wx=False,
+                          out_pool_all=False, out_pool="max", max_seq_len=5)
+    model = model.to(device)
+    assert engine.dataflow_groups(device, 2, 5, 256, 20) > 0
+    with torch.no_grad():
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")   # on the dataflow path: no fall-back warning
+            out = model(b.clone().to(device))
+        assert max(Hh.maxdiff(o, r) for o, r in zip(out, ref)) < TOL
+        monkeypatch.setattr(engine, "DATAFLOW", 0)
+        for c in model._derived.values():
+            c.invalidate()
+        out0 = model(b.clone().to(device))
+        monkeypatch.setattr(engine, "DATAFLOW", 1)
+        for c in model._derived.values():
+            c.invalidate()
+        assert max(Hh.maxdiff(o, r) for o, r in zip(out, out0)) < 2e-5
+    model.check()
+    y = torch.randint(0, 24, (20, 5), generator=torch.Generator().manual_seed(2))
+    sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    loss_ref, grads_ref = O.code2_grads(sd_cpu, copy.deepcopy(b), y, num_layers=5, bidirectional=True, max_seq_len=5)
+    loss, grads = _train_step(model, b.clone().to(device), y.to(device))
+    model.check()
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    for k, g in grads_ref.items():
+        scale = max(float(g.abs().max()), 1e-6)
+        got = grads.get(k)
+        got = torch.zeros_like(g) if got is None else got.cpu()
+        assert float((got - g).abs().max()) <= 2e-4 * scale + 2e-7, k
+    # a shape the kernel does not cover (h = 512) falls back to the per-layer launches and says so, once
+    from dagnn_amd import core
+    core._OFF_DATAFLOW_SEEN.clear()
+    wide = _headline_model(H=512, L=2, V=8, seed=1).to(device)
+    small = synth.code2_batch(3, 4, 12)
+    with torch.no_grad():
+        with pytest.warns(RuntimeWarning, match="per-layer launch path"):
+            wide(small.clone().to(device))
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            wide(small.clone().to(device))
+
+
 def _degenerate_batch():
     """Single-node graphs, a chain, stars with a 200-way fan-in / fan-out, a graph with no edges, a duplicate edge."""
     from dagnn_amd import GraphData

@@ -314,9 +314,12 @@ struct DfCell {
     int dir;
     int kind;
     int variant;          // KIND * 4 + (RR == 2 ? 2 : 0) + EXTRA
+    int partner;          // recurrent: index of the projection cell that reads this cell's state rows, or -1
 };
 
-#define DF_MAX_KCELLS 24   // (24 x 144 bytes of cell table + the rest stay inside the 4 KB kernel-argument segment)
+#define DF_MAX_KCELLS 24   // (24 x 112 bytes of cell table + the role table + the rest stay inside the 4 KB kernel-argument segment)
+#define DF_MAX_WGS 320     // workgroups the XCD-aware placement table covers (one per CU)
+#define DF_IDLE_ROLE 0xffffu
 
 struct DfArgs {
     DfCell cell[DF_MAX_KCELLS];
@@ -329,9 +332,17 @@ struct DfArgs {
     const int32_t* status;      // plan status word (dagnn_plan_build), or null
     int* err;
     unsigned long long* dbg;    // optional: [grid][2] start / end stamps, then [blocks][8] stamps of workgroup dbg_wg (100 MHz)
+    // XCD-aware placement (nroles > 0): role[b] = set << 10 | cell << 5 | slice of workgroup b (DF_IDLE_ROLE: none), chosen so
+    // that - with the observed dispatch rule "workgroup b runs on XCD b % 8" - a recurrent cell's 8 slices and the
+    // projection cell reading its rows share one XCD, i.e. one L2.  Nothing is ASSUMED about the placement: every
+    // workgroup publishes the XCD it actually runs on (xcc_tab, tagged granules) and a recurrent cell keeps its state rows
+    // in that L2 (plain stores instead of write-through ones) only when it SEES all their readers there.
+    gran_t* xcc_tab;
+    int nroles;
+    unsigned short role[DF_MAX_WGS];
 };
 
-static_assert(sizeof(DfArgs) + 8 <= 4096, "the cell table must fit the kernel-argument segment");
+static_assert(sizeof(DfArgs) + 8 <= 4096, "the cell and role tables must fit the kernel-argument segment");
 
 __device__ __forceinline__ float df_dpp_row_sum16(float v) {
 #define DF_DPP_ADD(ctrl) \
@@ -377,6 +388,7 @@ struct DfLds {
     int* rec;        // [NLS * RB][8][16]: row records of the loader waves, landed by LDS-DMA DF_RD of their blocks ahead
     int* rdy;        // [NLS][WPS]  per loader wave: blocks it has finished (relaxed workgroup-scope atomics: plain ds_ accesses;
     int* dn;         // [NLS][NCW]  per stream and compute wave likewise   a volatile access here compiles to a FLAT load + vmcnt(0))
+    int* local;      // [1] every reader of this cell's state rows runs on this workgroup's XCD (see DfArgs::role)
 };
 
 template <int KPT> struct DfSlot {
@@ -845,6 +857,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     float* const h_out = C.h_out;
     float* const aux_out = C.aux_out;
     gran_t* const g_out = C.g_out;
+    const bool local_st = !proj && lds.local[0] != 0;
     const int ld_h = S.ld_h, gld = S.gld, pld = S.pld, num_nodes = S.N;
     unsigned long long* const dbg = (DF_PROF && S.dbg) ? S.dbg + 2 * gridDim.x : nullptr;
     const bool prof = DF_PROF && dbg != nullptr && (int)blockIdx.x == S.dbg_wg && cw == 0 && lane == 0;
@@ -983,7 +996,10 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
                 __hip_atomic_store(po + 2 * H, gran_pack(epoch, g3[2] + b_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 h_out[(int64_t)gv * ld_h + unit] = hv;
-                __hip_atomic_store(g_out + (int64_t)gv * gld + unit, gran_pack(epoch, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // hand-off store: write-through (sc1: the line leaves this XCD's L2, any XCD's sc1 load finds it in
+                // memory), or - all readers are on this XCD - a plain 8-byte store that leaves the line in the shared L2
+                if (local_st) g_out[(int64_t)gv * gld + unit] = gran_pack(epoch, hv);
+                else __hip_atomic_store(g_out + (int64_t)gv * gld + unit, gran_pack(epoch, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (aux_out) {   // (behind the hand-off stores: nobody waits for these)
                 float* ao = aux_out + (int64_t)gv * (3 * H) + unit;
@@ -1009,11 +1025,18 @@ __global__ void __launch_bounds__(DF_THREADS, 3) dataflow_kernel(const int32_t* 
         return;                                                                                      // index gtab / grec out of bounds
     }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // a workgroup serves NLS groups ("streams"): workgroup ids are pair-major, then cell, then slice
-    const int per_pair = S.ncell * NS;
-    const int pair = blockIdx.x / per_pair;
-    const int rem = blockIdx.x - pair * per_pair;
-    const int c = rem / NS, sl = rem - c * NS;
+    // a workgroup serves NLS groups ("streams"): by the placement table, or workgroup ids pair-major, then cell, then slice
+    int pair, c, sl;
+    if (S.nroles > 0) {
+        const unsigned role = S.role[blockIdx.x];
+        if (role == DF_IDLE_ROLE) return;
+        pair = (int)(role >> 10); c = (int)((role >> 5) & 31u); sl = (int)(role & 31u);
+    } else {
+        const int per_pair = S.ncell * NS;
+        pair = blockIdx.x / per_pair;
+        const int rem = blockIdx.x - pair * per_pair;
+        c = rem / NS; sl = rem - c * NS;
+    }
     const DfCell& C = S.cell[c];
     DfLds lds;
     lds.ring = smem;
@@ -1022,7 +1045,38 @@ __global__ void __launch_bounds__(DF_THREADS, 3) dataflow_kernel(const int32_t* 
     int* flags = lds.rec + DF_NLS * DF_RB * 8 * 16;
     lds.rdy = flags;
     lds.dn = flags + DF_NLW;
-    if (tid < DF_NLW + DF_NLS * DF_NCW) flags[tid] = 0;
+    lds.local = flags + DF_NLW + DF_NLS * DF_NCW;
+    if (tid < DF_NLW + DF_NLS * DF_NCW + 1) flags[tid] = 0;
+    if (S.nroles > 0 && wave == 0) {
+        // where does this workgroup really run?  Publish it, and - recurrent cells - look where the readers of this cell's
+        // state rows run: its own slices and the slices of the projection cell above it, same workgroup set
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 15u;
+        if ((tid & 63) == 0)
+            __hip_atomic_store(S.xcc_tab + blockIdx.x, gran_pack(S.epoch, __uint_as_float(xcc)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (C.kind == DF_RECURRENT) {
+            bool same = true;
+            for (int b0 = 0; b0 < S.nroles; b0 += 64) {
+                const int b = b0 + (tid & 63);
+                const unsigned r = b < S.nroles ? S.role[b] : DF_IDLE_ROLE;
+                const int rc = (int)((r >> 5) & 31u);
+                const bool member = r != DF_IDLE_ROLE && (int)(r >> 10) == pair && (rc == c || rc == C.partner);
+                unsigned spins = 0;
+                bool have = !member;
+                unsigned theirs = xcc;
+                for (;;) {
+                    if (!have) {
+                        const gran_t g = gran_ld(S.xcc_tab + b);
+                        if ((unsigned)(g >> 32) == S.epoch) { theirs = (unsigned)g; have = true; }
+                    }
+                    if (__all(have) || !df_retry(spins, S.err, S.spin_limit)) break;
+                }
+                same = same && have && theirs == xcc;
+            }
+            if (__all(same) && (tid & 63) == 0) lds.local[0] = 1;
+        }
+    }
     if (DF_PROF && S.dbg && tid == 0) S.dbg[2 * blockIdx.x] = wall_clock64();
     if (DF_PROF && S.dbg && (int)blockIdx.x == S.dbg_wg && (tid & 63) == 0)   // where the waves of the stamped workgroup run (HW_REG_HW_ID)
         if (wave < 8) S.dbg[2 * gridDim.x + 8 * (int64_t)wave + 7] = 0x100000000ull | __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
@@ -1213,7 +1267,8 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
                 P.g_out = (gran_t*)c.proj_granules;
                 P.g_in = (const gran_t*)a->cell[d][i - 1].granules;
                 P.aux_out = c.gi_out;
-                P.dir = d; P.kind = DF_PROJECTION; P.variant = DFK_PROJ * 4;
+                P.dir = d; P.kind = DF_PROJECTION; P.variant = DFK_PROJ * 4; P.partner = -1;
+                S.cell[nc - 2].partner = nc - 1;   // (the cell before it in the table is the recurrent cell whose rows it reads)
             }
             DfCell& K = S.cell[nc++];
             K.w = (const float4*)c.w_hh; K.bias = c.b_hh;
@@ -1229,6 +1284,7 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
             K.aux_out = c.gh_out;
             K.dir = d; K.kind = DF_RECURRENT;
             K.variant = (i == 0 ? DFK_REC0 : DFK_RECP) * 4 + ((K.gain && pl->num_edge_feats == 2) ? 2 : 0) + ((K.sscore || K.vid) ? 1 : 0);
+            K.partner = -1;
         }
     }
     const DfLayout SL = df_layout_words(pl->N, pl->B, G);
@@ -1244,7 +1300,38 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
     S.dbg_wg = a->debug_wg;
     S.status = (const int32_t*)a->plan_status;
     const int32_t* plan = (const int32_t*)pl->data;
-    const unsigned grid = (unsigned)(df_sets_for(G) * nc * (H / DF_JS));
+    unsigned grid = (unsigned)(df_sets_for(G) * nc * (H / DF_JS));
+    // XCD-aware placement (optional: the caller names the CU count and lends a tagged table): units = a recurrent cell's
+    // slices + the slices of the projection cell reading its rows; bins = the 8 XCDs (num_cus / 8 CUs each, one workgroup
+    // per CU); largest units first, first fit; workgroup (slot k of XCD x) = k * 8 + x under the observed dispatch rule.
+    // If the units do not fit, the linear mapping stays (and every hand-off store is write-through, as before).
+    S.nroles = 0; S.xcc_tab = (gran_t*)a->xcc_table;
+    if (a->num_cus >= 8 && a->num_cus <= DF_MAX_WGS && a->xcc_table && df_sets_for(G) < 64 && nc <= 31) {
+        const int NS = H / DF_JS, sets = df_sets_for(G), cap = a->num_cus / 8;
+        int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < DF_MAX_WGS; ++b) S.role[b] = DF_IDLE_ROLE;
+        bool ok = true;
+        int top = 0;
+        for (int pass = 0; pass < 2 && ok; ++pass)       // pass 0: units with a partner (2 NS workgroups), pass 1: without
+            for (int set = 0; set < sets && ok; ++set)
+                for (int c = 0; c < nc && ok; ++c) {
+                    if (S.cell[c].kind != DF_RECURRENT || (S.cell[c].partner >= 0) != (pass == 0)) continue;
+                    const int members[2] = {c, S.cell[c].partner};
+                    const int size = NS * (members[1] >= 0 ? 2 : 1);
+                    int x = 0;
+                    while (x < 8 && fill[x] + size > cap) ++x;
+                    if (x == 8) { ok = false; break; }
+                    for (int m = 0; m < 2; ++m) {
+                        if (members[m] < 0) continue;
+                        for (int sl = 0; sl < NS; ++sl) {
+                            const int b = fill[x]++ * 8 + x;
+                            S.role[b] = (unsigned short)((set << 10) | (members[m] << 5) | sl);
+                            if (b + 1 > top) top = b + 1;
+                        }
+                    }
+                }
+        if (ok) { S.nroles = top; grid = (unsigned)top; }
+    }
     hipStream_t st = (hipStream_t)stream;
 #define DF_LAUNCH(KPT)                                                                                                   \
     do {                                                                                                                 \

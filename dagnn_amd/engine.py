@@ -86,6 +86,7 @@ DF_COST_LAYER = _env_int("DAGNN_AMD_DF_COST_LAYER", 6)      # schedule cost of o
                                                             # round 3, after the per-block cost dropped: 4 -> 6, scripts/df_cost_sweep.py)
 DF_COST_ROW = _env_int("DAGNN_AMD_DF_COST_ROW", 1)
 DF_GROUPS = _env_int("DAGNN_AMD_DF_GROUPS", 0)              # 0 = as many groups as the device hosts
+DF_XCD = _env_int("DAGNN_AMD_DF_XCD", 1)                    # 1: XCD-aware workgroup ids + hand-offs through the shared L2 where the run-time check allows
 BWD_DATAFLOW = _env_int("DAGNN_AMD_BWD_DATAFLOW", 1)        # 1: the reverse sweep as one persistent dataflow launch (H <= 256)
 SPIN_LIMIT = _env_int("DAGNN_AMD_SPIN_LIMIT", 0)            # polls before a device-side wait gives up; 0 = library default
 DEBUG_TIMING: Optional[torch.Tensor] = None  # int64[8] device tensor: phase ticks of the deepest work item
@@ -403,6 +404,9 @@ def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     args.debug_timing = DEBUG_TIMING.data_ptr() if DEBUG_TIMING is not None else None
     args.spin_limit = SPIN_LIMIT
     args.debug_wg = _env_int("DAGNN_AMD_DEBUG_WG", 0)
+    if DF_XCD:
+        args.num_cus = torch.cuda.get_device_properties(plan.ws.device).multi_processor_count
+        args.xcc_table = arena.xcc_table(plan.ws.device).data_ptr()
     args.plan_status = plan.status.data_ptr()
     with _span("dataflow_run", plan.ws):
         check(lib.dagnn_dataflow_run(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_dataflow_run")
@@ -442,6 +446,15 @@ class GranuleArena(object):
             self.err = torch.zeros(1, dtype=torch.int32, device=device)
         self.epoch += 1
         return self.bufs, self.epoch, self.err
+
+    def xcc_table(self, device):
+        """Tagged table the workgroups of a dataflow launch publish their XCD in (zero-initialised once, tagged with the
+        arena's epochs like the granule buffers; re-created with them)."""
+        t = getattr(self, "_xcc", None)
+        if t is None or t.device != device or getattr(self, "_xcc_gen", None) is not self.err:
+            t = self._xcc = torch.zeros(1024, dtype=torch.int64, device=device)
+            self._xcc_gen = self.err   # (the arena restarts its epochs whenever it re-creates `err`)
+        return t
 
     def side_stream(self, device):
         """Second stream for the split mode (created once): the persistent kernel runs on it next to the per-layer

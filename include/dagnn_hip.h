@@ -303,6 +303,14 @@ typedef struct dagnn_dataflow_args {
                             * workgroup, then [blocks][8] phase stamps of workgroup `debug_wg` */
     unsigned spin_limit;   /* polls before a wait gives up and raises `err`; 0 = default (1 << 22, seconds) */
     int debug_wg;          /* workgroup whose blocks are stamped (debug_timing) */
+    /* XCD-aware placement (optional, a speed hint that is verified at run time): with `num_cus` (CUs of the device, one
+     * workgroup per CU) and `xcc_table` (uint64 [num_cus], zero-initialised once, same epoch contract as `granules`) the
+     * workgroups of a recurrent cell and of the projection cell reading its rows are given ids that the observed dispatch
+     * rule (workgroup b -> XCD b % 8) puts on one XCD.  Every workgroup publishes the XCD it really runs on; a cell whose
+     * readers all share its XCD hands its rows over through that XCD's L2 (plain stores) instead of write-through ones -
+     * results are identical either way.  0 / NULL: linear ids, write-through stores. */
+    int num_cus;
+    void* xcc_table;
     const void* plan_status; /* NULL, or the device status word of dagnn_plan_build: if it is nonzero (the batch violates
                             * the layout contract) the launch walks nothing and raises bit 2 of `err` */
 } dagnn_dataflow_args;

@@ -64,9 +64,12 @@ struct BdCell {            // (104 bytes: 30 kernel cells - 8 stacked layers, bo
     float* sig;            // da: [N]
     float* mrel;           // da: [N, R] or null
     int dir, kind;
+    int partner, pad_;     // da: index of the input-gradient cell that reads this cell's dgi granules, or -1
 };
 
-#define BD_MAX_KCELLS 30
+#define BD_MAX_KCELLS 24
+#define BD_MAX_WGS 320
+#define BD_IDLE_ROLE 0xffffu
 
 struct BdArgs {
     BdCell cell[BD_MAX_KCELLS];
@@ -78,7 +81,13 @@ struct BdArgs {
     unsigned epoch, spin_limit;
     const int32_t* status;
     int* err;
+    // XCD-aware placement, verified at run time (see DfArgs::role in dataflow.hip): unit = a state-gradient cell's slices +
+    // the slices of its input-gradient cell; da / q / dgi granules stay in the XCD's L2 when all of them run there
+    gran_t* xcc_tab;
+    int nroles;
+    unsigned short role[BD_MAX_WGS];
 };
+static_assert(sizeof(BdArgs) + 8 <= 4096, "the cell and role tables must fit the kernel-argument segment");
 
 template <int KPT> struct BdPad { static constexpr int kp8 = 2 * KPT; static constexpr int seg = kp8 + 4; static constexpr int row = 8 * seg + 8; };
 
@@ -96,6 +105,7 @@ struct BdLds {
     int* rdy;      // [NLS][WPS]
     int* dn;       // [NLS][NCW]
     int* dump;     // [NLS * RB][64] landing area of the L2 warm-up DMAs (never read)
+    int* local;    // [1] every reader of this cell's granules runs on this workgroup's XCD
 };
 
 __device__ __forceinline__ int bd_flag_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -357,6 +367,7 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
     // L2 warm-up (see BD_STAT_1): lane l asks for line l of the next block's static record; the dump area is this wave's
     unsigned* const dump = reinterpret_cast<unsigned*>(lds.dump) + ((set * DF_RB + lw) * 64);
     const unsigned pl = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)dump);
+    const bool local_st = lds.local[0] != 0;
     const int myq = sl >> 1;
     const bool mine = (lane >> 5) == (sl & 1);
     auto pick = [&](const float (&a)[4]) -> float { return myq == 0 ? a[0] : (myq == 1 ? a[1] : (myq == 2 ? a[2] : a[3])); };
@@ -496,9 +507,13 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                 oh[c] = mr; oh[H + c] = mz; oh[2 * H + c] = mnr;
                 if (dgi_g) {
                     gran_t* pg = dgi_g + (int64_t)v * (3 * gld) + c;
-                    __hip_atomic_store(pg, gran_pack(epoch, mr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(pg + gld, gran_pack(epoch, mz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(pg + 2 * gld, gran_pack(epoch, mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (local_st) {   // (readers on this XCD: the lines stay in its L2)
+                        pg[0] = gran_pack(epoch, mr); pg[gld] = gran_pack(epoch, mz); pg[2 * gld] = gran_pack(epoch, mn);
+                    } else {
+                        __hip_atomic_store(pg, gran_pack(epoch, mr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(pg + gld, gran_pack(epoch, mz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(pg + 2 * gld, gran_pack(epoch, mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
             if (sl == 0) {   // q_v = G_v . c_q,v; the row's scalar outputs
@@ -508,7 +523,8 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                 if (NQ4 > 3) qd = fmaf(G[3], ST[ST_CQ].w, qd);
                 qd = bd_wave_sum(qd);
                 if (lane == 0) {
-                    __hip_atomic_store(q_out + v, gran_pack(epoch, qd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (local_st) q_out[v] = gran_pack(epoch, qd);
+                    else __hip_atomic_store(q_out + v, gran_pack(epoch, qd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     sig_out[v] = sig;
                     if (R >= 1) mrel[(int64_t)v * R] = m0;
                     if (R >= 2) mrel[(int64_t)v * R + 1] = m1;
@@ -673,6 +689,7 @@ __device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int
     int* const err = S.err;
     gran_t* const out_g = C.out_g;
     const int gld = S.gld, num_nodes = S.N;
+    const bool local_st = is_da && lds.local[0] != 0;
 
     int done[DF_NLS];
     int left = 0, pref = 0;
@@ -747,8 +764,10 @@ __device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int
         const bool live = gr < nr && (unsigned)gv < (unsigned)num_nodes && (lane & 16) == 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) bd_flag_st(lds.dn + st * DF_NCW + cw, b + 1);
-        if (live)
-            __hip_atomic_store(out_g + (int64_t)gv * gld + unit, gran_pack(epoch, gsum + zgv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (live) {
+            if (local_st) out_g[(int64_t)gv * gld + unit] = gran_pack(epoch, gsum + zgv);
+            else __hip_atomic_store(out_g + (int64_t)gv * gld + unit, gran_pack(epoch, gsum + zgv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -767,10 +786,17 @@ __global__ void __launch_bounds__(BD_THREADS, 3) bwd_dataflow_kernel(const int32
         return;
     }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int per_pair = S.ncell * NS;
-    const int pair = blockIdx.x / per_pair;
-    const int rem = blockIdx.x - pair * per_pair;
-    const int c = rem / NS, sl = rem - c * NS;
+    int pair, c, sl;
+    if (S.nroles > 0) {
+        const unsigned role = S.role[blockIdx.x];
+        if (role == BD_IDLE_ROLE) return;
+        pair = (int)(role >> 10); c = (int)((role >> 5) & 31u); sl = (int)(role & 31u);
+    } else {
+        const int per_pair = S.ncell * NS;
+        pair = blockIdx.x / per_pair;
+        const int rem = blockIdx.x - pair * per_pair;
+        c = rem / NS; sl = rem - c * NS;
+    }
     const BdCell& C = S.cell[c];
     BdLds lds;
     lds.ring = smem;
@@ -779,7 +805,37 @@ __global__ void __launch_bounds__(BD_THREADS, 3) bwd_dataflow_kernel(const int32
     lds.rdy = flags;
     lds.dn = flags + BD_NLW;
     lds.dump = flags + BD_NLW + DF_NLS * DF_NCW;
+    lds.local = lds.dump + DF_NLS * DF_RB * 64;
     if (tid < BD_NLW + DF_NLS * DF_NCW) flags[tid] = 0;
+    if (tid == 0) lds.local[0] = 0;
+    if (S.nroles > 0 && wave == 0) {   // publish where this workgroup runs; state-gradient cells look at their unit
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 15u;
+        if ((tid & 63) == 0)
+            __hip_atomic_store(S.xcc_tab + blockIdx.x, gran_pack(S.epoch, __uint_as_float(xcc)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (C.kind == BD_DA) {
+            bool same = true;
+            for (int b0 = 0; b0 < S.nroles; b0 += 64) {
+                const int b = b0 + (tid & 63);
+                const unsigned r = b < S.nroles ? S.role[b] : BD_IDLE_ROLE;
+                const int rc = (int)((r >> 5) & 31u);
+                const bool member = r != BD_IDLE_ROLE && (int)(r >> 10) == pair && (rc == c || rc == C.partner);
+                unsigned spins = 0;
+                bool have = !member;
+                unsigned theirs = xcc;
+                for (;;) {
+                    if (!have) {
+                        const gran_t g = gran_ld(S.xcc_tab + b);
+                        if ((unsigned)(g >> 32) == S.epoch) { theirs = (unsigned)g; have = true; }
+                    }
+                    if (__all(have) || !bd_retry(spins, S.err, S.spin_limit)) break;
+                }
+                same = same && have && theirs == xcc;
+            }
+            if (__all(same) && (tid & 63) == 0) lds.local[0] = 1;
+        }
+    }
     __syncthreads();
     if (wave < DF_NCW) {
         bd_compute<KPT>(S, C, sl, pair, lds, wave);
@@ -795,7 +851,7 @@ __global__ void __launch_bounds__(BD_THREADS, 3) bwd_dataflow_kernel(const int32
 }
 
 template <int KPT> size_t bd_lds_bytes() {
-    return (size_t)(DF_NLS * (BD_NSLOT * BdSlot<KPT>::words + DF_RB * 8 * 16) + BD_NLW + DF_NLS * DF_NCW + DF_NLS * DF_RB * 64) * 4 + 256;
+    return (size_t)(DF_NLS * (BD_NSLOT * BdSlot<KPT>::words + DF_RB * 8 * 16) + BD_NLW + DF_NLS * DF_NCW + DF_NLS * DF_RB * 64 + 4) * 4 + 256;
 }
 
 }  // namespace
@@ -866,14 +922,14 @@ extern "C" int dagnn_bwd_dataflow_run(const dagnn_plan* pl, const dagnn_bwd_data
             K.out_g = (gran_t*)c.da_granules; K.q_g = (gran_t*)c.q_granules;
             K.dgi_g = i > 0 ? (gran_t*)c.dgi_granules : nullptr;
             K.dgi = c.dgi; K.dgh = c.dgh; K.sig = c.sigma; K.mrel = pl->num_edge_feats > 0 ? c.edge_feat_grad : nullptr;
-            K.dir = d; K.kind = BD_DA;
+            K.dir = d; K.kind = BD_DA; K.partner = i > 0 ? nc + 1 : -1;
             cells[nc++] = K;
             if (i > 0) {
                 BdCell U = {};
                 U.w = (const float4*)c.w_ih_t;
                 U.dgi_g = (gran_t*)c.dgi_granules;
                 U.out_g = (gran_t*)a->cell[d][i - 1].du_granules;
-                U.dir = d; U.kind = BD_DU;
+                U.dir = d; U.kind = BD_DU; U.partner = -1;
                 cells[nc++] = U;
             }
         }
@@ -894,7 +950,34 @@ extern "C" int dagnn_bwd_dataflow_run(const dagnn_plan* pl, const dagnn_bwd_data
     S.epoch = a->epoch; S.spin_limit = a->spin_limit ? a->spin_limit : (1u << 22);
     S.status = (const int32_t*)a->plan_status;
     S.err = (int*)a->err;
-    const unsigned grid = (unsigned)(sets * nc * NS);
+    unsigned grid = (unsigned)(sets * nc * NS);
+    S.nroles = 0; S.xcc_tab = (gran_t*)a->xcc_table;
+    if (a->num_cus >= 8 && a->num_cus <= BD_MAX_WGS && a->xcc_table && sets < 64 && nc <= 31) {   // (dataflow.hip: same packing)
+        const int cap = a->num_cus / 8;
+        int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < BD_MAX_WGS; ++b) S.role[b] = BD_IDLE_ROLE;
+        bool ok = true;
+        int top = 0;
+        for (int pass = 0; pass < 2 && ok; ++pass)
+            for (int set = 0; set < sets && ok; ++set)
+                for (int c = 0; c < nc && ok; ++c) {
+                    if (S.cell[c].kind != BD_DA || (S.cell[c].partner >= 0) != (pass == 0)) continue;
+                    const int members[2] = {c, S.cell[c].partner};
+                    const int size = NS * (members[1] >= 0 ? 2 : 1);
+                    int x = 0;
+                    while (x < 8 && fill[x] + size > cap) ++x;
+                    if (x == 8) { ok = false; break; }
+                    for (int m = 0; m < 2; ++m) {
+                        if (members[m] < 0) continue;
+                        for (int sl = 0; sl < NS; ++sl) {
+                            const int b = fill[x]++ * 8 + x;
+                            S.role[b] = (unsigned short)((set << 10) | (members[m] << 5) | sl);
+                            if (b + 1 > top) top = b + 1;
+                        }
+                    }
+                }
+        if (ok) { S.nroles = top; grid = (unsigned)top; }
+    }
     const int32_t* plan = (const int32_t*)pl->data;
 #define BD_LAUNCH(KPT)                                                                                                   \
     do {                                                                                                                 \

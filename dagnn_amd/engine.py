@@ -879,6 +879,9 @@ def bwd_dataflow_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, ce
         keep.append(recs)
         args.schedule, args.records, args.err = sched.data_ptr(), recs.data_ptr(), err.data_ptr()
         args.plan_status = plan.status.data_ptr()
+        if DF_XCD:
+            args.num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            args.xcc_table = arena.xcc_table(dev).data_ptr()
         check(lib.dagnn_bwd_dataflow_prepare(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_bwd_dataflow_prepare")
     with _span("backward_run", plan.ws):
         check(lib.dagnn_bwd_dataflow_run(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_bwd_dataflow_run")

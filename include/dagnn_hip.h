@@ -470,6 +470,8 @@ typedef struct dagnn_bwd_dataflow_args {
     void* records;            /* dagnn_bwd_dataflow_record_bytes(N) */
     void* err;                /* device int32 */
     const void* plan_status;  /* or NULL */
+    int num_cus;              /* XCD-aware placement, as in dagnn_dataflow_args (0 / NULL: off) */
+    void* xcc_table;
 } dagnn_bwd_dataflow_args;
 
 size_t dagnn_bwd_dataflow_record_bytes(int64_t N);

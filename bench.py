@@ -233,7 +233,11 @@ def other_configs(device):
         torch.manual_seed(0)
         na = DAGNN_NA(8, 128, 128, 8, 8, 0, 1, hs=128, nz=56, num_nodes=8, num_layers=2, bidirectional=False).eval().to(device)
         b = synth.dvae_batch([synth.decode_enas_row(r) for r in synth.enas_rows(0, 64)]).to(device)
-        ms = timed(lambda: na(b.clone()), 30, 5)
+        def clones(batch, n):   # forward() mutates its batch: every timed call gets its own resident copy, made beforehand
+            it = iter([batch.clone() for _ in range(n)])
+            return lambda: next(it)
+        nb = clones(b, 35)
+        ms = timed(lambda: na(nb()), 30, 5)
         def small_roofline(ms, N, D, L, H, Din, T):
             # GRU products of the recurrence: D [2 N (Din + H) 3 H + (L - 1) 12 N H^2]  
             gf = D * (2.0 * N * (Din + H) * 3 * H + (L - 1) * 12.0 * N * H * H) / 1e9
@@ -247,7 +251,8 @@ def other_configs(device):
                                              "roofline": small_roofline(ms, int(b.x.shape[0]), 1, 2, 128, 8, T1)}
         bn = DAGNN_BN(10, 256, 256, 10, 10, 0, 1, hs=256, nz=56, num_nodes=10, num_layers=2, bidirectional=True).eval().to(device)
         b = synth.dvae_batch([synth.decode_bn_row(r) for r in synth.bn_rows(0, 128)]).to(device)
-        ms = timed(lambda: bn(b.clone()), 30, 5)
+        nb4 = clones(b, 35)
+        ms = timed(lambda: bn(nb4()), 30, 5)
         T4 = int(b.bi_layer_index[0][0].max()) + 1
         out["cfg4_BN_B128_h256_L2_bidir"] = {"ms_per_batch": round(ms, 4), "graphs_per_s": round(128 / ms * 1e3, 1),
                                              "roofline": small_roofline(ms, int(b.x.shape[0]), 2, 2, 256, 10, T4)}
@@ -264,7 +269,7 @@ def other_configs(device):
                                                 "frac_of_fp32_peak": round(gf / ms / FP32_MATRIX_PEAK_TFLOPS, 4),
                                                 "roofline": {"bound": "mfma", "achieved": round(gf / ms, 3), "peak": FP32_MATRIX_PEAK_TFLOPS,
                                                              "unit": "TFLOP/s", "frac": round(gf / ms / FP32_MATRIX_PEAK_TFLOPS, 5)},
-                                                "path": "lock-step launches (the dataflow kernel covers h <= 256)"}
+                                                "path": "lock-step launches (the dataflow kernels cover h <= 256)"}
         del m5
     return out
 
@@ -523,7 +528,8 @@ def main():
                              "whole recurrence - every (direction, stacked layer) cell plus the input-side projection "
                              "cells; graphs dealt to independent groups, two groups per workgroup set so that one "
                              "group's dependent hop hides behind the other's blocks; rows handed between workgroups "
-                             "as tagged granules; products on v_mfma_f32_4x4x1")
+                             "as tagged granules (through the shared L2 where a cell and its readers sit on one XCD - "
+                             "checked at run time); code specialised per cell variant; products on v_mfma_f32_4x4x1")
                 elif lock:
                     kname = ("recurrence = aggregate_rows_kernel + frontier_mfma_kernel + frontier_step_kernel (one launch "
                              "per topological layer) overlapped with frontier_tail_kernel (persistent, deep graphs); "

@@ -38,7 +38,10 @@ namespace {
 
 typedef float bf4 __attribute__((ext_vector_type(4)));
 
-constexpr int BD_NSLOT = 3;          // LDS ring depth per stream (a slot holds 3 operand rows per block row)
+#ifndef BD_NSLOT_V
+#define BD_NSLOT_V 3
+#endif
+constexpr int BD_NSLOT = BD_NSLOT_V;   // LDS ring depth per stream (a slot holds 3 operand rows per block row; 2 / 3 / 4: the same time)
 constexpr int BD_WPS = 4;            // loader waves per stream = rows per block
 constexpr int BD_NLW = DF_NLS * BD_WPS;
 constexpr int BD_THREADS = 64 * (DF_NCW + BD_NLW);
@@ -739,6 +742,7 @@ __device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int
         float gsum;
         {
             bf4 acc[3] = {(bf4){0.f, 0.f, 0.f, 0.f}, (bf4){0.f, 0.f, 0.f, 0.f}, (bf4){0.f, 0.f, 0.f, 0.f}};
+#ifndef BD_EXP_NOMFMA   // (timing experiment, scripts/build_variant.sh: without the products the sweep takes 1.96 instead of 2.15 ms)
 #pragma unroll
             for (int q = 0; q < NK4; ++q) {
                 const float4 b0 = *reinterpret_cast<const float4*>(a_seg + 4 * q);
@@ -752,6 +756,7 @@ __device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int
                     acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(wn[4 * q + e], q2[e], acc[2], 0, 0, 0);
                 }
             }
+#endif
             const bf4 t = acc[0] + acc[1] + acc[2];   // the three gate blocks of K: one reduce-scatter for their sum
             const float u0 = t[0] + bd_dpp<0x104>(t[0]), u1 = t[1] + bd_dpp<0x104>(t[1]);
             const float u2 = t[2] + bd_dpp<0x114>(t[2]), u3 = t[3] + bd_dpp<0x114>(t[3]);

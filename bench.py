@@ -333,6 +333,13 @@ def main():
     if args.streams > 1:
         # concurrent persistent tail kernels must all stay co-resident: shrink each one's grid
         os.environ.setdefault("DAGNN_AMD_TAIL_REPLICAS", str(max(1, 4 // args.streams)))
+        # ... and so must concurrent dataflow launches: each is sized to the whole device by default (one workgroup per CU;
+        # with k of them in flight, partially resident sets would fill the CUs and every wait would expire)
+        from dagnn_amd import engine as _e
+        full = _e.dataflow_groups(device, 2, args.layers, (args.hidden + 63) // 64 * 64, args.batch)
+        if full > 0:
+            _e.DF_GROUPS = max(2, (full // args.streams) // 2 * 2)
+            _e.DF_XCD = 0   # (the XCD packing assumes one launch owns the device)
     model = build_model(H, L, V, S, device)
     # weak scaling: one B-graph batch per rank, by default the same headline batch everywhere (module docstring)
     batch_cpu = code2_batch(seed=rank if args.rank_seeds else 0, num_graphs=B)

@@ -563,6 +563,9 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
     };
     auto rec_dma = [&](int j) { if (lane < 16) glds4(rec_src(j), rec_dst(j)); };
     auto gi_dma = [&](int blk, int node) { if (lane < 24) glds16(gi_src(node), gi_dst(blk)); };
+#ifdef DF_LOADER_PRIO
+    __builtin_amdgcn_s_setprio(DF_LOADER_PRIO);
+#endif
     if (nblk > 0) {   // prologue: records of this wave's rows of blocks 0..RD-1, gi0 slices of blocks 0..GD-1
         for (int rr = 0; rr < DF_RPW; ++rr) {
             set_row(w * DF_RPW + rr);
@@ -832,6 +835,9 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
         const int grp = df_stream_group(pair, q, S.groups);
         nb[q] = grp >= 0 ? S.sched[S.gtab[d] + 2 * grp + 1] : 0;
     }
+#ifdef DF_COMPUTE_PRIO
+    __builtin_amdgcn_s_setprio(DF_COMPUTE_PRIO);
+#endif
     float wr[KP8], wz[KP8], wn[KP8];   // the lane's K slice of the r / z / n rows of its unit
     {
         const float4* wp = C.w + (int64_t)sl * (3 * NK4) * 256 + tc;

@@ -200,6 +200,8 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
          for d in range(2)]
     plan.wait_ready()   # a plan built on the side stream (model._plan_of) meets the caller's stream here
     groups = engine.dataflow_groups(dev, len(dirs), L, Hp, plan.B) if (arena is not None and N > 0) else 0
+    if N * 3 * Hp >= (1 << 31):   # the dataflow kernels address their granule buffers with 32-bit row offsets
+        groups = 0
     if arena is not None:
         arena.poll()   # a failure an earlier pass reported (no synchronisation); either path below is watched
     if groups == 0 and arena is not None and N > 0 and engine.DATAFLOW:

@@ -392,6 +392,37 @@ def test_deep_stack_runs_on_the_dataflow_kernel(device, monkeypatch):
             wide(small.clone().to(device))
 
 
+def test_xcd_placement_changes_speed_not_results(device, monkeypatch):
+    """The XCD-aware workgroup placement of the dataflow kernels (hand-offs through the shared L2 where a cell and its
+    readers are SEEN on one XCD at run time) against the linear placement with write-through stores everywhere: logits,
+    hidden states and every parameter gradient are bitwise the same, on the headline shape and on a small one whose
+    group count (and therefore placement table) differs."""
+    for H, L, B, mean_n in ((256, 2, 128, 125), (64, 3, 6, 30)):
+        model = _headline_model(H=H, L=L, V=32, seed=4).to(device)
+        b = synth.code2_batch(11, B, mean_n)
+        y = torch.randint(0, 32, (B, 5), generator=torch.Generator().manual_seed(3)).to(device)
+        res = {}
+        for mode in (1, 0):
+            monkeypatch.setattr(engine, "DF_XCD", mode)
+            model.eval()
+            with torch.no_grad():
+                G = b.clone().to(device)
+                out = torch.stack(model(G))
+                hid = [h.clone() for hd in G.h for h in hd]
+            loss, grads = _train_step(model, b.clone().to(device), y)
+            model.check()
+            res[mode] = (out, hid, loss, {k: v.clone() for k, v in grads.items()})
+        assert torch.equal(res[0][0], res[1][0])
+        assert all(torch.equal(a, c) for a, c in zip(res[0][1], res[1][1]))
+        assert torch.equal(res[0][2], res[1][2])
+        for k in res[0][3]:
+            if "encoder." in k:   # (the embedding gradients are an atomic index_add: equal to rounding run to run, not bitwise)
+                scale = float(res[0][3][k].abs().max()) + 1e-12
+                assert float((res[0][3][k] - res[1][3][k]).abs().max()) <= 1e-5 * scale, k
+            else:
+                assert torch.equal(res[0][3][k], res[1][3][k]), k
+
+
 def _degenerate_batch():
     """Single-node graphs, a chain, stars with a 200-way fan-in / fan-out, a graph with no edges, a duplicate edge."""
     from dagnn_amd import GraphData

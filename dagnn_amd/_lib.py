@@ -146,6 +146,18 @@ class IpropLayer(C.Structure):
     _fields_ = [("w_ih", C.c_void_p), ("w_hh", C.c_void_p), ("b_ih", C.c_void_p), ("b_hh", C.c_void_p), ("in_dim", C.c_int)]
 
 
+class VariantBwdCell(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("lands", C.c_int32), ("in_dim", C.c_int32), ("proj_dim", C.c_int32)] + \
+        [(k, C.c_void_p) for k in ("h", "a", "gi", "gh", "node0", "node1", "alpha", "edge_mat0", "edge_vec0", "edge_mat1",
+                                   "edge_vec1", "w_node", "w_query", "w_hh", "w_ih", "g", "g_in", "da", "dgi", "dgh",
+                                   "dnode0", "dnode1", "dlogit", "esum")]
+
+
+class VariantBwdArgs(C.Structure):
+    _fields_ = [("cell", (VariantBwdCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
+                ("H", C.c_int)]
+
+
 class VariantArgs(C.Structure):
     _fields_ = [("cell", (VariantCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
                 ("H", C.c_int)]
@@ -204,6 +216,10 @@ SYMBOLS = {
                                           C.c_void_p]),
     "dagnn_variant_run": (C.c_int, [C.POINTER(Plan), C.POINTER(VariantArgs), C.POINTER(C.POINTER(C.c_int32)),
                                     C.POINTER(C.c_int32), C.c_void_p]),
+    "dagnn_variant_mattn_prepare": (C.c_int, [C.POINTER(Plan), C.POINTER(VariantBwdCell), C.c_int, C.c_int, C.c_int32,
+                                              C.c_int32, C.c_void_p]),
+    "dagnn_variant_backward_run": (C.c_int, [C.POINTER(Plan), C.POINTER(VariantBwdArgs), C.POINTER(C.POINTER(C.c_int32)),
+                                             C.POINTER(C.c_int32), C.c_void_p]),
     "dagnn_iprop_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int, C.POINTER(IpropLayer), C.c_int, C.c_void_p, C.c_void_p]),
     "dagnn_gather_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,

@@ -380,6 +380,16 @@ class DAGNN(nn.Module):
                 for c in (self._head_cache, self.__dict__.get("_variant_cache")):
                     if c is not None:
                         c.invalidate()
+                if self.variant_backend != "torch" and variants.hip_backward_supported(self, G):
+                    # gated_sum / mattn_h / add with GRU cells: forward AND reverse sweep in HIP (csrc/variants_bwd.hip)
+                    plan = self._plan_of(G, B)
+                    flat_params = [p for d in self.dirs for i in range(L) for _, p in variants._cell_params(self, d, i)]
+                    flat = variants.VariantRecurrence.apply(self, G, plan, G.x, *flat_params)
+                    h = [[None] * L for _ in range(2)]
+                    for q, d in enumerate(dirs):
+                        for i in range(L):
+                            h[d][i] = flat[q * L + i]
+                    return self._finish(G, None, G.x, h, B)
                 return self._finish(G, None, G.x, variants.run(self, G, G.x), B)   # training: differentiable torch ops
             plan = self._plan_of(G, B)
             return self._finish(G, plan, G.x, variants.run_hip(self, G, G.x, plan), B)

@@ -314,3 +314,231 @@ def run_hip(mod, G, x: torch.Tensor, plan) -> List[List[Optional[torch.Tensor]]]
                          "dagnn_variant_run")
     del keep
     return h
+
+
+# ---------------------------------------------------------------------------------------------- HIP training path
+_BWD_MODES = {"gated_sum": _lib.AGG_GATED, "mattn_h": _lib.AGG_MATTN, "add": _lib.AGG_ADD}
+
+
+def hip_backward_supported(mod, G) -> bool:
+    """`gated_sum`, `mattn_h` and `add` with GRU cells train through HIP (csrc/variants_bwd.hip); the other constructor
+    strings (`max`, `agg_x`, `recurr=0`) keep the differentiable torch-ops path."""
+    if mod.agg not in _BWD_MODES or not mod.recurr or mod.agg_x or len(mod.dirs) * mod.num_layers > 8:
+        return False
+    if mod.hidden_dim % 4 or mod.emb_dim % 4:
+        return False
+    has_enc = getattr(mod.node_aggr_0[0], "wea", False)
+    if has_enc and (getattr(G, "edge_attr", None) is None or G.edge_attr.view(G.edge_attr.shape[0], -1).shape[1] > 2):
+        return False
+    return True
+
+
+def _cell_params(mod, d, i):
+    """(name, parameter) of everything cell (d, i) reads, in a fixed order."""
+    c = getattr(mod, "cells_%d" % d)[i]
+    a = getattr(mod, "node_aggr_%d" % d)[i]
+    out = [("w_ih", c.weight_ih), ("w_hh", c.weight_hh), ("b_ih", c.bias_ih), ("b_hh", c.bias_hh)]
+    if mod.agg == "gated_sum":
+        out += [("wg", a.gate[0].weight), ("bg", a.gate[0].bias), ("wm", a.mapper.weight)]
+        if a.mapper.bias is not None:
+            out.append(("bm", a.mapper.bias))
+    elif mod.agg == "mattn_h":
+        out += [("wl", a.attn_linl.weight), ("bl", a.attn_linl.bias), ("wr", a.attn_linr.weight), ("br", a.attn_linr.bias)]
+    if getattr(a, "wea", False):
+        out += [("we", a.edge_encoder.weight), ("be", a.edge_encoder.bias)]
+    return out
+
+
+class VariantRecurrence(torch.autograd.Function):
+    """States h[d][i] of a `gated_sum` / `mattn_h` / `add` model, differentiable: forward = `run_hip` (the generic
+    lock-step kernels of csrc/variants.hip), backward = the reverse sweep of csrc/variants_bwd.hip + a parallel
+    epilogue (weight gradients as transposed products over all nodes).  Inputs after `x`: the parameters of every cell
+    in `_cell_params` order (a module shared by several cells - `add` - simply appears several times)."""
+
+    @staticmethod
+    def forward(ctx, mod, G, plan, x, *params):
+        h = run_hip(mod, G, x, plan)
+        ctx.mod, ctx.plan, ctx.h = mod, plan, h
+        ctx.ei, ctx.edge_attr = G.edge_index, getattr(G, "edge_attr", None)
+        ctx.save_for_backward(x, *params)
+        return tuple(h[d][i] for d in mod.dirs for i in range(mod.num_layers))
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        mod, plan, h = ctx.mod, ctx.plan, ctx.h
+        saved = list(ctx.saved_tensors)
+        x, params = saved[0].detach(), [p.detach() for p in saved[1:]]
+        N, H, L, E = x.shape[0], mod.hidden_dim, mod.num_layers, mod.emb_dim
+        dev = x.device
+        lib = _lib.load()
+        f32 = dict(dtype=torch.float32, device=dev)
+        mode = _BWD_MODES[mod.agg]
+        R = plan.R
+        sched = plan.read_schedule()
+        stream = engine._stream(x)
+        prm = _derive(mod)
+        shared_flow = mod.agg == "add"
+        # parameters of every cell by name
+        names, cellp, k = [], {}, 0
+        for d in mod.dirs:
+            for i in range(L):
+                spec = _cell_params(mod, d, i)
+                cellp[(d, i)] = {n: params[k + q] for q, (n, _) in enumerate(spec)}
+                names += [(d, i, n) for n, _ in spec]
+                k += len(spec)
+        args = _lib.VariantBwdArgs()
+        args.num_stacked, args.H, args.dir_mask = L, H, sum(1 << d for d in mod.dirs)
+        keep, res = [], {}
+        g = {}
+        q = 0
+        for d in mod.dirs:
+            for i in range(L):
+                go = gouts[q]
+                q += 1
+                g[(d, i)] = go.detach().float().contiguous().clone() if go is not None else torch.zeros(N, H, **f32)
+        dxd = {d: torch.zeros(N, E, **f32) for d in mod.dirs}
+        with torch.no_grad():
+            for d in mod.dirs:
+                lands = 0 if (shared_flow and d == 1) else 1
+                T = len(sched[d]) - 1
+                for i in range(L):
+                    p, cp, bc = prm[(d, i)], cellp[(d, i)], args.cell[d][i]
+                    hi = h[d][i]
+                    u = x if i == 0 else h[d][i - 1]
+                    in_dim = u.shape[1]
+                    a = torch.zeros(N, H, **f32)
+                    o = dict(a=a, u=u, dgi=torch.zeros(N, 3 * H, **f32), dgh=torch.zeros(N, 3 * H, **f32),
+                             da=torch.zeros(N, H, **f32))
+                    bc.mode, bc.lands, bc.in_dim = mode, lands, in_dim
+                    bc.edge_mat0, bc.edge_vec0 = _ptr(p.get("edge_mat0")), _ptr(p.get("edge_vec0"))
+                    bc.edge_mat1, bc.edge_vec1 = _ptr(p.get("edge_mat1")), _ptr(p.get("edge_vec1"))
+                    has_enc = "we" in cp
+                    if mode == _lib.AGG_GATED:
+                        pq = torch.addmm(p["pq_b"], hi, p["pq_w_t"])
+                        o["node0"], o["dnode0"] = pq, torch.zeros(N, 2 * H, **f32)
+                        o["w_node"] = torch.cat([cp["wg"], cp["wm"]], 0).contiguous()
+                        bc.node0, bc.dnode0, bc.w_node, bc.proj_dim = pq.data_ptr(), o["dnode0"].data_ptr(), o["w_node"].data_ptr(), H
+                        o["esum"] = torch.zeros(N, 2 * R * H, **f32) if (has_enc and R > 0) else None
+                        if T > 1:   # aggregates of every row beyond layer 0 (the forward's own aggregate kernel)
+                            ag = _lib.VariantAggregator()
+                            ag.mode, ag.lands, ag.val_dim, ag.out_dim = _lib.AGG_GATED, 1, H, H
+                            ag.vals, ag.ld_vals, ag.out, ag.ld_out = hi.data_ptr(), H, a.data_ptr(), H
+                            ag.node0, ag.node1, ag.ld_node = pq.data_ptr(), pq.data_ptr() + 4 * H, 2 * H
+                            ag.edge_mat0, ag.edge_vec0 = bc.edge_mat0, bc.edge_vec0
+                            ag.edge_mat1, ag.edge_vec1 = bc.edge_mat1, bc.edge_vec1
+                            engine.check(lib.dagnn_variant_aggregate(C.byref(plan.desc), C.byref(ag), d, int(sched[d][1]),
+                                                                     int(sched[d][T]), stream), "dagnn_variant_aggregate")
+                    elif mode == _lib.AGG_ADD:
+                        o["esum"] = torch.zeros(N, (R + 1) * H, **f32) if (has_enc and R > 0 and lands) else None
+                        if T > 1 and lands:
+                            ag = _lib.VariantAggregator()
+                            ag.mode, ag.lands, ag.val_dim, ag.out_dim = _lib.AGG_ADD, 1, H, H
+                            ag.vals, ag.ld_vals, ag.out, ag.ld_out = hi.data_ptr(), H, a.data_ptr(), H
+                            ag.edge_mat0, ag.edge_vec0 = bc.edge_mat0, bc.edge_vec0
+                            engine.check(lib.dagnn_variant_aggregate(C.byref(plan.desc), C.byref(ag), d, int(sched[d][1]),
+                                                                     int(sched[d][T]), stream), "dagnn_variant_aggregate")
+                    else:   # mattn
+                        P = cp["wl"].shape[0]
+                        kr = torch.addmm(cp["br"], hi, cp["wr"].t())
+                        ql = torch.addmm(cp["bl"], u, cp["wl"].t())
+                        o.update(node0=kr, node1=ql, dnode0=torch.zeros(N, P, **f32), dnode1=torch.zeros(N, P, **f32),
+                                 alpha=torch.zeros(max(plan.E, 1), **f32), dlogit=torch.zeros(max(plan.E, 1), **f32))
+                        o["esum"] = torch.zeros(N, R * P, **f32) if (has_enc and R > 0) else None
+                        bc.proj_dim = P
+                        bc.node0, bc.node1, bc.dnode0, bc.dnode1 = (o[n].data_ptr() for n in ("node0", "node1", "dnode0", "dnode1"))
+                        bc.alpha, bc.dlogit = o["alpha"].data_ptr(), o["dlogit"].data_ptr()
+                        bc.w_node, bc.w_query = cp["wr"].data_ptr(), cp["wl"].data_ptr()
+                        bc.h, bc.a = hi.data_ptr(), a.data_ptr()
+                        if T > 1:
+                            engine.check(lib.dagnn_variant_mattn_prepare(C.byref(plan.desc), C.byref(bc), d, H, int(sched[d][1]),
+                                                                         int(sched[d][T]), stream), "dagnn_variant_mattn_prepare")
+                    gi = engine.gemm_nt_bias([u], [cp["w_ih"]], [cp["b_ih"]])[0]
+                    gh = engine.gemm_nt_bias([a], [cp["w_hh"]], [cp["b_hh"]])[0]
+                    o["gi"], o["gh"] = gi, gh
+                    bc.h, bc.a, bc.gi, bc.gh = hi.data_ptr(), a.data_ptr(), gi.data_ptr(), gh.data_ptr()
+                    bc.w_hh, bc.w_ih = cp["w_hh"].data_ptr(), cp["w_ih"].data_ptr()
+                    bc.g = g[(d, i)].data_ptr()
+                    bc.g_in = (g[(d, i - 1)] if i > 0 else dxd[d]).data_ptr()
+                    bc.da, bc.dgi, bc.dgh = o["da"].data_ptr(), o["dgi"].data_ptr(), o["dgh"].data_ptr()
+                    bc.esum = _ptr(o.get("esum"))
+                    res[(d, i)] = o
+            ptrs = (C.POINTER(C.c_int32) * 2)()
+            nl = (C.c_int32 * 2)()
+            for d in (0, 1):
+                ptrs[d] = sched[d].ctypes.data_as(C.POINTER(C.c_int32))
+                nl[d] = len(sched[d]) - 1
+            with engine._span("variant_backward_run", x):
+                engine.check(lib.dagnn_variant_backward_run(C.byref(plan.desc), C.byref(args), ptrs, nl, stream),
+                             "dagnn_variant_backward_run")
+            # ---- epilogue: parameter gradients (transposed products over all nodes) ----
+            grads = {}
+            jobs = []
+            for d in mod.dirs:
+                for i in range(L):
+                    o = res[(d, i)]
+                    jobs += [(o["dgi"], o["u"], True), (o["dgh"], o["a"], True)]
+            wg = engine.wgrad(jobs, N, H, H) if N > 0 else None
+            kq = 0
+            for d in mod.dirs:
+                for i in range(L):
+                    o, cp = res[(d, i)], cellp[(d, i)]
+                    if wg is not None:
+                        (gw_ih, gb_ih), (gw_hh, gb_hh) = wg[kq], wg[kq + 1]
+                    else:
+                        gw_ih, gb_ih, gw_hh, gb_hh = (torch.zeros_like(cp[n]) for n in ("w_ih", "b_ih", "w_hh", "b_hh"))
+                    kq += 2
+                    grads[(d, i, "w_ih")], grads[(d, i, "b_ih")] = gw_ih, gb_ih
+                    grads[(d, i, "w_hh")], grads[(d, i, "b_hh")] = gw_hh, gb_hh
+                    hi = h[d][i]
+                    es = o.get("esum")
+                    if mode == _lib.AGG_GATED:
+                        dpq = o["dnode0"]
+                        prod = dpq.t() @ hi                       # [2H, H]: dP^T h | dM^T h
+                        sums = dpq.sum(0)
+                        gwg, gwm, dPs, dMs = prod[:H], prod[H:], sums[:H], sums[H:]
+                        if "we" in cp:
+                            We, be = cp["we"], cp["be"]
+                            gwg = gwg + torch.outer(dPs, be)
+                            gwm = gwm + torch.outer(dMs, be)
+                            gbe = cp["wg"].t() @ dPs + cp["wm"].t() @ dMs
+                            gwe = torch.zeros_like(We)
+                            if es is not None:
+                                esm = es.sum(0).view(2, R, H)      # [gate | map][r][k]
+                                for r in range(R):
+                                    gwg = gwg + torch.outer(esm[0, r], We[:, r])
+                                    gwm = gwm + torch.outer(esm[1, r], We[:, r])
+                                    gwe[:, r] = cp["wg"].t() @ esm[0, r] + cp["wm"].t() @ esm[1, r]
+                            grads[(d, i, "we")], grads[(d, i, "be")] = gwe, gbe
+                        grads[(d, i, "wg")], grads[(d, i, "bg")], grads[(d, i, "wm")] = gwg, dPs, gwm
+                        if "bm" in cp:
+                            grads[(d, i, "bm")] = dMs
+                    elif mode == _lib.AGG_MATTN:
+                        dkr, dql = o["dnode0"], o["dnode1"]
+                        dkrs = dkr.sum(0)
+                        gwr = dkr.t() @ hi
+                        grads[(d, i, "wl")], grads[(d, i, "bl")] = dql.t() @ o["u"], dql.sum(0)
+                        if "we" in cp:
+                            We, be = cp["we"], cp["be"]
+                            gwr = gwr + torch.outer(dkrs, be)
+                            gwe = torch.zeros_like(We)
+                            if es is not None:
+                                esm = es.sum(0).view(R, -1)
+                                for r in range(R):
+                                    gwr = gwr + torch.outer(esm[r], We[:, r])
+                                    gwe[:, r] = cp["wr"].t() @ esm[r]
+                            grads[(d, i, "we")], grads[(d, i, "be")] = gwe, cp["wr"].t() @ dkrs
+                        grads[(d, i, "wr")], grads[(d, i, "br")] = gwr, dkrs
+                    else:   # add: only the (shared) edge encoder has parameters
+                        if "we" in cp:
+                            gwe, gbe = torch.zeros_like(cp["we"]), torch.zeros_like(cp["be"])
+                            if es is not None:
+                                esm = es.sum(0).view(R + 1, H)
+                                for r in range(R):
+                                    gwe[:, r] = esm[r]
+                                gbe = esm[R]
+                            grads[(d, i, "we")], grads[(d, i, "be")] = gwe, gbe
+            dx = None
+            if ctx.needs_input_grad[3]:
+                dx = sum(dxd[d] for d in mod.dirs)
+        del keep
+        return (None, None, None, dx) + tuple(grads[n] for n in names)

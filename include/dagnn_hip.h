@@ -605,6 +605,39 @@ typedef struct dagnn_variant_args {
 int dagnn_variant_run(const dagnn_plan* plan /* host */, const dagnn_variant_args* args /* host */,
                       const int32_t* const* layer_ptr /* host */, const int32_t* num_layers /* host [2] */, void* stream);
 
+/* Reverse sweep of the variants `gated_sum`, `mattn_h`, `add` with GRU cells (csrc/variants_bwd.hip): what
+ * `loss.backward()` does to dagnn.py:144-182 with GatedSumConv (:254-276), MultAttnConv (:379-409) or AggConv add (:232-251).
+ * Every buffer is indexed by node id and contiguous ([N, width]); weights are in their torch layouts.  The caller
+ * provides the forward quantities (states h, aggregates a, pre-activations gi / gh, the per-node projections the forward
+ * pass of dagnn_variant_run computed: node0 = [P | M] for gated_sum, Kr for mattn; node1 = Ql for mattn; mattn also the
+ * attention weights alpha by original edge id - dagnn_variant_mattn_prepare computes a and alpha), `g` = the gradient
+ * reaching h from outside (modified: the sweep accumulates into it), `g_in` = the gradient of the cell's input (the `g`
+ * of the stacked layer below, or a zero-initialised dx buffer of ITS OWN per direction).  Outputs for the parallel
+ * epilogue: dgi, dgh [N,3H], dnode0 (dP | dM, or dKr), dnode1 (dQl), and per-node edge-feature sums `esum` (gated:
+ * [N, 2 R H], mattn: [N, R proj_dim], add: [N, (R + 1) H]; R <= 2; NULL without an edge encoder).  At most 8 cells. */
+typedef struct dagnn_variant_bwd_cell {
+    int32_t mode, lands, in_dim, proj_dim;
+    const float* h;  const float* a;  const float* gi;  const float* gh;
+    const float* node0;  const float* node1;  const float* alpha;
+    const float* edge_mat0;  const float* edge_vec0;  const float* edge_mat1;  const float* edge_vec1;
+    const float* w_node;     /* gated: [W_g ; W_m] [2H, H]; mattn: W_r [proj_dim, H] */
+    const float* w_query;    /* mattn: W_l [proj_dim, in_dim] */
+    const float* w_hh;       /* [3H, H] */
+    const float* w_ih;       /* [3H, in_dim] */
+    float* g;  float* g_in;  float* da;  float* dgi;  float* dgh;
+    float* dnode0;  float* dnode1;  float* dlogit;  float* esum;
+} dagnn_variant_bwd_cell;
+
+typedef struct dagnn_variant_bwd_args {
+    dagnn_variant_bwd_cell cell[DAGNN_MAX_DIRS][DAGNN_MAX_STACKED];
+    int num_stacked, dir_mask, H;
+} dagnn_variant_bwd_args;
+
+int dagnn_variant_mattn_prepare(const dagnn_plan* plan /* host */, const dagnn_variant_bwd_cell* cell /* host */, int dir, int H,
+                                int32_t row_begin, int32_t row_end, void* stream);
+int dagnn_variant_backward_run(const dagnn_plan* plan /* host */, const dagnn_variant_bwd_args* args /* host */,
+                               const int32_t* const* layer_ptr /* host */, const int32_t* num_layers /* host [2] */, void* stream);
+
 /* D-VAE read-out (dvae/dagnn.py:147-161, dvae/dagnn_bn.py:138-152): every graph has exactly
  * `stride` nodes; gather row g*stride + node_off of h [N,ld_h] into out[g, col_off : col_off+width]. */
 int dagnn_gather_rows(const float* h, int ld_h, int width, int64_t num_graphs, int stride, int node_off,

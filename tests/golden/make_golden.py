@@ -412,6 +412,18 @@ def main():
                         L=2, w_seed=123, y_seed=306, out_pool_all=True, out_pool="mean", **common)
     if only == "grad":
         return
+    if only in (None, "grad_var"):
+        # training-step gradients of the constructor-string variants that train through HIP (SURVEY §8 f3:
+        # csrc/variants_bwd.hip): GatedSumConv with / without mapper bias, MultAttnConv, AggConv add
+        for tag, seed, extra in (("gated_sum", 51, dict(agg="gated_sum")),
+                                 ("gated_nobias", 52, dict(agg="gated_sum", mapper_bias=False)),
+                                 ("mattn_h", 53, dict(agg="mattn_h")), ("add", 54, dict(agg="add")),
+                                 ("mattn_h_L3", 55, dict(agg="mattn_h", num_layers=3))):
+            L_ = extra.pop("num_layers", 2)
+            make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, "grad_var_h64_" + tag, data_seed=seed, B=5, mean_n=30,
+                            H=64, L=L_, w_seed=150 + seed, y_seed=350 + seed, **extra, **common)
+    if only == "grad_var":
+        return
 
     if only == "variants":
         return _variants_only(ref_dagnn, ref_utils, ref_dagutils, common)

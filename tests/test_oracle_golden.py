@@ -81,6 +81,30 @@ def test_oracle_training_step_gradients_match_reference(name):
     assert Hh.check_grads(meta, arr, grads, rtol=5e-5) < 5e-5
 
 
+@pytest.mark.parametrize("name", Hh.GRAD_VAR)
+def test_oracle_variant_training_step_gradients_match_reference(name):
+    """The same for the constructor-string variants that train through HIP (`gated_sum` with / without mapper bias,
+    `mattn_h`, `add`; dagnn.py:232-276,379-409): the oracle's autograd against the reference's `loss.backward()`."""
+    meta, arr = Hh.load(name)
+    model = Hh.code2_model(meta)
+    G = Hh.code2_batch(arr)
+    kw = meta["ctor"]
+    loss, grads = O.code2_grads(model.state_dict(), G, torch.from_numpy(arr["y"]), num_layers=kw["num_layers"],
+                                bidirectional=True, out_wx=kw["out_wx"], max_seq_len=meta["S"], agg=kw["agg"])
+    assert abs(float(loss) - float(arr["loss"])) < 1e-5
+    if kw["agg"] in ("add", "max"):
+        # the reference builds ONE AggConv for every layer and direction (dagnn.py:74-75): `named_parameters()` lists it
+        # once, under its first name, with the gradient of all its uses; the oracle differentiates a state_dict in
+        # which every alias is a tensor of its own - add the aliases up
+        import re
+        for k in [k for k in grads if re.match(r"node_aggr_\d+\.\d+\.", k)]:
+            first = re.sub(r"^node_aggr_\d+\.\d+\.", "node_aggr_0.0.", k)
+            if k != first:
+                grads[first] = grads[first] + grads[k]
+    # (fp32 on both sides; the dot-product attention of a 3-layer stack leaves ~2e-4 of rounding in its smallest gradients)
+    assert Hh.check_grads(meta, arr, grads, rtol=3e-4) < 3e-4
+
+
 @pytest.mark.parametrize("name", Hh.DVAE_GRAD)
 def test_oracle_dvae_encoder_gradients_match_reference(name):
     """`dvae_grads` against the reference encoder's own `.backward()` (dvae/dagnn.py:177-184 under autograd)."""

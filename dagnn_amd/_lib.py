@@ -147,7 +147,8 @@ class IpropLayer(C.Structure):
 
 
 class VariantBwdCell(C.Structure):
-    _fields_ = [("mode", C.c_int32), ("lands", C.c_int32), ("in_dim", C.c_int32), ("proj_dim", C.c_int32)] + \
+    _fields_ = [("mode", C.c_int32), ("lands", C.c_int32), ("in_dim", C.c_int32), ("proj_dim", C.c_int32),
+                ("recurrent", C.c_int32), ("reserved", C.c_int32)] + \
         [(k, C.c_void_p) for k in ("h", "a", "gi", "gh", "node0", "node1", "alpha", "edge_mat0", "edge_vec0", "edge_mat1",
                                    "edge_vec1", "w_node", "w_query", "w_hh", "w_ih", "g", "g_in", "da", "dgi", "dgh",
                                    "dnode0", "dnode1", "dlogit", "esum")]

@@ -1,4 +1,4 @@
-// variants_bwd.hip - reverse-mode sweep for the constructor-string aggregators `gated_sum`, `mattn_h` and `add`
+// variants_bwd.hip - reverse-mode sweep for the constructor-string aggregators `gated_sum`, `mattn_h`, `add` and `max`
 // (SURVEY.md section 8 a12 / f3): what `loss.backward()` (ogbg-code/main_pyg.py:62) does to the loops of
 // ogbg-code/model/dagnn.py:144-182 when `agg` selects GatedSumConv (dagnn.py:254-276), MultAttnConv (:379-409) or the
 // additive AggConv (:232-251) with GRU cells.  The forward of these variants is the generic lock-step pass of variants.hip;
@@ -14,7 +14,8 @@
 //     mattn      logit_e = Ql_w . (Kr_v + rho_e),  alpha = segment softmax over the in-edges of w,  a_w = sum alpha_e h_v:
 //                g_v += sum_e alpha_e da_w + (sum_e dlogit_e Ql_w) W_r,   dlogit_e = alpha_e (da_w . h_v - da_w . a_w)
 //                (dlogit_e was stored by edge id when w was processed - a later step of the forward is an earlier one here)
-//     add        g_v += sum_e da_w
+//     add        g_v += sum_e da_w            max: only where v's message attained the maximum a_w[k]
+//   `recurr=0` (the Linear cell h = W [u ; a] + b, dagnn.py:83-85): no gate algebra, da_v = g_v W[:, in:], du_v = g_v W[:, :in]
 //   GRU backward (gates recomputed from gi, gh):  dgi, dgh,  da_v = z (.) g_v + dgh_v W_hh,  du_v = dgi_v W_ih -> gradient
 //            of the cell's input (the state one stacked layer down, or the node input x)
 //   mattn, target side: dlogit_e for the in-edges of v, dQl_v = sum_e dlogit_e (Kr_j + rho_e), dq_v = dQl_v W_l -> the
@@ -83,13 +84,19 @@ __global__ void __launch_bounds__(256) vb_pull_kernel(const int32_t* __restrict_
                 for (int r = 0; r < R; ++r) { o[r * H + k] = eg[r]; o[(R + r) * H + k] = em[r]; }
             }
         }
-    } else if (C.mode == DAGNN_AGG_ADD) {
+    } else if (C.mode == DAGNN_AGG_ADD || C.mode == DAGNN_AGG_MAX) {
         if (!C.lands) return;   // the reference's shared AggConv: in this direction the messages land elsewhere (no gradient)
         const bool es = C.esum != nullptr && R > 0 && R <= 2;
+        const bool is_max = C.mode == DAGNN_AGG_MAX;
         for (int k = lane; k < H; k += 64) {
             float acc = 0.f, eg[2] = {0.f, 0.f};
+            const float hv = C.h[(int64_t)v * H + k];
             for (int e = eb; e < ee; ++e) {
-                const float dw = C.da[(int64_t)col[e] * H + k];
+                float dw = C.da[(int64_t)col[e] * H + k];
+                // max: the gradient of a_w[k] goes to the message that attained it - recomputed with the forward's own
+                // operations (variants.hip: vals + edge term), so the comparison with the stored maximum is exact
+                if (is_max && hv + vb_edge_term(C.edge_mat0, C.edge_vec0, k, R, ea + (int64_t)e * R) != C.a[(int64_t)col[e] * H + k])
+                    dw = 0.f;
                 acc += dw;
                 if (es)
                     for (int r = 0; r < R; ++r) eg[r] = fmaf(dw, ea[(int64_t)e * R + r], eg[r]);
@@ -133,6 +140,7 @@ __global__ void __launch_bounds__(256) vb_pull_kernel(const int32_t* __restrict_
 __global__ void __launch_bounds__(256) vb_gru_kernel(const int32_t* __restrict__ plan, PlanLayout L, VbStep S) {
     const int ci = blockIdx.y;
     const dagnn_variant_bwd_cell& C = S.c[ci];
+    if (!C.recurrent) return;   // Linear cell: its input gradients are plain maps of g
     const int H = S.H, H3 = 3 * H;
     const int rows = S.r1[ci] - S.r0[ci];
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)rows * H; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -316,10 +324,10 @@ extern "C" int dagnn_variant_backward_run(const dagnn_plan* pl, const dagnn_vari
         maxT = num_layers[d] > maxT ? num_layers[d] : maxT;
         for (int i = 0; i < Ls; ++i) {
             const dagnn_variant_bwd_cell& c = a->cell[d][i];
-            if (c.mode != DAGNN_AGG_GATED && c.mode != DAGNN_AGG_MATTN && c.mode != DAGNN_AGG_ADD) return DAGNN_EINVAL;
-            if (!c.h || !c.a || !c.gi || !c.gh || !c.w_hh || !c.w_ih || !c.g || !c.g_in || !c.da || !c.dgi || !c.dgh ||
-                c.in_dim <= 0)
+            if (c.mode != DAGNN_AGG_GATED && c.mode != DAGNN_AGG_MATTN && c.mode != DAGNN_AGG_ADD && c.mode != DAGNN_AGG_MAX)
                 return DAGNN_EINVAL;
+            if (!c.h || !c.a || !c.w_hh || !c.w_ih || !c.g || !c.g_in || !c.da || c.in_dim <= 0) return DAGNN_EINVAL;
+            if (c.recurrent && (!c.gi || !c.gh || !c.dgi || !c.dgh)) return DAGNN_EINVAL;
             if (c.mode == DAGNN_AGG_GATED && (!c.node0 || !c.dnode0 || !c.w_node)) return DAGNN_EINVAL;
             if (c.mode == DAGNN_AGG_MATTN && (!c.node0 || !c.node1 || !c.dnode0 || !c.dnode1 || !c.w_node || !c.w_query ||
                                               !c.alpha || !c.dlogit || c.proj_dim <= 0))
@@ -368,12 +376,16 @@ extern "C" int dagnn_variant_backward_run(const dagnn_plan* pl, const dagnn_vari
         hipLaunchKernelGGL(vb_gru_kernel, dim3((unsigned)((elems + 255) / 256 > 2048 ? 2048 : (elems + 255) / 256), (unsigned)S.n),
                            dim3(256), 0, st, plan, L, S);
         DAGNN_CHECK_LAUNCH();
-        // 4. da += dgh W_hh
-        for (int q = 0; q < S.n; ++q) M.j[M.n++] = VbMapJob{S.c[q].dgh, S.c[q].w_hh, S.c[q].da, 3 * H, H, S.dir[q], S.r0[q], S.r1[q]};
-        if (int rc = vb_launch_maps(plan, L, M, st)) return rc;
-        // 5. input gradient += dgi W_ih
+        // 4. da += dgh W_hh   (Linear cell: da += g W[:, in_dim:])
         for (int q = 0; q < S.n; ++q)
-            M.j[M.n++] = VbMapJob{S.c[q].dgi, S.c[q].w_ih, S.c[q].g_in, 3 * H, S.c[q].in_dim, S.dir[q], S.r0[q], S.r1[q]};
+            M.j[M.n++] = S.c[q].recurrent ? VbMapJob{S.c[q].dgh, S.c[q].w_hh, S.c[q].da, 3 * H, H, S.dir[q], S.r0[q], S.r1[q]}
+                                          : VbMapJob{S.c[q].g, S.c[q].w_hh, S.c[q].da, H, H, S.dir[q], S.r0[q], S.r1[q]};
+        if (int rc = vb_launch_maps(plan, L, M, st)) return rc;
+        // 5. input gradient += dgi W_ih   (Linear cell: += g W[:, :in_dim])
+        for (int q = 0; q < S.n; ++q)
+            M.j[M.n++] = S.c[q].recurrent
+                ? VbMapJob{S.c[q].dgi, S.c[q].w_ih, S.c[q].g_in, 3 * H, S.c[q].in_dim, S.dir[q], S.r0[q], S.r1[q]}
+                : VbMapJob{S.c[q].g, S.c[q].w_ih, S.c[q].g_in, H, S.c[q].in_dim, S.dir[q], S.r0[q], S.r1[q]};
         if (int rc = vb_launch_maps(plan, L, M, st)) return rc;
         if (any_mattn) {
             // 6. dlogit of the in-edges, dQl; 7. input gradient += dQl W_l

@@ -317,13 +317,14 @@ def run_hip(mod, G, x: torch.Tensor, plan) -> List[List[Optional[torch.Tensor]]]
 
 
 # ---------------------------------------------------------------------------------------------- HIP training path
-_BWD_MODES = {"gated_sum": _lib.AGG_GATED, "mattn_h": _lib.AGG_MATTN, "add": _lib.AGG_ADD}
+_BWD_MODES = {"gated_sum": _lib.AGG_GATED, "mattn_h": _lib.AGG_MATTN, "add": _lib.AGG_ADD, "max": _lib.AGG_MAX}
 
 
 def hip_backward_supported(mod, G) -> bool:
-    """`gated_sum`, `mattn_h` and `add` with GRU cells train through HIP (csrc/variants_bwd.hip); the other constructor
-    strings (`max`, `agg_x`, `recurr=0`) keep the differentiable torch-ops path."""
-    if mod.agg not in _BWD_MODES or not mod.recurr or mod.agg_x or len(mod.dirs) * mod.num_layers > 8:
+    """`gated_sum`, `mattn_h`, `add` and `max` with GRU or Linear (`recurr=0`) cells train through HIP
+    (csrc/variants_bwd.hip); `agg_x` and the additive-attention aggregators combined with `recurr=0` keep the
+    differentiable torch-ops path."""
+    if mod.agg not in _BWD_MODES or mod.agg_x or len(mod.dirs) * mod.num_layers > 8:
         return False
     if mod.hidden_dim % 4 or mod.emb_dim % 4:
         return False
@@ -337,7 +338,10 @@ def _cell_params(mod, d, i):
     """(name, parameter) of everything cell (d, i) reads, in a fixed order."""
     c = getattr(mod, "cells_%d" % d)[i]
     a = getattr(mod, "node_aggr_%d" % d)[i]
-    out = [("w_ih", c.weight_ih), ("w_hh", c.weight_hh), ("b_ih", c.bias_ih), ("b_hh", c.bias_hh)]
+    if mod.recurr:
+        out = [("w_ih", c.weight_ih), ("w_hh", c.weight_hh), ("b_ih", c.bias_ih), ("b_hh", c.bias_hh)]
+    else:
+        out = [("w_lin", c.weight), ("b_lin", c.bias)]
     if mod.agg == "gated_sum":
         out += [("wg", a.gate[0].weight), ("bg", a.gate[0].bias), ("wm", a.mapper.weight)]
         if a.mapper.bias is not None:
@@ -377,7 +381,8 @@ class VariantRecurrence(torch.autograd.Function):
         sched = plan.read_schedule()
         stream = engine._stream(x)
         prm = _derive(mod)
-        shared_flow = mod.agg == "add"
+        shared_flow = mod.agg in ("add", "max")
+        recurr = bool(mod.recurr)
         # parameters of every cell by name
         names, cellp, k = [], {}, 0
         for d in mod.dirs:
@@ -409,7 +414,7 @@ class VariantRecurrence(torch.autograd.Function):
                     a = torch.zeros(N, H, **f32)
                     o = dict(a=a, u=u, dgi=torch.zeros(N, 3 * H, **f32), dgh=torch.zeros(N, 3 * H, **f32),
                              da=torch.zeros(N, H, **f32))
-                    bc.mode, bc.lands, bc.in_dim = mode, lands, in_dim
+                    bc.mode, bc.lands, bc.in_dim, bc.recurrent = mode, lands, in_dim, int(recurr)
                     bc.edge_mat0, bc.edge_vec0 = _ptr(p.get("edge_mat0")), _ptr(p.get("edge_vec0"))
                     bc.edge_mat1, bc.edge_vec1 = _ptr(p.get("edge_mat1")), _ptr(p.get("edge_vec1"))
                     has_enc = "we" in cp
@@ -428,11 +433,11 @@ class VariantRecurrence(torch.autograd.Function):
                             ag.edge_mat1, ag.edge_vec1 = bc.edge_mat1, bc.edge_vec1
                             engine.check(lib.dagnn_variant_aggregate(C.byref(plan.desc), C.byref(ag), d, int(sched[d][1]),
                                                                      int(sched[d][T]), stream), "dagnn_variant_aggregate")
-                    elif mode == _lib.AGG_ADD:
+                    elif mode in (_lib.AGG_ADD, _lib.AGG_MAX):
                         o["esum"] = torch.zeros(N, (R + 1) * H, **f32) if (has_enc and R > 0 and lands) else None
                         if T > 1 and lands:
                             ag = _lib.VariantAggregator()
-                            ag.mode, ag.lands, ag.val_dim, ag.out_dim = _lib.AGG_ADD, 1, H, H
+                            ag.mode, ag.lands, ag.val_dim, ag.out_dim = mode, 1, H, H
                             ag.vals, ag.ld_vals, ag.out, ag.ld_out = hi.data_ptr(), H, a.data_ptr(), H
                             ag.edge_mat0, ag.edge_vec0 = bc.edge_mat0, bc.edge_vec0
                             engine.check(lib.dagnn_variant_aggregate(C.byref(plan.desc), C.byref(ag), d, int(sched[d][1]),
@@ -452,11 +457,17 @@ class VariantRecurrence(torch.autograd.Function):
                         if T > 1:
                             engine.check(lib.dagnn_variant_mattn_prepare(C.byref(plan.desc), C.byref(bc), d, H, int(sched[d][1]),
                                                                          int(sched[d][T]), stream), "dagnn_variant_mattn_prepare")
-                    gi = engine.gemm_nt_bias([u], [cp["w_ih"]], [cp["b_ih"]])[0]
-                    gh = engine.gemm_nt_bias([a], [cp["w_hh"]], [cp["b_hh"]])[0]
-                    o["gi"], o["gh"] = gi, gh
-                    bc.h, bc.a, bc.gi, bc.gh = hi.data_ptr(), a.data_ptr(), gi.data_ptr(), gh.data_ptr()
-                    bc.w_hh, bc.w_ih = cp["w_hh"].data_ptr(), cp["w_ih"].data_ptr()
+                    bc.h, bc.a = hi.data_ptr(), a.data_ptr()
+                    if recurr:
+                        gi = engine.gemm_nt_bias([u], [cp["w_ih"]], [cp["b_ih"]])[0]
+                        gh = engine.gemm_nt_bias([a], [cp["w_hh"]], [cp["b_hh"]])[0]
+                        o["gi"], o["gh"] = gi, gh
+                        bc.gi, bc.gh = gi.data_ptr(), gh.data_ptr()
+                        bc.w_hh, bc.w_ih = cp["w_hh"].data_ptr(), cp["w_ih"].data_ptr()
+                    else:   # Linear cell: W = [W_in | W_agg]
+                        o["w_in"] = cp["w_lin"][:, :in_dim].contiguous()
+                        o["w_agg"] = cp["w_lin"][:, in_dim:].contiguous()
+                        bc.w_ih, bc.w_hh = o["w_in"].data_ptr(), o["w_agg"].data_ptr()
                     bc.g = g[(d, i)].data_ptr()
                     bc.g_in = (g[(d, i - 1)] if i > 0 else dxd[d]).data_ptr()
                     bc.da, bc.dgi, bc.dgh = o["da"].data_ptr(), o["dgi"].data_ptr(), o["dgh"].data_ptr()
@@ -473,22 +484,28 @@ class VariantRecurrence(torch.autograd.Function):
             # ---- epilogue: parameter gradients (transposed products over all nodes) ----
             grads = {}
             jobs = []
-            for d in mod.dirs:
-                for i in range(L):
-                    o = res[(d, i)]
-                    jobs += [(o["dgi"], o["u"], True), (o["dgh"], o["a"], True)]
-            wg = engine.wgrad(jobs, N, H, H) if N > 0 else None
+            if recurr:
+                for d in mod.dirs:
+                    for i in range(L):
+                        o = res[(d, i)]
+                        jobs += [(o["dgi"], o["u"], True), (o["dgh"], o["a"], True)]
+            wg = engine.wgrad(jobs, N, H, H) if (N > 0 and jobs) else None
             kq = 0
             for d in mod.dirs:
                 for i in range(L):
                     o, cp = res[(d, i)], cellp[(d, i)]
-                    if wg is not None:
-                        (gw_ih, gb_ih), (gw_hh, gb_hh) = wg[kq], wg[kq + 1]
+                    if not recurr:   # Linear cell: dW = g^T [u ; a], db = sum g (g holds the total gradient of every row now)
+                        gt = g[(d, i)]
+                        grads[(d, i, "w_lin")] = torch.cat([gt.t() @ o["u"], gt.t() @ o["a"]], 1)
+                        grads[(d, i, "b_lin")] = gt.sum(0)
                     else:
-                        gw_ih, gb_ih, gw_hh, gb_hh = (torch.zeros_like(cp[n]) for n in ("w_ih", "b_ih", "w_hh", "b_hh"))
-                    kq += 2
-                    grads[(d, i, "w_ih")], grads[(d, i, "b_ih")] = gw_ih, gb_ih
-                    grads[(d, i, "w_hh")], grads[(d, i, "b_hh")] = gw_hh, gb_hh
+                        if wg is not None:
+                            (gw_ih, gb_ih), (gw_hh, gb_hh) = wg[kq], wg[kq + 1]
+                        else:
+                            gw_ih, gb_ih, gw_hh, gb_hh = (torch.zeros_like(cp[n]) for n in ("w_ih", "b_ih", "w_hh", "b_hh"))
+                        kq += 2
+                        grads[(d, i, "w_ih")], grads[(d, i, "b_ih")] = gw_ih, gb_ih
+                        grads[(d, i, "w_hh")], grads[(d, i, "b_hh")] = gw_hh, gb_hh
                     hi = h[d][i]
                     es = o.get("esum")
                     if mode == _lib.AGG_GATED:

@@ -605,8 +605,8 @@ typedef struct dagnn_variant_args {
 int dagnn_variant_run(const dagnn_plan* plan /* host */, const dagnn_variant_args* args /* host */,
                       const int32_t* const* layer_ptr /* host */, const int32_t* num_layers /* host [2] */, void* stream);
 
-/* Reverse sweep of the variants `gated_sum`, `mattn_h`, `add` with GRU cells (csrc/variants_bwd.hip): what
- * `loss.backward()` does to dagnn.py:144-182 with GatedSumConv (:254-276), MultAttnConv (:379-409) or AggConv add (:232-251).
+/* Reverse sweep of the variants `gated_sum`, `mattn_h`, `add`, `max` with GRU or Linear cells (csrc/variants_bwd.hip): what
+ * `loss.backward()` does to dagnn.py:144-182 with GatedSumConv (:254-276), MultAttnConv (:379-409) or AggConv add / max (:232-251).
  * Every buffer is indexed by node id and contiguous ([N, width]); weights are in their torch layouts.  The caller
  * provides the forward quantities (states h, aggregates a, pre-activations gi / gh, the per-node projections the forward
  * pass of dagnn_variant_run computed: node0 = [P | M] for gated_sum, Kr for mattn; node1 = Ql for mattn; mattn also the
@@ -614,9 +614,12 @@ int dagnn_variant_run(const dagnn_plan* plan /* host */, const dagnn_variant_arg
  * reaching h from outside (modified: the sweep accumulates into it), `g_in` = the gradient of the cell's input (the `g`
  * of the stacked layer below, or a zero-initialised dx buffer of ITS OWN per direction).  Outputs for the parallel
  * epilogue: dgi, dgh [N,3H], dnode0 (dP | dM, or dKr), dnode1 (dQl), and per-node edge-feature sums `esum` (gated:
- * [N, 2 R H], mattn: [N, R proj_dim], add: [N, (R + 1) H]; R <= 2; NULL without an edge encoder).  At most 8 cells. */
+ * [N, 2 R H], mattn: [N, R proj_dim], add / max: [N, (R + 1) H]; R <= 2; NULL without an edge encoder).  At most 8 cells. */
 typedef struct dagnn_variant_bwd_cell {
     int32_t mode, lands, in_dim, proj_dim;
+    int32_t recurrent;       /* 1: GRU cell; 0: the Linear cell of `recurr=0` (dagnn.py:83-85): h = W [u ; a] + b - then gi / gh / dgi /
+                              * dgh are unused, w_ih = W[:, :in_dim] and w_hh = W[:, in_dim:] as contiguous [H, .] copies */
+    int32_t reserved;
     const float* h;  const float* a;  const float* gi;  const float* gh;
     const float* node0;  const float* node1;  const float* alpha;
     const float* edge_mat0;  const float* edge_vec0;  const float* edge_mat1;  const float* edge_vec1;

@@ -956,7 +956,8 @@ def test_variant_forward_matches_reference_golden(device, name):
 
 @pytest.mark.parametrize("name", Hh.GRAD_VAR)
 def test_variant_training_step_gradients_match_reference_golden(device, name, monkeypatch):
-    """`gated_sum` (with / without mapper bias), `mattn_h` (L = 2 and 3) and `add`: forward + `loss.backward()` with the
+    """`gated_sum` (with / without mapper bias), `mattn_h` (L = 2 and 3), `add`, `max`, and `gated_sum` / `mattn_h` on the
+    Linear cell of `recurr=0`: forward + `loss.backward()` with the
     reverse sweep in HIP (`dagnn_variant_backward_run`, csrc/variants_bwd.hip) against the reference's own autograd on the
     same seeded step: loss and every parameter gradient; the HIP entry point really ran."""
     meta, arr = Hh.load(name)
@@ -976,8 +977,8 @@ def test_variant_training_step_gradients_match_reference_golden(device, name, mo
     assert abs(float(loss) - float(arr["loss"])) < 1e-5
     # every gradient within 1e-4 of its own largest entry + 2e-7 (check_grads asserts that); the returned worst RELATIVE
     # error is dominated by the dot-product attention's projections in the reverse direction, whose gradients are ~5e-5
-    # in size next to 1e-2 elsewhere: 2e-8 of fp32 rounding reads as 5e-4 there
-    assert Hh.check_grads(meta, arr, grads, rtol=1e-4) < 1e-3
+    # (and down to 1e-5 with the Linear cell) in size next to 1e-2 elsewhere: 2e-8 of fp32 rounding reads as 5e-4..2e-3 there
+    assert Hh.check_grads(meta, arr, grads, rtol=1e-4) < 5e-3
     loss2, grads2 = _train_step(model, Hh.code2_batch(arr, device), torch.from_numpy(arr["y"]).to(device))
     assert all(torch.equal(grads[k], grads2[k]) for k in grads if "encoder." not in k)   # deterministic
 

@@ -108,6 +108,40 @@ __global__ void __launch_bounds__(256) vb_pull_kernel(const int32_t* __restrict_
                 o[R * H + k] = acc;   // sum of the incoming gradients over the out-edges: the edge-encoder bias' share
             }
         }
+    } else if (C.mode == DAGNN_AGG_ATTN) {
+        // additive attention (AttnConv / SelfAttnConv, dagnn.py:279-313,347-376): logit_e = w_k . key_v + gain . attr_e (+ terms
+        // constant inside a soft-max segment), a_w = sum alpha_e h_v.  g_v += sum_e alpha_e da_w + sigma_v w_k (keys = states),
+        // sigma_v = sum_e ds_e, ds_e = alpha_e (da_w . h_v - da_w . a_w); outputs sigma_v and sum_e ds_e attr_e
+        const float* __restrict__ hv = C.h + (int64_t)v * H;
+        float sig = 0.f, m[2] = {0.f, 0.f};
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};   // H <= 256 per lane chunk; wider rows loop below
+        const bool narrow = H <= 256;
+        for (int e = eb; e < ee; ++e) {
+            const int w = col[e];
+            const float al = C.alpha[eidx[e]];
+            const float* __restrict__ daw = C.da + (int64_t)w * H;
+            const float* __restrict__ aw = C.a + (int64_t)w * H;
+            float dot = 0.f;
+            for (int k = lane, c = 0; k < H; k += 64, ++c) {
+                const float dv = daw[k];
+                dot = fmaf(dv, hv[k] - aw[k], dot);
+                if (narrow) acc[c] = fmaf(al, dv, acc[c]);
+                else g[k] = fmaf(al, dv, g[k]);
+            }
+            const float ds = al * wave_sum(dot);
+            sig += ds;
+            for (int r = 0; r < R && r < 2; ++r) m[r] = fmaf(ds, ea[(int64_t)e * R + r], m[r]);
+        }
+        const bool key_state = C.reserved != 0;
+        for (int k = lane, c = 0; k < H; k += 64, ++c) {
+            float t = narrow ? g[k] + acc[c] : g[k];
+            if (key_state) t = fmaf(sig, C.w_node[k], t);
+            g[k] = t;
+        }
+        if (lane == 0) {
+            C.dnode0[v] = sig;
+            if (C.esum) for (int r = 0; r < R && r < 2; ++r) C.esum[(int64_t)v * R + r] = m[r];
+        }
     } else {   // DAGNN_AGG_MATTN
         const int P = C.proj_dim;
         float* __restrict__ dkr = C.dnode0 + (int64_t)v * P;
@@ -279,6 +313,43 @@ __global__ void __launch_bounds__(256) vb_mattn_prepare_kernel(const int32_t* __
     }
 }
 
+// ---- additive attention, preparation: alpha of every edge (by edge id) and the aggregates a
+__global__ void __launch_bounds__(256) vb_attn_prepare_kernel(const int32_t* __restrict__ plan, PlanLayout L,
+                                                               dagnn_variant_bwd_cell C, int dir, int r0, int r1, int R, int H) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slot = r0 + blockIdx.x * 4 + wave;
+    if (slot >= r1) return;
+    const int kd = C.proj_dim;
+    const int32_t* __restrict__ rec = plan + L.rowrec[dir] + 16 * (int64_t)slot;
+    const int v = rec[0], eb = rec[1], ee = rec[2];
+    const int32_t* __restrict__ col = plan + L.col[dir];
+    const int32_t* __restrict__ eidx = plan + L.eidx[dir];
+    const float* __restrict__ ea = reinterpret_cast<const float*>(plan + L.eattr[dir]);
+    float* __restrict__ alpha = const_cast<float*>(C.alpha);
+    float* __restrict__ aout = const_cast<float*>(C.a) + (int64_t)v * H;
+    auto logit = [&](int e) {
+        const float* key = C.node0 + (int64_t)col[e] * kd;
+        float t = 0.f;
+        for (int k = lane; k < kd; k += 64) t = fmaf(C.w_node[k], key[k], t);
+        t = wave_sum(t);
+        if (C.edge_mat0)
+            for (int r = 0; r < R; ++r) t = fmaf(C.edge_mat0[r], ea[(int64_t)e * R + r], t);
+        return t;
+    };
+    float mx = -INFINITY;
+    for (int e = eb; e < ee; ++e) mx = fmaxf(mx, logit(e));
+    float sum = 0.f;
+    for (int e = eb; e < ee; ++e) sum += expf(logit(e) - mx);
+    const float den = sum + 1e-16f;
+    for (int k = lane; k < H; k += 64) aout[k] = 0.f;
+    for (int e = eb; e < ee; ++e) {
+        const float al = expf(logit(e) - mx) / den;
+        if (lane == 0) alpha[eidx[e]] = al;
+        const float* hj = C.h + (int64_t)col[e] * H;
+        for (int k = lane; k < H; k += 64) aout[k] = fmaf(al, hj[k], aout[k]);
+    }
+}
+
 int vb_launch_maps(const int32_t* plan, const PlanLayout& L, VbMaps& M, hipStream_t st) {
     if (M.n == 0) return DAGNN_OK;
     int rows = 0, J = 0, K = 0;
@@ -300,9 +371,16 @@ int vb_launch_maps(const int32_t* plan, const PlanLayout& L, VbMaps& M, hipStrea
 extern "C" int dagnn_variant_mattn_prepare(const dagnn_plan* pl, const dagnn_variant_bwd_cell* c, int dir, int H,
                                            int32_t row_begin, int32_t row_end, void* stream) {
     if (!pl || !pl->data || !c || (dir != 0 && dir != 1) || H <= 0 || row_begin < 0 || row_end > pl->N) return DAGNN_EINVAL;
-    if (!c->h || !c->a || !c->alpha || !c->node0 || !c->node1 || c->proj_dim <= 0) return DAGNN_EINVAL;
+    if (!c->h || !c->a || !c->alpha || !c->node0 || c->proj_dim <= 0) return DAGNN_EINVAL;
+    if (c->mode == DAGNN_AGG_MATTN ? !c->node1 : !c->w_node) return DAGNN_EINVAL;
     if (row_end <= row_begin) return DAGNN_OK;
     const PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
+    if (c->mode == DAGNN_AGG_ATTN) {
+        hipLaunchKernelGGL(vb_attn_prepare_kernel, dim3((unsigned)((row_end - row_begin + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const int32_t*)pl->data, L, *c, dir, row_begin, row_end, pl->num_edge_feats, H);
+        DAGNN_CHECK_LAUNCH();
+        return DAGNN_OK;
+    }
     hipLaunchKernelGGL(vb_mattn_prepare_kernel, dim3((unsigned)((row_end - row_begin + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const int32_t*)pl->data, L, *c, dir, row_begin, row_end, pl->num_edge_feats, H);
     DAGNN_CHECK_LAUNCH();
@@ -324,8 +402,10 @@ extern "C" int dagnn_variant_backward_run(const dagnn_plan* pl, const dagnn_vari
         maxT = num_layers[d] > maxT ? num_layers[d] : maxT;
         for (int i = 0; i < Ls; ++i) {
             const dagnn_variant_bwd_cell& c = a->cell[d][i];
-            if (c.mode != DAGNN_AGG_GATED && c.mode != DAGNN_AGG_MATTN && c.mode != DAGNN_AGG_ADD && c.mode != DAGNN_AGG_MAX)
+            if (c.mode != DAGNN_AGG_GATED && c.mode != DAGNN_AGG_MATTN && c.mode != DAGNN_AGG_ADD && c.mode != DAGNN_AGG_MAX &&
+                c.mode != DAGNN_AGG_ATTN)
                 return DAGNN_EINVAL;
+            if (c.mode == DAGNN_AGG_ATTN && (!c.alpha || !c.dnode0 || !c.w_node)) return DAGNN_EINVAL;
             if (!c.h || !c.a || !c.w_hh || !c.w_ih || !c.g || !c.g_in || !c.da || c.in_dim <= 0) return DAGNN_EINVAL;
             if (c.recurrent && (!c.gi || !c.gh || !c.dgi || !c.dgh)) return DAGNN_EINVAL;
             if (c.mode == DAGNN_AGG_GATED && (!c.node0 || !c.dnode0 || !c.w_node)) return DAGNN_EINVAL;

@@ -317,15 +317,26 @@ def run_hip(mod, G, x: torch.Tensor, plan) -> List[List[Optional[torch.Tensor]]]
 
 
 # ---------------------------------------------------------------------------------------------- HIP training path
-_BWD_MODES = {"gated_sum": _lib.AGG_GATED, "mattn_h": _lib.AGG_MATTN, "add": _lib.AGG_ADD, "max": _lib.AGG_MAX}
+_BWD_MODES = {"gated_sum": _lib.AGG_GATED, "mattn_h": _lib.AGG_MATTN, "add": _lib.AGG_ADD, "max": _lib.AGG_MAX,
+              "attn_h": _lib.AGG_ATTN, "attn_x": _lib.AGG_ATTN, "self_attn_h": _lib.AGG_ATTN, "self_attn_x": _lib.AGG_ATTN}
+
+
+def _attn_slice(mod, i):
+    """(offset of the key weights inside attn_lin.weight, key width) of stacked layer i - the rule of `_derive`."""
+    E, H = mod.emb_dim, mod.hidden_dim
+    off = 0 if "self_attn" in mod.agg else (E if (i == 0 or mod.agg_x) else (E if mod.agg_attn_x else H))
+    kd = E if (mod.agg_x or mod.agg_attn_x) else H
+    return off, kd
 
 
 def hip_backward_supported(mod, G) -> bool:
     """`gated_sum`, `mattn_h`, `add` and `max` with GRU or Linear (`recurr=0`) cells train through HIP
-    (csrc/variants_bwd.hip); `agg_x` and the additive-attention aggregators combined with `recurr=0` keep the
-    differentiable torch-ops path."""
+    (csrc/variants_bwd.hip), and so do the additive-attention aggregators on the Linear cell (with GRU cells they are the
+    tuned main path); `agg_x` keeps the differentiable torch-ops path."""
     if mod.agg not in _BWD_MODES or mod.agg_x or len(mod.dirs) * mod.num_layers > 8:
         return False
+    if _BWD_MODES[mod.agg] == _lib.AGG_ATTN and mod.recurr:
+        return False   # (never reached: that is the main path)
     if mod.hidden_dim % 4 or mod.emb_dim % 4:
         return False
     has_enc = getattr(mod.node_aggr_0[0], "wea", False)
@@ -348,6 +359,8 @@ def _cell_params(mod, d, i):
             out.append(("bm", a.mapper.bias))
     elif mod.agg == "mattn_h":
         out += [("wl", a.attn_linl.weight), ("bl", a.attn_linl.bias), ("wr", a.attn_linr.weight), ("br", a.attn_linr.bias)]
+    elif _BWD_MODES.get(mod.agg) == _lib.AGG_ATTN:
+        out += [("attn_w", a.attn_lin.weight), ("attn_b", a.attn_lin.bias)]
     if getattr(a, "wea", False):
         out += [("we", a.edge_encoder.weight), ("be", a.edge_encoder.bias)]
     return out
@@ -442,6 +455,18 @@ class VariantRecurrence(torch.autograd.Function):
                             ag.edge_mat0, ag.edge_vec0 = bc.edge_mat0, bc.edge_vec0
                             engine.check(lib.dagnn_variant_aggregate(C.byref(plan.desc), C.byref(ag), d, int(sched[d][1]),
                                                                      int(sched[d][T]), stream), "dagnn_variant_aggregate")
+                    elif mode == _lib.AGG_ATTN:   # additive attention (only reached with the Linear cell)
+                        keys = x if mod.agg_attn_x else hi
+                        off, kd = _attn_slice(mod, i)
+                        o.update(node0=keys, dnode0=torch.zeros(N, **f32), alpha=torch.zeros(max(plan.E, 1), **f32))
+                        o["esum"] = torch.zeros(N, R, **f32) if (has_enc and R > 0) else None
+                        bc.proj_dim, bc.reserved = kd, (0 if mod.agg_attn_x else 1)
+                        bc.node0, bc.dnode0, bc.alpha = keys.data_ptr(), o["dnode0"].data_ptr(), o["alpha"].data_ptr()
+                        bc.w_node = p["edge_vec0"].data_ptr()
+                        bc.h, bc.a = hi.data_ptr(), a.data_ptr()
+                        if T > 1:
+                            engine.check(lib.dagnn_variant_mattn_prepare(C.byref(plan.desc), C.byref(bc), d, H, int(sched[d][1]),
+                                                                         int(sched[d][T]), stream), "dagnn_variant_mattn_prepare")
                     else:   # mattn
                         P = cp["wl"].shape[0]
                         kr = torch.addmm(cp["br"], hi, cp["wr"].t())
@@ -545,7 +570,24 @@ class VariantRecurrence(torch.autograd.Function):
                                     gwe[:, r] = cp["wr"].t() @ esm[r]
                             grads[(d, i, "we")], grads[(d, i, "be")] = gwe, cp["wr"].t() @ dkrs
                         grads[(d, i, "wr")], grads[(d, i, "br")] = gwr, dkrs
-                    else:   # add: only the (shared) edge encoder has parameters
+                    elif mode == _lib.AGG_ATTN:
+                        # logit_e = w_k . (key_j + W_e attr_e + b_e) (+ query / bias terms that cancel inside a segment:
+                        # exact zeros); sigma_v = sum of ds over the out-edges of v
+                        sig = o["dnode0"]
+                        off, kd = _attn_slice(mod, i)
+                        wk = cp["attn_w"][0, off:off + kd]
+                        g_key = (o["node0"] * sig[:, None]).sum(0)
+                        if mod.agg_attn_x:   # the score of node v is w_k . x_v
+                            dxd[d] += sig[:, None] * wk[None, :]
+                        if "we" in cp:
+                            m = es.sum(0) if es is not None else torch.zeros(R, **f32)
+                            ssum = sig.sum()
+                            g_key = g_key + cp["we"] @ m + cp["be"] * ssum
+                            grads[(d, i, "we")], grads[(d, i, "be")] = torch.outer(wk, m), wk * ssum
+                        g_attn = torch.zeros_like(cp["attn_w"])
+                        g_attn[0, off:off + kd] = g_key
+                        grads[(d, i, "attn_w")], grads[(d, i, "attn_b")] = g_attn, torch.zeros_like(cp["attn_b"])
+                    else:   # add / max: only the (shared) edge encoder has parameters
                         if "we" in cp:
                             gwe, gbe = torch.zeros_like(cp["we"]), torch.zeros_like(cp["be"])
                             if es is not None:

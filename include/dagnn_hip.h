@@ -619,7 +619,9 @@ typedef struct dagnn_variant_bwd_cell {
     int32_t mode, lands, in_dim, proj_dim;
     int32_t recurrent;       /* 1: GRU cell; 0: the Linear cell of `recurr=0` (dagnn.py:83-85): h = W [u ; a] + b - then gi / gh / dgi /
                               * dgh are unused, w_ih = W[:, :in_dim] and w_hh = W[:, in_dim:] as contiguous [H, .] copies */
-    int32_t reserved;
+    int32_t reserved;        /* additive attention (DAGNN_AGG_ATTN): 1 = the keys are this cell's states (their gradient gets
+                              * sigma w_k), 0 = the keys are the node inputs; node0 = keys [N, proj_dim], w_node = w_k [proj_dim],
+                              * edge_mat0 = the folded edge gains [R]; outputs dnode0 = sigma [N], esum = sum_e ds_e attr_e [N, R] */
     const float* h;  const float* a;  const float* gi;  const float* gh;
     const float* node0;  const float* node1;  const float* alpha;
     const float* edge_mat0;  const float* edge_vec0;  const float* edge_mat1;  const float* edge_vec1;
@@ -636,6 +638,7 @@ typedef struct dagnn_variant_bwd_args {
     int num_stacked, dir_mask, H;
 } dagnn_variant_bwd_args;
 
+/* (also the additive-attention aggregators: mode DAGNN_AGG_ATTN) */
 int dagnn_variant_mattn_prepare(const dagnn_plan* plan /* host */, const dagnn_variant_bwd_cell* cell /* host */, int dir, int H,
                                 int32_t row_begin, int32_t row_end, void* stream);
 int dagnn_variant_backward_run(const dagnn_plan* plan /* host */, const dagnn_variant_bwd_args* args /* host */,

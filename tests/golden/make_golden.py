@@ -420,7 +420,10 @@ def main():
                                  ("mattn_h", 53, dict(agg="mattn_h")), ("add", 54, dict(agg="add")),
                                  ("mattn_h_L3", 55, dict(agg="mattn_h", num_layers=3)), ("max", 56, dict(agg="max")),
                                  ("recurr0_gated", 57, dict(agg="gated_sum", recurr=0)),
-                                 ("recurr0_mattn", 58, dict(agg="mattn_h", recurr=0))):
+                                 ("recurr0_mattn", 58, dict(agg="mattn_h", recurr=0)),
+                                 ("recurr0_attn_h", 59, dict(agg="attn_h", recurr=0)),
+                                 ("recurr0_attn_x", 60, dict(agg="attn_x", recurr=0)),
+                                 ("recurr0_self_attn_h", 61, dict(agg="self_attn_h", recurr=0))):
             L_ = extra.pop("num_layers", 2)
             make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, "grad_var_h64_" + tag, data_seed=seed, B=5, mean_n=30,
                             H=64, L=L_, w_seed=150 + seed, y_seed=350 + seed, **extra, **common)

@@ -219,6 +219,8 @@ SYMBOLS = {
                                     C.POINTER(C.c_int32), C.c_void_p]),
     "dagnn_variant_mattn_prepare": (C.c_int, [C.POINTER(Plan), C.POINTER(VariantBwdCell), C.c_int, C.c_int, C.c_int32,
                                               C.c_int32, C.c_void_p]),
+    "dagnn_variant_aggregator_backward": (C.c_int, [C.POINTER(Plan), C.POINTER(VariantBwdCell), C.c_int, C.c_int, C.c_int32,
+                                                    C.c_int32, C.c_void_p]),
     "dagnn_variant_backward_run": (C.c_int, [C.POINTER(Plan), C.POINTER(VariantBwdArgs), C.POINTER(C.POINTER(C.c_int32)),
                                              C.POINTER(C.c_int32), C.c_void_p]),
     "dagnn_iprop_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(256) vb_pull_kernel(const int32_t* __restrict_
     const int32_t* __restrict__ eidx = plan + L.eidx[od];
     const float* __restrict__ ea = reinterpret_cast<const float*>(plan + L.eattr[od]);
     float* __restrict__ g = C.g + (int64_t)v * H;
+    if (C.mode == DAGNN_AGG_GIVEN) return;   // `agg_x`: the aggregate is an input of the recurrence - nothing to pull
     if (C.mode == DAGNN_AGG_GATED) {
         const float* __restrict__ pq = C.node0 + (int64_t)v * 2 * H;
         float* __restrict__ dpq = C.dnode0 + (int64_t)v * 2 * H;
@@ -403,7 +404,7 @@ extern "C" int dagnn_variant_backward_run(const dagnn_plan* pl, const dagnn_vari
         for (int i = 0; i < Ls; ++i) {
             const dagnn_variant_bwd_cell& c = a->cell[d][i];
             if (c.mode != DAGNN_AGG_GATED && c.mode != DAGNN_AGG_MATTN && c.mode != DAGNN_AGG_ADD && c.mode != DAGNN_AGG_MAX &&
-                c.mode != DAGNN_AGG_ATTN)
+                c.mode != DAGNN_AGG_ATTN && c.mode != DAGNN_AGG_GIVEN)
                 return DAGNN_EINVAL;
             if (c.mode == DAGNN_AGG_ATTN && (!c.alpha || !c.dnode0 || !c.w_node)) return DAGNN_EINVAL;
             if (!c.h || !c.a || !c.w_hh || !c.w_ih || !c.g || !c.g_in || !c.da || c.in_dim <= 0) return DAGNN_EINVAL;
@@ -477,6 +478,44 @@ extern "C" int dagnn_variant_backward_run(const dagnn_plan* pl, const dagnn_vari
                                           S.r0[q], S.r1[q]};
             if (int rc = vb_launch_maps(plan, L, M, st)) return rc;
         }
+    }
+    return DAGNN_OK;
+}
+
+// `agg_x` (dagnn.py:159-169): the aggregator reads the node inputs only, so its reverse pass is ONE shot over all rows after
+// the cells' sweep: `cell` describes the aggregator with h = the inputs x [N, width], a = its output, da = the summed
+// gradient of that output over the stacked cells, g = g_in = the gradient of x (accumulated).
+extern "C" int dagnn_variant_aggregator_backward(const dagnn_plan* pl, const dagnn_variant_bwd_cell* c, int dir, int width,
+                                                 int32_t row_begin, int32_t row_end, void* stream) {
+    if (!pl || !pl->data || !c || (dir != 0 && dir != 1) || width <= 0 || row_begin < 0 || row_end > pl->N) return DAGNN_EINVAL;
+    if (!c->h || !c->a || !c->da || !c->g || !c->g_in) return DAGNN_EINVAL;
+    if (c->mode == DAGNN_AGG_GATED && (!c->node0 || !c->dnode0 || !c->w_node)) return DAGNN_EINVAL;
+    if (c->mode == DAGNN_AGG_MATTN && (!c->node0 || !c->node1 || !c->dnode0 || !c->dnode1 || !c->w_node || !c->w_query || !c->alpha ||
+                                       !c->dlogit || c->proj_dim <= 0))
+        return DAGNN_EINVAL;
+    if (c->mode == DAGNN_AGG_ATTN && (!c->alpha || !c->dnode0 || !c->w_node || !c->node0)) return DAGNN_EINVAL;
+    if (row_end <= row_begin) return DAGNN_OK;
+    const PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
+    const int32_t* plan = (const int32_t*)pl->data;
+    hipStream_t st = (hipStream_t)stream;
+    VbStep S;
+    S.n = 1; S.R = pl->num_edge_feats; S.H = width;
+    S.c[0] = *c; S.dir[0] = dir; S.r0[0] = row_begin; S.r1[0] = row_end;
+    const dim3 wgrid((unsigned)((row_end - row_begin + 3) / 4), 1);
+    if (c->mode == DAGNN_AGG_MATTN) {   // dlogit of every edge first: the pull below reads it for the out-edges
+        hipLaunchKernelGGL(vb_mattn_target_kernel, wgrid, dim3(256), 0, st, plan, L, S);
+        DAGNN_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(vb_pull_kernel, wgrid, dim3(256), 0, st, plan, L, S);
+    DAGNN_CHECK_LAUNCH();
+    VbMaps M;
+    M.n = 0;
+    if (c->mode == DAGNN_AGG_GATED) M.j[M.n++] = VbMapJob{c->dnode0, c->w_node, c->g, 2 * width, width, dir, row_begin, row_end};
+    else if (c->mode == DAGNN_AGG_MATTN) M.j[M.n++] = VbMapJob{c->dnode0, c->w_node, c->g, c->proj_dim, width, dir, row_begin, row_end};
+    if (int rc = vb_launch_maps(plan, L, M, st)) return rc;
+    if (c->mode == DAGNN_AGG_MATTN) {
+        M.j[M.n++] = VbMapJob{c->dnode1, c->w_query, c->g_in, c->proj_dim, c->in_dim, dir, row_begin, row_end};
+        if (int rc = vb_launch_maps(plan, L, M, st)) return rc;
     }
     return DAGNN_OK;
 }

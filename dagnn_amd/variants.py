@@ -330,14 +330,15 @@ def _attn_slice(mod, i):
 
 
 def hip_backward_supported(mod, G) -> bool:
-    """`gated_sum`, `mattn_h`, `add` and `max` with GRU or Linear (`recurr=0`) cells train through HIP
-    (csrc/variants_bwd.hip), and so do the additive-attention aggregators on the Linear cell (with GRU cells they are the
-    tuned main path); `agg_x` keeps the differentiable torch-ops path."""
-    if mod.agg not in _BWD_MODES or mod.agg_x or len(mod.dirs) * mod.num_layers > 8:
+    """Every constructor-string variant trains through HIP (csrc/variants_bwd.hip): `gated_sum`, `mattn_h`, `add`, `max`
+    with GRU or Linear (`recurr=0`) cells, the additive-attention aggregators on the Linear cell (with GRU cells they
+    are the tuned main path), and all of them with `agg_x`.  Left on the differentiable torch-ops path: more than 8
+    cells, widths that are not multiples of 4, more than two edge features with an edge encoder."""
+    if mod.agg not in _BWD_MODES or len(mod.dirs) * mod.num_layers > 8:
         return False
-    if _BWD_MODES[mod.agg] == _lib.AGG_ATTN and mod.recurr:
+    if _BWD_MODES[mod.agg] == _lib.AGG_ATTN and mod.recurr and not mod.agg_x:
         return False   # (never reached: that is the main path)
-    if mod.hidden_dim % 4 or mod.emb_dim % 4:
+    if mod.hidden_dim % 4 or mod.emb_dim % 4 or (mod.agg_x and mod.emb_dim > mod.hidden_dim):
         return False
     has_enc = getattr(mod.node_aggr_0[0], "wea", False)
     if has_enc and (getattr(G, "edge_attr", None) is None or G.edge_attr.view(G.edge_attr.shape[0], -1).shape[1] > 2):
@@ -346,13 +347,16 @@ def hip_backward_supported(mod, G) -> bool:
 
 
 def _cell_params(mod, d, i):
-    """(name, parameter) of everything cell (d, i) reads, in a fixed order."""
+    """(name, parameter) of everything cell (d, i) reads, in a fixed order.  With `agg_x` only stacked layer 0 owns an
+    aggregator (the reference calls `node_aggr[0]` once per direction, dagnn.py:159-169)."""
     c = getattr(mod, "cells_%d" % d)[i]
-    a = getattr(mod, "node_aggr_%d" % d)[i]
     if mod.recurr:
         out = [("w_ih", c.weight_ih), ("w_hh", c.weight_hh), ("b_ih", c.bias_ih), ("b_hh", c.bias_hh)]
     else:
         out = [("w_lin", c.weight), ("b_lin", c.bias)]
+    if mod.agg_x and i > 0:
+        return out
+    a = getattr(mod, "node_aggr_%d" % d)[i]
     if mod.agg == "gated_sum":
         out += [("wg", a.gate[0].weight), ("bg", a.gate[0].bias), ("wm", a.mapper.weight)]
         if a.mapper.bias is not None:
@@ -366,17 +370,156 @@ def _cell_params(mod, d, i):
     return out
 
 
+def _setup_aggregator(mod, plan, bc, o, p, cp, mode, lands, d, i, vals, query, W, a_out, rows, stream, x):
+    """Forward quantities of one aggregator for its reverse pass: the per-node projections (library GEMMs), the attention
+    weights and the aggregate `a_out` [N, W] of the rows `rows` = (first slot, end slot) (HIP), and the fields of the C
+    struct `bc` that describe it.  `vals` [N, W] are the aggregated values (the cell's states, or x with `agg_x`)."""
+    lib = _lib.load()
+    N, R = vals.shape[0], plan.R
+    f32 = dict(dtype=torch.float32, device=vals.device)
+    has_enc = "we" in cp
+    bc.mode, bc.lands = mode, lands
+    bc.edge_mat0, bc.edge_vec0 = _ptr(p.get("edge_mat0")), _ptr(p.get("edge_vec0"))
+    bc.edge_mat1, bc.edge_vec1 = _ptr(p.get("edge_mat1")), _ptr(p.get("edge_vec1"))
+    bc.h, bc.a = vals.data_ptr(), a_out.data_ptr()
+    o["esum"] = None
+
+    def aggregate(agg_mode, node0=None, node1=None, ld_node=0):
+        if rows[1] <= rows[0] or not lands:
+            return
+        ag = _lib.VariantAggregator()
+        ag.mode, ag.lands, ag.val_dim, ag.out_dim = agg_mode, 1, W, W
+        ag.vals, ag.ld_vals, ag.out, ag.ld_out = vals.data_ptr(), W, a_out.data_ptr(), W
+        ag.node0, ag.node1, ag.ld_node = node0, node1, ld_node
+        ag.edge_mat0, ag.edge_vec0, ag.edge_mat1, ag.edge_vec1 = bc.edge_mat0, bc.edge_vec0, bc.edge_mat1, bc.edge_vec1
+        engine.check(lib.dagnn_variant_aggregate(C.byref(plan.desc), C.byref(ag), d, rows[0], rows[1], stream),
+                     "dagnn_variant_aggregate")
+
+    if mode == _lib.AGG_GATED:
+        pq = torch.addmm(p["pq_b"], vals, p["pq_w_t"])
+        o["node0"], o["dnode0"] = pq, torch.zeros(N, 2 * W, **f32)
+        o["w_node"] = torch.cat([cp["wg"], cp["wm"]], 0).contiguous()
+        bc.node0, bc.dnode0, bc.w_node, bc.proj_dim = pq.data_ptr(), o["dnode0"].data_ptr(), o["w_node"].data_ptr(), W
+        if has_enc and R > 0:
+            o["esum"] = torch.zeros(N, 2 * R * W, **f32)
+        aggregate(_lib.AGG_GATED, pq.data_ptr(), pq.data_ptr() + 4 * W, 2 * W)
+    elif mode in (_lib.AGG_ADD, _lib.AGG_MAX):
+        if has_enc and R > 0 and lands:
+            o["esum"] = torch.zeros(N, (R + 1) * W, **f32)
+        aggregate(mode)
+    elif mode == _lib.AGG_ATTN:
+        keys = x if (mod.agg_attn_x or mod.agg_x) else vals
+        off, kd = _attn_slice(mod, i)
+        o.update(node0=keys, dnode0=torch.zeros(N, **f32), alpha=torch.zeros(max(plan.E, 1), **f32))
+        if has_enc and R > 0:
+            o["esum"] = torch.zeros(N, R, **f32)
+        bc.proj_dim = kd
+        bc.reserved = 1 if (mod.agg_x or not mod.agg_attn_x) else 0   # the keys are the aggregated values themselves
+        bc.node0, bc.dnode0, bc.alpha = keys.data_ptr(), o["dnode0"].data_ptr(), o["alpha"].data_ptr()
+        bc.w_node = p["edge_vec0"].data_ptr()
+        if rows[1] > rows[0]:
+            engine.check(lib.dagnn_variant_mattn_prepare(C.byref(plan.desc), C.byref(bc), d, W, rows[0], rows[1], stream),
+                         "dagnn_variant_mattn_prepare")
+    else:   # mattn
+        P = cp["wl"].shape[0]
+        kr = torch.addmm(cp["br"], vals, cp["wr"].t())
+        ql = torch.addmm(cp["bl"], query, cp["wl"].t())
+        o.update(node0=kr, node1=ql, dnode0=torch.zeros(N, P, **f32), dnode1=torch.zeros(N, P, **f32),
+                 alpha=torch.zeros(max(plan.E, 1), **f32), dlogit=torch.zeros(max(plan.E, 1), **f32))
+        if has_enc and R > 0:
+            o["esum"] = torch.zeros(N, R * P, **f32)
+        bc.proj_dim = P
+        bc.node0, bc.node1, bc.dnode0, bc.dnode1 = (o[n].data_ptr() for n in ("node0", "node1", "dnode0", "dnode1"))
+        bc.alpha, bc.dlogit = o["alpha"].data_ptr(), o["dlogit"].data_ptr()
+        bc.w_node, bc.w_query = cp["wr"].data_ptr(), cp["wl"].data_ptr()
+        if rows[1] > rows[0]:
+            engine.check(lib.dagnn_variant_mattn_prepare(C.byref(plan.desc), C.byref(bc), d, W, rows[0], rows[1], stream),
+                         "dagnn_variant_mattn_prepare")
+    bc.esum = _ptr(o["esum"])
+
+
+def _aggregator_grads(mod, mode, o, cp, vals, query, R, W, i, dx_d):
+    """{name: gradient} of one aggregator's parameters from the sweep's per-node outputs (transposed products and sums
+    over all nodes); `dx_d` additionally receives the key gradient of the `*_x` attention aggregators."""
+    g = {}
+    es = o.get("esum")
+    f32 = dict(dtype=torch.float32, device=vals.device)
+    if mode == _lib.AGG_GATED:
+        dpq = o["dnode0"]
+        prod = dpq.t() @ vals                       # [2W, W]: dP^T h | dM^T h
+        sums = dpq.sum(0)
+        gwg, gwm, dPs, dMs = prod[:W], prod[W:], sums[:W], sums[W:]
+        if "we" in cp:
+            We, be = cp["we"], cp["be"]
+            gwg = gwg + torch.outer(dPs, be)
+            gwm = gwm + torch.outer(dMs, be)
+            gbe = cp["wg"].t() @ dPs + cp["wm"].t() @ dMs
+            gwe = torch.zeros_like(We)
+            if es is not None:
+                esm = es.sum(0).view(2, R, W)      # [gate | map][r][k]
+                for r in range(R):
+                    gwg = gwg + torch.outer(esm[0, r], We[:, r])
+                    gwm = gwm + torch.outer(esm[1, r], We[:, r])
+                    gwe[:, r] = cp["wg"].t() @ esm[0, r] + cp["wm"].t() @ esm[1, r]
+            g["we"], g["be"] = gwe, gbe
+        g["wg"], g["bg"], g["wm"] = gwg, dPs, gwm
+        if "bm" in cp:
+            g["bm"] = dMs
+    elif mode == _lib.AGG_MATTN:
+        dkr, dql = o["dnode0"], o["dnode1"]
+        dkrs = dkr.sum(0)
+        gwr = dkr.t() @ vals
+        g["wl"], g["bl"] = dql.t() @ query, dql.sum(0)
+        if "we" in cp:
+            We, be = cp["we"], cp["be"]
+            gwr = gwr + torch.outer(dkrs, be)
+            gwe = torch.zeros_like(We)
+            if es is not None:
+                esm = es.sum(0).view(R, -1)
+                for r in range(R):
+                    gwr = gwr + torch.outer(esm[r], We[:, r])
+                    gwe[:, r] = cp["wr"].t() @ esm[r]
+            g["we"], g["be"] = gwe, cp["wr"].t() @ dkrs
+        g["wr"], g["br"] = gwr, dkrs
+    elif mode == _lib.AGG_ATTN:
+        # logit_e = w_k . (key_j + W_e attr_e + b_e) (+ query / bias terms that cancel inside a segment: exact zeros);
+        # sigma_v = sum of ds over the out-edges of v
+        sig = o["dnode0"]
+        off, kd = _attn_slice(mod, i)
+        wk = cp["attn_w"][0, off:off + kd]
+        g_key = (o["node0"] * sig[:, None]).sum(0)
+        if mod.agg_attn_x and not mod.agg_x:   # the keys are x, the values are the states: the key gradient goes to x here
+            dx_d += sig[:, None] * wk[None, :]
+        if "we" in cp:
+            m = es.sum(0) if es is not None else torch.zeros(R, **f32)
+            ssum = sig.sum()
+            g_key = g_key + cp["we"] @ m + cp["be"] * ssum
+            g["we"], g["be"] = torch.outer(wk, m), wk * ssum
+        g_attn = torch.zeros_like(cp["attn_w"])
+        g_attn[0, off:off + kd] = g_key
+        g["attn_w"], g["attn_b"] = g_attn, torch.zeros_like(cp["attn_b"])
+    else:   # add / max: only the (shared) edge encoder has parameters
+        if "we" in cp:
+            gwe, gbe = torch.zeros_like(cp["we"]), torch.zeros_like(cp["be"])
+            if es is not None:
+                esm = es.sum(0).view(R + 1, W)
+                for r in range(R):
+                    gwe[:, r] = esm[r]
+                gbe = esm[R]
+            g["we"], g["be"] = gwe, gbe
+    return g
+
+
 class VariantRecurrence(torch.autograd.Function):
-    """States h[d][i] of a `gated_sum` / `mattn_h` / `add` model, differentiable: forward = `run_hip` (the generic
-    lock-step kernels of csrc/variants.hip), backward = the reverse sweep of csrc/variants_bwd.hip + a parallel
-    epilogue (weight gradients as transposed products over all nodes).  Inputs after `x`: the parameters of every cell
-    in `_cell_params` order (a module shared by several cells - `add` - simply appears several times)."""
+    """States h[d][i] of a constructor-string variant, differentiable: forward = `run_hip` (the generic lock-step kernels
+    of csrc/variants.hip), backward = the reverse sweep of csrc/variants_bwd.hip + a parallel epilogue (weight gradients as
+    transposed products over all nodes).  Inputs after `x`: the parameters of every cell in `_cell_params` order (a
+    module shared by several cells - `add` / `max` - simply appears several times)."""
 
     @staticmethod
     def forward(ctx, mod, G, plan, x, *params):
         h = run_hip(mod, G, x, plan)
         ctx.mod, ctx.plan, ctx.h = mod, plan, h
-        ctx.ei, ctx.edge_attr = G.edge_index, getattr(G, "edge_attr", None)
         ctx.save_for_backward(x, *params)
         return tuple(h[d][i] for d in mod.dirs for i in range(mod.num_layers))
 
@@ -386,17 +529,15 @@ class VariantRecurrence(torch.autograd.Function):
         saved = list(ctx.saved_tensors)
         x, params = saved[0].detach(), [p.detach() for p in saved[1:]]
         N, H, L, E = x.shape[0], mod.hidden_dim, mod.num_layers, mod.emb_dim
-        dev = x.device
+        f32 = dict(dtype=torch.float32, device=x.device)
         lib = _lib.load()
-        f32 = dict(dtype=torch.float32, device=dev)
         mode = _BWD_MODES[mod.agg]
         R = plan.R
         sched = plan.read_schedule()
         stream = engine._stream(x)
         prm = _derive(mod)
         shared_flow = mod.agg in ("add", "max")
-        recurr = bool(mod.recurr)
-        # parameters of every cell by name
+        recurr, agg_x = bool(mod.recurr), bool(mod.agg_x)
         names, cellp, k = [], {}, 0
         for d in mod.dirs:
             for i in range(L):
@@ -406,8 +547,7 @@ class VariantRecurrence(torch.autograd.Function):
                 k += len(spec)
         args = _lib.VariantBwdArgs()
         args.num_stacked, args.H, args.dir_mask = L, H, sum(1 << d for d in mod.dirs)
-        keep, res = [], {}
-        g = {}
+        g, res, aggx = {}, {}, {}
         q = 0
         for d in mod.dirs:
             for i in range(L):
@@ -419,75 +559,37 @@ class VariantRecurrence(torch.autograd.Function):
             for d in mod.dirs:
                 lands = 0 if (shared_flow and d == 1) else 1
                 T = len(sched[d]) - 1
+                rows = (int(sched[d][1]), int(sched[d][T])) if T > 1 else (0, 0)
+                given = None
+                if agg_x:
+                    # the aggregator reads x only (dagnn.py:159-169): its output a_x [N, E] (zero-padded to H) is the
+                    # aggregate of EVERY stacked cell of the direction
+                    ao = dict(a=torch.zeros(N, E, **f32))
+                    bca = _lib.VariantBwdCell()
+                    bca.in_dim = E
+                    _setup_aggregator(mod, plan, bca, ao, prm[(d, 0)], cellp[(d, 0)], mode, lands, d, 0, x, x, E, ao["a"], rows, stream, x)
+                    given = torch.zeros(N, H, **f32)
+                    given[:, :E] = ao["a"]
+                    aggx[d] = (bca, ao)
                 for i in range(L):
                     p, cp, bc = prm[(d, i)], cellp[(d, i)], args.cell[d][i]
                     hi = h[d][i]
                     u = x if i == 0 else h[d][i - 1]
                     in_dim = u.shape[1]
-                    a = torch.zeros(N, H, **f32)
-                    o = dict(a=a, u=u, dgi=torch.zeros(N, 3 * H, **f32), dgh=torch.zeros(N, 3 * H, **f32),
-                             da=torch.zeros(N, H, **f32))
-                    bc.mode, bc.lands, bc.in_dim, bc.recurrent = mode, lands, in_dim, int(recurr)
-                    bc.edge_mat0, bc.edge_vec0 = _ptr(p.get("edge_mat0")), _ptr(p.get("edge_vec0"))
-                    bc.edge_mat1, bc.edge_vec1 = _ptr(p.get("edge_mat1")), _ptr(p.get("edge_vec1"))
-                    has_enc = "we" in cp
-                    if mode == _lib.AGG_GATED:
-                        pq = torch.addmm(p["pq_b"], hi, p["pq_w_t"])
-                        o["node0"], o["dnode0"] = pq, torch.zeros(N, 2 * H, **f32)
-                        o["w_node"] = torch.cat([cp["wg"], cp["wm"]], 0).contiguous()
-                        bc.node0, bc.dnode0, bc.w_node, bc.proj_dim = pq.data_ptr(), o["dnode0"].data_ptr(), o["w_node"].data_ptr(), H
-                        o["esum"] = torch.zeros(N, 2 * R * H, **f32) if (has_enc and R > 0) else None
-                        if T > 1:   # aggregates of every row beyond layer 0 (the forward's own aggregate kernel)
-                            ag = _lib.VariantAggregator()
-                            ag.mode, ag.lands, ag.val_dim, ag.out_dim = _lib.AGG_GATED, 1, H, H
-                            ag.vals, ag.ld_vals, ag.out, ag.ld_out = hi.data_ptr(), H, a.data_ptr(), H
-                            ag.node0, ag.node1, ag.ld_node = pq.data_ptr(), pq.data_ptr() + 4 * H, 2 * H
-                            ag.edge_mat0, ag.edge_vec0 = bc.edge_mat0, bc.edge_vec0
-                            ag.edge_mat1, ag.edge_vec1 = bc.edge_mat1, bc.edge_vec1
-                            engine.check(lib.dagnn_variant_aggregate(C.byref(plan.desc), C.byref(ag), d, int(sched[d][1]),
-                                                                     int(sched[d][T]), stream), "dagnn_variant_aggregate")
-                    elif mode in (_lib.AGG_ADD, _lib.AGG_MAX):
-                        o["esum"] = torch.zeros(N, (R + 1) * H, **f32) if (has_enc and R > 0 and lands) else None
-                        if T > 1 and lands:
-                            ag = _lib.VariantAggregator()
-                            ag.mode, ag.lands, ag.val_dim, ag.out_dim = mode, 1, H, H
-                            ag.vals, ag.ld_vals, ag.out, ag.ld_out = hi.data_ptr(), H, a.data_ptr(), H
-                            ag.edge_mat0, ag.edge_vec0 = bc.edge_mat0, bc.edge_vec0
-                            engine.check(lib.dagnn_variant_aggregate(C.byref(plan.desc), C.byref(ag), d, int(sched[d][1]),
-                                                                     int(sched[d][T]), stream), "dagnn_variant_aggregate")
-                    elif mode == _lib.AGG_ATTN:   # additive attention (only reached with the Linear cell)
-                        keys = x if mod.agg_attn_x else hi
-                        off, kd = _attn_slice(mod, i)
-                        o.update(node0=keys, dnode0=torch.zeros(N, **f32), alpha=torch.zeros(max(plan.E, 1), **f32))
-                        o["esum"] = torch.zeros(N, R, **f32) if (has_enc and R > 0) else None
-                        bc.proj_dim, bc.reserved = kd, (0 if mod.agg_attn_x else 1)
-                        bc.node0, bc.dnode0, bc.alpha = keys.data_ptr(), o["dnode0"].data_ptr(), o["alpha"].data_ptr()
-                        bc.w_node = p["edge_vec0"].data_ptr()
-                        bc.h, bc.a = hi.data_ptr(), a.data_ptr()
-                        if T > 1:
-                            engine.check(lib.dagnn_variant_mattn_prepare(C.byref(plan.desc), C.byref(bc), d, H, int(sched[d][1]),
-                                                                         int(sched[d][T]), stream), "dagnn_variant_mattn_prepare")
-                    else:   # mattn
-                        P = cp["wl"].shape[0]
-                        kr = torch.addmm(cp["br"], hi, cp["wr"].t())
-                        ql = torch.addmm(cp["bl"], u, cp["wl"].t())
-                        o.update(node0=kr, node1=ql, dnode0=torch.zeros(N, P, **f32), dnode1=torch.zeros(N, P, **f32),
-                                 alpha=torch.zeros(max(plan.E, 1), **f32), dlogit=torch.zeros(max(plan.E, 1), **f32))
-                        o["esum"] = torch.zeros(N, R * P, **f32) if (has_enc and R > 0) else None
-                        bc.proj_dim = P
-                        bc.node0, bc.node1, bc.dnode0, bc.dnode1 = (o[n].data_ptr() for n in ("node0", "node1", "dnode0", "dnode1"))
-                        bc.alpha, bc.dlogit = o["alpha"].data_ptr(), o["dlogit"].data_ptr()
-                        bc.w_node, bc.w_query = cp["wr"].data_ptr(), cp["wl"].data_ptr()
-                        bc.h, bc.a = hi.data_ptr(), a.data_ptr()
-                        if T > 1:
-                            engine.check(lib.dagnn_variant_mattn_prepare(C.byref(plan.desc), C.byref(bc), d, H, int(sched[d][1]),
-                                                                         int(sched[d][T]), stream), "dagnn_variant_mattn_prepare")
-                    bc.h, bc.a = hi.data_ptr(), a.data_ptr()
+                    o = dict(u=u, dgi=torch.zeros(N, 3 * H, **f32), dgh=torch.zeros(N, 3 * H, **f32), da=torch.zeros(N, H, **f32))
+                    bc.in_dim, bc.recurrent = in_dim, int(recurr)
+                    if agg_x:
+                        o["a"] = given
+                        bc.mode, bc.lands = _lib.AGG_GIVEN, 1
+                        bc.h, bc.a = hi.data_ptr(), given.data_ptr()
+                    else:
+                        o["a"] = torch.zeros(N, H, **f32)
+                        _setup_aggregator(mod, plan, bc, o, p, cp, mode, lands, d, i, hi, u, H, o["a"], rows, stream, x)
+                    a = o["a"]
                     if recurr:
-                        gi = engine.gemm_nt_bias([u], [cp["w_ih"]], [cp["b_ih"]])[0]
-                        gh = engine.gemm_nt_bias([a], [cp["w_hh"]], [cp["b_hh"]])[0]
-                        o["gi"], o["gh"] = gi, gh
-                        bc.gi, bc.gh = gi.data_ptr(), gh.data_ptr()
+                        o["gi"] = engine.gemm_nt_bias([u], [cp["w_ih"]], [cp["b_ih"]])[0]
+                        o["gh"] = engine.gemm_nt_bias([a], [cp["w_hh"]], [cp["b_hh"]])[0]
+                        bc.gi, bc.gh = o["gi"].data_ptr(), o["gh"].data_ptr()
                         bc.w_hh, bc.w_ih = cp["w_hh"].data_ptr(), cp["w_ih"].data_ptr()
                     else:   # Linear cell: W = [W_in | W_agg]
                         o["w_in"] = cp["w_lin"][:, :in_dim].contiguous()
@@ -496,16 +598,30 @@ class VariantRecurrence(torch.autograd.Function):
                     bc.g = g[(d, i)].data_ptr()
                     bc.g_in = (g[(d, i - 1)] if i > 0 else dxd[d]).data_ptr()
                     bc.da, bc.dgi, bc.dgh = o["da"].data_ptr(), o["dgi"].data_ptr(), o["dgh"].data_ptr()
-                    bc.esum = _ptr(o.get("esum"))
                     res[(d, i)] = o
+            import numpy as np
             ptrs = (C.POINTER(C.c_int32) * 2)()
             nl = (C.c_int32 * 2)()
+            one = np.array([0, N], dtype=np.int32)   # agg_x: nothing couples the layers - one pseudo-layer of all rows
             for d in (0, 1):
-                ptrs[d] = sched[d].ctypes.data_as(C.POINTER(C.c_int32))
-                nl[d] = len(sched[d]) - 1
+                sd = one if agg_x else sched[d]
+                ptrs[d] = sd.ctypes.data_as(C.POINTER(C.c_int32))
+                nl[d] = len(sd) - 1
             with engine._span("variant_backward_run", x):
                 engine.check(lib.dagnn_variant_backward_run(C.byref(plan.desc), C.byref(args), ptrs, nl, stream),
                              "dagnn_variant_backward_run")
+                if agg_x:   # the aggregator's own reverse pass: one shot over all rows, into the gradient of x
+                    for d in mod.dirs:
+                        bca, ao = aggx[d]
+                        if not bca.lands:
+                            continue
+                        dps = res[(d, 0)]["da"]
+                        for i in range(1, L):
+                            dps = dps + res[(d, i)]["da"]
+                        ao["da"] = dps[:, :E].contiguous()
+                        bca.da, bca.g, bca.g_in = ao["da"].data_ptr(), dxd[d].data_ptr(), dxd[d].data_ptr()
+                        engine.check(lib.dagnn_variant_aggregator_backward(C.byref(plan.desc), C.byref(bca), d, E, 0, N, stream),
+                                     "dagnn_variant_aggregator_backward")
             # ---- epilogue: parameter gradients (transposed products over all nodes) ----
             grads = {}
             jobs = []
@@ -531,73 +647,17 @@ class VariantRecurrence(torch.autograd.Function):
                         kq += 2
                         grads[(d, i, "w_ih")], grads[(d, i, "b_ih")] = gw_ih, gb_ih
                         grads[(d, i, "w_hh")], grads[(d, i, "b_hh")] = gw_hh, gb_hh
-                    hi = h[d][i]
-                    es = o.get("esum")
-                    if mode == _lib.AGG_GATED:
-                        dpq = o["dnode0"]
-                        prod = dpq.t() @ hi                       # [2H, H]: dP^T h | dM^T h
-                        sums = dpq.sum(0)
-                        gwg, gwm, dPs, dMs = prod[:H], prod[H:], sums[:H], sums[H:]
-                        if "we" in cp:
-                            We, be = cp["we"], cp["be"]
-                            gwg = gwg + torch.outer(dPs, be)
-                            gwm = gwm + torch.outer(dMs, be)
-                            gbe = cp["wg"].t() @ dPs + cp["wm"].t() @ dMs
-                            gwe = torch.zeros_like(We)
-                            if es is not None:
-                                esm = es.sum(0).view(2, R, H)      # [gate | map][r][k]
-                                for r in range(R):
-                                    gwg = gwg + torch.outer(esm[0, r], We[:, r])
-                                    gwm = gwm + torch.outer(esm[1, r], We[:, r])
-                                    gwe[:, r] = cp["wg"].t() @ esm[0, r] + cp["wm"].t() @ esm[1, r]
-                            grads[(d, i, "we")], grads[(d, i, "be")] = gwe, gbe
-                        grads[(d, i, "wg")], grads[(d, i, "bg")], grads[(d, i, "wm")] = gwg, dPs, gwm
-                        if "bm" in cp:
-                            grads[(d, i, "bm")] = dMs
-                    elif mode == _lib.AGG_MATTN:
-                        dkr, dql = o["dnode0"], o["dnode1"]
-                        dkrs = dkr.sum(0)
-                        gwr = dkr.t() @ hi
-                        grads[(d, i, "wl")], grads[(d, i, "bl")] = dql.t() @ o["u"], dql.sum(0)
-                        if "we" in cp:
-                            We, be = cp["we"], cp["be"]
-                            gwr = gwr + torch.outer(dkrs, be)
-                            gwe = torch.zeros_like(We)
-                            if es is not None:
-                                esm = es.sum(0).view(R, -1)
-                                for r in range(R):
-                                    gwr = gwr + torch.outer(esm[r], We[:, r])
-                                    gwe[:, r] = cp["wr"].t() @ esm[r]
-                            grads[(d, i, "we")], grads[(d, i, "be")] = gwe, cp["wr"].t() @ dkrs
-                        grads[(d, i, "wr")], grads[(d, i, "br")] = gwr, dkrs
-                    elif mode == _lib.AGG_ATTN:
-                        # logit_e = w_k . (key_j + W_e attr_e + b_e) (+ query / bias terms that cancel inside a segment:
-                        # exact zeros); sigma_v = sum of ds over the out-edges of v
-                        sig = o["dnode0"]
-                        off, kd = _attn_slice(mod, i)
-                        wk = cp["attn_w"][0, off:off + kd]
-                        g_key = (o["node0"] * sig[:, None]).sum(0)
-                        if mod.agg_attn_x:   # the score of node v is w_k . x_v
-                            dxd[d] += sig[:, None] * wk[None, :]
-                        if "we" in cp:
-                            m = es.sum(0) if es is not None else torch.zeros(R, **f32)
-                            ssum = sig.sum()
-                            g_key = g_key + cp["we"] @ m + cp["be"] * ssum
-                            grads[(d, i, "we")], grads[(d, i, "be")] = torch.outer(wk, m), wk * ssum
-                        g_attn = torch.zeros_like(cp["attn_w"])
-                        g_attn[0, off:off + kd] = g_key
-                        grads[(d, i, "attn_w")], grads[(d, i, "attn_b")] = g_attn, torch.zeros_like(cp["attn_b"])
-                    else:   # add / max: only the (shared) edge encoder has parameters
-                        if "we" in cp:
-                            gwe, gbe = torch.zeros_like(cp["we"]), torch.zeros_like(cp["be"])
-                            if es is not None:
-                                esm = es.sum(0).view(R + 1, H)
-                                for r in range(R):
-                                    gwe[:, r] = esm[r]
-                                gbe = esm[R]
-                            grads[(d, i, "we")], grads[(d, i, "be")] = gwe, gbe
+                    if agg_x:
+                        if i == 0:
+                            _, ao = aggx[d]
+                            ag = _aggregator_grads(mod, mode, ao, cp, x, x, R, E, 0, dxd[d]) if "da" in ao else {}
+                            for n in cp:
+                                if n not in ("w_ih", "w_hh", "b_ih", "b_hh", "w_lin", "b_lin"):
+                                    grads[(d, i, n)] = ag.get(n, torch.zeros_like(cp[n]))
+                    else:
+                        for n, v in _aggregator_grads(mod, mode, o, cp, h[d][i], o["u"], R, H, i, dxd[d]).items():
+                            grads[(d, i, n)] = v
             dx = None
             if ctx.needs_input_grad[3]:
                 dx = sum(dxd[d] for d in mod.dirs)
-        del keep
         return (None, None, None, dx) + tuple(grads[n] for n in names)

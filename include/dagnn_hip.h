@@ -643,6 +643,12 @@ int dagnn_variant_mattn_prepare(const dagnn_plan* plan /* host */, const dagnn_v
                                 int32_t row_begin, int32_t row_end, void* stream);
 int dagnn_variant_backward_run(const dagnn_plan* plan /* host */, const dagnn_variant_bwd_args* args /* host */,
                                const int32_t* const* layer_ptr /* host */, const int32_t* num_layers /* host [2] */, void* stream);
+/* `agg_x` (dagnn.py:159-169: the aggregator reads the node inputs only): the cells' sweep runs with mode DAGNN_AGG_GIVEN
+ * (nothing is pulled) over ONE pseudo-layer holding all rows, then the aggregator's reverse pass is one shot over all rows:
+ * `cell` with h = x [N, width], a = the aggregator's output, da = the gradient of that output summed over the stacked
+ * cells, g = g_in = the gradient of x (accumulated into). */
+int dagnn_variant_aggregator_backward(const dagnn_plan* plan /* host */, const dagnn_variant_bwd_cell* cell /* host */, int dir,
+                                      int width, int32_t row_begin, int32_t row_end, void* stream);
 
 /* D-VAE read-out (dvae/dagnn.py:147-161, dvae/dagnn_bn.py:138-152): every graph has exactly
  * `stride` nodes; gather row g*stride + node_off of h [N,ld_h] into out[g, col_off : col_off+width]. */

@@ -423,7 +423,12 @@ def main():
                                  ("recurr0_mattn", 58, dict(agg="mattn_h", recurr=0)),
                                  ("recurr0_attn_h", 59, dict(agg="attn_h", recurr=0)),
                                  ("recurr0_attn_x", 60, dict(agg="attn_x", recurr=0)),
-                                 ("recurr0_self_attn_h", 61, dict(agg="self_attn_h", recurr=0))):
+                                 ("recurr0_self_attn_h", 61, dict(agg="self_attn_h", recurr=0)),
+                                 ("aggx_attn_h", 62, dict(agg="attn_h", agg_x=True)),
+                                 ("aggx_add", 63, dict(agg="add", agg_x=True)),
+                                 ("aggx_gated", 64, dict(agg="gated_sum", agg_x=True)),
+                                 ("aggx_mattn", 65, dict(agg="mattn_h", agg_x=True)),
+                                 ("aggx_max_recurr0", 66, dict(agg="max", agg_x=True, recurr=0))):
             L_ = extra.pop("num_layers", 2)
             make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, "grad_var_h64_" + tag, data_seed=seed, B=5, mean_n=30,
                             H=64, L=L_, w_seed=150 + seed, y_seed=350 + seed, **extra, **common)

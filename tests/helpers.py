@@ -22,7 +22,8 @@ VARIANTS = ["var_h64_" + t for t in ("gated_sum", "gated_nobias", "mattn_h", "ad
 GRAD = ["grad_h32_bidir", "grad_h256_bidir", "grad_h128_deep", "grad_h64_L3_wx", "grad_h64_unidir",
         "grad_h64_mean_all"]
 GRAD_VAR = ["grad_var_h64_" + t for t in ("gated_sum", "gated_nobias", "mattn_h", "add", "mattn_h_L3", "max", "recurr0_gated",
-                                           "recurr0_mattn", "recurr0_attn_h", "recurr0_attn_x", "recurr0_self_attn_h")]
+                                           "recurr0_mattn", "recurr0_attn_h", "recurr0_attn_x", "recurr0_self_attn_h",
+                                           "aggx_attn_h", "aggx_add", "aggx_gated", "aggx_mattn", "aggx_max_recurr0")]
 DVAE_GRAD = ["grad_na_h64_unidir", "grad_bn_h64_bidir"]
 DVAE = ["na_h128_unidir", "na_h64_bidir", "bn_h256_bidir", "bn_h64_unidir", "na_h64_poolall_max", "bn_h64_poolall_mean"]
 

@@ -91,7 +91,7 @@ def test_oracle_variant_training_step_gradients_match_reference(name):
     kw = meta["ctor"]
     loss, grads = O.code2_grads(model.state_dict(), G, torch.from_numpy(arr["y"]), num_layers=kw["num_layers"],
                                 bidirectional=True, out_wx=kw["out_wx"], max_seq_len=meta["S"], agg=kw["agg"],
-                                recurr=kw.get("recurr", 1))
+                                recurr=kw.get("recurr", 1), agg_x=kw.get("agg_x", False))
     assert abs(float(loss) - float(arr["loss"])) < 1e-5
     if kw["agg"] in ("add", "max"):
         # the reference builds ONE AggConv for every layer and direction (dagnn.py:74-75): `named_parameters()` lists it

@@ -32,7 +32,7 @@ def _check_line(j, n_gpus, steps, warmup, with_cpu=True):
         assert c["kind"] in ("port", "reference") and c["unit"] == j["unit"] and c["cores"] >= 1 and c["value"] > 0
 
 
-@pytest.mark.parametrize("name", ["r01_final_bench.json.log", "r02_final_bench.json.log"])
+@pytest.mark.parametrize("name", ["r01_final_bench.json.log", "r02_final_bench.json.log", "r03_final_bench.json.log"])
 def test_committed_round_line_keeps_the_contract(name):
     path = os.path.join(ROOT, "profiles", name)
     lines = [l for l in open(path).read().splitlines() if l.startswith("{")]
@@ -45,6 +45,11 @@ def test_committed_round_line_keeps_the_contract(name):
         assert j["cpu_baseline"]["vectorised"]["value"] > 0 and j["cpu_baseline"]["cpu"]
         assert set(j["other_configs"]) >= {"cfg1_NA_B64_h128_L2_unidir", "cfg4_BN_B128_h256_L2_bidir"}
         assert j["training_step"]["ms_per_step_median"] > 0
+    if name.startswith("r03"):   # round 3: traffic tied to the kernel sources, one reverse launch, all three other configurations
+        assert j["roofline"]["traffic_source"].startswith("profiles/r03_pmc_traffic.json") and j["roofline"]["traffic"] > 0
+        assert j["roofline"]["schedule"] == "dataflow" and j["roofline"]["frac"] > 0.15
+        assert set(j["other_configs"]) >= {"cfg1_NA_B64_h128_L2_unidir", "cfg4_BN_B128_h256_L2_bidir", "cfg5_code2_B256_h512_L5_bidir"}
+        assert j["training_step"]["kernels_ms_per_step"]["backward_run"] < 3.0
 
 
 def _run_bench(args, env_extra=None, launcher=()):

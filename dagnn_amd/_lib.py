@@ -142,6 +142,10 @@ class VariantCell(C.Structure):
                 ("num_maps", C.c_int32), ("reserved", C.c_int32)]
 
 
+class GatherJob(C.Structure):
+    _fields_ = [("h", C.c_void_p), ("ld_h", C.c_int), ("width", C.c_int), ("node_off", C.c_int), ("col_off", C.c_int)]
+
+
 class IpropLayer(C.Structure):
     _fields_ = [("w_ih", C.c_void_p), ("w_hh", C.c_void_p), ("b_ih", C.c_void_p), ("b_hh", C.c_void_p), ("in_dim", C.c_int)]
 
@@ -225,6 +229,7 @@ SYMBOLS = {
                                              C.POINTER(C.c_int32), C.c_void_p]),
     "dagnn_iprop_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int, C.POINTER(IpropLayer), C.c_int, C.c_void_p, C.c_void_p]),
+    "dagnn_gather_rows_batch": (C.c_int, [C.POINTER(GatherJob), C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_gather_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int, C.c_void_p]),
 }

@@ -133,6 +133,15 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restric
     for (int j = threadIdx.x; j < width; j += blockDim.x) out[g * ld_out + col_off + j] = src[j];
 }
 
+// the same for up to 16 (matrix, node offset, column offset) jobs in one launch (blockIdx.y = job)
+struct GatherJobs { const float* h[16]; int ld_h[16], width[16], node_off[16], col_off[16]; };
+__global__ void __launch_bounds__(256) gather_rows_batch_kernel(GatherJobs J, int stride, float* __restrict__ out, int ld_out) {
+    const int64_t g = blockIdx.x;
+    const int q = blockIdx.y;
+    const float* src = J.h[q] + (g * stride + J.node_off[q]) * (int64_t)J.ld_h[q];
+    for (int j = threadIdx.x; j < J.width[q]; j += blockDim.x) out[g * ld_out + J.col_off[q] + j] = src[j];
+}
+
 // ---- decoder-side single-vertex step (dvae/dagnn.py:187-239, dvae/dagnn_bn.py:179-238): for every graph that has
 // vertex v, aggregate the states of v's predecessors with the reference's PADDED soft-max (the predecessor lists are
 // padded to the longest one with zero rows, and the soft-max runs over the padding as well: a padded key scores
@@ -288,6 +297,24 @@ extern "C" int dagnn_gather_rows(const float* h, int ld_h, int width, int64_t nu
     if (num_graphs == 0) return DAGNN_OK;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)num_graphs), dim3(256), 0, (hipStream_t)stream, h, ld_h,
                        width, stride, node_off, out, ld_out, col_off);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
+extern "C" int dagnn_gather_rows_batch(const dagnn_gather_job* jobs, int n, int64_t num_graphs, int stride, float* out, int ld_out,
+                                       void* stream) {
+    if (!jobs || !out || n < 0 || n > 16 || num_graphs < 0 || stride <= 0) return DAGNN_EINVAL;
+    if (num_graphs == 0 || n == 0) return DAGNN_OK;
+    GatherJobs J;
+    for (int q = 0; q < n; ++q) {
+        const dagnn_gather_job& j = jobs[q];
+        if (!j.h || j.width <= 0 || j.ld_h < j.width || j.node_off < 0 || j.node_off >= stride || j.col_off < 0 ||
+            ld_out < j.col_off + j.width)
+            return DAGNN_EINVAL;
+        J.h[q] = j.h; J.ld_h[q] = j.ld_h; J.width[q] = j.width; J.node_off[q] = j.node_off; J.col_off[q] = j.col_off;
+    }
+    hipLaunchKernelGGL(gather_rows_batch_kernel, dim3((unsigned)num_graphs, (unsigned)n), dim3(256), 0, (hipStream_t)stream, J,
+                       stride, out, ld_out);
     DAGNN_CHECK_LAUNCH();
     return DAGNN_OK;
 }

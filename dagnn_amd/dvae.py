@@ -163,10 +163,14 @@ class _DvaeDagnn(_DvaeBase):
         """End vertex of every graph for d = 0, start vertex for d = 1 (dvae/dagnn.py:147-161, dagnn_bn.py:138-152)."""
         L, H, nn_ = self.num_layers, self.hidden_dim, self.num_nodes
         hcat = torch.empty(B, len(self.dirs) * L * H, dtype=torch.float32, device=x.device)
-        for i in range(L):
-            engine.gather_rows(h[0][i], B, nn_, nn_ - 1, hcat, i * H)
-            if self.bidirectional:
-                engine.gather_rows(h[1][i], B, nn_, 0, hcat, (L + i) * H)
+        jobs = [(h[0][i], nn_ - 1, i * H) for i in range(L)]
+        if self.bidirectional:
+            jobs += [(h[1][i], 0, (L + i) * H) for i in range(L)]
+        if len(jobs) <= 16:
+            engine.gather_rows_batch(jobs, B, nn_, hcat)   # one launch for every (direction, stacked layer)
+        else:
+            for t, off, col in jobs:
+                engine.gather_rows(t, B, nn_, off, hcat, col)
         return hcat
 
     def _readout_backward(self, plan, x, h, gout, g_ext, dx):

@@ -988,6 +988,18 @@ def iprop_step(values: Optional[torch.Tensor], pred_vid: Optional[torch.Tensor],
     return states
 
 
+def gather_rows_batch(jobs, num_graphs: int, stride: int, out: torch.Tensor) -> None:
+    """`gather_rows` for several (h, node_off, col_off) in one launch."""
+    arr = (_lib.GatherJob * len(jobs))()
+    keep = []
+    for k, (h, node_off, col_off) in enumerate(jobs):
+        h = _rows(h, "h")
+        keep.append(h)
+        arr[k] = _lib.GatherJob(h.data_ptr(), h.stride(0), h.shape[1], int(node_off), int(col_off))
+    check(_lib.load().dagnn_gather_rows_batch(arr, len(jobs), num_graphs, stride, out.data_ptr(), out.shape[1], _stream(out)),
+          "dagnn_gather_rows_batch")
+
+
 def topo_layers(edge_index: torch.Tensor, batch: torch.Tensor, num_graphs: int):
     """(layer_fwd, layer_bwd, status): longest-path layer ids of both orientations for a collated batch, on the
     device (`src/utils_dag.py:8-52` without the per-graph numpy pass).  `status` is a device int32[1]: bit 16 =

@@ -654,6 +654,10 @@ int dagnn_variant_aggregator_backward(const dagnn_plan* plan /* host */, const d
  * `stride` nodes; gather row g*stride + node_off of h [N,ld_h] into out[g, col_off : col_off+width]. */
 int dagnn_gather_rows(const float* h, int ld_h, int width, int64_t num_graphs, int stride, int node_off,
                       float* out, int ld_out, int col_off, void* stream);
+/* ... for up to 16 (matrix, node offset, column offset) jobs in one launch: every (direction, stacked layer) of the read-out */
+typedef struct dagnn_gather_job { const float* h; int ld_h, width, node_off, col_off; } dagnn_gather_job;
+int dagnn_gather_rows_batch(const dagnn_gather_job* jobs /* host */, int n, int64_t num_graphs, int stride, float* out, int ld_out,
+                            void* stream);
 
 /* Decoder-side single-vertex step of the D-VAE models: `_ipropagate_to(G, v, propagator, H)` (dvae/dagnn.py:187-239,
  * dvae/dagnn_bn.py:179-238; called as `_update_iv` from models_pyg.py:247-250), for all B graphs that have vertex v, in

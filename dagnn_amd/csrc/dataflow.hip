@@ -104,7 +104,28 @@ __global__ void __launch_bounds__(256) df_assign_kernel(const int32_t* __restric
     // fast form of the B-step chain when (cost << 6 | group) fits 32 bits: ONE wave minimum per graph gives the least
     // load and, through the low bits, the lowest group that has it (38 -> 17 us at B = 128)
     const long long bound = (long long)c_row * plan[L.node_ptr + B] + (long long)c_layer * (staged && count > 0 ? s_d[0] : 0);
-    if (staged && bound < (1ll << 25)) {
+    // every graph has the same node count (the D-VAE batches: dvae/dagnn.py:150-158 hard-codes that stride): no B-step chain -
+    // the depth-sorted graphs are dealt round-robin (graph j of the order -> group j mod G), all lanes at once
+    bool uniform = staged && count > 0;
+#ifdef DF_EXP_NO_UNIFORM
+    uniform = false;
+#endif
+    if (uniform) {
+        int lo = 0x7fffffff, hi = 0;
+        for (int j = lane; j < count; j += 64) { lo = min(lo, s_n[j]); hi = max(hi, s_n[j]); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+        uniform = lo == hi;
+    }
+    if (uniform) {
+        const int ng = s_n[0];
+        for (int j = lane; j < count; j += 64) ws[S.grp_of + s_g[j]] = j % G;
+        if (lane < G && lane < count) {
+            depth = s_d[lane];
+            empty = false;
+            load = (long long)c_layer * depth + (long long)c_row * ng * ((count - lane + G - 1) / G);
+        }
+    } else if (staged && bound < (1ll << 25)) {
         unsigned load32 = 0;
 #pragma unroll 4
         for (int j = 0; j < count; ++j) {

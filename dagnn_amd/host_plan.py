@@ -254,10 +254,17 @@ def build_dataflow_schedule_host(plan_words, N: int, E: int, B: int, R: int, gro
     gdepth = np.zeros(G, dtype=np.int64)
     empty = np.ones(G, dtype=bool)
     grp = np.zeros(B, dtype=np.int64)
-    for it in items:
-        if it & 1:
-            continue
-        g = int(it) >> 1
+    order = [int(it) >> 1 for it in items if not (it & 1)]   # graphs, deepest first (direction-0 entries of `items`)
+    if B <= 4096 and len(order) > 0 and int(n_of.min()) == int(n_of.max()):
+        # every graph has the same node count (the D-VAE batches): dealt round-robin in depth order, no sequential chain
+        for j, g in enumerate(order):
+            grp[g] = j % G
+        for k in range(min(G, len(order))):
+            dg = int(max(depth[0][order[k]], depth[1][order[k]]))
+            gdepth[k] = dg
+            load[k] = cost_layer * dg + cost_row * int(n_of[0]) * ((len(order) - k + G - 1) // G)
+        order = []
+    for g in order:
         dg = int(max(depth[0][g], depth[1][g]))
         cand = load + cost_row * int(n_of[g]) + np.where(empty, cost_layer * dg, 0)
         k = int(np.argmin(cand))   # first minimum = lowest group

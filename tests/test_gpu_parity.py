@@ -600,6 +600,7 @@ def test_host_plan_equals_device_plan_word_for_word(device, seed, B, mean_n):
 
 
 @pytest.mark.parametrize("seed,B,mean_n,G", [(2, 17, 60, 5), (0, 128, 125, 5), (5, 1, 12, 1), (7, 64, 14, 21), (8, 300, 20, 8),
+                                             (9, 40, 4, 6), (10, 7, 4, 16),   # every graph 11 nodes: the round-robin deal
                                              (-1, 6, 0, 3)])
 def test_dataflow_schedule_host_equals_device_word_for_word(device, seed, B, mean_n, G):
     """`dagnn_dataflow_schedule` (LPT groups, group-ordered padded records) against its numpy mirror."""

@@ -28,7 +28,7 @@ class ReadoutJob(C.Structure):
 
 class Plan(C.Structure):
     _fields_ = [("data", C.c_void_p), ("bytes", C.c_size_t), ("N", C.c_int64), ("E", C.c_int64),
-                ("B", C.c_int64), ("num_edge_feats", C.c_int)]
+                ("B", C.c_int64), ("num_edge_feats", C.c_int), ("flags", C.c_int)]
 
 
 class GemmGroup(C.Structure):
@@ -172,6 +172,7 @@ class VariantArgs(C.Structure):
 SYMBOLS = {
     "dagnn_version": (C.c_char_p, []),
     "dagnn_plan_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int]),
+    "dagnn_plan_is_small": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     "dagnn_plan_layout": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
     "dagnn_plan_build": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),

@@ -164,13 +164,16 @@ __device__ __host__ __forceinline__ int bd_stream_group(int pair, int set, int g
 // {v, first / last CSR slot of v's row in direction 1 - d, 0, first four successors, their original edge ids, 0 x 4}
 __global__ void __launch_bounds__(256) bd_records_kernel(const int32_t* __restrict__ plan, PlanLayout L,
                                                           const int32_t* __restrict__ sched, DfLayout S,
-                                                          int32_t* __restrict__ brecs, int64_t nrec,
+                                                          int32_t* __restrict__ brecs, int64_t nrec, int groups,
                                                           const int32_t* __restrict__ status) {
     if (status && status[0] != 0) return;
     const int d = blockIdx.y, od = 1 - d;
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrec) return;
-    const int v = sched[S.grec[d] + 16 * r];
+    // the schedule defines the records its groups use (first record of the last group + its blocks); behind them: padding
+    const int32_t* last = sched + S.gtab[d] + 2 * (groups - 1);
+    const int64_t used = (int64_t)last[0] + (int64_t)DF_RB * last[1];
+    const int v = r < used ? sched[S.grec[d] + 16 * r] : -1;
     int4* out = reinterpret_cast<int4*>(brecs + (int64_t)d * 16 * nrec + 16 * r);
     if (v < 0) {
         out[0] = make_int4(-1, 0, 0, 0);
@@ -883,7 +886,7 @@ extern "C" int dagnn_bwd_dataflow_prepare(const dagnn_plan* pl, const dagnn_bwd_
     const DfLayout SL = df_layout_words(pl->N, pl->B, G);
     const int64_t nrec = 4 * pl->N + 4;
     hipLaunchKernelGGL(bd_records_kernel, dim3((unsigned)((nrec + 255) / 256), 2), dim3(256), 0, st, (const int32_t*)pl->data, L,
-                       (const int32_t*)a->schedule, SL, (int32_t*)a->records, nrec, (const int32_t*)a->plan_status);
+                       (const int32_t*)a->schedule, SL, (int32_t*)a->records, nrec, G, (const int32_t*)a->plan_status);
     DAGNN_CHECK_LAUNCH();
     BdStatArgs A;
     A.ncell = 0; A.H = H; A.ld_h = a->ld_h; A.ld_g = a->ld_g;

@@ -101,6 +101,15 @@ enum { PH_N = 0, PH_E = 1, PH_B = 2, PH_R = 3, PH_MAGIC = 4, PH_THR0 = 5, PH_THR
 #define DAGNN_PLAN_THIN_ROWS 14
 #define DAGNN_PLAN_MAGIC 0x44414731  // "DAG1"
 
+// ------------------------------------------------------------------ small batches (small.hip)
+// One-workgroup builds of plan and dataflow schedule, word for word the arrays of the general kernels; taken by
+// dagnn_plan_build / dagnn_dataflow_schedule when dagnn_plan_is_small(N, E, B) and the plan's flags allow it.
+extern "C" int dagnn_plan_is_small(int64_t N, int64_t E, int64_t B);
+int dagnn_plan_build_small(const dagnn_plan* pl, const int64_t* edge_index, const int64_t* layer_fwd, const int64_t* layer_bwd,
+                           const int64_t* batch, const float* edge_attr, int32_t* status, hipStream_t stream);
+int dagnn_dataflow_schedule_small(const dagnn_plan* pl, int32_t* ws, int groups, int cost_layer, int cost_row,
+                                  const int32_t* status, hipStream_t stream);
+
 // ------------------------------------------------------------------ wave-level reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

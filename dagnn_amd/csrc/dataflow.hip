@@ -40,18 +40,6 @@ namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// minimum over the 64 lanes as a wave-uniform value: inclusive row scans (row_shr 1, 2, 4, 8), then the last lane of a
-// row into the next row (row_bcast15) and of the first half into the second (row_bcast31); a lane without a source
-// keeps its own value (old operand = the value, bound_ctrl off)
-__device__ __forceinline__ unsigned df_wave_umin(unsigned v) {
-#define DF_DPP_MIN(ctrl, rmask) \
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false))
-    DF_DPP_MIN(0x111, 0xf); DF_DPP_MIN(0x112, 0xf); DF_DPP_MIN(0x114, 0xf); DF_DPP_MIN(0x118, 0xf);
-    DF_DPP_MIN(0x142, 0xa); DF_DPP_MIN(0x143, 0xc);
-#undef DF_DPP_MIN
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
 // ---- LPT assignment: graphs in order of decreasing depth (plan items), each to the group whose load it raises the
 // least; load_k = c_layer * (depth of the first = deepest graph of k) + c_row * (nodes of k).  One wave, lane = group.
 // Workgroups 1.. of the launch initialise the rest of the workspace meanwhile (tables and counters = 0, records = -1:
@@ -74,108 +62,7 @@ __global__ void __launch_bounds__(256) df_assign_kernel(const int32_t* __restric
     // staged in LDS first - from global memory every step is three dependent round trips (measured 76 us at B = 128)
     constexpr int CAP = 4096;
     __shared__ int32_t s_g[CAP], s_d[CAP], s_n[CAP];
-    const int32_t* items = plan + L.items;
-    const bool staged = B <= CAP;
-    const int lane = threadIdx.x;
-    // compact the direction-0 entries in order (wave-level prefix over 64 entries at a time)
-    int count = 0;
-    if (staged) {
-        for (int j0 = 0; j0 < 2 * B; j0 += 64) {
-            const int j = j0 + lane;
-            const int it = j < 2 * B ? items[j] : 1;
-            const bool keep = !(it & 1);
-            const unsigned long long m = __ballot(keep);
-            if (keep) {
-                const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-                const int g = it >> 1;
-                s_g[pos] = g;
-                s_d[pos] = max(plan[L.depth[0] + g], plan[L.depth[1] + g]);
-                s_n[pos] = plan[L.node_ptr + g + 1] - plan[L.node_ptr + g];
-            }
-            count += __popcll(m);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    long long load = 0;
-    int depth = 0;
-    bool empty = true;
-    const int steps = staged ? count : 2 * B;
-    // fast form of the B-step chain when (cost << 6 | group) fits 32 bits: ONE wave minimum per graph gives the least
-    // load and, through the low bits, the lowest group that has it (38 -> 17 us at B = 128)
-    const long long bound = (long long)c_row * plan[L.node_ptr + B] + (long long)c_layer * (staged && count > 0 ? s_d[0] : 0);
-    // every graph has the same node count (the D-VAE batches: dvae/dagnn.py:150-158 hard-codes that stride): no B-step chain -
-    // the depth-sorted graphs are dealt round-robin (graph j of the order -> group j mod G), all lanes at once
-    bool uniform = staged && count > 0;
-#ifdef DF_EXP_NO_UNIFORM
-    uniform = false;
-#endif
-    if (uniform) {
-        int lo = 0x7fffffff, hi = 0;
-        for (int j = lane; j < count; j += 64) { lo = min(lo, s_n[j]); hi = max(hi, s_n[j]); }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
-        uniform = lo == hi;
-    }
-    if (uniform) {
-        const int ng = s_n[0];
-        for (int j = lane; j < count; j += 64) ws[S.grp_of + s_g[j]] = j % G;
-        if (lane < G && lane < count) {
-            depth = s_d[lane];
-            empty = false;
-            load = (long long)c_layer * depth + (long long)c_row * ng * ((count - lane + G - 1) / G);
-        }
-    } else if (staged && bound < (1ll << 25)) {
-        unsigned load32 = 0;
-#pragma unroll 4
-        for (int j = 0; j < count; ++j) {
-            const int g = s_g[j], dg = s_d[j], ng = s_n[j];
-            const unsigned cand = load32 + (unsigned)(c_row * ng) + (empty ? (unsigned)(c_layer * dg) : 0u);
-            const unsigned best = df_wave_umin(lane < G ? (cand << 6) | (unsigned)lane : 0xffffffffu);
-            const int k = (int)(best & 63u);
-            if (lane == k) {
-                load32 = cand;
-                if (empty) { depth = dg; empty = false; }
-            }
-            if (lane == 0) ws[S.grp_of + g] = k;
-        }
-        load = load32;
-    } else
-    for (int j = 0; j < steps; ++j) {
-        int g, dg, ng;
-        if (staged) {
-            g = s_g[j]; dg = s_d[j]; ng = s_n[j];
-        } else {
-            const int it = items[j];
-            if (it & 1) continue;
-            g = it >> 1;
-            dg = max(plan[L.depth[0] + g], plan[L.depth[1] + g]);
-            ng = plan[L.node_ptr + g + 1] - plan[L.node_ptr + g];
-        }
-        long long cand = load + (long long)c_row * ng + (empty ? (long long)c_layer * dg : 0);
-        if (lane >= G) cand = 0x7fffffffffffffffLL;
-        // wave minimum of the 64-bit candidates, high words first (two DPP scans instead of six 64-bit shuffles through
-        // the LDS crossbar on the B-step dependent chain: 57 -> 20 us at B = 128)
-        const unsigned hi = (unsigned)((unsigned long long)cand >> 32), lo = (unsigned)cand;
-        const unsigned best_hi = df_wave_umin(hi);
-        const unsigned best_lo = df_wave_umin(hi == best_hi ? lo : 0xffffffffu);
-        const unsigned long long m = __ballot(hi == best_hi && lo == best_lo);
-        const int k = __ffsll((long long)m) - 1;
-        if (lane == k) {
-            load = cand;
-            if (empty) { depth = dg; empty = false; }
-        }
-        if (lane == 0) ws[S.grp_of + g] = k;
-    }
-    if (lane < G) { ws[S.gdepth + lane] = depth; ws[S.gload + lane] = (int)(load > 0x7fffffff ? 0x7fffffff : load); }
-    // loff = exclusive prefix of (depth_k + 1)
-    int x = lane < G ? depth + 1 : 0;
-    const int own = x;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-    if (lane < G) ws[S.loff + lane] = x - own;
-    if (lane == G - 1) ws[S.loff + G] = x;
-    if (lane == 0) { ws[0] = G; ws[1] = DF_MAGIC; ws[2] = DF_RB; }
+    df_assign_wave<CAP>(plan, L, ws, S, B, G, c_layer, c_row, s_g, s_d, s_n);
 }
 
 // rows per (group, layer): one workgroup per (graph, direction) adds its layer widths
@@ -1226,6 +1113,8 @@ extern "C" int dagnn_dataflow_schedule(const dagnn_plan* pl, void* ws_, size_t w
         e = hipMemsetAsync(ws + S.grec[0], 0xff, (size_t)(S.total - S.grec[0]) * 4, st);
         return e == hipSuccess ? DAGNN_OK : DAGNN_EHIP(e);
     }
+    if (!(pl->flags & DAGNN_PLAN_GENERAL_BUILD) && dagnn_plan_is_small(N, 0, B))   // one workgroup, everything in LDS (small.hip)
+        return dagnn_dataflow_schedule_small(pl, ws, groups, cost_layer, cost_row, status, st);
     // workgroup 0: the LPT assignment; the others initialise tables and records next to it
     hipLaunchKernelGGL(df_assign_kernel, dim3(1 + 512), dim3(256), 0, st, plan, L, ws, S, (int)B, groups, cost_layer, cost_row, status);
     DAGNN_CHECK_LAUNCH();

@@ -411,6 +411,8 @@ extern "C" int dagnn_plan_build(const dagnn_plan* pl, const int64_t* edge_index,
     PlanLayout L = dagnn_plan_layout_words(N, E, B, R);
     if ((size_t)L.total * 4 > plan_bytes) return DAGNN_ENOSPC;
     hipStream_t stream = (hipStream_t)stream_;
+    if (!(pl->flags & DAGNN_PLAN_GENERAL_BUILD) && dagnn_plan_is_small(N, E, B))   // one workgroup, everything in LDS (small.hip)
+        return dagnn_plan_build_small(pl, edge_index, layer_fwd, layer_bwd, batch, edge_attr, status, stream);
     int32_t* p = (int32_t*)plan;
     int64_t work = N + 2 > E ? N + 2 : E;
     if (work < B + 1) work = B + 1;

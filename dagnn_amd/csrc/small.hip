@@ -1,0 +1,453 @@
+// small.hip - plan and dataflow schedule of a SMALL batch, each by ONE workgroup with every table in LDS.
+//
+// Reference path replaced: the same as plan.hip (frontier selection dagnn.py:146-147, the per-node edge scan :151-157,
+// `_get_output_nodes` :119-126 - and dvae/dagnn.py:112-125 for the D-VAE batches this path is made for).
+//
+// Why.  plan.hip + dataflow.hip's schedule kernels are 13 launches; every one is a few dependent round trips to memory
+// plus ~4 us of launch, and on a 64-graph D-VAE batch (512 nodes) they were 96 us of a 0.22 ms forward pass
+// (profiles/README.md, cfg 1 / cfg 4).  Up to PS_N nodes / PS_E edges / PS_B graphs the whole build fits one CU's LDS:
+// one workgroup of 1024 threads walks the same phases with workgroup barriers in place of launches, and writes the
+// SAME words (tests: host mirror == general build == this build, word for word).
+// The stable placements (nodes by layer, edges by row) count the earlier items of the same graph with the same key by
+// a plain loop over LDS: graphs of such batches are tens of nodes; the loop is bounded by the graph, the cliff of a
+// degenerate batch (one 2048-node graph) is ~0.1 ms.
+#include "df_common.h"
+
+namespace {
+
+constexpr int PS_T = 1024;   // threads
+constexpr int PS_N = 2048;   // nodes
+constexpr int PS_E = 4096;   // edges
+constexpr int PS_B = 512;    // graphs
+constexpr int PS_F = PS_N + PS_B + 1;   // flat per-graph tables (n_g + 1 words per graph)
+constexpr int PS_PER = 3;    // elements per thread of a workgroup scan (3 * 1024 >= PS_F)
+static_assert(PS_PER * PS_T >= PS_F && PS_PER * PS_T >= PS_N + 2, "scan width");
+typedef unsigned short u16;
+
+// Inclusive scans of a0[0..n0) and a1[0..n1) in place (LDS), both at once; every thread of the workgroup calls.
+__device__ __forceinline__ void ps_scan2(int32_t* a0, int n0, int32_t* a1, int n1, int32_t (*wsum)[PS_T / 64]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = tid * PS_PER;
+    int v0[PS_PER], v1[PS_PER];
+#pragma unroll
+    for (int k = 0; k < PS_PER; ++k) {
+        v0[k] = i0 + k < n0 ? a0[i0 + k] : 0;
+        v1[k] = i0 + k < n1 ? a1[i0 + k] : 0;
+        if (k) { v0[k] += v0[k - 1]; v1[k] += v1[k - 1]; }
+    }
+    int x0 = v0[PS_PER - 1], x1 = v1[PS_PER - 1];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y0 = __shfl_up(x0, o, 64), y1 = __shfl_up(x1, o, 64);
+        if (lane >= o) { x0 += y0; x1 += y1; }
+    }
+    if (lane == 63) { wsum[0][wave] = x0; wsum[1][wave] = x1; }
+    __syncthreads();
+    int b0 = x0 - v0[PS_PER - 1], b1 = x1 - v1[PS_PER - 1];
+    for (int w = 0; w < wave; ++w) { b0 += wsum[0][w]; b1 += wsum[1][w]; }
+#pragma unroll
+    for (int k = 0; k < PS_PER; ++k) {
+        if (i0 + k < n0) a0[i0 + k] = b0 + v0[k];
+        if (i0 + k < n1) a1[i0 + k] = b1 + v1[k];
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------ the plan
+__global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLayout L, const int64_t* __restrict__ edge_index,
+                                                           const int64_t* __restrict__ layer_fwd,
+                                                           const int64_t* __restrict__ layer_bwd,
+                                                           const int64_t* __restrict__ batch,
+                                                           const float* __restrict__ edge_attr, int N, int E, int B, int R,
+                                                           int32_t* status) {
+    __shared__ u16 s_gof[PS_N];            // graph of every node
+    __shared__ u16 s_layer[2][PS_N];       // clamped layer of every node
+    __shared__ int32_t s_nptr[PS_B + 1], s_eptr[PS_B + 1];
+    __shared__ int32_t s_depth[2][PS_B];
+    __shared__ int32_t s_ls[2][PS_F];      // lstart, flat: graph g's depth_g + 1 entries at node_ptr[g] + g
+    __shared__ int32_t s_rp[2][PS_F];      // rowptr, flat: graph g's n_g + 1 entries at node_ptr[g] + g
+    __shared__ u16 s_pos[2][PS_N];         // sorted position of every node
+    __shared__ u16 s_order[2][PS_N];       // node at every sorted position
+    __shared__ int32_t s_bl[2][PS_N + 2];  // batch-level layer offsets
+    __shared__ u16 s_edge[2][PS_E];        // [0] sources, [1] targets; dead after the edge placement: ...
+    __shared__ u16 s_col[2][PS_E], s_eid[2][PS_E];   // predecessor / original edge per CSR slot
+    __shared__ int32_t s_key[2 * PS_B];
+    __shared__ int32_t s_wsum[2][PS_T / 64];
+    __shared__ int32_t s_bad, s_T[2], s_thr[2];
+    u16 (*s_lb)[PS_F] = reinterpret_cast<u16 (*)[PS_F]>(&s_edge[0][0]);   // ... lbase lives there afterwards
+    static_assert(sizeof(u16) * 2 * PS_F <= sizeof(u16) * 2 * PS_E, "lbase aliases the edge lists");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int F = N + B;   // words of a flat table
+    const int64_t* const layer_of[2] = {layer_fwd, layer_bwd};
+
+    // ---- phase A: header, zero tables, stage batch vector and edge lists, contract checks (plan_ptr_kernel)
+    if (tid == 0) {
+        plan[PH_N] = N; plan[PH_E] = E; plan[PH_B] = B; plan[PH_R] = R; plan[PH_MAGIC] = DAGNN_PLAN_MAGIC;
+        s_bad = status ? status[0] : 0;
+        s_T[0] = s_T[1] = 0; s_thr[0] = s_thr[1] = 0;
+    }
+    for (int i = tid; i < 2 * PS_F; i += PS_T) { (&s_ls[0][0])[i] = 0; (&s_rp[0][0])[i] = 0; }
+    for (int i = tid; i < 2 * PS_B; i += PS_T) (&s_depth[0][0])[i] = 0;
+    for (int i = tid; i < 2 * (PS_N + 2); i += PS_T) (&s_bl[0][0])[i] = 0;
+    for (int i = tid; i <= B; i += PS_T) { s_nptr[i] = 0; s_eptr[i] = 0; }
+    for (int i = tid; i < N + 2; i += PS_T) {
+        plan[L.blptr[0] + i] = 0; plan[L.blptr[1] + i] = 0; plan[L.blsplit[0] + i] = 0; plan[L.blsplit[1] + i] = 0;
+    }
+    int bad = 0;
+    for (int i = tid; i < N; i += PS_T) {
+        const int64_t b = batch[i];
+        if (i > 0 && b < batch[i - 1]) bad |= 4;
+        if (b < 0 || b >= B) bad |= 4;
+        s_gof[i] = (u16)(b < 0 ? 0 : (b >= B ? B - 1 : b));
+    }
+    for (int e = tid; e < E; e += PS_T) {
+        const int64_t s = edge_index[e], t = edge_index[(int64_t)E + e];
+        const bool ok = s >= 0 && s < N && t >= 0 && t < N;
+        if (!ok) bad |= 2;
+        else {
+            const int64_t bs = batch[s];
+            if (bs != batch[t]) bad |= 2;
+            if (e > 0) { const int64_t sp = edge_index[e - 1]; if (sp >= 0 && sp < N && batch[sp] > bs) bad |= 1; }
+        }
+        s_edge[0][e] = (u16)(ok ? s : 0);
+        s_edge[1][e] = (u16)(ok ? t : 0);
+    }
+    __syncthreads();
+    if (bad && status) atomicOr(&s_bad, bad);
+    // node_ptr[g] = first node of a graph >= g, edge_ptr[g] = first edge whose source is in a graph >= g: node i (edge e)
+    // is that first one for every g in (graph of its predecessor, its own graph]
+    for (int i = tid; i <= N; i += PS_T) {
+        const int prev = i > 0 ? (int)s_gof[i - 1] : -1, cur = i < N ? (int)s_gof[i] : B;
+        for (int g = prev + 1; g <= cur; ++g) s_nptr[g] = i;
+    }
+    for (int e = tid; e <= E; e += PS_T) {
+        const int prev = e > 0 ? (int)s_gof[s_edge[0][e - 1]] : -1, cur = e < E ? (int)s_gof[s_edge[0][e]] : B;
+        for (int g = prev + 1; g <= cur; ++g) s_eptr[g] = e;
+    }
+    __syncthreads();
+    for (int i = tid; i <= B; i += PS_T) { plan[L.node_ptr + i] = s_nptr[i]; plan[L.edge_ptr + i] = s_eptr[i]; }
+    const bool broken = (s_bad & 7) != 0;   // contract violated: the tables would be garbage - nothing below walks them
+
+    if (!broken) {
+        // ---- phase B: layers, depths, histograms (plan_graph_kernel, first half)
+        for (int it = tid; it < 2 * N; it += PS_T) {
+            const int d = it >= N, v = it - d * N;
+            const int g = s_gof[v], n0 = s_nptr[g], n = s_nptr[g + 1] - n0;
+            int64_t l = layer_of[d][v];
+            if (l < 0 || l >= n) { if (status) atomicOr(&s_bad, 8); l = l < 0 ? 0 : n - 1; }
+            s_layer[d][v] = (u16)l;
+            atomicMax(&s_depth[d][g], (int)l + 1);
+            atomicMax(&s_T[d], (int)l + 1);
+            atomicAdd(&s_ls[d][n0 + g + (int)l + 1], 1);
+            atomicAdd(&s_bl[d][(int)l + 1], 1);
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * B; i += PS_T) {
+            const int d = i >= B, g = i - d * B;
+            plan[L.depth[d] + g] = s_depth[d][g];
+        }
+        ps_scan2(s_ls[0], F, s_ls[1], F, s_wsum);
+        // lstart: entries 0 .. depth_g of every graph
+        for (int i = tid; i < 2 * B; i += PS_T) {
+            const int d = i >= B, g = i - d * B, j = s_nptr[g] + g;
+            plan[L.lstart[d] + j] = s_ls[d][j];
+        }
+        for (int it = tid; it < 2 * N; it += PS_T) {
+            const int d = it >= N, v = it - d * N;
+            const int g = s_gof[v], n0 = s_nptr[g], i = v - n0 + 1;
+            if (i <= s_depth[d][g]) plan[L.lstart[d] + n0 + g + i] = s_ls[d][n0 + g + i];
+        }
+        // ---- phase C: nodes in (graph, layer, id) order
+        for (int it = tid; it < 2 * N; it += PS_T) {
+            const int d = it >= N, v = it - d * N;
+            const int g = s_gof[v], n0 = s_nptr[g];
+            const u16 l = s_layer[d][v];
+            int cnt = 0;
+            for (int u = n0; u < v; ++u) cnt += s_layer[d][u] == l;
+            const int p = s_ls[d][n0 + g + l] + cnt;
+            s_pos[d][v] = (u16)p;
+            s_order[d][p] = (u16)v;
+            plan[L.order[d] + p] = v;
+        }
+        __syncthreads();
+        // ---- phase D: rows of the CSR (d = 0: an edge feeds its target, d = 1: its source)
+        for (int it = tid; it < 2 * E; it += PS_T) {
+            const int d = it >= E, e = it - d * E;
+            const int f = s_edge[1 - d][e];
+            atomicAdd(&s_rp[d][(int)s_pos[d][f] + (int)s_gof[f] + 1], 1);
+        }
+        __syncthreads();
+        ps_scan2(s_rp[0], F, s_rp[1], F, s_wsum);
+        for (int it = tid; it < 2 * F; it += PS_T) {
+            const int d = it >= F, j = it - d * F;
+            plan[L.rowptr[d] + j] = s_rp[d][j];
+        }
+        // ---- phase E: edges in (row, original order) order
+        for (int it = tid; it < 2 * E; it += PS_T) {
+            const int d = it >= E, e = it - d * E;
+            const u16 f = s_edge[1 - d][e];
+            const int g = s_gof[f];
+            int cnt = 0;
+            for (int q = s_eptr[g]; q < e; ++q) cnt += s_edge[1 - d][q] == f;
+            const int slot = s_rp[d][(int)s_pos[d][f] + g] + cnt;
+            const int o = s_edge[d][e];
+            s_col[d][slot] = (u16)o;
+            s_eid[d][slot] = (u16)e;
+            plan[L.col[d] + slot] = o;
+            plan[L.eidx[d] + slot] = e;
+            float* eattr = reinterpret_cast<float*>(plan + L.eattr[d]);
+            for (int r = 0; r < R; ++r) eattr[(int64_t)slot * R + r] = edge_attr[(int64_t)e * R + r];
+        }
+        // ---- phase F: work items (g * 2 + d) by depth, deepest first, ties by index (plan_items_kernel)
+        const int nitems = 2 * B;
+        for (int i = tid; i < nitems; i += PS_T) s_key[i] = s_depth[i & 1][i >> 1];
+        __syncthreads();   // (also: the edge lists are dead from here on, s_col / s_eid complete)
+        {
+            int split = 1;   // threads per item: a power of two, <= 64, split * nitems <= PS_T
+            while (split < 64 && 2 * split * nitems <= PS_T) split <<= 1;
+            const int item = tid / split, part = tid % split;
+            const int len = (nitems + split - 1) / split;
+            int rank = 0;
+            if (item < nitems) {
+                const int ki = s_key[item];
+                const int j1 = min(nitems, (part + 1) * len);
+                for (int j = part * len; j < j1; ++j) { const int kj = s_key[j]; rank += (kj > ki) || (kj == ki && j < item); }
+            }
+            for (int o = 1; o < split; o <<= 1) rank += __shfl_xor(rank, o, 64);
+            if (item < nitems && part == 0) plan[L.items + rank] = item;
+        }
+        // ---- phase G: batch-level layers (plan_blptr_kernel)
+        const int T0 = s_T[0], T1 = s_T[1];
+        ps_scan2(s_bl[0], T0 + 1, s_bl[1], T1 + 1, s_wsum);
+        for (int it = tid; it < 2 * (N + 2); it += PS_T) {
+            const int d = it >= N + 2, t = it - d * (N + 2);
+            const int T = d ? T1 : T0;
+            if (t <= T) plan[L.blptr[d] + t] = s_bl[d][t];
+            if (t < T && s_bl[d][t + 1] - s_bl[d][t] > DAGNN_PLAN_THIN_ROWS) atomicMax(&s_thr[d], t + 1);
+        }
+        if (tid < 2) plan[L.blptr[tid] + N + 1] = tid ? T1 : T0;
+        __syncthreads();
+        if (tid < 2) plan[PH_THR0 + tid] = s_thr[tid];
+        // ---- phase H: first slot of every (graph, layer): shallow graphs first, then the deep ones (plan_lbase_kernel)
+        for (int idx = wave; idx < T0 + T1; idx += PS_T / 64) {
+            const int d = idx >= T0, t = idx - d * T0;
+            const int thr = s_thr[d];
+            int carry = s_bl[d][t];
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 1 && lane == 0) plan[L.blsplit[d] + t] = carry;
+                for (int g0 = 0; g0 < B; g0 += 64) {
+                    const int g = g0 + lane;
+                    int cnt = 0, base = 0;
+                    bool has = false;
+                    if (g < B && t < s_depth[d][g] && (s_depth[d][g] > thr) == (pass == 1)) {
+                        base = s_nptr[g] + g + t;
+                        cnt = s_ls[d][base + 1] - s_ls[d][base];
+                        has = true;
+                    }
+                    int x = cnt;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+                    if (has) { s_lb[d][base] = (u16)(carry + x - cnt); plan[L.lbase[d] + base] = carry + x - cnt; }
+                    carry += __shfl(x, 63, 64);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase I: 64-byte row records in slot order (plan_rowrec_kernel)
+        for (int it = tid; it < 2 * N; it += PS_T) {
+            const int d = it >= N, p = it - d * N;
+            const int v = s_order[d][p], g = s_gof[v];
+            const int base = s_nptr[g] + g + s_layer[d][v];
+            const int slot = (int)s_lb[d][base] + (p - s_ls[d][base]);
+            const int eb = s_rp[d][p + g], ee = s_rp[d][p + g + 1];
+            int w[16];
+            w[0] = v; w[1] = eb; w[2] = ee; w[3] = g;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool ok = eb + q < ee;
+                w[4 + q] = ok ? (int)s_col[d][eb + q] : 0;
+                const int32_t* ea = reinterpret_cast<const int32_t*>(edge_attr) + (ok ? (int64_t)s_eid[d][eb + q] * R : 0);
+                w[8 + 2 * q] = (ok && R >= 1) ? ea[0] : 0;
+                w[9 + 2 * q] = (ok && R >= 2) ? ea[1] : 0;
+            }
+            plan[L.pos[d] + v] = slot;
+            int4* out = reinterpret_cast<int4*>(plan + L.rowrec[d] + 16 * (int64_t)slot);
+            out[0] = make_int4(w[0], w[1], w[2], w[3]);
+            out[1] = make_int4(w[4], w[5], w[6], w[7]);
+            out[2] = make_int4(w[8], w[9], w[10], w[11]);
+            out[3] = make_int4(w[12], w[13], w[14], w[15]);
+        }
+    }
+    // ---- seal (plan_seal_kernel): a batch that violates the contract leaves an EMPTY plan behind
+    __syncthreads();
+    if (status && s_bad != 0) {
+        for (int i = tid; i < B; i += PS_T) { plan[L.depth[0] + i] = 0; plan[L.depth[1] + i] = 0; }
+        for (int i = tid; i < N + 2; i += PS_T) {
+            plan[L.blptr[0] + i] = 0; plan[L.blptr[1] + i] = 0; plan[L.blsplit[0] + i] = 0; plan[L.blsplit[1] + i] = 0;
+        }
+        if (tid == 0) atomicOr(status, s_bad);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the dataflow schedule
+// dagnn_dataflow_schedule of a small batch (dataflow.hip: df_assign / count / prefix / base / lbase / records kernels).
+// Writes the tables in full and the records every group USES (first record .. first record + 4 * blocks, padding
+// records node = -1); the unused tail of the record arrays keeps whatever the workspace held - nothing reads it.
+__global__ void __launch_bounds__(PS_T) schedule_small_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws, DfLayout S,
+                                                               int N, int B, int G, int c_layer, int c_row,
+                                                               const int32_t* __restrict__ status) {
+    if (status && status[0] != 0) return;   // the batch violates the plan contract: nothing here can be trusted
+    __shared__ int32_t s_nptr[PS_B + 1];
+    __shared__ int32_t s_dep[2][PS_B];
+    __shared__ int32_t s_ls[2][PS_F];
+    __shared__ int32_t s_grp[PS_B];
+    __shared__ int32_t s_gd[DF_MAX_GROUPS], s_loff[DF_MAX_GROUPS + 1];
+    __shared__ int32_t s_gtab[2][2 * DF_MAX_GROUPS];
+    __shared__ int32_t s_lcnt[2][PS_N + DF_MAX_GROUPS + 1];
+    __shared__ int32_t s_glb[2][PS_F];
+    __shared__ u16 s_slot[2][PS_N];        // rowrec slot of the node at every sorted position
+    __shared__ int32_t s_g[PS_B], s_d[PS_B], s_n[PS_B];
+    __shared__ int32_t s_used[2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int F = N + B;
+    // ---- tables and header of the workspace = 0; stage the plan's per-graph tables
+    {
+        int4* z = reinterpret_cast<int4*>(ws);
+        const int nz = (int)(S.grec[0] / 4);
+        for (int i = tid; i < nz; i += PS_T) z[i] = make_int4(0, 0, 0, 0);
+    }
+    for (int i = tid; i <= B; i += PS_T) s_nptr[i] = plan[L.node_ptr + i];
+    for (int i = tid; i < 2 * B; i += PS_T) { const int d = i >= B, g = i - d * B; s_dep[d][g] = plan[L.depth[d] + g]; }
+    for (int it = tid; it < 2 * F; it += PS_T) { const int d = it >= F, j = it - d * F; s_ls[d][j] = plan[L.lstart[d] + j]; s_glb[d][j] = 0; }
+    for (int it = tid; it < 2 * N; it += PS_T) {
+        const int d = it >= N, p = it - d * N;
+        s_slot[d][p] = (u16)plan[L.pos[d] + plan[L.order[d] + p]];
+    }
+    for (int i = tid; i < 2 * (PS_N + DF_MAX_GROUPS + 1); i += PS_T) (&s_lcnt[0][0])[i] = 0;
+    __syncthreads();
+    // ---- the LPT assignment (one wave), straight into the workspace
+    if (wave == 0) df_assign_wave<PS_B>(plan, L, ws, S, B, G, c_layer, c_row, s_g, s_d, s_n);
+    __syncthreads();
+    for (int i = tid; i < B; i += PS_T) s_grp[i] = ws[S.grp_of + i];
+    for (int i = tid; i < G; i += PS_T) s_gd[i] = ws[S.gdepth + i];
+    for (int i = tid; i <= G; i += PS_T) s_loff[i] = ws[S.loff + i];
+    __syncthreads();
+    // ---- rows per (group, layer): a wave per (graph, direction), lanes over its layers
+    for (int i = wave; i < 2 * B; i += PS_T / 64) {
+        const int d = i >= B, g = i - d * B;
+        const int k = s_grp[g], j = s_nptr[g] + g;
+        const int depth = min(s_dep[d][g], s_gd[k]);
+        for (int t = lane; t < depth; t += 64) atomicAdd(&s_lcnt[d][s_loff[k] + t], s_ls[d][j + t + 1] - s_ls[d][j + t]);
+    }
+    __syncthreads();
+    // ---- per (group, direction): exclusive prefix of the block-padded counts; blocks of the group
+    for (int i = wave; i < 2 * G; i += PS_T / 64) {
+        const int d = i >= G, k = i - d * G;
+        const int depth = s_gd[k];
+        int32_t* cnt = s_lcnt[d] + s_loff[k];
+        int carry = 0;
+        for (int c0 = 0; c0 <= depth; c0 += 64) {
+            const int t = c0 + lane;
+            const int c = t < depth ? cnt[t] : 0;
+            const int padded = (c + DF_RB - 1) / DF_RB * DF_RB;
+            int x = padded;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+            if (t <= depth) cnt[t] = carry + x - padded;
+            carry += __shfl(x, 63, 64);
+        }
+        if (lane == 0) s_gtab[d][2 * k + 1] = carry / DF_RB;
+    }
+    __syncthreads();
+    // ---- first record of every group
+    if (wave < 2) {
+        const int d = wave;
+        int x = lane < G ? s_gtab[d][2 * lane + 1] * DF_RB : 0;
+        const int own = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane < G) s_gtab[d][2 * lane] = x - own;
+        if (lane == 63) s_used[d] = x;
+    }
+    __syncthreads();
+    // ---- the used records = -1 (padding), and meanwhile glbase: a wave per (direction, group, layer)
+    for (int d = 0; d < 2; ++d) {
+        int4* f = reinterpret_cast<int4*>(ws + S.grec[d]);
+        const int nf = s_used[d] * 4;
+        for (int i = tid; i < nf; i += PS_T) f[i] = make_int4(-1, -1, -1, -1);
+    }
+    {
+        const int total = s_loff[G];
+        for (int i = wave; i < 2 * total; i += PS_T / 64) {
+            const int d = i >= total, pair = i - d * total;
+            const int k = __popcll(__ballot(lane < G && s_loff[min(lane + 1, G)] <= pair));
+            const int t = pair - s_loff[k];
+            if (t >= s_gd[k]) continue;   // the table has depth + 1 entries per group
+            int carry = s_lcnt[d][pair];
+            for (int g0 = 0; g0 < B; g0 += 64) {
+                const int g = g0 + lane;
+                int cnt = 0, base = 0;
+                bool has = false;
+                if (g < B && s_grp[g] == k && t < s_dep[d][g]) {
+                    base = s_nptr[g] + g + t;
+                    cnt = s_ls[d][base + 1] - s_ls[d][base];
+                    has = true;
+                }
+                int x = cnt;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+                if (has) s_glb[d][base] = carry + x - cnt;
+                carry += __shfl(x, 63, 64);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- tables out
+    for (int it = tid; it < 4 * G; it += PS_T) { const int d = it >= 2 * G, j = it - d * 2 * G; ws[S.gtab[d] + j] = s_gtab[d][j]; }
+    {
+        const int total = s_loff[G];
+        for (int it = tid; it < 2 * total; it += PS_T) { const int d = it >= total, j = it - d * total; ws[S.lcnt[d] + j] = s_lcnt[d][j]; }
+    }
+    for (int it = tid; it < 2 * F; it += PS_T) { const int d = it >= F, j = it - d * F; ws[S.glbase[d] + j] = s_glb[d][j]; }
+    // ---- every row record to its place in the group order
+    for (int it = tid; it < 2 * N; it += PS_T) {
+        const int d = it >= N, p = it - d * N;
+        const int4* src = reinterpret_cast<const int4*>(plan + L.rowrec[d]) + 4 * (int64_t)s_slot[d][p];
+        const int4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+        const int g = r0.w, n0 = s_nptr[g];
+        const int32_t* ls = s_ls[d] + n0 + g;
+        int lo = 0, hi = s_dep[d][g];                    // largest t with ls[t] <= p
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ls[mid] <= p) lo = mid; else hi = mid; }
+        const int rec = s_gtab[d][2 * s_grp[g]] + s_glb[d][n0 + g + lo] + (p - ls[lo]);
+        int4* dst = reinterpret_cast<int4*>(ws + S.grec[d]) + 4 * (int64_t)rec;
+        dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+    }
+}
+
+}  // namespace
+
+// 1 when this batch takes the one-workgroup builds (host-side decision: sizes only)
+extern "C" int dagnn_plan_is_small(int64_t N, int64_t E, int64_t B) {
+    return N >= 1 && B >= 1 && N <= PS_N && E <= PS_E && B <= PS_B;
+}
+
+int dagnn_plan_build_small(const dagnn_plan* pl, const int64_t* edge_index, const int64_t* layer_fwd, const int64_t* layer_bwd,
+                           const int64_t* batch, const float* edge_attr, int32_t* status, hipStream_t stream) {
+    const PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
+    hipLaunchKernelGGL(plan_small_kernel, dim3(1), dim3(PS_T), 0, stream, (int32_t*)pl->data, L, edge_index, layer_fwd, layer_bwd,
+                       batch, edge_attr, (int)pl->N, (int)pl->E, (int)pl->B, pl->num_edge_feats, status);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
+int dagnn_dataflow_schedule_small(const dagnn_plan* pl, int32_t* ws, int groups, int cost_layer, int cost_row,
+                                  const int32_t* status, hipStream_t stream) {
+    const PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
+    const DfLayout S = df_layout_words(pl->N, pl->B, groups);
+    hipLaunchKernelGGL(schedule_small_kernel, dim3(1), dim3(PS_T), 0, stream, (const int32_t*)pl->data, L, ws, S, (int)pl->N,
+                       (int)pl->B, groups, cost_layer, cost_row, status);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}

@@ -81,6 +81,8 @@ BWD_TAIL_MAX_BLOCKS = _env_int("DAGNN_AMD_BWD_TAIL_MAX_BLOCKS", 4)
 # they then run concurrently but 2-4x slower (plan_ptr 61 us instead of 15, plan_graph 103 instead of 49), bench.py
 # 2.302-2.312 against 2.3085 ms - nothing - and two processes sharing one GPU (the two-rank bench test) failed.
 PLAN_OVERLAP = _env_int("DAGNN_AMD_PLAN_OVERLAP", 0)
+PLAN_SMALL = _env_int("DAGNN_AMD_PLAN_SMALL", 1)            # 1: batches of <= 2048 nodes / 4096 edges / 512 graphs build plan and schedule with one workgroup each (csrc/small.hip)
+PLAN_GENERAL_BUILD = 1                                      # dagnn_plan.flags: keep the plan on the general kernels
 DATAFLOW = _env_int("DAGNN_AMD_DATAFLOW", 1)                # 1: the persistent graph-affine dataflow kernel where it applies (H <= 256)
 DF_COST_LAYER = _env_int("DAGNN_AMD_DF_COST_LAYER", 6)      # schedule cost of one dependent layer, in rows (hop latency / row cost;
                                                             # round 3, after the per-block cost dropped: 4 -> 6, scripts/df_cost_sweep.py)
@@ -135,7 +137,7 @@ class PlanHandle(object):
         nbytes = lib.dagnn_plan_bytes(self.N, self.E, self.B, self.R)
         self.ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device)
         self.status = torch.zeros(4, dtype=torch.int32, device=device)
-        self.desc = Plan(self.ws.data_ptr(), nbytes, self.N, self.E, self.B, self.R)
+        self.desc = Plan(self.ws.data_ptr(), nbytes, self.N, self.E, self.B, self.R, 0 if PLAN_SMALL else PLAN_GENERAL_BUILD)
         self.ready = None   # event to wait for when the plan was built on another stream
 
     def wait_ready(self) -> None:
@@ -161,7 +163,7 @@ class PlanHandle(object):
             raise DagnnHipError("host-built plan has %d bytes, the layout needs %d" % (ws.numel() * 4, nbytes))
         self.ws = ws
         self.status = torch.zeros(4, dtype=torch.int32, device=ws.device)
-        self.desc = Plan(ws.data_ptr(), nbytes, self.N, self.E, self.B, self.R)
+        self.desc = Plan(ws.data_ptr(), nbytes, self.N, self.E, self.B, self.R, 0 if PLAN_SMALL else PLAN_GENERAL_BUILD)
         self._schedule = [a for a in meta["schedule"]]
         self._splits = [a for a in meta["splits"]]
         if dataflow_words is not None and meta.get("dataflow_key") is not None and dataflow_words.is_cuda:

@@ -56,7 +56,15 @@ typedef struct dagnn_plan {
     size_t bytes;
     int64_t N, E, B;     /* nodes, edges, graphs in the batch */
     int num_edge_feats;  /* floats of edge_attr per edge carried into the plan (0 = none) */
+    int flags;           /* 0, or DAGNN_PLAN_GENERAL_BUILD */
 } dagnn_plan;
+
+/* Batches of up to 2048 nodes, 4096 edges and 512 graphs (the D-VAE batches of dvae/dagnn.py:99-175) have their plan and
+ * their dataflow schedule built by ONE workgroup each instead of 7 + 6 launches - the same words either way.  This flag
+ * keeps a plan on the general kernels whatever its size (tests compare the two). */
+#define DAGNN_PLAN_GENERAL_BUILD 1
+/* 1 when dagnn_plan_build takes the one-workgroup path for these sizes (dagnn_dataflow_schedule: E does not matter, pass 0) */
+int dagnn_plan_is_small(int64_t N, int64_t E, int64_t B);
 
 /* Bytes of device workspace `dagnn_plan_build` needs for N nodes, E edges, B graphs and
  * `num_edge_feats` floats of edge_attr per edge (0 if the model has no edge features). */
@@ -259,7 +267,8 @@ int dagnn_frontier_run(const dagnn_plan* plan /* host */, const dagnn_frontier_a
  *      cost_layer * depth + cost_row * nodes, integer arithmetic, ties to the lowest group - and re-sorts the plan's
  *      64-byte row records by (group, topological layer, graph, node), every group-layer padded to whole blocks of 4
  *      records (padding records: node = -1).  The result depends on the plan and on (G, costs) only: build it once per
- *      batch (it also serves the backward pass).  Workspace: dagnn_dataflow_bytes(N, B, G), any contents.
+ *      batch (it also serves the backward pass).  Workspace: dagnn_dataflow_bytes(N, B, G), any contents; the record
+ *      arrays are defined over the records the groups use (first record .. first record + 4 * blocks of every group).
  *   3. dagnn_dataflow_run: the launch.  Every (direction, stacked layer) cell needs `granules`: uint64 [N, gld]
  *      (gld >= H) tagged copies {epoch, fp32 bits} of its state rows - the hand-off format between workgroups.  The
  *      buffers must have been zero-initialised once and only ever used with strictly increasing `epoch`s (a replayed

@@ -34,8 +34,10 @@ def _plan_arrays(plan):
     return ws, lay
 
 
+@pytest.mark.parametrize("small", [1, 0])   # 1: batches of <= 2048 nodes on the one-workgroup build (csrc/small.hip)
 @pytest.mark.parametrize("seed,B,mean_n", [(1, 5, 20), (2, 17, 60), (0, 128, 125)])
-def test_plan_matches_oracle_csr(device, seed, B, mean_n):
+def test_plan_matches_oracle_csr(device, monkeypatch, seed, B, mean_n, small):
+    monkeypatch.setattr(engine, "PLAN_SMALL", small)
     b = synth.code2_batch(seed, B, mean_n)
     plan = engine.build_plan(b.edge_index.to(device), b._bi_layer_idx0.to(device), b._bi_layer_idx1.to(device),
                              b.batch.to(device), B, b.edge_attr.to(device))
@@ -106,15 +108,30 @@ def test_plan_matches_oracle_csr(device, seed, B, mean_n):
     assert sorted(items.tolist()) == list(range(2 * B)) and dep == sorted(dep, reverse=True)
 
 
-def test_plan_flags_contract_violations(device):
+@pytest.mark.parametrize("small", [1, 0])
+def test_plan_flags_contract_violations(device, monkeypatch, small):
+    monkeypatch.setattr(engine, "PLAN_SMALL", small)
     b = synth.code2_batch(4, 4, 20)
+    dev = lambda t: t.to(device)   # noqa: E731
+    N = b.x.shape[0]
     bad_batch = b.batch.clone()
     bad_batch[3] = 2  # not sorted
-    plan = engine.build_plan(b.edge_index.to(device), b._bi_layer_idx0.to(device), b._bi_layer_idx1.to(device),
-                             bad_batch.to(device), 4, None)
-    torch.cuda.synchronize()
-    with pytest.raises(DagnnHipError):
-        plan.check_status()
+    crossing = b.edge_index.clone()
+    crossing[1, 0] = N - 1   # an edge from the first graph into the last
+    ungrouped = torch.cat([b.edge_index[:, -1:], b.edge_index[:, :-1]], 1)   # the last graph's edge first
+    deep = b._bi_layer_idx0.clone()
+    deep[0] = N   # a layer id >= nodes of its graph
+    cases = [(b.edge_index, b._bi_layer_idx0, bad_batch, "not sorted"), (crossing, b._bi_layer_idx0, b.batch, "crosses"),
+             (ungrouped, b._bi_layer_idx0, b.batch, "not grouped"), (b.edge_index, deep, b.batch, "layer id")]
+    for ei, l0, bt, what in cases:
+        plan = engine.build_plan(dev(ei), dev(l0), dev(b._bi_layer_idx1), dev(bt), 4, None)
+        torch.cuda.synchronize()
+        with pytest.raises(DagnnHipError, match=what):
+            plan.check_status()
+        ws, lay = _plan_arrays(plan)   # sealed: no depths, no batch-level layers
+        for d in (0, 1):
+            assert not ws[lay["depth%d" % d]:lay["depth%d" % d] + 4].any()
+            assert not ws[lay["blptr%d" % d]:lay["blptr%d" % d] + N + 2].any()
 
 
 @pytest.mark.parametrize("H", [32, 256, 300])
@@ -582,9 +599,11 @@ def test_training_and_inference_forward_agree(device):
 
 # ----------------------------------------------------------------------------- loader-side plan
 @pytest.mark.parametrize("seed,B,mean_n", [(2, 17, 60), (0, 128, 125), (5, 1, 12), (6, 3, 11), (7, 64, 14), (8, 300, 20),
-                                           (-1, 6, 0)])
-def test_host_plan_equals_device_plan_word_for_word(device, seed, B, mean_n):
+                                           (11, 150, 4), (12, 2, 900), (13, 1, 1500), (-1, 6, 0)])
+@pytest.mark.parametrize("small", [1, 0])   # 1: batches of <= 2048 nodes on the one-workgroup build (csrc/small.hip)
+def test_host_plan_equals_device_plan_word_for_word(device, monkeypatch, seed, B, mean_n, small):
     from dagnn_amd import host_plan
+    monkeypatch.setattr(engine, "PLAN_SMALL", small)
     b = _degenerate_batch() if seed < 0 else synth.code2_batch(seed, B, mean_n)   # -1: single nodes, no edges, stars
     plan = engine.build_plan(b.edge_index.to(device), b._bi_layer_idx0.to(device), b._bi_layer_idx1.to(device),
                              b.batch.to(device), B, b.edge_attr.to(device))
@@ -599,12 +618,28 @@ def test_host_plan_equals_device_plan_word_for_word(device, seed, B, mean_n):
         assert np.array_equal(sched[d], plan.read_schedule()[d])
 
 
+def _schedule_words_equal(host, dev, lay, G, whole):
+    """Tables word for word; records over what the groups use (`whole`: and the -1 fill of the unused tail)."""
+    assert host.shape == dev.shape
+    assert np.array_equal(host[:lay["grec0"]], dev[:lay["grec0"]])
+    ends = [lay["grec1"], lay["total"]]
+    for d in (0, 1):
+        gtab = host[lay["gtab%d" % d]:lay["gtab%d" % d] + 2 * G]
+        used = 16 * int(gtab[2 * (G - 1)] + 4 * gtab[2 * (G - 1) + 1])
+        g0 = lay["grec%d" % d]
+        assert np.array_equal(host[g0:g0 + used], dev[g0:g0 + used])
+        if whole:
+            assert np.array_equal(host[g0:ends[d]], dev[g0:ends[d]])
+
+
+@pytest.mark.parametrize("small", [1, 0])   # 1: batches of <= 2048 nodes on the one-workgroup builds (csrc/small.hip)
 @pytest.mark.parametrize("seed,B,mean_n,G", [(2, 17, 60, 5), (0, 128, 125, 5), (5, 1, 12, 1), (7, 64, 14, 21), (8, 300, 20, 8),
                                              (9, 40, 4, 6), (10, 7, 4, 16),   # every graph 11 nodes: the round-robin deal
-                                             (-1, 6, 0, 3)])
-def test_dataflow_schedule_host_equals_device_word_for_word(device, seed, B, mean_n, G):
+                                             (11, 150, 4, 64), (12, 2, 900, 2), (13, 1, 1500, 3), (-1, 6, 0, 3)])
+def test_dataflow_schedule_host_equals_device_word_for_word(device, monkeypatch, seed, B, mean_n, G, small):
     """`dagnn_dataflow_schedule` (LPT groups, group-ordered padded records) against its numpy mirror."""
     from dagnn_amd import host_plan
+    monkeypatch.setattr(engine, "PLAN_SMALL", small)
     b = _degenerate_batch() if seed < 0 else synth.code2_batch(seed, B, mean_n)
     plan = engine.build_plan(b.edge_index.to(device), b._bi_layer_idx0.to(device), b._bi_layer_idx1.to(device),
                              b.batch.to(device), B, b.edge_attr.to(device))
@@ -612,9 +647,35 @@ def test_dataflow_schedule_host_equals_device_word_for_word(device, seed, B, mea
     ws = host_plan.build_plan_host(b.edge_index, b._bi_layer_idx0, b._bi_layer_idx1, b.batch, B, b.edge_attr)[0]
     N, E = b.x.shape[0], b.edge_index.shape[1]
     host = host_plan.build_dataflow_schedule_host(ws, N, E, B, 2, G, engine.DF_COST_LAYER, engine.DF_COST_ROW)
-    assert host.shape == dev.shape
     assert plan.dataflow_layout(G) == host_plan.dataflow_layout(N, B, G)
-    assert np.array_equal(host, dev)
+    lib_small = bool(small) and bool(engine._lib.load().dagnn_plan_is_small(N, 0, B))
+    _schedule_words_equal(host, dev, plan.dataflow_layout(G), G, whole=not lib_small)
+
+
+@pytest.mark.parametrize("n_graphs,kind", [(64, "enas"), (128, "bn"), (1, "enas"), (200, "bn")])
+def test_small_builds_equal_the_general_kernels_on_dvae_batches(device, monkeypatch, n_graphs, kind):
+    """The D-VAE batches (uniform graphs, no edge features): plan and schedule of csrc/small.hip against plan.hip /
+    dataflow.hip's kernels, and both against the host mirror."""
+    from dagnn_amd import host_plan
+    rows = synth.enas_rows(3, n_graphs) if kind == "enas" else synth.bn_rows(3, n_graphs)
+    dec = synth.decode_enas_row if kind == "enas" else synth.decode_bn_row
+    b = synth.dvae_batch([dec(r) for r in rows])
+    N, E, B = b.x.shape[0], b.edge_index.shape[1], n_graphs
+    bl = b.bi_layer_index
+    G = min(10, B)
+    got = []
+    for small in (1, 0):
+        monkeypatch.setattr(engine, "PLAN_SMALL", small)
+        plan = engine.build_plan(b.edge_index.to(device), bl[0][0].to(device), bl[1][0].to(device), b.batch.to(device), B, None)
+        sched = plan.dataflow_schedule(G).cpu().numpy()
+        plan.check_status()
+        got.append((plan.ws.cpu().numpy(), sched, plan.dataflow_layout(G)))
+    ws, _, _, written = host_plan.build_plan_host(b.edge_index, bl[0][0], bl[1][0], b.batch, B, None, return_written=True)
+    host = host_plan.build_dataflow_schedule_host(ws, N, E, B, 0, G, engine.DF_COST_LAYER, engine.DF_COST_ROW)
+    for words, sched, lay in got:
+        assert np.array_equal(ws[written], words[written])
+    _schedule_words_equal(host, got[0][1], got[0][2], G, whole=False)
+    _schedule_words_equal(host, got[1][1], got[1][2], G, whole=True)
 
 
 def test_dataflow_with_loader_side_schedule(device, monkeypatch):

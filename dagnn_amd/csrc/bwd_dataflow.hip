@@ -786,7 +786,7 @@ __global__ void __launch_bounds__(BD_THREADS, 3) bwd_dataflow_kernel(const int32
     constexpr int NS = 16 * KPT / DF_JS;
     const int tid = threadIdx.x;
     if (S.status && S.status[0] != 0) {
-        if (tid == 0) __hip_atomic_fetch_or(S.err, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_or(S.err, 4 | ((S.status[0] & 0xff) << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     if (S.sched[0] != S.groups || S.sched[1] != DF_MAGIC || S.sched[2] != DF_RB) {

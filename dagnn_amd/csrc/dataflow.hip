@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) df_assign_kernel(const int32_t* __restric
     // staged in LDS first - from global memory every step is three dependent round trips (measured 76 us at B = 128)
     constexpr int CAP = 4096;
     __shared__ int32_t s_g[CAP], s_d[CAP], s_n[CAP];
-    df_assign_wave<CAP>(plan, L, ws, S, B, G, c_layer, c_row, s_g, s_d, s_n);
+    df_assign_wave<CAP>(plan + L.items, plan + L.depth[0], plan + L.depth[1], plan + L.node_ptr, ws, S, B, G, c_layer, c_row, s_g, s_d, s_n);
 }
 
 // rows per (group, layer): one workgroup per (graph, direction) adds its layer widths
@@ -931,7 +931,7 @@ __global__ void __launch_bounds__(DF_THREADS, 3) dataflow_kernel(const int32_t* 
     constexpr int NS = 16 * KPT / DF_JS;
     const int tid = threadIdx.x;
     if (S.status && S.status[0] != 0) {   // the batch violates the plan contract: the schedule is garbage - do not walk it
-        if (tid == 0) __hip_atomic_fetch_or(S.err, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_or(S.err, 4 | ((S.status[0] & 0xff) << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     if (S.sched[0] != S.groups || S.sched[1] != DF_MAGIC || S.sched[2] != DF_RB) {   // a schedule built for another group count

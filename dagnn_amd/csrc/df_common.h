@@ -81,11 +81,12 @@ __device__ __forceinline__ unsigned df_wave_umin(unsigned v) {
 // Graphs in order of decreasing depth (plan items), each to the group whose load it raises the least; load_k = c_layer *
 // (depth of the first = deepest graph of k) + c_row * (nodes of k).  Called by the 64 lanes of ONE wave (threadIdx.x < 64);
 // writes grp_of / gdepth / gload / loff and the header words of the schedule workspace `ws`.  s_g / s_d / s_n: LDS staging
-// of CAP words each.  Shared by df_assign_kernel (dataflow.hip) and the one-workgroup build of small batches (small.hip).
+// of CAP words each.  The plan's tables (items [2B], depth of either direction [B], node_ptr [B + 1]) come as pointers:
+// global memory for df_assign_kernel (dataflow.hip), LDS copies for the one-workgroup build of small batches (small.hip).
 template <int CAP>
-__device__ __forceinline__ void df_assign_wave(const int32_t* __restrict__ plan, const PlanLayout& L, int32_t* ws, const DfLayout& S,
+__device__ __forceinline__ void df_assign_wave(const int32_t* items, const int32_t* depth0, const int32_t* depth1,
+                                               const int32_t* node_ptr, int32_t* ws, const DfLayout& S,
                                                int B, int G, int c_layer, int c_row, int32_t* s_g, int32_t* s_d, int32_t* s_n) {
-    const int32_t* items = plan + L.items;
     const bool staged = B <= CAP;
     const int lane = threadIdx.x;
     // compact the direction-0 entries in order (wave-level prefix over 64 entries at a time)
@@ -100,8 +101,8 @@ __device__ __forceinline__ void df_assign_wave(const int32_t* __restrict__ plan,
                 const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
                 const int g = it >> 1;
                 s_g[pos] = g;
-                s_d[pos] = max(plan[L.depth[0] + g], plan[L.depth[1] + g]);
-                s_n[pos] = plan[L.node_ptr + g + 1] - plan[L.node_ptr + g];
+                s_d[pos] = max(depth0[g], depth1[g]);
+                s_n[pos] = node_ptr[g + 1] - node_ptr[g];
             }
             count += __popcll(m);
         }
@@ -114,7 +115,7 @@ __device__ __forceinline__ void df_assign_wave(const int32_t* __restrict__ plan,
     const int steps = staged ? count : 2 * B;
     // fast form of the B-step chain when (cost << 6 | group) fits 32 bits: ONE wave minimum per graph gives the least
     // load and, through the low bits, the lowest group that has it (38 -> 17 us at B = 128)
-    const long long bound = (long long)c_row * plan[L.node_ptr + B] + (long long)c_layer * (staged && count > 0 ? s_d[0] : 0);
+    const long long bound = (long long)c_row * node_ptr[B] + (long long)c_layer * (staged && count > 0 ? s_d[0] : 0);
     // every graph has the same node count (the D-VAE batches: dvae/dagnn.py:150-158 hard-codes that stride): no B-step chain -
     // the depth-sorted graphs are dealt round-robin (graph j of the order -> group j mod G), all lanes at once
     bool uniform = staged && count > 0;
@@ -160,8 +161,8 @@ __device__ __forceinline__ void df_assign_wave(const int32_t* __restrict__ plan,
             const int it = items[j];
             if (it & 1) continue;
             g = it >> 1;
-            dg = max(plan[L.depth[0] + g], plan[L.depth[1] + g]);
-            ng = plan[L.node_ptr + g + 1] - plan[L.node_ptr + g];
+            dg = max(depth0[g], depth1[g]);
+            ng = node_ptr[g + 1] - node_ptr[g];
         }
         long long cand = load + (long long)c_row * ng + (empty ? (long long)c_layer * dg : 0);
         if (lane >= G) cand = 0x7fffffffffffffffLL;

@@ -24,6 +24,37 @@ constexpr int PS_PER = 3;    // elements per thread of a workgroup scan (3 * 102
 static_assert(PS_PER * PS_T >= PS_F && PS_PER * PS_T >= PS_N + 2, "scan width");
 typedef unsigned short u16;
 
+// phase stamps (100 MHz) of thread 0, only in a build with -DPS_STAMPS (scripts/small_stamps.py): the plan kernel's go to the
+// plan's cursor scratch, the schedule kernel's to the last 64 words of the workspace
+#ifdef PS_STAMPS
+#define PS_STAMP(buf, k) do { if (threadIdx.x == 0) (buf)[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PS_STAMP(buf, k) do { } while (0)
+#endif
+
+// inclusive sum scan over the 64 lanes on DPP (row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast15 / row_bcast31):
+// six VALU operations - the same scan on __shfl_up is six round trips through the LDS crossbar, and these kernels are
+// chains of such scans
+__device__ __forceinline__ int ps_wave_scan(int x) {
+#define PS_DPP_ADD(ctrl, rmask) x += __builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, true)
+    PS_DPP_ADD(0x111, 0xf); PS_DPP_ADD(0x112, 0xf); PS_DPP_ADD(0x114, 0xf); PS_DPP_ADD(0x118, 0xf);
+    PS_DPP_ADD(0x142, 0xa); PS_DPP_ADD(0x143, 0xc);
+#undef PS_DPP_ADD
+    return x;
+}
+__device__ __forceinline__ int ps_wave_total(int scanned) { return __builtin_amdgcn_readlane(scanned, 63); }
+
+// number of elements of keys[lo, hi) equal to `key` (u16 keys in LDS, 8-byte aligned array): four keys per LDS read
+__device__ __forceinline__ int ps_count_equal(const unsigned short* keys, int lo, int hi, unsigned key) {
+    int cnt = 0;
+    for (int q = lo & ~3; q < hi; q += 4) {
+        const uint2 w = *reinterpret_cast<const uint2*>(keys + q);
+        cnt += (q >= lo && (w.x & 0xffffu) == key) + (q + 1 >= lo && q + 1 < hi && (w.x >> 16) == key) +
+               (q + 2 >= lo && q + 2 < hi && (w.y & 0xffffu) == key) + (q + 3 >= lo && q + 3 < hi && (w.y >> 16) == key);
+    }
+    return cnt;
+}
+
 // Inclusive scans of a0[0..n0) and a1[0..n1) in place (LDS), both at once; every thread of the workgroup calls.
 __device__ __forceinline__ void ps_scan2(int32_t* a0, int n0, int32_t* a1, int n1, int32_t (*wsum)[PS_T / 64]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -35,12 +66,7 @@ __device__ __forceinline__ void ps_scan2(int32_t* a0, int n0, int32_t* a1, int n
         v1[k] = i0 + k < n1 ? a1[i0 + k] : 0;
         if (k) { v0[k] += v0[k - 1]; v1[k] += v1[k - 1]; }
     }
-    int x0 = v0[PS_PER - 1], x1 = v1[PS_PER - 1];
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int y0 = __shfl_up(x0, o, 64), y1 = __shfl_up(x1, o, 64);
-        if (lane >= o) { x0 += y0; x1 += y1; }
-    }
+    const int x0 = ps_wave_scan(v0[PS_PER - 1]), x1 = ps_wave_scan(v1[PS_PER - 1]);
     if (lane == 63) { wsum[0][wave] = x0; wsum[1][wave] = x1; }
     __syncthreads();
     int b0 = x0 - v0[PS_PER - 1], b1 = x1 - v1[PS_PER - 1];
@@ -61,7 +87,7 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
                                                            const float* __restrict__ edge_attr, int N, int E, int B, int R,
                                                            int32_t* status) {
     __shared__ u16 s_gof[PS_N];            // graph of every node
-    __shared__ u16 s_layer[2][PS_N];       // clamped layer of every node
+    __shared__ __attribute__((aligned(16))) u16 s_layer[2][PS_N];       // clamped layer of every node
     __shared__ int32_t s_nptr[PS_B + 1], s_eptr[PS_B + 1];
     __shared__ int32_t s_depth[2][PS_B];
     __shared__ int32_t s_ls[2][PS_F];      // lstart, flat: graph g's depth_g + 1 entries at node_ptr[g] + g
@@ -69,9 +95,9 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
     __shared__ u16 s_pos[2][PS_N];         // sorted position of every node
     __shared__ u16 s_order[2][PS_N];       // node at every sorted position
     __shared__ int32_t s_bl[2][PS_N + 2];  // batch-level layer offsets
-    __shared__ u16 s_edge[2][PS_E];        // [0] sources, [1] targets; dead after the edge placement: ...
+    __shared__ __attribute__((aligned(16))) u16 s_edge[2][PS_E];        // [0] sources, [1] targets; dead after the edge placement: ...
     __shared__ u16 s_col[2][PS_E], s_eid[2][PS_E];   // predecessor / original edge per CSR slot
-    __shared__ int32_t s_key[2 * PS_B];
+    __shared__ __attribute__((aligned(16))) int32_t s_key[2 * PS_B + 4];
     __shared__ int32_t s_wsum[2][PS_T / 64];
     __shared__ int32_t s_bad, s_T[2], s_thr[2];
     u16 (*s_lb)[PS_F] = reinterpret_cast<u16 (*)[PS_F]>(&s_edge[0][0]);   // ... lbase lives there afterwards
@@ -80,11 +106,13 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int F = N + B;   // words of a flat table
     const int64_t* const layer_of[2] = {layer_fwd, layer_bwd};
+    [[maybe_unused]] unsigned long long* stamp = reinterpret_cast<unsigned long long*>(plan + L.cursor[0]);
+    PS_STAMP(stamp, 0);
 
     // ---- phase A: header, zero tables, stage batch vector and edge lists, contract checks (plan_ptr_kernel)
     if (tid == 0) {
         plan[PH_N] = N; plan[PH_E] = E; plan[PH_B] = B; plan[PH_R] = R; plan[PH_MAGIC] = DAGNN_PLAN_MAGIC;
-        s_bad = status ? status[0] : 0;
+        s_bad = 0;   // (the status word is WRITTEN at the end, not accumulated: the caller need not clear it for this build)
         s_T[0] = s_T[1] = 0; s_thr[0] = s_thr[1] = 0;
     }
     for (int i = tid; i < 2 * PS_F; i += PS_T) { (&s_ls[0][0])[i] = 0; (&s_rp[0][0])[i] = 0; }
@@ -114,6 +142,7 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
         s_edge[1][e] = (u16)(ok ? t : 0);
     }
     __syncthreads();
+    PS_STAMP(stamp, 1);
     if (bad && status) atomicOr(&s_bad, bad);
     // node_ptr[g] = first node of a graph >= g, edge_ptr[g] = first edge whose source is in a graph >= g: node i (edge e)
     // is that first one for every g in (graph of its predecessor, its own graph]
@@ -129,25 +158,47 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
     for (int i = tid; i <= B; i += PS_T) { plan[L.node_ptr + i] = s_nptr[i]; plan[L.edge_ptr + i] = s_eptr[i]; }
     const bool broken = (s_bad & 7) != 0;   // contract violated: the tables would be garbage - nothing below walks them
 
+    PS_STAMP(stamp, 2);
     if (!broken) {
         // ---- phase B: layers, depths, histograms (plan_graph_kernel, first half)
-        for (int it = tid; it < 2 * N; it += PS_T) {
-            const int d = it >= N, v = it - d * N;
-            const int g = s_gof[v], n0 = s_nptr[g], n = s_nptr[g + 1] - n0;
-            int64_t l = layer_of[d][v];
-            if (l < 0 || l >= n) { if (status) atomicOr(&s_bad, 8); l = l < 0 ? 0 : n - 1; }
-            s_layer[d][v] = (u16)l;
-            atomicMax(&s_depth[d][g], (int)l + 1);
-            atomicMax(&s_T[d], (int)l + 1);
-            atomicAdd(&s_ls[d][n0 + g + (int)l + 1], 1);
-            atomicAdd(&s_bl[d][(int)l + 1], 1);
+        // (a D-VAE batch has ten layers: the batch-level counters are bumped once per wave and distinct layer, not once
+        // per node - same-address LDS atomics of a wave are served one lane after the other)
+        for (int it0 = 0; it0 < 2 * N; it0 += PS_T) {
+            const int it = it0 + tid;
+            const bool on = it < 2 * N;
+            int d = 0, key = -1;
+            if (on) {
+                d = it >= N;
+                const int v = it - d * N;
+                const int g = s_gof[v], n0 = s_nptr[g], n = s_nptr[g + 1] - n0;
+                int64_t l = layer_of[d][v];
+                if (l < 0 || l >= n) { if (status) atomicOr(&s_bad, 8); l = l < 0 ? 0 : n - 1; }
+                s_layer[d][v] = (u16)l;
+                atomicMax(&s_depth[d][g], (int)l + 1);
+                atomicAdd(&s_ls[d][n0 + g + (int)l + 1], 1);
+                key = d * (PS_N + 2) + (int)l + 1;   // flat index into s_bl
+            }
+            unsigned long long todo = __ballot(on);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int k = __builtin_amdgcn_readlane(key, leader);
+                const unsigned long long m = __ballot(key == k);
+                if (lane == leader) {
+                    atomicAdd(&(&s_bl[0][0])[k], __popcll(m));
+                    const int dd = k >= PS_N + 2;
+                    atomicMax(&s_T[dd], k - dd * (PS_N + 2));   // (l + 1 of this key)
+                }
+                todo &= ~m;
+            }
         }
         __syncthreads();
         for (int i = tid; i < 2 * B; i += PS_T) {
             const int d = i >= B, g = i - d * B;
             plan[L.depth[d] + g] = s_depth[d][g];
         }
+        PS_STAMP(stamp, 3);
         ps_scan2(s_ls[0], F, s_ls[1], F, s_wsum);
+        PS_STAMP(stamp, 4);
         // lstart: entries 0 .. depth_g of every graph
         for (int i = tid; i < 2 * B; i += PS_T) {
             const int d = i >= B, g = i - d * B, j = s_nptr[g] + g;
@@ -158,19 +209,19 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
             const int g = s_gof[v], n0 = s_nptr[g], i = v - n0 + 1;
             if (i <= s_depth[d][g]) plan[L.lstart[d] + n0 + g + i] = s_ls[d][n0 + g + i];
         }
+        PS_STAMP(stamp, 5);
         // ---- phase C: nodes in (graph, layer, id) order
         for (int it = tid; it < 2 * N; it += PS_T) {
             const int d = it >= N, v = it - d * N;
             const int g = s_gof[v], n0 = s_nptr[g];
             const u16 l = s_layer[d][v];
-            int cnt = 0;
-            for (int u = n0; u < v; ++u) cnt += s_layer[d][u] == l;
-            const int p = s_ls[d][n0 + g + l] + cnt;
+            const int p = s_ls[d][n0 + g + l] + ps_count_equal(s_layer[d], n0, v, l);
             s_pos[d][v] = (u16)p;
             s_order[d][p] = (u16)v;
             plan[L.order[d] + p] = v;
         }
         __syncthreads();
+        PS_STAMP(stamp, 6);
         // ---- phase D: rows of the CSR (d = 0: an edge feeds its target, d = 1: its source)
         for (int it = tid; it < 2 * E; it += PS_T) {
             const int d = it >= E, e = it - d * E;
@@ -178,19 +229,20 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
             atomicAdd(&s_rp[d][(int)s_pos[d][f] + (int)s_gof[f] + 1], 1);
         }
         __syncthreads();
+        PS_STAMP(stamp, 7);
         ps_scan2(s_rp[0], F, s_rp[1], F, s_wsum);
+        PS_STAMP(stamp, 8);
         for (int it = tid; it < 2 * F; it += PS_T) {
             const int d = it >= F, j = it - d * F;
             plan[L.rowptr[d] + j] = s_rp[d][j];
         }
+        PS_STAMP(stamp, 9);
         // ---- phase E: edges in (row, original order) order
         for (int it = tid; it < 2 * E; it += PS_T) {
             const int d = it >= E, e = it - d * E;
             const u16 f = s_edge[1 - d][e];
             const int g = s_gof[f];
-            int cnt = 0;
-            for (int q = s_eptr[g]; q < e; ++q) cnt += s_edge[1 - d][q] == f;
-            const int slot = s_rp[d][(int)s_pos[d][f] + g] + cnt;
+            const int slot = s_rp[d][(int)s_pos[d][f] + g] + ps_count_equal(s_edge[1 - d], s_eptr[g], e, f);
             const int o = s_edge[d][e];
             s_col[d][slot] = (u16)o;
             s_eid[d][slot] = (u16)e;
@@ -199,24 +251,30 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
             float* eattr = reinterpret_cast<float*>(plan + L.eattr[d]);
             for (int r = 0; r < R; ++r) eattr[(int64_t)slot * R + r] = edge_attr[(int64_t)e * R + r];
         }
+        PS_STAMP(stamp, 10);
         // ---- phase F: work items (g * 2 + d) by depth, deepest first, ties by index (plan_items_kernel)
         const int nitems = 2 * B;
-        for (int i = tid; i < nitems; i += PS_T) s_key[i] = s_depth[i & 1][i >> 1];
+        for (int i = tid; i < nitems + 4; i += PS_T) s_key[i] = i < nitems ? s_depth[i & 1][i >> 1] : -1;   // (-1: ranks behind every item)
         __syncthreads();   // (also: the edge lists are dead from here on, s_col / s_eid complete)
         {
             int split = 1;   // threads per item: a power of two, <= 64, split * nitems <= PS_T
             while (split < 64 && 2 * split * nitems <= PS_T) split <<= 1;
             const int item = tid / split, part = tid % split;
-            const int len = (nitems + split - 1) / split;
+            const int len = ((nitems + split - 1) / split + 3) & ~3;   // four keys per LDS read
             int rank = 0;
             if (item < nitems) {
                 const int ki = s_key[item];
                 const int j1 = min(nitems, (part + 1) * len);
-                for (int j = part * len; j < j1; ++j) { const int kj = s_key[j]; rank += (kj > ki) || (kj == ki && j < item); }
+                for (int j = part * len; j < j1; j += 4) {
+                    const int4 kj = *reinterpret_cast<const int4*>(s_key + j);
+                    rank += ((kj.x > ki) || (kj.x == ki && j < item)) + ((kj.y > ki) || (kj.y == ki && j + 1 < item)) +
+                            ((kj.z > ki) || (kj.z == ki && j + 2 < item)) + ((kj.w > ki) || (kj.w == ki && j + 3 < item));
+                }
             }
             for (int o = 1; o < split; o <<= 1) rank += __shfl_xor(rank, o, 64);
             if (item < nitems && part == 0) plan[L.items + rank] = item;
         }
+        PS_STAMP(stamp, 11);
         // ---- phase G: batch-level layers (plan_blptr_kernel)
         const int T0 = s_T[0], T1 = s_T[1];
         ps_scan2(s_bl[0], T0 + 1, s_bl[1], T1 + 1, s_wsum);
@@ -229,6 +287,7 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
         if (tid < 2) plan[L.blptr[tid] + N + 1] = tid ? T1 : T0;
         __syncthreads();
         if (tid < 2) plan[PH_THR0 + tid] = s_thr[tid];
+        PS_STAMP(stamp, 12);
         // ---- phase H: first slot of every (graph, layer): shallow graphs first, then the deep ones (plan_lbase_kernel)
         for (int idx = wave; idx < T0 + T1; idx += PS_T / 64) {
             const int d = idx >= T0, t = idx - d * T0;
@@ -245,15 +304,14 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
                         cnt = s_ls[d][base + 1] - s_ls[d][base];
                         has = true;
                     }
-                    int x = cnt;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+                    const int x = ps_wave_scan(cnt);
                     if (has) { s_lb[d][base] = (u16)(carry + x - cnt); plan[L.lbase[d] + base] = carry + x - cnt; }
-                    carry += __shfl(x, 63, 64);
+                    carry += ps_wave_total(x);
                 }
             }
         }
         __syncthreads();
+        PS_STAMP(stamp, 13);
         // ---- phase I: 64-byte row records in slot order (plan_rowrec_kernel)
         for (int it = tid; it < 2 * N; it += PS_T) {
             const int d = it >= N, p = it - d * N;
@@ -281,13 +339,14 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
     }
     // ---- seal (plan_seal_kernel): a batch that violates the contract leaves an EMPTY plan behind
     __syncthreads();
+    PS_STAMP(stamp, 14);
     if (status && s_bad != 0) {
         for (int i = tid; i < B; i += PS_T) { plan[L.depth[0] + i] = 0; plan[L.depth[1] + i] = 0; }
         for (int i = tid; i < N + 2; i += PS_T) {
             plan[L.blptr[0] + i] = 0; plan[L.blptr[1] + i] = 0; plan[L.blsplit[0] + i] = 0; plan[L.blsplit[1] + i] = 0;
         }
-        if (tid == 0) atomicOr(status, s_bad);
     }
+    if (tid == 0 && status) status[0] = s_bad;
 }
 
 // ------------------------------------------------------------------------------------------------ the dataflow schedule
@@ -307,11 +366,15 @@ __global__ void __launch_bounds__(PS_T) schedule_small_kernel(const int32_t* __r
     __shared__ int32_t s_lcnt[2][PS_N + DF_MAX_GROUPS + 1];
     __shared__ int32_t s_glb[2][PS_F];
     __shared__ u16 s_slot[2][PS_N];        // rowrec slot of the node at every sorted position
+    __shared__ u16 s_gof[PS_N];            // graph of every sorted position (= of every node: graphs are contiguous)
+    __shared__ int32_t s_items[2 * PS_B];
     __shared__ int32_t s_g[PS_B], s_d[PS_B], s_n[PS_B];
     __shared__ int32_t s_used[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int F = N + B;
+    [[maybe_unused]] unsigned long long* stamp = reinterpret_cast<unsigned long long*>(ws + S.total - 64);
+    PS_STAMP(stamp, 0);
     // ---- tables and header of the workspace = 0; stage the plan's per-graph tables
     {
         int4* z = reinterpret_cast<int4*>(ws);
@@ -319,7 +382,7 @@ __global__ void __launch_bounds__(PS_T) schedule_small_kernel(const int32_t* __r
         for (int i = tid; i < nz; i += PS_T) z[i] = make_int4(0, 0, 0, 0);
     }
     for (int i = tid; i <= B; i += PS_T) s_nptr[i] = plan[L.node_ptr + i];
-    for (int i = tid; i < 2 * B; i += PS_T) { const int d = i >= B, g = i - d * B; s_dep[d][g] = plan[L.depth[d] + g]; }
+    for (int i = tid; i < 2 * B; i += PS_T) { const int d = i >= B, g = i - d * B; s_dep[d][g] = plan[L.depth[d] + g]; s_items[i] = plan[L.items + i]; }
     for (int it = tid; it < 2 * F; it += PS_T) { const int d = it >= F, j = it - d * F; s_ls[d][j] = plan[L.lstart[d] + j]; s_glb[d][j] = 0; }
     for (int it = tid; it < 2 * N; it += PS_T) {
         const int d = it >= N, p = it - d * N;
@@ -327,21 +390,31 @@ __global__ void __launch_bounds__(PS_T) schedule_small_kernel(const int32_t* __r
     }
     for (int i = tid; i < 2 * (PS_N + DF_MAX_GROUPS + 1); i += PS_T) (&s_lcnt[0][0])[i] = 0;
     __syncthreads();
+    PS_STAMP(stamp, 1);
     // ---- the LPT assignment (one wave), straight into the workspace
-    if (wave == 0) df_assign_wave<PS_B>(plan, L, ws, S, B, G, c_layer, c_row, s_g, s_d, s_n);
+    if (wave == 0) df_assign_wave<PS_B>(s_items, s_dep[0], s_dep[1], s_nptr, ws, S, B, G, c_layer, c_row, s_g, s_d, s_n);
+    else   // meanwhile: graph of every position (last g with node_ptr[g] <= p; empty graphs share their successor's offset)
+        for (int p = tid - 64; p < N; p += PS_T - 64) {
+            int lo = 0, hi = B;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_nptr[mid] <= p) lo = mid; else hi = mid; }
+            s_gof[p] = (u16)lo;
+        }
     __syncthreads();
+    PS_STAMP(stamp, 2);
     for (int i = tid; i < B; i += PS_T) s_grp[i] = ws[S.grp_of + i];
     for (int i = tid; i < G; i += PS_T) s_gd[i] = ws[S.gdepth + i];
     for (int i = tid; i <= G; i += PS_T) s_loff[i] = ws[S.loff + i];
     __syncthreads();
-    // ---- rows per (group, layer): a wave per (graph, direction), lanes over its layers
-    for (int i = wave; i < 2 * B; i += PS_T / 64) {
-        const int d = i >= B, g = i - d * B;
-        const int k = s_grp[g], j = s_nptr[g] + g;
-        const int depth = min(s_dep[d][g], s_gd[k]);
-        for (int t = lane; t < depth; t += 64) atomicAdd(&s_lcnt[d][s_loff[k] + t], s_ls[d][j + t + 1] - s_ls[d][j + t]);
+    PS_STAMP(stamp, 3);
+    // ---- rows per (group, layer): position n0 + t of a graph stands for its layer t (a graph has at least as many nodes
+    // as layers)
+    for (int it = tid; it < 2 * N; it += PS_T) {
+        const int d = it >= N, p = it - d * N;
+        const int g = s_gof[p], n0 = s_nptr[g], t = p - n0, k = s_grp[g];
+        if (t < min(s_dep[d][g], s_gd[k])) atomicAdd(&s_lcnt[d][s_loff[k] + t], s_ls[d][n0 + g + t + 1] - s_ls[d][n0 + g + t]);
     }
     __syncthreads();
+    PS_STAMP(stamp, 4);
     // ---- per (group, direction): exclusive prefix of the block-padded counts; blocks of the group
     for (int i = wave; i < 2 * G; i += PS_T / 64) {
         const int d = i >= G, k = i - d * G;
@@ -352,26 +425,24 @@ __global__ void __launch_bounds__(PS_T) schedule_small_kernel(const int32_t* __r
             const int t = c0 + lane;
             const int c = t < depth ? cnt[t] : 0;
             const int padded = (c + DF_RB - 1) / DF_RB * DF_RB;
-            int x = padded;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+            const int x = ps_wave_scan(padded);
             if (t <= depth) cnt[t] = carry + x - padded;
-            carry += __shfl(x, 63, 64);
+            carry += ps_wave_total(x);
         }
         if (lane == 0) s_gtab[d][2 * k + 1] = carry / DF_RB;
     }
     __syncthreads();
+    PS_STAMP(stamp, 5);
     // ---- first record of every group
     if (wave < 2) {
         const int d = wave;
-        int x = lane < G ? s_gtab[d][2 * lane + 1] * DF_RB : 0;
-        const int own = x;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        const int own = lane < G ? s_gtab[d][2 * lane + 1] * DF_RB : 0;
+        const int x = ps_wave_scan(own);
         if (lane < G) s_gtab[d][2 * lane] = x - own;
         if (lane == 63) s_used[d] = x;
     }
     __syncthreads();
+    PS_STAMP(stamp, 6);
     // ---- the used records = -1 (padding), and meanwhile glbase: a wave per (direction, group, layer)
     for (int d = 0; d < 2; ++d) {
         int4* f = reinterpret_cast<int4*>(ws + S.grec[d]);
@@ -395,15 +466,14 @@ __global__ void __launch_bounds__(PS_T) schedule_small_kernel(const int32_t* __r
                     cnt = s_ls[d][base + 1] - s_ls[d][base];
                     has = true;
                 }
-                int x = cnt;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+                const int x = ps_wave_scan(cnt);
                 if (has) s_glb[d][base] = carry + x - cnt;
-                carry += __shfl(x, 63, 64);
+                carry += ps_wave_total(x);
             }
         }
     }
     __syncthreads();
+    PS_STAMP(stamp, 7);
     // ---- tables out
     for (int it = tid; it < 4 * G; it += PS_T) { const int d = it >= 2 * G, j = it - d * 2 * G; ws[S.gtab[d] + j] = s_gtab[d][j]; }
     {
@@ -411,19 +481,35 @@ __global__ void __launch_bounds__(PS_T) schedule_small_kernel(const int32_t* __r
         for (int it = tid; it < 2 * total; it += PS_T) { const int d = it >= total, j = it - d * total; ws[S.lcnt[d] + j] = s_lcnt[d][j]; }
     }
     for (int it = tid; it < 2 * F; it += PS_T) { const int d = it >= F, j = it - d * F; ws[S.glbase[d] + j] = s_glb[d][j]; }
-    // ---- every row record to its place in the group order
-    for (int it = tid; it < 2 * N; it += PS_T) {
-        const int d = it >= N, p = it - d * N;
-        const int4* src = reinterpret_cast<const int4*>(plan + L.rowrec[d]) + 4 * (int64_t)s_slot[d][p];
-        const int4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
-        const int g = r0.w, n0 = s_nptr[g];
-        const int32_t* ls = s_ls[d] + n0 + g;
-        int lo = 0, hi = s_dep[d][g];                    // largest t with ls[t] <= p
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ls[mid] <= p) lo = mid; else hi = mid; }
-        const int rec = s_gtab[d][2 * s_grp[g]] + s_glb[d][n0 + g + lo] + (p - ls[lo]);
-        int4* dst = reinterpret_cast<int4*>(ws + S.grec[d]) + 4 * (int64_t)rec;
-        dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+    PS_STAMP(stamp, 8);
+    // ---- every row record to its place in the group order (all loads of a thread's records first: one trip to memory)
+    {
+        constexpr int PER = 2 * PS_N / PS_T;
+        int4 r[PER][4];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int it = min(tid + q * PS_T, 2 * N - 1);   // (clamped: the loads are unconditional, the stores below are not)
+            const int d = it >= N, p = it - d * N;
+            const int4* src = reinterpret_cast<const int4*>(plan + L.rowrec[d]) + 4 * (int64_t)s_slot[d][p];
+            r[q][0] = src[0]; r[q][1] = src[1]; r[q][2] = src[2]; r[q][3] = src[3];
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int it = tid + q * PS_T;
+            if (it < 2 * N) {
+                const int d = it >= N, p = it - d * N;
+                const int g = s_gof[p], n0 = s_nptr[g];
+                const int32_t* ls = s_ls[d] + n0 + g;
+                int lo = 0, hi = s_dep[d][g];                    // largest t with ls[t] <= p
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ls[mid] <= p) lo = mid; else hi = mid; }
+                const int rec = s_gtab[d][2 * s_grp[g]] + s_glb[d][n0 + g + lo] + (p - ls[lo]);
+                int4* dst = reinterpret_cast<int4*>(ws + S.grec[d]) + 4 * (int64_t)rec;
+                dst[0] = r[q][0]; dst[1] = r[q][1]; dst[2] = r[q][2]; dst[3] = r[q][3];
+            }
+        }
     }
+    __builtin_amdgcn_s_waitcnt(0);
+    PS_STAMP(stamp, 9);
 }
 
 }  // namespace

@@ -90,6 +90,7 @@ DF_COST_ROW = _env_int("DAGNN_AMD_DF_COST_ROW", 1)
 DF_GROUPS = _env_int("DAGNN_AMD_DF_GROUPS", 0)              # 0 = as many groups as the device hosts
 DF_XCD = _env_int("DAGNN_AMD_DF_XCD", 1)                    # 1: XCD-aware workgroup ids + hand-offs through the shared L2 where the run-time check allows
 BWD_DATAFLOW = _env_int("DAGNN_AMD_BWD_DATAFLOW", 1)        # 1: the reverse sweep as one persistent dataflow launch (H <= 256)
+DEBUG_WG = _env_int("DAGNN_AMD_DEBUG_WG", 0)                # workgroup whose blocks scripts/df_stamps.py stamps
 SPIN_LIMIT = _env_int("DAGNN_AMD_SPIN_LIMIT", 0)            # polls before a device-side wait gives up; 0 = library default
 DEBUG_TIMING: Optional[torch.Tensor] = None  # int64[8] device tensor: phase ticks of the deepest work item
 _NOSPAN = _NoSpan()
@@ -99,8 +100,26 @@ def _span(name, tensor):
     return TIMER.span(name, tensor.device) if TIMER is not None else _NOSPAN
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t: torch.Tensor) -> int:
+    """Raw hipStream_t of torch's current stream on the tensor's device (the Stream object costs ~1.5 us per call and
+    the small-batch forward asks seven times)."""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(t.device.index if t.device.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+_CUS = {}
+
+
+def _num_cus(device) -> int:
+    key = device.index if isinstance(device, torch.device) else device
+    n = _CUS.get(key)
+    if n is None:
+        n = _CUS[key] = torch.cuda.get_device_properties(device).multi_processor_count
+    return n
 
 
 def _dev(t: torch.Tensor, what: str, dtype=None) -> torch.Tensor:
@@ -136,7 +155,8 @@ class PlanHandle(object):
         self.N, self.E, self.B, self.R = int(N), int(E), int(B), int(R)
         nbytes = lib.dagnn_plan_bytes(self.N, self.E, self.B, self.R)
         self.ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device)
-        self.status = torch.zeros(4, dtype=torch.int32, device=device)
+        small = PLAN_SMALL and lib.dagnn_plan_is_small(self.N, self.E, self.B)   # that build writes the status word itself
+        self.status = (torch.empty if small else torch.zeros)(4, dtype=torch.int32, device=device)
         self.desc = Plan(self.ws.data_ptr(), nbytes, self.N, self.E, self.B, self.R, 0 if PLAN_SMALL else PLAN_GENERAL_BUILD)
         self.ready = None   # event to wait for when the plan was built on another stream
 
@@ -355,7 +375,7 @@ def dataflow_groups(device, num_dirs: int, num_stacked: int, H: int, B: int) -> 
     """Groups the dataflow kernel runs on this device for this model shape; 0 = not applicable."""
     if not DATAFLOW:
         return 0
-    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    cus = _num_cus(device)
     g = _lib.load().dagnn_dataflow_groups(cus, int(num_dirs), int(num_stacked), int(H), int(B))
     return min(g, DF_GROUPS) if DF_GROUPS > 0 else g
 
@@ -405,9 +425,9 @@ def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     args.schedule, args.err = sched.data_ptr(), err.data_ptr()
     args.debug_timing = DEBUG_TIMING.data_ptr() if DEBUG_TIMING is not None else None
     args.spin_limit = SPIN_LIMIT
-    args.debug_wg = _env_int("DAGNN_AMD_DEBUG_WG", 0)
+    args.debug_wg = DEBUG_WG
     if DF_XCD:
-        args.num_cus = torch.cuda.get_device_properties(plan.ws.device).multi_processor_count
+        args.num_cus = _num_cus(plan.ws.device)
         args.xcc_table = arena.xcc_table(plan.ws.device).data_ptr()
     args.plan_status = plan.status.data_ptr()
     with _span("dataflow_run", plan.ws):
@@ -417,7 +437,7 @@ def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
             for i in range(L):
                 check(lib.dagnn_score_parts(h[d][i].data_ptr(), h[d][i].shape[1], H, cells[(d, i)].w_key.data_ptr(),
                                             plan.N, _stream(plan.ws)), "dagnn_score_parts")
-    arena.watch(plan)
+    arena.watch(plan, folded=True)
 
 
 def frontier_ld(H: int) -> int:
@@ -479,29 +499,35 @@ class GranuleArena(object):
 
     WATCH_SLOTS = 64   # read-backs in flight before the oldest one is waited for
 
-    def watch(self, plan=None) -> None:
+    def watch(self, plan=None, folded: bool = False) -> None:
         """Queue an asynchronous read-back of the device-side error words (the kernels' bounded-wait flag and the
         plan's contract status) behind the work just launched; `poll()` looks at the finished ones without
         synchronising.  Every watch owns a slot of a pinned ring and an event: an async evaluation loop that issues
         many passes before anything synchronises loses none of their reports (one shared buffer would let a later clean
-        pass overwrite a violation)."""
+        pass overwrite a violation).  `folded`: the launch was one of the dataflow kernels, which carry the plan's status
+        in bits 8-15 of the error word themselves - one copy instead of two."""
         import collections
         dev = self.err.device
         if getattr(self, "_host", None) is None:
             self._host = torch.zeros(self.WATCH_SLOTS, 2, dtype=torch.int32).pin_memory()
+            self._host_err = [self._host[k, 0:1] for k in range(self.WATCH_SLOTS)]
+            self._host_status = [self._host[k, 1:2] for k in range(self.WATCH_SLOTS)]
+            self._events = [None] * self.WATCH_SLOTS
             self._pending = collections.deque()
             self._seq = 0
         if len(self._pending) >= self.WATCH_SLOTS:
             self._drain(block_first=True)   # (raises if that oldest pass failed)
         slot = self._seq % self.WATCH_SLOTS
         self._seq += 1
-        st = torch.cuda.current_stream(dev)
-        self._host[slot, 1] = 0
-        self._host[slot, 0:1].copy_(self.err, non_blocking=True)
-        if plan is not None:
-            self._host[slot, 1:2].copy_(plan.status[0:1], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(st)
+        self._host_err[slot].copy_(self.err, non_blocking=True)
+        if plan is not None and not folded:
+            self._host_status[slot].copy_(plan.status[0:1], non_blocking=True)
+        else:
+            self._host_status[slot].zero_()
+        ev = self._events[slot]   # (the slot's previous watch has been drained: its event is free again)
+        if ev is None:
+            ev = self._events[slot] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
         self._pending.append((ev, slot))
 
     def _drain(self, block: bool = False, block_first: bool = False) -> None:
@@ -516,6 +542,8 @@ class GranuleArena(object):
                 break
             pend.popleft()
             e, s = int(self._host[slot, 0]), int(self._host[slot, 1])
+            if e & 0xff00:   # a dataflow kernel found the plan's status word set and reported it in bits 8-15
+                s, e = s | ((e >> 8) & 0xff), e & ~0xff00
             if (e or s) and failed is None:
                 failed = (e, s)
         if failed is None:
@@ -581,7 +609,7 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
             fc.h_out = h[d][i].data_ptr()
     args.num_stacked, args.dir_mask, args.H, args.ld_h, args.vid_mod = L, mask, H, h[dirs[0]][0].shape[1], int(vid_mod)
     args.debug_timing = DEBUG_TIMING.data_ptr() if DEBUG_TIMING is not None else None
-    args.num_cus = torch.cuda.get_device_properties(plan.ws.device).multi_processor_count
+    args.num_cus = _num_cus(plan.ws.device)
     args.rb4_max_wgs = RB4_MAX_WGS
     # everything above is independent of the schedule: the one device->host read of the forward pass comes
     # last, so the host-side argument marshalling overlaps the plan / GEMM kernels still in flight
@@ -733,7 +761,7 @@ def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells,
             bc.sigma, bc.edge_feat_grad = o["sigma"].data_ptr(), _ptr(o["edge_feat_grad"])
     args.num_stacked, args.dir_mask, args.H, args.ld_h = L, mask, H, h[dirs[0]][0].shape[1]
     args.vid_mod = int(vid_mod)
-    args.num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    args.num_cus = _num_cus(dev)
     args.thin_wgs = BWD_THIN_WGS
     args.tail_replicas, args.tail_max_blocks = (BWD_TAIL_REPLICAS if use_tail else 0), BWD_TAIL_MAX_BLOCKS
     args.epoch, args.tail_err = epoch, _ptr(err)
@@ -882,12 +910,12 @@ def bwd_dataflow_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, ce
         args.schedule, args.records, args.err = sched.data_ptr(), recs.data_ptr(), err.data_ptr()
         args.plan_status = plan.status.data_ptr()
         if DF_XCD:
-            args.num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            args.num_cus = _num_cus(dev)
             args.xcc_table = arena.xcc_table(dev).data_ptr()
         check(lib.dagnn_bwd_dataflow_prepare(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_bwd_dataflow_prepare")
     with _span("backward_run", plan.ws):
         check(lib.dagnn_bwd_dataflow_run(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_bwd_dataflow_run")
-    arena.watch(plan)
+    arena.watch(plan, folded=True)
     for o in out.values():
         o.pop("_wkey", None)
     out["_keep"] = keep   # buffers the launch reads: alive until the caller drops the result
@@ -914,7 +942,7 @@ def wgrad(jobs, N: int, Hp: int, H: int):
         db = torch.empty(3 * H, dtype=torch.float32, device=dev) if want_bias else None
         outs.append((dW, db))
         arr[q] = _lib.WgradJob(dg.data_ptr(), inp.data_ptr(), dW.data_ptr(), _ptr(db), dg.stride(0), inp.stride(0), K2)
-    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    cus = _num_cus(dev)
     splits = max(lib.dagnn_wgrad_splits(cus, len(jobs), Hp, kmax, max(N, 1)), 1)
     nbytes = lib.dagnn_wgrad_workspace_bytes(len(jobs), Hp, kmax, splits)
     ws = _WGRAD_WS.get(dev)

@@ -79,8 +79,9 @@ size_t dagnn_plan_bytes(int64_t N, int64_t E, int64_t B, int num_edge_feats);
  * Edges must be grouped by graph in the same order as nodes (what PyG collation produces).
  * `status` [4] int32 device words, written by the kernels: status[0] != 0 flags a contract
  * violation (bit 0: edges not grouped by graph, bit 1: edge crosses graphs, bit 2: batch not
- * sorted, bit 3: layer id >= nodes of its graph).  Read it back only when debugging: the
- * forward path itself never synchronises. */
+ * sorted, bit 3: layer id >= nodes of its graph).  The caller clears status[0] before the call (the
+ * kernels OR into it); a batch for which dagnn_plan_is_small() holds has it written, cleared or not.
+ * Read it back only when debugging: the forward path itself never synchronises. */
 int dagnn_plan_build(const dagnn_plan* plan /* host */,
                      const int64_t* edge_index, const int64_t* layer_fwd, const int64_t* layer_bwd,
                      const int64_t* batch, const float* edge_attr, int32_t* status, void* stream);
@@ -274,7 +275,7 @@ int dagnn_frontier_run(const dagnn_plan* plan /* host */, const dagnn_frontier_a
  *      buffers must have been zero-initialised once and only ever used with strictly increasing `epoch`s (a replayed
  *      hipGraph must contain the memset).  `err` (device int32, zeroed by the caller) is set when a bounded wait
  *      expires (results are then invalid): bit 0 a granule poll, bit 1 an LDS flag; bit 2: the plan's status word
- *      (`plan_status`) was nonzero, nothing was computed; bit 3: `schedule` does not carry the header of a schedule
+ *      (`plan_status`) was nonzero, nothing was computed - bits 8-15 then carry that status word; bit 3: `schedule` does not carry the header of a schedule
  *      built for `groups` groups (dagnn_dataflow_schedule), nothing was computed.
  *      State rows h_out [N, ld_h] receive the H states only; dagnn_score_parts adds the H/16 partial attention scores
  *      behind them (the format dagnn_backward_prepare reads) when a backward pass follows.

@@ -55,6 +55,10 @@ __device__ __forceinline__ int ps_count_equal(const unsigned short* keys, int lo
     return cnt;
 }
 
+// Workgroup barrier for data exchanged through LDS ONLY: waits for this wave's LDS operations, not for its global stores
+// (__syncthreads() also drains those - a store round trip per barrier, and these kernels are a dozen barriers long).
+__device__ __forceinline__ void ps_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Inclusive scans of a0[0..n0) and a1[0..n1) in place (LDS), both at once; every thread of the workgroup calls.
 __device__ __forceinline__ void ps_scan2(int32_t* a0, int n0, int32_t* a1, int n1, int32_t (*wsum)[PS_T / 64]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -68,7 +72,7 @@ __device__ __forceinline__ void ps_scan2(int32_t* a0, int n0, int32_t* a1, int n
     }
     const int x0 = ps_wave_scan(v0[PS_PER - 1]), x1 = ps_wave_scan(v1[PS_PER - 1]);
     if (lane == 63) { wsum[0][wave] = x0; wsum[1][wave] = x1; }
-    __syncthreads();
+    ps_barrier();
     int b0 = x0 - v0[PS_PER - 1], b1 = x1 - v1[PS_PER - 1];
     for (int w = 0; w < wave; ++w) { b0 += wsum[0][w]; b1 += wsum[1][w]; }
 #pragma unroll
@@ -76,7 +80,7 @@ __device__ __forceinline__ void ps_scan2(int32_t* a0, int n0, int32_t* a1, int n
         if (i0 + k < n0) a0[i0 + k] = b0 + v0[k];
         if (i0 + k < n1) a1[i0 + k] = b1 + v1[k];
     }
-    __syncthreads();
+    ps_barrier();
 }
 
 // ------------------------------------------------------------------------------------------------ the plan
@@ -109,7 +113,28 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
     [[maybe_unused]] unsigned long long* stamp = reinterpret_cast<unsigned long long*>(plan + L.cursor[0]);
     PS_STAMP(stamp, 0);
 
-    // ---- phase A: header, zero tables, stage batch vector and edge lists, contract checks (plan_ptr_kernel)
+    // ---- phase A: every global load of the kernel is issued here, in one trip to memory (batch vector, edge lists, layer
+    // ids; clamped indices: the loads are unconditional); header, zeroed tables
+    constexpr int NPER = PS_N / PS_T, EPER = PS_E / PS_T, LPER = 2 * PS_N / PS_T;
+    int64_t r_b[NPER], r_bp[NPER], r_s[EPER], r_t[EPER], r_l[LPER];
+#pragma unroll
+    for (int q = 0; q < NPER; ++q) {
+        const int i = min(tid + q * PS_T, N - 1);
+        r_b[q] = batch[i];
+        r_bp[q] = batch[max(i - 1, 0)];
+    }
+#pragma unroll
+    for (int q = 0; q < EPER; ++q) {
+        const int e = min(tid + q * PS_T, max(E - 1, 0));
+        r_s[q] = E > 0 ? edge_index[e] : 0;
+        r_t[q] = E > 0 ? edge_index[(int64_t)E + e] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < LPER; ++q) {
+        const int it = min(tid + q * PS_T, 2 * N - 1);
+        const int d = it >= N;
+        r_l[q] = layer_of[d][it - d * N];
+    }
     if (tid == 0) {
         plan[PH_N] = N; plan[PH_E] = E; plan[PH_B] = B; plan[PH_R] = R; plan[PH_MAGIC] = DAGNN_PLAN_MAGIC;
         s_bad = 0;   // (the status word is WRITTEN at the end, not accumulated: the caller need not clear it for this build)
@@ -119,30 +144,40 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
     for (int i = tid; i < 2 * PS_B; i += PS_T) (&s_depth[0][0])[i] = 0;
     for (int i = tid; i < 2 * (PS_N + 2); i += PS_T) (&s_bl[0][0])[i] = 0;
     for (int i = tid; i <= B; i += PS_T) { s_nptr[i] = 0; s_eptr[i] = 0; }
-    for (int i = tid; i < N + 2; i += PS_T) {
-        plan[L.blptr[0] + i] = 0; plan[L.blptr[1] + i] = 0; plan[L.blsplit[0] + i] = 0; plan[L.blsplit[1] + i] = 0;
-    }
     int bad = 0;
-    for (int i = tid; i < N; i += PS_T) {
-        const int64_t b = batch[i];
-        if (i > 0 && b < batch[i - 1]) bad |= 4;
-        if (b < 0 || b >= B) bad |= 4;
-        s_gof[i] = (u16)(b < 0 ? 0 : (b >= B ? B - 1 : b));
-    }
-    for (int e = tid; e < E; e += PS_T) {
-        const int64_t s = edge_index[e], t = edge_index[(int64_t)E + e];
-        const bool ok = s >= 0 && s < N && t >= 0 && t < N;
-        if (!ok) bad |= 2;
-        else {
-            const int64_t bs = batch[s];
-            if (bs != batch[t]) bad |= 2;
-            if (e > 0) { const int64_t sp = edge_index[e - 1]; if (sp >= 0 && sp < N && batch[sp] > bs) bad |= 1; }
+#pragma unroll
+    for (int q = 0; q < NPER; ++q) {
+        const int i = tid + q * PS_T;
+        if (i < N) {
+            const int64_t b = r_b[q];
+            if (i > 0 && b < r_bp[q]) bad |= 4;
+            if (b < 0 || b >= B) bad |= 4;
+            s_gof[i] = (u16)(b < 0 ? 0 : (b >= B ? B - 1 : b));
         }
-        s_edge[0][e] = (u16)(ok ? s : 0);
-        s_edge[1][e] = (u16)(ok ? t : 0);
     }
-    __syncthreads();
+    bool e_ok[EPER];
+#pragma unroll
+    for (int q = 0; q < EPER; ++q) {
+        const int e = tid + q * PS_T;
+        e_ok[q] = r_s[q] >= 0 && r_s[q] < N && r_t[q] >= 0 && r_t[q] < N;
+        if (e < E) {
+            if (!e_ok[q]) bad |= 2;
+            s_edge[0][e] = (u16)(e_ok[q] ? r_s[q] : 0);
+            s_edge[1][e] = (u16)(e_ok[q] ? r_t[q] : 0);
+        }
+    }
+    ps_barrier();
     PS_STAMP(stamp, 1);
+    // contract checks on the staged copies (plan_ptr_kernel; graph ids are in range or bit 2 is up already)
+#pragma unroll
+    for (int q = 0; q < EPER; ++q) {
+        const int e = tid + q * PS_T;
+        if (e < E && e_ok[q]) {
+            const int bs = s_gof[s_edge[0][e]];
+            if (bs != (int)s_gof[s_edge[1][e]]) bad |= 2;
+            if (e > 0 && (int)s_gof[s_edge[0][e - 1]] > bs) bad |= 1;
+        }
+    }
     if (bad && status) atomicOr(&s_bad, bad);
     // node_ptr[g] = first node of a graph >= g, edge_ptr[g] = first edge whose source is in a graph >= g: node i (edge e)
     // is that first one for every g in (graph of its predecessor, its own graph]
@@ -154,7 +189,7 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
         const int prev = e > 0 ? (int)s_gof[s_edge[0][e - 1]] : -1, cur = e < E ? (int)s_gof[s_edge[0][e]] : B;
         for (int g = prev + 1; g <= cur; ++g) s_eptr[g] = e;
     }
-    __syncthreads();
+    ps_barrier();
     for (int i = tid; i <= B; i += PS_T) { plan[L.node_ptr + i] = s_nptr[i]; plan[L.edge_ptr + i] = s_eptr[i]; }
     const bool broken = (s_bad & 7) != 0;   // contract violated: the tables would be garbage - nothing below walks them
 
@@ -163,35 +198,37 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
         // ---- phase B: layers, depths, histograms (plan_graph_kernel, first half)
         // (a D-VAE batch has ten layers: the batch-level counters are bumped once per wave and distinct layer, not once
         // per node - same-address LDS atomics of a wave are served one lane after the other)
-        for (int it0 = 0; it0 < 2 * N; it0 += PS_T) {
-            const int it = it0 + tid;
+#pragma unroll
+        for (int q = 0; q < LPER; ++q) {
+            const int it = tid + q * PS_T;
             const bool on = it < 2 * N;
-            int d = 0, key = -1;
+            int key = -1;
             if (on) {
-                d = it >= N;
-                const int v = it - d * N;
+                const int d = it >= N, v = it - d * N;
                 const int g = s_gof[v], n0 = s_nptr[g], n = s_nptr[g + 1] - n0;
-                int64_t l = layer_of[d][v];
+                int64_t l = r_l[q];
                 if (l < 0 || l >= n) { if (status) atomicOr(&s_bad, 8); l = l < 0 ? 0 : n - 1; }
                 s_layer[d][v] = (u16)l;
                 atomicMax(&s_depth[d][g], (int)l + 1);
                 atomicAdd(&s_ls[d][n0 + g + (int)l + 1], 1);
                 key = d * (PS_N + 2) + (int)l + 1;   // flat index into s_bl
             }
-            unsigned long long todo = __ballot(on);
-            while (todo) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const int k = __builtin_amdgcn_readlane(key, leader);
-                const unsigned long long m = __ballot(key == k);
-                if (lane == leader) {
-                    atomicAdd(&(&s_bl[0][0])[k], __popcll(m));
-                    const int dd = k >= PS_N + 2;
-                    atomicMax(&s_T[dd], k - dd * (PS_N + 2));   // (l + 1 of this key)
+            if (q * PS_T < 2 * N) {   // (uniform: the ballots below need every lane of the waves that take part)
+                unsigned long long todo = __ballot(on);
+                while (todo) {
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const int k = __builtin_amdgcn_readlane(key, leader);
+                    const unsigned long long m = __ballot(key == k);
+                    if (lane == leader) {
+                        atomicAdd(&(&s_bl[0][0])[k], __popcll(m));
+                        const int dd = k >= PS_N + 2;
+                        atomicMax(&s_T[dd], k - dd * (PS_N + 2));   // (l + 1 of this key)
+                    }
+                    todo &= ~m;
                 }
-                todo &= ~m;
             }
         }
-        __syncthreads();
+        ps_barrier();
         for (int i = tid; i < 2 * B; i += PS_T) {
             const int d = i >= B, g = i - d * B;
             plan[L.depth[d] + g] = s_depth[d][g];
@@ -220,7 +257,7 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
             s_order[d][p] = (u16)v;
             plan[L.order[d] + p] = v;
         }
-        __syncthreads();
+        ps_barrier();
         PS_STAMP(stamp, 6);
         // ---- phase D: rows of the CSR (d = 0: an edge feeds its target, d = 1: its source)
         for (int it = tid; it < 2 * E; it += PS_T) {
@@ -228,7 +265,7 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
             const int f = s_edge[1 - d][e];
             atomicAdd(&s_rp[d][(int)s_pos[d][f] + (int)s_gof[f] + 1], 1);
         }
-        __syncthreads();
+        ps_barrier();
         PS_STAMP(stamp, 7);
         ps_scan2(s_rp[0], F, s_rp[1], F, s_wsum);
         PS_STAMP(stamp, 8);
@@ -255,7 +292,7 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
         // ---- phase F: work items (g * 2 + d) by depth, deepest first, ties by index (plan_items_kernel)
         const int nitems = 2 * B;
         for (int i = tid; i < nitems + 4; i += PS_T) s_key[i] = i < nitems ? s_depth[i & 1][i >> 1] : -1;   // (-1: ranks behind every item)
-        __syncthreads();   // (also: the edge lists are dead from here on, s_col / s_eid complete)
+        ps_barrier();   // (also: the edge lists are dead from here on, s_col / s_eid complete)
         {
             int split = 1;   // threads per item: a power of two, <= 64, split * nitems <= PS_T
             while (split < 64 && 2 * split * nitems <= PS_T) split <<= 1;
@@ -275,17 +312,17 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
             if (item < nitems && part == 0) plan[L.items + rank] = item;
         }
         PS_STAMP(stamp, 11);
-        // ---- phase G: batch-level layers (plan_blptr_kernel)
+        // ---- phase G: batch-level layers (plan_blptr_kernel); every word of blptr, the tail of blsplit
         const int T0 = s_T[0], T1 = s_T[1];
         ps_scan2(s_bl[0], T0 + 1, s_bl[1], T1 + 1, s_wsum);
         for (int it = tid; it < 2 * (N + 2); it += PS_T) {
             const int d = it >= N + 2, t = it - d * (N + 2);
             const int T = d ? T1 : T0;
-            if (t <= T) plan[L.blptr[d] + t] = s_bl[d][t];
+            plan[L.blptr[d] + t] = t <= T ? s_bl[d][t] : (t == N + 1 ? T : 0);
+            if (t >= T) plan[L.blsplit[d] + t] = 0;
             if (t < T && s_bl[d][t + 1] - s_bl[d][t] > DAGNN_PLAN_THIN_ROWS) atomicMax(&s_thr[d], t + 1);
         }
-        if (tid < 2) plan[L.blptr[tid] + N + 1] = tid ? T1 : T0;
-        __syncthreads();
+        ps_barrier();
         if (tid < 2) plan[PH_THR0 + tid] = s_thr[tid];
         PS_STAMP(stamp, 12);
         // ---- phase H: first slot of every (graph, layer): shallow graphs first, then the deep ones (plan_lbase_kernel)
@@ -310,7 +347,7 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
                 }
             }
         }
-        __syncthreads();
+        ps_barrier();
         PS_STAMP(stamp, 13);
         // ---- phase I: 64-byte row records in slot order (plan_rowrec_kernel)
         for (int it = tid; it < 2 * N; it += PS_T) {
@@ -338,9 +375,10 @@ __global__ void __launch_bounds__(PS_T) plan_small_kernel(int32_t* plan, PlanLay
         }
     }
     // ---- seal (plan_seal_kernel): a batch that violates the contract leaves an EMPTY plan behind
-    __syncthreads();
+    ps_barrier();
     PS_STAMP(stamp, 14);
     if (status && s_bad != 0) {
+        __syncthreads();   // (the zeros below must land after the values the phases above stored to the same words)
         for (int i = tid; i < B; i += PS_T) { plan[L.depth[0] + i] = 0; plan[L.depth[1] + i] = 0; }
         for (int i = tid; i < N + 2; i += PS_T) {
             plan[L.blptr[0] + i] = 0; plan[L.blptr[1] + i] = 0; plan[L.blsplit[0] + i] = 0; plan[L.blsplit[1] + i] = 0;
@@ -359,23 +397,29 @@ __global__ void __launch_bounds__(PS_T) schedule_small_kernel(const int32_t* __r
     if (status && status[0] != 0) return;   // the batch violates the plan contract: nothing here can be trusted
     __shared__ int32_t s_nptr[PS_B + 1];
     __shared__ int32_t s_dep[2][PS_B];
-    __shared__ int32_t s_ls[2][PS_F];
+    __shared__ int32_t s_ls[2][PS_F];      // the plan's lstart (flat)
+    __shared__ u16 s_lb[2][PS_F];          // the plan's lbase (flat): first rowrec slot of every (graph, layer)
     __shared__ int32_t s_grp[PS_B];
+    __shared__ __attribute__((aligned(16))) u16 s_grp16[PS_B];
+    __shared__ int32_t s_gcnt[DF_MAX_GROUPS], s_goff[DF_MAX_GROUPS + 1];
+    __shared__ u16 s_glist[PS_B];          // graphs in (group, graph) order
     __shared__ int32_t s_gd[DF_MAX_GROUPS], s_loff[DF_MAX_GROUPS + 1];
     __shared__ int32_t s_gtab[2][2 * DF_MAX_GROUPS];
-    __shared__ int32_t s_lcnt[2][PS_N + DF_MAX_GROUPS + 1];
+    __shared__ int32_t s_lcnt[2][PS_N + DF_MAX_GROUPS + 1];   // rows per (group, layer), then their padded exclusive prefix
+    __shared__ u16 s_cnt[2][PS_N + DF_MAX_GROUPS + 1];        // ... the rows, kept
+    __shared__ unsigned char s_kof[PS_N + DF_MAX_GROUPS + 1]; // group of every (group, layer) pair
     __shared__ int32_t s_glb[2][PS_F];
-    __shared__ u16 s_slot[2][PS_N];        // rowrec slot of the node at every sorted position
     __shared__ u16 s_gof[PS_N];            // graph of every sorted position (= of every node: graphs are contiguous)
+    __shared__ u16 s_gslot[2][PS_N];       // graph of every rowrec slot
+    __shared__ u16 s_rec[2][PS_N];         // schedule record of every rowrec slot
     __shared__ int32_t s_items[2 * PS_B];
     __shared__ int32_t s_g[PS_B], s_d[PS_B], s_n[PS_B];
-    __shared__ int32_t s_used[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int F = N + B;
     [[maybe_unused]] unsigned long long* stamp = reinterpret_cast<unsigned long long*>(ws + S.total - 64);
     PS_STAMP(stamp, 0);
-    // ---- tables and header of the workspace = 0; stage the plan's per-graph tables
+    // ---- tables and header of the workspace = 0; stage the plan's per-graph tables (one trip to memory)
     {
         int4* z = reinterpret_cast<int4*>(ws);
         const int nz = (int)(S.grec[0] / 4);
@@ -383,13 +427,14 @@ __global__ void __launch_bounds__(PS_T) schedule_small_kernel(const int32_t* __r
     }
     for (int i = tid; i <= B; i += PS_T) s_nptr[i] = plan[L.node_ptr + i];
     for (int i = tid; i < 2 * B; i += PS_T) { const int d = i >= B, g = i - d * B; s_dep[d][g] = plan[L.depth[d] + g]; s_items[i] = plan[L.items + i]; }
-    for (int it = tid; it < 2 * F; it += PS_T) { const int d = it >= F, j = it - d * F; s_ls[d][j] = plan[L.lstart[d] + j]; s_glb[d][j] = 0; }
-    for (int it = tid; it < 2 * N; it += PS_T) {
-        const int d = it >= N, p = it - d * N;
-        s_slot[d][p] = (u16)plan[L.pos[d] + plan[L.order[d] + p]];
+    for (int it = tid; it < 2 * F; it += PS_T) {
+        const int d = it >= F, j = it - d * F;
+        s_ls[d][j] = plan[L.lstart[d] + j]; s_lb[d][j] = (u16)plan[L.lbase[d] + j]; s_glb[d][j] = 0;
     }
+    for (int it = tid; it < 2 * N; it += PS_T) { const int d = it >= N, r = it - d * N; s_gslot[d][r] = (u16)plan[L.rowrec[d] + 16 * (int64_t)r + 3]; }
     for (int i = tid; i < 2 * (PS_N + DF_MAX_GROUPS + 1); i += PS_T) (&s_lcnt[0][0])[i] = 0;
-    __syncthreads();
+    if (tid < DF_MAX_GROUPS) s_gcnt[tid] = 0;
+    __syncthreads();   // (the zeros must be in memory before the values below go to the same words)
     PS_STAMP(stamp, 1);
     // ---- the LPT assignment (one wave), straight into the workspace
     if (wave == 0) df_assign_wave<PS_B>(s_items, s_dep[0], s_dep[1], s_nptr, ws, S, B, G, c_layer, c_row, s_g, s_d, s_n);
@@ -399,39 +444,49 @@ __global__ void __launch_bounds__(PS_T) schedule_small_kernel(const int32_t* __r
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_nptr[mid] <= p) lo = mid; else hi = mid; }
             s_gof[p] = (u16)lo;
         }
-    __syncthreads();
+    __syncthreads();   // (the assignment is read back from memory)
     PS_STAMP(stamp, 2);
-    for (int i = tid; i < B; i += PS_T) s_grp[i] = ws[S.grp_of + i];
+    for (int i = tid; i < B; i += PS_T) { const int k = ws[S.grp_of + i]; s_grp[i] = k; s_grp16[i] = (u16)k; atomicAdd(&s_gcnt[k], 1); }
     for (int i = tid; i < G; i += PS_T) s_gd[i] = ws[S.gdepth + i];
     for (int i = tid; i <= G; i += PS_T) s_loff[i] = ws[S.loff + i];
-    __syncthreads();
+    ps_barrier();
     PS_STAMP(stamp, 3);
     // ---- rows per (group, layer): position n0 + t of a graph stands for its layer t (a graph has at least as many nodes
-    // as layers)
+    // as layers); group of every (group, layer) pair; graphs in (group, graph) order
     for (int it = tid; it < 2 * N; it += PS_T) {
         const int d = it >= N, p = it - d * N;
         const int g = s_gof[p], n0 = s_nptr[g], t = p - n0, k = s_grp[g];
         if (t < min(s_dep[d][g], s_gd[k])) atomicAdd(&s_lcnt[d][s_loff[k] + t], s_ls[d][n0 + g + t + 1] - s_ls[d][n0 + g + t]);
     }
-    __syncthreads();
+    for (int k = wave; k < G; k += PS_T / 64)
+        for (int t = lane; t <= s_gd[k]; t += 64) s_kof[s_loff[k] + t] = (unsigned char)k;
+    if (wave == 0) {
+        const int own = lane < G ? s_gcnt[lane] : 0;
+        const int x = ps_wave_scan(own);
+        if (lane < G) s_goff[lane] = x - own;
+        if (lane == 63) s_goff[G] = x;
+    }
+    ps_barrier();
+    for (int g = tid; g < B; g += PS_T) s_glist[s_goff[s_grp[g]] + ps_count_equal(s_grp16, 0, g, s_grp16[g])] = (u16)g;
     PS_STAMP(stamp, 4);
     // ---- per (group, direction): exclusive prefix of the block-padded counts; blocks of the group
     for (int i = wave; i < 2 * G; i += PS_T / 64) {
         const int d = i >= G, k = i - d * G;
         const int depth = s_gd[k];
         int32_t* cnt = s_lcnt[d] + s_loff[k];
+        u16* raw = s_cnt[d] + s_loff[k];
         int carry = 0;
         for (int c0 = 0; c0 <= depth; c0 += 64) {
             const int t = c0 + lane;
             const int c = t < depth ? cnt[t] : 0;
             const int padded = (c + DF_RB - 1) / DF_RB * DF_RB;
             const int x = ps_wave_scan(padded);
-            if (t <= depth) cnt[t] = carry + x - padded;
+            if (t <= depth) { cnt[t] = carry + x - padded; raw[t] = (u16)c; }
             carry += ps_wave_total(x);
         }
         if (lane == 0) s_gtab[d][2 * k + 1] = carry / DF_RB;
     }
-    __syncthreads();
+    ps_barrier();
     PS_STAMP(stamp, 5);
     // ---- first record of every group
     if (wave < 2) {
@@ -439,21 +494,15 @@ __global__ void __launch_bounds__(PS_T) schedule_small_kernel(const int32_t* __r
         const int own = lane < G ? s_gtab[d][2 * lane + 1] * DF_RB : 0;
         const int x = ps_wave_scan(own);
         if (lane < G) s_gtab[d][2 * lane] = x - own;
-        if (lane == 63) s_used[d] = x;
     }
-    __syncthreads();
+    ps_barrier();
     PS_STAMP(stamp, 6);
-    // ---- the used records = -1 (padding), and meanwhile glbase: a wave per (direction, group, layer)
-    for (int d = 0; d < 2; ++d) {
-        int4* f = reinterpret_cast<int4*>(ws + S.grec[d]);
-        const int nf = s_used[d] * 4;
-        for (int i = tid; i < nf; i += PS_T) f[i] = make_int4(-1, -1, -1, -1);
-    }
-    {
-        const int total = s_loff[G];
+    // ---- glbase, and the padding records (node = -1) behind the rows of every (group, layer)
+    const int total = s_loff[G];
+    if (B > 16 * G) {   // many graphs per group: a wave per (direction, group, layer), lanes over ALL graphs
         for (int i = wave; i < 2 * total; i += PS_T / 64) {
             const int d = i >= total, pair = i - d * total;
-            const int k = __popcll(__ballot(lane < G && s_loff[min(lane + 1, G)] <= pair));
+            const int k = s_kof[pair];
             const int t = pair - s_loff[k];
             if (t >= s_gd[k]) continue;   // the table has depth + 1 entries per group
             int carry = s_lcnt[d][pair];
@@ -471,40 +520,67 @@ __global__ void __launch_bounds__(PS_T) schedule_small_kernel(const int32_t* __r
                 carry += ps_wave_total(x);
             }
         }
+    } else {            // a thread per (direction, group, layer) walks the group's graphs
+        for (int it = tid; it < 2 * total; it += PS_T) {
+            const int d = it >= total, pair = it - d * total;
+            const int k = s_kof[pair];
+            const int t = pair - s_loff[k];
+            if (t >= s_gd[k]) continue;
+            int run = s_lcnt[d][pair];
+            for (int q = s_goff[k]; q < s_goff[k + 1]; ++q) {
+                const int g = s_glist[q];
+                if (t < s_dep[d][g]) {
+                    const int base = s_nptr[g] + g + t;
+                    s_glb[d][base] = run;
+                    run += s_ls[d][base + 1] - s_ls[d][base];
+                }
+            }
+        }
     }
-    __syncthreads();
+    for (int it = tid; it < 2 * total; it += PS_T) {
+        const int d = it >= total, pair = it - d * total;
+        const int k = s_kof[pair];
+        if (pair - s_loff[k] >= s_gd[k]) continue;
+        const int first = s_gtab[d][2 * k] + s_lcnt[d][pair] + s_cnt[d][pair], end = s_gtab[d][2 * k] + s_lcnt[d][pair + 1];
+        for (int r = first; r < end; ++r) {   // (at most three)
+            int4* f = reinterpret_cast<int4*>(ws + S.grec[d]) + 4 * (int64_t)r;
+            f[0] = make_int4(-1, -1, -1, -1); f[1] = f[0]; f[2] = f[0]; f[3] = f[0];
+        }
+    }
+    ps_barrier();
     PS_STAMP(stamp, 7);
     // ---- tables out
     for (int it = tid; it < 4 * G; it += PS_T) { const int d = it >= 2 * G, j = it - d * 2 * G; ws[S.gtab[d] + j] = s_gtab[d][j]; }
-    {
-        const int total = s_loff[G];
-        for (int it = tid; it < 2 * total; it += PS_T) { const int d = it >= total, j = it - d * total; ws[S.lcnt[d] + j] = s_lcnt[d][j]; }
-    }
+    for (int it = tid; it < 2 * total; it += PS_T) { const int d = it >= total, j = it - d * total; ws[S.lcnt[d] + j] = s_lcnt[d][j]; }
     for (int it = tid; it < 2 * F; it += PS_T) { const int d = it >= F, j = it - d * F; ws[S.glbase[d] + j] = s_glb[d][j]; }
     PS_STAMP(stamp, 8);
-    // ---- every row record to its place in the group order (all loads of a thread's records first: one trip to memory)
+    // ---- every row record to its place in the group order: the record of every rowrec slot (its layer: the last one whose
+    // first slot is not behind it), then four lanes per record copy its 64 bytes
+    for (int it = tid; it < 2 * N; it += PS_T) {
+        const int d = it >= N, r = it - d * N;
+        const int g = s_gslot[d][r], j = s_nptr[g] + g;
+        int lo = 0, hi = s_dep[d][g];
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)s_lb[d][j + mid] <= r) lo = mid; else hi = mid; }
+        s_rec[d][r] = (u16)(s_gtab[d][2 * s_grp[g]] + s_glb[d][j + lo] + (r - (int)s_lb[d][j + lo]));
+    }
+    ps_barrier();
     {
-        constexpr int PER = 2 * PS_N / PS_T;
-        int4 r[PER][4];
+        constexpr int PER = 2 * PS_N * 4 / PS_T / 2;   // two halves of PER loads each
+        for (int half = 0; half < 2; ++half) {
+            int4 v[PER];
 #pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int it = min(tid + q * PS_T, 2 * N - 1);   // (clamped: the loads are unconditional, the stores below are not)
-            const int d = it >= N, p = it - d * N;
-            const int4* src = reinterpret_cast<const int4*>(plan + L.rowrec[d]) + 4 * (int64_t)s_slot[d][p];
-            r[q][0] = src[0]; r[q][1] = src[1]; r[q][2] = src[2]; r[q][3] = src[3];
-        }
+            for (int q = 0; q < PER; ++q) {
+                const int it = min(tid + (half * PER + q) * PS_T, 8 * N - 1);   // (clamped: the loads are unconditional)
+                const int d = it >= 4 * N, j = it - d * 4 * N;
+                v[q] = reinterpret_cast<const int4*>(plan + L.rowrec[d])[j];
+            }
 #pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int it = tid + q * PS_T;
-            if (it < 2 * N) {
-                const int d = it >= N, p = it - d * N;
-                const int g = s_gof[p], n0 = s_nptr[g];
-                const int32_t* ls = s_ls[d] + n0 + g;
-                int lo = 0, hi = s_dep[d][g];                    // largest t with ls[t] <= p
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ls[mid] <= p) lo = mid; else hi = mid; }
-                const int rec = s_gtab[d][2 * s_grp[g]] + s_glb[d][n0 + g + lo] + (p - ls[lo]);
-                int4* dst = reinterpret_cast<int4*>(ws + S.grec[d]) + 4 * (int64_t)rec;
-                dst[0] = r[q][0]; dst[1] = r[q][1]; dst[2] = r[q][2]; dst[3] = r[q][3];
+            for (int q = 0; q < PER; ++q) {
+                const int it = tid + (half * PER + q) * PS_T;
+                if (it < 8 * N) {
+                    const int d = it >= 4 * N, j = it - d * 4 * N;
+                    reinterpret_cast<int4*>(ws + S.grec[d])[4 * (int64_t)s_rec[d][j >> 2] + (j & 3)] = v[q];
+                }
             }
         }
     }

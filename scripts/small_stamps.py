@@ -11,8 +11,8 @@ b1 = synth.dvae_batch([synth.decode_enas_row(r) for r in synth.enas_rows(0, 64)]
 b4 = synth.dvae_batch([synth.decode_bn_row(r) for r in synth.bn_rows(0, 128)])
 PLAN = ["A stage+checks", "ptr", "B layers/hist", "scan ls", "lstart out", "C node order", "D row hist", "scan rp",
         "rowptr out", "E edge order", "F items", "G blptr", "H lbase", "I rowrec"]
-SCHED = ["zero+stage", "assign", "reload", "count", "prefix", "base", "fill+glbase", "tables out", "records", ]
-for name, b, G in (("cfg1", b1, 8), ("cfg4", b4, 10)):
+SCHED = ["zero+stage", "assign", "reload", "count+lists", "prefix", "base", "glbase+padding", "tables out", "records", ]
+for name, b, G in (("cfg1", b1, 42), ("cfg4", b4, 10)):
     B = int(b.batch.max()) + 1
     bl = b.bi_layer_index
     args = [t.to(dev) for t in (b.edge_index, bl[0][0], bl[1][0], b.batch)]

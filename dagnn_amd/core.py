@@ -51,7 +51,7 @@ class DerivedCache(object):
         self._val = None
 
     def get(self, params: Sequence[torch.Tensor], fn: Callable[[], object], fresh: bool = False):
-        key = None if fresh else tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        key = None if fresh else tuple([(p.data_ptr(), p._version, p.device.index) for p in params])
         if fresh or key != self._key:
             with torch.no_grad():
                 self._val = fn()

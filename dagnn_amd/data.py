@@ -65,6 +65,11 @@ class GraphData(object):
         return self
 
     def to(self, device, *args, **kwargs):
+        if not args and not kwargs and isinstance(device, torch.device):   # already there: nothing to convert (a
+            x = self.__dict__.get("x")                                     # forward pass calls this on every batch)
+            if isinstance(x, torch.Tensor) and x.device == device and all(
+                    v.device == device for v in self.__dict__.values() if isinstance(v, torch.Tensor)):
+                return self
         return self._apply(lambda t: t.to(device, *args, **kwargs))
 
     def contiguous(self):

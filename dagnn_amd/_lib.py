@@ -82,6 +82,16 @@ class DataflowArgs(C.Structure):
                 ("plan_status", C.c_void_p)]
 
 
+class TilesCell(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("w_hh", "w_ih", "b_hh", "b_ih", "w_key", "edge_gain", "gi0", "h_out")]
+
+
+class TilesArgs(C.Structure):
+    _fields_ = [("cell", (TilesCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
+                ("H", C.c_int), ("ld_h", C.c_int), ("num_cus", C.c_int), ("epoch", C.c_uint), ("counters", C.c_void_p),
+                ("err", C.c_void_p), ("spin_limit", C.c_uint), ("plan_status", C.c_void_p), ("debug_timing", C.c_void_p)]
+
+
 class BackwardCell(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("w_hh", "w_ih", "w_key", "edge_gain", "vid_bias", "static_score", "h", "a", "alpha", "gi", "gh", "g_ext",
                                           "da", "dgi", "dgh", "sigma", "edge_feat_grad", "da_granules", "du_granules",
@@ -193,6 +203,8 @@ SYMBOLS = {
     "dagnn_dataflow_schedule": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p, C.c_void_p]),
     "dagnn_dataflow_run": (C.c_int, [C.POINTER(Plan), C.POINTER(DataflowArgs), C.c_void_p]),
+    "dagnn_tiles_launches": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dagnn_tiles_run": (C.c_int, [C.POINTER(Plan), C.POINTER(TilesArgs), C.c_void_p]),
     "dagnn_pack_dataflow": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_pack_dataflow_transposed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_score_parts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -100,6 +100,8 @@ def pack_lockstep(cells, force: bool = False) -> None:
     if cells and engine.DATAFLOW and cells[0].Hp <= 256 and not force:
         pack_dataflow(cells)
         return
+    if cells and engine.TILES and cells[0].Hp == 512 and not force:
+        return   # the tile kernel (csrc/tiles.hip) reads the torch layouts; the fallback packs with `force` if it is taken
     cells = [c for c in cells if c.w_hh_pk is None]
     todo = []
     for c in cells:
@@ -204,9 +206,15 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
         groups = 0
     if arena is not None:
         arena.poll()   # a failure an earlier pass reported (no synchronisation); either path below is watched
-    if groups == 0 and arena is not None and N > 0 and engine.DATAFLOW:
+    tiles = 0
+    if groups == 0 and arena is not None and N > 0 and static_score is None and not vid_nodes and \
+            N * ld * 4 < (1 << 31) - 16 and all(cells[(d, 0)].w_key is not None for d in dirs):
+        tiles = engine.tiles_launches(dev, len(dirs), L, Hp, plan.R, N)   # wide states (H = 512): csrc/tiles.hip
+    if groups == 0 and tiles == 0 and arena is not None and N > 0 and engine.DATAFLOW:
         _warn_off_dataflow(dev, len(dirs), L, Hp)
-    if groups > 0:
+    if tiles > 0:
+        engine.tiles_run(plan, dirs, L, Hp, cells, gi, h, arena)
+    elif groups > 0:
         pack_dataflow(cells.values())
         preact = {} if (keep is not None and engine.BWD_DATAFLOW) else None
         engine.dataflow_run(plan, dirs, L, Hp, cells, gi, h, groups, vid_mod=vid_nodes, arena=arena,

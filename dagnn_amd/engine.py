@@ -13,7 +13,8 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import BackwardArgs, BwdDataflowArgs, DagnnHipError, DataflowArgs, FrontierArgs, GemmGroup, LayerArgs, Plan, check
+from ._lib import (BackwardArgs, BwdDataflowArgs, DagnnHipError, DataflowArgs, FrontierArgs, GemmGroup, LayerArgs, Plan,
+                   TilesArgs, check)
 
 
 class KernelTimer(object):
@@ -89,6 +90,10 @@ DF_COST_LAYER = _env_int("DAGNN_AMD_DF_COST_LAYER", 6)      # schedule cost of o
 DF_COST_ROW = _env_int("DAGNN_AMD_DF_COST_ROW", 1)
 DF_GROUPS = _env_int("DAGNN_AMD_DF_GROUPS", 0)              # 0 = as many groups as the device hosts
 DF_XCD = _env_int("DAGNN_AMD_DF_XCD", 1)                    # 1: XCD-aware workgroup ids + hand-offs through the shared L2 where the run-time check allows
+TILES = _env_int("DAGNN_AMD_TILES", 1)                      # 1: the weight-stationary tile kernel (H = 512: csrc/tiles.hip) where it is the faster path
+                                                            # (>= 3 stacked layers, batches up to TILES_MAX_NODES nodes); 2: wherever it is supported; 0: never
+TILES_MAX_NODES = _env_int("DAGNN_AMD_TILES_MAX_NODES", 20000)  # measured on MI355X at L = 5 (scripts/tiles_sweep.py): 0.69-0.78x the per-layer launches' time up
+                                                            # to 8 k nodes, 0.89x at 15 k, 1.04-1.10x at 30 k (cfg 5): the launches keep the largest batches
 BWD_DATAFLOW = _env_int("DAGNN_AMD_BWD_DATAFLOW", 1)        # 1: the reverse sweep as one persistent dataflow launch (H <= 256)
 DEBUG_WG = _env_int("DAGNN_AMD_DEBUG_WG", 0)                # workgroup whose blocks scripts/df_stamps.py stamps
 SPIN_LIMIT = _env_int("DAGNN_AMD_SPIN_LIMIT", 0)            # polls before a device-side wait gives up; 0 = library default
@@ -437,6 +442,49 @@ def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
             for i in range(L):
                 check(lib.dagnn_score_parts(h[d][i].data_ptr(), h[d][i].shape[1], H, cells[(d, i)].w_key.data_ptr(),
                                             plan.N, _stream(plan.ws)), "dagnn_score_parts")
+    arena.watch(plan, folded=True)
+
+
+def tiles_launches(device, num_dirs: int, num_stacked: int, H: int, num_edge_feats: int, num_nodes: int = 0) -> int:
+    """Launches the weight-stationary tile kernel makes for this model shape on this device; 0 = not applicable, or (with
+    the default `DAGNN_AMD_TILES=1`) not the faster path for this depth / batch size."""
+    if not TILES:
+        return 0
+    if TILES == 1 and (num_stacked < 3 or num_nodes > TILES_MAX_NODES):
+        return 0
+    return _lib.load().dagnn_tiles_launches(_num_cus(device), int(num_dirs), int(num_stacked), int(H), int(num_edge_feats))
+
+
+def tiles_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0, h, arena: "GranuleArena") -> None:
+    """The whole recurrence at H = 512 as one persistent launch per chunk of stacked layers (csrc/tiles.hip): the
+    weights stay in registers, the rows pass in tiles of 16.  Same operands as `frontier_run` (raw torch-layout
+    matrices: nothing is packed); writes the states and the partial attention scores behind them; no device->host
+    read."""
+    if arena is None:
+        raise DagnnHipError("the tile kernel needs a GranuleArena (persistent, zero-initialised progress counters)")
+    args = TilesArgs()
+    bufs, epoch, err = arena.get(["tiles"], 4096, 1, plan.ws.device)
+    mask = 0
+    for d in dirs:
+        mask |= 1 << d
+        for i in range(L):
+            c, fc = cells[(d, i)], args.cell[d][i]
+            fc.w_hh = c.w_hh_raw.data_ptr()
+            fc.b_hh = c.b_hh.data_ptr()
+            if i > 0:
+                fc.w_ih, fc.b_ih = c.w_ih.data_ptr(), c.b_ih.data_ptr()
+            fc.w_key = c.w_key.data_ptr()
+            fc.edge_gain = _ptr(c.edge_gain) if plan.R > 0 else None
+            fc.gi0 = gi0[d].data_ptr() if i == 0 else None
+            fc.h_out = h[d][i].data_ptr()
+    args.num_stacked, args.dir_mask, args.H, args.ld_h = L, mask, H, h[dirs[0]][0].shape[1]
+    args.num_cus = _num_cus(plan.ws.device)
+    args.epoch, args.counters, args.err = epoch, bufs["tiles"].data_ptr(), err.data_ptr()
+    args.spin_limit = SPIN_LIMIT
+    args.plan_status = plan.status.data_ptr()
+    args.debug_timing = DEBUG_TIMING.data_ptr() if DEBUG_TIMING is not None else None
+    with _span("tiles_run", plan.ws):
+        check(_lib.load().dagnn_tiles_run(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_tiles_run")
     arena.watch(plan, folded=True)
 
 

@@ -339,6 +339,51 @@ int dagnn_score_parts(float* h /* [N,ld_h] */, int ld_h, int H, const float* w_k
 int dagnn_dataflow_layout(int64_t N, int64_t B, int groups, int64_t* offsets13 /* host */);
 
 /* ------------------------------------------------------------------------------------------
+ * Weight-stationary tile schedule of the same recurrence for WIDE hidden states (H = 512; dagnn_amd/csrc/tiles.hip): the
+ * path of BASELINE.json's cfg 5 (batch 256, hidden 512, 5 stacked layers, bidirectional), where the GRU matrices (56.6 MB)
+ * are too large to be streamed once per topological layer (dagnn_frontier_run) and the rows too many for the 4-row blocks
+ * of dagnn_dataflow_run.  One persistent launch per CHUNK of stacked layers (chunk 0 = stacked layer 0, then as many
+ * layers at a time as the device hosts at 32 workgroups per cell): every workgroup keeps its 16-unit slice of one cell's
+ * W_ih | W_hh (torch layouts, read once) in registers and walks the plan's batch-level layers in tiles of 16 rows
+ * (v_mfma_f32_16x16x4_f32); rows are handed between workgroups by write-through stores + {epoch, tiles done} progress
+ * counters.  Replaces the loop nest of dagnn.py:144-182 like the two schedules above; needs no device->host read.
+ *   h_out [N, ld_h], ld_h >= H + H/16: states + the H/16 partial attention scores behind them (as dagnn_frontier_run);
+ *   counters: uint64 [2 * DAGNN_MAX_STACKED * 8 * 32], zero-initialised once, only ever used with strictly increasing
+ *             `epoch`s (the granule contract); err: device int32, zeroed by the caller - bit 0 / 1 a bounded wait expired,
+ *             bit 2 (+ bits 8-15) the plan's status word was set and nothing was computed.
+ * dagnn_tiles_launches: number of launches dagnn_tiles_run makes for this shape, 0 = shape not supported (H != 512, more
+ * than 2 edge features, fewer than 32 * num_dirs CUs): use dagnn_frontier_run.  Vertex-id key biases and static scores
+ * (the `*_x` aggregators) are not supported either.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dagnn_tiles_cell {
+    const float* w_hh;      /* [3H,H] torch layout */
+    const float* w_ih;      /* [3H,H] torch layout (stacked layers > 0), else NULL */
+    const float* b_hh;      /* [3H] */
+    const float* b_ih;      /* [3H] (stacked layers > 0; layer 0 has it folded into gi0) */
+    const float* w_key;     /* [H] key half of attn_lin.weight */
+    const float* edge_gain; /* [num_edge_feats] or NULL */
+    const float* gi0;       /* [N,3H] W_ih x + b_ih (stacked layer 0 only), from dagnn_gemm_nt_bias */
+    float* h_out;           /* [N,ld_h] */
+} dagnn_tiles_cell;
+
+typedef struct dagnn_tiles_args {
+    dagnn_tiles_cell cell[DAGNN_MAX_DIRS][DAGNN_MAX_STACKED];
+    int num_stacked, dir_mask;
+    int H, ld_h;
+    int num_cus;             /* compute units of the device: every workgroup of a launch must be resident */
+    unsigned epoch;
+    void* counters;
+    void* err;
+    unsigned spin_limit;     /* polls before a wait gives up and raises `err`; 0 = default (1 << 22) */
+    const void* plan_status; /* NULL, or the device status word of dagnn_plan_build */
+    void* debug_timing;      /* NULL, or uint64 [launches][1024][32] device words: per-workgroup phase sums in 100 MHz ticks,
+                              * written by a -DT_STAMPS build only (scripts/tiles_stamps.py) */
+} dagnn_tiles_args;
+
+int dagnn_tiles_launches(int num_cus, int num_dirs, int num_stacked, int H, int num_edge_feats);
+int dagnn_tiles_run(const dagnn_plan* plan /* host */, const dagnn_tiles_args* args /* host */, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Read-out over output nodes (dagnn.py:119-126,184-193 with out_pool='max', out_pool_all=0):
  *   out[g, col_off[d] + j] = max over { v in graph g : layer_{1-d}(v) == 0 } of h[d][v, j]
  * d = 0 pools the sinks, d = 1 the sources.  h[d] is [N,ld_h]; `width` columns are pooled

@@ -440,8 +440,9 @@ def test_xcd_placement_changes_speed_not_results(device, monkeypatch):
                 assert torch.equal(res[0][3][k], res[1][3][k]), k
 
 
-def _degenerate_batch():
-    """Single-node graphs, a chain, stars with a 200-way fan-in / fan-out, a graph with no edges, a duplicate edge."""
+def _degenerate_batch(extra=()):
+    """Single-node graphs, a chain, stars with a 200-way fan-in / fan-out, a graph with no edges, a duplicate edge
+    (`extra`: more graphs behind them)."""
     from dagnn_amd import GraphData
     from dagnn_amd.dag_utils import add_order_info_01
 
@@ -456,7 +457,7 @@ def _degenerate_batch():
     graphs = [g(1, []), g(5, []), g(40, [(i, i + 1) for i in range(39)]),
               g(201, [(i, 200) for i in range(200)], [[i % 2, 0] for i in range(200)]),
               g(201, [(0, i) for i in range(1, 201)]), g(2, [(0, 1), (0, 1)])]
-    return synth.GraphBatch.from_data_list(graphs)
+    return synth.GraphBatch.from_data_list(graphs + list(extra))
 
 
 def test_edge_cases(device, schedule):
@@ -1274,3 +1275,114 @@ def test_large_batch_properties(device):
         parts = [torch.stack(model(synth.GraphBatch.from_data_list(graphs[q:q + 256]).to(device)))
                  for q in range(0, 1024, 256)]
     assert Hh.maxdiff(torch.cat(parts, dim=1), a) < 2e-5
+
+
+# ----------------------------------------------------------------------------- weight-stationary tile kernel (H = 512, csrc/tiles.hip)
+def _both_paths(model, make_G, monkeypatch):
+    """Logits and state rows of `model` on the tile kernel (forced) and on the per-layer launches."""
+    res, ran = {}, []
+    orig = engine.tiles_run
+    monkeypatch.setattr(engine, "tiles_run", lambda *a, **k: (ran.append(1), orig(*a, **k))[1])
+    for mode in (2, 0):
+        monkeypatch.setattr(engine, "TILES", mode)
+        for c in model._derived.values():
+            c.invalidate()
+        G = make_G()
+        with torch.no_grad():
+            out = model(G)
+        model.check()
+        hs = [h.clone() for d in G.h for h in (d if isinstance(d, (list, tuple)) else [d]) if h is not None] \
+            if isinstance(G.h, (list, tuple)) else [G.h.clone()]
+        res[mode] = ([o.clone() for o in (out if isinstance(out, list) else [out])], hs)
+    assert ran, "the tile kernel did not run"
+    return res
+
+
+def test_tile_kernel_matches_reference_golden_and_launches(device, monkeypatch):
+    """`code2_h512_L5` (the reference's own logits) through dagnn_tiles_run; its state rows against the per-layer launches;
+    bitwise run to run."""
+    meta, arr = Hh.load("code2_h512_L5")
+    model = Hh.code2_model(meta).to(device)
+    res = _both_paths(model, lambda: Hh.code2_batch(arr, device), monkeypatch)
+    for mode in (2, 0):
+        assert max(Hh.maxdiff(o, r) for o, r in zip(res[mode][0], arr["pred"])) < TOL
+    assert max(Hh.maxdiff(a, b) for a, b in zip(res[2][1], res[0][1])) < 5e-6
+    monkeypatch.setattr(engine, "TILES", 2)
+    with torch.no_grad():
+        again = model(Hh.code2_batch(arr, device))
+    assert all(torch.equal(a, b) for a, b in zip(again, res[2][0]))
+
+
+@pytest.mark.parametrize("kw", [dict(L=5), dict(L=3), dict(L=1), dict(L=4, bidirectional=False), dict(L=3, w_edge_attr=False)])
+def test_tile_kernel_shapes_and_edge_cases(device, monkeypatch, kw):
+    """Chunking (stacked layer 0 alone, the layers above together; one direction: two replicas per cell there), no edge
+    features, and the degenerate graphs: single nodes, no edges, a chain, 200-way fan-in / fan-out (rows with more than two
+    predecessors take further trips through the plan's CSR), duplicate edges - against the oracle and the launches."""
+    from dagnn_amd import DAGNN, ASTNodeEncoder
+    L = kw["L"]
+    enc = ASTNodeEncoder(512, 98, 10030, 20)
+    args = dict(w_edge_attr=kw.get("w_edge_attr", True), num_layers=L, bidirectional=kw.get("bidirectional", True), agg="attn_h",
+                out_wx=False, out_pool_all=False, out_pool="max", dropout=0.0)
+    model = DAGNN(num_vocab=16, max_seq_len=2, emb_dim=512, hidden_dim=512, out_dim=None, encoder=enc, **args).eval()
+    seeded_fill(model, 4242 + L)
+    b = _degenerate_batch(synth.code2_graphs(12, 10, 40))
+    ref = O.code2_forward(model.state_dict(), copy.deepcopy(b), num_layers=L, bidirectional=args["bidirectional"], out_wx=False,
+                          out_pool_all=False, out_pool="max", max_seq_len=2)
+    model = model.to(device)
+    res = _both_paths(model, lambda: copy.deepcopy(b).to(device), monkeypatch)
+    assert max(Hh.maxdiff(o, r) for o, r in zip(res[2][0], ref)) < TOL
+    assert max(Hh.maxdiff(a, c) for a, c in zip(res[2][0], res[0][0])) < 2e-5
+    assert max(Hh.maxdiff(a, c) for a, c in zip(res[2][1], res[0][1])) < 5e-6
+
+
+def test_tile_kernel_full_size_properties(device, monkeypatch):
+    """cfg 5 at BASELINE.json's full size (B=256, h=512, L=5, bidirectional) on the tile kernel: bitwise run to run, graph
+    order permutes the rows and nothing else (a row's value does not depend on which tile carries it: BITWISE), the
+    per-layer launches agree to rounding, and the policy (`DAGNN_AMD_TILES=1`) picks the kernel by batch size."""
+    monkeypatch.setattr(engine, "TILES", 2)
+    model = _headline_model(H=512, L=5, V=32, seed=5).to(device)
+    graphs = synth.code2_graphs(3, 256)
+    full = synth.GraphBatch.from_data_list(graphs)
+    with torch.no_grad():
+        a = torch.stack(model(full.clone().to(device)))
+        b = torch.stack(model(full.clone().to(device)))
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+        rev = torch.stack(model(synth.GraphBatch.from_data_list(graphs[::-1]).to(device)))
+        assert torch.equal(rev.flip(1), a)
+        order = sorted(range(256), key=lambda g: -graphs[g].x.shape[0])[:64]
+        sub = torch.stack(model(synth.GraphBatch.from_data_list([graphs[g] for g in order]).to(device)))
+        assert torch.equal(sub, a[:, order])
+        model.check()
+        monkeypatch.setattr(engine, "TILES", 0)
+        for c in model._derived.values():
+            c.invalidate()
+        c0 = torch.stack(model(full.clone().to(device)))
+        assert Hh.maxdiff(c0, a) < 2e-5
+    N = full.x.shape[0]
+    monkeypatch.setattr(engine, "TILES", 1)
+    assert engine.tiles_launches(device, 2, 5, 512, 2, N) == 0 and engine.tiles_launches(device, 2, 5, 512, 2, 8000) == 2
+    assert engine.tiles_launches(device, 2, 2, 512, 2, 8000) == 0 and engine.tiles_launches(device, 2, 5, 256, 2, 8000) == 0
+
+
+def test_tile_kernel_failures_surface(device, monkeypatch):
+    """A bounded wait that expires (spin limit 1) and a batch that violates the plan contract both reach `model.check()`;
+    the next healthy pass is clean."""
+    monkeypatch.setattr(engine, "TILES", 2)
+    model = _headline_model(H=512, L=3, V=8, seed=2).to(device).eval()
+    b = synth.code2_batch(4, 12, 60)
+    with torch.no_grad():
+        ref = model(b.clone().to(device))
+        model.check()
+        monkeypatch.setattr(engine, "SPIN_LIMIT", 1)
+        model(b.clone().to(device))
+        monkeypatch.setattr(engine, "SPIN_LIMIT", 0)
+        with pytest.raises(DagnnHipError, match="bounded device-side wait"):
+            model.check()
+        bad = b.clone().to(device)
+        bad.batch = bad.batch.flip(0).contiguous()
+        model(bad)
+        with pytest.raises(DagnnHipError, match="plan contract"):
+            model.check()
+        out = model(b.clone().to(device))
+        model.check()
+        assert all(torch.equal(x, y) for x, y in zip(out, ref))

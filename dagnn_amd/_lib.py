@@ -89,7 +89,8 @@ class TilesCell(C.Structure):
 class TilesArgs(C.Structure):
     _fields_ = [("cell", (TilesCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
                 ("H", C.c_int), ("ld_h", C.c_int), ("num_cus", C.c_int), ("epoch", C.c_uint), ("counters", C.c_void_p),
-                ("err", C.c_void_p), ("spin_limit", C.c_uint), ("plan_status", C.c_void_p), ("debug_timing", C.c_void_p)]
+                ("err", C.c_void_p), ("spin_limit", C.c_uint), ("plan_status", C.c_void_p), ("first_layer", C.c_int * MAX_DIRS),
+                ("debug_timing", C.c_void_p)]
 
 
 class BackwardCell(C.Structure):

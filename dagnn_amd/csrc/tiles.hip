@@ -79,6 +79,7 @@ struct TCell {
 struct TArgs {
     TCell cell[TMAXCELL];
     int ncell, R, ld_h, nfeat;
+    int first_layer[2];       // per direction: the walk starts at this batch-level layer (the layers before it are complete)
     unsigned epoch, spin_limit;
     gran_t* prog;             // [TMAXCID][TMAXREP][TNS] {epoch, P}: every tile k < P of this (cell, replica, slice) is published
     int* err;
@@ -120,20 +121,34 @@ static_assert(TShape<true>::lds_bytes <= 160 * 1024 && TShape<false>::lds_bytes 
 
 struct Tile { int k, t, tb, te, slot0, nr, valid; };   // te: first tile index of the next layer
 
-// walks the batch-level layers of one direction; at(k) must be called with non-decreasing k
+// Walks the batch-level layers of one direction.  Tile k of layer t (first tile tb) belongs to replica (k - tb) % R: the
+// FIRST tile of every layer - in the thin tail the only one - is replica 0's, so the dependent chain of the thin layers
+// stays inside one replica's 32 workgroups (one XCD) instead of hopping across replicas with every layer (measured on the
+// stacked-layer-0 launch, 4 replicas: 20 us per layer with tiles dealt k % R).
 struct TileWalk {
     const int32_t* bl;
-    int T, t, tb, r0, r1;
-    __device__ __forceinline__ void init(const int32_t* bl_, int T_) {
-        bl = bl_; T = T_; t = 0; tb = 0; r0 = bl[0]; r1 = T > 0 ? bl[1] : r0;
+    int T, R, rep, t, tb, r0, r1;
+    __device__ __forceinline__ int ntl() const { return (r1 - r0 + TR - 1) / TR; }
+    __device__ __forceinline__ void init(const int32_t* bl_, int T_, int R_, int rep_, int t0) {   // t0: first layer to walk (tile 0)
+        bl = bl_; T = T_; R = R_; rep = rep_; t = t0 < T_ ? t0 : T_; tb = 0; r0 = bl[t]; r1 = t < T ? bl[t + 1] : r0;
     }
-    __device__ __forceinline__ Tile at(int k) {
-        while (t < T && k >= tb + (r1 - r0 + TR - 1) / TR) {
-            tb += (r1 - r0 + TR - 1) / TR; ++t; r0 = r1; r1 = t < T ? bl[t + 1] : r1;
-        }
+    __device__ __forceinline__ void advance() { tb += ntl(); ++t; r0 = r1; r1 = t < T ? bl[t + 1] : r1; }
+    __device__ __forceinline__ Tile make(int k) const {
         Tile x;
-        x.valid = t < T ? 1 : 0; x.k = k; x.t = t; x.tb = tb; x.te = tb + (r1 - r0 + TR - 1) / TR; x.slot0 = r0 + (k - tb) * TR; x.nr = min(TR, r1 - x.slot0);
+        x.valid = t < T ? 1 : 0; x.k = k; x.t = t; x.tb = tb; x.te = tb + ntl(); x.slot0 = r0 + (k - tb) * TR; x.nr = min(TR, r1 - x.slot0);
         return x;
+    }
+    // this replica's first tile
+    __device__ __forceinline__ Tile first() {
+        while (t < T && ntl() <= rep) advance();
+        return make(tb + rep);
+    }
+    // this replica's next tile after its tile k (k must be the tile returned last)
+    __device__ __forceinline__ Tile next(int k) {
+        if (t < T && k + R < tb + ntl()) return make(k + R);
+        if (t < T) advance();
+        while (t < T && ntl() <= rep) advance();
+        return make(tb + rep);
     }
 };
 
@@ -199,23 +214,6 @@ struct TWait {
     }
 };
 
-// every counter this tile waits for, by the 64 lanes of one wave
-__device__ __forceinline__ bool t_deps_ok(const gran_t* own, const gran_t* low, const Tile& x, int R, unsigned epoch, int lane) {
-    bool ok = true;
-    for (int e = lane; e < R * TNS; e += 64) {
-        const int r = e / TNS;
-        if (r < x.tb) {   // replica r owns a tile before this layer: all of them must be out
-            const gran_t g = gran_ld(own + e);
-            ok = ok && (unsigned)(g >> 32) == epoch && (unsigned)g >= (unsigned)x.tb;
-        }
-    }
-    if (low != nullptr && lane < TNS) {   // the same tile of the stacked layer below
-        const gran_t g = gran_ld(low + (x.k % R) * TNS + lane);
-        ok = ok && (unsigned)(g >> 32) == epoch && (unsigned)g >= (unsigned)(x.k + 1);
-    }
-    return __all(ok);
-}
-
 template <bool HAS_IN>
 __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, const PlanLayout& L, const TArgs& S, const TCell& C,
                                           const int slice, const int rep, float* smem) {
@@ -237,8 +235,8 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
     const int Nn = plan[PH_N];
     const int T = bl[(int64_t)Nn + 1];
     TileWalk W;
-    W.init(bl, T);
-    Tile cur = W.at(rep);
+    W.init(bl, T, S.R, rep, S.first_layer[d]);
+    Tile cur = W.first();
     if (threadIdx.x < 8) flags[threadIdx.x] = 0u;
     if (threadIdx.x < SH::CST) {   // gate constants of the slice: (b_ir + b_hr, b_iz + b_hz, b_in, b_hn, w_key)
         const int k = threadIdx.x >> 4, j = slice * TU + (threadIdx.x & 15);
@@ -252,7 +250,7 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
     }
     __syncthreads();
     if (!cur.valid) return;
-    Tile nxt = W.at(cur.k + R);
+    Tile nxt = W.next(cur.k);
 
     // Roles by SIMD (wave w runs on SIMD w % 4): an fp32 MFMA runs at the VECTOR rate - it keeps the SIMD's vector ALU busy, and a
     // loader wave sharing a SIMD with two waves of back-to-back MFMAs gets no issue slot until they are done (measured:
@@ -321,7 +319,7 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
             }
 #endif
             if (!nxt.valid) break;
-            cur = nxt; nxt = W.at(cur.k + R); ++it;
+            cur = nxt; nxt = W.next(cur.k); ++it;
         }
 #ifdef T_STAMPS
         if (S.dbg && (wave == 0 || wave == 4) && lane == 0) {
@@ -345,6 +343,22 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
     const int nfeat = C.gain ? S.nfeat : 0;
     const float gain0 = nfeat >= 1 ? C.gain[0] : 0.f, gain1 = nfeat >= 2 ? C.gain[1] : 0.f;
     unsigned own_ok_tb = 0u, low_min = 0u;   // the polling wave's memory of what it has seen (progress only grows)
+    // first tile of every replica of a cell (0x7fffffff: it has none): replica r only owes a counter to layers behind it
+    int f0 = 0x7fffffff, f1 = 0x7fffffff, f2 = 0x7fffffff, f3 = 0x7fffffff;
+    {
+        TileWalk V;
+        V.init(bl, T, R, 0, S.first_layer[d]);
+        int found = 0;
+        while (V.t < T && found < R) {
+            const int n = V.ntl();
+            if (found < 1 && n > 0) f0 = V.tb;
+            if (found < 2 && n > 1) f1 = V.tb + 1;
+            if (found < 3 && n > 2) f2 = V.tb + 2;
+            if (found < 4 && n > 3) f3 = V.tb + 3;
+            found = max(found, min(n, 4));
+            V.advance();
+        }
+    }
 #ifdef T_STAMPS
     unsigned long long n_block = 0;
 #endif
@@ -371,7 +385,7 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
                 for (;;) {
                     unsigned val = 0xffffffffu;
                     if (lane < TNS) {
-                        const gran_t g = gran_ld(low + (x.k % R) * TNS + lane);
+                        const gran_t g = gran_ld(low + ((x.k - x.tb) % R) * TNS + lane);
                         val = (unsigned)(g >> 32) == S.epoch ? (unsigned)g : 0u;
                     }
                     const unsigned mn = df_wave_umin(val);
@@ -393,16 +407,57 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
                 unsigned spins = 0;
                 for (;;) {
                     unsigned val = 0xffffffffu;
-                    for (int e = lane; e < R * TNS; e += 64)
-                        if (e / TNS < x.tb) {   // replica e / TNS owns a tile before this layer
+                    for (int e = lane; e < R * TNS; e += 64) {
+                        const int r = e / TNS;
+                        if ((r == 0 ? f0 : r == 1 ? f1 : r == 2 ? f2 : f3) < x.tb) {   // replica r owns a tile before this layer
                             const gran_t g = gran_ld(own + e);
                             val = min(val, (unsigned)(g >> 32) == S.epoch ? (unsigned)g : 0u);
                         }
+                    }
                     if (df_wave_umin(val) >= (unsigned)x.tb) { own_ok_tb = (unsigned)x.tb; break; }
                     if (!wt.again(spins, 1)) break;
                 }
             }
             if (lane == 0) lds_st(&flags[2], seq);
+        } else {
+            unsigned spins = 0;
+            while (lds_ld(&flags[2]) < seq) if (!wt.again(spins, 2)) break;
+        }
+        asm volatile("" ::: "memory");
+    };
+
+    // both waits in ONE polling loop (the first tile of a layer: the two sets of counters arrive at about the same time, and
+    // one after the other they cost a round trip each)
+    auto wait_both = [&](const Tile& x, unsigned seq) {
+        if (lw == TNLW - 1) {
+            const bool need_low = low != nullptr && !(R == 1 && low_min >= (unsigned)(x.k + 1));
+            const bool need_own = (unsigned)x.tb > own_ok_tb;
+            if (need_low || need_own) {
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned vl = 0xffffffffu, vo = 0xffffffffu;
+                    if (need_low && lane < TNS) {
+                        const gran_t g = gran_ld(low + ((x.k - x.tb) % R) * TNS + lane);
+                        vl = (unsigned)(g >> 32) == S.epoch ? (unsigned)g : 0u;
+                    }
+                    if (need_own)
+                        for (int e = lane; e < R * TNS; e += 64) {
+                            const int r = e / TNS;
+                            if ((r == 0 ? f0 : r == 1 ? f1 : r == 2 ? f2 : f3) < x.tb) {
+                                const gran_t g = gran_ld(own + e);
+                                vo = min(vo, (unsigned)(g >> 32) == S.epoch ? (unsigned)g : 0u);
+                            }
+                        }
+                    const unsigned ml = df_wave_umin(vl), mo = df_wave_umin(vo);
+                    if (ml >= (unsigned)(x.k + 1) && mo >= (unsigned)x.tb) {
+                        if (need_low) low_min = ml;
+                        if (need_own) own_ok_tb = (unsigned)x.tb;
+                        break;
+                    }
+                    if (!wt.again(spins, 1)) break;
+                }
+            }
+            if (lane == 0) { lds_st(&flags[0], seq); lds_st(&flags[2], seq); }
         } else {
             unsigned spins = 0;
             while (lds_ld(&flags[2]) < seq) if (!wt.again(spins, 2)) break;
@@ -615,10 +670,10 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
             if (q == 0) __hip_atomic_store(C.h_out + (int64_t)v * ld_h + TH + slice, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-    auto publish = [&](const int x_k) {
+    auto publish = [&](const int p_next) {   // p_next: this replica's next tile (all its tiles before that one are out)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have landed
         if (lane == 0)
-            __hip_atomic_store(own + rep * TNS + slice, ((gran_t)S.epoch << 32) | (gran_t)(unsigned)(x_k + R), __ATOMIC_RELAXED,
+            __hip_atomic_store(own + rep * TNS + slice, ((gran_t)S.epoch << 32) | (gran_t)(unsigned)p_next, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
     };
 
@@ -636,8 +691,7 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
     __syncthreads();
     {
         Preds P;
-        wait_low(cur, 1u);
-        wait_own(cur, 1u);
+        wait_both(cur, 1u);
         issue_direct(cur, 0);
         issue_preds(cur, 0, P);
         consume(cur, 0, P);
@@ -665,13 +719,13 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
             }
             T_CLK(a1);
             // (off the rows' path: the tile after the next and its row records)
-            if (nxt.valid) nn = W.at(nxt.k + R);
+            if (nxt.valid) nn = W.next(nxt.k);
             if (lw == 1 && nn.valid) dma_records(nn, it + 2);
             if (pend && lw == 0) epilogue(pend_k, pend_nr, it - 1);   // while the rows are on their way
             T_CLK(a2);
             if (pipelined) consume(nxt, it + 1, P);
             if (refresh) low_min = max(low_min, df_wave_umin((unsigned)(fresh_g >> 32) == S.epoch ? (unsigned)fresh_g : 0u));
-            if (pend && lw == 0) publish(pend_k);
+            if (pend && lw == 0) publish(cur.k);
             T_CLK(a3);
             __syncthreads();
             T_CLK(a4);
@@ -690,13 +744,12 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
 #ifdef T_STAMPS
             unsigned long long b2x = b0;
 #endif
-            if (lw == 0) { epilogue(cur.k, cur.nr, it); publish(cur.k); }
+            if (lw == 0) { epilogue(cur.k, cur.nr, it); publish(nxt.valid ? nxt.k : 0x7fffffff); }
             T_CLK(b1);
             if (nxt.valid) {
                 Preds P;
-                wait_low(nxt, (unsigned)(it + 2));
+                wait_both(nxt, (unsigned)(it + 2));
                 T_CLK(w1);
-                wait_own(nxt, (unsigned)(it + 2));
                 T_CLK(w2);
                 issue_direct(nxt, it + 1);
                 issue_preds(nxt, it + 1, P);
@@ -817,6 +870,7 @@ extern "C" int dagnn_tiles_run(const dagnn_plan* pl, const dagnn_tiles_args* a, 
                 K.low = i > first[ch] ? d * DAGNN_MAX_STACKED + i - 1 : -1;
             }
         S.ncell = nc; S.R = reps[ch]; S.ld_h = a->ld_h; S.nfeat = pl->num_edge_feats;
+        for (int d = 0; d < 2; ++d) S.first_layer[d] = a->first_layer[d] > 0 ? a->first_layer[d] : 0;
         S.epoch = a->epoch; S.spin_limit = a->spin_limit ? a->spin_limit : (1u << 22);
         S.prog = (gran_t*)a->counters; S.err = (int*)a->err; S.status = (const int32_t*)a->plan_status;
         S.dbg = a->debug_timing ? (unsigned long long*)a->debug_timing + (size_t)ch * 32 * 1024 : nullptr;

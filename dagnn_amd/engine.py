@@ -92,6 +92,8 @@ DF_GROUPS = _env_int("DAGNN_AMD_DF_GROUPS", 0)              # 0 = as many groups
 DF_XCD = _env_int("DAGNN_AMD_DF_XCD", 1)                    # 1: XCD-aware workgroup ids + hand-offs through the shared L2 where the run-time check allows
 TILES = _env_int("DAGNN_AMD_TILES", 1)                      # 1: the weight-stationary tile kernel (H = 512: csrc/tiles.hip) where it is the faster path
                                                             # (>= 3 stacked layers, batches up to TILES_MAX_NODES nodes); 2: wherever it is supported; 0: never
+TILES_TAIL_ROWS = _env_int("DAGNN_AMD_TILES_TAIL_ROWS", 32)    # larger batches: per-layer launches for the wide first layers, the tile kernel from the
+                                                            # first layer on behind which no layer has more rows than this (0: no such split)
 TILES_MAX_NODES = _env_int("DAGNN_AMD_TILES_MAX_NODES", 20000)  # measured on MI355X at L = 5 (scripts/tiles_sweep.py): 0.69-0.78x the per-layer launches' time up
                                                             # to 8 k nodes, 0.89x at 15 k, 1.04-1.10x at 30 k (cfg 5): the launches keep the largest batches
 BWD_DATAFLOW = _env_int("DAGNN_AMD_BWD_DATAFLOW", 1)        # 1: the reverse sweep as one persistent dataflow launch (H <= 256)
@@ -455,7 +457,25 @@ def tiles_launches(device, num_dirs: int, num_stacked: int, H: int, num_edge_fea
     return _lib.load().dagnn_tiles_launches(_num_cus(device), int(num_dirs), int(num_stacked), int(H), int(num_edge_feats))
 
 
-def tiles_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0, h, arena: "GranuleArena") -> None:
+def tiles_tail_split(plan: PlanHandle, dirs: Sequence[int]):
+    """Where the tile kernel takes over from the per-layer launches on a large batch: per direction the first batch-level
+    layer behind which no layer has more than `TILES_TAIL_ROWS` rows - the long thin tail, where a launch per layer costs
+    30-50 us and a layer of the tile kernel 12.  None: no tail worth a second kernel (or the split is switched off)."""
+    if TILES_TAIL_ROWS <= 0:
+        return None
+    import numpy as np
+    sched = plan.read_schedule()
+    first, tail = [0, 0], 0
+    for d in dirs:
+        rows = np.diff(sched[d].astype(np.int64))
+        wide = np.nonzero(rows > TILES_TAIL_ROWS)[0]
+        first[d] = int(wide[-1]) + 1 if len(wide) else 0
+        tail = max(tail, len(rows) - first[d])
+    return first if tail >= 32 else None
+
+
+def tiles_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0, h, arena: "GranuleArena",
+              first_layer: Optional[Sequence[int]] = None) -> None:
     """The whole recurrence at H = 512 as one persistent launch per chunk of stacked layers (csrc/tiles.hip): the
     weights stay in registers, the rows pass in tiles of 16.  Same operands as `frontier_run` (raw torch-layout
     matrices: nothing is packed); writes the states and the partial attention scores behind them; no device->host
@@ -482,6 +502,9 @@ def tiles_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0,
     args.epoch, args.counters, args.err = epoch, bufs["tiles"].data_ptr(), err.data_ptr()
     args.spin_limit = SPIN_LIMIT
     args.plan_status = plan.status.data_ptr()
+    if first_layer is not None:   # the layers before these are complete already (`frontier_run(stop_layer=...)`)
+        for d in dirs:
+            args.first_layer[d] = int(first_layer[d])
     args.debug_timing = DEBUG_TIMING.data_ptr() if DEBUG_TIMING is not None else None
     with _span("tiles_run", plan.ws):
         check(_lib.load().dagnn_tiles_run(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_tiles_run")
@@ -628,7 +651,7 @@ class GranuleArena(object):
 
 
 def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0, h, vid_mod: int = 0,
-                 arena: Optional[GranuleArena] = None, static_score=None) -> None:
+                 arena: Optional[GranuleArena] = None, static_score=None, stop_layer: Optional[Sequence[int]] = None) -> None:
     """Lock-step recurrence over all batch-level layers.  `cells[(d, i)]` are kernel-ready parameter
     holders (core.CellParams); gi0[d] [N,3H]; h[d][i] [N, frontier_ld(H)] outputs."""
     args = FrontierArgs()
@@ -662,6 +685,8 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     # everything above is independent of the schedule: the one device->host read of the forward pass comes
     # last, so the host-side argument marshalling overlaps the plan / GEMM kernels still in flight
     sched = plan.read_schedule()
+    if stop_layer is not None:   # only the batch-level layers before these (the rest: `tiles_run(first_layer=...)`)
+        sched = [s_[:min(len(s_), int(stop_layer[d]) + 1)] for d, s_ in enumerate(sched)]
     args.mfma_min_rows = MFMA_MIN_ROWS
     if AGG_SPLIT or MFMA_MIN_ROWS > 0:  # fat launches aggregate every row once in a separate gather kernel
         import numpy as np

@@ -376,6 +376,9 @@ typedef struct dagnn_tiles_args {
     void* err;
     unsigned spin_limit;     /* polls before a wait gives up and raises `err`; 0 = default (1 << 22) */
     const void* plan_status; /* NULL, or the device status word of dagnn_plan_build */
+    int first_layer[DAGNN_MAX_DIRS]; /* per direction: walk the batch-level layers from this one on (0 = all).  The layers
+                              * before it must be complete in every h_out (e.g. by dagnn_frontier_run called with num_layers =
+                              * first_layer): the wide first layers on per-layer launches, the long thin tail on this kernel */
     void* debug_timing;      /* NULL, or uint64 [launches][1024][32] device words: per-workgroup phase sums in 100 MHz ticks,
                               * written by a -DT_STAMPS build only (scripts/tiles_stamps.py) */
 } dagnn_tiles_args;

@@ -42,22 +42,22 @@ def main():
         model = _headline_model(H=512, L=a.layers, V=32, seed=5).to(dev)
         b = synth.code2_batch(3, B, mean_n)
         res = {}
-        for mode in (1, 0):
+        for mode in (2, 0):
             engine.TILES = mode
             for c in model._derived.values():
                 c.invalidate()
             res[mode] = states(model, b.clone().to(dev))
-        engine.TILES = 1
+        engine.TILES = 2
         worst = 0.0
         for d in range(2):
             for i in range(a.layers):
-                df = float((res[1][1][d][i] - res[0][1][d][i]).abs().max())
+                df = float((res[2][1][d][i] - res[0][1][d][i]).abs().max())
                 worst = max(worst, df)
                 print("  B=%d cell (%d,%d): max |tiles - launches| = %.3g  (|h| max %.3g)" % (B, d, i, df, float(res[0][1][d][i].abs().max())))
-        print("B=%d: states %.3g, logits %.3g" % (B, worst, max(Hh.maxdiff(x, y) for x, y in zip(res[1][0], res[0][0]))), flush=True)
+        print("B=%d: states %.3g, logits %.3g" % (B, worst, max(Hh.maxdiff(x, y) for x, y in zip(res[2][0], res[0][0]))), flush=True)
         again = states(model, b.clone().to(dev))
-        print("  run-to-run bitwise: %s" % all(torch.equal(x, y) for x, y in zip(again[0], res[1][0])))
-        for mode in (1, 0):
+        print("  run-to-run bitwise: %s" % all(torch.equal(x, y) for x, y in zip(again[0], res[2][0])))
+        for mode in (2, 0):
             engine.TILES = mode
             for c in model._derived.values():
                 c.invalidate()
@@ -71,7 +71,7 @@ def main():
                     model(G.clone())
                 torch.cuda.synchronize()
             print("  B=%d %s: %.3f ms per forward" % (B, "tiles   " if mode else "launches", (time.perf_counter() - t0) / a.steps * 1e3), flush=True)
-        engine.TILES = 1
+        engine.TILES = 2
 
 
 if __name__ == "__main__":

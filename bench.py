@@ -269,14 +269,14 @@ def other_configs(device):
                                                 "frac_of_fp32_peak": round(gf / ms / FP32_MATRIX_PEAK_TFLOPS, 4),
                                                 "roofline": {"bound": "mfma", "achieved": round(gf / ms, 3), "peak": FP32_MATRIX_PEAK_TFLOPS,
                                                              "unit": "TFLOP/s", "frac": round(gf / ms / FP32_MATRIX_PEAK_TFLOPS, 5)},
-                                                "path": "lock-step launches (the dataflow kernels cover h <= 256; the tile kernel "
-                                                        "of csrc/tiles.hip is the default up to DAGNN_AMD_TILES_MAX_NODES nodes)"}
+                                                "path": "per-layer launches for the wide first layers, then the weight-stationary tile kernel "
+                                                        "(csrc/tiles.hip) for the thin tail (the dataflow kernels cover h <= 256)"}
         # the weight-stationary tile kernel (csrc/tiles.hip) on the same batch (forced) and on HALF the batch, where it is
         # the default path - each next to the per-layer launches
         from dagnn_amd import engine as _eng
         def both(batch, n):
             r = {}
-            for name, mode in (("tiles_ms", 2), ("launches_ms", 0)):
+            for name, mode in (("split_ms", 1), ("tiles_ms", 2), ("launches_ms", 0)):
                 old_mode, _eng.TILES = _eng.TILES, mode
                 for c in m5._derived.values():
                     c.invalidate()
@@ -291,8 +291,10 @@ def other_configs(device):
         tk_half = both(half, 5)
         tk_half["nodes"] = int(half.x.shape[0])
         out["cfg5_code2_B256_h512_L5_bidir"]["tile_kernel"] = {
-            "what": "dagnn_tiles_run: weights resident in registers, rows in tiles of 16 (one persistent launch per chunk of "
-                    "stacked layers) against dagnn_frontier_run (a launch per topological layer), forward(G) end to end",
+            "what": "forward(G) end to end on the default path (split_ms: dagnn_frontier_run for the wide first layers + "
+                    "dagnn_tiles_run for the thin tail on batches above default_max_nodes, dagnn_tiles_run alone below), on "
+                    "dagnn_tiles_run alone (tiles_ms: weights resident in registers, rows in tiles of 16, one persistent launch "
+                    "per chunk of stacked layers) and on dagnn_frontier_run alone (launches_ms: a launch per topological layer)",
             "cfg5_batch": tk, "half_batch_B128": tk_half,
             "default_max_nodes": int(_eng.TILES_MAX_NODES)}
         del m5

@@ -91,11 +91,13 @@ DF_COST_ROW = _env_int("DAGNN_AMD_DF_COST_ROW", 1)
 DF_GROUPS = _env_int("DAGNN_AMD_DF_GROUPS", 0)              # 0 = as many groups as the device hosts
 DF_XCD = _env_int("DAGNN_AMD_DF_XCD", 1)                    # 1: XCD-aware workgroup ids + hand-offs through the shared L2 where the run-time check allows
 TILES = _env_int("DAGNN_AMD_TILES", 1)                      # 1: the weight-stationary tile kernel (H = 512: csrc/tiles.hip) where it is the faster path
-                                                            # (>= 3 stacked layers, batches up to TILES_MAX_NODES nodes); 2: wherever it is supported; 0: never
+                                                            # (>= 3 stacked layers: alone up to TILES_MAX_NODES nodes, behind the per-layer launches of the wide first
+                                                            # layers on larger batches); 2: alone wherever it is supported; 0: never
 TILES_TAIL_ROWS = _env_int("DAGNN_AMD_TILES_TAIL_ROWS", 32)    # larger batches: per-layer launches for the wide first layers, the tile kernel from the
                                                             # first layer on behind which no layer has more rows than this (0: no such split)
-TILES_MAX_NODES = _env_int("DAGNN_AMD_TILES_MAX_NODES", 20000)  # measured on MI355X at L = 5 (scripts/tiles_sweep.py): 0.69-0.78x the per-layer launches' time up
-                                                            # to 8 k nodes, 0.89x at 15 k, 1.04-1.10x at 30 k (cfg 5): the launches keep the largest batches
+TILES_MAX_NODES = _env_int("DAGNN_AMD_TILES_MAX_NODES", 10000)  # measured on MI355X at L = 5 (scripts/tiles_sweep.py, tiles_hybrid.py): the kernel alone takes
+                                                            # 0.75-0.82x the per-layer launches' time up to 8 k nodes, 0.95x at 15 k, 1.04-1.10x at 30 k
+                                                            # (cfg 5); split at the thin tail 0.86x at 15 k and 0.88x at 30 k: larger batches are split
 BWD_DATAFLOW = _env_int("DAGNN_AMD_BWD_DATAFLOW", 1)        # 1: the reverse sweep as one persistent dataflow launch (H <= 256)
 DEBUG_WG = _env_int("DAGNN_AMD_DEBUG_WG", 0)                # workgroup whose blocks scripts/df_stamps.py stamps
 SPIN_LIMIT = _env_int("DAGNN_AMD_SPIN_LIMIT", 0)            # polls before a device-side wait gives up; 0 = library default

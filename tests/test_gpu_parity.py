@@ -1358,6 +1358,26 @@ def test_tile_kernel_full_size_properties(device, monkeypatch):
             c.invalidate()
         c0 = torch.stack(model(full.clone().to(device)))
         assert Hh.maxdiff(c0, a) < 2e-5
+        # the default path at this size: per-layer launches for the wide first layers, the tile kernel for the thin tail
+        monkeypatch.setattr(engine, "TILES", 1)
+        for c in model._derived.values():
+            c.invalidate()
+        ran = {"frontier": [], "tiles": []}
+        f_orig, t_orig = engine.frontier_run, engine.tiles_run
+        monkeypatch.setattr(engine, "frontier_run", lambda *a_, **k: (ran["frontier"].append(k.get("stop_layer")), f_orig(*a_, **k))[1])
+        monkeypatch.setattr(engine, "tiles_run", lambda *a_, **k: (ran["tiles"].append(k.get("first_layer")), t_orig(*a_, **k))[1])
+        G1 = full.clone().to(device)
+        s1 = torch.stack(model(G1))
+        s2 = torch.stack(model(full.clone().to(device)))
+        model.check()
+        assert len(ran["frontier"]) == 2 and ran["frontier"][0] is not None and ran["frontier"][0] == ran["tiles"][0]
+        assert min(ran["tiles"][0]) > 0 and torch.equal(s1, s2) and Hh.maxdiff(s1, c0) < 2e-5 and Hh.maxdiff(s1, a) < 2e-5
+        monkeypatch.setattr(engine, "TILES", 0)
+        for c in model._derived.values():
+            c.invalidate()
+        G0 = full.clone().to(device)
+        model(G0)
+        assert max(Hh.maxdiff(x, y) for d in range(2) for x, y in zip(G1.h[d], G0.h[d])) < 5e-6   # every state row
     N = full.x.shape[0]
     monkeypatch.setattr(engine, "TILES", 1)
     assert engine.tiles_launches(device, 2, 5, 512, 2, N) == 0 and engine.tiles_launches(device, 2, 5, 512, 2, 8000) == 2

@@ -409,3 +409,27 @@ def test_ipropagate_to_has_no_cpu_path():
     G = Hh.iprop_graphs(meta, arr, "cpu")
     with pytest.raises(DagnnHipError):
         model._ipropagate_to(G, meta["vs"][0], model.grud)
+
+
+def test_tile_kernel_tail_split_policy(monkeypatch):
+    """Where a large h = 512 batch is handed from the per-layer launches to the tile kernel (engine.tiles_tail_split): per
+    direction the first batch-level layer behind which no layer has more than TILES_TAIL_ROWS rows; no split without a
+    tail of at least 32 layers, or when switched off."""
+    from dagnn_amd import engine
+
+    class Plan(object):
+        def __init__(self, rows):
+            self.rows = rows
+
+        def read_schedule(self):
+            return [np.concatenate([[0], np.cumsum(r)]).astype(np.int32) for r in self.rows]
+
+    fwd = [300, 200, 90, 40, 33] + [5] * 60
+    bwd = [50, 60, 70, 20, 10, 33, 8] + [2] * 40
+    monkeypatch.setattr(engine, "TILES_TAIL_ROWS", 32)
+    assert engine.tiles_tail_split(Plan([fwd, bwd]), [0, 1]) == [5, 6]
+    assert engine.tiles_tail_split(Plan([fwd, bwd]), [0]) == [5, 0]
+    assert engine.tiles_tail_split(Plan([[400] * 10 + [3] * 20, [400] * 10 + [3] * 20]), [0, 1]) is None   # tail of 20 layers
+    assert engine.tiles_tail_split(Plan([[4] * 100, [7] * 90]), [0, 1]) == [0, 0]                          # nothing wide at all
+    monkeypatch.setattr(engine, "TILES_TAIL_ROWS", 0)
+    assert engine.tiles_tail_split(Plan([fwd, bwd]), [0, 1]) is None

@@ -1406,3 +1406,29 @@ def test_tile_kernel_failures_surface(device, monkeypatch):
         out = model(b.clone().to(device))
         model.check()
         assert all(torch.equal(x, y) for x, y in zip(out, ref))
+
+
+def test_tile_kernel_feeds_the_backward_pass(device, monkeypatch):
+    """A training step of an h = 512, L = 3 model with the forward on the tile kernel: the state rows and the partial
+    attention scores it leaves behind are what the reverse sweep (csrc/backward.hip) reads - loss and every parameter
+    gradient against the same step on the per-layer launches and against autograd through the oracle."""
+    model = _headline_model(H=512, L=3, V=12, seed=6)
+    b = synth.code2_batch(8, 10, 40)
+    y = torch.randint(0, 12, (10, 5), generator=torch.Generator().manual_seed(5))
+    sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    loss_ref, grads_ref = O.code2_grads(sd_cpu, copy.deepcopy(b), y, num_layers=3, bidirectional=True, max_seq_len=5)
+    model = model.to(device)
+    res, ran = {}, []
+    orig = engine.tiles_run
+    monkeypatch.setattr(engine, "tiles_run", lambda *a, **k: (ran.append(1), orig(*a, **k))[1])
+    for mode in (2, 0):
+        monkeypatch.setattr(engine, "TILES", mode)
+        loss, grads = _train_step(model, b.clone().to(device), y.to(device))
+        model.check()
+        res[mode] = (float(loss), {k: v.detach().cpu().clone() for k, v in grads.items()})
+    assert len(ran) == 1
+    assert abs(res[2][0] - float(loss_ref)) < 1e-5 and abs(res[2][0] - res[0][0]) < 1e-6
+    for k, g in grads_ref.items():
+        scale = max(float(g.abs().max()), 1e-6)
+        assert float((res[2][1][k] - g).abs().max()) <= 2e-4 * scale + 2e-7, k
+        assert float((res[2][1][k] - res[0][1][k]).abs().max()) <= 2e-5 * scale + 2e-7, k

@@ -846,6 +846,9 @@ extern "C" int dagnn_tiles_run(const dagnn_plan* pl, const dagnn_tiles_args* a, 
     int first[DAGNN_MAX_STACKED + 1], count[DAGNN_MAX_STACKED + 1], reps[DAGNN_MAX_STACKED + 1];
     const int nchunk = tiles_chunks(a->num_cus, ndir, Ls, first, count, reps);
     if (nchunk <= 0) return DAGNN_EINVAL;
+    bool tail = true;   // only the thin tail is walked (first_layer > 0 everywhere): a layer holds one or two tiles, more replicas
+    for (int q = 0; q < ndir; ++q) tail = tail && a->first_layer[dirs[q]] > 0;   // only add counters to poll (4 -> 2: cfg 5 21.56 -> 21.14 ms)
+    if (tail && reps[0] > 2) reps[0] = 2;
     const PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
     const int32_t* plan = (const int32_t*)pl->data;
     const void* fn = reinterpret_cast<const void*>(tiles_kernel);

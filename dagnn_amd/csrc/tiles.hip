@@ -265,7 +265,7 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
 
     if (is_compute) {
         // ------------------------------------------------------------------ compute waves
-        // this wave's KW/4 weights, the A operands: lane l holds W[gate row 16 s + (l & 15)][k0 + 16 j + 4 (l >> 4) + e]
+        // this wave's KW/4 weights, the A operands: lane l holds W[gate row 16 s + (l & 15)][k0 + k(j, l >> 4) + e] (K order: below)
         const int m = lane & 15, kq = lane >> 4;
         const int g = simd, hh = wave >> 2;   // gate; K half: with an input side 0 = W_ih on the lower-layer row, 1 = W_hh on the aggregate
         const float* Wm = (HAS_IN && hh == 0) ? C.wih : C.whh;
@@ -273,10 +273,14 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
         float wr[KJ][4];
 #pragma unroll
         for (int j = 0; j < KJ; ++j) {
-            const float4 w4 = *reinterpret_cast<const float4*>(Wm + (int64_t)(g * TH + slice * TU + m) * TH + kb + 16 * j + 4 * kq);
+            const float4 w4 = *reinterpret_cast<const float4*>(Wm + (int64_t)(g * TH + slice * TU + m) * TH + kb + 256 * (j >> 4) + 64 * kq + 4 * (j & 15));
             wr[j][0] = w4.x; wr[j][1] = w4.y; wr[j][2] = w4.z; wr[j][3] = w4.w;
         }
-        const int b_off = m * PITCH + hh * KW + 4 * kq;
+        // K order of the products: step j of lane group kq takes k = 256 (j / 16) + 64 kq + 4 (j % 16) .. + 3 (any order is as good
+        // for the sum, both operands follow it).  The 16 lanes a ds_read_b128 serves together then read node rows PITCH = 4
+        // (mod 64) dwords apart at the same in-row offset mod 64: their 16-byte windows tile the 64 banks, no conflict
+        // (with k = 16 j + 4 kq the kq = 0 and kq = 1 lanes of a group collided: 35 % of the LDS cycles, profiles/r03_pmc_tiles.json)
+        const int b_off = m * PITCH + hh * KW + 64 * kq;
 #ifdef T_STAMPS
         unsigned long long c_mfma = 0, c_red = 0, c_bar = 0;
 #endif
@@ -290,7 +294,7 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
 #ifndef T_EXP_NOMFMA
 #pragma unroll
             for (int j = 0; j < KJ; ++j) {
-                const float4 b4 = *reinterpret_cast<const float4*>(bp + 16 * j);
+                const float4 b4 = *reinterpret_cast<const float4*>(bp + 256 * (j >> 4) + 4 * (j & 15));
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][0], b4.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][1], b4.y, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][2], b4.z, acc, 0, 0, 0);

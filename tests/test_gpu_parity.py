@@ -1432,3 +1432,24 @@ def test_tile_kernel_feeds_the_backward_pass(device, monkeypatch):
         scale = max(float(g.abs().max()), 1e-6)
         assert float((res[2][1][k] - g).abs().max()) <= 2e-4 * scale + 2e-7, k
         assert float((res[2][1][k] - res[0][1][k]).abs().max()) <= 2e-5 * scale + 2e-7, k
+
+
+@pytest.mark.parametrize("mode", ["alone", "split"])
+def test_tile_kernel_back_to_back_forwards_are_race_free(device, monkeypatch, mode):
+    """60 forwards issued back to back with nothing synchronising in between (state buffers and progress counters recycled
+    every pass, epochs advancing): every pass reproduces the first bit for bit and no bounded wait expires - on the tile
+    kernel alone and behind the per-layer launches of the wide first layers."""
+    from bench import fresh_inputs
+    monkeypatch.setattr(engine, "TILES", 2 if mode == "alone" else 1)
+    if mode == "split":
+        monkeypatch.setattr(engine, "TILES_MAX_NODES", 0)
+    model = _headline_model(H=512, L=3, V=16, seed=8).to(device)
+    master = synth.code2_batch(6, 48, 110).to(device)
+    ins = fresh_inputs(master, 60)
+    with torch.no_grad():
+        first = [o.clone() for o in model(ins[0])]
+        for g in ins[1:]:
+            out = model(g)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(first, out))
+    model.check()

@@ -1453,3 +1453,25 @@ def test_tile_kernel_back_to_back_forwards_are_race_free(device, monkeypatch, mo
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(first, out))
     model.check()
+
+
+def test_tile_kernel_split_feeds_the_backward_pass(device, monkeypatch):
+    """The same for a batch that is split (per-layer launches for the wide first layers, tile kernel for the thin tail): one
+    training step against the step on the launches alone."""
+    model = _headline_model(H=512, L=3, V=12, seed=7).to(device)
+    b = synth.code2_batch(9, 48, 110)
+    y = torch.randint(0, 12, (48, 5), generator=torch.Generator().manual_seed(6)).to(device)
+    monkeypatch.setattr(engine, "TILES_MAX_NODES", 0)
+    res, ran = {}, []
+    orig = engine.tiles_run
+    monkeypatch.setattr(engine, "tiles_run", lambda *a, **k: (ran.append(k.get("first_layer")), orig(*a, **k))[1])
+    for mode in (1, 0):
+        monkeypatch.setattr(engine, "TILES", mode)
+        loss, grads = _train_step(model, b.clone().to(device), y)
+        model.check()
+        res[mode] = (float(loss), {k: v.detach().clone() for k, v in grads.items()})
+    assert len(ran) == 1 and ran[0] is not None and max(ran[0]) > 0
+    assert abs(res[1][0] - res[0][0]) < 1e-6
+    for k, g in res[0][1].items():
+        scale = max(float(g.abs().max()), 1e-6)
+        assert float((res[1][1][k] - g).abs().max()) <= 2e-5 * scale + 2e-7, k

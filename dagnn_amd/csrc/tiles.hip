@@ -11,25 +11,31 @@
 // from the infinity cache 375 times (frontier.hip: 25 ms per batch, of which 9 ms in 250 thin launches that do nothing
 // else), and the 4-row blocks of the dataflow kernel (dataflow.hip) cannot feed 977 GFLOP of products.  Here the weights
 // never move: ONE persistent launch per chunk of stacked layers, every workgroup = (cell, 16-unit slice[, replica]) keeps
-// its 48 gate rows x K of W_ih | W_hh in the registers of its 8 compute waves (96 VGPRs each at K = 1024) for the whole
-// pass, and the frontier rows stream past it in tiles of 16:
-//   * 4 loader waves build the tile's operand rows in LDS: the node's lower-layer state row and the attention aggregate
-//     over its predecessors' rows (online segment soft-max, PyG's exp(x - max) / (sum + 1e-16); scores from the 16-unit
-//     partial dots the producers store behind every state row), one tile AHEAD of the products;
-//   * 8 compute waves run [16 rows x K] x [K x 48] on v_mfma_f32_16x16x4_f32 (exact fp32, k ascending), K split 8 ways
-//     (waves 0-3 the input side, 4-7 the hidden side: the GRU's n gate needs the two sums apart anyway), partial tiles
-//     to LDS;
-//   * loader wave 0 sums the partials in wave order, evaluates the gates for the tile BEHIND the products, stores the
-//     16-unit state slices (write-through) and their partial attention score, and publishes a progress counter.
+// its 48 gate rows x K of W_ih | W_hh in the registers of its 6 compute waves (128 VGPRs each at K = 1024) for the whole
+// pass, and the frontier rows stream past it in tiles of 16.  Roles follow the SIMD a wave runs on (wave w -> SIMD w % 4):
+// an fp32 MFMA runs at the vector rate and keeps its SIMD's vector ALU busy, so a loader wave next to two waves of
+// back-to-back MFMAs gets no issue slot until they are done (measured) -
+//   * SIMD 3: three loader waves build the tile's operand rows in LDS, one tile AHEAD of the products: the node's
+//     lower-layer state row and the row of its first predecessor by LDS-DMA straight into the operand tile (most rows
+//     have one predecessor: that row IS the aggregate), the second predecessor and the partial scores into registers,
+//     rows with more predecessors folded in place (online segment soft-max, PyG's exp(x - max) / (sum + 1e-16); scores
+//     from the 16-unit partial dots the producers store behind every state row);
+//   * SIMDs 0-2: one gate each on two compute waves (the K halves - with an input side: W_ih on the lower-layer row and
+//     W_hh on the aggregate, which the GRU's n gate needs apart anyway), [16 rows x K/2] x [K/2 x 16] per wave on
+//     v_mfma_f32_16x16x4_f32 (exact fp32), partial tiles to LDS; waves 8-10 have no role and exit;
+//   * loader wave 0 adds the two partials of each gate, evaluates the gates for the tile BEHIND the products, stores its
+//     16-unit state slice (write-through) and the slice's partial attention score, and publishes a progress counter.
 // Hand-off between workgroups (cdna_hip_programming.md Guideline 16, form R1): payload by write-through (sc1) stores,
-// `s_waitcnt vmcnt(0)`, then ONE 8-byte {epoch, tiles done} counter per (cell, replica, slice); a consumer polls the 32
-// counters of its own cell (all earlier LAYERS complete) and of the cell below (the same TILE complete) with relaxed
-// agent-scope loads and reads the rows with sc1 loads (served by L2, never by the CU's L1).  Nothing depends on
-// placement or timing; every wait is bounded and raises `err`.
+// `s_waitcnt vmcnt(0)`, then ONE 8-byte {epoch, next own tile} counter per (cell, replica, slice); a consumer polls the
+// 32 counters of its own cell (all earlier LAYERS complete) and of the cell below (the same TILE complete) with relaxed
+// agent-scope loads.  Rows are then read with ordinary cached loads: a row is only ever read after the counters say it
+// is complete, so no cache of the reader's XCD can hold an older copy.  Nothing depends on placement or timing; every
+// wait is bounded and raises `err`.
 // Tiles follow the plan's batch-level layers (blptr / rowrec of plan.hip): tile k of layer t covers record slots
-// [blptr[t] + 16 (k - first tile of t), +16); replica r of a cell takes the tiles k = r (mod R).
+// [blptr[t] + 16 (k - first tile of t), +16); replica r of a cell takes the tiles whose position in their layer is r mod R.
 // Chunks: stacked layer 0 (hidden side only, gi0 from the batched GEMM) is one launch with as many replicas as fit;
 // the layers above run together while 32 workgroups per cell fit the device (4 layers x 2 directions = 256 CUs).
+// `first_layer`: the walk may start behind the wide first layers (done by dagnn_frontier_run): DESIGN.md 4f.
 #include "df_common.h"   // (df_wave_umin)
 
 namespace {
@@ -53,9 +59,6 @@ constexpr int TMAXCID = 2 * DAGNN_MAX_STACKED;   // counters: [cell id][replica]
 #endif
 #ifndef T_CHUNK
 #define T_CHUNK 2                                // predecessors per further trip of a row with more than two
-#endif
-#ifndef T_ROWS_PER_TRIP
-#define T_ROWS_PER_TRIP 2                        // rows a loader wave has in flight per trip to memory (4 rows per wave and tile)
 #endif
 
 typedef float tf4 __attribute__((ext_vector_type(4)));

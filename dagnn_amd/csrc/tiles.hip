@@ -118,7 +118,8 @@ template <bool HAS_IN> struct TShape {
     static constexpr int GSV = HAS_IN ? 0 : 3 * TR * 3 * TU;   // stacked layer 0: the slice's gi0 values likewise
     static constexpr int RING = 4 * TR * 16;         // row records (64 B each) of four tiles in flight
     static constexpr int CST = 5 * TU;               // the slice's biases (r, z, n input side, n hidden side) and key weights
-    static constexpr size_t lds_bytes = (size_t)(BT + RED + ASV + GSV + RING + CST + 8) * 4;
+    static constexpr int PSV = 2 * TR * 64;          // partial attention scores of the rows' first two predecessors (32 + 32 per row)
+    static constexpr size_t lds_bytes = (size_t)(BT + RED + ASV + GSV + RING + CST + PSV + 8) * 4;
 };
 static_assert(TShape<true>::lds_bytes <= 160 * 1024 && TShape<false>::lds_bytes <= 160 * 1024, "LDS budget");
 
@@ -231,7 +232,8 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
     float* gsv = asv + SH::ASV;
     int* ring = reinterpret_cast<int*>(gsv + SH::GSV);
     float* cst = reinterpret_cast<float*>(ring + SH::RING);
-    unsigned* flags = reinterpret_cast<unsigned*>(cst + SH::CST);   // [0] / [2] tiles whose lower-layer / own-cell inputs are
+    float* psv = cst + SH::CST;
+    unsigned* flags = reinterpret_cast<unsigned*>(psv + SH::PSV);   // [0] / [2] tiles whose lower-layer / own-cell inputs are
                                                                     // there, [1] partial tiles the gate stage has read
 
     const int32_t* bl = plan + L.blptr[d];
@@ -485,9 +487,9 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
         const int* rr = ring + (ord & 3) * (TR * 16);
 #pragma unroll
         for (int q = 0; q < TNQ; ++q) {
-            const int nraw = (TNLW - 1 - lwo) + TNLW * q;   // (the wave with the gate stage takes 5 rows, the polling wave 6)
-            const int n = nraw < TR ? nraw : nraw - TNLW;     // (no 6th row: the 5th once more - same source, same destination, no branch around loads)
-            const int v = rr[min(n, x.nr - 1) * 16];   // (rows past the end of the tile: a copy of its last row, never stored)
+            const int n = (TNLW - 1 - lwo) + TNLW * q;   // (the wave with the gate stage takes 5 rows, the polling wave 6)
+            if (n >= x.nr) break;                        // (nothing behind the tile's last row: a thin tile issues a row or two per wave)
+            const int v = rr[n * 16];
             if (HAS_IN) {
                 const float* src = C.h_in + (int64_t)v * ld_h + 4 * ln;
                 float* dst = Bt + ((ord & 1) * TR + n) * PITCH;
@@ -504,8 +506,8 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
     };
     // first two predecessors of the four rows, one trip to memory: the first one's row by LDS-DMA into the aggregate half of
     // the operand tile (most rows have ONE predecessor: that row IS the aggregate), the second one's into registers
-    struct Preds { float4 p1[TNQ][2]; float sp[TNQ][2]; int deg[TNQ], eb[TNQ]; };
-    // Every load below is UNCONDITIONAL: a load inside a branch ends in a register copy at the join, and the copy waits for
+    struct Preds { float4 p1[TNQ][2]; int deg[TNQ], eb[TNQ]; };
+    // Every load of a live row is UNCONDITIONAL: a load inside a branch ends in a register copy at the join, and the copy waits for
     // the load - four dependent round trips per tile instead of one.  A row without a first / second predecessor reads a
     // row that is certainly complete instead (the node's own lower-layer row; stacked layer 0: its gi0 row) and ignores it.
     // Rows are read with ordinary CACHED loads: a row is only ever read after the counters say it is complete, so no
@@ -514,7 +516,7 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
     auto issue_preds = [&](const Tile& x, int ord, Preds& P) {
 #ifdef T_EXP_NOLOAD
 #pragma unroll
-        for (int q = 0; q < TNQ; ++q) { P.deg[q] = 0; P.eb[q] = 0; P.p1[q][0] = P.p1[q][1] = make_float4(0.f, 0.f, 0.f, 0.f); P.sp[q][0] = P.sp[q][1] = 0.f; }
+        for (int q = 0; q < TNQ; ++q) { P.deg[q] = 0; P.eb[q] = 0; P.p1[q][0] = P.p1[q][1] = make_float4(0.f, 0.f, 0.f, 0.f); }
         return;
 #endif
         int lwo = lw;
@@ -524,9 +526,9 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
         const int4* rr = reinterpret_cast<const int4*>(ring + (ord & 3) * (TR * 16));
 #pragma unroll
         for (int q = 0; q < TNQ; ++q) {
-            const int nraw = (TNLW - 1 - lwo) + TNLW * q;   // (the wave with the gate stage takes 5 rows, the polling wave 6)
-            const int n = nraw < TR ? nraw : nraw - TNLW;     // (no 6th row: the 5th once more - same source, same destination, no branch around loads)
-            const bool live = n < x.nr && x.t > 0;
+            const int n = (TNLW - 1 - lwo) + TNLW * q;
+            if (n >= x.nr) break;   // (the slots behind stay undefined and unused: no value to merge at the exit, so no copy that would wait)
+            const bool live = x.t > 0;
             const int4 a0 = rr[n * 4], a1 = rr[n * 4 + 1];
             const int dg = a0.z - a0.y;
             P.deg[q] = live ? __builtin_amdgcn_readfirstlane(dg) : 0;
@@ -541,8 +543,9 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
                                              (__attribute__((address_space(3))) void*)(dst + 256), 16, 0, 0);
             P.p1[q][0] = *reinterpret_cast<const float4*>(r1 + 4 * ln);
             P.p1[q][1] = *reinterpret_cast<const float4*>(r1 + 256 + 4 * ln);
-            P.sp[q][0] = r0[TH + (ln & (TNS - 1))];   // (lanes 32-63: copies, masked in consume)
-            P.sp[q][1] = r1[TH + (ln & (TNS - 1))];
+            // the 32 + 32 partial scores of the two: ONE 4-byte LDS-DMA (lanes 0-31 the first predecessor's, 32-63 the second's)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((ln < TNS ? r0 : r1) + TH + (ln & (TNS - 1))),
+                                             (__attribute__((address_space(3))) void*)(psv + ((ord & 1) * TR + n) * 64), 4, 0, 0);
         }
     };
     // attention aggregate of the four rows -> aggregate half of the operand tile
@@ -565,8 +568,9 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
             }
             if (P.deg[q] >= 2) {
                 const int4 ft = reinterpret_cast<const int4*>(ring + (ord & 3) * (TR * 16))[n * 4 + 2];   // edge features of the two
-                const float s0 = fmaf(gain1, __int_as_float(ft.y), fmaf(gain0, __int_as_float(ft.x), t_wave_total(ln < TNS ? P.sp[q][0] : 0.f)));
-                const float s1 = fmaf(gain1, __int_as_float(ft.w), fmaf(gain0, __int_as_float(ft.z), t_wave_total(ln < TNS ? P.sp[q][1] : 0.f)));
+                const float pv = psv[((ord & 1) * TR + n) * 64 + ln];
+                const float s0 = fmaf(gain1, __int_as_float(ft.y), fmaf(gain0, __int_as_float(ft.x), t_wave_total(ln < TNS ? pv : 0.f)));
+                const float s1 = fmaf(gain1, __int_as_float(ft.w), fmaf(gain0, __int_as_float(ft.z), t_wave_total(ln < TNS ? 0.f : pv)));
                 float mx = fmaxf(s0, s1);
                 const float w0 = __expf(s0 - mx), w1 = __expf(s1 - mx);
                 float ssum = w0 + w1;

@@ -320,6 +320,7 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
 #pragma unroll
                     for (int j = 0; j < KJ; ++j) {
                         if (j + 3 < KJ) bq[(j + 3) & 3] = *reinterpret_cast<const float4*>(xp + 256 * ((j + 3) >> 4) + 4 * ((j + 3) & 15));
+                        __builtin_amdgcn_sched_barrier(0);   // (the read stays three steps ahead: hipcc otherwise sinks it to one)
                         const float4 b4 = bq[j & 3];
                         a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[j][0], b4.x, a0, 0, 0, 0);
                         a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[j][1], b4.y, a1, 0, 0, 0);

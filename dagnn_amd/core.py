@@ -210,10 +210,10 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
     if groups == 0 and arena is not None and N > 0 and static_score is None and not vid_nodes and \
             N * ld * 4 < (1 << 31) - 16 and all(cells[(d, 0)].w_key is not None for d in dirs):
         tiles = engine.tiles_launches(dev, len(dirs), L, Hp, plan.R, N)   # wide states (H = 512): csrc/tiles.hip
-    if groups == 0 and tiles == 0 and arena is not None and N > 0 and engine.DATAFLOW and not (engine.TILES == 1 and L >= 3 and Hp == 512):
+    if groups == 0 and tiles == 0 and arena is not None and N > 0 and engine.DATAFLOW and not (engine.TILES == 1 and L >= 2 and Hp == 512):
         _warn_off_dataflow(dev, len(dirs), L, Hp)
     split = None
-    if tiles == 0 and groups == 0 and engine.TILES == 1 and L >= 3 and arena is not None and N > 0 and static_score is None and \
+    if tiles == 0 and groups == 0 and engine.TILES == 1 and L >= 2 and arena is not None and N > 0 and static_score is None and \
             not vid_nodes and N * ld * 4 < (1 << 31) - 16 and all(cells[(d, 0)].w_key is not None for d in dirs) and \
             engine._lib.load().dagnn_tiles_launches(engine._num_cus(dev), len(dirs), L, Hp, plan.R) > 0:
         split = engine.tiles_tail_split(plan, dirs)   # a batch too large for the tile kernel alone: it takes the thin tail

@@ -873,6 +873,13 @@ int tiles_chunks(int num_cus, int ndir, int Ls, int* first, int* count, int* rep
     if (ndir <= 0 || Ls <= 0 || num_cus < TNS * ndir) return 0;
     const int per = num_cus / (TNS * ndir);   // cells of one direction the device hosts
     int n = 0;
+#ifndef T_NO_SINGLE_CHUNK
+    if (Ls > 1 && Ls <= per) {   // every cell fits at once (L <= 4 with two directions on 256 CUs): ONE launch, ONE dependent chain
+        int r = per / Ls; if (r > 4) r = 4;
+        first[0] = 0; count[0] = Ls; reps[0] = r;
+        return 1;
+    }
+#endif
     first[n] = 0; count[n] = 1; reps[n] = per < TMAXREP ? per : TMAXREP; if (reps[n] > T_REP0) reps[n] = T_REP0; ++n;
     for (int i = 1; i < Ls;) {
         const int c = (Ls - i) < per ? (Ls - i) : per;
@@ -913,7 +920,7 @@ extern "C" int dagnn_tiles_run(const dagnn_plan* pl, const dagnn_tiles_args* a, 
     if (nchunk <= 0) return DAGNN_EINVAL;
     bool tail = true;   // only the thin tail is walked (first_layer > 0 everywhere): a layer holds one or two tiles, more replicas
     for (int q = 0; q < ndir; ++q) tail = tail && a->first_layer[dirs[q]] > 0;   // only add counters to poll (4 -> 2: cfg 5 21.56 -> 21.14 ms)
-    if (tail && reps[0] > 2) reps[0] = 2;
+    if (tail && reps[0] > 2 && count[0] == 1) reps[0] = 2;
     const PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
     const int32_t* plan = (const int32_t*)pl->data;
     const void* fn = reinterpret_cast<const void*>(tiles_kernel);
@@ -942,7 +949,7 @@ extern "C" int dagnn_tiles_run(const dagnn_plan* pl, const dagnn_tiles_args* a, 
         S.epoch = a->epoch; S.spin_limit = a->spin_limit ? a->spin_limit : (1u << 22);
         S.prog = (gran_t*)a->counters; S.err = (int*)a->err; S.status = (const int32_t*)a->plan_status;
         S.dbg = a->debug_timing ? (unsigned long long*)a->debug_timing + (size_t)ch * 32 * 1024 : nullptr;
-        const size_t lds = first[ch] == 0 ? TShape<false>::lds_bytes : TShape<true>::lds_bytes;
+        const size_t lds = first[ch] + count[ch] > 1 ? TShape<true>::lds_bytes : TShape<false>::lds_bytes;   // (any cell with an input side)
         hipLaunchKernelGGL(tiles_kernel, dim3((unsigned)(nc * reps[ch] * TNS)), dim3(TTHREADS), lds, (hipStream_t)stream, plan, L, S);
         DAGNN_CHECK_LAUNCH();
     }

@@ -91,7 +91,7 @@ DF_COST_ROW = _env_int("DAGNN_AMD_DF_COST_ROW", 1)
 DF_GROUPS = _env_int("DAGNN_AMD_DF_GROUPS", 0)              # 0 = as many groups as the device hosts
 DF_XCD = _env_int("DAGNN_AMD_DF_XCD", 1)                    # 1: XCD-aware workgroup ids + hand-offs through the shared L2 where the run-time check allows
 TILES = _env_int("DAGNN_AMD_TILES", 1)                      # 1: the weight-stationary tile kernel (H = 512: csrc/tiles.hip) where it is the faster path
-                                                            # (>= 3 stacked layers: alone up to TILES_MAX_NODES nodes, behind the per-layer launches of the wide first
+                                                            # (>= 2 stacked layers: alone up to TILES_MAX_NODES nodes, behind the per-layer launches of the wide first
                                                             # layers on larger batches); 2: alone wherever it is supported; 0: never
 TILES_TAIL_ROWS = _env_int("DAGNN_AMD_TILES_TAIL_ROWS", 32)    # larger batches: per-layer launches for the wide first layers, the tile kernel from the
                                                             # first layer on behind which no layer has more rows than this (0: no such split)
@@ -454,7 +454,7 @@ def tiles_launches(device, num_dirs: int, num_stacked: int, H: int, num_edge_fea
     the default `DAGNN_AMD_TILES=1`) not the faster path for this depth / batch size."""
     if not TILES:
         return 0
-    if TILES == 1 and (num_stacked < 3 or num_nodes > TILES_MAX_NODES):
+    if TILES == 1 and (num_stacked < 2 or num_nodes > TILES_MAX_NODES):
         return 0
     return _lib.load().dagnn_tiles_launches(_num_cus(device), int(num_dirs), int(num_stacked), int(H), int(num_edge_feats))
 

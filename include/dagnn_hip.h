@@ -342,8 +342,8 @@ int dagnn_dataflow_layout(int64_t N, int64_t B, int groups, int64_t* offsets13 /
  * Weight-stationary tile schedule of the same recurrence for WIDE hidden states (H = 512; dagnn_amd/csrc/tiles.hip): the
  * path of BASELINE.json's cfg 5 (batch 256, hidden 512, 5 stacked layers, bidirectional), where the GRU matrices (56.6 MB)
  * are too large to be streamed once per topological layer (dagnn_frontier_run) and the rows too many for the 4-row blocks
- * of dagnn_dataflow_run.  One persistent launch per CHUNK of stacked layers (chunk 0 = stacked layer 0, then as many
- * layers at a time as the device hosts at 32 workgroups per cell): every workgroup keeps its 16-unit slice of one cell's
+ * of dagnn_dataflow_run.  One persistent launch per CHUNK of stacked layers (all of them at once when 32 workgroups per cell
+ * fit the device - up to 4 layers x 2 directions on 256 CUs; else chunk 0 = stacked layer 0, then as many layers at a time as fit): every workgroup keeps its 16-unit slice of one cell's
  * W_ih | W_hh (torch layouts, read once) in registers and walks the plan's batch-level layers in tiles of 16 rows
  * (v_mfma_f32_16x16x4_f32); rows are handed between workgroups by write-through stores + {epoch, tiles done} progress
  * counters.  Replaces the loop nest of dagnn.py:144-182 like the two schedules above; needs no device->host read.

@@ -7,12 +7,12 @@ from tests.test_gpu_parity import _headline_model
 dev = torch.device("cuda:0")
 import warnings
 warnings.simplefilter("ignore")
-for L in (5, 2):
+for L in [int(v) for v in os.environ.get("LS", "5,2").split(",")]:
     model = _headline_model(H=512, L=L, V=32, seed=5).to(dev)
     for B, mean_n in ((8, 60), (16, 125), (32, 125), (64, 125), (128, 125), (256, 125)):
         G = synth.code2_batch(1, B, mean_n).to(dev)
         res = []
-        for mode in (1, 0):
+        for mode in ((2 if os.environ.get("FORCE") else 1), 0):
             engine.TILES = mode
             for c in model._derived.values():
                 c.invalidate()

@@ -396,10 +396,11 @@ def test_deep_stack_runs_on_the_dataflow_kernel(device, monkeypatch):
         got = grads.get(k)
         got = torch.zeros_like(g) if got is None else got.cpu()
         assert float((got - g).abs().max()) <= 2e-4 * scale + 2e-7, k
-    # a shape the kernel does not cover (h = 512) falls back to the per-layer launches and says so, once
+    # a shape neither persistent kernel covers (h = 320: the dataflow kernel stops at 256, the tile kernel is built for 512)
+    # falls back to the per-layer launches and says so, once
     from dagnn_amd import core
     core._OFF_DATAFLOW_SEEN.clear()
-    wide = _headline_model(H=512, L=2, V=8, seed=1).to(device)
+    wide = _headline_model(H=320, L=2, V=8, seed=1).to(device)
     small = synth.code2_batch(3, 4, 12)
     with torch.no_grad():
         with pytest.warns(RuntimeWarning, match="per-layer launch path"):
@@ -1380,7 +1381,8 @@ def test_tile_kernel_full_size_properties(device, monkeypatch):
     N = full.x.shape[0]
     monkeypatch.setattr(engine, "TILES", 1)
     assert engine.tiles_launches(device, 2, 5, 512, 2, N) == 0 and engine.tiles_launches(device, 2, 5, 512, 2, 8000) == 2
-    assert engine.tiles_launches(device, 2, 2, 512, 2, 8000) == 0 and engine.tiles_launches(device, 2, 5, 256, 2, 8000) == 0
+    assert engine.tiles_launches(device, 2, 2, 512, 2, 8000) == 1 and engine.tiles_launches(device, 2, 4, 512, 2, 8000) == 1   # (every cell fits at once)
+    assert engine.tiles_launches(device, 2, 1, 512, 2, 8000) == 0 and engine.tiles_launches(device, 2, 5, 256, 2, 8000) == 0
 
 
 def test_tile_kernel_failures_surface(device, monkeypatch):

@@ -162,14 +162,6 @@ struct TileWalk {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t t_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7ffffffc, 0x00020000);
 }
-// 16 bytes of a row another workgroup of this launch may have written: sc1 (never served by this CU's L1)
-__device__ __forceinline__ float4 t_ld16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    const tu4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-__device__ __forceinline__ float t_ld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 16));
-}
 __device__ __forceinline__ void t_st16(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
     tu4 x;
     x.x = __float_as_uint(v.x); x.y = __float_as_uint(v.y); x.z = __float_as_uint(v.z); x.w = __float_as_uint(v.w);

@@ -116,16 +116,17 @@ def pack_lockstep(cells, force: bool = False) -> None:
 
 def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: bool,
                 edge_w: Optional[torch.Tensor], vid_nodes: int, schedule: str = "pergraph",
-                key_dim: Optional[int] = None, pack: bool = True) -> CellParams:
+                key_dim: Optional[int] = None, pack: bool = True, stacked: int = 1) -> CellParams:
     """Fold / pack one cell's parameters for the kernels.
 
     attn_w is `attn_lin.weight` [1, dq + H (+ vid_nodes)]: the first dq entries multiply the query
     (they cancel in the segment softmax, as does the bias), the next H the key h_j, and for the NA
     variant the last `vid_nodes` the one-hot vertex id of the key (`dvae/dagnn.py:130-134`).
     `edge_w` is `edge_encoder.weight` [H, R]; its bias is constant inside a segment and cancels.
+    `stacked` is the number of stacked cells of the model: it only picks the padded width (`engine.state_width`).
     """
     lock = schedule == "lockstep"
-    Hp = round_up(H, 64) if lock else round_up4(H)
+    Hp = engine.state_width(H, stacked, 0 if edge_w is None else int(edge_w.shape[1])) if lock else round_up4(H)
     c = CellParams()
     c.Hp = Hp
     wi = _pad_gate_rows(w_ih.detach().float(), H, Hp)

@@ -124,7 +124,7 @@ class _DvaeDagnn(_DvaeBase):
                     dq = self.emb_dim if i == 0 else self.hidden_dim + extra
                     out[(d, i)] = derive_cell(c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh, a.attn_lin.weight,
                                               self.hidden_dim, dq, i > 0, None, extra, schedule=self.schedule,
-                                              pack=False)
+                                              pack=False, stacked=self.num_layers)
             if self.schedule == "lockstep":
                 pack_lockstep(out.values())
             return out

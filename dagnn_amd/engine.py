@@ -93,6 +93,7 @@ DF_XCD = _env_int("DAGNN_AMD_DF_XCD", 1)                    # 1: XCD-aware workg
 TILES = _env_int("DAGNN_AMD_TILES", 1)                      # 1: the weight-stationary tile kernel (H = 512: csrc/tiles.hip) where it is the faster path
                                                             # (>= 2 stacked layers: alone up to TILES_MAX_NODES nodes, behind the per-layer launches of the wide first
                                                             # layers on larger batches); 2: alone wherever it is supported; 0: never
+TILES_PAD = _env_int("DAGNN_AMD_TILES_PAD", 1)              # 1: hidden sizes in (256, 512) of stacked models are zero-padded to 512 so that the tile kernel takes them
 TILES_TAIL_ROWS = _env_int("DAGNN_AMD_TILES_TAIL_ROWS", 32)    # larger batches: per-layer launches for the wide first layers, the tile kernel from the
                                                             # first layer on behind which no layer has more rows than this (0: no such split)
 TILES_MAX_NODES = _env_int("DAGNN_AMD_TILES_MAX_NODES", 10000)  # measured on MI355X at L = 5 (scripts/tiles_sweep.py, tiles_hybrid.py): the kernel alone takes
@@ -447,6 +448,20 @@ def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
                 check(lib.dagnn_score_parts(h[d][i].data_ptr(), h[d][i].shape[1], H, cells[(d, i)].w_key.data_ptr(),
                                             plan.N, _stream(plan.ws)), "dagnn_score_parts")
     arena.watch(plan, folded=True)
+
+
+def state_width(H: int, num_stacked: int = 1, num_edge_feats: int = 0) -> int:
+    """Padded width of a state row on the lock-step path: the next multiple of 64 - except that 256 < H < 512 is padded
+    to 512 for a stacked model (and 384 < H for a single-layer one).  512 is the one width the tile kernel (csrc/tiles.hip)
+    is built for and the one above 256 whose per-layer kernels, forward and reverse, run on MFMA tiles; padded units stay
+    exactly 0 (zero weight rows and biases give r = z = 1/2, n = 0, h' = z * a = 0).  Measured (scripts/tiles_pad.py;
+    DESIGN 4f): L >= 2 forward 0.46-0.98x and training step 0.46-0.99x of the unpadded width, one case of 1.06x
+    (H = 300, L = 5, B = 32 forward); L = 1 wins from 448 up only, hence the second rule.  `DAGNN_AMD_TILES_PAD=0`
+    keeps the next multiple of 64, `=2` pads every 256 < H < 512."""
+    Hp = (int(H) + 63) // 64 * 64
+    if TILES == 1 and TILES_PAD and 256 < Hp < 512 and num_edge_feats <= 2 and (num_stacked >= 2 or Hp > 384 or TILES_PAD >= 2):
+        Hp = 512
+    return Hp
 
 
 def tiles_launches(device, num_dirs: int, num_stacked: int, H: int, num_edge_feats: int, num_nodes: int = 0) -> int:

@@ -232,7 +232,7 @@ class DAGNN(nn.Module):
                     dq, kd = self._attn_geometry(i)
                     out[(d, i)] = derive_cell(c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh, a.attn_lin.weight,
                                               self.hidden_dim, dq, i > 0, a.edge_encoder.weight if a.wea else None, 0,
-                                              schedule=self.schedule, key_dim=kd, pack=False)
+                                              schedule=self.schedule, key_dim=kd, pack=False, stacked=self.num_layers)
             if self.schedule == "lockstep":
                 pack_lockstep(out.values())
             return out
@@ -353,7 +353,7 @@ class DAGNN(nn.Module):
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             plan = engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B, ea)
-            Hp = (self.hidden_dim + 63) // 64 * 64
+            Hp = engine.state_width(self.hidden_dim, self.num_layers, plan.R)
             groups = engine.dataflow_groups(dev, len(self.dirs), self.num_layers, Hp, B) if self.schedule == "lockstep" else 0
             if groups > 0:
                 plan.dataflow_schedule(groups)

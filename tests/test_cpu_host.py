@@ -433,3 +433,23 @@ def test_tile_kernel_tail_split_policy(monkeypatch):
     assert engine.tiles_tail_split(Plan([[4] * 100, [7] * 90]), [0, 1]) == [0, 0]                          # nothing wide at all
     monkeypatch.setattr(engine, "TILES_TAIL_ROWS", 0)
     assert engine.tiles_tail_split(Plan([fwd, bwd]), [0, 1]) is None
+
+
+def test_state_width_policy(monkeypatch):
+    """engine.state_width: the next multiple of 64, except that 256 < H < 512 goes to 512 (the tile kernel's width) for
+    stacked models, and for single-layer ones from 385 up; never with more than two edge features, nor when the tile
+    kernel or the padding is switched off."""
+    from dagnn_amd import engine
+    monkeypatch.setattr(engine, "TILES", 1)
+    monkeypatch.setattr(engine, "TILES_PAD", 1)
+    assert [engine.state_width(h, 2) for h in (32, 200, 256, 257, 300, 384, 448, 501, 512, 600)] == \
+        [64, 256, 256, 512, 512, 512, 512, 512, 512, 640]
+    assert [engine.state_width(h, 1) for h in (257, 320, 384, 385, 448, 512)] == [320, 320, 384, 512, 512, 512]
+    assert engine.state_width(300, 3, 3) == 320
+    monkeypatch.setattr(engine, "TILES_PAD", 2)
+    assert engine.state_width(300, 1) == 512
+    monkeypatch.setattr(engine, "TILES_PAD", 0)
+    assert engine.state_width(300, 3) == 320
+    monkeypatch.setattr(engine, "TILES_PAD", 1)
+    monkeypatch.setattr(engine, "TILES", 0)
+    assert engine.state_width(300, 3) == 320

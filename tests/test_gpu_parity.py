@@ -396,11 +396,13 @@ def test_deep_stack_runs_on_the_dataflow_kernel(device, monkeypatch):
         got = grads.get(k)
         got = torch.zeros_like(g) if got is None else got.cpu()
         assert float((got - g).abs().max()) <= 2e-4 * scale + 2e-7, k
-    # a shape neither persistent kernel covers (h = 320: the dataflow kernel stops at 256, the tile kernel is built for 512)
-    # falls back to the per-layer launches and says so, once
+    # a shape neither persistent kernel covers (h = 320, one layer: the dataflow kernel stops at 256, the tile kernel is
+    # built for 512 and stacked models - engine.state_width leaves this one at 320) falls back to the per-layer launches
+    # and says so, once
     from dagnn_amd import core
     core._OFF_DATAFLOW_SEEN.clear()
-    wide = _headline_model(H=320, L=2, V=8, seed=1).to(device)
+    assert engine.state_width(320, 1, 2) == 320
+    wide = _headline_model(H=320, L=1, V=8, seed=1).to(device)
     small = synth.code2_batch(3, 4, 12)
     with torch.no_grad():
         with pytest.warns(RuntimeWarning, match="per-layer launch path"):
@@ -979,10 +981,13 @@ def test_training_step_other_additive_aggregators_match_oracle_autograd(device, 
         assert Hh.maxdiff(g, ref[k]) <= 1e-4 * scale + 2e-7, k
 
 
-@pytest.mark.parametrize("H,L", [(512, 3), (320, 2)])
-def test_training_step_wide_hidden_matches_oracle_autograd(device, H, L):
-    """Hidden sizes beyond the register-resident path: H = 512 (streamed slice kernel, K-chunked MFMA tiles, no
-    persistent kernels) and H = 320 (padded to 384, not MFMA-eligible: 8-row blocks), with fat layers present."""
+@pytest.mark.parametrize("H,L,pad", [(512, 3, 1), (320, 2, 1), (320, 2, 0), (320, 1, 1)])
+def test_training_step_wide_hidden_matches_oracle_autograd(device, monkeypatch, H, L, pad):
+    """Hidden sizes beyond the register-resident path: H = 512 (streamed slice kernel, K-chunked MFMA tiles), H = 320
+    stacked (zero-padded to 512 by engine.state_width, so the same kernels - and with DAGNN_AMD_TILES_PAD=0 at its own
+    width, not MFMA-eligible: 8-row blocks) and H = 320 single-layer (never padded), with fat layers present."""
+    monkeypatch.setattr(engine, "TILES_PAD", pad)
+    assert engine.state_width(H, L, 2) == (512 if (H == 512 or (pad and L >= 2)) else 320)
     meta = dict(H=H, n_attr=300, V=24, S=2, w_seed=55,
                 ctor=dict(w_edge_attr=True, num_layers=L, bidirectional=True, agg="attn_h", out_wx=False,
                           out_pool_all=False, out_pool="max", dropout=0.0))
@@ -1334,6 +1339,46 @@ def test_tile_kernel_shapes_and_edge_cases(device, monkeypatch, kw):
     assert max(Hh.maxdiff(o, r) for o, r in zip(res[2][0], ref)) < TOL
     assert max(Hh.maxdiff(a, c) for a, c in zip(res[2][0], res[0][0])) < 2e-5
     assert max(Hh.maxdiff(a, c) for a, c in zip(res[2][1], res[0][1])) < 5e-6
+
+
+@pytest.mark.parametrize("H,L", [(300, 3), (448, 1), (384, 2)])
+def test_hidden_sizes_between_256_and_512_run_padded_to_512(device, monkeypatch, H, L):
+    """engine.state_width: a stacked model with 256 < H < 512 (and a single-layer one above 384) is zero-padded to 512 -
+    the tile kernel takes the stacked ones - and nothing of the padding shows: logits and every state row against the
+    oracle and against the same model at its own width (`DAGNN_AMD_TILES_PAD=0`), state rows H wide."""
+    model = _headline_model(H=H, L=L, V=16, seed=9)
+    b = _degenerate_batch(synth.code2_graphs(17, 12, 40))
+    ref = O.code2_forward(model.state_dict(), copy.deepcopy(b), num_layers=L, bidirectional=True, out_wx=False,
+                          out_pool_all=False, out_pool="max", max_seq_len=5)
+    model = model.to(device)
+    lib = engine._lib.load()
+    calls = []
+    orig = lib.dagnn_tiles_run
+
+    class _Spy(object):
+        def __call__(self, *a):
+            calls.append(1)
+            return orig(*a)
+    monkeypatch.setattr(lib, "dagnn_tiles_run", _Spy(), raising=False)
+    res = {}
+    for pad in (1, 0):
+        monkeypatch.setattr(engine, "TILES_PAD", pad)
+        for c in model._derived.values():
+            c.invalidate()
+        G = copy.deepcopy(b).to(device)
+        with torch.no_grad():
+            out = model(G)
+        model.check()
+        assert all(h.shape[1] == H for hd in G.h for h in hd)
+        res[pad] = ([o.clone() for o in out], [h.clone() for hd in G.h for h in hd])
+        if pad:
+            assert engine.state_width(H, L, 2) == 512 and bool(calls) == (L >= 2)
+            calls.clear()
+        else:
+            assert engine.state_width(H, L, 2) == (H + 63) // 64 * 64 and not calls
+    assert max(Hh.maxdiff(o, r) for o, r in zip(res[1][0], ref)) < TOL
+    assert max(Hh.maxdiff(a, c) for a, c in zip(res[1][0], res[0][0])) < 2e-5
+    assert max(Hh.maxdiff(a, c) for a, c in zip(res[1][1], res[0][1])) < 5e-6
 
 
 def test_tile_kernel_full_size_properties(device, monkeypatch):

@@ -211,6 +211,8 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
     if groups == 0 and arena is not None and N > 0 and static_score is None and not vid_nodes and \
             N * ld * 4 < (1 << 31) - 16 and all(cells[(d, 0)].w_key is not None for d in dirs):
         tiles = engine.tiles_launches(dev, len(dirs), L, Hp, plan.R, N)   # wide states (H = 512): csrc/tiles.hip
+        if tiles > 0 and engine.tiles_batch_too_flat(plan, dirs):
+            tiles = 0   # few wide layers: the launches' 32-row tiles win (no thin tail either: the split below says None)
     if groups == 0 and tiles == 0 and arena is not None and N > 0 and engine.DATAFLOW and not (engine.TILES == 1 and L >= 2 and Hp == 512):
         _warn_off_dataflow(dev, len(dirs), L, Hp)
     split = None

@@ -94,7 +94,8 @@ TILES = _env_int("DAGNN_AMD_TILES", 1)                      # 1: the weight-stat
                                                             # (>= 2 stacked layers: alone up to TILES_MAX_NODES nodes, behind the per-layer launches of the wide first
                                                             # layers on larger batches); 2: alone wherever it is supported; 0: never
 TILES_PAD = _env_int("DAGNN_AMD_TILES_PAD", 1)              # 1: hidden sizes in (256, 512) of stacked models are zero-padded to 512 so that the tile kernel takes them
-TILES_TAIL_ROWS = _env_int("DAGNN_AMD_TILES_TAIL_ROWS", 32)    # larger batches: per-layer launches for the wide first layers, the tile kernel from the
+TILES_TAIL_ROWS = _env_int("DAGNN_AMD_TILES_TAIL_ROWS", 32)
+TILES_MAX_MEAN_ROWS = _env_int("DAGNN_AMD_TILES_MAX_MEAN_ROWS", 160)   # policy (TILES=1): batches above 1536 nodes with more rows per batch-level layer than this stay on the launches    # larger batches: per-layer launches for the wide first layers, the tile kernel from the
                                                             # first layer on behind which no layer has more rows than this (0: no such split)
 TILES_MAX_NODES = _env_int("DAGNN_AMD_TILES_MAX_NODES", 10000)  # measured on MI355X at L = 5 (scripts/tiles_sweep.py, tiles_hybrid.py): the kernel alone takes
                                                             # 0.75-0.82x the per-layer launches' time up to 8 k nodes, 0.95x at 15 k, 1.04-1.10x at 30 k
@@ -472,6 +473,20 @@ def tiles_launches(device, num_dirs: int, num_stacked: int, H: int, num_edge_fea
     if TILES == 1 and (num_stacked < 2 or num_nodes > TILES_MAX_NODES):
         return 0
     return _lib.load().dagnn_tiles_launches(_num_cus(device), int(num_dirs), int(num_stacked), int(H), int(num_edge_feats))
+
+
+def tiles_batch_too_flat(plan: PlanHandle, dirs: Sequence[int]) -> bool:
+    """Policy (`DAGNN_AMD_TILES=1`): True for a batch of few, wide layers, which the per-layer launches' 32-row MFMA tiles
+    take faster than the tile kernel's 16-row tiles gathered by all 32 slices - D-VAE BN batches at the reference's default
+    width, 10 layers deep (scripts/dvae_wide.py, hs = 501, L = 2, both directions, tile kernel : launches): 32 rows per layer
+    0.23 : 0.36 ms, 128: 0.46 : 0.50, 192: 0.62 : 0.61, 256: 0.77 : 0.66, 512: 1.42 : 0.99; code2 batches have ~40 rows per
+    layer.  Batches of up to 1536 nodes are never too flat (and cost no read of the schedule: the tile kernel walks the
+    plan's layers on the device)."""
+    if TILES != 1 or TILES_MAX_MEAN_ROWS <= 0 or plan.N <= 1536:
+        return False
+    sched = plan.read_schedule()
+    T = max([len(sched[d]) - 1 for d in dirs] + [1])
+    return plan.N > TILES_MAX_MEAN_ROWS * T
 
 
 def tiles_tail_split(plan: PlanHandle, dirs: Sequence[int]):

@@ -367,6 +367,16 @@ def _ipropagate_only():
     make_ipropagate(ref_bn, "DAGNN_BN", "iprop_bn_h32_L3", kind="bn", hs=32, L=3, w_seed=222, data_seed=32, K=5, n=10)
 
 
+def _dvae_default_hs():
+    """The reference's own default width (`dvae/train.py:55`: --hs 501): not a multiple of anything the kernels tile by."""
+    ref_util = importlib.import_module("util")
+    ref_batch_mod = importlib.import_module("batch")
+    ref_na = importlib.import_module("dagnn")
+    ref_bn = importlib.import_module("dagnn_bn")
+    make_na(ref_na, ref_util, ref_batch_mod, "na_h501_unidir", hs=501, L=2, bidir=False, w_seed=231, nrows=16)
+    make_bn(ref_bn, ref_util, ref_batch_mod, "bn_h501_bidir", hs=501, L=2, bidir=True, w_seed=232, data_seed=9, nrows=12)
+
+
 def _dvae_only():
     ref_util = importlib.import_module("util")
     ref_na = importlib.import_module("dagnn")
@@ -394,6 +404,8 @@ def main():
         return _dvae_only()
     if only == "ipropagate":
         return _ipropagate_only()
+    if only == "dvae_default_hs":
+        return _dvae_default_hs()
     # training-step gradients: loss and parameter gradients of one step
     if True:
         make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, "grad_h32_bidir", data_seed=11, B=6, mean_n=30, H=32,
@@ -486,6 +498,7 @@ def main():
     make_bn(ref_bn, ref_util, ref_batch_mod, "bn_h64_poolall_mean", hs=64, L=2, bidir=True, w_seed=206, data_seed=8,
             nrows=12, out_pool_all=True, out_pool="mean")
     _ipropagate_only()   # decoder-side single-vertex step (needs the igraph stand-in)
+    _dvae_default_hs()
 
 
 if __name__ == "__main__":

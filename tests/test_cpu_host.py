@@ -433,6 +433,24 @@ def test_tile_kernel_tail_split_policy(monkeypatch):
     assert engine.tiles_tail_split(Plan([[4] * 100, [7] * 90]), [0, 1]) == [0, 0]                          # nothing wide at all
     monkeypatch.setattr(engine, "TILES_TAIL_ROWS", 0)
     assert engine.tiles_tail_split(Plan([fwd, bwd]), [0, 1]) is None
+    # few wide layers (D-VAE batches at hs = 501) stay on the launches: more than TILES_MAX_MEAN_ROWS rows per layer
+    monkeypatch.setattr(engine, "TILES", 1)
+    monkeypatch.setattr(engine, "TILES_MAX_MEAN_ROWS", 160)
+    for rows, flat in (([128] * 10, False), ([512] * 10, True), ([200] * 10, True), ([150] * 12, False), ([44] * 374, False)):
+        p = Plan([rows, rows[::-1]])
+        p.N = sum(rows)
+        assert engine.tiles_batch_too_flat(p, [0, 1]) == flat, rows[0]
+
+    class NoRead(object):
+        N = 1536
+
+        def read_schedule(self):
+            raise AssertionError("a small batch reads no schedule")
+    assert engine.tiles_batch_too_flat(NoRead(), [0]) is False
+    monkeypatch.setattr(engine, "TILES", 2)
+    p = Plan([[512] * 10, [512] * 10])
+    p.N = 5120
+    assert engine.tiles_batch_too_flat(p, [0, 1]) is False
 
 
 def test_state_width_policy(monkeypatch):

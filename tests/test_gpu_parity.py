@@ -2,6 +2,7 @@
 (a) golden vectors produced by the real reference, (b) the CPU oracle on the same seeded inputs,
 (c) size-independent properties at the BASELINE sizes.  fp32 tolerance 1e-4 (north_star)."""
 import copy
+import warnings
 
 import numpy as np
 import pytest
@@ -1339,6 +1340,62 @@ def test_tile_kernel_shapes_and_edge_cases(device, monkeypatch, kw):
     assert max(Hh.maxdiff(o, r) for o, r in zip(res[2][0], ref)) < TOL
     assert max(Hh.maxdiff(a, c) for a, c in zip(res[2][0], res[0][0])) < 2e-5
     assert max(Hh.maxdiff(a, c) for a, c in zip(res[2][1], res[0][1])) < 5e-6
+
+
+def test_dvae_default_width_takes_the_tile_kernel(device, monkeypatch):
+    """The reference's default D-VAE width (`dvae/train.py:55`: --hs 501) is 512 wide on the lock-step path: the BN
+    encoder (two stacked layers, both directions) is ONE launch of the tile kernel, the NA encoder - whose keys carry the
+    vertex-id bias the tile kernel does not know (`dvae/dagnn.py:130-134`) - stays on the per-layer launches; both against
+    the reference's own outputs, and the BN encoder also against itself on the launches."""
+    monkeypatch.setenv("DAGNN_AMD_SCHEDULE", "lockstep")
+    lib = engine._lib.load()
+    calls = []
+    orig = lib.dagnn_tiles_run
+
+    class _Spy(object):
+        def __call__(self, *a):
+            calls.append(1)
+            return orig(*a)
+    monkeypatch.setattr(lib, "dagnn_tiles_run", _Spy(), raising=False)
+    for name, on_tiles in (("bn_h501_bidir", True), ("na_h501_unidir", False)):
+        meta, arr = Hh.load(name)
+        model = Hh.dvae_model(meta)[0].to(device)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with torch.no_grad():
+                Hg = model(Hh.dvae_batch(arr, device))
+        model.check()
+        assert bool(calls) == on_tiles, name
+        calls.clear()
+        assert Hh.maxdiff(Hg, arr["Hg"]) < TOL
+        if on_tiles:
+            monkeypatch.setattr(engine, "TILES", 0)
+            for c in model._derived.values():
+                c.invalidate()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                with torch.no_grad():
+                    Hg0 = model(Hh.dvae_batch(arr, device))
+            model.check()
+            assert not calls and Hh.maxdiff(Hg, Hg0) < 2e-5
+            monkeypatch.setattr(engine, "TILES", 1)
+            # 384 such graphs are 384 rows in each of 10 layers: too flat for the tile kernel under the policy
+            # (engine.tiles_batch_too_flat), which agrees with the kernel forced on
+            big = synth.dvae_batch([synth.decode_bn_row(r) for r in synth.bn_rows(4, 384)]).to(device)
+            for c in model._derived.values():
+                c.invalidate()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                with torch.no_grad():
+                    a = model(big.clone())
+                    assert not calls
+                    monkeypatch.setattr(engine, "TILES", 2)
+                    b = model(big.clone())
+                    assert calls
+            model.check()
+            calls.clear()
+            assert Hh.maxdiff(a, b) < 2e-5
+            monkeypatch.setattr(engine, "TILES", 1)
 
 
 @pytest.mark.parametrize("H,L", [(300, 3), (448, 1), (384, 2)])

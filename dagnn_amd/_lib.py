@@ -83,14 +83,14 @@ class DataflowArgs(C.Structure):
 
 
 class TilesCell(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("w_hh", "w_ih", "b_hh", "b_ih", "w_key", "edge_gain", "gi0", "h_out")]
+    _fields_ = [(k, C.c_void_p) for k in ("w_hh", "w_ih", "b_hh", "b_ih", "w_key", "edge_gain", "gi0", "h_out", "vid_bias")]
 
 
 class TilesArgs(C.Structure):
     _fields_ = [("cell", (TilesCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
                 ("H", C.c_int), ("ld_h", C.c_int), ("num_cus", C.c_int), ("epoch", C.c_uint), ("counters", C.c_void_p),
                 ("err", C.c_void_p), ("spin_limit", C.c_uint), ("plan_status", C.c_void_p), ("first_layer", C.c_int * MAX_DIRS),
-                ("debug_timing", C.c_void_p)]
+                ("debug_timing", C.c_void_p), ("vid_mod", C.c_int)]
 
 
 class BackwardCell(C.Structure):

@@ -208,7 +208,7 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
     if arena is not None:
         arena.poll()   # a failure an earlier pass reported (no synchronisation); either path below is watched
     tiles = 0
-    if groups == 0 and arena is not None and N > 0 and static_score is None and not vid_nodes and \
+    if groups == 0 and arena is not None and N > 0 and static_score is None and \
             N * ld * 4 < (1 << 31) - 16 and all(cells[(d, 0)].w_key is not None for d in dirs):
         tiles = engine.tiles_launches(dev, len(dirs), L, Hp, plan.R, N)   # wide states (H = 512): csrc/tiles.hip
         if tiles > 0 and engine.tiles_batch_too_flat(plan, dirs):
@@ -217,15 +217,15 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
         _warn_off_dataflow(dev, len(dirs), L, Hp)
     split = None
     if tiles == 0 and groups == 0 and engine.TILES == 1 and L >= 2 and arena is not None and N > 0 and static_score is None and \
-            not vid_nodes and N * ld * 4 < (1 << 31) - 16 and all(cells[(d, 0)].w_key is not None for d in dirs) and \
+            N * ld * 4 < (1 << 31) - 16 and all(cells[(d, 0)].w_key is not None for d in dirs) and \
             engine._lib.load().dagnn_tiles_launches(engine._num_cus(dev), len(dirs), L, Hp, plan.R) > 0:
         split = engine.tiles_tail_split(plan, dirs)   # a batch too large for the tile kernel alone: it takes the thin tail
     if tiles > 0:
-        engine.tiles_run(plan, dirs, L, Hp, cells, gi, h, arena)
+        engine.tiles_run(plan, dirs, L, Hp, cells, gi, h, arena, vid_mod=vid_nodes)
     elif split is not None:
         pack_lockstep(cells.values(), force=True)
         engine.frontier_run(plan, dirs, L, Hp, cells, gi, h, vid_mod=vid_nodes, arena=None, static_score=static_score, stop_layer=split)
-        engine.tiles_run(plan, dirs, L, Hp, cells, gi, h, arena, first_layer=split)
+        engine.tiles_run(plan, dirs, L, Hp, cells, gi, h, arena, first_layer=split, vid_mod=vid_nodes)
     elif groups > 0:
         pack_dataflow(cells.values())
         preact = {} if (keep is not None and engine.BWD_DATAFLOW) else None

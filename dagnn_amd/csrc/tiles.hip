@@ -74,6 +74,7 @@ struct TCell {
     const float* bih;    // [3H] (with wih)
     const float* wkey;   // [H]
     const float* gain;   // [R] or null
+    const float* vid;    // [vid_mod] key bias by vertex id (the NA encoder, dvae/dagnn.py:130-134) or null
     const float* gi0;    // [N, 3H] (stacked layer 0) or null
     const float* h_in;   // [N, ld_h] the stacked layer below (with wih)
     float* h_out;        // [N, ld_h]: H states + H/16 partial scores per row
@@ -84,7 +85,7 @@ struct TCell {
 
 struct TArgs {
     TCell cell[TMAXCELL];
-    int ncell, R, ld_h, nfeat;
+    int ncell, R, ld_h, nfeat, vid_mod;
     int first_layer[2];       // per direction: the walk starts at this batch-level layer (the layers before it are complete)
     unsigned epoch, spin_limit;
     gran_t* prog;             // [TMAXCID][TMAXREP][TNS] {epoch, P}: every tile k < P of this (cell, replica, slice) is published
@@ -216,7 +217,7 @@ struct TWait {
     }
 };
 
-template <bool HAS_IN>
+template <bool HAS_IN, bool VID>
 __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, const PlanLayout& L, const TArgs& S, const TCell& C,
                                           const int slice, const int rep, float* smem) {
     using SH = TShape<HAS_IN>;
@@ -608,8 +609,13 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
             if (P.deg[q] >= 2) {
                 const int4 ft = reinterpret_cast<const int4*>(ring + (ord & 3) * (TR * 16))[n * 4 + 2];   // edge features of the two
                 const float pv = psv[((ord & 1) * TR + n) * 64 + ln];
-                const float s0 = fmaf(gain1, __int_as_float(ft.y), fmaf(gain0, __int_as_float(ft.x), t_wave_total(ln < TNS ? pv : 0.f)));
-                const float s1 = fmaf(gain1, __int_as_float(ft.w), fmaf(gain0, __int_as_float(ft.z), t_wave_total(ln < TNS ? 0.f : pv)));
+                float s0 = fmaf(gain1, __int_as_float(ft.y), fmaf(gain0, __int_as_float(ft.x), t_wave_total(ln < TNS ? pv : 0.f)));
+                float s1 = fmaf(gain1, __int_as_float(ft.w), fmaf(gain0, __int_as_float(ft.z), t_wave_total(ln < TNS ? 0.f : pv)));
+                if (VID) {   // the key's vertex id scores too (one-hot `vids` of dvae/dagnn.py:130-134 folded into a table)
+                    const int4 pr = reinterpret_cast<const int4*>(ring + (ord & 3) * (TR * 16))[n * 4 + 1];
+                    s0 += C.vid[(unsigned)pr.x % (unsigned)S.vid_mod];
+                    s1 += C.vid[(unsigned)pr.y % (unsigned)S.vid_mod];
+                }
                 float mx = fmaxf(s0, s1);
                 const float w0 = __expf(s0 - mx), w1 = __expf(s1 - mx);
                 float ssum = w0 + w1;
@@ -640,6 +646,7 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
 #pragma unroll
                     for (int c = 0; c < T_CHUNK; ++c) {
                         sc[c] = t_wave_total(cs[c]) + cf[c];
+                        if (VID) sc[c] += C.vid[(unsigned)col[P.eb[q] + (e0 + c < P.deg[q] ? e0 + c : e0)] % (unsigned)S.vid_mod];
                         if (e0 + c < P.deg[q]) cm = fmaxf(cm, sc[c]);
                     }
                     const float rs = __expf(mx - cm);
@@ -840,6 +847,7 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
 #endif
 }
 
+template <bool VID>
 __global__ void __launch_bounds__(TTHREADS, 1) tiles_kernel(const int32_t* __restrict__ plan, PlanLayout L, TArgs S) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (S.status != nullptr) {
@@ -856,8 +864,8 @@ __global__ void __launch_bounds__(TTHREADS, 1) tiles_kernel(const int32_t* __res
     const int unit = blockIdx.x % units, slice = blockIdx.x / units;
     const TCell& C = S.cell[unit / S.R];
     const int rep = unit % S.R;
-    if (C.wih != nullptr) tile_body<true>(plan, L, S, C, slice, rep, smem);
-    else tile_body<false>(plan, L, S, C, slice, rep, smem);
+    if (C.wih != nullptr) tile_body<true, VID>(plan, L, S, C, slice, rep, smem);
+    else tile_body<false, VID>(plan, L, S, C, slice, rep, smem);
 }
 
 int tiles_chunks(int num_cus, int ndir, int Ls, int* first, int* count, int* reps) {
@@ -905,6 +913,7 @@ extern "C" int dagnn_tiles_run(const dagnn_plan* pl, const dagnn_tiles_args* a, 
             if (!c.w_hh || !c.b_hh || !c.w_key || !c.h_out) return DAGNN_EINVAL;
             if (i == 0 ? !c.gi0 : (!c.w_ih || !c.b_ih)) return DAGNN_EINVAL;
             if (pl->num_edge_feats > 0 && !c.edge_gain) return DAGNN_EINVAL;
+            if (a->vid_mod > 0 && !c.vid_bias) return DAGNN_EINVAL;
         }
     if (pl->B == 0 || pl->N == 0) return DAGNN_OK;
     int first[DAGNN_MAX_STACKED + 1], count[DAGNN_MAX_STACKED + 1], reps[DAGNN_MAX_STACKED + 1];
@@ -915,7 +924,8 @@ extern "C" int dagnn_tiles_run(const dagnn_plan* pl, const dagnn_tiles_args* a, 
     if (tail && reps[0] > 2 && count[0] == 1) reps[0] = 2;
     const PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
     const int32_t* plan = (const int32_t*)pl->data;
-    const void* fn = reinterpret_cast<const void*>(tiles_kernel);
+    const bool vid = a->vid_mod > 0;   // (its own instantiation: the plain kernel's code is the one without the table look-ups)
+    const void* fn = vid ? reinterpret_cast<const void*>(tiles_kernel<true>) : reinterpret_cast<const void*>(tiles_kernel<false>);
     const size_t lds_max = TShape<true>::lds_bytes > TShape<false>::lds_bytes ? TShape<true>::lds_bytes : TShape<false>::lds_bytes;
     const hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     if (ea != hipSuccess) return DAGNN_EHIP(ea);
@@ -928,7 +938,7 @@ extern "C" int dagnn_tiles_run(const dagnn_plan* pl, const dagnn_tiles_args* a, 
                 const dagnn_tiles_cell& c = a->cell[d][i];
                 TCell& K = S.cell[nc++];
                 K.whh = c.w_hh; K.wih = i > 0 ? c.w_ih : nullptr; K.bhh = c.b_hh; K.bih = i > 0 ? c.b_ih : nullptr;
-                K.wkey = c.w_key; K.gain = pl->num_edge_feats > 0 ? c.edge_gain : nullptr;
+                K.wkey = c.w_key; K.gain = pl->num_edge_feats > 0 ? c.edge_gain : nullptr; K.vid = vid ? c.vid_bias : nullptr;
                 K.gi0 = i == 0 ? c.gi0 : nullptr;
                 K.h_in = i > 0 ? a->cell[d][i - 1].h_out : nullptr;
                 K.h_out = c.h_out;
@@ -936,13 +946,14 @@ extern "C" int dagnn_tiles_run(const dagnn_plan* pl, const dagnn_tiles_args* a, 
                 K.cid = d * DAGNN_MAX_STACKED + i;
                 K.low = i > first[ch] ? d * DAGNN_MAX_STACKED + i - 1 : -1;
             }
-        S.ncell = nc; S.R = reps[ch]; S.ld_h = a->ld_h; S.nfeat = pl->num_edge_feats;
+        S.ncell = nc; S.R = reps[ch]; S.ld_h = a->ld_h; S.nfeat = pl->num_edge_feats; S.vid_mod = vid ? a->vid_mod : 1;
         for (int d = 0; d < 2; ++d) S.first_layer[d] = a->first_layer[d] > 0 ? a->first_layer[d] : 0;
         S.epoch = a->epoch; S.spin_limit = a->spin_limit ? a->spin_limit : (1u << 22);
         S.prog = (gran_t*)a->counters; S.err = (int*)a->err; S.status = (const int32_t*)a->plan_status;
         S.dbg = a->debug_timing ? (unsigned long long*)a->debug_timing + (size_t)ch * 32 * 1024 : nullptr;
         const size_t lds = first[ch] + count[ch] > 1 ? TShape<true>::lds_bytes : TShape<false>::lds_bytes;   // (any cell with an input side)
-        hipLaunchKernelGGL(tiles_kernel, dim3((unsigned)(nc * reps[ch] * TNS)), dim3(TTHREADS), lds, (hipStream_t)stream, plan, L, S);
+        if (vid) hipLaunchKernelGGL(tiles_kernel<true>, dim3((unsigned)(nc * reps[ch] * TNS)), dim3(TTHREADS), lds, (hipStream_t)stream, plan, L, S);
+        else hipLaunchKernelGGL(tiles_kernel<false>, dim3((unsigned)(nc * reps[ch] * TNS)), dim3(TTHREADS), lds, (hipStream_t)stream, plan, L, S);
         DAGNN_CHECK_LAUNCH();
     }
     return DAGNN_OK;

@@ -507,7 +507,7 @@ def tiles_tail_split(plan: PlanHandle, dirs: Sequence[int]):
 
 
 def tiles_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0, h, arena: "GranuleArena",
-              first_layer: Optional[Sequence[int]] = None) -> None:
+              first_layer: Optional[Sequence[int]] = None, vid_mod: int = 0) -> None:
     """The whole recurrence at H = 512 as one persistent launch per chunk of stacked layers (csrc/tiles.hip): the
     weights stay in registers, the rows pass in tiles of 16.  Same operands as `frontier_run` (raw torch-layout
     matrices: nothing is packed); writes the states and the partial attention scores behind them; no device->host
@@ -529,8 +529,9 @@ def tiles_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0,
             fc.edge_gain = _ptr(c.edge_gain) if plan.R > 0 else None
             fc.gi0 = gi0[d].data_ptr() if i == 0 else None
             fc.h_out = h[d][i].data_ptr()
+            fc.vid_bias = _ptr(c.vid_bias) if vid_mod > 0 else None
     args.num_stacked, args.dir_mask, args.H, args.ld_h = L, mask, H, h[dirs[0]][0].shape[1]
-    args.num_cus = _num_cus(plan.ws.device)
+    args.num_cus, args.vid_mod = _num_cus(plan.ws.device), int(vid_mod)
     args.epoch, args.counters, args.err = epoch, bufs["tiles"].data_ptr(), err.data_ptr()
     args.spin_limit = SPIN_LIMIT
     args.plan_status = plan.status.data_ptr()
@@ -1040,12 +1041,18 @@ def wgrad(jobs, N: int, Hp: int, H: int):
     kmax = 0
     for q, (dg, inp, want_bias) in enumerate(jobs):
         dg, inp = _rows(dg, "dg"), _rows(inp, "wgrad input")
+        K0 = K2 = inp.shape[1]
+        if K2 % 2:   # the kernel reads input columns in pairs (an odd width: the reference's default hs = 501, dvae/train.py:55)
+            if inp.stride(0) > K2 and inp.stride(0) % 2 == 0:   # a view of wider rows: take the next word of each row along (its
+                inp = inp.as_strided((inp.shape[0], K2 + 1), inp.stride())   # column of d_weight is dropped below)
+            else:
+                inp = torch.nn.functional.pad(inp, (0, 1))
+            K2 += 1
         keep += [dg, inp]
-        K2 = inp.shape[1]
         kmax = max(kmax, K2)
         dW = torch.empty(3 * H, K2, dtype=torch.float32, device=dev)
         db = torch.empty(3 * H, dtype=torch.float32, device=dev) if want_bias else None
-        outs.append((dW, db))
+        outs.append((dW if K2 == K0 else dW[:, :K0], db))
         arr[q] = _lib.WgradJob(dg.data_ptr(), inp.data_ptr(), dW.data_ptr(), _ptr(db), dg.stride(0), inp.stride(0), K2)
     cus = _num_cus(dev)
     splits = max(lib.dagnn_wgrad_splits(cus, len(jobs), Hp, kmax, max(N, 1)), 1)
@@ -1055,7 +1062,7 @@ def wgrad(jobs, N: int, Hp: int, H: int):
         ws = _WGRAD_WS[dev] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
     check(lib.dagnn_wgrad_run(arr, len(jobs), N, Hp, H, splits, ws.data_ptr(), ws.numel() * 4, _stream(jobs[0][0])),
           "dagnn_wgrad_run")
-    return outs
+    return [(dW if dW.is_contiguous() else dW.contiguous(), db) for dW, db in outs]
 
 
 def colsums(jobs, N: int):

@@ -352,8 +352,8 @@ int dagnn_dataflow_layout(int64_t N, int64_t B, int groups, int64_t* offsets13 /
  *             `epoch`s (the granule contract); err: device int32, zeroed by the caller - bit 0 / 1 a bounded wait expired,
  *             bit 2 (+ bits 8-15) the plan's status word was set and nothing was computed.
  * dagnn_tiles_launches: number of launches dagnn_tiles_run makes for this shape, 0 = shape not supported (H != 512, more
- * than 2 edge features, fewer than 32 * num_dirs CUs): use dagnn_frontier_run.  Vertex-id key biases and static scores
- * (the `*_x` aggregators) are not supported either.
+ * than 2 edge features, fewer than 32 * num_dirs CUs): use dagnn_frontier_run.  Static scores (the `*_x` aggregators)
+ * are not supported either; the vertex-id key bias of the NA encoder (vid_bias / vid_mod) is.
  * ---------------------------------------------------------------------------------------- */
 typedef struct dagnn_tiles_cell {
     const float* w_hh;      /* [3H,H] torch layout */
@@ -364,6 +364,7 @@ typedef struct dagnn_tiles_cell {
     const float* edge_gain; /* [num_edge_feats] or NULL */
     const float* gi0;       /* [N,3H] W_ih x + b_ih (stacked layer 0 only), from dagnn_gemm_nt_bias */
     float* h_out;           /* [N,ld_h] */
+    const float* vid_bias;  /* [vid_mod] or NULL: score bias by vertex id (NA variant), as in dagnn_frontier_cell */
 } dagnn_tiles_cell;
 
 typedef struct dagnn_tiles_args {
@@ -381,6 +382,7 @@ typedef struct dagnn_tiles_args {
                               * first_layer): the wide first layers on per-layer launches, the long thin tail on this kernel */
     void* debug_timing;      /* NULL, or uint64 [launches][1024][32] device words: per-workgroup phase sums in 100 MHz ticks,
                               * written by a -DT_STAMPS build only (scripts/tiles_stamps.py) */
+    int vid_mod;             /* 0, or the node count per graph of the NA variant (node id % vid_mod selects vid_bias) */
 } dagnn_tiles_args;
 
 int dagnn_tiles_launches(int num_cus, int num_dirs, int num_stacked, int H, int num_edge_feats);

@@ -375,6 +375,8 @@ def _dvae_default_hs():
     ref_bn = importlib.import_module("dagnn_bn")
     make_na(ref_na, ref_util, ref_batch_mod, "na_h501_unidir", hs=501, L=2, bidir=False, w_seed=231, nrows=16)
     make_bn(ref_bn, ref_util, ref_batch_mod, "bn_h501_bidir", hs=501, L=2, bidir=True, w_seed=232, data_seed=9, nrows=12)
+    make_na_grad(ref_na, ref_util, "grad_na_h501_unidir", hs=501, L=2, bidir=False, w_seed=233, nrows=12)
+    make_bn_grad(ref_bn, ref_util, "grad_bn_h501_bidir", hs=501, L=2, bidir=True, w_seed=234, data_seed=10, nrows=10)
 
 
 def _dvae_only():

@@ -24,7 +24,7 @@ GRAD = ["grad_h32_bidir", "grad_h256_bidir", "grad_h128_deep", "grad_h64_L3_wx",
 GRAD_VAR = ["grad_var_h64_" + t for t in ("gated_sum", "gated_nobias", "mattn_h", "add", "mattn_h_L3", "max", "recurr0_gated",
                                            "recurr0_mattn", "recurr0_attn_h", "recurr0_attn_x", "recurr0_self_attn_h",
                                            "aggx_attn_h", "aggx_add", "aggx_gated", "aggx_mattn", "aggx_max_recurr0")]
-DVAE_GRAD = ["grad_na_h64_unidir", "grad_bn_h64_bidir"]
+DVAE_GRAD = ["grad_na_h64_unidir", "grad_bn_h64_bidir", "grad_na_h501_unidir", "grad_bn_h501_bidir"]
 DVAE = ["na_h128_unidir", "na_h64_bidir", "bn_h256_bidir", "bn_h64_unidir", "na_h64_poolall_max", "bn_h64_poolall_mean",
         "na_h501_unidir", "bn_h501_bidir"]   # the last two: the reference's default width (dvae/train.py:55)
 

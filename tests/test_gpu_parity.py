@@ -1344,9 +1344,9 @@ def test_tile_kernel_shapes_and_edge_cases(device, monkeypatch, kw):
 
 def test_dvae_default_width_takes_the_tile_kernel(device, monkeypatch):
     """The reference's default D-VAE width (`dvae/train.py:55`: --hs 501) is 512 wide on the lock-step path: the BN
-    encoder (two stacked layers, both directions) is ONE launch of the tile kernel, the NA encoder - whose keys carry the
-    vertex-id bias the tile kernel does not know (`dvae/dagnn.py:130-134`) - stays on the per-layer launches; both against
-    the reference's own outputs, and the BN encoder also against itself on the launches."""
+    encoder (two stacked layers, both directions) and the NA encoder (one direction; its keys carry the vertex-id bias of
+    `dvae/dagnn.py:130-134`: the kernel's VID instantiation) are ONE launch of the tile kernel each - against the
+    reference's own outputs and against themselves on the per-layer launches."""
     monkeypatch.setenv("DAGNN_AMD_SCHEDULE", "lockstep")
     lib = engine._lib.load()
     calls = []
@@ -1357,7 +1357,7 @@ def test_dvae_default_width_takes_the_tile_kernel(device, monkeypatch):
             calls.append(1)
             return orig(*a)
     monkeypatch.setattr(lib, "dagnn_tiles_run", _Spy(), raising=False)
-    for name, on_tiles in (("bn_h501_bidir", True), ("na_h501_unidir", False)):
+    for name, on_tiles in (("bn_h501_bidir", True), ("na_h501_unidir", True)):
         meta, arr = Hh.load(name)
         model = Hh.dvae_model(meta)[0].to(device)
         with warnings.catch_warnings():
@@ -1379,9 +1379,10 @@ def test_dvae_default_width_takes_the_tile_kernel(device, monkeypatch):
             model.check()
             assert not calls and Hh.maxdiff(Hg, Hg0) < 2e-5
             monkeypatch.setattr(engine, "TILES", 1)
-            # 384 such graphs are 384 rows in each of 10 layers: too flat for the tile kernel under the policy
+            # 384 such graphs are 384 rows in each of 8-10 layers: too flat for the tile kernel under the policy
             # (engine.tiles_batch_too_flat), which agrees with the kernel forced on
-            big = synth.dvae_batch([synth.decode_bn_row(r) for r in synth.bn_rows(4, 384)]).to(device)
+            big = synth.dvae_batch([synth.decode_bn_row(r) for r in synth.bn_rows(4, 384)] if meta["kind"] == "bn" else
+                                   [synth.decode_enas_row(r) for r in synth.enas_rows(4, 384)]).to(device)
             for c in model._derived.values():
                 c.invalidate()
             with warnings.catch_warnings():

@@ -1005,6 +1005,44 @@ def test_training_step_wide_hidden_matches_oracle_autograd(device, monkeypatch, 
         assert Hh.maxdiff(g, ref[k]) <= 1e-4 * scale + 2e-7, k
 
 
+@pytest.mark.parametrize("H,L,E", [(33, 2, 64), (127, 3, 128), (255, 2, 300), (301, 2, 300), (501, 2, 300)])
+def test_training_step_odd_hidden_sizes_match_oracle_autograd(device, H, L, E):
+    """Odd hidden widths (the reference's D-VAE default is 501; nothing in `ogbg-code/model/dagnn.py` asks for an even one):
+    the padded units of every path, and the weight-gradient kernel's paired input columns (engine.wgrad), on a full
+    step; an embedding width that is not a multiple of 4 is refused loudly for training and runs under no_grad."""
+    from dagnn_amd import DAGNN, ASTNodeEncoder
+
+    def make(emb):
+        m = DAGNN(num_vocab=24, max_seq_len=2, emb_dim=emb, hidden_dim=H, out_dim=None, encoder=ASTNodeEncoder(emb, 98, 300, 20),
+                  w_edge_attr=True, num_layers=L, bidirectional=True, agg="attn_h", out_wx=False, out_pool_all=False,
+                  out_pool="max", dropout=0.0)
+        seeded_fill(m, 77 + H)
+        return m
+    model = make(E)
+    b = synth.code2_batch(43, 12, 40)
+    b.x[:, 1] %= 300
+    y = torch.from_numpy(np.random.default_rng(8).integers(0, 24, size=(12, 2)))
+    loss_ref, ref = O.code2_grads(model.state_dict(), b.clone(), y, num_layers=L, bidirectional=True, max_seq_len=2)
+    model = model.to(device)
+    loss, grads = _train_step(model, b.clone().to(device), y.to(device))
+    model.check()
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    for k, g in grads.items():
+        scale = float(ref[k].abs().max())
+        assert Hh.maxdiff(g, ref[k]) <= 1e-4 * scale + 2e-7, k
+    odd = make(H)   # embedding as wide as the states: odd
+    want = O.code2_forward(odd.state_dict(), b.clone(), num_layers=L, bidirectional=True, out_wx=False, out_pool_all=False,
+                           out_pool="max", max_seq_len=2)
+    odd = odd.to(device)
+    with pytest.raises(NotImplementedError):
+        _train_step(odd, b.clone().to(device), y.to(device))
+    odd.eval()
+    with torch.no_grad():
+        out = odd(b.clone().to(device))
+    odd.check()
+    assert max(Hh.maxdiff(o, r) for o, r in zip(out, want)) < TOL
+
+
 # ----------------------------------------------------------------------------- constructor-string variants (row a12)
 @pytest.mark.parametrize("name", Hh.VARIANTS)
 def test_variant_forward_matches_reference_golden(device, name):

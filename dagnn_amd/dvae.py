@@ -21,6 +21,8 @@ from . import constants as K
 from . import engine
 from .core import DerivedCache, default_schedule, derive_cell, pack_lockstep, run_stack
 from .data import GraphBatch
+
+OWN_LINEAR_MAX = 1 << 22   # multiply-adds up to which the final Linear of an evaluation pass runs on dagnn_gemm_nt_bias (see forward)
 from .model import _EdgeAttnParams
 
 
@@ -244,9 +246,17 @@ class _DvaeDagnn(_DvaeBase):
             hcat = self._readout(plan, B, x, h)
         G.h = hcat
         G.batch = G.batch[0::nn_] if self.bidirectional else G.batch[nn_ - 1::nn_]
-        if self.bidirectional:
-            return self.hg_unify(G.h)
-        return self.out_linear(G.h) if L > 1 else G.h
+        lin = self.hg_unify if self.bidirectional else (self.out_linear if L > 1 else None)
+        if lin is None:
+            return G.h
+        if isinstance(lin, nn.Sequential) and len(lin) == 1:   # (`hg_unify` is a Sequential of one Linear: dvae/dagnn.py:66-68)
+            lin = lin[0]
+        if train or not isinstance(lin, nn.Linear) or G.h.shape[0] * lin.weight.numel() > OWN_LINEAR_MAX:
+            return lin(G.h)
+        # evaluation, small product (cfg 1: 64 x 256 x 128): on the path's own GEMM - nn.Linear costs the host ~27 us of
+        # library dispatch and cfg 1 is host-bound (scripts/small_host_profile.py: 155 -> 134 us per forward); cfg 4's
+        # 128 x 1024 x 256 stays with the library (its split-K kernel is the faster one there: 196 vs 285 us)
+        return engine.gemm_nt_bias([G.h], [lin.weight.detach()], [None if lin.bias is None else lin.bias.detach()])[0]
 
     def encode(self, G):
         """(mu, logvar) of a list of graphs (`dvae/dagnn.py:177-184`)."""

@@ -256,6 +256,17 @@ def other_configs(device):
         T4 = int(b.bi_layer_index[0][0].max()) + 1
         out["cfg4_BN_B128_h256_L2_bidir"] = {"ms_per_batch": round(ms, 4), "graphs_per_s": round(128 / ms * 1e3, 1),
                                              "roofline": small_roofline(ms, int(b.x.shape[0]), 2, 2, 256, 10, T4)}
+        # the same two encoders at the reference's own default width (dvae/train.py:55: --hs 501; 512-wide rows, the tile
+        # kernel of csrc/tiles.hip in one launch each) - not a BASELINE configuration, reported next to cfg 1 / cfg 4
+        wide = {}
+        for tag, cls, nn_, rows, dec, bidir, Bw in (("NA_B64_unidir", DAGNN_NA, 8, synth.enas_rows, synth.decode_enas_row, False, 64),
+                                                    ("BN_B128_bidir", DAGNN_BN, 10, synth.bn_rows, synth.decode_bn_row, True, 128)):
+            mw = cls(nn_, 501, 501, nn_, nn_, 0, 1, hs=501, nz=56, num_nodes=nn_, num_layers=2, bidirectional=bidir).eval().to(device)
+            nbw = clones(synth.dvae_batch([dec(r) for r in rows(0, Bw)]).to(device), 25)
+            msw = timed(lambda: mw(nbw()), 20, 5)
+            mw.check()
+            wide[tag] = {"ms_per_batch": round(msw, 4), "graphs_per_s": round(Bw / msw * 1e3, 1)}
+        out["dvae_default_width_hs501_L2"] = wide
         m5 = build_model(512, 5, 5002, 5, device)
         b5 = synth.code2_batch(seed=0, num_graphs=256)
         N5, E5 = b5.x.shape[0], b5.edge_index.shape[1]

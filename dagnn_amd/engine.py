@@ -460,7 +460,7 @@ def state_width(H: int, num_stacked: int = 1, num_edge_feats: int = 0) -> int:
     (H = 300, L = 5, B = 32 forward); L = 1 wins from 448 up only, hence the second rule.  `DAGNN_AMD_TILES_PAD=0`
     keeps the next multiple of 64, `=2` pads every 256 < H < 512."""
     Hp = (int(H) + 63) // 64 * 64
-    if TILES == 1 and TILES_PAD and 256 < Hp < 512 and num_edge_feats <= 2 and (num_stacked >= 2 or Hp > 384 or TILES_PAD >= 2):
+    if TILES and TILES_PAD and 256 < Hp < 512 and num_edge_feats <= 2 and (num_stacked >= 2 or Hp > 384 or TILES_PAD >= 2):
         Hp = 512
     return Hp
 

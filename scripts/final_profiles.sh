@@ -14,5 +14,5 @@ import json, sys
 d = json.load(open("gpurun_out/%s_final_bench.json" % sys.argv[1]))
 print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["recurrence_ms_per_forward"], d["roofline"]["traffic"])
 print(d["loader_side_plan"]["ms_per_step"], {k: v for k, v in d["training_step"].items() if k in ("ms_per_step", "ms_per_step_median", "kernels_ms_per_step")})
-print({k: v["ms_per_batch"] for k, v in d["other_configs"].items()}, d["cpu_baseline"]["value"], d["cpu_baseline"]["vectorised"]["value"])
+print({k: v.get("ms_per_batch", v) for k, v in d["other_configs"].items()}, d["cpu_baseline"]["value"], d["cpu_baseline"]["vectorised"]["value"])
 PY

@@ -1005,7 +1005,7 @@ def test_training_step_wide_hidden_matches_oracle_autograd(device, monkeypatch, 
         assert Hh.maxdiff(g, ref[k]) <= 1e-4 * scale + 2e-7, k
 
 
-@pytest.mark.parametrize("H,L,E", [(33, 2, 64), (127, 3, 128), (255, 2, 300), (301, 2, 300), (501, 2, 300)])
+@pytest.mark.parametrize("H,L,E", [(33, 2, 64), (255, 2, 300), (501, 2, 300)])
 def test_training_step_odd_hidden_sizes_match_oracle_autograd(device, H, L, E):
     """Odd hidden widths (the reference's D-VAE default is 501; nothing in `ogbg-code/model/dagnn.py` asks for an even one):
     the padded units of every path, and the weight-gradient kernel's paired input columns (engine.wgrad), on a full

@@ -23,7 +23,7 @@ from .core import DerivedCache, default_schedule, derive_cell, pack_lockstep, ru
 from .data import GraphBatch
 
 OWN_LINEAR_MAX = 1 << 22   # multiply-adds up to which the final Linear of an evaluation pass runs on dagnn_gemm_nt_bias (see forward)
-from .model import _EdgeAttnParams
+from .model import _EdgeAttnParams, _SelfAttnParams
 
 
 class _DvaeBase(nn.Module):
@@ -87,17 +87,23 @@ class _DvaeDagnn(_DvaeBase):
         self.emb_dim = emb_dim
         self.hidden_dim = hidden_dim
         self.out_hidden_dim = emb_dim + hidden_dim * num_layers if out_wx else hidden_dim * num_layers
-        if agg != K.NA_ATTN_H:
-            raise NotImplementedError("only agg='attn_h' is implemented for the D-VAE encoders so far")
+        if agg not in (K.NA_ATTN_H, K.NA_SELF_ATTN_H):
+            raise NotImplementedError("the D-VAE encoders implement agg='attn_h' (the reference's default, dvae/train.py:86) "
+                                      "and 'self_attn_h' so far")
         extra = num_nodes if self._use_vids else 0
         pred_dim = hidden_dim + extra
         attn_dim = hidden_dim + extra
-        self.node_aggr_0 = nn.ModuleList([
-            _EdgeAttnParams(emb_dim if l == 0 else attn_dim, pred_dim, num_relations=1, attn_dim=attn_dim)
-            for l in range(num_layers)])
-        self.node_aggr_1 = nn.ModuleList([
-            _EdgeAttnParams(emb_dim if l == 0 else attn_dim, pred_dim, num_relations=1, attn_dim=attn_dim,
-                            reverse=True) for l in range(num_layers)])
+        if agg == K.NA_SELF_ATTN_H:   # keys scored alone: `attn_lin` has no query half (dvae/dagnn.py:49-54, 301-312)
+            self.node_aggr_0 = nn.ModuleList([_SelfAttnParams(attn_dim, num_relations=1) for _ in range(num_layers)])
+            self.node_aggr_1 = nn.ModuleList([_SelfAttnParams(attn_dim, num_relations=1, reverse=True)
+                                              for _ in range(num_layers)])
+        else:
+            self.node_aggr_0 = nn.ModuleList([
+                _EdgeAttnParams(emb_dim if l == 0 else attn_dim, pred_dim, num_relations=1, attn_dim=attn_dim)
+                for l in range(num_layers)])
+            self.node_aggr_1 = nn.ModuleList([
+                _EdgeAttnParams(emb_dim if l == 0 else attn_dim, pred_dim, num_relations=1, attn_dim=attn_dim,
+                                reverse=True) for l in range(num_layers)])
         # the cells ARE the base class's encoder GRUs (aliased names, dvae/dagnn.py:73-75)
         self.cells_0 = self.grue_forward
         if bidirectional:
@@ -123,7 +129,7 @@ class _DvaeDagnn(_DvaeBase):
                 for i in range(self.num_layers):
                     c = getattr(self, "cells_%d" % d)[i]
                     a = getattr(self, "node_aggr_%d" % d)[i]
-                    dq = self.emb_dim if i == 0 else self.hidden_dim + extra
+                    dq = self._key_offset(i)
                     out[(d, i)] = derive_cell(c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh, a.attn_lin.weight,
                                               self.hidden_dim, dq, i > 0, None, extra, schedule=self.schedule,
                                               pack=False, stacked=self.num_layers)
@@ -145,6 +151,9 @@ class _DvaeDagnn(_DvaeBase):
         return self.num_nodes if self._use_vids else 0
 
     def _key_offset(self, i: int) -> int:
+        """Where the key half of `attn_lin.weight` starts: behind the query half - which `self_attn_h` does not have."""
+        if self.agg == K.NA_SELF_ATTN_H:
+            return 0
         return self.emb_dim if i == 0 else self.hidden_dim + self._vid_nodes
 
     def _static_scores(self, x, cells):
@@ -299,6 +308,9 @@ class _DvaeDagnn(_DvaeBase):
         layer above (`H` is no longer None in the later iterations of the reference's loop).  The host side only
         gathers the igraph-style inputs into dense tensors and writes the new states back into the vertices."""
         assert not reverse
+        if self.agg == K.NA_SELF_ATTN_H:
+            raise NotImplementedError("the decoder-side step with agg='self_attn_h': the reference's own SelfAttnConv calls an "
+                                      "undefined `attn_linear` on this path (dvae/dagnn.py:317-321)")
         G = [g for g in G if g.vcount() > v]
         if len(G) == 0:
             return None

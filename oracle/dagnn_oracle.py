@@ -383,16 +383,19 @@ def code2_grads(sd: Dict[str, Tensor], G, y: Tensor, *, dtype: torch.dtype = tor
 def dvae_forward(sd: Dict[str, Tensor], G, *, num_layers: int = 2, bidirectional: bool = False,
                  num_nodes: int = 8, vids: bool = True, mode: str = "csr",
                  dtype: torch.dtype = torch.float32, keep_graph: bool = False, out_pool_all: bool = False,
-                 out_pool: str = "max") -> Tensor:
+                 out_pool: str = "max", agg: str = "attn_h") -> Tensor:
     """`DAGNN.forward` of `dvae/dagnn.py:99-175` (`vids=True`, NA) or `DAGNN_BN.forward` of
     `dvae/dagnn_bn.py:98-168` (`vids=False`), `out_pool_all=False`: read-out = the end vertex of
-    every graph for d=0 and the start vertex for d=1 (fixed stride `num_nodes`)."""
+    every graph for d=0 and the start vertex for d=1 (fixed stride `num_nodes`).  `agg`: `attn_h` or `self_attn_h`
+    (`dvae/dagnn.py:49-59`: `SelfAttnConv` scores the keys alone - no query half in `attn_lin`)."""
     sd = _cast(sd, dtype, keep_graph)
     dirs = [0, 1] if bidirectional else [0]
     H = sd["cells_0.0.weight_hh"].shape[1]
     x = G.x.to(dtype)
     layers = [G.bi_layer_index[0][0], G.bi_layer_index[1][0]]
-    cfg = _Cfg(sd, dirs, num_layers, H, "cells_", False, num_nodes if vids else 0)
+    if agg not in ("attn_h", "self_attn_h"):
+        raise NotImplementedError(agg)
+    cfg = _Cfg(sd, dirs, num_layers, H, "cells_", False, num_nodes if vids else 0, agg)
     rec = recurrence_faithful if mode == "faithful" else recurrence_csr
     h = rec(cfg, x, G.edge_index, None, layers)
     N = x.shape[0]

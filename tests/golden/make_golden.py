@@ -179,7 +179,7 @@ def _dvae_case(model, graphs, ref_batch_mod):
 
 
 def make_na(ref_na, ref_util, ref_batch_mod, name, *, hs, L, bidir, w_seed, nrows=64, out_pool_all=False,
-            out_pool="max"):
+            out_pool="max", agg="attn_h"):
     rows = []
     with open(os.path.join(REF, "dvae", "data", "final_structures6.txt")) as f:
         for i, line in enumerate(f):
@@ -189,13 +189,13 @@ def make_na(ref_na, ref_util, ref_batch_mod, name, *, hs, L, bidir, w_seed, nrow
             if len(rows) == nrows:
                 break
     graphs = [ref_util.decode_ENAS_to_pygraph(r)[0] for r in rows]
-    model = ref_na.DAGNN(8, hs, hs, 8, 8, 0, 1, hs=hs, nz=56, num_nodes=8, agg="attn_h", num_layers=L,
+    model = ref_na.DAGNN(8, hs, hs, 8, 8, 0, 1, hs=hs, nz=56, num_nodes=8, agg=agg, num_layers=L,
                          bidirectional=bidir, out_wx=False, out_pool_all=out_pool_all, out_pool=out_pool,
                          dropout=0.0).eval()
     seeded_fill(model, w_seed)
     b, Hg, mu, logvar = _dvae_case(model, graphs, ref_batch_mod)
     meta = dict(kind="na", hs=hs, L=L, bidir=bool(bidir), w_seed=w_seed, nrows=nrows, out_pool_all=out_pool_all,
-                out_pool=out_pool,
+                out_pool=out_pool, agg=agg,
                 state_dict={k: list(v.shape) for k, v in model.state_dict().items()})
     _save(name, meta, rows=np.array([json.dumps(r) for r in rows]),
           x=_np(b.x), edge_index=_np(b.edge_index), bi_layer_index=_np(b.bi_layer_index), batch=_np(b.batch_before), batch_after=_np(b.batch),
@@ -203,16 +203,16 @@ def make_na(ref_na, ref_util, ref_batch_mod, name, *, hs, L, bidir, w_seed, nrow
 
 
 def make_bn(ref_bn, ref_util, ref_batch_mod, name, *, hs, L, bidir, w_seed, data_seed, nrows, out_pool_all=False,
-            out_pool="max"):
+            out_pool="max", agg="attn_h"):
     rows = synth.bn_rows(data_seed, nrows)
     graphs = [ref_util.decode_BN_to_pygraph(r)[0] for r in rows]
-    model = ref_bn.DAGNN_BN(10, hs, hs, 10, 10, 0, 1, hs=hs, nz=56, num_nodes=10, agg="attn_h", num_layers=L,
+    model = ref_bn.DAGNN_BN(10, hs, hs, 10, 10, 0, 1, hs=hs, nz=56, num_nodes=10, agg=agg, num_layers=L,
                             bidirectional=bidir, out_wx=False, out_pool_all=out_pool_all, out_pool=out_pool,
                             dropout=0.0).eval()
     seeded_fill(model, w_seed)
     b, Hg, mu, logvar = _dvae_case(model, graphs, ref_batch_mod)
     meta = dict(kind="bn", hs=hs, L=L, bidir=bool(bidir), w_seed=w_seed, data_seed=data_seed, nrows=nrows,
-                out_pool_all=out_pool_all, out_pool=out_pool,
+                out_pool_all=out_pool_all, out_pool=out_pool, agg=agg,
                 state_dict={k: list(v.shape) for k, v in model.state_dict().items()})
     _save(name, meta, rows=np.array([json.dumps(r) for r in rows]),
           x=_np(b.x), edge_index=_np(b.edge_index), bi_layer_index=_np(b.bi_layer_index), batch=_np(b.batch_before), batch_after=_np(b.batch),
@@ -318,7 +318,7 @@ def _dvae_grad_case(model, graphs, name, meta, seed):
     return meta, arrays
 
 
-def make_na_grad(ref_na, ref_util, name, *, hs, L, bidir, w_seed, nrows):
+def make_na_grad(ref_na, ref_util, name, *, hs, L, bidir, w_seed, nrows, agg="attn_h"):
     rows = []
     with open(os.path.join(REF, "dvae", "data", "final_structures6.txt")) as f:
         for i, line in enumerate(f):
@@ -328,22 +328,22 @@ def make_na_grad(ref_na, ref_util, name, *, hs, L, bidir, w_seed, nrows):
             if len(rows) == nrows:
                 break
     graphs = [ref_util.decode_ENAS_to_pygraph(r)[0] for r in rows]
-    model = ref_na.DAGNN(8, hs, hs, 8, 8, 0, 1, hs=hs, nz=56, num_nodes=8, agg="attn_h", num_layers=L,
+    model = ref_na.DAGNN(8, hs, hs, 8, 8, 0, 1, hs=hs, nz=56, num_nodes=8, agg=agg, num_layers=L,
                          bidirectional=bidir, out_wx=False, out_pool_all=False, out_pool="max", dropout=0.0)
     seeded_fill(model, w_seed)
     meta, arrays = _dvae_grad_case(model, graphs, name, dict(kind="na", hs=hs, L=L, bidir=bool(bidir), w_seed=w_seed,
-                                                                nrows=nrows), 401)
+                                                                nrows=nrows, agg=agg), 401)
     _save(name, meta, rows=np.array([json.dumps(r) for r in rows]), **arrays)
 
 
-def make_bn_grad(ref_bn, ref_util, name, *, hs, L, bidir, w_seed, data_seed, nrows):
+def make_bn_grad(ref_bn, ref_util, name, *, hs, L, bidir, w_seed, data_seed, nrows, agg="attn_h"):
     rows = synth.bn_rows(data_seed, nrows)
     graphs = [ref_util.decode_BN_to_pygraph(r)[0] for r in rows]
-    model = ref_bn.DAGNN_BN(10, hs, hs, 10, 10, 0, 1, hs=hs, nz=56, num_nodes=10, agg="attn_h", num_layers=L,
+    model = ref_bn.DAGNN_BN(10, hs, hs, 10, 10, 0, 1, hs=hs, nz=56, num_nodes=10, agg=agg, num_layers=L,
                             bidirectional=bidir, out_wx=False, out_pool_all=False, out_pool="max", dropout=0.0)
     seeded_fill(model, w_seed)
     meta, arrays = _dvae_grad_case(model, graphs, name, dict(kind="bn", hs=hs, L=L, bidir=bool(bidir), w_seed=w_seed,
-                                                                data_seed=data_seed, nrows=nrows), 402)
+                                                                data_seed=data_seed, nrows=nrows, agg=agg), 402)
     _save(name, meta, rows=np.array([json.dumps(r) for r in rows]), **arrays)
 
 
@@ -379,6 +379,20 @@ def _dvae_default_hs():
     make_bn_grad(ref_bn, ref_util, "grad_bn_h501_bidir", hs=501, L=2, bidir=True, w_seed=234, data_seed=10, nrows=10)
 
 
+def _dvae_self_attn():
+    """The D-VAE encoders with `agg='self_attn_h'` (`dvae/dagnn.py:49-54`: keys scored alone, no query half)."""
+    ref_util = importlib.import_module("util")
+    ref_batch_mod = importlib.import_module("batch")
+    ref_na = importlib.import_module("dagnn")
+    ref_bn = importlib.import_module("dagnn_bn")
+    make_na(ref_na, ref_util, ref_batch_mod, "na_h64_self_attn_h", hs=64, L=2, bidir=True, w_seed=241, nrows=16, agg="self_attn_h")
+    make_bn(ref_bn, ref_util, ref_batch_mod, "bn_h128_self_attn_h", hs=128, L=2, bidir=True, w_seed=242, data_seed=11, nrows=12,
+            agg="self_attn_h")
+    make_na_grad(ref_na, ref_util, "grad_na_h64_self_attn_h", hs=64, L=2, bidir=False, w_seed=243, nrows=16, agg="self_attn_h")
+    make_bn_grad(ref_bn, ref_util, "grad_bn_h64_self_attn_h", hs=64, L=2, bidir=True, w_seed=244, data_seed=12, nrows=12,
+                 agg="self_attn_h")
+
+
 def _dvae_only():
     ref_util = importlib.import_module("util")
     ref_na = importlib.import_module("dagnn")
@@ -408,6 +422,8 @@ def main():
         return _ipropagate_only()
     if only == "dvae_default_hs":
         return _dvae_default_hs()
+    if only == "dvae_self_attn":
+        return _dvae_self_attn()
     # training-step gradients: loss and parameter gradients of one step
     if True:
         make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, "grad_h32_bidir", data_seed=11, B=6, mean_n=30, H=32,
@@ -501,6 +517,7 @@ def main():
             nrows=12, out_pool_all=True, out_pool="mean")
     _ipropagate_only()   # decoder-side single-vertex step (needs the igraph stand-in)
     _dvae_default_hs()
+    _dvae_self_attn()
 
 
 if __name__ == "__main__":

@@ -24,9 +24,11 @@ GRAD = ["grad_h32_bidir", "grad_h256_bidir", "grad_h128_deep", "grad_h64_L3_wx",
 GRAD_VAR = ["grad_var_h64_" + t for t in ("gated_sum", "gated_nobias", "mattn_h", "add", "mattn_h_L3", "max", "recurr0_gated",
                                            "recurr0_mattn", "recurr0_attn_h", "recurr0_attn_x", "recurr0_self_attn_h",
                                            "aggx_attn_h", "aggx_add", "aggx_gated", "aggx_mattn", "aggx_max_recurr0")]
-DVAE_GRAD = ["grad_na_h64_unidir", "grad_bn_h64_bidir", "grad_na_h501_unidir", "grad_bn_h501_bidir"]
+DVAE_GRAD = ["grad_na_h64_unidir", "grad_bn_h64_bidir", "grad_na_h501_unidir", "grad_bn_h501_bidir",
+             "grad_na_h64_self_attn_h", "grad_bn_h64_self_attn_h"]
 DVAE = ["na_h128_unidir", "na_h64_bidir", "bn_h256_bidir", "bn_h64_unidir", "na_h64_poolall_max", "bn_h64_poolall_mean",
-        "na_h501_unidir", "bn_h501_bidir"]   # the last two: the reference's default width (dvae/train.py:55)
+        "na_h501_unidir", "bn_h501_bidir",   # the reference's default width (dvae/train.py:55)
+        "na_h64_self_attn_h", "bn_h128_self_attn_h"]   # agg='self_attn_h' (dvae/dagnn.py:49-54)
 
 
 def load(name):
@@ -65,7 +67,7 @@ def dvae_graphs(meta, arr):
 def dvae_model(meta):
     cls, nn_ = (DAGNN_NA, 8) if meta["kind"] == "na" else (DAGNN_BN, 10)
     hs = meta["hs"]
-    model = cls(nn_, hs, hs, nn_, nn_, 0, 1, hs=hs, nz=56, num_nodes=nn_, agg="attn_h", num_layers=meta["L"],
+    model = cls(nn_, hs, hs, nn_, nn_, 0, 1, hs=hs, nz=56, num_nodes=nn_, agg=meta.get("agg", "attn_h"), num_layers=meta["L"],
                 bidirectional=meta["bidir"], out_wx=False, out_pool_all=meta.get("out_pool_all", False),
                 out_pool=meta.get("out_pool", "max"), dropout=0.0).eval()
     seeded_fill(model, meta["w_seed"])

@@ -50,7 +50,8 @@ def test_dvae_oracle_matches_reference(name, mode):
     G = Hh.dvae_batch(arr)
     mu, logvar = O.dvae_encode(model.state_dict(), G, num_layers=meta["L"], bidirectional=meta["bidir"],
                                num_nodes=nn_, vids=meta["kind"] == "na", mode=mode,
-                               out_pool_all=meta.get("out_pool_all", False), out_pool=meta.get("out_pool", "max"))
+                               out_pool_all=meta.get("out_pool_all", False), out_pool=meta.get("out_pool", "max"),
+                               agg=meta.get("agg", "attn_h"))
     assert Hh.maxdiff(mu, arr["mu"]) < TOL
     assert Hh.maxdiff(logvar, arr["logvar"]) < TOL
 
@@ -115,6 +116,6 @@ def test_oracle_dvae_encoder_gradients_match_reference(name):
     G = dagnn_amd.GraphBatch.from_data_list(Hh.dvae_graphs(meta, arr))
     loss, grads = O.dvae_grads(model.state_dict(), G, torch.from_numpy(arr["r1"]), torch.from_numpy(arr["r2"]),
                                num_layers=meta["L"], bidirectional=meta["bidir"], num_nodes=nn_,
-                               vids=meta["kind"] == "na")
+                               vids=meta["kind"] == "na", agg=meta.get("agg", "attn_h"))
     assert abs(float(loss) - float(arr["loss"])) < 1e-4 * max(1.0, abs(float(arr["loss"])))
     assert Hh.check_grads(meta, arr, grads, rtol=5e-5) < 5e-5

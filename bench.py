@@ -308,6 +308,15 @@ def other_configs(device):
                     "per chunk of stacked layers) and on dagnn_frontier_run alone (launches_ms: a launch per topological layer)",
             "cfg5_batch": tk, "half_batch_B128": tk_half,
             "default_max_nodes": int(_eng.TILES_MAX_NODES)}
+        # BASELINE.json quotes cfg 5 on 8 GPUs: under the reference's split of a batch over the devices (tg/dataloader.py:17-27)
+        # a rank holds 32 of the 256 graphs - timed here on the first such shard, default policy and per-layer launches
+        shard = synth.code2_batch(seed=0, num_graphs=32).to(device)   # (graphs are drawn one after another: the first 32 of the 256)
+        tk_shard = both(shard, 5)
+        out["cfg5_code2_B256_h512_L5_bidir"]["one_of_eight_shards_B32"] = {
+            "what": "graphs 0..31 of the cfg 5 batch (one rank's share on 8 GPUs, no data-path collective): default policy "
+                    "(split_ms: here the tile kernel alone), tile kernel forced, per-layer launches",
+            "nodes": int(shard.x.shape[0]), **tk_shard,
+            "graphs_per_s_x8": round(8 * 32 / tk_shard["split_ms"] * 1e3, 1)}
         del m5
     return out
 

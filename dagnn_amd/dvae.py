@@ -115,12 +115,20 @@ class _DvaeDagnn(_DvaeBase):
         self.schedule = default_schedule()  # 'lockstep' (frontier launches) or 'pergraph' (persistent workgroups)
 
     def _cells(self, fresh: bool = False):
+        # (the registries are read directly: `getattr(self, "cells_0")[i].weight_ih` is three trips through
+        # nn.Module.__getattr__ - 15 us for the ten tensors of cfg 1, whose forward is host-bound; same objects, always current)
         srcs: List[torch.Tensor] = []
+        mods = self._modules
         for d in self.dirs:
+            cells, aggrs = mods["cells_%d" % d]._modules, mods["node_aggr_%d" % d]._modules
             for i in range(self.num_layers):
-                c = getattr(self, "cells_%d" % d)[i]
-                a = getattr(self, "node_aggr_%d" % d)[i]
-                srcs += [c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh, a.attn_lin.weight]
+                c, a = cells[str(i)], aggrs[str(i)]._modules["attn_lin"]
+                cp = c._parameters
+                for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                    t = cp.get(name)
+                    srcs.append(t if t is not None else getattr(c, name))   # (a re-parametrised weight is a plain attribute)
+                t = a._parameters.get("weight")
+                srcs.append(t if t is not None else a.weight)
         extra = self.num_nodes if self._use_vids else 0
 
         def make():

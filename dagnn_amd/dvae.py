@@ -175,8 +175,11 @@ class _DvaeDagnn(_DvaeBase):
         check_arenas(self)
 
     def _arena_for(self, x, role="forward"):
-        return self._arenas.setdefault((role, x.device, torch.cuda.current_stream(x.device).cuda_stream),
-                                       engine.GranuleArena())
+        key = (role, x.device, engine._stream(x))   # one arena per stream: passes on different streams may overlap
+        arena = self._arenas.get(key)
+        if arena is None:
+            arena = self._arenas[key] = engine.GranuleArena()
+        return arena
 
     def _readout(self, plan, B, x, h):
         """End vertex of every graph for d = 0, start vertex for d = 1 (dvae/dagnn.py:147-161, dagnn_bn.py:138-152)."""

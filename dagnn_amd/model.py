@@ -247,8 +247,11 @@ class DAGNN(nn.Module):
         check_arenas(self)
 
     def _arena_for(self, x, role="forward"):
-        return self._arenas.setdefault((role, x.device, torch.cuda.current_stream(x.device).cuda_stream),
-                                       engine.GranuleArena())
+        key = (role, x.device, engine._stream(x))   # one arena per stream: passes on different streams may overlap
+        arena = self._arenas.get(key)
+        if arena is None:
+            arena = self._arenas[key] = engine.GranuleArena()
+        return arena
 
     def _training_pass(self) -> bool:
         """True when this call must be differentiable.  The HIP backward (csrc/backward.hip) covers what the

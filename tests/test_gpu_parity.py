@@ -151,7 +151,7 @@ def test_encoder_kernel(device, H):
 
 
 @pytest.mark.parametrize("M,Nc,K", [(1, 96, 8), (77, 768, 10), (300, 384, 256), (1000, 900, 300), (129, 1536, 512),
-                                     (4099, 768, 256)])
+                                     (4099, 768, 256), (64, 128, 256), (515, 96, 32), (2049, 300, 100)])   # (the last three, and the first: the small-matrix kernel)
 def test_gemm_nt_bias(device, M, Nc, K):
     g = torch.Generator().manual_seed(M + Nc + K)
     A = torch.randn(M, K, generator=g)

@@ -297,6 +297,8 @@ struct DfLds {
     int* rdy;        // [NLS][WPS]  per loader wave: blocks it has finished (relaxed workgroup-scope atomics: plain ds_ accesses;
     int* dn;         // [NLS][NCW]  per stream and compute wave likewise   a volatile access here compiles to a FLAT load + vmcnt(0))
     int* local;      // [1] every reader of this cell's state rows runs on this workgroup's XCD (see DfArgs::role)
+    float* bias;     // [3][DF_JS] the slice's biases, gate-major (the thin-block path evaluates other units per lane than the
+                     // MFMA path, whose lanes keep their three biases in registers)
 };
 
 template <int KPT> struct DfSlot {
@@ -667,6 +669,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                 }
                 c0 += 4;
             } while (c0 < deg);
+            if (prof) { asm volatile("" :: "v"(acc[0]), "v"(acc[3]), "v"(l)); dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + set) + 4] = wall_clock64(); }   // fold done
             if (deg > 1) {   // PyG softmax: exp(x - max) / (sum + 1e-16)
                 const float inv = __builtin_amdgcn_rcpf(l + 1e-16f);
 #pragma unroll
@@ -687,6 +690,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
         }
         if (lane == 0) v_s[lw] = v;
       }
+        if (prof_wave) dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64();   // LDS writes issued
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) df_flag_st(lds.rdy + set * DF_WPS + w, b + 1);
         if (prof_wave) dbg[8 * (int64_t)(DF_NLS * b + set) + 3] = wall_clock64();
@@ -764,8 +768,10 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     const int unit_l = 8 * cw + 4 * quad + 2 * (ks & 1) + ((ks >> 1) & 1), unit = sl * DF_JS + unit_l;   // after the reduction
     float b_r = C.bias[unit], b_z = C.bias[H + unit], b_n = C.bias[2 * H + unit];
     asm volatile("" : "+v"(b_r), "+v"(b_z), "+v"(b_n));   // landed before the loop (see the weights above)
-    const int gr = x;   // row of the block this lane evaluates the gates of
     const int apos = unit + (SEG - KP8) * (unit / KP8);   // LDS position of column `unit` of an operand row
+    // the thin-block path (below): this lane's unit there and its LDS position
+    const int unit_lt = 8 * cw + 4 * quad + x, unit_t = sl * DF_JS + unit_lt;
+    const int apos_t = unit_t + (SEG - KP8) * (unit_t / KP8);
     const unsigned epoch = S.epoch, spin_limit = S.spin_limit;
     int* const err = S.err;
     float* const h_out = C.h_out;
@@ -847,19 +853,64 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
         const float* sbase = lds.ring + (st * DF_NSLOT + slot) * Slot::words;
         if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 0] = wall_clock64();
         const int4 ids = *reinterpret_cast<const int4*>(sbase + Slot::v_off);
-        const int nr = (ids.x >= 0) + (ids.y >= 0) + (ids.z >= 0) + (ids.w >= 0);   // live records come first
-        const float* a_seg = sbase + Slot::a_off + x * Slot::AP + ks * SEG;   // B operand: row x, K slice ks
+        const int nr = __builtin_amdgcn_readfirstlane((ids.x >= 0) + (ids.y >= 0) + (ids.z >= 0) + (ids.w >= 0));   // live records come first
+        // Blocks of <= DF_FMA_ROWS live rows (the dependent chain of a deep graph is one such block per layer) skip the
+        // matrix cores: v_mfma_f32_4x4x1 spends 3 H/8 x 8 cycles on a block whatever it holds, the same lanes' plain FMAs
+        // 3 H/8 x 2 cycles per live row.  The lane keeps its role on the K side (unit 4 quad + x, K slice ks) and sums ITS
+        // unit's partial dot products in the MFMA's order (k ascending, one fused multiply-add per k: bitwise the matrix
+        // core's accumulator); the 8 K slices are added by a butterfly along the reduce-scatter's tree (pairs of ks bit 0,
+        // then bit 1, then bit 2: fp32 addition commutes, so every sum has the bits the MFMA path gives it) - a row's value
+        // does not depend on the path its block takes.  Afterwards lane (quad, ks = row, x) holds unit 4 quad + x of row ks.
+        const bool thin = DF_FMA_ROWS > 0 && nr <= DF_FMA_ROWS;
+        if (prof) dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + st) + 0] = wall_clock64();   // ids landed
+        const int gr = thin ? ks : x;                 // row of the block this lane evaluates the gates of
+        const int unit_ls = thin ? unit_lt : unit_l;  // ... and its unit inside the slice
+        const int unit_s = sl * DF_JS + unit_ls;
         // operands of the gate algebra: requested now, used after the products
         float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, aval = 0.f;
+        float c_r = b_r, c_z = b_z, c_n = b_n;
+        if (thin) { c_r = lds.bias[unit_lt]; c_z = lds.bias[DF_JS + unit_lt]; c_n = lds.bias[2 * DF_JS + unit_lt]; }
         if (!proj && gr < nr) {
             if (has_gi) {   // from the gi0 ring (stacked layer 0) or from the slot (projection granules)
-                const float* gp = (gi_ring ? lds.giring + (st * DF_GIRING + b % DF_GIRING) * (DF_RB * 3 * DF_JS) : sbase + Slot::gi_off) + gr * (3 * DF_JS) + unit_l;
+                const float* gp = (gi_ring ? lds.giring + (st * DF_GIRING + b % DF_GIRING) * (DF_RB * 3 * DF_JS) : sbase + Slot::gi_off) + gr * (3 * DF_JS) + unit_ls;
                 gi_r = gp[0]; gi_z = gp[DF_JS]; gi_n = gp[2 * DF_JS];
             }
-            aval = sbase[Slot::a_off + gr * Slot::AP + apos];
+            aval = sbase[Slot::a_off + gr * Slot::AP + (thin ? apos_t : apos)];
         }
-        float g3[3];
-        {
+        float g3[3] = {0.f, 0.f, 0.f};
+        if (thin) {
+#pragma unroll 1
+            for (int r = 0; r < nr; ++r) {
+                const float* a_row = sbase + Slot::a_off + r * Slot::AP + ks * SEG;   // row r, K slice ks (a broadcast read over x and quad)
+                float4 bv[NK4];
+#pragma unroll
+                for (int q = 0; q < NK4; ++q) bv[q] = *reinterpret_cast<const float4*>(a_row + 4 * q);
+                if (prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + st) + 1] = wall_clock64(); }   // operands landed
+                float p3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < NK4; ++q) {
+                    const float bq[4] = {bv[q].x, bv[q].y, bv[q].z, bv[q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        p3[0] = __builtin_fmaf(wr[4 * q + e], bq[e], p3[0]);
+                        p3[1] = __builtin_fmaf(wz[4 * q + e], bq[e], p3[1]);
+                        p3[2] = __builtin_fmaf(wn[4 * q + e], bq[e], p3[2]);
+                    }
+                }
+                if (prof) { asm volatile("" :: "v"(p3[0]), "v"(p3[1]), "v"(p3[2])); dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + st) + 2] = wall_clock64(); }   // products done
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    // (every DPP op outside the selects, as below)
+                    const float up4 = p3[a] + df_dpp<0x104>(p3[a]), dn4 = p3[a] + df_dpp<0x114>(p3[a]);
+                    const float t1 = s0 ? dn4 : up4;
+                    const float up8 = t1 + df_dpp<0x108>(t1), dn8 = t1 + df_dpp<0x118>(t1);
+                    const float t2 = s1 ? dn8 : up8;
+                    const float t3 = df_row_pair_sum(t2);
+                    g3[a] = ks == r ? t3 : g3[a];
+                }
+            }
+        } else {
+            const float* a_seg = sbase + Slot::a_off + x * Slot::AP + ks * SEG;   // B operand: row x, K slice ks
             float4 bv[NK4];
 #pragma unroll
             for (int q = 0; q < NK4; ++q) bv[q] = *reinterpret_cast<const float4*>(a_seg + 4 * q);
@@ -894,30 +945,31 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
         float hv = 0.f;
         if (live) {
             if (!proj) {
-                const float rg = df_sigm(g3[0] + b_r + gi_r);
-                const float zg = df_sigm(g3[1] + b_z + gi_z);
-                const float ng = df_tanh(fmaf(rg, g3[2] + b_n, gi_n));
+                const float rg = df_sigm(g3[0] + c_r + gi_r);
+                const float zg = df_sigm(g3[1] + c_z + gi_z);
+                const float ng = df_tanh(fmaf(rg, g3[2] + c_n, gi_n));
                 hv = fmaf(zg, aval - ng, ng);   // n + z * (a - n)
             }
         }
+        if (prof) { asm volatile("" :: "v"(hv)); dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + st) + 3] = wall_clock64(); }   // gates done
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) df_flag_st(lds.dn + st * DF_NCW + cw, b + 1);   // this wave is done with the slot (LDS executes a wave's accesses in order)
         if (live) {
             if (proj) {   // input-side pre-activations of the upper cell: W_ih u + b_ih, gate-major
-                gran_t* po = g_out + (int64_t)gv * pld + unit;
-                __hip_atomic_store(po, gran_pack(epoch, g3[0] + b_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(po + H, gran_pack(epoch, g3[1] + b_z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(po + 2 * H, gran_pack(epoch, g3[2] + b_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gran_t* po = g_out + (int64_t)gv * pld + unit_s;
+                __hip_atomic_store(po, gran_pack(epoch, g3[0] + c_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(po + H, gran_pack(epoch, g3[1] + c_z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(po + 2 * H, gran_pack(epoch, g3[2] + c_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
-                h_out[(int64_t)gv * ld_h + unit] = hv;
+                h_out[(int64_t)gv * ld_h + unit_s] = hv;
                 // hand-off store: write-through (sc1: the line leaves this XCD's L2, any XCD's sc1 load finds it in
                 // memory), or - all readers are on this XCD - a plain 8-byte store that leaves the line in the shared L2
-                if (local_st) g_out[(int64_t)gv * gld + unit] = gran_pack(epoch, hv);
-                else __hip_atomic_store(g_out + (int64_t)gv * gld + unit, gran_pack(epoch, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (local_st) g_out[(int64_t)gv * gld + unit_s] = gran_pack(epoch, hv);
+                else __hip_atomic_store(g_out + (int64_t)gv * gld + unit_s, gran_pack(epoch, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (aux_out) {   // (behind the hand-off stores: nobody waits for these)
-                float* ao = aux_out + (int64_t)gv * (3 * H) + unit;
-                ao[0] = g3[0] + b_r; ao[H] = g3[1] + b_z; ao[2 * H] = g3[2] + b_n;
+                float* ao = aux_out + (int64_t)gv * (3 * H) + unit_s;
+                ao[0] = g3[0] + c_r; ao[H] = g3[1] + c_z; ao[2 * H] = g3[2] + c_n;
             }
         }
         if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 2] = wall_clock64();
@@ -960,7 +1012,10 @@ __global__ void __launch_bounds__(DF_THREADS, 3) dataflow_kernel(const int32_t* 
     lds.rdy = flags;
     lds.dn = flags + DF_NLW;
     lds.local = flags + DF_NLW + DF_NLS * DF_NCW;
+    lds.bias = reinterpret_cast<float*>(flags + 32);
     if (tid < DF_NLW + DF_NLS * DF_NCW + 1) flags[tid] = 0;
+    static_assert(DF_NLW + DF_NLS * DF_NCW + 1 <= 32, "flag words");
+    if (tid >= 64 && tid < 64 + 3 * DF_JS) lds.bias[tid - 64] = C.bias[((tid - 64) / DF_JS) * (16 * KPT) + sl * DF_JS + (tid - 64) % DF_JS];
     if (S.nroles > 0 && wave == 0) {
         // where does this workgroup really run?  Publish it, and - recurrent cells - look where the readers of this cell's
         // state rows run: its own slices and the slices of the projection cell above it, same workgroup set
@@ -1023,7 +1078,7 @@ __global__ void __launch_bounds__(DF_THREADS, 3) dataflow_kernel(const int32_t* 
 }
 
 template <int KPT> size_t df_lds_bytes() {
-    return (size_t)DF_NLS * (DF_NSLOT * DfSlot<KPT>::words + DF_GIRING * DF_RB * 3 * DF_JS + DF_RB * 8 * 16) * 4 + 256;
+    return (size_t)DF_NLS * (DF_NSLOT * DfSlot<KPT>::words + DF_GIRING * DF_RB * 3 * DF_JS + DF_RB * 8 * 16) * 4 + 128 + 3 * DF_JS * 4 + 128;
 }
 
 // Pack W [3H, K = H] (torch GRUCell layout) for the dataflow kernel: out[(sl * NQ + q) * 256 + tc] (float4), NQ = 3 H/32,

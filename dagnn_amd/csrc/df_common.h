@@ -31,6 +31,14 @@ constexpr int DF_WPS = DF_NLW / DF_NLS;     // ... per stream
 constexpr int DF_RPW = DF_RB / DF_WPS;      // rows of a block per loader wave (one after the other)
 static_assert(DF_NLS == 2 || DF_NLS == 4 || DF_NLS == 8, "streams per workgroup");
 constexpr int DF_THREADS = 64 * (DF_NCW * DF_TEAMS + DF_NLW);
+#ifndef DF_FMA_ROWS_V
+#define DF_FMA_ROWS_V 0
+#endif
+constexpr int DF_FMA_ROWS = DF_FMA_ROWS_V;    // forward kernel: blocks of at most this many live rows run their products as plain FMAs
+                                              // (dataflow.hip, df_compute), 0 = every block on v_mfma_f32_4x4x1.  Measured (round 4): bitwise the
+                                              // MFMA path's values, but 1.54 (2 rows) / 1.565 (1 row) against 1.50 ms per forward - ONE wave issues
+                                              // an independent VALU op every ~5.4 cycles (scripts/ubench/branch_cost.hip), so 96 FMAs per row cost it
+                                              // ~520 cycles against 768 for the 96 MFMAs, and the butterfly behind them eats the difference: off.
 constexpr int DF_MAX_GROUPS = 64;
 constexpr int DF_MAGIC = 0x44463031;   // "DF01"
 

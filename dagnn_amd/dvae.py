@@ -26,6 +26,85 @@ OWN_LINEAR_MAX = 1 << 22   # multiply-adds up to which the final Linear of an ev
 from .model import _EdgeAttnParams, _SelfAttnParams
 
 
+class _CellView:
+    """The four GRUCell tensors `engine.iprop_step` reads, without the module around them."""
+    __slots__ = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
+
+    def __init__(self, w_ih, w_hh, b_ih, b_hh):
+        self.weight_ih, self.weight_hh, self.bias_ih, self.bias_hh = w_ih, w_hh, b_ih, b_hh
+
+
+def _iprop_dense(values, pred_vid, w_key, vid_bias, H, X, cells):
+    """The decoder-side step as dense device-side torch ops, the form its reverse pass differentiates (`dvae/dagnn.py:187-239`):
+    padded slots score 0 (their key is a zero row, and the query term `w_q.q + b` is common to every slot of a soft-max
+    row, so it cancels - the query half of `attn_lin` and its bias get exact zero gradients), the aggregate of the
+    layer-0 states feeds every stacked layer."""
+    B = X.shape[0]
+    if H is None:
+        if values is None or values.shape[1] == 0:
+            H = X.new_zeros(B, cells[0].weight_hh.shape[1])
+        else:
+            scores = values @ w_key
+            if vid_bias is not None:
+                real = pred_vid >= 0
+                scores = scores + torch.where(real, vid_bias[pred_vid.clamp(min=0).long()], torch.zeros_like(scores))
+            H = torch.einsum("bp,bpj->bj", torch.softmax(scores, dim=-1), values)
+    Hv, out = X, []
+    for c in cells:
+        gi = F.linear(Hv, c.weight_ih, c.bias_ih)
+        gh = F.linear(H, c.weight_hh, c.bias_hh)
+        i_r, i_z, i_n = gi.chunk(3, 1)
+        h_r, h_z, h_n = gh.chunk(3, 1)
+        r, z = torch.sigmoid(i_r + h_r), torch.sigmoid(i_z + h_z)
+        n = torch.tanh(i_n + r * h_n)
+        Hv = n + z * (H - n)
+        out.append(Hv)
+    return torch.stack(out, 0)
+
+
+class _IpropStep(torch.autograd.Function):
+    """`_ipropagate_to` under autograd: forward = the ONE HIP launch (`dagnn_iprop_step`), backward = the reverse pass of
+    the same step on the device (the step is a handful of [B, hs] products: recomputed densely from the saved inputs and
+    differentiated there - no state of the forward launch is kept besides its inputs)."""
+
+    @staticmethod
+    def forward(ctx, values, pred_vid, w_key, vid_bias, H, X, L, *flat):
+        cells = [_CellView(*flat[4 * l:4 * l + 4]) for l in range(L)]
+        ctx.save_for_backward(*[t for t in (values, pred_vid, w_key, vid_bias, H, X) if t is not None], *flat)
+        ctx.have = [t is not None for t in (values, pred_vid, w_key, vid_bias, H, X)]
+        ctx.L = L
+        return engine.iprop_step(values, pred_vid, w_key, vid_bias, H, X, cells)
+
+    @staticmethod
+    def backward(ctx, g_states):
+        saved = list(ctx.saved_tensors)
+        head = [saved.pop(0) if h else None for h in ctx.have]
+        values, pred_vid, w_key, vid_bias, H, X = head
+        flat = saved
+        need = list(ctx.needs_input_grad)
+        leaves, slots = [], []
+
+        def leaf(t, slot):
+            if t is None or not t.is_floating_point():
+                return t
+            t = t.detach().requires_grad_(need[slot])
+            if need[slot]:
+                leaves.append(t)
+                slots.append(slot)
+            return t
+
+        values, w_key, vid_bias, H = leaf(values, 0), leaf(w_key, 2), leaf(vid_bias, 3), leaf(H, 4)
+        flat = [leaf(t, 7 + k) for k, t in enumerate(flat)]
+        grads = [None] * (7 + len(flat))
+        if leaves:
+            with torch.enable_grad():
+                cells = [_CellView(*flat[4 * l:4 * l + 4]) for l in range(ctx.L)]
+                out = _iprop_dense(values, pred_vid, w_key, vid_bias, H, X, cells)
+            for slot, g in zip(slots, torch.autograd.grad(out, leaves, g_states.contiguous(), allow_unused=True)):
+                grads[slot] = g
+        return tuple(grads)
+
+
 class _DvaeBase(nn.Module):
     """Parameters of `DVAE_PYG.__init__` (`dvae/models_pyg.py:18-85`), same names and order."""
 
@@ -332,7 +411,7 @@ class _DvaeDagnn(_DvaeBase):
         values = pred_vid = None
         lin = self.node_aggr_0[0].attn_lin   # AttnConv.forward with edge_index=None (`dagnn.py:391-399`), stacked layer 0
         dq = self._key_offset(0)
-        w = lin.weight.detach()[0]
+        w = lin.weight[0]   # (not detached: the training caller `loss()` -> `_update_iv` backpropagates through this step)
         if H is None:
             preds = [g.predecessors(v) for g in G]
             P = max(len(p) for p in preds)
@@ -344,9 +423,17 @@ class _DvaeDagnn(_DvaeBase):
                     ids += list(p) + [-1] * (P - len(p))
                 values = torch.cat(rows, 0).view(len(G), P, self.hs)
                 pred_vid = torch.tensor(ids, dtype=torch.int32).view(len(G), P).to(dev)
-        states = engine.iprop_step(values, pred_vid, w[dq:dq + self.hs],
-                                   w[dq + self.hs:dq + self.hs + self.max_n] if self._use_vids else None, H, X,
-                                   list(propagator)[:self.num_layers])
+        cells = list(propagator)[:self.num_layers]
+        w_key = w[dq:dq + self.hs]
+        vid_bias = w[dq + self.hs:dq + self.hs + self.max_n] if self._use_vids else None
+        flat = [t for c in cells for t in (c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh)]
+        diff = [t for t in [values, H, w_key, vid_bias] + flat if t is not None]
+        if torch.is_grad_enabled() and any(t.requires_grad for t in diff):
+            # training (`models_pyg.py:398-442`: the reconstruction loss reaches `grud`, `attn_lin` and `H0 = tanh(fc3(z))`
+            # through these states): the same HIP launch forward, its reverse pass behind an autograd.Function
+            states = _IpropStep.apply(values, pred_vid, w_key, vid_bias, H, X, len(cells), *flat)
+        else:
+            states = engine.iprop_step(values, pred_vid, w_key, vid_bias, H, X, cells)
         for l in range(self.num_layers):
             for i, g in enumerate(G):
                 g.vs[v]["H_forward%d" % l] = states[l, i:i + 1]

@@ -879,6 +879,69 @@ def test_ipropagate_to_matches_reference_on_the_gpu(device, name):
     assert Hh.maxdiff(got, ref.numpy()) < 5e-6
 
 
+@pytest.mark.parametrize("name", ["iprop_na_h64_L2", "iprop_bn_h32_L3"])
+def test_ipropagate_to_is_differentiable(device, name):
+    """The training caller of `_ipropagate_to` (`dvae/models_pyg.py:398-442`: `loss()` -> `_update_iv`) backpropagates
+    through the returned states into `grud`, `attn_lin` and the predecessors' states.  The HIP step under autograd against
+    autograd through the CPU restatement: every parameter gradient and the gradient of every predecessor state, also
+    for the `H`-given form; under `no_grad` the step stays the bare launch."""
+    from oracle.iprop_oracle import ipropagate_to
+    import copy
+    meta, arr = Hh.load(name)
+    model, _ = Hh.dvae_model(dict(meta, bidir=False))
+    ref_model = copy.deepcopy(model)
+    model = model.to(device)
+    v = meta["vs"][-1]
+
+    def run(m, dev, H):
+        G = Hh.iprop_graphs(meta, arr, dev)
+        leaves = []
+        for g in G:
+            for u in range(g.vcount()):
+                for l in range(meta["L"]):
+                    t = g.vs[u]["H_forward%d" % l].requires_grad_(True)
+                    leaves.append(t)
+        if H is not None:
+            H = H.to(dev).requires_grad_(True)
+        step = (lambda: m._ipropagate_to(G, v, m.grud, H=H)) if dev != "cpu" else (lambda: ipropagate_to(m, G, v, m.grud, H=H))
+        out = step()
+        assert out.requires_grad
+        wts = torch.linspace(-1.0, 1.0, out.numel()).view_as(out).to(out.device)
+        # the states written into the vertices carry the graph as well (the decoder reads them in later steps)
+        extra = sum((g.vs[v]["H_forward0"] * 0.5).sum() for g in G if g.vcount() > v)
+        ((out * wts).sum() + extra).backward()
+        pg = {k: (p.grad.detach().cpu().clone() if p.grad is not None else None) for k, p in m.named_parameters()}
+        lg = [None if t.grad is None else t.grad.detach().cpu().clone() for t in leaves]
+        hg = None if H is None else H.grad.detach().cpu().clone()
+        m.zero_grad()
+        return out.detach().cpu(), pg, lg, hg
+
+    for H in (None, torch.from_numpy(arr["H_given"].copy())):
+        out_r, pg_r, lg_r, hg_r = run(ref_model, "cpu", H)
+        out_g, pg_g, lg_g, hg_g = run(model, device, H)
+        assert float((out_r - out_g).abs().max()) < 5e-6
+        touched = 0
+        for k, r in pg_r.items():
+            g = pg_g[k]
+            if r is None or float(r.abs().max()) < 1e-6:   # (bias of attn_lin: exact zeros here, ~1e-9 noise in the oracle)
+                assert g is None or float(g.abs().max()) < 1e-6, k
+                continue
+            assert g is not None, k
+            scale = float(r.abs().max())
+            assert float((g - r).abs().max()) <= 1e-4 * scale + 1e-7, k
+            touched += 1
+        assert touched >= 4 * meta["L"] + (1 if H is None else 0)
+        for r, g in zip(lg_r, lg_g):
+            if r is None:
+                assert g is None or float(g.abs().max()) == 0.0
+            else:
+                assert g is not None and float((g - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-7
+        if H is not None:
+            assert float((hg_g - hg_r).abs().max()) <= 1e-4 * float(hg_r.abs().max()) + 1e-7
+    with torch.no_grad():
+        assert not model._ipropagate_to(Hh.iprop_graphs(meta, arr, device), v, model.grud).requires_grad
+
+
 def test_check_raises_for_the_last_forward_of_a_loop(device, monkeypatch):
     """A device-side failure of the LAST forward of a loop has no next forward to report it: `model.check()` (and the
     `DataParallel` wrapper in eval mode, which calls it) raises; earlier healthy passes of the same async loop do not

@@ -135,6 +135,7 @@ def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
     y = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(1)).to(device)
     ce = torch.nn.CrossEntropyLoss()
     exposed = []
+    CLIP = float(os.environ.get("DAGNN_BENCH_CLIP", "0.25"))   # the reference's training script: CLIP=0.25 (scripts/ogb_tok.sh:16)
 
     def step(G, timed=False):
         if red is not None:
@@ -148,10 +149,12 @@ def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
             if timed:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-            red.finish()
+            red.finish(clip=CLIP)
             if timed:
                 b.record()
                 exposed.append((a, b))
+        elif CLIP > 0:   # main_pyg.py:63-64 (`--clip`, 0.25 in scripts/ogb_tok.sh:16): global-norm clip in front of the update
+            torch.nn.utils.clip_grad_norm_(params, CLIP, foreach=True)
         opt.step()
         return loss
 
@@ -195,9 +198,9 @@ def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
                               "allreduce_exposed_ms = median stream time between the end of backward() and both buckets "
                               "reduced and normalised" % (red.early.numel / 1e6 if red.early else 0.0,
                                                           red.late.numel / 1e6 if red.late else 0.0)}
-    return {"what": "zero_grad + forward + mean-CE over %d heads + backward%s + Adam step (main_pyg.py:39-65)"
+    return {"what": "zero_grad + forward + mean-CE over %d heads + backward%s + clip_grad_norm(%.2f) + Adam step (main_pyg.py:39-65)"
                     % (S, " + RCCL all-reduce of the %.1f M gradient floats in two buckets" % (nparams / 1e6)
-                       if world > 1 else ""),
+                       if world > 1 else "", CLIP),
             **extra,
             "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
             "ms_per_step_median": round(per_step[len(per_step) // 2], 4),

@@ -106,7 +106,8 @@ class Recurrence(torch.autograd.Function):
                     if gouts[q * L + i] is not None:
                         g_ext[d][i][:, :H] = gouts[q * L + i]
         groups = keep.get("groups", 0)
-        if groups > 0 and engine.bwd_dataflow_groups(dev, len(dirs), L, Hp, plan.B) == groups:
+        if groups > 0 and engine.bwd_dataflow_groups(dev, len(dirs), L, Hp, plan.B) == groups and \
+                engine.bwd_dataflow_fits(dev, N, len(dirs) * L):
             res = engine.bwd_dataflow_sweep(plan, dirs, L, Hp, cells, keep["h_buf"], keep["gi0"], g_ext, groups,
                                             arena=mod._arena_for(x, "backward"), vid_mod=mod._vid_nodes,
                                             static_score=ctx.sscore, preact=keep.get("preact"))

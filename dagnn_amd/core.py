@@ -202,7 +202,7 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
     h = [[torch.empty(N, ld, dtype=torch.float32, device=dev) if d in dirs else None for _ in range(L)]
          for d in range(2)]
     plan.wait_ready()   # a plan built on the side stream (model._plan_of) meets the caller's stream here
-    groups = engine.dataflow_groups(dev, len(dirs), L, Hp, plan.B) if (arena is not None and N > 0) else 0
+    groups = engine.dataflow_groups(dev, len(dirs), L, Hp, plan.B, training=keep is not None) if (arena is not None and N > 0) else 0
     if N * 3 * Hp >= (1 << 31):   # the dataflow kernels address their granule buffers with 32-bit row offsets
         groups = 0
     if arena is not None:
@@ -230,7 +230,7 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
         pack_dataflow(cells.values())
         preact = {} if (keep is not None and engine.BWD_DATAFLOW) else None
         engine.dataflow_run(plan, dirs, L, Hp, cells, gi, h, groups, vid_mod=vid_nodes, arena=arena,
-                            static_score=static_score, score_parts=keep is not None, preact=preact)
+                            static_score=static_score, score_parts=keep is not None, preact=preact, training=keep is not None)
         if keep is not None:
             keep["preact"] = preact
     else:

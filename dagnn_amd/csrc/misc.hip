@@ -224,6 +224,26 @@ __global__ void __launch_bounds__(256) iprop_step_kernel(const float* __restrict
 
 }  // namespace
 
+namespace {
+// a stand-in for another process's / library's kernels: `ticks` of the 100 MHz clock of pure spinning per workgroup
+__global__ void occupy_kernel(long long ticks, float* sink) {
+    const unsigned long long t0 = wall_clock64();
+    float acc = (float)threadIdx.x;
+    while ((long long)(wall_clock64() - t0) < ticks) {
+        for (int i = 0; i < 64; ++i) acc = fmaf(acc, 1.0001f, 0.5f);
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (sink && acc == 12345.678f) *sink = acc;   // (keeps the loop)
+}
+}  // namespace
+
+extern "C" int dagnn_debug_occupy(int num_wgs, int threads, int64_t ticks, float* sink, void* stream) {
+    if (num_wgs <= 0 || threads <= 0 || threads > 1024 || (threads % 64) || ticks < 0 || ticks > (1ll << 31)) return DAGNN_EINVAL;
+    hipLaunchKernelGGL(occupy_kernel, dim3((unsigned)num_wgs), dim3((unsigned)threads), 0, (hipStream_t)stream, (long long)ticks, sink);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
 extern "C" const char* dagnn_version(void) { return "dagnn_hip 0.1 gfx950"; }
 
 extern "C" int dagnn_encode_ast(const int64_t* x, int64_t* depth, const float* type_emb, const float* attr_emb,

@@ -18,13 +18,20 @@ from typing import Optional, Sequence
 import torch
 import torch.distributed as dist
 
-from .train import GradBucket
+from .train import GradBucket, clip_flat_grad_norm_
 
 
 class DataParallel(torch.nn.Module):
-    def __init__(self, module: torch.nn.Module, device_ids: Optional[Sequence] = None, output_device=None):
+    def __init__(self, module: torch.nn.Module, device_ids: Optional[Sequence] = None, output_device=None,
+                 sync_check: bool = True):
+        """`sync_check` (evaluation mode only): True - every forward ends with the module's blocking `check()`, i.e. a device
+        synchronisation per evaluation batch; the reference's loop reads the predictions back right away
+        (`main_pyg.py:91-124`), so nothing is lost there.  False - the forward stays asynchronous (failures of EARLIER
+        passes still surface at the next forward, from the arenas' pinned rings); call `model.module.check()` once behind
+        the last batch of the loop."""
         super().__init__()
         self.module = module
+        self.sync_check = bool(sync_check)
         if device_ids is None:
             device_ids = [torch.cuda.current_device()] if torch.cuda.is_available() else []
         self.device_ids = [d.index if isinstance(d, torch.device) else int(d) for d in device_ids]
@@ -88,7 +95,7 @@ class DataParallel(torch.nn.Module):
             if data is None:
                 return None
             out = self.module(data.to(dev))
-        if not self.training:
+        if not self.training and self.sync_check:
             # evaluation consumes the outputs right away (`main_pyg.py:91-124`): surface a device-side failure of THIS
             # pass now instead of at the next forward (a loop's last batch has no next forward)
             check = getattr(self.module, "check", None)
@@ -118,6 +125,15 @@ class DataParallel(torch.nn.Module):
         every call checks that they still live there (see `_attach_bucket`)."""
         self._attach_bucket()
         self._bucket.all_reduce_mean(local_count, group)
+
+    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+        """The reference's `torch.nn.utils.clip_grad_norm(model.parameters(), args.clip)` (`main_pyg.py:63-64`): call it
+        AFTER `reduce_gradients` (the norm is the global batch's, the same on every rank) and before `optimizer.step()`.
+        With a bucket: one norm over the flat buffer; without (single process, no `reduce_gradients`): torch's own."""
+        if self._bucket is not None:
+            self._bucket.rebind()
+            return clip_flat_grad_norm_([self._bucket.flat], max_norm)
+        return torch.nn.utils.clip_grad_norm_(self.module.parameters(), max_norm)
 
     def zero_grad(self, set_to_none: bool = False) -> None:   # keeps the bucket's views (no copy on the next step)
         if self._bucket is not None:

@@ -382,18 +382,47 @@ def pack_dataflow(w: torch.Tensor, H: int) -> torch.Tensor:
     return out
 
 
-def dataflow_groups(device, num_dirs: int, num_stacked: int, H: int, B: int) -> int:
-    """Groups the dataflow kernel runs on this device for this model shape; 0 = not applicable."""
+RESERVED_CUS = _env_int("DAGNN_AMD_RESERVED_CUS", -1)   # CUs the persistent kernels of a TRAINING pass leave free; -1 = automatic (below)
+
+
+def reserved_cus(training: bool) -> int:
+    """The dataflow kernels need EVERY workgroup resident (one per CU, the whole register file of the CU each: 240 of 256
+    CUs at the headline shape).  In a data-parallel training step the heads' gradient bucket is all-reduced WHILE the
+    reverse sweep runs (`train.OverlappedGradReducer`): the collective's kernels (RCCL: one workgroup per channel, up to 64)
+    were launched first and hold CUs the sweep counts on - the resident part of the sweep then spins on granules of
+    workgroups that cannot be dispatched before the collective drains: a serialisation at best, an expired bounded wait
+    at worst.  So a training pass under an active communicator (torch.distributed initialised, world > 1) sizes its
+    persistent launches - forward and reverse share one schedule - for `num_cus - 64` and spreads them evenly over the
+    XCDs (24 of 32 CUs each at the headline shape: 4 workgroup sets instead of 5), which leaves 8 CUs per XCD to whatever
+    else runs.  `DAGNN_AMD_RESERVED_CUS=n` overrides the rule in both directions (0: never reserve; n: always, also in a
+    single process - what the GPU test of the rule uses).  Inference passes overlap no collective and keep every CU."""
+    if RESERVED_CUS >= 0:
+        return RESERVED_CUS if training else 0
+    if not training:
+        return 0
+    import torch.distributed as dist
+    return 64 if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else 0
+
+
+def effective_cus(device, training: bool = False) -> int:
+    n = _num_cus(device)
+    r = reserved_cus(training)
+    return max(n - r, 8) if r > 0 else n
+
+
+def dataflow_groups(device, num_dirs: int, num_stacked: int, H: int, B: int, training: bool = False) -> int:
+    """Groups the dataflow kernel runs on this device for this model shape; 0 = not applicable.  `training`: a pass
+    whose reverse sweep may overlap a gradient collective (`reserved_cus`)."""
     if not DATAFLOW:
         return 0
-    cus = _num_cus(device)
+    cus = effective_cus(device, training)
     g = _lib.load().dagnn_dataflow_groups(cus, int(num_dirs), int(num_stacked), int(H), int(B))
     return min(g, DF_GROUPS) if DF_GROUPS > 0 else g
 
 
 def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0, h, groups: int, vid_mod: int = 0,
                  arena: Optional["GranuleArena"] = None, static_score=None, score_parts: bool = False,
-                 preact: Optional[dict] = None) -> None:
+                 preact: Optional[dict] = None, training: bool = False) -> None:
     """The whole recurrence as one persistent launch (csrc/dataflow.hip).  Same operands as `frontier_run`;
     `score_parts` adds the partial attention scores behind the state rows (what the backward pass reads); `preact`
     (a dict, training passes) receives the pre-activations the kernel computed anyway - `("gh", d, i)` [N,3H] for every
@@ -438,7 +467,7 @@ def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     args.spin_limit = SPIN_LIMIT
     args.debug_wg = DEBUG_WG
     if DF_XCD:
-        args.num_cus = _num_cus(plan.ws.device)
+        args.num_cus = effective_cus(plan.ws.device, training)   # (the placement spreads the workgroups over num_cus / 8 per XCD)
         args.xcc_table = arena.xcc_table(plan.ws.device).data_ptr()
     args.plan_status = plan.status.data_ptr()
     with _span("dataflow_run", plan.ws):
@@ -928,7 +957,25 @@ def bwd_dataflow_groups(device, num_dirs: int, num_stacked: int, H: int, B: int)
     forward pass's schedule workspace serves both); 0 = not applicable."""
     if not BWD_DATAFLOW:
         return 0
-    return dataflow_groups(device, num_dirs, num_stacked, H, B)
+    return dataflow_groups(device, num_dirs, num_stacked, H, B, training=True)
+
+
+BWD_DF_MAX_BYTES = _env_int("DAGNN_AMD_BWD_DF_MAX_BYTES", 0)   # cap on the reverse dataflow sweep's static records (0: half of the free memory)
+
+
+def bwd_dataflow_fits(device, N: int, cells: int) -> bool:
+    """The persistent reverse sweep keeps ONE 8 KB static record per (cell, node) (`dagnn_bwd_dataflow_static_bytes`) whatever
+    H is - 0.5 GB for the headline batch, tens of GB for a very large batch at H = 64.  Above 1 GB the estimate is held
+    against the memory that is actually free (the device's + what torch's allocator has cached); a batch that does not
+    fit takes the reverse lock-step launches (`backward_sweep`), which need none of it."""
+    need = int(_lib.load().dagnn_bwd_dataflow_static_bytes(int(N))) * int(cells)
+    if BWD_DF_MAX_BYTES > 0:
+        return need <= BWD_DF_MAX_BYTES
+    if need <= (1 << 30):
+        return True
+    free, _ = torch.cuda.mem_get_info(device)
+    free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+    return need <= free // 2
 
 
 def bwd_dataflow_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, h, gi0, g_ext, groups: int,
@@ -1016,7 +1063,7 @@ def bwd_dataflow_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, ce
         args.schedule, args.records, args.err = sched.data_ptr(), recs.data_ptr(), err.data_ptr()
         args.plan_status = plan.status.data_ptr()
         if DF_XCD:
-            args.num_cus = _num_cus(dev)
+            args.num_cus = effective_cus(dev, True)
             args.xcc_table = arena.xcc_table(dev).data_ptr()
         check(lib.dagnn_bwd_dataflow_prepare(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_bwd_dataflow_prepare")
     with _span("backward_run", plan.ws):
@@ -1028,12 +1075,30 @@ def bwd_dataflow_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, ce
     return out
 
 
-_WGRAD_WS = {}   # per device: the partial-tile workspace of `wgrad` (grown on demand, reused by every step)
+_WGRAD_WS = {}   # per (kind, device, stream): the partial-tile workspaces of `wgrad` / `colsums` (grown on demand, reused by
+                 # every step of that stream; backward passes on different streams of one device never share a buffer)
+WGRAD_MAX_JOBS = 32   # jobs one `dagnn_wgrad_run` / `dagnn_colsum_run` call takes (WG_MAX_JOBS / CS_MAX_JOBS in csrc/wgrad.hip)
+
+
+def _wgrad_ws(kind: str, ref: torch.Tensor, nbytes: int) -> torch.Tensor:
+    key = (kind, ref.device, _stream(ref))
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        # (a grown buffer replaces one that launches already queued on this stream may still read: stream-ordered
+        # allocation keeps the old block alive until they have run)
+        ws = _WGRAD_WS[key] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=ref.device)
+    return ws
 
 
 def wgrad(jobs, N: int, Hp: int, H: int):
     """Weight / bias gradients of GRU cells in one batch (`dagnn_wgrad_run`).  `jobs`: list of (dg [N, >= 3 Hp], inp
-    [N, in_dim] (row pitch kept), want_bias); returns a list of (d_weight [3H, in_dim], d_bias [3H] or None)."""
+    [N, in_dim] (row pitch kept), want_bias); returns a list of (d_weight [3H, in_dim], d_bias [3H] or None).  More than
+    WGRAD_MAX_JOBS jobs (bidirectional models of more than 8 stacked layers) go in several launches."""
+    if len(jobs) > WGRAD_MAX_JOBS:
+        out = []
+        for k in range(0, len(jobs), WGRAD_MAX_JOBS):
+            out += wgrad(jobs[k:k + WGRAD_MAX_JOBS], N, Hp, H)
+        return out
     lib = _lib.load()
     dev = jobs[0][0].device
     arr = (_lib.WgradJob * len(jobs))()
@@ -1057,9 +1122,7 @@ def wgrad(jobs, N: int, Hp: int, H: int):
     cus = _num_cus(dev)
     splits = max(lib.dagnn_wgrad_splits(cus, len(jobs), Hp, kmax, max(N, 1)), 1)
     nbytes = lib.dagnn_wgrad_workspace_bytes(len(jobs), Hp, kmax, splits)
-    ws = _WGRAD_WS.get(dev)
-    if ws is None or ws.numel() * 4 < nbytes:
-        ws = _WGRAD_WS[dev] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+    ws = _wgrad_ws("wg", jobs[0][0], nbytes)
     check(lib.dagnn_wgrad_run(arr, len(jobs), N, Hp, H, splits, ws.data_ptr(), ws.numel() * 4, _stream(jobs[0][0])),
           "dagnn_wgrad_run")
     return [(dW if dW.is_contiguous() else dW.contiguous(), db) for dW, db in outs]
@@ -1067,7 +1130,13 @@ def wgrad(jobs, N: int, Hp: int, H: int):
 
 def colsums(jobs, N: int):
     """Weighted column sums in one batch (`dagnn_colsum_run`).  `jobs`: list of (x [N, cols] (row pitch kept; a 1-d
-    tensor counts as [N, 1]), weight [N] or None); returns the list of [cols] sums."""
+    tensor counts as [N, 1]), weight [N] or None); returns the list of [cols] sums.  More than WGRAD_MAX_JOBS jobs (a
+    bidirectional model with edge features has three per cell: 12 cells = 36) go in several launches."""
+    if len(jobs) > WGRAD_MAX_JOBS:
+        out = []
+        for k in range(0, len(jobs), WGRAD_MAX_JOBS):
+            out += colsums(jobs[k:k + WGRAD_MAX_JOBS], N)
+        return out
     lib = _lib.load()
     dev = jobs[0][0].device
     arr = (_lib.ColsumJob * len(jobs))()
@@ -1084,9 +1153,7 @@ def colsums(jobs, N: int):
         kmax = max(kmax, x.shape[1])
         arr[q] = _lib.ColsumJob(x.data_ptr(), _ptr(w), o.data_ptr(), x.stride(0) if x.shape[0] > 1 else x.shape[1], x.shape[1])
     nbytes = lib.dagnn_colsum_workspace_bytes(len(jobs), kmax)
-    ws = _WGRAD_WS.get(("cs", dev))
-    if ws is None or ws.numel() * 4 < nbytes:
-        ws = _WGRAD_WS[("cs", dev)] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+    ws = _wgrad_ws("cs", jobs[0][0], nbytes)
     check(lib.dagnn_colsum_run(arr, len(jobs), N, ws.data_ptr(), ws.numel() * 4, _stream(jobs[0][0])), "dagnn_colsum_run")
     return outs
 

@@ -9,7 +9,10 @@ runs in hand-written HIP (libdagnn_hip.so); there is no CPU or eager-PyTorch fal
 Aggregators: the additive-attention family (`attn_h` - every BASELINE config - `attn_x`, `self_attn_h`,
 `self_attn_x`) runs in HIP, forward and backward.  The reference's other constructor strings (`mattn_h`,
 `gated_sum`, `add`, `max`, `agg_x=True`, `recurr=0`; SURVEY.md §8(a) row a12: exercised by no BASELINE
-configuration) keep the same contract and run on torch-ROCm ops (`dagnn_amd/variants.py`).
+configuration) keep the same contract on the generic HIP kernels of `csrc/variants.hip` (forward) and
+`csrc/variants_bwd.hip` (the reverse sweep of a training step), marshalled by `dagnn_amd/variants.py`; only what those
+kernels do not take (more than 8 cells, widths that are not multiples of 4, more than two edge features behind an edge
+encoder) trains on torch-ROCm ops, and says so once (`variants.warn_torch_path`).
 """
 from __future__ import annotations
 
@@ -194,8 +197,9 @@ class DAGNN(nn.Module):
         self._head_cache = DerivedCache()
         self._arenas = {}  # per device: granule buffers of the persistent tail kernel
         self.schedule = default_schedule()  # 'lockstep' (frontier launches) or 'pergraph' (persistent workgroups)
-        self.variant_backend = "hip"       # constructor-string variants (a12): 'hip' kernels when no gradient is needed,
-                                            # 'torch' = always the differentiable torch-ROCm ops (the training path)
+        self.variant_backend = "hip"       # constructor-string variants (a12): 'hip' = csrc/variants.hip forward and
+                                            # csrc/variants_bwd.hip reverse sweep; 'torch' = always the differentiable
+                                            # torch-ROCm ops (the checker of the HIP sweep in the GPU tests)
 
     # ------------------------------------------------------------------------------ helpers
     # additive-attention aggregators: the logit is w . [query ; key (+ edge)] (+ b); query and bias cancel
@@ -393,6 +397,8 @@ class DAGNN(nn.Module):
                         for i in range(L):
                             h[d][i] = flat[q * L + i]
                     return self._finish(G, None, G.x, h, B)
+                if self.variant_backend != "torch":   # (an explicit 'torch' backend is a choice, not a cliff)
+                    variants.warn_torch_path(self, G)
                 return self._finish(G, None, G.x, variants.run(self, G, G.x), B)   # training: differentiable torch ops
             plan = self._plan_of(G, B)
             return self._finish(G, plan, G.x, variants.run_hip(self, G, G.x, plan), B)

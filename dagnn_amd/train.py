@@ -85,6 +85,24 @@ class GradBucket(object):
         self.flat.div_(self._buf[-1].clamp(min=1.0))
 
 
+def clip_flat_grad_norm_(flats, max_norm: float, eps: float = 1e-6) -> torch.Tensor:
+    """`torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)` (`ogbg-code/main_pyg.py:63-64`, `--clip`, 0.25 in
+    `scripts/ogb_tok.sh:16`) over flat gradient buffers: the global 2-norm of ALL gradients, every buffer scaled by
+    `min(1, max_norm / (norm + eps))`.  One norm kernel per buffer instead of one per parameter, no device->host read
+    (the scale stays on the device).  Under data parallelism it must see the REDUCED gradients - the mean over the
+    global batch, identical on every rank - so it sits behind the last collective of the step and in front of
+    `optimizer.step()`; every rank then applies the same scale without another exchange.  Returns the norm."""
+    flats = [f for f in flats if f is not None and f.numel() > 0]
+    if not flats:
+        return torch.zeros(())
+    sq = torch.stack([torch.linalg.vector_norm(f, 2.0) for f in flats])
+    total = torch.linalg.vector_norm(sq, 2.0)
+    coef = torch.clamp(float(max_norm) / (total + eps), max=1.0)
+    for f in flats:
+        f.mul_(coef)
+    return total
+
+
 class OverlappedGradReducer(object):
     """Gradient exchange of one training step in TWO buckets so that most of it hides behind the reverse sweep.
 
@@ -136,8 +154,20 @@ class OverlappedGradReducer(object):
             self.early.rebind()   # (a gradient autograd allocated outside the bucket is copied in first)
             self._work = self.early.launch(self._count, self.group)
 
-    def finish(self) -> None:
-        """After `backward()`: exchange the late bucket, wait for the early one, normalise both."""
+    def finish(self, clip: float = 0.0) -> Optional[torch.Tensor]:
+        """After `backward()`: exchange the late bucket, wait for the early one, normalise both - and, with `clip` > 0, the
+        reference's `clip_grad_norm(model.parameters(), clip)` (`main_pyg.py:63-64`) on the reduced gradients of BOTH
+        buckets (it needs the global norm, so it cannot start before the last collective has landed); then
+        `optimizer.step()`.  Returns the gradient norm when clipping."""
+        self._exchange()
+        if clip and clip > 0:
+            for b in (self.early, self.late):   # (single process: the gradients may live outside the buckets)
+                if b is not None and not self._active():
+                    b.rebind()
+            return clip_flat_grad_norm_([b.flat for b in (self.early, self.late) if b is not None], clip)
+        return None
+
+    def _exchange(self) -> None:
         if not self._active():
             return
         if self.early is not None and self._work is None:   # no hook fired (a head without gradient): exchange it now

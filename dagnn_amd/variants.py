@@ -76,6 +76,26 @@ def _conv(agg: str, p, vals: torch.Tensor, keys: Optional[torch.Tensor], query: 
     return out.index_add_(0, seg, hj * alpha.unsqueeze(-1))
 
 
+_TORCH_PATH_SEEN = set()
+
+
+def warn_torch_path(mod, G) -> None:
+    """Say ONCE per model shape that a training step of this constructor string runs the reference's loop nest on torch
+    ops (`run` below) instead of the HIP reverse sweep (`VariantRecurrence`): 10-100x slower per step, otherwise silent.
+    The HIP sweep covers up to 8 cells, widths that are multiples of 4 and at most two edge features behind an edge
+    encoder (`hip_backward_supported`)."""
+    key = (mod.agg, bool(mod.agg_x), bool(mod.recurr), mod.hidden_dim, mod.emb_dim, mod.num_layers, len(mod.dirs))
+    if key in _TORCH_PATH_SEEN:
+        return
+    _TORCH_PATH_SEEN.add(key)
+    import warnings
+    warnings.warn("dagnn_amd: training agg=%r (agg_x=%s, recurr=%s, hidden %d, %d stacked layers, %d direction(s)) runs on "
+                  "torch ops, layer by layer - the HIP reverse sweep of the constructor-string variants takes at most 8 "
+                  "cells, widths that are multiples of 4 and at most two edge features; expect 10-100x the step time"
+                  % (mod.agg, mod.agg_x, mod.recurr, mod.hidden_dim, mod.num_layers, len(mod.dirs)),
+                  RuntimeWarning, stacklevel=3)
+
+
 def run(mod, G, x: torch.Tensor) -> List[List[Optional[torch.Tensor]]]:
     """h[d][i] ([N, hidden], d over both direction slots, None for an unused direction) for the variant configured on
     `mod` (a dagnn_amd.DAGNN).  Differentiable: plain torch ops throughout."""

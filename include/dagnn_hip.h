@@ -748,6 +748,11 @@ int dagnn_topo_layers(const int64_t* edge_index /* [2,E] */, const int64_t* batc
                       int64_t B, int64_t* layer_fwd, int64_t* layer_bwd, int32_t* status /* device int32 or NULL */,
                       void* stream);
 
+/* Test utility for the co-residency rule of the persistent kernels (engine.reserved_cus): occupies `num_wgs` workgroups of
+ * `threads` threads for `ticks` of the 100 MHz constant clock (bounded: at most 2^31 ticks) on `stream` - a stand-in for the
+ * kernels of a collective that runs next to a training pass.  Touches no memory besides `sink` (one float, may be NULL). */
+int dagnn_debug_occupy(int num_wgs, int threads, int64_t ticks, float* sink, void* stream);
+
 /* Introspection (tests, and the host-side read-back of the lock-step schedule): byte offsets of the
  * plan's arrays from `plan->data`, into a host array of 26 entries: [node_ptr, edge_ptr, depth0,
  * depth1, order0, order1, lstart0, lstart1, rowptr0, rowptr1, col0, col1, eattr0, eattr1, items,

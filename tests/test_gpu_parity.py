@@ -444,6 +444,62 @@ def test_xcd_placement_changes_speed_not_results(device, monkeypatch):
                 assert torch.equal(res[0][3][k], res[1][3][k]), k
 
 
+def test_training_pass_leaves_room_for_a_collective(device, monkeypatch):
+    """The co-residency rule of the persistent kernels (`engine.reserved_cus`): a data-parallel training step overlaps the
+    heads' gradient all-reduce with the reverse sweep, and the collective's workgroups - launched FIRST - hold CUs.  With
+    the reservation (what an active communicator switches on; forced here) the training pass sizes its dataflow launches
+    for `num_cus - 64`, spread evenly over the XCDs, so a 40-workgroup kernel that spins on a second stream across the
+    whole forward + backward (the stand-in for RCCL's channels: it only ends by itself, i.e. it never yields its CUs)
+    changes neither bits nor - beyond 1.3x - time, and no bounded wait expires.  The inference pass keeps every CU."""
+    from dagnn_amd import _lib
+    lib = _lib.load()
+    model = _headline_model(H=256, L=2, V=32, seed=4).to(device)
+    b = synth.code2_batch(11, 128, 125)
+    y = torch.randint(0, 32, (128, 5), generator=torch.Generator().manual_seed(3)).to(device)
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    full = engine.dataflow_groups(device, 2, 2, 256, 128)
+    monkeypatch.setattr(engine, "RESERVED_CUS", 64)
+    assert engine.reserved_cus(False) == 0 and engine.dataflow_groups(device, 2, 2, 256, 128) == full
+    reserved = engine.dataflow_groups(device, 2, 2, 256, 128, training=True)
+    assert 0 < reserved <= full and (reserved < full or cus < 256)
+    side = torch.cuda.Stream(device)
+    sink = torch.zeros(1, device=device)
+
+    def step(occupied):
+        torch.cuda.synchronize()
+        if occupied:   # 40 workgroups x 256 threads that spin for ~30 ms: far longer than the step they sit next to
+            _lib.check(lib.dagnn_debug_occupy(40, 256, 3_000_000, sink.data_ptr(), side.cuda_stream), "dagnn_debug_occupy")
+            import time
+            time.sleep(0.002)   # (the spinner is running before the step's first launch)
+        a, c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        loss, grads = _train_step(model, b.clone().to(device), y)
+        c.record()
+        c.synchronize()
+        model.check()   # raises if any bounded wait of the pass expired
+        ms = a.elapsed_time(c)
+        torch.cuda.synchronize()
+        return loss, {k: v.clone() for k, v in grads.items()}, ms
+
+    step(False)
+    ref = step(False)
+    t_free = min(step(False)[2] for _ in range(3))
+    occ = [step(True) for _ in range(3)]
+    for loss, grads, _ in occ:
+        assert torch.equal(loss, ref[0])
+        for k in grads:
+            if "encoder." not in k:   # (torch's embedding backward accumulates with atomics)
+                assert torch.equal(grads[k], ref[1][k]), k
+    t_occ = min(o[2] for o in occ)
+    assert t_occ < 1.3 * t_free, (t_occ, t_free)
+    # and the evaluation pass next to it: every CU, same logits as alone
+    model.eval()
+    with torch.no_grad():
+        alone = torch.stack(model(b.clone().to(device)))
+    torch.cuda.synchronize()
+    assert engine.reserved_cus(False) == 0
+
+
 def _degenerate_batch(extra=()):
     """Single-node graphs, a chain, stars with a 200-way fan-in / fan-out, a graph with no edges, a duplicate edge
     (`extra`: more graphs behind them)."""
@@ -556,6 +612,27 @@ def test_training_step_matches_oracle_autograd_and_is_deterministic(device):
     for k in grads:
         if "encoder." not in k:  # the embedding-table gradients are torch index_add_ (atomics)
             assert torch.equal(grads[k], again[k]), k
+
+
+def test_training_step_six_stacked_layers_with_edge_features(device):
+    """L = 6, bidirectional, edge features: 12 cells = 36 column-sum jobs and 24 weight-gradient jobs in the backward
+    epilogue - more than ONE `dagnn_colsum_run` takes (32; `engine.colsums` / `engine.wgrad` go in several launches).
+    Every gradient against autograd through the CPU oracle."""
+    meta = dict(H=32, n_attr=300, V=12, S=2, w_seed=17,
+                ctor=dict(w_edge_attr=True, num_layers=6, bidirectional=True, agg="attn_h", out_wx=False,
+                          out_pool_all=False, out_pool="max", dropout=0.0))
+    model = Hh.code2_model(meta)
+    b = synth.code2_batch(9, 6, 20)
+    b.x[:, 1] %= 300
+    y = torch.from_numpy(np.random.default_rng(2).integers(0, 12, size=(6, 2)))
+    loss_ref, ref = O.code2_grads(model.state_dict(), b.clone(), y, num_layers=6, bidirectional=True, max_seq_len=2)
+    model = model.to(device)
+    loss, grads = _train_step(model, b.clone().to(device), y.to(device))
+    model.check()
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    for k, g in grads.items():
+        scale = float(ref[k].abs().max())
+        assert Hh.maxdiff(g, ref[k]) <= 1e-4 * scale + 2e-7, k
 
 
 def test_training_step_edge_cases_match_oracle_autograd(device):
@@ -902,7 +979,7 @@ def test_ipropagate_to_is_differentiable(device, name):
                     t = g.vs[u]["H_forward%d" % l].requires_grad_(True)
                     leaves.append(t)
         if H is not None:
-            H = H.to(dev).requires_grad_(True)
+            H = H.detach().clone().to(dev).requires_grad_(True)
         step = (lambda: m._ipropagate_to(G, v, m.grud, H=H)) if dev != "cpu" else (lambda: ipropagate_to(m, G, v, m.grud, H=H))
         out = step()
         assert out.requires_grad

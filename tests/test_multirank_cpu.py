@@ -310,6 +310,24 @@ def _overlap_worker(rank, world, port, out):
                 assert torch.allclose(pa.grad, pf.grad, atol=1e-6), k         # == the single-process global-mean gradient
         # the heads' exchange left from the hook, before the core's gradients existed
         assert launched_mid_backward and all(launched_mid_backward)
+        # the reference's step clips the GLOBAL gradient norm between backward() and step() (main_pyg.py:63-64, --clip 0.25):
+        # behind both buckets' exchange, == torch's clip_grad_norm_ on the single-process global-mean gradient; both ranks
+        # end with the same gradients, and a norm under the threshold leaves them alone
+        for clip in (1e-3, 1e3):
+            red.zero(local_count=mine.num_graphs)
+            loss_of(a, mine).backward()
+            norm = red.finish(clip=clip)
+            full.zero_grad()
+            loss_of(full, synth.GraphBatch.from_data_list(graphs)).backward()
+            ref_norm = torch.nn.utils.clip_grad_norm_(full.parameters(), clip)
+            assert abs(float(norm) - float(ref_norm)) <= 1e-5 * float(ref_norm)
+            assert (float(ref_norm) > clip) == (clip < 1.0)
+            for (k, pa), pf in zip(a.named_parameters(), full.parameters()):
+                assert torch.allclose(pa.grad, pf.grad, rtol=1e-5, atol=1e-9), k
+            flat = torch.cat([pa.grad.reshape(-1) for pa in a.parameters()])
+            both = [torch.zeros_like(flat) for _ in range(world)]
+            dist.all_gather(both, flat)
+            assert torch.equal(both[0], both[1])
         out[rank] = mine.num_graphs
     finally:
         dist.destroy_process_group()

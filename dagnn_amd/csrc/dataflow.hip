@@ -277,6 +277,22 @@ __device__ __forceinline__ float df_tanh(float x) { return 1.0f - 2.0f * __built
 // starts at s * (KP8 + 4): the 8 segments a half DPP row reads concurrently (ds_read_b128) fall on disjoint banks
 template <int KPT> struct DfPad { static constexpr int kp8 = 2 * KPT; static constexpr int seg = kp8 + 4; static constexpr int row = 8 * seg + 8; };
 
+#ifndef DF_WAKEUP
+#define DF_WAKEUP 0     // a wave that raises an LDS flag pings the workgroup's sleeping waves (s_wakeup): the flag's readers sleep
+#endif                  // longer between looks (fewer issue slots taken from the waves that work) and still see it at once
+#ifndef DF_CSLEEP_N
+#define DF_CSLEEP_N (DF_WAKEUP ? 8 : 1)   // s_sleep argument (x 64 cycles) of the compute waves' look at the ready flags
+#endif
+#ifndef DF_WSLEEP_N
+#define DF_WSLEEP_N (DF_WAKEUP ? 8 : 1)   // ... of a loader's wait for its ring slot
+#endif
+#ifndef DF_ROT
+#define DF_ROT 0        // stream s gives row r of its blocks to loader wave (r + s) mod 4: the rows 0 of the two streams - all a thin
+#endif                  // dependent chain has - are polled and folded on different SIMDs
+__device__ __forceinline__ void df_wakeup() {
+    if (DF_WAKEUP) asm volatile("s_wakeup" ::: "memory");
+}
+
 constexpr int DF_RD = 6;       // a loader wave requests a row record this many of ITS blocks ahead (record ring: 8 entries)
 constexpr int DF_GD = 2;       // a gi0 slice this many (its node id must have landed: DF_RD >= DF_GD + 2)
 constexpr int DF_GIRING = DF_NSLOT + DF_GD + 2;   // blocks in a stream's gi0 ring: slots in use + prefetch distance + slack
@@ -317,7 +333,7 @@ __device__ __forceinline__ bool df_wait4(const int* f, int target, int* err, uns
     for (;;) {
         const int a = df_flag_ld(f), b = df_flag_ld(f + 1), c = df_flag_ld(f + 2), d = df_flag_ld(f + 3);
         if (min(min(a, b), min(c, d)) >= target) return true;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(DF_WSLEEP_N);
         if (++spins > 4 * limit) { __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
         // once any wait of the launch has failed, nobody waits long again (the pass is lost; it must still end)
         if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
@@ -693,6 +709,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
         if (prof_wave) dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64();   // LDS writes issued
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) df_flag_st(lds.rdy + set * DF_WPS + w, b + 1);
+        df_wakeup();
         if (prof_wave) dbg[8 * (int64_t)(DF_NLS * b + set) + 3] = wall_clock64();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of ours is in flight when the wave ends
@@ -700,6 +717,303 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
 #undef DF_CASE
 #undef DF_CASES
 }
+
+// ---- the loader of the configurations that are benchmarked (two edge features or a projection cell, no static scores, no
+// vertex-id key biases, one row per loader wave), rebuilt around what a wave's time is made of (round 4,
+// scripts/ubench/branch_cost.hip: ONE wave issues a dependent VALU operation every ~9 cycles, an independent one every ~5,
+// a taken branch costs ~22, a not-taken one ~8 - a hop of the dependent chain is ~8000 cycles of exactly that).  Same
+// protocol, same arithmetic as df_loader above (the rows it writes are bitwise the same); what differs is the shape of the code:
+//   * the in-degree of a row picks ONE straight-line body (0 / 1 / 2 / 3 / 4 predecessors: >= 97 % of the rows of an AST
+//     batch) - a trip is one statically shaped asm statement, its re-poll loop is [trip, minimum of the tags, compare,
+//     branch], the soft-max of a single chunk needs no running rescale, nothing is predicated per lane;
+//   * everything that does not depend on the polled rows happens BEFORE the poll (ring-slot wait, addresses, edge gains);
+//   * rows with more than 4 in-edges take the general chunk loop (online soft-max), as before.
+struct DfSweep { gran_t x[4][4]; gran_t xp[3]; };
+
+#define DF_TRIP(n, p, d)                                                                                                   \
+    asm volatile(DF_ROWS_##n DF_PROJ_##p DF_DMA_##d                                                                        \
+                 : [x00] "=v"(W.x[0][0]), [x01] "=v"(W.x[0][1]), [x02] "=v"(W.x[0][2]), [x03] "=v"(W.x[0][3]),             \
+                   [x10] "=v"(W.x[1][0]), [x11] "=v"(W.x[1][1]), [x12] "=v"(W.x[1][2]), [x13] "=v"(W.x[1][3]),             \
+                   [x20] "=v"(W.x[2][0]), [x21] "=v"(W.x[2][1]), [x22] "=v"(W.x[2][2]), [x23] "=v"(W.x[2][3]),             \
+                   [x30] "=v"(W.x[3][0]), [x31] "=v"(W.x[3][1]), [x32] "=v"(W.x[3][2]), [x33] "=v"(W.x[3][3]),             \
+                   [p0] "=v"(W.xp[0]), [p1] "=v"(W.xp[1]), [p2] "=v"(W.xp[2]), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)  \
+                 : [vo] "v"(lane8), [vp] "v"(lane31x8), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),            \
+                   [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [ra] "v"(ra), [rl] "s"(rl), [ga] "v"(ga), [gl] "s"(gl),    \
+                   [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)                                                                \
+                 : "memory")
+#define DF_IFC(n, p, d) if constexpr (NN == (n) && PP == (p) && DMA == (d)) { DF_TRIP(n, p, d); } else
+#define DF_IFCS(n) DF_IFC(n, 0, 0) DF_IFC(n, 0, 1) DF_IFC(n, 0, 2) DF_IFC(n, 1, 0) DF_IFC(n, 1, 1) DF_IFC(n, 1, 2)
+
+struct DfTripArgs {
+    const gran_t* b[4];        // wave-uniform row bases
+    const gran_t* c;           // projection slice of the node (gate 0; the gates are H granules apart)
+    const void* ra; unsigned rl;   // prefetch group: record (global source per lane, LDS destination)
+    const void* ga; unsigned gl;   //                 gi0 slice
+};
+
+// one trip to memory: NN rows (+ the projection slice) into W, the prefetch group behind them, the counted wait - ONE asm
+// statement of a static shape (see df_loader)
+template <int NQ4, int H, int NN, int PP, int DMA>
+__device__ __forceinline__ void df_trip(DfSweep& W, const DfTripArgs& T, unsigned lane8, unsigned lane31x8) {
+    constexpr int O1 = (NQ4 > 1 ? 1 : 0) * 512, O2 = (NQ4 > 2 ? 2 : NQ4 - 1) * 512, O3 = (NQ4 - 1) * 512;
+    const gran_t* b0 = T.b[0]; const gran_t* b1 = T.b[1]; const gran_t* b2 = T.b[2]; const gran_t* b3 = T.b[3];
+    const gran_t* c0p = T.c; const gran_t* c1p = T.c + H; const gran_t* c2p = T.c + 2 * H;
+    const void* ra = T.ra; const unsigned rl = T.rl; const void* ga = T.ga; const unsigned gl = T.gl;
+    unsigned keep_m0;
+    unsigned long long keep_exec;
+    DF_IFCS(0) DF_IFCS(1) DF_IFCS(2) DF_IFCS(3) DF_IFCS(4) {}
+}
+
+// every granule of the trip carries this pass's tag.  Tags never exceed the current epoch (the arena hands out strictly
+// increasing ones and starts over on zeroed buffers), so "all equal" is "the minimum equals": one v_min3 per two tags
+template <int NN, int PP>
+__device__ __forceinline__ bool df_landed(const DfSweep& W, unsigned epoch) {
+    unsigned m = epoch;
+#pragma unroll
+    for (int e = 0; e < NN; ++e)
+        m = min(min(m, min((unsigned)(W.x[e][0] >> 32), (unsigned)(W.x[e][1] >> 32))), min((unsigned)(W.x[e][2] >> 32), (unsigned)(W.x[e][3] >> 32)));
+    if (PP) m = min(min(m, (unsigned)(W.xp[0] >> 32)), min((unsigned)(W.xp[1] >> 32), (unsigned)(W.xp[2] >> 32)));
+    return __builtin_amdgcn_uicmp(m, epoch, 33 /* ICMP_NE */) == 0ull;
+}
+
+template <int KPT, int KIND>
+__device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan, const DfArgs& S,
+                                               const DfCell& C, int sl, int group, const DfLds& lds, int w, int set) {
+    static_assert(DF_RPW == 1, "one row per loader wave");
+    constexpr int H = 16 * KPT;
+    constexpr int SEG = DfPad<KPT>::seg, KP8 = DfPad<KPT>::kp8;
+    typedef DfSlot<KPT> Slot;
+    constexpr bool proj = KIND == DFK_PROJ, has_gi0 = KIND == DFK_REC0;
+    constexpr int PPK = KIND == DFK_RECP ? 1 : 0;      // the node's projection slice rides in every trip
+    constexpr int DMA1 = has_gi0 ? 2 : 1;              // prefetch group of a block's first trip
+    constexpr int NQ4 = H / 64;
+    const int lane = threadIdx.x & 63;
+    const int d = C.dir;
+    const int32_t* tab = S.sched + S.gtab[d] + 2 * group;
+    const int rec_base = tab[0], nblk = tab[1];
+    const int32_t* __restrict__ recs = S.sched + S.grec[d] + 16 * (int64_t)rec_base;
+    const int32_t* __restrict__ col = plan + S.col[d];
+    const float* __restrict__ eattr = reinterpret_cast<const float*>(plan + S.eattr[d]);
+    const unsigned epoch = S.epoch, spin_limit = S.spin_limit;
+    int* const err = S.err;
+    const gran_t* const g_src = proj ? C.g_in : C.g_out;
+    const unsigned gld = (unsigned)S.gld, pld = (unsigned)S.pld;
+    const gran_t* const p_in = KIND == DFK_RECP ? C.p_in : nullptr;
+    const float* const gi0 = has_gi0 ? C.gi0 : nullptr;
+    const float gain0 = proj ? 0.f : C.gain[0], gain1 = proj ? 0.f : C.gain[1];
+    int* const dn = lds.dn + set * DF_NCW;
+    float wk[4] = {0.f, 0.f, 0.f, 0.f};
+    int cpos[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = 64 * q + lane;
+        cpos[q] = c + (SEG - KP8) * (c / KP8);
+        if (!proj && q < NQ4) wk[q] = C.wkey[c];
+    }
+    const unsigned lane8 = 8u * lane, lane31x8 = 8u * (lane & 31);
+    const int lw = w;
+    int* const rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
+    const unsigned rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
+    const unsigned gi_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds.giring + (set * DF_GIRING * DF_RB + lw) * (3 * DF_JS)));
+    const int32_t* const rec_w = recs + 16 * lw + (lane & 15);
+    const int64_t wstride = 16 * DF_RB;
+    const int gi_lane_off = ((lane % 24) >> 3) * H + sl * DF_JS + 4 * (lane & 7);
+    auto rec_src = [&](int j) -> const void* { return rec_w + (int64_t)min(j, nblk - 1) * wstride; };
+    auto rec_dst = [&](int j) -> unsigned { return rec_ring_a + (j & 7) * 64; };
+    auto gi_src = [&](int node) -> const void* { return gi0 + (int64_t)max(node, 0) * 3 * H + gi_lane_off; };
+    auto gi_dst = [&](int blk) -> unsigned { return gi_ring_a + (blk % DF_GIRING) * (DF_RB * 3 * DF_JS * 4); };
+    if (nblk > 0) {   // prologue: records of blocks 0..RD-1, gi0 slices of blocks 0..GD-1
+        auto glds4 = [&](const void* gsrc, unsigned lds_dst) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+        };
+        auto glds16 = [&](const void* gsrc, unsigned lds_dst) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+        };
+#pragma unroll
+        for (int j = 0; j < DF_RD; ++j) if (lane < 16) glds4(rec_src(j), rec_dst(j));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (has_gi0) {
+#pragma unroll
+            for (int j = 0; j < DF_GD; ++j) {
+                const int node = __builtin_amdgcn_readfirstlane(rec_ring[j * 16]);
+                if (lane < 24) glds16(gi_src(node), gi_dst(j));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+
+    unsigned long long* const dbg = (DF_PROF && S.dbg) ? S.dbg + 2 * gridDim.x : nullptr;
+    const bool prof = DF_PROF && dbg != nullptr && (int)blockIdx.x == S.dbg_wg && w == 0 && lane == 0;
+    unsigned long long t_issue = 0ull;
+    unsigned polls = 0;
+    DfSweep A;
+    for (int b = 0; b < nblk; ++b) {
+        if (prof) { dbg[8 * (int64_t)(DF_NLS * b + set) + 4] = wall_clock64(); polls = 0; }
+        const int cur = rec_ring[(b & 7) * 16 + (lane & 15)];
+        const int v2 = has_gi0 ? __builtin_amdgcn_readfirstlane(rec_ring[((b + DF_GD) & 7) * 16]) : 0;   // node of block b + GD (landed long ago)
+#define DF_W(i) __builtin_amdgcn_readlane(cur, i)
+        const int v = DF_W(0);
+        float* const sbase = lds.ring + (set * DF_NSLOT + b % DF_NSLOT) * Slot::words;
+        // the ring slot has been handed back (off the dependent chain: the loaders run ahead of the compute waves only
+        // where rows are already waiting)
+        if (b >= DF_NSLOT) df_wait4(dn, b - DF_NSLOT + 1, err, spin_limit);
+        DfTripArgs T;
+        T.ra = rec_src(b + DF_RD); T.rl = rec_dst(b + DF_RD);
+        T.ga = has_gi0 ? gi_src(v2) : T.ra; T.gl = gi_dst(b + DF_GD);
+        T.b[0] = T.b[1] = T.b[2] = T.b[3] = g_src; T.c = g_src;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (v >= 0) {
+            const int eb = DF_W(1);
+            const int deg = proj ? 1 : DF_W(2) - eb;
+            if (PPK) T.c = p_in + (unsigned)v * pld + sl * DF_JS;
+            // poll until every granule of the trip carries this pass's tag: first trip with the prefetch group behind it
+            auto poll = [&](auto nn_c, auto dma_c) {
+                constexpr int NN = decltype(nn_c)::value, DM = decltype(dma_c)::value;
+                if (prof) { t_issue = wall_clock64(); ++polls; }
+                df_trip<NQ4, H, NN, PPK, DM>(A, T, lane8, lane31x8);
+                if (NN + PPK > 0 && !df_landed<NN, PPK>(A, epoch)) {
+                    unsigned spins = 0;
+                    do {
+                        if (!df_retry(spins, err, spin_limit)) break;
+                        if (prof) { t_issue = wall_clock64(); ++polls; }
+                        df_trip<NQ4, H, NN, PPK, 0>(A, T, lane8, lane31x8);
+                    } while (!df_landed<NN, PPK>(A, epoch));
+                }
+                if (prof && DM != 0) {
+                    dbg[8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64(); dbg[8 * (int64_t)(DF_NLS * b + set) + 6] = polls;
+                    if (DF_NLS * b + set >= 8) dbg[8 * (int64_t)(DF_NLS * b + set) + 7] = t_issue;
+                }
+            };
+#define DF_ROWF(e, q) __uint_as_float((unsigned)A.x[e][q])
+            // single chunk: s_e = w_key . h_e + gain . feat_e, alpha = exp(s - max) / (sum + 1e-16) (PyG), a = sum alpha_e h_e
+            auto row_n = [&](auto nn_c) {
+                constexpr int NN = decltype(nn_c)::value;
+                static_assert(NN >= 2 && NN <= 4, "");
+                T.b[0] = g_src + (unsigned)DF_W(4) * gld;
+                T.b[1] = g_src + (unsigned)DF_W(5) * gld;
+                if (NN > 2) T.b[2] = g_src + (unsigned)DF_W(6) * gld;
+                if (NN > 3) T.b[3] = g_src + (unsigned)DF_W(7) * gld;
+                float fe[NN];
+#pragma unroll
+                for (int e = 0; e < NN; ++e)
+                    fe[e] = gain0 * __int_as_float(DF_W(8 + 2 * e)) + gain1 * __int_as_float(DF_W(9 + 2 * e));
+                poll(nn_c, std::integral_constant<int, DMA1>());
+                float s[NN];
+#pragma unroll
+                for (int e = 0; e < NN; ++e) s[e] = DF_ROWF(e, 0) * wk[0] + DF_ROWF(e, 1) * wk[1] + DF_ROWF(e, 2) * wk[2] + DF_ROWF(e, 3) * wk[3];
+#pragma unroll
+                for (int e = 0; e < NN; ++e) s[e] = df_wave_sum(s[e]);
+                float mc = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < NN; ++e) { s[e] += fe[e]; mc = fmaxf(mc, s[e]); }
+                float l = 0.f;
+#pragma unroll
+                for (int e = 0; e < NN; ++e) {
+                    const float pe = __expf(s[e] - mc);
+                    l += pe;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = fmaf(pe, DF_ROWF(e, q), acc[q]);
+                }
+                const float inv = __builtin_amdgcn_rcpf(l + 1e-16f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] *= inv;
+            };
+            if (deg == 1) {          // the aggregate IS the predecessor's row (alpha = 1 / (1 + 1e-16) = 1)
+                T.b[0] = g_src + (unsigned)(proj ? v : DF_W(4)) * gld;
+                poll(std::integral_constant<int, 1>(), std::integral_constant<int, DMA1>());
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = DF_ROWF(0, q);
+            } else if (deg == 2) {
+                row_n(std::integral_constant<int, 2>());
+            } else if (deg == 3) {
+                row_n(std::integral_constant<int, 3>());
+            } else if (deg == 4) {
+                row_n(std::integral_constant<int, 4>());
+            } else if (deg <= 0) {   // a node without predecessors: zero aggregate (its projection slice still has to land)
+                poll(std::integral_constant<int, 0>(), std::integral_constant<int, DMA1>());
+            } else {                 // more than 4 in-edges: chunks of <= 4 under an online soft-max (ids / features of the
+                                     // chunks behind the first through the plan's CSR)
+                float m = -INFINITY, l = 0.f;
+                for (int c0 = 0; c0 < deg; c0 += 4) {
+                    const int nn = min(4, deg - c0);
+                    int pj[4] = {0, 0, 0, 0};
+                    float fe[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (c0 == 0) {
+                        pj[0] = DF_W(4); pj[1] = DF_W(5); pj[2] = DF_W(6); pj[3] = DF_W(7);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) fe[e] = gain0 * __int_as_float(DF_W(8 + 2 * e)) + gain1 * __int_as_float(DF_W(9 + 2 * e));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (e < nn) {
+                                pj[e] = col[eb + c0 + e];
+                                fe[e] = fmaf(gain1, eattr[(int64_t)(eb + c0 + e) * 2 + 1], fmaf(gain0, eattr[(int64_t)(eb + c0 + e) * 2], 0.f));
+                            }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) T.b[e] = g_src + (unsigned)pj[e] * gld;
+                    if (c0 == 0) poll(std::integral_constant<int, 4>(), std::integral_constant<int, DMA1>());
+                    else if (nn == 4) poll(std::integral_constant<int, 4>(), std::integral_constant<int, 0>());
+                    else if (nn == 3) poll(std::integral_constant<int, 3>(), std::integral_constant<int, 0>());
+                    else if (nn == 2) poll(std::integral_constant<int, 2>(), std::integral_constant<int, 0>());
+                    else poll(std::integral_constant<int, 1>(), std::integral_constant<int, 0>());
+                    float s[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[e] = DF_ROWF(e, 0) * wk[0] + DF_ROWF(e, 1) * wk[1] + DF_ROWF(e, 2) * wk[2] + DF_ROWF(e, 3) * wk[3];
+                    float mc = m;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s[e] = df_wave_sum(s[e]) + fe[e];
+                        if (e < nn) mc = fmaxf(mc, s[e]);
+                    }
+                    const float sc = __expf(m - mc);   // 0 on the first chunk (m = -inf)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] *= sc;
+                    l *= sc;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (e < nn) {
+                            const float pe = __expf(s[e] - mc);
+                            l += pe;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[q] = fmaf(pe, DF_ROWF(e, q), acc[q]);
+                        }
+                    }
+                    m = mc;
+                }
+                const float inv = __builtin_amdgcn_rcpf(l + 1e-16f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] *= inv;
+            }
+#undef DF_ROWF
+            if (prof) { asm volatile("" :: "v"(acc[0]), "v"(acc[3])); dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + set) + 4] = wall_clock64(); }   // fold done
+            float* a_row = sbase + Slot::a_off + lw * Slot::AP;
+#pragma unroll
+            for (int q = 0; q < NQ4; ++q) a_row[cpos[q]] = acc[q];
+            if (PPK) {   // input-side pre-activations of the slice: lanes l and l + 32 loaded the same granules (same words, same place)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) sbase[Slot::gi_off + lw * (3 * DF_JS) + g * DF_JS + (lane & 31)] = __uint_as_float((unsigned)A.xp[g]);
+            }
+        } else {
+            df_trip<NQ4, H, 0, 0, DMA1>(A, T, lane8, lane31x8);   // an idle row keeps the cadence: P(b) out, P(b - 1) landed
+        }
+#undef DF_W
+        reinterpret_cast<int*>(sbase + Slot::v_off)[lw] = v;   // (every lane: same word, same value - no lane-0 predicate)
+        if (prof) dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64();   // LDS writes issued
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        df_flag_st(lds.rdy + set * DF_WPS + w, b + 1);
+        df_wakeup();
+        if (prof) dbg[8 * (int64_t)(DF_NLS * b + set) + 3] = wall_clock64();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of ours is in flight when the wave ends
+}
+#undef DF_TRIP
+#undef DF_IFC
+#undef DF_IFCS
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 template <int CTRL> __device__ __forceinline__ float df_dpp(float v) {   // 0 where the source lane is outside the DPP row
@@ -828,7 +1142,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
                 }
                 if (st >= 0) break;
 #ifndef DF_NO_CSLEEP
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(DF_CSLEEP_N);
 #endif
                 bool give_up = false;
                 if (++spins > 4 * spin_limit) {   // the pass is lost; it must still end (node ids are bounded below)
@@ -954,6 +1268,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
         if (prof) { asm volatile("" :: "v"(hv)); dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + st) + 3] = wall_clock64(); }   // gates done
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) df_flag_st(lds.dn + st * DF_NCW + cw, b + 1);   // this wave is done with the slot (LDS executes a wave's accesses in order)
+        df_wakeup();
         if (live) {
             if (proj) {   // input-side pre-activations of the upper cell: W_ih u + b_ih, gate-major
                 gran_t* po = g_out + (int64_t)gv * pld + unit_s;
@@ -1061,9 +1376,15 @@ __global__ void __launch_bounds__(DF_THREADS, 3) dataflow_kernel(const int32_t* 
     } else {
         const int set = (wave - DF_NCW * DF_TEAMS) / DF_WPS;
         const int grp = df_stream_group(pair, set, S.groups);
-        const int w = (wave - DF_NCW * DF_TEAMS) % DF_WPS;
+        const int w = ((wave - DF_NCW * DF_TEAMS) % DF_WPS + (DF_ROT ? set : 0)) % DF_WPS;   // the row of its stream's blocks this wave serves
         if (grp >= 0) {
 #define DF_LOADER_CASE(K, RR, EX) case (K) * 4 + ((RR) == 2 ? 2 : 0) + ((EX) ? 1 : 0): df_loader<KPT, K, RR, EX>(plan, S, C, sl, grp, lds, w, set); break;
+#ifndef DF_NO_FAST_LOADER
+            if (DF_RPW == 1 && variant == DFK_REC0 * 4 + 2) { df_loader_fast<KPT, DFK_REC0>(plan, S, C, sl, grp, lds, w, set); }
+            else if (DF_RPW == 1 && variant == DFK_RECP * 4 + 2) { df_loader_fast<KPT, DFK_RECP>(plan, S, C, sl, grp, lds, w, set); }
+            else if (DF_RPW == 1 && (variant >> 2) == DFK_PROJ) { df_loader_fast<KPT, DFK_PROJ>(plan, S, C, sl, grp, lds, w, set); }
+            else
+#endif
             switch (variant) {
                 DF_LOADER_CASE(DFK_REC0, 2, false) DF_LOADER_CASE(DFK_REC0, 2, true)
                 DF_LOADER_CASE(DFK_REC0, -1, false) DF_LOADER_CASE(DFK_REC0, -1, true)

@@ -286,6 +286,9 @@ template <int KPT> struct DfPad { static constexpr int kp8 = 2 * KPT; static con
 #ifndef DF_WSLEEP_N
 #define DF_WSLEEP_N (DF_WAKEUP ? 8 : 1)   // ... of a loader's wait for its ring slot
 #endif
+#ifndef DF_LEAN_COMPUTE
+#define DF_LEAN_COMPUTE 1
+#endif
 #ifndef DF_ROT
 #define DF_ROT 0        // stream s gives row r of its blocks to loader wave (r + s) mod 4: the rows 0 of the two streams - all a thin
 #endif                  // dependent chain has - are polled and folded on different SIMDs
@@ -779,7 +782,6 @@ __device__ __forceinline__ bool df_landed(const DfSweep& W, unsigned epoch) {
 template <int KPT, int KIND>
 __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan, const DfArgs& S,
                                                const DfCell& C, int sl, int group, const DfLds& lds, int w, int set) {
-    static_assert(DF_RPW == 1, "one row per loader wave");
     constexpr int H = 16 * KPT;
     constexpr int SEG = DfPad<KPT>::seg, KP8 = DfPad<KPT>::kp8;
     typedef DfSlot<KPT> Slot;
@@ -811,11 +813,19 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
         if (!proj && q < NQ4) wk[q] = C.wkey[c];
     }
     const unsigned lane8 = 8u * lane, lane31x8 = 8u * (lane & 31);
-    const int lw = w;
-    int* const rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
-    const unsigned rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
-    const unsigned gi_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds.giring + (set * DF_GIRING * DF_RB + lw) * (3 * DF_JS)));
-    const int32_t* const rec_w = recs + 16 * lw + (lane & 15);
+    // (a wave serves DF_RPW rows of every block, one after the other: `lw` and the ring addresses follow the row)
+    int lw = w * DF_RPW;
+    int* rec_ring;
+    unsigned rec_ring_a, gi_ring_a;
+    const int32_t* rec_w;
+    auto set_row = [&](int row) {
+        lw = row;
+        rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
+        rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
+        gi_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds.giring + (set * DF_GIRING * DF_RB + lw) * (3 * DF_JS)));
+        rec_w = recs + 16 * lw + (lane & 15);
+    };
+    set_row(lw);
     const int64_t wstride = 16 * DF_RB;
     const int gi_lane_off = ((lane % 24) >> 3) * H + sl * DF_JS + 4 * (lane & 7);
     auto rec_src = [&](int j) -> const void* { return rec_w + (int64_t)min(j, nblk - 1) * wstride; };
@@ -833,16 +843,19 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
         };
+        for (int rr = 0; rr < DF_RPW; ++rr) {
+            set_row(w * DF_RPW + rr);
 #pragma unroll
-        for (int j = 0; j < DF_RD; ++j) if (lane < 16) glds4(rec_src(j), rec_dst(j));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (has_gi0) {
-#pragma unroll
-            for (int j = 0; j < DF_GD; ++j) {
-                const int node = __builtin_amdgcn_readfirstlane(rec_ring[j * 16]);
-                if (lane < 24) glds16(gi_src(node), gi_dst(j));
-            }
+            for (int j = 0; j < DF_RD; ++j) if (lane < 16) glds4(rec_src(j), rec_dst(j));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (has_gi0) {
+#pragma unroll
+                for (int j = 0; j < DF_GD; ++j) {
+                    const int node = __builtin_amdgcn_readfirstlane(rec_ring[j * 16]);
+                    if (lane < 24) glds16(gi_src(node), gi_dst(j));
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
     }
 
@@ -852,15 +865,18 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
     unsigned polls = 0;
     DfSweep A;
     for (int b = 0; b < nblk; ++b) {
+        // the ring slot has been handed back (off the dependent chain: the loaders run ahead of the compute waves only
+        // where rows are already waiting)
+        if (b >= DF_NSLOT) df_wait4(dn, b - DF_NSLOT + 1, err, spin_limit);
+#pragma unroll 1
+      for (int rr = 0; rr < DF_RPW; ++rr) {
+        if (DF_RPW > 1) set_row(w * DF_RPW + rr);
         if (prof) { dbg[8 * (int64_t)(DF_NLS * b + set) + 4] = wall_clock64(); polls = 0; }
         const int cur = rec_ring[(b & 7) * 16 + (lane & 15)];
         const int v2 = has_gi0 ? __builtin_amdgcn_readfirstlane(rec_ring[((b + DF_GD) & 7) * 16]) : 0;   // node of block b + GD (landed long ago)
 #define DF_W(i) __builtin_amdgcn_readlane(cur, i)
         const int v = DF_W(0);
         float* const sbase = lds.ring + (set * DF_NSLOT + b % DF_NSLOT) * Slot::words;
-        // the ring slot has been handed back (off the dependent chain: the loaders run ahead of the compute waves only
-        // where rows are already waiting)
-        if (b >= DF_NSLOT) df_wait4(dn, b - DF_NSLOT + 1, err, spin_limit);
         DfTripArgs T;
         T.ra = rec_src(b + DF_RD); T.rl = rec_dst(b + DF_RD);
         T.ga = has_gi0 ? gi_src(v2) : T.ra; T.gl = gi_dst(b + DF_GD);
@@ -1003,6 +1019,7 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
         }
 #undef DF_W
         reinterpret_cast<int*>(sbase + Slot::v_off)[lw] = v;   // (every lane: same word, same value - no lane-0 predicate)
+      }
         if (prof) dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64();   // LDS writes issued
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         df_flag_st(lds.rdy + set * DF_WPS + w, b + 1);
@@ -1125,6 +1142,36 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
                 if (++spins > 4 * spin_limit) { __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                 if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
             }
+        } else if (DF_LEAN_COMPUTE && DF_NLS == 2 && DF_WPS == 4) {
+            // the same choice (smallest positive lead first, ties alternate) with ONE trip to LDS per look: the 2 x 4 ready
+            // flags are two ds_read_b128 behind one wait (asm: a compiler-visible LDS access next to LDS-DMA traffic is fenced
+            // with vmcnt(0)), the rest is scalar
+            typedef int i4v __attribute__((ext_vector_type(4)));
+            const unsigned rdy_a = (unsigned)(uintptr_t)lds.rdy;
+            unsigned spins = 0;
+            for (;;) {
+                i4v r0, r1;
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(r0), "=&v"(r1) : "v"(rdy_a) : "memory");
+                const int m0 = __builtin_amdgcn_readfirstlane(min(min(r0.x, r0.y), min(r0.z, r0.w)));
+                const int m1 = __builtin_amdgcn_readfirstlane(min(min(r1.x, r1.y), min(r1.z, r1.w)));
+                const int l0 = done[0] < nb[0] ? m0 - done[0] : 0, l1 = done[1] < nb[1] ? m1 - done[1] : 0;
+                if (l0 > 0 || l1 > 0) {
+                    st = l0 <= 0 ? 1 : (l1 <= 0 ? 0 : (l0 != l1 ? (l0 < l1 ? 0 : 1) : pref));
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(DF_CSLEEP_N);
+                bool give_up = false;
+                if (++spins > 4 * spin_limit) {   // the pass is lost; it must still end (node ids are bounded below)
+                    __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    give_up = true;
+                }
+                if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = true;
+                if (give_up) {
+                    st = done[0] < nb[0] ? 0 : 1;
+                    break;
+                }
+            }
         } else {
             unsigned spins = 0;
             for (;;) {
@@ -1184,7 +1231,9 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
         float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, aval = 0.f;
         float c_r = b_r, c_z = b_z, c_n = b_n;
         if (thin) { c_r = lds.bias[unit_lt]; c_z = lds.bias[DF_JS + unit_lt]; c_n = lds.bias[2 * DF_JS + unit_lt]; }
-        if (!proj && gr < nr) {
+        // (without the thin-block path nothing in front of the products depends on the ids: every LDS read of the block - ids,
+        // gate operands, operand rows - leaves in one go; a dead row's lanes read their slot's stale words and drop them)
+        if (!proj && (DF_FMA_ROWS == 0 || gr < nr)) {
             if (has_gi) {   // from the gi0 ring (stacked layer 0) or from the slot (projection granules)
                 const float* gp = (gi_ring ? lds.giring + (st * DF_GIRING + b % DF_GIRING) * (DF_RB * 3 * DF_JS) : sbase + Slot::gi_off) + gr * (3 * DF_JS) + unit_ls;
                 gi_r = gp[0]; gi_z = gp[DF_JS]; gi_n = gp[2 * DF_JS];
@@ -1276,11 +1325,12 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
                 __hip_atomic_store(po + H, gran_pack(epoch, g3[1] + c_z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(po + 2 * H, gran_pack(epoch, g3[2] + c_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
-                h_out[(int64_t)gv * ld_h + unit_s] = hv;
-                // hand-off store: write-through (sc1: the line leaves this XCD's L2, any XCD's sc1 load finds it in
-                // memory), or - all readers are on this XCD - a plain 8-byte store that leaves the line in the shared L2
+                // hand-off store first (the consumers poll it): write-through (sc1: the line leaves this XCD's L2, any XCD's sc1
+                // load finds it in memory), or - all readers are on this XCD - a plain 8-byte store that leaves the line in the
+                // shared L2; the plain state row behind it
                 if (local_st) g_out[(int64_t)gv * gld + unit_s] = gran_pack(epoch, hv);
                 else __hip_atomic_store(g_out + (int64_t)gv * gld + unit_s, gran_pack(epoch, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                h_out[(int64_t)gv * ld_h + unit_s] = hv;
             }
             if (aux_out) {   // (behind the hand-off stores: nobody waits for these)
                 float* ao = aux_out + (int64_t)gv * (3 * H) + unit_s;
@@ -1380,9 +1430,9 @@ __global__ void __launch_bounds__(DF_THREADS, 3) dataflow_kernel(const int32_t* 
         if (grp >= 0) {
 #define DF_LOADER_CASE(K, RR, EX) case (K) * 4 + ((RR) == 2 ? 2 : 0) + ((EX) ? 1 : 0): df_loader<KPT, K, RR, EX>(plan, S, C, sl, grp, lds, w, set); break;
 #ifndef DF_NO_FAST_LOADER
-            if (DF_RPW == 1 && variant == DFK_REC0 * 4 + 2) { df_loader_fast<KPT, DFK_REC0>(plan, S, C, sl, grp, lds, w, set); }
-            else if (DF_RPW == 1 && variant == DFK_RECP * 4 + 2) { df_loader_fast<KPT, DFK_RECP>(plan, S, C, sl, grp, lds, w, set); }
-            else if (DF_RPW == 1 && (variant >> 2) == DFK_PROJ) { df_loader_fast<KPT, DFK_PROJ>(plan, S, C, sl, grp, lds, w, set); }
+            if (variant == DFK_REC0 * 4 + 2) { df_loader_fast<KPT, DFK_REC0>(plan, S, C, sl, grp, lds, w, set); }
+            else if (variant == DFK_RECP * 4 + 2) { df_loader_fast<KPT, DFK_RECP>(plan, S, C, sl, grp, lds, w, set); }
+            else if ((variant >> 2) == DFK_PROJ) { df_loader_fast<KPT, DFK_PROJ>(plan, S, C, sl, grp, lds, w, set); }
             else
 #endif
             switch (variant) {

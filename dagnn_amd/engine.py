@@ -85,8 +85,8 @@ PLAN_OVERLAP = _env_int("DAGNN_AMD_PLAN_OVERLAP", 0)
 PLAN_SMALL = _env_int("DAGNN_AMD_PLAN_SMALL", 1)            # 1: batches of <= 2048 nodes / 4096 edges / 512 graphs build plan and schedule with one workgroup each (csrc/small.hip)
 PLAN_GENERAL_BUILD = 1                                      # dagnn_plan.flags: keep the plan on the general kernels
 DATAFLOW = _env_int("DAGNN_AMD_DATAFLOW", 1)                # 1: the persistent graph-affine dataflow kernel where it applies (H <= 256)
-DF_COST_LAYER = _env_int("DAGNN_AMD_DF_COST_LAYER", 6)      # schedule cost of one dependent layer, in rows (hop latency / row cost;
-                                                            # round 3, after the per-block cost dropped: 4 -> 6, scripts/df_cost_sweep.py)
+DF_COST_LAYER = _env_int("DAGNN_AMD_DF_COST_LAYER", 4)      # schedule cost of one dependent layer, in rows (hop latency / row cost;
+                                                            # round 3: 4 -> 6 after the block got cheaper; round 4: back to 4 after the hop did (lean loader), scripts/df_cost_sweep.py)
 DF_COST_ROW = _env_int("DAGNN_AMD_DF_COST_ROW", 1)
 DF_GROUPS = _env_int("DAGNN_AMD_DF_GROUPS", 0)              # 0 = as many groups as the device hosts
 DF_XCD = _env_int("DAGNN_AMD_DF_XCD", 1)                    # 1: XCD-aware workgroup ids + hand-offs through the shared L2 where the run-time check allows

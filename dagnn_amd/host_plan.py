@@ -231,7 +231,7 @@ def dataflow_layout(N: int, B: int, G: int) -> Dict[str, int]:
     return L
 
 
-def build_dataflow_schedule_host(plan_words, N: int, E: int, B: int, R: int, groups: int, cost_layer: int = 6,
+def build_dataflow_schedule_host(plan_words, N: int, E: int, B: int, R: int, groups: int, cost_layer: int = 4,
                                  cost_row: int = 1) -> np.ndarray:
     """The dataflow kernel's schedule (`dagnn_dataflow_schedule`, csrc/dataflow.hip) from a plan, on the host: graphs
     dealt to `groups` groups longest-processing-time first (integer costs, ties to the lowest group), row records
@@ -342,7 +342,7 @@ def build_dataflow_schedule_host(plan_words, N: int, E: int, B: int, R: int, gro
     return out
 
 
-def attach_plan(batch, num_graphs: Optional[int] = None, dataflow_groups: int = 0, cost_layer: int = 6, cost_row: int = 1):
+def attach_plan(batch, num_graphs: Optional[int] = None, dataflow_groups: int = 0, cost_layer: int = 4, cost_row: int = 1):
     """Build the host plan of a collated batch and attach it (`_dagnn_plan`: int32 tensor that moves with
     `batch.to(device)`; `_dagnn_plan_meta`: sizes + the host schedule).  `DAGNN.forward` uses it when present.  With
     `dataflow_groups` the schedule of the persistent dataflow kernel is built here as well (`_dagnn_df`)."""

@@ -204,6 +204,7 @@ SYMBOLS = {
     "dagnn_dataflow_schedule": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p, C.c_void_p]),
     "dagnn_dataflow_run": (C.c_int, [C.POINTER(Plan), C.POINTER(DataflowArgs), C.c_void_p]),
+    "dagnn_dataflow_run_wide": (C.c_int, [C.POINTER(Plan), C.POINTER(DataflowArgs), C.c_void_p]),
     "dagnn_tiles_launches": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dagnn_tiles_run": (C.c_int, [C.POINTER(Plan), C.POINTER(TilesArgs), C.c_void_p]),
     "dagnn_pack_dataflow": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

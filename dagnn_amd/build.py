@@ -74,7 +74,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in sources():
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+        src_time = os.path.getmtime(src)
+        with open(src) as fh:   # a translation unit that includes another source (dataflow_w.hip <- dataflow.hip) follows it
+            for line in fh:
+                if line.startswith("#include \"") and line.rstrip().endswith(".hip\""):
+                    inc = os.path.join(CSRC, line.split("\"")[1])
+                    if os.path.exists(inc):
+                        src_time = max(src_time, os.path.getmtime(inc))
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(src_time, hdr_time):
             jobs.append((src, obj))
     with ThreadPoolExecutor(max_workers=min(8, max(len(jobs), 1))) as pool:
         for f in [pool.submit(_compile, s_, o_, verbose) for s_, o_ in jobs]:

@@ -97,7 +97,7 @@ def pack_lockstep(cells, force: bool = False) -> None:
     for all matrices instead of three launches per matrix.  Cells the dataflow kernel serves (Hp <= 256) get its
     layout instead; `force` (the fallback inside `run_stack_lockstep`) packs the per-layer launches' layouts too."""
     cells = list(cells)
-    if cells and engine.DATAFLOW and cells[0].Hp <= 256 and not force:
+    if cells and engine.DATAFLOW and engine.dataflow_width(cells[0].Hp) and not force:
         pack_dataflow(cells)
         return
     if cells and engine.TILES and cells[0].Hp == 512 and not force:
@@ -126,7 +126,8 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
     `stacked` is the number of stacked cells of the model: it only picks the padded width (`engine.state_width`).
     """
     lock = schedule == "lockstep"
-    Hp = engine.state_width(H, stacked, 0 if edge_w is None else int(edge_w.shape[1])) if lock else round_up4(H)
+    wide_ok = edge_w is not None and not vid_nodes and (key_dim is None or key_dim == H)   # what dagnn_dataflow_run_wide takes
+    Hp = engine.state_width(H, stacked, 0 if edge_w is None else int(edge_w.shape[1]), wide_ok=wide_ok) if lock else round_up4(H)
     c = CellParams()
     c.Hp = Hp
     wi = _pad_gate_rows(w_ih.detach().float(), H, Hp)
@@ -140,7 +141,7 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
     c.w_hh_pk = c.w_ih_pk = None
     c.w_hh_df = c.w_ih_df = None
     c.w_hh_bt = c.w_ih_bt = None   # reverse sweep: packed gate-wise transposes (engine.bwd_dataflow_sweep)
-    use_df = engine.DATAFLOW and Hp <= 256   # the dataflow kernel's layout instead (packed below)
+    use_df = engine.DATAFLOW and engine.dataflow_width(Hp)   # the dataflow kernel's layout instead (packed below)
     if lock and pack and not use_df:   # pack=False: the caller batches the packing of all its cells (pack_lockstep)
         c.w_hh_pk = {js: engine.pack_slices(whh, Hp, js) for js in (16, 32)}
         c.w_hh_pk["mfma"] = engine.pack_mfma(whh, Hp)
@@ -205,6 +206,8 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
     groups = engine.dataflow_groups(dev, len(dirs), L, Hp, plan.B, training=keep is not None) if (arena is not None and N > 0) else 0
     if N * 3 * Hp >= (1 << 31):   # the dataflow kernels address their granule buffers with 32-bit row offsets
         groups = 0
+    if Hp > 256 and (plan.R != 2 or static_score is not None or vid_nodes or any(c.edge_gain is None or c.w_key is None for c in cells.values())):
+        groups = 0   # the H = 320 shape has the lean loaders only (dagnn_dataflow_run_wide)
     if arena is not None:
         arena.poll()   # a failure an earlier pass reported (no synchronisation); either path below is watched
     tiles = 0

@@ -731,7 +731,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
 //     branch], the soft-max of a single chunk needs no running rescale, nothing is predicated per lane;
 //   * everything that does not depend on the polled rows happens BEFORE the poll (ring-slot wait, addresses, edge gains);
 //   * rows with more than 4 in-edges take the general chunk loop (online soft-max), as before.
-struct DfSweep { gran_t x[4][4]; gran_t xp[3]; };
+struct DfSweep { gran_t x[4][5]; gran_t xp[3]; };   // (the fifth column block: H = 320 only)
 
 #define DF_TRIP(n, p, d)                                                                                                   \
     asm volatile(DF_ROWS_##n DF_PROJ_##p DF_DMA_##d                                                                        \
@@ -744,7 +744,25 @@ struct DfSweep { gran_t x[4][4]; gran_t xp[3]; };
                    [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [ra] "v"(ra), [rl] "s"(rl), [ga] "v"(ga), [gl] "s"(gl),    \
                    [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)                                                                \
                  : "memory")
-#define DF_IFC(n, p, d) if constexpr (NN == (n) && PP == (p) && DMA == (d)) { DF_TRIP(n, p, d); } else
+// H = 320: five column blocks per lane
+#define DF_ROW_LD5(e) DF_ROW_LD(e) "global_load_dwordx2 %[x" #e "4], %[vo], %[b" #e "] offset:%[o4] sc1\n\t"
+#define DF_ROWS5_0 ""
+#define DF_ROWS5_1 DF_ROW_LD5(0)
+#define DF_ROWS5_2 DF_ROWS5_1 DF_ROW_LD5(1)
+#define DF_ROWS5_3 DF_ROWS5_2 DF_ROW_LD5(2)
+#define DF_ROWS5_4 DF_ROWS5_3 DF_ROW_LD5(3)
+#define DF_TRIP5(n, p, d)                                                                                                  \
+    asm volatile(DF_ROWS5_##n DF_PROJ_##p DF_DMA_##d                                                                       \
+                 : [x00] "=v"(W.x[0][0]), [x01] "=v"(W.x[0][1]), [x02] "=v"(W.x[0][2]), [x03] "=v"(W.x[0][3]), [x04] "=v"(W.x[0][4]), \
+                   [x10] "=v"(W.x[1][0]), [x11] "=v"(W.x[1][1]), [x12] "=v"(W.x[1][2]), [x13] "=v"(W.x[1][3]), [x14] "=v"(W.x[1][4]), \
+                   [x20] "=v"(W.x[2][0]), [x21] "=v"(W.x[2][1]), [x22] "=v"(W.x[2][2]), [x23] "=v"(W.x[2][3]), [x24] "=v"(W.x[2][4]), \
+                   [x30] "=v"(W.x[3][0]), [x31] "=v"(W.x[3][1]), [x32] "=v"(W.x[3][2]), [x33] "=v"(W.x[3][3]), [x34] "=v"(W.x[3][4]), \
+                   [p0] "=v"(W.xp[0]), [p1] "=v"(W.xp[1]), [p2] "=v"(W.xp[2]), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)  \
+                 : [vo] "v"(lane8), [vp] "v"(lane31x8), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),            \
+                   [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [ra] "v"(ra), [rl] "s"(rl), [ga] "v"(ga), [gl] "s"(gl),    \
+                   [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3), [o4] "n"(2048)                                                \
+                 : "memory")
+#define DF_IFC(n, p, d) if constexpr (NN == (n) && PP == (p) && DMA == (d)) { if constexpr (NQ4 == 5) { DF_TRIP5(n, p, d); } else { DF_TRIP(n, p, d); } } else
 #define DF_IFCS(n) DF_IFC(n, 0, 0) DF_IFC(n, 0, 1) DF_IFC(n, 0, 2) DF_IFC(n, 1, 0) DF_IFC(n, 1, 1) DF_IFC(n, 1, 2)
 
 struct DfTripArgs {
@@ -758,7 +776,7 @@ struct DfTripArgs {
 // statement of a static shape (see df_loader)
 template <int NQ4, int H, int NN, int PP, int DMA>
 __device__ __forceinline__ void df_trip(DfSweep& W, const DfTripArgs& T, unsigned lane8, unsigned lane31x8) {
-    constexpr int O1 = (NQ4 > 1 ? 1 : 0) * 512, O2 = (NQ4 > 2 ? 2 : NQ4 - 1) * 512, O3 = (NQ4 - 1) * 512;
+    constexpr int O1 = (NQ4 > 1 ? 1 : 0) * 512, O2 = (NQ4 > 2 ? 2 : NQ4 - 1) * 512, O3 = (NQ4 > 3 ? 3 : NQ4 - 1) * 512;
     const gran_t* b0 = T.b[0]; const gran_t* b1 = T.b[1]; const gran_t* b2 = T.b[2]; const gran_t* b3 = T.b[3];
     const gran_t* c0p = T.c; const gran_t* c1p = T.c + H; const gran_t* c2p = T.c + 2 * H;
     const void* ra = T.ra; const unsigned rl = T.rl; const void* ga = T.ga; const unsigned gl = T.gl;
@@ -769,12 +787,14 @@ __device__ __forceinline__ void df_trip(DfSweep& W, const DfTripArgs& T, unsigne
 
 // every granule of the trip carries this pass's tag.  Tags never exceed the current epoch (the arena hands out strictly
 // increasing ones and starts over on zeroed buffers), so "all equal" is "the minimum equals": one v_min3 per two tags
-template <int NN, int PP>
+template <int NN, int PP, int NQ4 = 4>
 __device__ __forceinline__ bool df_landed(const DfSweep& W, unsigned epoch) {
     unsigned m = epoch;
 #pragma unroll
-    for (int e = 0; e < NN; ++e)
+    for (int e = 0; e < NN; ++e) {
         m = min(min(m, min((unsigned)(W.x[e][0] >> 32), (unsigned)(W.x[e][1] >> 32))), min((unsigned)(W.x[e][2] >> 32), (unsigned)(W.x[e][3] >> 32)));
+        if (NQ4 == 5) m = min(m, (unsigned)(W.x[e][4] >> 32));
+    }
     if (PP) m = min(min(m, (unsigned)(W.xp[0] >> 32)), min((unsigned)(W.xp[1] >> 32), (unsigned)(W.xp[2] >> 32)));
     return __builtin_amdgcn_uicmp(m, epoch, 33 /* ICMP_NE */) == 0ull;
 }
@@ -804,13 +824,14 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
     const float* const gi0 = has_gi0 ? C.gi0 : nullptr;
     const float gain0 = proj ? 0.f : C.gain[0], gain1 = proj ? 0.f : C.gain[1];
     int* const dn = lds.dn + set * DF_NCW;
-    float wk[4] = {0.f, 0.f, 0.f, 0.f};
-    int cpos[4];
+    constexpr int NC = NQ4 > 4 ? NQ4 : 4;   // column blocks a lane carries (H < 256 repeats the last one: same trip shape for every H <= 256)
+    float wk[NC];
+    int cpos[NC];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NC; ++q) {
         const int c = 64 * q + lane;
         cpos[q] = c + (SEG - KP8) * (c / KP8);
-        if (!proj && q < NQ4) wk[q] = C.wkey[c];
+        wk[q] = (!proj && q < NQ4) ? C.wkey[c] : 0.f;
     }
     const unsigned lane8 = 8u * lane, lane31x8 = 8u * (lane & 31);
     // (a wave serves DF_RPW rows of every block, one after the other: `lw` and the ring addresses follow the row)
@@ -881,7 +902,9 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
         T.ra = rec_src(b + DF_RD); T.rl = rec_dst(b + DF_RD);
         T.ga = has_gi0 ? gi_src(v2) : T.ra; T.gl = gi_dst(b + DF_GD);
         T.b[0] = T.b[1] = T.b[2] = T.b[3] = g_src; T.c = g_src;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float acc[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) acc[q] = 0.f;
         if (v >= 0) {
             const int eb = DF_W(1);
             const int deg = proj ? 1 : DF_W(2) - eb;
@@ -891,13 +914,13 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
                 constexpr int NN = decltype(nn_c)::value, DM = decltype(dma_c)::value;
                 if (prof) { t_issue = wall_clock64(); ++polls; }
                 df_trip<NQ4, H, NN, PPK, DM>(A, T, lane8, lane31x8);
-                if (NN + PPK > 0 && !df_landed<NN, PPK>(A, epoch)) {
+                if (NN + PPK > 0 && !df_landed<NN, PPK, NQ4>(A, epoch)) {
                     unsigned spins = 0;
                     do {
                         if (!df_retry(spins, err, spin_limit)) break;
                         if (prof) { t_issue = wall_clock64(); ++polls; }
                         df_trip<NQ4, H, NN, PPK, 0>(A, T, lane8, lane31x8);
-                    } while (!df_landed<NN, PPK>(A, epoch));
+                    } while (!df_landed<NN, PPK, NQ4>(A, epoch));
                 }
                 if (prof && DM != 0) {
                     dbg[8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64(); dbg[8 * (int64_t)(DF_NLS * b + set) + 6] = polls;
@@ -920,7 +943,7 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
                 poll(nn_c, std::integral_constant<int, DMA1>());
                 float s[NN];
 #pragma unroll
-                for (int e = 0; e < NN; ++e) s[e] = DF_ROWF(e, 0) * wk[0] + DF_ROWF(e, 1) * wk[1] + DF_ROWF(e, 2) * wk[2] + DF_ROWF(e, 3) * wk[3];
+                for (int e = 0; e < NN; ++e) { s[e] = DF_ROWF(e, 0) * wk[0] + DF_ROWF(e, 1) * wk[1] + DF_ROWF(e, 2) * wk[2] + DF_ROWF(e, 3) * wk[3]; if (NC > 4) s[e] = fmaf(DF_ROWF(e, 4), wk[NC - 1], s[e]); }
 #pragma unroll
                 for (int e = 0; e < NN; ++e) s[e] = df_wave_sum(s[e]);
                 float mc = -INFINITY;
@@ -932,17 +955,17 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
                     const float pe = __expf(s[e] - mc);
                     l += pe;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] = fmaf(pe, DF_ROWF(e, q), acc[q]);
+                    for (int q = 0; q < NC; ++q) acc[q] = fmaf(pe, DF_ROWF(e, q), acc[q]);
                 }
                 const float inv = __builtin_amdgcn_rcpf(l + 1e-16f);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] *= inv;
+                for (int q = 0; q < NC; ++q) acc[q] *= inv;
             };
             if (deg == 1) {          // the aggregate IS the predecessor's row (alpha = 1 / (1 + 1e-16) = 1)
                 T.b[0] = g_src + (unsigned)(proj ? v : DF_W(4)) * gld;
                 poll(std::integral_constant<int, 1>(), std::integral_constant<int, DMA1>());
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = DF_ROWF(0, q);
+                for (int q = 0; q < NC; ++q) acc[q] = DF_ROWF(0, q);
             } else if (deg == 2) {
                 row_n(std::integral_constant<int, 2>());
             } else if (deg == 3) {
@@ -979,7 +1002,7 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
                     else poll(std::integral_constant<int, 1>(), std::integral_constant<int, 0>());
                     float s[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) s[e] = DF_ROWF(e, 0) * wk[0] + DF_ROWF(e, 1) * wk[1] + DF_ROWF(e, 2) * wk[2] + DF_ROWF(e, 3) * wk[3];
+                    for (int e = 0; e < 4; ++e) { s[e] = DF_ROWF(e, 0) * wk[0] + DF_ROWF(e, 1) * wk[1] + DF_ROWF(e, 2) * wk[2] + DF_ROWF(e, 3) * wk[3]; if (NC > 4) s[e] = fmaf(DF_ROWF(e, 4), wk[NC - 1], s[e]); }
                     float mc = m;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -988,7 +1011,7 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
                     }
                     const float sc = __expf(m - mc);   // 0 on the first chunk (m = -inf)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] *= sc;
+                    for (int q = 0; q < NC; ++q) acc[q] *= sc;
                     l *= sc;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -996,17 +1019,17 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
                             const float pe = __expf(s[e] - mc);
                             l += pe;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[q] = fmaf(pe, DF_ROWF(e, q), acc[q]);
+                            for (int q = 0; q < NC; ++q) acc[q] = fmaf(pe, DF_ROWF(e, q), acc[q]);
                         }
                     }
                     m = mc;
                 }
                 const float inv = __builtin_amdgcn_rcpf(l + 1e-16f);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] *= inv;
+                for (int q = 0; q < NC; ++q) acc[q] *= inv;
             }
 #undef DF_ROWF
-            if (prof) { asm volatile("" :: "v"(acc[0]), "v"(acc[3])); dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + set) + 4] = wall_clock64(); }   // fold done
+            if (prof) { asm volatile("" :: "v"(acc[0]), "v"(acc[NC - 1])); dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + set) + 4] = wall_clock64(); }   // fold done
             float* a_row = sbase + Slot::a_off + lw * Slot::AP;
 #pragma unroll
             for (int q = 0; q < NQ4; ++q) a_row[cpos[q]] = acc[q];
@@ -1029,6 +1052,7 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of ours is in flight when the wave ends
 }
 #undef DF_TRIP
+#undef DF_TRIP5
 #undef DF_IFC
 #undef DF_IFCS
 
@@ -1342,7 +1366,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
 }
 
 template <int KPT>
-__global__ void __launch_bounds__(DF_THREADS, 3) dataflow_kernel(const int32_t* __restrict__ plan, DfArgs S) {
+__global__ void __launch_bounds__(DF_THREADS, DF_THREADS / 256) dataflow_kernel(const int32_t* __restrict__ plan, DfArgs S) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef DfSlot<KPT> Slot;
     constexpr int NS = 16 * KPT / DF_JS;
@@ -1435,12 +1459,16 @@ __global__ void __launch_bounds__(DF_THREADS, 3) dataflow_kernel(const int32_t* 
             else if ((variant >> 2) == DFK_PROJ) { df_loader_fast<KPT, DFK_PROJ>(plan, S, C, sl, grp, lds, w, set); }
             else
 #endif
-            switch (variant) {
-                DF_LOADER_CASE(DFK_REC0, 2, false) DF_LOADER_CASE(DFK_REC0, 2, true)
-                DF_LOADER_CASE(DFK_REC0, -1, false) DF_LOADER_CASE(DFK_REC0, -1, true)
-                DF_LOADER_CASE(DFK_RECP, 2, false) DF_LOADER_CASE(DFK_RECP, 2, true)
-                DF_LOADER_CASE(DFK_RECP, -1, false) DF_LOADER_CASE(DFK_RECP, -1, true)
-                default: df_loader<KPT, DFK_PROJ, -1, false>(plan, S, C, sl, grp, lds, w, set); break;
+            if constexpr (KPT <= 16) {
+                switch (variant) {
+                    DF_LOADER_CASE(DFK_REC0, 2, false) DF_LOADER_CASE(DFK_REC0, 2, true)
+                    DF_LOADER_CASE(DFK_REC0, -1, false) DF_LOADER_CASE(DFK_REC0, -1, true)
+                    DF_LOADER_CASE(DFK_RECP, 2, false) DF_LOADER_CASE(DFK_RECP, 2, true)
+                    DF_LOADER_CASE(DFK_RECP, -1, false) DF_LOADER_CASE(DFK_RECP, -1, true)
+                    default: df_loader<KPT, DFK_PROJ, -1, false>(plan, S, C, sl, grp, lds, w, set); break;
+                }
+            } else {   // H = 320 exists for the benchmarked cell variants only (the host checks: dagnn_dataflow_run)
+                if (tid % 64 == 0) __hip_atomic_fetch_or(S.err, 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #undef DF_LOADER_CASE
         }
@@ -1484,19 +1512,25 @@ __global__ void __launch_bounds__(256) df_score_parts_kernel(float* __restrict__
     const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= N) return;
     float* row = h + v * ld_h;
-    float s = 0.f;
-    if (4 * lane < H) {
-        const float4 x = reinterpret_cast<const float4*>(row)[lane];
-        const float4 w = reinterpret_cast<const float4*>(wkey)[lane];
-        s = x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w;
+    for (int l4 = lane; 4 * l4 < ((H + 255) & ~255); l4 += 64) {   // (wave-uniform trip count: the shuffles below see every lane; H = 320: two rounds)
+        float s = 0.f;
+        if (4 * l4 < H) {
+            const float4 x = reinterpret_cast<const float4*>(row)[l4];
+            const float4 w = reinterpret_cast<const float4*>(wkey)[l4];
+            s = x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w;
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if ((l4 & 3) == 0 && 4 * l4 < H) row[H + (l4 >> 2)] = s;
     }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if ((lane & 3) == 0 && 4 * lane < H) row[H + (lane >> 2)] = s;
 }
 
 }  // namespace
 
+#ifdef DF_WIDE_TU
+constexpr int DF_TU_MAX_H = 320;   // this translation unit: csrc/dataflow_w.hip, the 8-wave workgroup shape of H = 320
+#else
+constexpr int DF_TU_MAX_H = 256;
 extern "C" size_t dagnn_dataflow_bytes(int64_t N, int64_t B, int groups) {
     if (N < 0 || B < 0 || groups < 1 || groups > DF_MAX_GROUPS) return 0;
     return (size_t)df_layout_words(N, B, groups).total * sizeof(int32_t);
@@ -1512,7 +1546,7 @@ extern "C" int dagnn_dataflow_layout(int64_t N, int64_t B, int groups, int64_t* 
 }
 
 extern "C" int dagnn_dataflow_groups(int num_cus, int num_dirs, int num_stacked, int H, int64_t B) {
-    if (num_cus <= 0 || num_dirs < 1 || num_dirs > DAGNN_MAX_DIRS || num_stacked < 1 || H <= 0 || (H % 64) || H > 256 || B <= 0)
+    if (num_cus <= 0 || num_dirs < 1 || num_dirs > DAGNN_MAX_DIRS || num_stacked < 1 || H <= 0 || (H % 64) || H > 320 || B <= 0)
         return 0;
     const int kcells = num_dirs * (2 * num_stacked - 1);   // one projection cell per stacked layer above the first
     if (kcells > DF_MAX_KCELLS) return 0;
@@ -1560,7 +1594,7 @@ extern "C" int dagnn_dataflow_schedule(const dagnn_plan* pl, void* ws_, size_t w
 }
 
 static int df_pack(const float* w, float* out, int H, int transposed, void* stream) {
-    if (!w || !out || H <= 0 || (H % 64) || H > 256) return DAGNN_EINVAL;
+    if (!w || !out || H <= 0 || (H % 64) || H > 320) return DAGNN_EINVAL;
     const int64_t total = (int64_t)3 * H * H / 4;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -1583,10 +1617,24 @@ extern "C" int dagnn_score_parts(float* h, int ld_h, int H, const float* w_key, 
     return DAGNN_OK;
 }
 
+#endif   // !DF_WIDE_TU
+
+#ifdef DF_WIDE_TU
+extern "C" int dagnn_dataflow_run_wide(const dagnn_plan* pl, const dagnn_dataflow_args* a, void* stream) {
+    if (!pl || !pl->data || !a || !a->schedule) return DAGNN_EINVAL;
+    if (a->H <= 256) return DAGNN_EINVAL;
+    // (the wide shape has the lean loaders only: two edge features folded inline, no static scores / vertex-id key biases)
+    if (pl->num_edge_feats != 2 || a->vid_mod > 0) return DAGNN_EINVAL;
+    for (int d = 0; d < 2; ++d)
+        for (int i = 0; i < a->num_stacked && i < DAGNN_MAX_STACKED; ++i)
+            if (((a->dir_mask >> d) & 1) && (a->cell[d][i].static_score || !a->cell[d][i].edge_gain)) return DAGNN_EINVAL;
+#else
 extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_args* a, void* stream) {
     if (!pl || !pl->data || !a || !a->schedule) return DAGNN_EINVAL;
+    if (a->H > 256) return dagnn_dataflow_run_wide(pl, a, stream);   // H = 320: csrc/dataflow_w.hip
+#endif
     const int H = a->H, Ls = a->num_stacked, dir_mask = a->dir_mask & 3, G = a->groups;
-    if (H <= 0 || (H % 64) || H > 256 || Ls <= 0 || Ls > DAGNN_MAX_STACKED || !dir_mask || a->ld_h < H || a->gld < H ||
+    if (H <= 0 || (H % 64) || H > DF_TU_MAX_H || Ls <= 0 || Ls > DAGNN_MAX_STACKED || !dir_mask || a->ld_h < H || a->gld < H ||
         (Ls > 1 && a->pld < 3 * H) || G < 1 || G > DF_MAX_GROUPS || a->epoch == 0 || !a->err)
         return DAGNN_EINVAL;
     if (pl->B == 0 || pl->N == 0) return DAGNN_OK;
@@ -1682,12 +1730,16 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
         if (ea != hipSuccess) return DAGNN_EHIP(ea);                                                                     \
         hipLaunchKernelGGL((dataflow_kernel<KPT>), dim3(grid), dim3(DF_THREADS), df_lds_bytes<KPT>(), st, plan, S);      \
     } while (0)
+#ifdef DF_WIDE_TU
+    DF_LAUNCH(20);
+#else
     switch (H / 16) {
         case 4: DF_LAUNCH(4); break;
         case 8: DF_LAUNCH(8); break;
         case 12: DF_LAUNCH(12); break;
         default: DF_LAUNCH(16); break;
     }
+#endif
 #undef DF_LAUNCH
     DAGNN_CHECK_LAUNCH();
     return DAGNN_OK;

@@ -26,7 +26,10 @@ constexpr int DF_NSLOT = DF_NSLOT_V;    // LDS ring depth (blocks the loaders ma
 constexpr int DF_TEAMS = DF_TEAMS_V;          // compute teams (of DF_NCW waves): 1 = one team takes the blocks of every stream
                                               // as they become ready; DF_NLS = a team per stream (two waves per SIMD)
 static_assert(DF_TEAMS == 1 || DF_TEAMS == DF_NLS, "compute teams");
-constexpr int DF_NLW = 12 - DF_NCW * DF_TEAMS;   // loader waves per workgroup (12 waves = 3 per SIMD at <= 168 VGPRs)
+#ifndef DF_NLW_V
+#define DF_NLW_V (12 - DF_NCW * DF_TEAMS_V)
+#endif
+constexpr int DF_NLW = DF_NLW_V;                 // loader waves per workgroup (12 waves = 3 per SIMD at <= 168 VGPRs)
 constexpr int DF_WPS = DF_NLW / DF_NLS;     // ... per stream
 constexpr int DF_RPW = DF_RB / DF_WPS;      // rows of a block per loader wave (one after the other)
 static_assert(DF_NLS == 2 || DF_NLS == 4 || DF_NLS == 8, "streams per workgroup");

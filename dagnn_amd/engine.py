@@ -413,7 +413,7 @@ def effective_cus(device, training: bool = False) -> int:
 def dataflow_groups(device, num_dirs: int, num_stacked: int, H: int, B: int, training: bool = False) -> int:
     """Groups the dataflow kernel runs on this device for this model shape; 0 = not applicable.  `training`: a pass
     whose reverse sweep may overlap a gradient collective (`reserved_cus`)."""
-    if not DATAFLOW:
+    if not DATAFLOW or not dataflow_width(int(H)):
         return 0
     cus = effective_cus(device, training)
     g = _lib.load().dagnn_dataflow_groups(cus, int(num_dirs), int(num_stacked), int(H), int(B))
@@ -480,7 +480,16 @@ def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     arena.watch(plan, folded=True)
 
 
-def state_width(H: int, num_stacked: int = 1, num_edge_feats: int = 0) -> int:
+DF_WIDE = _env_int("DAGNN_AMD_DF_WIDE", 1)   # 1: hidden sizes 257..320 run 320 wide on the dataflow kernel's 8-wave shape (csrc/dataflow_w.hip)
+
+
+def dataflow_width(Hp: int) -> bool:
+    """Padded widths the forward dataflow kernel exists for: multiples of 64 up to 256, and 320 (`dagnn_dataflow_run_wide`:
+    two edge features, hidden-state keys, no vertex-id key biases - `state_width` only picks 320 for such models)."""
+    return Hp <= 256 or (Hp == 320 and bool(DF_WIDE))
+
+
+def state_width(H: int, num_stacked: int = 1, num_edge_feats: int = 0, wide_ok: bool = False) -> int:
     """Padded width of a state row on the lock-step path: the next multiple of 64 - except that 256 < H < 512 is padded
     to 512 for a stacked model (and 384 < H for a single-layer one).  512 is the one width the tile kernel (csrc/tiles.hip)
     is built for and the one above 256 whose per-layer kernels, forward and reverse, run on MFMA tiles; padded units stay
@@ -489,6 +498,10 @@ def state_width(H: int, num_stacked: int = 1, num_edge_feats: int = 0) -> int:
     (H = 300, L = 5, B = 32 forward); L = 1 wins from 448 up only, hence the second rule.  `DAGNN_AMD_TILES_PAD=0`
     keeps the next multiple of 64, `=2` pads every 256 < H < 512."""
     Hp = (int(H) + 63) // 64 * 64
+    if Hp == 320 and wide_ok and DATAFLOW and DF_WIDE and num_edge_feats == 2:
+        # hidden sizes 257..320 (the reference trains at 300, scripts/ogb_tok.sh:17): the dataflow kernel at H = 320 -
+        # measured (round 4, B = 160, L = 2): forward 8.7 ms padded to 512 on the tile kernel / launches
+        return 320
     if TILES and TILES_PAD and 256 < Hp < 512 and num_edge_feats <= 2 and (num_stacked >= 2 or Hp > 384 or TILES_PAD >= 2):
         Hp = 512
     return Hp
@@ -955,7 +968,7 @@ def pack_dataflow_transposed(w: torch.Tensor, H: int) -> torch.Tensor:
 def bwd_dataflow_groups(device, num_dirs: int, num_stacked: int, H: int, B: int) -> int:
     """Groups the reverse dataflow launch runs with (same cell count and workgroup shape as the forward kernel, so the
     forward pass's schedule workspace serves both); 0 = not applicable."""
-    if not BWD_DATAFLOW:
+    if not BWD_DATAFLOW or H > 256:   # (the reverse kernel's static rows are 256 floats: H = 320 takes the reverse lock-step launches)
         return 0
     return dataflow_groups(device, num_dirs, num_stacked, H, B, training=True)
 

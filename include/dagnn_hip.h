@@ -330,6 +330,11 @@ size_t dagnn_dataflow_bytes(int64_t N, int64_t B, int groups);
 int dagnn_dataflow_schedule(const dagnn_plan* plan /* host */, void* workspace, size_t workspace_bytes, int groups,
                             int cost_layer, int cost_row, const int32_t* plan_status /* device, or NULL */, void* stream);
 int dagnn_dataflow_run(const dagnn_plan* plan /* host */, const dagnn_dataflow_args* args /* host */, void* stream);
+/* H = 320 (hidden sizes 257..320, zero-padded by the caller: the reference trains at emb_dim = 300, scripts/ogb_tok.sh:17): the
+ * same launch in an 8-wave workgroup shape (csrc/dataflow_w.hip).  Exactly two edge features, no static scores, no vertex-id
+ * key biases (anything else: DAGNN_EINVAL - the caller keeps such models on the other paths).  dagnn_dataflow_run forwards
+ * H > 256 here; dagnn_dataflow_groups / dagnn_pack_dataflow accept H = 320. */
+int dagnn_dataflow_run_wide(const dagnn_plan* plan /* host */, const dagnn_dataflow_args* args /* host */, void* stream);
 int dagnn_pack_dataflow(const float* w /* [3H,H] */, float* out /* 3H*H floats */, int H, void* stream);
 /* the same order of the gate-wise transposed matrix W'[g H + j][u] = W[g H + u][j] (reverse sweep, dagnn_bwd_dataflow_run) */
 int dagnn_pack_dataflow_transposed(const float* w /* [3H,H] */, float* out /* 3H*H floats */, int H, void* stream);

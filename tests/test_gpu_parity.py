@@ -1582,6 +1582,7 @@ def test_hidden_sizes_between_256_and_512_run_padded_to_512(device, monkeypatch,
     """engine.state_width: a stacked model with 256 < H < 512 (and a single-layer one above 384) is zero-padded to 512 -
     the tile kernel takes the stacked ones - and nothing of the padding shows: logits and every state row against the
     oracle and against the same model at its own width (`DAGNN_AMD_TILES_PAD=0`), state rows H wide."""
+    monkeypatch.setattr(engine, "DF_WIDE", 0)   # (with it, 257..320 run 320 wide on the dataflow kernel: the test below)
     model = _headline_model(H=H, L=L, V=16, seed=9)
     b = _degenerate_batch(synth.code2_graphs(17, 12, 40))
     ref = O.code2_forward(model.state_dict(), copy.deepcopy(b), num_layers=L, bidirectional=True, out_wx=False,
@@ -1615,6 +1616,63 @@ def test_hidden_sizes_between_256_and_512_run_padded_to_512(device, monkeypatch,
     assert max(Hh.maxdiff(o, r) for o, r in zip(res[1][0], ref)) < TOL
     assert max(Hh.maxdiff(a, c) for a, c in zip(res[1][0], res[0][0])) < 2e-5
     assert max(Hh.maxdiff(a, c) for a, c in zip(res[1][1], res[0][1])) < 5e-6
+
+
+@pytest.mark.parametrize("H,L", [(300, 2), (300, 3), (320, 1), (264, 2)])
+def test_hidden_sizes_up_to_320_run_on_the_wide_dataflow_kernel(device, monkeypatch, H, L):
+    """Hidden sizes 257..320 (the reference trains at emb_dim = 300, scripts/ogb_tok.sh:17) run zero-padded to 320 on the
+    8-wave shape of the dataflow kernel (`dagnn_dataflow_run_wide`, csrc/dataflow_w.hip): logits and every state row against
+    the oracle and against the other paths (`DAGNN_AMD_DF_WIDE=0`), bitwise run to run, on a batch with fan-in / fan-out
+    of 200, single nodes and no-edge graphs; a training step through the same forward against autograd through the oracle;
+    models the wide shape does not take (no edge features) keep their old path."""
+    model = _headline_model(H=H, L=L, V=16, seed=9)
+    b = _degenerate_batch(synth.code2_graphs(17, 12, 40))
+    ref = O.code2_forward(model.state_dict(), copy.deepcopy(b), num_layers=L, bidirectional=True, out_wx=False,
+                          out_pool_all=False, out_pool="max", max_seq_len=5)
+    y = torch.from_numpy(np.random.default_rng(4).integers(0, 16, size=(b.num_graphs, 5)))
+    loss_ref, gref = O.code2_grads(model.state_dict(), copy.deepcopy(b), y, num_layers=L, bidirectional=True, max_seq_len=5)
+    model = model.to(device)
+    lib = engine._lib.load()
+    calls = []
+    orig = lib.dagnn_dataflow_run
+
+    class _Spy(object):
+        def __call__(self, plan, args, stream):
+            calls.append(args._obj.H)
+            return orig(plan, args, stream)
+    monkeypatch.setattr(lib, "dagnn_dataflow_run", _Spy(), raising=False)
+    res = {}
+    for wide in (1, 0):
+        monkeypatch.setattr(engine, "DF_WIDE", wide)
+        for c in model._derived.values():
+            c.invalidate()
+        model.eval()
+        outs = []
+        for rep in range(2):
+            G = copy.deepcopy(b).to(device)
+            with torch.no_grad():
+                out = model(G)
+            model.check()
+            assert all(h.shape[1] == H for hd in G.h for h in hd)
+            outs.append(([o.clone() for o in out], [h.clone() for hd in G.h for h in hd]))
+        assert all(torch.equal(a, c) for a, c in zip(outs[0][0] + outs[0][1], outs[1][0] + outs[1][1]))
+        res[wide] = outs[0]
+        if wide:
+            assert engine.state_width(H, L, 2, wide_ok=True) == 320 and calls and all(h == 320 for h in calls)
+            loss, grads = _train_step(model, copy.deepcopy(b).to(device), y.to(device))
+            model.check()
+            assert abs(float(loss) - float(loss_ref)) < 1e-5
+            for k, g in grads.items():
+                scale = float(gref[k].abs().max())
+                assert Hh.maxdiff(g, gref[k]) <= 1e-4 * scale + 2e-7, k
+        else:
+            assert not calls
+        calls.clear()
+    assert max(Hh.maxdiff(o, r) for o, r in zip(res[1][0], ref)) < TOL
+    assert max(Hh.maxdiff(a, c) for a, c in zip(res[1][0], res[0][0])) < 2e-5
+    assert max(Hh.maxdiff(a, c) for a, c in zip(res[1][1], res[0][1])) < 5e-6
+    monkeypatch.setattr(engine, "DF_WIDE", 1)
+    assert engine.state_width(300, 2, 0, wide_ok=False) == 512 and engine.state_width(300, 2, 2, wide_ok=False) == 512
 
 
 def test_tile_kernel_full_size_properties(device, monkeypatch):

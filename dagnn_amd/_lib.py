@@ -220,6 +220,7 @@ SYMBOLS = {
                                      C.POINTER(C.c_int32), C.c_void_p]),
     "dagnn_bwd_dataflow_record_bytes": (C.c_size_t, [C.c_int64]),
     "dagnn_bwd_dataflow_static_bytes": (C.c_size_t, [C.c_int64]),
+    "dagnn_bwd_dataflow_static_bytes_h": (C.c_size_t, [C.c_int64, C.c_int]),
     "dagnn_bwd_dataflow_prepare": (C.c_int, [C.POINTER(Plan), C.POINTER(BwdDataflowArgs), C.c_void_p]),
     "dagnn_bwd_dataflow_run": (C.c_int, [C.POINTER(Plan), C.POINTER(BwdDataflowArgs), C.c_void_p]),
     "dagnn_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),

@@ -37,6 +37,7 @@
 namespace {
 
 typedef float bf4 __attribute__((ext_vector_type(4)));
+constexpr int BD_NSTAT_C = 8;
 
 #ifndef BD_NSLOT_V
 #define BD_NSLOT_V 3
@@ -46,6 +47,9 @@ constexpr int BD_WPS = 4;            // loader waves per stream = rows per block
 constexpr int BD_NLW = DF_NLS * BD_WPS;
 constexpr int BD_THREADS = 64 * (DF_NCW + BD_NLW);
 constexpr int BD_SP = 256;           // pitch of a static row (floats): lane l holds columns {l, 64 + l, 128 + l, 192 + l} at [4l, 4l + 4)
+// H = 320 (round 4): a fifth column block {256 + l}.  The record of a (cell, node) is then part A = the eight 256-float rows as
+// before, part B = eight 64-float rows behind them (row r, lane l at 8 * 256 + 64 r + l): 10 KB instead of 8
+__host__ __device__ constexpr int bd_stat_floats(int H) { return BD_NSTAT_C * (H > 256 ? 320 : 256); }
 constexpr int BD_NSTAT = 8;          // static rows per (cell, node): Gext, h, c_r, c_z, c_nr, c_n, z, c_q
 constexpr int BD_RD = 6;             // a loader wave requests a record this many of its blocks ahead (ring: 8 entries)
 enum { BD_DA = 0, BD_DU = 1 };
@@ -211,9 +215,9 @@ __global__ void __launch_bounds__(256) bd_stat_kernel(BdStatArgs A, int64_t N) {
     if (v >= N) return;
     const BdStatCell& C = A.cell[blockIdx.y];
     const int H = A.H, H3 = 3 * H;
-    float o[BD_NSTAT][4];
+    float o[BD_NSTAT][5];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 5; ++q) {
         const int c = 64 * q + lane;
 #pragma unroll
         for (int r = 0; r < BD_NSTAT; ++r) o[r][q] = 0.f;
@@ -234,9 +238,14 @@ __global__ void __launch_bounds__(256) bd_stat_kernel(BdStatArgs A, int64_t N) {
             o[ST_CQ][q] = zz * av + cr * (ghr - C.b_hh[c]) + cz * (ghz - C.b_hh[H + c]) + cnr * (ghn - C.b_hh[2 * H + c]);
         }
     }
-    float4* dst = reinterpret_cast<float4*>(C.stat + v * (BD_NSTAT * BD_SP)) + lane;
+    float* rec = C.stat + v * bd_stat_floats(H);
+    float4* dst = reinterpret_cast<float4*>(rec) + lane;
 #pragma unroll
     for (int r = 0; r < BD_NSTAT; ++r) dst[r * (BD_SP / 4)] = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
+    if (H > 256) {
+#pragma unroll
+        for (int r = 0; r < BD_NSTAT; ++r) rec[BD_NSTAT * BD_SP + 64 * r + lane] = o[r][4];
+    }
 }
 
 // ---------------------------------------------------------------- loader waves
@@ -245,9 +254,9 @@ __global__ void __launch_bounds__(256) bd_stat_kernel(BdStatArgs A, int64_t N) {
 // wait (the DMA stays in flight).  A destination register the compiler can see while its load is in flight gets copied
 // sooner or later; loads and wait in the same statement leave it nothing to see.
 struct BdSweep {
-    gran_t x[4][4];   // da rows of up to four successors: columns {lane, 64 + lane, 128 + lane, 192 + lane}
+    gran_t x[4][5];   // da rows of up to four successors: columns {lane, 64 + lane, 128 + lane, 192 + lane} (+ 256 + lane: H = 320)
     gran_t q[4];      // their q scalars (every lane loads the same granule)
-    gran_t u[4];      // the node's du row
+    gran_t u[5];      // the node's du row
 };
 
 #define BD_ROW_LD(e)                                                            \
@@ -284,13 +293,32 @@ struct BdSweep {
     "s_mov_b64 %[ke], exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %[rl]\n\t" \
     "s_nop 0\n\tglobal_load_lds_dword %[ra], off\n\t"                 \
     "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]\n\ts_waitcnt vmcnt(2)"
+// H = 320: the fifth column block of every polled row, and part B of the static record
+#define BD_ROW_LD5(e) BD_ROW_LD(e) "global_load_dwordx2 %[x" #e "4], %[vo], %[b" #e "] offset:2048 sc1\n\t"
+#define BD_ROWS5_0 ""
+#define BD_ROWS5_1 BD_ROW_LD5(0)
+#define BD_ROWS5_2 BD_ROWS5_1 BD_ROW_LD5(1)
+#define BD_ROWS5_3 BD_ROWS5_2 BD_ROW_LD5(2)
+#define BD_ROWS5_4 BD_ROWS5_3 BD_ROW_LD5(3)
+#define BD_DU5_0 ""
+#define BD_DU5_1 BD_DU_1 "global_load_dwordx2 %[u4], %[vo], %[ub] offset:2048 sc1\n\t"
+#define BD_STAT5_1                                                    \
+    "global_load_dword %[t0], %[vt], %[sc] offset:0\n\t"              \
+    "global_load_dword %[t1], %[vt], %[sc] offset:256\n\t"            \
+    "global_load_dword %[t2], %[vt], %[sc] offset:512\n\t"            \
+    "global_load_dword %[t3], %[vt], %[sc] offset:768\n\t"            \
+    "global_load_dword %[t4], %[vt], %[sc] offset:1024\n\t"           \
+    "global_load_dword %[t5], %[vt], %[sc] offset:1280\n\t"           \
+    "global_load_dword %[t6], %[vt], %[sc] offset:1536\n\t"           \
+    "global_load_dword %[t7], %[vt], %[sc] offset:1792\n\t"           \
+    BD_STAT_1
 #define BD_ROW_OUTS                                                                                                         \
-                   [x00] "=v"(W.x[0][0]), [x01] "=v"(W.x[0][1]), [x02] "=v"(W.x[0][2]), [x03] "=v"(W.x[0][3]),              \
-                   [x10] "=v"(W.x[1][0]), [x11] "=v"(W.x[1][1]), [x12] "=v"(W.x[1][2]), [x13] "=v"(W.x[1][3]),              \
-                   [x20] "=v"(W.x[2][0]), [x21] "=v"(W.x[2][1]), [x22] "=v"(W.x[2][2]), [x23] "=v"(W.x[2][3]),              \
-                   [x30] "=v"(W.x[3][0]), [x31] "=v"(W.x[3][1]), [x32] "=v"(W.x[3][2]), [x33] "=v"(W.x[3][3]),              \
-                   [q0] "=v"(W.q[0]), [q1] "=v"(W.q[1]), [q2] "=v"(W.q[2]), [q3] "=v"(W.q[3]),                              \
-                   [u0] "=v"(W.u[0]), [u1] "=v"(W.u[1]), [u2] "=v"(W.u[2]), [u3] "=v"(W.u[3])
+                   [x00] "=&v"(W.x[0][0]), [x01] "=&v"(W.x[0][1]), [x02] "=&v"(W.x[0][2]), [x03] "=&v"(W.x[0][3]),              \
+                   [x10] "=&v"(W.x[1][0]), [x11] "=&v"(W.x[1][1]), [x12] "=&v"(W.x[1][2]), [x13] "=&v"(W.x[1][3]),              \
+                   [x20] "=&v"(W.x[2][0]), [x21] "=&v"(W.x[2][1]), [x22] "=&v"(W.x[2][2]), [x23] "=&v"(W.x[2][3]),              \
+                   [x30] "=&v"(W.x[3][0]), [x31] "=&v"(W.x[3][1]), [x32] "=&v"(W.x[3][2]), [x33] "=&v"(W.x[3][3]),              \
+                   [q0] "=&v"(W.q[0]), [q1] "=&v"(W.q[1]), [q2] "=&v"(W.q[2]), [q3] "=&v"(W.q[3]),                              \
+                   [u0] "=&v"(W.u[0]), [u1] "=&v"(W.u[1]), [u2] "=&v"(W.u[2]), [u3] "=&v"(W.u[3])
 #define BD_ROW_INS                                                                                                          \
                    [vo] "v"(lane8), [vz] "v"(vzero), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),                \
                    [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [c3] "s"(c3p), [ub] "s"(ub),                                \
@@ -298,15 +326,32 @@ struct BdSweep {
 #define BD_TRIP_FIRST(n_, du_)                                                                                              \
     asm volatile(BD_ROWS_##n_ BD_DU_##du_ BD_STAT_1                                                                         \
                  : BD_ROW_OUTS,                                                                                             \
-                   [s0] "=v"(ST[0]), [s1] "=v"(ST[1]), [s2] "=v"(ST[2]), [s3] "=v"(ST[3]),                                  \
-                   [s4] "=v"(ST[4]), [s5] "=v"(ST[5]), [s6] "=v"(ST[6]), [s7] "=v"(ST[7]),                                  \
+                   [s0] "=&v"(ST[0]), [s1] "=&v"(ST[1]), [s2] "=&v"(ST[2]), [s3] "=&v"(ST[3]),                                  \
+                   [s4] "=&v"(ST[4]), [s5] "=&v"(ST[5]), [s6] "=&v"(ST[6]), [s7] "=&v"(ST[7]),                                  \
                    [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)                                                               \
                  : BD_ROW_INS, [vs] "v"(lane16), [sa] "s"(sa), [sb] "s"(sb), [ra] "v"(ra), [rl] "s"(rl),                    \
                    [pa] "v"(pa), [pl] "s"(pl)                                                                               \
                  : "memory")
 #define BD_TRIP_POLL(n_, du_)                                                                                               \
     asm volatile(BD_ROWS_##n_ BD_DU_##du_ "s_waitcnt vmcnt(0)" : BD_ROW_OUTS : BD_ROW_INS : "memory")
-#define BD_CASE(n_, du_) case (n_) * 2 + (du_): if (stat_pending) BD_TRIP_FIRST(n_, du_); else BD_TRIP_POLL(n_, du_); break;
+#define BD_ROW_OUTS5 BD_ROW_OUTS, [x04] "=&v"(W.x[0][4]), [x14] "=&v"(W.x[1][4]), [x24] "=&v"(W.x[2][4]), [x34] "=&v"(W.x[3][4]), [u4] "=&v"(W.u[4])
+#define BD_TRIP_FIRST5(n_, du_)                                                                                             \
+    asm volatile(BD_ROWS5_##n_ BD_DU5_##du_ BD_STAT5_1                                                                      \
+                 : BD_ROW_OUTS5,                                                                                            \
+                   [s0] "=&v"(ST[0]), [s1] "=&v"(ST[1]), [s2] "=&v"(ST[2]), [s3] "=&v"(ST[3]),                                  \
+                   [s4] "=&v"(ST[4]), [s5] "=&v"(ST[5]), [s6] "=&v"(ST[6]), [s7] "=&v"(ST[7]),                                  \
+                   [t0] "=&v"(ST5[0]), [t1] "=&v"(ST5[1]), [t2] "=&v"(ST5[2]), [t3] "=&v"(ST5[3]),                              \
+                   [t4] "=&v"(ST5[4]), [t5] "=&v"(ST5[5]), [t6] "=&v"(ST5[6]), [t7] "=&v"(ST5[7]),                              \
+                   [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)                                                               \
+                 : BD_ROW_INS, [vs] "v"(lane16), [sa] "s"(sa), [sb] "s"(sb), [ra] "v"(ra), [rl] "s"(rl),                    \
+                   [pa] "v"(pa), [pl] "s"(pl), [vt] "v"(lane4), [sc] "s"(sc)                                                \
+                 : "memory")
+#define BD_TRIP_POLL5(n_, du_)                                                                                              \
+    asm volatile(BD_ROWS5_##n_ BD_DU5_##du_ "s_waitcnt vmcnt(0)" : BD_ROW_OUTS5 : BD_ROW_INS : "memory")
+#define BD_CASE(n_, du_) case (n_) * 2 + (du_):                                                                             \
+        if constexpr (NQ4 == 5) { if (stat_pending) BD_TRIP_FIRST5(n_, du_); else BD_TRIP_POLL5(n_, du_); }                 \
+        else { if (stat_pending) BD_TRIP_FIRST(n_, du_); else BD_TRIP_POLL(n_, du_); }                                      \
+        break;
 #define BD_CASES(n_) BD_CASE(n_, 0) BD_CASE(n_, 1)
 
 template <int KPT, bool HAS_DU>
@@ -340,16 +385,18 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
     float* const sig_out = C.sig;
     float* const mrel = C.mrel;
     int* const dn = lds.dn + set * DF_NCW;
-    float wk[4] = {0.f, 0.f, 0.f, 0.f};
-    int cpos[4];
+    constexpr int NC = NQ4 > 4 ? NQ4 : 4;   // column blocks a lane carries
+    constexpr int SREC = bd_stat_floats(H);
+    float wk[NC];
+    int cpos[NC];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NC; ++q) {
         const int c = 64 * q + lane;
         cpos[q] = c + (SEG - KP8) * (c / KP8);
-        if (q < NQ4) wk[q] = C.wkey[c];
+        wk[q] = q < NQ4 ? C.wkey[c] : 0.f;
     }
-    const unsigned lane8 = 8u * lane, lane16 = 16u * lane, vzero = 0u;
-    constexpr int O1 = (NQ4 > 1 ? 1 : 0) * 512, O2 = (NQ4 > 2 ? 2 : NQ4 - 1) * 512, O3 = (NQ4 - 1) * 512;
+    const unsigned lane8 = 8u * lane, lane16 = 16u * lane, lane4 = 4u * lane, vzero = 0u;
+    constexpr int O1 = (NQ4 > 1 ? 1 : 0) * 512, O2 = (NQ4 > 2 ? 2 : NQ4 - 1) * 512, O3 = (NQ4 > 3 ? 3 : NQ4 - 1) * 512;
     const int lw = w;   // this wave's row of every block
     int* const rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
     const unsigned rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
@@ -376,7 +423,12 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
     const bool local_st = lds.local[0] != 0;
     const int myq = sl >> 1;
     const bool mine = (lane >> 5) == (sl & 1);
-    auto pick = [&](const float (&a)[4]) -> float { return myq == 0 ? a[0] : (myq == 1 ? a[1] : (myq == 2 ? a[2] : a[3])); };
+    auto pick = [&](const float (&a)[NC]) -> float {
+        float r = a[0];
+#pragma unroll
+        for (int q = 1; q < NC; ++q) r = myq == q ? a[q] : r;
+        return r;
+    };
 
     BdSweep A;
     for (int b = 0; b < nblk; ++b) {
@@ -393,16 +445,23 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
         const void* ra = rec_src(j + BD_RD);
         const unsigned rl = rec_dst(j + BD_RD);
         const int vnext = __builtin_amdgcn_readfirstlane(rec_ring[((j + 1) & 7) * 16]);   // (past the end: the last block's again)
-        const void* pa = stat + (int64_t)max(vnext, 0) * (BD_NSTAT * BD_SP) + 32 * lane;
+        const void* pa = stat + (int64_t)max(vnext, 0) * SREC + 32 * lane;
         if (v >= 0) {
             const int deg = ee - eb;
-            const float* sa = stat + (int64_t)v * (BD_NSTAT * BD_SP);
+            const float* sa = stat + (int64_t)v * SREC;
             const float* sb = sa + 4 * BD_SP;
+            const float* sc = sa + BD_NSTAT * BD_SP;   // part B of the record (H = 320)
+            float ST5[BD_NSTAT];                       // ... the lane's fifth column of the eight static rows
             const gran_t* ub = HAS_DU ? du_in + (unsigned)v * (unsigned)gld : da_g;
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            float acc[NC];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) acc[q] = 0.f;
             float sig = 0.f, m0 = 0.f, m1 = 0.f;
             bf4 ST[BD_NSTAT];   // the node's static rows: outputs of the FIRST trip only, so they stay put across re-polls
-            float du[4] = {0.f, 0.f, 0.f, 0.f};
+            float du[NC];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) du[q] = 0.f;
+            if (NC == 4) { (void)sc; }
             int c0 = 0;
             do {
                 const int nn = max(0, min(4, deg - c0));
@@ -443,17 +502,17 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                     for (int e = 0; e < 4; ++e) {
                         if (e < nn) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(A.x[e][q] >> 32) == epoch;
+                            for (int q = 0; q < NC; ++q) ok = ok && (unsigned)(A.x[e][q] >> 32) == epoch;
                             ok = ok && (unsigned)(A.q[e] >> 32) == epoch;
                         }
                     }
                     if (du_pending) {
                         bool oku = true;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) oku = oku && (unsigned)(A.u[q] >> 32) == epoch;
+                        for (int q = 0; q < NC; ++q) oku = oku && (unsigned)(A.u[q] >> 32) == epoch;
                         if (__all(oku)) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) du[q] = __uint_as_float((unsigned)A.u[q]);
+                            for (int q = 0; q < NC; ++q) du[q] = __uint_as_float((unsigned)A.u[q]);
                             du_pending = false;
                         }
                     }
@@ -468,32 +527,28 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                         if (NQ4 > 1) dot = fmaf(BD_X(1), ST[ST_H].y, dot);
                         if (NQ4 > 2) dot = fmaf(BD_X(2), ST[ST_H].z, dot);
                         if (NQ4 > 3) dot = fmaf(BD_X(3), ST[ST_H].w, dot);
+                        if (NQ4 > 4) dot = fmaf(BD_X(4), ST5[ST_H], dot);
                         const float ds = al[e] * (bd_wave_sum(dot) - __uint_as_float((unsigned)A.q[e]));
                         sig += ds;
                         m0 = fmaf(ds, f0[e], m0);
                         m1 = fmaf(ds, f1[e], m1);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[q] = fmaf(al[e], BD_X(q), acc[q]);
+                        for (int q = 0; q < NC; ++q) acc[q] = fmaf(al[e], BD_X(q), acc[q]);
 #undef BD_X
                     }
                 }
                 c0 += 4;
             } while (c0 < deg);
             // G_v, then everything that is linear in it
-            float G[4];
-            G[0] = ST[ST_GEXT].x + du[0] + acc[0] + sig * wk[0];
-            G[1] = ST[ST_GEXT].y + du[1] + acc[1] + sig * wk[1];
-            G[2] = ST[ST_GEXT].z + du[2] + acc[2] + sig * wk[2];
-            G[3] = ST[ST_GEXT].w + du[3] + acc[3] + sig * wk[3];
-            const float cr[4] = {ST[ST_CR].x, ST[ST_CR].y, ST[ST_CR].z, ST[ST_CR].w};
-            const float cz[4] = {ST[ST_CZ].x, ST[ST_CZ].y, ST[ST_CZ].z, ST[ST_CZ].w};
-            const float cnr[4] = {ST[ST_CNR].x, ST[ST_CNR].y, ST[ST_CNR].z, ST[ST_CNR].w};
-            const float cn[4] = {ST[ST_CN].x, ST[ST_CN].y, ST[ST_CN].z, ST[ST_CN].w};
-            const float zz[4] = {ST[ST_Z].x, ST[ST_Z].y, ST[ST_Z].z, ST[ST_Z].w};
-            float dr[4], dz[4], dnr[4], dnn[4], zg[4];
+            auto stv = [&](int r, int q) -> float { return q < 4 ? ST[r][q] : ST5[r]; };   // (q is a constant after unrolling)
+            float G[NC];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                dr[q] = G[q] * cr[q]; dz[q] = G[q] * cz[q]; dnr[q] = G[q] * cnr[q]; dnn[q] = G[q] * cn[q]; zg[q] = G[q] * zz[q];
+            for (int q = 0; q < NC; ++q) G[q] = stv(ST_GEXT, q) + du[q] + acc[q] + sig * wk[q];
+            float dr[NC], dz[NC], dnr[NC], dnn[NC], zg[NC];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                dr[q] = G[q] * stv(ST_CR, q); dz[q] = G[q] * stv(ST_CZ, q); dnr[q] = G[q] * stv(ST_CNR, q);
+                dnn[q] = G[q] * stv(ST_CN, q); zg[q] = G[q] * stv(ST_Z, q);
             }
             if (b >= BD_NSLOT) bd_wait4(dn, b - BD_NSLOT + 1, err, spin_limit);   // the ring slot is free again
             float* op = sbase + Slot::op_off + lw * Slot::AP;
@@ -527,6 +582,7 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                 if (NQ4 > 1) qd = fmaf(G[1], ST[ST_CQ].y, qd);
                 if (NQ4 > 2) qd = fmaf(G[2], ST[ST_CQ].z, qd);
                 if (NQ4 > 3) qd = fmaf(G[3], ST[ST_CQ].w, qd);
+                if (NQ4 > 4) qd = fmaf(G[4], ST5[ST_CQ], qd);
                 qd = bd_wave_sum(qd);
                 if (lane == 0) {
                     if (local_st) q_out[v] = gran_pack(epoch, qd);
@@ -548,6 +604,8 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
 }
 #undef BD_TRIP_FIRST
 #undef BD_TRIP_POLL
+#undef BD_TRIP_FIRST5
+#undef BD_TRIP_POLL5
 #undef BD_CASE
 #undef BD_CASES
 
@@ -562,11 +620,21 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
     "s_mov_b32 %[km], m0\n\ts_mov_b64 %[ke], exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %[rl]\n\t" \
     "s_nop 0\n\tglobal_load_lds_dword %[ra], off\n\t"                                              \
     "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]\n\ts_waitcnt vmcnt(1)"
+#define BD_G_LD5(g) BD_G_LD(g) "global_load_dwordx2 %[y" #g "4], %[vo], %[g" #g "] offset:2048 sc1\n\t"
+#define BD_GTRIP5(dm)                                                                                                        \
+    asm volatile(BD_G_LD5(0) BD_G_LD5(1) BD_G_LD5(2) BD_DMA_##dm                                                             \
+                 : [y00] "=&v"(Y[0][0]), [y01] "=&v"(Y[0][1]), [y02] "=&v"(Y[0][2]), [y03] "=&v"(Y[0][3]), [y04] "=&v"(Y[0][4]),  \
+                   [y10] "=&v"(Y[1][0]), [y11] "=&v"(Y[1][1]), [y12] "=&v"(Y[1][2]), [y13] "=&v"(Y[1][3]), [y14] "=&v"(Y[1][4]),  \
+                   [y20] "=&v"(Y[2][0]), [y21] "=&v"(Y[2][1]), [y22] "=&v"(Y[2][2]), [y23] "=&v"(Y[2][3]), [y24] "=&v"(Y[2][4]),  \
+                   [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)                                                                \
+                 : [vo] "v"(lane8), [g0] "s"(g0), [g1] "s"(g1), [g2] "s"(g2), [ra] "v"(ra), [rl] "s"(rl),                    \
+                   [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)                                                                  \
+                 : "memory")
 #define BD_GTRIP(dm)                                                                                                         \
     asm volatile(BD_G_LD(0) BD_G_LD(1) BD_G_LD(2) BD_DMA_##dm                                                                \
-                 : [y00] "=v"(Y[0][0]), [y01] "=v"(Y[0][1]), [y02] "=v"(Y[0][2]), [y03] "=v"(Y[0][3]),                       \
-                   [y10] "=v"(Y[1][0]), [y11] "=v"(Y[1][1]), [y12] "=v"(Y[1][2]), [y13] "=v"(Y[1][3]),                       \
-                   [y20] "=v"(Y[2][0]), [y21] "=v"(Y[2][1]), [y22] "=v"(Y[2][2]), [y23] "=v"(Y[2][3]),                       \
+                 : [y00] "=&v"(Y[0][0]), [y01] "=&v"(Y[0][1]), [y02] "=&v"(Y[0][2]), [y03] "=&v"(Y[0][3]),                       \
+                   [y10] "=&v"(Y[1][0]), [y11] "=&v"(Y[1][1]), [y12] "=&v"(Y[1][2]), [y13] "=&v"(Y[1][3]),                       \
+                   [y20] "=&v"(Y[2][0]), [y21] "=&v"(Y[2][1]), [y22] "=&v"(Y[2][2]), [y23] "=&v"(Y[2][3]),                       \
                    [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)                                                                \
                  : [vo] "v"(lane8), [g0] "s"(g0), [g1] "s"(g1), [g2] "s"(g2), [ra] "v"(ra), [rl] "s"(rl),                    \
                    [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)                                                                  \
@@ -588,14 +656,15 @@ __device__ __forceinline__ void bd_loader_du(const BdArgs& S, const BdCell& C, i
     const int gld = S.gld;
     const gran_t* const dgi_in = C.dgi_g;
     int* const dn = lds.dn + set * DF_NCW;
-    int cpos[4];
+    constexpr int NC = NQ4 > 4 ? NQ4 : 4;
+    int cpos[NC];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NC; ++q) {
         const int c = 64 * q + lane;
         cpos[q] = c + (SEG - KP8) * (c / KP8);
     }
     const unsigned lane8 = 8u * lane;
-    constexpr int O1 = (NQ4 > 1 ? 1 : 0) * 512, O2 = (NQ4 > 2 ? 2 : NQ4 - 1) * 512, O3 = (NQ4 - 1) * 512;
+    constexpr int O1 = (NQ4 > 1 ? 1 : 0) * 512, O2 = (NQ4 > 2 ? 2 : NQ4 - 1) * 512, O3 = (NQ4 > 3 ? 3 : NQ4 - 1) * 512;
     const int lw = w;
     int* const rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
     const unsigned rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
@@ -613,7 +682,7 @@ __device__ __forceinline__ void bd_loader_du(const BdArgs& S, const BdCell& C, i
         for (int j = 0; j < BD_RD; ++j) if (lane < 16) glds4(rec_src(j), rec_dst(j));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    gran_t Y[3][4];
+    gran_t Y[3][5];
     for (int b = 0; b < nblk; ++b) {
         const int j = b;
         const int v = __builtin_amdgcn_readfirstlane(rec_ring[(j & 7) * 16]);
@@ -630,13 +699,13 @@ __device__ __forceinline__ void bd_loader_du(const BdArgs& S, const BdCell& C, i
             for (;;) {
                 unsigned keep_m0;
                 unsigned long long keep_exec;
-                if (dma) BD_GTRIP(1); else BD_GTRIP(0);
+                if constexpr (NQ4 == 5) { if (dma) BD_GTRIP5(1); else BD_GTRIP5(0); } else { if (dma) BD_GTRIP(1); else BD_GTRIP(0); }
                 dma = false;
                 bool ok = true;
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(Y[g][q] >> 32) == epoch;
+                    for (int q = 0; q < NC; ++q) ok = ok && (unsigned)(Y[g][q] >> 32) == epoch;
                 if (__all(ok) || !bd_retry(spins, err, spin_limit)) break;
             }
             if (b >= BD_NSLOT) bd_wait4(dn, b - BD_NSLOT + 1, err, spin_limit);
@@ -656,6 +725,7 @@ __device__ __forceinline__ void bd_loader_du(const BdArgs& S, const BdCell& C, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 #undef BD_GTRIP
+#undef BD_GTRIP5
 
 // ---- compute wave `cw`: output units [8 cw, 8 cw + 8) of the slice (lane layout and reduce-scatter of dataflow.hip's
 // df_compute; the A operands are the packed gate-wise transposed matrix, the B operands differ per gate block)
@@ -874,10 +944,15 @@ extern "C" size_t dagnn_bwd_dataflow_static_bytes(int64_t N) {
     return (size_t)N * BD_NSTAT * BD_SP * sizeof(float);
 }
 
+extern "C" size_t dagnn_bwd_dataflow_static_bytes_h(int64_t N, int H) {   // H = 320: 10 KB per (cell, node)
+    if (N < 0 || H <= 0) return 0;
+    return (size_t)N * bd_stat_floats(H) * sizeof(float);
+}
+
 extern "C" int dagnn_bwd_dataflow_prepare(const dagnn_plan* pl, const dagnn_bwd_dataflow_args* a, void* stream) {
     if (!pl || !pl->data || !a || !a->schedule || !a->records) return DAGNN_EINVAL;
     const int H = a->H, Ls = a->num_stacked, dir_mask = a->dir_mask & 3, G = a->groups;
-    if (H <= 0 || (H % 64) || H > 256 || Ls <= 0 || Ls > DAGNN_MAX_STACKED || !dir_mask || G < 1 || G > DF_MAX_GROUPS ||
+    if (H <= 0 || (H % 64) || H > 320 || Ls <= 0 || Ls > DAGNN_MAX_STACKED || !dir_mask || G < 1 || G > DF_MAX_GROUPS ||
         a->ld_h < H || a->ld_g < H)
         return DAGNN_EINVAL;
     if (pl->B == 0 || pl->N == 0) return DAGNN_OK;
@@ -907,7 +982,7 @@ extern "C" int dagnn_bwd_dataflow_prepare(const dagnn_plan* pl, const dagnn_bwd_
 extern "C" int dagnn_bwd_dataflow_run(const dagnn_plan* pl, const dagnn_bwd_dataflow_args* a, void* stream) {
     if (!pl || !pl->data || !a || !a->schedule || !a->records) return DAGNN_EINVAL;
     const int H = a->H, Ls = a->num_stacked, dir_mask = a->dir_mask & 3, G = a->groups;
-    if (H <= 0 || (H % 64) || H > 256 || Ls <= 0 || Ls > DAGNN_MAX_STACKED || !dir_mask || a->gld < H || G < 1 ||
+    if (H <= 0 || (H % 64) || H > 320 || Ls <= 0 || Ls > DAGNN_MAX_STACKED || !dir_mask || a->gld < H || G < 1 ||
         G > DF_MAX_GROUPS || a->epoch == 0 || !a->err)
         return DAGNN_EINVAL;
     if (pl->B == 0 || pl->N == 0) return DAGNN_OK;
@@ -998,6 +1073,7 @@ extern "C" int dagnn_bwd_dataflow_run(const dagnn_plan* pl, const dagnn_bwd_data
         case 4: BD_LAUNCH(4); break;
         case 8: BD_LAUNCH(8); break;
         case 12: BD_LAUNCH(12); break;
+        case 20: BD_LAUNCH(20); break;
         default: BD_LAUNCH(16); break;
     }
 #undef BD_LAUNCH

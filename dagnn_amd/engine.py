@@ -968,7 +968,7 @@ def pack_dataflow_transposed(w: torch.Tensor, H: int) -> torch.Tensor:
 def bwd_dataflow_groups(device, num_dirs: int, num_stacked: int, H: int, B: int) -> int:
     """Groups the reverse dataflow launch runs with (same cell count and workgroup shape as the forward kernel, so the
     forward pass's schedule workspace serves both); 0 = not applicable."""
-    if not BWD_DATAFLOW or H > 256:   # (the reverse kernel's static rows are 256 floats: H = 320 takes the reverse lock-step launches)
+    if not BWD_DATAFLOW or not dataflow_width(int(H)):
         return 0
     return dataflow_groups(device, num_dirs, num_stacked, H, B, training=True)
 
@@ -981,7 +981,7 @@ def bwd_dataflow_fits(device, N: int, cells: int) -> bool:
     H is - 0.5 GB for the headline batch, tens of GB for a very large batch at H = 64.  Above 1 GB the estimate is held
     against the memory that is actually free (the device's + what torch's allocator has cached); a batch that does not
     fit takes the reverse lock-step launches (`backward_sweep`), which need none of it."""
-    need = int(_lib.load().dagnn_bwd_dataflow_static_bytes(int(N))) * int(cells)
+    need = int(_lib.load().dagnn_bwd_dataflow_static_bytes(int(N))) * int(cells) * 5 // 4   # (H = 320: 10 KB records)
     if BWD_DF_MAX_BYTES > 0:
         return need <= BWD_DF_MAX_BYTES
     if need <= (1 << 30):
@@ -1048,7 +1048,7 @@ def bwd_dataflow_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, ce
         widths = {k: (1 if k[0] == "q" else 3 * H) for k in gkeys if k[0] in ("q", "dgi")}
         gran, epoch, err = arena.get(gkeys, N, H, dev, widths=widths)
         args = BwdDataflowArgs()
-        stat_bytes = lib.dagnn_bwd_dataflow_static_bytes(N)
+        stat_bytes = lib.dagnn_bwd_dataflow_static_bytes_h(N, H)
         for k in keys:
             d, i = k
             c, bc, o = cells[k], args.cell[d][i], out[k]

@@ -541,6 +541,7 @@ typedef struct dagnn_bwd_dataflow_args {
 
 size_t dagnn_bwd_dataflow_record_bytes(int64_t N);
 size_t dagnn_bwd_dataflow_static_bytes(int64_t N);
+size_t dagnn_bwd_dataflow_static_bytes_h(int64_t N, int H);   /* ... for a given H: 8 KB per (cell, node) up to H = 256, 10 KB at H = 320 */
 int dagnn_bwd_dataflow_prepare(const dagnn_plan* plan /* host */, const dagnn_bwd_dataflow_args* args /* host */, void* stream);
 int dagnn_bwd_dataflow_run(const dagnn_plan* plan /* host */, const dagnn_bwd_dataflow_args* args /* host */, void* stream);
 

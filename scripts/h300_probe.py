@@ -44,5 +44,11 @@ for H in [int(h) for h in os.environ.get("HS", "300,256").split(",")]:
         step()
     torch.cuda.synchronize()
     tr = (time.perf_counter() - t0) / 12 * 1e3
+    engine.TIMER = engine.KernelTimer()
+    for _ in range(6):
+        step()
+    torch.cuda.synchronize()
+    print("   spans per step (ms):", {k: round(n * ms / 6, 3) for k, (n, ms) in engine.TIMER.summary().items()})
+    engine.TIMER = None
     model.check()
     print("H=%d (state width %d): forward %.3f ms, training step %.3f ms" % (H, engine.state_width(H, L, 2), fwd, tr), flush=True)

@@ -223,6 +223,7 @@ SYMBOLS = {
     "dagnn_bwd_dataflow_static_bytes_h": (C.c_size_t, [C.c_int64, C.c_int]),
     "dagnn_bwd_dataflow_prepare": (C.c_int, [C.POINTER(Plan), C.POINTER(BwdDataflowArgs), C.c_void_p]),
     "dagnn_bwd_dataflow_run": (C.c_int, [C.POINTER(Plan), C.POINTER(BwdDataflowArgs), C.c_void_p]),
+    "dagnn_bwd_dataflow_run_wide": (C.c_int, [C.POINTER(Plan), C.POINTER(BwdDataflowArgs), C.c_void_p]),
     "dagnn_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "dagnn_colsum_run": (C.c_int, [C.POINTER(ColsumJob), C.c_int, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dagnn_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -43,7 +43,11 @@ constexpr int BD_NSTAT_C = 8;
 #define BD_NSLOT_V 3
 #endif
 constexpr int BD_NSLOT = BD_NSLOT_V;   // LDS ring depth per stream (a slot holds 3 operand rows per block row; 2 / 3 / 4: the same time)
-constexpr int BD_WPS = 4;            // loader waves per stream = rows per block
+#ifndef BD_WPS_V
+#define BD_WPS_V 4
+#endif
+constexpr int BD_WPS = BD_WPS_V;     // loader waves per stream (4: one row of a block each; 2: the 8-wave shape of H = 320, two rows each)
+constexpr int BD_RPW = DF_RB / BD_WPS;   // rows of a block per loader wave, one after the other
 constexpr int BD_NLW = DF_NLS * BD_WPS;
 constexpr int BD_THREADS = 64 * (DF_NCW + BD_NLW);
 constexpr int BD_SP = 256;           // pitch of a static row (floats): lane l holds columns {l, 64 + l, 128 + l, 192 + l} at [4l, 4l + 4)
@@ -348,6 +352,12 @@ struct BdSweep {
                  : "memory")
 #define BD_TRIP_POLL5(n_, du_)                                                                                              \
     asm volatile(BD_ROWS5_##n_ BD_DU5_##du_ "s_waitcnt vmcnt(0)" : BD_ROW_OUTS5 : BD_ROW_INS : "memory")
+#define BD_SEL1(n_, du_) if constexpr (NN == (n_) && DUK == (du_)) {                                                          \
+        if constexpr (NQ4 == 5) { if constexpr (FST) BD_TRIP_FIRST5(n_, du_); else BD_TRIP_POLL5(n_, du_); }                \
+        else { if constexpr (FST) BD_TRIP_FIRST(n_, du_); else BD_TRIP_POLL(n_, du_); } } else
+#define BD_SELS(n_) BD_SEL1(n_, 0) BD_SEL1(n_, 1)
+#define BD_TRIP_SEL(nn_, du_, fst_) do { constexpr int DUK = (du_); constexpr bool FST = (fst_) != 0; (void)DUK; (void)FST;         \
+        BD_SELS(0) BD_SELS(1) BD_SELS(2) BD_SELS(3) BD_SELS(4) {} } while (0)
 #define BD_CASE(n_, du_) case (n_) * 2 + (du_):                                                                             \
         if constexpr (NQ4 == 5) { if (stat_pending) BD_TRIP_FIRST5(n_, du_); else BD_TRIP_POLL5(n_, du_); }                 \
         else { if (stat_pending) BD_TRIP_FIRST(n_, du_); else BD_TRIP_POLL(n_, du_); }                                      \
@@ -397,10 +407,19 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
     }
     const unsigned lane8 = 8u * lane, lane16 = 16u * lane, lane4 = 4u * lane, vzero = 0u;
     constexpr int O1 = (NQ4 > 1 ? 1 : 0) * 512, O2 = (NQ4 > 2 ? 2 : NQ4 - 1) * 512, O3 = (NQ4 > 3 ? 3 : NQ4 - 1) * 512;
-    const int lw = w;   // this wave's row of every block
-    int* const rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
-    const unsigned rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
-    const int32_t* const rec_w = recs + 16 * lw + (lane & 15);
+    int lw = w * BD_RPW;   // this wave's row(s) of every block
+    int* rec_ring;
+    unsigned rec_ring_a, pl;
+    const int32_t* rec_w;
+    auto set_row = [&](int row) {
+        lw = row;
+        rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
+        rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
+        rec_w = recs + 16 * lw + (lane & 15);
+        // L2 warm-up (see BD_STAT_1): lane l asks for line l of the next block's static record; the dump area is this row's
+        pl = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(reinterpret_cast<unsigned*>(lds.dump) + ((set * DF_RB + lw) * 64)));
+    };
+    set_row(lw);
     const int64_t wstride = 16 * DF_RB;
     // block j of this wave (the j-th from the END of the stream's record list: the sweep runs the layers in reverse)
     auto rec_src = [&](int j) -> const void* { return rec_w + (int64_t)(nblk - 1 - min(j, nblk - 1)) * wstride; };
@@ -411,15 +430,15 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
     };
     if (nblk > 0) {
+        for (int rr = 0; rr < BD_RPW; ++rr) {
+            set_row(w * BD_RPW + rr);
 #pragma unroll
-        for (int j = 0; j < BD_RD; ++j) if (lane < 16) glds4(rec_src(j), rec_dst(j));
+            for (int j = 0; j < BD_RD; ++j) if (lane < 16) glds4(rec_src(j), rec_dst(j));
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // the slice's share of a full row in the loader's column layout: units [32 sl, 32 sl + 32) = column block q = sl / 2,
     // lanes [32 (sl & 1), + 32)
-    // L2 warm-up (see BD_STAT_1): lane l asks for line l of the next block's static record; the dump area is this wave's
-    unsigned* const dump = reinterpret_cast<unsigned*>(lds.dump) + ((set * DF_RB + lw) * 64);
-    const unsigned pl = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)dump);
     const bool local_st = lds.local[0] != 0;
     const int myq = sl >> 1;
     const bool mine = (lane >> 5) == (sl & 1);
@@ -433,6 +452,9 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
     BdSweep A;
     for (int b = 0; b < nblk; ++b) {
         const int j = b;
+#pragma unroll 1
+      for (int rr = 0; rr < BD_RPW; ++rr) {
+        if (BD_RPW > 1) set_row(w * BD_RPW + rr);
         const int cur = rec_ring[(j & 7) * 16 + (lane & 15)];
 #define BD_W(i) __builtin_amdgcn_readlane(cur, i)
         const int v = BD_W(0), eb = BD_W(1), ee = BD_W(2);
@@ -462,21 +484,24 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
 #pragma unroll
             for (int q = 0; q < NC; ++q) du[q] = 0.f;
             if (NC == 4) { (void)sc; }
-            int c0 = 0;
-            do {
-                const int nn = max(0, min(4, deg - c0));
+            // Chunks of <= 4 successors, each ONE statically shaped body (round 4; see df_loader_fast in dataflow.hip for what a
+            // wave's time is made of): the trip is a fixed asm statement per (successors, du, first), the re-poll loop is
+            // [trip, minimum of the tags, compare, branch] - tags never exceed the pass's epoch, so "all landed" is "the minimum
+            // equals" - and the pull runs over exactly NN rows.
+            auto chunk = [&](auto nn_c, auto first_c, int c0) {
+                constexpr int NN = decltype(nn_c)::value;
+                constexpr bool FIRST = decltype(first_c)::value;
+                constexpr int DU = (FIRST && HAS_DU) ? 1 : 0;
                 int pj[4] = {0, 0, 0, 0};
                 float al[4] = {0.f, 0.f, 0.f, 0.f}, f0[4] = {0.f, 0.f, 0.f, 0.f}, f1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (e < nn) {
-                        int eid;
-                        if (c0 == 0) { pj[e] = s4[e]; eid = e4[e]; }
-                        else { pj[e] = col[eb + c0 + e]; eid = eidx[eb + c0 + e]; }
-                        al[e] = alpha[eid];
-                        if (R >= 1) f0[e] = eattr[(int64_t)(eb + c0 + e) * R];
-                        if (R >= 2) f1[e] = eattr[(int64_t)(eb + c0 + e) * R + 1];
-                    }
+                for (int e = 0; e < NN; ++e) {
+                    int eid;
+                    if (FIRST) { pj[e] = s4[e]; eid = e4[e]; }
+                    else { pj[e] = col[eb + c0 + e]; eid = eidx[eb + c0 + e]; }
+                    al[e] = alpha[eid];
+                    if (R >= 1) f0[e] = eattr[(int64_t)(eb + c0 + e) * R];
+                    if (R >= 2) f1[e] = eattr[(int64_t)(eb + c0 + e) * R + 1];
                 }
                 // (N * 3 gld granules fit 32 bits - host check: one 32-bit multiply per row base)
                 const gran_t* b0 = da_g + (unsigned)pj[0] * (unsigned)gld;
@@ -484,61 +509,70 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                 const gran_t* b2 = da_g + (unsigned)pj[2] * (unsigned)gld;
                 const gran_t* b3 = da_g + (unsigned)pj[3] * (unsigned)gld;
                 const gran_t* c0p = q_in + pj[0], * c1p = q_in + pj[1], * c2p = q_in + pj[2], * c3p = q_in + pj[3];
-                const bool first = c0 == 0;
-                bool stat_pending = first;
-                bool du_pending = HAS_DU && first;
-                unsigned spins = 0;
-                for (;;) {
-                    unsigned keep_m0;
-                    unsigned long long keep_exec;
-                    BdSweep& W = A;
-                    switch (nn * 2 + (du_pending ? 1 : 0)) {
-                        BD_CASES(0) BD_CASES(1) BD_CASES(2) BD_CASES(3)
-                        default: BD_CASES(4)
+                unsigned keep_m0;
+                unsigned long long keep_exec;
+                BdSweep& W = A;
+                auto landed = [&]() -> bool {
+                    unsigned m = epoch;
+#pragma unroll
+                    for (int e = 0; e < NN; ++e) {
+#pragma unroll
+                        for (int q = 0; q < NC; ++q) m = min(m, (unsigned)(A.x[e][q] >> 32));
+                        m = min(m, (unsigned)(A.q[e] >> 32));
                     }
-                    stat_pending = false;
-                    bool ok = true;
+                    if (DU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (e < nn) {
-#pragma unroll
-                            for (int q = 0; q < NC; ++q) ok = ok && (unsigned)(A.x[e][q] >> 32) == epoch;
-                            ok = ok && (unsigned)(A.q[e] >> 32) == epoch;
-                        }
+                        for (int q = 0; q < NC; ++q) m = min(m, (unsigned)(A.u[q] >> 32));
                     }
-                    if (du_pending) {
-                        bool oku = true;
-#pragma unroll
-                        for (int q = 0; q < NC; ++q) oku = oku && (unsigned)(A.u[q] >> 32) == epoch;
-                        if (__all(oku)) {
-#pragma unroll
-                            for (int q = 0; q < NC; ++q) du[q] = __uint_as_float((unsigned)A.u[q]);
-                            du_pending = false;
-                        }
-                    }
-                    if ((__all(ok) && !du_pending) || !bd_retry(spins, err, spin_limit)) break;
+                    return __builtin_amdgcn_uicmp(m, epoch, 33 /* ICMP_NE */) == 0ull;
+                };
+                if (FIRST) { BD_TRIP_SEL(NN, DU, 1); } else { BD_TRIP_SEL(NN, 0, 0); }
+                if (NN + DU > 0 && !landed()) {
+                    unsigned spins = 0;
+                    do {
+                        if (!bd_retry(spins, err, spin_limit)) break;
+                        BD_TRIP_SEL(NN, DU, 0);
+                    } while (!landed());
                 }
-                // pull: ds_e = alpha_e (da_w . h_v - q_w), G += alpha_e da_w (nn is wave-uniform)
+                if (DU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (e < nn) {
+                    for (int q = 0; q < NC; ++q) du[q] = __uint_as_float((unsigned)A.u[q]);
+                }
+                // pull: ds_e = alpha_e (da_w . h_v - q_w), G += alpha_e da_w
+#pragma unroll
+                for (int e = 0; e < NN; ++e) {
 #define BD_X(q) __uint_as_float((unsigned)A.x[e][q])
-                        float dot = BD_X(0) * ST[ST_H].x;
-                        if (NQ4 > 1) dot = fmaf(BD_X(1), ST[ST_H].y, dot);
-                        if (NQ4 > 2) dot = fmaf(BD_X(2), ST[ST_H].z, dot);
-                        if (NQ4 > 3) dot = fmaf(BD_X(3), ST[ST_H].w, dot);
-                        if (NQ4 > 4) dot = fmaf(BD_X(4), ST5[ST_H], dot);
-                        const float ds = al[e] * (bd_wave_sum(dot) - __uint_as_float((unsigned)A.q[e]));
-                        sig += ds;
-                        m0 = fmaf(ds, f0[e], m0);
-                        m1 = fmaf(ds, f1[e], m1);
+                    float dot = BD_X(0) * ST[ST_H].x;
+                    if (NQ4 > 1) dot = fmaf(BD_X(1), ST[ST_H].y, dot);
+                    if (NQ4 > 2) dot = fmaf(BD_X(2), ST[ST_H].z, dot);
+                    if (NQ4 > 3) dot = fmaf(BD_X(3), ST[ST_H].w, dot);
+                    if (NQ4 > 4) dot = fmaf(BD_X(4), ST5[ST_H], dot);
+                    const float ds = al[e] * (bd_wave_sum(dot) - __uint_as_float((unsigned)A.q[e]));
+                    sig += ds;
+                    m0 = fmaf(ds, f0[e], m0);
+                    m1 = fmaf(ds, f1[e], m1);
 #pragma unroll
-                        for (int q = 0; q < NC; ++q) acc[q] = fmaf(al[e], BD_X(q), acc[q]);
+                    for (int q = 0; q < NC; ++q) acc[q] = fmaf(al[e], BD_X(q), acc[q]);
 #undef BD_X
-                    }
                 }
-                c0 += 4;
-            } while (c0 < deg);
+            };
+            typedef std::integral_constant<bool, true> first_t;
+            typedef std::integral_constant<bool, false> later_t;
+            if (b >= BD_NSLOT) bd_wait4(dn, b - BD_NSLOT + 1, err, spin_limit);   // the ring slot is free again (before the poll: off the dependent chain)
+            if (deg <= 0) chunk(std::integral_constant<int, 0>(), first_t(), 0);
+            else if (deg == 1) chunk(std::integral_constant<int, 1>(), first_t(), 0);
+            else if (deg == 2) chunk(std::integral_constant<int, 2>(), first_t(), 0);
+            else if (deg == 3) chunk(std::integral_constant<int, 3>(), first_t(), 0);
+            else {
+                chunk(std::integral_constant<int, 4>(), first_t(), 0);
+                for (int c0 = 4; c0 < deg; c0 += 4) {
+                    const int nn = min(4, deg - c0);
+                    if (nn == 4) chunk(std::integral_constant<int, 4>(), later_t(), c0);
+                    else if (nn == 3) chunk(std::integral_constant<int, 3>(), later_t(), c0);
+                    else if (nn == 2) chunk(std::integral_constant<int, 2>(), later_t(), c0);
+                    else chunk(std::integral_constant<int, 1>(), later_t(), c0);
+                }
+            }
             // G_v, then everything that is linear in it
             auto stv = [&](int r, int q) -> float { return q < 4 ? ST[r][q] : ST5[r]; };   // (q is a constant after unrolling)
             float G[NC];
@@ -550,7 +584,6 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                 dr[q] = G[q] * stv(ST_CR, q); dz[q] = G[q] * stv(ST_CZ, q); dnr[q] = G[q] * stv(ST_CNR, q);
                 dnn[q] = G[q] * stv(ST_CN, q); zg[q] = G[q] * stv(ST_Z, q);
             }
-            if (b >= BD_NSLOT) bd_wait4(dn, b - BD_NSLOT + 1, err, spin_limit);   // the ring slot is free again
             float* op = sbase + Slot::op_off + lw * Slot::AP;
 #pragma unroll
             for (int q = 0; q < NQ4; ++q) {
@@ -597,6 +630,7 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
             if (b >= BD_NSLOT) bd_wait4(dn, b - BD_NSLOT + 1, err, spin_limit);
         }
         if (lane == 0) v_s[lw] = v;
+      }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) bd_flag_st(lds.rdy + set * BD_WPS + w, b + 1);
     }
@@ -665,10 +699,17 @@ __device__ __forceinline__ void bd_loader_du(const BdArgs& S, const BdCell& C, i
     }
     const unsigned lane8 = 8u * lane;
     constexpr int O1 = (NQ4 > 1 ? 1 : 0) * 512, O2 = (NQ4 > 2 ? 2 : NQ4 - 1) * 512, O3 = (NQ4 > 3 ? 3 : NQ4 - 1) * 512;
-    const int lw = w;
-    int* const rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
-    const unsigned rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
-    const int32_t* const rec_w = recs + 16 * lw + (lane & 15);
+    int lw = w * BD_RPW;
+    int* rec_ring;
+    unsigned rec_ring_a;
+    const int32_t* rec_w;
+    auto set_row = [&](int row) {
+        lw = row;
+        rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
+        rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
+        rec_w = recs + 16 * lw + (lane & 15);
+    };
+    set_row(lw);
     const int64_t wstride = 16 * DF_RB;
     auto rec_src = [&](int j) -> const void* { return rec_w + (int64_t)(nblk - 1 - min(j, nblk - 1)) * wstride; };
     auto rec_dst = [&](int j) -> unsigned { return rec_ring_a + (j & 7) * 64; };
@@ -678,13 +719,19 @@ __device__ __forceinline__ void bd_loader_du(const BdArgs& S, const BdCell& C, i
                      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
     };
     if (nblk > 0) {
+        for (int rr = 0; rr < BD_RPW; ++rr) {
+            set_row(w * BD_RPW + rr);
 #pragma unroll
-        for (int j = 0; j < BD_RD; ++j) if (lane < 16) glds4(rec_src(j), rec_dst(j));
+            for (int j = 0; j < BD_RD; ++j) if (lane < 16) glds4(rec_src(j), rec_dst(j));
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     gran_t Y[3][5];
     for (int b = 0; b < nblk; ++b) {
         const int j = b;
+#pragma unroll 1
+      for (int rr = 0; rr < BD_RPW; ++rr) {
+        if (BD_RPW > 1) set_row(w * BD_RPW + rr);
         const int v = __builtin_amdgcn_readfirstlane(rec_ring[(j & 7) * 16]);
         const int slot = b % BD_NSLOT;
         float* sbase = lds.ring + (set * BD_NSLOT + slot) * Slot::words;
@@ -719,6 +766,7 @@ __device__ __forceinline__ void bd_loader_du(const BdArgs& S, const BdCell& C, i
             if (b >= BD_NSLOT) bd_wait4(dn, b - BD_NSLOT + 1, err, spin_limit);
         }
         if (lane == 0) v_s[lw] = v;
+      }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) bd_flag_st(lds.rdy + set * BD_WPS + w, b + 1);
     }
@@ -850,7 +898,7 @@ __device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int
 }
 
 template <int KPT>
-__global__ void __launch_bounds__(BD_THREADS, 3) bwd_dataflow_kernel(const int32_t* __restrict__ plan, BdArgs S) {
+__global__ void __launch_bounds__(BD_THREADS, BD_THREADS / 256) bwd_dataflow_kernel(const int32_t* __restrict__ plan, BdArgs S) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef BdSlot<KPT> Slot;
     constexpr int NS = 16 * KPT / DF_JS;
@@ -934,6 +982,10 @@ template <int KPT> size_t bd_lds_bytes() {
 
 }  // namespace
 
+#ifdef BD_WIDE_TU
+constexpr int BD_TU_MAX_H = 320;   // csrc/bwd_dataflow_w.hip: the 8-wave workgroup shape of H = 320
+#else
+constexpr int BD_TU_MAX_H = 256;
 extern "C" size_t dagnn_bwd_dataflow_record_bytes(int64_t N) {
     if (N < 0) return 0;
     return (size_t)2 * 16 * (4 * N + 4) * sizeof(int32_t);
@@ -979,10 +1031,19 @@ extern "C" int dagnn_bwd_dataflow_prepare(const dagnn_plan* pl, const dagnn_bwd_
     return DAGNN_OK;
 }
 
+#endif   // !BD_WIDE_TU
+
+#ifdef BD_WIDE_TU
+extern "C" int dagnn_bwd_dataflow_run_wide(const dagnn_plan* pl, const dagnn_bwd_dataflow_args* a, void* stream) {
+    if (!pl || !pl->data || !a || !a->schedule || !a->records) return DAGNN_EINVAL;
+    if (a->H <= 256) return DAGNN_EINVAL;
+#else
 extern "C" int dagnn_bwd_dataflow_run(const dagnn_plan* pl, const dagnn_bwd_dataflow_args* a, void* stream) {
     if (!pl || !pl->data || !a || !a->schedule || !a->records) return DAGNN_EINVAL;
+    if (a->H > 256) return dagnn_bwd_dataflow_run_wide(pl, a, stream);   // H = 320: csrc/bwd_dataflow_w.hip
+#endif
     const int H = a->H, Ls = a->num_stacked, dir_mask = a->dir_mask & 3, G = a->groups;
-    if (H <= 0 || (H % 64) || H > 320 || Ls <= 0 || Ls > DAGNN_MAX_STACKED || !dir_mask || a->gld < H || G < 1 ||
+    if (H <= 0 || (H % 64) || H > BD_TU_MAX_H || Ls <= 0 || Ls > DAGNN_MAX_STACKED || !dir_mask || a->gld < H || G < 1 ||
         G > DF_MAX_GROUPS || a->epoch == 0 || !a->err)
         return DAGNN_EINVAL;
     if (pl->B == 0 || pl->N == 0) return DAGNN_OK;
@@ -1069,13 +1130,16 @@ extern "C" int dagnn_bwd_dataflow_run(const dagnn_plan* pl, const dagnn_bwd_data
         if (ea != hipSuccess) return DAGNN_EHIP(ea);                                                                     \
         hipLaunchKernelGGL((bwd_dataflow_kernel<KPT>), dim3(grid), dim3(BD_THREADS), bd_lds_bytes<KPT>(), st, plan, S);  \
     } while (0)
+#ifdef BD_WIDE_TU
+    BD_LAUNCH(20);
+#else
     switch (H / 16) {
         case 4: BD_LAUNCH(4); break;
         case 8: BD_LAUNCH(8); break;
         case 12: BD_LAUNCH(12); break;
-        case 20: BD_LAUNCH(20); break;
         default: BD_LAUNCH(16); break;
     }
+#endif
 #undef BD_LAUNCH
     DAGNN_CHECK_LAUNCH();
     return DAGNN_OK;

@@ -210,6 +210,56 @@ def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
             "kernels_ms_per_step": {k: round(n * ms / steps, 4) for k, (n, ms) in summ.items()}}
 
 
+def ogb_tok_config(device, timed):
+    """emb_dim 300, B = 160, L = 2, bidirectional: forward(G) end to end and one training step (zero_grad, forward, CE over 5
+    heads, backward, clip_grad_norm 0.25, fused Adam), with the roofline of the forward's dataflow launch at H = 320."""
+    from dagnn_amd import synth, engine
+    H, B, L, V, S = 300, 160, 2, 5002, 5
+    model = build_model(H, L, V, S, device)
+    master = synth.code2_batch(seed=0, num_graphs=B)
+    master.x[:, 1] %= 10030
+    N, E = int(master.x.shape[0]), int(master.edge_index.shape[1])
+    T = int(master._bi_layer_idx0.max()) + 1
+    master = master.to(device)
+    with torch.no_grad():
+        it = iter(fresh_inputs(master, 30))
+        fwd = timed(lambda: model(next(it)), 20, 5)
+        engine.TIMER = engine.KernelTimer(only=("dataflow_run",))
+        it = iter(fresh_inputs(master, 12))
+        for _ in range(10):
+            model(next(it))
+        torch.cuda.synchronize()
+        rec = engine.TIMER.summary().get("dataflow_run", (0, float("nan")))[1]
+        engine.TIMER = None
+    model.check()
+    Hp = 320
+    gf = (2 * L * N * 6.0 * Hp * Hp + 2 * (L - 1) * N * 6.0 * Hp * Hp) / 1e9   # the products the launch really does (padded width)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    ce = torch.nn.CrossEntropyLoss()
+    y = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(1)).to(device)
+    it = iter(fresh_inputs(master, 24))
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        pred = model(next(it))
+        loss = sum(ce(pred[s], y[:, s]) for s in range(S)) / S
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.25, foreach=True)
+        opt.step()
+    train = timed(step, 12, 4)
+    model.check()
+    model.eval()
+    return {"what": "ogbg-code/scripts/ogb_tok.sh: emb_dim = hidden = 300 (320-wide rows), batch 160, L = 2, bidirectional, clip 0.25",
+            "nodes": N, "edges": E, "topo_layers": T,
+            "forward_ms_per_batch": round(fwd, 4), "forward_graphs_per_s": round(B / fwd * 1e3, 1),
+            "training_step_ms": round(train, 4), "training_graphs_per_s": round(B / train * 1e3, 1),
+            "roofline": {"kernel": "dataflow_kernel<20> (dagnn_dataflow_run_wide)", "bound": "mfma", "achieved": round(gf / rec, 3),
+                         "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gf / rec / FP32_MATRIX_PEAK_TFLOPS, 5),
+                         "recurrence_ms_per_forward": round(rec, 4), "gflop_per_forward": round(gf, 2),
+                         "us_per_topological_layer": round(rec / T * 1e3, 3)}}
+
+
 def other_configs(device):
     """BASELINE.json's other configurations, briefly (same code, forward only, inputs resident; medians of HIP-event
     times): cfg 1 (NA: 64 ENAS-shaped DAGs, h=128, L=2, unidirectional), cfg 4 (BN: 128 ten-node DAGs, h=256, L=2,
@@ -270,6 +320,14 @@ def other_configs(device):
             mw.check()
             wide[tag] = {"ms_per_batch": round(msw, 4), "graphs_per_s": round(Bw / msw * 1e3, 1)}
         out["dvae_default_width_hs501_L2"] = wide
+    # the reference's own training shape (scripts/ogb_tok.sh:17,63: --emb_dim=300, batch 160, 2 stacked layers, bidirectional,
+    # --clip 0.25): hidden sizes 257..320 run 320 wide on the 8-wave shape of the dataflow kernels (csrc/dataflow_w.hip,
+    # csrc/bwd_dataflow_w.hip) - forward and the whole training step
+    try:
+        out["ogb_tok_h300_L2_B160"] = ogb_tok_config(device, timed)
+    except Exception as exc:   # (never lose the line over a side entry)
+        out["ogb_tok_h300_L2_B160"] = {"error": repr(exc)}
+    with torch.no_grad():
         m5 = build_model(512, 5, 5002, 5, device)
         b5 = synth.code2_batch(seed=0, num_graphs=256)
         N5, E5 = b5.x.shape[0], b5.edge_index.shape[1]

@@ -591,24 +591,14 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                 op[DF_RB * Slot::AP + cpos[q]] = dz[q];
                 op[2 * DF_RB * Slot::AP + cpos[q]] = dnr[q];
             }
-            if (mine) {
-                const int c = 64 * myq + lane;   // = 32 sl + (lane & 31)
-                sbase[Slot::zg_off + lw * DF_JS + (lane & 31)] = pick(zg);
-                const float mr = pick(dr), mz = pick(dz), mn = pick(dnn), mnr = pick(dnr);
-                float* og = dgi + (int64_t)v * (3 * H);
-                float* oh = dgh + (int64_t)v * (3 * H);
-                og[c] = mr; og[H + c] = mz; og[2 * H + c] = mn;
-                oh[c] = mr; oh[H + c] = mz; oh[2 * H + c] = mnr;
-                if (dgi_g) {
-                    gran_t* pg = dgi_g + (int64_t)v * (3 * gld) + c;
-                    if (local_st) {   // (readers on this XCD: the lines stay in its L2)
-                        pg[0] = gran_pack(epoch, mr); pg[gld] = gran_pack(epoch, mz); pg[2 * gld] = gran_pack(epoch, mn);
-                    } else {
-                        __hip_atomic_store(pg, gran_pack(epoch, mr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(pg + gld, gran_pack(epoch, mz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(pg + 2 * gld, gran_pack(epoch, mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
+            if (mine) sbase[Slot::zg_off + lw * DF_JS + (lane & 31)] = pick(zg);
+            v_s[lw] = v;   // (every lane: same word, same value)
+            // the compute waves need nothing but the LDS slot: the last row of the wave raises the flag BEFORE the row's
+            // outputs to memory (q for the predecessors' pulls first, then the dgi granules, then the plain rows the weight-
+            // gradient epilogue reads)
+            if (rr == BD_RPW - 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                bd_flag_st(lds.rdy + set * BD_WPS + w, b + 1);
             }
             if (sl == 0) {   // q_v = G_v . c_q,v; the row's scalar outputs
                 float qd = G[0] * ST[ST_CQ].x;
@@ -625,14 +615,34 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                     if (R >= 2) mrel[(int64_t)v * R + 1] = m1;
                 }
             }
+            if (mine) {
+                const int c = 64 * myq + lane;   // = 32 sl + (lane & 31)
+                const float mr = pick(dr), mz = pick(dz), mn = pick(dnn), mnr = pick(dnr);
+                if (dgi_g) {
+                    gran_t* pg = dgi_g + (int64_t)v * (3 * gld) + c;
+                    if (local_st) {   // (readers on this XCD: the lines stay in its L2)
+                        pg[0] = gran_pack(epoch, mr); pg[gld] = gran_pack(epoch, mz); pg[2 * gld] = gran_pack(epoch, mn);
+                    } else {
+                        __hip_atomic_store(pg, gran_pack(epoch, mr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(pg + gld, gran_pack(epoch, mz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(pg + 2 * gld, gran_pack(epoch, mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                float* og = dgi + (int64_t)v * (3 * H);
+                float* oh = dgh + (int64_t)v * (3 * H);
+                og[c] = mr; og[H + c] = mz; og[2 * H + c] = mn;
+                oh[c] = mr; oh[H + c] = mz; oh[2 * H + c] = mnr;
+            }
         } else {
             if (lane < 16) glds4(ra, rl);   // an idle row keeps the record ring moving
             if (b >= BD_NSLOT) bd_wait4(dn, b - BD_NSLOT + 1, err, spin_limit);
+            v_s[lw] = v;
+            if (rr == BD_RPW - 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                bd_flag_st(lds.rdy + set * BD_WPS + w, b + 1);
+            }
         }
-        if (lane == 0) v_s[lw] = v;
       }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) bd_flag_st(lds.rdy + set * BD_WPS + w, b + 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

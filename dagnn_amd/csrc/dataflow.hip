@@ -286,6 +286,12 @@ template <int KPT> struct DfPad { static constexpr int kp8 = 2 * KPT; static con
 #ifndef DF_WSLEEP_N
 #define DF_WSLEEP_N (DF_WAKEUP ? 8 : 1)   // ... of a loader's wait for its ring slot
 #endif
+#ifndef DF_PIPE
+#define DF_PIPE 0       // compute waves: the next block's flag look and LDS reads under the current block's reduction / gates / stores.
+                        // Measured (round 4), bitwise the plain loop's rows: at 12 waves the two operand register sets spill (208 VGPRs,
+                        // 5.5 ms); in the 8-wave shape (256 registers, -DDF_NLW_V=4) 1.405 against 1.425 ms without it - and 1.355
+                        // for the plain loop at 12 waves: the look + LDS round trip it hides is not what a block's time is made of
+#endif
 #ifndef DF_LEAN_COMPUTE
 #define DF_LEAN_COMPUTE 1
 #endif
@@ -1137,6 +1143,135 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     unsigned long long* const dbg = (DF_PROF && S.dbg) ? S.dbg + 2 * gridDim.x : nullptr;
     const bool prof = DF_PROF && dbg != nullptr && (int)blockIdx.x == S.dbg_wg && cw == 0 && lane == 0;
 
+    if constexpr (DF_PIPE && DF_TEAMS == 1 && DF_NLS == 2 && DF_WPS == 4 && DF_FMA_ROWS == 0 && !DF_PROF) {
+        // ---- software-pipelined form (round 4).  A workgroup's compute waves are its scarce resource (~940 blocks x ~1.05 us
+        // of a 1.35 ms pass): per block ~0.25 us of that is the look at the ready flags plus the LDS round trip of the block's
+        // operands.  Both move under the PREVIOUS block's reduction / gates / stores: right after a block's products (its
+        // operand registers are free, its LDS slot goes back) the wave looks for the next ready block and, if there is one,
+        // issues its LDS reads; only when none is ready yet (the thin dependent chain) it waits as before.  Two register
+        // sets in ping-pong (the loop body exists twice), same choice rule (smallest positive lead first, ties alternate),
+        // same arithmetic in the same order: the rows are bitwise those of the plain loop.
+        typedef int i4v __attribute__((ext_vector_type(4)));
+        const unsigned rdy_a = (unsigned)(uintptr_t)lds.rdy;
+        const int nb0 = nb[0], nb1 = nb[1];
+        int done0 = 0, done1 = 0, pref = 0;
+        int left = nb0 + nb1;
+        if (left == 0) return;
+        auto look = [&]() -> int {   // ONE trip to LDS: the stream to serve next, or -1
+            i4v r0, r1;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(r0), "=&v"(r1) : "v"(rdy_a) : "memory");
+            const int m0 = __builtin_amdgcn_readfirstlane(min(min(r0.x, r0.y), min(r0.z, r0.w)));
+            const int m1 = __builtin_amdgcn_readfirstlane(min(min(r1.x, r1.y), min(r1.z, r1.w)));
+            const int l0 = done0 < nb0 ? m0 - done0 : 0, l1 = done1 < nb1 ? m1 - done1 : 0;
+            if (l0 <= 0 && l1 <= 0) return -1;
+            return l0 <= 0 ? 1 : (l1 <= 0 ? 0 : (l0 != l1 ? (l0 < l1 ? 0 : 1) : pref));
+        };
+        auto wait_block = [&]() -> int {
+            unsigned spins = 0;
+            for (;;) {
+                const int st = look();
+                if (st >= 0) return st;
+                __builtin_amdgcn_s_sleep(DF_CSLEEP_N);
+                bool give_up = false;
+                if (++spins > 4 * spin_limit) {   // the pass is lost; it must still end (node ids are bounded below)
+                    __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    give_up = true;
+                }
+                if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = true;
+                if (give_up) return done0 < nb0 ? 0 : 1;
+            }
+        };
+        struct Ops { float4 bv[NK4]; float gi_r, gi_z, gi_n, aval; int4 ids; int st, b; };
+        auto take = [&](int st, Ops& o) {   // claim the stream's next block and issue every LDS read of it (no wait here)
+            o.st = st;
+            o.b = st ? done1 : done0;
+            if (st) ++done1; else ++done0;
+            pref = st ^ 1;
+            const float* sbase = lds.ring + (st * DF_NSLOT + o.b % DF_NSLOT) * Slot::words;
+            o.ids = *reinterpret_cast<const int4*>(sbase + Slot::v_off);
+            o.gi_r = o.gi_z = o.gi_n = o.aval = 0.f;
+            if (!proj) {
+                if (has_gi) {
+                    const float* gp = (gi_ring ? lds.giring + (st * DF_GIRING + o.b % DF_GIRING) * (DF_RB * 3 * DF_JS) : sbase + Slot::gi_off) + x * (3 * DF_JS) + unit_l;
+                    o.gi_r = gp[0]; o.gi_z = gp[DF_JS]; o.gi_n = gp[2 * DF_JS];
+                }
+                o.aval = sbase[Slot::a_off + x * Slot::AP + apos];
+            }
+            const float* a_seg = sbase + Slot::a_off + x * Slot::AP + ks * SEG;
+#pragma unroll
+            for (int q = 0; q < NK4; ++q) o.bv[q] = *reinterpret_cast<const float4*>(a_seg + 4 * q);
+        };
+        // one block: products, slot release, (next block's reads), reduction, gates, stores.  Returns false after the last
+        auto body = [&](Ops& cur, Ops& nxt) -> bool {
+            --left;
+            f4v acc[3] = {(f4v){0.f, 0.f, 0.f, 0.f}, (f4v){0.f, 0.f, 0.f, 0.f}, (f4v){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int q = 0; q < NK4; ++q) {
+                const float bq[4] = {cur.bv[q].x, cur.bv[q].y, cur.bv[q].z, cur.bv[q].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q + e], bq[e], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wz[4 * q + e], bq[e], acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(wn[4 * q + e], bq[e], acc[2], 0, 0, 0);
+                }
+            }
+            const int4 ids = cur.ids;
+            const float gi_r = cur.gi_r, gi_z = cur.gi_z, gi_n = cur.gi_n, aval = cur.aval;
+            const int st = cur.st, b = cur.b;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of this block has landed: the slot goes back
+            if (lane == 0) df_flag_st(lds.dn + st * DF_NCW + cw, b + 1);
+            df_wakeup();
+            int nst = -1;
+            if (left > 0) {
+                nst = look();
+                if (nst >= 0) take(nst, nxt);
+            }
+            float g3[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float u0 = acc[a][0] + df_dpp<0x104>(acc[a][0]), u1 = acc[a][1] + df_dpp<0x104>(acc[a][1]);
+                const float u2 = acc[a][2] + df_dpp<0x114>(acc[a][2]), u3 = acc[a][3] + df_dpp<0x114>(acc[a][3]);
+                const float e0 = s0 ? u2 : u0, e1 = s0 ? u3 : u1;
+                const float f0 = e0 + df_dpp<0x108>(e0), f1 = e1 + df_dpp<0x118>(e1);
+                const float f = s1 ? f1 : f0;
+                g3[a] = df_row_pair_sum(f);
+            }
+            const int nr = (ids.x >= 0) + (ids.y >= 0) + (ids.z >= 0) + (ids.w >= 0);   // live records come first
+            const int gv = x == 0 ? ids.x : (x == 1 ? ids.y : (x == 2 ? ids.z : ids.w));
+            const bool live = x < nr && (unsigned)gv < (unsigned)num_nodes && (lane & 16) == 0;   // (lanes 16 away hold the same sums)
+            if (live) {
+                if (proj) {
+                    gran_t* po = g_out + (int64_t)gv * pld + unit;
+                    __hip_atomic_store(po, gran_pack(epoch, g3[0] + b_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(po + H, gran_pack(epoch, g3[1] + b_z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(po + 2 * H, gran_pack(epoch, g3[2] + b_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    const float rg = df_sigm(g3[0] + b_r + gi_r);
+                    const float zg = df_sigm(g3[1] + b_z + gi_z);
+                    const float ng = df_tanh(fmaf(rg, g3[2] + b_n, gi_n));
+                    const float hv = fmaf(zg, aval - ng, ng);   // n + z * (a - n)
+                    if (local_st) g_out[(int64_t)gv * gld + unit] = gran_pack(epoch, hv);
+                    else __hip_atomic_store(g_out + (int64_t)gv * gld + unit, gran_pack(epoch, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    h_out[(int64_t)gv * ld_h + unit] = hv;
+                }
+                if (aux_out) {
+                    float* ao = aux_out + (int64_t)gv * (3 * H) + unit;
+                    ao[0] = g3[0] + b_r; ao[H] = g3[1] + b_z; ao[2 * H] = g3[2] + b_n;
+                }
+            }
+            if (left == 0) return false;
+            if (nst < 0) take(wait_block(), nxt);
+            return true;
+        };
+        Ops A, B;
+        take(wait_block(), A);
+        for (;;) {
+            if (!body(A, B)) break;
+            if (!body(B, A)) break;
+        }
+        return;
+    }
     // Blocks of the two streams in whatever order they become ready.  A stream inside a thin dependent chain is ready
     // once per hop (~3 us, of which this wave works ~0.8): the other stream's blocks fill the gap.  When both have a
     // block, the one whose loader is LESS far ahead goes first (it is the latency-bound one); ties alternate.

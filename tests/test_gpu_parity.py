@@ -291,8 +291,7 @@ def test_headline_batch_matches_oracle(device, schedule):
     """cfg 2 at full size (seed-0 batch: B=128, N=16 561, E=25 377, T=374; h=256, L=2, bidir)."""
     model = _headline_model()
     b = synth.code2_batch(0, 128)
-    ref = O.code2_forward(model.state_dict(), copy.deepcopy(b), num_layers=2, bidirectional=True, out_wx=False,
-                          out_pool_all=False, out_pool="max", max_seq_len=5)
+    ref = _oracle_forward("cfg2_full", model, b, 2)
     model = model.to(device)
     G = b.to(device)
     with torch.no_grad():
@@ -345,12 +344,23 @@ def test_wide_deep_config_full_size_properties(device):
         assert Hh.maxdiff(sub, a[:, order]) < 2e-5
 
 
+_ORACLE_CACHE = {}
+
+
+def _oracle_forward(key, model, b, L):
+    """The CPU oracle's logits of (model, batch): computed once per session and key - the schedule parametrisations compare
+    three GPU paths against the SAME reference, and the oracle is what these tests spend their time in."""
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = O.code2_forward(model.state_dict(), copy.deepcopy(b), num_layers=L, bidirectional=True, out_wx=False,
+                                             out_pool_all=False, out_pool="max", max_seq_len=5)
+    return _ORACLE_CACHE[key]
+
+
 def test_wide_deep_config_matches_oracle(device, schedule):
     """cfg 5 shape (h=512, L=5, bidir) on a 24-graph batch."""
     model = _headline_model(H=512, L=5, V=32, seed=5)
     b = synth.code2_batch(21, 24)
-    ref = O.code2_forward(model.state_dict(), copy.deepcopy(b), num_layers=5, bidirectional=True, out_wx=False,
-                          out_pool_all=False, out_pool="max", max_seq_len=5)
+    ref = _oracle_forward("cfg5_24", model, b, 5)
     model = model.to(device)
     with torch.no_grad():
         out = model(b.to(device))
@@ -397,13 +407,13 @@ def test_deep_stack_runs_on_the_dataflow_kernel(device, monkeypatch):
         got = grads.get(k)
         got = torch.zeros_like(g) if got is None else got.cpu()
         assert float((got - g).abs().max()) <= 2e-4 * scale + 2e-7, k
-    # a shape neither persistent kernel covers (h = 320, one layer: the dataflow kernel stops at 256, the tile kernel is
-    # built for 512 and stacked models - engine.state_width leaves this one at 320) falls back to the per-layer launches
+    # a shape neither persistent kernel covers (h = 384, one layer: the dataflow kernels stop at 320, the tile kernel is
+    # built for 512 and stacked models - engine.state_width leaves this one at 384) falls back to the per-layer launches
     # and says so, once
     from dagnn_amd import core
     core._OFF_DATAFLOW_SEEN.clear()
-    assert engine.state_width(320, 1, 2) == 320
-    wide = _headline_model(H=320, L=1, V=8, seed=1).to(device)
+    assert engine.state_width(384, 1, 2) == 384
+    wide = _headline_model(H=384, L=1, V=8, seed=1).to(device)
     small = synth.code2_batch(3, 4, 12)
     with torch.no_grad():
         with pytest.warns(RuntimeWarning, match="per-layer launch path"):
@@ -1618,7 +1628,7 @@ def test_hidden_sizes_between_256_and_512_run_padded_to_512(device, monkeypatch,
     assert max(Hh.maxdiff(a, c) for a, c in zip(res[1][1], res[0][1])) < 5e-6
 
 
-@pytest.mark.parametrize("H,L", [(300, 2), (300, 3), (320, 1), (264, 2)])
+@pytest.mark.parametrize("H,L", [(300, 2), (300, 3), (320, 1)])
 def test_hidden_sizes_up_to_320_run_on_the_wide_dataflow_kernel(device, monkeypatch, H, L):
     """Hidden sizes 257..320 (the reference trains at emb_dim = 300, scripts/ogb_tok.sh:17) run zero-padded to 320 on the
     8-wave shape of the dataflow kernel (`dagnn_dataflow_run_wide`, csrc/dataflow_w.hip): logits and every state row against

@@ -79,7 +79,7 @@ class DataflowArgs(C.Structure):
                 ("H", C.c_int), ("ld_h", C.c_int), ("gld", C.c_int), ("pld", C.c_int), ("vid_mod", C.c_int), ("groups", C.c_int),
                 ("epoch", C.c_uint), ("schedule", C.c_void_p), ("err", C.c_void_p), ("debug_timing", C.c_void_p),
                 ("spin_limit", C.c_uint), ("debug_wg", C.c_int), ("num_cus", C.c_int), ("xcc_table", C.c_void_p),
-                ("plan_status", C.c_void_p)]
+                ("plan_status", C.c_void_p), ("xcd_first", C.c_int)]
 
 
 class TilesCell(C.Structure):
@@ -126,7 +126,7 @@ class BwdDataflowArgs(C.Structure):
     _fields_ = [("cell", (BwdDataflowCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
                 ("H", C.c_int), ("ld_h", C.c_int), ("ld_g", C.c_int), ("gld", C.c_int), ("groups", C.c_int),
                 ("epoch", C.c_uint), ("spin_limit", C.c_uint), ("schedule", C.c_void_p), ("records", C.c_void_p),
-                ("err", C.c_void_p), ("plan_status", C.c_void_p), ("num_cus", C.c_int), ("xcc_table", C.c_void_p)]
+                ("err", C.c_void_p), ("plan_status", C.c_void_p), ("num_cus", C.c_int), ("xcc_table", C.c_void_p), ("xcd_first", C.c_int)]
 
 
 AGG_ATTN, AGG_MATTN, AGG_GATED, AGG_ADD, AGG_MAX, AGG_GIVEN = range(6)

@@ -1109,6 +1109,7 @@ extern "C" int dagnn_bwd_dataflow_run(const dagnn_plan* pl, const dagnn_bwd_data
     if (a->num_cus >= 8 && a->num_cus <= BD_MAX_WGS && a->xcc_table && sets < 64 && nc <= 31) {   // (dataflow.hip: same packing)
         const int cap = a->num_cus / 8;
         int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int xrot = (a->xcd_first % 8 + 8) % 8;   // bin x of the packing = XCD (x + xcd_first) mod 8
         for (int b = 0; b < BD_MAX_WGS; ++b) S.role[b] = BD_IDLE_ROLE;
         bool ok = true;
         int top = 0;
@@ -1124,7 +1125,7 @@ extern "C" int dagnn_bwd_dataflow_run(const dagnn_plan* pl, const dagnn_bwd_data
                     for (int m = 0; m < 2; ++m) {
                         if (members[m] < 0) continue;
                         for (int sl = 0; sl < NS; ++sl) {
-                            const int b = fill[x]++ * 8 + x;
+                            const int b = fill[x]++ * 8 + (x + xrot) % 8;
                             S.role[b] = (unsigned short)((set << 10) | (members[m] << 5) | sl);
                             if (b + 1 > top) top = b + 1;
                         }

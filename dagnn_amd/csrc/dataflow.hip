@@ -1834,6 +1834,7 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
     if (a->num_cus >= 8 && a->num_cus <= DF_MAX_WGS && a->xcc_table && df_sets_for(G) < 64 && nc <= 31) {
         const int NS = H / DF_JS, sets = df_sets_for(G), cap = a->num_cus / 8;
         int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int xrot = (a->xcd_first % 8 + 8) % 8;   // bin x of the packing = XCD (x + xcd_first) mod 8
         for (int b = 0; b < DF_MAX_WGS; ++b) S.role[b] = DF_IDLE_ROLE;
         bool ok = true;
         int top = 0;
@@ -1849,7 +1850,7 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
                     for (int m = 0; m < 2; ++m) {
                         if (members[m] < 0) continue;
                         for (int sl = 0; sl < NS; ++sl) {
-                            const int b = fill[x]++ * 8 + x;
+                            const int b = fill[x]++ * 8 + (x + xrot) % 8;
                             S.role[b] = (unsigned short)((set << 10) | (members[m] << 5) | sl);
                             if (b + 1 > top) top = b + 1;
                         }

@@ -257,7 +257,10 @@ class _DvaeDagnn(_DvaeBase):
         key = (role, x.device, engine._stream(x))   # one arena per stream: passes on different streams may overlap
         arena = self._arenas.get(key)
         if arena is None:
-            arena = self._arenas[key] = engine.GranuleArena()
+            arena = engine.GranuleArena()
+            # passes of further streams (micro-batches in flight) start their workgroup packing two XCDs further on
+            arena.xcd_first = 2 * sum(1 for k in self._arenas if k[0] == role and k[1] == x.device) % 8
+            self._arenas[key] = arena
         return arena
 
     def _readout(self, plan, B, x, h):

@@ -469,6 +469,7 @@ def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     if DF_XCD:
         args.num_cus = effective_cus(plan.ws.device, training)   # (the placement spreads the workgroups over num_cus / 8 per XCD)
         args.xcc_table = arena.xcc_table(plan.ws.device).data_ptr()
+        args.xcd_first = arena.xcd_first
     args.plan_status = plan.status.data_ptr()
     with _span("dataflow_run", plan.ws):
         check(lib.dagnn_dataflow_run(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_dataflow_run")
@@ -603,6 +604,7 @@ class GranuleArena(object):
         self.epoch = 0
         self.err = None
         self.side = None   # second stream: the persistent kernel runs next to the per-layer launches (split mode)
+        self.xcd_first = 0   # XCD the dataflow launches of this arena pack their workgroups from (arenas of further streams: 2, 4, ..)
 
     def get(self, keys, N: int, gld: int, device, widths=None):
         """`widths`: row pitch (granules) of the buffers that differ from `gld`."""
@@ -1078,6 +1080,7 @@ def bwd_dataflow_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, ce
         if DF_XCD:
             args.num_cus = effective_cus(dev, True)
             args.xcc_table = arena.xcc_table(dev).data_ptr()
+            args.xcd_first = arena.xcd_first
         check(lib.dagnn_bwd_dataflow_prepare(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_bwd_dataflow_prepare")
     with _span("backward_run", plan.ws):
         check(lib.dagnn_bwd_dataflow_run(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_bwd_dataflow_run")

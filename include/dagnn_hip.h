@@ -323,6 +323,9 @@ typedef struct dagnn_dataflow_args {
     void* xcc_table;
     const void* plan_status; /* NULL, or the device status word of dagnn_plan_build: if it is nonzero (the batch violates
                             * the layout contract) the launch walks nothing and raises bit 2 of `err` */
+    int xcd_first;          /* XCD-aware placement: the XCD the packing starts with (0..7).  Launches that run next to each other
+                            * (micro-batches in flight on several streams, each sized for a part of the device) pass different
+                            * values, otherwise all of them pack their workgroups onto the same first XCDs and take turns */
 } dagnn_dataflow_args;
 
 int dagnn_dataflow_groups(int num_cus, int num_dirs, int num_stacked, int H, int64_t B);
@@ -537,6 +540,7 @@ typedef struct dagnn_bwd_dataflow_args {
     const void* plan_status;  /* or NULL */
     int num_cus;              /* XCD-aware placement, as in dagnn_dataflow_args (0 / NULL: off) */
     void* xcc_table;
+    int xcd_first;            /* as in dagnn_dataflow_args */
 } dagnn_bwd_dataflow_args;
 
 size_t dagnn_bwd_dataflow_record_bytes(int64_t N);

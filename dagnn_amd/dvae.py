@@ -26,6 +26,34 @@ OWN_LINEAR_MAX = 1 << 22   # multiply-adds up to which the final Linear of an ev
 from .model import _EdgeAttnParams, _SelfAttnParams
 
 
+class _NoParams(object):
+    wea = False   # no edge encoder (num_rels = 1 in the D-VAE models)
+
+
+class _AggView(object):
+    """What `dagnn_amd.variants` reads from a model, for a D-VAE encoder with agg in {add, max}: GRU cells, values = the
+    cell's own states, no edge features, and - unlike the ogbg model - one AggConv PER direction (`reverse=True` for the
+    second, dvae/dagnn.py:66-70), so the messages land on the frontier in both."""
+    agg_x = False
+    recurr = 1
+    agg_attn = False
+    agg_attn_x = False
+    shared_agg_flow = False
+
+    def __init__(self, m):
+        self._m = m
+        self.agg, self.hidden_dim, self.num_layers, self.dirs = m.agg, m.hidden_dim, m.num_layers, m.dirs
+        self.emb_dim = m.cells_0[0].weight_ih.shape[1]   # the node inputs are the one-hot vertex types (nvt wide)
+        self.node_aggr_0 = [_NoParams() for _ in range(m.num_layers)]
+        self.node_aggr_1 = [_NoParams() for _ in range(m.num_layers)]
+
+    def __getattr__(self, name):   # cells_0 / cells_1, training, ...
+        return getattr(self.__dict__["_m"], name)
+
+    def parameters(self):
+        return self._m.parameters()
+
+
 class _CellView:
     """The four GRUCell tensors `engine.iprop_step` reads, without the module around them."""
     __slots__ = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
@@ -166,13 +194,28 @@ class _DvaeDagnn(_DvaeBase):
         self.emb_dim = emb_dim
         self.hidden_dim = hidden_dim
         self.out_hidden_dim = emb_dim + hidden_dim * num_layers if out_wx else hidden_dim * num_layers
-        if agg not in (K.NA_ATTN_H, K.NA_SELF_ATTN_H):
-            raise NotImplementedError("the D-VAE encoders implement agg='attn_h' (the reference's default, dvae/train.py:86) "
-                                      "and 'self_attn_h' so far")
+        self._agg_plain = agg in (K.NA_GATED_SUM, K.NA_SUM, K.NA_MAX)
+        if not self._agg_plain and agg not in (K.NA_ATTN_H, K.NA_SELF_ATTN_H):
+            raise NotImplementedError("D-VAE encoders: agg=%r (attn_h - the reference's default, dvae/train.py:86 -, self_attn_h, "
+                                      "gated_sum, add, max)" % (agg,))
+        if agg == K.NA_GATED_SUM and not self._use_vids:
+            raise NotImplementedError("DAGNN_BN with agg='gated_sum': the reference itself cannot run it - DVAE_BN_PYG re-creates the "
+                                      "first layer's mapper / gate with nvt inputs (dvae/models_pyg.py:539-560) and GatedSumConv feeds "
+                                      "them hs-wide states (dvae/dagnn_bn.py:289): a shape error in its first message")
         extra = num_nodes if self._use_vids else 0
         pred_dim = hidden_dim + extra
         attn_dim = hidden_dim + extra
-        if agg == K.NA_SELF_ATTN_H:   # keys scored alone: `attn_lin` has no query half (dvae/dagnn.py:49-54, 301-312)
+        if self._agg_plain:
+            # GatedSumConv / AggConv own no parameters of their own here: gated_sum uses the base class's mapper / gate
+            # (dvae/dagnn.py:60-65), add / max have none (num_rels = 1: no edge encoder)
+            def conv(mapper, gate):   # (same `state_dict` names as the reference's GatedSumConv: it registers the shared modules)
+                m = nn.Module()
+                if agg == K.NA_GATED_SUM:
+                    m.mapper, m.gate = mapper, gate
+                return m
+            self.node_aggr_0 = nn.ModuleList([conv(self.mapper_forward[l], self.gate_forward[l]) for l in range(num_layers)])
+            self.node_aggr_1 = nn.ModuleList([conv(self.mapper_backward[l], self.gate_backward[l]) for l in range(num_layers)])
+        elif agg == K.NA_SELF_ATTN_H:   # keys scored alone: `attn_lin` has no query half (dvae/dagnn.py:49-54, 301-312)
             self.node_aggr_0 = nn.ModuleList([_SelfAttnParams(attn_dim, num_relations=1) for _ in range(num_layers)])
             self.node_aggr_1 = nn.ModuleList([_SelfAttnParams(attn_dim, num_relations=1, reverse=True)
                                               for _ in range(num_layers)])
@@ -316,6 +359,8 @@ class _DvaeDagnn(_DvaeBase):
         B = N // nn_
         bl = G.bi_layer_index
         plan = engine.build_plan(G.edge_index, bl[0][0], bl[1][0], G.batch, B, None)
+        if self._agg_plain:
+            return self._forward_plain_agg(G, plan, x, B, train)
         if self.output_all:   # pool over ALL nodes (dvae/dagnn.py:163-172): states, per-node projection, torch pooling
             if train:
                 from .autograd import Recurrence
@@ -359,6 +404,104 @@ class _DvaeDagnn(_DvaeBase):
         # library dispatch and cfg 1 is host-bound (scripts/small_host_profile.py: 155 -> 134 us per forward); cfg 4's
         # 128 x 1024 x 256 stays with the library (its split-K kernel is the faster one there: 196 vs 285 us)
         return engine.gemm_nt_bias([G.h], [lin.weight.detach()], [None if lin.bias is None else lin.bias.detach()])[0]
+
+    # ------------------------------------------------------------------ agg in {gated_sum, add, max} (dvae/dagnn.py:60-70)
+    def _agg_view(self):
+        v = self.__dict__.get("_agg_view_obj")
+        if v is None:
+            v = self.__dict__["_agg_view_obj"] = _AggView(self)
+        return v
+
+    def _gated_sum_states(self, G, x):
+        """`gated_sum` on the NA encoder: the messages are gate(hs_j) * mapper(hs_j) with hs_j = [state ; one-hot vertex id]
+        (dvae/dagnn.py:124-137, 269-299), i.e. per NODE P_j = W_g[:, :H] h_j + W_g[:, H + j mod n] + b_g (likewise the
+        mapper) - the vertex-id columns are a per-node bias.  Layer by layer on device-side torch ops (a D-VAE batch has
+        as many layers as a graph has vertices: <= ~10 steps; differentiable as it stands)."""
+        N, H, L, nn_ = x.shape[0], self.hidden_dim, self.num_layers, self.num_nodes
+        dev = x.device
+        vid = torch.arange(N, device=dev) % nn_
+        ei = G.edge_index
+        h = [[None] * L for _ in range(2)]
+        for d in self.dirs:
+            layer_of = G.bi_layer_index[d][0]
+            T = int(layer_of.max()) + 1 if N else 0
+            feed, other = ei[1 - d], ei[d]          # an edge feeds node `feed` from node `other`
+            order = torch.argsort(layer_of[feed] * N + feed, stable=True)
+            counts = torch.bincount(layer_of[feed], minlength=T).cumsum(0).cpu().tolist()
+            gates = self.gate_forward if d == 0 else self.gate_backward
+            maps = self.mapper_forward if d == 0 else self.mapper_backward
+            cells = getattr(self, "cells_%d" % d)
+            hs = [x.new_zeros(N, H) for _ in range(L)]
+            ids = torch.arange(N, device=dev)
+            for t in range(T):
+                rows = ids[layer_of == t]
+                inp = x[rows]
+                if t > 0:
+                    eids = order[(counts[t - 1]):(counts[t])]
+                    src, dst = other[eids], feed[eids]
+                for i in range(L):
+                    ps = None
+                    if t > 0:
+                        wg, bg, wm = gates[i][0].weight, gates[i][0].bias, maps[i][0].weight
+                        hj = hs[i][src]
+                        g = torch.sigmoid(hj @ wg[:, :H].t() + wg[:, H + vid[src]].t() + bg)
+                        m = hj @ wm[:, :H].t() + wm[:, H + vid[src]].t()
+                        ps = x.new_zeros(N, H).index_add_(0, dst, g * m)[rows]
+                    inp = cells[i](inp, ps)
+                    hs[i] = hs[i].index_add(0, rows, inp)   # `G.h[d][i][layer] += inp` (dvae/dagnn.py:145)
+            h[d] = hs
+        return h
+
+    def _forward_plain_agg(self, G, plan, x, B, train):
+        """`forward` for agg in {gated_sum, add, max}: `add` / `max` through the generic HIP kernels of csrc/variants.hip
+        (`dagnn_variant_run`; training: the reverse sweep of csrc/variants_bwd.hip where it applies, `variants.hip_backward_
+        supported`), `gated_sum` (NA) on torch ops; then the read-outs of `dvae/dagnn.py:147-172`."""
+        from . import variants
+        L, H, nn_ = self.num_layers, self.hidden_dim, self.num_nodes
+        if self.agg == K.NA_GATED_SUM:
+            if train:
+                h = self._gated_sum_states(G, x)
+            else:
+                with torch.no_grad():
+                    h = self._gated_sum_states(G, x)
+        else:
+            view = self._agg_view()
+            if train:
+                if variants.hip_backward_supported(view, G):
+                    flat_params = [p for d in self.dirs for i in range(L) for _, p in variants._cell_params(view, d, i)]
+                    flat = variants.VariantRecurrence.apply(view, G, plan, x, *flat_params)
+                    h = [[None] * L for _ in range(2)]
+                    for q, d in enumerate(self.dirs):
+                        for i in range(L):
+                            h[d][i] = flat[q * L + i]
+                else:
+                    variants.warn_torch_path(view, G)
+                    h = variants.run(view, G, x)
+            else:
+                h = variants.run_hip(view, G, x, plan)
+        N = x.shape[0]
+        if self.output_all:
+            G.h = torch.cat(([x] if self.out_wx else []) + [h[d][i] for d in self.dirs for i in range(L)], dim=-1)
+            if self.bidirectional:
+                G.h = self.hg_unify(G.h)
+            elif L > 1:
+                G.h = self.out_linear(G.h)
+            idx = G.batch.view(-1, 1).expand_as(G.h)
+            out = G.h.new_zeros(B, G.h.shape[1])
+            if self.out_pool == K.P_MAX:
+                return out.scatter_reduce(0, idx, G.h, "amax", include_self=False)
+            out = out.scatter_add(0, idx, G.h)
+            return out / nn_ if self.out_pool == K.P_MEAN else out
+        first = torch.arange(0, N, nn_, device=x.device)
+        last = first + (nn_ - 1)
+        parts = [h[0][i][last] for i in range(L)]
+        if self.bidirectional:
+            parts += [h[1][i][first] for i in range(L)]
+        G.h = torch.cat(parts, dim=-1)
+        G.batch = G.batch[first] if self.bidirectional else G.batch[last]
+        if self.bidirectional:
+            return self.hg_unify(G.h)
+        return self.out_linear(G.h) if L > 1 else G.h
 
     def encode(self, G):
         """(mu, logvar) of a list of graphs (`dvae/dagnn.py:177-184`)."""

@@ -105,7 +105,9 @@ def run(mod, G, x: torch.Tensor) -> List[List[Optional[torch.Tensor]]]:
     ei = G.edge_index
     edge_attr = G.edge_attr if getattr(G, "edge_attr", None) is not None else None
     h: List[List[Optional[torch.Tensor]]] = [[None] * L for _ in range(2)]
-    shared_flow = mod.agg in ("add", "max")   # one AggConv for both directions: flow is always source -> target
+    # one AggConv for both directions (ogbg-code/model/dagnn.py:74-75): flow is always source -> target.  The D-VAE models
+    # build one per direction (dvae/dagnn.py:66-70: `reverse=True` for the second), so there the messages land on the frontier
+    shared_flow = mod.agg in ("add", "max") and getattr(mod, "shared_agg_flow", True)
     for d in mod.dirs:
         aggr = getattr(mod, "node_aggr_%d" % d)
         cells = getattr(mod, "cells_%d" % d)
@@ -232,7 +234,7 @@ def run_hip(mod, G, x: torch.Tensor, plan) -> List[List[Optional[torch.Tensor]]]
     sched = plan.read_schedule()
     stream = engine._stream(x)
     mode = _MODES.get(mod.agg, _lib.AGG_MATTN if "mattn" in mod.agg else _lib.AGG_ATTN)
-    shared_flow = mod.agg in ("add", "max")
+    shared_flow = mod.agg in ("add", "max") and getattr(mod, "shared_agg_flow", True)
     keep = []   # tensors the launches read: alive until the call returns (stream-ordered afterwards)
     h: List[List[Optional[torch.Tensor]]] = [[None] * L for _ in range(2)]
     args = _lib.VariantArgs()
@@ -556,7 +558,7 @@ class VariantRecurrence(torch.autograd.Function):
         sched = plan.read_schedule()
         stream = engine._stream(x)
         prm = _derive(mod)
-        shared_flow = mod.agg in ("add", "max")
+        shared_flow = mod.agg in ("add", "max") and getattr(mod, "shared_agg_flow", True)
         recurr, agg_x = bool(mod.recurr), bool(mod.agg_x)
         names, cellp, k = [], {}, 0
         for d in mod.dirs:

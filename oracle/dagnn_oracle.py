@@ -380,6 +380,43 @@ def code2_grads(sd: Dict[str, Tensor], G, y: Tensor, *, dtype: torch.dtype = tor
     return loss.detach(), {k: (torch.zeros_like(leaves[k]) if g is None else g) for k, g in zip(names, gs)}
 
 
+def recurrence_dvae_plain(sd: Dict[str, Tensor], x: Tensor, edge_index: Tensor, layers: Sequence[Tensor], dirs, L: int,
+                          H: int, agg: str, vid_nodes: int) -> List[List[Tensor]]:
+    """The loop nest of `dvae/dagnn.py:106-145` (`dvae/dagnn_bn.py:104-137`) for agg in {gated_sum, add, max}, op for op:
+    `GatedSumConv` (`dagnn.py:269-299`) on hs = [state ; one-hot vertex id] with the base class's mapper / gate of the
+    direction (`:60-65`), `AggConv` (`:242-267`) on the plain states - one conv per direction (`reverse=True` for the
+    second: messages flow to the frontier in both); rows nothing lands on are zero (PyG-1.6 propagate)."""
+    N = x.shape[0]
+    ids = torch.arange(N)
+    h = [[x.new_zeros(N, H) for _ in range(L)] for _ in range(2)]
+    T = int(layers[0].max()) + 1
+    for d in dirs:
+        tgt_row, src_row = (1, 0) if d == 0 else (0, 1)
+        name = "forward" if d == 0 else "backward"
+        for t in range(T):
+            layer = ids[layers[d] == t]
+            inp = x[layer]
+            if t > 0:
+                le = torch.cat([(edge_index[1 - d] == n).nonzero().squeeze(-1) for n in layer], dim=-1)
+                lp = edge_index[:, le]
+            for i in range(L):
+                ps = None
+                if t > 0:
+                    hv = h[d][i]
+                    if agg == "gated_sum":
+                        hs = torch.cat([hv, _vids(N, vid_nodes, x)], -1) if vid_nodes else hv
+                        hj = hs[lp[src_row]]
+                        gate = torch.sigmoid(hj @ sd["gate_%s.%d.0.weight" % (name, i)].t() + sd["gate_%s.%d.0.bias" % (name, i)])
+                        msg = gate * (hj @ sd["mapper_%s.%d.0.weight" % (name, i)].t())
+                        ps = _propagate(msg, lp[tgt_row], N, "add")[layer]
+                    else:
+                        ps = _propagate(hv[lp[src_row]], lp[tgt_row], N, agg)[layer]
+                p = "cells_%d.%d." % (d, i)
+                inp = gru_cell(inp, ps, sd[p + "weight_ih"], sd[p + "weight_hh"], sd[p + "bias_ih"], sd[p + "bias_hh"])
+                h[d][i] = h[d][i].index_add(0, layer, inp)
+    return [h[d] for d in dirs]
+
+
 def dvae_forward(sd: Dict[str, Tensor], G, *, num_layers: int = 2, bidirectional: bool = False,
                  num_nodes: int = 8, vids: bool = True, mode: str = "csr",
                  dtype: torch.dtype = torch.float32, keep_graph: bool = False, out_pool_all: bool = False,
@@ -393,11 +430,14 @@ def dvae_forward(sd: Dict[str, Tensor], G, *, num_layers: int = 2, bidirectional
     H = sd["cells_0.0.weight_hh"].shape[1]
     x = G.x.to(dtype)
     layers = [G.bi_layer_index[0][0], G.bi_layer_index[1][0]]
-    if agg not in ("attn_h", "self_attn_h"):
+    if agg in ("gated_sum", "add", "max"):
+        h = recurrence_dvae_plain(sd, x, G.edge_index, layers, dirs, num_layers, H, agg, num_nodes if vids else 0)
+    elif agg not in ("attn_h", "self_attn_h"):
         raise NotImplementedError(agg)
-    cfg = _Cfg(sd, dirs, num_layers, H, "cells_", False, num_nodes if vids else 0, agg)
-    rec = recurrence_faithful if mode == "faithful" else recurrence_csr
-    h = rec(cfg, x, G.edge_index, None, layers)
+    else:
+        cfg = _Cfg(sd, dirs, num_layers, H, "cells_", False, num_nodes if vids else 0, agg)
+        rec = recurrence_faithful if mode == "faithful" else recurrence_csr
+        h = rec(cfg, x, G.edge_index, None, layers)
     N = x.shape[0]
     if out_pool_all:   # dvae/dagnn.py:163-172: per-node projection, then pooling over all nodes of a graph
         G.h = torch.cat([h[q][l] for q in range(len(dirs)) for l in range(num_layers)], -1)

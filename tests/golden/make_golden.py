@@ -393,6 +393,26 @@ def _dvae_self_attn():
                  agg="self_attn_h")
 
 
+def _dvae_aggs():
+    """The D-VAE encoders with the non-attention aggregators (`dvae/dagnn.py:60-70`, `dvae/dagnn_bn.py` same block):
+    `gated_sum` (mapper / gate of the base class on [state ; vertex id] for NA, on the state for BN), `add`, `max`."""
+    ref_util = importlib.import_module("util")
+    ref_batch_mod = importlib.import_module("batch")
+    ref_na = importlib.import_module("dagnn")
+    ref_bn = importlib.import_module("dagnn_bn")
+    k = 0
+    for agg in ("gated_sum", "add", "max"):
+        make_na(ref_na, ref_util, ref_batch_mod, "na_h64_%s" % agg, hs=64, L=2, bidir=(agg != "add"), w_seed=251 + k, nrows=16, agg=agg)
+        make_na_grad(ref_na, ref_util, "grad_na_h64_%s" % agg, hs=64, L=2, bidir=(agg == "max"), w_seed=257 + k, nrows=12, agg=agg)
+        if agg != "gated_sum":   # (the reference's own DAGNN_BN cannot run gated_sum: DVAE_BN_PYG re-creates the first layer's mapper /
+            # gate with nvt inputs, models_pyg.py:539-560, and GatedSumConv feeds them hs-wide states - a shape error at the first layer)
+            make_bn(ref_bn, ref_util, ref_batch_mod, "bn_h64_%s" % agg, hs=64, L=2, bidir=True, w_seed=254 + k, data_seed=13 + k,
+                    nrows=12, agg=agg)
+            make_bn_grad(ref_bn, ref_util, "grad_bn_h64_%s" % agg, hs=64, L=2, bidir=True, w_seed=260 + k, data_seed=16 + k,
+                         nrows=10, agg=agg)
+        k += 1
+
+
 def _dvae_only():
     ref_util = importlib.import_module("util")
     ref_na = importlib.import_module("dagnn")
@@ -418,6 +438,8 @@ def main():
         return
     if only == "dvae_grad":
         return _dvae_only()
+    if only == "dvae_aggs":
+        return _dvae_aggs()
     if only == "ipropagate":
         return _ipropagate_only()
     if only == "dvae_default_hs":

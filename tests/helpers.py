@@ -25,10 +25,12 @@ GRAD_VAR = ["grad_var_h64_" + t for t in ("gated_sum", "gated_nobias", "mattn_h"
                                            "recurr0_mattn", "recurr0_attn_h", "recurr0_attn_x", "recurr0_self_attn_h",
                                            "aggx_attn_h", "aggx_add", "aggx_gated", "aggx_mattn", "aggx_max_recurr0")]
 DVAE_GRAD = ["grad_na_h64_unidir", "grad_bn_h64_bidir", "grad_na_h501_unidir", "grad_bn_h501_bidir",
-             "grad_na_h64_self_attn_h", "grad_bn_h64_self_attn_h"]
+             "grad_na_h64_self_attn_h", "grad_bn_h64_self_attn_h",
+             "grad_na_h64_gated_sum", "grad_na_h64_add", "grad_na_h64_max", "grad_bn_h64_add", "grad_bn_h64_max"]
 DVAE = ["na_h128_unidir", "na_h64_bidir", "bn_h256_bidir", "bn_h64_unidir", "na_h64_poolall_max", "bn_h64_poolall_mean",
         "na_h501_unidir", "bn_h501_bidir",   # the reference's default width (dvae/train.py:55)
-        "na_h64_self_attn_h", "bn_h128_self_attn_h"]   # agg='self_attn_h' (dvae/dagnn.py:49-54)
+        "na_h64_self_attn_h", "bn_h128_self_attn_h",   # agg='self_attn_h' (dvae/dagnn.py:49-54)
+        "na_h64_gated_sum", "na_h64_add", "na_h64_max", "bn_h64_add", "bn_h64_max"]   # dvae/dagnn.py:60-70
 
 
 def load(name):

@@ -630,7 +630,7 @@ def main():
             if ms_fwd > 0:
                 tf = flops / (ms_fwd * 1e-3) / 1e12
                 traffic, traffic_source = None, None
-                tname = "r03_pmc_traffic.json" if df else "pmc_traffic.json"
+                tname = "r04_pmc_traffic.json" if df else "pmc_traffic.json"
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if lock and os.path.exists(tpath):  # separate rocprofv3 --pmc passes of this command, see profiles/README.md
                     rec = json.load(open(tpath))

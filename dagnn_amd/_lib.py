@@ -129,6 +129,20 @@ class BwdDataflowArgs(C.Structure):
                 ("err", C.c_void_p), ("plan_status", C.c_void_p), ("num_cus", C.c_int), ("xcc_table", C.c_void_p), ("xcd_first", C.c_int)]
 
 
+class GatherJob0(C.Structure):   # (dagnn_gather_job inside dagnn_encode_args; `GatherJob` below has the same layout)
+    _fields_ = [("h", C.c_void_p), ("ld_h", C.c_int), ("width", C.c_int), ("node_off", C.c_int), ("col_off", C.c_int)]
+
+
+class EncodeArgs(C.Structure):
+    _fields_ = [("plan", Plan), ("edge_index", C.c_void_p), ("layer_fwd", C.c_void_p), ("layer_bwd", C.c_void_p),
+                ("batch", C.c_void_p), ("edge_attr", C.c_void_p), ("plan_status", C.c_void_p),
+                ("gemm", GemmGroup * 2), ("num_gemm", C.c_int), ("gemm_cols", C.c_int), ("in_dim", C.c_int), ("ld_x", C.c_int),
+                ("schedule", C.c_void_p), ("schedule_bytes", C.c_size_t), ("cost_layer", C.c_int), ("cost_row", C.c_int),
+                ("df", DataflowArgs), ("jobs", GatherJob0 * 16), ("num_jobs", C.c_int), ("stride", C.c_int),
+                ("hcat", C.c_void_p), ("ld_hcat", C.c_int), ("w_out", C.c_void_p), ("b_out", C.c_void_p), ("out", C.c_void_p),
+                ("out_dim", C.c_int)]
+
+
 AGG_ATTN, AGG_MATTN, AGG_GATED, AGG_ADD, AGG_MAX, AGG_GIVEN = range(6)
 POOL_MAX, POOL_ADD, POOL_MEAN = range(3)
 
@@ -246,6 +260,7 @@ SYMBOLS = {
                                              C.POINTER(C.c_int32), C.c_void_p]),
     "dagnn_iprop_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int, C.POINTER(IpropLayer), C.c_int, C.c_void_p, C.c_void_p]),
+    "dagnn_encode_forward": (C.c_int, [C.POINTER(EncodeArgs), C.c_void_p]),
     "dagnn_debug_occupy": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "dagnn_gather_rows_batch": (C.c_int, [C.POINTER(GatherJob), C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_gather_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,

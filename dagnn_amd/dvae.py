@@ -22,6 +22,7 @@ from . import engine
 from .core import DerivedCache, default_schedule, derive_cell, pack_lockstep, run_stack
 from .data import GraphBatch
 
+ENCODE_FUSED = int(__import__("os").environ.get("DAGNN_AMD_ENCODE_FUSED", "1"))   # 1: evaluation passes of the encoders as ONE library call (csrc/encode.hip)
 OWN_LINEAR_MAX = 1 << 22   # multiply-adds up to which the final Linear of an evaluation pass runs on dagnn_gemm_nt_bias (see forward)
 from .model import _EdgeAttnParams, _SelfAttnParams
 
@@ -358,6 +359,11 @@ class _DvaeDagnn(_DvaeBase):
             raise ValueError("every graph must have exactly num_nodes=%d nodes (dvae/dagnn.py:150-158)" % nn_)
         B = N // nn_
         bl = G.bi_layer_index
+        if not train and not self._agg_plain and not self.output_all and ENCODE_FUSED and self.schedule == "lockstep" \
+                and engine.TIMER is None:
+            out = self._encode_fused(G, x, B)
+            if out is not None:
+                return out
         plan = engine.build_plan(G.edge_index, bl[0][0], bl[1][0], G.batch, B, None)
         if self._agg_plain:
             return self._forward_plain_agg(G, plan, x, B, train)
@@ -502,6 +508,79 @@ class _DvaeDagnn(_DvaeBase):
         if self.bidirectional:
             return self.hg_unify(G.h)
         return self.out_linear(G.h) if L > 1 else G.h
+
+    def _encode_fused(self, G, x, B):
+        """The evaluation pass up to (and including, when it is small) the final Linear as ONE call into the library
+        (`dagnn_encode_forward`, csrc/encode.hip): the same launches as the step-by-step path below, without the Python
+        between them - these batches (64 x 8 / 128 x 10 nodes) are host-bound.  None: the shape is not one the dataflow
+        kernel serves (the caller takes the general path)."""
+        import ctypes as C
+        from . import _lib
+        from .core import pack_dataflow
+        L, H, nn_, dirs = self.num_layers, self.hidden_dim, self.num_nodes, self.dirs
+        cells = self._cells()
+        Hp = cells[(dirs[0], 0)].Hp
+        N, dev = x.shape[0], x.device
+        if N == 0 or not engine.dataflow_width(Hp) or Hp > 256 or N * 3 * Hp >= (1 << 31):
+            return None
+        groups = engine.dataflow_groups(dev, len(dirs), L, Hp, B)
+        if groups <= 0:
+            return None
+        lib = _lib.load()
+        arena = self._arena_for(x)
+        arena.poll()   # a failure an earlier pass reported (no synchronisation)
+        pack_dataflow(cells.values())
+        ei = engine._dev(G.edge_index, "edge_index", torch.int64)
+        bl = G.bi_layer_index
+        lf, lb = engine._dev(bl[0][0], "layer ids", torch.int64), engine._dev(bl[1][0], "layer ids", torch.int64)
+        batch = engine._dev(G.batch, "batch", torch.int64)
+        plan = engine.PlanHandle(N, ei.shape[1], B, 0, dev)
+        a = _lib.EncodeArgs()
+        a.plan = plan.desc
+        a.edge_index, a.layer_fwd, a.layer_bwd, a.batch = ei.data_ptr(), lf.data_ptr(), lb.data_ptr(), batch.data_ptr()
+        a.plan_status = plan.status.data_ptr()
+        f32 = dict(dtype=torch.float32, device=dev)
+        gi = [None, None]
+        for q, d in enumerate(dirs):
+            c = cells[(d, 0)]
+            gi[d] = torch.empty(N, 3 * Hp, **f32)
+            a.gemm[q] = _lib.GemmGroup(x.data_ptr(), c.w_ih.data_ptr(), c.b_ih.data_ptr(), gi[d].data_ptr())
+        a.num_gemm, a.gemm_cols, a.in_dim, a.ld_x = len(dirs), 3 * Hp, x.shape[1], x.stride(0)
+        sbytes = lib.dagnn_dataflow_bytes(N, B, groups)
+        sched = torch.empty((sbytes + 3) // 4, dtype=torch.int32, device=dev)
+        plan.__dict__["_df"] = {(int(groups), engine.DF_COST_LAYER, engine.DF_COST_ROW): sched}   # (built inside the call)
+        a.schedule, a.schedule_bytes = sched.data_ptr(), sbytes
+        a.cost_layer, a.cost_row = engine.DF_COST_LAYER, engine.DF_COST_ROW
+        ld = engine.frontier_ld(Hp)
+        h = [[torch.empty(N, ld, **f32) if d in dirs else None for _ in range(L)] for d in range(2)]
+        engine.dataflow_args(plan, dirs, L, Hp, cells, gi, h, groups, vid_mod=self._vid_nodes, arena=arena, args=a.df)
+        hcat = torch.empty(B, len(dirs) * L * H, **f32)
+        jobs = [(h[0][i], nn_ - 1, i * H) for i in range(L)]
+        if self.bidirectional:
+            jobs += [(h[1][i], 0, (L + i) * H) for i in range(L)]
+        if len(jobs) > 16:
+            return None
+        for k, (t, off, col) in enumerate(jobs):
+            a.jobs[k] = _lib.GatherJob0(t.data_ptr(), t.stride(0), H, int(off), int(col))
+        a.num_jobs, a.stride, a.hcat, a.ld_hcat = len(jobs), nn_, hcat.data_ptr(), hcat.shape[1]
+        lin = self.hg_unify if self.bidirectional else (self.out_linear if L > 1 else None)
+        if isinstance(lin, nn.Sequential) and len(lin) == 1:
+            lin = lin[0]
+        out = None
+        fused_lin = isinstance(lin, nn.Linear) and hcat.shape[0] * lin.weight.numel() <= OWN_LINEAR_MAX and \
+            lin.weight.shape[1] == hcat.shape[1] and hcat.shape[1] % 4 == 0
+        if fused_lin:
+            w = lin.weight.detach()
+            out = torch.empty(B, w.shape[0], **f32)
+            a.w_out, a.b_out = w.data_ptr(), (None if lin.bias is None else lin.bias.detach().data_ptr())
+            a.out, a.out_dim = out.data_ptr(), w.shape[0]
+        engine.check(lib.dagnn_encode_forward(C.byref(a), engine._stream(x)), "dagnn_encode_forward")
+        arena.watch(None, folded=True)
+        G.h = hcat
+        G.batch = G.batch[0::nn_] if self.bidirectional else G.batch[nn_ - 1::nn_]
+        if lin is None:
+            return hcat
+        return out if fused_lin else lin(hcat)
 
     def encode(self, G):
         """(mu, logvar) of a list of graphs (`dvae/dagnn.py:177-184`)."""

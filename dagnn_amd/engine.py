@@ -430,7 +430,24 @@ def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     if arena is None:
         raise DagnnHipError("the dataflow kernel needs a GranuleArena (persistent, zero-initialised granule buffers)")
     lib = _lib.load()
-    args = DataflowArgs()
+    args = dataflow_args(plan, dirs, L, H, cells, gi0, h, groups, vid_mod, arena, static_score, preact, training)
+    with _span("dataflow_run", plan.ws):
+        check(lib.dagnn_dataflow_run(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_dataflow_run")
+    if score_parts and static_score is None:
+        for d in dirs:
+            for i in range(L):
+                check(lib.dagnn_score_parts(h[d][i].data_ptr(), h[d][i].shape[1], H, cells[(d, i)].w_key.data_ptr(),
+                                            plan.N, _stream(plan.ws)), "dagnn_score_parts")
+    arena.watch(plan, folded=True)
+
+
+def dataflow_args(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0, h, groups: int, vid_mod: int = 0,
+                  arena: Optional["GranuleArena"] = None, static_score=None, preact: Optional[dict] = None,
+                  training: bool = False, args=None):
+    """The argument struct of `dagnn_dataflow_run` for this pass (a fresh epoch of `arena`'s granule buffers, the plan's
+    schedule for `groups`); `args`: fill this struct instead of a new one (the `df` member of `EncodeArgs`)."""
+    if args is None:
+        args = DataflowArgs()
     gld = H + H // 16
     keys = [(d, i) for d in dirs for i in range(L)] + [("p", d, i) for d in dirs for i in range(1, L)]
     gran, epoch, err = arena.get(keys, plan.N, gld, plan.ws.device, widths={k: 3 * H for k in keys if k[0] == "p"})
@@ -471,14 +488,7 @@ def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
         args.xcc_table = arena.xcc_table(plan.ws.device).data_ptr()
         args.xcd_first = arena.xcd_first
     args.plan_status = plan.status.data_ptr()
-    with _span("dataflow_run", plan.ws):
-        check(lib.dagnn_dataflow_run(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_dataflow_run")
-    if score_parts and static_score is None:
-        for d in dirs:
-            for i in range(L):
-                check(lib.dagnn_score_parts(h[d][i].data_ptr(), h[d][i].shape[1], H, cells[(d, i)].w_key.data_ptr(),
-                                            plan.N, _stream(plan.ws)), "dagnn_score_parts")
-    arena.watch(plan, folded=True)
+    return args
 
 
 DF_WIDE = _env_int("DAGNN_AMD_DF_WIDE", 1)   # 1: hidden sizes 257..320 run 320 wide on the dataflow kernel's 8-wave shape (csrc/dataflow_w.hip)

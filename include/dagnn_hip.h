@@ -760,6 +760,30 @@ int dagnn_topo_layers(const int64_t* edge_index /* [2,E] */, const int64_t* batc
                       int64_t B, int64_t* layer_fwd, int64_t* layer_bwd, int32_t* status /* device int32 or NULL */,
                       void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * A whole encoder pass from ONE call (the evaluation pass of the D-VAE encoders, dvae/dagnn.py:99-161,
+ * dvae/dagnn_bn.py:98-152: batches of 64 x 8 / 128 x 10 nodes are host-bound - the device needs ~95 us for what one call
+ * at a time took the host 115-135 us to issue).  Issues, in this order, exactly the launches of dagnn_plan_build,
+ * dagnn_gemm_nt_bias (stacked layer 0's input side, one group per direction: C = x W_ih^T + b_ih), dagnn_dataflow_schedule,
+ * dagnn_dataflow_run (`df`: the cells' gi0 must point at the GEMM groups' outputs), dagnn_gather_rows_batch (the end /
+ * start vertex of every graph into `hcat`) and - `w_out` given - the model's final Linear (out = hcat W_out^T + b_out).
+ * Every buffer is the caller's; nothing is allocated or synchronised.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dagnn_encode_args {
+    dagnn_plan plan;
+    const int64_t* edge_index; const int64_t* layer_fwd; const int64_t* layer_bwd; const int64_t* batch;
+    const float* edge_attr;          /* or NULL */
+    int32_t* plan_status;            /* device int32[4] */
+    dagnn_gemm_group gemm[2];        /* per direction: {x, W_ih [gemm_cols, in_dim], b_ih, gi0 [N, gemm_cols]} */
+    int num_gemm, gemm_cols, in_dim, ld_x;
+    void* schedule; size_t schedule_bytes; int cost_layer, cost_row;
+    dagnn_dataflow_args df;
+    dagnn_gather_job jobs[16]; int num_jobs, stride;
+    float* hcat; int ld_hcat;        /* [B, ld_hcat] */
+    const float* w_out; const float* b_out; float* out; int out_dim;   /* w_out [out_dim, ld_hcat] or NULL */
+} dagnn_encode_args;
+int dagnn_encode_forward(const dagnn_encode_args* args /* host */, void* stream);
+
 /* Test utility for the co-residency rule of the persistent kernels (engine.reserved_cus): occupies `num_wgs` workgroups of
  * `threads` threads for `ticks` of the 100 MHz constant clock (bounded: at most 2^31 ticks) on `stream` - a stand-in for the
  * kernels of a collective that runs next to a training pass.  Touches no memory besides `sink` (one float, may be NULL). */

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-end artefacts: kernel stats of the forward and of the training leg, ISA metadata, the default bench line
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${1:-r03}
+R=${1:-r04}
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_fwd -o tr -- python bench.py --steps 5 --warmup 2 --cpu-passes 0 --train-steps 0 --other-configs 0 > gpurun_out/${R}_fwd.log 2>&1
 cp $(find gpurun_out/${R}_fwd -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_train -o tr -- python bench.py --steps 2 --warmup 1 --cpu-passes 0 --train-steps 5 --other-configs 0 > gpurun_out/${R}_train.log 2>&1

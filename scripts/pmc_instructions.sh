@@ -1,7 +1,7 @@
 #!/bin/bash
 # instruction / wave-cycle counters of the dominant kernel: separate rocprofv3 --pmc passes (<= 4 counters each, no trace
 # domains next to them), averaged per launch of dataflow_kernel<16> -> profiles/<name>.json
-name=${1:-r03_pmc_instructions}
+name=${1:-r04_pmc_instructions}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 CMD="python bench.py --steps 2 --warmup 1 --cpu-passes 0 --no-kernel-timer --train-steps 0 --other-configs 0"
 i=0

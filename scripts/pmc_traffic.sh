@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the forward pass from the PMC counters: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; no
 # trace domains next to them), folded by scripts/pmc_summary.py into profiles/<name>.json
-name=${1:-r03_pmc_traffic}
+name=${1:-r04_pmc_traffic}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 CMD="python bench.py --steps 2 --warmup 1 --cpu-passes 0 --no-kernel-timer --train-steps 0 --other-configs 0"
 rm -rf gpurun_out/${name}_fetch gpurun_out/${name}_write

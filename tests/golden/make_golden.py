@@ -540,6 +540,7 @@ def main():
     _ipropagate_only()   # decoder-side single-vertex step (needs the igraph stand-in)
     _dvae_default_hs()
     _dvae_self_attn()
+    _dvae_aggs()
 
 
 if __name__ == "__main__":

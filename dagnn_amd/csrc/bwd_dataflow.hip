@@ -317,12 +317,12 @@ struct BdSweep {
     "global_load_dword %[t7], %[vt], %[sc] offset:1792\n\t"           \
     BD_STAT_1
 #define BD_ROW_OUTS                                                                                                         \
-                   [x00] "=&v"(W.x[0][0]), [x01] "=&v"(W.x[0][1]), [x02] "=&v"(W.x[0][2]), [x03] "=&v"(W.x[0][3]),              \
-                   [x10] "=&v"(W.x[1][0]), [x11] "=&v"(W.x[1][1]), [x12] "=&v"(W.x[1][2]), [x13] "=&v"(W.x[1][3]),              \
-                   [x20] "=&v"(W.x[2][0]), [x21] "=&v"(W.x[2][1]), [x22] "=&v"(W.x[2][2]), [x23] "=&v"(W.x[2][3]),              \
-                   [x30] "=&v"(W.x[3][0]), [x31] "=&v"(W.x[3][1]), [x32] "=&v"(W.x[3][2]), [x33] "=&v"(W.x[3][3]),              \
-                   [q0] "=&v"(W.q[0]), [q1] "=&v"(W.q[1]), [q2] "=&v"(W.q[2]), [q3] "=&v"(W.q[3]),                              \
-                   [u0] "=&v"(W.u[0]), [u1] "=&v"(W.u[1]), [u2] "=&v"(W.u[2]), [u3] "=&v"(W.u[3])
+                   [x00] "=v"(W.x[0][0]), [x01] "=v"(W.x[0][1]), [x02] "=v"(W.x[0][2]), [x03] "=v"(W.x[0][3]),              \
+                   [x10] "=v"(W.x[1][0]), [x11] "=v"(W.x[1][1]), [x12] "=v"(W.x[1][2]), [x13] "=v"(W.x[1][3]),              \
+                   [x20] "=v"(W.x[2][0]), [x21] "=v"(W.x[2][1]), [x22] "=v"(W.x[2][2]), [x23] "=v"(W.x[2][3]),              \
+                   [x30] "=v"(W.x[3][0]), [x31] "=v"(W.x[3][1]), [x32] "=v"(W.x[3][2]), [x33] "=v"(W.x[3][3]),              \
+                   [q0] "=v"(W.q[0]), [q1] "=v"(W.q[1]), [q2] "=v"(W.q[2]), [q3] "=v"(W.q[3]),                              \
+                   [u0] "=v"(W.u[0]), [u1] "=v"(W.u[1]), [u2] "=v"(W.u[2]), [u3] "=v"(W.u[3])
 #define BD_ROW_INS                                                                                                          \
                    [vo] "v"(lane8), [vz] "v"(vzero), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),                \
                    [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [c3] "s"(c3p), [ub] "s"(ub),                                \
@@ -330,25 +330,25 @@ struct BdSweep {
 #define BD_TRIP_FIRST(n_, du_)                                                                                              \
     asm volatile(BD_ROWS_##n_ BD_DU_##du_ BD_STAT_1                                                                         \
                  : BD_ROW_OUTS,                                                                                             \
-                   [s0] "=&v"(ST[0]), [s1] "=&v"(ST[1]), [s2] "=&v"(ST[2]), [s3] "=&v"(ST[3]),                                  \
-                   [s4] "=&v"(ST[4]), [s5] "=&v"(ST[5]), [s6] "=&v"(ST[6]), [s7] "=&v"(ST[7]),                                  \
-                   [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)                                                               \
-                 : BD_ROW_INS, [vs] "v"(lane16), [sa] "s"(sa), [sb] "s"(sb), [ra] "v"(ra), [rl] "s"(rl),                    \
-                   [pa] "v"(pa), [pl] "s"(pl)                                                                               \
+                   [s0] "=v"(ST[0]), [s1] "=v"(ST[1]), [s2] "=v"(ST[2]), [s3] "=v"(ST[3]),                                  \
+                   [s4] "=v"(ST[4]), [s5] "=v"(ST[5]), [s6] "=v"(ST[6]), [s7] "=v"(ST[7]),                                  \
+                   [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra), [pa] "+v"(pa)                                                               \
+                 : BD_ROW_INS, [vs] "v"(lane16), [sa] "s"(sa), [sb] "s"(sb), [rl] "s"(rl),                    \
+                   [pl] "s"(pl)                                                                               \
                  : "memory")
 #define BD_TRIP_POLL(n_, du_)                                                                                               \
     asm volatile(BD_ROWS_##n_ BD_DU_##du_ "s_waitcnt vmcnt(0)" : BD_ROW_OUTS : BD_ROW_INS : "memory")
-#define BD_ROW_OUTS5 BD_ROW_OUTS, [x04] "=&v"(W.x[0][4]), [x14] "=&v"(W.x[1][4]), [x24] "=&v"(W.x[2][4]), [x34] "=&v"(W.x[3][4]), [u4] "=&v"(W.u[4])
+#define BD_ROW_OUTS5 BD_ROW_OUTS, [x04] "=v"(W.x[0][4]), [x14] "=v"(W.x[1][4]), [x24] "=v"(W.x[2][4]), [x34] "=v"(W.x[3][4]), [u4] "=v"(W.u[4])
 #define BD_TRIP_FIRST5(n_, du_)                                                                                             \
     asm volatile(BD_ROWS5_##n_ BD_DU5_##du_ BD_STAT5_1                                                                      \
                  : BD_ROW_OUTS5,                                                                                            \
-                   [s0] "=&v"(ST[0]), [s1] "=&v"(ST[1]), [s2] "=&v"(ST[2]), [s3] "=&v"(ST[3]),                                  \
-                   [s4] "=&v"(ST[4]), [s5] "=&v"(ST[5]), [s6] "=&v"(ST[6]), [s7] "=&v"(ST[7]),                                  \
-                   [t0] "=&v"(ST5[0]), [t1] "=&v"(ST5[1]), [t2] "=&v"(ST5[2]), [t3] "=&v"(ST5[3]),                              \
-                   [t4] "=&v"(ST5[4]), [t5] "=&v"(ST5[5]), [t6] "=&v"(ST5[6]), [t7] "=&v"(ST5[7]),                              \
-                   [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)                                                               \
-                 : BD_ROW_INS, [vs] "v"(lane16), [sa] "s"(sa), [sb] "s"(sb), [ra] "v"(ra), [rl] "s"(rl),                    \
-                   [pa] "v"(pa), [pl] "s"(pl), [vt] "v"(lane4), [sc] "s"(sc)                                                \
+                   [s0] "=v"(ST[0]), [s1] "=v"(ST[1]), [s2] "=v"(ST[2]), [s3] "=v"(ST[3]),                                  \
+                   [s4] "=v"(ST[4]), [s5] "=v"(ST[5]), [s6] "=v"(ST[6]), [s7] "=v"(ST[7]),                                  \
+                   [t0] "=v"(ST5[0]), [t1] "=v"(ST5[1]), [t2] "=v"(ST5[2]), [t3] "=v"(ST5[3]),                              \
+                   [t4] "=v"(ST5[4]), [t5] "=v"(ST5[5]), [t6] "=v"(ST5[6]), [t7] "=v"(ST5[7]),                              \
+                   [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra), [pa] "+v"(pa)                                                               \
+                 : BD_ROW_INS, [vs] "v"(lane16), [sa] "s"(sa), [sb] "s"(sb), [rl] "s"(rl),                    \
+                   [pl] "s"(pl), [vt] "v"(lane4), [sc] "s"(sc)                                                \
                  : "memory")
 #define BD_TRIP_POLL5(n_, du_)                                                                                              \
     asm volatile(BD_ROWS5_##n_ BD_DU5_##du_ "s_waitcnt vmcnt(0)" : BD_ROW_OUTS5 : BD_ROW_INS : "memory")
@@ -593,6 +593,13 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
             }
             if (mine) sbase[Slot::zg_off + lw * DF_JS + (lane & 31)] = pick(zg);
             v_s[lw] = v;   // (every lane: same word, same value)
+            // what the outputs behind the flag need, reduced to scalars now (the row arrays die here)
+            const float mr = pick(dr), mz = pick(dz), mn = pick(dnn), mnr = pick(dnr);
+            float qd = G[0] * ST[ST_CQ].x;
+            if (NQ4 > 1) qd = fmaf(G[1], ST[ST_CQ].y, qd);
+            if (NQ4 > 2) qd = fmaf(G[2], ST[ST_CQ].z, qd);
+            if (NQ4 > 3) qd = fmaf(G[3], ST[ST_CQ].w, qd);
+            if (NQ4 > 4) qd = fmaf(G[4], ST5[ST_CQ], qd);
             // the compute waves need nothing but the LDS slot: the last row of the wave raises the flag BEFORE the row's
             // outputs to memory (q for the predecessors' pulls first, then the dgi granules, then the plain rows the weight-
             // gradient epilogue reads)
@@ -601,11 +608,6 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                 bd_flag_st(lds.rdy + set * BD_WPS + w, b + 1);
             }
             if (sl == 0) {   // q_v = G_v . c_q,v; the row's scalar outputs
-                float qd = G[0] * ST[ST_CQ].x;
-                if (NQ4 > 1) qd = fmaf(G[1], ST[ST_CQ].y, qd);
-                if (NQ4 > 2) qd = fmaf(G[2], ST[ST_CQ].z, qd);
-                if (NQ4 > 3) qd = fmaf(G[3], ST[ST_CQ].w, qd);
-                if (NQ4 > 4) qd = fmaf(G[4], ST5[ST_CQ], qd);
                 qd = bd_wave_sum(qd);
                 if (lane == 0) {
                     if (local_st) q_out[v] = gran_pack(epoch, qd);
@@ -617,7 +619,6 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
             }
             if (mine) {
                 const int c = 64 * myq + lane;   // = 32 sl + (lane & 31)
-                const float mr = pick(dr), mz = pick(dz), mn = pick(dnn), mnr = pick(dnr);
                 if (dgi_g) {
                     gran_t* pg = dgi_g + (int64_t)v * (3 * gld) + c;
                     if (local_st) {   // (readers on this XCD: the lines stay in its L2)
@@ -667,20 +668,20 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
 #define BD_G_LD5(g) BD_G_LD(g) "global_load_dwordx2 %[y" #g "4], %[vo], %[g" #g "] offset:2048 sc1\n\t"
 #define BD_GTRIP5(dm)                                                                                                        \
     asm volatile(BD_G_LD5(0) BD_G_LD5(1) BD_G_LD5(2) BD_DMA_##dm                                                             \
-                 : [y00] "=&v"(Y[0][0]), [y01] "=&v"(Y[0][1]), [y02] "=&v"(Y[0][2]), [y03] "=&v"(Y[0][3]), [y04] "=&v"(Y[0][4]),  \
-                   [y10] "=&v"(Y[1][0]), [y11] "=&v"(Y[1][1]), [y12] "=&v"(Y[1][2]), [y13] "=&v"(Y[1][3]), [y14] "=&v"(Y[1][4]),  \
-                   [y20] "=&v"(Y[2][0]), [y21] "=&v"(Y[2][1]), [y22] "=&v"(Y[2][2]), [y23] "=&v"(Y[2][3]), [y24] "=&v"(Y[2][4]),  \
-                   [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)                                                                \
-                 : [vo] "v"(lane8), [g0] "s"(g0), [g1] "s"(g1), [g2] "s"(g2), [ra] "v"(ra), [rl] "s"(rl),                    \
+                 : [y00] "=v"(Y[0][0]), [y01] "=v"(Y[0][1]), [y02] "=v"(Y[0][2]), [y03] "=v"(Y[0][3]), [y04] "=v"(Y[0][4]),  \
+                   [y10] "=v"(Y[1][0]), [y11] "=v"(Y[1][1]), [y12] "=v"(Y[1][2]), [y13] "=v"(Y[1][3]), [y14] "=v"(Y[1][4]),  \
+                   [y20] "=v"(Y[2][0]), [y21] "=v"(Y[2][1]), [y22] "=v"(Y[2][2]), [y23] "=v"(Y[2][3]), [y24] "=v"(Y[2][4]),  \
+                   [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra)                                                                \
+                 : [vo] "v"(lane8), [g0] "s"(g0), [g1] "s"(g1), [g2] "s"(g2), [rl] "s"(rl),                    \
                    [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)                                                                  \
                  : "memory")
 #define BD_GTRIP(dm)                                                                                                         \
     asm volatile(BD_G_LD(0) BD_G_LD(1) BD_G_LD(2) BD_DMA_##dm                                                                \
-                 : [y00] "=&v"(Y[0][0]), [y01] "=&v"(Y[0][1]), [y02] "=&v"(Y[0][2]), [y03] "=&v"(Y[0][3]),                       \
-                   [y10] "=&v"(Y[1][0]), [y11] "=&v"(Y[1][1]), [y12] "=&v"(Y[1][2]), [y13] "=&v"(Y[1][3]),                       \
-                   [y20] "=&v"(Y[2][0]), [y21] "=&v"(Y[2][1]), [y22] "=&v"(Y[2][2]), [y23] "=&v"(Y[2][3]),                       \
-                   [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)                                                                \
-                 : [vo] "v"(lane8), [g0] "s"(g0), [g1] "s"(g1), [g2] "s"(g2), [ra] "v"(ra), [rl] "s"(rl),                    \
+                 : [y00] "=v"(Y[0][0]), [y01] "=v"(Y[0][1]), [y02] "=v"(Y[0][2]), [y03] "=v"(Y[0][3]),                       \
+                   [y10] "=v"(Y[1][0]), [y11] "=v"(Y[1][1]), [y12] "=v"(Y[1][2]), [y13] "=v"(Y[1][3]),                       \
+                   [y20] "=v"(Y[2][0]), [y21] "=v"(Y[2][1]), [y22] "=v"(Y[2][2]), [y23] "=v"(Y[2][3]),                       \
+                   [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra)                                                                \
+                 : [vo] "v"(lane8), [g0] "s"(g0), [g1] "s"(g1), [g2] "s"(g2), [rl] "s"(rl),                    \
                    [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)                                                                  \
                  : "memory")
 

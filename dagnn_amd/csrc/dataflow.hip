@@ -453,13 +453,13 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
     "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]\n\ts_waitcnt vmcnt(2)"
 #define DF_TRIP(n, p, d)                                                                                                   \
     asm volatile(DF_ROWS_##n DF_PROJ_##p DF_DMA_##d                                                                        \
-                 : [x00] "=&v"(W.x[0][0]), [x01] "=&v"(W.x[0][1]), [x02] "=&v"(W.x[0][2]), [x03] "=&v"(W.x[0][3]),             \
-                   [x10] "=&v"(W.x[1][0]), [x11] "=&v"(W.x[1][1]), [x12] "=&v"(W.x[1][2]), [x13] "=&v"(W.x[1][3]),             \
-                   [x20] "=&v"(W.x[2][0]), [x21] "=&v"(W.x[2][1]), [x22] "=&v"(W.x[2][2]), [x23] "=&v"(W.x[2][3]),             \
-                   [x30] "=&v"(W.x[3][0]), [x31] "=&v"(W.x[3][1]), [x32] "=&v"(W.x[3][2]), [x33] "=&v"(W.x[3][3]),             \
-                   [p0] "=&v"(W.xp[0]), [p1] "=&v"(W.xp[1]), [p2] "=&v"(W.xp[2]), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)  \
+                 : [x00] "=v"(W.x[0][0]), [x01] "=v"(W.x[0][1]), [x02] "=v"(W.x[0][2]), [x03] "=v"(W.x[0][3]),             \
+                   [x10] "=v"(W.x[1][0]), [x11] "=v"(W.x[1][1]), [x12] "=v"(W.x[1][2]), [x13] "=v"(W.x[1][3]),             \
+                   [x20] "=v"(W.x[2][0]), [x21] "=v"(W.x[2][1]), [x22] "=v"(W.x[2][2]), [x23] "=v"(W.x[2][3]),             \
+                   [x30] "=v"(W.x[3][0]), [x31] "=v"(W.x[3][1]), [x32] "=v"(W.x[3][2]), [x33] "=v"(W.x[3][3]),             \
+                   [p0] "=v"(W.xp[0]), [p1] "=v"(W.xp[1]), [p2] "=v"(W.xp[2]), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra), [ga] "+v"(ga)  \
                  : [vo] "v"(lane8), [vp] "v"(lane31x8), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),            \
-                   [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [ra] "v"(ra), [rl] "s"(rl), [ga] "v"(ga), [gl] "s"(gl),    \
+                   [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [rl] "s"(rl), [gl] "s"(gl),    \
                    [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)                                                                \
                  : "memory")
 #define DF_CASE(n, p, d) case (n) * 6 + (p) * 3 + (d): DF_TRIP(n, p, d); break;
@@ -741,13 +741,13 @@ struct DfSweep { gran_t x[4][5]; gran_t xp[3]; };   // (the fifth column block: 
 
 #define DF_TRIP(n, p, d)                                                                                                   \
     asm volatile(DF_ROWS_##n DF_PROJ_##p DF_DMA_##d                                                                        \
-                 : [x00] "=&v"(W.x[0][0]), [x01] "=&v"(W.x[0][1]), [x02] "=&v"(W.x[0][2]), [x03] "=&v"(W.x[0][3]),             \
-                   [x10] "=&v"(W.x[1][0]), [x11] "=&v"(W.x[1][1]), [x12] "=&v"(W.x[1][2]), [x13] "=&v"(W.x[1][3]),             \
-                   [x20] "=&v"(W.x[2][0]), [x21] "=&v"(W.x[2][1]), [x22] "=&v"(W.x[2][2]), [x23] "=&v"(W.x[2][3]),             \
-                   [x30] "=&v"(W.x[3][0]), [x31] "=&v"(W.x[3][1]), [x32] "=&v"(W.x[3][2]), [x33] "=&v"(W.x[3][3]),             \
-                   [p0] "=&v"(W.xp[0]), [p1] "=&v"(W.xp[1]), [p2] "=&v"(W.xp[2]), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)  \
+                 : [x00] "=v"(W.x[0][0]), [x01] "=v"(W.x[0][1]), [x02] "=v"(W.x[0][2]), [x03] "=v"(W.x[0][3]),             \
+                   [x10] "=v"(W.x[1][0]), [x11] "=v"(W.x[1][1]), [x12] "=v"(W.x[1][2]), [x13] "=v"(W.x[1][3]),             \
+                   [x20] "=v"(W.x[2][0]), [x21] "=v"(W.x[2][1]), [x22] "=v"(W.x[2][2]), [x23] "=v"(W.x[2][3]),             \
+                   [x30] "=v"(W.x[3][0]), [x31] "=v"(W.x[3][1]), [x32] "=v"(W.x[3][2]), [x33] "=v"(W.x[3][3]),             \
+                   [p0] "=v"(W.xp[0]), [p1] "=v"(W.xp[1]), [p2] "=v"(W.xp[2]), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra), [ga] "+v"(ga)  \
                  : [vo] "v"(lane8), [vp] "v"(lane31x8), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),            \
-                   [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [ra] "v"(ra), [rl] "s"(rl), [ga] "v"(ga), [gl] "s"(gl),    \
+                   [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [rl] "s"(rl), [gl] "s"(gl),    \
                    [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)                                                                \
                  : "memory")
 // H = 320: five column blocks per lane
@@ -759,13 +759,13 @@ struct DfSweep { gran_t x[4][5]; gran_t xp[3]; };   // (the fifth column block: 
 #define DF_ROWS5_4 DF_ROWS5_3 DF_ROW_LD5(3)
 #define DF_TRIP5(n, p, d)                                                                                                  \
     asm volatile(DF_ROWS5_##n DF_PROJ_##p DF_DMA_##d                                                                       \
-                 : [x00] "=&v"(W.x[0][0]), [x01] "=&v"(W.x[0][1]), [x02] "=&v"(W.x[0][2]), [x03] "=&v"(W.x[0][3]), [x04] "=&v"(W.x[0][4]), \
-                   [x10] "=&v"(W.x[1][0]), [x11] "=&v"(W.x[1][1]), [x12] "=&v"(W.x[1][2]), [x13] "=&v"(W.x[1][3]), [x14] "=&v"(W.x[1][4]), \
-                   [x20] "=&v"(W.x[2][0]), [x21] "=&v"(W.x[2][1]), [x22] "=&v"(W.x[2][2]), [x23] "=&v"(W.x[2][3]), [x24] "=&v"(W.x[2][4]), \
-                   [x30] "=&v"(W.x[3][0]), [x31] "=&v"(W.x[3][1]), [x32] "=&v"(W.x[3][2]), [x33] "=&v"(W.x[3][3]), [x34] "=&v"(W.x[3][4]), \
-                   [p0] "=&v"(W.xp[0]), [p1] "=&v"(W.xp[1]), [p2] "=&v"(W.xp[2]), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)  \
+                 : [x00] "=v"(W.x[0][0]), [x01] "=v"(W.x[0][1]), [x02] "=v"(W.x[0][2]), [x03] "=v"(W.x[0][3]), [x04] "=v"(W.x[0][4]), \
+                   [x10] "=v"(W.x[1][0]), [x11] "=v"(W.x[1][1]), [x12] "=v"(W.x[1][2]), [x13] "=v"(W.x[1][3]), [x14] "=v"(W.x[1][4]), \
+                   [x20] "=v"(W.x[2][0]), [x21] "=v"(W.x[2][1]), [x22] "=v"(W.x[2][2]), [x23] "=v"(W.x[2][3]), [x24] "=v"(W.x[2][4]), \
+                   [x30] "=v"(W.x[3][0]), [x31] "=v"(W.x[3][1]), [x32] "=v"(W.x[3][2]), [x33] "=v"(W.x[3][3]), [x34] "=v"(W.x[3][4]), \
+                   [p0] "=v"(W.xp[0]), [p1] "=v"(W.xp[1]), [p2] "=v"(W.xp[2]), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra), [ga] "+v"(ga)  \
                  : [vo] "v"(lane8), [vp] "v"(lane31x8), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),            \
-                   [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [ra] "v"(ra), [rl] "s"(rl), [ga] "v"(ga), [gl] "s"(gl),    \
+                   [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [rl] "s"(rl), [gl] "s"(gl),    \
                    [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3), [o4] "n"(2048)                                                \
                  : "memory")
 #define DF_IFC(n, p, d) if constexpr (NN == (n) && PP == (p) && DMA == (d)) { if constexpr (NQ4 == 5) { DF_TRIP5(n, p, d); } else { DF_TRIP(n, p, d); } } else

@@ -56,6 +56,10 @@ constexpr int BD_SP = 256;           // pitch of a static row (floats): lane l h
 __host__ __device__ constexpr int bd_stat_floats(int H) { return BD_NSTAT_C * (H > 256 ? 320 : 256); }
 constexpr int BD_NSTAT = 8;          // static rows per (cell, node): Gext, h, c_r, c_z, c_nr, c_n, z, c_q
 constexpr int BD_RD = 6;             // a loader wave requests a record this many of its blocks ahead (ring: 8 entries)
+// a successor record (bd_records_kernel): 64 words = one DMA of a full wave
+//   [0..3] v, first / last CSR slot of v's row in direction 1 - d, 0     [4..7] first four successors   [8..11] their edge ids
+//   [16..19] / [20..23] first / second edge feature of those edges       [24 + 4 i + e] alpha of edge e in stacked layer i
+constexpr int BD_RECW = 64;
 enum { BD_DA = 0, BD_DU = 1 };
 enum { ST_GEXT = 0, ST_H = 1, ST_CR = 2, ST_CZ = 3, ST_CNR = 4, ST_CN = 5, ST_Z = 6, ST_CQ = 7 };
 
@@ -75,7 +79,7 @@ struct BdCell {            // (104 bytes: 30 kernel cells - 8 stacked layers, bo
     float* sig;            // da: [N]
     float* mrel;           // da: [N, R] or null
     int dir, kind;
-    int partner, pad_;     // da: index of the input-gradient cell that reads this cell's dgi granules, or -1
+    int partner, layer;    // da: index of the input-gradient cell that reads this cell's dgi granules, or -1; the stacked layer
 };
 
 #define BD_MAX_KCELLS 24
@@ -97,7 +101,19 @@ struct BdArgs {
     gran_t* xcc_tab;
     int nroles;
     unsigned short role[BD_MAX_WGS];
+#ifdef BD_STAMPS
+    unsigned long long* dbg;   // [grid][2] start / end of every workgroup, then [blocks][NLS][16] stamps of the workgroup with role dbg_role
+    unsigned dbg_role;
+#endif
 };
+// per-block stamps (scripts/bd_hops.py) only in a build with -DBD_STAMPS (scripts/build_variant.sh stamps SRC=bwd_dataflow -DBD_STAMPS)
+#ifdef BD_STAMPS
+#define BD_STAMP(on, blk, st, k) do { if (on) S.dbg[2 * (int64_t)gridDim.x + 16 * (int64_t)(DF_NLS * (blk) + (st)) + (k)] = wall_clock64(); } while (0)
+#define BD_STAMP_V(on, blk, st, k, val) do { if (on) S.dbg[2 * (int64_t)gridDim.x + 16 * (int64_t)(DF_NLS * (blk) + (st)) + (k)] = (val); } while (0)
+#else
+#define BD_STAMP(on, blk, st, k) do { } while (0)
+#define BD_STAMP_V(on, blk, st, k, val) do { } while (0)
+#endif
 static_assert(sizeof(BdArgs) + 8 <= 4096, "the cell and role tables must fit the kernel-argument segment");
 
 template <int KPT> struct BdPad { static constexpr int kp8 = 2 * KPT; static constexpr int seg = kp8 + 4; static constexpr int row = 8 * seg + 8; };
@@ -112,7 +128,7 @@ template <int KPT> struct BdSlot {
 
 struct BdLds {
     float* ring;   // [NLS][NSLOT] slots
-    int* rec;      // [NLS * RB][8][16] row records, landed by LDS-DMA BD_RD blocks ahead
+    int* rec;      // [NLS * RB][8][BD_RECW] row records, landed by LDS-DMA BD_RD blocks ahead
     int* rdy;      // [NLS][WPS]
     int* dn;       // [NLS][NCW]
     int* dump;     // [NLS * RB][64] landing area of the L2 warm-up DMAs (never read)
@@ -140,6 +156,12 @@ __device__ __forceinline__ bool bd_retry(unsigned& spins, int* err, unsigned lim
     return true;
 }
 
+// a pointer / value the "s" operand of an asm statement can take (the compiler does not always see that it is wave-uniform)
+__device__ __forceinline__ const void* bd_sptr(const void* p) {
+    const unsigned long long u = (unsigned long long)(uintptr_t)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return reinterpret_cast<const void*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ float bd_dpp_row_sum16(float v) {
 #define BD_DPP_ADD(ctrl) \
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
@@ -163,17 +185,19 @@ __device__ __forceinline__ float bd_row_pair_sum(float x) {   // (see df_row_pai
     return a + b;
 }
 __device__ __host__ __forceinline__ int bd_stream_group(int pair, int set, int groups) {
-    const int g = DF_NLS * pair + set;
-    return g < groups ? g : -1;
+    return df_group_of_stream(pair, set, groups);
 }
 
 // ---------------------------------------------------------------- preparation kernels
 // successor records in schedule order: for schedule record r of direction d (node v, or -1 = padding) the 64 bytes
 // {v, first / last CSR slot of v's row in direction 1 - d, 0, first four successors, their original edge ids, 0 x 4}
+struct BdRecAlpha { const float* alpha[DAGNN_MAX_DIRS][DAGNN_MAX_STACKED]; int Ls, R; };
+static_assert(24 + 4 * DAGNN_MAX_STACKED <= BD_RECW, "a record holds the attention weights of every stacked layer");
+
 __global__ void __launch_bounds__(256) bd_records_kernel(const int32_t* __restrict__ plan, PlanLayout L,
                                                           const int32_t* __restrict__ sched, DfLayout S,
                                                           int32_t* __restrict__ brecs, int64_t nrec, int groups,
-                                                          const int32_t* __restrict__ status) {
+                                                          const int32_t* __restrict__ status, BdRecAlpha AL) {
     if (status && status[0] != 0) return;
     const int d = blockIdx.y, od = 1 - d;
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -182,10 +206,10 @@ __global__ void __launch_bounds__(256) bd_records_kernel(const int32_t* __restri
     const int32_t* last = sched + S.gtab[d] + 2 * (groups - 1);
     const int64_t used = (int64_t)last[0] + (int64_t)DF_RB * last[1];
     const int v = r < used ? sched[S.grec[d] + 16 * r] : -1;
-    int4* out = reinterpret_cast<int4*>(brecs + (int64_t)d * 16 * nrec + 16 * r);
+    int4* out = reinterpret_cast<int4*>(brecs + ((int64_t)d * nrec + r) * BD_RECW);
     if (v < 0) {
         out[0] = make_int4(-1, 0, 0, 0);
-        out[1] = make_int4(0, 0, 0, 0); out[2] = out[1]; out[3] = out[1];
+        for (int i = 1; i < BD_RECW / 4; ++i) out[i] = make_int4(0, 0, 0, 0);
         return;
     }
     const int4* orec = reinterpret_cast<const int4*>(plan + L.rowrec[od]) + 4 * (int64_t)plan[L.pos[od] + v];
@@ -194,9 +218,27 @@ __global__ void __launch_bounds__(256) bd_records_kernel(const int32_t* __restri
     const int32_t* eidx = plan + L.eidx[od];
     out[0] = make_int4(v, eb, ee, 0);
     out[1] = r1;
-    out[2] = make_int4(eb < ee ? eidx[eb] : 0, eb + 1 < ee ? eidx[eb + 1] : 0, eb + 2 < ee ? eidx[eb + 2] : 0,
-                       eb + 3 < ee ? eidx[eb + 3] : 0);
+    const int e4[4] = {eb < ee ? eidx[eb] : 0, eb + 1 < ee ? eidx[eb + 1] : 0, eb + 2 < ee ? eidx[eb + 2] : 0, eb + 3 < ee ? eidx[eb + 3] : 0};
+    out[2] = make_int4(e4[0], e4[1], e4[2], e4[3]);
     out[3] = make_int4(0, 0, 0, 0);
+    // what the sweep's pull needs per edge, so that a row costs its loader no trip to memory beyond the record: the edge
+    // features (the sweep sums ds_e f_e) and the attention weights of every stacked layer
+    const float* eattr = reinterpret_cast<const float*>(plan + L.eattr[od]);
+    float f[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[k][e] = (k < AL.R && eb + e < ee) ? eattr[(int64_t)(eb + e) * AL.R + k] : 0.f;
+    float4* outf = reinterpret_cast<float4*>(out);
+    outf[4] = make_float4(f[0][0], f[0][1], f[0][2], f[0][3]);
+    outf[5] = make_float4(f[1][0], f[1][1], f[1][2], f[1][3]);
+    for (int i = 0; i < DAGNN_MAX_STACKED; ++i) {
+        const float* al = i < AL.Ls ? AL.alpha[d][i] : nullptr;
+        outf[6 + i] = al ? make_float4(eb < ee ? al[e4[0]] : 0.f, eb + 1 < ee ? al[e4[1]] : 0.f, eb + 2 < ee ? al[e4[2]] : 0.f,
+                                       eb + 3 < ee ? al[e4[3]] : 0.f)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int i = 6 + DAGNN_MAX_STACKED; i < BD_RECW / 4; ++i) out[i] = make_int4(0, 0, 0, 0);
 }
 
 struct BdStatCell {
@@ -269,8 +311,8 @@ struct BdSweep {
     "global_load_dwordx2 %[x" #e "2], %[vo], %[b" #e "] offset:%[o2] sc1\n\t"    \
     "global_load_dwordx2 %[x" #e "3], %[vo], %[b" #e "] offset:%[o3] sc1\n\t"    \
     "global_load_dwordx2 %[q" #e "], %[vz], %[c" #e "] offset:0 sc1\n\t"
-#define BD_ROWS_0 ""
-#define BD_ROWS_1 BD_ROW_LD(0)
+#define BD_ROWS_0 "v_mov_b32 %[vz], 0\n\t"
+#define BD_ROWS_1 BD_ROWS_0 BD_ROW_LD(0)
 #define BD_ROWS_2 BD_ROWS_1 BD_ROW_LD(1)
 #define BD_ROWS_3 BD_ROWS_2 BD_ROW_LD(2)
 #define BD_ROWS_4 BD_ROWS_3 BD_ROW_LD(3)
@@ -285,6 +327,7 @@ struct BdSweep {
 // reads: the lines are in this XCD's L2 when the next block's trip asks for them - a cold static row costs ~1.5 us, an L2
 // hit less than the polls next to it); both DMAs stay in flight behind the counted wait
 #define BD_STAT_1                                                     \
+    "v_lshlrev_b32 %[vs], 1, %[vo]\n\t"                               \
     "global_load_dwordx4 %[s0], %[vs], %[sa] offset:0\n\t"            \
     "global_load_dwordx4 %[s1], %[vs], %[sa] offset:1024\n\t"         \
     "global_load_dwordx4 %[s2], %[vs], %[sa] offset:2048\n\t"         \
@@ -293,20 +336,21 @@ struct BdSweep {
     "global_load_dwordx4 %[s5], %[vs], %[sb] offset:1024\n\t"         \
     "global_load_dwordx4 %[s6], %[vs], %[sb] offset:2048\n\t"         \
     "global_load_dwordx4 %[s7], %[vs], %[sb] offset:3072\n\t"         \
-    "s_mov_b32 %[km], m0\n\ts_mov_b32 m0, %[pl]\n\ts_nop 0\n\tglobal_load_lds_dword %[pa], off\n\t" \
-    "s_mov_b64 %[ke], exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %[rl]\n\t" \
-    "s_nop 0\n\tglobal_load_lds_dword %[ra], off\n\t"                 \
-    "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]\n\ts_waitcnt vmcnt(2)"
+    "s_mov_b32 %[km], m0\n\ts_mov_b32 m0, %[pl]\n\tv_lshlrev_b32 %[vs], 4, %[vo]\n\tglobal_load_lds_dword %[vs], %[pa]\n\t" \
+    "s_mov_b32 m0, %[rl]\n\t" \
+    "v_lshrrev_b32 %[vs], 1, %[vo]\n\tglobal_load_lds_dword %[vs], %[ra]\n\t"                 \
+    "s_mov_b32 m0, %[km]\n\ts_waitcnt vmcnt(2)"
 // H = 320: the fifth column block of every polled row, and part B of the static record
 #define BD_ROW_LD5(e) BD_ROW_LD(e) "global_load_dwordx2 %[x" #e "4], %[vo], %[b" #e "] offset:2048 sc1\n\t"
-#define BD_ROWS5_0 ""
-#define BD_ROWS5_1 BD_ROW_LD5(0)
+#define BD_ROWS5_0 BD_ROWS_0
+#define BD_ROWS5_1 BD_ROWS5_0 BD_ROW_LD5(0)
 #define BD_ROWS5_2 BD_ROWS5_1 BD_ROW_LD5(1)
 #define BD_ROWS5_3 BD_ROWS5_2 BD_ROW_LD5(2)
 #define BD_ROWS5_4 BD_ROWS5_3 BD_ROW_LD5(3)
 #define BD_DU5_0 ""
 #define BD_DU5_1 BD_DU_1 "global_load_dwordx2 %[u4], %[vo], %[ub] offset:2048 sc1\n\t"
 #define BD_STAT5_1                                                    \
+    "v_lshrrev_b32 %[vt], 1, %[vo]\n\t"                               \
     "global_load_dword %[t0], %[vt], %[sc] offset:0\n\t"              \
     "global_load_dword %[t1], %[vt], %[sc] offset:256\n\t"            \
     "global_load_dword %[t2], %[vt], %[sc] offset:512\n\t"            \
@@ -322,9 +366,9 @@ struct BdSweep {
                    [x20] "=v"(W.x[2][0]), [x21] "=v"(W.x[2][1]), [x22] "=v"(W.x[2][2]), [x23] "=v"(W.x[2][3]),              \
                    [x30] "=v"(W.x[3][0]), [x31] "=v"(W.x[3][1]), [x32] "=v"(W.x[3][2]), [x33] "=v"(W.x[3][3]),              \
                    [q0] "=v"(W.q[0]), [q1] "=v"(W.q[1]), [q2] "=v"(W.q[2]), [q3] "=v"(W.q[3]),                              \
-                   [u0] "=v"(W.u[0]), [u1] "=v"(W.u[1]), [u2] "=v"(W.u[2]), [u3] "=v"(W.u[3])
+                   [u0] "=v"(W.u[0]), [u1] "=v"(W.u[1]), [u2] "=v"(W.u[2]), [u3] "=v"(W.u[3]), [vz] "=&v"(tmp_vz)
 #define BD_ROW_INS                                                                                                          \
-                   [vo] "v"(lane8), [vz] "v"(vzero), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),                \
+                   [vo] "v"(lane8), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),                \
                    [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [c3] "s"(c3p), [ub] "s"(ub),                                \
                    [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)
 #define BD_TRIP_FIRST(n_, du_)                                                                                              \
@@ -332,8 +376,8 @@ struct BdSweep {
                  : BD_ROW_OUTS,                                                                                             \
                    [s0] "=v"(ST[0]), [s1] "=v"(ST[1]), [s2] "=v"(ST[2]), [s3] "=v"(ST[3]),                                  \
                    [s4] "=v"(ST[4]), [s5] "=v"(ST[5]), [s6] "=v"(ST[6]), [s7] "=v"(ST[7]),                                  \
-                   [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra), [pa] "+v"(pa)                                                               \
-                 : BD_ROW_INS, [vs] "v"(lane16), [sa] "s"(sa), [sb] "s"(sb), [rl] "s"(rl),                    \
+                   [km] "=&s"(keep_m0), [vs] "=&v"(tmp_vs)                                                                         \
+                 : BD_ROW_INS, [sa] "s"(sa), [sb] "s"(sb), [rl] "s"(rl), [ra] "s"(ra), [pa] "s"(pa),          \
                    [pl] "s"(pl)                                                                               \
                  : "memory")
 #define BD_TRIP_POLL(n_, du_)                                                                                               \
@@ -346,9 +390,9 @@ struct BdSweep {
                    [s4] "=v"(ST[4]), [s5] "=v"(ST[5]), [s6] "=v"(ST[6]), [s7] "=v"(ST[7]),                                  \
                    [t0] "=v"(ST5[0]), [t1] "=v"(ST5[1]), [t2] "=v"(ST5[2]), [t3] "=v"(ST5[3]),                              \
                    [t4] "=v"(ST5[4]), [t5] "=v"(ST5[5]), [t6] "=v"(ST5[6]), [t7] "=v"(ST5[7]),                              \
-                   [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra), [pa] "+v"(pa)                                                               \
-                 : BD_ROW_INS, [vs] "v"(lane16), [sa] "s"(sa), [sb] "s"(sb), [rl] "s"(rl),                    \
-                   [pl] "s"(pl), [vt] "v"(lane4), [sc] "s"(sc)                                                \
+                   [km] "=&s"(keep_m0), [vs] "=&v"(tmp_vs), [vt] "=&v"(tmp_vt)                                                     \
+                 : BD_ROW_INS, [sa] "s"(sa), [sb] "s"(sb), [rl] "s"(rl), [ra] "s"(ra), [pa] "s"(pa),          \
+                   [pl] "s"(pl), [sc] "s"(sc)                                                                 \
                  : "memory")
 #define BD_TRIP_POLL5(n_, du_)                                                                                              \
     asm volatile(BD_ROWS5_##n_ BD_DU5_##du_ "s_waitcnt vmcnt(0)" : BD_ROW_OUTS5 : BD_ROW_INS : "memory")
@@ -375,11 +419,14 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
     const int d = C.dir, od = 1 - d;
     const int32_t* tab = S.sched + S.gtab[d] + 2 * group;
     const int rec_base = tab[0], nblk = tab[1];
-    const int32_t* __restrict__ recs = S.brecs + S.brec[d] + 16 * (int64_t)rec_base;
+    const int32_t* __restrict__ recs = S.brecs + S.brec[d] + BD_RECW * (int64_t)rec_base;
     const int32_t* __restrict__ col = plan + S.col[od];
     const int32_t* __restrict__ eidx = plan + S.eidx[od];
     const float* __restrict__ eattr = reinterpret_cast<const float*>(plan + S.eattr[od]);
     const int R = C.mrel ? S.R : 0;
+    const int r1 = R > 1 ? 1 : 0;
+    const int al_w = 24 + 4 * C.layer;   // word of the record that holds this stacked layer's alpha of the first edge
+    const float* __restrict__ ea = R > 0 ? eattr : C.alpha;
     const unsigned epoch = S.epoch, spin_limit = S.spin_limit;
     int* const err = S.err;
     const int gld = S.gld;
@@ -398,14 +445,14 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
     constexpr int NC = NQ4 > 4 ? NQ4 : 4;   // column blocks a lane carries
     constexpr int SREC = bd_stat_floats(H);
     float wk[NC];
-    int cpos[NC];
+    int cpos[NC];   // (64 % KP8 == 0: cpos[q] = cpos[0] + a constant - one address register, immediate offsets)
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
         const int c = 64 * q + lane;
-        cpos[q] = c + (SEG - KP8) * (c / KP8);
+        cpos[q] = (64 % KP8 == 0) ? lane + (SEG - KP8) * (lane / KP8) + q * (64 + (SEG - KP8) * (64 / KP8)) : c + (SEG - KP8) * (c / KP8);
         wk[q] = q < NQ4 ? C.wkey[c] : 0.f;
     }
-    const unsigned lane8 = 8u * lane, lane16 = 16u * lane, lane4 = 4u * lane, vzero = 0u;
+    const unsigned lane8 = 8u * lane;   // (the 16- and 4-byte lane offsets and the zero offset of the q loads are temporaries of the trips)
     constexpr int O1 = (NQ4 > 1 ? 1 : 0) * 512, O2 = (NQ4 > 2 ? 2 : NQ4 - 1) * 512, O3 = (NQ4 > 3 ? 3 : NQ4 - 1) * 512;
     int lw = w * BD_RPW;   // this wave's row(s) of every block
     int* rec_ring;
@@ -413,61 +460,84 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
     const int32_t* rec_w;
     auto set_row = [&](int row) {
         lw = row;
-        rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
+        rec_ring = lds.rec + (set * DF_RB + lw) * (8 * BD_RECW);
         rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
-        rec_w = recs + 16 * lw + (lane & 15);
+        rec_w = recs + BD_RECW * lw;   // (uniform; lane l adds its 4 l bytes inside the DMA statements)
         // L2 warm-up (see BD_STAT_1): lane l asks for line l of the next block's static record; the dump area is this row's
         pl = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(reinterpret_cast<unsigned*>(lds.dump) + ((set * DF_RB + lw) * 64)));
     };
     set_row(lw);
-    const int64_t wstride = 16 * DF_RB;
+    const int64_t wstride = BD_RECW * DF_RB;
     // block j of this wave (the j-th from the END of the stream's record list: the sweep runs the layers in reverse)
-    auto rec_src = [&](int j) -> const void* { return rec_w + (int64_t)(nblk - 1 - min(j, nblk - 1)) * wstride; };
-    auto rec_dst = [&](int j) -> unsigned { return rec_ring_a + (j & 7) * 64; };
-    auto glds4 = [&](const void* gsrc, unsigned lds_dst) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    auto rec_src = [&](int j) -> const void* { return bd_sptr(rec_w + (int64_t)(nblk - 1 - min(j, nblk - 1)) * wstride); };
+    auto rec_dst = [&](int j) -> unsigned { return rec_ring_a + (j & 7) * (BD_RECW * 4); };
+    auto glds4 = [&](const void* gsrc, unsigned lds_dst) {   // (lane l moves word l of the record)
+        unsigned keep, off;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\tv_lshrrev_b32 %1, 1, %4\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&v"(off) : "s"(gsrc), "s"(lds_dst), "v"(lane8) : "memory");
     };
     if (nblk > 0) {
         for (int rr = 0; rr < BD_RPW; ++rr) {
             set_row(w * BD_RPW + rr);
 #pragma unroll
-            for (int j = 0; j < BD_RD; ++j) if (lane < 16) glds4(rec_src(j), rec_dst(j));
+            for (int j = 0; j < BD_RD; ++j) glds4(rec_src(j), rec_dst(j));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // the slice's share of a full row in the loader's column layout: units [32 sl, 32 sl + 32) = column block q = sl / 2,
     // lanes [32 (sl & 1), + 32)
     const bool local_st = lds.local[0] != 0;
-    const int myq = sl >> 1;
-    const bool mine = (lane >> 5) == (sl & 1);
+    const int myq = __builtin_amdgcn_readfirstlane(sl >> 1), odd = __builtin_amdgcn_readfirstlane(sl & 1);
+    const bool mine = (lane >> 5) == odd;
+    const unsigned myq512 = 512u * (unsigned)myq;
+    // the slice's column block of a row array.  (As `myq == q ? a[q] : r` the compiler turns the chain into a dynamically indexed
+    // array in SCRATCH memory - five round trips to memory per row, two of them in front of the ready flag: v_cndmask by hand.)
+    // (the lane masks are made per row from the 32-bit `myq` / `odd`: 64-bit masks kept across the sweep end up parked in VGPRs)
+    unsigned long long pmask[5], mine_mask;
+    unsigned mask_sh;
+    auto make_masks = [&]() {
+        asm volatile("s_cmp_eq_u32 %[q], 1\n\ts_cselect_b64 %[p1], -1, 0\n\ts_cmp_eq_u32 %[q], 2\n\ts_cselect_b64 %[p2], -1, 0\n\t"
+                     "s_cmp_eq_u32 %[q], 3\n\ts_cselect_b64 %[p3], -1, 0\n\ts_cmp_eq_u32 %[q], 4\n\ts_cselect_b64 %[p4], -1, 0\n\t"
+                     "s_lshl_b32 %[sh], %[o], 5\n\ts_bfm_b64 %[mm], 32, %[sh]"
+                     : [p1] "=&s"(pmask[1]), [p2] "=&s"(pmask[2]), [p3] "=&s"(pmask[3]), [p4] "=&s"(pmask[4]), [mm] "=&s"(mine_mask),
+                       [sh] "=&s"(mask_sh)
+                     : [q] "s"(myq), [o] "s"(odd) : "scc");
+    };
     auto pick = [&](const float (&a)[NC]) -> float {
         float r = a[0];
 #pragma unroll
-        for (int q = 1; q < NC; ++q) r = myq == q ? a[q] : r;
+        for (int q = 1; q < NC; ++q) asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r) : "v"(a[q]), "s"(pmask[q]));
         return r;
     };
 
     BdSweep A;
+#ifdef BD_STAMPS
+    const bool prof = S.dbg && lds.local[1] != 0 && w == 0 && lane == 0;
+    unsigned long long npoll = 0;
+#endif
     for (int b = 0; b < nblk; ++b) {
         const int j = b;
 #pragma unroll 1
       for (int rr = 0; rr < BD_RPW; ++rr) {
         if (BD_RPW > 1) set_row(w * BD_RPW + rr);
-        const int cur = rec_ring[(j & 7) * 16 + (lane & 15)];
+        BD_STAMP(prof, b, set, 0);   // row start
+        const int cur = rec_ring[(j & 7) * BD_RECW + lane];
 #define BD_W(i) __builtin_amdgcn_readlane(cur, i)
         const int v = BD_W(0), eb = BD_W(1), ee = BD_W(2);
         const int s4[4] = {BD_W(4), BD_W(5), BD_W(6), BD_W(7)};
-        const int e4[4] = {BD_W(8), BD_W(9), BD_W(10), BD_W(11)};
+        // the first four edges' features and attention weights ride in the record (bd_records_kernel): no loads in front of the trip
+        const float rf0[4] = {__int_as_float(BD_W(16)), __int_as_float(BD_W(17)), __int_as_float(BD_W(18)), __int_as_float(BD_W(19))};
+        const float rf1[4] = {__int_as_float(BD_W(20)), __int_as_float(BD_W(21)), __int_as_float(BD_W(22)), __int_as_float(BD_W(23))};
+        const float ral[4] = {__int_as_float(BD_W(al_w)), __int_as_float(BD_W(al_w + 1)), __int_as_float(BD_W(al_w + 2)),
+                              __int_as_float(BD_W(al_w + 3))};
 #undef BD_W
         const int slot = b % BD_NSLOT;
         float* sbase = lds.ring + (set * BD_NSLOT + slot) * Slot::words;
         int* v_s = reinterpret_cast<int*>(sbase + Slot::v_off);
         const void* ra = rec_src(j + BD_RD);
         const unsigned rl = rec_dst(j + BD_RD);
-        const int vnext = __builtin_amdgcn_readfirstlane(rec_ring[((j + 1) & 7) * 16]);   // (past the end: the last block's again)
-        const void* pa = stat + (int64_t)max(vnext, 0) * SREC + 32 * lane;
+        const int vnext = __builtin_amdgcn_readfirstlane(rec_ring[((j + 1) & 7) * BD_RECW]);   // (past the end: the last block's again)
+        const void* pa = bd_sptr(stat + (int64_t)max(vnext, 0) * SREC);   // (+ 128 lane bytes in the statement)
         if (v >= 0) {
             const int deg = ee - eb;
             const float* sa = stat + (int64_t)v * SREC;
@@ -496,12 +566,15 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                 float al[4] = {0.f, 0.f, 0.f, 0.f}, f0[4] = {0.f, 0.f, 0.f, 0.f}, f1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < NN; ++e) {
-                    int eid;
-                    if (FIRST) { pj[e] = s4[e]; eid = e4[e]; }
-                    else { pj[e] = col[eb + c0 + e]; eid = eidx[eb + c0 + e]; }
-                    al[e] = alpha[eid];
-                    if (R >= 1) f0[e] = eattr[(int64_t)(eb + c0 + e) * R];
-                    if (R >= 2) f1[e] = eattr[(int64_t)(eb + c0 + e) * R + 1];
+                    if (FIRST) { pj[e] = s4[e]; al[e] = ral[e]; f0[e] = rf0[e]; f1[e] = rf1[e]; }
+                    else {
+                        pj[e] = col[eb + c0 + e];
+                        al[e] = alpha[eidx[eb + c0 + e]];
+                        // (unconditional: `R >= 1` as a hoisted condition ends up as a 0 / 1 VGPR in scratch memory, reloaded in
+                        // front of every trip; with R = 0 the loads read alpha[0], with R = 1 f1 = f0 - neither sum is stored then)
+                        f0[e] = ea[(int64_t)(eb + c0 + e) * R];
+                        f1[e] = ea[(int64_t)(eb + c0 + e) * R + r1];
+                    }
                 }
                 // (N * 3 gld granules fit 32 bits - host check: one 32-bit multiply per row base)
                 const gran_t* b0 = da_g + (unsigned)pj[0] * (unsigned)gld;
@@ -509,8 +582,8 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                 const gran_t* b2 = da_g + (unsigned)pj[2] * (unsigned)gld;
                 const gran_t* b3 = da_g + (unsigned)pj[3] * (unsigned)gld;
                 const gran_t* c0p = q_in + pj[0], * c1p = q_in + pj[1], * c2p = q_in + pj[2], * c3p = q_in + pj[3];
-                unsigned keep_m0;
-                unsigned long long keep_exec;
+                unsigned keep_m0, tmp_vz, tmp_vs, tmp_vt;
+                (void)tmp_vs; (void)tmp_vt;
                 BdSweep& W = A;
                 auto landed = [&]() -> bool {
                     unsigned m = epoch;
@@ -527,13 +600,23 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                     return __builtin_amdgcn_uicmp(m, epoch, 33 /* ICMP_NE */) == 0ull;
                 };
                 if (FIRST) { BD_TRIP_SEL(NN, DU, 1); } else { BD_TRIP_SEL(NN, 0, 0); }
+#ifdef BD_STAMPS
+                if (FIRST) { BD_STAMP(prof, b, set, 2); npoll = 1; }   // first trip back (static rows + the first look at the successors)
+                unsigned long long t_issue = 0;
+#endif
                 if (NN + DU > 0 && !landed()) {
                     unsigned spins = 0;
                     do {
                         if (!bd_retry(spins, err, spin_limit)) break;
+#ifdef BD_STAMPS
+                        t_issue = wall_clock64(); ++npoll;
+#endif
                         BD_TRIP_SEL(NN, DU, 0);
                     } while (!landed());
                 }
+#ifdef BD_STAMPS
+                if (FIRST) { BD_STAMP(prof, b, set, 3); BD_STAMP_V(prof, b, set, 7, t_issue); }   // the successors' rows are here; when the winning poll was issued
+#endif
                 if (DU) {
 #pragma unroll
                     for (int q = 0; q < NC; ++q) du[q] = __uint_as_float((unsigned)A.u[q]);
@@ -559,6 +642,7 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
             typedef std::integral_constant<bool, true> first_t;
             typedef std::integral_constant<bool, false> later_t;
             if (b >= BD_NSLOT) bd_wait4(dn, b - BD_NSLOT + 1, err, spin_limit);   // the ring slot is free again (before the poll: off the dependent chain)
+            BD_STAMP(prof, b, set, 1);   // slot free
             if (deg <= 0) chunk(std::integral_constant<int, 0>(), first_t(), 0);
             else if (deg == 1) chunk(std::integral_constant<int, 1>(), first_t(), 0);
             else if (deg == 2) chunk(std::integral_constant<int, 2>(), first_t(), 0);
@@ -573,6 +657,10 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                     else chunk(std::integral_constant<int, 1>(), later_t(), c0);
                 }
             }
+#ifdef BD_STAMPS
+            { asm volatile("" :: "v"(acc[0]), "v"(acc[NC - 1]), "v"(sig)); BD_STAMP(prof, b, set, 4); BD_STAMP_V(prof, b, set, 8, npoll); }   // pulls done
+#endif
+            make_masks();
             // G_v, then everything that is linear in it
             auto stv = [&](int r, int q) -> float { return q < 4 ? ST[r][q] : ST5[r]; };   // (q is a constant after unrolling)
             float G[NC];
@@ -607,35 +695,61 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 bd_flag_st(lds.rdy + set * BD_WPS + w, b + 1);
             }
+            BD_STAMP(prof, b, set, 5);   // flag raised
             if (sl == 0) {   // q_v = G_v . c_q,v; the row's scalar outputs
                 qd = bd_wave_sum(qd);
                 if (lane == 0) {
                     if (local_st) q_out[v] = gran_pack(epoch, qd);
                     else __hip_atomic_store(q_out + v, gran_pack(epoch, qd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     sig_out[v] = sig;
-                    if (R >= 1) mrel[(int64_t)v * R] = m0;
-                    if (R >= 2) mrel[(int64_t)v * R + 1] = m1;
+                    int Rf;   // (compared on the spot, see the note at the loads)
+                    asm volatile("s_mov_b32 %0, %1" : "=s"(Rf) : "s"(R));
+                    if (Rf >= 1) mrel[(int64_t)v * Rf] = m0;
+                    if (Rf >= 2) mrel[(int64_t)v * Rf + 1] = m1;
                 }
             }
-            if (mine) {
-                const int c = 64 * myq + lane;   // = 32 sl + (lane & 31)
+            {   // the slice's 32 columns of dgi (granules for the input-gradient cell + plain) and dgh (plain): row bases in
+                // SGPRs (v is uniform), ONE per-lane byte offset, the half-wave that owns the columns under an exec mask - as
+                // C++ the compiler keeps three per-lane 64-bit base pointers alive across the sweep (and spills them)
+                const char* og = reinterpret_cast<const char*>(dgi) + (uint64_t)(unsigned)v * (unsigned)(3 * H * 4);
+                const char* oh = reinterpret_cast<const char*>(dgh) + (uint64_t)(unsigned)v * (unsigned)(3 * H * 4);
+                unsigned long long keep_e;
+                unsigned c8;   // byte offsets of column 32 sl + (lane & 31) = 64 myq + lane in a granule / plain row, made per row
+                asm volatile("v_add_u32 %0, %1, %2" : "=v"(c8) : "v"(lane8), "s"(myq512));
+                const unsigned c4 = c8 >> 1;
                 if (dgi_g) {
-                    gran_t* pg = dgi_g + (int64_t)v * (3 * gld) + c;
-                    if (local_st) {   // (readers on this XCD: the lines stay in its L2)
-                        pg[0] = gran_pack(epoch, mr); pg[gld] = gran_pack(epoch, mz); pg[2 * gld] = gran_pack(epoch, mn);
-                    } else {
-                        __hip_atomic_store(pg, gran_pack(epoch, mr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(pg + gld, gran_pack(epoch, mz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(pg + 2 * gld, gran_pack(epoch, mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                    const char* pg0 = reinterpret_cast<const char*>(dgi_g) + (uint64_t)((unsigned)v * (unsigned)(3 * gld)) * 8u;
+                    const char* pg1 = pg0 + (uint64_t)(unsigned)gld * 8u;
+                    const char* pg2 = pg1 + (uint64_t)(unsigned)gld * 8u;
+                    const gran_t g0 = gran_pack(epoch, mr), g1 = gran_pack(epoch, mz), g2 = gran_pack(epoch, mn);
+                    if (local_st)   // (readers on this XCD: the lines stay in its L2)
+                        asm volatile("s_mov_b64 %[ke], exec\n\ts_mov_b64 exec, %[mm]\n\t"
+                                     "global_store_dwordx2 %[c8], %[g0], %[p0]\n\tglobal_store_dwordx2 %[c8], %[g1], %[p1]\n\t"
+                                     "global_store_dwordx2 %[c8], %[g2], %[p2]\n\ts_mov_b64 exec, %[ke]"
+                                     : [ke] "=&s"(keep_e)
+                                     : [mm] "s"(mine_mask), [c8] "v"(c8), [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [p0] "s"(pg0), [p1] "s"(pg1), [p2] "s"(pg2)
+                                     : "memory");
+                    else
+                        asm volatile("s_mov_b64 %[ke], exec\n\ts_mov_b64 exec, %[mm]\n\t"
+                                     "global_store_dwordx2 %[c8], %[g0], %[p0] sc1\n\tglobal_store_dwordx2 %[c8], %[g1], %[p1] sc1\n\t"
+                                     "global_store_dwordx2 %[c8], %[g2], %[p2] sc1\n\ts_mov_b64 exec, %[ke]"
+                                     : [ke] "=&s"(keep_e)
+                                     : [mm] "s"(mine_mask), [c8] "v"(c8), [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [p0] "s"(pg0), [p1] "s"(pg1), [p2] "s"(pg2)
+                                     : "memory");
                 }
-                float* og = dgi + (int64_t)v * (3 * H);
-                float* oh = dgh + (int64_t)v * (3 * H);
-                og[c] = mr; og[H + c] = mz; og[2 * H + c] = mn;
-                oh[c] = mr; oh[H + c] = mz; oh[2 * H + c] = mnr;
+                asm volatile("s_mov_b64 %[ke], exec\n\ts_mov_b64 exec, %[mm]\n\t"
+                             "global_store_dword %[c4], %[mr], %[og]\n\tglobal_store_dword %[c4], %[mz], %[og] offset:%[h1]\n\t"
+                             "global_store_dword %[c4], %[mn], %[og] offset:%[h2]\n\t"
+                             "global_store_dword %[c4], %[mr], %[oh]\n\tglobal_store_dword %[c4], %[mz], %[oh] offset:%[h1]\n\t"
+                             "global_store_dword %[c4], %[mnr], %[oh] offset:%[h2]\n\ts_mov_b64 exec, %[ke]"
+                             : [ke] "=&s"(keep_e)
+                             : [mm] "s"(mine_mask), [c4] "v"(c4), [mr] "v"(mr), [mz] "v"(mz), [mn] "v"(mn), [mnr] "v"(mnr),
+                               [og] "s"(og), [oh] "s"(oh), [h1] "n"(4 * H), [h2] "n"(8 * H)
+                             : "memory");
             }
+            BD_STAMP(prof, b, set, 6);   // row outputs issued
         } else {
-            if (lane < 16) glds4(ra, rl);   // an idle row keeps the record ring moving
+            glds4(ra, rl);   // an idle row keeps the record ring moving
             if (b >= BD_NSLOT) bd_wait4(dn, b - BD_NSLOT + 1, err, spin_limit);
             v_s[lw] = v;
             if (rr == BD_RPW - 1) {
@@ -662,17 +776,17 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
     "global_load_dwordx2 %[y" #g "3], %[vo], %[g" #g "] offset:%[o3] sc1\n\t"
 #define BD_DMA_0 "s_waitcnt vmcnt(0)"
 #define BD_DMA_1                                                                                   \
-    "s_mov_b32 %[km], m0\n\ts_mov_b64 %[ke], exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %[rl]\n\t" \
-    "s_nop 0\n\tglobal_load_lds_dword %[ra], off\n\t"                                              \
-    "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]\n\ts_waitcnt vmcnt(1)"
+    "s_mov_b32 %[km], m0\n\ts_mov_b32 m0, %[rl]\n\t" \
+    "v_lshrrev_b32 %[vs], 1, %[vo]\n\tglobal_load_lds_dword %[vs], %[ra]\n\t"                     \
+    "s_mov_b32 m0, %[km]\n\ts_waitcnt vmcnt(1)"
 #define BD_G_LD5(g) BD_G_LD(g) "global_load_dwordx2 %[y" #g "4], %[vo], %[g" #g "] offset:2048 sc1\n\t"
 #define BD_GTRIP5(dm)                                                                                                        \
     asm volatile(BD_G_LD5(0) BD_G_LD5(1) BD_G_LD5(2) BD_DMA_##dm                                                             \
                  : [y00] "=v"(Y[0][0]), [y01] "=v"(Y[0][1]), [y02] "=v"(Y[0][2]), [y03] "=v"(Y[0][3]), [y04] "=v"(Y[0][4]),  \
                    [y10] "=v"(Y[1][0]), [y11] "=v"(Y[1][1]), [y12] "=v"(Y[1][2]), [y13] "=v"(Y[1][3]), [y14] "=v"(Y[1][4]),  \
                    [y20] "=v"(Y[2][0]), [y21] "=v"(Y[2][1]), [y22] "=v"(Y[2][2]), [y23] "=v"(Y[2][3]), [y24] "=v"(Y[2][4]),  \
-                   [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra)                                                                \
-                 : [vo] "v"(lane8), [g0] "s"(g0), [g1] "s"(g1), [g2] "s"(g2), [rl] "s"(rl),                    \
+                   [km] "=&s"(keep_m0), [vs] "=&v"(tmp_vs)                                                           \
+                 : [vo] "v"(lane8), [g0] "s"(g0), [g1] "s"(g1), [g2] "s"(g2), [rl] "s"(rl), [ra] "s"(ra),      \
                    [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)                                                                  \
                  : "memory")
 #define BD_GTRIP(dm)                                                                                                         \
@@ -680,8 +794,8 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                  : [y00] "=v"(Y[0][0]), [y01] "=v"(Y[0][1]), [y02] "=v"(Y[0][2]), [y03] "=v"(Y[0][3]),                       \
                    [y10] "=v"(Y[1][0]), [y11] "=v"(Y[1][1]), [y12] "=v"(Y[1][2]), [y13] "=v"(Y[1][3]),                       \
                    [y20] "=v"(Y[2][0]), [y21] "=v"(Y[2][1]), [y22] "=v"(Y[2][2]), [y23] "=v"(Y[2][3]),                       \
-                   [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra)                                                                \
-                 : [vo] "v"(lane8), [g0] "s"(g0), [g1] "s"(g1), [g2] "s"(g2), [rl] "s"(rl),                    \
+                   [km] "=&s"(keep_m0), [vs] "=&v"(tmp_vs)                                                           \
+                 : [vo] "v"(lane8), [g0] "s"(g0), [g1] "s"(g1), [g2] "s"(g2), [rl] "s"(rl), [ra] "s"(ra),      \
                    [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)                                                                  \
                  : "memory")
 
@@ -695,7 +809,7 @@ __device__ __forceinline__ void bd_loader_du(const BdArgs& S, const BdCell& C, i
     const int d = C.dir;
     const int32_t* tab = S.sched + S.gtab[d] + 2 * group;
     const int rec_base = tab[0], nblk = tab[1];
-    const int32_t* __restrict__ recs = S.brecs + S.brec[d] + 16 * (int64_t)rec_base;
+    const int32_t* __restrict__ recs = S.brecs + S.brec[d] + BD_RECW * (int64_t)rec_base;
     const unsigned epoch = S.epoch, spin_limit = S.spin_limit;
     int* const err = S.err;
     const int gld = S.gld;
@@ -706,7 +820,7 @@ __device__ __forceinline__ void bd_loader_du(const BdArgs& S, const BdCell& C, i
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
         const int c = 64 * q + lane;
-        cpos[q] = c + (SEG - KP8) * (c / KP8);
+        cpos[q] = (64 % KP8 == 0) ? lane + (SEG - KP8) * (lane / KP8) + q * (64 + (SEG - KP8) * (64 / KP8)) : c + (SEG - KP8) * (c / KP8);
     }
     const unsigned lane8 = 8u * lane;
     constexpr int O1 = (NQ4 > 1 ? 1 : 0) * 512, O2 = (NQ4 > 2 ? 2 : NQ4 - 1) * 512, O3 = (NQ4 > 3 ? 3 : NQ4 - 1) * 512;
@@ -716,34 +830,35 @@ __device__ __forceinline__ void bd_loader_du(const BdArgs& S, const BdCell& C, i
     const int32_t* rec_w;
     auto set_row = [&](int row) {
         lw = row;
-        rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
+        rec_ring = lds.rec + (set * DF_RB + lw) * (8 * BD_RECW);
         rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
-        rec_w = recs + 16 * lw + (lane & 15);
+        rec_w = recs + BD_RECW * lw;   // (uniform; lane l adds its 4 l bytes inside the DMA statements)
     };
     set_row(lw);
-    const int64_t wstride = 16 * DF_RB;
-    auto rec_src = [&](int j) -> const void* { return rec_w + (int64_t)(nblk - 1 - min(j, nblk - 1)) * wstride; };
-    auto rec_dst = [&](int j) -> unsigned { return rec_ring_a + (j & 7) * 64; };
-    auto glds4 = [&](const void* gsrc, unsigned lds_dst) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    const int64_t wstride = BD_RECW * DF_RB;
+    auto rec_src = [&](int j) -> const void* { return bd_sptr(rec_w + (int64_t)(nblk - 1 - min(j, nblk - 1)) * wstride); };
+    auto rec_dst = [&](int j) -> unsigned { return rec_ring_a + (j & 7) * (BD_RECW * 4); };
+    auto glds4 = [&](const void* gsrc, unsigned lds_dst) {   // (lane l moves word l of the record)
+        unsigned keep, off;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\tv_lshrrev_b32 %1, 1, %4\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&v"(off) : "s"(gsrc), "s"(lds_dst), "v"(lane8) : "memory");
     };
     if (nblk > 0) {
         for (int rr = 0; rr < BD_RPW; ++rr) {
             set_row(w * BD_RPW + rr);
 #pragma unroll
-            for (int j = 0; j < BD_RD; ++j) if (lane < 16) glds4(rec_src(j), rec_dst(j));
+            for (int j = 0; j < BD_RD; ++j) glds4(rec_src(j), rec_dst(j));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     gran_t Y[3][5];
+    unsigned tmp_vs;
     for (int b = 0; b < nblk; ++b) {
         const int j = b;
 #pragma unroll 1
       for (int rr = 0; rr < BD_RPW; ++rr) {
         if (BD_RPW > 1) set_row(w * BD_RPW + rr);
-        const int v = __builtin_amdgcn_readfirstlane(rec_ring[(j & 7) * 16]);
+        const int v = __builtin_amdgcn_readfirstlane(rec_ring[(j & 7) * BD_RECW]);
         const int slot = b % BD_NSLOT;
         float* sbase = lds.ring + (set * BD_NSLOT + slot) * Slot::words;
         int* v_s = reinterpret_cast<int*>(sbase + Slot::v_off);
@@ -756,7 +871,6 @@ __device__ __forceinline__ void bd_loader_du(const BdArgs& S, const BdCell& C, i
             bool dma = true;
             for (;;) {
                 unsigned keep_m0;
-                unsigned long long keep_exec;
                 if constexpr (NQ4 == 5) { if (dma) BD_GTRIP5(1); else BD_GTRIP5(0); } else { if (dma) BD_GTRIP(1); else BD_GTRIP(0); }
                 dma = false;
                 bool ok = true;
@@ -773,7 +887,7 @@ __device__ __forceinline__ void bd_loader_du(const BdArgs& S, const BdCell& C, i
 #pragma unroll
                 for (int q = 0; q < NQ4; ++q) op[g * DF_RB * Slot::AP + cpos[q]] = __uint_as_float((unsigned)Y[g][q]);
         } else {
-            if (lane < 16) glds4(ra, rl);
+            glds4(ra, rl);
             if (b >= BD_NSLOT) bd_wait4(dn, b - BD_NSLOT + 1, err, spin_limit);
         }
         if (lane == 0) v_s[lw] = v;
@@ -830,6 +944,9 @@ __device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int
     int left = 0, pref = 0;
 #pragma unroll
     for (int q = 0; q < DF_NLS; ++q) { done[q] = 0; left += nb[q]; }
+#ifdef BD_STAMPS
+    const bool prof = S.dbg && lds.local[1] != 0 && cw == 0 && lane == 0;
+#endif
     while (left > 0) {
         int st = -1;
         unsigned spins = 0;
@@ -864,6 +981,7 @@ __device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int
 #pragma unroll
         for (int e = 0; e < DF_NLS; ++e) if (e == st) { b = done[e]; ++done[e]; }
         --left;
+        BD_STAMP(prof, b, st, 9);   // block seen
         const int slot = b % BD_NSLOT;
         const float* sbase = lds.ring + (st * BD_NSLOT + slot) * Slot::words;
         const int4 ids = *reinterpret_cast<const int4*>(sbase + Slot::v_off);
@@ -890,6 +1008,9 @@ __device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int
             }
 #endif
             const bf4 t = acc[0] + acc[1] + acc[2];   // the three gate blocks of K: one reduce-scatter for their sum
+#ifdef BD_STAMPS
+            { asm volatile("" :: "v"(t[0]), "v"(t[3])); BD_STAMP(prof, b, st, 10); }   // products done
+#endif
             const float u0 = t[0] + bd_dpp<0x104>(t[0]), u1 = t[1] + bd_dpp<0x104>(t[1]);
             const float u2 = t[2] + bd_dpp<0x114>(t[2]), u3 = t[3] + bd_dpp<0x114>(t[3]);
             const float e0 = s0 ? u2 : u0, e1 = s0 ? u3 : u1;
@@ -905,6 +1026,7 @@ __device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int
             if (local_st) out_g[(int64_t)gv * gld + unit] = gran_pack(epoch, gsum + zgv);
             else __hip_atomic_store(out_g + (int64_t)gv * gld + unit, gran_pack(epoch, gsum + zgv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        BD_STAMP(prof, b, st, 11);   // stores issued
     }
 }
 
@@ -938,13 +1060,18 @@ __global__ void __launch_bounds__(BD_THREADS, BD_THREADS / 256) bwd_dataflow_ker
     BdLds lds;
     lds.ring = smem;
     lds.rec = reinterpret_cast<int*>(lds.ring + DF_NLS * BD_NSLOT * Slot::words);
-    int* flags = lds.rec + DF_NLS * DF_RB * 8 * 16;
+    int* flags = lds.rec + DF_NLS * DF_RB * 8 * BD_RECW;
     lds.rdy = flags;
     lds.dn = flags + BD_NLW;
     lds.dump = flags + BD_NLW + DF_NLS * DF_NCW;
     lds.local = lds.dump + DF_NLS * DF_RB * 64;
     if (tid < BD_NLW + DF_NLS * DF_NCW) flags[tid] = 0;
     if (tid == 0) lds.local[0] = 0;
+#ifdef BD_STAMPS
+    if (tid == 0) lds.local[1] = S.dbg && (unsigned)((pair << 10) | (c << 5) | sl) == S.dbg_role;
+    if (S.dbg && tid == 0) S.dbg[2 * blockIdx.x] = wall_clock64();
+    if (S.dbg && tid == 0 && blockIdx.x == 0) S.dbg[(1 << 20) - 1] = gridDim.x;
+#endif
     if (S.nroles > 0 && wave == 0) {   // publish where this workgroup runs; state-gradient cells look at their unit
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -976,6 +1103,9 @@ __global__ void __launch_bounds__(BD_THREADS, BD_THREADS / 256) bwd_dataflow_ker
     __syncthreads();
     if (wave < DF_NCW) {
         bd_compute<KPT>(S, C, sl, pair, lds, wave);
+#ifdef BD_STAMPS
+        if (S.dbg && tid == 0) S.dbg[2 * blockIdx.x + 1] = wall_clock64();
+#endif
     } else {
         const int set = (wave - DF_NCW) / BD_WPS, w = (wave - DF_NCW) % BD_WPS;
         const int grp = bd_stream_group(pair, set, S.groups);
@@ -988,18 +1118,24 @@ __global__ void __launch_bounds__(BD_THREADS, BD_THREADS / 256) bwd_dataflow_ker
 }
 
 template <int KPT> size_t bd_lds_bytes() {
-    return (size_t)(DF_NLS * (BD_NSLOT * BdSlot<KPT>::words + DF_RB * 8 * 16) + BD_NLW + DF_NLS * DF_NCW + DF_NLS * DF_RB * 64 + 4) * 4 + 256;
+    return (size_t)(DF_NLS * (BD_NSLOT * BdSlot<KPT>::words + DF_RB * 8 * BD_RECW) + BD_NLW + DF_NLS * DF_NCW + DF_NLS * DF_RB * 64 + 4) * 4 + 256;
 }
 
 }  // namespace
 
+#ifdef BD_STAMPS
+static unsigned long long* g_bd_dbg = nullptr;
+static unsigned g_bd_dbg_role = 0;
+// (stamps build only: the buffer and the role - (set << 10) | (cell << 5) | slice - of the stamped workgroup)
+extern "C" void dagnn_debug_bwd_stamps(void* buf, unsigned role) { g_bd_dbg = (unsigned long long*)buf; g_bd_dbg_role = role; }
+#endif
 #ifdef BD_WIDE_TU
 constexpr int BD_TU_MAX_H = 320;   // csrc/bwd_dataflow_w.hip: the 8-wave workgroup shape of H = 320
 #else
 constexpr int BD_TU_MAX_H = 256;
 extern "C" size_t dagnn_bwd_dataflow_record_bytes(int64_t N) {
     if (N < 0) return 0;
-    return (size_t)2 * 16 * (4 * N + 4) * sizeof(int32_t);
+    return (size_t)2 * BD_RECW * (4 * N + 4) * sizeof(int32_t);
 }
 
 extern "C" size_t dagnn_bwd_dataflow_static_bytes(int64_t N) {
@@ -1023,8 +1159,15 @@ extern "C" int dagnn_bwd_dataflow_prepare(const dagnn_plan* pl, const dagnn_bwd_
     PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
     const DfLayout SL = df_layout_words(pl->N, pl->B, G);
     const int64_t nrec = 4 * pl->N + 4;
+    BdRecAlpha AL = {};
+    AL.Ls = Ls; AL.R = pl->num_edge_feats;
+    for (int d = 0; d < 2; ++d)
+        for (int i = 0; i < Ls; ++i) {
+            AL.alpha[d][i] = ((dir_mask >> d) & 1) ? a->cell[d][i].alpha : nullptr;
+            if (((dir_mask >> d) & 1) && !AL.alpha[d][i]) return DAGNN_EINVAL;
+        }
     hipLaunchKernelGGL(bd_records_kernel, dim3((unsigned)((nrec + 255) / 256), 2), dim3(256), 0, st, (const int32_t*)pl->data, L,
-                       (const int32_t*)a->schedule, SL, (int32_t*)a->records, nrec, G, (const int32_t*)a->plan_status);
+                       (const int32_t*)a->schedule, SL, (int32_t*)a->records, nrec, G, (const int32_t*)a->plan_status, AL);
     DAGNN_CHECK_LAUNCH();
     BdStatArgs A;
     A.ncell = 0; A.H = H; A.ld_h = a->ld_h; A.ld_g = a->ld_g;
@@ -1077,14 +1220,14 @@ extern "C" int dagnn_bwd_dataflow_run(const dagnn_plan* pl, const dagnn_bwd_data
             K.out_g = (gran_t*)c.da_granules; K.q_g = (gran_t*)c.q_granules;
             K.dgi_g = i > 0 ? (gran_t*)c.dgi_granules : nullptr;
             K.dgi = c.dgi; K.dgh = c.dgh; K.sig = c.sigma; K.mrel = pl->num_edge_feats > 0 ? c.edge_feat_grad : nullptr;
-            K.dir = d; K.kind = BD_DA; K.partner = i > 0 ? nc + 1 : -1;
+            K.dir = d; K.kind = BD_DA; K.partner = i > 0 ? nc + 1 : -1; K.layer = i;
             cells[nc++] = K;
             if (i > 0) {
                 BdCell U = {};
                 U.w = (const float4*)c.w_ih_t;
                 U.dgi_g = (gran_t*)c.dgi_granules;
                 U.out_g = (gran_t*)a->cell[d][i - 1].du_granules;
-                U.dir = d; U.kind = BD_DU; U.partner = -1;
+                U.dir = d; U.kind = BD_DU; U.partner = -1; U.layer = i;
                 cells[nc++] = U;
             }
         }
@@ -1098,7 +1241,7 @@ extern "C" int dagnn_bwd_dataflow_run(const dagnn_plan* pl, const dagnn_bwd_data
     PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
     const int64_t nrec = 4 * pl->N + 4;
     for (int d = 0; d < 2; ++d) {
-        S.gtab[d] = SL.gtab[d]; S.brec[d] = (int64_t)d * 16 * nrec;
+        S.gtab[d] = SL.gtab[d]; S.brec[d] = (int64_t)d * BD_RECW * nrec;
         S.col[d] = L.col[d]; S.eidx[d] = L.eidx[d]; S.eattr[d] = L.eattr[d];
     }
     S.ncell = nc; S.H = H; S.gld = a->gld; S.R = pl->num_edge_feats; S.groups = G; S.N = (int)pl->N;
@@ -1134,6 +1277,9 @@ extern "C" int dagnn_bwd_dataflow_run(const dagnn_plan* pl, const dagnn_bwd_data
                 }
         if (ok) { S.nroles = top; grid = (unsigned)top; }
     }
+#ifdef BD_STAMPS
+    S.dbg = g_bd_dbg; S.dbg_role = g_bd_dbg_role;
+#endif
     const int32_t* plan = (const int32_t*)pl->data;
 #define BD_LAUNCH(KPT)                                                                                                   \
     do {                                                                                                                 \

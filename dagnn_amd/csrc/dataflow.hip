@@ -310,8 +310,7 @@ constexpr int DF_GIRING = DF_NSLOT + DF_GD + 2;   // blocks in a stream's gi0 ri
 // deepest graph's group alone, 9 groups on 5 sets - 2.15 ms against 1.93: what binds the pass is the sets'
 // throughput, not that one chain.)
 __device__ __host__ __forceinline__ int df_stream_group(int pair, int set, int groups) {
-    const int g = DF_NLS * pair + set;
-    return g < groups ? g : -1;
+    return df_group_of_stream(pair, set, groups);
 }
 __host__ inline int df_sets_for(int groups) { return (groups + DF_NLS - 1) / DF_NLS; }
 

@@ -33,6 +33,19 @@ constexpr int DF_NLW = DF_NLW_V;                 // loader waves per workgroup (
 constexpr int DF_WPS = DF_NLW / DF_NLS;     // ... per stream
 constexpr int DF_RPW = DF_RB / DF_WPS;      // rows of a block per loader wave (one after the other)
 static_assert(DF_NLS == 2 || DF_NLS == 4 || DF_NLS == 8, "streams per workgroup");
+// group served by stream `set` of workgroup set `pair` (-1: none).  DF_PAIR_FOLD (two streams): the g-th deepest seed graph
+// shares its workgroups with the (G - 1 - g)-th instead of the (g + 1)-th (the LPT seeds group g with the g-th deepest graph)
+#ifndef DF_PAIR_FOLD
+#define DF_PAIR_FOLD 0
+#endif
+__device__ __host__ __forceinline__ int df_group_of_stream(int pair, int set, int groups) {
+    if (DF_PAIR_FOLD && DF_NLS == 2) {
+        const int g = set == 0 ? pair : groups - 1 - pair;
+        return (set == 0 || g > pair) ? g : -1;
+    }
+    const int g = DF_NLS * pair + set;
+    return g < groups ? g : -1;
+}
 constexpr int DF_THREADS = 64 * (DF_NCW * DF_TEAMS + DF_NLW);
 #ifndef DF_FMA_ROWS_V
 #define DF_FMA_ROWS_V 0

@@ -481,13 +481,19 @@ class DAGNN(nn.Module):
         out = self.dropout(out)
         if self.num_class > 0:
             return self.graph_pred_linear(out)
-        if self.num_vocab > 1 and self.max_seq_len > 1 and not torch.is_grad_enabled():
+        if self.num_vocab > 1 and self.max_seq_len > 1:
             # the S vocabulary heads as ONE library GEMM over the concatenated weights (dagnn.py:212-215);
-            # the list entries are views of its output
+            # the list entries are views of its output.  With gradients (round 4): the concatenation is taken from the
+            # live parameters inside the graph, so the backward pass is two GEMMs instead of ten and every head's
+            # weight gradient is a slice of one product (S = 5: 15 launches of ~25 us -> 3 of ~35)
             heads = list(self.graph_pred_linear_list)
-            wcat, bcat = self._head_cache.get([p for hd in heads for p in (hd.weight, hd.bias)],
-                                              lambda: (torch.cat([hd.weight for hd in heads], 0),
-                                                       torch.cat([hd.bias for hd in heads], 0)), fresh=self.training)
+            if torch.is_grad_enabled():
+                wcat = torch.cat([hd.weight for hd in heads], 0)
+                bcat = torch.cat([hd.bias for hd in heads], 0)
+            else:
+                wcat, bcat = self._head_cache.get([p for hd in heads for p in (hd.weight, hd.bias)],
+                                                  lambda: (torch.cat([hd.weight for hd in heads], 0),
+                                                           torch.cat([hd.bias for hd in heads], 0)), fresh=self.training)
             logits = torch.addmm(bcat, out, wcat.t())
             return list(logits.split(self.num_vocab, dim=1))
         return [self.graph_pred_linear_list[i](out) for i in range(self.max_seq_len)]

@@ -60,6 +60,31 @@ constexpr int BD_RD = 6;             // a loader wave requests a record this man
 //   [0..3] v, first / last CSR slot of v's row in direction 1 - d, 0     [4..7] first four successors   [8..11] their edge ids
 //   [16..19] / [20..23] first / second edge feature of those edges       [24 + 4 i + e] alpha of edge e in stacked layer i
 constexpr int BD_RECW = 64;
+// who stores a row's outputs (0: the compute wave of the row, after its own granule store; 1: the row's loader wave, behind the
+// ready flag).  A loader row is ~2.4 us of single-wave issue without them, a block costs the compute waves ~1.05 us and they
+// serve two streams: the split that balances the two depends on the workgroup shape (measured per translation unit)
+#ifndef BD_Q_LOADER
+#define BD_Q_LOADER 1      // q_v: in the compute wave it sits in front of the products, i.e. on the dependent chain of slice 0
+#endif
+#ifndef BD_GRAN_LOADER
+#define BD_GRAN_LOADER (BD_WPS_V == 4)   // (the 12-wave shape of H <= 256: its compute waves serve two streams and are the scarcer resource)
+#endif
+#ifndef BD_PLAIN_LOADER
+#define BD_PLAIN_LOADER (BD_WPS_V == 4)
+#endif
+// compute waves, measured per workgroup shape (scripts/abt.sh): the flag look as one trip to LDS, the slot's output values read
+// with the operands (before the node ids are known), the z (.) G term read without waiting for the ids - all three help the
+// 12-wave shape of H <= 256 (1.50 -> 1.47 ms) and cost the 8-wave shape of H = 320 (2.94 -> 3.11 ms)
+#ifndef BD_LEAN_LOOK
+#define BD_LEAN_LOOK (BD_WPS_V == 4)
+#endif
+#ifndef BD_EAGER_OUT
+#define BD_EAGER_OUT (BD_WPS_V == 4)
+#endif
+#ifndef BD_IDS_FIRST
+#define BD_IDS_FIRST (BD_WPS_V != 4)
+#endif
+constexpr int BD_SCAL_SL = 1;        // slice whose compute waves store sigma_v and the edge-feature sums (slice 0 stores q_v)
 enum { BD_DA = 0, BD_DU = 1 };
 enum { ST_GEXT = 0, ST_H = 1, ST_CR = 2, ST_CZ = 3, ST_CNR = 4, ST_CN = 5, ST_Z = 6, ST_CQ = 7 };
 
@@ -122,7 +147,10 @@ template <int KPT> struct BdSlot {
     static constexpr int AP = BdPad<KPT>::row;
     static constexpr int op_off = 0;                          // [3][RB][AP] operand rows: gate block g of row r at (g * RB + r) * AP
     static constexpr int zg_off = 3 * DF_RB * AP;             // [RB][32]    z (.) G of the slice's units
-    static constexpr int v_off = zg_off + DF_RB * DF_JS;      // [RB] ints
+    static constexpr int dn_off = zg_off + DF_RB * DF_JS;     // [RB][32]    c_n (.) G of the slice's units (the n block of dgi)
+    static constexpr int qp_off = dn_off + DF_RB * DF_JS;     // [RB][64]    per-lane parts of q_v = G_v . c_q,v (slice 0)
+    static constexpr int sc_off = qp_off + DF_RB * 64;        // [RB][4]     sigma_v and the two edge-feature sums (slice 1)
+    static constexpr int v_off = sc_off + DF_RB * 4;          // [RB] ints
     static constexpr int words = v_off + 4;
 };
 
@@ -435,12 +463,6 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
     const gran_t* const du_in = C.du_in;
     const float* const stat = C.stat;
     const float* const alpha = C.alpha;
-    gran_t* const q_out = C.q_g;
-    gran_t* const dgi_g = C.dgi_g;
-    float* const dgi = C.dgi;
-    float* const dgh = C.dgh;
-    float* const sig_out = C.sig;
-    float* const mrel = C.mrel;
     int* const dn = lds.dn + set * DF_NCW;
     constexpr int NC = NQ4 > 4 ? NQ4 : 4;   // column blocks a lane carries
     constexpr int SREC = bd_stat_floats(H);
@@ -487,21 +509,18 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
     // the slice's share of a full row in the loader's column layout: units [32 sl, 32 sl + 32) = column block q = sl / 2,
     // lanes [32 (sl & 1), + 32)
     const bool local_st = lds.local[0] != 0;
+    (void)local_st;
     const int myq = __builtin_amdgcn_readfirstlane(sl >> 1), odd = __builtin_amdgcn_readfirstlane(sl & 1);
     const bool mine = (lane >> 5) == odd;
-    const unsigned myq512 = 512u * (unsigned)myq;
     // the slice's column block of a row array.  (As `myq == q ? a[q] : r` the compiler turns the chain into a dynamically indexed
     // array in SCRATCH memory - five round trips to memory per row, two of them in front of the ready flag: v_cndmask by hand.)
     // (the lane masks are made per row from the 32-bit `myq` / `odd`: 64-bit masks kept across the sweep end up parked in VGPRs)
-    unsigned long long pmask[5], mine_mask;
-    unsigned mask_sh;
+    unsigned long long pmask[5];
     auto make_masks = [&]() {
         asm volatile("s_cmp_eq_u32 %[q], 1\n\ts_cselect_b64 %[p1], -1, 0\n\ts_cmp_eq_u32 %[q], 2\n\ts_cselect_b64 %[p2], -1, 0\n\t"
-                     "s_cmp_eq_u32 %[q], 3\n\ts_cselect_b64 %[p3], -1, 0\n\ts_cmp_eq_u32 %[q], 4\n\ts_cselect_b64 %[p4], -1, 0\n\t"
-                     "s_lshl_b32 %[sh], %[o], 5\n\ts_bfm_b64 %[mm], 32, %[sh]"
-                     : [p1] "=&s"(pmask[1]), [p2] "=&s"(pmask[2]), [p3] "=&s"(pmask[3]), [p4] "=&s"(pmask[4]), [mm] "=&s"(mine_mask),
-                       [sh] "=&s"(mask_sh)
-                     : [q] "s"(myq), [o] "s"(odd) : "scc");
+                     "s_cmp_eq_u32 %[q], 3\n\ts_cselect_b64 %[p3], -1, 0\n\ts_cmp_eq_u32 %[q], 4\n\ts_cselect_b64 %[p4], -1, 0"
+                     : [p1] "=&s"(pmask[1]), [p2] "=&s"(pmask[2]), [p3] "=&s"(pmask[3]), [p4] "=&s"(pmask[4])
+                     : [q] "s"(myq) : "scc");
     };
     auto pick = [&](const float (&a)[NC]) -> float {
         float r = a[0];
@@ -679,46 +698,53 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                 op[DF_RB * Slot::AP + cpos[q]] = dz[q];
                 op[2 * DF_RB * Slot::AP + cpos[q]] = dnr[q];
             }
-            if (mine) sbase[Slot::zg_off + lw * DF_JS + (lane & 31)] = pick(zg);
+            if (mine) {
+                sbase[Slot::zg_off + lw * DF_JS + (lane & 31)] = pick(zg);
+                sbase[Slot::dn_off + lw * DF_JS + (lane & 31)] = pick(dnn);
+            }
             v_s[lw] = v;   // (every lane: same word, same value)
-            // what the outputs behind the flag need, reduced to scalars now (the row arrays die here)
-            const float mr = pick(dr), mz = pick(dz), mn = pick(dnn), mnr = pick(dnr);
-            float qd = G[0] * ST[ST_CQ].x;
+            // The row's outputs to memory (q, sigma, the edge-feature sums, the slice's columns of dgi / dgh) are the COMPUTE
+            // waves' job (round 4: a row costs its loader wave ~3 us of single-wave instruction issue, the compute waves idle
+            // two thirds of the sweep): compute wave r stores row r, from the operand rows it reads anyway + what follows
+            float qd = G[0] * ST[ST_CQ].x;   // q_v = G_v . c_q,v: the per-lane parts
             if (NQ4 > 1) qd = fmaf(G[1], ST[ST_CQ].y, qd);
             if (NQ4 > 2) qd = fmaf(G[2], ST[ST_CQ].z, qd);
             if (NQ4 > 3) qd = fmaf(G[3], ST[ST_CQ].w, qd);
             if (NQ4 > 4) qd = fmaf(G[4], ST5[ST_CQ], qd);
-            // the compute waves need nothing but the LDS slot: the last row of the wave raises the flag BEFORE the row's
-            // outputs to memory (q for the predecessors' pulls first, then the dgi granules, then the plain rows the weight-
-            // gradient epilogue reads)
+            if (!BD_Q_LOADER && sl == 0) sbase[Slot::qp_off + lw * 64 + lane] = qd;
+#if BD_GRAN_LOADER || BD_PLAIN_LOADER
+            const float mr = pick(dr), mz = pick(dz), mn = pick(dnn);
+#endif
+#if BD_PLAIN_LOADER
+            const float mnr = pick(dnr);
+#endif
+            if (sl == BD_SCAL_SL) {   // (every lane: same words, same values)
+                float* sc = sbase + Slot::sc_off + lw * 4;
+                sc[0] = sig; sc[1] = m0; sc[2] = m1;
+            }
             if (rr == BD_RPW - 1) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 bd_flag_st(lds.rdy + set * BD_WPS + w, b + 1);
             }
             BD_STAMP(prof, b, set, 5);   // flag raised
-            if (sl == 0) {   // q_v = G_v . c_q,v; the row's scalar outputs
+            if (BD_Q_LOADER && sl == 0) {   // (next to the compute waves' products: off the dependent chain)
                 qd = bd_wave_sum(qd);
                 if (lane == 0) {
-                    if (local_st) q_out[v] = gran_pack(epoch, qd);
-                    else __hip_atomic_store(q_out + v, gran_pack(epoch, qd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    sig_out[v] = sig;
-                    int Rf;   // (compared on the spot, see the note at the loads)
-                    asm volatile("s_mov_b32 %0, %1" : "=s"(Rf) : "s"(R));
-                    if (Rf >= 1) mrel[(int64_t)v * Rf] = m0;
-                    if (Rf >= 2) mrel[(int64_t)v * Rf + 1] = m1;
+                    if (local_st) C.q_g[v] = gran_pack(epoch, qd);
+                    else __hip_atomic_store(C.q_g + v, gran_pack(epoch, qd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            {   // the slice's 32 columns of dgi (granules for the input-gradient cell + plain) and dgh (plain): row bases in
-                // SGPRs (v is uniform), ONE per-lane byte offset, the half-wave that owns the columns under an exec mask - as
-                // C++ the compiler keeps three per-lane 64-bit base pointers alive across the sweep (and spills them)
-                const char* og = reinterpret_cast<const char*>(dgi) + (uint64_t)(unsigned)v * (unsigned)(3 * H * 4);
-                const char* oh = reinterpret_cast<const char*>(dgh) + (uint64_t)(unsigned)v * (unsigned)(3 * H * 4);
-                unsigned long long keep_e;
-                unsigned c8;   // byte offsets of column 32 sl + (lane & 31) = 64 myq + lane in a granule / plain row, made per row
-                asm volatile("v_add_u32 %0, %1, %2" : "=v"(c8) : "v"(lane8), "s"(myq512));
-                const unsigned c4 = c8 >> 1;
-                if (dgi_g) {
-                    const char* pg0 = reinterpret_cast<const char*>(dgi_g) + (uint64_t)((unsigned)v * (unsigned)(3 * gld)) * 8u;
+#if BD_GRAN_LOADER || BD_PLAIN_LOADER
+            {   // the slice's 32 columns: row bases in SGPRs (v is uniform), ONE per-lane byte offset, the half-wave that owns the
+                // columns under an exec mask - as C++ the compiler keeps per-lane 64-bit base pointers alive across the sweep
+                unsigned long long keep_e, mine_mask;
+                unsigned c8, msh;   // byte offset of column 32 sl + (lane & 31) = 64 myq + lane in a granule row, made per row
+                asm volatile("v_lshl_add_u32 %[c8], %[q], 9, %[l8]\n\ts_lshl_b32 %[sh], %[o], 5\n\ts_bfm_b64 %[mm], 32, %[sh]"
+                             : [c8] "=&v"(c8), [mm] "=&s"(mine_mask), [sh] "=&s"(msh) : [l8] "v"(lane8), [q] "s"(myq), [o] "s"(odd));
+                (void)msh;
+#if BD_GRAN_LOADER
+                if (C.dgi_g) {
+                    const char* pg0 = reinterpret_cast<const char*>(C.dgi_g) + (uint64_t)((unsigned)v * (unsigned)(3 * gld)) * 8u;
                     const char* pg1 = pg0 + (uint64_t)(unsigned)gld * 8u;
                     const char* pg2 = pg1 + (uint64_t)(unsigned)gld * 8u;
                     const gran_t g0 = gran_pack(epoch, mr), g1 = gran_pack(epoch, mz), g2 = gran_pack(epoch, mn);
@@ -737,6 +763,11 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                                      : [mm] "s"(mine_mask), [c8] "v"(c8), [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [p0] "s"(pg0), [p1] "s"(pg1), [p2] "s"(pg2)
                                      : "memory");
                 }
+#endif
+#if BD_PLAIN_LOADER
+                const char* og = reinterpret_cast<const char*>(C.dgi) + (uint64_t)(unsigned)v * (unsigned)(3 * H * 4);
+                const char* oh = reinterpret_cast<const char*>(C.dgh) + (uint64_t)(unsigned)v * (unsigned)(3 * H * 4);
+                const unsigned c4 = c8 >> 1;
                 asm volatile("s_mov_b64 %[ke], exec\n\ts_mov_b64 exec, %[mm]\n\t"
                              "global_store_dword %[c4], %[mr], %[og]\n\tglobal_store_dword %[c4], %[mz], %[og] offset:%[h1]\n\t"
                              "global_store_dword %[c4], %[mn], %[og] offset:%[h2]\n\t"
@@ -746,7 +777,9 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                              : [mm] "s"(mine_mask), [c4] "v"(c4), [mr] "v"(mr), [mz] "v"(mz), [mn] "v"(mn), [mnr] "v"(mnr),
                                [og] "s"(og), [oh] "s"(oh), [h1] "n"(4 * H), [h2] "n"(8 * H)
                              : "memory");
+#endif
             }
+#endif
             BD_STAMP(prof, b, set, 6);   // row outputs issued
         } else {
             glds4(ra, rl);   // an idle row keeps the record ring moving
@@ -940,6 +973,14 @@ __device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int
     const int gld = S.gld, num_nodes = S.N;
     const bool local_st = is_da && lds.local[0] != 0;
 
+    // where this lane finds its output values of row cw inside a slot (the third value: the c_n block for the dgi half-wave,
+    // gate block 2 of the operand rows for the dgh half-wave; both advance by a constant per row)
+    const int out_col = sl * DF_JS + (lane & 31);
+    const int out_pos = out_col + (SEG - KP8) * (out_col / KP8);
+    const int out_third = lane < 32 ? Slot::dn_off + (lane & 31) : Slot::op_off + 2 * DF_RB * Slot::AP + out_pos;
+    const int out_third_step = lane < 32 ? DF_JS : Slot::AP;
+    const int R = C.mrel ? S.R : 0;
+
     int done[DF_NLS];
     int left = 0, pref = 0;
 #pragma unroll
@@ -950,6 +991,43 @@ __device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int
     while (left > 0) {
         int st = -1;
         unsigned spins = 0;
+        if (BD_LEAN_LOOK && DF_NLS == 2) {
+            // (dataflow.hip's compute waves: the smallest positive lead first, ties alternate - ONE trip to LDS per look, the
+            // ready flags of both streams behind one wait, the rest scalar)
+            typedef int i4v __attribute__((ext_vector_type(4)));
+            const unsigned rdy_a = (unsigned)(uintptr_t)lds.rdy;
+            for (;;) {
+                int m0, m1;
+                if (BD_WPS == 4) {
+                    i4v r0, r1;
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(r0), "=&v"(r1) : "v"(rdy_a) : "memory");
+                    m0 = __builtin_amdgcn_readfirstlane(min(min(r0.x, r0.y), min(r0.z, r0.w)));
+                    m1 = __builtin_amdgcn_readfirstlane(min(min(r1.x, r1.y), min(r1.z, r1.w)));
+                } else {
+                    i4v r0;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0) : "v"(rdy_a) : "memory");
+                    m0 = __builtin_amdgcn_readfirstlane(min(r0.x, r0.y));
+                    m1 = __builtin_amdgcn_readfirstlane(min(r0.z, r0.w));
+                }
+                const int l0 = done[0] < nb[0] ? m0 - done[0] : 0, l1 = done[DF_NLS - 1] < nb[DF_NLS - 1] ? m1 - done[DF_NLS - 1] : 0;
+                if (l0 > 0 || l1 > 0) {
+                    st = l0 <= 0 ? 1 : (l1 <= 0 ? 0 : (l0 != l1 ? (l0 < l1 ? 0 : 1) : pref));
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                bool give_up = false;
+                if (++spins > 4 * spin_limit) {
+                    __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    give_up = true;
+                }
+                if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = true;
+                if (give_up) {
+                    st = done[0] < nb[0] ? 0 : 1;
+                    break;
+                }
+            }
+        } else
         for (;;) {
             int best = 0x7fffffff;
 #pragma unroll
@@ -984,11 +1062,37 @@ __device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int
         BD_STAMP(prof, b, st, 9);   // block seen
         const int slot = b % BD_NSLOT;
         const float* sbase = lds.ring + (st * BD_NSLOT + slot) * Slot::words;
+        // every read of the slot leaves in one go: nothing in front of the products depends on the node ids (the values
+        // read for rows that turn out idle are never stored)
         const int4 ids = *reinterpret_cast<const int4*>(sbase + Slot::v_off);
-        const int nr = (ids.x >= 0) + (ids.y >= 0) + (ids.z >= 0) + (ids.w >= 0);   // live records come first
         const float* a_seg = sbase + Slot::op_off + x * Slot::AP + ks * SEG;   // gate block 0, row x, K slice ks
-        float zgv = 0.f;
-        if (is_da && gr < nr) zgv = sbase[Slot::zg_off + gr * DF_JS + unit_l];
+        float zgv = 0.f;   // (input-gradient cells: no such term)
+#if BD_IDS_FIRST
+        const int nr0 = (ids.x >= 0) + (ids.y >= 0) + (ids.z >= 0) + (ids.w >= 0);
+        if (is_da && gr < nr0) zgv = sbase[Slot::zg_off + gr * DF_JS + unit_l];
+#else
+        if (is_da) zgv = sbase[Slot::zg_off + gr * DF_JS + unit_l];
+#endif
+        // row `cw` of the block is this wave's to store (see the loader): lanes 0..31 hold the slice's columns of dgi
+        // (c_r G, c_z G, c_n G), lanes 32..63 those of dgh (c_r G, c_z G, c_nr G); slice 0: the parts of q; slice 1: the scalars
+        float o_r = 0.f, o_z = 0.f, o_3 = 0.f, o_q = 0.f, o_s = 0.f;
+        if (!(BD_PLAIN_LOADER && BD_GRAN_LOADER) && (BD_EAGER_OUT || (is_da && (unsigned)(cw == 0 ? ids.x : (cw == 1 ? ids.y : (cw == 2 ? ids.z : ids.w))) < (unsigned)num_nodes))) {
+            o_r = sbase[Slot::op_off + cw * Slot::AP + out_pos];
+            o_z = sbase[Slot::op_off + (DF_RB + cw) * Slot::AP + out_pos];
+            o_3 = sbase[out_third + cw * out_third_step];
+        }
+        if (!BD_Q_LOADER && sl == 0) o_q = sbase[Slot::qp_off + cw * 64 + lane];
+        if (sl == BD_SCAL_SL) o_s = sbase[Slot::sc_off + cw * 4 + (lane & 3)];
+        {   // (BD_Q_LOADER = 0) q_v first: the predecessors' pulls poll it next to the da row this block produces
+            const int qrow_v = cw == 0 ? ids.x : (cw == 1 ? ids.y : (cw == 2 ? ids.z : ids.w));
+            if (!BD_Q_LOADER && is_da && sl == 0 && (unsigned)qrow_v < (unsigned)num_nodes) {
+                const float qv = bd_wave_sum(o_q);
+                if (lane == 0) {
+                    if (local_st) C.q_g[qrow_v] = gran_pack(epoch, qv);
+                    else __hip_atomic_store(C.q_g + qrow_v, gran_pack(epoch, qv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
         float gsum;
         {
             bf4 acc[3] = {(bf4){0.f, 0.f, 0.f, 0.f}, (bf4){0.f, 0.f, 0.f, 0.f}, (bf4){0.f, 0.f, 0.f, 0.f}};
@@ -1018,6 +1122,9 @@ __device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int
             const float f = s1 ? f1 : f0;
             gsum = bd_row_pair_sum(f);
         }
+        const int nr = (ids.x >= 0) + (ids.y >= 0) + (ids.z >= 0) + (ids.w >= 0);   // live records come first
+        const int row_v = cw == 0 ? ids.x : (cw == 1 ? ids.y : (cw == 2 ? ids.z : ids.w));
+        const bool row_live = is_da && cw < nr && (unsigned)row_v < (unsigned)num_nodes;
         int gv = gr == 0 ? ids.x : (gr == 1 ? ids.y : (gr == 2 ? ids.z : ids.w));
         const bool live = gr < nr && (unsigned)gv < (unsigned)num_nodes && (lane & 16) == 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1025,6 +1132,32 @@ __device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int
         if (live) {
             if (local_st) out_g[(int64_t)gv * gld + unit] = gran_pack(epoch, gsum + zgv);
             else __hip_atomic_store(out_g + (int64_t)gv * gld + unit, gran_pack(epoch, gsum + zgv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (row_live) {   // off the dependent chain: the plain rows the weight-gradient epilogue reads, dgi also as granules
+            if (!BD_PLAIN_LOADER) {
+                float* o = (lane < 32 ? C.dgi : C.dgh) + (int64_t)row_v * (3 * H) + out_col;
+                o[0] = o_r; o[H] = o_z; o[2 * H] = o_3;
+            }
+            if (!BD_GRAN_LOADER && C.dgi_g && lane < 32) {
+                gran_t* pg = C.dgi_g + (int64_t)row_v * (3 * gld) + out_col;
+                if (local_st) {   // (readers on this XCD: the lines stay in its L2)
+                    pg[0] = gran_pack(epoch, o_r); pg[gld] = gran_pack(epoch, o_z); pg[2 * gld] = gran_pack(epoch, o_3);
+                } else {
+                    __hip_atomic_store(pg, gran_pack(epoch, o_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(pg + gld, gran_pack(epoch, o_z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(pg + 2 * gld, gran_pack(epoch, o_3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (sl == BD_SCAL_SL) {
+                const int o_si = __float_as_int(o_s);
+                const float s_sig = __int_as_float(__builtin_amdgcn_readlane(o_si, 0)), s_m0 = __int_as_float(__builtin_amdgcn_readlane(o_si, 1)),
+                            s_m1 = __int_as_float(__builtin_amdgcn_readlane(o_si, 2));
+                if (lane == 0) {
+                    C.sig[row_v] = s_sig;
+                    if (R >= 1) C.mrel[(int64_t)row_v * R] = s_m0;
+                    if (R >= 2) C.mrel[(int64_t)row_v * R + 1] = s_m1;
+                }
+            }
         }
         BD_STAMP(prof, b, st, 11);   // stores issued
     }

@@ -388,13 +388,14 @@ struct BdSweep {
     "global_load_dword %[t6], %[vt], %[sc] offset:1536\n\t"           \
     "global_load_dword %[t7], %[vt], %[sc] offset:1792\n\t"           \
     BD_STAT_1
-#define BD_ROW_OUTS                                                                                                         \
-                   [x00] "=v"(W.x[0][0]), [x01] "=v"(W.x[0][1]), [x02] "=v"(W.x[0][2]), [x03] "=v"(W.x[0][3]),              \
-                   [x10] "=v"(W.x[1][0]), [x11] "=v"(W.x[1][1]), [x12] "=v"(W.x[1][2]), [x13] "=v"(W.x[1][3]),              \
-                   [x20] "=v"(W.x[2][0]), [x21] "=v"(W.x[2][1]), [x22] "=v"(W.x[2][2]), [x23] "=v"(W.x[2][3]),              \
-                   [x30] "=v"(W.x[3][0]), [x31] "=v"(W.x[3][1]), [x32] "=v"(W.x[3][2]), [x33] "=v"(W.x[3][3]),              \
-                   [q0] "=v"(W.q[0]), [q1] "=v"(W.q[1]), [q2] "=v"(W.q[2]), [q3] "=v"(W.q[3]),                              \
-                   [u0] "=v"(W.u[0]), [u1] "=v"(W.u[1]), [u2] "=v"(W.u[2]), [u3] "=v"(W.u[3]), [vz] "=&v"(tmp_vz)
+#define BD_ROW_OUTS_C(CS)                                                                                                        \
+                   [x00] CS(W.x[0][0]), [x01] CS(W.x[0][1]), [x02] CS(W.x[0][2]), [x03] CS(W.x[0][3]),              \
+                   [x10] CS(W.x[1][0]), [x11] CS(W.x[1][1]), [x12] CS(W.x[1][2]), [x13] CS(W.x[1][3]),              \
+                   [x20] CS(W.x[2][0]), [x21] CS(W.x[2][1]), [x22] CS(W.x[2][2]), [x23] CS(W.x[2][3]),              \
+                   [x30] CS(W.x[3][0]), [x31] CS(W.x[3][1]), [x32] CS(W.x[3][2]), [x33] CS(W.x[3][3]),              \
+                   [q0] CS(W.q[0]), [q1] CS(W.q[1]), [q2] CS(W.q[2]), [q3] CS(W.q[3]),                              \
+                   [u0] CS(W.u[0]), [u1] CS(W.u[1]), [u2] CS(W.u[2]), [u3] CS(W.u[3]), [vz] "=&v"(tmp_vz)
+#define BD_ROW_OUTS BD_ROW_OUTS_C("=v")
 #define BD_ROW_INS                                                                                                          \
                    [vo] "v"(lane8), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),                \
                    [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [c3] "s"(c3p), [ub] "s"(ub),                                \
@@ -408,9 +409,13 @@ struct BdSweep {
                  : BD_ROW_INS, [sa] "s"(sa), [sb] "s"(sb), [rl] "s"(rl), [ra] "s"(ra), [pa] "s"(pa),          \
                    [pl] "s"(pl)                                                                               \
                  : "memory")
+// (a poll keeps the sweep in the registers it arrived in: in / out operands, see DF_TRIP in dataflow.hip)
 #define BD_TRIP_POLL(n_, du_)                                                                                               \
     asm volatile(BD_ROWS_##n_ BD_DU_##du_ "s_waitcnt vmcnt(0)" : BD_ROW_OUTS : BD_ROW_INS : "memory")
-#define BD_ROW_OUTS5 BD_ROW_OUTS, [x04] "=v"(W.x[0][4]), [x14] "=v"(W.x[1][4]), [x24] "=v"(W.x[2][4]), [x34] "=v"(W.x[3][4]), [u4] "=v"(W.u[4])
+#define BD_TRIP_REPOLL(n_, du_)                                                                                             \
+    asm volatile(BD_ROWS_##n_ BD_DU_##du_ "s_waitcnt vmcnt(0)" : BD_ROW_OUTS_C("+v") : BD_ROW_INS : "memory")
+#define BD_ROW_OUTS5_C(CS) BD_ROW_OUTS_C(CS), [x04] CS(W.x[0][4]), [x14] CS(W.x[1][4]), [x24] CS(W.x[2][4]), [x34] CS(W.x[3][4]), [u4] CS(W.u[4])
+#define BD_ROW_OUTS5 BD_ROW_OUTS5_C("=v")
 #define BD_TRIP_FIRST5(n_, du_)                                                                                             \
     asm volatile(BD_ROWS5_##n_ BD_DU5_##du_ BD_STAT5_1                                                                      \
                  : BD_ROW_OUTS5,                                                                                            \
@@ -424,11 +429,13 @@ struct BdSweep {
                  : "memory")
 #define BD_TRIP_POLL5(n_, du_)                                                                                              \
     asm volatile(BD_ROWS5_##n_ BD_DU5_##du_ "s_waitcnt vmcnt(0)" : BD_ROW_OUTS5 : BD_ROW_INS : "memory")
+#define BD_TRIP_REPOLL5(n_, du_)                                                                                            \
+    asm volatile(BD_ROWS5_##n_ BD_DU5_##du_ "s_waitcnt vmcnt(0)" : BD_ROW_OUTS5_C("+v") : BD_ROW_INS : "memory")
 #define BD_SEL1(n_, du_) if constexpr (NN == (n_) && DUK == (du_)) {                                                          \
-        if constexpr (NQ4 == 5) { if constexpr (FST) BD_TRIP_FIRST5(n_, du_); else BD_TRIP_POLL5(n_, du_); }                \
-        else { if constexpr (FST) BD_TRIP_FIRST(n_, du_); else BD_TRIP_POLL(n_, du_); } } else
+        if constexpr (NQ4 == 5) { if constexpr (FST == 1) BD_TRIP_FIRST5(n_, du_); else if constexpr (FST == 2) BD_TRIP_REPOLL5(n_, du_); else BD_TRIP_POLL5(n_, du_); } \
+        else { if constexpr (FST == 1) BD_TRIP_FIRST(n_, du_); else if constexpr (FST == 2) BD_TRIP_REPOLL(n_, du_); else BD_TRIP_POLL(n_, du_); } } else
 #define BD_SELS(n_) BD_SEL1(n_, 0) BD_SEL1(n_, 1)
-#define BD_TRIP_SEL(nn_, du_, fst_) do { constexpr int DUK = (du_); constexpr bool FST = (fst_) != 0; (void)DUK; (void)FST;         \
+#define BD_TRIP_SEL(nn_, du_, fst_) do { constexpr int DUK = (du_); constexpr int FST = (fst_); (void)DUK; (void)FST;   /* 1 first trip of a row, 2 re-poll, 0 first poll of a later chunk */ \
         BD_SELS(0) BD_SELS(1) BD_SELS(2) BD_SELS(3) BD_SELS(4) {} } while (0)
 #define BD_CASE(n_, du_) case (n_) * 2 + (du_):                                                                             \
         if constexpr (NQ4 == 5) { if (stat_pending) BD_TRIP_FIRST5(n_, du_); else BD_TRIP_POLL5(n_, du_); }                 \
@@ -625,13 +632,16 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
 #endif
                 if (NN + DU > 0 && !landed()) {
                     unsigned spins = 0;
+                    // (a lost pass leaves the loop BEHIND its trip: with a way out in front of it the rows of the previous
+                    // trip stay live across the statement and the register allocator copies the whole sweep every turn)
+                    bool more;
                     do {
-                        if (!bd_retry(spins, err, spin_limit)) break;
+                        more = bd_retry(spins, err, spin_limit);
 #ifdef BD_STAMPS
                         t_issue = wall_clock64(); ++npoll;
 #endif
                         BD_TRIP_SEL(NN, DU, 0);
-                    } while (!landed());
+                    } while (more && !landed());
                 }
 #ifdef BD_STAMPS
                 if (FIRST) { BD_STAMP(prof, b, set, 3); BD_STAMP_V(prof, b, set, 7, t_issue); }   // the successors' rows are here; when the winning poll was issued

@@ -921,11 +921,14 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
                 df_trip<NQ4, H, NN, PPK, DM>(A, T, lane8, lane31x8);
                 if (NN + PPK > 0 && !df_landed<NN, PPK, NQ4>(A, epoch)) {
                     unsigned spins = 0;
+                    // (a lost pass leaves the loop BEHIND its trip: with a way out in front of it the rows of the previous trip
+                    // stay live across the statement and the register allocator copies the whole sweep on every turn)
+                    bool more;
                     do {
-                        if (!df_retry(spins, err, spin_limit)) break;
+                        more = df_retry(spins, err, spin_limit);
                         if (prof) { t_issue = wall_clock64(); ++polls; }
                         df_trip<NQ4, H, NN, PPK, 0>(A, T, lane8, lane31x8);
-                    } while (!df_landed<NN, PPK, NQ4>(A, epoch));
+                    } while (more && !df_landed<NN, PPK, NQ4>(A, epoch));
                 }
                 if (prof && DM != 0) {
                     dbg[8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64(); dbg[8 * (int64_t)(DF_NLS * b + set) + 6] = polls;

@@ -26,7 +26,10 @@
 //                   contiguous 8 KB record of dagnn_bwd_dataflow_prepare), poll the successors' da rows + q scalars (and
 //                   the node's du row), pull, coefficients -> dgh into the stream's LDS ring slot (3 operand rows), zg
 //                   slice; its slice of dgi / dgh to memory (the weight-gradient epilogue reads them), dgi also as
-//                   granules for the input-gradient cell; slice 0 publishes q_v, sigma_v and the edge-feature sums;
+//                   granules for the input-gradient cell; slice 0 publishes q_v.  (Round 4: the row's outputs can ride
+//                   the LDS slot to compute wave r instead - BD_*_LOADER, chosen per workgroup shape; sigma_v and the
+//                   edge-feature sums always leave through slice 1's compute waves.)  A row's edge scalars (alpha of every
+//                   stacked layer, the edge features of its first four successors) come with its 64-word record;
 //   loader wave (du cell)  polls the dgi granules of the node, no arithmetic;
 //   compute wave    v_mfma_f32_4x4x1 products exactly as in dataflow.hip (A = resident weights, B = the block's operand
 //                   rows), the three gate accumulators summed BEFORE the K reduce-scatter, + zg, granule store.

@@ -429,16 +429,31 @@ class DAGNN(nn.Module):
                     h[d][i] = flat[q * L + i]
             if fused_readout:
                 G.h = [[h[d][i] for i in range(L)] for d in dirs]
-                out = self.dropout(res[0])
-                if self.num_class > 0:
-                    return self.graph_pred_linear(out)
-                return [self.graph_pred_linear_list[i](out) for i in range(self.max_seq_len)]
+                return self._heads(self.dropout(res[0]))
             return self._finish(G, plan, x, h, B)
         cells = self._cells()
         sscore = self._static_scores(x, cells)
         h = run_stack(plan, x, cells, dirs, L, H, schedule=self.schedule, static_score=sscore,
                       arena=self._arena_for(x))
         return self._finish(G, plan, x, h, B)
+
+    def _heads(self, out):
+        """The prediction heads on the pooled graph vectors (dagnn.py:204-215)."""
+        if self.num_class > 0:
+            return self.graph_pred_linear(out)
+        if self.num_vocab > 1 and self.max_seq_len > 1 and not torch.is_grad_enabled():
+            # the S vocabulary heads as ONE library GEMM over the concatenated weights (dagnn.py:212-215);
+            # the list entries are views of its output.  (Under autograd the heads stay S separate Linear calls: the
+            # concatenation inside the graph - one forward GEMM, two backward - bought nothing end to end, 5.52 against
+            # 5.49 ms per training step with F.linear, 7.1 ms with addmm on the transposed view: that part of the step is
+            # bound by the host's launch rate, not by the fifteen 25-us GEMMs.)
+            heads = list(self.graph_pred_linear_list)
+            wcat, bcat = self._head_cache.get([p for hd in heads for p in (hd.weight, hd.bias)],
+                                              lambda: (torch.cat([hd.weight for hd in heads], 0),
+                                                       torch.cat([hd.bias for hd in heads], 0)), fresh=self.training)
+            logits = torch.addmm(bcat, out, wcat.t())
+            return list(logits.split(self.num_vocab, dim=1))
+        return [self.graph_pred_linear_list[i](out) for i in range(self.max_seq_len)]
 
     def _finish(self, G, plan, x, h, B):
         """Read-out + heads (dagnn.py:184-215) on the states h[d][i]."""
@@ -478,22 +493,4 @@ class DAGNN(nn.Module):
             if not hip_pool:
                 out = self._pool(G.h, G.batch, B)
 
-        out = self.dropout(out)
-        if self.num_class > 0:
-            return self.graph_pred_linear(out)
-        if self.num_vocab > 1 and self.max_seq_len > 1:
-            # the S vocabulary heads as ONE library GEMM over the concatenated weights (dagnn.py:212-215);
-            # the list entries are views of its output.  With gradients (round 4): the concatenation is taken from the
-            # live parameters inside the graph, so the backward pass is two GEMMs instead of ten and every head's
-            # weight gradient is a slice of one product (S = 5: 15 launches of ~25 us -> 3 of ~35)
-            heads = list(self.graph_pred_linear_list)
-            if torch.is_grad_enabled():
-                wcat = torch.cat([hd.weight for hd in heads], 0)
-                bcat = torch.cat([hd.bias for hd in heads], 0)
-            else:
-                wcat, bcat = self._head_cache.get([p for hd in heads for p in (hd.weight, hd.bias)],
-                                                  lambda: (torch.cat([hd.weight for hd in heads], 0),
-                                                           torch.cat([hd.bias for hd in heads], 0)), fresh=self.training)
-            logits = torch.addmm(bcat, out, wcat.t())
-            return list(logits.split(self.num_vocab, dim=1))
-        return [self.graph_pred_linear_list[i](out) for i in range(self.max_seq_len)]
+        return self._heads(self.dropout(out))

@@ -499,8 +499,9 @@ int dagnn_backward_run(const dagnn_plan* plan /* host */, const dagnn_backward_a
  * The same reverse sweep as ONE persistent dataflow launch (csrc/bwd_dataflow.hip; H <= 256): the mirror image of
  * dagnn_dataflow_run on the same schedule workspace, replacing dagnn_backward_run's T + L - 1 launches.
  *   1. dagnn_backward_prepare (a, alpha) and the two pre-activation GEMMs (gi, gh) as before;
- *   2. dagnn_bwd_dataflow_prepare: successor records in schedule order (`records`, dagnn_bwd_dataflow_record_bytes) and the
- *      per-(cell, node) static rows `stat` (dagnn_bwd_dataflow_static_bytes each): Gext, h and the GRU-backward
+ *   2. dagnn_bwd_dataflow_prepare: successor records in schedule order (`records`, dagnn_bwd_dataflow_record_bytes: 256 bytes
+ *      per record - the node, its successor row, the first four successors with their edge features and the attention weight
+ *      of every stacked layer, so `alpha` of step 1 must be final) and the per-(cell, node) static rows `stat` (dagnn_bwd_dataflow_static_bytes each): Gext, h and the GRU-backward
  *      coefficients - the gate algebra is linear in the incoming gradient, so it leaves the dependent chain;
  *   3. dagnn_bwd_dataflow_run: the launch.  Hand-off buffers (uint64 granules {epoch, fp32 bits}, zero-initialised once,
  *      strictly increasing epochs): da [N,gld], q [N], dgi [N,3 gld] (stacked layers > 0), du [N,gld] (stacked layers
@@ -512,7 +513,7 @@ typedef struct dagnn_bwd_dataflow_cell {
     const float* w_hh_t;    /* packed gate-wise transposed W_hh */
     const float* w_ih_t;    /* ... W_ih (stacked layers > 0), else NULL */
     const float* w_key;     /* [H] (zeros when the scores are static) */
-    const float* alpha;     /* [E] (dagnn_backward_prepare) */
+    const float* alpha;     /* [E] (dagnn_backward_prepare); read by dagnn_bwd_dataflow_prepare (into the successor records) and run */
     const float* gi;        /* prepare: [N,3H] */
     const float* gh;        /* prepare: [N,3H] */
     const float* a;         /* prepare: [N,H] */

@@ -357,10 +357,10 @@ def _oracle_forward(key, model, b, L):
 
 
 def test_wide_deep_config_matches_oracle(device, schedule):
-    """cfg 5 shape (h=512, L=5, bidir) on a 24-graph batch."""
+    """cfg 5 shape (h=512, L=5, bidir) on a 14-graph batch."""
     model = _headline_model(H=512, L=5, V=32, seed=5)
-    b = synth.code2_batch(21, 24)
-    ref = _oracle_forward("cfg5_24", model, b, 5)
+    b = synth.code2_batch(21, 14)
+    ref = _oracle_forward("cfg5_14", model, b, 5)
     model = model.to(device)
     with torch.no_grad():
         out = model(b.to(device))

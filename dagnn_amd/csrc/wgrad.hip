@@ -33,7 +33,7 @@ struct WgJob {
 
 struct WgArgs {
     WgJob job[WG_MAX_JOBS];
-    int njob, M, Hp, H, splits, tiles_m, tiles_k;
+    int njob, M, Hp, H, splits, tiles_m, tiles_k, wgs_per;   // tiles_k: 64-column tiles; wgs_per: workgroups per (job, split)
     int64_t N;
     float* part;        // [njob][splits][M][K2max] partial products
     float* bpart;       // [njob][splits][M] partial column sums
@@ -43,17 +43,22 @@ struct WgArgs {
 __global__ void __launch_bounds__(64 * WG_WAVES, 2) wgrad_partial_kernel(WgArgs S) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // A wave owns one 128 x 64 output tile; the waves share nothing, so the tiles of a (job, split) are dealt to waves
+    // DENSELY - tile id = 4 workgroup + wave, column tile fastest (round 4: with whole workgroups of 128 x 256 an input width
+    // of 320 left three of the four waves of every second workgroup without a tile: 58 % of the launch useful)
     int bid = blockIdx.x;
-    const int tm = bid % S.tiles_m; bid /= S.tiles_m;
-    const int tk = bid % S.tiles_k; bid /= S.tiles_k;
+    const int wg = bid % S.wgs_per; bid /= S.wgs_per;
     const int split = bid % S.splits;
     const int jb = bid / S.splits;
     const WgJob& J = S.job[jb];
+    const int tile = wg * WG_WAVES + wave;
+    if (tile >= S.tiles_m * S.tiles_k) return;
+    const int tm = tile / S.tiles_k, tk = tile - tm * S.tiles_k;
     const int r = lane & 31, kk = lane >> 5;
-    const int m0 = tm * WG_TM, k0 = (tk * WG_WAVES + wave) * WG_TK;
+    const int m0 = tm * WG_TM, k0 = tk * WG_TK;
     const int ma = m0 + 4 * r, kb = k0 + 2 * r;          // first output row / column this lane feeds
     const bool a_on = ma < S.M, b_on = kb < J.K2;
-    if (k0 >= J.K2 && !(wave == 0 && tk == 0)) return;   // nothing to do for this wave (whole-wave exit)
+    if (k0 >= J.K2 && tk != 0) return;   // nothing to do for this wave (whole-wave exit; column tile 0 also sums the bias)
     // nodes of this split: pairs (n, n + 1)
     int64_t chunk = (S.N + S.splits - 1) / S.splits;
     chunk += chunk & 1;
@@ -66,7 +71,7 @@ __global__ void __launch_bounds__(64 * WG_WAVES, 2) wgrad_partial_kernel(WgArgs 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = J.db != nullptr && wave == 0 && tk == 0;
+    const bool do_bias = J.db != nullptr && tk == 0;
     const float* ap = J.A + ma;
     const float* bp = J.B + kb;
     constexpr int UN = 4;
@@ -249,7 +254,7 @@ extern "C" size_t dagnn_wgrad_workspace_bytes(int njob, int Hp, int K2max, int s
 
 extern "C" int dagnn_wgrad_splits(int num_cus, int njob, int Hp, int K2max, int64_t N) {
     if (num_cus <= 0 || njob <= 0 || Hp <= 0 || K2max <= 0 || N <= 0) return 0;
-    const int tiles = njob * ((3 * Hp + WG_TM - 1) / WG_TM) * ((K2max + WG_WAVES * WG_TK - 1) / (WG_WAVES * WG_TK));
+    const int tiles = njob * ((((3 * Hp + WG_TM - 1) / WG_TM) * ((K2max + WG_TK - 1) / WG_TK) + WG_WAVES - 1) / WG_WAVES);   // workgroups per split
     int s = 2 * num_cus / tiles;   // two workgroups per CU, all resident at once
     if (s < 1) s = 1;
     if (s > 64) s = 64;
@@ -276,11 +281,12 @@ extern "C" int dagnn_wgrad_run(const dagnn_wgrad_job* jobs, int njob, int64_t N,
     if (dagnn_wgrad_workspace_bytes(njob, Hp, K2max, splits) > workspace_bytes) return DAGNN_ENOSPC;
     S.njob = njob; S.M = 3 * Hp; S.Hp = Hp; S.H = H; S.splits = splits; S.N = N; S.K2max = K2max;
     S.tiles_m = (S.M + WG_TM - 1) / WG_TM;
-    S.tiles_k = (K2max + WG_WAVES * WG_TK - 1) / (WG_WAVES * WG_TK);
+    S.tiles_k = (K2max + WG_TK - 1) / WG_TK;
+    S.wgs_per = (S.tiles_m * S.tiles_k + WG_WAVES - 1) / WG_WAVES;
     S.part = (float*)workspace;
     S.bpart = S.part + (size_t)njob * splits * S.M * K2max;
     hipStream_t st = (hipStream_t)stream;
-    const unsigned grid = (unsigned)(S.tiles_m * S.tiles_k * splits * njob);
+    const unsigned grid = (unsigned)(S.wgs_per * splits * njob);
     hipLaunchKernelGGL(wgrad_partial_kernel, dim3(grid), dim3(64 * WG_WAVES), 0, st, S);
     DAGNN_CHECK_LAUNCH();
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(96, (unsigned)njob), dim3(256), 0, st, S);

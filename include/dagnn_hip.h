@@ -549,7 +549,7 @@ size_t dagnn_bwd_dataflow_static_bytes(int64_t N);
 size_t dagnn_bwd_dataflow_static_bytes_h(int64_t N, int H);   /* ... for a given H: 8 KB per (cell, node) up to H = 256, 10 KB at H = 320 */
 int dagnn_bwd_dataflow_prepare(const dagnn_plan* plan /* host */, const dagnn_bwd_dataflow_args* args /* host */, void* stream);
 int dagnn_bwd_dataflow_run(const dagnn_plan* plan /* host */, const dagnn_bwd_dataflow_args* args /* host */, void* stream);
-/* H = 320: the same sweep in the 8-wave workgroup shape (csrc/bwd_dataflow_w.hip); dagnn_bwd_dataflow_run forwards H > 256 here */
+/* H = 320: the same sweep with five column blocks per lane (csrc/bwd_dataflow_w.hip; 12 waves like H <= 256); dagnn_bwd_dataflow_run forwards H > 256 here */
 int dagnn_bwd_dataflow_run_wide(const dagnn_plan* plan /* host */, const dagnn_bwd_dataflow_args* args /* host */, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -29,319 +29,9 @@
 //   B  fp32 FMA GEMV on the slice, hidden- and input-side, RB rows register-blocked;
 //   C  RB x JS threads: gates, h' store, partial score store.
 // fp32 VALU FMA: at <= 8 rows per weight pass the fp32 MFMA has the same per-row rate.
-#include "common.h"
-
-#define DAGNN_MAX_CELLS 16
+#include "frontier_dev.h"
 
 namespace {
-
-constexpr int FT = 384;     // threads per workgroup (6 waves)
-constexpr int PU = 16;      // hidden units per stored score part
-
-struct Cell {
-    const float4* whh;   // packed hidden-side slices
-    const float4* wih;   // packed input-side slices, or null (stacked layer 0: gi0 instead)
-    const float4* whh_m; // the same matrices in MFMA fragment order (fat launches), or null
-    const float4* wih_m;
-    const float* bhh;    // [3H]
-    const float* bih;    // [3H] (only with wih)
-    const float* wkey;   // [H], or null when the scores are static
-    const float* sscore; // [N] static attention score of every node (keys taken from the inputs x), or null
-    const float* gain;   // [R] or null
-    const float* vid;    // [vid_mod] or null
-    const float* gi0;    // [N,3H] precomputed input side (stacked layer 0) or null
-    const float* h_in;   // [N,ld_h] lower stacked layer (with wih) or null
-    float* h_out;        // [N,ld_h]: H state floats + H/16 partial scores per row
-    const float* a_pre;  // fat launches: aggregates of this launch's rows [row_end - row_base, H], written by
-                         // aggregate_rows_kernel one launch earlier; null = aggregate inside the block
-    unsigned long long* g_out;        // [N,gld] {epoch tag, fp32 bits} granules of h_out rows + parts, or null
-    const unsigned long long* g_in;   // granules of h_in, or null
-    int dir;             // direction (selects the plan arrays)
-    int row_base;        // first rowrec slot of the layer processed in this launch
-    int row_end;         // one past the last
-    int has_pred;        // layer > 0
-};
-
-struct StepArgs {
-    Cell cell[DAGNN_MAX_CELLS];
-    int blk_start[DAGNN_MAX_CELLS + 1];  // row-block prefix sums over the active cells
-    int ncell, H, ld_h, R, vid_mod, step;
-    unsigned epoch;           // tag of this forward pass in the granule copies (never 0)
-    unsigned long long* dbg;  // optional [steps][8] wall_clock64 stamps of workgroup 0
-};
-
-// LDS index of element k of an operand row: 4 floats of pad per K-lane segment so the 16
-// segments a DPP row reads concurrently (ds_read_b128) fall on disjoint banks.
-__device__ __forceinline__ int apad(int k, int kpt) { return k + 4 * (k / kpt); }
-
-__device__ __forceinline__ float dpp_row_sum16(float v) {
-    // inclusive scan over the 16 lanes of a DPP row (row_shr 1,2,4,8; out-of-row lanes read 0):
-    // lane 15 of every row ends with the row total, always in the same order -> deterministic
-#define DAGNN_DPP_ADD(ctrl) \
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
-    DAGNN_DPP_ADD(0x111); DAGNN_DPP_ADD(0x112); DAGNN_DPP_ADD(0x114); DAGNN_DPP_ADD(0x118);
-#undef DAGNN_DPP_ADD
-    return v;
-}
-
-__device__ __forceinline__ void fma4(float4& acc, float al, const float4& v) {
-    acc.x = fmaf(al, v.x, acc.x); acc.y = fmaf(al, v.y, acc.y); acc.z = fmaf(al, v.z, acc.z); acc.w = fmaf(al, v.w, acc.w);
-}
-
-// sum of the H/16 partial scores stored behind a state row, in index order (deterministic).
-__device__ __forceinline__ float score_of(const float* __restrict__ hrow_tail, int nparts) {
-    float s = 0.f;
-    for (int q = 0; q < nparts; q += 4) {
-        const float4 p = *reinterpret_cast<const float4*>(hrow_tail + q);
-        s += p.x; if (q + 1 < nparts) s += p.y; if (q + 2 < nparts) s += p.z; if (q + 3 < nparts) s += p.w;
-    }
-    return s;
-}
-
-// One wave: float4 chunk `lane` of granule row `grow` (H <= 256: one chunk per lane), waiting for it.
-__device__ __forceinline__ float4 gran_row_chunk(const gran_t* grow, int lane, int H4, const GranCtx& G) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned spins = 0;
-    for (;;) {
-        bool ok = true;
-        if (lane < H4) {
-            const gran_t x0 = gran_ld(grow + 4 * lane), x1 = gran_ld(grow + 4 * lane + 1),
-                         x2 = gran_ld(grow + 4 * lane + 2), x3 = gran_ld(grow + 4 * lane + 3);
-            ok = (unsigned)(x0 >> 32) == G.epoch && (unsigned)(x1 >> 32) == G.epoch &&
-                 (unsigned)(x2 >> 32) == G.epoch && (unsigned)(x3 >> 32) == G.epoch;
-            v = make_float4(__uint_as_float((unsigned)x0), __uint_as_float((unsigned)x1),
-                            __uint_as_float((unsigned)x2), __uint_as_float((unsigned)x3));
-        }
-        if (__all(ok) || !gran_retry(spins, G)) break;
-    }
-    return v;
-}
-
-// One wave: a_row[:] = sum_e alpha_e * h[pred_e, :] with alpha = softmax_e(score[pred_e] + gain . feat_e)
-// (PyG: exp(x - max) / (sum + 1e-16)).  rec1 = first four predecessors, rec2/rec3 = their edge features.
-// GRAN: predecessor rows and scores are read (and waited for) through their granule copies.
-template <bool GRAN>
-__device__ __forceinline__ void aggregate(const Cell& C, const int32_t* __restrict__ col,
-                                          const float* __restrict__ eattr, int eb, int ee, int4 rec1, int4 rec2,
-                                          int4 rec3, int H, int ld_h, int R, int vid_mod, int kpt, float* a_row,
-                                          int lane, const GranCtx& G) {
-    const int H4 = H >> 2;
-    const int nparts = H / PU;
-    const int gld = H + nparts;
-    const float* hsrc = C.h_out;  // predecessors' states of THIS stacked layer (earlier launches)
-    const gran_t* gsrc = C.g_out;
-    const int deg = ee - eb;
-    if (deg <= 4 && R <= 2) {
-        // ---- inline path: predecessor ids and edge features came with the row record
-        const int pj[4] = {rec1.x, rec1.y, rec1.z, rec1.w};
-        const float f0[4] = {__int_as_float(rec2.x), __int_as_float(rec2.z), __int_as_float(rec3.x), __int_as_float(rec3.z)};
-        const float f1[4] = {__int_as_float(rec2.y), __int_as_float(rec2.w), __int_as_float(rec3.y), __int_as_float(rec3.w)};
-        float al[4] = {1.f, 0.f, 0.f, 0.f};
-        float4 row0[4];
-        float sc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (GRAN) {
-            // rows and score parts of all <= 4 predecessors in ONE polling loop (one round trip when ready)
-            float pv[4] = {0.f, 0.f, 0.f, 0.f};
-            unsigned spins = 0;
-            const gran_t ready = (gran_t)G.epoch << 32;   // stands in for granules that are not read
-            const bool want_parts = deg > 1 && !C.sscore && lane < nparts;
-            for (;;) {
-                // every load of the iteration is issued before the first tag is looked at: the loads are atomics,
-                // which the compiler keeps in program order - a compare between two groups would serialise them
-                gran_t x[4][4], xp[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const gran_t* grow = gsrc + (int64_t)pj[e] * gld;
-                    const bool on = e < deg && lane < H4;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) x[e][q] = on ? gran_ld(grow + 4 * lane + q) : ready;
-                    xp[e] = (e < deg && want_parts) ? gran_ld(grow + H + lane) : ready;
-                }
-                bool ok = true;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(x[e][q] >> 32) == G.epoch;
-                    ok = ok && (unsigned)(xp[e] >> 32) == G.epoch;
-                    row0[e] = make_float4(__uint_as_float((unsigned)x[e][0]), __uint_as_float((unsigned)x[e][1]),
-                                          __uint_as_float((unsigned)x[e][2]), __uint_as_float((unsigned)x[e][3]));
-                    pv[e] = __uint_as_float((unsigned)xp[e]);
-                }
-                if (__all(ok) || !gran_retry(spins, G)) break;
-            }
-            if (deg > 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (e >= deg) continue;
-                    if (C.sscore) sc[e] = C.sscore[pj[e]];
-                    else  // the <= 16 parts sit in lanes 0..15 (0 beyond nparts): one DPP row scan, fixed order
-                        sc[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
-                                    __builtin_bit_cast(int, dpp_row_sum16(pv[e])), 15));
-                }
-            }
-        } else {
-            // first 64 float4 columns of every predecessor row: issued before the scores are touched so
-            // that rows and scores share one memory round trip
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                row0[e] = (e < deg && lane < H4) ? reinterpret_cast<const float4*>(hsrc + (int64_t)pj[e] * ld_h)[lane]
-                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (deg > 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (e < deg) sc[e] = C.sscore ? C.sscore[pj[e]] : score_of(hsrc + (int64_t)pj[e] * ld_h + H, nparts);
-            }
-        }
-        if (deg > 1) {
-            float lg[4], mx = -INFINITY;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                lg[e] = -INFINITY;
-                if (e < deg) {
-                    float s = sc[e];
-                    if (C.vid) s += C.vid[pj[e] % vid_mod];
-                    if (R >= 1) s = fmaf(C.gain[0], f0[e], s);
-                    if (R >= 2) s = fmaf(C.gain[1], f1[e], s);
-                    lg[e] = s;
-                    mx = fmaxf(mx, s);
-                }
-            }
-            float sum = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { al[e] = e < deg ? expf(lg[e] - mx) : 0.f; sum += al[e]; }
-            const float denom = sum + 1e-16f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) al[e] = al[e] / denom;
-        }
-        if (lane < H4) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) fma4(acc, al[e], row0[e]);  // al[e] == 0 and row0[e] == 0 beyond deg
-            *reinterpret_cast<float4*>(a_row + apad(4 * lane, kpt)) = acc;
-        }
-        if (!GRAN) {
-            for (int c = lane + 64; c < H4; c += 64) {
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (e < deg) fma4(acc, al[e], reinterpret_cast<const float4*>(hsrc + (int64_t)pj[e] * ld_h)[c]);
-                *reinterpret_cast<float4*>(a_row + apad(4 * c, kpt)) = acc;
-            }
-        }
-        return;
-    }
-    // ---- general path (fan-in > 4): lanes own edges
-    auto logit = [&](int e, int cj) {
-        float s = 0.f;
-        if (C.sscore) {
-            s = C.sscore[cj];
-        } else if (GRAN) {  // this lane's predecessor: its H/16 part granules (H <= 256: at most 16), all loads in
-                            // flight together, re-polled as a group, summed in index order
-            const gran_t* gp = gsrc + (int64_t)cj * gld + H;
-            unsigned spins = 0;
-            for (;;) {
-                gran_t x[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) x[q] = q < nparts ? gran_ld(gp + q) : ((gran_t)G.epoch << 32);
-                bool ok = true;
-                s = 0.f;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    ok = ok && (unsigned)(x[q] >> 32) == G.epoch;
-                    if (q < nparts) s += __uint_as_float((unsigned)x[q]);
-                }
-                if (ok) break;   // per-lane wait: producers never wait on us
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 22)) { __hip_atomic_store(G.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-        } else {
-            s = score_of(hsrc + (int64_t)cj * ld_h + H, nparts);
-        }
-        if (C.vid) s += C.vid[cj % vid_mod];
-        for (int r = 0; r < R; ++r) s = fmaf(C.gain[r], eattr[(int64_t)e * R + r], s);
-        return s;
-    };
-    float mx = -INFINITY, sum = 0.f, lg0 = -INFINITY;
-    int col0 = 0;
-    const bool one_pass = deg <= 64;  // every lane owns at most one edge: its logit stays in a register
-    if (one_pass) {
-        if (lane < deg) { col0 = col[eb + lane]; lg0 = logit(eb + lane, col0); }
-        mx = wave_max(lg0);
-        sum = wave_sum(lane < deg ? expf(lg0 - mx) : 0.f);
-    } else {
-        for (int e = eb + lane; e < ee; e += 64) mx = fmaxf(mx, logit(e, col[e]));
-        mx = wave_max(mx);
-        for (int e = eb + lane; e < ee; e += 64) sum += expf(logit(e, col[e]) - mx);
-        sum = wave_sum(sum);
-    }
-    const float denom = sum + 1e-16f;
-    for (int c0 = 0; c0 < H4; c0 += 64) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int c = c0 + lane;
-        for (int base = eb; base < ee; base += 64) {
-            const int e = base + lane;
-            float my_alpha = 0.f;
-            int my_col = 0;
-            if (e < ee) {
-                if (one_pass) { my_col = col0; my_alpha = expf(lg0 - mx) / denom; }
-                else { my_col = col[e]; my_alpha = expf(logit(e, my_col) - mx) / denom; }
-            }
-            const int cnt = min(64, ee - base);
-            int i = 0;
-            if (!GRAN) {
-                for (; i + 4 <= cnt; i += 4) {  // four row loads in flight per lane
-                    float4 v[4]; float a4[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        a4[u] = __shfl(my_alpha, i + u, 64);
-                        const int cj = __shfl(my_col, i + u, 64);
-                        v[u] = c < H4 ? reinterpret_cast<const float4*>(hsrc + (int64_t)cj * ld_h)[c] : make_float4(0, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) fma4(acc, a4[u], v[u]);
-                }
-            }
-            if (GRAN) {
-                for (; i + 4 <= cnt; i += 4) {  // four granule rows polled together: one round trip when they are ready
-                    float a4[4]; const gran_t* gr[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        a4[u] = __shfl(my_alpha, i + u, 64);
-                        gr[u] = gsrc + (int64_t)__shfl(my_col, i + u, 64) * gld;
-                    }
-                    float4 v[4];
-                    unsigned spins = 0;
-                    for (;;) {
-                        gran_t x[4][4];   // all 16 loads first, then the tags (see the inline path)
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                x[u][q] = lane < H4 ? gran_ld(gr[u] + 4 * lane + q) : ((gran_t)G.epoch << 32);
-                        bool ok = true;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(x[u][q] >> 32) == G.epoch;
-                            v[u] = make_float4(__uint_as_float((unsigned)x[u][0]), __uint_as_float((unsigned)x[u][1]),
-                                               __uint_as_float((unsigned)x[u][2]), __uint_as_float((unsigned)x[u][3]));
-                        }
-                        if (__all(ok) || !gran_retry(spins, G)) break;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) fma4(acc, a4[u], v[u]);
-                }
-            }
-            for (; i < cnt; ++i) {
-                const float a1 = __shfl(my_alpha, i, 64);
-                const int cj = __shfl(my_col, i, 64);
-                if (GRAN) fma4(acc, a1, gran_row_chunk(gsrc + (int64_t)cj * gld, lane, H4, G));
-                else if (c < H4) fma4(acc, a1, reinterpret_cast<const float4*>(hsrc + (int64_t)cj * ld_h)[c]);
-            }
-        }
-        if (c < H4) *reinterpret_cast<float4*>(a_row + apad(4 * c, kpt)) = acc;
-    }
-}
 
 // acc[r] += W-slice x operand row r for the first NRW rows of the block (NRW <= RBT is a compile-time
 // bound so that blocks with few live rows do not pay for the padding rows).
@@ -361,7 +51,6 @@ __device__ __forceinline__ void fma_rows(float4 (&acc)[RBT], const float4 (&w)[K
     }
 }
 
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // -----------------------------------------------------------------------------------------------
 // One row block (<= RBT frontier rows of one cell) x one slice of JS hidden units.
@@ -444,11 +133,7 @@ __device__ __forceinline__ void process_block(const int32_t* __restrict__ plan, 
                         *reinterpret_cast<float4*>(u_row + apad(4 * cc, kpt)) = ur[cc];
                 }
             }
-            if (!RESIDENT && C.a_pre != nullptr) {
-                // fat launch: the aggregate was computed once per row by aggregate_rows_kernel
-                const float4* ap = reinterpret_cast<const float4*>(C.a_pre + (int64_t)(slot0 + r - C.row_base) * H);
-                for (int cc = lane; cc < H4; cc += 64) *reinterpret_cast<float4*>(a_row + apad(4 * cc, kpt)) = ap[cc];
-            } else if (has_pred && rec0.z > rec0.y) {
+            if (has_pred && rec0.z > rec0.y) {
                 aggregate<RESIDENT>(C, col, eattr, rec0.y, rec0.z, rp[1], rp[2], rp[3], H, ld_h, R, vid_mod, kpt, a_row,
                                     lane, G);
             } else {
@@ -571,235 +256,24 @@ __device__ __forceinline__ void process_block(const int32_t* __restrict__ plan, 
     if (stamp) stamp[5] = wall_clock64();
 }
 
-// ---- fat launches, stage 1: the aggregate of every frontier row ONCE (one wave per row, 4 rows per
-// workgroup: a low-register, high-occupancy gather kernel) instead of once per weight slice.
-__global__ void __launch_bounds__(256) aggregate_rows_kernel(const int32_t* __restrict__ plan, PlanLayout L, StepArgs S) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int row = blockIdx.x * 4 + wave;          // row index over all cells of this launch
-    int c = 0;
-    while (c + 1 < S.ncell && row >= S.blk_start[c + 1]) ++c;   // blk_start = ROW prefix sums here
-    if (row >= S.blk_start[S.ncell]) return;
-    const Cell& C = S.cell[c];
-    const int local = row - S.blk_start[c];
-    const int d = C.dir, H = S.H, H4 = H >> 2;
-    const int4* rp = reinterpret_cast<const int4*>(plan + L.rowrec[d]) + 4 * (int64_t)(C.row_base + local);
-    const int4 rec0 = rp[0];
-    float* out = const_cast<float*>(C.a_pre) + (int64_t)local * H;
-    GranCtx G;
-    G.epoch = S.epoch; G.err = nullptr;
-    if (C.has_pred && rec0.z > rec0.y) {
-        // kpt = H (no padding): apad(k, H) == k for k < H, so the rows land contiguously
-        aggregate<false>(C, plan + L.col[d], reinterpret_cast<const float*>(plan + L.eattr[d]), rec0.y, rec0.z, rp[1],
-                         rp[2], rp[3], H, S.ld_h, C.gain ? S.R : 0, S.vid_mod, H, out, lane, G);
-    } else {
-        for (int cc = lane; cc < H4; cc += 64) reinterpret_cast<float4*>(out)[cc] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-
-
-// ---- fat launches, stage 2 on the matrix cores: 32 frontier rows x one 32-unit slice per workgroup.
-// The widest topological layers hold thousands of rows; with 8-row blocks every block re-reads its
-// 98-196 KB weight slice (528 MB of L2->CU traffic for one 2 700-row layer).  Here the aggregates
-// (stage 1, aggregate_rows_kernel) and the nodes' lower-layer rows of 32 rows are staged k-major in
-// LDS and the slice GEMMs [32 x K] x [K x 96] run as v_mfma_f32_32x32x2_f32 chains (exact fp32, the
-// fmaf order is k ascending), one (matrix, gate) chain per wave: 4x fewer weight bytes per row and 4x
-// fewer workgroups.  The B fragments are pre-packed in lane order (dagnn_pack_mfma), 16 B per lane.
-typedef float mf32x16 __attribute__((ext_vector_type(16)));
-constexpr int MT = 32;          // rows per tile
-constexpr int MLD = MT + 1;     // k-major LDS pitch (conflict-free lane == row reads)
-constexpr int MKC = 256;        // K chunk staged in LDS at a time
-
-__global__ void __launch_bounds__(512, 2) frontier_mfma_kernel(const int32_t* __restrict__ plan, PlanLayout L, StepArgs S) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int H = S.H, ld_h = S.ld_h, NS = H / 32;
-    const int sl = blockIdx.x % NS;
-    const int gb = blockIdx.x / NS;
-    int c = 0;
-    while (c + 1 < S.ncell && gb >= S.blk_start[c + 1]) ++c;   // blk_start = 32-row tile prefix sums
-    const Cell& C = S.cell[c];
-    const int slot0 = C.row_base + (gb - S.blk_start[c]) * MT;
-    const int nr = min(MT, C.row_end - slot0);
-    const int d = C.dir;
-    const bool has_in = C.wih_m != nullptr;
-    const bool has_pred = C.has_pred != 0;
-    unsigned long long* stamp = (S.dbg != nullptr && blockIdx.x == 0 && tid == 0) ? S.dbg + 8 * (int64_t)S.step : nullptr;
-    if (stamp) { stamp[0] = wall_clock64(); stamp[6] = gridDim.x; }
-
-    const int KC = min(H, MKC);           // K is staged through LDS in chunks of <= MKC
-    float* a_t = smem;                    // [KC][MLD]  aggregates, k-major
-    float* u_t = a_t + KC * MLD;          // [KC][MLD]  own lower-layer rows, k-major; later the GEMM outputs
-    float* g_s = u_t;                     // [2][MT][96] + [MT][64] after the MFMA phase (u_t is dead by then)
-    int* v_s = reinterpret_cast<int*>(u_t + max(KC * MLD, 2 * MT * 96 + MT * 64));  // [MT] node ids
-
-    const int4* __restrict__ recs = reinterpret_cast<const int4*>(plan + L.rowrec[d]);
-    if (tid < MT) v_s[tid] = tid < nr ? recs[4 * (int64_t)(slot0 + tid)].x : 0;
-    __syncthreads();
-
-    // operands of the gate epilogue that do not depend on the products: issued now, consumed after the chains
-    // {input-side pre-activations or biases (r, z, n), hidden-side biases (r, z, n), aggregate, key weight}
-    float pre[2][8];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int id = p * 512 + tid;
-        const int r = id >> 5, j = sl * 32 + (id & 31);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) pre[p][q] = 0.f;
-        if (r < nr) {
-            if (has_in) { pre[p][0] = C.bih[j]; pre[p][1] = C.bih[H + j]; pre[p][2] = C.bih[2 * H + j]; }
-            else {
-                const float* g0 = C.gi0 + (int64_t)v_s[r] * 3 * H;
-                pre[p][0] = g0[j]; pre[p][1] = g0[H + j]; pre[p][2] = g0[2 * H + j];
-            }
-            pre[p][3] = C.bhh[j]; pre[p][4] = C.bhh[H + j]; pre[p][5] = C.bhh[2 * H + j];
-            pre[p][6] = C.a_pre[(int64_t)(slot0 + r - C.row_base) * H + j];
-            pre[p][7] = C.wkey ? C.wkey[j] : 0.f;
-        }
-    }
-
-    mf32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    // chain c = matrix * 3 + gate.  With both products (6 chains on 4 SIMDs, two waves per SIMD) waves 0-3 run
-    // chains 0-3 over the whole K and waves 4|5, 6|7 the two K halves of chains 4, 5: 1.5 chains per SIMD
-    // instead of 2 on two of them; the second halves land in their own LDS tile and are added in the epilogue.
-    const int cid = has_in ? (wave < 4 ? wave : 4 + ((wave - 4) >> 1)) : wave;
-    const int khalf = (has_in && wave >= 4) ? ((wave - 4) & 1) : -1;   // -1: whole K
-    const int mat = cid / 3, gate = cid - mat * 3;
-    const bool chain = cid < 6 && (mat == 0 ? has_pred : has_in);
-    const float* op = mat == 0 ? a_t : u_t;
-    const float4* wp = chain ? (mat == 0 ? C.whh_m : C.wih_m) + ((int64_t)(sl * 3 + gate) * (H / 8)) * 64 + lane : nullptr;
-    const int arow = lane & 31, ak = lane >> 5;
-
-    for (int k0 = 0; k0 < H; k0 += KC) {
-        const int kc = min(KC, H - k0);
-        if (k0 > 0) __syncthreads();   // the previous chunk's MFMAs are done with a_t / u_t
-        // this wave's k range of the chunk and its first group of B fragments: in flight during the staging
-        const int k8n = kc >> 3, k8b = khalf < 0 ? 0 : khalf * (k8n >> 1), k8e = khalf < 0 ? k8n : k8b + (k8n >> 1);
-        float4 wn[4];
-        if (chain) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wn[q] = wp[(int64_t)((k0 >> 3) + k8b + q) * 64];
-        }
-        // ---- stage the operand chunk k-major: wave w copies rows w, w+8, w+16, w+24 (coalesced float4 row
-        // reads); the loads of all four rows are issued before the first LDS store - one round trip, not four
-        for (int cc = lane; cc < (kc >> 2); cc += 64) {
-            float4 av[MT / 8], uv[MT / 8];
-#pragma unroll
-            for (int q = 0; q < MT / 8; ++q) {
-                const int r = wave + 8 * q;
-                av[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                uv[q] = av[q];
-                if (r < nr) {
-                    av[q] = reinterpret_cast<const float4*>(C.a_pre + (int64_t)(slot0 + r - C.row_base) * H + k0)[cc];
-                    if (has_in) uv[q] = reinterpret_cast<const float4*>(C.h_in + (int64_t)v_s[r] * ld_h + k0)[cc];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < MT / 8; ++q) {
-                const int r = wave + 8 * q;
-                a_t[(4 * cc + 0) * MLD + r] = av[q].x; a_t[(4 * cc + 1) * MLD + r] = av[q].y;
-                a_t[(4 * cc + 2) * MLD + r] = av[q].z; a_t[(4 * cc + 3) * MLD + r] = av[q].w;
-                if (has_in) {
-                    u_t[(4 * cc + 0) * MLD + r] = uv[q].x; u_t[(4 * cc + 1) * MLD + r] = uv[q].y;
-                    u_t[(4 * cc + 2) * MLD + r] = uv[q].z; u_t[(4 * cc + 3) * MLD + r] = uv[q].w;
-                }
-            }
-        }
-        __syncthreads();
-        if (stamp) stamp[1] = wall_clock64();
-        // ---- MFMA chains over this K chunk
-        if (chain) {
-            for (int k8 = k8b; k8 < k8e; k8 += 4) {   // 4 x 16 B of B fragments per group, the next group in flight
-                float4 w4[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) w4[q] = wn[q];
-                if (k8 + 4 < k8e) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) wn[q] = wp[(int64_t)((k0 >> 3) + k8 + 4 + q) * 64];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int kb = 8 * (k8 + q) + ak;   // this lane's k (within the chunk) for the first MFMA of the fragment
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[(kb + 0) * MLD + arow], w4[q].x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[(kb + 2) * MLD + arow], w4[q].y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[(kb + 4) * MLD + arow], w4[q].z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[(kb + 6) * MLD + arow], w4[q].w, acc, 0, 0, 0);
-                }
-            }
-        }
-    }
-    if (stamp) stamp[2] = wall_clock64();
-    __syncthreads();   // every chain has read u_t: it can now hold the outputs
-    if (stamp) stamp[3] = wall_clock64();
-    if (cid < 6) {
-        // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-        const bool second = khalf == 1;   // second K half of chain 4 / 5: its own [MT][64] tile behind g_s
-        float* out = second ? g_s + 2 * MT * 96 + (gate - 1) * 32 + (lane & 31) : g_s + mat * (MT * 96) + gate * 32 + (lane & 31);
-        const int pitch = second ? 64 : 96;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) out[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * pitch] = acc[e];
-    }
-    __syncthreads();
-
-    if (stamp) stamp[4] = wall_clock64();
-    // ---- gates: 32 rows x 32 units, two elements per thread; 16 consecutive lanes = 16 units of a row
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int id = p * 512 + tid;
-        const int r = id >> 5, jj = id & 31;
-        const bool live = r < nr;
-        float sp = 0.f, hv = 0.f;
-        const int gv = live ? v_s[r] : 0;
-        const int j = sl * 32 + jj;
-        if (live) {
-            float gr = pre[p][0], gz = pre[p][1], gn = pre[p][2];
-            if (has_in) {
-                const float* gi = g_s + MT * 96 + r * 96;
-                const float* g2 = g_s + 2 * MT * 96 + r * 64;
-                gr += gi[jj]; gz += gi[32 + jj] + g2[jj]; gn += gi[64 + jj] + g2[32 + jj];
-            }
-            const float* gh = g_s + r * 96;
-            const float hr = gh[jj] + pre[p][3], hz = gh[32 + jj] + pre[p][4], hn = gh[64 + jj] + pre[p][5];
-            const float a = pre[p][6];
-            const float rg = sigm(gr + hr);
-            const float zg = sigm(gz + hz);
-            const float ng = tanhf(fmaf(rg, hn, gn));
-            hv = fmaf(zg, a - ng, ng);
-            sp = pre[p][7] * hv;
-        }
-        sp = dpp_row_sum16(sp);
-        if (live) {
-            float* po = C.h_out + (int64_t)gv * ld_h;
-            po[j] = hv;
-            if ((tid & 15) == 15) po[H + (j >> 4)] = sp;
-            if (C.g_out) {
-                gran_t* pg = C.g_out + (int64_t)gv * (H + H / PU);
-                pg[j] = gran_pack(S.epoch, hv);
-                if ((tid & 15) == 15) pg[H + (j >> 4)] = gran_pack(S.epoch, sp);
-            }
-        }
-    }
-    if (stamp) stamp[5] = wall_clock64();
-}
-
-// Pack W [3H, K] (torch layout) into MFMA B-fragment order for 32-unit slices:
-// out[((sl * 3 + g) * (K/8) + k8) * 64 + lane] (float4): element q = W[g*H + sl*32 + (lane & 31)][8*k8 + 2*q + (lane >> 5)],
-// i.e. the B operand of the q-th of four consecutive v_mfma_f32_32x32x2_f32 (k pair 2*(4*k8+q)).
+// Pack W [3H, K] (torch layout) into MFMA B-fragment order for 32-unit slices (the fat launches, csrc/fat.hip): a slice is
+// six 16-column blocks n = 2 * gate + half;
+// out[((sl * 6 + n) * (K/16) + k16) * 64 + lane] (float4): element q = W[gate*H + sl*32 + half*16 + (lane & 15)][16*k16 + 4*(lane >> 4) + q],
+// i.e. the B operand of the q-th of four consecutive v_mfma_f32_16x16x4_f32 over k16's sixteen k values: instruction q
+// multiplies k = 16 k16 + 4 kq + q on the lanes of k quarter kq = lane >> 4, so that the matching A fragment of a lane is four
+// CONSECUTIVE floats of its row (one ds_read_b128) and every load of a wave is one contiguous 1 KiB.
 __device__ __forceinline__ void pack_mfma_range(const float* __restrict__ W, float4* __restrict__ out, int H, int K,
                                                 int64_t total, int64_t first, int64_t stride) {
-    const int k8n = K >> 3;
+    const int k16n = K >> 4;
     for (int64_t idx = first; idx < total; idx += stride) {
         const int lane = (int)(idx & 63);
         int64_t rest = idx >> 6;
-        const int k8 = (int)(rest % k8n); rest /= k8n;
-        const int g = (int)(rest % 3);
-        const int sl = (int)(rest / 3);
-        const int64_t row = (int64_t)g * H + sl * 32 + (lane & 31);
-        const int k = 8 * k8 + (lane >> 5);
-        out[idx] = make_float4(W[row * K + k], W[row * K + k + 2], W[row * K + k + 4], W[row * K + k + 6]);
+        const int k16 = (int)(rest % k16n); rest /= k16n;
+        const int n = (int)(rest % 6);
+        const int sl = (int)(rest / 6);
+        const int64_t row = (int64_t)(n >> 1) * H + sl * 32 + (n & 1) * 16 + (lane & 15);
+        const int k = 16 * k16 + 4 * (lane >> 4);
+        out[idx] = *reinterpret_cast<const float4*>(W + row * K + k);
     }
 }
 
@@ -1016,7 +490,7 @@ static void fill_cell(Cell& K, const dagnn_frontier_args* a, const dagnn_plan* p
 }
 
 extern "C" int dagnn_pack_mfma(const float* w, float* out, int H, int K, void* stream) {
-    if (!w || !out || H <= 0 || K <= 0 || (H % 32) || (K % 8)) return DAGNN_EINVAL;
+    if (!w || !out || H <= 0 || K <= 0 || (H % 32) || (K % 16)) return DAGNN_EINVAL;
     const int64_t total = (int64_t)3 * H * K / 4;  // float4 elements
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -1183,34 +657,14 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         S.step = s;
         hipError_t e;
         // the fattest launches: aggregate every row once (stage 1), then 32-row MFMA tiles (stage 2)
-        bool mfma_ok = a->agg_scratch != nullptr && rows_total <= a->agg_scratch_rows && (H <= MKC || H % MKC == 0) &&
-                       a->mfma_min_rows > 0 && rows_total >= a->mfma_min_rows;
+        bool mfma_ok = a->agg_scratch != nullptr && rows_total <= a->agg_scratch_rows && a->mfma_min_rows > 0 &&
+                       rows_total >= a->mfma_min_rows;
         for (int k = 0; k < nc && mfma_ok; ++k)
             mfma_ok = S.cell[k].whh_m != nullptr && (S.cell[k].wih == nullptr || S.cell[k].wih_m != nullptr);
-        if (mfma_ok) {
-            StepArgs A = S;
-            int off = 0, tiles = 0;
-            for (int k = 0; k < nc; ++k) {
-                const int n = S.cell[k].row_end - S.cell[k].row_base;
-                A.cell[k].a_pre = (const float*)a->agg_scratch + (int64_t)off * H;
-                S.cell[k].a_pre = A.cell[k].a_pre;
-                A.blk_start[k] = off;
-                S.blk_start[k] = tiles;
-                off += n;
-                tiles += (n + MT - 1) / MT;
-            }
-            A.blk_start[nc] = off;
-            S.blk_start[nc] = tiles;
-            hipLaunchKernelGGL(aggregate_rows_kernel, dim3((unsigned)((off + 3) / 4)), dim3(256), 0, st, plan, L, A);
-            e = hipGetLastError();
-            if (e != hipSuccess) return DAGNN_EHIP(e);
-            const int kcl = H < MKC ? H : MKC;
-            const int outw = 2 * MT * 96 + MT * 64;
-            const size_t lds = (size_t)(kcl * MLD + (kcl * MLD > outw ? kcl * MLD : outw)) * sizeof(float) +
-                               MT * sizeof(int);
-            hipLaunchKernelGGL(frontier_mfma_kernel, dim3((unsigned)(tiles * (H / 32))), dim3(512), lds, st, plan, L, S);
-            e = hipGetLastError();
-            if (e != hipSuccess) return DAGNN_EHIP(e);
+        if (mfma_ok) {   // ONE launch: 64-row MFMA tiles, gather and soft-max fused into the A staging (csrc/fat.hip)
+            const int rc = dagnn_fat_launch(plan, L, S.cell, nc, H, a->ld_h, pl->num_edge_feats, a->vid_mod, a->epoch,
+                                            (float*)a->agg_scratch, st);
+            if (rc != DAGNN_OK) return rc;
             continue;
         }
         if (js == 32) e = rb == 8 ? launch_step<32, 8, 4, 4>(blocks, H, st, plan, L, S)

@@ -67,7 +67,6 @@ def _env_int(name: str, default: int) -> int:
 # Tests flip some of them to force the less common code paths.
 RB4_MAX_WGS = _env_int("DAGNN_AMD_RB4_MAX_WGS", 0)          # 4-row vs 8-row blocks of the streamed kernel; 0 = library default
 MFMA_MIN_ROWS = _env_int("DAGNN_AMD_MFMA_MIN_ROWS", 300)    # launches with at least this many rows use MFMA tiles; 0 = never
-AGG_SPLIT = _env_int("DAGNN_AMD_AGG_SPLIT", 0)              # allocate the gather scratch even without MFMA tiles (tests)
 TAIL_SLICE = _env_int("DAGNN_AMD_TAIL_SLICE", 32)           # hidden units per workgroup of the persistent kernel (16 | 32)
 TAIL_REPLICAS = _env_int("DAGNN_AMD_TAIL_REPLICAS", 4)      # workgroups per (cell, slice); 0 = one launch per layer throughout
 TAIL_MAX_BLOCKS = _env_int("DAGNN_AMD_TAIL_MAX_BLOCKS", 2)  # without split mode: layers of <= 4 * replicas * this rows go to it
@@ -775,7 +774,7 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     if stop_layer is not None:   # only the batch-level layers before these (the rest: `tiles_run(first_layer=...)`)
         sched = [s_[:min(len(s_), int(stop_layer[d]) + 1)] for d, s_ in enumerate(sched)]
     args.mfma_min_rows = MFMA_MIN_ROWS
-    if AGG_SPLIT or MFMA_MIN_ROWS > 0:  # fat launches aggregate every row once in a separate gather kernel
+    if MFMA_MIN_ROWS > 0:  # fat launches (csrc/fat.hip): scratch rows for the aggregates of rows with more than 4 predecessors
         import numpy as np
         nst = max(len(sched[0]), len(sched[1])) - 1 + L
         width = np.zeros(nst, dtype=np.int64)

@@ -227,20 +227,17 @@ def test_dvae_encode_matches_reference_golden(device, name, schedule):
 
 @pytest.mark.parametrize("name", ["code2_h256_bidir", "code2_h64_unidir", "code2_h128_deep", "code2_h64_attn_x",
                                   "code2_h512_L5"])
-@pytest.mark.parametrize("knob", ["mfma_tiles", "no_tail", "agg_split"])
+@pytest.mark.parametrize("knob", ["mfma_tiles", "no_tail"])
 def test_launch_shape_variants_match_reference_golden(device, name, knob, monkeypatch):
-    """Force the code paths the small fixtures would not reach on their own: 32-row MFMA tiles for
-    every launch, every layer as its own launch (no persistent tail), the separate gather kernel."""
+    """Force the code paths the small fixtures would not reach on their own: 64-row MFMA tiles (csrc/fat.hip) for
+    every launch, every layer as its own launch (no persistent tail)."""
     monkeypatch.setenv("DAGNN_AMD_SCHEDULE", "lockstep")
     monkeypatch.setattr(engine, "DATAFLOW", 0)
     if knob == "mfma_tiles":
         monkeypatch.setattr(engine, "MFMA_MIN_ROWS", 1)
         monkeypatch.setattr(engine, "TAIL_REPLICAS", 0)
-    elif knob == "no_tail":
-        monkeypatch.setattr(engine, "TAIL_REPLICAS", 0)
-        monkeypatch.setattr(engine, "MFMA_MIN_ROWS", 0)
     else:
-        monkeypatch.setattr(engine, "AGG_SPLIT", 1)
+        monkeypatch.setattr(engine, "TAIL_REPLICAS", 0)
         monkeypatch.setattr(engine, "MFMA_MIN_ROWS", 0)
     meta, arr = Hh.load(name)
     model = Hh.code2_model(meta).to(device)

@@ -404,9 +404,10 @@ def main():
     ap.add_argument("--schedule", choices=["lockstep", "pergraph"], default=None,
                     help="recurrence schedule (default: the library default, lock-step frontier launches)")
     ap.add_argument("--streams", type=int, default=1,
-                    help="issue the timed forward passes round-robin on this many HIP streams (independent "
-                         "batches overlap, as in an evaluation loop with a prefetching loader); 1 = strictly "
-                         "one batch after the other (the headline number)")
+                    help="issue the timed forward passes round-robin on this many HIP streams (an evaluation loop with a "
+                         "prefetching loader): plan / encoder / GEMMs / heads of one batch overlap the recurrence of "
+                         "another; the all-resident persistent launches themselves are ordered device-wide "
+                         "(engine.persistent_launch); 1 = strictly one batch after the other (the headline number)")
     ap.add_argument("--cpu-threads", type=int, default=8,
                     help="torch threads for the CPU baseline leg (8 = the thread count BASELINE.md was measured with; "
                          "the op-by-op path is slower with every core of a big host)")
@@ -438,16 +439,9 @@ def main():
     H, L, S, V, B = args.hidden, args.layers, 5, args.vocab, args.batch
     if args.schedule:
         os.environ["DAGNN_AMD_SCHEDULE"] = args.schedule
-    if args.streams > 1:
-        # concurrent persistent tail kernels must all stay co-resident: shrink each one's grid
-        os.environ.setdefault("DAGNN_AMD_TAIL_REPLICAS", str(max(1, 4 // args.streams)))
-        # ... and so must concurrent dataflow launches: each is sized to the whole device by default (one workgroup per CU;
-        # with k of them in flight, partially resident sets would fill the CUs and every wait would expire)
-        from dagnn_amd import engine as _e
-        full = _e.dataflow_groups(device, 2, args.layers, (args.hidden + 63) // 64 * 64, args.batch)
-        if full > 0:
-            _e.DF_GROUPS = max(2, (full // args.streams) // 2 * 2)
-            _e.DF_XCD = 0   # (the XCD packing assumes one launch owns the device)
+    # (--streams k: the persistent recurrence launches of different streams never overlap - engine.persistent_launch
+    # orders them on the device - so nothing has to be shrunk; what overlaps is plan / encoder / GEMMs / heads of one
+    # pass with the recurrence of another)
     model = build_model(H, L, V, S, device)
     # weak scaling: one B-graph batch per rank, by default the same headline batch everywhere (module docstring)
     batch_cpu = code2_batch(seed=rank if args.rank_seeds else 0, num_graphs=B)

@@ -81,7 +81,7 @@ class CellParams(object):
     """Device-side, kernel-ready parameters of one (direction, stacked layer) cell."""
 
     __slots__ = ("w_ih", "b_ih", "w_hh_t", "b_hh", "w_key", "edge_gain", "vid_bias", "w_hh_pk", "w_ih_pk",
-                 "b_ih_dev", "Hp", "key_raw", "w_hh_raw", "w_hh_df", "w_ih_df", "w_hh_bt", "w_ih_bt")
+                 "b_ih_dev", "Hp", "key_raw", "w_hh_raw", "w_hh_df", "w_ih_df", "w_hh_bt", "w_ih_bt", "df_ok")
 
 
 def pack_dataflow(cells) -> None:
@@ -97,7 +97,7 @@ def pack_lockstep(cells, force: bool = False) -> None:
     for all matrices instead of three launches per matrix.  Cells the dataflow kernel serves (Hp <= 256) get its
     layout instead; `force` (the fallback inside `run_stack_lockstep`) packs the per-layer launches' layouts too."""
     cells = list(cells)
-    if cells and engine.DATAFLOW and engine.dataflow_width(cells[0].Hp) and not force:
+    if cells and cells[0].df_ok and not force:
         pack_dataflow(cells)
         return
     if cells and engine.TILES and cells[0].Hp == 512 and not force:
@@ -141,7 +141,12 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
     c.w_hh_pk = c.w_ih_pk = None
     c.w_hh_df = c.w_ih_df = None
     c.w_hh_bt = c.w_ih_bt = None   # reverse sweep: packed gate-wise transposes (engine.bwd_dataflow_sweep)
-    use_df = engine.DATAFLOW and engine.dataflow_width(Hp)   # the dataflow kernel's layout instead (packed below)
+    # the dataflow kernel's layout instead (packed below); a 320-wide cell only where `dagnn_dataflow_run_wide` applies (two
+    # edge features, hidden-state keys, no vertex-id biases) - other 320-wide shapes run on the per-layer launches and
+    # would otherwise be packed twice on every training step
+    use_df = bool(engine.DATAFLOW and engine.dataflow_width(Hp) and
+                  (Hp <= 256 or (wide_ok and edge_w is not None and int(edge_w.shape[1]) == 2)))
+    c.df_ok = use_df
     if lock and pack and not use_df:   # pack=False: the caller batches the packing of all its cells (pack_lockstep)
         c.w_hh_pk = {js: engine.pack_slices(whh, Hp, js) for js in (16, 32)}
         c.w_hh_pk["mfma"] = engine.pack_mfma(whh, Hp)
@@ -174,7 +179,9 @@ def _warn_off_dataflow(dev, ndirs: int, L: int, Hp: int) -> None:
     import warnings
     cells = ndirs * (2 * L - 1)
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    if Hp > 256:
+    if Hp == 320:
+        why = "hidden size 320 runs on the dataflow kernel only with exactly two edge features, hidden-state keys and no vertex-id key biases"
+    elif Hp > 256:
         why = "hidden size %d > 256 (a 32-unit slice of the [3H, H] matrices no longer fits the register file)" % Hp
     elif cells > 24:
         why = "%d kernel cells (directions x (2 x stacked layers - 1)) > 24" % cells
@@ -227,7 +234,8 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
         engine.tiles_run(plan, dirs, L, Hp, cells, gi, h, arena, vid_mod=vid_nodes)
     elif split is not None:
         pack_lockstep(cells.values(), force=True)
-        engine.frontier_run(plan, dirs, L, Hp, cells, gi, h, vid_mod=vid_nodes, arena=None, static_score=static_score, stop_layer=split)
+        engine.frontier_run(plan, dirs, L, Hp, cells, gi, h, vid_mod=vid_nodes, arena=None, static_score=static_score, stop_layer=split,
+                            chains=arena)
         engine.tiles_run(plan, dirs, L, Hp, cells, gi, h, arena, first_layer=split, vid_mod=vid_nodes)
     elif groups > 0:
         pack_dataflow(cells.values())
@@ -238,7 +246,7 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
             keep["preact"] = preact
     else:
         pack_lockstep(cells.values(), force=True)
-        engine.frontier_run(plan, dirs, L, Hp, cells, gi, h, vid_mod=vid_nodes, arena=arena, static_score=static_score)
+        engine.frontier_run(plan, dirs, L, Hp, cells, gi, h, vid_mod=vid_nodes, arena=arena, static_score=static_score, chains=arena)
     if keep is not None:
         keep["h_buf"], keep["gi0"], keep["Hp"], keep["groups"] = h, gi, Hp, groups
     return [[h[d][i][:, :H] if h[d][i] is not None else None for i in range(L)] for d in range(2)]

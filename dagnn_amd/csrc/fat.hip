@@ -69,6 +69,8 @@ __device__ __forceinline__ int a_idx(int r, int c) { return r * 64 + ((c ^ (r & 
 
 #ifdef FAT_STAMPS   // experiment build (scripts/fat_stamps.py): phase sums over the workgroups of every launch
 __device__ unsigned long long fat_stamp_sum[8];
+__device__ int fat_cu_res[4096];              // workgroups resident per (XCD, SE, SH, CU)
+__device__ unsigned long long fat_res_hist[8];   // histogram: co-resident workgroups seen at a workgroup's start / end
 #define FAT_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&fat_stamp_sum[i], t_ - T.t0); const_cast<FatTile&>(T).t0 = t_; } } while (0)
 #else
 #define FAT_STAMP(i) do { } while (0)
@@ -140,7 +142,11 @@ __device__ __forceinline__ void fat_prologue(const int32_t* __restrict__ plan, c
         const bool mine = e < deg && deg <= 4;
         float lg = -INFINITY;
         if (mine && deg > 1) {
+#ifdef FAT_EXP_NOSCORE
+            float s = 0.f * (float)(nparts + pj);
+#else
             float s = C.sscore ? C.sscore[pj] : score_of(C.h_out + (int64_t)pj * ld_h + H, nparts);
+#endif
             if (C.vid) s += C.vid[pj % S.vid_mod];
             if (C.gain) {
                 if (S.R >= 1) s = fmaf(C.gain[0], f0, s);
@@ -186,7 +192,11 @@ __device__ __forceinline__ void fat_prologue(const int32_t* __restrict__ plan, c
         }
     }
     __syncthreads();
+#ifdef FAT_EXP_NOP1
+    const int ng = 0, nm = 0;
+#else
     const int ng = M.gen_n[0], nm = M.gen_n[1];
+#endif
     if (ng + nm > 0) {   // plain stores; the same workgroup reads the rows back behind the barrier
         const int H4 = H >> 2;
         for (int it = tid; it < nm * H4; it += FAT_THREADS) {   // P1: (row, 16-byte chunk) items, four loads in flight each
@@ -486,13 +496,30 @@ __global__ void __launch_bounds__(FAT_THREADS, 2) fat_layer_kernel(const int32_t
     __builtin_amdgcn_s_setprio(3);
 #ifdef FAT_STAMPS
     T.t0 = wall_clock64();
-    if (threadIdx.x == 0) atomicAdd(&fat_stamp_sum[7], 1ull);
+    int fat_cu_key = 0;
+    if (threadIdx.x == 0) {
+        atomicAdd(&fat_stamp_sum[7], 1ull);
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+        fat_cu_key = (int)(((xcc & 15) << 8) | ((hw >> 8) & 0xff));
+        const int seen = atomicAdd(&fat_cu_res[fat_cu_key], 1);
+        atomicAdd(&fat_res_hist[min(seen, 3)], 1ull);
+    }
 #endif
     fat_prologue(plan, L, S, T, M);
     FAT_STAMP(0);
     if (T.two) fat_pick<2>(S, T, M);
     else fat_pick<1>(S, T, M);
+#ifdef FAT_STAMPS
+    if (threadIdx.x == 0) {
+        const int seen = atomicAdd(&fat_cu_res[fat_cu_key], -1) - 1;
+        atomicAdd(&fat_res_hist[4 + min(seen, 3)], 1ull);
+    }
+#endif
 }
+
+constexpr size_t FAT_LDS_ALONE = 96 * 1024;   // more than half a CU's 160 KB
 
 inline size_t fat_lds_bytes() {
     return (size_t)FAT_MAIN * sizeof(float) + (size_t)FTM * (4 * sizeof(float*) + sizeof(float*) + 4 * sizeof(float) + 2 * sizeof(int)) +
@@ -502,9 +529,14 @@ inline size_t fat_lds_bytes() {
 }  // namespace
 
 #ifdef FAT_STAMPS
-extern "C" int dagnn_fat_debug_read(unsigned long long* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(fat_stamp_sum), sizeof(fat_stamp_sum)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(fat_stamp_sum), z, sizeof(z)); }
+extern "C" int dagnn_fat_debug_read(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(fat_stamp_sum), sizeof(fat_stamp_sum)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out16 + 8, HIP_SYMBOL(fat_res_hist), sizeof(fat_res_hist)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(fat_stamp_sum), z, sizeof(z));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(fat_res_hist), z, sizeof(z));
+    }
     return 0;
 }
 #endif
@@ -512,12 +544,12 @@ extern "C" int dagnn_fat_debug_read(unsigned long long* out8, int reset) {
 // One fat launch: every active cell of `cells` ([row_base, row_end) = the rows of its layer) in 64-row tiles.
 // `scratch` = fp32 [>= total rows of the launch, H]: aggregates of the rows with more than four predecessors.
 int dagnn_fat_launch(const int32_t* plan, const PlanLayout& L, const Cell* cells, int ncell, int H, int ld_h, int R, int vid_mod,
-                     unsigned epoch, float* scratch, hipStream_t st) {
+                     unsigned epoch, float* scratch, int num_cus, hipStream_t st) {
     if (ncell <= 0 || ncell > DAGNN_MAX_CELLS || (H % 64) || !scratch) return DAGNN_EINVAL;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(fat_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)fat_lds_bytes()) != hipSuccess)
+                                (int)FAT_LDS_ALONE) != hipSuccess)
             return DAGNN_EHIP(hipGetLastError());
         attr_set = true;
     }
@@ -534,7 +566,11 @@ int dagnn_fat_launch(const int32_t* plan, const PlanLayout& L, const Cell* cells
     }
     A.ncell = ncell; A.H = H; A.ld_h = ld_h; A.R = R; A.vid_mod = vid_mod > 0 ? vid_mod : 1; A.epoch = epoch;
     if (tiles == 0) return DAGNN_OK;
-    hipLaunchKernelGGL(fat_layer_kernel, dim3((unsigned)(tiles * (H / 32))), dim3(FAT_THREADS), fat_lds_bytes(), st, plan, L, A);
+    // a launch that fits one workgroup per CU asks for more LDS than two workgroups can share: the dispatcher would
+    // otherwise pair workgroups on some CUs (they halve each other's matrix pipe) while other CUs stay empty
+    const int wgs = tiles * (H / 32);
+    const size_t lds = wgs <= num_cus ? FAT_LDS_ALONE : fat_lds_bytes();
+    hipLaunchKernelGGL(fat_layer_kernel, dim3((unsigned)wgs), dim3(FAT_THREADS), lds, st, plan, L, A);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DAGNN_OK : DAGNN_EHIP(e);
 }

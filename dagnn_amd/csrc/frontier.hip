@@ -615,20 +615,39 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         if (rc != DAGNN_OK) return rc;
     }
 
+    // ---- two chains: the directions share nothing, so with a second stream (and no persistent tail in this call) each
+    // direction's launches run on a stream of their own - the launches of a chain are 1-3 rounds of workgroups long, and the
+    // other chain's workgroups fill the CUs a launch leaves idle while its last round drains (cfg 5: the fat part of the
+    // forward 13.6 -> see DESIGN 4f).  The side stream forks from / joins into the caller's stream on the caller's events.
+    const bool dual = !split && s_tail >= nsteps && ndir == 2 && a->side_stream != nullptr && a->debug_timing == nullptr &&
+                      a->fork_event != nullptr && a->join_event != nullptr;
+    hipStream_t chain_st[2] = {st, st};
+    int scratch_off[2] = {0, 0};
+    if (dual) {
+        const hipError_t ef = fj.begin(st, (hipStream_t)a->side_stream, a->fork_event, a->join_event);
+        if (ef != hipSuccess) return DAGNN_EHIP(ef);
+        chain_st[1] = (hipStream_t)a->side_stream;
+        for (int s = 0; s < s_eager; ++s) {   // the scratch rows of chain 1 sit behind the most chain 0 ever needs at once
+            int n0 = 0;
+            for (int i = 0; i < Ls; ++i) n0 += rows_of(dirs[0], i, s);
+            if (n0 > scratch_off[1]) scratch_off[1] = n0;
+        }
+    }
     StepArgs S;
     S.H = H; S.ld_h = a->ld_h; S.R = pl->num_edge_feats; S.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
     S.dbg = (unsigned long long*)a->debug_timing;
     S.epoch = a->epoch;
-    for (int s = 0; s < s_eager; ++s) {
+    // one launch: the cells of directions dirs[q0 .. q1) at step s, on stream `cs`
+    auto launch_group = [&](int s, int q0, int q1, hipStream_t cs, int scr_off) -> int {
         // geometry of this launch: thin launches use 16-unit slices (and 4-row blocks when that
         // still fits one round of workgroups), fat ones 32-unit slices, 8-row blocks, 2 per CU
         int rows_total = 0, blocks8 = 0, blocks4 = 0;
-        for (int q = 0; q < ndir; ++q)
+        for (int q = q0; q < q1; ++q)
             for (int i = 0; i < Ls; ++i) {
                 const int n = rows_of(dirs[q], i, s);
                 rows_total += n; blocks8 += (n + 7) / 8; blocks4 += (n + 3) / 4;
             }
-        if (rows_total == 0) continue;
+        if (rows_total == 0) return DAGNN_OK;
         // Launch shape {slice units, rows per block}: thin launches prefetch a whole 16-unit slice per
         // workgroup (1 workgroup per CU) and must fit ONE round of CUs; otherwise 32-unit slices with
         // streamed weights: 4-row blocks (96 VGPRs: three 6-wave workgroups per CU) while they fit one
@@ -640,7 +659,7 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         else { js = 32; rb = 8; }
         int nc = 0, blocks = 0;
         S.blk_start[0] = 0;
-        for (int q = 0; q < ndir; ++q) {
+        for (int q = q0; q < q1; ++q) {
             const int d = dirs[q];
             for (int i = 0; i < Ls; ++i) {
                 const int n = rows_of(d, i, s);
@@ -655,24 +674,34 @@ extern "C" int dagnn_frontier_run(const dagnn_plan* pl, const dagnn_frontier_arg
         }
         S.ncell = nc;
         S.step = s;
-        hipError_t e;
-        // the fattest launches: aggregate every row once (stage 1), then 32-row MFMA tiles (stage 2)
-        bool mfma_ok = a->agg_scratch != nullptr && rows_total <= a->agg_scratch_rows && a->mfma_min_rows > 0 &&
-                       rows_total >= a->mfma_min_rows;
+        // fat launches: 64-row MFMA tiles, gather and soft-max fused into the A staging (csrc/fat.hip).  The threshold
+        // is stated for a launch over every direction: a chain of one direction takes its share of it.
+        bool mfma_ok = a->agg_scratch != nullptr && scr_off + rows_total <= a->agg_scratch_rows && a->mfma_min_rows > 0 &&
+                       rows_total * ndir >= a->mfma_min_rows * (q1 - q0);
         for (int k = 0; k < nc && mfma_ok; ++k)
             mfma_ok = S.cell[k].whh_m != nullptr && (S.cell[k].wih == nullptr || S.cell[k].wih_m != nullptr);
-        if (mfma_ok) {   // ONE launch: 64-row MFMA tiles, gather and soft-max fused into the A staging (csrc/fat.hip)
-            const int rc = dagnn_fat_launch(plan, L, S.cell, nc, H, a->ld_h, pl->num_edge_feats, a->vid_mod, a->epoch,
-                                            (float*)a->agg_scratch, st);
+        if (mfma_ok)
+            return dagnn_fat_launch(plan, L, S.cell, nc, H, a->ld_h, pl->num_edge_feats, a->vid_mod, a->epoch,
+                                    (float*)a->agg_scratch + (int64_t)scr_off * H, a->num_cus, cs);
+        hipError_t e;
+        if (js == 32) e = rb == 8 ? launch_step<32, 8, 4, 4>(blocks, H, cs, plan, L, S)
+                                  : launch_step<32, 4, 4, 3>(blocks, H, cs, plan, L, S);
+        else if (rb == 4) e = launch_step<16, 4, 16, 1>(blocks, H, cs, plan, L, S);
+        else e = launch_step<16, 8, 16, 1>(blocks, H, cs, plan, L, S);
+        return e == hipSuccess ? DAGNN_OK : DAGNN_EHIP(e);
+    };
+    for (int s = 0; s < s_eager; ++s) {
+        if (dual) {
+            for (int q = 0; q < 2; ++q) {
+                const int rc = launch_group(s, q, q + 1, chain_st[q], scratch_off[q]);
+                if (rc != DAGNN_OK) return rc;
+            }
+        } else {
+            const int rc = launch_group(s, 0, ndir, st, 0);
             if (rc != DAGNN_OK) return rc;
-            continue;
         }
-        if (js == 32) e = rb == 8 ? launch_step<32, 8, 4, 4>(blocks, H, st, plan, L, S)
-                                  : launch_step<32, 4, 4, 3>(blocks, H, st, plan, L, S);
-        else if (rb == 4) e = launch_step<16, 4, 16, 1>(blocks, H, st, plan, L, S);
-        else e = launch_step<16, 8, 16, 1>(blocks, H, st, plan, L, S);
-        if (e != hipSuccess) return DAGNN_EHIP(e);
     }
+    if (dual) fj.mark();
     if (forked) {   // join (fj's destructor): the caller's stream continues only when the deep graphs are finished too
     } else if (!split && s_tail < nsteps) {
         const int rc = launch_tail(st, s_tail);

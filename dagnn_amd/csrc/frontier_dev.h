@@ -325,4 +325,4 @@ __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x))
 
 // csrc/fat.hip: one fat launch of the lock-step schedule (64-row MFMA tiles); `cells` as dagnn_frontier_run fills them.
 int dagnn_fat_launch(const int32_t* plan, const PlanLayout& L, const Cell* cells, int ncell, int H, int ld_h, int R, int vid_mod,
-                     unsigned epoch, float* scratch, hipStream_t st);
+                     unsigned epoch, float* scratch, int num_cus, hipStream_t st);

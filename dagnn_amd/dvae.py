@@ -274,6 +274,14 @@ class _DvaeDagnn(_DvaeBase):
         """Mode switches drop the derived-weight caches (see core.DerivedCache)."""
         for c in self.__dict__.get("_derived", {}).values():
             c.invalidate()
+        # the `add` / `max` aggregators derive their weights on the cached view object (variants._derive keeps its
+        # DerivedCache on the module it is handed): fused optimizers and `.data` writes do not bump `_version`, so a
+        # train() / eval() switch must drop that cache too, exactly as DAGNN.train() does for its own
+        view = self.__dict__.get("_agg_view_obj")
+        if view is not None:
+            vc = view.__dict__.get("_variant_cache")
+            if vc is not None:
+                vc.invalidate()
         return super().train(mode)
 
     # ---- hooks of autograd.Recurrence
@@ -574,7 +582,8 @@ class _DvaeDagnn(_DvaeBase):
             out = torch.empty(B, w.shape[0], **f32)
             a.w_out, a.b_out = w.data_ptr(), (None if lin.bias is None else lin.bias.detach().data_ptr())
             a.out, a.out_dim = out.data_ptr(), w.shape[0]
-        engine.check(lib.dagnn_encode_forward(C.byref(a), engine._stream(x)), "dagnn_encode_forward")
+        with engine.persistent_launch(x):
+            engine.check(lib.dagnn_encode_forward(C.byref(a), engine._stream(x)), "dagnn_encode_forward")
         arena.watch(None, folded=True)
         G.h = hcat
         G.batch = G.batch[0::nn_] if self.bidirectional else G.batch[nn_ - 1::nn_]

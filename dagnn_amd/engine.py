@@ -66,6 +66,7 @@ def _env_int(name: str, default: int) -> int:
 # Launch-geometry knobs (read once at import; the defaults are the measured optima on MI355X).
 # Tests flip some of them to force the less common code paths.
 RB4_MAX_WGS = _env_int("DAGNN_AMD_RB4_MAX_WGS", 0)          # 4-row vs 8-row blocks of the streamed kernel; 0 = library default
+DUAL_CHAINS = _env_int("DAGNN_AMD_DUAL_CHAINS", 1)         # the two directions' per-layer launches on two streams (H > 256)
 MFMA_MIN_ROWS = _env_int("DAGNN_AMD_MFMA_MIN_ROWS", 300)    # launches with at least this many rows use MFMA tiles; 0 = never
 TAIL_SLICE = _env_int("DAGNN_AMD_TAIL_SLICE", 32)           # hidden units per workgroup of the persistent kernel (16 | 32)
 TAIL_REPLICAS = _env_int("DAGNN_AMD_TAIL_REPLICAS", 4)      # workgroups per (cell, slice); 0 = one launch per layer throughout
@@ -122,6 +123,41 @@ def _stream(t: torch.Tensor) -> int:
 
 
 _CUS = {}
+
+
+class persistent_launch(object):
+    """Device-wide rule for the all-resident persistent kernels (`dagnn_dataflow_run[_wide]`, `dagnn_bwd_dataflow_run[_wide]`,
+    `dagnn_tiles_run`, the persistent tails of `dagnn_frontier_run` / `dagnn_backward_run`, `dagnn_encode_forward`): each of
+    them sizes its grid to the whole device (one workgroup per CU, every workgroup resident, bounded spins on the others'
+    granules), so two of them in flight on different streams would each hold part of the CUs and wait for workgroups
+    that cannot be dispatched - the micro-batch experiment of round 4 DEADLOCKED exactly like that until the bounded
+    waits expired.  Rule: inside one process, persistent launches on one device never overlap - a launch on stream B
+    first waits (on the DEVICE: `hipStreamWaitEvent`, the host never blocks) for the previous persistent launch of
+    another stream A to drain.  Everything else of a pass (plan, encoder, GEMMs, read-out, heads) still overlaps freely.
+    Across processes nothing can enforce it: ranks must not share a GPU (multi-GPU section)."""
+    _last = {}   # device index -> (event, stream handle) of the most recent persistent launch
+
+    def __init__(self, tensor: torch.Tensor):
+        self.dev = tensor.device
+
+    def __enter__(self):
+        if self.dev.type != "cuda":
+            return self
+        cur = torch.cuda.current_stream(self.dev)
+        rec = persistent_launch._last.get(self.dev.index)
+        if rec is not None and rec[1] != cur.cuda_stream:
+            cur.wait_event(rec[0])
+        return self
+
+    def __exit__(self, *exc):
+        if self.dev.type != "cuda":
+            return False
+        cur = torch.cuda.current_stream(self.dev)
+        rec = persistent_launch._last.get(self.dev.index)
+        ev = rec[0] if (rec is not None and rec[1] == cur.cuda_stream) else torch.cuda.Event()
+        ev.record(cur)   # (a waiter that was queued on an earlier record of this event keeps that earlier record)
+        persistent_launch._last[self.dev.index] = (ev, cur.cuda_stream)
+        return False
 
 
 def _num_cus(device) -> int:
@@ -430,7 +466,7 @@ def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
         raise DagnnHipError("the dataflow kernel needs a GranuleArena (persistent, zero-initialised granule buffers)")
     lib = _lib.load()
     args = dataflow_args(plan, dirs, L, H, cells, gi0, h, groups, vid_mod, arena, static_score, preact, training)
-    with _span("dataflow_run", plan.ws):
+    with persistent_launch(plan.ws), _span("dataflow_run", plan.ws):
         check(lib.dagnn_dataflow_run(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_dataflow_run")
     if score_parts and static_score is None:
         for d in dirs:
@@ -591,7 +627,7 @@ def tiles_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0,
         for d in dirs:
             args.first_layer[d] = int(first_layer[d])
     args.debug_timing = DEBUG_TIMING.data_ptr() if DEBUG_TIMING is not None else None
-    with _span("tiles_run", plan.ws):
+    with persistent_launch(plan.ws), _span("tiles_run", plan.ws):
         check(_lib.load().dagnn_tiles_run(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_tiles_run")
     arena.watch(plan, folded=True)
 
@@ -737,9 +773,12 @@ class GranuleArena(object):
 
 
 def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0, h, vid_mod: int = 0,
-                 arena: Optional[GranuleArena] = None, static_score=None, stop_layer: Optional[Sequence[int]] = None) -> None:
+                 arena: Optional[GranuleArena] = None, static_score=None, stop_layer: Optional[Sequence[int]] = None,
+                 chains: Optional[GranuleArena] = None) -> None:
     """Lock-step recurrence over all batch-level layers.  `cells[(d, i)]` are kernel-ready parameter
-    holders (core.CellParams); gi0[d] [N,3H]; h[d][i] [N, frontier_ld(H)] outputs."""
+    holders (core.CellParams); gi0[d] [N,3H]; h[d][i] [N, frontier_ld(H)] outputs.  `chains`: an arena whose side stream
+    and events the call may use to run the two directions' launches as two independent chains (no persistent tail in
+    the call: `arena` is None or the width has no tail kernel)."""
     args = FrontierArgs()
     mask = 0
     use_tail = arena is not None and TAIL_REPLICAS > 0 and H <= 256
@@ -777,12 +816,13 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     if MFMA_MIN_ROWS > 0:  # fat launches (csrc/fat.hip): scratch rows for the aggregates of rows with more than 4 predecessors
         import numpy as np
         nst = max(len(sched[0]), len(sched[1])) - 1 + L
-        width = np.zeros(nst, dtype=np.int64)
-        for d in dirs:
+        widest = 0
+        for d in dirs:   # per direction: the two directions' launches may run as two chains, each with its own rows
+            width = np.zeros(nst, dtype=np.int64)
             w = np.diff(sched[d].astype(np.int64))
             for i in range(L):  # layer t of stacked layer i runs in launch t + i
                 width[i:i + len(w)] += w
-        widest = int(width.max())
+            widest += int(width.max())
         plan.agg_scratch = torch.empty(max(widest, 1) * H, dtype=torch.float32, device=plan.ws.device)
         args.agg_scratch, args.agg_scratch_rows = plan.agg_scratch.data_ptr(), widest
     args.tail_replicas, args.tail_max_blocks = (TAIL_REPLICAS if use_tail else 0), TAIL_MAX_BLOCKS
@@ -793,13 +833,16 @@ def frontier_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     for d in (0, 1):
         ptrs[d] = sched[d].ctypes.data_as(C.POINTER(C.c_int32))
         nl[d] = len(sched[d]) - 1
+    if chains is not None and not use_tail and len(dirs) == 2 and DUAL_CHAINS and DEBUG_TIMING is None:
+        args.side_stream = chains.side_stream(plan.ws.device).cuda_stream
+        args.fork_event, args.join_event = chains.fork_join_events(plan.ws.device)
     if use_tail and SPLIT_DEEP and DEBUG_TIMING is None:
         splits = plan.read_splits()
         args.side_stream = arena.side_stream(plan.ws.device).cuda_stream
         args.fork_event, args.join_event = arena.fork_join_events(plan.ws.device)
         for d in dirs:
             args.layer_split[d] = splits[d].ctypes.data_as(C.POINTER(C.c_int32))
-    with _span("frontier_run", plan.ws):
+    with persistent_launch(plan.ws), _span("frontier_run", plan.ws):
         check(_lib.load().dagnn_frontier_run(C.byref(plan.desc), C.byref(args), ptrs, nl, _stream(plan.ws)),
               "dagnn_frontier_run")
     if arena is not None and arena.err is not None:
@@ -956,7 +999,7 @@ def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells,
         args.fork_event, args.join_event = arena.fork_join_events(dev)
         for d in dirs:
             args.layer_split[d] = splits[d].ctypes.data_as(C.POINTER(C.c_int32))
-    with _span("backward_run", plan.ws):
+    with persistent_launch(plan.ws), _span("backward_run", plan.ws):
         check(lib.dagnn_backward_run(C.byref(plan.desc), C.byref(args), ptrs, nl, _stream(plan.ws)),
               "dagnn_backward_run")
     if use_tail:
@@ -984,22 +1027,19 @@ def bwd_dataflow_groups(device, num_dirs: int, num_stacked: int, H: int, B: int)
     return dataflow_groups(device, num_dirs, num_stacked, H, B, training=True)
 
 
-BWD_DF_MAX_BYTES = _env_int("DAGNN_AMD_BWD_DF_MAX_BYTES", 0)   # cap on the reverse dataflow sweep's static records (0: half of the free memory)
+BWD_DF_MAX_BYTES = _env_int("DAGNN_AMD_BWD_DF_MAX_BYTES", 96 << 30)   # cap on what the reverse dataflow sweep may keep (a third of 288 GB)
 
 
 def bwd_dataflow_fits(device, N: int, cells: int) -> bool:
-    """The persistent reverse sweep keeps ONE 8 KB static record per (cell, node) (`dagnn_bwd_dataflow_static_bytes`) whatever
-    H is - 0.5 GB for the headline batch, tens of GB for a very large batch at H = 64.  Above 1 GB the estimate is held
-    against the memory that is actually free (the device's + what torch's allocator has cached); a batch that does not
-    fit takes the reverse lock-step launches (`backward_sweep`), which need none of it."""
-    need = int(_lib.load().dagnn_bwd_dataflow_static_bytes(int(N))) * int(cells) * 5 // 4   # (H = 320: 10 KB records)
-    if BWD_DF_MAX_BYTES > 0:
-        return need <= BWD_DF_MAX_BYTES
-    if need <= (1 << 30):
-        return True
-    free, _ = torch.cuda.mem_get_info(device)
-    free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
-    return need <= free // 2
+    """The persistent reverse sweep keeps ONE 8 KB (H = 320: 10 KB) static record per (cell, node)
+    (`dagnn_bwd_dataflow_static_bytes`) whatever H is, plus - about as much again, twice at H = 256 - the 256-byte
+    successor records, the hand-off granules (`da`, `dgi`, `du`) and the forward pass's pre-activations: ~1.5 GB for the
+    headline batch, tens of GB for a very large batch at H = 64.  The choice between the sweep and the reverse
+    lock-step launches (`backward_sweep`, which need none of it) is a pure function of (N, cells) and a FIXED byte cap
+    (`DAGNN_AMD_BWD_DF_MAX_BYTES`, default a third of an MI355X's 288 GB) - not of the memory that happens to be free - so
+    every rank and every step takes the same reverse path and gradients stay bitwise reproducible run to run."""
+    need = int(_lib.load().dagnn_bwd_dataflow_static_bytes(int(N))) * int(cells) * 3   # records x 1.25 (H = 320) + granules + preact
+    return need <= BWD_DF_MAX_BYTES
 
 
 def bwd_dataflow_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, h, gi0, g_ext, groups: int,
@@ -1091,7 +1131,7 @@ def bwd_dataflow_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, ce
             args.xcc_table = arena.xcc_table(dev).data_ptr()
             args.xcd_first = arena.xcd_first
         check(lib.dagnn_bwd_dataflow_prepare(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_bwd_dataflow_prepare")
-    with _span("backward_run", plan.ws):
+    with persistent_launch(plan.ws), _span("backward_run", plan.ws):
         check(lib.dagnn_bwd_dataflow_run(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_bwd_dataflow_run")
     arena.watch(plan, folded=True)
     for o in out.values():

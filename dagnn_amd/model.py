@@ -251,7 +251,10 @@ class DAGNN(nn.Module):
         check_arenas(self)
 
     def _arena_for(self, x, role="forward"):
-        key = (role, x.device, engine._stream(x))   # one arena per stream: passes on different streams may overlap
+        # one arena per stream: passes issued on different streams keep their own granule buffers, epochs and error words
+        # (their plan / encoder / GEMM / head kernels may overlap; the all-resident persistent launches themselves are
+        # ordered device-wide by engine.persistent_launch - two of them in flight would deadlock on each other's CUs)
+        key = (role, x.device, engine._stream(x))
         arena = self._arenas.get(key)
         if arena is None:
             arena = engine.GranuleArena()
@@ -363,8 +366,12 @@ class DAGNN(nn.Module):
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             plan = engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B, ea)
-            Hp = engine.state_width(self.hidden_dim, self.num_layers, plan.R)
-            groups = engine.dataflow_groups(dev, len(self.dirs), self.num_layers, Hp, B) if self.schedule == "lockstep" else 0
+            # the same (width, group count) key `run_stack_lockstep` will ask for: hidden sizes 257..320 run 320 wide on the
+            # dataflow kernel (`wide_ok`), a training pass under an active communicator reserves CUs for the collective
+            wide_ok = has_edge_enc and not (self.agg_x or self.agg_attn_x)
+            Hp = engine.state_width(self.hidden_dim, self.num_layers, plan.R, wide_ok=wide_ok)
+            groups = engine.dataflow_groups(dev, len(self.dirs), self.num_layers, Hp, B, training=self._training_pass()) \
+                if self.schedule == "lockstep" else 0
             if groups > 0:
                 plan.dataflow_schedule(groups)
             plan.ready = torch.cuda.Event()

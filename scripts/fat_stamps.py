@@ -12,7 +12,7 @@ G = synth.code2_batch(0, B).to(dev)
 lib = _lib.load()
 lib.dagnn_fat_debug_read.restype = C.c_int
 lib.dagnn_fat_debug_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 16)()
 with torch.no_grad():
     for _ in range(2):
         model(G.clone())
@@ -29,3 +29,4 @@ for i, nm in enumerate(names):
 print("  total                    %8.2f us" % (sum(buf[i] for i in range(6)) / max(n, 1) / 100.0))
 if buf[1]:
     print("  shader clock during the stage loops: %.2f GHz" % (buf[6] / (buf[1] * 10.0)))
+print("  other workgroups on the CU at start:", [int(buf[8 + k]) for k in range(4)], " at end:", [int(buf[12 + k]) for k in range(4)])

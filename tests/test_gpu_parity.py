@@ -225,6 +225,31 @@ def test_dvae_encode_matches_reference_golden(device, name, schedule):
     assert Hh.maxdiff(mu2, arr["mu"]) < TOL and Hh.maxdiff(lv2, arr["logvar"]) < TOL
 
 
+@pytest.mark.parametrize("name", ["na_h64_add", "bn_h64_max"])
+def test_dvae_aggregator_weights_follow_silent_parameter_updates(device, name):
+    """`add` / `max` on the D-VAE encoders derive their weights on a cached view object (variants._derive).  A fused
+    optimizer (or a write through `.data`) changes parameters without bumping `_version`: a train() / eval() switch has
+    to drop that cache too (round-4 advisor finding: eval -> silent update -> eval returned the OLD weights)."""
+    meta, arr = Hh.load(name)
+    model, _ = Hh.dvae_model(meta)
+    model = model.to(device)
+    with torch.no_grad():
+        before = model(Hh.dvae_batch(arr, device)).clone()   # eval: fills the derived-weight cache of the view
+    model.train()
+    with torch.no_grad():
+        for p_ in model.parameters():
+            p_.data.mul_(0.5)                                # no `_version` bump, like torch.optim.Adam(fused=True)
+    model.eval()
+    fresh, _ = Hh.dvae_model(meta)
+    fresh = fresh.to(device)
+    with torch.no_grad():
+        for q, p_ in zip(fresh.parameters(), model.parameters()):
+            q.copy_(p_)
+        after, want = model(Hh.dvae_batch(arr, device)), fresh(Hh.dvae_batch(arr, device))
+    assert Hh.maxdiff(after, want) < 1e-6
+    assert Hh.maxdiff(after, before) > 1e-4                  # (the update really changed the outputs)
+
+
 @pytest.mark.parametrize("name", ["code2_h256_bidir", "code2_h64_unidir", "code2_h128_deep", "code2_h64_attn_x",
                                   "code2_h512_L5"])
 @pytest.mark.parametrize("knob", ["mfma_tiles", "no_tail"])
@@ -341,6 +366,31 @@ def test_wide_deep_config_full_size_properties(device):
         assert Hh.maxdiff(sub, a[:, order]) < 2e-5
 
 
+def test_persistent_launches_of_two_streams_never_overlap(device):
+    """Device-wide rule (engine.persistent_launch): the all-resident persistent kernels size their grids to the whole
+    device, so passes issued on DIFFERENT streams must not run their recurrences at the same time (round 4's micro-batch
+    experiment deadlocked until the bounded waits expired).  Eight forwards alternating over two streams - headline shape
+    (dataflow kernel) and a 512-wide model (tile kernel) - give the bits of the one-stream passes, no bounded wait
+    expires, and the rule records the handover (the later launch waited on the earlier stream's event)."""
+    for H, L in ((256, 2), (512, 2)):
+        model = _headline_model(H=H, L=L, V=32, seed=4).to(device)
+        batches = [synth.code2_batch(30 + k, 48, 60).to(device) for k in range(2)]
+        with torch.no_grad():
+            ref = [torch.stack(model(b.clone())) for b in batches]
+            torch.cuda.synchronize()
+            streams = [torch.cuda.Stream(device) for _ in range(2)]
+            outs = []
+            for k in range(8):
+                with torch.cuda.stream(streams[k % 2]):
+                    outs.append(torch.stack(model(batches[k % 2].clone())))
+            last = engine.persistent_launch._last.get(torch.device(device).index or 0)
+            assert last is not None and last[1] == streams[1].cuda_stream
+            torch.cuda.synchronize()
+        model.check()
+        for k, o in enumerate(outs):
+            assert torch.equal(o, ref[k % 2]), (H, k)
+
+
 _ORACLE_CACHE = {}
 
 
@@ -353,11 +403,20 @@ def _oracle_forward(key, model, b, L):
     return _ORACLE_CACHE[key]
 
 
-def test_wide_deep_config_matches_oracle(device, schedule):
-    """cfg 5 shape (h=512, L=5, bidir) on a 14-graph batch."""
+@pytest.mark.parametrize("path", ["default", "fat_launches", "fat_one_chain"])
+def test_wide_deep_config_matches_oracle(device, schedule, path, monkeypatch):
+    """cfg 5 shape (h=512, L=5, bidir) on a 24-graph batch (the oracle runs once per session): the default policy (the
+    tile kernel alone at this size), every layer as a fat launch of 64-row MFMA tiles (csrc/fat.hip) on two chains, and
+    the same on one chain."""
+    if path != "default":
+        if schedule != "lockstep":
+            pytest.skip("the fat launches belong to the lock-step schedule")
+        monkeypatch.setattr(engine, "TILES", 0)
+        monkeypatch.setattr(engine, "MFMA_MIN_ROWS", 1)
+        monkeypatch.setattr(engine, "DUAL_CHAINS", 1 if path == "fat_launches" else 0)
     model = _headline_model(H=512, L=5, V=32, seed=5)
-    b = synth.code2_batch(21, 14)
-    ref = _oracle_forward("cfg5_14", model, b, 5)
+    b = synth.code2_batch(21, 24)
+    ref = _oracle_forward("cfg5_24", model, b, 5)
     model = model.to(device)
     with torch.no_grad():
         out = model(b.to(device))

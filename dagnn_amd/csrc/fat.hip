@@ -37,10 +37,14 @@ namespace {
 
 typedef float mf32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef FAT_WGS_PER_CU
+#define FAT_WGS_PER_CU 2              // co-resident workgroups per CU the kernel is built for (3: <= 168 VGPRs, lean shape)
+#endif
+constexpr bool FAT_LEAN = FAT_WGS_PER_CU >= 3;   // single B register set refilled in place, row pointers re-read from LDS per stage
 constexpr int FTM = 64;               // rows per tile
 constexpr int FAT_THREADS = 256;
 constexpr int FAT_SLOT = FTM * 64;    // floats per A slot: 64 rows x 64 k
-constexpr int FAT_OP = 100;           // row pitch of the epilogue tile (96 sums + 4: rows 4 apart fall on different banks)
+constexpr int FAT_OP = 96;            // row pitch of the epilogue tile
 constexpr int FAT_OUT = 2 * FTM * FAT_OP;   // floats of the epilogue tile: [side][row][3 gates x 32 units]
 constexpr int FAT_MAIN = FAT_OUT > 2 * FAT_SLOT ? FAT_OUT : 2 * FAT_SLOT;
 
@@ -87,9 +91,9 @@ struct FatTile {            // what the prologue hands to the main part (all uni
 
 struct FatLds {
     float* ring;            // [2][64][64] A slots | [2][64][96] outputs
-    uint64_t* hptr;         // [64][4] predecessor rows (or a finite dummy), as addresses
+    uint64_t* hptr;         // [64][2] predecessor rows (or a finite dummy), as addresses
     uint64_t* iptr;         // [64] lower-layer row
-    float* alpha;           // [64][4]
+    float* alpha;           // [64][2]
     int* node_s;            // [64]
     int* gen_s;             // [64] rows with more than 4 predecessors
     int* gen_n;             // [0] their count, [1] some row gathers 3-4 inline predecessors
@@ -99,9 +103,9 @@ __device__ __forceinline__ FatLds fat_lds(float* smem) {
     FatLds M;
     M.ring = smem;
     M.hptr = reinterpret_cast<uint64_t*>(smem + FAT_MAIN);
-    M.iptr = M.hptr + FTM * 4;
+    M.iptr = M.hptr + FTM * 2;
     M.alpha = reinterpret_cast<float*>(M.iptr + FTM);
-    M.node_s = reinterpret_cast<int*>(M.alpha + FTM * 4);
+    M.node_s = reinterpret_cast<int*>(M.alpha + FTM * 2);
     M.gen_s = M.node_s + FTM;
     M.gen_n = M.gen_s + FTM;
     return M;
@@ -184,8 +188,10 @@ __device__ __forceinline__ void fat_prologue(const int32_t* __restrict__ plan, c
             p = e == 0 ? C.a_pre + (int64_t)(T.slot0 - C.row_base + r) * H : dummy;
             al = e == 0 ? 1.f : 0.f;
         }
-        M.hptr[r * 4 + e] = reinterpret_cast<uint64_t>(p);
-        M.alpha[r * 4 + e] = al;
+        if (e < 2) {
+            M.hptr[r * 2 + e] = reinterpret_cast<uint64_t>(p);
+            M.alpha[r * 2 + e] = al;
+        }
         if (e == 0) {
             M.node_s[r] = rec0.x;
             M.iptr[r] = reinterpret_cast<uint64_t>(T.has_in ? C.h_in + (int64_t)rec0.x * ld_h : dummy);
@@ -255,13 +261,16 @@ __device__ __forceinline__ void fat_main(const FatArgs& S, const FatTile& T, con
     uint64_t sp_in[2];             // input rows of my two staging rows (addresses)
     uint64_t sp_h[2][MD];          // predecessor rows
     float sa[2][MD];
+    auto row_meta = [&]() {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int r = rr + 32 * it;
-        sp_in[it] = M.iptr[r] + 16 * c8;
+        for (int it = 0; it < 2; ++it) {
+            const int r = rr + 32 * it;
+            sp_in[it] = M.iptr[r] + 16 * c8;
 #pragma unroll
-        for (int e = 0; e < MD; ++e) { sp_h[it][e] = M.hptr[r * 4 + e] + 16 * c8; sa[it][e] = M.alpha[r * 4 + e]; }
-    }
+            for (int e = 0; e < MD; ++e) { sp_h[it][e] = M.hptr[r * 2 + e] + 16 * c8; sa[it][e] = M.alpha[r * 2 + e]; }
+        }
+    };
+    if constexpr (!FAT_LEAN) row_meta();
     // compute role: wave = (side hs, row block rb); lane = (row / column i, k quarter kq) of a 16x16x4 fragment
     const int hs = wave >> 1, rb = wave & 1;
     const int fi = lane & 15, kq = lane >> 4;
@@ -280,6 +289,7 @@ __device__ __forceinline__ void fat_main(const FatArgs& S, const FatTile& T, con
 
     float4 areg[2][2][MD];   // [row half][side][predecessor] loads in flight
     auto a_issue = [&](int s) {
+        if constexpr (FAT_LEAN) row_meta();   // (a handful of LDS reads per stage instead of 16 more live registers)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = kmul * s + koff[h];
@@ -297,6 +307,12 @@ __device__ __forceinline__ void fat_main(const FatArgs& S, const FatTile& T, con
     };
     auto a_commit = [&](int slot) {
         float* base = ring + slot * FAT_SLOT;
+        if constexpr (FAT_LEAN) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int e = 0; e < MD; ++e) sa[it][e] = M.alpha[(rr + 32 * it) * 2 + e];
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -315,22 +331,21 @@ __device__ __forceinline__ void fat_main(const FatArgs& S, const FatTile& T, con
         }
     };
     // B fragments: two register sets used in turn (even / odd stages): a whole stage of lead for the weight loads, no copies
-    float4 bA[2][6], bB[2][6];
-    auto b_issue = [&](int s, float4 (&dst)[2][6]) {
-        const int k16 = (kmul * s + my_koff) >> 4;
+    float4 bA[2][6], bB[FAT_LEAN ? 1 : 2][6];
+    auto b_issue_g = [&](int s, int gq, float4 (&dst)[6]) {
+        const int k16 = ((kmul * s + my_koff) >> 4) + gq;
 #pragma unroll
-        for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-            for (int n = 0; n < 6; ++n) dst[gq][n] = wp[n * blk_stride + (int64_t)(k16 + gq) * 64];
+        for (int n = 0; n < 6; ++n) dst[n] = wp[n * blk_stride + (int64_t)k16 * 64];
     };
+    auto b_issue = [&](int s, float4 (&dst)[2][6]) { b_issue_g(s, 0, dst[0]); b_issue_g(s, 1, dst[1]); };
     // one stage: products of slot s & 1 with `cur`; meanwhile the next stage's B fragments -> `nxt`, its A tile -> the other
     // slot, the A rows of stage s + 2 -> registers
-    auto stage = [&](int s, float4 (&cur)[2][6], float4 (&nxt)[2][6]) {
+    auto stage = [&](int s, float4 (&cur)[2][6], float4 (&nxt)[FAT_LEAN ? 1 : 2][6]) {
         const float* slot = ring + (s & 1) * FAT_SLOT;
         // every load below is unconditional (the last stages re-read the final stage's operands): a load behind a
         // branch makes hipcc's wait counts assume the shortest queue, and the products then wait for loads they do not use
         const int s1 = min(s + 1, nstage - 1), s2 = min(s + 2, nstage - 1);
-        b_issue(s1, nxt);
+        if constexpr (!FAT_LEAN) b_issue(s1, nxt);
         float4 af[2][MB];   // [k group][row block] A fragments: k = 16 gq + 4 kq + q for q = 0..3
 #pragma unroll
         for (int gq = 0; gq < 2; ++gq)
@@ -353,6 +368,7 @@ __device__ __forceinline__ void fat_main(const FatArgs& S, const FatTile& T, con
                     }
                 }
             }
+            if constexpr (FAT_LEAN) b_issue_g(s1, gq, cur[gq]);   // this half's fragments are consumed: refill them for the next stage
         }
         a_commit((s + 1) & 1);
         a_issue(s2);
@@ -372,9 +388,13 @@ __device__ __forceinline__ void fat_main(const FatArgs& S, const FatTile& T, con
         a_commit(0);
         a_issue(min(1, nstage - 1));
         __syncthreads();
-        for (int s = 0; s < nstage; s += 2) {
-            stage(s, bA, bB);
-            if (s + 1 < nstage) stage(s + 1, bB, bA);
+        if constexpr (FAT_LEAN) {
+            for (int s = 0; s < nstage; ++s) stage(s, bA, bB);
+        } else {
+            for (int s = 0; s < nstage; s += 2) {
+                stage(s, bA, bB);
+                if (s + 1 < nstage) stage(s + 1, bB, bA);
+            }
         }
 #ifdef FAT_STAMPS
         if (threadIdx.x == 0) atomicAdd(&fat_stamp_sum[6], (unsigned long long)(clock64() - cyc0));
@@ -396,7 +416,7 @@ __device__ __forceinline__ void fat_main(const FatArgs& S, const FatTile& T, con
         av[p] = 0.f; g0r[p] = 0.f; g0z[p] = 0.f; g0n[p] = 0.f;
         if constexpr (has_hid) {
 #pragma unroll
-            for (int e = 0; e < MD; ++e) av[p] = fmaf(M.alpha[r * 4 + e], ldg1(M.hptr[r * 4 + e] + 4 * (uint64_t)j), av[p]);
+            for (int e = 0; e < MD; ++e) av[p] = fmaf(M.alpha[r * 2 + e], ldg1(M.hptr[r * 2 + e] + 4 * (uint64_t)j), av[p]);
         }
         if constexpr (!has_in) {
             const float* g0 = C.gi0 + (int64_t)gvv[p] * 3 * H;
@@ -478,7 +498,7 @@ __device__ __forceinline__ void fat_pick(const FatArgs& S, const FatTile& T, con
     else fat_main<0, MB>(S, T, M);
 }
 
-__global__ void __launch_bounds__(FAT_THREADS, 2) fat_layer_kernel(const int32_t* __restrict__ plan, PlanLayout L, FatArgs S) {
+__global__ void __launch_bounds__(FAT_THREADS, FAT_WGS_PER_CU) fat_layer_kernel(const int32_t* __restrict__ plan, PlanLayout L, FatArgs S) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int NS = S.H >> 5;
     const int gb = blockIdx.x / NS;
@@ -522,7 +542,7 @@ __global__ void __launch_bounds__(FAT_THREADS, 2) fat_layer_kernel(const int32_t
 constexpr size_t FAT_LDS_ALONE = 96 * 1024;   // more than half a CU's 160 KB
 
 inline size_t fat_lds_bytes() {
-    return (size_t)FAT_MAIN * sizeof(float) + (size_t)FTM * (4 * sizeof(float*) + sizeof(float*) + 4 * sizeof(float) + 2 * sizeof(int)) +
+    return (size_t)FAT_MAIN * sizeof(float) + (size_t)FTM * (2 * sizeof(float*) + sizeof(float*) + 2 * sizeof(float) + 2 * sizeof(int)) +
            16 * sizeof(int);
 }
 

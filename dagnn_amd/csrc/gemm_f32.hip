@@ -12,6 +12,8 @@
 // the per-MFMA fragment reads (lane&31 -> consecutive rows, lane>>5 -> k) are conflict-free
 // ds_read_b32.  Register prefetch + double-buffered LDS: one barrier per K tile.  Blocks are
 // remapped so that the Nc/128 column tiles of one row tile run on the same XCD and share A in L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -147,6 +149,116 @@ __global__ void __launch_bounds__(256) gemm_nt_bias_kernel(GemmGroups G, int64_t
     }
 }
 
+// ---- K a multiple of 32, 16-byte aligned rows (every GRU matrix of the models here): the same 128 x 128 block tile on
+// 128-bit LDS traffic.  The kernel above stores every operand float with its own ds_write_b32 (k-major transpose), reads one
+// ds_read_b32 per MFMA operand and meets a barrier every 16 k: 52 % (headline, K = 256) to 63 % (cfg 5, K = 512) of the
+// fp32 matrix peak.  Here a stage is 32 k, both operands stay ROW-major in LDS (pitch 36 floats: the 16 rows of a
+// ds_read_b128 lane group fall on 16 different bank quads, no swizzle), a thread moves four 16-byte chunks per operand and
+// stage (global_load_dwordx4 -> ds_write_b128, one stage ahead in registers), and a lane's A / B fragment for FOUR
+// consecutive MFMAs is one ds_read_b128: lane (i, hh) holds k = 8 g + 4 hh + q, q = 0..3 - instruction q multiplies k = 8 g + q
+// (lanes 0-31) and 8 g + 4 + q (lanes 32-63).  The sum over k is the same set of exact fp32 fmaf steps in another order
+// (deterministic; which kernel runs depends on (K, alignment) only, never on M or the group count).
+constexpr int GK = 32, GP = GK + 4;
+
+__device__ __forceinline__ void load_rows4(const float* __restrict__ P, int64_t rows, int ld, int64_t row0, int k0, int tid,
+                                           float4 (&v)[4]) {
+    const int c = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int64_t r = row0 + (tid >> 3) + 32 * i;
+        r = r < rows ? r : rows - 1;   // rows past the end repeat the last one (their outputs are never stored)
+        v[i] = *reinterpret_cast<const float4*>(P + r * ld + k0 + 4 * c);
+    }
+}
+
+__device__ __forceinline__ void store_rows4(float* __restrict__ S, int tid, const float4 (&v)[4]) {
+    const int c = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(S + ((tid >> 3) + 32 * i) * GP + 4 * c) = v[i];
+}
+
+__global__ void __launch_bounds__(256, 2) gemm_nt_bias_k32_kernel(GemmGroups G, int64_t M, int Nc, int K, int lda, int ldw,
+                                                                  int ldc, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];   // [2][A: 128 x GP | B: 128 x GP]
+    const int g = blockIdx.y;
+    const float* __restrict__ A = G.A[g];
+    const float* __restrict__ W = G.W[g];
+    const float* __restrict__ bias = G.bias[g];
+    float* __restrict__ C = G.C[g];
+    const int nwg = tiles_m * tiles_n;   // XCD-aware remap, as above
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tm = swz / tiles_n, tn = swz - tm * tiles_n;
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int fr = lane & 31, fk = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float4 ra[4], rb[4];
+    load_rows4(A, M, lda, m0, 0, tid, ra);
+    load_rows4(W, Nc, ldw, n0, 0, tid, rb);
+    store_rows4(gsm, tid, ra);
+    store_rows4(gsm + BM * GP, tid, rb);
+    __syncthreads();
+    const int nk = K / GK;
+    for (int t = 0; t < nk; ++t) {
+        const int tn1 = min(t + 1, nk - 1);   // unconditional (the last stage re-reads itself): no load behind a branch
+        load_rows4(A, M, lda, m0, tn1 * GK, tid, ra);
+        load_rows4(W, Nc, ldw, n0, tn1 * GK, tid, rb);
+        const float* as = gsm + (t & 1) * (2 * BM * GP);
+        const float* bs = as + BM * GP;
+#pragma unroll
+        for (int kg = 0; kg < GK / 8; ++kg) {
+            float4 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const float4*>(as + (wm + 32 * i + fr) * GP + 8 * kg + 4 * fk);
+                bf[i] = *reinterpret_cast<const float4*>(bs + (wn + 32 * i + fr) * GP + 8 * kg + 4 * fk);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float av = q == 0 ? af[i].x : q == 1 ? af[i].y : q == 2 ? af[i].z : af[i].w;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float bv = q == 0 ? bf[j].x : q == 1 ? bf[j].y : q == 2 ? bf[j].z : bf[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        float* ns = gsm + ((t + 1) & 1) * (2 * BM * GP);
+        store_rows4(ns, tid, ra);
+        store_rows4(ns + BM * GP, tid, rb);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn + j * 32 + fr;
+        if (col >= Nc) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fk;
+                if (row < M) C[row * ldc + col] = acc[i][j][e] + bv;
+            }
+        }
+    }
+}
+
 // ---- small weight matrices (Nc * K <= 32 K words, or K <= 16; K a multiple of 4, 16-byte aligned rows): one output per thread.  The D-VAE encoders' input
 // products have K = 8 / 10 (one-hot vertex types) and their final projection is 64 x 256 x 128: the 128 x 128 MFMA tile
 // kernel above runs those on 1-12 workgroups in ~21 us (rocprofv3: 42 of the 125 us of kernels in a cfg 1 forward).
@@ -202,7 +314,19 @@ extern "C" int dagnn_gemm_nt_bias(const dagnn_gemm_group* groups, int num_groups
     if (tiles_m64 * tiles_n >= (int64_t(1) << 31)) return DAGNN_EINVAL;
     const int tiles_m = (int)tiles_m64;
     dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)num_groups);
-    if (vec)
+    static const bool k32_off = getenv("DAGNN_AMD_GEMM_K32") && getenv("DAGNN_AMD_GEMM_K32")[0] == '0';   // A/B knob
+    if (vec && K % GK == 0 && !k32_off) {
+        constexpr size_t lds = (size_t)2 * 2 * BM * GP * sizeof(float);   // 72 KB: two blocks per CU
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bias_k32_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return DAGNN_EHIP(hipGetLastError());
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_nt_bias_k32_kernel, grid, dim3(256), lds, (hipStream_t)stream, G, M, Nc, K, lda, ldw, ldc,
+                           tiles_m, tiles_n);
+    } else if (vec)
         hipLaunchKernelGGL(gemm_nt_bias_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, G, M, Nc, K, lda, ldw,
                            ldc, tiles_m, tiles_n);
     else

@@ -82,6 +82,7 @@ BWD_TAIL_MAX_BLOCKS = _env_int("DAGNN_AMD_BWD_TAIL_MAX_BLOCKS", 4)
 # they then run concurrently but 2-4x slower (plan_ptr 61 us instead of 15, plan_graph 103 instead of 49), bench.py
 # 2.302-2.312 against 2.3085 ms - nothing - and two processes sharing one GPU (the two-rank bench test) failed.
 PLAN_OVERLAP = _env_int("DAGNN_AMD_PLAN_OVERLAP", 0)
+SIDE_PRIORITY = _env_int("DAGNN_AMD_SIDE_PRIORITY", 0)     # stream priority of an arena's side stream (-1: high)
 PLAN_SMALL = _env_int("DAGNN_AMD_PLAN_SMALL", 1)            # 1: batches of <= 2048 nodes / 4096 edges / 512 graphs build plan and schedule with one workgroup each (csrc/small.hip)
 PLAN_GENERAL_BUILD = 1                                      # dagnn_plan.flags: keep the plan on the general kernels
 DATAFLOW = _env_int("DAGNN_AMD_DATAFLOW", 1)                # 1: the persistent graph-affine dataflow kernel where it applies (H <= 256)
@@ -675,7 +676,7 @@ class GranuleArena(object):
         """Second stream for the split mode (created once): the persistent kernel runs on it next to the per-layer
         launches of the caller's stream."""
         if self.side is None or self.side.device != device:
-            self.side = torch.cuda.Stream(device)
+            self.side = torch.cuda.Stream(device, priority=SIDE_PRIORITY)
         return self.side
 
     def fork_join_events(self, device):

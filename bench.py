@@ -581,6 +581,46 @@ def main():
                                    "time >= max(layers) x the dependent hop of the dataflow kernel (~3 us) - strong scaling of ONE "
                                    "128-graph batch saturates near 1x; ranks scale by taking MORE graphs each (the weak-scaling headline)",
                           "deepest_shard_layers": max(int(a[2]) for a in allinfo)}
+    # N > 1: what explains a scaling line - per rank the group count of the persistent launches (inference pass / training pass
+    # under the active communicator), the CUs a training pass leaves to the collective, and a second weak-scaling entry on
+    # DIFFERENT batches per rank (seed = rank: other depths, the slowest rank binds) next to the same-batch headline
+    multi_res = None
+    if world > 1 and args.streams == 1:
+        from dagnn_amd import engine as _eng
+        Hp_ = (H + 63) // 64 * 64
+        mine_info = torch.tensor([_eng.dataflow_groups(device, 2, L, Hp_, B), _eng.dataflow_groups(device, 2, L, Hp_, B, training=True),
+                                  _eng.reserved_cus(True), _eng._num_cus(device)], dtype=torch.int64, device=device)
+        infos = [torch.zeros_like(mine_info) for _ in range(world)]
+        dist.all_gather(infos, mine_info)
+        multi_res = {"per_rank": [{"rank": r, "dataflow_groups_inference": int(a[0]), "dataflow_groups_training": int(a[1]),
+                                   "reserved_cus_training": int(a[2]), "num_cus": int(a[3])} for r, a in enumerate(infos)],
+                     "expected_weak_scaling": "N x the N = 1 value for the forward (no data-path collective, one process per GPU: "
+                                              "DESIGN.md section 6 states the predicted N = 2 / 4 / 8 values); a training pass "
+                                              "under the communicator runs dataflow_groups_training groups (reserved CUs) instead "
+                                              "of dataflow_groups_inference"}
+        if not args.rank_seeds:
+            rb = code2_batch(seed=rank, num_graphs=B).to(device)
+            rin = fresh_inputs(rb, args.warmup + args.steps)
+            with torch.no_grad():
+                for i in range(args.warmup):
+                    model(rin[i])
+                barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(args.warmup, args.warmup + args.steps):
+                    model(rin[i])
+                torch.cuda.synchronize()
+                barrier()
+                tr = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+            rinfo = torch.tensor([rb.x.shape[0], int(rb._bi_layer_idx0.max()) + 1], dtype=torch.int64, device=device)
+            rall = [torch.zeros_like(rinfo) for _ in range(world)]
+            dist.all_gather(rall, rinfo)
+            multi_res["weak_scaling_rank_seeds"] = {
+                "scaling": "weak", "what": "one %d-graph batch per rank drawn with seed = rank (different depths per rank); "
+                                           "time = slowest rank" % B,
+                "ms_per_step": round(float(tr) / args.steps * 1e3, 4), "graphs_per_s": round(world * B * args.steps / float(tr), 1),
+                "nodes_layers_per_rank": [[int(v) for v in a.tolist()] for a in rall]}
     train_res = None
     if args.train_steps > 0 and args.streams == 1 and model.schedule == "lockstep":
         tw = 5
@@ -624,7 +664,7 @@ def main():
             if ms_fwd > 0:
                 tf = flops / (ms_fwd * 1e-3) / 1e12
                 traffic, traffic_source = None, None
-                tname = "r04_pmc_traffic.json" if df else "pmc_traffic.json"
+                tname = "r05_pmc_traffic.json" if df else "pmc_traffic.json"
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if lock and os.path.exists(tpath):  # separate rocprofv3 --pmc passes of this command, see profiles/README.md
                     rec = json.load(open(tpath))
@@ -644,8 +684,8 @@ def main():
                              "as tagged granules (through the shared L2 where a cell and its readers sit on one XCD - "
                              "checked at run time); code specialised per cell variant; products on v_mfma_f32_4x4x1")
                 elif lock:
-                    kname = ("recurrence = aggregate_rows_kernel + frontier_mfma_kernel + frontier_step_kernel (one launch "
-                             "per topological layer) overlapped with frontier_tail_kernel (persistent, deep graphs); "
+                    kname = ("recurrence = fat_layer_kernel (64-row MFMA tiles, gather fused) + frontier_step_kernel (one launch "
+                             "per topological layer and direction) + frontier_tail_kernel / tiles_kernel (persistent, thin tail); "
                              "figures are per forward(G)")
                 else:
                     kname = ("recurrence_kernel<KSL> (dagnn_recurrence_layer): %d launches per forward, one per stacked "
@@ -678,6 +718,8 @@ def main():
             result["loader_side_plan"] = planned_res
         if strong_res is not None:
             result["strong_scaling"] = strong_res
+        if multi_res is not None:
+            result["multi_gpu"] = multi_res
         if train_res is not None:
             result["training_step"] = train_res
         if other_res is not None:

@@ -446,6 +446,13 @@ def main():
         return _dvae_default_hs()
     if only == "dvae_self_attn":
         return _dvae_self_attn()
+    if only in (None, "grad", "grad_h300"):
+        # the reference's own training width (scripts/ogb_tok.sh:17: --emb_dim=300): the 320-wide reverse sweep
+        # (csrc/bwd_dataflow_w.hip) against the reference's loss.backward(), not only against the oracle's autograd
+        make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, "grad_h300_bidir", data_seed=31, B=6, mean_n=40, H=300,
+                        L=2, w_seed=131, y_seed=331, **common)
+    if only == "grad_h300":
+        return
     # training-step gradients: loss and parameter gradients of one step
     if True:
         make_code2_grad(ref_dagnn, ref_utils, ref_dagutils, "grad_h32_bidir", data_seed=11, B=6, mean_n=30, H=32,

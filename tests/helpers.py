@@ -19,7 +19,7 @@ CODE2 = ["code2_h32_bidir", "code2_h256_bidir", "code2_h512_L5", "code2_h300_L3"
          "code2_h64_self_attn_x"]
 VARIANTS = ["var_h64_" + t for t in ("gated_sum", "gated_nobias", "mattn_h", "add", "max", "aggx_attn_h", "aggx_add",
                                         "recurr0", "recurr0_gated")]
-GRAD = ["grad_h32_bidir", "grad_h256_bidir", "grad_h128_deep", "grad_h64_L3_wx", "grad_h64_unidir",
+GRAD = ["grad_h32_bidir", "grad_h256_bidir", "grad_h128_deep", "grad_h64_L3_wx", "grad_h300_bidir", "grad_h64_unidir",
         "grad_h64_mean_all"]
 GRAD_VAR = ["grad_var_h64_" + t for t in ("gated_sum", "gated_nobias", "mattn_h", "add", "mattn_h_L3", "max", "recurr0_gated",
                                            "recurr0_mattn", "recurr0_attn_h", "recurr0_attn_x", "recurr0_self_attn_h",

@@ -321,6 +321,40 @@ def test_headline_batch_matches_oracle(device, schedule):
     assert max(Hh.maxdiff(o, r) for o, r in zip(out, ref)) < TOL
 
 
+def test_bn_config_full_batch_matches_oracle(device, schedule):
+    """cfg 4 at BASELINE.json's full size: `DAGNN_BN`, the bench's own batch (B = 128 synthetic Bayesian-network rows of seed 0,
+    N = 1 280), h = 256, L = 2, bidirectional - `(mu, logvar)` and the graph vectors against the oracle (the reference fixture
+    `bn_h256_bidir` holds 32 graphs; the plan / schedule word-for-word tests run at 128 but compare no states)."""
+    from dagnn_amd import DAGNN_BN
+    model = DAGNN_BN(10, 256, 256, 10, 10, 0, 1, hs=256, nz=56, num_nodes=10, num_layers=2, bidirectional=True).eval()
+    seeded_fill(model, 4128)
+    G = synth.dvae_batch([synth.decode_bn_row(r) for r in synth.bn_rows(0, 128)])
+    key = "cfg4_full"
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = O.dvae_encode(model.state_dict(), copy.deepcopy(G), num_layers=2, bidirectional=True, num_nodes=10,
+                                           vids=False)
+    mu_ref, lv_ref = _ORACLE_CACHE[key]
+    model = model.to(device)
+    with torch.no_grad():
+        Hg = model(G.to(device))
+        mu, lv = model.fc1(Hg), model.fc2(Hg)
+    assert Hh.maxdiff(mu, mu_ref) < TOL and Hh.maxdiff(lv, lv_ref) < TOL
+
+
+def test_reference_training_shape_matches_oracle(device):
+    """The reference's own training shape (scripts/ogb_tok.sh:17,63: emb_dim = hidden = 300, batch 160, L = 2, bidirectional) on
+    the bench's batch (seed 0, B = 160: N = 20 168): the 320-wide dataflow kernels against the oracle at the model's own width -
+    logits of all five heads (the 18-graph tests of the wide shape do not reach the bench batch's depth of 374 layers)."""
+    model = _headline_model(H=300, L=2, V=32, seed=6)
+    b = synth.code2_batch(0, 160)
+    ref = _oracle_forward("ogb_tok_h300_B160", model, b, 2)
+    model = model.to(device)
+    with torch.no_grad():
+        out = model(b.to(device))
+    assert max(Hh.maxdiff(o, r) for o, r in zip(out, ref)) < TOL
+    model.check()
+
+
 def test_headline_properties(device, schedule):
     """Size-independent properties at BASELINE size: run-to-run bitwise determinism, graph
     independence (any sharding of the batch gives the same rows), graph-order equivariance."""

@@ -13,6 +13,8 @@ from . import build as _build
 
 MAX_DIRS = 2
 MAX_GROUPS = 4
+MAX_READOUT_JOBS = 24      # DAGNN_MAX_READOUT_JOBS
+ATTN_GRAD_MAX_JOBS = 16    # DAGNN_ATTN_GRAD_MAX_JOBS
 
 DAGNN_OK = 0
 _ERRORS = {-22: "DAGNN_EINVAL (bad argument)", -28: "DAGNN_ENOSPC (workspace too small)"}
@@ -24,6 +26,22 @@ class DagnnHipError(RuntimeError):
 
 class ReadoutJob(C.Structure):
     _fields_ = [("h", C.c_void_p), ("ld_h", C.c_int), ("width", C.c_int), ("dir", C.c_int), ("col_off", C.c_int)]
+
+
+class DfPackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("aux", C.c_void_p), ("transposed", C.c_int32), ("rows", C.c_int32),
+                ("cols", C.c_int32)]
+
+
+class ReadoutBwdJob(C.Structure):
+    _fields_ = [("h", C.c_void_p), ("grad_h", C.c_void_p), ("ld_h", C.c_int32), ("ld_g", C.c_int32), ("width", C.c_int32),
+                ("dir", C.c_int32), ("col_off", C.c_int32)]
+
+
+class AttnGradJob(C.Structure):
+    _fields_ = [("key_sum", C.c_void_p), ("feat_sum", C.c_void_p), ("sigma_sum", C.c_void_p), ("edge_w", C.c_void_p),
+                ("edge_b", C.c_void_p), ("attn_w", C.c_void_p), ("g_attn", C.c_void_p), ("g_edge_w", C.c_void_p),
+                ("g_edge_b", C.c_void_p), ("dq", C.c_int32), ("kd", C.c_int32), ("attn_len", C.c_int32), ("R", C.c_int32)]
 
 
 class Plan(C.Structure):
@@ -246,6 +264,10 @@ SYMBOLS = {
                                   C.c_size_t, C.c_void_p]),
     "dagnn_readout_max_backward": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                              C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "dagnn_pack_dataflow_batch": (C.c_int, [C.POINTER(DfPackJob), C.c_int, C.c_int, C.c_void_p]),
+    "dagnn_attn_grads_run": (C.c_int, [C.POINTER(AttnGradJob), C.c_int, C.c_void_p]),
+    "dagnn_readout_max_backward_batch": (C.c_int, [C.POINTER(Plan), C.POINTER(ReadoutBwdJob), C.c_int, C.c_void_p, C.c_int,
+                                                   C.c_void_p]),
     "dagnn_topo_layers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
     "dagnn_variant_aggregate": (C.c_int, [C.POINTER(Plan), C.POINTER(VariantAggregator), C.c_int, C.c_int32, C.c_int32,

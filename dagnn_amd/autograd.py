@@ -95,8 +95,8 @@ class Recurrence(torch.autograd.Function):
         params = [next(it) if present else None for present in ctx.present]
         L, H, dirs, Hp = mod.num_layers, mod.hidden_dim, mod.dirs, keep["Hp"]
         N, dev = x.shape[0], x.device
-        g_ext = [[torch.zeros(N, Hp, dtype=torch.float32, device=dev) if d in dirs else None for _ in range(L)]
-                 for d in range(2)]
+        g_all = torch.zeros(len(dirs) * L, N, Hp, dtype=torch.float32, device=dev)   # (one fill instead of one per cell)
+        g_ext = [[g_all[dirs.index(d) * L + i] if d in dirs else None for i in range(L)] for d in range(2)]
         dx = torch.zeros_like(x)
         if ctx.fused:
             mod._readout_backward(plan, x, h, gouts[0].contiguous().float(), g_ext, dx)
@@ -143,40 +143,47 @@ class Recurrence(torch.autograd.Function):
                     if r["edge_feat_grad"] is not None:
                         cs_jobs += [(r["edge_feat_grad"], None), (r["sigma"], None)]
         cs = engine.colsums(cs_jobs, N) if cs_jobs else None
+        # gradients of attn_lin.weight and of the edge encoder, every cell in ONE launch (csrc/wgrad.hip).  The attention logit is
+        # s_e = w_key . (h_p + W_e feat_e + b_e) [+ w_vid[p mod n]] (+ query and bias terms that cancel in the segment
+        # softmax: their gradients are exact zeros)
+        ag = None
+        if cs is not None:
+            ag_jobs = []
+            for k, (d, i) in enumerate([(d, i) for d in dirs for i in range(L)]):
+                w_ih, w_hh, b_ih, b_hh, attn_w, attn_b, edge_w, edge_b = params[k * Recurrence.PER_CELL:(k + 1) * Recurrence.PER_CELL]
+                at = cs_at[(d, i)]
+                has_e = edge_w is not None and res[(d, i)]["edge_feat_grad"] is not None
+                ag_jobs.append({"key_sum": cs[at], "feat_sum": cs[at + 1] if has_e else None,
+                                "sigma_sum": cs[at + 2] if has_e else None, "edge_w": edge_w if has_e else None, "edge_b": edge_b,
+                                "attn_w": attn_w, "dq": mod._key_offset(i)})
+            ag = engine.attn_grads(ag_jobs)
         grads = []
         k = 0
         for d in dirs:
             for i in range(L):
                 w_ih, w_hh, b_ih, b_hh, attn_w, attn_b, edge_w, edge_b = params[k:k + Recurrence.PER_CELL]
                 r = res[(d, i)]
-                dgi = gates(r["dgi"])
+                ci = k // Recurrence.PER_CELL
                 if wg is not None:
-                    (g_wih, g_bih), (g_whh, g_bhh) = wg[2 * (k // Recurrence.PER_CELL)], wg[2 * (k // Recurrence.PER_CELL) + 1]
+                    (g_wih, g_bih), (g_whh, g_bhh) = wg[2 * ci], wg[2 * ci + 1]
                 else:
                     g_wih, g_bih, g_whh, g_bhh = (torch.zeros_like(t) for t in (w_ih, b_ih, w_hh, b_hh))
                 k += Recurrence.PER_CELL
                 if i == 0 and x.requires_grad:
-                    dx = dx + dgi @ w_ih
-                # attention logit s_e = w_key . (h_p + W_e feat_e + b_e) [+ w_vid[p mod n]] (+ query and bias terms
-                # that cancel in the segment softmax: their gradients are exact zeros)
+                    dx.addmm_(gates(r["dgi"]), w_ih)   # (dx is this call's own buffer: accumulate in place, no add kernel)
                 dq = mod._key_offset(i)
                 sigma = r["sigma"]
                 kd = attn_w.shape[1] - dq - mod._vid_nodes     # key width: H, or the input width for the `*_x` aggregators
-                keys = x if ctx.sscore is not None else h[d][i]
-                g_key = cs[cs_at[(d, i)]] if cs is not None else torch.zeros(kd, dtype=torch.float32, device=dev)
                 if ctx.sscore is not None and x.requires_grad:   # the score of node v is w_key . x_v
                     dx = dx + sigma[:, None] * attn_w[0, dq:dq + kd][None, :]
-                g_edge_w = g_edge_b = None
-                if edge_w is not None:
-                    if cs is not None:
-                        m, ssum = cs[cs_at[(d, i)] + 1], cs[cs_at[(d, i)] + 2][0]
-                    else:
-                        m, ssum = r["edge_feat_grad"].sum(0), sigma.sum()
-                    w_key = attn_w[0, dq:dq + kd]
-                    g_key = g_key + edge_w @ m + edge_b * ssum
-                    g_edge_w, g_edge_b = torch.outer(w_key, m), w_key * ssum
-                g_attn = torch.zeros_like(attn_w)
-                g_attn[0, dq:dq + kd] = g_key
+                if ag is not None:
+                    g_attn, g_edge_w, g_edge_b = ag[ci]
+                    if edge_w is not None and g_edge_w is None:
+                        g_edge_w, g_edge_b = torch.zeros_like(edge_w), torch.zeros_like(edge_b)
+                else:   # an empty batch
+                    g_attn = torch.zeros_like(attn_w)
+                    g_edge_w = None if edge_w is None else torch.zeros_like(edge_w)
+                    g_edge_b = None if edge_w is None else torch.zeros_like(edge_b)
                 if mod._vid_nodes:   # node v carries the one-hot of (v mod n): d w_vid[j] = sum of sigma over those nodes
                     g_attn[0, dq + kd:dq + kd + mod._vid_nodes] = sigma.view(-1, mod._vid_nodes).sum(0)
                 grads += [g_wih, g_whh, g_bih, g_bhh, g_attn, None if attn_b is None else torch.zeros_like(attn_b),

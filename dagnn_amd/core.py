@@ -81,15 +81,42 @@ class CellParams(object):
     """Device-side, kernel-ready parameters of one (direction, stacked layer) cell."""
 
     __slots__ = ("w_ih", "b_ih", "w_hh_t", "b_hh", "w_key", "edge_gain", "vid_bias", "w_hh_pk", "w_ih_pk",
-                 "b_ih_dev", "Hp", "key_raw", "w_hh_raw", "w_hh_df", "w_ih_df", "w_hh_bt", "w_ih_bt", "df_ok")
+                 "b_ih_dev", "Hp", "key_raw", "w_hh_raw", "w_hh_df", "w_ih_df", "w_hh_bt", "w_ih_bt", "df_ok", "gain_src")
 
 
-def pack_dataflow(cells) -> None:
-    """The dataflow kernel's weight layout of every cell (Hp <= 256)."""
+def pack_dataflow(cells, transposed_too: bool = False) -> None:
+    """The dataflow kernel's weight layout of every cell (Hp <= 320), all matrices in one launch; `transposed_too` (training
+    passes): the reverse sweep's gate-wise transposed layouts in the same launch; the edge gains of cells derived with
+    `pack=False` ride along."""
+    cells = list(cells)
+    todo = []
     for c in cells:
         if c.w_hh_df is None:
-            c.w_hh_df = engine.pack_dataflow(c.w_hh_raw, c.Hp)
-            c.w_ih_df = engine.pack_dataflow(c.w_ih, c.Hp) if c.b_ih_dev is not None else None
+            todo.append((c, "w_hh_df", c.w_hh_raw, False))
+            if c.b_ih_dev is not None:
+                todo.append((c, "w_ih_df", c.w_ih, False))
+        if transposed_too and c.w_hh_bt is None:
+            todo.append((c, "w_hh_bt", c.w_hh_raw, True))
+            if c.b_ih_dev is not None:
+                todo.append((c, "w_ih_bt", c.w_ih, True))
+    gains = [c for c in cells if c.gain_src is not None]
+    if not todo:
+        fill_gains(gains)
+        return
+    packed_all = engine.pack_dataflow_batch([(w, tr) for _, _, w, tr in todo], todo[0][0].Hp,
+                                            gains=[(c.gain_src[0], c.gain_src[1], c.edge_gain) for c in gains])
+    for c in gains:
+        c.gain_src = None
+    for (c, name, _, _), packed in zip(todo, packed_all):
+        setattr(c, name, packed)
+
+
+def fill_gains(cells) -> None:
+    """Edge gains `W_e^T w_key` of cells derived with `pack=False` that no batched pack launch took along."""
+    for c in cells:
+        if c.gain_src is not None:
+            c.edge_gain.copy_(c.gain_src[0].t() @ c.gain_src[1])
+            c.gain_src = None
 
 
 def pack_lockstep(cells, force: bool = False) -> None:
@@ -100,6 +127,7 @@ def pack_lockstep(cells, force: bool = False) -> None:
     if cells and cells[0].df_ok and not force:
         pack_dataflow(cells)
         return
+    fill_gains(cells)
     if cells and engine.TILES and cells[0].Hp == 512 and not force:
         return   # the tile kernel (csrc/tiles.hip) reads the torch layouts; the fallback packs with `force` if it is taken
     cells = [c for c in cells if c.w_hh_pk is None]
@@ -161,7 +189,14 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
     key = attn_w.detach().float()[0, dq:dq + kd]
     c.key_raw = key.contiguous()
     c.w_key = _pad_cols(key, Hp) if kd == H else None
-    c.edge_gain = (edge_w.detach().float().t() @ key).contiguous() if edge_w is not None else None
+    c.gain_src = None
+    if edge_w is None:
+        c.edge_gain = None
+    elif pack or not lock:
+        c.edge_gain = (edge_w.detach().float().t() @ key).contiguous()
+    else:   # the caller batches: the gain is computed by `pack_lockstep` (inside the dataflow pack launch where that runs)
+        c.edge_gain = torch.empty(edge_w.shape[1], dtype=torch.float32, device=edge_w.device)
+        c.gain_src = (edge_w.detach().float().contiguous(), c.key_raw)
     c.vid_bias = attn_w.detach().float()[0, dq + kd:dq + kd + vid_nodes].contiguous() if vid_nodes else None
     return c
 
@@ -238,7 +273,7 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
                             chains=arena)
         engine.tiles_run(plan, dirs, L, Hp, cells, gi, h, arena, first_layer=split, vid_mod=vid_nodes)
     elif groups > 0:
-        pack_dataflow(cells.values())
+        pack_dataflow(cells.values(), transposed_too=keep is not None and bool(engine.BWD_DATAFLOW))
         preact = {} if (keep is not None and engine.BWD_DATAFLOW) else None
         engine.dataflow_run(plan, dirs, L, Hp, cells, gi, h, groups, vid_mod=vid_nodes, arena=arena,
                             static_score=static_score, score_parts=keep is not None, preact=preact, training=keep is not None)

@@ -824,6 +824,31 @@ __global__ void __launch_bounds__(256) readout_max_bwd_kernel(const int32_t* __r
     }
 }
 
+// the same for several (state buffer, direction, column block) jobs in one launch (blockIdx.y = job)
+struct RbJobs { dagnn_readout_bwd_job j[DAGNN_MAX_READOUT_JOBS]; };
+__global__ void __launch_bounds__(256) readout_max_bwd_batch_kernel(const int32_t* __restrict__ plan, PlanLayout L, RbJobs J,
+                                                                     const float* __restrict__ gout, int ld_out) {
+    const dagnn_readout_bwd_job& K = J.j[blockIdx.y];
+    const int g = blockIdx.x;
+    const int od = 1 - K.dir;
+    const int n0 = plan[L.node_ptr + g];
+    const int depth = plan[L.depth[od] + g];
+    const int32_t* ls = plan + L.lstart[od] + n0 + g;
+    const int32_t* order = plan + L.order[od];
+    const int p0 = depth > 0 ? ls[0] : 0, p1 = depth > 0 ? ls[1] : 0;
+    if (p1 <= p0) return;
+    for (int j = threadIdx.x; j < K.width; j += blockDim.x) {
+        int best = order[p0];
+        float m = K.h[(int64_t)best * K.ld_h + j];
+        for (int p = p0 + 1; p < p1; ++p) {
+            const int v = order[p];
+            const float x = K.h[(int64_t)v * K.ld_h + j];
+            if (x > m) { m = x; best = v; }
+        }
+        K.grad_h[(int64_t)best * K.ld_g + j] += gout[(int64_t)g * ld_out + K.col_off + j];
+    }
+}
+
 inline bool H3_fits_registers(int H) { return 3 * H / (ST / BJS) <= KREG; }
 
 template <int RB>
@@ -1035,6 +1060,24 @@ extern "C" int dagnn_backward_run(const dagnn_plan* pl, const dagnn_backward_arg
         }
     }
     return run_steps(st, s_first, part);   // join (fj's destructor): the caller's stream continues only when the shallow graphs are finished too
+}
+
+extern "C" int dagnn_readout_max_backward_batch(const dagnn_plan* pl, const dagnn_readout_bwd_job* jobs, int n, const float* grad_out,
+                                                int ld_out, void* stream) {
+    if (!pl || !pl->data || !jobs || !grad_out || n <= 0 || n > DAGNN_MAX_READOUT_JOBS) return DAGNN_EINVAL;
+    RbJobs J;
+    for (int q = 0; q < n; ++q) {
+        if (!jobs[q].h || !jobs[q].grad_h || jobs[q].width <= 0 || (jobs[q].dir != 0 && jobs[q].dir != 1)) return DAGNN_EINVAL;
+        for (int p = 0; p < q; ++p)   // two jobs adding into the same rows would race
+            if (jobs[p].grad_h == jobs[q].grad_h) return DAGNN_EINVAL;
+        J.j[q] = jobs[q];
+    }
+    if (pl->B == 0) return DAGNN_OK;
+    PlanLayout L = dagnn_plan_layout_words(pl->N, pl->E, pl->B, pl->num_edge_feats);
+    hipLaunchKernelGGL(readout_max_bwd_batch_kernel, dim3((unsigned)pl->B, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                       (const int32_t*)pl->data, L, J, grad_out, ld_out);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
 }
 
 extern "C" int dagnn_readout_max_backward(const dagnn_plan* pl, const float* h, int ld_h, int width, int dir,

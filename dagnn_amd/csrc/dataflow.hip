@@ -1641,6 +1641,37 @@ __global__ void __launch_bounds__(256) df_pack_kernel(const float* __restrict__ 
     }
 }
 
+// several matrices (and their transposes) in one launch: a training step re-packs every cell's weights, 6 + 6 launches at L = 2
+struct DfPackJobs { dagnn_df_pack_job j[DAGNN_MAX_PACK_JOBS]; };
+__global__ void __launch_bounds__(256) df_pack_batch_kernel(DfPackJobs P, int H, int64_t total) {
+    const dagnn_df_pack_job& J = P.j[blockIdx.y];
+    const float* __restrict__ W = J.w;
+    if (J.transposed == 2) {   // edge gain of a cell: out[r] = sum_j edge_w[j, r] key[j] (= W_e^T w_key, dagnn.py:363,370), j ascending
+        if (blockIdx.x == 0 && (int)threadIdx.x < J.cols) {
+            float acc = 0.f;
+            for (int j = 0; j < J.rows; ++j) acc = fmaf(W[(int64_t)j * J.cols + threadIdx.x], J.aux[j], acc);
+            J.out[threadIdx.x] = acc;
+        }
+        return;
+    }
+    float4* __restrict__ out = reinterpret_cast<float4*>(J.out);
+    const int kp8 = H >> 3, nk4 = kp8 >> 2, nq = 3 * nk4;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int tc = (int)(idx & 255);
+        int64_t rest = idx >> 8;
+        const int q = (int)(rest % nq);
+        const int sl = (int)(rest / nq);
+        const int g = q / nk4, k4 = q - g * nk4;
+        const int unit = sl * DF_JS + 8 * (tc >> 6) + 4 * ((tc >> 5) & 1) + (tc & 3), ks = (tc >> 2) & 7;
+        if (!J.transposed) {
+            out[idx] = *reinterpret_cast<const float4*>(W + (int64_t)(g * H + unit) * H + ks * kp8 + 4 * k4);
+        } else {
+            const float* src = W + (int64_t)(g * H + ks * kp8 + 4 * k4) * H + unit;
+            out[idx] = make_float4(src[0], src[H], src[2 * (int64_t)H], src[3 * (int64_t)H]);
+        }
+    }
+}
+
 // partial attention scores behind the state rows (the format the backward pass reads): part q of row v =
 // w_key[16q : 16q + 16] . h[v, 16q : 16q + 16].  One wave per row.
 __global__ void __launch_bounds__(256) df_score_parts_kernel(float* __restrict__ h, int ld_h, int H,
@@ -1744,6 +1775,22 @@ static int df_pack(const float* w, float* out, int H, int transposed, void* stre
 extern "C" int dagnn_pack_dataflow(const float* w, float* out, int H, void* stream) { return df_pack(w, out, H, 0, stream); }
 
 extern "C" int dagnn_pack_dataflow_transposed(const float* w, float* out, int H, void* stream) { return df_pack(w, out, H, 1, stream); }
+
+extern "C" int dagnn_pack_dataflow_batch(const dagnn_df_pack_job* jobs, int njob, int H, void* stream) {
+    if (!jobs || njob <= 0 || njob > DAGNN_MAX_PACK_JOBS || H <= 0 || (H % 64) || H > 320) return DAGNN_EINVAL;
+    DfPackJobs P;
+    for (int q = 0; q < njob; ++q) {
+        if (!jobs[q].w || !jobs[q].out) return DAGNN_EINVAL;
+        if (jobs[q].transposed == 2 && (!jobs[q].aux || jobs[q].rows <= 0 || jobs[q].cols <= 0 || jobs[q].cols > 256)) return DAGNN_EINVAL;
+        P.j[q] = jobs[q];
+    }
+    const int64_t total = (int64_t)3 * H * H / 4;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(df_pack_batch_kernel, dim3((unsigned)blocks, (unsigned)njob), dim3(256), 0, (hipStream_t)stream, P, H, total);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
 
 extern "C" int dagnn_score_parts(float* h, int ld_h, int H, const float* w_key, int64_t N, void* stream) {
     if (!h || !w_key || H <= 0 || (H % 16) || ld_h < H + H / 16 || N < 0) return DAGNN_EINVAL;

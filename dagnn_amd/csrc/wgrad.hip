@@ -247,6 +247,49 @@ extern "C" int dagnn_colsum_run(const dagnn_colsum_job* jobs, int njob, int64_t 
     return DAGNN_OK;
 }
 
+// ---- the rest of the epilogue in ONE launch: per cell the gradients of attn_lin.weight and of the edge encoder from the three
+// column sums (dagnn_amd/autograd.py did this with ~10 tiny torch ops per cell: ~40 launches of a host-bound stretch of the step)
+struct AgArgs { dagnn_attn_grad_job job[DAGNN_ATTN_GRAD_MAX_JOBS]; };
+__global__ void __launch_bounds__(256) attn_grads_kernel(AgArgs S) {
+    const dagnn_attn_grad_job& J = S.job[blockIdx.x];
+    const float ssum = J.sigma_sum ? J.sigma_sum[0] : 0.f;
+    const bool edge = J.edge_w != nullptr && J.feat_sum != nullptr;
+    for (int j = threadIdx.x; j < J.attn_len; j += blockDim.x) {
+        float v = 0.f;
+        const int k = j - J.dq;
+        if (k >= 0 && k < J.kd) {
+            v = J.key_sum[k];
+            if (edge) {
+                float e = 0.f;
+                for (int r = 0; r < J.R; ++r) e = fmaf(J.edge_w[(int64_t)k * J.R + r], J.feat_sum[r], e);
+                v = v + e + J.edge_b[k] * ssum;
+            }
+        }
+        J.g_attn[j] = v;
+    }
+    if (edge) {
+        for (int k = threadIdx.x; k < J.kd; k += blockDim.x) {
+            const float wk = J.attn_w[J.dq + k];
+            for (int r = 0; r < J.R; ++r) J.g_edge_w[(int64_t)k * J.R + r] = wk * J.feat_sum[r];
+            J.g_edge_b[k] = wk * ssum;
+        }
+    }
+}
+
+extern "C" int dagnn_attn_grads_run(const dagnn_attn_grad_job* jobs, int njob, void* stream) {
+    if (!jobs || njob <= 0 || njob > DAGNN_ATTN_GRAD_MAX_JOBS) return DAGNN_EINVAL;
+    AgArgs S;
+    for (int q = 0; q < njob; ++q) {
+        const dagnn_attn_grad_job& j = jobs[q];
+        if (!j.key_sum || !j.attn_w || !j.g_attn || j.kd <= 0 || j.dq < 0 || j.attn_len < j.dq + j.kd || j.R < 0) return DAGNN_EINVAL;
+        if (j.edge_w && (!j.feat_sum || !j.sigma_sum || !j.edge_b || !j.g_edge_w || !j.g_edge_b || j.R <= 0)) return DAGNN_EINVAL;
+        S.job[q] = j;
+    }
+    hipLaunchKernelGGL(attn_grads_kernel, dim3((unsigned)njob), dim3(256), 0, (hipStream_t)stream, S);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
 extern "C" size_t dagnn_wgrad_workspace_bytes(int njob, int Hp, int K2max, int splits) {
     if (njob <= 0 || Hp <= 0 || K2max <= 0 || splits <= 0) return 0;
     return (size_t)njob * splits * 3 * Hp * ((size_t)K2max + 1) * sizeof(float);

@@ -418,6 +418,31 @@ def pack_dataflow(w: torch.Tensor, H: int) -> torch.Tensor:
     return out
 
 
+def pack_dataflow_batch(mats, H: int, gains=()):
+    """`pack_dataflow` / `pack_dataflow_transposed` of several [3H, H] matrices in ONE launch per 16: `mats` = list of (w,
+    transposed); returns the packed tensors in order.  `gains`: (edge_w [kd, R], key [kd], out [R]) triples - the cells' edge
+    gains `W_e^T w_key` ride in the same launch (their outputs are written in place)."""
+    lib = _lib.load()
+    outs, jobs, keep = [], [], []
+    for w, tr in mats:
+        w = _dev(w, "weight", torch.float32)
+        if tuple(w.shape) != (3 * H, H):
+            raise DagnnHipError("pack_dataflow_batch needs [3H, H] matrices, got %s" % (tuple(w.shape),))
+        o = torch.empty(3 * H * H, dtype=torch.float32, device=w.device)
+        keep.append(w)
+        outs.append(o)
+        jobs.append(_lib.DfPackJob(w.data_ptr(), o.data_ptr(), None, 1 if tr else 0, 0, 0))
+    for ew, key, out in gains:
+        ew, key = _dev(ew, "edge_encoder.weight", torch.float32), _dev(key, "key weights", torch.float32)
+        keep += [ew, key]
+        jobs.append(_lib.DfPackJob(ew.data_ptr(), out.data_ptr(), key.data_ptr(), 2, ew.shape[0], ew.shape[1]))
+    for k0 in range(0, len(jobs), _lib.MAX_PACK_JOBS):
+        part = jobs[k0:k0 + _lib.MAX_PACK_JOBS]
+        arr = (_lib.DfPackJob * len(part))(*part)
+        check(lib.dagnn_pack_dataflow_batch(arr, len(part), H, _stream(keep[0])), "dagnn_pack_dataflow_batch")
+    return outs
+
+
 RESERVED_CUS = _env_int("DAGNN_AMD_RESERVED_CUS", -1)   # CUs the persistent kernels of a TRAINING pass leave free; -1 = automatic (below)
 
 
@@ -915,6 +940,56 @@ def readout_max_backward(plan: PlanHandle, h: torch.Tensor, direction: int, grad
     check(_lib.load().dagnn_readout_max_backward(C.byref(plan.desc), h.data_ptr(), h.stride(0), h.shape[1], direction,
                                                  grad_out.data_ptr(), grad_out.shape[1], col_off, grad_h.data_ptr(),
                                                  grad_h.stride(0), _stream(h)), "dagnn_readout_max_backward")
+
+
+def readout_max_backward_batch(plan: PlanHandle, jobs, grad_out: torch.Tensor) -> None:
+    """`readout_max_backward` for several (h, direction, col_off, grad_h) jobs in ONE launch (distinct `grad_h` each)."""
+    if not jobs:
+        return
+    grad_out = _dev(grad_out, "grad_out", torch.float32)
+    lib = _lib.load()
+    for k0 in range(0, len(jobs), _lib.MAX_READOUT_JOBS):
+        part = jobs[k0:k0 + _lib.MAX_READOUT_JOBS]
+        arr = (_lib.ReadoutBwdJob * len(part))()
+        for q, (h, d, col, gh) in enumerate(part):
+            h = _rows(h, "h")
+            arr[q] = _lib.ReadoutBwdJob(h.data_ptr(), gh.data_ptr(), h.stride(0), gh.stride(0), h.shape[1], int(d), int(col))
+        check(lib.dagnn_readout_max_backward_batch(C.byref(plan.desc), arr, len(part), grad_out.data_ptr(), grad_out.shape[1],
+                                                   _stream(grad_out)), "dagnn_readout_max_backward_batch")
+
+
+def attn_grads(jobs):
+    """Gradients of attn_lin.weight / edge_encoder.{weight, bias} of every cell from the epilogue's column sums, ONE launch
+    (`dagnn_attn_grads_run`).  `jobs`: list of dicts {key_sum [kd], feat_sum [R] | None, sigma_sum [1] | None, edge_w [kd, R] |
+    None, edge_b, attn_w [1, attn_len], dq}; returns a list of (g_attn [1, attn_len], g_edge_w | None, g_edge_b | None) - views of
+    one buffer."""
+    lib = _lib.load()
+    dev = jobs[0]["attn_w"].device
+    sizes = []
+    for j in jobs:
+        kd = j["key_sum"].numel()
+        R = j["edge_w"].shape[1] if j["edge_w"] is not None else 0
+        sizes.append((j["attn_w"].shape[1], kd * R, kd if R else 0))
+    buf = torch.empty(sum(a + b + c for a, b, c in sizes), dtype=torch.float32, device=dev)
+    out, off = [], 0
+    arr = (_lib.AttnGradJob * len(jobs))()
+    keep = []
+    for q, (j, (a, b, c)) in enumerate(zip(jobs, sizes)):
+        g_attn = buf[off:off + a].view(1, a); off += a
+        g_ew = buf[off:off + b].view(-1, j["edge_w"].shape[1]) if b else None; off += b
+        g_eb = buf[off:off + c] if c else None; off += c
+        t = {k: (None if j[k] is None else j[k].detach().contiguous()) for k in ("key_sum", "feat_sum", "sigma_sum", "edge_w", "edge_b", "attn_w")}
+        keep.append(t)
+        kd = t["key_sum"].numel()
+        arr[q] = _lib.AttnGradJob(t["key_sum"].data_ptr(), _ptr(t["feat_sum"]), _ptr(t["sigma_sum"]), _ptr(t["edge_w"]), _ptr(t["edge_b"]),
+                                  t["attn_w"].data_ptr(), g_attn.data_ptr(), _ptr(g_ew), _ptr(g_eb), int(j["dq"]), kd, a,
+                                  0 if t["edge_w"] is None else t["edge_w"].shape[1])
+        out.append((g_attn, g_ew, g_eb))
+    for k0 in range(0, len(jobs), _lib.ATTN_GRAD_MAX_JOBS):
+        n = min(_lib.ATTN_GRAD_MAX_JOBS, len(jobs) - k0)
+        sub = (_lib.AttnGradJob * n)(*[arr[k0 + i] for i in range(n)])
+        check(lib.dagnn_attn_grads_run(sub, n, _stream(buf)), "dagnn_attn_grads_run")
+    return out
 
 
 def backward_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, h, gi0, g_ext,

@@ -304,14 +304,15 @@ class DAGNN(nn.Module):
         return out
 
     def _readout_backward(self, plan, x, h, gout, g_ext, dx):
-        col = 0
+        col, jobs = 0, []
         for d in (0, 1):  # to the arg-max output node of every (graph, column)
-            if self.out_wx:
+            if self.out_wx:   # (both directions add into dx: one after the other, not in one launch)
                 engine.readout_max_backward(plan, x, d, gout, col, dx)
                 col += x.shape[1]
             for i in range(self.num_layers):
-                engine.readout_max_backward(plan, h[d][i], d, gout, col, g_ext[d][i])
+                jobs.append((h[d][i], d, col, g_ext[d][i]))
                 col += self.hidden_dim
+        engine.readout_max_backward_batch(plan, jobs, gout)   # one launch for all (direction, stacked layer) state buffers
 
     def _train_params(self):
         flat = []

@@ -341,6 +341,15 @@ int dagnn_dataflow_run_wide(const dagnn_plan* plan /* host */, const dagnn_dataf
 int dagnn_pack_dataflow(const float* w /* [3H,H] */, float* out /* 3H*H floats */, int H, void* stream);
 /* the same order of the gate-wise transposed matrix W'[g H + j][u] = W[g H + u][j] (reverse sweep, dagnn_bwd_dataflow_run) */
 int dagnn_pack_dataflow_transposed(const float* w /* [3H,H] */, float* out /* 3H*H floats */, int H, void* stream);
+/* Both layouts of several [3H, H] matrices in ONE launch (a training step re-packs every cell's weights). */
+typedef struct dagnn_df_pack_job {
+    const float* w;       /* [3H, H] torch layout (mode 2: edge_encoder.weight [rows, cols]) */
+    float* out;           /* 3H*H floats (mode 2: [cols]) */
+    const float* aux;     /* mode 2: the key weights [rows]; else unused */
+    int32_t transposed;   /* 0: as dagnn_pack_dataflow, 1: as dagnn_pack_dataflow_transposed, 2: edge gain out = w^T aux */
+    int32_t rows, cols;   /* mode 2 only */
+} dagnn_df_pack_job;
+int dagnn_pack_dataflow_batch(const dagnn_df_pack_job* jobs /* host */, int njob, int H, void* stream);
 int dagnn_score_parts(float* h /* [N,ld_h] */, int ld_h, int H, const float* w_key /* [H] */, int64_t N, void* stream);
 /* Introspection (tests, host-side mirror): byte offsets of the schedule workspace's arrays, 13 entries: [grp_of,
  * gdepth, gload, loff, gtab0, gtab1, lcnt0, lcnt1, glbase0, glbase1, grec0, grec1, total]. */
@@ -583,10 +592,39 @@ int dagnn_wgrad_splits(int num_cus, int njob, int Hp, int max_in_dim, int64_t N)
 int dagnn_wgrad_run(const dagnn_wgrad_job* jobs /* host */, int njob, int64_t N, int Hp, int H, int splits, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* The small gradients of one cell's attention / edge encoder from the three column sums above, every cell in ONE launch
+ * (replaces ~10 torch ops per cell behind `loss.backward()`, dagnn.py:362-373 under autograd):
+ *   g_attn[j]      = 0 outside [dq, dq + kd);  g_attn[dq + k] = key_sum[k] + edge_w[k, :] . feat_sum + edge_b[k] * sigma_sum
+ *   g_edge_w[k, r] = attn_w[dq + k] * feat_sum[r];   g_edge_b[k] = attn_w[dq + k] * sigma_sum        (edge_w != NULL only) */
+#define DAGNN_ATTN_GRAD_MAX_JOBS 16
+typedef struct dagnn_attn_grad_job {
+    const float* key_sum;    /* [kd]  sum_v sigma_v keys_v */
+    const float* feat_sum;   /* [R]   sum_v (edge-feature sums)_v, or NULL */
+    const float* sigma_sum;  /* [1]   sum_v sigma_v, or NULL */
+    const float* edge_w;     /* [kd, R] edge_encoder.weight, or NULL: no edge encoder */
+    const float* edge_b;     /* [kd] */
+    const float* attn_w;     /* [attn_len] attn_lin.weight row */
+    float* g_attn;           /* [attn_len] */
+    float* g_edge_w;         /* [kd, R] */
+    float* g_edge_b;         /* [kd] */
+    int32_t dq, kd, attn_len, R;
+} dagnn_attn_grad_job;
+int dagnn_attn_grads_run(const dagnn_attn_grad_job* jobs /* host */, int njob, void* stream);
+
 /* grad_h[v, j] += grad_out[g, col_off + j] for the first output node v of graph g attaining the maximum
  * of column j (the single winner of scatter-max); grad_h must be initialised by the caller. */
 int dagnn_readout_max_backward(const dagnn_plan* plan /* host */, const float* h, int ld_h, int width, int dir,
                                const float* grad_out, int ld_out, int col_off, float* grad_h, int ld_g, void* stream);
+
+/* ... for several state buffers in one launch (distinct grad_h per job) */
+#define DAGNN_MAX_READOUT_JOBS 24
+typedef struct dagnn_readout_bwd_job {
+    const float* h;      /* [N, ld_h] */
+    float* grad_h;       /* [N, ld_g] */
+    int32_t ld_h, ld_g, width, dir, col_off;
+} dagnn_readout_bwd_job;
+int dagnn_readout_max_backward_batch(const dagnn_plan* plan /* host */, const dagnn_readout_bwd_job* jobs /* host */, int n,
+                                     const float* grad_out, int ld_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Constructor-string variants of the same loop (no BASELINE configuration selects

@@ -6,41 +6,48 @@
 //   inp  = GRUCell(inp, ps_h)     (:181)      h[d][i][layer] += inp (:182)
 //
 // Shape of the work (cfg 5: H = 512, L = 5, both directions): a launch holds 10 cells x 40..3000 rows, a row of a
-// cell is [1 x 1024] x [1024 x 1536] (input | hidden side) = 3.1 MFLOP of exact-fp32 products.  Round 1-4 ran these
+// cell is [1 x 1024] x [1024 x 1536] (input | hidden side) = 3.1 MFLOP of exact-fp32 products.  Rounds 1-4 ran these
 // launches as a gather kernel (aggregates through HBM) + 32-row x 32-unit tiles that re-streamed a 393 KB weight
-// slice per 32 rows and staged K in 256-wide chunks behind __syncthreads without a second buffer: 45-50 % of the
-// fp32 matrix peak.  Here:
+// slice per 32 rows and staged K in 256-wide chunks behind __syncthreads without a second buffer.  Here:
 //   * a tile is 64 rows x 32 units (x 3 gates): a weight pass is amortised over 64 rows, 16 slices x ceil(rows / 64)
 //     workgroups per cell, two workgroups (4 waves each) per CU so that one's prologue / epilogue / barriers hide
-//     behind the other's products;
+//     behind the other's products (a launch that fits one workgroup per CU asks for more LDS than two can share);
 //   * K is walked in stages of 64: 32 k of the input side + 32 k of the hidden side (or 64 of the one side a cell has:
 //     stacked layer 0 reads gi0 from the batched GEMM, layer 0 of a direction has no predecessors).  Wave w = (side
-//     h = w >> 1, k half sub = w & 1) multiplies ALL 64 rows by its 16 k of side h: 6 accumulators of
-//     v_mfma_f32_32x32x2_f32 (2 row blocks x 3 gates), every B fragment is fetched once per workgroup - straight
-//     from global memory in fragment order (dagnn_pack_mfma: one contiguous 1 KiB per wave-load), one stage ahead;
+//     hs = w >> 1, k half sub = w & 1) multiplies ALL rows of the tile by its 16 k of side hs on
+//     v_mfma_f32_16x16x4_f32: 4 row blocks x 6 column blocks = 24 accumulators, every B fragment is fetched ONCE per
+//     workgroup - straight from global memory in fragment order (dagnn_pack_mfma: one contiguous 1 KiB per wave-load)
+//     into one of two register sets, a whole stage ahead.  16x16x4 and not 32x32x2: an fp32 MFMA holds the SIMD's issue
+//     port for its whole duration and the OTHER waves of the SIMD get exactly one vector instruction in per MFMA
+//     (scripts/ubench/mfma_share.hip: a partner's v_fma takes 5.8 cycles alone, 37.8 beside 16x16x4, 69.8 beside
+//     32x32x2) - the partner workgroup's prologue / epilogue runs at that rate;
 //   * the A tile of a stage ([64 rows x 64 k], 16 KB, two LDS slots) is built by all 256 threads: a thread owns a
 //     16-byte chunk of two rows, the loads of stage s + 1 are in flight while the products of stage s run; hidden
-//     side: a = sum_e alpha_e h[pred_e] over the row's <= 4 inline predecessors (alpha from the prologue: PyG's
+//     side: a = sum_e alpha_e h[pred_e] over a row's one or two predecessors (alpha from the prologue: PyG's
 //     exp(x - max) / (sum + 1e-16) over the partial scores stored behind the state rows), input side: the node's
-//     lower-layer row.  The aggregate never goes to memory.  Rows with more than 4 predecessors (reverse direction:
-//     nodes with many children) are aggregated once per workgroup into a scratch row by one wave (the generic
-//     routine of the per-layer kernels) and then read like a single predecessor with alpha = 1;
-//   * A fragments are ONE ds_read_b128 per four MFMAs (lane (i, hh) holds k = 8 k8 + 4 hh + q for q = 0..3; the B
+//     lower-layer row.  The aggregate never goes to memory.  A row with three or four predecessors becomes a scratch row,
+//     built in the prologue by all threads from its four (pointer, alpha) pairs; a row with more than four is
+//     aggregated once per workgroup by one wave (the generic routine of the per-layer kernels); both are then read
+//     like a single predecessor with alpha = 1.  Every load of the stage loop is unconditional: a load behind a branch
+//     makes hipcc's wait counts assume the shortest queue, and the products then wait for loads they do not use;
+//   * A fragments are ONE ds_read_b128 per four MFMAs (lane (i, kq) holds k = 16 g + 4 kq + q for q = 0..3; the B
 //     fragments are packed with the same k map); rows are 256 B apart in LDS with the 16-byte chunk index XOR-ed by
 //     (row & 15): reads and writes are bank-conflict free;
-//   * epilogue: the two k halves of a side are added through LDS (the tile's outputs alias the A slots), gates
-//     (r, z, n) / h' / partial scores exactly as the per-layer kernels compute them, row stores.
-// Exact fp32 (v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain); results are bitwise run-to-run deterministic.
+//   * epilogue: the two k halves of a side are added through LDS (the tile's outputs alias the A slots; plain read -
+//     add - write a barrier apart: ds_add_f32 measured 0.3 us per wave instruction), gates (r, z, n) on the hardware
+//     exp / rcp, h', partial scores as the per-layer kernels store them, row stores; the operands of the gate algebra
+//     that do not depend on the products (aggregate, gi0) are loaded before the merge.
+// What binds it (scripts/fat_stamps.py on a -DFAT_STAMPS build, cfg 5): a workgroup spends ~15 us in the prologue, ~29
+// in the stage loop (two workgroups share the CU's matrix pipes: 2 x 11.2 us of products at the measured 2.2 GHz), ~9 in
+// merge + gates; with the products compiled out (-DFAT_EXP_NOMFMA) the fat launches of a forward still take 7.0 of 12.3 ms
+// - launch-level fill / drain and the per-tile dependent round trips, not the matrix pipe, are what is left.
+// Exact fp32 (v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain per k quarter); results are bitwise run-to-run deterministic.
 #include "frontier_dev.h"
 
 namespace {
 
 typedef float mf32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef FAT_WGS_PER_CU
-#define FAT_WGS_PER_CU 2              // co-resident workgroups per CU the kernel is built for (3: <= 168 VGPRs, lean shape)
-#endif
-constexpr bool FAT_LEAN = FAT_WGS_PER_CU >= 3;   // single B register set refilled in place, row pointers re-read from LDS per stage
 constexpr int FTM = 64;               // rows per tile
 constexpr int FAT_THREADS = 256;
 constexpr int FAT_SLOT = FTM * 64;    // floats per A slot: 64 rows x 64 k
@@ -146,11 +153,7 @@ __device__ __forceinline__ void fat_prologue(const int32_t* __restrict__ plan, c
         const bool mine = e < deg && deg <= 4;
         float lg = -INFINITY;
         if (mine && deg > 1) {
-#ifdef FAT_EXP_NOSCORE
-            float s = 0.f * (float)(nparts + pj);
-#else
             float s = C.sscore ? C.sscore[pj] : score_of(C.h_out + (int64_t)pj * ld_h + H, nparts);
-#endif
             if (C.vid) s += C.vid[pj % S.vid_mod];
             if (C.gain) {
                 if (S.R >= 1) s = fmaf(C.gain[0], f0, s);
@@ -198,11 +201,7 @@ __device__ __forceinline__ void fat_prologue(const int32_t* __restrict__ plan, c
         }
     }
     __syncthreads();
-#ifdef FAT_EXP_NOP1
-    const int ng = 0, nm = 0;
-#else
     const int ng = M.gen_n[0], nm = M.gen_n[1];
-#endif
     if (ng + nm > 0) {   // plain stores; the same workgroup reads the rows back behind the barrier
         const int H4 = H >> 2;
         for (int it = tid; it < nm * H4; it += FAT_THREADS) {   // P1: (row, 16-byte chunk) items, four loads in flight each
@@ -233,13 +232,14 @@ __device__ __forceinline__ void fat_prologue(const int32_t* __restrict__ plan, c
 
 // SIDES = which products the cell has at this layer: bit 0 hidden side (the layer has predecessors), bit 1 input side
 // (stacked layers above 0); 0: stacked layer 0 at layer 0 of a direction - gates of gi0 and the biases only.
-// MB = 16-row MFMA blocks per wave: 2 for a 64-row tile (wave = side x 32 rows), 1 for a tile of <= 32 rows (wave = side
-// x 16 rows).  Either way a wave owns ALL k of its side for its rows, so no partial sums ever meet in LDS.
-template <int SIDES, int MB>
+// TB = 16-row MFMA blocks of the tile: 4 (64 rows) or 2 (a tile of <= 32 rows).  Wave = (side hs, k half sub): it multiplies
+// ALL rows of the tile by its 16 k of every stage, so each B fragment is fetched ONCE per workgroup; the two k halves of a
+// side meet in LDS behind the loop.
+template <int SIDES, int TB>
 __device__ __forceinline__ void fat_main(const FatArgs& S, const FatTile& T, const FatLds& M) {
     constexpr int MD = 2;                 // predecessor rows a hidden-side item gathers (more: scratch row, see the prologue)
-    constexpr int RB = 16 * MB;           // rows per wave
-    constexpr bool two = MB == 2;         // rows 32..63 of the tile exist
+    constexpr int MB = TB;                // 16-row blocks per wave: the whole tile
+    constexpr bool two = TB == 4;         // rows 32..63 of the tile exist
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const Cell& C = *T.C;
@@ -270,9 +270,9 @@ __device__ __forceinline__ void fat_main(const FatArgs& S, const FatTile& T, con
             for (int e = 0; e < MD; ++e) { sp_h[it][e] = M.hptr[r * 2 + e] + 16 * c8; sa[it][e] = M.alpha[r * 2 + e]; }
         }
     };
-    if constexpr (!FAT_LEAN) row_meta();
-    // compute role: wave = (side hs, row block rb); lane = (row / column i, k quarter kq) of a 16x16x4 fragment
-    const int hs = wave >> 1, rb = wave & 1;
+    row_meta();
+    // compute role: wave = (side hs, k half sub); lane = (row / column fi, k quarter kq) of a 16x16x4 fragment
+    const int hs = wave >> 1, sub = wave & 1;
     const int fi = lane & 15, kq = lane >> 4;
     const bool my_in = hs == 0 ? side_in[0] : side_in[1];
     const int my_koff = hs == 0 ? koff[0] : koff[1];
@@ -289,7 +289,6 @@ __device__ __forceinline__ void fat_main(const FatArgs& S, const FatTile& T, con
 
     float4 areg[2][2][MD];   // [row half][side][predecessor] loads in flight
     auto a_issue = [&](int s) {
-        if constexpr (FAT_LEAN) row_meta();   // (a handful of LDS reads per stage instead of 16 more live registers)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = kmul * s + koff[h];
@@ -307,12 +306,6 @@ __device__ __forceinline__ void fat_main(const FatArgs& S, const FatTile& T, con
     };
     auto a_commit = [&](int slot) {
         float* base = ring + slot * FAT_SLOT;
-        if constexpr (FAT_LEAN) {
-#pragma unroll
-            for (int it = 0; it < 2; ++it)
-#pragma unroll
-                for (int e = 0; e < MD; ++e) sa[it][e] = M.alpha[(rr + 32 * it) * 2 + e];
-        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -330,45 +323,43 @@ __device__ __forceinline__ void fat_main(const FatArgs& S, const FatTile& T, con
             }
         }
     };
-    // B fragments: two register sets used in turn (even / odd stages): a whole stage of lead for the weight loads, no copies
-    float4 bA[2][6], bB[FAT_LEAN ? 1 : 2][6];
-    auto b_issue_g = [&](int s, int gq, float4 (&dst)[6]) {
-        const int k16 = ((kmul * s + my_koff) >> 4) + gq;
+    // B fragments (this wave's 16 k x the slice's six 16-column blocks): two register sets used in turn (even / odd stages) - a
+    // whole stage of lead for the weight loads, no copies
+    float4 bA[6], bB[6];
+    auto b_issue = [&](int s, float4 (&dst)[6]) {
+        const int k16 = ((kmul * s + my_koff) >> 4) + sub;
 #pragma unroll
         for (int n = 0; n < 6; ++n) dst[n] = wp[n * blk_stride + (int64_t)k16 * 64];
     };
-    auto b_issue = [&](int s, float4 (&dst)[2][6]) { b_issue_g(s, 0, dst[0]); b_issue_g(s, 1, dst[1]); };
     // one stage: products of slot s & 1 with `cur`; meanwhile the next stage's B fragments -> `nxt`, its A tile -> the other
     // slot, the A rows of stage s + 2 -> registers
-    auto stage = [&](int s, float4 (&cur)[2][6], float4 (&nxt)[FAT_LEAN ? 1 : 2][6]) {
+    auto stage = [&](int s, float4 (&cur)[6], float4 (&nxt)[6]) {
         const float* slot = ring + (s & 1) * FAT_SLOT;
         // every load below is unconditional (the last stages re-read the final stage's operands): a load behind a
         // branch makes hipcc's wait counts assume the shortest queue, and the products then wait for loads they do not use
         const int s1 = min(s + 1, nstage - 1), s2 = min(s + 2, nstage - 1);
-        if constexpr (!FAT_LEAN) b_issue(s1, nxt);
-        float4 af[2][MB];   // [k group][row block] A fragments: k = 16 gq + 4 kq + q for q = 0..3
+        b_issue(s1, nxt);
+        float4 af[MB];   // A fragments of the tile's row blocks: k = 16 sub + 4 kq + q for q = 0..3
 #pragma unroll
-        for (int gq = 0; gq < 2; ++gq)
+        for (int m = 0; m < MB; ++m)
+            af[m] = *reinterpret_cast<const float4*>(slot + a_idx(m * 16 + fi, 8 * hs + 4 * sub + kq));
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
-                af[gq][m] = *reinterpret_cast<const float4*>(slot + a_idx(rb * RB + m * 16 + fi, 8 * hs + 4 * gq + kq));
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-        for (int gq = 0; gq < 2; ++gq) {
+            for (int m = 0; m < MB; ++m) {
+                const float4 aw = af[m];
+                const float aq = q == 0 ? aw.x : q == 1 ? aw.y : q == 2 ? aw.z : aw.w;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int m = 0; m < MB; ++m) {
-                    const float4 aw = af[gq][m];
-                    const float aq = q == 0 ? aw.x : q == 1 ? aw.y : q == 2 ? aw.z : aw.w;
-#pragma unroll
-                    for (int n = 0; n < 6; ++n) {
-                        const float4 bw = cur[gq][n];
-                        const float bq = q == 0 ? bw.x : q == 1 ? bw.y : q == 2 ? bw.z : bw.w;
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, bq, acc[m][n], 0, 0, 0);
-                    }
+                for (int n = 0; n < 6; ++n) {
+                    const float4 bw = cur[n];
+                    const float bq = q == 0 ? bw.x : q == 1 ? bw.y : q == 2 ? bw.z : bw.w;
+#ifdef FAT_EXP_NOMFMA   // timing experiment: everything but the products
+                    acc[m][n][0] += aq * bq;
+#else
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, bq, acc[m][n], 0, 0, 0);
+#endif
                 }
             }
-            if constexpr (FAT_LEAN) b_issue_g(s1, gq, cur[gq]);   // this half's fragments are consumed: refill them for the next stage
         }
         a_commit((s + 1) & 1);
         a_issue(s2);
@@ -376,10 +367,6 @@ __device__ __forceinline__ void fat_main(const FatArgs& S, const FatTile& T, con
     };
 
     if constexpr (SIDES != 0) {
-        // fp32 MFMA runs on the vector ALU's own lanes: next to a wave that issues them back to back every VALU instruction
-        // of the other workgroup waits for a whole MFMA (measured: prologue 4 us alone, 16-18 us beside a partner in its stage
-        // loop; s_setprio does not change it).  Hence 16x16x4 (32 cycles) instead of 32x32x2 (64), and as little vector work
-        // as possible outside this loop.
 #ifdef FAT_STAMPS
         const unsigned long long cyc0 = clock64();
 #endif
@@ -388,13 +375,9 @@ __device__ __forceinline__ void fat_main(const FatArgs& S, const FatTile& T, con
         a_commit(0);
         a_issue(min(1, nstage - 1));
         __syncthreads();
-        if constexpr (FAT_LEAN) {
-            for (int s = 0; s < nstage; ++s) stage(s, bA, bB);
-        } else {
-            for (int s = 0; s < nstage; s += 2) {
-                stage(s, bA, bB);
-                if (s + 1 < nstage) stage(s + 1, bB, bA);
-            }
+        for (int s = 0; s < nstage; s += 2) {
+            stage(s, bA, bB);
+            if (s + 1 < nstage) stage(s + 1, bB, bA);
         }
 #ifdef FAT_STAMPS
         if (threadIdx.x == 0) atomicAdd(&fat_stamp_sum[6], (unsigned long long)(clock64() - cyc0));
@@ -405,7 +388,7 @@ __device__ __forceinline__ void fat_main(const FatArgs& S, const FatTile& T, con
     // ---- epilogue operands that do not depend on the products: in flight while the tile goes to LDS.  Element
     // (row r = 8 p + tid / 32, unit jj = tid % 32) for p = 0..NP-1; 16 consecutive lanes = 16 units of a row.  Every load is
     // unconditional (dead rows carry node 0 and the finite dummy row with alpha = 0).
-    constexpr int NP = 4 * MB;
+    constexpr int NP = 2 * TB;
     const int jj = tid & 31, j = sl * 32 + jj, r0 = tid >> 5;
     int gvv[NP];
     float av[NP], g0r[NP], g0z[NP], g0n[NP];
@@ -428,18 +411,30 @@ __device__ __forceinline__ void fat_main(const FatArgs& S, const FatTile& T, con
     if constexpr (has_in) { bi_r = C.bih[j]; bi_z = C.bih[H + j]; bi_n = C.bih[2 * H + j]; }
     const float wk = C.wkey ? C.wkey[j] : 0.f;
 
-    // ---- the tile's sums -> LDS: out[side][row][gate * 32 + unit] (row pitch FAT_OP: the four rows a lane quarter
-    // holds fall on different banks).  C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + e.
+    // ---- the two k halves of a side meet in LDS: out[side][row][gate * 32 + unit].  Pass 1: the sub = 0 wave of a side stores the
+    // first half of its row blocks, the sub = 1 wave the second half; pass 2: each adds its other half to what the partner stored
+    // (plain read - add - write: the two passes are a barrier apart; LDS float atomics cost ~0.3 us per wave instruction here).
+    // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + e.
     float* out = ring;
     if constexpr (SIDES != 0) {
+        auto tile_rw = [&](int half, bool add) {
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+            for (int mm = 0; mm < MB / 2; ++mm) {
+                const int m = half * (MB / 2) + mm;
 #pragma unroll
-            for (int n = 0; n < 6; ++n) {
-                float* o = out + hs * (FTM * FAT_OP) + (rb * RB + m * 16 + 4 * kq) * FAT_OP + n * 16 + fi;
+                for (int n = 0; n < 6; ++n) {
+                    float* o = out + hs * (FTM * FAT_OP) + (m * 16 + 4 * kq) * FAT_OP + n * 16 + fi;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e * FAT_OP] = acc[m][n][e];
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = half == 0 ? acc[mm][n][e] : acc[MB / 2 + mm][n][e];
+                        o[e * FAT_OP] = add ? o[e * FAT_OP] + v : v;
+                    }
+                }
             }
+        };
+        if (sub == 0) tile_rw(0, false); else tile_rw(1, false);
+        __syncthreads();
+        if (sub == 0) tile_rw(1, true); else tile_rw(0, true);
         __syncthreads();
     }
 
@@ -490,15 +485,15 @@ __device__ __forceinline__ void fat_main(const FatArgs& S, const FatTile& T, con
     FAT_STAMP(3);
 }
 
-template <int MB>
+template <int TB>
 __device__ __forceinline__ void fat_pick(const FatArgs& S, const FatTile& T, const FatLds& M) {
-    if (T.has_in && T.has_hid) fat_main<3, MB>(S, T, M);
-    else if (T.has_hid) fat_main<1, MB>(S, T, M);
-    else if (T.has_in) fat_main<2, MB>(S, T, M);
-    else fat_main<0, MB>(S, T, M);
+    if (T.has_in && T.has_hid) fat_main<3, TB>(S, T, M);
+    else if (T.has_hid) fat_main<1, TB>(S, T, M);
+    else if (T.has_in) fat_main<2, TB>(S, T, M);
+    else fat_main<0, TB>(S, T, M);
 }
 
-__global__ void __launch_bounds__(FAT_THREADS, FAT_WGS_PER_CU) fat_layer_kernel(const int32_t* __restrict__ plan, PlanLayout L, FatArgs S) {
+__global__ void __launch_bounds__(FAT_THREADS, 2) fat_layer_kernel(const int32_t* __restrict__ plan, PlanLayout L, FatArgs S) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int NS = S.H >> 5;
     const int gb = blockIdx.x / NS;
@@ -529,8 +524,8 @@ __global__ void __launch_bounds__(FAT_THREADS, FAT_WGS_PER_CU) fat_layer_kernel(
 #endif
     fat_prologue(plan, L, S, T, M);
     FAT_STAMP(0);
-    if (T.two) fat_pick<2>(S, T, M);
-    else fat_pick<1>(S, T, M);
+    if (T.two) fat_pick<4>(S, T, M);
+    else fat_pick<2>(S, T, M);
 #ifdef FAT_STAMPS
     if (threadIdx.x == 0) {
         const int seen = atomicAdd(&fat_cu_res[fat_cu_key], -1) - 1;

@@ -175,7 +175,7 @@ class VariantAggregator(C.Structure):
 
 class VariantMap(C.Structure):
     _fields_ = [("w_t", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("ld_out", C.c_int64),
-                ("out_dim", C.c_int32), ("reserved", C.c_int32)]
+                ("out_dim", C.c_int32), ("vid_mod", C.c_int32), ("vid_bias", C.c_void_p)]
 
 
 class VariantCell(C.Structure):

@@ -171,6 +171,7 @@ struct VJob {
     const float* input; int64_t ld_in;
     const float* agg; int64_t ld_agg; int agg_dim, pad;
     const float* w_in_t; const float* w_agg_t; const float* b_in; const float* b_agg;
+    const float* b_vid; int vid_mod, pad2;    // linear maps: + b_vid[(node % vid_mod) * out_dim + unit] (per-vertex-id bias), or NULL
     float* out; int64_t ld_out;
 };
 struct VJobArgs {
@@ -265,6 +266,7 @@ __global__ void __launch_bounds__(256) variant_cell_kernel(const int32_t* __rest
             res = (1.f - zz) * nn + zz * hp;
         } else {
             res = ai[r][0] + ah[r][0] + (J.b_in ? J.b_in[unit] : 0.f);
+            if (J.b_vid) res += J.b_vid[(int64_t)(v % J.vid_mod) * J.out_dim + unit];
         }
         J.out[(int64_t)v * J.ld_out + unit] = res;
     }
@@ -362,6 +364,7 @@ __global__ void __launch_bounds__(256) variant_cell_thin_kernel(const int32_t* _
         res = (1.f - zz) * nn + zz * hp;
     } else {
         res = p[0] + p[1] + (J.b_in ? J.b_in[unit] : 0.f);
+        if (J.b_vid) res += J.b_vid[(int64_t)(v % J.vid_mod) * J.out_dim + unit];
     }
     J.out[(int64_t)v * J.ld_out + unit] = res;
 }
@@ -475,7 +478,8 @@ extern "C" int dagnn_variant_run(const dagnn_plan* pl, const dagnn_variant_args*
             if (c.recurrent && (!c.b_in || !c.b_agg)) return DAGNN_EINVAL;
             if (c.num_maps < 0 || c.num_maps > 3) return DAGNN_EINVAL;
             for (int m = 0; m < c.num_maps; ++m)
-                if (!c.map[m].w_t || !c.map[m].out || c.map[m].out_dim <= 0 || c.map[m].ld_out < c.map[m].out_dim)
+                if (!c.map[m].w_t || !c.map[m].out || c.map[m].out_dim <= 0 || c.map[m].ld_out < c.map[m].out_dim ||
+                    (c.map[m].vid_mod > 0 && !c.map[m].vid_bias))
                     return DAGNN_EINVAL;
         }
     }
@@ -516,6 +520,7 @@ extern "C" int dagnn_variant_run(const dagnn_plan* pl, const dagnn_variant_args*
                 J.input = c.input; J.ld_in = c.ld_input;
                 J.agg = c.agg.out; J.ld_agg = c.agg.ld_out; J.agg_dim = H; J.pad = 0;
                 J.w_in_t = c.w_in_t; J.w_agg_t = c.w_agg_t; J.b_in = c.b_in; J.b_agg = c.b_agg;
+                J.b_vid = nullptr; J.vid_mod = 1;
                 J.out = c.h; J.ld_out = c.ld_h;
                 CJ.r0[ncj] = r0; CJ.r1[ncj] = r1;
                 ++ncj;
@@ -543,6 +548,7 @@ extern "C" int dagnn_variant_run(const dagnn_plan* pl, const dagnn_variant_args*
                     J.input = c.h; J.ld_in = c.ld_h;
                     J.agg = nullptr; J.ld_agg = 0; J.agg_dim = 0; J.pad = 0;
                     J.w_in_t = c.map[m].w_t; J.w_agg_t = nullptr; J.b_in = c.map[m].bias; J.b_agg = nullptr;
+                    J.b_vid = c.map[m].vid_mod > 0 ? c.map[m].vid_bias : nullptr; J.vid_mod = c.map[m].vid_mod > 0 ? c.map[m].vid_mod : 1;
                     J.out = c.map[m].out; J.ld_out = c.map[m].ld_out;
                     MJ.r0[nmj] = r0; MJ.r1[nmj] = r1;
                     ++nmj;

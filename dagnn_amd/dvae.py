@@ -31,6 +31,13 @@ class _NoParams(object):
     wea = False   # no edge encoder (num_rels = 1 in the D-VAE models)
 
 
+class _GatedParams(object):
+    wea = False
+
+    def __init__(self, gate, mapper):
+        self.gate, self.mapper = gate, mapper   # gate: Sequential(Linear, Sigmoid); mapper: Linear(bias=False)
+
+
 class _AggView(object):
     """What `dagnn_amd.variants` reads from a model, for a D-VAE encoder with agg in {add, max}: GRU cells, values = the
     cell's own states, no edge features, and - unlike the ogbg model - one AggConv PER direction (`reverse=True` for the
@@ -41,10 +48,19 @@ class _AggView(object):
     agg_attn_x = False
     shared_agg_flow = False
 
+    vid_nodes = 0
+
     def __init__(self, m):
         self._m = m
         self.agg, self.hidden_dim, self.num_layers, self.dirs = m.agg, m.hidden_dim, m.num_layers, m.dirs
         self.emb_dim = m.cells_0[0].weight_ih.shape[1]   # the node inputs are the one-hot vertex types (nvt wide)
+        if m.agg == K.NA_GATED_SUM:
+            # GatedSumConv over hs_j = [state ; one-hot vertex id] (dvae/dagnn.py:124-137,269-299): gate / mapper are Linear(hs +
+            # num_nodes, hs); csrc/variants.hip takes the one-hot columns as a per-vertex-id bias of the per-node projections
+            self.vid_nodes = m.num_nodes
+            self.node_aggr_0 = [_GatedParams(m.gate_forward[l], m.mapper_forward[l][0]) for l in range(m.num_layers)]
+            self.node_aggr_1 = [_GatedParams(m.gate_backward[l], m.mapper_backward[l][0]) for l in range(m.num_layers)]
+            return
         self.node_aggr_0 = [_NoParams() for _ in range(m.num_layers)]
         self.node_aggr_1 = [_NoParams() for _ in range(m.num_layers)]
 
@@ -426,6 +442,11 @@ class _DvaeDagnn(_DvaeBase):
             v = self.__dict__["_agg_view_obj"] = _AggView(self)
         return v
 
+    def _gated_hip_ok(self) -> bool:
+        """`gated_sum` through csrc/variants.hip: the states must be as wide as the gate / mapper inputs say (hs + num_nodes)."""
+        w = self.gate_forward[0][0].weight
+        return w.shape[1] == self.hidden_dim + self.num_nodes and w.shape[0] == self.hidden_dim
+
     def _gated_sum_states(self, G, x):
         """`gated_sum` on the NA encoder: the messages are gate(hs_j) * mapper(hs_j) with hs_j = [state ; one-hot vertex id]
         (dvae/dagnn.py:124-137, 269-299), i.e. per NODE P_j = W_g[:, :H] h_j + W_g[:, H + j mod n] + b_g (likewise the
@@ -472,12 +493,14 @@ class _DvaeDagnn(_DvaeBase):
         supported`), `gated_sum` (NA) on torch ops; then the read-outs of `dvae/dagnn.py:147-172`."""
         from . import variants
         L, H, nn_ = self.num_layers, self.hidden_dim, self.num_nodes
-        if self.agg == K.NA_GATED_SUM:
-            if train:
+        if self.agg == K.NA_GATED_SUM and (train or not self._gated_hip_ok()):
+            if train:   # differentiable device-side torch ops (the reverse sweep of csrc/variants_bwd.hip has no vertex-id columns)
                 h = self._gated_sum_states(G, x)
             else:
                 with torch.no_grad():
                     h = self._gated_sum_states(G, x)
+        elif self.agg == K.NA_GATED_SUM:   # evaluation: the generic HIP kernels, the one-hot columns as a per-vertex-id bias
+            h = variants.run_hip(self._agg_view(), G, x, plan)
         else:
             view = self._agg_view()
             if train:

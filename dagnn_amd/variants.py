@@ -190,6 +190,10 @@ def _derive(mod):
                     p["edge_vec0"] = be.contiguous() if We is not None else None
                 elif mod.agg == "gated_sum":
                     Wg, bg, Wm, bm = a.gate[0].weight, a.gate[0].bias, a.mapper.weight, a.mapper.bias
+                    nv = int(getattr(mod, "vid_nodes", 0))
+                    if nv:   # D-VAE NA: the mapped vector is [state ; one-hot(vertex id)] - the one-hot columns are a per-id bias
+                        p["pq_vid"] = torch.cat([Wg[:, H:H + nv], Wm[:, H:H + nv]], 0).t().contiguous()   # [nv, 2H]
+                        Wg, Wm = Wg[:, :H], Wm[:, :H]
                     p["pq_w_t"] = torch.cat([Wg, Wm], 0).t().contiguous()
                     p["pq_b"] = torch.cat([bg, bm if bm is not None else torch.zeros_like(bg)])
                     if We is not None:
@@ -300,6 +304,8 @@ def run_hip(mod, G, x: torch.Tensor, plan) -> List[List[Optional[torch.Tensor]]]
                     m = vc.map[nm]
                     m.w_t, m.bias, m.out, m.ld_out, m.out_dim = p["pq_w_t"].data_ptr(), p["pq_b"].data_ptr(), \
                         pq.data_ptr(), 2 * H, 2 * H
+                    if p.get("pq_vid") is not None:
+                        m.vid_mod, m.vid_bias = int(mod.vid_nodes), p["pq_vid"].data_ptr()
                     nm += 1
                 elif mode == _lib.AGG_MATTN:
                     qd = p["kr_w"].shape[0]

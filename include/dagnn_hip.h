@@ -680,13 +680,15 @@ typedef struct dagnn_variant_aggregator {
 int dagnn_variant_aggregate(const dagnn_plan* plan /* host */, const dagnn_variant_aggregator* agg /* host */, int dir,
                             int32_t slot_begin, int32_t slot_end, void* stream);
 
-typedef struct dagnn_variant_map { /* out[v, 0:out_dim] = w_t^T h[v] + bias for every row v the cell just produced */
+typedef struct dagnn_variant_map { /* out[v, 0:out_dim] = w_t^T h[v] + bias (+ vid_bias[v mod vid_mod]) for every row v the cell just produced */
     const float* w_t;  /* [H,out_dim]: the weight transposed (k-major) */
     const float* bias; /* [out_dim] or NULL */
     float* out;        /* [N,ld_out] */
     int64_t ld_out;
     int32_t out_dim;
-    int32_t reserved;
+    int32_t vid_mod;   /* > 0: the mapped vector is [state ; one-hot(v mod vid_mod)] (D-VAE NA, dvae/dagnn.py:124-137): the one-hot
+                        * columns of the weight act as a per-vertex-id bias */
+    const float* vid_bias; /* [vid_mod, out_dim] (the weight's one-hot columns, transposed) when vid_mod > 0 */
 } dagnn_variant_map;
 
 typedef struct dagnn_variant_cell {

@@ -225,7 +225,7 @@ def test_dvae_encode_matches_reference_golden(device, name, schedule):
     assert Hh.maxdiff(mu2, arr["mu"]) < TOL and Hh.maxdiff(lv2, arr["logvar"]) < TOL
 
 
-@pytest.mark.parametrize("name", ["na_h64_add", "bn_h64_max"])
+@pytest.mark.parametrize("name", ["na_h64_add", "bn_h64_max", "na_h64_gated_sum"])
 def test_dvae_aggregator_weights_follow_silent_parameter_updates(device, name):
     """`add` / `max` on the D-VAE encoders derive their weights on a cached view object (variants._derive).  A fused
     optimizer (or a write through `.data`) changes parameters without bumping `_version`: a train() / eval() switch has

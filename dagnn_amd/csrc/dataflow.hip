@@ -277,31 +277,9 @@ __device__ __forceinline__ float df_tanh(float x) { return 1.0f - 2.0f * __built
 // starts at s * (KP8 + 4): the 8 segments a half DPP row reads concurrently (ds_read_b128) fall on disjoint banks
 template <int KPT> struct DfPad { static constexpr int kp8 = 2 * KPT; static constexpr int seg = kp8 + 4; static constexpr int row = 8 * seg + 8; };
 
-#ifndef DF_WAKEUP
-#define DF_WAKEUP 0     // a wave that raises an LDS flag pings the workgroup's sleeping waves (s_wakeup): the flag's readers sleep
-#endif                  // longer between looks (fewer issue slots taken from the waves that work) and still see it at once
-#ifndef DF_CSLEEP_N
-#define DF_CSLEEP_N (DF_WAKEUP ? 8 : 1)   // s_sleep argument (x 64 cycles) of the compute waves' look at the ready flags
-#endif
-#ifndef DF_WSLEEP_N
-#define DF_WSLEEP_N (DF_WAKEUP ? 8 : 1)   // ... of a loader's wait for its ring slot
-#endif
-#ifndef DF_PIPE
-#define DF_PIPE 0       // compute waves: the next block's flag look and LDS reads under the current block's reduction / gates / stores.
-                        // Measured (round 4), bitwise the plain loop's rows: at 12 waves the two operand register sets spill (208 VGPRs,
-                        // 5.5 ms); in the 8-wave shape (256 registers, -DDF_NLW_V=4) 1.405 against 1.425 ms without it - and 1.355
-                        // for the plain loop at 12 waves: the look + LDS round trip it hides is not what a block's time is made of
-#endif
-#ifndef DF_LEAN_COMPUTE
-#define DF_LEAN_COMPUTE 1
-#endif
-#ifndef DF_ROT
-#define DF_ROT 0        // stream s gives row r of its blocks to loader wave (r + s) mod 4: the rows 0 of the two streams - all a thin
-#endif                  // dependent chain has - are polled and folded on different SIMDs
-__device__ __forceinline__ void df_wakeup() {
-    if (DF_WAKEUP) asm volatile("s_wakeup" ::: "memory");
-}
-
+constexpr int DF_CSLEEP_N = 1;   // s_sleep argument (x 64 cycles) of the compute waves' look at the ready flags
+constexpr int DF_WSLEEP_N = 1;   // ... of a loader's wait for its ring slot
+constexpr bool DF_LEAN_COMPUTE = true;   // (the 12-wave shape: the 2 x 4 ready flags are one trip to LDS; the 8-wave shape of H = 320 has 2 x 2)
 constexpr int DF_RD = 6;       // a loader wave requests a row record this many of ITS blocks ahead (record ring: 8 entries)
 constexpr int DF_GD = 2;       // a gi0 slice this many (its node id must have landed: DF_RD >= DF_GD + 2)
 constexpr int DF_GIRING = DF_NSLOT + DF_GD + 2;   // blocks in a stream's gi0 ring: slots in use + prefetch distance + slack
@@ -349,11 +327,8 @@ __device__ __forceinline__ bool df_wait4(const int* f, int target, int* err, uns
 }
 
 // bounded global poll: false (and error bit 0) once the budget is spent
-#ifndef DF_POLL_SLEEP
-#define DF_POLL_SLEEP 1
-#endif
 __device__ __forceinline__ bool df_retry(unsigned& spins, int* err, unsigned limit) {
-    __builtin_amdgcn_s_sleep(DF_POLL_SLEEP);
+    __builtin_amdgcn_s_sleep(1);
     if (++spins > limit) { __hip_atomic_fetch_or(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
     if ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
     return true;
@@ -497,9 +472,6 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
     };
     auto rec_dma = [&](int j) { if (lane < 16) glds4(rec_src(j), rec_dst(j)); };
     auto gi_dma = [&](int blk, int node) { if (lane < 24) glds16(gi_src(node), gi_dst(blk)); };
-#ifdef DF_LOADER_PRIO
-    __builtin_amdgcn_s_setprio(DF_LOADER_PRIO);
-#endif
     if (nblk > 0) {   // prologue: records of this wave's rows of blocks 0..RD-1, gi0 slices of blocks 0..GD-1
         for (int rr = 0; rr < DF_RPW; ++rr) {
             set_row(w * DF_RPW + rr);
@@ -717,7 +689,6 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
         if (prof_wave) dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64();   // LDS writes issued
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) df_flag_st(lds.rdy + set * DF_WPS + w, b + 1);
-        df_wakeup();
         if (prof_wave) dbg[8 * (int64_t)(DF_NLS * b + set) + 3] = wall_clock64();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of ours is in flight when the wave ends
@@ -1054,7 +1025,6 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
         if (prof) dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64();   // LDS writes issued
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         df_flag_st(lds.rdy + set * DF_WPS + w, b + 1);
-        df_wakeup();
         if (prof) dbg[8 * (int64_t)(DF_NLS * b + set) + 3] = wall_clock64();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of ours is in flight when the wave ends
@@ -1091,11 +1061,11 @@ __device__ __forceinline__ float df_row_pair_sum(float x) {
 // 4 quad + 2 (ks & 1) + ((ks >> 1) & 1) for row x, evaluates the gates and stores h' itself - no LDS exchange, no
 // barrier.  Always the same order of additions -> deterministic.
 template <int KPT, int KIND>
-__device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int sl, int pair, const DfLds& lds, int cw, int team) {
+__device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int sl, int pair, const DfLds& lds, int cw) {
     constexpr int H = 16 * KPT;
     constexpr int SEG = DfPad<KPT>::seg, KP8 = DfPad<KPT>::kp8, NK4 = KP8 / 4;
     typedef DfSlot<KPT> Slot;
-    const int tc = threadIdx.x & 255;   // position inside the team
+    const int tc = threadIdx.x & 255;   // position among the compute waves
     const int lane = tc & 63;
     const int quad = lane >> 5, ks = (lane >> 2) & 7, x = lane & 3;
     const bool s0 = (ks & 1) != 0, s1 = (ks & 2) != 0;
@@ -1110,9 +1080,6 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
         const int grp = df_stream_group(pair, q, S.groups);
         nb[q] = grp >= 0 ? S.sched[S.gtab[d] + 2 * grp + 1] : 0;
     }
-#ifdef DF_COMPUTE_PRIO
-    __builtin_amdgcn_s_setprio(DF_COMPUTE_PRIO);
-#endif
     float wr[KP8], wz[KP8], wn[KP8];   // the lane's K slice of the r / z / n rows of its unit
     {
         const float4* wp = C.w + (int64_t)sl * (3 * NK4) * 256 + tc;
@@ -1132,9 +1099,6 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     float b_r = C.bias[unit], b_z = C.bias[H + unit], b_n = C.bias[2 * H + unit];
     asm volatile("" : "+v"(b_r), "+v"(b_z), "+v"(b_n));   // landed before the loop (see the weights above)
     const int apos = unit + (SEG - KP8) * (unit / KP8);   // LDS position of column `unit` of an operand row
-    // the thin-block path (below): this lane's unit there and its LDS position
-    const int unit_lt = 8 * cw + 4 * quad + x, unit_t = sl * DF_JS + unit_lt;
-    const int apos_t = unit_t + (SEG - KP8) * (unit_t / KP8);
     const unsigned epoch = S.epoch, spin_limit = S.spin_limit;
     int* const err = S.err;
     float* const h_out = C.h_out;
@@ -1145,135 +1109,6 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     unsigned long long* const dbg = (DF_PROF && S.dbg) ? S.dbg + 2 * gridDim.x : nullptr;
     const bool prof = DF_PROF && dbg != nullptr && (int)blockIdx.x == S.dbg_wg && cw == 0 && lane == 0;
 
-    if constexpr (DF_PIPE && DF_TEAMS == 1 && DF_NLS == 2 && DF_WPS == 4 && DF_FMA_ROWS == 0 && !DF_PROF) {
-        // ---- software-pipelined form (round 4).  A workgroup's compute waves are its scarce resource (~940 blocks x ~1.05 us
-        // of a 1.35 ms pass): per block ~0.25 us of that is the look at the ready flags plus the LDS round trip of the block's
-        // operands.  Both move under the PREVIOUS block's reduction / gates / stores: right after a block's products (its
-        // operand registers are free, its LDS slot goes back) the wave looks for the next ready block and, if there is one,
-        // issues its LDS reads; only when none is ready yet (the thin dependent chain) it waits as before.  Two register
-        // sets in ping-pong (the loop body exists twice), same choice rule (smallest positive lead first, ties alternate),
-        // same arithmetic in the same order: the rows are bitwise those of the plain loop.
-        typedef int i4v __attribute__((ext_vector_type(4)));
-        const unsigned rdy_a = (unsigned)(uintptr_t)lds.rdy;
-        const int nb0 = nb[0], nb1 = nb[1];
-        int done0 = 0, done1 = 0, pref = 0;
-        int left = nb0 + nb1;
-        if (left == 0) return;
-        auto look = [&]() -> int {   // ONE trip to LDS: the stream to serve next, or -1
-            i4v r0, r1;
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(r0), "=&v"(r1) : "v"(rdy_a) : "memory");
-            const int m0 = __builtin_amdgcn_readfirstlane(min(min(r0.x, r0.y), min(r0.z, r0.w)));
-            const int m1 = __builtin_amdgcn_readfirstlane(min(min(r1.x, r1.y), min(r1.z, r1.w)));
-            const int l0 = done0 < nb0 ? m0 - done0 : 0, l1 = done1 < nb1 ? m1 - done1 : 0;
-            if (l0 <= 0 && l1 <= 0) return -1;
-            return l0 <= 0 ? 1 : (l1 <= 0 ? 0 : (l0 != l1 ? (l0 < l1 ? 0 : 1) : pref));
-        };
-        auto wait_block = [&]() -> int {
-            unsigned spins = 0;
-            for (;;) {
-                const int st = look();
-                if (st >= 0) return st;
-                __builtin_amdgcn_s_sleep(DF_CSLEEP_N);
-                bool give_up = false;
-                if (++spins > 4 * spin_limit) {   // the pass is lost; it must still end (node ids are bounded below)
-                    __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    give_up = true;
-                }
-                if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = true;
-                if (give_up) return done0 < nb0 ? 0 : 1;
-            }
-        };
-        struct Ops { float4 bv[NK4]; float gi_r, gi_z, gi_n, aval; int4 ids; int st, b; };
-        auto take = [&](int st, Ops& o) {   // claim the stream's next block and issue every LDS read of it (no wait here)
-            o.st = st;
-            o.b = st ? done1 : done0;
-            if (st) ++done1; else ++done0;
-            pref = st ^ 1;
-            const float* sbase = lds.ring + (st * DF_NSLOT + o.b % DF_NSLOT) * Slot::words;
-            o.ids = *reinterpret_cast<const int4*>(sbase + Slot::v_off);
-            o.gi_r = o.gi_z = o.gi_n = o.aval = 0.f;
-            if (!proj) {
-                if (has_gi) {
-                    const float* gp = (gi_ring ? lds.giring + (st * DF_GIRING + o.b % DF_GIRING) * (DF_RB * 3 * DF_JS) : sbase + Slot::gi_off) + x * (3 * DF_JS) + unit_l;
-                    o.gi_r = gp[0]; o.gi_z = gp[DF_JS]; o.gi_n = gp[2 * DF_JS];
-                }
-                o.aval = sbase[Slot::a_off + x * Slot::AP + apos];
-            }
-            const float* a_seg = sbase + Slot::a_off + x * Slot::AP + ks * SEG;
-#pragma unroll
-            for (int q = 0; q < NK4; ++q) o.bv[q] = *reinterpret_cast<const float4*>(a_seg + 4 * q);
-        };
-        // one block: products, slot release, (next block's reads), reduction, gates, stores.  Returns false after the last
-        auto body = [&](Ops& cur, Ops& nxt) -> bool {
-            --left;
-            f4v acc[3] = {(f4v){0.f, 0.f, 0.f, 0.f}, (f4v){0.f, 0.f, 0.f, 0.f}, (f4v){0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int q = 0; q < NK4; ++q) {
-                const float bq[4] = {cur.bv[q].x, cur.bv[q].y, cur.bv[q].z, cur.bv[q].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q + e], bq[e], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wz[4 * q + e], bq[e], acc[1], 0, 0, 0);
-                    acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(wn[4 * q + e], bq[e], acc[2], 0, 0, 0);
-                }
-            }
-            const int4 ids = cur.ids;
-            const float gi_r = cur.gi_r, gi_z = cur.gi_z, gi_n = cur.gi_n, aval = cur.aval;
-            const int st = cur.st, b = cur.b;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of this block has landed: the slot goes back
-            if (lane == 0) df_flag_st(lds.dn + st * DF_NCW + cw, b + 1);
-            df_wakeup();
-            int nst = -1;
-            if (left > 0) {
-                nst = look();
-                if (nst >= 0) take(nst, nxt);
-            }
-            float g3[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float u0 = acc[a][0] + df_dpp<0x104>(acc[a][0]), u1 = acc[a][1] + df_dpp<0x104>(acc[a][1]);
-                const float u2 = acc[a][2] + df_dpp<0x114>(acc[a][2]), u3 = acc[a][3] + df_dpp<0x114>(acc[a][3]);
-                const float e0 = s0 ? u2 : u0, e1 = s0 ? u3 : u1;
-                const float f0 = e0 + df_dpp<0x108>(e0), f1 = e1 + df_dpp<0x118>(e1);
-                const float f = s1 ? f1 : f0;
-                g3[a] = df_row_pair_sum(f);
-            }
-            const int nr = (ids.x >= 0) + (ids.y >= 0) + (ids.z >= 0) + (ids.w >= 0);   // live records come first
-            const int gv = x == 0 ? ids.x : (x == 1 ? ids.y : (x == 2 ? ids.z : ids.w));
-            const bool live = x < nr && (unsigned)gv < (unsigned)num_nodes && (lane & 16) == 0;   // (lanes 16 away hold the same sums)
-            if (live) {
-                if (proj) {
-                    gran_t* po = g_out + (int64_t)gv * pld + unit;
-                    __hip_atomic_store(po, gran_pack(epoch, g3[0] + b_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(po + H, gran_pack(epoch, g3[1] + b_z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(po + 2 * H, gran_pack(epoch, g3[2] + b_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    const float rg = df_sigm(g3[0] + b_r + gi_r);
-                    const float zg = df_sigm(g3[1] + b_z + gi_z);
-                    const float ng = df_tanh(fmaf(rg, g3[2] + b_n, gi_n));
-                    const float hv = fmaf(zg, aval - ng, ng);   // n + z * (a - n)
-                    if (local_st) g_out[(int64_t)gv * gld + unit] = gran_pack(epoch, hv);
-                    else __hip_atomic_store(g_out + (int64_t)gv * gld + unit, gran_pack(epoch, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    h_out[(int64_t)gv * ld_h + unit] = hv;
-                }
-                if (aux_out) {
-                    float* ao = aux_out + (int64_t)gv * (3 * H) + unit;
-                    ao[0] = g3[0] + b_r; ao[H] = g3[1] + b_z; ao[2 * H] = g3[2] + b_n;
-                }
-            }
-            if (left == 0) return false;
-            if (nst < 0) take(wait_block(), nxt);
-            return true;
-        };
-        Ops A, B;
-        take(wait_block(), A);
-        for (;;) {
-            if (!body(A, B)) break;
-            if (!body(B, A)) break;
-        }
-        return;
-    }
     // Blocks of the two streams in whatever order they become ready.  A stream inside a thin dependent chain is ready
     // once per hop (~3 us, of which this wave works ~0.8): the other stream's blocks fill the gap.  When both have a
     // block, the one whose loader is LESS far ahead goes first (it is the latency-bound one); ties alternate.
@@ -1281,29 +1116,9 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     int left = 0, pref = 0;
 #pragma unroll
     for (int q = 0; q < DF_NLS; ++q) { done[q] = 0; left += nb[q]; }
-    if (DF_TEAMS > 1) {   // this team serves its own stream only
-        left = 0;
-#pragma unroll
-        for (int q = 0; q < DF_NLS; ++q) if (q == team) left = nb[q];
-    }
     while (left > 0) {
         int st = -1;
-        if (DF_TEAMS > 1) {
-            st = team;
-            int bnext = 0;
-#pragma unroll
-            for (int q = 0; q < DF_NLS; ++q) if (q == team) bnext = done[q];
-            unsigned spins = 0;
-            for (;;) {
-                int r = df_flag_ld(lds.rdy + team * DF_WPS);
-#pragma unroll
-                for (int x2 = 1; x2 < DF_WPS; ++x2) r = min(r, df_flag_ld(lds.rdy + team * DF_WPS + x2));
-                if (r > bnext) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > 4 * spin_limit) { __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-            }
-        } else if (DF_LEAN_COMPUTE && DF_NLS == 2 && DF_WPS == 4) {
+        if (DF_LEAN_COMPUTE && DF_NLS == 2 && DF_WPS == 4) {
             // the same choice (smallest positive lead first, ties alternate) with ONE trip to LDS per look: the 2 x 4 ready
             // flags are two ds_read_b128 behind one wait (asm: a compiler-visible LDS access next to LDS-DMA traffic is fenced
             // with vmcnt(0)), the rest is scalar
@@ -1349,9 +1164,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
                     if (lead > 0 && key < best) { best = key; st = e; }
                 }
                 if (st >= 0) break;
-#ifndef DF_NO_CSLEEP
                 __builtin_amdgcn_s_sleep(DF_CSLEEP_N);
-#endif
                 bool give_up = false;
                 if (++spins > 4 * spin_limit) {   // the pass is lost; it must still end (node ids are bounded below)
                     __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1376,64 +1189,24 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
         if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 0] = wall_clock64();
         const int4 ids = *reinterpret_cast<const int4*>(sbase + Slot::v_off);
         const int nr = __builtin_amdgcn_readfirstlane((ids.x >= 0) + (ids.y >= 0) + (ids.z >= 0) + (ids.w >= 0));   // live records come first
-        // Blocks of <= DF_FMA_ROWS live rows (the dependent chain of a deep graph is one such block per layer) skip the
-        // matrix cores: v_mfma_f32_4x4x1 spends 3 H/8 x 8 cycles on a block whatever it holds, the same lanes' plain FMAs
-        // 3 H/8 x 2 cycles per live row.  The lane keeps its role on the K side (unit 4 quad + x, K slice ks) and sums ITS
-        // unit's partial dot products in the MFMA's order (k ascending, one fused multiply-add per k: bitwise the matrix
-        // core's accumulator); the 8 K slices are added by a butterfly along the reduce-scatter's tree (pairs of ks bit 0,
-        // then bit 1, then bit 2: fp32 addition commutes, so every sum has the bits the MFMA path gives it) - a row's value
-        // does not depend on the path its block takes.  Afterwards lane (quad, ks = row, x) holds unit 4 quad + x of row ks.
-        const bool thin = DF_FMA_ROWS > 0 && nr <= DF_FMA_ROWS;
         if (prof) dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + st) + 0] = wall_clock64();   // ids landed
-        const int gr = thin ? ks : x;                 // row of the block this lane evaluates the gates of
-        const int unit_ls = thin ? unit_lt : unit_l;  // ... and its unit inside the slice
-        const int unit_s = sl * DF_JS + unit_ls;
+        const int gr = x;                 // row of the block this lane evaluates the gates of
+        const int unit_ls = unit_l;       // ... and its unit inside the slice
+        const int unit_s = unit;
         // operands of the gate algebra: requested now, used after the products
         float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, aval = 0.f;
-        float c_r = b_r, c_z = b_z, c_n = b_n;
-        if (thin) { c_r = lds.bias[unit_lt]; c_z = lds.bias[DF_JS + unit_lt]; c_n = lds.bias[2 * DF_JS + unit_lt]; }
-        // (without the thin-block path nothing in front of the products depends on the ids: every LDS read of the block - ids,
-        // gate operands, operand rows - leaves in one go; a dead row's lanes read their slot's stale words and drop them)
-        if (!proj && (DF_FMA_ROWS == 0 || gr < nr)) {
+        const float c_r = b_r, c_z = b_z, c_n = b_n;
+        // (nothing in front of the products depends on the ids: every LDS read of the block - ids, gate operands, operand
+        // rows - leaves in one go; a dead row's lanes read their slot's stale words and drop them)
+        if (!proj) {
             if (has_gi) {   // from the gi0 ring (stacked layer 0) or from the slot (projection granules)
                 const float* gp = (gi_ring ? lds.giring + (st * DF_GIRING + b % DF_GIRING) * (DF_RB * 3 * DF_JS) : sbase + Slot::gi_off) + gr * (3 * DF_JS) + unit_ls;
                 gi_r = gp[0]; gi_z = gp[DF_JS]; gi_n = gp[2 * DF_JS];
             }
-            aval = sbase[Slot::a_off + gr * Slot::AP + (thin ? apos_t : apos)];
+            aval = sbase[Slot::a_off + gr * Slot::AP + apos];
         }
         float g3[3] = {0.f, 0.f, 0.f};
-        if (thin) {
-#pragma unroll 1
-            for (int r = 0; r < nr; ++r) {
-                const float* a_row = sbase + Slot::a_off + r * Slot::AP + ks * SEG;   // row r, K slice ks (a broadcast read over x and quad)
-                float4 bv[NK4];
-#pragma unroll
-                for (int q = 0; q < NK4; ++q) bv[q] = *reinterpret_cast<const float4*>(a_row + 4 * q);
-                if (prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + st) + 1] = wall_clock64(); }   // operands landed
-                float p3[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < NK4; ++q) {
-                    const float bq[4] = {bv[q].x, bv[q].y, bv[q].z, bv[q].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        p3[0] = __builtin_fmaf(wr[4 * q + e], bq[e], p3[0]);
-                        p3[1] = __builtin_fmaf(wz[4 * q + e], bq[e], p3[1]);
-                        p3[2] = __builtin_fmaf(wn[4 * q + e], bq[e], p3[2]);
-                    }
-                }
-                if (prof) { asm volatile("" :: "v"(p3[0]), "v"(p3[1]), "v"(p3[2])); dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + st) + 2] = wall_clock64(); }   // products done
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    // (every DPP op outside the selects, as below)
-                    const float up4 = p3[a] + df_dpp<0x104>(p3[a]), dn4 = p3[a] + df_dpp<0x114>(p3[a]);
-                    const float t1 = s0 ? dn4 : up4;
-                    const float up8 = t1 + df_dpp<0x108>(t1), dn8 = t1 + df_dpp<0x118>(t1);
-                    const float t2 = s1 ? dn8 : up8;
-                    const float t3 = df_row_pair_sum(t2);
-                    g3[a] = ks == r ? t3 : g3[a];
-                }
-            }
-        } else {
+        {
             const float* a_seg = sbase + Slot::a_off + x * Slot::AP + ks * SEG;   // B operand: row x, K slice ks
             float4 bv[NK4];
 #pragma unroll
@@ -1478,7 +1251,6 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
         if (prof) { asm volatile("" :: "v"(hv)); dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + st) + 3] = wall_clock64(); }   // gates done
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) df_flag_st(lds.dn + st * DF_NCW + cw, b + 1);   // this wave is done with the slot (LDS executes a wave's accesses in order)
-        df_wakeup();
         if (live) {
             if (proj) {   // input-side pre-activations of the upper cell: W_ih u + b_ih, gate-major
                 gran_t* po = g_out + (int64_t)gv * pld + unit_s;
@@ -1577,26 +1349,23 @@ __global__ void __launch_bounds__(DF_THREADS, DF_THREADS / 256) dataflow_kernel(
         if (wave < 8) S.dbg[2 * gridDim.x + 8 * (int64_t)wave + 7] = 0x100000000ull | __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
     __syncthreads();
     const int variant = C.variant;
-    if (wave < DF_NCW * DF_TEAMS) {
-        const int cw = wave % DF_NCW, team = wave / DF_NCW;
+    if (wave < DF_NCW) {
+        const int cw = wave;
         switch (variant >> 2) {
-            case DFK_REC0: df_compute<KPT, DFK_REC0>(S, C, sl, pair, lds, cw, team); break;
-            case DFK_RECP: df_compute<KPT, DFK_RECP>(S, C, sl, pair, lds, cw, team); break;
-            default: df_compute<KPT, DFK_PROJ>(S, C, sl, pair, lds, cw, team); break;
+            case DFK_REC0: df_compute<KPT, DFK_REC0>(S, C, sl, pair, lds, cw); break;
+            case DFK_RECP: df_compute<KPT, DFK_RECP>(S, C, sl, pair, lds, cw); break;
+            default: df_compute<KPT, DFK_PROJ>(S, C, sl, pair, lds, cw); break;
         }
     } else {
-        const int set = (wave - DF_NCW * DF_TEAMS) / DF_WPS;
+        const int set = (wave - DF_NCW) / DF_WPS;
         const int grp = df_stream_group(pair, set, S.groups);
-        const int w = ((wave - DF_NCW * DF_TEAMS) % DF_WPS + (DF_ROT ? set : 0)) % DF_WPS;   // the row of its stream's blocks this wave serves
+        const int w = (wave - DF_NCW) % DF_WPS;   // the row of its stream's blocks this wave serves
         if (grp >= 0) {
 #define DF_LOADER_CASE(K, RR, EX) case (K) * 4 + ((RR) == 2 ? 2 : 0) + ((EX) ? 1 : 0): df_loader<KPT, K, RR, EX>(plan, S, C, sl, grp, lds, w, set); break;
-#ifndef DF_NO_FAST_LOADER
             if (variant == DFK_REC0 * 4 + 2) { df_loader_fast<KPT, DFK_REC0>(plan, S, C, sl, grp, lds, w, set); }
             else if (variant == DFK_RECP * 4 + 2) { df_loader_fast<KPT, DFK_RECP>(plan, S, C, sl, grp, lds, w, set); }
             else if ((variant >> 2) == DFK_PROJ) { df_loader_fast<KPT, DFK_PROJ>(plan, S, C, sl, grp, lds, w, set); }
-            else
-#endif
-            if constexpr (KPT <= 16) {
+            else if constexpr (KPT <= 16) {
                 switch (variant) {
                     DF_LOADER_CASE(DFK_REC0, 2, false) DF_LOADER_CASE(DFK_REC0, 2, true)
                     DF_LOADER_CASE(DFK_REC0, -1, false) DF_LOADER_CASE(DFK_REC0, -1, true)

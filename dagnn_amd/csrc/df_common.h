@@ -9,52 +9,23 @@ namespace {
 constexpr int DF_JS = 32;      // hidden units per slice
 constexpr int DF_RB = 4;       // rows per block = loader waves
 constexpr int DF_NCW = 4;      // compute waves
-#ifndef DF_NLS_V
-#define DF_NLS_V 2
-#endif
-constexpr int DF_NLS = DF_NLS_V;   // streams per workgroup = loader sets: set s serves group NLS * pair + s - a block costs a loader wave one trip to
+constexpr int DF_NLS = 2;          // streams per workgroup = loader sets: set s serves group NLS * pair + s - a block costs a loader wave one trip to
                                // memory plus ~1 us of scalar work, twice what the compute waves need for it
-#ifndef DF_NSLOT_V
-#define DF_NSLOT_V (DF_NLS_V <= 2 ? 4 : 2)
-#endif
-constexpr int DF_NSLOT = DF_NSLOT_V;    // LDS ring depth (blocks the loaders may run ahead)
+constexpr int DF_NSLOT = 4;             // LDS ring depth (blocks the loaders may run ahead)
 // (Measured and removed: two chunks per trip for rows with > 4 in-edges - the second sweep's 32 registers spilled the
 // loader at 3 waves per SIMD.)
-#ifndef DF_TEAMS_V
-#define DF_TEAMS_V 1
-#endif
-constexpr int DF_TEAMS = DF_TEAMS_V;          // compute teams (of DF_NCW waves): 1 = one team takes the blocks of every stream
-                                              // as they become ready; DF_NLS = a team per stream (two waves per SIMD)
-static_assert(DF_TEAMS == 1 || DF_TEAMS == DF_NLS, "compute teams");
 #ifndef DF_NLW_V
-#define DF_NLW_V (12 - DF_NCW * DF_TEAMS_V)
+#define DF_NLW_V (12 - DF_NCW)
 #endif
 constexpr int DF_NLW = DF_NLW_V;                 // loader waves per workgroup (12 waves = 3 per SIMD at <= 168 VGPRs)
 constexpr int DF_WPS = DF_NLW / DF_NLS;     // ... per stream
 constexpr int DF_RPW = DF_RB / DF_WPS;      // rows of a block per loader wave (one after the other)
-static_assert(DF_NLS == 2 || DF_NLS == 4 || DF_NLS == 8, "streams per workgroup");
-// group served by stream `set` of workgroup set `pair` (-1: none).  DF_PAIR_FOLD (two streams): the g-th deepest seed graph
-// shares its workgroups with the (G - 1 - g)-th instead of the (g + 1)-th (the LPT seeds group g with the g-th deepest graph)
-#ifndef DF_PAIR_FOLD
-#define DF_PAIR_FOLD 0
-#endif
+// group served by stream `set` of workgroup set `pair` (-1: none)
 __device__ __host__ __forceinline__ int df_group_of_stream(int pair, int set, int groups) {
-    if (DF_PAIR_FOLD && DF_NLS == 2) {
-        const int g = set == 0 ? pair : groups - 1 - pair;
-        return (set == 0 || g > pair) ? g : -1;
-    }
     const int g = DF_NLS * pair + set;
     return g < groups ? g : -1;
 }
-constexpr int DF_THREADS = 64 * (DF_NCW * DF_TEAMS + DF_NLW);
-#ifndef DF_FMA_ROWS_V
-#define DF_FMA_ROWS_V 0
-#endif
-constexpr int DF_FMA_ROWS = DF_FMA_ROWS_V;    // forward kernel: blocks of at most this many live rows run their products as plain FMAs
-                                              // (dataflow.hip, df_compute), 0 = every block on v_mfma_f32_4x4x1.  Measured (round 4): bitwise the
-                                              // MFMA path's values, but 1.54 (2 rows) / 1.565 (1 row) against 1.50 ms per forward - ONE wave issues
-                                              // an independent VALU op every ~5.4 cycles (scripts/ubench/branch_cost.hip), so 96 FMAs per row cost it
-                                              // ~520 cycles against 768 for the 96 MFMAs, and the butterfly behind them eats the difference: off.
+constexpr int DF_THREADS = 64 * (DF_NCW + DF_NLW);
 constexpr int DF_MAX_GROUPS = 64;
 constexpr int DF_MAGIC = 0x44463031;   // "DF01"
 
@@ -143,9 +114,6 @@ __device__ __forceinline__ void df_assign_wave(const int32_t* items, const int32
     // every graph has the same node count (the D-VAE batches: dvae/dagnn.py:150-158 hard-codes that stride): no B-step chain -
     // the depth-sorted graphs are dealt round-robin (graph j of the order -> group j mod G), all lanes at once
     bool uniform = staged && count > 0;
-#ifdef DF_EXP_NO_UNIFORM
-    uniform = false;
-#endif
     if (uniform) {
         int lo = 0x7fffffff, hi = 0;
         for (int j = lane; j < count; j += 64) { lo = min(lo, s_n[j]); hi = max(hi, s_n[j]); }

@@ -335,7 +335,6 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
                     *reinterpret_cast<float4*>(red + ((TNCW + hh * 3 + g) * 64 + lane) * 4) = make_float4(r[0], r[1], r[2], r[3]);
                 }
             } else {
-#ifndef T_EXP_NOMFMA
 #pragma unroll
             for (int j = 0; j < KJ; ++j) {
                 const float4 b4 = *reinterpret_cast<const float4*>(bp + 256 * (j >> 4) + 4 * (j & 15));
@@ -344,9 +343,6 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][2], b4.z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][3], b4.w, acc, 0, 0, 0);
             }
-#else
-            acc[0] = wr[0][0] + bp[0];
-#endif
             }
 #ifdef T_STAMPS
             asm volatile("s_nop 0" : "+v"(acc));   // the stamp below waits for the products
@@ -380,9 +376,7 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
     }
 
     // ---------------------------------------------------------------------- loader waves
-#ifndef T_EXP_NOPRIO
     __builtin_amdgcn_s_setprio(3);   // ahead of the compute waves' back-to-back MFMAs: a loader instruction never waits behind them
-#endif
     gran_t* own = S.prog + (int64_t)C.cid * (TMAXREP * TNS);
     const gran_t* low = C.low >= 0 ? S.prog + (int64_t)C.low * (TMAXREP * TNS) : nullptr;
     const __amdgpu_buffer_rsrc_t rs_own = t_rsrc(C.h_out);
@@ -517,9 +511,6 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
     // the rows this wave builds: 4 of the tile's 16.  Everything of a row that needs no arithmetic goes by LDS-DMA
     // straight into the operand tile (the node's lower-layer row; stacked layer 0: the slice's gi0 values).
     auto issue_direct = [&](const Tile& x, int ord) {
-#ifdef T_EXP_NOLOAD
-        return;
-#endif
         int lwo = lw;
         asm volatile("" : "+s"(lwo));
         int ln = lane;
@@ -554,11 +545,6 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
     // cache of this XCD can hold an older copy, and the 32 workgroups of a cell (one XCD when the dispatch rule holds)
     // fetch a remote row ONCE into their shared L2 instead of 32 times across the fabric (sc1 loads: 40 GB per forward).
     auto issue_preds = [&](const Tile& x, int ord, Preds& P) {
-#ifdef T_EXP_NOLOAD
-#pragma unroll
-        for (int q = 0; q < TNQ; ++q) { P.deg[q] = 0; P.eb[q] = 0; P.p1[q][0] = P.p1[q][1] = make_float4(0.f, 0.f, 0.f, 0.f); }
-        return;
-#endif
         int lwo = lw;
         asm volatile("" : "+s"(lwo));
         int ln = lane;
@@ -677,10 +663,6 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
 
     // ------------------------------------------------------------------ loader wave 0: gates of a finished tile
     auto epilogue = [&](const int x_k, const int x_nr, int ord) {
-#ifdef T_EXP_NOEPI
-        if (lane == 0) lds_st(&flags[1], (unsigned)(ord + 1));
-        return;
-#endif
         int ln = lane;
         asm volatile("" : "+v"(ln));   // (opaque per call: addresses derived from it are recomputed, not hoisted out of the tile loop and spilled)
         const int n = ln & 15, q = ln >> 4, slot3 = ord % 3;
@@ -770,11 +752,7 @@ __device__ __forceinline__ void tile_body(const int32_t* __restrict__ plan, cons
             // the polling wave looks at the lower cell's counters once per tile WITHOUT waiting for the answer (it is used
             // behind the rows' own wait below): in the steady state its memory is always ahead of the tile it needs
             const bool refresh = lw == TNLW - 1 && low != nullptr && R == 1 && pipelined;
-#ifdef T_EXP_NOPOLL
-            const gran_t fresh_g = 0;
-#else
             const gran_t fresh_g = gran_ld((refresh ? low : own) + (lane & (TNS - 1)));   // (unconditional: see issue_preds)
-#endif
             if (pipelined) {
                 wait_low(nxt, (unsigned)(it + 2));
                 wait_own(nxt, (unsigned)(it + 2));
@@ -873,13 +851,11 @@ int tiles_chunks(int num_cus, int ndir, int Ls, int* first, int* count, int* rep
     if (ndir <= 0 || Ls <= 0 || num_cus < TNS * ndir) return 0;
     const int per = num_cus / (TNS * ndir);   // cells of one direction the device hosts
     int n = 0;
-#ifndef T_NO_SINGLE_CHUNK
     if (Ls > 1 && Ls <= per) {   // every cell fits at once (L <= 4 with two directions on 256 CUs): ONE launch, ONE dependent chain
         int r = per / Ls; if (r > 4) r = 4;
         first[0] = 0; count[0] = Ls; reps[0] = r;
         return 1;
     }
-#endif
     first[n] = 0; count[n] = 1; reps[n] = per < TMAXREP ? per : TMAXREP; if (reps[n] > T_REP0) reps[n] = T_REP0; ++n;
     for (int i = 1; i < Ls;) {
         const int c = (Ls - i) < per ? (Ls - i) : per;

@@ -5,7 +5,7 @@ for c in 1 4; do
   CFG=$c timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_small_$c -o tr -- python scripts/small_time.py > gpurun_out/prof_small_$c.log 2>&1
   grep "us per" gpurun_out/prof_small_$c.log
   f=$(find gpurun_out/prof_small_$c -name "*kernel_stats.csv" | head -1)
-  cp $f gpurun_out/r04_cfg${c}_kernel_stats.csv
+  cp $f gpurun_out/${R:-r04}_cfg${c}_kernel_stats.csv
   python - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))

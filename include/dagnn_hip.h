@@ -177,8 +177,8 @@ int dagnn_recurrence_layer(const dagnn_plan* plan /* host */, const dagnn_layer_
 int dagnn_pack_slices(const float* w /* [3H,K] */, float* out /* 3H*K floats */, int H, int K, int slice_units,
                       void* stream);
 
-/* W [3H,K] -> B-fragment order of v_mfma_f32_32x32x2_f32 for 32-unit slices (3H*K floats out); used by
- * the 32-row tiles of the fattest launches. */
+/* W [3H,K] -> B-fragment order of v_mfma_f32_16x16x4_f32 for 32-unit slices (six 16-column blocks per slice, 16 k per
+ * 1-KiB wave load; 3H*K floats out; K % 16 == 0); used by the 64-row tiles of the fat launches (csrc/fat.hip). */
 int dagnn_pack_mfma(const float* w /* [3H,K] */, float* out, int H, int K, void* stream);
 
 /* Both slice layouts and the MFMA layout of several matrices in ONE launch (a training step re-packs every cell's
@@ -223,9 +223,12 @@ typedef struct dagnn_frontier_args {
     int num_cus;     /* compute units of the device (launch geometry heuristic), e.g. 256 */
     int rb4_max_wgs; /* streamed 32-unit slices: launches of up to this many 4-row-block workgroups use 4-row blocks,
                       * bigger ones 8-row blocks; 0 = default (1.5 per CU) */
-    int mfma_min_rows;    /* launches with at least this many rows (all cells) run as 32-row MFMA tiles; 0 = never */
-    void* agg_scratch;    /* NULL, or fp32 [agg_scratch_rows, H]: fat launches aggregate every row once into it */
-    int agg_scratch_rows; /* >= the largest number of rows (over all cells) of any single launch */
+    int mfma_min_rows;    /* launches with at least this many rows (all cells of both directions; a one-direction chain takes its
+                           * share) run as 64-row MFMA tiles with the gather fused (csrc/fat.hip); 0 = never */
+    void* agg_scratch;    /* NULL, or fp32 [agg_scratch_rows, H]: scratch rows for the aggregates of rows with more than two
+                           * predecessors (the fat launches build them in their prologue; nothing else goes through memory) */
+    int agg_scratch_rows; /* >= (largest number of rows of direction 0's cells in one launch) + (the same for direction 1): the two
+                           * directions' launches may run concurrently (below) and keep their scratch rows apart */
     /* persistent tail: one dataflow launch for all layers after the fat head (needs every cell's
      * `granules`, epoch != 0 and H <= 256): */
     int tail_replicas;   /* workgroups per (cell, slice) in the tail kernel; 0 disables it */
@@ -240,7 +243,11 @@ typedef struct dagnn_frontier_args {
      * joins back into `stream` with the caller's `fork_event` / `join_event` (capturable); results agree with the unsplit mode to rounding (a row may be
      * handled by a different kernel), each mode by itself is deterministic.  (CU-masked streams for the two
      * halves were measured and dropped: masked queues slowed every other launch of the process.) */
-    void* side_stream;                              /* hipStream_t or NULL: runs the persistent kernel */
+    void* side_stream;                              /* hipStream_t or NULL: runs the persistent kernel.  Without a persistent tail in
+                                                     * the call (H > 256, or tail_replicas = 0) and with both directions, the same
+                                                     * stream and events run direction 1's per-layer launches as a second chain next to
+                                                     * direction 0's on `stream` (the directions share nothing; each chain's launches
+                                                     * fill the CUs the other's leave idle while their last workgroups drain) */
     const int32_t* layer_split[DAGNN_MAX_DIRS];     /* HOST, num_layers[d] int32: first deep slot of every layer, or NULL */
     void* fork_event;                               /* hipEvent_t x 2, CALLER-OWNED (the library creates nothing): split */
     void* join_event;                               /* mode needs both, otherwise it is off */

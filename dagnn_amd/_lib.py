@@ -212,6 +212,19 @@ class VariantArgs(C.Structure):
 
 
 # every symbol include/dagnn_hip.h declares: (restype, argtypes)
+class PrepTable(C.Structure):
+    _fields_ = [("type_emb", C.c_void_p), ("attr_emb", C.c_void_p), ("depth_emb", C.c_void_p), ("out", C.c_void_p),
+                ("width", C.c_int), ("ld_out", C.c_int)]
+
+
+PREPARE_MAX_TABLES = 3
+
+
+class PrepareRows(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("depth", C.c_void_p), ("max_depth", C.c_int), ("num_tables", C.c_int),
+                ("table", PrepTable * PREPARE_MAX_TABLES), ("stack_src", C.c_void_p * 4), ("stack_out", C.c_void_p)]
+
+
 SYMBOLS = {
     "dagnn_version": (C.c_char_p, []),
     "dagnn_plan_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int]),
@@ -219,6 +232,8 @@ SYMBOLS = {
     "dagnn_plan_layout": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
     "dagnn_plan_build": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
+    "dagnn_prepare": (C.c_int, [C.POINTER(Plan), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(PrepareRows), C.c_void_p]),
     "dagnn_encode_ast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "dagnn_gemm_nt_bias": (C.c_int, [C.POINTER(GemmGroup), C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,

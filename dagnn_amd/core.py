@@ -81,7 +81,7 @@ class CellParams(object):
     """Device-side, kernel-ready parameters of one (direction, stacked layer) cell."""
 
     __slots__ = ("w_ih", "b_ih", "w_hh_t", "b_hh", "w_key", "edge_gain", "vid_bias", "w_hh_pk", "w_ih_pk",
-                 "b_ih_dev", "Hp", "key_raw", "w_hh_raw", "w_hh_df", "w_ih_df", "w_hh_bt", "w_ih_bt", "df_ok", "gain_src")
+                 "b_ih_dev", "Hp", "key_raw", "w_hh_raw", "w_hh_df", "w_ih_df", "w_hh_bt", "w_ih_bt", "df_ok", "gain_src", "fold")
 
 
 def pack_dataflow(cells, transposed_too: bool = False) -> None:
@@ -158,6 +158,7 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
     Hp = engine.state_width(H, stacked, 0 if edge_w is None else int(edge_w.shape[1]), wide_ok=wide_ok) if lock else round_up4(H)
     c = CellParams()
     c.Hp = Hp
+    c.fold = None   # (model._folded_tables: the encoder's tables folded through this cell's W_ih, stacked layer 0 only)
     wi = _pad_gate_rows(w_ih.detach().float(), H, Hp)
     if in_is_hidden:
         wi = _pad_cols(wi, Hp)
@@ -231,13 +232,15 @@ def _warn_off_dataflow(dev, ndirs: int, L: int, Hp: int) -> None:
 def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tuple[int, int], CellParams],
                        dirs: Sequence[int], L: int, H: int, vid_nodes: int = 0,
                        arena: Optional[engine.GranuleArena] = None, static_score=None,
-                       keep: Optional[dict] = None) -> List[List[torch.Tensor]]:
+                       keep: Optional[dict] = None, gi0: Optional[Sequence[torch.Tensor]] = None) -> List[List[torch.Tensor]]:
     """Lock-step schedule (default): one batched input GEMM for stacked layer 0 of every direction,
     then T + L - 1 frontier launches covering all cells (csrc/frontier.hip).  `keep` (training) receives
-    what the backward pass needs: the raw state buffers (`h_buf`) and `gi0`."""
+    what the backward pass needs: the raw state buffers (`h_buf`) and `gi0`.  `gi0` (one [N, 3Hp] per direction): the
+    input-side pre-activations of stacked layer 0 when the caller already has them (model._folded_gi0)."""
     Hp = cells[(dirs[0], 0)].Hp
     N, dev = x.shape[0], x.device
-    gi0 = engine.gemm_nt_bias([x] * len(dirs), [cells[(d, 0)].w_ih for d in dirs], [cells[(d, 0)].b_ih for d in dirs])
+    if gi0 is None:
+        gi0 = engine.gemm_nt_bias([x] * len(dirs), [cells[(d, 0)].w_ih for d in dirs], [cells[(d, 0)].b_ih for d in dirs])
     gi = [None, None]
     for q, d in enumerate(dirs):
         gi[d] = gi0[q]
@@ -290,11 +293,11 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
 def run_stack(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tuple[int, int], CellParams],
               dirs: Sequence[int], L: int, H: int, vid_nodes: int = 0,
               schedule: str = "pergraph", arena: Optional[engine.GranuleArena] = None,
-              static_score=None) -> List[List[torch.Tensor]]:
+              static_score=None, gi0: Optional[Sequence[torch.Tensor]] = None) -> List[List[torch.Tensor]]:
     """Hidden states h[d][i] ([N, H] each) of all stacked layers and directions.  `static_score[(d, i)]`
     ([N]) replaces the hidden-state attention scores for the aggregators whose keys are the inputs."""
     if schedule == "lockstep":
-        return run_stack_lockstep(plan, x, cells, dirs, L, H, vid_nodes, arena, static_score)
+        return run_stack_lockstep(plan, x, cells, dirs, L, H, vid_nodes, arena, static_score, gi0=gi0)
     Hp = round_up4(H)
     N = x.shape[0]
     dev = x.device

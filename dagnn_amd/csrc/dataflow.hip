@@ -32,7 +32,7 @@
 //                   barrier anywhere), h' -> plain row store + granule store.
 // The loaders run up to NSLOT blocks ahead, so wide layers stream while a thin dependent chain costs one hand-off +
 // ~1 us of compute per hop.  DESIGN.md section 4a has the measurements.
-#include "df_common.h"
+#include "sched_dev.h"
 #include <type_traits>
 
 
@@ -40,145 +40,48 @@ namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// ---- LPT assignment: graphs in order of decreasing depth (plan items), each to the group whose load it raises the
-// least; load_k = c_layer * (depth of the first = deepest graph of k) + c_row * (nodes of k).  One wave, lane = group.
-// Workgroups 1.. of the launch initialise the rest of the workspace meanwhile (tables and counters = 0, records = -1:
-// two memsets less on a launch-bound path); workgroup 0 clears the head it writes into itself.
+// ---- the schedule's kernels: one body of sched_dev.h each (csrc/prepare.hip runs the same bodies several per launch)
+// LPT assignment by workgroup 0; workgroups 1.. of the launch initialise the rest of the workspace meanwhile (tables and
+// counters = 0, records = -1: two memsets less on a launch-bound path)
 __global__ void __launch_bounds__(256) df_assign_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws,
                                                          DfLayout S, int B, int G, int c_layer, int c_row, const int32_t* __restrict__ status) {
     if (status && status[0] != 0) return;   // the batch violates the plan contract: nothing here can be trusted
     if (blockIdx.x > 0) {
-        const int64_t nfill = (int64_t)(gridDim.x - 1) * blockDim.x, me = (int64_t)(blockIdx.x - 1) * blockDim.x + threadIdx.x;
-        int4* z = reinterpret_cast<int4*>(ws + S.gtab[0]);   // (every array of the layout starts on a multiple of 4 words)
-        const int64_t nz = (S.grec[0] - S.gtab[0]) / 4, nf = (S.total - S.grec[0]) / 4;
-        for (int64_t i = me; i < nz; i += nfill) z[i] = make_int4(0, 0, 0, 0);
-        int4* f = reinterpret_cast<int4*>(ws + S.grec[0]);
-        for (int64_t i = me; i < nf; i += nfill) f[i] = make_int4(-1, -1, -1, -1);
+        df_fill_body(ws, S, (int64_t)(blockIdx.x - 1) * blockDim.x + threadIdx.x, (int64_t)(gridDim.x - 1) * blockDim.x);
         return;
     }
-    if (threadIdx.x >= 64) return;
-    for (int64_t i = threadIdx.x; i < S.gtab[0]; i += 64) ws[i] = 0;   // header + grp_of / gdepth / gload / loff (+ padding)
-    // the sequential part below is B dependent steps: its operands (graph, depth, nodes, in schedule order) are
-    // staged in LDS first - from global memory every step is three dependent round trips (measured 76 us at B = 128)
     constexpr int CAP = 4096;
     __shared__ int32_t s_g[CAP], s_d[CAP], s_n[CAP];
-    df_assign_wave<CAP>(plan + L.items, plan + L.depth[0], plan + L.depth[1], plan + L.node_ptr, ws, S, B, G, c_layer, c_row, s_g, s_d, s_n);
+    df_assign_block<CAP>(plan, L, ws, S, B, G, c_layer, c_row, s_g, s_d, s_n);
 }
 
-// rows per (group, layer): one workgroup per (graph, direction) adds its layer widths
 __global__ void __launch_bounds__(256) df_count_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws,
                                                         DfLayout S, const int32_t* __restrict__ status) {
     if (status && status[0] != 0) return;   // the batch violates the plan contract: nothing here can be trusted
-    const int g = blockIdx.x, d = blockIdx.y;
-    const int n0 = plan[L.node_ptr + g];
-    const int k = ws[S.grp_of + g];
-    // (the group's table has gdepth_k + 1 entries, gdepth_k = max over its graphs of max(depth0, depth1): the bound
-    // below holds even if a batch's two layerings ever disagreed in depth)
-    const int depth = min(plan[L.depth[d] + g], ws[S.gdepth + k]);
-    const int32_t* ls = plan + L.lstart[d] + n0 + g;
-    int32_t* cnt = ws + S.lcnt[d] + ws[S.loff + k];
-    for (int t = threadIdx.x; t < depth; t += blockDim.x) atomicAdd(&cnt[t], ls[t + 1] - ls[t]);
+    df_count_body(plan, L, ws, S, blockIdx.x, blockIdx.y);
 }
 
-// per (group, direction): counts -> exclusive prefix of the block-padded counts; gtab = {.., blocks}
 __global__ void __launch_bounds__(256) df_prefix_kernel(int32_t* ws, DfLayout S, int G, const int32_t* __restrict__ status) {
     if (status && status[0] != 0) return;   // the batch violates the plan contract: nothing here can be trusted
-    __shared__ int32_t wsum[4];
-    __shared__ int32_t carry_s;
-    const int k = blockIdx.x, d = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-    const int depth = ws[S.gdepth + k];
-    int32_t* cnt = ws + S.lcnt[d] + ws[S.loff + k];
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int c0 = 0; c0 <= depth; c0 += 256) {
-        const int t = c0 + tid;
-        const int c = t < depth ? cnt[t] : 0;
-        const int padded = (c + DF_RB - 1) / DF_RB * DF_RB;
-        int x = padded;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-        if (lane == 63) wsum[tid >> 6] = x;
-        __syncthreads();
-        int woff = 0, tot = 0;
-        for (int w = 0; w < 4; ++w) { if (w < (tid >> 6)) woff += wsum[w]; tot += wsum[w]; }
-        const int carry = carry_s;
-        if (t <= depth) cnt[t] = carry + woff + x - padded;
-        __syncthreads();
-        if (tid == 0) carry_s = carry + tot;
-        __syncthreads();
-    }
-    if (tid == 0) ws[S.gtab[d] + 2 * k + 1] = carry_s / DF_RB;
+    df_prefix_body(ws, S, blockIdx.x, blockIdx.y);
 }
 
-// first record of every group (exclusive prefix over the groups' record counts); one wave per direction
 __global__ void __launch_bounds__(64) df_base_kernel(int32_t* ws, DfLayout S, int G, const int32_t* __restrict__ status) {
     if (status && status[0] != 0) return;   // the batch violates the plan contract: nothing here can be trusted
-    const int d = blockIdx.x, lane = threadIdx.x;
-    int x = lane < G ? ws[S.gtab[d] + 2 * lane + 1] * DF_RB : 0;
-    const int own = x;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-    if (lane < G) ws[S.gtab[d] + 2 * lane] = x - own;
+    const int base = df_base_wave(ws, S, G, blockIdx.x, threadIdx.x);
+    if ((int)threadIdx.x < G) ws[S.gtab[blockIdx.x] + 2 * threadIdx.x] = base;
 }
 
-// glbase[(g, t)] = padded prefix of (group, t) + rows of layer t in the group's graphs ordered before g.
-// One wave per (group, layer) pair, lanes over graphs.
 __global__ void __launch_bounds__(256) df_lbase_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws,
                                                         DfLayout S, int B, int G, const int32_t* __restrict__ status) {
     if (status && status[0] != 0) return;   // the batch violates the plan contract: nothing here can be trusted
-    const int d = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int nw = gridDim.x * 4;
-    const int total = ws[S.loff + G];
-    const int32_t* __restrict__ ls = plan + L.lstart[d];
-    const int32_t* __restrict__ node_ptr = plan + L.node_ptr;
-    const int32_t* __restrict__ depth = plan + L.depth[d];
-    for (int pair = blockIdx.x * 4 + (threadIdx.x >> 6); pair < total; pair += nw) {
-        int k = 0;
-        while (k + 1 < G && pair >= ws[S.loff + k + 1]) ++k;
-        const int t = pair - ws[S.loff + k];
-        if (t >= ws[S.gdepth + k]) continue;   // the table has depth + 1 entries per group
-        int carry = ws[S.lcnt[d] + pair];
-        for (int g0 = 0; g0 < B; g0 += 64) {
-            const int g = g0 + lane;
-            int cnt = 0, base = 0;
-            bool has = false;
-            if (g < B && ws[S.grp_of + g] == k && t < depth[g]) {
-                base = node_ptr[g] + g + t;
-                cnt = ls[base + 1] - ls[base];
-                has = true;
-            }
-            int x = cnt;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-            if (has) ws[S.glbase[d] + base] = carry + x - cnt;
-            carry += __shfl(x, 63, 64);
-        }
-    }
+    df_lbase_body(plan, L, ws, S, B, G, blockIdx.x * 4 + (threadIdx.x >> 6), gridDim.x * 4, blockIdx.y);
 }
 
-// copy every row record to its place in the group order (padding records were preset to -1)
 __global__ void __launch_bounds__(256) df_records_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws,
                                                           DfLayout S, int N, const int32_t* __restrict__ status) {
     if (status && status[0] != 0) return;   // the batch violates the plan contract: nothing here can be trusted
-    const int d = blockIdx.y;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;   // per-graph sorted position
-    if (p >= N) return;
-    const int v = plan[L.order[d] + p];
-    const int slot = plan[L.pos[d] + v];
-    const int4* src = reinterpret_cast<const int4*>(plan + L.rowrec[d]) + 4 * (int64_t)slot;
-    const int4 r0 = src[0];
-    const int g = r0.w;
-    const int n0 = plan[L.node_ptr + g];
-    const int depth = plan[L.depth[d] + g];
-    const int32_t* ls = plan + L.lstart[d] + n0 + g;   // depth + 1 absolute positions
-    int lo = 0, hi = depth;                            // largest t with ls[t] <= p
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ls[mid] <= p) lo = mid; else hi = mid; }
-    const int t = lo;
-    const int k = ws[S.grp_of + g];
-    const int rec = ws[S.gtab[d] + 2 * k] + ws[S.glbase[d] + n0 + g + t] + (p - ls[t]);
-    int4* dst = reinterpret_cast<int4*>(ws + S.grec[d]) + 4 * (int64_t)rec;
-    dst[0] = r0; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+    df_records_body(plan, L, ws, S, N, blockIdx.x, blockIdx.y, ws + S.gtab[blockIdx.y], 2);
 }
 
 // ---------------------------------------------------------------- the persistent kernel

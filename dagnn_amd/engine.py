@@ -81,8 +81,11 @@ BWD_TAIL_MAX_BLOCKS = _env_int("DAGNN_AMD_BWD_TAIL_MAX_BLOCKS", 4)
 # Tried again with the plan kernels' LDS cut to 17 / 12 KB so that they fit next to the GEMM's four workgroups per CU:
 # they then run concurrently but 2-4x slower (plan_ptr 61 us instead of 15, plan_graph 103 instead of 49), bench.py
 # 2.302-2.312 against 2.3085 ms - nothing - and two processes sharing one GPU (the two-rank bench test) failed.
-PLAN_OVERLAP = _env_int("DAGNN_AMD_PLAN_OVERLAP", 0)
+PLAN_OVERLAP = _env_int("DAGNN_AMD_PLAN_OVERLAP", 1)              # 1: plan / schedule kernels (+ side effect 1) on the arena's side stream next to encoder + input GEMM (model._plan_of)
 SIDE_PRIORITY = _env_int("DAGNN_AMD_SIDE_PRIORITY", 0)     # stream priority of an arena's side stream (-1: high)
+FOLD_INPUT = _env_int("DAGNN_AMD_FOLD_INPUT", 1)              # 1: evaluation passes over an ASTNodeEncoder fold the embedding tables through W_ih of stacked layer 0 once per
+                                                            # weight version (gi0 = three folded rows summed per node instead of the [N, emb] x [emb, 3H] GEMM; model._folded_tables)
+PREPARE_FUSED = _env_int("DAGNN_AMD_PREPARE", 1)            # 1: evaluation passes build plan + schedule + encoder rows + side effect 1 as one pipeline of 7 launches (csrc/prepare.hip)
 PLAN_SMALL = _env_int("DAGNN_AMD_PLAN_SMALL", 1)            # 1: batches of <= 2048 nodes / 4096 edges / 512 graphs build plan and schedule with one workgroup each (csrc/small.hip)
 PLAN_GENERAL_BUILD = 1                                      # dagnn_plan.flags: keep the plan on the general kernels
 DATAFLOW = _env_int("DAGNN_AMD_DATAFLOW", 1)                # 1: the persistent graph-affine dataflow kernel where it applies (H <= 256)
@@ -115,9 +118,32 @@ def _span(name, tensor):
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+_LAUNCH_ON = []   # innermost `launch_on` stream (the module is used from one thread per device context)
+
+
+class launch_on(object):
+    """Library launches inside the block go to `stream`; torch's CURRENT stream - hence the caching allocator's pool and
+    every torch op - stays the caller's.  Memory allocated inside is the caller stream's: no `record_stream`, no
+    foreign-pool blocks that cannot be reused (a forward pass that allocated under a side stream cost seven `hipMalloc`
+    calls per batch).  The caller orders the two streams itself (fork before, join after)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        _LAUNCH_ON.append(self.stream.cuda_stream if self.stream is not None else None)
+        return self
+
+    def __exit__(self, *exc):
+        _LAUNCH_ON.pop()
+        return False
+
+
 def _stream(t: torch.Tensor) -> int:
     """Raw hipStream_t of torch's current stream on the tensor's device (the Stream object costs ~1.5 us per call and
     the small-batch forward asks seven times)."""
+    if _LAUNCH_ON and _LAUNCH_ON[-1] is not None:
+        return _LAUNCH_ON[-1]
     if _RAW_STREAM is not None:
         return _RAW_STREAM(t.device.index if t.device.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(t.device).cuda_stream
@@ -194,6 +220,22 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+_STATUS_POOL = {}
+
+
+def _status_words(device) -> torch.Tensor:
+    """Four zeroed int32 words (a plan's contract status).  They come from a pool zeroed 1024 plans at a time - a fill kernel
+    per plan sat on the critical path of every forward (4.4 us + its launch gap) - and a slot is never handed out twice: the
+    plan's view keeps its pool alive, an exhausted pool is simply dropped."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    pool = _STATUS_POOL.get(key)
+    if pool is None or pool[1] >= pool[0].shape[0]:
+        pool = _STATUS_POOL[key] = [torch.zeros(1024, 4, dtype=torch.int32, device=dev), 0]
+    pool[1] += 1
+    return pool[0][pool[1] - 1]
+
+
 class PlanHandle(object):
     """Device workspace holding the layer-sorted per-graph CSR of one batch (both directions)."""
 
@@ -202,10 +244,66 @@ class PlanHandle(object):
         self.N, self.E, self.B, self.R = int(N), int(E), int(B), int(R)
         nbytes = lib.dagnn_plan_bytes(self.N, self.E, self.B, self.R)
         self.ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device)
-        small = PLAN_SMALL and lib.dagnn_plan_is_small(self.N, self.E, self.B)   # that build writes the status word itself
-        self.status = (torch.empty if small else torch.zeros)(4, dtype=torch.int32, device=device)
+        self.status = _status_words(device)
         self.desc = Plan(self.ws.data_ptr(), nbytes, self.N, self.E, self.B, self.R, 0 if PLAN_SMALL else PLAN_GENERAL_BUILD)
         self.ready = None   # event to wait for when the plan was built on another stream
+
+    def launch_build(self) -> None:
+        edge_index, layer_fwd, layer_bwd, batch, edge_attr = self._keep
+        with _span("plan_build", edge_index):
+            check(_lib.load().dagnn_plan_build(C.byref(self.desc), edge_index.data_ptr(), layer_fwd.data_ptr(),
+                                               layer_bwd.data_ptr(), batch.data_ptr(), _ptr(edge_attr),
+                                               self.status.data_ptr(), _stream(edge_index)), "dagnn_plan_build")
+
+    def launch_prepare(self, groups: int = 0, enc=None, stack=None) -> None:
+        """The fused pipeline (`dagnn_prepare`, csrc/prepare.hip): this plan, its dataflow schedule for `groups` groups
+        (0: none) and the row work that rides along - `enc` = (x [N,2], depth [N], max_depth, [(type, attr, depth tables, out),
+        ...]): encoder rows of up to three table sets; `stack` = (four [N] int64 tensors, out [4, N]): side effect 1."""
+        lib = _lib.load()
+        edge_index, layer_fwd, layer_bwd, batch, edge_attr = self._keep
+        rows = _lib.PrepareRows()
+        keep = []
+        if enc is not None:
+            x, depth, max_depth, tables = enc
+            x = _dev(x, "x", torch.int64)
+            if not (depth.is_cuda and depth.dtype == torch.int64 and depth.is_contiguous()):
+                raise DagnnHipError("node_depth must be a contiguous int64 GPU tensor (it is clamped in place)")
+            rows.x, rows.depth, rows.max_depth, rows.num_tables = x.data_ptr(), depth.data_ptr(), int(max_depth), len(tables)
+            for k, (tw, aw, dw, out) in enumerate(tables):
+                tw, aw, dw = _dev(tw, "type table", torch.float32), _dev(aw, "attribute table", torch.float32), _dev(dw, "depth table", torch.float32)
+                keep += [tw, aw, dw]
+                t = rows.table[k]
+                t.type_emb, t.attr_emb, t.depth_emb, t.out = tw.data_ptr(), aw.data_ptr(), dw.data_ptr(), out.data_ptr()
+                t.width, t.ld_out = tw.shape[1], out.stride(0)
+            keep.append(x)
+        if stack is not None:
+            srcs, out = stack
+            srcs = [_dev(t, "layer index", torch.int64) for t in srcs]
+            keep += srcs
+            for j in range(4):
+                rows.stack_src[j] = srcs[j].data_ptr()
+            rows.stack_out = out.data_ptr()
+        ws, nbytes, key = None, 0, None
+        if groups > 0:
+            key = (int(groups), DF_COST_LAYER, DF_COST_ROW)
+            ws = self.dataflow_schedule(groups, launch=False)
+            if key in self._df:   # (it came with the plan from the loader)
+                ws, groups, key = None, 0, None
+            else:
+                nbytes = lib.dagnn_dataflow_bytes(self.N, self.B, key[0])
+        with _span("prepare", edge_index):
+            check(lib.dagnn_prepare(C.byref(self.desc), edge_index.data_ptr(), layer_fwd.data_ptr(), layer_bwd.data_ptr(),
+                                    batch.data_ptr(), _ptr(edge_attr), self.status.data_ptr(), _ptr(ws), nbytes, int(groups),
+                                    DF_COST_LAYER, DF_COST_ROW, C.byref(rows) if (enc is not None or stack is not None) else None,
+                                    _stream(edge_index)), "dagnn_prepare")
+        if key is not None and key in self.__dict__.get("_df_pending", {}):
+            self._df[key] = self._df_pending.pop(key)
+
+    def wait_after(self) -> None:
+        """Order the caller's stream behind what `model._plan_of` queued on the side stream BEHIND the plan."""
+        ev = self.__dict__.pop("after", None)
+        if ev is not None:
+            torch.cuda.current_stream(self.ws.device).wait_event(ev)
 
     def wait_ready(self) -> None:
         """Order the caller's stream behind the plan's construction (no-op for a plan built on this stream)."""
@@ -229,7 +327,7 @@ class PlanHandle(object):
         if ws.numel() * 4 < nbytes:
             raise DagnnHipError("host-built plan has %d bytes, the layout needs %d" % (ws.numel() * 4, nbytes))
         self.ws = ws
-        self.status = torch.zeros(4, dtype=torch.int32, device=ws.device)
+        self.status = _status_words(ws.device)
         self.desc = Plan(ws.data_ptr(), nbytes, self.N, self.E, self.B, self.R, 0 if PLAN_SMALL else PLAN_GENERAL_BUILD)
         self._schedule = [a for a in meta["schedule"]]
         self._splits = [a for a in meta["splits"]]
@@ -267,9 +365,11 @@ class PlanHandle(object):
         self.read_schedule()
         return self._splits
 
-    def dataflow_schedule(self, groups: int) -> torch.Tensor:
-        """The plan's rows dealt to `groups` independent groups (`dagnn_dataflow_schedule`), built once per plan."""
+    def dataflow_schedule(self, groups: int, launch: bool = True) -> torch.Tensor:
+        """The plan's rows dealt to `groups` independent groups (`dagnn_dataflow_schedule`), built once per plan.
+        `launch=False` allocates the workspace only; the next call with the same key issues the kernels."""
         cache = self.__dict__.setdefault("_df", {})
+        pending = self.__dict__.setdefault("_df_pending", {})
         key = (int(groups), DF_COST_LAYER, DF_COST_ROW)
         if key not in cache:
             meta = getattr(self, "_df_host", None)
@@ -278,7 +378,12 @@ class PlanHandle(object):
             else:
                 lib = _lib.load()
                 nbytes = lib.dagnn_dataflow_bytes(self.N, self.B, key[0])
-                ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=self.ws.device)
+                ws = pending.pop(key, None)
+                if ws is None:
+                    ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=self.ws.device)
+                if not launch:
+                    pending[key] = ws
+                    return ws
                 with _span("dataflow_schedule", self.ws):
                     check(lib.dagnn_dataflow_schedule(C.byref(self.desc), ws.data_ptr(), nbytes, key[0], key[1], key[2],
                                                       self.status.data_ptr(), _stream(self.ws)), "dagnn_dataflow_schedule")
@@ -302,7 +407,8 @@ class PlanHandle(object):
 
 
 def build_plan(edge_index: torch.Tensor, layer_fwd: torch.Tensor, layer_bwd: torch.Tensor, batch: torch.Tensor,
-               num_graphs: int, edge_attr: Optional[torch.Tensor] = None) -> PlanHandle:
+               num_graphs: int, edge_attr: Optional[torch.Tensor] = None, launch: bool = True) -> PlanHandle:
+    """`launch=False`: allocate and initialise only; `plan.launch_build()` issues the kernels (e.g. under `launch_on`)."""
     edge_index = _dev(edge_index, "edge_index", torch.int64)
     layer_fwd = _dev(layer_fwd, "layer ids", torch.int64)
     layer_bwd = _dev(layer_bwd, "layer ids", torch.int64)
@@ -313,11 +419,9 @@ def build_plan(edge_index: torch.Tensor, layer_fwd: torch.Tensor, layer_bwd: tor
         edge_attr = _dev(edge_attr, "edge_attr", torch.float32).view(E, -1)
         R = edge_attr.shape[1]
     plan = PlanHandle(N, E, num_graphs, R, edge_index.device)
-    with _span("plan_build", edge_index):
-        check(_lib.load().dagnn_plan_build(C.byref(plan.desc), edge_index.data_ptr(), layer_fwd.data_ptr(),
-                                           layer_bwd.data_ptr(), batch.data_ptr(), _ptr(edge_attr),
-                                           plan.status.data_ptr(), _stream(edge_index)), "dagnn_plan_build")
     plan._keep = (edge_index, layer_fwd, layer_bwd, batch, edge_attr)
+    if launch:
+        plan.launch_build()
     return plan
 
 

@@ -243,6 +243,79 @@ class DAGNN(nn.Module):
 
         return self._derived.setdefault(self.schedule, DerivedCache()).get(srcs, make, fresh=fresh or self.training)
 
+    def _folded_tables(self, cells):
+        """Input side of stacked layer 0 by constant folding (evaluation only).  The node embedding is a sum of three table
+        rows (utils.py:26-28) and nothing non-linear sits between it and `GRUCell`'s `W_ih x + b_ih` (dagnn.py:139,148,181), so
+        `W_ih x_v + b_ih = (T W_ih^T)[type_v] + (A W_ih^T)[attr_v] + (D W_ih^T + b_ih)[depth_v]`: the three products depend on
+        the PARAMETERS only and are made once per weight version (kept on the derived cell, like the packed matrices); per batch the
+        [N, emb] x [emb, 3H] GEMM of every direction becomes the encoder's own row kernel on the folded tables.  Per
+        direction (type, attribute, depth) tables of width 3Hp, or None where it does not apply (other encoders, odd widths;
+        training passes never ask)."""
+        if not engine.FOLD_INPUT or type(self.encoder) is not ASTNodeEncoder or self.schedule != "lockstep" or self.agg_x:
+            return None
+        enc = self.encoder
+        tabs = [enc.type_encoder.weight, enc.attribute_encoder.weight, enc.depth_encoder.weight]
+        if tabs[0].shape[1] % 4 or not tabs[0].is_cuda:
+            return None
+        key = tuple((p.data_ptr(), p._version) for p in tabs)
+        out = []
+        with torch.no_grad():
+            for d in self.dirs:
+                c = cells[(d, 0)]   # (the folded tables live and die with the derived cell: same invalidation rules, same width)
+                if c.fold is None or c.fold[0] != key:
+                    t, a, dp = (engine.gemm_nt_bias([tab.detach()], [c.w_ih], [b])[0]
+                                for tab, b in zip(tabs, (None, None, c.b_ih)))   # (every node takes exactly one depth row: the bias rides on it)
+                    c.fold = (key, (t, a, dp))
+                out.append(c.fold[1])
+        return out
+
+    @staticmethod
+    def _rows_ok(x_idx, depth) -> bool:
+        return bool(x_idx.is_cuda and x_idx.dtype == torch.int64 and x_idx.dim() == 2 and x_idx.shape[1] == 2
+                    and x_idx.is_contiguous() and depth.is_cuda and depth.dtype == torch.int64 and depth.is_contiguous())
+
+    def _folded_gi0(self, x_idx, depth, cells):
+        """gi0 of every direction from the folded tables (`_folded_tables`), or None."""
+        if not self._rows_ok(x_idx, depth):
+            return None
+        folded = self._folded_tables(cells)
+        if folded is None:
+            return None
+        return [engine.encode_ast(x_idx, depth, t, a, dp, self.encoder.max_depth) for (t, a, dp) in folded]
+
+    def _prepare_fused(self, G, B, cells):
+        """Evaluation passes: plan + dataflow schedule + encoder rows (+ folded gi0 rows) + side effect 1 as ONE pipeline of 7
+        launches (`dagnn_prepare`, csrc/prepare.hip).  Returns (plan, gi0 or None) with `G.x` / `G.bi_layer_index` set, or None
+        where the pipeline does not apply (the caller then takes the separate calls)."""
+        if not engine.PREPARE_FUSED or self.schedule != "lockstep" or type(self.encoder) is not ASTNodeEncoder or \
+                getattr(G, "_dagnn_plan", None) is not None:
+            return None
+        x_idx, depth = G.x, G.node_depth.view(-1, )
+        enc = self.encoder
+        if not (self._rows_ok(x_idx, depth) and enc.type_encoder.weight.shape[1] % 4 == 0 and G.edge_index.is_cuda):
+            return None
+        has_edge_enc = getattr(self.node_aggr_0[0], "wea", False)
+        ea = G.edge_attr if has_edge_enc else None
+        dev, N = x_idx.device, x_idx.shape[0]
+        R = 0 if ea is None else int(ea.numel() // max(1, G.edge_index.shape[1]))
+        wide_ok = has_edge_enc and not (self.agg_x or self.agg_attn_x)
+        Hp = engine.state_width(self.hidden_dim, self.num_layers, R, wide_ok=wide_ok)
+        groups = engine.dataflow_groups(dev, len(self.dirs), self.num_layers, Hp, B, training=False)
+        tables = [(enc.type_encoder.weight, enc.attribute_encoder.weight, enc.depth_encoder.weight,
+                   torch.empty(N, enc.type_encoder.weight.shape[1], dtype=torch.float32, device=dev))]
+        folded = self._folded_tables(cells)
+        gi0 = None
+        if folded is not None:
+            gi0 = [torch.empty(N, t.shape[1], dtype=torch.float32, device=dev) for (t, _, _) in folded]
+            tables += [(t, a, dp, o) for (t, a, dp), o in zip(folded, gi0)]
+        srcs = [G._bi_layer_idx0, G._bi_layer_index0, G._bi_layer_idx1, G._bi_layer_index1]
+        lidx = torch.empty(4, N, dtype=torch.int64, device=dev)
+        plan = engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B, ea, launch=False)
+        plan.launch_prepare(groups, enc=(x_idx, depth, enc.max_depth, tables), stack=(srcs, lidx))
+        G.bi_layer_index = lidx.view(2, 2, -1)   # side effect 1 (dagnn.py:130-133)
+        G.x = tables[0][3]                       # side effects 2 + 3 (dagnn.py:139, utils.py:27)
+        return plan, gi0
+
     def check(self) -> None:
         """Blocking check for device-side failures of every pass launched so far (`core.check_arenas`): call it where
         the outputs of the LAST forward of a loop are consumed - the non-blocking poll inside `forward` only reports
@@ -355,31 +428,52 @@ class DAGNN(nn.Module):
         has_edge_enc = getattr(self.node_aggr_0[0], "wea", False)
         if getattr(G, "_dagnn_plan", None) is not None:  # built by the loader (dagnn_amd.host_plan.attach_plan)
             if has_edge_enc or int(G._dagnn_plan_meta.get("R", 0)) == 0:
+                if overlap:
+                    self._set_layer_index(G)
                 return engine.PlanHandle.from_words(G._dagnn_plan, G._dagnn_plan_meta, getattr(G, "_dagnn_df", None))
             # the loader packed edge features this model has no encoder for (w_edge_attr=False): the kernels would
             # want an edge gain per feature - build the plan without them here instead
         ea = G.edge_attr if has_edge_enc else None
-        if not (overlap and engine.PLAN_OVERLAP and G.edge_index.is_cuda):
+        if not (overlap and engine.PLAN_OVERLAP and G.edge_index.is_cuda and self.schedule == "lockstep"):
+            if overlap:
+                self._set_layer_index(G)
             return engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B, ea)
         dev = G.edge_index.device
         cur = torch.cuda.current_stream(dev)
         side = self._arena_for(G.edge_index).side_stream(dev)
+        # the same (width, group count) key `run_stack_lockstep` will ask for: hidden sizes 257..320 run 320 wide on the
+        # dataflow kernel (`wide_ok`), a training pass under an active communicator reserves CUs for the collective
+        R = 0 if ea is None else int(ea.numel() // max(1, G.edge_index.shape[1]))
+        wide_ok = has_edge_enc and not (self.agg_x or self.agg_attn_x)
+        Hp = engine.state_width(self.hidden_dim, self.num_layers, R, wide_ok=wide_ok)
+        groups = engine.dataflow_groups(dev, len(self.dirs), self.num_layers, Hp, B, training=self._training_pass()) \
+            if self.schedule == "lockstep" else 0
+        # every buffer comes from the CALLER's pool and is initialised on the caller's stream; only the library's launches
+        # go to the side stream, which forks here and joins at `plan.wait_ready()`
+        plan = engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B, ea, launch=False)
+        sched_ws = plan.dataflow_schedule(groups, launch=False) if groups > 0 else None
+        lidx = torch.empty(4, G._bi_layer_idx0.shape[0], dtype=G._bi_layer_idx0.dtype, device=dev)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            plan = engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B, ea)
-            # the same (width, group count) key `run_stack_lockstep` will ask for: hidden sizes 257..320 run 320 wide on the
-            # dataflow kernel (`wide_ok`), a training pass under an active communicator reserves CUs for the collective
-            wide_ok = has_edge_enc and not (self.agg_x or self.agg_attn_x)
-            Hp = engine.state_width(self.hidden_dim, self.num_layers, plan.R, wide_ok=wide_ok)
-            groups = engine.dataflow_groups(dev, len(self.dirs), self.num_layers, Hp, B, training=self._training_pass()) \
-                if self.schedule == "lockstep" else 0
-            if groups > 0:
+        with engine.launch_on(side):
+            plan.launch_build()
+            if sched_ws is not None:
                 plan.dataflow_schedule(groups)
-            plan.ready = torch.cuda.Event()
-            plan.ready.record(side)
-        for t in (plan.ws, plan.status) + tuple(plan.__dict__.get("_df", {}).values()):
-            t.record_stream(cur)   # allocated on the side stream, used on the caller's from here on
+        plan.ready = torch.cuda.Event()
+        plan.ready.record(side)
+        # side effect 1 BEHIND the plan on the side stream: nothing in forward() reads it, so it runs under the recurrence (beside
+        # the GEMM it would sit on the critical path at a third of its speed: an fp32 MFMA holds its SIMD's issue port); the
+        # caller's stream meets it at the end of forward() (`plan.wait_after`)
+        with torch.cuda.stream(side):   # (allocates nothing: `out=` comes from the caller's pool)
+            self._set_layer_index(G, out=lidx)
+        plan.after = torch.cuda.Event()
+        plan.after.record(side)
         return plan
+
+    @staticmethod
+    def _set_layer_index(G, out=None):
+        """side effect 1 (dagnn.py:130-133): `G.bi_layer_index` [2, 2, N] (one copy kernel instead of three)"""
+        srcs = [G._bi_layer_idx0, G._bi_layer_index0, G._bi_layer_idx1, G._bi_layer_index1]
+        G.bi_layer_index = (torch.stack(srcs, dim=0) if out is None else torch.stack(srcs, dim=0, out=out)).view(2, 2, -1)
 
     # ------------------------------------------------------------------------------ forward
     def forward(self, G):
@@ -415,13 +509,23 @@ class DAGNN(nn.Module):
             return self._finish(G, plan, G.x, variants.run_hip(self, G, G.x, plan), B)
         train = self._training_pass()
 
-        # side effect 1 (dagnn.py:130-133)
-        G.bi_layer_index = torch.stack([G._bi_layer_idx0, G._bi_layer_index0, G._bi_layer_idx1, G._bi_layer_index1],
-                                        dim=0).view(2, 2, -1)   # (one copy kernel instead of three)
         B = num_graphs_of(G)
-        plan = self._plan_of(G, B, overlap=True)   # (optionally on a side stream, next to the encoder and the input GEMM)
+        if not train:
+            cells = self._cells()
+            fused = self._prepare_fused(G, B, cells)   # (plan + schedule + encoder + side effect 1: one pipeline, csrc/prepare.hip)
+            if fused is not None:
+                plan, gi0 = fused
+                x = G.x
+                sscore = self._static_scores(x, cells)
+                h = run_stack(plan, x, cells, dirs, L, H, schedule=self.schedule, static_score=sscore,
+                              arena=self._arena_for(x), gi0=gi0)
+                return self._finish(G, plan, x, h, B)
+        # side effect 1 (dagnn.py:130-133) + the plan: on a side stream next to the encoder and the input GEMM, which do not
+        # depend on them (`engine.PLAN_OVERLAP`); the caller's stream meets it again in front of the recurrence
+        plan = self._plan_of(G, B, overlap=True)
         # side effects 2+3 (dagnn.py:139, utils.py:27): embedding replaces G.x, depth clamped in place
-        G.x = self.encoder(G.x, G.node_depth.view(-1, ))
+        x_idx, depth = G.x, G.node_depth.view(-1, )
+        G.x = self.encoder(x_idx, depth)
         x = G.x
         fused_readout = self.bidirectional and not self.output_all and self.out_pool == K.P_MAX
         if train:
@@ -430,6 +534,7 @@ class DAGNN(nn.Module):
             # (scripts/ogb_tok.sh), otherwise differentiable states and the torch read-outs below
             from .autograd import Recurrence
             res = Recurrence.apply(self, plan, B, fused_readout, x, *self._train_params())
+            plan.wait_after()
             flat = res[1:] if fused_readout else res
             h = [[None] * L for _ in range(2)]
             for q, d in enumerate(dirs):
@@ -442,7 +547,8 @@ class DAGNN(nn.Module):
         cells = self._cells()
         sscore = self._static_scores(x, cells)
         h = run_stack(plan, x, cells, dirs, L, H, schedule=self.schedule, static_score=sscore,
-                      arena=self._arena_for(x))
+                      arena=self._arena_for(x), gi0=self._folded_gi0(x_idx, depth, cells))
+        plan.wait_after()
         return self._finish(G, plan, x, h, B)
 
     def _heads(self, out):

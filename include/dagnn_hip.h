@@ -97,6 +97,38 @@ int dagnn_encode_ast(const int64_t* x, int64_t* depth, const float* type_emb, co
                      int64_t N, int H, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Everything in front of the recurrence as ONE fused pipeline of 7 launches (instead of 13 + the encoder's): the plan
+ * (dagnn_plan_build: dagnn.py:146-157), the dataflow schedule (dagnn_dataflow_schedule, groups > 0) and - riding on the
+ * plan's longest kernel, which is latency-bound - the HBM-bound row work of forward() that does not depend on the plan:
+ * the node encoder (utils.py:26-28, dagnn.py:139), up to three table sets at once (the embedding itself and, for an
+ * evaluation pass, the tables folded through W_ih of stacked layer 0 of every direction: gi0 = (T W_ih^T)[type] +
+ * (A W_ih^T)[attr] + (D W_ih^T + b_ih)[depth]), and side effect 1 (dagnn.py:130-133: four [N] index arrays stacked).
+ * Launches: pointers | per-graph sorts + rows | batch-level layers + work items + LPT assignment + workspace fill |
+ * first slots + group-layer counts | row records (+ seal) + group prefixes | group-layer bases | schedule records.
+ * Same plan / schedule words as the separate calls (tests compare them); small batches (dagnn_plan_is_small) and empty
+ * ones take the separate calls internally.
+ * ---------------------------------------------------------------------------------------- */
+#define DAGNN_PREPARE_MAX_TABLES 3
+typedef struct dagnn_prepare_rows {
+    const int64_t* x;            /* [N,2] (type, attribute) indices; NULL: no encoder rows */
+    int64_t* depth;              /* [N], clamped IN PLACE to max_depth (utils.py:27) */
+    int max_depth;
+    int num_tables;              /* 1..DAGNN_PREPARE_MAX_TABLES */
+    struct {
+        const float *type_emb, *attr_emb, *depth_emb;   /* [*, width] each */
+        float* out;                                     /* [N, ld_out]: (type + attr) + depth rows */
+        int width, ld_out;                              /* multiples of 4 */
+    } table[DAGNN_PREPARE_MAX_TABLES];
+    const int64_t* stack_src[4]; /* four [N] arrays ... */
+    int64_t* stack_out;          /* ... copied to [4, N]; NULL: none */
+} dagnn_prepare_rows;
+
+int dagnn_prepare(const dagnn_plan* plan, const int64_t* edge_index, const int64_t* layer_fwd, const int64_t* layer_bwd,
+                  const int64_t* batch, const float* edge_attr, int32_t* status,
+                  void* schedule, size_t schedule_bytes, int groups, int cost_layer, int cost_row,   /* groups = 0: no schedule */
+                  const dagnn_prepare_rows* rows /* or NULL */, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Input-side GRU GEMMs, batched over all nodes (the W_i* x + b_i* half of nn.GRUCell,
  * dagnn.py:181; independent of the recurrence, so done once per layer on the MFMA units):
  *   for g < num_groups:  C_g[M,Nc] = A_g[M,K] * W_g[Nc,K]^T + bias_g[Nc]

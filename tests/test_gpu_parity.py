@@ -122,10 +122,15 @@ def test_plan_flags_contract_violations(device, monkeypatch, small):
     ungrouped = torch.cat([b.edge_index[:, -1:], b.edge_index[:, :-1]], 1)   # the last graph's edge first
     deep = b._bi_layer_idx0.clone()
     deep[0] = N   # a layer id >= nodes of its graph
+    seen = set()
     cases = [(b.edge_index, b._bi_layer_idx0, bad_batch, "not sorted"), (crossing, b._bi_layer_idx0, b.batch, "crosses"),
              (ungrouped, b._bi_layer_idx0, b.batch, "not grouped"), (b.edge_index, deep, b.batch, "layer id")]
-    for ei, l0, bt, what in cases:
-        plan = engine.build_plan(dev(ei), dev(l0), dev(b._bi_layer_idx1), dev(bt), 4, None)
+    for ei, l0, bt, what in cases * 2:
+        fused = what in seen   # second round: the same batches through the fused pipeline (csrc/prepare.hip)
+        seen.add(what)
+        plan = engine.build_plan(dev(ei), dev(l0), dev(b._bi_layer_idx1), dev(bt), 4, None, launch=not fused)
+        if fused:
+            plan.launch_prepare(2)
         torch.cuda.synchronize()
         with pytest.raises(DagnnHipError, match=what):
             plan.check_status()
@@ -319,6 +324,39 @@ def test_headline_batch_matches_oracle(device, schedule):
     with torch.no_grad():
         out = model(G)
     assert max(Hh.maxdiff(o, r) for o, r in zip(out, ref)) < TOL
+
+
+def test_folded_input_tables_and_side_stream_plan_agree_with_the_plain_path(device, monkeypatch):
+    """Evaluation passes fold the three embedding tables through `W_ih` of stacked layer 0 (model._folded_gi0: gi0 = three
+    folded rows summed per node instead of the [N, emb] x [emb, 3H] GEMM) and build plan + schedule on a side stream next to
+    the encoder (`engine.PLAN_OVERLAP`): both against the in-line GEMM path on the headline batch - the logits agree to
+    rounding (another summation order of the same products), and the folded tables follow a parameter update."""
+    model = _headline_model().to(device)
+    b = synth.code2_batch(0, 128)
+    outs = {}
+    for fold, overlap in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        monkeypatch.setattr(engine, "FOLD_INPUT", fold)
+        monkeypatch.setattr(engine, "PLAN_OVERLAP", overlap)
+        with torch.no_grad():
+            G = b.clone().to(device)
+            outs[(fold, overlap)] = [o.clone() for o in model(G)]
+            assert G.bi_layer_index.shape == (2, 2, b.x.shape[0])
+            assert torch.equal(G.bi_layer_index[1][1].cpu(), b._bi_layer_index1)   # (side effect 1, made on the side stream)
+    model.check()
+    base = outs[(0, 0)]
+    assert max(Hh.maxdiff(a, c) for a, c in zip(outs[(0, 1)], base)) == 0.0      # the same kernels on another stream: bitwise
+    assert max(Hh.maxdiff(a, c) for a, c in zip(outs[(1, 1)], outs[(1, 0)])) == 0.0
+    assert max(Hh.maxdiff(a, c) for a, c in zip(outs[(1, 0)], base)) < 2e-5
+    # a parameter update (version counter bumped) reaches the folded tables
+    monkeypatch.setattr(engine, "FOLD_INPUT", 1)
+    with torch.no_grad():
+        model.encoder.depth_encoder.weight.mul_(1.5)
+        model.cells_0[0].bias_ih.add_(0.25)
+        folded = [o.clone() for o in model(b.clone().to(device))]
+        monkeypatch.setattr(engine, "FOLD_INPUT", 0)
+        plain = [o.clone() for o in model(b.clone().to(device))]
+    assert max(Hh.maxdiff(a, c) for a, c in zip(folded, plain)) < 2e-5
+    assert max(Hh.maxdiff(a, c) for a, c in zip(plain, base)) > 1e-3
 
 
 def test_bn_config_full_batch_matches_oracle(device, schedule):
@@ -798,6 +836,55 @@ def test_host_plan_equals_device_plan_word_for_word(device, monkeypatch, seed, B
     assert np.array_equal(ws[written], dev_words[written])
     for d in (0, 1):
         assert np.array_equal(sched[d], plan.read_schedule()[d])
+
+
+@pytest.mark.parametrize("seed,B,mean_n,G", [(2, 17, 60, 5), (0, 128, 125, 10), (5, 1, 12, 1), (7, 64, 14, 21), (8, 300, 20, 8),
+                                             (12, 2, 900, 2), (13, 1, 1500, 1), (-1, 6, 0, 3), (0, 128, 125, 0)])
+@pytest.mark.parametrize("small", [1, 0])
+def test_fused_prepare_equals_the_separate_calls_word_for_word(device, monkeypatch, seed, B, mean_n, G, small):
+    """`dagnn_prepare` (csrc/prepare.hip: plan + schedule + encoder rows + index stack in 7 launches, several device bodies per
+    launch) against `dagnn_plan_build` + `dagnn_dataflow_schedule` + `dagnn_encode_ast`: both workspaces start from the same
+    fill pattern, so EVERY word - scratch included - must come out the same; the rows bit for bit."""
+    monkeypatch.setattr(engine, "PLAN_SMALL", small)
+    b = _degenerate_batch() if seed < 0 else synth.code2_batch(seed, B, mean_n)
+    N = b.x.shape[0]
+    dev = lambda t: t.to(device)   # noqa: E731
+    args = (dev(b.edge_index), dev(b._bi_layer_idx0), dev(b._bi_layer_idx1), dev(b.batch), B, dev(b.edge_attr))
+    gen = torch.Generator().manual_seed(3)
+    tabs = [[dev(torch.randn(r, w, generator=gen)) for r in (98, 10030, 21)] for w in (64, 192)]
+    x = dev(torch.stack([torch.randint(0, 98, (N,), generator=gen), torch.randint(0, 10030, (N,), generator=gen)], 1))
+    depth0 = torch.randint(0, 40, (N,), generator=gen)
+    srcs = [dev(t) for t in (b._bi_layer_idx0, b._bi_layer_index0, b._bi_layer_idx1, b._bi_layer_index1)]
+
+    def words(plan, fused):
+        plan.ws.fill_(-7)
+        sched = None
+        if G > 0:
+            sched = plan.dataflow_schedule(G, launch=False)
+            sched.fill_(-7)
+        depth = dev(depth0.clone())
+        if fused:
+            outs = [torch.empty(N, w, device=device) for w in (64, 192)]
+            stack = torch.empty(4, N, dtype=torch.int64, device=device)
+            plan.launch_prepare(G, enc=(x, depth, 20, [(t[0], t[1], t[2], o) for t, o in zip(tabs, outs)]), stack=(srcs, stack))
+        else:
+            plan.launch_build()
+            if G > 0:
+                plan.dataflow_schedule(G)
+            outs = [engine.encode_ast(x, depth, t[0], t[1], t[2], 20) for t in tabs]
+            stack = torch.stack(srcs, 0)
+        torch.cuda.synchronize()
+        assert int(plan.status[0]) == 0
+        return plan.ws.cpu().numpy(), None if sched is None else plan.dataflow_schedule(G).cpu().numpy(), outs, stack, depth
+
+    ref = words(engine.build_plan(*args, launch=False), False)
+    got = words(engine.build_plan(*args, launch=False), True)
+    assert np.array_equal(ref[0], got[0])
+    if G > 0:
+        assert np.array_equal(ref[1], got[1])
+    for a, c in zip(ref[2], got[2]):
+        assert torch.equal(a, c)
+    assert torch.equal(ref[3], got[3]) and torch.equal(ref[4], got[4]) and int(got[4].max()) <= 20
 
 
 def _schedule_words_equal(host, dev, lay, G, whole):

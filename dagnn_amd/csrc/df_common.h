@@ -74,43 +74,22 @@ __device__ __forceinline__ unsigned df_wave_umin(unsigned v) {
 }
 
 // Graphs in order of decreasing depth (plan items), each to the group whose load it raises the least; load_k = c_layer *
-// (depth of the first = deepest graph of k) + c_row * (nodes of k).  Called by the 64 lanes of ONE wave (threadIdx.x < 64);
-// writes grp_of / gdepth / gload / loff and the header words of the schedule workspace `ws`.  s_g / s_d / s_n: LDS staging
-// of CAP words each.  The plan's tables (items [2B], depth of either direction [B], node_ptr [B + 1]) come as pointers:
-// global memory for df_assign_kernel (dataflow.hip), LDS copies for the one-workgroup build of small batches (small.hip).
-template <int CAP>
-__device__ __forceinline__ void df_assign_wave(const int32_t* items, const int32_t* depth0, const int32_t* depth1,
-                                               const int32_t* node_ptr, int32_t* ws, const DfLayout& S,
-                                               int B, int G, int c_layer, int c_row, int32_t* s_g, int32_t* s_d, int32_t* s_n) {
-    const bool staged = B <= CAP;
+// (depth of the first = deepest graph of k) + c_row * (nodes of k); writes grp_of / gdepth / gload / loff and the header
+// words of the schedule workspace `ws`.
+// The chain itself: `count` graphs staged in schedule order in s_g / s_d / s_n (graph, max depth of the two directions, nodes)
+// when `staged`, else read through `items` (B > CAP).  The 64 lanes of ONE wave; `n_total` = nodes of the batch.
+__device__ __forceinline__ void df_assign_chain(const int32_t* items, const int32_t* depth0, const int32_t* depth1,
+                                                const int32_t* node_ptr, int32_t* ws, const DfLayout& S,
+                                                int B, int G, int c_layer, int c_row, const int32_t* s_g, const int32_t* s_d, const int32_t* s_n,
+                                                const bool staged, const int count, const long long n_total) {
     const int lane = threadIdx.x;
-    // compact the direction-0 entries in order (wave-level prefix over 64 entries at a time)
-    int count = 0;
-    if (staged) {
-        for (int j0 = 0; j0 < 2 * B; j0 += 64) {
-            const int j = j0 + lane;
-            const int it = j < 2 * B ? items[j] : 1;
-            const bool keep = !(it & 1);
-            const unsigned long long m = __ballot(keep);
-            if (keep) {
-                const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-                const int g = it >> 1;
-                s_g[pos] = g;
-                s_d[pos] = max(depth0[g], depth1[g]);
-                s_n[pos] = node_ptr[g + 1] - node_ptr[g];
-            }
-            count += __popcll(m);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
     long long load = 0;
     int depth = 0;
     bool empty = true;
     const int steps = staged ? count : 2 * B;
     // fast form of the B-step chain when (cost << 6 | group) fits 32 bits: ONE wave minimum per graph gives the least
     // load and, through the low bits, the lowest group that has it (38 -> 17 us at B = 128)
-    const long long bound = (long long)c_row * node_ptr[B] + (long long)c_layer * (staged && count > 0 ? s_d[0] : 0);
+    const long long bound = (long long)c_row * n_total + (long long)c_layer * (staged && count > 0 ? s_d[0] : 0);
     // every graph has the same node count (the D-VAE batches: dvae/dagnn.py:150-158 hard-codes that stride): no B-step chain -
     // the depth-sorted graphs are dealt round-robin (graph j of the order -> group j mod G), all lanes at once
     bool uniform = staged && count > 0;
@@ -180,6 +159,38 @@ __device__ __forceinline__ void df_assign_wave(const int32_t* items, const int32
     if (lane < G) ws[S.loff + lane] = x - own;
     if (lane == G - 1) ws[S.loff + G] = x;
     if (lane == 0) { ws[0] = G; ws[1] = DF_MAGIC; ws[2] = DF_RB; }
+}
+
+// Staging + chain, called by the 64 lanes of ONE wave (threadIdx.x < 64).  s_g / s_d / s_n: LDS staging of CAP words each.
+// The plan's tables (items [2B], depth of either direction [B], node_ptr [B + 1]) come as pointers: global memory for
+// df_assign_kernel (dataflow.hip), LDS copies for the one-workgroup build of small batches (small.hip).
+template <int CAP>
+__device__ __forceinline__ void df_assign_wave(const int32_t* items, const int32_t* depth0, const int32_t* depth1,
+                                               const int32_t* node_ptr, int32_t* ws, const DfLayout& S,
+                                               int B, int G, int c_layer, int c_row, int32_t* s_g, int32_t* s_d, int32_t* s_n) {
+    const bool staged = B <= CAP;
+    const int lane = threadIdx.x;
+    // compact the direction-0 entries in order (wave-level prefix over 64 entries at a time)
+    int count = 0;
+    if (staged) {
+        for (int j0 = 0; j0 < 2 * B; j0 += 64) {
+            const int j = j0 + lane;
+            const int it = j < 2 * B ? items[j] : 1;
+            const bool keep = !(it & 1);
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                const int g = it >> 1;
+                s_g[pos] = g;
+                s_d[pos] = max(depth0[g], depth1[g]);
+                s_n[pos] = node_ptr[g + 1] - node_ptr[g];
+            }
+            count += __popcll(m);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    df_assign_chain(items, depth0, depth1, node_ptr, ws, S, B, G, c_layer, c_row, s_g, s_d, s_n, staged, count, (long long)node_ptr[B]);
 }
 
 }  // namespace

@@ -11,6 +11,9 @@ namespace {
 
 constexpr int PB = 256;  // threads per plan workgroup
 constexpr int PLAN_NMAX = 2048;  // graphs up to this many nodes are planned in LDS
+constexpr int PLAN_FAST_N = 4 * PB, PLAN_FAST_E = 8 * PB;   // ... and those up to this many nodes and edges (<= 2 edge features) on the FAST form of plan_graph_impl
+constexpr int PLAN_GRAPH_LDS = 4 * (PLAN_FAST_N + 1) + 8 * (PLAN_FAST_N + 1);   // words: its four arrays + the key masks (> 4 (PLAN_NMAX + 1))
+static_assert(PLAN_GRAPH_LDS >= 4 * (PLAN_NMAX + 1) && (4 * (PLAN_FAST_N + 1)) % 4 == 0, "LDS layout of plan_graph_body");
 
 // node_ptr / edge_ptr + contract checks; thread i of max(N + 2, E, B + 1).
 // node_ptr[k] = first node whose graph id is >= k, edge_ptr[k] = first edge whose SOURCE node belongs to a graph >= k: the
@@ -84,18 +87,21 @@ __device__ void block_scan_inplace(int32_t* a, int n, int base, int32_t* lds /* 
 // waves take turns on the cursors so that the order across waves is the thread order.
 __device__ __forceinline__ int chunk_place(int key, int32_t* cur) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long lt = (1ull << lane) - 1ull;
     int rank = 0, count = 0;
     bool last = false;
+    // one trip per distinct key of the wave, everything wave-uniform but the three results: the leader's key by v_readlane
+    // (lane index in an SGPR - `__shfl` with a lane it cannot prove uniform is a ds_bpermute, ~100 cycles on the loop's
+    // dependent chain: 5-6 us per chunk of mostly distinct keys, 40 of plan_graph's 49 us on the headline batch), members
+    // by one compare, the rank by v_mbcnt
     unsigned long long todo = __ballot(key >= 0);
     while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int k = __shfl(key, leader, 64);
+        const int leader = __builtin_ctzll(todo);
+        const int k = __builtin_amdgcn_readlane(key, leader);
         const unsigned long long m = __ballot(key == k);
         if (key == k) {
-            rank = __popcll(m & lt);
+            rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
             count = __popcll(m);
-            last = (m >> lane) == 1ull;  // highest lane holding this key
+            last = lane == 63 - __builtin_clzll(m);  // highest lane holding this key
         }
         todo &= ~m;
     }
@@ -117,6 +123,219 @@ __device__ __forceinline__ int chunk_place(int key, int32_t* cur) {
 // node they feed (rows of the CSR, original edge order kept inside a row so that the softmax /
 // weighted sum adds in the same order as the reference's scan produces).  Everything is int32;
 // the int64 inputs are narrowed on the way in.
+// FAST (graphs of <= 4 PB nodes and <= 8 PB edges, <= 2 edge features: every AST of ogbg-code2 but a handful): the workgroup
+// reads ALL its inputs in one go - four layer ids and eight (feeding node, other node, features) per thread, held in registers -
+// and its ~15 dependent passes then touch LDS only; the general form re-reads them pass by pass (a round trip to memory in
+// five of the passes, two more per chunk of edges: 49 us for the 657-node graph of the headline batch, 2/3 of it waiting).
+// The same placement for a FAST graph (keys < 4 PB), without the trip per distinct key: every lane ORs its bit into the
+// 256-bit mask of its key (one 64-bit word per wave: four waves, no conflict, no order), a barrier later the four words of
+// a key ARE the ballot of the whole chunk - rank = set bits below this thread, the highest set bit advances the cursor and
+// clears the words.  Three barriers and three LDS round trips per chunk whatever the keys (the loop above: ~100 ns per
+// distinct key, and an AST's 64 consecutive nodes / edges have ~64 distinct keys: 4-6 us per chunk, 31 of plan_graph's 37 us
+// on the headline batch's largest graph).  `masks`: [keys][4] words, zero on entry and on exit.
+__device__ __forceinline__ int chunk_place_masks(int key, int32_t* cur, unsigned long long* masks) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (key >= 0) atomicOr(&masks[key * 4 + wave], 1ull << lane);
+    __syncthreads();
+    int slot = -1, count = 0;
+    bool last = false;
+    if (key >= 0) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(masks + key * 4), b = *reinterpret_cast<const ulonglong2*>(masks + key * 4 + 2);
+        const unsigned long long m[4] = {a.x, a.y, b.x, b.y};
+        int before = 0, hw = 0;
+        unsigned long long mine = 0ull, top = 0ull;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int c = __popcll(m[w]);
+            if (w < wave) before += c;
+            if (w == wave) mine = m[w];
+            if (m[w]) { hw = w; top = m[w]; }
+            count += c;
+        }
+        const int rank = before + __popcll(mine & ((1ull << lane) - 1ull));
+        last = wave == hw && lane == 63 - __builtin_clzll(top);
+        slot = cur[key] + rank;
+    }
+    __syncthreads();   // every thread has read its cursor and its masks
+    if (last) {
+        cur[key] += count;
+        *reinterpret_cast<ulonglong2*>(masks + key * 4) = make_ulonglong2(0ull, 0ull);
+        *reinterpret_cast<ulonglong2*>(masks + key * 4 + 2) = make_ulonglong2(0ull, 0ull);
+    }
+    __syncthreads();
+    return slot;
+}
+
+#ifdef PG_STAMPS
+#define PG_STAMP(k) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    plan[L.cursor[d] + n0 + g + (k)] = (int)(t_ & 0x7fffffff); } } while (0)
+#else
+#define PG_STAMP(k)
+#endif
+template <bool FAST, bool SMALL>
+__device__ __forceinline__ void plan_graph_impl(int32_t* plan, const PlanLayout& L, const int64_t* __restrict__ edge_index,
+                                                const int64_t* __restrict__ layer, const float* __restrict__ edge_attr,
+                                                int R, int64_t E, int32_t* status, const int g, const int d,
+                                                const int n0, const int n1, const int e0, const int e1,
+                                                int32_t* lds, int32_t* s_depth, int32_t* small_ws) {
+    constexpr int NC = PLAN_FAST_N / PB, NCE = PLAN_FAST_E / PB;   // chunks of PB nodes / edges a FAST graph has at most
+    const int tid = threadIdx.x;
+    const int n = n1 - n0;
+    // SMALL is a template parameter, not a run-time choice: a pointer SELECTED between LDS and global memory is a generic
+    // pointer, and every access through it a flat_load / flat_store / flat_atomic at a vector-memory round trip each - the four
+    // cursor turns of chunk_place alone were 5 us per chunk, 40 of this kernel's 49 us on the headline batch
+    constexpr bool small = SMALL;
+    int32_t* ls_g = plan + L.lstart[d] + n0 + g;   // n+1 words (final home)
+    int32_t* rp_g = plan + L.rowptr[d] + n0 + g;   // n+1 words (final home)
+    int32_t *ls, *rp, *cur, *pos;
+    constexpr int SN = FAST ? PLAN_FAST_N : PLAN_NMAX;   // nodes the LDS arrays are laid out for
+    unsigned long long* masks = nullptr;
+    if constexpr (SMALL) {
+        ls = small_ws; rp = small_ws + (SN + 1); cur = small_ws + 2 * (SN + 1);
+        pos = small_ws + 3 * (SN + 1) - n0;   // indexed by node id
+        if constexpr (FAST) {
+            masks = reinterpret_cast<unsigned long long*>(small_ws + 4 * (SN + 1));   // (a multiple of 16 bytes in)
+            for (int i = tid; i < 4 * (n + 1); i += PB) masks[i] = 0ull;           // (the first barrier below is long before their first use)
+        }
+    } else {
+        ls = ls_g; rp = rp_g; cur = plan + L.cursor[d] + n0 + g;  // n+1 words
+        pos = plan + L.pos[d];                                    // indexed by node id
+    }
+    int32_t* order = plan + L.order[d];
+    int32_t* col = plan + L.col[d];
+    int32_t* eidx = plan + L.eidx[d];
+    float* eattr = reinterpret_cast<float*>(plan + L.eattr[d]);
+    // the node an edge feeds is its target (d=0) or its source (d=1)
+    const int64_t* feed = d == 0 ? edge_index + E : edge_index;
+    const int64_t* other = d == 0 ? edge_index : edge_index + E;
+    const int nchunk_n = FAST ? NC : (n + PB - 1) / PB, nchunk_e = FAST ? NCE : (e1 - e0 + PB - 1) / PB;
+
+    // ---- FAST: everything this workgroup will ever read, in one trip
+    int lreg[NC], freg[NCE], oreg[NCE];   // (narrowed on the way in: values outside int32 are out of range anyway)
+    float areg[NCE][2];
+    if constexpr (FAST) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int v = n0 + c * PB + tid;
+            const int64_t l = v < n1 ? layer[v] : 0;
+            lreg[c] = l < 0 ? -1 : l > 0x7fffffff ? 0x7fffffff : (int)l;
+        }
+#pragma unroll
+        for (int c = 0; c < NCE; ++c) {
+            const int e = e0 + c * PB + tid;
+            const int64_t f = e < e1 ? feed[e] : -1, o = e < e1 ? other[e] : -1;
+            freg[c] = (f < 0 || f > 0x7fffffff) ? -1 : (int)f;
+            oreg[c] = (o < 0 || o > 0x7fffffff) ? -1 : (int)o;
+            areg[c][0] = (e < e1 && R >= 1) ? edge_attr[(int64_t)e * R] : 0.f;
+            areg[c][1] = (e < e1 && R >= 2) ? edge_attr[(int64_t)e * R + 1] : 0.f;
+        }
+    }
+    auto layer_of = [&](int c, int v) -> int64_t { if constexpr (FAST) return lreg[c]; else return layer[v]; };
+    auto feed_of = [&](int c, int e) -> int64_t { if constexpr (FAST) return freg[c]; else return feed[e]; };
+
+    PG_STAMP(0);
+    // ---- depth of this graph in this direction
+    int mx = -1, bad = 0;
+#pragma unroll
+    for (int c = 0; c < nchunk_n; ++c) {
+        const int v = n0 + c * PB + tid;
+        if (v < n1) {
+            int64_t l = layer_of(c, v);
+            if (l < 0 || l >= n) { bad = 8; l = l < 0 ? 0 : n - 1; }
+            mx = max(mx, (int)l);
+        }
+    }
+    mx = wave_max_i(mx);
+    if (tid == 0) *s_depth = -1;
+    __syncthreads();
+    if ((tid & 63) == 0) atomicMax(s_depth, mx);
+    if (bad && status) atomicOr(status, bad);
+    for (int i = tid; i <= n; i += PB) { ls[i] = 0; rp[i] = 0; }
+    __syncthreads();
+    const int depth = *s_depth + 1;  // 0 for an empty graph
+    if (tid == 0) plan[L.depth[d] + g] = depth;
+
+    PG_STAMP(1);
+    // ---- histogram of layers -> lstart (absolute positions into order[])
+#pragma unroll
+    for (int c = 0; c < nchunk_n; ++c) {
+        const int v = n0 + c * PB + tid;
+        if (v < n1) {
+            int l = (int)min((int64_t)max(layer_of(c, v), (int64_t)0), (int64_t)(n - 1));
+            atomicAdd(&ls[l + 1], 1);
+        }
+    }
+    __syncthreads();
+    PG_STAMP(2);
+    block_scan_inplace(ls, depth + 1, n0, lds);
+    __syncthreads();
+    for (int i = tid; i < depth; i += PB) {
+        cur[i] = ls[i];
+        atomicAdd(&plan[L.blptr[d] + i + 1], ls[i + 1] - ls[i]);  // rows of batch-level layer i
+    }
+    if (small) for (int i = tid; i <= depth; i += PB) ls_g[i] = ls[i];
+    __syncthreads();
+
+    PG_STAMP(3);
+    // ---- stable placement of nodes: order[] sorted by (layer, node id)
+#pragma unroll
+    for (int c = 0; c < nchunk_n; ++c) {
+        if (c * PB >= n) break;   // (uniform)
+        const int v = n0 + c * PB + tid;
+        int key = -1;
+        if (v < n1) key = (int)min((int64_t)max(layer_of(c, v), (int64_t)0), (int64_t)(n - 1));
+        int slot;
+        if constexpr (FAST) slot = chunk_place_masks(key, cur, masks); else slot = chunk_place(key, cur);
+        if (key >= 0) {
+            order[slot] = v;
+            pos[v] = slot;
+        }
+    }
+    __syncthreads();  // pos[] is read across waves below: an unwritten LDS word is an arbitrary index into rp[]
+
+    PG_STAMP(4);
+    // ---- rows of the CSR
+#pragma unroll
+    for (int c = 0; c < nchunk_e; ++c) {
+        const int e = e0 + c * PB + tid;
+        if (e < e1) {
+            const int64_t f = feed_of(c, e);
+            if (f >= n0 && f < n1) atomicAdd(&rp[pos[f] - n0 + 1], 1);
+        }
+    }
+    __syncthreads();
+    PG_STAMP(5);
+    block_scan_inplace(rp, n + 1, e0, lds);
+    __syncthreads();
+    PG_STAMP(6);
+    for (int i = tid; i < n; i += PB) cur[i] = rp[i];
+    if (small) for (int i = tid; i <= n; i += PB) rp_g[i] = rp[i];
+    __syncthreads();
+    PG_STAMP(7);
+#pragma unroll
+    for (int c = 0; c < nchunk_e; ++c) {
+        if (c * PB >= e1 - e0) break;   // (uniform)
+        const int e = e0 + c * PB + tid;
+        int key = -1;
+        int64_t f = -1;
+        if (e < e1) { f = feed_of(c, e); if (f >= n0 && f < n1) key = pos[f] - n0; }
+        int slot;
+        if constexpr (FAST) slot = chunk_place_masks(key, cur, masks); else slot = chunk_place(key, cur);
+        if (key >= 0) {
+            int64_t o;
+            if constexpr (FAST) o = oreg[c]; else o = other[e];
+            col[slot] = (int)((o >= n0 && o < n1) ? o : f);
+            eidx[slot] = e;  // original edge id: per-edge quantities of the backward pass are stored by it
+            if constexpr (FAST) {
+                if (R >= 1) eattr[(int64_t)slot * R] = areg[c][0];
+                if (R >= 2) eattr[(int64_t)slot * R + 1] = areg[c][1];
+            } else {
+                for (int r = 0; r < R; ++r) eattr[(int64_t)slot * R + r] = edge_attr[(int64_t)e * R + r];
+            }
+        }
+    }    PG_STAMP(8);
+}
+
 __device__ __forceinline__ void plan_graph_body(int32_t* plan, const PlanLayout& L, const int64_t* __restrict__ edge_index,
                                                 const int64_t* __restrict__ layer_fwd, const int64_t* __restrict__ layer_bwd,
                                                 const float* __restrict__ edge_attr, int R, int64_t N, int64_t E,
@@ -127,94 +346,16 @@ __device__ __forceinline__ void plan_graph_body(int32_t* plan, const PlanLayout&
     // graphs of up to PLAN_NMAX nodes (all of ogbg-code2's typical ASTs) keep their counters, cursors
     // and positions in LDS: the kernel is a chain of ~15 dependent passes, and every pass through
     // global memory costs a round trip
-    __shared__ int32_t small_ws[4 * (PLAN_NMAX + 1)];
-    const int tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) int32_t small_ws[PLAN_GRAPH_LDS];
     const int n0 = plan[L.node_ptr + g], n1 = plan[L.node_ptr + g + 1];
     const int e0 = plan[L.edge_ptr + g], e1 = plan[L.edge_ptr + g + 1];
-    const int n = n1 - n0;
-    const bool small = n <= PLAN_NMAX;
     const int64_t* layer = d == 0 ? layer_fwd : layer_bwd;
-    int32_t* ls_g = plan + L.lstart[d] + n0 + g;   // n+1 words (final home)
-    int32_t* rp_g = plan + L.rowptr[d] + n0 + g;   // n+1 words (final home)
-    int32_t* ls = small ? small_ws : ls_g;
-    int32_t* rp = small ? small_ws + (PLAN_NMAX + 1) : rp_g;
-    int32_t* cur = small ? small_ws + 2 * (PLAN_NMAX + 1) : plan + L.cursor[d] + n0 + g;  // n+1 words
-    int32_t* pos = (small ? small_ws + 3 * (PLAN_NMAX + 1) : plan + L.pos[d] + n0) - n0;  // indexed by node id
-    int32_t* order = plan + L.order[d];
-    int32_t* col = plan + L.col[d];
-    int32_t* eidx = plan + L.eidx[d];
-    float* eattr = reinterpret_cast<float*>(plan + L.eattr[d]);
-
-    // ---- depth of this graph in this direction
-    int mx = -1, bad = 0;
-    for (int v = n0 + tid; v < n1; v += PB) {
-        int64_t l = layer[v];
-        if (l < 0 || l >= n) { bad = 8; l = l < 0 ? 0 : n - 1; }
-        mx = max(mx, (int)l);
-    }
-    mx = wave_max_i(mx);
-    if (tid == 0) s_depth = -1;
-    __syncthreads();
-    if ((tid & 63) == 0) atomicMax(&s_depth, mx);
-    if (bad && status) atomicOr(status, bad);
-    for (int i = tid; i <= n; i += PB) { ls[i] = 0; rp[i] = 0; }
-    __syncthreads();
-    const int depth = s_depth + 1;  // 0 for an empty graph
-    if (tid == 0) plan[L.depth[d] + g] = depth;
-
-    // ---- histogram of layers -> lstart (absolute positions into order[])
-    for (int v = n0 + tid; v < n1; v += PB) {
-        int l = (int)min((int64_t)max((int64_t)layer[v], (int64_t)0), (int64_t)(n - 1));
-        atomicAdd(&ls[l + 1], 1);
-    }
-    __syncthreads();
-    block_scan_inplace(ls, depth + 1, n0, lds);
-    __syncthreads();
-    for (int i = tid; i < depth; i += PB) {
-        cur[i] = ls[i];
-        atomicAdd(&plan[L.blptr[d] + i + 1], ls[i + 1] - ls[i]);  // rows of batch-level layer i
-    }
-    if (small) for (int i = tid; i <= depth; i += PB) ls_g[i] = ls[i];
-    __syncthreads();
-
-    // ---- stable placement of nodes: order[] sorted by (layer, node id)
-    for (int c0 = n0; c0 < n1; c0 += PB) {
-        int v = c0 + tid;
-        int key = -1;
-        if (v < n1) key = (int)min((int64_t)max((int64_t)layer[v], (int64_t)0), (int64_t)(n - 1));
-        const int slot = chunk_place(key, cur);
-        if (key >= 0) {
-            order[slot] = v;
-            pos[v] = slot;
-        }
-    }
-    __syncthreads();  // pos[] is read across waves below: an unwritten LDS word is an arbitrary index into rp[]
-
-    // ---- rows of the CSR: the node an edge feeds is its target (d=0) or its source (d=1)
-    const int64_t* feed = d == 0 ? edge_index + E : edge_index;
-    const int64_t* other = d == 0 ? edge_index : edge_index + E;
-    for (int e = e0 + tid; e < e1; e += PB) {
-        int64_t f = feed[e];
-        if (f >= n0 && f < n1) atomicAdd(&rp[pos[f] - n0 + 1], 1);
-    }
-    __syncthreads();
-    block_scan_inplace(rp, n + 1, e0, lds);
-    __syncthreads();
-    for (int i = tid; i < n; i += PB) cur[i] = rp[i];
-    if (small) for (int i = tid; i <= n; i += PB) rp_g[i] = rp[i];
-    __syncthreads();
-    for (int c0 = e0; c0 < e1; c0 += PB) {
-        int e = c0 + tid;
-        int key = -1;
-        if (e < e1) { int64_t f = feed[e]; if (f >= n0 && f < n1) key = pos[f] - n0; }
-        const int slot = chunk_place(key, cur);
-        if (key >= 0) {
-            int64_t o = other[e];
-            col[slot] = (int)((o >= n0 && o < n1) ? o : feed[e]);
-            eidx[slot] = e;  // original edge id: per-edge quantities of the backward pass are stored by it
-            for (int r = 0; r < R; ++r) eattr[(int64_t)slot * R + r] = edge_attr[(int64_t)e * R + r];
-        }
-    }
+    if (n1 - n0 <= PLAN_FAST_N && e1 - e0 <= PLAN_FAST_E && R <= 2)
+        plan_graph_impl<true, true>(plan, L, edge_index, layer, edge_attr, R, E, status, g, d, n0, n1, e0, e1, lds, &s_depth, small_ws);
+    else if (n1 - n0 <= PLAN_NMAX)
+        plan_graph_impl<false, true>(plan, L, edge_index, layer, edge_attr, R, E, status, g, d, n0, n1, e0, e1, lds, &s_depth, small_ws);
+    else
+        plan_graph_impl<false, false>(plan, L, edge_index, layer, edge_attr, R, E, status, g, d, n0, n1, e0, e1, lds, &s_depth, small_ws);
 }
 
 // Last step of the build.  Once the status word is set (unsorted `batch`, edges across graphs, layers out of range)

@@ -13,7 +13,7 @@
 //   2  plan_graph (2B workgroups)  |  rows                per-graph sorts (latency-bound: 15 dependent passes of ONE workgroup
 //                                                         per graph, the 657-node graph sets the time) next to the HBM-bound
 //                                                         encoder rows / folded gi0 rows / index stack
-//   3  plan_blptr (2)  |  plan_items + LPT assignment (1)  |  workspace fill
+//   3  plan_blptr (2)  |  plan_items + LPT assignment (1)  |  workspace fill  |  the other half of the rows
 //   4  df_count (2B)  |  plan_lbase
 //   5  df_prefix (2G)  |  plan_rowrec (+ seal)
 //   6  df_lbase
@@ -21,6 +21,10 @@
 // Measured: DESIGN.md section 4h.
 #include "plan_dev.h"
 #include "sched_dev.h"
+
+#ifndef DAGNN_PREPARE_SPLIT_PCT
+#define DAGNN_PREPARE_SPLIT_PCT 20
+#endif
 
 namespace {
 
@@ -38,19 +42,20 @@ struct PrepRows {
     int64_t N;
 };
 
-// Workgroup rb of nrb (256 threads): the index stack as one flat coalesced copy, then one wave per node: indices read
+// Workgroup rb of nrb, nodes [v0, v1): the index stack as one flat coalesced copy, then one wave per node: indices read
 // once, out_k[v,:] = (type_k[x0] + attr_k[x1]) + depth_k[min(depth, max_depth)] for every table set k (the association of
 // utils.py:28; misc.hip's encode_ast_kernel is the single-table form).
-__device__ __forceinline__ void rows_body(const PrepRows& J, const int64_t rb, const int64_t nrb) {
+__device__ __forceinline__ void rows_body(const PrepRows& J, const int64_t rb, const int64_t nrb, const int64_t v0, const int64_t v1,
+                                          const bool with_stack) {
     const int64_t N = J.N;
-    if (J.stack_out)
-        for (int64_t idx = rb * 256 + threadIdx.x; idx < 4 * N; idx += nrb * 256) {
+    if (with_stack && J.stack_out)
+        for (int64_t idx = rb * blockDim.x + threadIdx.x; idx < 4 * N; idx += nrb * blockDim.x) {
             const int j = (int)(idx / N);
             J.stack_out[idx] = J.stack_src[j][idx - j * N];
         }
     if (!J.x) return;
-    const int lane = threadIdx.x & 63;
-    for (int64_t v = rb * 4 + (threadIdx.x >> 6); v < N; v += nrb * 4) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int64_t v = v0 + rb * wpb + (threadIdx.x >> 6); v < v1; v += nrb * wpb) {
         const int64_t t = J.x[2 * v], a = J.x[2 * v + 1];
         int64_t dp = J.depth[v];
         if (dp > J.max_depth) { dp = J.max_depth; if (lane == 0) J.depth[v] = dp; }
@@ -75,30 +80,73 @@ __global__ void __launch_bounds__(256) prep_ptr_kernel(int32_t* plan, PlanLayout
     plan_ptr_body(plan, L, edge_index, batch, N, E, B, R, status, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
-__global__ void __launch_bounds__(256) prep_rows_kernel(PrepRows J) { rows_body(J, blockIdx.x, gridDim.x); }
+__global__ void __launch_bounds__(256) prep_rows_kernel(PrepRows J) { rows_body(J, blockIdx.x, gridDim.x, 0, J.N, true); }
 
 // launch 2: workgroups [0, 2B) = (graph, direction) sorts - dispatched first: they are the long pole -, the rest = rows
 __global__ void __launch_bounds__(PB) prep_graph_rows_kernel(int32_t* plan, PlanLayout L, const int64_t* __restrict__ edge_index,
                                                               const int64_t* __restrict__ layer_fwd, const int64_t* __restrict__ layer_bwd,
                                                               const float* __restrict__ edge_attr, int R, int64_t N, int64_t E,
-                                                              int32_t* status, int B, PrepRows J) {
+                                                              int32_t* status, int B, PrepRows J, int64_t v_split) {
     const int b = blockIdx.x;
     if (b < 2 * B) {
         plan_graph_body(plan, L, edge_index, layer_fwd, layer_bwd, edge_attr, R, N, E, status, b >> 1, b & 1);
         return;
     }
-    rows_body(J, b - 2 * B, gridDim.x - 2 * B);
+    rows_body(J, b - 2 * B, gridDim.x - 2 * B, 0, v_split, true);
+}
+
+// Work items AND the schedule's assignment by one workgroup of 1024 threads, from ONE trip to memory (B <= 2048): the depths
+// of both directions and the node counts go to LDS, every thread ranks its item (plan_items_body: depth descending, ties by
+// index) and its graph (the direction-0 items in that order = graphs by depth0 descending, ties by graph: what
+// df_assign_wave compacts out of the item list), wave 0 walks the chain.  The separate bodies go through memory three
+// times on the way (items -> cursor -> items, then items -> depths / node counts, 64 at a time): 13 + 25 us at B = 128.
+// buf: 12288 words.
+__device__ __forceinline__ void prep_items_assign_body(int32_t* plan, const PlanLayout& L, int32_t* ws, const DfLayout& S, int N, int B,
+                                                       int G, int c_layer, int c_row, int32_t* buf) {
+    int32_t* keys = buf;            // [2B] depth of item i = 2 g + d
+    int32_t* nn = buf + 4096;       // [B] nodes of graph g
+    int32_t* s_g = buf + 6144, *s_d = buf + 8192, *s_n = buf + 10240;
+    const int tid = threadIdx.x, n = 2 * B;
+    for (int i = tid; i < n; i += blockDim.x) keys[i] = plan[L.depth[i & 1] + (i >> 1)];
+    for (int g = tid; g < B; g += blockDim.x) nn[g] = plan[L.node_ptr + g + 1] - plan[L.node_ptr + g];
+    if (G > 0) for (int64_t i = tid; i < S.gtab[0]; i += blockDim.x) ws[i] = 0;   // header + grp_of / gdepth / gload / loff (+ padding)
+    __syncthreads();
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int ki = keys[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (keys[j] > ki) || (keys[j] == ki && j < i);
+        plan[L.items + rank] = i;
+    }
+    if (G <= 0) return;
+    for (int g = tid; g < B; g += blockDim.x) {
+        const int kg = keys[2 * g];
+        int rank = 0;
+        for (int j = 0; j < B; ++j) rank += (keys[2 * j] > kg) || (keys[2 * j] == kg && j < g);
+        s_g[rank] = g; s_d[rank] = max(kg, keys[2 * g + 1]); s_n[rank] = nn[g];
+    }
+    __syncthreads();   // (also: the header's zeros are in memory before the chain writes into it)
+    if (tid < 64) df_assign_chain(nullptr, nullptr, nullptr, nullptr, ws, S, B, G, c_layer, c_row, s_g, s_d, s_n, true, B, (long long)N);
 }
 
 // launch 3 (1024 threads): workgroups 0 / 1 the batch-level layers of a direction, workgroup 2 the work items and - they
 // are its input, still in this workgroup's hands - the LPT assignment of the schedule, the rest the workspace's initial state
 __global__ void __launch_bounds__(1024) prep_mid_kernel(int32_t* plan, PlanLayout L, int N, int B, const int32_t* __restrict__ status,
-                                                         int32_t* ws, DfLayout S, int G, int c_layer, int c_row) {
+                                                         int32_t* ws, DfLayout S, int G, int c_layer, int c_row, int nfill,
+                                                         PrepRows J, int64_t v_split) {
     constexpr int CAP = 4096;
     __shared__ int32_t buf[3 * CAP];   // the items' keys, then the assignment's three staging arrays
     const int b = blockIdx.x;
+    if (b >= 3 + nfill) {   // the rest of the rows: this launch waits for ONE wave's 128-step chain (the assignment) otherwise
+        rows_body(J, b - 3 - nfill, gridDim.x - 3 - nfill, v_split, J.N, false);
+        return;
+    }
     if (b < 2) { plan_blptr_body(plan, L, N, B, status, b); return; }
     if (b == 2) {
+        if (status[0] & 7) return;   // contract violated (plan_ptr_body): the tables are garbage - do not walk them
+        if (B <= 2048) {
+            prep_items_assign_body(plan, L, ws, S, N, B, status[0] != 0 ? 0 : G, c_layer, c_row, buf);
+            return;
+        }
         plan_items_body(plan, L, B, status, buf);
         if (G <= 0 || status[0] != 0) return;   // (no schedule asked for; or the batch violates the plan contract)
         __syncthreads();                        // the items are in memory, the keys are done with
@@ -106,7 +154,7 @@ __global__ void __launch_bounds__(1024) prep_mid_kernel(int32_t* plan, PlanLayou
         return;
     }
     if (G <= 0 || status[0] != 0) return;
-    df_fill_body(ws, S, (int64_t)(b - 3) * blockDim.x + threadIdx.x, (int64_t)(gridDim.x - 3) * blockDim.x);
+    df_fill_body(ws, S, (int64_t)(b - 3) * blockDim.x + threadIdx.x, (int64_t)nfill * blockDim.x);
 }
 
 // launch 4: workgroups [0, 2B) (with a schedule) the rows per (group, layer), the rest the first slot of every (graph, layer)
@@ -233,13 +281,16 @@ extern "C" int dagnn_prepare(const dagnn_plan* pl, const int64_t* edge_index, co
     // 1
     hipLaunchKernelGGL(prep_ptr_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, p, L, edge_index, batch, N, E, B, R, status);
     DAGNN_CHECK_LAUNCH();
-    // 2
+    // 2, 3: the encoder rows are split between the two launches that wait for a single workgroup's dependent chain (with a
+    // schedule; the share of launch 2: DAGNN_PREPARE_SPLIT_PCT, measured in DESIGN.md section 4h)
+    const int64_t v_split = (J.x && groups > 0) ? N * DAGNN_PREPARE_SPLIT_PCT / 100 : N;
+    const int nfill = groups > 0 ? 128 : 0;
+    const int64_t rows3 = (J.x && v_split < N) ? ((N - v_split + 15) / 16 < 512 ? (N - v_split + 15) / 16 : 512) : 0;
     hipLaunchKernelGGL(prep_graph_rows_kernel, dim3((unsigned)(2 * B + rows_blocks)), dim3(PB), 0, stream, p, L, edge_index, layer_fwd,
-                       layer_bwd, edge_attr, R, N, E, status, (int)B, J);
+                       layer_bwd, edge_attr, R, N, E, status, (int)B, J, v_split);
     DAGNN_CHECK_LAUNCH();
-    // 3
-    hipLaunchKernelGGL(prep_mid_kernel, dim3(3 + (groups > 0 ? 128 : 0)), dim3(1024), 0, stream, p, L, (int)N, (int)B, status, ws, S, groups,
-                       cost_layer, cost_row);
+    hipLaunchKernelGGL(prep_mid_kernel, dim3((unsigned)(3 + nfill + rows3)), dim3(1024), 0, stream, p, L, (int)N, (int)B, status, ws, S, groups,
+                       cost_layer, cost_row, nfill, J, v_split);
     DAGNN_CHECK_LAUNCH();
     // 4
     const int64_t lb = (N + 3) / 4;

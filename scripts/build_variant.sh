@@ -1,14 +1,12 @@
 #!/bin/bash
-# Experiment build of the library: scripts/build_variant.sh <name> [SRC=<file>.hip] [-DFLAG ...]  ->  scripts/tmp/lib_<name>.so
-# (one source - dataflow.hip by default - recompiled with the flags, the other objects re-used); run with DAGNN_AMD_LIB=<that path>.
+# build a variant of the library with extra hipcc flags for ONE source: scripts/build_variant.sh <name> <source.hip> <flags...>
+# -> dagnn_amd/lib/variants/libdagnn_hip_<name>.so (run with DAGNN_AMD_LIB=...); the other objects come from the normal build
 set -e
-cd "$(dirname "$0")/.."
-name=$1; shift
-src=dataflow
-if [[ "$1" == SRC=* ]]; then src=${1#SRC=}; src=${src%.hip}; shift; fi
-mkdir -p scripts/tmp
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -c -o scripts/tmp/${src}_$name.o dagnn_amd/csrc/$src.hip "$@" -Rpass-analysis=kernel-resource-usage 2> scripts/tmp/build_$name.log || { tail -30 scripts/tmp/build_$name.log; exit 1; }
-objs=$(ls dagnn_amd/lib/obj/*.o | grep -v "/$src.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scripts/tmp/lib_$name.so $objs scripts/tmp/${src}_$name.o
-grep -A12 "_kernelILi16" scripts/tmp/build_$name.log | grep -i "VGPRs:\|Spill\|Occupancy" | head -8
-echo scripts/tmp/lib_$name.so
+name=$1; src=$2; shift 2
+root=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p $root/dagnn_amd/lib/variants
+obj=$root/dagnn_amd/lib/variants/$(basename $src .hip)_$name.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -c -o $obj $root/dagnn_amd/csrc/$src "$@"
+objs=$(ls $root/dagnn_amd/lib/obj/*.o | grep -v "/$(basename $src .hip).o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/dagnn_amd/lib/variants/libdagnn_hip_$name.so $objs $obj
+echo built $root/dagnn_amd/lib/variants/libdagnn_hip_$name.so

@@ -34,12 +34,8 @@ if __name__ == "__main__":
         child()
     else:
         variants = []
-        for rep in range(2):
-            for name, env in (("r05_baseline", {"DAGNN_AMD_PLAN_OVERLAP": "0", "DAGNN_AMD_FOLD_INPUT": "0", "DAGNN_AMD_PREPARE": "0"}),
-                              ("fold_only", {"DAGNN_AMD_PLAN_OVERLAP": "0", "DAGNN_AMD_FOLD_INPUT": "1", "DAGNN_AMD_PREPARE": "0"}),
-                              ("fused_nofold", {"DAGNN_AMD_FOLD_INPUT": "0", "DAGNN_AMD_PREPARE": "1"}),
-                              ("fused_fold", {"DAGNN_AMD_FOLD_INPUT": "1", "DAGNN_AMD_PREPARE": "1"})):
-                variants.append((name, env))
+        for rep in range(3):
+            variants.append(("default", {}))
         for name, env in variants:
             e = dict(os.environ); e.update(env)
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=e, capture_output=True, text=True)

@@ -546,6 +546,27 @@ def main():
                                "(attach_plan): no plan / schedule kernels inside the step",
                        "ms_per_step": round(float(tp) / args.steps * 1e3, 4),
                        "graphs_per_s": round(world * B * args.steps / float(tp), 1)}
+    # the same forward on round 5's front of the recurrence: 13 plan / schedule launches, the encoder, the [N, emb] x [emb, 3H]
+    # input GEMM of both directions - no fused pipeline, no tables folded through W_ih.  Reported next to the headline so that
+    # what the folding and the fusion buy stays visible; never `value`.
+    front_res = None
+    if args.streams == 1 and model.schedule == "lockstep" and rank == 0:
+        saved = (engine.FOLD_INPUT, engine.PREPARE_FUSED, engine.PLAN_OVERLAP)
+        engine.FOLD_INPUT, engine.PREPARE_FUSED, engine.PLAN_OVERLAP = 0, 0, 0
+        fin = fresh_inputs(master, args.warmup + args.steps)
+        with torch.no_grad():
+            for i in range(args.warmup):
+                model(fin[i])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.warmup, args.warmup + args.steps):
+                model(fin[i])
+            torch.cuda.synchronize()
+            tf_ = time.perf_counter() - t0
+        engine.FOLD_INPUT, engine.PREPARE_FUSED, engine.PLAN_OVERLAP = saved
+        front_res = {"what": "forward(G) with DAGNN_AMD_PREPARE=0 DAGNN_AMD_FOLD_INPUT=0 DAGNN_AMD_PLAN_OVERLAP=0: plan and "
+                             "dataflow schedule as 13 separate launches, encoder, input GEMM of stacked layer 0 (round 5's path)",
+                     "ms_per_step": round(tf_ / args.steps * 1e3, 4), "graphs_per_s": round(B * args.steps / tf_, 1)}
     # N > 1: the reference's own use of k devices - ONE global batch split by its Collater rule (tg/dataloader.py:17-27,
     # node-balanced contiguous shards) - next to the weak-scaling headline.  Bounded by the shard holding the deepest graph.
     strong_res = None
@@ -640,6 +661,10 @@ def main():
                                "bidirectional attn_h, max-pool over output nodes, %d heads x vocab %d, forward(G) "
                                "end-to-end incl. plan build" % ("seed=rank" if args.rank_seeds else
                                                                 "seed 0: the headline batch on every rank", B, H, L, S, V),
+                   "front_of_recurrence": "dagnn_prepare: plan + dataflow schedule + encoder rows + side effect 1 in 7 launches; "
+                                          "evaluation passes read stacked layer 0's input side from the embedding tables folded "
+                                          "through W_ih once per weight version (constant folding of parameters: no input GEMM per "
+                                          "batch; `separate_calls_no_folding` times the same forward without either)",
                    "global_batch": world * B, "nodes_per_batch": N, "edges_per_batch": E, "topo_layers": T,
                    "parallelism": "graph-parallel x%d, no data-path collective" % world,
                    "streams_per_gpu": args.streams},
@@ -716,6 +741,8 @@ def main():
                                "kernels_ms_per_step: the instrumented second pass (HIP events around every step and launch)"
         if planned_res is not None:
             result["loader_side_plan"] = planned_res
+        if front_res is not None:
+            result["separate_calls_no_folding"] = front_res
         if strong_res is not None:
             result["strong_scaling"] = strong_res
         if multi_res is not None:

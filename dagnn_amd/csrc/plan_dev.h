@@ -166,12 +166,6 @@ __device__ __forceinline__ int chunk_place_masks(int key, int32_t* cur, unsigned
     return slot;
 }
 
-#ifdef PG_STAMPS
-#define PG_STAMP(k) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
-    plan[L.cursor[d] + n0 + g + (k)] = (int)(t_ & 0x7fffffff); } } while (0)
-#else
-#define PG_STAMP(k)
-#endif
 template <bool FAST, bool SMALL>
 __device__ __forceinline__ void plan_graph_impl(int32_t* plan, const PlanLayout& L, const int64_t* __restrict__ edge_index,
                                                 const int64_t* __restrict__ layer, const float* __restrict__ edge_attr,
@@ -233,7 +227,6 @@ __device__ __forceinline__ void plan_graph_impl(int32_t* plan, const PlanLayout&
     auto layer_of = [&](int c, int v) -> int64_t { if constexpr (FAST) return lreg[c]; else return layer[v]; };
     auto feed_of = [&](int c, int e) -> int64_t { if constexpr (FAST) return freg[c]; else return feed[e]; };
 
-    PG_STAMP(0);
     // ---- depth of this graph in this direction
     int mx = -1, bad = 0;
 #pragma unroll
@@ -255,7 +248,6 @@ __device__ __forceinline__ void plan_graph_impl(int32_t* plan, const PlanLayout&
     const int depth = *s_depth + 1;  // 0 for an empty graph
     if (tid == 0) plan[L.depth[d] + g] = depth;
 
-    PG_STAMP(1);
     // ---- histogram of layers -> lstart (absolute positions into order[])
 #pragma unroll
     for (int c = 0; c < nchunk_n; ++c) {
@@ -266,7 +258,6 @@ __device__ __forceinline__ void plan_graph_impl(int32_t* plan, const PlanLayout&
         }
     }
     __syncthreads();
-    PG_STAMP(2);
     block_scan_inplace(ls, depth + 1, n0, lds);
     __syncthreads();
     for (int i = tid; i < depth; i += PB) {
@@ -276,7 +267,6 @@ __device__ __forceinline__ void plan_graph_impl(int32_t* plan, const PlanLayout&
     if (small) for (int i = tid; i <= depth; i += PB) ls_g[i] = ls[i];
     __syncthreads();
 
-    PG_STAMP(3);
     // ---- stable placement of nodes: order[] sorted by (layer, node id)
 #pragma unroll
     for (int c = 0; c < nchunk_n; ++c) {
@@ -293,7 +283,6 @@ __device__ __forceinline__ void plan_graph_impl(int32_t* plan, const PlanLayout&
     }
     __syncthreads();  // pos[] is read across waves below: an unwritten LDS word is an arbitrary index into rp[]
 
-    PG_STAMP(4);
     // ---- rows of the CSR
 #pragma unroll
     for (int c = 0; c < nchunk_e; ++c) {
@@ -304,14 +293,11 @@ __device__ __forceinline__ void plan_graph_impl(int32_t* plan, const PlanLayout&
         }
     }
     __syncthreads();
-    PG_STAMP(5);
     block_scan_inplace(rp, n + 1, e0, lds);
     __syncthreads();
-    PG_STAMP(6);
     for (int i = tid; i < n; i += PB) cur[i] = rp[i];
     if (small) for (int i = tid; i <= n; i += PB) rp_g[i] = rp[i];
     __syncthreads();
-    PG_STAMP(7);
 #pragma unroll
     for (int c = 0; c < nchunk_e; ++c) {
         if (c * PB >= e1 - e0) break;   // (uniform)
@@ -333,8 +319,7 @@ __device__ __forceinline__ void plan_graph_impl(int32_t* plan, const PlanLayout&
                 for (int r = 0; r < R; ++r) eattr[(int64_t)slot * R + r] = edge_attr[(int64_t)e * R + r];
             }
         }
-    }    PG_STAMP(8);
-}
+    }}
 
 __device__ __forceinline__ void plan_graph_body(int32_t* plan, const PlanLayout& L, const int64_t* __restrict__ edge_index,
                                                 const int64_t* __restrict__ layer_fwd, const int64_t* __restrict__ layer_bwd,

@@ -13,7 +13,7 @@
 //   2  plan_graph (2B workgroups)  |  rows                per-graph sorts (latency-bound: 15 dependent passes of ONE workgroup
 //                                                         per graph, the 657-node graph sets the time) next to the HBM-bound
 //                                                         encoder rows / folded gi0 rows / index stack
-//   3  plan_blptr (2)  |  plan_items + LPT assignment (1)  |  workspace fill  |  the other half of the rows
+//   3  plan_blptr (2)  |  plan_items + LPT assignment (1)  |  workspace fill  |  the rest of the rows
 //   4  df_count (2B)  |  plan_lbase
 //   5  df_prefix (2G)  |  plan_rowrec (+ seal)
 //   6  df_lbase
@@ -22,8 +22,8 @@
 #include "plan_dev.h"
 #include "sched_dev.h"
 
-#ifndef DAGNN_PREPARE_SPLIT_PCT
-#define DAGNN_PREPARE_SPLIT_PCT 20
+#ifndef DAGNN_PREPARE_SHARES
+#define DAGNN_PREPARE_SHARES 20, 80, 0, 0, 0, 0   // percent of the encoder rows that ride on launches 2..7 (with a schedule); measured: DESIGN.md 4h
 #endif
 
 namespace {
@@ -41,6 +41,9 @@ struct PrepRows {
     int64_t* stack_out;
     int64_t N;
 };
+
+// the share of the rows that rides on one launch: nodes [v0, v1) by the workgroups from `first` on
+struct RowsShare { int64_t v0, v1; int first; };
 
 // Workgroup rb of nrb, nodes [v0, v1): the index stack as one flat coalesced copy, then one wave per node: indices read
 // once, out_k[v,:] = (type_k[x0] + attr_k[x1]) + depth_k[min(depth, max_depth)] for every table set k (the association of
@@ -69,7 +72,10 @@ __device__ __forceinline__ void rows_body(const PrepRows& J, const int64_t rb, c
                 const float4 u = pt[c], w = pa[c], z = pd[c];
                 float4 r;
                 r.x = (u.x + w.x) + z.x; r.y = (u.y + w.y) + z.y; r.z = (u.z + w.z) + z.z; r.w = (u.w + w.w) + z.w;
-                po[c] = r;
+                // (non-temporal: the rows are read next by the recurrence, a whole launch later - they need not push the
+                // tables out of the L2 on their way to memory; measured -5 us per forward)
+                typedef float prep_v4f __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(prep_v4f{r.x, r.y, r.z, r.w}, reinterpret_cast<prep_v4f*>(po + c));
             }
         }
     }
@@ -86,13 +92,13 @@ __global__ void __launch_bounds__(256) prep_rows_kernel(PrepRows J) { rows_body(
 __global__ void __launch_bounds__(PB) prep_graph_rows_kernel(int32_t* plan, PlanLayout L, const int64_t* __restrict__ edge_index,
                                                               const int64_t* __restrict__ layer_fwd, const int64_t* __restrict__ layer_bwd,
                                                               const float* __restrict__ edge_attr, int R, int64_t N, int64_t E,
-                                                              int32_t* status, int B, PrepRows J, int64_t v_split) {
+                                                              int32_t* status, int B, PrepRows J, RowsShare rs) {
     const int b = blockIdx.x;
     if (b < 2 * B) {
         plan_graph_body(plan, L, edge_index, layer_fwd, layer_bwd, edge_attr, R, N, E, status, b >> 1, b & 1);
         return;
     }
-    rows_body(J, b - 2 * B, gridDim.x - 2 * B, 0, v_split, true);
+    rows_body(J, b - 2 * B, gridDim.x - 2 * B, rs.v0, rs.v1, true);
 }
 
 // Work items AND the schedule's assignment by one workgroup of 1024 threads, from ONE trip to memory (B <= 2048): the depths
@@ -132,12 +138,12 @@ __device__ __forceinline__ void prep_items_assign_body(int32_t* plan, const Plan
 // are its input, still in this workgroup's hands - the LPT assignment of the schedule, the rest the workspace's initial state
 __global__ void __launch_bounds__(1024) prep_mid_kernel(int32_t* plan, PlanLayout L, int N, int B, const int32_t* __restrict__ status,
                                                          int32_t* ws, DfLayout S, int G, int c_layer, int c_row, int nfill,
-                                                         PrepRows J, int64_t v_split) {
+                                                         PrepRows J, RowsShare rs) {
     constexpr int CAP = 4096;
     __shared__ int32_t buf[3 * CAP];   // the items' keys, then the assignment's three staging arrays
     const int b = blockIdx.x;
     if (b >= 3 + nfill) {   // the rest of the rows: this launch waits for ONE wave's 128-step chain (the assignment) otherwise
-        rows_body(J, b - 3 - nfill, gridDim.x - 3 - nfill, v_split, J.N, false);
+        rows_body(J, b - 3 - nfill, gridDim.x - 3 - nfill, rs.v0, rs.v1, false);
         return;
     }
     if (b < 2) { plan_blptr_body(plan, L, N, B, status, b); return; }
@@ -159,9 +165,10 @@ __global__ void __launch_bounds__(1024) prep_mid_kernel(int32_t* plan, PlanLayou
 
 // launch 4: workgroups [0, 2B) (with a schedule) the rows per (group, layer), the rest the first slot of every (graph, layer)
 __global__ void __launch_bounds__(256) prep_lbase_count_kernel(int32_t* plan, PlanLayout L, int N, int B, const int32_t* __restrict__ status,
-                                                                int32_t* ws, DfLayout S, int G) {
+                                                                int32_t* ws, DfLayout S, int G, PrepRows J, RowsShare rs) {
     const int nc = G > 0 ? 2 * B : 0;
     const int b = blockIdx.x;
+    if (b >= rs.first) { rows_body(J, b - rs.first, gridDim.x - rs.first, rs.v0, rs.v1, false); return; }
     if (b < nc) {
         if (status[0] != 0) return;
         df_count_body(plan, L, ws, S, b >> 1, b & 1);
@@ -175,43 +182,48 @@ __global__ void __launch_bounds__(256) prep_lbase_count_kernel(int32_t* plan, Pl
 __global__ void __launch_bounds__(256) prep_rowrec_prefix_kernel(int32_t* plan, PlanLayout L, const int64_t* __restrict__ batch,
                                                                   const int64_t* __restrict__ layer_fwd, const int64_t* __restrict__ layer_bwd,
                                                                   int N, int B, int R, const int32_t* __restrict__ status,
-                                                                  int32_t* ws, DfLayout S, int G) {
+                                                                  int32_t* ws, DfLayout S, int G, PrepRows J, RowsShare rs) {
     const int np = G > 0 ? 2 * G : 0;
     const int b = blockIdx.x;
+    if (b >= rs.first) { rows_body(J, b - rs.first, gridDim.x - rs.first, rs.v0, rs.v1, false); return; }
     if (b < np) {
         if (status[0] != 0) return;
         df_prefix_body(ws, S, b >> 1, b & 1);
         return;
     }
     if (status[0] != 0) {
-        plan_seal_body(plan, L, N, B, (int64_t)(b - np) * 256 + threadIdx.x, (int64_t)(gridDim.x - np) * 256);
+        plan_seal_body(plan, L, N, B, (int64_t)(b - np) * 256 + threadIdx.x, (int64_t)(rs.first - np) * 256);
         return;
     }
     plan_rowrec_body(plan, L, batch, layer_fwd, layer_bwd, N, R, status, (b - np) >> 1, (b - np) & 1);
 }
 
 __global__ void __launch_bounds__(256) prep_df_lbase_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws, DfLayout S,
-                                                             int B, int G, const int32_t* __restrict__ status) {
+                                                             int B, int G, const int32_t* __restrict__ status, PrepRows J, RowsShare rs) {
+    const int b = blockIdx.x;
+    if (b >= rs.first) { rows_body(J, b - rs.first, gridDim.x - rs.first, rs.v0, rs.v1, false); return; }
     if (status[0] != 0) return;
-    df_lbase_body(plan, L, ws, S, B, G, blockIdx.x * 4 + (threadIdx.x >> 6), gridDim.x * 4, blockIdx.y);
+    df_lbase_body(plan, L, ws, S, B, G, (b >> 1) * 4 + (threadIdx.x >> 6), (rs.first >> 1) * 4, b & 1);
 }
 
 // launch 7: the schedule's records; every workgroup derives the groups' first records itself (one wave scan over <= 64
 // block counts), workgroup 0 of a direction also stores them (gtab[2k]: what the dataflow kernels read)
 __global__ void __launch_bounds__(256) prep_records_kernel(const int32_t* __restrict__ plan, PlanLayout L, int32_t* ws, DfLayout S,
-                                                            int N, int G, const int32_t* __restrict__ status) {
+                                                            int N, int G, const int32_t* __restrict__ status, PrepRows J, RowsShare rs) {
+    const int b = blockIdx.x;
+    if (b >= rs.first) { rows_body(J, b - rs.first, gridDim.x - rs.first, rs.v0, rs.v1, false); return; }
     if (status[0] != 0) return;
     __shared__ int32_t s_base[DF_MAX_GROUPS];
-    const int d = blockIdx.y;
+    const int d = b & 1;
     if (threadIdx.x < 64) {
         const int base = df_base_wave(ws, S, G, d, threadIdx.x);
         if ((int)threadIdx.x < G) {
             s_base[threadIdx.x] = base;
-            if (blockIdx.x == 0) ws[S.gtab[d] + 2 * threadIdx.x] = base;
+            if (b < 2) ws[S.gtab[d] + 2 * threadIdx.x] = base;
         }
     }
     __syncthreads();
-    df_records_body(plan, L, ws, S, N, blockIdx.x, d, s_base, 1);
+    df_records_body(plan, L, ws, S, N, b >> 1, d, s_base, 1);
 }
 
 }  // namespace
@@ -281,34 +293,65 @@ extern "C" int dagnn_prepare(const dagnn_plan* pl, const int64_t* edge_index, co
     // 1
     hipLaunchKernelGGL(prep_ptr_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, p, L, edge_index, batch, N, E, B, R, status);
     DAGNN_CHECK_LAUNCH();
-    // 2, 3: the encoder rows are split between the two launches that wait for a single workgroup's dependent chain (with a
-    // schedule; the share of launch 2: DAGNN_PREPARE_SPLIT_PCT, measured in DESIGN.md section 4h)
-    const int64_t v_split = (J.x && groups > 0) ? N * DAGNN_PREPARE_SPLIT_PCT / 100 : N;
+    // The rows ride on the launches that wait for ONE workgroup's dependent steps anyway (with a schedule; shares in percent
+    // of the nodes, DAGNN_PREPARE_SHARES): launch 2 the largest graph's sorts (12 us), launch 3 one wave's 128-step chain
+    // (25 us).  Launches 4-7 can carry a share too, but a few microseconds of launch floor each hide nothing: measured
+    // 1.43 ms per forward with 9 % of the rows on each against 1.41 ms without
+    static const int share_sched[6] = {DAGNN_PREPARE_SHARES};
+    int64_t cut[7];
+    cut[0] = 0;
+    for (int k = 0; k < 6; ++k) {
+        int64_t pct = (J.x && groups > 0) ? share_sched[k] : (k == 0 ? 100 : 0);
+        cut[k + 1] = k == 5 ? N : cut[k] + N * pct / 100;
+        if (cut[k + 1] > N) cut[k + 1] = N;
+    }
+    if (!J.x) for (int k = 1; k <= 6; ++k) cut[k] = N;
+    auto rows_wgs = [&](int k, int64_t per_wg, int64_t cap) -> int64_t {   // workgroups of launch k + 2 for its share
+        const int64_t n = J.x ? cut[k + 1] - cut[k] : 0;
+        const int64_t w = (n + per_wg - 1) / per_wg;
+        return w < cap ? w : cap;
+    };
     const int nfill = groups > 0 ? 128 : 0;
-    const int64_t rows3 = (J.x && v_split < N) ? ((N - v_split + 15) / 16 < 512 ? (N - v_split + 15) / 16 : 512) : 0;
-    hipLaunchKernelGGL(prep_graph_rows_kernel, dim3((unsigned)(2 * B + rows_blocks)), dim3(PB), 0, stream, p, L, edge_index, layer_fwd,
-                       layer_bwd, edge_attr, R, N, E, status, (int)B, J, v_split);
-    DAGNN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(prep_mid_kernel, dim3((unsigned)(3 + nfill + rows3)), dim3(1024), 0, stream, p, L, (int)N, (int)B, status, ws, S, groups,
-                       cost_layer, cost_row, nfill, J, v_split);
-    DAGNN_CHECK_LAUNCH();
-    // 4
-    const int64_t lb = (N + 3) / 4;
-    hipLaunchKernelGGL(prep_lbase_count_kernel, dim3((unsigned)((groups > 0 ? 2 * B : 0) + 2 * lb)), dim3(256), 0, stream, p, L, (int)N, (int)B,
-                       status, ws, S, groups);
-    DAGNN_CHECK_LAUNCH();
-    // 5
+    {   // 2 (also the index stack)
+        int64_t rw = rows_wgs(0, 4, 2048);
+        if (J.stack_out && rw < 64) rw = 64;
+        const RowsShare rs = {cut[0], cut[1], (int)(2 * B)};
+        hipLaunchKernelGGL(prep_graph_rows_kernel, dim3((unsigned)(2 * B + rw)), dim3(PB), 0, stream, p, L, edge_index, layer_fwd,
+                           layer_bwd, edge_attr, R, N, E, status, (int)B, J, rs);
+        DAGNN_CHECK_LAUNCH();
+    }
+    {   // 3
+        const RowsShare rs = {cut[1], cut[2], 3 + nfill};
+        hipLaunchKernelGGL(prep_mid_kernel, dim3((unsigned)(3 + nfill + rows_wgs(1, 16, 512))), dim3(1024), 0, stream, p, L, (int)N, (int)B,
+                           status, ws, S, groups, cost_layer, cost_row, nfill, J, rs);
+        DAGNN_CHECK_LAUNCH();
+    }
+    {   // 4
+        const int64_t own = (groups > 0 ? 2 * B : 0) + 2 * ((N + 3) / 4);
+        const RowsShare rs = {cut[2], cut[3], (int)own};
+        hipLaunchKernelGGL(prep_lbase_count_kernel, dim3((unsigned)(own + rows_wgs(2, 4, 2048))), dim3(256), 0, stream, p, L, (int)N, (int)B,
+                           status, ws, S, groups, J, rs);
+        DAGNN_CHECK_LAUNCH();
+    }
     const int64_t rb = (N + 255) / 256;
-    hipLaunchKernelGGL(prep_rowrec_prefix_kernel, dim3((unsigned)((groups > 0 ? 2 * groups : 0) + 2 * rb)), dim3(256), 0, stream, p, L, batch,
-                       layer_fwd, layer_bwd, (int)N, (int)B, R, status, ws, S, groups);
-    DAGNN_CHECK_LAUNCH();
+    {   // 5
+        const int64_t own = (groups > 0 ? 2 * groups : 0) + 2 * rb;
+        const RowsShare rs = {cut[3], cut[4], (int)own};
+        hipLaunchKernelGGL(prep_rowrec_prefix_kernel, dim3((unsigned)(own + rows_wgs(3, 4, 2048))), dim3(256), 0, stream, p, L, batch,
+                           layer_fwd, layer_bwd, (int)N, (int)B, R, status, ws, S, groups, J, rs);
+        DAGNN_CHECK_LAUNCH();
+    }
     if (groups > 0) {
         // 6, 7
         int64_t dlb = (N + groups + 3) / 4;
         if (dlb > 2048) dlb = 2048;
-        hipLaunchKernelGGL(prep_df_lbase_kernel, dim3((unsigned)dlb, 2), dim3(256), 0, stream, p, L, ws, S, (int)B, groups, status);
+        const RowsShare r6 = {cut[4], cut[5], (int)(2 * dlb)};
+        hipLaunchKernelGGL(prep_df_lbase_kernel, dim3((unsigned)(2 * dlb + rows_wgs(4, 4, 2048))), dim3(256), 0, stream, p, L, ws, S, (int)B,
+                           groups, status, J, r6);
         DAGNN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(prep_records_kernel, dim3((unsigned)rb, 2), dim3(256), 0, stream, p, L, ws, S, (int)N, groups, status);
+        const RowsShare r7 = {cut[5], cut[6], (int)(2 * rb)};
+        hipLaunchKernelGGL(prep_records_kernel, dim3((unsigned)(2 * rb + rows_wgs(5, 4, 2048))), dim3(256), 0, stream, p, L, ws, S, (int)N,
+                           groups, status, J, r7);
         DAGNN_CHECK_LAUNCH();
     }
     return DAGNN_OK;

@@ -34,8 +34,10 @@ if __name__ == "__main__":
         child()
     else:
         variants = []
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         for rep in range(3):
             variants.append(("default", {}))
+            variants.append(("nt_store", {"DAGNN_AMD_LIB": os.path.join(root, "dagnn_amd/lib/variants/libdagnn_hip_nt.so")}))
         for name, env in variants:
             e = dict(os.environ); e.update(env)
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=e, capture_output=True, text=True)

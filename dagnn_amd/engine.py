@@ -81,7 +81,7 @@ BWD_TAIL_MAX_BLOCKS = _env_int("DAGNN_AMD_BWD_TAIL_MAX_BLOCKS", 4)
 # Tried again with the plan kernels' LDS cut to 17 / 12 KB so that they fit next to the GEMM's four workgroups per CU:
 # they then run concurrently but 2-4x slower (plan_ptr 61 us instead of 15, plan_graph 103 instead of 49), bench.py
 # 2.302-2.312 against 2.3085 ms - nothing - and two processes sharing one GPU (the two-rank bench test) failed.
-PLAN_OVERLAP = _env_int("DAGNN_AMD_PLAN_OVERLAP", 1)              # 1: plan / schedule kernels (+ side effect 1) on the arena's side stream next to encoder + input GEMM (model._plan_of)
+PLAN_OVERLAP = _env_int("DAGNN_AMD_PLAN_OVERLAP", 0)              # 1: training passes launch plan / schedule on the arena's side stream next to encoder + input GEMM (model._plan_of); measured: 13 separate launches 1.64 -> 1.59 ms per forward, the fused pipeline (csrc/prepare.hip) gains nothing from it (fork + join cost what it hides: training step 5.42 against 5.32 ms)
 SIDE_PRIORITY = _env_int("DAGNN_AMD_SIDE_PRIORITY", 0)     # stream priority of an arena's side stream (-1: high)
 FOLD_INPUT = _env_int("DAGNN_AMD_FOLD_INPUT", 1)              # 1: evaluation passes over an ASTNodeEncoder fold the embedding tables through W_ih of stacked layer 0 once per
                                                             # weight version (gi0 = three folded rows summed per node instead of the [N, emb] x [emb, 3H] GEMM; model._folded_tables)

@@ -434,39 +434,51 @@ class DAGNN(nn.Module):
             # the loader packed edge features this model has no encoder for (w_edge_attr=False): the kernels would
             # want an edge gain per feature - build the plan without them here instead
         ea = G.edge_attr if has_edge_enc else None
-        if not (overlap and engine.PLAN_OVERLAP and G.edge_index.is_cuda and self.schedule == "lockstep"):
+        if not (overlap and G.edge_index.is_cuda and self.schedule == "lockstep"):
             if overlap:
                 self._set_layer_index(G)
             return engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B, ea)
         dev = G.edge_index.device
-        cur = torch.cuda.current_stream(dev)
-        side = self._arena_for(G.edge_index).side_stream(dev)
         # the same (width, group count) key `run_stack_lockstep` will ask for: hidden sizes 257..320 run 320 wide on the
         # dataflow kernel (`wide_ok`), a training pass under an active communicator reserves CUs for the collective
         R = 0 if ea is None else int(ea.numel() // max(1, G.edge_index.shape[1]))
         wide_ok = has_edge_enc and not (self.agg_x or self.agg_attn_x)
         Hp = engine.state_width(self.hidden_dim, self.num_layers, R, wide_ok=wide_ok)
-        groups = engine.dataflow_groups(dev, len(self.dirs), self.num_layers, Hp, B, training=self._training_pass()) \
-            if self.schedule == "lockstep" else 0
-        # every buffer comes from the CALLER's pool and is initialised on the caller's stream; only the library's launches
-        # go to the side stream, which forks here and joins at `plan.wait_ready()`
+        groups = engine.dataflow_groups(dev, len(self.dirs), self.num_layers, Hp, B, training=self._training_pass())
+        # every buffer comes from the CALLER's pool (no `record_stream`, no foreign-pool blocks that cannot be reused: a forward
+        # that allocated under a side stream cost seven hipMalloc calls per batch); only the launches may go to a side stream
         plan = engine.build_plan(G.edge_index, G._bi_layer_idx0, G._bi_layer_idx1, G.batch, B, ea, launch=False)
-        sched_ws = plan.dataflow_schedule(groups, launch=False) if groups > 0 else None
-        lidx = torch.empty(4, G._bi_layer_idx0.shape[0], dtype=G._bi_layer_idx0.dtype, device=dev)
-        side.wait_stream(cur)
-        with engine.launch_on(side):
-            plan.launch_build()
-            if sched_ws is not None:
-                plan.dataflow_schedule(groups)
-        plan.ready = torch.cuda.Event()
-        plan.ready.record(side)
-        # side effect 1 BEHIND the plan on the side stream: nothing in forward() reads it, so it runs under the recurrence (beside
-        # the GEMM it would sit on the critical path at a third of its speed: an fp32 MFMA holds its SIMD's issue port); the
-        # caller's stream meets it at the end of forward() (`plan.wait_after`)
-        with torch.cuda.stream(side):   # (allocates nothing: `out=` comes from the caller's pool)
-            self._set_layer_index(G, out=lidx)
-        plan.after = torch.cuda.Event()
-        plan.after.record(side)
+        if groups > 0:
+            plan.dataflow_schedule(groups, launch=False)
+        srcs = [G._bi_layer_idx0, G._bi_layer_index0, G._bi_layer_idx1, G._bi_layer_index1]
+        stack = None
+        if engine.PREPARE_FUSED and all(t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() for t in srcs):
+            stack = (srcs, torch.empty(4, srcs[0].shape[0], dtype=torch.int64, device=dev))
+
+        def launch():
+            if engine.PREPARE_FUSED:   # plan + schedule (+ side effect 1 on its second launch) as one pipeline (csrc/prepare.hip)
+                plan.launch_prepare(groups, stack=stack)
+            else:
+                plan.launch_build()
+                if groups > 0:
+                    plan.dataflow_schedule(groups)
+
+        if engine.PLAN_OVERLAP:
+            # ... on the arena's side stream, next to the encoder and the input GEMM of a training pass, which do not depend on
+            # them; the side stream forks here and joins at `plan.wait_ready()`
+            cur = torch.cuda.current_stream(dev)
+            side = self._arena_for(G.edge_index).side_stream(dev)
+            side.wait_stream(cur)
+            with engine.launch_on(side):
+                launch()
+            plan.ready = torch.cuda.Event()
+            plan.ready.record(side)
+        else:
+            launch()
+        if stack is not None:
+            G.bi_layer_index = stack[1].view(2, 2, -1)   # side effect 1 (dagnn.py:130-133); on the caller's stream after `plan.wait_ready()`
+        else:
+            self._set_layer_index(G)
         return plan
 
     @staticmethod

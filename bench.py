@@ -565,7 +565,7 @@ def main():
             tf_ = time.perf_counter() - t0
         engine.FOLD_INPUT, engine.PREPARE_FUSED, engine.PLAN_OVERLAP = saved
         front_res = {"what": "forward(G) with DAGNN_AMD_PREPARE=0 DAGNN_AMD_FOLD_INPUT=0 DAGNN_AMD_PLAN_OVERLAP=0: plan and "
-                             "dataflow schedule as 13 separate launches, encoder, input GEMM of stacked layer 0 (round 5's path)",
+                             "dataflow schedule as 13 separate launches (the separate entry points), encoder, input GEMM of stacked layer 0",
                      "ms_per_step": round(tf_ / args.steps * 1e3, 4), "graphs_per_s": round(B * args.steps / tf_, 1)}
     # N > 1: the reference's own use of k devices - ONE global batch split by its Collater rule (tg/dataloader.py:17-27,
     # node-balanced contiguous shards) - next to the weak-scaling headline.  Bounded by the shard holding the deepest graph.

@@ -45,10 +45,12 @@ def sources_sha16():
 
 
 def main():
-    fetch_csv, write_csv, forwards = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    fetch_csv, write_csv = sys.argv[1], sys.argv[2]
     out_name = sys.argv[4] if len(sys.argv) > 4 else "pmc_traffic.json"
     ft, fc = fold(fetch_csv)
     wt, _ = fold(write_csv)
+    # "auto": every forward of the command launches the recurrence kernel exactly once, whatever legs bench.py runs
+    forwards = int(sum(fc[k] for k in fc if k.startswith(RECURRENCE))) if sys.argv[3] == "auto" else int(sys.argv[3])
     per = {}
     rec_bytes = 0.0
     for k in sorted(ft, key=lambda k: -ft[k]):
@@ -61,7 +63,7 @@ def main():
             rec_bytes += (2 * f_kib + w_kib) * 1024
     out = {
         "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over `python bench.py "
-                "--steps 2 --warmup 1 --cpu-passes 0 --no-kernel-timer --train-steps 0 --other-configs 0` (%d forwards: the headline leg and the loader-side-plan leg). Counter "
+                "--steps 2 --warmup 1 --cpu-passes 0 --no-kernel-timer --train-steps 0 --other-configs 0` (%d forwards: the headline leg, the loader-side-plan leg and the separate-calls leg; the recurrence kernel is the same in all three). Counter "
                 "unit is KiB (calibrated: encode_ast_kernel WRITE_SIZE = N*H*4 bytes per launch). FETCH_SIZE is "
                 "doubled before use, as MI355X_MICROARCH.md (HBM section) prescribes for wide coalesced reads on "
                 "gfx950; WRITE_SIZE is used as reported. Produced by scripts/pmc_summary.py." % forwards,

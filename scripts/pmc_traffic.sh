@@ -9,5 +9,5 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${name}_fetch -o f 
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${name}_write -o w -- $CMD > gpurun_out/${name}_write.log 2>&1
 F=$(find gpurun_out/${name}_fetch -name "*counter_collection.csv" | head -1)
 W=$(find gpurun_out/${name}_write -name "*counter_collection.csv" | head -1)
-python scripts/pmc_summary.py $F $W 6 $name.json | head -12
+python scripts/pmc_summary.py $F $W auto $name.json | head -12
 cp profiles/$name.json gpurun_out/$name.json

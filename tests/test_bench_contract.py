@@ -61,6 +61,10 @@ def test_committed_round_line_keeps_the_contract(name):
                                            "ogb_tok_h300_L2_B160"}
         assert j["training_step"]["kernels_ms_per_step"]["backward_run"] < 2.0 and j["training_step"]["ms_per_step_median"] > 0
         assert j["loader_side_plan"]["ms_per_step"] < j["ms_per_step"]
+    if name.startswith("r05"):   # round 5: the line says how the front of the recurrence is built, and times the unfused / unfolded path beside it
+        assert "dagnn_prepare" in j["config"]["front_of_recurrence"] and "folded" in j["config"]["front_of_recurrence"]
+        assert j["separate_calls_no_folding"]["ms_per_step"] > j["ms_per_step"] > 0
+        assert j["kernels_ms_per_step"]["prepare"] < 0.15
 
 
 def _run_bench(args, env_extra=None, launcher=()):

@@ -45,10 +45,12 @@ class DerivedCache(object):
     def __init__(self):
         self._key = None
         self._val = None
+        self._built = None   # (event behind the kernels that built the value, stream they ran on, streams that have met it)
 
     def invalidate(self) -> None:
         self._key = None
         self._val = None
+        self._built = None
 
     def get(self, params: Sequence[torch.Tensor], fn: Callable[[], object], fresh: bool = False):
         key = None if fresh else tuple([(p.data_ptr(), p._version, p.device.index) for p in params])
@@ -56,7 +58,31 @@ class DerivedCache(object):
             with torch.no_grad():
                 self._val = fn()
             self._key = key
+            self._built = built_marker(params[0] if params else None)
+        else:
+            meet_built(self._built)
         return self._val
+
+
+def built_marker(t):
+    """(event, stream, seen) behind derived tensors just built on the current stream of `t`'s device - a pass on ANOTHER
+    stream (`bench.py --streams k`, micro-batches in flight) must not read them before the kernels that made them are done."""
+    if t is None or not t.is_cuda:
+        return None
+    st = torch.cuda.current_stream(t.device)
+    ev = torch.cuda.Event()
+    ev.record(st)
+    return (ev, st.cuda_stream, {st.cuda_stream}, t.device)
+
+
+def meet_built(built) -> None:
+    if built is None:
+        return
+    ev, _, seen, dev = built
+    cur = torch.cuda.current_stream(dev)
+    if cur.cuda_stream not in seen:
+        cur.wait_event(ev)
+        seen.add(cur.cuda_stream)
 
 
 def _pad_gate_rows(w: torch.Tensor, H: int, Hp: int) -> torch.Tensor:
@@ -81,7 +107,7 @@ class CellParams(object):
     """Device-side, kernel-ready parameters of one (direction, stacked layer) cell."""
 
     __slots__ = ("w_ih", "b_ih", "w_hh_t", "b_hh", "w_key", "edge_gain", "vid_bias", "w_hh_pk", "w_ih_pk",
-                 "b_ih_dev", "Hp", "key_raw", "w_hh_raw", "w_hh_df", "w_ih_df", "w_hh_bt", "w_ih_bt", "df_ok", "gain_src", "fold")
+                 "b_ih_dev", "Hp", "key_raw", "w_hh_raw", "w_hh_df", "w_ih_df", "w_hh_bt", "w_ih_bt", "df_ok", "gain_src", "fold", "built")
 
 
 def pack_dataflow(cells, transposed_too: bool = False) -> None:
@@ -102,6 +128,8 @@ def pack_dataflow(cells, transposed_too: bool = False) -> None:
     gains = [c for c in cells if c.gain_src is not None]
     if not todo:
         fill_gains(gains)
+        if cells:
+            meet_built(cells[0].built)   # (packed by a pass on another stream, perhaps still in flight)
         return
     packed_all = engine.pack_dataflow_batch([(w, tr) for _, _, w, tr in todo], todo[0][0].Hp,
                                             gains=[(c.gain_src[0], c.gain_src[1], c.edge_gain) for c in gains])
@@ -109,6 +137,9 @@ def pack_dataflow(cells, transposed_too: bool = False) -> None:
         c.gain_src = None
     for (c, name, _, _), packed in zip(todo, packed_all):
         setattr(c, name, packed)
+    marker = built_marker(packed_all[0])
+    for c in cells:
+        c.built = marker
 
 
 def fill_gains(cells) -> None:
@@ -159,6 +190,7 @@ def derive_cell(w_ih, w_hh, b_ih, b_hh, attn_w, H: int, dq: int, in_is_hidden: b
     c = CellParams()
     c.Hp = Hp
     c.fold = None   # (model._folded_tables: the encoder's tables folded through this cell's W_ih, stacked layer 0 only)
+    c.built = None  # (`built_marker` behind the last lazy pack launch: passes on other streams meet it before they read the layouts)
     wi = _pad_gate_rows(w_ih.detach().float(), H, Hp)
     if in_is_hidden:
         wi = _pad_cols(wi, Hp)

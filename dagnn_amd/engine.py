@@ -228,8 +228,9 @@ def _status_words(device) -> torch.Tensor:
     per plan sat on the critical path of every forward (4.4 us + its launch gap) - and a slot is never handed out twice: the
     plan's view keeps its pool alive, an exhausted pool is simply dropped."""
     dev = torch.device(device)
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    pool = _STATUS_POOL.get(key)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, _RAW_STREAM(idx) if _RAW_STREAM is not None else torch.cuda.current_stream(dev).cuda_stream)
+    pool = _STATUS_POOL.get(key)   # one pool per (device, stream): zeroed on, and owned by, the stream whose passes use it
     if pool is None or pool[1] >= pool[0].shape[0]:
         pool = _STATUS_POOL[key] = [torch.zeros(1024, 4, dtype=torch.int32, device=dev), 0]
     pool[1] += 1

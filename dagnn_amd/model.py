@@ -24,7 +24,7 @@ import torch.nn.functional as F
 
 from . import constants as K
 from . import engine
-from .core import DerivedCache, default_schedule, derive_cell, num_graphs_of, pack_lockstep, run_stack
+from .core import DerivedCache, built_marker, default_schedule, derive_cell, meet_built, num_graphs_of, pack_lockstep, run_stack
 
 
 class ASTNodeEncoder(nn.Module):
@@ -265,7 +265,9 @@ class DAGNN(nn.Module):
                 if c.fold is None or c.fold[0] != key:
                     t, a, dp = (engine.gemm_nt_bias([tab.detach()], [c.w_ih], [b])[0]
                                 for tab, b in zip(tabs, (None, None, c.b_ih)))   # (every node takes exactly one depth row: the bias rides on it)
-                    c.fold = (key, (t, a, dp))
+                    c.fold = (key, (t, a, dp), built_marker(t))
+                else:
+                    meet_built(c.fold[2])   # (built by a pass on another stream, perhaps still in flight)
                 out.append(c.fold[1])
         return out
 

@@ -890,6 +890,40 @@ def test_fused_prepare_equals_the_separate_calls_word_for_word(device, monkeypat
     assert torch.equal(ref[3], got[3]) and torch.equal(ref[4], got[4]) and int(got[4].max()) <= 20
 
 
+def test_plan_of_graphs_beyond_the_lds_paths(device, monkeypatch):
+    """`plan_graph_body` has three forms: FAST (<= 1024 nodes, <= 2048 edges: everything read once, placement by LDS masks), SMALL
+    (<= 2048 nodes: LDS arrays, the trip-per-key placement) and the global-memory form.  One batch with a graph of each kind
+    (a 700-node and a 1500-node AST-like tree with skip edges, a 5000-node path with skip edges) - separate calls and the fused
+    pipeline against the host build, word for word."""
+    from dagnn_amd import GraphData, host_plan
+    from dagnn_amd.dag_utils import add_order_info_01
+    monkeypatch.setattr(engine, "PLAN_SMALL", 0)
+
+    def g(n, step):
+        ei = torch.cat([torch.stack([torch.arange(n - 1), torch.arange(1, n)]),
+                        torch.stack([torch.arange(0, n - step, 3), torch.arange(step, n, 3)])], 1)
+        ea = (torch.arange(ei.shape[1] * 2) % 2).float().view(-1, 2)
+        d = GraphData(x=torch.stack([torch.arange(n) % 98, torch.arange(n) % 300], 1), node_depth=(torch.arange(n) % 30).view(-1, 1),
+                      edge_index=ei, edge_attr=ea)
+        add_order_info_01(d)
+        return d
+
+    b = synth.GraphBatch.from_data_list([g(700, 5), g(1500, 7), g(5000, 11), g(30, 2)])
+    B, N = 4, b.x.shape[0]
+    args = [t.to(device) for t in (b.edge_index, b._bi_layer_idx0, b._bi_layer_idx1, b.batch)] + [B, b.edge_attr.to(device)]
+    ws, sched, splits, written = host_plan.build_plan_host(b.edge_index, b._bi_layer_idx0, b._bi_layer_idx1, b.batch, B, b.edge_attr,
+                                                          return_written=True)
+    for fused in (False, True):
+        plan = engine.build_plan(*args, launch=not fused)
+        if fused:
+            plan.launch_prepare(3)
+        torch.cuda.synchronize()
+        assert int(plan.status[0]) == 0
+        assert np.array_equal(ws[written], plan.ws.cpu().numpy()[written]), fused
+        for d in (0, 1):
+            assert np.array_equal(sched[d], plan.read_schedule()[d])
+
+
 def _schedule_words_equal(host, dev, lay, G, whole):
     """Tables word for word; records over what the groups use (`whole`: and the -1 fill of the unused tail)."""
     assert host.shape == dev.shape

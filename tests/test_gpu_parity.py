@@ -849,7 +849,9 @@ def test_fused_prepare_equals_the_separate_calls_word_for_word(device, monkeypat
     b = _degenerate_batch() if seed < 0 else synth.code2_batch(seed, B, mean_n)
     N = b.x.shape[0]
     dev = lambda t: t.to(device)   # noqa: E731
-    args = (dev(b.edge_index), dev(b._bi_layer_idx0), dev(b._bi_layer_idx1), dev(b.batch), B, dev(b.edge_attr))
+    # edge features: the two of ogbg-code2, none (seed 5), three (seed 7: beyond the FAST form of plan_graph_body)
+    ea = None if seed == 5 else torch.cat([b.edge_attr, b.edge_attr[:, :1] * 0.5 + 0.25], 1) if seed == 7 else b.edge_attr
+    args = (dev(b.edge_index), dev(b._bi_layer_idx0), dev(b._bi_layer_idx1), dev(b.batch), B, None if ea is None else dev(ea))
     gen = torch.Generator().manual_seed(3)
     tabs = [[dev(torch.randn(r, w, generator=gen)) for r in (98, 10030, 21)] for w in (64, 192)]
     x = dev(torch.stack([torch.randint(0, 98, (N,), generator=gen), torch.randint(0, 10030, (N,), generator=gen)], 1))

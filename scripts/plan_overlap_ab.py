@@ -1,5 +1,6 @@
-"""A/B of the forward pass with the plan / schedule kernels (a) in line, (b) on the arena's side stream next to encoder + input
-GEMM.  Each variant runs in its own process (the knob is read at import).
+"""A/B harness of the headline forward pass: each variant = a set of environment knobs, run in its own process (the knobs are read at
+import), median of 60 forwards after 10 warm-up passes.  Used for everything in DESIGN.md section 4h (fused pipeline, folded tables,
+side / CU-masked streams, row shares, LPT costs, read-back variants).
   python scripts/plan_overlap_ab.py            # driver
 """
 import os, subprocess, sys, json
@@ -34,10 +35,11 @@ if __name__ == "__main__":
         child()
     else:
         variants = []
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        for rep in range(3):
+        for rep in range(2):   # (edit to taste: every variant is a set of environment knobs read at import)
             variants.append(("default", {}))
-            variants.append(("nt_store", {"DAGNN_AMD_LIB": os.path.join(root, "dagnn_amd/lib/variants/libdagnn_hip_nt.so")}))
+            variants.append(("separate_calls_no_folding", {"DAGNN_AMD_PREPARE": "0", "DAGNN_AMD_FOLD_INPUT": "0"}))
+            variants.append(("fold_only", {"DAGNN_AMD_PREPARE": "0"}))
+            variants.append(("fused_only", {"DAGNN_AMD_FOLD_INPUT": "0"}))
         for name, env in variants:
             e = dict(os.environ); e.update(env)
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=e, capture_output=True, text=True)

@@ -247,7 +247,9 @@ def _warn_off_dataflow(dev, ndirs: int, L: int, Hp: int) -> None:
     import warnings
     cells = ndirs * (2 * L - 1)
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    if Hp == 320:
+    if Hp == 320 and not engine.DF_WIDE:
+        why = "DAGNN_AMD_DF_WIDE=0 keeps hidden sizes 257..320 off the dataflow kernel's 320-wide shape"
+    elif Hp == 320:
         why = "hidden size 320 runs on the dataflow kernel only with exactly two edge features, hidden-state keys and no vertex-id key biases"
     elif Hp > 256:
         why = "hidden size %d > 256 (a 32-unit slice of the [3H, H] matrices no longer fits the register file)" % Hp

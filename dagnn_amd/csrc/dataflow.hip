@@ -184,11 +184,7 @@ __device__ __forceinline__ float df_tanh(float x) { return 1.0f - 2.0f * __built
 //                cw and cw + 4 share a SIMD (a workgroup's waves go to the SIMDs cyclically), so one wave's reduce / gate /
 //                store epilogue issues beside the other's MFMA burst; 16 waves per workgroup = 4 per SIMD at <= 128 VGPRs.
 #ifndef DFF_NCW_V
-#ifdef DF_WIDE_TU
-#define DFF_NCW_V 4
-#else
-#define DFF_NCW_V 8
-#endif
+#define DFF_NCW_V 4   // (8: measured in round 6, 1.50 against 1.33 ms on the headline batch, 9.15 against 8.26 at B = 1024: DESIGN 4a)
 #endif
 constexpr int DFF_NCW = DFF_NCW_V;
 constexpr int DFF_THREADS = 64 * (DFF_NCW + DF_NLW);
@@ -983,6 +979,10 @@ __device__ __forceinline__ float df_row_pair_sum(float x) {
     return a + b;
 }
 
+// element index of (row v, column c) in a buffer of `ld` elements per row: ONE full-rate v_mad_u32_u24 instead of the 64-bit
+// multiply (quarter rate, on the compute wave's serial chain) - v < 2^24 and v * ld + c < 2^31 (the host checks N * ld < 2^31)
+__device__ __forceinline__ unsigned df_idx(int v, int ld, int c) { return __umul24((unsigned)v, (unsigned)ld) + (unsigned)c; }
+
 // ---- compute wave `cw`: hidden units [8 cw, 8 cw + 8) of the slice, every block of the workgroup's streams.
 // The products run on the matrix cores as v_mfma_f32_4x4x1 (16 independent 4 x 4 x 1 outer products per instruction:
 // the only MFMA shape a 4-row block fills).  Lane = (unit quad = lane >> 5, K slice ks = (lane >> 2) & 7, x = lane & 3):
@@ -1030,7 +1030,12 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
 #pragma unroll
         for (int k = 0; k < KP8; ++k) asm volatile("" : "+v"(wr[k]), "+v"(wz[k]), "+v"(wn[k]));
     }
-    const int unit_l = 8 * cw + 4 * quad + 2 * (ks & 1) + ((ks >> 1) & 1), unit = sl * DF_JS + unit_l;   // after the reduction
+    // after the reduction: lane (quad, ks, x) holds unit 4 quad + x of the wave's eight and ROW 2 (ks & 1) + ((ks >> 1) & 1) of the block
+    // (the activations are the MFMA's A operand, the weights its B operand: D register i = row i, lane x = unit x - the four lanes
+    // of a quad store four consecutive units of one row, 32 contiguous bytes of granules; with the operands the other way round
+    // every lane of a store went to another row: 32 eight-byte transactions per instruction, a quarter of the wave's time)
+    const int unit_l = 8 * cw + 4 * quad + x, unit = sl * DF_JS + unit_l;
+    const int row_l = 2 * (ks & 1) + ((ks >> 1) & 1);
     float b_r = C.bias[unit], b_z = C.bias[H + unit], b_n = C.bias[2 * H + unit];
     asm volatile("" : "+v"(b_r), "+v"(b_z), "+v"(b_n));   // landed before the loop (see the weights above)
     const int apos = unit + (SEG - KP8) * (unit / KP8);   // LDS position of column `unit` of an operand row
@@ -1047,178 +1052,179 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     // Blocks of the two streams in whatever order they become ready.  A stream inside a thin dependent chain is ready
     // once per hop (~3 us, of which this wave works ~0.8): the other stream's blocks fill the gap.  When both have a
     // block, the one whose loader is LESS far ahead goes first (it is the latency-bound one); ties alternate.
-    int done[DF_NLS];
-    int left = 0, pref = 0;
-#pragma unroll
-    for (int q = 0; q < DF_NLS; ++q) { done[q] = 0; left += nb[q]; }
-    while (left > 0) {
-        int st = -1;
-        if (DF_LEAN_COMPUTE && DF_NLS == 2 && DF_WPS == 4) {
-            // the same choice (smallest positive lead first, ties alternate) with ONE trip to LDS per look: the 2 x 4 ready
-            // flags are two ds_read_b128 behind one wait (asm: a compiler-visible LDS access next to LDS-DMA traffic is fenced
-            // with vmcnt(0)), the rest is scalar
-            typedef int i4v __attribute__((ext_vector_type(4)));
-            const unsigned rdy_a = (unsigned)(uintptr_t)lds.rdy;
-            unsigned spins = 0;
-            for (;;) {
-                i4v r0, r1;
-                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(r0), "=&v"(r1) : "v"(rdy_a) : "memory");
-                const int m0 = __builtin_amdgcn_readfirstlane(min(min(r0.x, r0.y), min(r0.z, r0.w)));
-                const int m1 = __builtin_amdgcn_readfirstlane(min(min(r1.x, r1.y), min(r1.z, r1.w)));
-                const int l0 = done[0] < nb[0] ? m0 - done[0] : 0, l1 = done[1] < nb[1] ? m1 - done[1] : 0;
-                if (l0 > 0 || l1 > 0) {
-                    st = l0 <= 0 ? 1 : (l1 <= 0 ? 0 : (l0 != l1 ? (l0 < l1 ? 0 : 1) : pref));
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(DF_CSLEEP_N);
-                bool give_up = false;
-                if (++spins > 4 * spin_limit) {   // the pass is lost; it must still end (node ids are bounded below)
-                    __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    give_up = true;
-                }
-                if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = true;
-                if (give_up) {
-                    st = done[0] < nb[0] ? 0 : 1;
-                    break;
+    //
+    // Round 6: what a block costs this wave was measured with subtractive builds on a free-running compute wave (-DDF_EXP_*,
+    // B = 1024): 0.89 us = products 0.40 + reduction and gates 0.11 + the look at the flags 0.11 + ~0.25 of bookkeeping, and
+    // NOT latencies - moving 40 vector instructions into the products' shadow, or the stores' lanes onto contiguous bytes,
+    // changed nothing: ONE wave issues an instruction every ~8 cycles whatever it is, so the block costs its instruction
+    // count.  Hence the shape of this loop: all bookkeeping scalar and branch-free (m0 / m1 = the ready counts as last seen;
+    // a loader never passes its stream's block count, so m - done is the lead without further conditions), the next look at
+    // the flags as two ds_read_b128 issued behind the last product (its verdict is there when the block ends), one LDS word
+    // per lane for the row's node id (no select chain, no live-row count), the done flag stored without a predicate (the
+    // other lanes write into a dump area), the gates evaluated by every lane, the store variants hoisted out of the loop.
+    typedef int i4v __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const volatile i4v* lds_i4p;
+    const lds_i4p rdy_p = (lds_i4p)(unsigned)(uintptr_t)lds.rdy;
+    const bool lane_st = (lane & 16) == 0;   // (lanes 16 away hold the same sums)
+    // done flag: lane 0 writes dn[st][cw], the others a word of their own in the dump area
+    int* const dn_or_dump0 = lane == 0 ? lds.dn + 0 * DFF_NCW + cw : reinterpret_cast<int*>(lds.bias) + lane;
+    int* const dn_or_dump1 = lane == 0 ? lds.dn + (DF_NLS - 1) * DFF_NCW + cw : reinterpret_cast<int*>(lds.bias) + lane;
+    const int nb0 = nb[0], nb1 = DF_NLS > 1 ? nb[DF_NLS - 1] : 0;
+    static_assert(DF_NLS == 2, "two streams per workgroup");
+
+    auto run = [&](auto local_c, auto aux_c) {
+        constexpr bool LOCAL = decltype(local_c)::value, AUX = decltype(aux_c)::value;
+        int done0 = 0, done1 = 0, pref = 0;
+        int m0 = 0, m1 = 0;   // blocks the streams' loaders had finished at the last look (wave-uniform)
+        auto flags_min = [&](const i4v& r0, const i4v& r1) {   // DF_WPS flags per stream, stream-major
+            if (DF_WPS == 4) {
+                m0 = __builtin_amdgcn_readfirstlane(min(min(r0.x, r0.y), min(r0.z, r0.w)));
+                m1 = __builtin_amdgcn_readfirstlane(min(min(r1.x, r1.y), min(r1.z, r1.w)));
+            } else {
+                m0 = __builtin_amdgcn_readfirstlane(min(r0.x, r0.y));
+                m1 = __builtin_amdgcn_readfirstlane(min(r0.z, r0.w));
+            }
+        };
+        static_assert(DF_WPS == 4 || DF_WPS == 2, "");
+        for (int left = nb0 + nb1; left > 0; --left) {
+            int l0 = m0 - done0, l1 = m1 - done1;   // leads (>= 0: a loader stops at its stream's last block)
+#ifdef DF_EXP_NOLOOK   // timing experiment: no look at the ready flags (only meaningful with DF_EXP_NOLOAD)
+            l0 = nb0 - done0; l1 = nb1 - done1;
+#endif
+            if (l0 <= 0 && l1 <= 0) {   // nothing known to be ready: look until there is
+                unsigned spins = 0;
+                for (;;) {
+                    const i4v r0 = rdy_p[0], r1 = DF_WPS == 4 ? rdy_p[1] : r0;
+                    flags_min(r0, r1);
+                    l0 = m0 - done0; l1 = m1 - done1;
+                    if (l0 > 0 || l1 > 0) break;
+                    __builtin_amdgcn_s_sleep(DF_CSLEEP_N);
+                    bool give_up = false;
+                    if (++spins > 4 * spin_limit) {   // the pass is lost; it must still end (node ids are bounded below)
+                        __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        give_up = true;
+                    }
+                    if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = true;
+                    if (give_up) { l0 = nb0 - done0; l1 = nb1 - done1; break; }
                 }
             }
-        } else {
-            unsigned spins = 0;
-            for (;;) {
-                // lead of a stream = blocks its loader has finished beyond what this wave has consumed; the smallest
-                // positive lead goes first, ties round-robin starting behind the last stream served
-                int best = 0x7fffffff;
-#pragma unroll
-                for (int e = 0; e < DF_NLS; ++e) {
-                    int r = df_flag_ld(lds.rdy + e * DF_WPS);
-#pragma unroll
-                    for (int x2 = 1; x2 < DF_WPS; ++x2) r = min(r, df_flag_ld(lds.rdy + e * DF_WPS + x2));
-                    const int lead = done[e] < nb[e] ? r - done[e] : 0;
-                    const int key = lead * DF_NLS + ((e - pref + DF_NLS) % DF_NLS);
-                    if (lead > 0 && key < best) { best = key; st = e; }
-                }
-                if (st >= 0) break;
-                __builtin_amdgcn_s_sleep(DF_CSLEEP_N);
-                bool give_up = false;
-                if (++spins > 4 * spin_limit) {   // the pass is lost; it must still end (node ids are bounded below)
-                    __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    give_up = true;
-                }
-                if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = true;
-                if (give_up) {
-#pragma unroll
-                    for (int e = DF_NLS - 1; e >= 0; --e) if (done[e] < nb[e]) st = e;
-                    break;
-                }
-            }
-        }
-        st = __builtin_amdgcn_readfirstlane(st);
-        pref = (st + 1) % DF_NLS;
-        int b = 0;
-#pragma unroll
-        for (int e = 0; e < DF_NLS; ++e) if (e == st) { b = done[e]; ++done[e]; }
-        --left;
-        const int slot = b % DF_NSLOT;
-        const float* sbase = lds.ring + (st * DF_NSLOT + slot) * Slot::words;
-        if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 0] = wall_clock64();
-        const int4 ids = *reinterpret_cast<const int4*>(sbase + Slot::v_off);
-        const int nr = __builtin_amdgcn_readfirstlane((ids.x >= 0) + (ids.y >= 0) + (ids.z >= 0) + (ids.w >= 0));   // live records come first
-        if (prof) dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + st) + 0] = wall_clock64();   // ids landed
-        const int gr = x;                 // row of the block this lane evaluates the gates of
-        const int unit_ls = unit_l;       // ... and its unit inside the slice
-        const int unit_s = unit;
-        // operands of the gate algebra: requested now, used after the products
-        float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, aval = 0.f;
-        const float c_r = b_r, c_z = b_z, c_n = b_n;
-        // (nothing in front of the products depends on the ids: every LDS read of the block - ids, gate operands, operand
-        // rows - leaves in one go; a dead row's lanes read their slot's stale words and drop them)
-        if (!proj) {
-            if (has_gi) {   // from the gi0 ring (stacked layer 0) or from the slot (projection granules)
-                const float* gp = (gi_ring ? lds.giring + (st * DF_GIRING + b % DF_GIRING) * (DF_RB * 3 * DF_JS) : sbase + Slot::gi_off) + gr * (3 * DF_JS) + unit_ls;
+            // smallest positive lead first, ties alternate
+            const bool take0 = l0 > 0 && (l1 <= 0 || l0 < l1 || (l0 == l1 && pref == 0));
+            const int st = take0 ? 0 : 1;
+            pref = st ^ 1;
+            const int b = take0 ? done0 : done1;
+            done0 += take0 ? 1 : 0;
+            done1 += take0 ? 0 : 1;
+            const float* sbase = lds.ring + (st * DF_NSLOT + (b & (DF_NSLOT - 1))) * Slot::words;
+            static_assert((DF_NSLOT & (DF_NSLOT - 1)) == 0 && (DF_GIRING & (DF_GIRING - 1)) == 0, "ring sizes are powers of two");
+            if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 0] = wall_clock64();
+            // every LDS read of the block leaves in one go: the row's node id, the gate operands, the operand rows (a dead
+            // row's lanes read their slot's stale words and drop them)
+            const int gv = reinterpret_cast<const int*>(sbase + Slot::v_off)[row_l];
+            float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, aval = 0.f;
+            if (!proj) {   // from the gi0 ring (stacked layer 0) or from the slot (projection granules)
+                const float* gp = (gi_ring ? lds.giring + (st * DF_GIRING + (b & (DF_GIRING - 1))) * (DF_RB * 3 * DF_JS) : sbase + Slot::gi_off) +
+                                  row_l * (3 * DF_JS) + unit_l;
                 gi_r = gp[0]; gi_z = gp[DF_JS]; gi_n = gp[2 * DF_JS];
+                aval = sbase[Slot::a_off + row_l * Slot::AP + apos];
             }
-            aval = sbase[Slot::a_off + gr * Slot::AP + apos];
-        }
-        float g3[3] = {0.f, 0.f, 0.f};
-        {
-            const float* a_seg = sbase + Slot::a_off + x * Slot::AP + ks * SEG;   // B operand: row x, K slice ks
-            float4 bv[NK4];
+            float g3[3];
+            float rg = 0.f, zg = 0.f;
+            {
+                const float* a_seg = sbase + Slot::a_off + x * Slot::AP + ks * SEG;   // A operand: row x, K slice ks
+                float4 bv[NK4];
 #pragma unroll
-            for (int q = 0; q < NK4; ++q) bv[q] = *reinterpret_cast<const float4*>(a_seg + 4 * q);
-            f4v acc[3] = {(f4v){0.f, 0.f, 0.f, 0.f}, (f4v){0.f, 0.f, 0.f, 0.f}, (f4v){0.f, 0.f, 0.f, 0.f}};
+                for (int q = 0; q < NK4; ++q) bv[q] = *reinterpret_cast<const float4*>(a_seg + 4 * q);
+#ifdef DF_EXP_NOOPLD   // timing experiment: no operand reads from LDS
 #pragma unroll
-            for (int q = 0; q < NK4; ++q) {
-                const float bq[4] = {bv[q].x, bv[q].y, bv[q].z, bv[q].w};
+                for (int q = 0; q < NK4; ++q) bv[q] = make_float4(wr[q], wz[q], wn[q], aval);
+#endif
+                f4v acc[3] = {(f4v){0.f, 0.f, 0.f, 0.f}, (f4v){0.f, 0.f, 0.f, 0.f}, (f4v){0.f, 0.f, 0.f, 0.f}};
+                // reduce-scatter of one gate's accumulators over the 8 K slices
+                // (every DPP op outside the selects: inside a divergent branch its source lanes would be switched off)
+                auto reduce = [&](const f4v& A) -> float {
+                    const float u0 = A[0] + df_dpp<0x104>(A[0]), u1 = A[1] + df_dpp<0x104>(A[1]);   // + the lane 4 up
+                    const float u2 = A[2] + df_dpp<0x114>(A[2]), u3 = A[3] + df_dpp<0x114>(A[3]);   // + the lane 4 down
+                    const float e0 = s0 ? u2 : u0, e1 = s0 ? u3 : u1;   // rows (2, 3) | (0, 1) of the block
+                    const float f0 = e0 + df_dpp<0x108>(e0), f1 = e1 + df_dpp<0x118>(e1);
+                    return df_row_pair_sum(s1 ? f1 : f0);
+                };
+#pragma unroll
+                for (int q = 0; q < NK4; ++q) {
+                    const float bq[4] = {bv[q].x, bv[q].y, bv[q].z, bv[q].w};
 #ifdef DF_EXP_NOMFMA   // timing experiment: everything but the products
-                if (q < 3) acc[q] += (f4v){bq[0] * wr[q], bq[1] * wz[q], bq[2] * wn[q], bq[3]};
+                    if (q < 3) acc[q] += (f4v){bq[0] * wr[q], bq[1] * wz[q], bq[2] * wn[q], bq[3]};
 #else
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q + e], bq[e], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wz[4 * q + e], bq[e], acc[1], 0, 0, 0);
-                    acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(wn[4 * q + e], bq[e], acc[2], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(bq[e], wr[4 * q + e], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(bq[e], wz[4 * q + e], acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(bq[e], wn[4 * q + e], acc[2], 0, 0, 0);
+                    }
+#endif
+                }
+#ifndef DF_EXP_NOLOOK
+                {   // the look for the NEXT block: issued behind the last product, read at the top of the next iteration
+                    __builtin_amdgcn_sched_barrier(0);
+                    const i4v r0 = rdy_p[0], r1 = DF_WPS == 4 ? rdy_p[1] : r0;
+#endif
+#ifdef DF_EXP_NOEPI   // timing experiment: no reduction, no gates
+#pragma unroll
+                for (int a = 0; a < 3; ++a) g3[a] = acc[a][0] + acc[a][1] + acc[a][2] + acc[a][3];
+#else
+#pragma unroll
+                for (int a = 0; a < 3; ++a) g3[a] = reduce(acc[a]);
+#endif
+#ifndef DF_EXP_NOLOOK
+                    flags_min(r0, r1);
                 }
 #endif
             }
-            // reduce-scatter over the 8 K slices
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-#ifdef DF_EXP_NOEPI   // timing experiment: no reduction (and no gates below)
-                g3[a] = acc[a][0] + acc[a][1] + acc[a][2] + acc[a][3];
-                continue;
-#endif
-                        // (every DPP op outside the selects: inside a divergent branch its source lanes would be switched off)
-                const float u0 = acc[a][0] + df_dpp<0x104>(acc[a][0]), u1 = acc[a][1] + df_dpp<0x104>(acc[a][1]);   // + the lane 4 up
-                const float u2 = acc[a][2] + df_dpp<0x114>(acc[a][2]), u3 = acc[a][3] + df_dpp<0x114>(acc[a][3]);   // + the lane 4 down
-                const float e0 = s0 ? u2 : u0, e1 = s0 ? u3 : u1;   // units (2, 3) | (0, 1) of the quad
-                const float f0 = e0 + df_dpp<0x108>(e0), f1 = e1 + df_dpp<0x118>(e1);
-                const float f = s1 ? f1 : f0;
-                g3[a] = df_row_pair_sum(f);
-            }
-        }
-        if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 1] = wall_clock64();
-        // (the bound on the node id only matters once a wait has expired and the slot may hold anything: the pass is
-        // lost then, but it must not write outside its buffers)
-        int gv = gr == 0 ? ids.x : (gr == 1 ? ids.y : (gr == 2 ? ids.z : ids.w));
-        const bool live = gr < nr && (unsigned)gv < (unsigned)num_nodes && (lane & 16) == 0;   // (lanes 16 away hold the same sums)
-        float hv = 0.f;
-        if (live) {
-            if (!proj) {
+            if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 1] = wall_clock64();
+            const float p_r = g3[0] + b_r, p_z = g3[1] + b_z, p_n = g3[2] + b_n;   // W a + b: the cell's pre-activations
+            float hv = 0.f;
+            if (!proj) {   // (every lane: no branch around the gates)
 #ifdef DF_EXP_NOEPI
-                hv = g3[0] + c_r + gi_r + g3[1] + c_z + gi_z + g3[2] + c_n + gi_n + aval;
+                hv = p_r + gi_r + p_z + gi_z + p_n + gi_n + aval;
 #else
-                const float rg = df_sigm(g3[0] + c_r + gi_r);
-                const float zg = df_sigm(g3[1] + c_z + gi_z);
-                const float ng = df_tanh(fmaf(rg, g3[2] + c_n, gi_n));
+                rg = df_sigm(p_r + gi_r);
+                zg = df_sigm(p_z + gi_z);
+                const float ng = df_tanh(fmaf(rg, p_n, gi_n));
                 hv = fmaf(zg, aval - ng, ng);   // n + z * (a - n)
 #endif
             }
-        }
-        if (prof) { asm volatile("" :: "v"(hv)); dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + st) + 3] = wall_clock64(); }   // gates done
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) df_flag_st(lds.dn + st * DFF_NCW + cw, b + 1);   // this wave is done with the slot (LDS executes a wave's accesses in order)
-        if (live) {
-            if (proj) {   // input-side pre-activations of the upper cell: W_ih u + b_ih, gate-major
-                gran_t* po = g_out + (int64_t)gv * pld + unit_s;
-                __hip_atomic_store(po, gran_pack(epoch, g3[0] + c_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(po + H, gran_pack(epoch, g3[1] + c_z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(po + 2 * H, gran_pack(epoch, g3[2] + c_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                // hand-off store first (the consumers poll it): write-through (sc1: the line leaves this XCD's L2, any XCD's sc1
-                // load finds it in memory), or - all readers are on this XCD - a plain 8-byte store that leaves the line in the
-                // shared L2; the plain state row behind it
-                if (local_st) g_out[(int64_t)gv * gld + unit_s] = gran_pack(epoch, hv);
-                else __hip_atomic_store(g_out + (int64_t)gv * gld + unit_s, gran_pack(epoch, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                h_out[(int64_t)gv * ld_h + unit_s] = hv;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            df_flag_st(take0 ? dn_or_dump0 : dn_or_dump1, b + 1);   // this wave is done with the slot (LDS executes a wave's accesses in order)
+#ifdef DF_EXP_NOSTORE   // timing experiment: no global stores (only meaningful with DF_EXP_NOLOAD: nobody polls)
+            asm volatile("" :: "v"(hv), "v"(p_r), "v"(p_z), "v"(p_n), "v"(gv));
+            if (num_nodes > 0) continue;
+#endif
+            // (the bound on the node id also covers padding rows, id -1, and a slot that may hold anything once a wait has
+            // expired: the pass is lost then, but it must not write outside its buffers)
+            if (lane_st && (unsigned)gv < (unsigned)num_nodes) {
+                if (proj) {   // input-side pre-activations of the upper cell: W_ih u + b_ih, gate-major
+                    gran_t* po = g_out + df_idx(gv, pld, unit);
+                    __hip_atomic_store(po, gran_pack(epoch, p_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(po + H, gran_pack(epoch, p_z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(po + 2 * H, gran_pack(epoch, p_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    // hand-off store first (the consumers poll it): write-through (sc1: the line leaves this XCD's L2, any XCD's
+                    // sc1 load finds it in memory), or - all readers are on this XCD - a plain 8-byte store that leaves the line in
+                    // the shared L2; the plain state row behind it
+                    if (LOCAL) g_out[df_idx(gv, gld, unit)] = gran_pack(epoch, hv);
+                    else __hip_atomic_store(g_out + df_idx(gv, gld, unit), gran_pack(epoch, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    h_out[df_idx(gv, ld_h, unit)] = hv;
+                }
+                if (AUX) {   // (behind the hand-off stores: nobody waits for these)
+                    float* ao = aux_out + df_idx(gv, 3 * H, unit);
+                    ao[0] = p_r; ao[H] = p_z; ao[2 * H] = p_n;
+                }
             }
-            if (aux_out) {   // (behind the hand-off stores: nobody waits for these)
-                float* ao = aux_out + (int64_t)gv * (3 * H) + unit_s;
-                ao[0] = g3[0] + c_r; ao[H] = g3[1] + c_z; ao[2 * H] = g3[2] + c_n;
-            }
+            if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 2] = wall_clock64();
         }
-        if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 2] = wall_clock64();
-    }
+    };
+    if (local_st) { if (aux_out) run(std::true_type(), std::true_type()); else run(std::true_type(), std::false_type()); }
+    else { if (aux_out) run(std::false_type(), std::true_type()); else run(std::false_type(), std::false_type()); }
 }
 
 // x + (x of the lane 32 away): v_permlane32_swap on two copies of x leaves the low half of the wave in both halves of one
@@ -1745,6 +1751,10 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
     if (pl->B == 0 || pl->N == 0) return DAGNN_OK;
     // row offsets inside the granule buffers are 32-bit in the kernel (granules: 8 bytes each)
     if ((int64_t)pl->N * a->gld >= (1ll << 31) || (int64_t)pl->N * a->pld >= (1ll << 31)) return DAGNN_EINVAL;
+    // ... and the compute waves index every row-major buffer with a 24 x 24 -> 32-bit multiply-add (df_idx)
+    if (pl->N >= (1 << 24) || (int64_t)pl->N * a->ld_h >= (1ll << 31) || (int64_t)pl->N * 3 * H >= (1ll << 31) || a->ld_h >= (1 << 24) ||
+        a->gld >= (1 << 24) || a->pld >= (1 << 24))
+        return DAGNN_EINVAL;
     DfArgs S;
     int nc = 0;
     for (int d = 0; d < 2; ++d) {

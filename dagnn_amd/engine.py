@@ -118,7 +118,26 @@ def _span(name, tensor):
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
-_LAUNCH_ON = []   # innermost `launch_on` stream (the module is used from one thread per device context)
+import threading
+
+_LAUNCH_TLS = threading.local()   # per thread: stack of `launch_on` streams (the reference's DataParallel runs one thread per
+                                  # device, tg/data_parallel.py:59-62: one thread's override must not redirect another's launches)
+
+
+def _launch_stack() -> list:
+    st = getattr(_LAUNCH_TLS, "stack", None)
+    if st is None:
+        st = _LAUNCH_TLS.stack = []
+    return st
+
+
+def _stream_obj(device):
+    """The stream library launches go to for `device`: the innermost `launch_on` stream of this thread, else torch's current
+    stream.  `_stream` (raw handle) and `persistent_launch` (events) both resolve it here."""
+    st = _launch_stack()
+    if st and st[-1] is not None:
+        return st[-1]
+    return torch.cuda.current_stream(device)
 
 
 class launch_on(object):
@@ -131,19 +150,20 @@ class launch_on(object):
         self.stream = stream
 
     def __enter__(self):
-        _LAUNCH_ON.append(self.stream.cuda_stream if self.stream is not None else None)
+        _launch_stack().append(self.stream)
         return self
 
     def __exit__(self, *exc):
-        _LAUNCH_ON.pop()
+        _launch_stack().pop()
         return False
 
 
 def _stream(t: torch.Tensor) -> int:
     """Raw hipStream_t of torch's current stream on the tensor's device (the Stream object costs ~1.5 us per call and
     the small-batch forward asks seven times)."""
-    if _LAUNCH_ON and _LAUNCH_ON[-1] is not None:
-        return _LAUNCH_ON[-1]
+    st = getattr(_LAUNCH_TLS, "stack", None)
+    if st and st[-1] is not None:
+        return st[-1].cuda_stream
     if _RAW_STREAM is not None:
         return _RAW_STREAM(t.device.index if t.device.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(t.device).cuda_stream
@@ -170,7 +190,7 @@ class persistent_launch(object):
     def __enter__(self):
         if self.dev.type != "cuda":
             return self
-        cur = torch.cuda.current_stream(self.dev)
+        cur = _stream_obj(self.dev)   # (the stream the kernel really goes to: a `launch_on` override counts)
         rec = persistent_launch._last.get(self.dev.index)
         if rec is not None and rec[1] != cur.cuda_stream:
             cur.wait_event(rec[0])
@@ -179,7 +199,7 @@ class persistent_launch(object):
     def __exit__(self, *exc):
         if self.dev.type != "cuda":
             return False
-        cur = torch.cuda.current_stream(self.dev)
+        cur = _stream_obj(self.dev)
         rec = persistent_launch._last.get(self.dev.index)
         ev = rec[0] if (rec is not None and rec[1] == cur.cuda_stream) else torch.cuda.Event()
         ev.record(cur)   # (a waiter that was queued on an earlier record of this event keeps that earlier record)
@@ -299,12 +319,6 @@ class PlanHandle(object):
                                     _stream(edge_index)), "dagnn_prepare")
         if key is not None and key in self.__dict__.get("_df_pending", {}):
             self._df[key] = self._df_pending.pop(key)
-
-    def wait_after(self) -> None:
-        """Order the caller's stream behind what `model._plan_of` queued on the side stream BEHIND the plan."""
-        ev = self.__dict__.pop("after", None)
-        if ev is not None:
-            torch.cuda.current_stream(self.ws.device).wait_event(ev)
 
     def wait_ready(self) -> None:
         """Order the caller's stream behind the plan's construction (no-op for a plan built on this stream)."""
@@ -1208,7 +1222,19 @@ def bwd_dataflow_groups(device, num_dirs: int, num_stacked: int, H: int, B: int)
     return dataflow_groups(device, num_dirs, num_stacked, H, B, training=True)
 
 
-BWD_DF_MAX_BYTES = _env_int("DAGNN_AMD_BWD_DF_MAX_BYTES", 96 << 30)   # cap on what the reverse dataflow sweep may keep (a third of 288 GB)
+# cap on what the reverse dataflow sweep may keep: unset (-1) = a third of the device's memory (96 GB on an MI355X); a value is
+# taken as it is - 0 switches the reverse dataflow sweep off (every training pass then takes the reverse lock-step launches)
+BWD_DF_MAX_BYTES = _env_int("DAGNN_AMD_BWD_DF_MAX_BYTES", -1)
+
+
+_TOTAL_MEMORY = {}
+
+
+def _total_memory(device) -> int:
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _TOTAL_MEMORY:
+        _TOTAL_MEMORY[key] = int(torch.cuda.get_device_properties(key).total_memory)
+    return _TOTAL_MEMORY[key]
 
 
 def bwd_dataflow_fits(device, N: int, cells: int) -> bool:
@@ -1216,11 +1242,15 @@ def bwd_dataflow_fits(device, N: int, cells: int) -> bool:
     (`dagnn_bwd_dataflow_static_bytes`) whatever H is, plus - about as much again, twice at H = 256 - the 256-byte
     successor records, the hand-off granules (`da`, `dgi`, `du`) and the forward pass's pre-activations: ~1.5 GB for the
     headline batch, tens of GB for a very large batch at H = 64.  The choice between the sweep and the reverse
-    lock-step launches (`backward_sweep`, which need none of it) is a pure function of (N, cells) and a FIXED byte cap
-    (`DAGNN_AMD_BWD_DF_MAX_BYTES`, default a third of an MI355X's 288 GB) - not of the memory that happens to be free - so
-    every rank and every step takes the same reverse path and gradients stay bitwise reproducible run to run."""
+    lock-step launches (`backward_sweep`, which need none of it) is a pure function of (device model, N, cells): the byte cap
+    is a third of the device's TOTAL memory (96 GB on an MI355X; `DAGNN_AMD_BWD_DF_MAX_BYTES` overrides it, 0 = never) - not
+    of the memory that happens to be free - so every rank and every step takes the same reverse path and gradients stay
+    bitwise reproducible run to run, and a smaller device falls back to the launches instead of running out of memory."""
     need = int(_lib.load().dagnn_bwd_dataflow_static_bytes(int(N))) * int(cells) * 3   # records x 1.25 (H = 320) + granules + preact
-    return need <= BWD_DF_MAX_BYTES
+    cap = BWD_DF_MAX_BYTES
+    if cap < 0:
+        cap = _total_memory(device) // 3
+    return need <= cap
 
 
 def bwd_dataflow_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, h, gi0, g_ext, groups: int,

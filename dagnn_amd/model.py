@@ -548,7 +548,6 @@ class DAGNN(nn.Module):
             # (scripts/ogb_tok.sh), otherwise differentiable states and the torch read-outs below
             from .autograd import Recurrence
             res = Recurrence.apply(self, plan, B, fused_readout, x, *self._train_params())
-            plan.wait_after()
             flat = res[1:] if fused_readout else res
             h = [[None] * L for _ in range(2)]
             for q, d in enumerate(dirs):
@@ -562,7 +561,6 @@ class DAGNN(nn.Module):
         sscore = self._static_scores(x, cells)
         h = run_stack(plan, x, cells, dirs, L, H, schedule=self.schedule, static_score=sscore,
                       arena=self._arena_for(x), gi0=self._folded_gi0(x_idx, depth, cells))
-        plan.wait_after()
         return self._finish(G, plan, x, h, B)
 
     def _heads(self, out):

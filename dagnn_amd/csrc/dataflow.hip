@@ -1067,8 +1067,8 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     const lds_i4p rdy_p = (lds_i4p)(unsigned)(uintptr_t)lds.rdy;
     const bool lane_st = (lane & 16) == 0;   // (lanes 16 away hold the same sums)
     // done flag: lane 0 writes dn[st][cw], the others a word of their own in the dump area
-    int* const dn_or_dump0 = lane == 0 ? lds.dn + 0 * DFF_NCW + cw : reinterpret_cast<int*>(lds.bias) + lane;
-    int* const dn_or_dump1 = lane == 0 ? lds.dn + (DF_NLS - 1) * DFF_NCW + cw : reinterpret_cast<int*>(lds.bias) + lane;
+    int* const dn_or_dump = lane == 0 ? lds.dn + cw : reinterpret_cast<int*>(lds.bias) + lane;
+    const int dn_step = lane == 0 ? DFF_NCW : 0;   // (words between the two streams' flags)
     const int nb0 = nb[0], nb1 = DF_NLS > 1 ? nb[DF_NLS - 1] : 0;
     static_assert(DF_NLS == 2, "two streams per workgroup");
 
@@ -1108,13 +1108,14 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
                     if (give_up) { l0 = nb0 - done0; l1 = nb1 - done1; break; }
                 }
             }
-            // smallest positive lead first, ties alternate
-            const bool take0 = l0 > 0 && (l1 <= 0 || l0 < l1 || (l0 == l1 && pref == 0));
-            const int st = take0 ? 0 : 1;
+            // smallest positive lead first, ties alternate - as ONE unsigned comparison: key = (lead - 1) << 1 | (1 if the
+            // stream was served last); no lead wraps to the largest keys
+            const unsigned k0 = ((unsigned)(l0 - 1) << 1) | (unsigned)pref, k1 = ((unsigned)(l1 - 1) << 1) | (unsigned)(pref ^ 1);
+            const int st = k1 < k0 ? 1 : 0;
             pref = st ^ 1;
-            const int b = take0 ? done0 : done1;
-            done0 += take0 ? 1 : 0;
-            done1 += take0 ? 0 : 1;
+            const int b = st ? done1 : done0;
+            done0 += st ^ 1;
+            done1 += st;
             const float* sbase = lds.ring + (st * DF_NSLOT + (b & (DF_NSLOT - 1))) * Slot::words;
             static_assert((DF_NSLOT & (DF_NSLOT - 1)) == 0 && (DF_GIRING & (DF_GIRING - 1)) == 0, "ring sizes are powers of two");
             if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 0] = wall_clock64();
@@ -1135,19 +1136,31 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
                 float4 bv[NK4];
 #pragma unroll
                 for (int q = 0; q < NK4; ++q) bv[q] = *reinterpret_cast<const float4*>(a_seg + 4 * q);
+                __builtin_amdgcn_sched_barrier(0);   // (every read in flight before the first product: left alone the scheduler
+                                                     // sinks them between the products, two registers ahead of their use)
 #ifdef DF_EXP_NOOPLD   // timing experiment: no operand reads from LDS
 #pragma unroll
                 for (int q = 0; q < NK4; ++q) bv[q] = make_float4(wr[q], wz[q], wn[q], aval);
 #endif
                 f4v acc[3] = {(f4v){0.f, 0.f, 0.f, 0.f}, (f4v){0.f, 0.f, 0.f, 0.f}, (f4v){0.f, 0.f, 0.f, 0.f}};
                 // reduce-scatter of one gate's accumulators over the 8 K slices
-                // (every DPP op outside the selects: inside a divergent branch its source lanes would be switched off)
+                // (six DPP additions whose bank masks do the selecting: lanes with ks bit 0 clear keep rows (0, 1) and add the
+                // lane 4 up, the others rows (2, 3) and the lane 4 down; then the same over ks bit 1 and 8 lanes.  Inline asm: the
+                // destination is written under a mask, which the builtins cannot express; the wait states in front of a DPP
+                // read of a fresh result - 6 behind an MFMA, 2 behind a vector instruction - are written out, the compiler
+                // inserts none around asm.  Same additions in the same order as the select form.)
                 auto reduce = [&](const f4v& A) -> float {
-                    const float u0 = A[0] + df_dpp<0x104>(A[0]), u1 = A[1] + df_dpp<0x104>(A[1]);   // + the lane 4 up
-                    const float u2 = A[2] + df_dpp<0x114>(A[2]), u3 = A[3] + df_dpp<0x114>(A[3]);   // + the lane 4 down
-                    const float e0 = s0 ? u2 : u0, e1 = s0 ? u3 : u1;   // rows (2, 3) | (0, 1) of the block
-                    const float f0 = e0 + df_dpp<0x108>(e0), f1 = e1 + df_dpp<0x118>(e1);
-                    return df_row_pair_sum(s1 ? f1 : f0);
+                    float e0, e1, f;
+                    asm("s_nop 5\n\t"
+                        "v_add_f32_dpp %0, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                        "v_add_f32_dpp %1, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                        "v_add_f32_dpp %0, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                        "v_add_f32_dpp %1, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                        "s_nop 1\n\t"
+                        "v_add_f32_dpp %2, %0, %0 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+                        "v_add_f32_dpp %2, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xc"
+                        : "=&v"(e0), "=&v"(e1), "=&v"(f) : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]));
+                    return df_row_pair_sum(f);
                 };
 #pragma unroll
                 for (int q = 0; q < NK4; ++q) {
@@ -1194,7 +1207,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
 #endif
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            df_flag_st(take0 ? dn_or_dump0 : dn_or_dump1, b + 1);   // this wave is done with the slot (LDS executes a wave's accesses in order)
+            df_flag_st(dn_or_dump + st * dn_step, b + 1);   // this wave is done with the slot (LDS executes a wave's accesses in order)
 #ifdef DF_EXP_NOSTORE   // timing experiment: no global stores (only meaningful with DF_EXP_NOLOAD: nobody polls)
             asm volatile("" :: "v"(hv), "v"(p_r), "v"(p_z), "v"(p_n), "v"(gv));
             if (num_nodes > 0) continue;

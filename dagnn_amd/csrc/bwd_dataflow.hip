@@ -63,30 +63,11 @@ constexpr int BD_RD = 6;             // a loader wave requests a record this man
 //   [0..3] v, first / last CSR slot of v's row in direction 1 - d, 0     [4..7] first four successors   [8..11] their edge ids
 //   [16..19] / [20..23] first / second edge feature of those edges       [24 + 4 i + e] alpha of edge e in stacked layer i
 constexpr int BD_RECW = 64;
-// who stores a row's outputs (0: the compute wave of the row, after its own granule store; 1: the row's loader wave, behind the
-// ready flag).  A loader row is ~2.4 us of single-wave issue without them, a block costs the compute waves ~1.05 us and they
-// serve two streams: the split that balances the two depends on the workgroup shape (measured per translation unit)
-#ifndef BD_Q_LOADER
-#define BD_Q_LOADER 1      // q_v: in the compute wave it sits in front of the products, i.e. on the dependent chain of slice 0
-#endif
-#ifndef BD_GRAN_LOADER
-#define BD_GRAN_LOADER (BD_WPS_V == 4)   // (the 12-wave shape of H <= 256: its compute waves serve two streams and are the scarcer resource)
-#endif
-#ifndef BD_PLAIN_LOADER
-#define BD_PLAIN_LOADER (BD_WPS_V == 4)
-#endif
-// compute waves, measured per workgroup shape (scripts/abt.sh): the flag look as one trip to LDS, the slot's output values read
-// with the operands (before the node ids are known), the z (.) G term read without waiting for the ids - all three help the
-// 12-wave shape of H <= 256 (1.50 -> 1.47 ms) and cost the 8-wave shape of H = 320 (2.94 -> 3.11 ms)
-#ifndef BD_LEAN_LOOK
-#define BD_LEAN_LOOK (BD_WPS_V == 4)
-#endif
-#ifndef BD_EAGER_OUT
-#define BD_EAGER_OUT (BD_WPS_V == 4)
-#endif
-#ifndef BD_IDS_FIRST
-#define BD_IDS_FIRST (BD_WPS_V != 4)
-#endif
+// Who stores a row's outputs: its LOADER wave, behind the ready flag - q_v, the slice's columns of dgi (granules and plain
+// rows) and dgh; a block costs the compute waves more than a row costs its loader, and they serve two streams (measured per
+// workgroup shape in round 4; the compute-wave forms of these stores live in scripts/experiments/).  The compute
+// wave of row r keeps sigma_v and the edge-feature sums of slice BD_SCAL_SL.
+static_assert(BD_WPS_V == 4, "the workgroup shape: 4 compute + 2 x 4 loader waves (the 8-wave shape of round 4 is in scripts/experiments/)");
 constexpr int BD_SCAL_SL = 1;        // slice whose compute waves store sigma_v and the edge-feature sums (slice 0 stores q_v)
 enum { BD_DA = 0, BD_DU = 1 };
 enum { ST_GEXT = 0, ST_H = 1, ST_CR = 2, ST_CZ = 3, ST_CNR = 4, ST_CN = 5, ST_Z = 6, ST_CQ = 7 };
@@ -151,8 +132,7 @@ template <int KPT> struct BdSlot {
     static constexpr int op_off = 0;                          // [3][RB][AP] operand rows: gate block g of row r at (g * RB + r) * AP
     static constexpr int zg_off = 3 * DF_RB * AP;             // [RB][32]    z (.) G of the slice's units
     static constexpr int dn_off = zg_off + DF_RB * DF_JS;     // [RB][32]    c_n (.) G of the slice's units (the n block of dgi)
-    static constexpr int qp_off = dn_off + DF_RB * DF_JS;     // [RB][64]    per-lane parts of q_v = G_v . c_q,v (slice 0)
-    static constexpr int sc_off = qp_off + DF_RB * 64;        // [RB][4]     sigma_v and the two edge-feature sums (slice 1)
+    static constexpr int sc_off = dn_off + DF_RB * DF_JS;     // [RB][4]     sigma_v and the two edge-feature sums (slice 1)
     static constexpr int v_off = sc_off + DF_RB * 4;          // [RB] ints
     static constexpr int words = v_off + 4;
 };
@@ -724,13 +704,7 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
             if (NQ4 > 2) qd = fmaf(G[2], ST[ST_CQ].z, qd);
             if (NQ4 > 3) qd = fmaf(G[3], ST[ST_CQ].w, qd);
             if (NQ4 > 4) qd = fmaf(G[4], ST5[ST_CQ], qd);
-            if (!BD_Q_LOADER && sl == 0) sbase[Slot::qp_off + lw * 64 + lane] = qd;
-#if BD_GRAN_LOADER || BD_PLAIN_LOADER
-            const float mr = pick(dr), mz = pick(dz), mn = pick(dnn);
-#endif
-#if BD_PLAIN_LOADER
-            const float mnr = pick(dnr);
-#endif
+            const float mr = pick(dr), mz = pick(dz), mn = pick(dnn), mnr = pick(dnr);
             if (sl == BD_SCAL_SL) {   // (every lane: same words, same values)
                 float* sc = sbase + Slot::sc_off + lw * 4;
                 sc[0] = sig; sc[1] = m0; sc[2] = m1;
@@ -740,14 +714,13 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                 bd_flag_st(lds.rdy + set * BD_WPS + w, b + 1);
             }
             BD_STAMP(prof, b, set, 5);   // flag raised
-            if (BD_Q_LOADER && sl == 0) {   // (next to the compute waves' products: off the dependent chain)
+            if (sl == 0) {   // (next to the compute waves' products: off the dependent chain)
                 qd = bd_wave_sum(qd);
                 if (lane == 0) {
                     if (local_st) C.q_g[v] = gran_pack(epoch, qd);
                     else __hip_atomic_store(C.q_g + v, gran_pack(epoch, qd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-#if BD_GRAN_LOADER || BD_PLAIN_LOADER
             {   // the slice's 32 columns: row bases in SGPRs (v is uniform), ONE per-lane byte offset, the half-wave that owns the
                 // columns under an exec mask - as C++ the compiler keeps per-lane 64-bit base pointers alive across the sweep
                 unsigned long long keep_e, mine_mask;
@@ -755,7 +728,6 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                 asm volatile("v_lshl_add_u32 %[c8], %[q], 9, %[l8]\n\ts_lshl_b32 %[sh], %[o], 5\n\ts_bfm_b64 %[mm], 32, %[sh]"
                              : [c8] "=&v"(c8), [mm] "=&s"(mine_mask), [sh] "=&s"(msh) : [l8] "v"(lane8), [q] "s"(myq), [o] "s"(odd));
                 (void)msh;
-#if BD_GRAN_LOADER
                 if (C.dgi_g) {
                     const char* pg0 = reinterpret_cast<const char*>(C.dgi_g) + (uint64_t)((unsigned)v * (unsigned)(3 * gld)) * 8u;
                     const char* pg1 = pg0 + (uint64_t)(unsigned)gld * 8u;
@@ -776,8 +748,6 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                                      : [mm] "s"(mine_mask), [c8] "v"(c8), [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [p0] "s"(pg0), [p1] "s"(pg1), [p2] "s"(pg2)
                                      : "memory");
                 }
-#endif
-#if BD_PLAIN_LOADER
                 const char* og = reinterpret_cast<const char*>(C.dgi) + (uint64_t)(unsigned)v * (unsigned)(3 * H * 4);
                 const char* oh = reinterpret_cast<const char*>(C.dgh) + (uint64_t)(unsigned)v * (unsigned)(3 * H * 4);
                 const unsigned c4 = c8 >> 1;
@@ -790,9 +760,7 @@ __device__ __forceinline__ void bd_loader_da(const int32_t* __restrict__ plan, c
                              : [mm] "s"(mine_mask), [c4] "v"(c4), [mr] "v"(mr), [mz] "v"(mz), [mn] "v"(mn), [mnr] "v"(mnr),
                                [og] "s"(og), [oh] "s"(oh), [h1] "n"(4 * H), [h2] "n"(8 * H)
                              : "memory");
-#endif
             }
-#endif
             BD_STAMP(prof, b, set, 6);   // row outputs issued
         } else {
             glds4(ra, rl);   // an idle row keeps the record ring moving
@@ -985,183 +953,115 @@ __device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int
     gran_t* const out_g = C.out_g;
     const int gld = S.gld, num_nodes = S.N;
     const bool local_st = is_da && lds.local[0] != 0;
-
-    // where this lane finds its output values of row cw inside a slot (the third value: the c_n block for the dgi half-wave,
-    // gate block 2 of the operand rows for the dgh half-wave; both advance by a constant per row)
-    const int out_col = sl * DF_JS + (lane & 31);
-    const int out_pos = out_col + (SEG - KP8) * (out_col / KP8);
-    const int out_third = lane < 32 ? Slot::dn_off + (lane & 31) : Slot::op_off + 2 * DF_RB * Slot::AP + out_pos;
-    const int out_third_step = lane < 32 ? DF_JS : Slot::AP;
     const int R = C.mrel ? S.R : 0;
-
-    int done[DF_NLS];
-    int left = 0, pref = 0;
-#pragma unroll
-    for (int q = 0; q < DF_NLS; ++q) { done[q] = 0; left += nb[q]; }
 #ifdef BD_STAMPS
     const bool prof = S.dbg && lds.local[1] != 0 && cw == 0 && lane == 0;
 #endif
-    while (left > 0) {
-        int st = -1;
-        unsigned spins = 0;
-        if (BD_LEAN_LOOK && DF_NLS == 2) {
-            // (dataflow.hip's compute waves: the smallest positive lead first, ties alternate - ONE trip to LDS per look, the
-            // ready flags of both streams behind one wait, the rest scalar)
-            typedef int i4v __attribute__((ext_vector_type(4)));
-            const unsigned rdy_a = (unsigned)(uintptr_t)lds.rdy;
-            for (;;) {
-                int m0, m1;
-                if (BD_WPS == 4) {
-                    i4v r0, r1;
-                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(r0), "=&v"(r1) : "v"(rdy_a) : "memory");
-                    m0 = __builtin_amdgcn_readfirstlane(min(min(r0.x, r0.y), min(r0.z, r0.w)));
-                    m1 = __builtin_amdgcn_readfirstlane(min(min(r1.x, r1.y), min(r1.z, r1.w)));
-                } else {
-                    i4v r0;
-                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0) : "v"(rdy_a) : "memory");
-                    m0 = __builtin_amdgcn_readfirstlane(min(r0.x, r0.y));
-                    m1 = __builtin_amdgcn_readfirstlane(min(r0.z, r0.w));
-                }
-                const int l0 = done[0] < nb[0] ? m0 - done[0] : 0, l1 = done[DF_NLS - 1] < nb[DF_NLS - 1] ? m1 - done[DF_NLS - 1] : 0;
-                if (l0 > 0 || l1 > 0) {
-                    st = l0 <= 0 ? 1 : (l1 <= 0 ? 0 : (l0 != l1 ? (l0 < l1 ? 0 : 1) : pref));
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-                bool give_up = false;
-                if (++spins > 4 * spin_limit) {
-                    __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    give_up = true;
-                }
-                if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = true;
-                if (give_up) {
-                    st = done[0] < nb[0] ? 0 : 1;
-                    break;
+
+    // The block loop, shaped like dataflow.hip's df_compute (round 6: ONE wave pays for every instruction it issues, so the
+    // bookkeeping is scalar and branch-free, the next look at the ready flags leaves behind the last product, a lane reads the
+    // one node id it needs, the done flag is stored without a predicate - the other lanes write into the DMA dump area - and
+    // the store variants are hoisted out of the loop).
+    typedef int i4v __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const volatile i4v* lds_i4p;
+    const lds_i4p rdy_p = (lds_i4p)(unsigned)(uintptr_t)lds.rdy;
+    static_assert(DF_NLS == 2 && BD_WPS == 4, "two streams, four ready flags each");
+    const bool lane_st = (lane & 16) == 0;   // (lanes 16 away hold the same sums)
+    int* const dn_or_dump = lane == 0 ? lds.dn + cw : lds.dump + lane;
+    const int dn_step = lane == 0 ? DF_NCW : 0;
+    const int nb0 = nb[0], nb1 = nb[DF_NLS - 1];
+    const bool scal = sl == BD_SCAL_SL;
+
+    auto run = [&](auto local_c, auto da_c) {
+        constexpr bool LOCAL = decltype(local_c)::value, DA = decltype(da_c)::value;
+        int done0 = 0, done1 = 0, pref = 0;
+        int m0 = 0, m1 = 0;   // blocks the streams' loaders had finished at the last look (wave-uniform)
+        auto flags_min = [&](const i4v& r0, const i4v& r1) {
+            m0 = __builtin_amdgcn_readfirstlane(min(min(r0.x, r0.y), min(r0.z, r0.w)));
+            m1 = __builtin_amdgcn_readfirstlane(min(min(r1.x, r1.y), min(r1.z, r1.w)));
+        };
+        int slot0 = 0, slot1 = 0;   // ring slots of the streams' next blocks (BD_NSLOT need not be a power of two)
+        for (int left = nb0 + nb1; left > 0; --left) {
+            int l0 = m0 - done0, l1 = m1 - done1;   // leads (>= 0: a loader stops at its stream's last block)
+            if (l0 <= 0 && l1 <= 0) {   // nothing known to be ready: look until there is
+                unsigned spins = 0;
+                for (;;) {
+                    const i4v r0 = rdy_p[0], r1 = rdy_p[1];
+                    flags_min(r0, r1);
+                    l0 = m0 - done0; l1 = m1 - done1;
+                    if (l0 > 0 || l1 > 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    bool give_up = false;
+                    if (++spins > 4 * spin_limit) {
+                        __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        give_up = true;
+                    }
+                    if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = true;
+                    if (give_up) { l0 = nb0 - done0; l1 = nb1 - done1; break; }
                 }
             }
-        } else
-        for (;;) {
-            int best = 0x7fffffff;
-#pragma unroll
-            for (int e = 0; e < DF_NLS; ++e) {
-                int r = bd_flag_ld(lds.rdy + e * BD_WPS);
-#pragma unroll
-                for (int x2 = 1; x2 < BD_WPS; ++x2) r = min(r, bd_flag_ld(lds.rdy + e * BD_WPS + x2));
-                const int lead = done[e] < nb[e] ? r - done[e] : 0;
-                const int key = lead * DF_NLS + ((e - pref + DF_NLS) % DF_NLS);
-                if (lead > 0 && key < best) { best = key; st = e; }
+            // smallest positive lead first, ties alternate (one unsigned comparison: dataflow.hip)
+            const unsigned k0 = ((unsigned)(l0 - 1) << 1) | (unsigned)pref, k1 = ((unsigned)(l1 - 1) << 1) | (unsigned)(pref ^ 1);
+            const int st = k1 < k0 ? 1 : 0;
+            pref = st ^ 1;
+            const int b = st ? done1 : done0;
+            const int slot = st ? slot1 : slot0;
+            done0 += st ^ 1;
+            done1 += st;
+            { const int nx = slot + 1 == BD_NSLOT ? 0 : slot + 1; if (st) slot1 = nx; else slot0 = nx; }
+            BD_STAMP(prof, b, st, 9);   // block seen
+            const float* sbase = lds.ring + (st * BD_NSLOT + slot) * Slot::words;
+            // every read of the slot leaves in one go (the values read for rows that turn out idle are never stored)
+            const int gv = reinterpret_cast<const int*>(sbase + Slot::v_off)[gr];
+            const float zgv = DA ? sbase[Slot::zg_off + gr * DF_JS + unit_l] : 0.f;   // (input-gradient cells: no such term)
+            int row_v = -1;
+            float o_s = 0.f;
+            if (DA && scal) {   // row `cw` of the block: this wave stores its sigma_v and edge-feature sums
+                row_v = reinterpret_cast<const int*>(sbase + Slot::v_off)[cw];
+                o_s = sbase[Slot::sc_off + cw * 4 + (lane & 3)];
             }
-            if (st >= 0) break;
-            __builtin_amdgcn_s_sleep(1);
-            bool give_up = false;
-            if (++spins > 4 * spin_limit) {
-                __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                give_up = true;
-            }
-            if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = true;
-            if (give_up) {
+            const float* a_seg = sbase + Slot::op_off + x * Slot::AP + ks * SEG;   // gate block 0, row x, K slice ks
+            float gsum;
+            {
+                bf4 acc[3] = {(bf4){0.f, 0.f, 0.f, 0.f}, (bf4){0.f, 0.f, 0.f, 0.f}, (bf4){0.f, 0.f, 0.f, 0.f}};
+#ifndef BD_EXP_NOMFMA   // (timing experiment, scripts/build_variant.sh)
 #pragma unroll
-                for (int e = DF_NLS - 1; e >= 0; --e) if (done[e] < nb[e]) st = e;
-                break;
-            }
-        }
-        st = __builtin_amdgcn_readfirstlane(st);
-        pref = (st + 1) % DF_NLS;
-        int b = 0;
+                for (int q = 0; q < NK4; ++q) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(a_seg + 4 * q);
+                    const float4 b1 = *reinterpret_cast<const float4*>(a_seg + DF_RB * Slot::AP + 4 * q);
+                    const float4 b2 = *reinterpret_cast<const float4*>(a_seg + 2 * DF_RB * Slot::AP + 4 * q);
+                    const float q0[4] = {b0.x, b0.y, b0.z, b0.w}, q1[4] = {b1.x, b1.y, b1.z, b1.w}, q2[4] = {b2.x, b2.y, b2.z, b2.w};
 #pragma unroll
-        for (int e = 0; e < DF_NLS; ++e) if (e == st) { b = done[e]; ++done[e]; }
-        --left;
-        BD_STAMP(prof, b, st, 9);   // block seen
-        const int slot = b % BD_NSLOT;
-        const float* sbase = lds.ring + (st * BD_NSLOT + slot) * Slot::words;
-        // every read of the slot leaves in one go: nothing in front of the products depends on the node ids (the values
-        // read for rows that turn out idle are never stored)
-        const int4 ids = *reinterpret_cast<const int4*>(sbase + Slot::v_off);
-        const float* a_seg = sbase + Slot::op_off + x * Slot::AP + ks * SEG;   // gate block 0, row x, K slice ks
-        float zgv = 0.f;   // (input-gradient cells: no such term)
-#if BD_IDS_FIRST
-        const int nr0 = (ids.x >= 0) + (ids.y >= 0) + (ids.z >= 0) + (ids.w >= 0);
-        if (is_da && gr < nr0) zgv = sbase[Slot::zg_off + gr * DF_JS + unit_l];
-#else
-        if (is_da) zgv = sbase[Slot::zg_off + gr * DF_JS + unit_l];
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q + e], q0[e], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wz[4 * q + e], q1[e], acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(wn[4 * q + e], q2[e], acc[2], 0, 0, 0);
+                    }
+                }
 #endif
-        // row `cw` of the block is this wave's to store (see the loader): lanes 0..31 hold the slice's columns of dgi
-        // (c_r G, c_z G, c_n G), lanes 32..63 those of dgh (c_r G, c_z G, c_nr G); slice 0: the parts of q; slice 1: the scalars
-        float o_r = 0.f, o_z = 0.f, o_3 = 0.f, o_q = 0.f, o_s = 0.f;
-        if (!(BD_PLAIN_LOADER && BD_GRAN_LOADER) && (BD_EAGER_OUT || (is_da && (unsigned)(cw == 0 ? ids.x : (cw == 1 ? ids.y : (cw == 2 ? ids.z : ids.w))) < (unsigned)num_nodes))) {
-            o_r = sbase[Slot::op_off + cw * Slot::AP + out_pos];
-            o_z = sbase[Slot::op_off + (DF_RB + cw) * Slot::AP + out_pos];
-            o_3 = sbase[out_third + cw * out_third_step];
-        }
-        if (!BD_Q_LOADER && sl == 0) o_q = sbase[Slot::qp_off + cw * 64 + lane];
-        if (sl == BD_SCAL_SL) o_s = sbase[Slot::sc_off + cw * 4 + (lane & 3)];
-        {   // (BD_Q_LOADER = 0) q_v first: the predecessors' pulls poll it next to the da row this block produces
-            const int qrow_v = cw == 0 ? ids.x : (cw == 1 ? ids.y : (cw == 2 ? ids.z : ids.w));
-            if (!BD_Q_LOADER && is_da && sl == 0 && (unsigned)qrow_v < (unsigned)num_nodes) {
-                const float qv = bd_wave_sum(o_q);
-                if (lane == 0) {
-                    if (local_st) C.q_g[qrow_v] = gran_pack(epoch, qv);
-                    else __hip_atomic_store(C.q_g + qrow_v, gran_pack(epoch, qv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        float gsum;
-        {
-            bf4 acc[3] = {(bf4){0.f, 0.f, 0.f, 0.f}, (bf4){0.f, 0.f, 0.f, 0.f}, (bf4){0.f, 0.f, 0.f, 0.f}};
-#ifndef BD_EXP_NOMFMA   // (timing experiment, scripts/build_variant.sh: without the products the sweep takes 1.96 instead of 2.15 ms)
-#pragma unroll
-            for (int q = 0; q < NK4; ++q) {
-                const float4 b0 = *reinterpret_cast<const float4*>(a_seg + 4 * q);
-                const float4 b1 = *reinterpret_cast<const float4*>(a_seg + DF_RB * Slot::AP + 4 * q);
-                const float4 b2 = *reinterpret_cast<const float4*>(a_seg + 2 * DF_RB * Slot::AP + 4 * q);
-                const float q0[4] = {b0.x, b0.y, b0.z, b0.w}, q1[4] = {b1.x, b1.y, b1.z, b1.w}, q2[4] = {b2.x, b2.y, b2.z, b2.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q + e], q0[e], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wz[4 * q + e], q1[e], acc[1], 0, 0, 0);
-                    acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(wn[4 * q + e], q2[e], acc[2], 0, 0, 0);
-                }
-            }
-#endif
-            const bf4 t = acc[0] + acc[1] + acc[2];   // the three gate blocks of K: one reduce-scatter for their sum
+                // the look for the NEXT block: issued behind the last product, read at the top of the next iteration
+                __builtin_amdgcn_sched_barrier(0);
+                const i4v r0 = rdy_p[0], r1 = rdy_p[1];
+                const bf4 t = acc[0] + acc[1] + acc[2];   // the three gate blocks of K: one reduce-scatter for their sum
 #ifdef BD_STAMPS
-            { asm volatile("" :: "v"(t[0]), "v"(t[3])); BD_STAMP(prof, b, st, 10); }   // products done
+                { asm volatile("" :: "v"(t[0]), "v"(t[3])); BD_STAMP(prof, b, st, 10); }   // products done
 #endif
-            const float u0 = t[0] + bd_dpp<0x104>(t[0]), u1 = t[1] + bd_dpp<0x104>(t[1]);
-            const float u2 = t[2] + bd_dpp<0x114>(t[2]), u3 = t[3] + bd_dpp<0x114>(t[3]);
-            const float e0 = s0 ? u2 : u0, e1 = s0 ? u3 : u1;
-            const float f0 = e0 + bd_dpp<0x108>(e0), f1 = e1 + bd_dpp<0x118>(e1);
-            const float f = s1 ? f1 : f0;
-            gsum = bd_row_pair_sum(f);
-        }
-        const int nr = (ids.x >= 0) + (ids.y >= 0) + (ids.z >= 0) + (ids.w >= 0);   // live records come first
-        const int row_v = cw == 0 ? ids.x : (cw == 1 ? ids.y : (cw == 2 ? ids.z : ids.w));
-        const bool row_live = is_da && cw < nr && (unsigned)row_v < (unsigned)num_nodes;
-        int gv = gr == 0 ? ids.x : (gr == 1 ? ids.y : (gr == 2 ? ids.z : ids.w));
-        const bool live = gr < nr && (unsigned)gv < (unsigned)num_nodes && (lane & 16) == 0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) bd_flag_st(lds.dn + st * DF_NCW + cw, b + 1);
-        if (live) {
-            if (local_st) out_g[(int64_t)gv * gld + unit] = gran_pack(epoch, gsum + zgv);
-            else __hip_atomic_store(out_g + (int64_t)gv * gld + unit, gran_pack(epoch, gsum + zgv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (row_live) {   // off the dependent chain: the plain rows the weight-gradient epilogue reads, dgi also as granules
-            if (!BD_PLAIN_LOADER) {
-                float* o = (lane < 32 ? C.dgi : C.dgh) + (int64_t)row_v * (3 * H) + out_col;
-                o[0] = o_r; o[H] = o_z; o[2 * H] = o_3;
+                const float u0 = t[0] + bd_dpp<0x104>(t[0]), u1 = t[1] + bd_dpp<0x104>(t[1]);
+                const float u2 = t[2] + bd_dpp<0x114>(t[2]), u3 = t[3] + bd_dpp<0x114>(t[3]);
+                const float e0 = s0 ? u2 : u0, e1 = s0 ? u3 : u1;
+                const float f0 = e0 + bd_dpp<0x108>(e0), f1 = e1 + bd_dpp<0x118>(e1);
+                gsum = bd_row_pair_sum(s1 ? f1 : f0);
+                flags_min(r0, r1);
             }
-            if (!BD_GRAN_LOADER && C.dgi_g && lane < 32) {
-                gran_t* pg = C.dgi_g + (int64_t)row_v * (3 * gld) + out_col;
-                if (local_st) {   // (readers on this XCD: the lines stay in its L2)
-                    pg[0] = gran_pack(epoch, o_r); pg[gld] = gran_pack(epoch, o_z); pg[2 * gld] = gran_pack(epoch, o_3);
-                } else {
-                    __hip_atomic_store(pg, gran_pack(epoch, o_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(pg + gld, gran_pack(epoch, o_z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(pg + 2 * gld, gran_pack(epoch, o_3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bd_flag_st(dn_or_dump + st * dn_step, b + 1);   // this wave is done with the slot
+            // (the bound on the node id also covers padding rows, id -1, and whatever a slot holds once a wait has expired)
+            if (lane_st && (unsigned)gv < (unsigned)num_nodes) {
+                gran_t* po = out_g + (__umul24((unsigned)gv, (unsigned)gld) + (unsigned)unit);   // (N * gld < 2^31, N < 2^24: host check)
+                if (LOCAL) *po = gran_pack(epoch, gsum + zgv);
+                else __hip_atomic_store(po, gran_pack(epoch, gsum + zgv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (sl == BD_SCAL_SL) {
+            if (DA && scal && (unsigned)row_v < (unsigned)num_nodes) {   // off the dependent chain
                 const int o_si = __float_as_int(o_s);
                 const float s_sig = __int_as_float(__builtin_amdgcn_readlane(o_si, 0)), s_m0 = __int_as_float(__builtin_amdgcn_readlane(o_si, 1)),
                             s_m1 = __int_as_float(__builtin_amdgcn_readlane(o_si, 2));
@@ -1171,9 +1071,11 @@ __device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int
                     if (R >= 2) C.mrel[(int64_t)row_v * R + 1] = s_m1;
                 }
             }
+            BD_STAMP(prof, b, st, 11);   // stores issued
         }
-        BD_STAMP(prof, b, st, 11);   // stores issued
-    }
+    };
+    if (is_da) { if (local_st) run(std::true_type(), std::true_type()); else run(std::false_type(), std::true_type()); }
+    else run(std::false_type(), std::false_type());
 }
 
 template <int KPT>

@@ -199,7 +199,10 @@ template <int KPT> struct DfPad {
 };
 
 constexpr int DF_CSLEEP_N = 1;   // s_sleep argument (x 64 cycles) of the compute waves' look at the ready flags
-constexpr int DF_WSLEEP_N = 1;   // ... of a loader's wait for its ring slot
+#ifndef DF_WSLEEP_V
+#define DF_WSLEEP_V 1
+#endif
+constexpr int DF_WSLEEP_N = DF_WSLEEP_V;   // ... of a loader's wait for its ring slot
 constexpr bool DF_LEAN_COMPUTE = true;   // (the 12-wave shape: the 2 x 4 ready flags are one trip to LDS; the 8-wave shape of H = 320 has 2 x 2)
 constexpr int DF_RD = 6;       // a loader wave requests a row record this many of ITS blocks ahead (record ring: 8 entries)
 constexpr int DF_GD = 2;       // a gi0 slice this many (its node id must have landed: DF_RD >= DF_GD + 2)

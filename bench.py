@@ -621,6 +621,8 @@ def main():
         dist.all_gather(infos, mine_info)
         multi_res = {"per_rank": [{"rank": r, "dataflow_groups_inference": int(a[0]), "dataflow_groups_training": int(a[1]),
                                    "reserved_cus_training": int(a[2]), "num_cus": int(a[3])} for r, a in enumerate(infos)],
+                     "reserved_cus_why": _eng.reserved_cus_info(True)[1] + " (rank 0; DAGNN_AMD_RESERVED_CUS overrides; "
+                                         "NCCL_MAX_NCHANNELS=16 would leave all five workgroup sets of the headline shape)",
                      "expected_weak_scaling": "N x the N = 1 value for the forward (no data-path collective, one process per GPU: "
                                               "DESIGN.md section 6 states the predicted N = 2 / 4 / 8 values); a training pass "
                                               "under the communicator runs dataflow_groups_training groups (reserved CUs) instead "

@@ -64,6 +64,50 @@ class DerivedCache(object):
         return self._val
 
 
+class ParamGuard(object):
+    """Catches what `DerivedCache` cannot see.  The caches key on (data_ptr, _version); a fused optimizer step or a write
+    through `.data` moves neither, and an evaluation loop that interleaves such updates without a `train()` / `eval()` call
+    would read derived weights of the OLD parameters - silently.  Every evaluation pass therefore fingerprints the module's
+    parameters on the device (`dagnn_param_fingerprint`: 1024 words spread over each tensor, ONE small launch): when the
+    cache key moved the fingerprints are recorded, otherwise they are compared and a difference sets a bit of the arena's
+    error word, which travels to the host with the pass's other error words (no synchronisation) and raises at the next
+    `poll()` / `check()` like any device-side failure.  A sampled check: an update that touches every element (any optimizer
+    step, `copy_` of new weights) is caught with certainty, a write to a few hand-picked elements need not be.
+    `DAGNN_AMD_PARAM_GUARD=0` switches it off."""
+
+    def __init__(self):
+        self._key = None
+        self._fp = None
+        self._args = None
+
+    def reset(self) -> None:
+        self._key = None
+
+    def check(self, params: Sequence[torch.Tensor], err: Optional[torch.Tensor]) -> None:
+        if not engine.PARAM_GUARD or err is None or not params:
+            return
+        import ctypes as C
+        key = tuple([(p.data_ptr(), p._version) for p in params])
+        record = key != self._key
+        if record or self._args is None:
+            chunks = []
+            cap = 96
+            for o in range(0, len(params), cap):
+                part = [p for p in params[o:o + cap]]
+                ptrs = (C.c_void_p * len(part))(*[p.data_ptr() for p in part])
+                numel = (C.c_int64 * len(part))(*[p.numel() if p.element_size() == 4 else 0 for p in part])
+                chunks.append((ptrs, numel, len(part), o))
+            self._args = chunks
+            if self._fp is None or self._fp.numel() < len(params) or self._fp.device != err.device:
+                self._fp = torch.empty(max(len(params), 1), dtype=torch.int64, device=err.device)
+            self._key = key
+        lib = engine._lib.load()
+        st = engine._stream(err)
+        for ptrs, numel, n, o in self._args:
+            engine.check(lib.dagnn_param_fingerprint(ptrs, numel, n, self._fp.data_ptr() + 8 * o, 0 if record else 1,
+                                                     err.data_ptr(), engine.ERR_PARAMS_MOVED, st), "dagnn_param_fingerprint")
+
+
 def built_marker(t):
     """(event, stream, seen) behind derived tensors just built on the current stream of `t`'s device - a pass on ANOTHER
     stream (`bench.py --streams k`, micro-batches in flight) must not read them before the kernels that made them are done."""

@@ -244,6 +244,51 @@ extern "C" int dagnn_debug_occupy(int num_wgs, int threads, int64_t ticks, float
     return DAGNN_OK;
 }
 
+namespace {
+struct FpJobs { const unsigned* p[DAGNN_MAX_FP_TENSORS]; long long words[DAGNN_MAX_FP_TENSORS]; };
+// one workgroup per tensor: 1024 words spread evenly over it, each weighted by an odd constant of its position, summed mod 2^64
+// (in a fixed order: the value is a pure function of the tensor's contents)
+__global__ void __launch_bounds__(256) param_fingerprint_kernel(FpJobs J, unsigned long long* fp, int mode, int* err, int bit) {
+    __shared__ unsigned long long part[4];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const unsigned* __restrict__ p = J.p[t];
+    const long long n = J.words[t];
+    unsigned long long acc = 0ull;
+    if (n > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long k = j * 256 + tid;
+            const long long idx = n >= 1024 ? (k * n) >> 10 : (k < n ? k : -1);
+            if (idx >= 0) acc += (unsigned long long)p[idx] * (0x9E3779B97F4A7C15ull * (unsigned long long)(2 * k + 1) | 1ull);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((tid & 63) == 0) part[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long v = part[0] + part[1] + part[2] + part[3];
+        if (mode == 0) fp[t] = v;
+        else if (fp[t] != v) __hip_atomic_fetch_or(err, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+}  // namespace
+
+extern "C" int dagnn_param_fingerprint(const void* const* ptrs, const int64_t* numel, int n, uint64_t* fp, int mode, int* err,
+                                       int bit, void* stream) {
+    if (!ptrs || !numel || !fp || n < 0 || n > DAGNN_MAX_FP_TENSORS || (mode != 0 && mode != 1) || (mode == 1 && !err)) return DAGNN_EINVAL;
+    if (n == 0) return DAGNN_OK;
+    FpJobs J;
+    for (int t = 0; t < n; ++t) {
+        if (numel[t] < 0 || (numel[t] > 0 && !ptrs[t])) return DAGNN_EINVAL;
+        J.p[t] = (const unsigned*)ptrs[t]; J.words[t] = numel[t];
+    }
+    hipLaunchKernelGGL(param_fingerprint_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, J,
+                       reinterpret_cast<unsigned long long*>(fp), mode, err, bit);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
 extern "C" const char* dagnn_version(void) { return "dagnn_hip 0.1 gfx950"; }
 
 extern "C" int dagnn_encode_ast(const int64_t* x, int64_t* depth, const float* type_emb, const float* attr_emb,

@@ -83,6 +83,8 @@ BWD_TAIL_MAX_BLOCKS = _env_int("DAGNN_AMD_BWD_TAIL_MAX_BLOCKS", 4)
 # 2.302-2.312 against 2.3085 ms - nothing - and two processes sharing one GPU (the two-rank bench test) failed.
 PLAN_OVERLAP = _env_int("DAGNN_AMD_PLAN_OVERLAP", 0)              # 1: training passes launch plan / schedule on the arena's side stream next to encoder + input GEMM (model._plan_of); measured: 13 separate launches 1.64 -> 1.59 ms per forward, the fused pipeline (csrc/prepare.hip) gains nothing from it (fork + join cost what it hides: training step 5.42 against 5.32 ms)
 SIDE_PRIORITY = _env_int("DAGNN_AMD_SIDE_PRIORITY", 0)     # stream priority of an arena's side stream (-1: high)
+PARAM_GUARD = _env_int("DAGNN_AMD_PARAM_GUARD", 1)            # 1: evaluation passes fingerprint the parameters behind the derived-weight caches (core.ParamGuard: one small launch per pass); a write the version counters missed is reported like a device-side failure
+ERR_PARAMS_MOVED = 0x10000                                       # bit of the arena's error word the guard sets
 FOLD_INPUT = _env_int("DAGNN_AMD_FOLD_INPUT", 1)              # 1: evaluation passes over an ASTNodeEncoder fold the embedding tables through W_ih of stacked layer 0 once per
                                                             # weight version (gi0 = three folded rows summed per node instead of the [N, emb] x [emb, 3H] GEMM; model._folded_tables)
 PREPARE_FUSED = _env_int("DAGNN_AMD_PREPARE", 1)            # 1: evaluation passes build plan + schedule + encoder rows + side effect 1 as one pipeline of 7 launches (csrc/prepare.hip)
@@ -563,25 +565,54 @@ def pack_dataflow_batch(mats, H: int, gains=()):
 
 
 RESERVED_CUS = _env_int("DAGNN_AMD_RESERVED_CUS", -1)   # CUs the persistent kernels of a TRAINING pass leave free; -1 = automatic (below)
+RCCL_MAX_WORKGROUPS = 64   # upper bound of RCCL's channel count (one workgroup per channel) when NCCL_MAX_NCHANNELS does not pin it
+_COLLECTIVE = {"registered": False, "group": None}
+
+
+def register_collective(group=None) -> None:
+    """The process group the gradient exchange of this process runs on (`train.GradBucket` / `OverlappedGradReducer` /
+    `DataParallel` call this): `reserved_cus` then looks at THAT group's size instead of the default group's - a model trained
+    under a one-rank sub-group overlaps no collective and keeps every CU."""
+    _COLLECTIVE["registered"] = True
+    _COLLECTIVE["group"] = group
+
+
+def reserved_cus_info(training: bool):
+    """(CUs a training pass leaves free, why) - see `reserved_cus`."""
+    if RESERVED_CUS >= 0:
+        return (RESERVED_CUS if training else 0), "DAGNN_AMD_RESERVED_CUS=%d" % RESERVED_CUS
+    if not training:
+        return 0, "inference passes overlap no collective"
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, "no communicator"
+    try:
+        world = dist.get_world_size(_COLLECTIVE["group"]) if _COLLECTIVE["registered"] else dist.get_world_size()
+    except (RuntimeError, ValueError):   # (this rank is not a member of the registered group)
+        world = 1
+    if world <= 1:
+        return 0, "the gradient exchange's group has one rank"
+    pinned = _env_int("NCCL_MAX_NCHANNELS", 0)
+    ch = pinned if pinned > 0 else RCCL_MAX_WORKGROUPS
+    r = min((ch + 7) // 8 * 8, RCCL_MAX_WORKGROUPS)   # whole CUs per XCD: the launches are spread evenly over the 8 XCDs
+    return r, ("NCCL_MAX_NCHANNELS=%d pins RCCL's workgroups" % pinned if pinned > 0 else
+               "RCCL may run up to %d channels (one workgroup each); NCCL_MAX_NCHANNELS pins fewer" % RCCL_MAX_WORKGROUPS)
 
 
 def reserved_cus(training: bool) -> int:
     """The dataflow kernels need EVERY workgroup resident (one per CU, the whole register file of the CU each: 240 of 256
     CUs at the headline shape).  In a data-parallel training step the heads' gradient bucket is all-reduced WHILE the
-    reverse sweep runs (`train.OverlappedGradReducer`): the collective's kernels (RCCL: one workgroup per channel, up to 64)
-    were launched first and hold CUs the sweep counts on - the resident part of the sweep then spins on granules of
-    workgroups that cannot be dispatched before the collective drains: a serialisation at best, an expired bounded wait
-    at worst.  So a training pass under an active communicator (torch.distributed initialised, world > 1) sizes its
-    persistent launches - forward and reverse share one schedule - for `num_cus - 64` and spreads them evenly over the
-    XCDs (24 of 32 CUs each at the headline shape: 4 workgroup sets instead of 5), which leaves 8 CUs per XCD to whatever
-    else runs.  `DAGNN_AMD_RESERVED_CUS=n` overrides the rule in both directions (0: never reserve; n: always, also in a
-    single process - what the GPU test of the rule uses).  Inference passes overlap no collective and keep every CU."""
-    if RESERVED_CUS >= 0:
-        return RESERVED_CUS if training else 0
-    if not training:
-        return 0
-    import torch.distributed as dist
-    return 64 if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else 0
+    reverse sweep runs (`train.OverlappedGradReducer`): the collective's kernels (RCCL: one workgroup per channel) were
+    launched first and hold CUs the sweep counts on - the resident part of the sweep then spins on granules of workgroups
+    that cannot be dispatched before the collective drains: a serialisation at best, an expired bounded wait at worst.  So
+    a training pass whose gradient exchange runs on a group of more than one rank (`register_collective`; the default group
+    when nothing registered) sizes its persistent launches - forward and reverse share one schedule - for `num_cus - r`,
+    spread evenly over the XCDs, where r = RCCL's channel count rounded up to whole CUs per XCD: `NCCL_MAX_NCHANNELS` when
+    the launcher pins it (16 leaves 240 CUs = all five workgroup sets of the headline shape), else RCCL's upper bound of 64
+    (24 of 32 CUs per XCD: four sets).  `DAGNN_AMD_RESERVED_CUS=n` overrides the rule in both directions (0: never
+    reserve; n: always, also in a single process - what the GPU tests of the rule use).  Inference passes overlap no
+    collective and keep every CU.  Reserving changes which group a graph is dealt to, never a result (GPU test)."""
+    return reserved_cus_info(training)[0]
 
 
 def effective_cus(device, training: bool = False) -> int:
@@ -890,6 +921,13 @@ class GranuleArena(object):
         if self.err is not None:
             self.err.zero_()   # the flag is sticky on the device (a lost pass makes later ones give up early): consumed here
         msgs = []
+        if e & ERR_PARAMS_MOVED:
+            msgs.append("a parameter changed without its version counter moving (a fused optimizer step, a write through "
+                        ".data) while the module was in evaluation mode: the pass read derived weights cached from the OLD "
+                        "values - call module.train() / .eval() (or .invalidate_caches()) after such an update")
+            e &= ~ERR_PARAMS_MOVED
+            if not e and not s:
+                raise DagnnHipError("results of an earlier DAGNN pass are invalid: " + msgs[0])
         if e & 3:
             msgs.append("a bounded device-side wait expired (code %d): the persistent kernel's workgroups were not "
                         "co-resident, or a producer failed" % e)
@@ -913,7 +951,11 @@ class GranuleArena(object):
         """Synchronising check of every pass launched so far (bounded waits and plan contract)."""
         self._drain(block=True)
         if self.err is not None and int(self.err[0]):
+            e = int(self.err[0])
             self.err.zero_()
+            if e == ERR_PARAMS_MOVED:
+                raise DagnnHipError("a parameter changed without its version counter moving while the module was in evaluation "
+                                    "mode: the last pass read stale derived weights (call module.train() / .eval() after such an update)")
             raise DagnnHipError("persistent kernel: a bounded wait expired (results are invalid)")
 
 

@@ -253,6 +253,10 @@ class DAGNN(nn.Module):
         training passes never ask)."""
         if not engine.FOLD_INPUT or type(self.encoder) is not ASTNodeEncoder or self.schedule != "lockstep" or self.agg_x:
             return None
+        if self.training:
+            # a no-grad pass on a module left in train() mode (validation without eval(), MC dropout): the derived cells are
+            # rebuilt on every pass there, and re-folding three tables per direction each time costs what the fold saves
+            return None
         enc = self.encoder
         tabs = [enc.type_encoder.weight, enc.attribute_encoder.weight, enc.depth_encoder.weight]
         if tabs[0].shape[1] % 4 or not tabs[0].is_cuda:
@@ -269,6 +273,7 @@ class DAGNN(nn.Module):
                 else:
                     meet_built(c.fold[2])   # (built by a pass on another stream, perhaps still in flight)
                 out.append(c.fold[1])
+        self.__dict__["fold_passes"] = self.__dict__.get("fold_passes", 0) + 1   # (tests assert the path a pass took)
         return out
 
     @staticmethod
@@ -418,10 +423,7 @@ class DAGNN(nn.Module):
     def train(self, mode: bool = True):
         """Mode switches drop the derived-weight caches (core.DerivedCache: an optimizer may have updated the
         parameters without bumping their version counters)."""
-        for c in list(self.__dict__.get("_derived", {}).values()) + [self.__dict__.get("_head_cache"),
-                                                                      self.__dict__.get("_variant_cache")]:
-            if c is not None:
-                c.invalidate()
+        self.invalidate_caches()
         return super().train(mode)
 
     def _plan_of(self, G, B, overlap: bool = False):
@@ -533,6 +535,7 @@ class DAGNN(nn.Module):
                 sscore = self._static_scores(x, cells)
                 h = run_stack(plan, x, cells, dirs, L, H, schedule=self.schedule, static_score=sscore,
                               arena=self._arena_for(x), gi0=gi0)
+                self._guard_params(x)
                 return self._finish(G, plan, x, h, B)
         # side effect 1 (dagnn.py:130-133) + the plan: on a side stream next to the encoder and the input GEMM, which do not
         # depend on them (`engine.PLAN_OVERLAP`); the caller's stream meets it again in front of the recurrence
@@ -561,7 +564,33 @@ class DAGNN(nn.Module):
         sscore = self._static_scores(x, cells)
         h = run_stack(plan, x, cells, dirs, L, H, schedule=self.schedule, static_score=sscore,
                       arena=self._arena_for(x), gi0=self._folded_gi0(x_idx, depth, cells))
+        self._guard_params(x)
         return self._finish(G, plan, x, h, B)
+
+    def _guard_params(self, x) -> None:
+        """Evaluation passes: the parameters behind the derived-weight caches still are what the caches were built from
+        (`core.ParamGuard`; a training-mode pass rebuilds everything anyway)."""
+        if self.training or not engine.PARAM_GUARD:
+            return
+        g = self.__dict__.get("_param_guard")
+        if g is None:
+            from .core import ParamGuard
+            g = self.__dict__["_param_guard"] = ParamGuard()
+            self.__dict__["_param_list"] = [p for p in self.parameters() if p.is_cuda and p.dtype == torch.float32]
+        g.check(self.__dict__["_param_list"], self._arena_for(x).err)
+
+    def invalidate_caches(self) -> None:
+        """Drop every tensor derived from the parameters (what `train()` / `eval()` do): call it after updating parameters in
+        evaluation mode through a path the version counters do not see (`.data`, a fused optimizer)."""
+        for c in list(self.__dict__.get("_derived", {}).values()) + [self.__dict__.get("_head_cache"),
+                                                                      self.__dict__.get("_variant_cache")]:
+            if c is not None:
+                c.invalidate()
+        g = self.__dict__.get("_param_guard")
+        if g is not None:
+            g.reset()
+        self.__dict__.pop("_param_list", None)
+        self.__dict__.pop("_param_guard", None)
 
     def _heads(self, out):
         """The prediction heads on the pooled graph vectors (dagnn.py:204-215)."""

@@ -124,6 +124,8 @@ class OverlappedGradReducer(object):
         ids = {id(p) for p in early}
         rest = [p for p in params if p.requires_grad and id(p) not in ids]
         self.group = group
+        from . import engine
+        engine.register_collective(group)   # (the co-residency rule of the persistent kernels looks at THIS group: engine.reserved_cus)
         self.early = GradBucket(early) if early else None
         self.late = GradBucket(rest) if rest else None
         self._count = 1.0

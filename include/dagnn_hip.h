@@ -864,6 +864,15 @@ typedef struct dagnn_encode_args {
 } dagnn_encode_args;
 int dagnn_encode_forward(const dagnn_encode_args* args /* host */, void* stream);
 
+/* Guard of the host side's derived-weight caches (dagnn_amd/core.py: ParamGuard; nothing in the reference corresponds - its
+ * modules read their parameters on every call).  A fingerprint of up to DAGNN_MAX_FP_TENSORS fp32 / int32 tensors: 1024 words
+ * spread evenly over each, weighted by position, summed mod 2^64.  mode 0 writes fp[t]; mode 1 compares with fp[t] and ORs
+ * `bit` into *err (device word) for every tensor whose fingerprint moved - read back with the pass's other error words, no
+ * synchronisation.  One launch, one workgroup per tensor. */
+#define DAGNN_MAX_FP_TENSORS 96
+int dagnn_param_fingerprint(const void* const* ptrs /* host array of device pointers */, const int64_t* numel /* host */, int n,
+                            uint64_t* fp /* device [n] */, int mode, int* err /* device */, int bit, void* stream);
+
 /* Test utility for the co-residency rule of the persistent kernels (engine.reserved_cus): occupies `num_wgs` workgroups of
  * `threads` threads for `ticks` of the 100 MHz constant clock (bounded: at most 2^31 ticks) on `stream` - a stand-in for the
  * kernels of a collective that runs next to a training pass.  Touches no memory besides `sink` (one float, may be NULL). */

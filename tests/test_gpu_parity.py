@@ -173,6 +173,39 @@ def test_gemm_nt_bias(device, M, Nc, K):
     assert float((C2.cpu().double() - A.double() @ W2.double().t()).abs().max()) < 2e-6 * float(scale) * 4
 
 
+def test_parameter_writes_the_version_counters_miss_are_reported(device):
+    """core.ParamGuard: an evaluation loop that updates parameters through `.data` (or a fused optimizer) WITHOUT a train() /
+    eval() call in between reads derived weights cached from the old values; the version counters the caches key on do not
+    move.  The pass after such a write must not go unnoticed: the guard's fingerprint of the parameters differs, the error
+    word says so, check() raises; `invalidate_caches()` is the remedy and the pass after it sees the new values."""
+    model = _headline_model().to(device)
+    b = synth.code2_batch(0, 16)
+    with torch.no_grad():
+        base = [o.clone() for o in model(b.clone().to(device))]
+        again = [o.clone() for o in model(b.clone().to(device))]
+    model.check()   # two clean passes: recorded, then compared - no report
+    assert max(Hh.maxdiff(a, c) for a, c in zip(again, base)) == 0.0
+    v = model.cells_0[0].weight_hh._version
+    model.cells_0[0].weight_hh.data.mul_(1.25)   # (no version bump: DerivedCache keeps serving the packed old matrix)
+    assert model.cells_0[0].weight_hh._version == v
+    with torch.no_grad():
+        stale = [o.clone() for o in model(b.clone().to(device))]
+    assert max(Hh.maxdiff(a, c) for a, c in zip(stale, base)) == 0.0   # the stale read itself ...
+    with pytest.raises(DagnnHipError, match="version counter"):
+        model.check()                                                  # ... is reported
+    model.invalidate_caches()
+    with torch.no_grad():
+        fresh = [o.clone() for o in model(b.clone().to(device))]
+    model.check()
+    assert max(Hh.maxdiff(a, c) for a, c in zip(fresh, base)) > 1e-4
+    # an update the counters DO see re-records instead of reporting
+    with torch.no_grad():
+        model.cells_1[0].bias_hh.add_(0.5)
+        model(b.clone().to(device))
+        model(b.clone().to(device))
+    model.check()
+
+
 def test_pack_whh(device):
     W = torch.randn(3 * 76, 76)
     assert torch.equal(engine.pack_whh(W.to(device)).cpu(), W.t().contiguous())
@@ -196,6 +229,11 @@ def test_code2_forward_matches_reference_golden(device, name, schedule):
     for o, ref in zip(out, arr["pred"]):
         assert tuple(o.shape) == ref.shape
         assert Hh.maxdiff(o, ref) < TOL
+    # which input path the pass took is part of what this test pins: an evaluation pass on the lock-step schedule reads stacked
+    # layer 0's input side from the folded embedding tables (model._folded_tables) wherever its conditions hold - if they ever
+    # stop holding, the folded path would otherwise lose its reference check without anybody noticing
+    fold_applies = schedule == "lockstep" and engine.FOLD_INPUT and meta["H"] % 4 == 0 and not model.agg_x
+    assert model.__dict__.get("fold_passes", 0) == (1 if fold_applies else 0)
     rows = arr["rows"]
     assert Hh.maxdiff(G.x[rows], arr["x_emb"]) < 1e-6
     assert np.array_equal(G.node_depth.cpu().numpy(), arr["node_depth_after"])
@@ -636,6 +674,37 @@ def test_training_pass_leaves_room_for_a_collective(device, monkeypatch):
         alone = torch.stack(model(b.clone().to(device)))
     torch.cuda.synchronize()
     assert engine.reserved_cus(False) == 0
+
+
+def test_reserved_cus_change_the_schedule_not_the_gradients(device, monkeypatch):
+    """`DAGNN_AMD_RESERVED_CUS` = 0 / 32 / 64 (what `engine.reserved_cus` derives from the gradient exchange's group and RCCL's
+    channel count): a training pass sized for fewer CUs deals the graphs to fewer groups - another schedule, the same
+    arithmetic per row in the same order: loss and every gradient of the cells, heads and attention must agree to the last
+    bit (the embedding tables' backward in torch accumulates with atomics: rounding), and the rule reports why it reserved."""
+    model = _headline_model(H=256, L=2, V=32, seed=5).to(device)
+    b = synth.code2_batch(12, 128, 125)
+    y = torch.randint(0, 32, (128, 5), generator=torch.Generator().manual_seed(4)).to(device)
+    got = {}
+    for r in (0, 32, 64):
+        monkeypatch.setattr(engine, "RESERVED_CUS", r)
+        assert engine.reserved_cus(True) == r and engine.reserved_cus(False) == 0
+        assert "DAGNN_AMD_RESERVED_CUS" in engine.reserved_cus_info(True)[1]
+        groups = engine.dataflow_groups(device, 2, 2, 256, 128, training=True)
+        loss, grads = _train_step(model, b.clone().to(device), y)
+        model.check()
+        got[r] = (groups, loss.clone(), {k: v.clone() for k, v in grads.items()})
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    if cus >= 256:
+        assert got[0][0] > got[64][0]   # 5 workgroup sets against 4 at the headline shape
+    for r in (32, 64):
+        assert torch.equal(got[r][1], got[0][1])
+        for k, g in got[r][2].items():
+            if "encoder." in k:
+                assert Hh.maxdiff(g, got[0][2][k]) <= 1e-6 * max(1.0, float(got[0][2][k].abs().max())), k
+            else:
+                assert torch.equal(g, got[0][2][k]), k
+    monkeypatch.setattr(engine, "RESERVED_CUS", -1)
+    assert engine.reserved_cus_info(True) == (0, "no communicator")   # (a single process without torch.distributed)
 
 
 def _degenerate_batch(extra=()):

@@ -343,3 +343,44 @@ def test_two_rank_overlapped_two_bucket_reduce_equals_single_bucket_gloo():
     out = mgr.dict()
     mp.spawn(_overlap_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert len(out) == 2 and sum(out.values()) == 11
+
+
+def _reserve_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dagnn_amd import engine
+        got = []
+        assert engine.RESERVED_CUS == -1
+        engine._COLLECTIVE.update(registered=False, group=None)
+        os.environ.pop("NCCL_MAX_NCHANNELS", None)
+        got.append(engine.reserved_cus_info(True)[0])          # default group, world 2, no pin: RCCL's upper bound
+        os.environ["NCCL_MAX_NCHANNELS"] = "12"
+        got.append(engine.reserved_cus_info(True)[0])          # pinned: 12 channels -> 16 CUs (whole CUs per XCD)
+        assert "NCCL_MAX_NCHANNELS=12" in engine.reserved_cus_info(True)[1]
+        got.append(engine.reserved_cus_info(False)[0])         # inference passes never reserve
+        groups = [dist.new_group([r]) for r in range(world)]   # every rank creates every group
+        engine.register_collective(groups[rank])               # the exchange runs on a one-rank group: nothing to leave room for
+        got.append(engine.reserved_cus_info(True)[0])
+        engine.register_collective(None)                       # the default group again
+        got.append(engine.reserved_cus_info(True)[0])
+        os.environ.pop("NCCL_MAX_NCHANNELS", None)
+        engine._COLLECTIVE.update(registered=False, group=None)
+        dist.barrier()
+        out[rank] = got
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_reserved_cus_follow_the_exchange_group_and_the_channel_pin_gloo():
+    """`engine.reserved_cus`: CUs a training pass leaves to the gradient collective = the channel count RCCL may use
+    (`NCCL_MAX_NCHANNELS` when pinned, else its upper bound of 64), on the group the exchange really runs on
+    (`engine.register_collective`, called by `OverlappedGradReducer`), never for an inference pass."""
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_reserve_worker, args=(world, port, out), nprocs=world, join=True)
+        for r in range(world):
+            assert list(out[r]) == [64, 16, 0, 0, 16]

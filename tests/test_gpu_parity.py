@@ -232,7 +232,7 @@ def test_code2_forward_matches_reference_golden(device, name, schedule):
     # which input path the pass took is part of what this test pins: an evaluation pass on the lock-step schedule reads stacked
     # layer 0's input side from the folded embedding tables (model._folded_tables) wherever its conditions hold - if they ever
     # stop holding, the folded path would otherwise lose its reference check without anybody noticing
-    fold_applies = schedule == "lockstep" and engine.FOLD_INPUT and meta["H"] % 4 == 0 and not model.agg_x
+    fold_applies = schedule != "pergraph" and engine.FOLD_INPUT and meta["H"] % 4 == 0 and not model.agg_x
     assert model.__dict__.get("fold_passes", 0) == (1 if fold_applies else 0)
     rows = arr["rows"]
     assert Hh.maxdiff(G.x[rows], arr["x_emb"]) < 1e-6

@@ -134,6 +134,10 @@ def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
     opt = torch.optim.Adam(params, lr=1e-3, fused=os.environ.get("DAGNN_BENCH_ADAM", "fused") == "fused")
     y = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(1)).to(device)
     ce = torch.nn.CrossEntropyLoss()
+    # the loss of main_pyg.py:55-60 (sum of the S heads' CrossEntropyLoss / S): through the library's one-launch entry
+    # (dagnn_amd.train.seq_cross_entropy: same value, csrc/loss.hip) or - DAGNN_BENCH_LOSS=loop - the reference's loop verbatim
+    from dagnn_amd.train import seq_cross_entropy
+    LOSS_LOOP = os.environ.get("DAGNN_BENCH_LOSS", "fused") == "loop"
     exposed = []
     CLIP = float(os.environ.get("DAGNN_BENCH_CLIP", "0.25"))   # the reference's training script: CLIP=0.25 (scripts/ogb_tok.sh:16)
 
@@ -143,7 +147,7 @@ def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
         else:
             opt.zero_grad(set_to_none=True)
         pred = model(G)
-        loss = sum(ce(pred[s], y[:, s]) for s in range(S)) / S
+        loss = sum(ce(pred[s], y[:, s]) for s in range(S)) / S if LOSS_LOOP else seq_cross_entropy(pred, y)
         loss.backward()
         if red is not None:
             if timed:
@@ -201,6 +205,9 @@ def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
     return {"what": "zero_grad + forward + mean-CE over %d heads + backward%s + clip_grad_norm(%.2f) + Adam step (main_pyg.py:39-65)"
                     % (S, " + RCCL all-reduce of the %.1f M gradient floats in two buckets" % (nparams / 1e6)
                        if world > 1 else "", CLIP),
+            "loss": "the reference's loop over the heads, verbatim (DAGNN_BENCH_LOSS=loop)" if LOSS_LOOP else
+                    "dagnn_amd.train.seq_cross_entropy(pred_list, y_arr): the same value as the reference's loop over the heads "
+                    "(main_pyg.py:55-60), loss + d logits in one launch (DAGNN_BENCH_LOSS=loop times the loop itself)",
             **extra,
             "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
             "ms_per_step_median": round(per_step[len(per_step) // 2], 4),
@@ -239,14 +246,14 @@ def ogb_tok_config(device, timed):
     gf_padded = (2 * L * N * 6.0 * Hp * Hp + 2 * (L - 1) * N * 6.0 * Hp * Hp) / 1e9
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
-    ce = torch.nn.CrossEntropyLoss()
+    from dagnn_amd.train import seq_cross_entropy
     y = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(1)).to(device)
     it = iter(fresh_inputs(master, 24))
 
     def step():
         opt.zero_grad(set_to_none=True)
         pred = model(next(it))
-        loss = sum(ce(pred[s], y[:, s]) for s in range(S)) / S
+        loss = seq_cross_entropy(pred, y)   # (= sum(ce(pred[s], y[:, s]) for s in range(S)) / S: training_leg)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 0.25, foreach=True)
         opt.step()

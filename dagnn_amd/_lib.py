@@ -299,6 +299,8 @@ SYMBOLS = {
                                    C.c_void_p, C.c_int, C.POINTER(IpropLayer), C.c_int, C.c_void_p, C.c_void_p]),
     "dagnn_encode_forward": (C.c_int, [C.POINTER(EncodeArgs), C.c_void_p]),
     "dagnn_debug_occupy": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "dagnn_seq_ce": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_void_p]),
     "dagnn_param_fingerprint": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_gather_rows_batch": (C.c_int, [C.POINTER(GatherJob), C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_gather_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,

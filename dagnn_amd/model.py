@@ -110,6 +110,32 @@ def _init_encoder(word_vectors, emb_dims):  # dagnn.py:218-223
     return None
 
 
+class _HeadsLinear(torch.autograd.Function):
+    """`out @ Wcat^T + bcat` for the S heads at once (their parameters are views of `wcat` / `bcat`: `DAGNN._head_storage`)
+    with the gradients of the S weights and biases as views of ONE product."""
+
+    @staticmethod
+    def forward(ctx, out, wcat, bcat, V, *params):
+        ctx.save_for_backward(out)
+        ctx.wcat, ctx.V, ctx.S = wcat, V, len(params) // 2
+        ctx.needs = (out.requires_grad, any(p.requires_grad for p in params))
+        return torch.addmm(bcat, out, wcat.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        wcat, V, S = ctx.wcat, ctx.V, ctx.S
+        g = g.contiguous()
+        d_out = g @ wcat if ctx.needs_input_grad[0] else None
+        if ctx.needs[1]:
+            dw = g.t() @ out            # [S V, D]: the S weight gradients, one product
+            db = g.sum(0)
+            gw, gb = list(dw.split(V, 0)), list(db.split(V, 0))
+        else:
+            gw, gb = [None] * S, [None] * S
+        return (d_out, None, None, None, *gw, *gb)
+
+
 class DAGNN(nn.Module):
     """See module docstring.  Constructor mirrors `dagnn.py:18-112` argument for argument."""
 
@@ -592,21 +618,49 @@ class DAGNN(nn.Module):
         self.__dict__.pop("_param_list", None)
         self.__dict__.pop("_param_guard", None)
 
+    def _head_storage(self):
+        """The S vocabulary heads' weights and biases as ONE [S V, D] / [S V] pair: each head's parameter is (made) a VIEW of
+        it - same names, shapes and values in `state_dict`, same `Parameter` objects for the optimizer - so the heads are one
+        matrix for the library GEMMs without a concatenation per pass (102 MB at the headline shape) and without a cache that
+        could go stale: an in-place update of a head IS an update of the matrix.  Re-established when something re-seated the
+        parameters' storage (`module.to()`, `deepcopy`)."""
+        heads = list(self.graph_pred_linear_list)
+        V, D = heads[0].weight.shape
+        st = self.__dict__.get("_heads_flat")
+        w0 = heads[0].weight
+        ok = st is not None and st[0].device == w0.device and st[0].dtype == w0.dtype
+        if ok:
+            for i, hd in enumerate(heads):
+                if hd.weight.data_ptr() != st[0].data_ptr() + i * V * D * st[0].element_size() or \
+                        hd.bias.data_ptr() != st[1].data_ptr() + i * V * st[1].element_size():
+                    ok = False
+                    break
+        if not ok:
+            with torch.no_grad():
+                w = torch.cat([hd.weight.data for hd in heads], 0)
+                b = torch.cat([hd.bias.data for hd in heads], 0)
+                for i, hd in enumerate(heads):
+                    hd.weight.data = w[i * V:(i + 1) * V]
+                    hd.bias.data = b[i * V:(i + 1) * V]
+            st = self.__dict__["_heads_flat"] = (w, b)
+        return st
+
     def _heads(self, out):
         """The prediction heads on the pooled graph vectors (dagnn.py:204-215)."""
         if self.num_class > 0:
             return self.graph_pred_linear(out)
-        if self.num_vocab > 1 and self.max_seq_len > 1 and not torch.is_grad_enabled():
-            # the S vocabulary heads as ONE library GEMM over the concatenated weights (dagnn.py:212-215);
-            # the list entries are views of its output.  (Under autograd the heads stay S separate Linear calls: the
-            # concatenation inside the graph - one forward GEMM, two backward - bought nothing end to end, 5.52 against
-            # 5.49 ms per training step with F.linear, 7.1 ms with addmm on the transposed view: that part of the step is
-            # bound by the host's launch rate, not by the fifteen 25-us GEMMs.)
-            heads = list(self.graph_pred_linear_list)
-            wcat, bcat = self._head_cache.get([p for hd in heads for p in (hd.weight, hd.bias)],
-                                              lambda: (torch.cat([hd.weight for hd in heads], 0),
-                                                       torch.cat([hd.bias for hd in heads], 0)), fresh=self.training)
-            logits = torch.addmm(bcat, out, wcat.t())
+        if self.num_vocab > 1 and self.max_seq_len > 1 and out.is_cuda and out.dtype == torch.float32 and \
+                all(isinstance(hd, nn.Linear) for hd in self.graph_pred_linear_list):
+            # the S vocabulary heads as ONE library GEMM (dagnn.py:212-215 runs S): their parameters are views of one matrix
+            # (`_head_storage`), the list entries are views of its output.  Under autograd the GEMM and its two backward
+            # products are one node (`_HeadsLinear`); a caller that takes the loss through `train.seq_cross_entropy` meets
+            # the logits as ONE tensor there too (fifteen 25-us GEMMs + ~50 loss launches -> 3 + 2).
+            wcat, bcat = self._head_storage()
+            if torch.is_grad_enabled() and (out.requires_grad or any(p.requires_grad for p in self.graph_pred_linear_list.parameters())):
+                heads = list(self.graph_pred_linear_list)
+                logits = _HeadsLinear.apply(out, wcat, bcat, self.num_vocab, *[hd.weight for hd in heads], *[hd.bias for hd in heads])
+            else:
+                logits = torch.addmm(bcat, out, wcat.t())
             return list(logits.split(self.num_vocab, dim=1))
         return [self.graph_pred_linear_list[i](out) for i in range(self.max_seq_len)]
 

@@ -189,3 +189,62 @@ class OverlappedGradReducer(object):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+
+# ----------------------------------------------------------------------------- the TOK task's loss (main_pyg.py:55-60)
+_CE_COUNTERS = {}
+
+
+class _SeqCE(torch.autograd.Function):
+    """Mean cross-entropy over the S heads' logits laid side by side in ONE [B, S * V] tensor, loss and gradient in one HIP
+    launch (`dagnn_seq_ce`, csrc/loss.hip); the backward is one multiplication by the incoming scalar."""
+
+    @staticmethod
+    def forward(ctx, base, y, S, V):
+        from . import engine
+        lib = engine._lib.load()
+        B = base.shape[0]
+        dev = base.device
+        need_grad = base.requires_grad
+        dl = torch.empty_like(base) if need_grad else None
+        row = torch.empty(B * S, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        key = (dev.index, engine._stream(base))
+        cnt = _CE_COUNTERS.get(key)
+        if cnt is None:
+            cnt = _CE_COUNTERS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+        engine.check(lib.dagnn_seq_ce(base.data_ptr(), base.stride(0), y.data_ptr(), B, S, V, None if dl is None else dl.data_ptr(),
+                                      row.data_ptr(), loss.data_ptr(), cnt.data_ptr(), engine._stream(base)), "dagnn_seq_ce")
+        ctx.dl = dl
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dl, ctx.dl = ctx.dl, None
+        return dl.mul_(g), None, None, None
+
+
+def seq_cross_entropy(pred_list, y_arr: torch.Tensor) -> torch.Tensor:
+    """`sum_i CrossEntropyLoss()(pred_list[i], y_arr[:, i]) / len(pred_list)` - the loss of the reference's training loop
+    (ogbg-code/main_pyg.py:55-60).  When the list is what `DAGNN.forward` returns on a GPU - views of one [B, S * V] tensor, the
+    heads' outputs side by side - loss and gradient are ONE launch (`dagnn_seq_ce`) and the backward pass meets the heads as
+    one matrix; any other list takes the plain loop.  Targets must lie in [0, V) (no `ignore_index`)."""
+    S = len(pred_list)
+    p0 = pred_list[0]
+    base = getattr(p0, "_base", None)
+    fused = base is not None and base.is_cuda and base.dtype == torch.float32 and base.dim() == 2 and base.stride(1) == 1 \
+        and y_arr.is_cuda and y_arr.dtype == torch.int64 and y_arr.dim() == 2 and y_arr.shape[1] == S and y_arr.is_contiguous()
+    if fused:
+        V = p0.shape[1]
+        for i, p in enumerate(pred_list):
+            if getattr(p, "_base", None) is not base or p.shape != p0.shape or p.stride() != base.stride() or \
+                    p.data_ptr() != base.data_ptr() + 4 * i * V:
+                fused = False
+                break
+        fused = fused and base.shape[1] == S * V and y_arr.shape[0] == base.shape[0]
+    if not fused:
+        loss = 0
+        for i in range(S):
+            loss = loss + torch.nn.functional.cross_entropy(pred_list[i].to(torch.float32), y_arr[:, i])
+        return loss / S
+    return _SeqCE.apply(base, y_arr, S, V)

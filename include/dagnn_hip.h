@@ -864,6 +864,15 @@ typedef struct dagnn_encode_args {
 } dagnn_encode_args;
 int dagnn_encode_forward(const dagnn_encode_args* args /* host */, void* stream);
 
+/* The TOK task's training loss and its gradient in one launch (csrc/loss.hip; replaces the caller-side loop of
+ * ogbg-code/main_pyg.py:55-60: `loss += CrossEntropyLoss()(pred_list[i], y_arr[:, i])` over the S heads, `/ S`).
+ * logits [B, ld >= S * V]: head s's V outputs of graph b at b * ld + s * V (how DAGNN lays its heads' outputs side by side);
+ * y [B, S] int64 targets in [0, V) (no ignore_index: an out-of-range target makes the loss NaN); dlogits (same layout, may be
+ * NULL) receives d loss / d logits = (softmax - onehot) / (B S); row_loss [B * S] scratch; loss [1]; counter [1] device word,
+ * zero before the first call (the kernel leaves it zero).  Sums in a fixed order: bitwise reproducible. */
+int dagnn_seq_ce(const float* logits, int64_t ld, const int64_t* y, int B, int S, int V, float* dlogits, float* row_loss,
+                 float* loss, unsigned* counter, void* stream);
+
 /* Guard of the host side's derived-weight caches (dagnn_amd/core.py: ParamGuard; nothing in the reference corresponds - its
  * modules read their parameters on every call).  A fingerprint of up to DAGNN_MAX_FP_TENSORS fp32 / int32 tensors: 1024 words
  * spread evenly over each, weighted by position, summed mod 2^64.  mode 0 writes fp[t]; mode 1 compares with fp[t] and ORs

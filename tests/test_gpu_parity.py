@@ -676,6 +676,49 @@ def test_training_pass_leaves_room_for_a_collective(device, monkeypatch):
     assert engine.reserved_cus(False) == 0
 
 
+def test_fused_sequence_loss_is_the_loss_loop(device):
+    """`train.seq_cross_entropy` on the list `DAGNN.forward` returns: the value of the reference's loop
+    `sum_i CrossEntropyLoss()(pred[i], y[:, i]) / S` and the same gradients (one launch for loss + d logits, the heads' weight
+    gradients as one product); the heads' parameters stay ordinary entries of `state_dict` although they share one matrix;
+    lists that are not views of one tensor take the plain loop; an out-of-range target is loud."""
+    from dagnn_amd.train import seq_cross_entropy
+    model = _headline_model(H=256, L=2, V=5002, seed=6).to(device)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    b = synth.code2_batch(13, 64, 125)
+    y = torch.randint(0, 5002, (64, 5), generator=torch.Generator().manual_seed(5)).to(device)
+    loss_a, grads_a = _train_step(model, b.clone().to(device), y, fused_loss=False)
+    grads_a = {k: v.clone() for k, v in grads_a.items()}
+    loss_b, grads_b = _train_step(model, b.clone().to(device), y, fused_loss=True)
+    assert abs(float(loss_a) - float(loss_b)) < 2e-6
+    for k, g in grads_a.items():
+        assert Hh.maxdiff(grads_b[k], g) <= 2e-6 * max(1.0, float(g.abs().max())) + 1e-9, k
+    # bitwise reproducible (fixed summation order)
+    loss_c, grads_c = _train_step(model, b.clone().to(device), y, fused_loss=True)
+    assert torch.equal(loss_b, loss_c)
+    for k in ("graph_pred_linear_list.0.weight", "graph_pred_linear_list.4.bias"):
+        assert torch.equal(grads_b[k], grads_c[k])
+    # the heads still are five ordinary parameters
+    sd1 = model.state_dict()
+    assert list(sd1.keys()) == list(sd0.keys())
+    for k, v in sd0.items():
+        assert sd1[k].shape == v.shape and torch.equal(sd1[k], v), k
+    w, _ = model._head_storage()
+    with torch.no_grad():
+        model.graph_pred_linear_list[3].weight.add_(1.0)       # an in-place update of a head IS an update of the matrix
+    assert torch.equal(w[3 * 5002:4 * 5002], model.graph_pred_linear_list[3].weight)
+    # not views of one tensor: the plain loop
+    model.eval()
+    with torch.no_grad():
+        pred = [p.clone() for p in model(b.clone().to(device))]
+        ref = sum(torch.nn.functional.cross_entropy(p, y[:, s]) for s, p in enumerate(pred)) / 5
+        assert abs(float(seq_cross_entropy(pred, y)) - float(ref)) < 1e-6
+        views = model(b.clone().to(device))
+        assert abs(float(seq_cross_entropy(views, y)) - float(ref)) < 2e-6     # (no gradient asked for: the same kernel, no d logits)
+        bad = y.clone()
+        bad[3, 2] = 5002
+        assert torch.isnan(seq_cross_entropy(views, bad))
+
+
 def test_reserved_cus_change_the_schedule_not_the_gradients(device, monkeypatch):
     """`DAGNN_AMD_RESERVED_CUS` = 0 / 32 / 64 (what `engine.reserved_cus` derives from the gradient exchange's group and RCCL's
     channel count): a training pass sized for fewer CUs deals the graphs to fewer groups - another schedule, the same
@@ -775,23 +818,31 @@ def test_smoke_entry(device):
 
 
 # ----------------------------------------------------------------------------- training step
-def _train_step(model, G, y):
+def _train_step(model, G, y, fused_loss=False):
     model.train()
     model.zero_grad(set_to_none=True)
     pred = model(G)
-    loss = sum(torch.nn.functional.cross_entropy(p, y[:, s]) for s, p in enumerate(pred)) / len(pred)  # main_pyg.py:55-60
+    if fused_loss:   # the same loss through the library's one-launch entry (train.seq_cross_entropy, csrc/loss.hip)
+        from dagnn_amd.train import seq_cross_entropy
+        loss = seq_cross_entropy(pred, y)
+    else:
+        loss = sum(torch.nn.functional.cross_entropy(p, y[:, s]) for s, p in enumerate(pred)) / len(pred)  # main_pyg.py:55-60
     loss.backward()
     return loss.detach(), {k: (torch.zeros_like(p) if p.grad is None else p.grad) for k, p in model.named_parameters()}
 
 
+@pytest.mark.parametrize("fused_loss", [False, True])
 @pytest.mark.parametrize("name", Hh.GRAD)
-def test_training_step_gradients_match_reference_golden(device, name):
+def test_training_step_gradients_match_reference_golden(device, name, fused_loss):
     """forward + `loss.backward()` through the HIP path against the reference's own autograd on the same
-    seeded step: loss and every parameter gradient."""
+    seeded step: loss and every parameter gradient - with the reference's loss loop (main_pyg.py:55-60) and with the
+    library's fused loss entry in its place."""
     meta, arr = Hh.load(name)
     model = Hh.code2_model(meta).to(device)
     G = Hh.code2_batch(arr, device)
-    loss, grads = _train_step(model, G, torch.from_numpy(arr["y"]).to(device))
+    if fused_loss and model.num_class > 0:
+        pytest.skip("a single classification head: the fused entry is the S-head loss")
+    loss, grads = _train_step(model, G, torch.from_numpy(arr["y"]).to(device), fused_loss=fused_loss)
     assert abs(float(loss) - float(arr["loss"])) < 1e-5
     with torch.no_grad():
         assert Hh.maxdiff(torch.stack(model(Hh.code2_batch(arr, device))), arr["pred"]) < TOL

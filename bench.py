@@ -131,7 +131,15 @@ def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
     red = OverlappedGradReducer(params, early=heads) if world > 1 else None
     # the reference's optimizer (main_pyg.py:179: optim.Adam, default hyper-parameters); `fused=True` is the same update
     # as ONE kernel over all parameters instead of five foreach passes
-    opt = torch.optim.Adam(params, lr=1e-3, fused=os.environ.get("DAGNN_BENCH_ADAM", "fused") == "fused")
+    # N = 1 default: the library's ClipAdam - the same update with the clip coefficient applied as the gradient is read (three
+    # launches, csrc/optim.hip; DAGNN_BENCH_ADAM=fused / foreach time torch's pair clip_grad_norm_ + Adam instead)
+    ADAM = os.environ.get("DAGNN_BENCH_ADAM", "clipadam" if world == 1 else "fused")
+    CLIP = float(os.environ.get("DAGNN_BENCH_CLIP", "0.25"))   # the reference's training script: CLIP=0.25 (scripts/ogb_tok.sh:16)
+    if ADAM == "clipadam" and world == 1:
+        from dagnn_amd.train import ClipAdam
+        opt = ClipAdam(params, lr=1e-3, max_norm=CLIP if CLIP > 0 else None)
+    else:
+        opt = torch.optim.Adam(params, lr=1e-3, fused=ADAM == "fused")
     y = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(1)).to(device)
     ce = torch.nn.CrossEntropyLoss()
     # the loss of main_pyg.py:55-60 (sum of the S heads' CrossEntropyLoss / S): through the library's one-launch entry
@@ -139,7 +147,6 @@ def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
     from dagnn_amd.train import seq_cross_entropy
     LOSS_LOOP = os.environ.get("DAGNN_BENCH_LOSS", "fused") == "loop"
     exposed = []
-    CLIP = float(os.environ.get("DAGNN_BENCH_CLIP", "0.25"))   # the reference's training script: CLIP=0.25 (scripts/ogb_tok.sh:16)
 
     def step(G, timed=False):
         if red is not None:
@@ -157,9 +164,9 @@ def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
             if timed:
                 b.record()
                 exposed.append((a, b))
-        elif CLIP > 0:   # main_pyg.py:63-64 (`--clip`, 0.25 in scripts/ogb_tok.sh:16): global-norm clip in front of the update
+        elif CLIP > 0 and ADAM != "clipadam":   # main_pyg.py:63-64 (`--clip`, 0.25 in scripts/ogb_tok.sh:16): global-norm clip in front of the update
             torch.nn.utils.clip_grad_norm_(params, CLIP, foreach=True)
-        opt.step()
+        opt.step()   # (ClipAdam: clip + update)
         return loss
 
     for i in range(warmup):
@@ -205,6 +212,9 @@ def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
     return {"what": "zero_grad + forward + mean-CE over %d heads + backward%s + clip_grad_norm(%.2f) + Adam step (main_pyg.py:39-65)"
                     % (S, " + RCCL all-reduce of the %.1f M gradient floats in two buckets" % (nparams / 1e6)
                        if world > 1 else "", CLIP),
+            "optimizer": "dagnn_amd.train.ClipAdam(max_norm=%.2f): clip_grad_norm_ + Adam's update in three launches "
+                         "(DAGNN_BENCH_ADAM=fused times torch's pair)" % CLIP if (ADAM == "clipadam" and world == 1) else
+                         "torch.nn.utils.clip_grad_norm_ + torch.optim.Adam(fused=%s)" % (ADAM == "fused"),
             "loss": "the reference's loop over the heads, verbatim (DAGNN_BENCH_LOSS=loop)" if LOSS_LOOP else
                     "dagnn_amd.train.seq_cross_entropy(pred_list, y_arr): the same value as the reference's loop over the heads "
                     "(main_pyg.py:55-60), loss + d logits in one launch (DAGNN_BENCH_LOSS=loop times the loop itself)",
@@ -245,7 +255,8 @@ def ogb_tok_config(device, timed):
     gf = (2 * L * N * 6.0 * H * H + 2 * (L - 1) * N * 6.0 * H * H) / 1e9
     gf_padded = (2 * L * N * 6.0 * Hp * Hp + 2 * (L - 1) * N * 6.0 * Hp * Hp) / 1e9
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    from dagnn_amd.train import ClipAdam
+    opt = ClipAdam(model.parameters(), lr=1e-3, max_norm=0.25)   # (= clip_grad_norm_(0.25) + Adam: training_leg)
     from dagnn_amd.train import seq_cross_entropy
     y = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(1)).to(device)
     it = iter(fresh_inputs(master, 24))
@@ -255,7 +266,6 @@ def ogb_tok_config(device, timed):
         pred = model(next(it))
         loss = seq_cross_entropy(pred, y)   # (= sum(ce(pred[s], y[:, s]) for s in range(S)) / S: training_leg)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.25, foreach=True)
         opt.step()
     train = timed(step, 12, 4)
     model.check()

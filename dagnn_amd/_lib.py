@@ -28,6 +28,10 @@ class ReadoutJob(C.Structure):
     _fields_ = [("h", C.c_void_p), ("ld_h", C.c_int), ("width", C.c_int), ("dir", C.c_int), ("col_off", C.c_int)]
 
 
+class OptTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("numel", C.c_int64)]
+
+
 class DfPackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("aux", C.c_void_p), ("transposed", C.c_int32), ("rows", C.c_int32),
                 ("cols", C.c_int32)]
@@ -301,6 +305,11 @@ SYMBOLS = {
     "dagnn_debug_occupy": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "dagnn_seq_ce": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p]),
+    "dagnn_opt_chunks": (C.c_int64, [C.c_void_p, C.c_int]),
+    "dagnn_grad_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "dagnn_clip_adam": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_float,
+                                  C.c_void_p, C.c_void_p]),
+    "dagnn_score_parts_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "dagnn_param_fingerprint": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_gather_rows_batch": (C.c_int, [C.POINTER(GatherJob), C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dagnn_gather_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,

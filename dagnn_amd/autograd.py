@@ -71,6 +71,7 @@ class Recurrence(torch.autograd.Function):
         not differentiable; otherwise returns the states h[d][i] ([N, H] each, d over `dirs`, i over layers) as
         differentiable outputs - any torch read-out can follow (other pools, all nodes, unidirectional)."""
         L, H, dirs = mod.num_layers, mod.hidden_dim, mod.dirs
+        ctx.set_materialize_grads(False)   # (outputs nobody differentiates arrive as None in backward, not as [N, H] zero fills)
         cells = mod._cells(fresh=True)   # a differentiable pass: the optimizer changes the parameters every step
         keep = {}
         sscore = mod._static_scores(x, cells)   # keys from the inputs (`*_x` aggregators): one score per node and cell
@@ -99,7 +100,8 @@ class Recurrence(torch.autograd.Function):
         g_ext = [[g_all[dirs.index(d) * L + i] if d in dirs else None for i in range(L)] for d in range(2)]
         dx = torch.zeros_like(x)
         if ctx.fused:
-            mod._readout_backward(plan, x, h, gouts[0].contiguous().float(), g_ext, dx)
+            if gouts[0] is not None:
+                mod._readout_backward(plan, x, h, gouts[0].contiguous().float(), g_ext, dx)
         else:   # gradients of the states themselves, from whatever torch read-out followed
             for q, d in enumerate(dirs):
                 for i in range(L):

@@ -1617,8 +1617,10 @@ __global__ void __launch_bounds__(256) df_pack_batch_kernel(DfPackJobs P, int H,
 
 // partial attention scores behind the state rows (the format the backward pass reads): part q of row v =
 // w_key[16q : 16q + 16] . h[v, 16q : 16q + 16].  One wave per row.
-__global__ void __launch_bounds__(256) df_score_parts_kernel(float* __restrict__ h, int ld_h, int H,
-                                                              const float* __restrict__ wkey, int64_t N) {
+struct DfScoreJobs { float* h[DAGNN_MAX_PACK_JOBS]; const float* wkey[DAGNN_MAX_PACK_JOBS]; };
+__global__ void __launch_bounds__(256) df_score_parts_kernel(DfScoreJobs J, int ld_h, int H, int64_t N) {
+    float* __restrict__ h = J.h[blockIdx.y];
+    const float* __restrict__ wkey = J.wkey[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= N) return;
@@ -1735,13 +1737,21 @@ extern "C" int dagnn_pack_dataflow_batch(const dagnn_df_pack_job* jobs, int njob
     return DAGNN_OK;
 }
 
-extern "C" int dagnn_score_parts(float* h, int ld_h, int H, const float* w_key, int64_t N, void* stream) {
-    if (!h || !w_key || H <= 0 || (H % 16) || ld_h < H + H / 16 || N < 0) return DAGNN_EINVAL;
+extern "C" int dagnn_score_parts_batch(float* const* h, const float* const* w_key, int n, int ld_h, int H, int64_t N, void* stream) {
+    if (!h || !w_key || n <= 0 || n > DAGNN_MAX_PACK_JOBS || H <= 0 || (H % 16) || ld_h < H + H / 16 || N < 0) return DAGNN_EINVAL;
     if (N == 0) return DAGNN_OK;
-    hipLaunchKernelGGL(df_score_parts_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, ld_h, H,
-                       w_key, N);
+    DfScoreJobs J;
+    for (int q = 0; q < n; ++q) {
+        if (!h[q] || !w_key[q]) return DAGNN_EINVAL;
+        J.h[q] = h[q]; J.wkey[q] = w_key[q];
+    }
+    hipLaunchKernelGGL(df_score_parts_kernel, dim3((unsigned)((N + 3) / 4), (unsigned)n), dim3(256), 0, (hipStream_t)stream, J, ld_h, H, N);
     DAGNN_CHECK_LAUNCH();
     return DAGNN_OK;
+}
+
+extern "C" int dagnn_score_parts(float* h, int ld_h, int H, const float* w_key, int64_t N, void* stream) {
+    return dagnn_score_parts_batch(&h, &w_key, 1, ld_h, H, N, stream);
 }
 
 #endif   // !DF_WIDE_TU

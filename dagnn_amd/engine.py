@@ -645,10 +645,12 @@ def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     with persistent_launch(plan.ws), _span("dataflow_run", plan.ws):
         check(lib.dagnn_dataflow_run(C.byref(plan.desc), C.byref(args), _stream(plan.ws)), "dagnn_dataflow_run")
     if score_parts and static_score is None:
-        for d in dirs:
-            for i in range(L):
-                check(lib.dagnn_score_parts(h[d][i].data_ptr(), h[d][i].shape[1], H, cells[(d, i)].w_key.data_ptr(),
-                                            plan.N, _stream(plan.ws)), "dagnn_score_parts")
+        pairs = [(h[d][i], cells[(d, i)].w_key) for d in dirs for i in range(L)]   # (same row pitch, width and N: one launch per 16)
+        for o in range(0, len(pairs), 16):
+            part = pairs[o:o + 16]
+            hp = (C.c_void_p * len(part))(*[t.data_ptr() for t, _ in part])
+            wp = (C.c_void_p * len(part))(*[w.data_ptr() for _, w in part])
+            check(lib.dagnn_score_parts_batch(hp, wp, len(part), part[0][0].shape[1], H, plan.N, _stream(plan.ws)), "dagnn_score_parts_batch")
     arena.watch(plan, folded=True)
 
 

@@ -248,3 +248,101 @@ def seq_cross_entropy(pred_list, y_arr: torch.Tensor) -> torch.Tensor:
             loss = loss + torch.nn.functional.cross_entropy(pred_list[i].to(torch.float32), y_arr[:, i])
         return loss / S
     return _SeqCE.apply(base, y_arr, S, V)
+
+
+# ----------------------------------------------------------------------------- clip_grad_norm_ + Adam (main_pyg.py:63-65)
+class ClipAdam(torch.optim.Optimizer):
+    """`torch.nn.utils.clip_grad_norm_(params, max_norm)` followed by `torch.optim.Adam(params, ...).step()` - the tail of the
+    reference's training step (ogbg-code/main_pyg.py:63-65, optimizer at :179) - as three launches (csrc/optim.hip): the global
+    gradient 2-norm as a device float (fixed summation order), then Adam's update with the clip coefficient applied to the
+    gradient as it is read.  Every tensor crosses the memory bus once; torch's pair is ~12 launches that move the gradients
+    three times and walk the small tensors at a fraction of the memory rate (0.36 -> 0.2 ms at the headline shape).
+
+    Same update as `torch.optim.Adam` (no amsgrad, no maximize; `weight_decay` is Adam's L2 term) and the same `state_dict`
+    layout (`step`, `exp_avg`, `exp_avg_sq` per parameter), so checkpoints move between the two.  `max_norm=None` (or <= 0)
+    leaves the gradients unclipped.  Gradients themselves are NOT scaled in place (unlike `clip_grad_norm_`): the coefficient
+    only enters the update.  `last_norm` is the device float of the last step's total norm (what `clip_grad_norm_` returns).
+    fp32 parameters on one ROCm device."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 max_norm: Optional[float] = None):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("invalid Adam hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self.max_norm = max_norm
+        self.last_norm = None
+        self._scratch = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        import ctypes as C
+        from . import engine
+        from ._lib import OptTensor
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = engine._lib.load()
+        work = []   # (group, [params with a gradient])
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if ps:
+                work.append((group, ps))
+        if not work:
+            return loss
+        allp = [p for _, ps in work for p in ps]
+        dev = allp[0].device
+        for p in allp:
+            if not p.is_cuda or p.device != dev or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse:
+                raise engine.DagnnHipError("ClipAdam needs dense fp32 parameters and gradients on one ROCm device")
+        grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in allp]
+        st = engine._stream(allp[0])
+        cap = 48
+        clip = self.max_norm is not None and self.max_norm > 0
+        if clip:
+            numel = (C.c_int64 * len(allp))(*[g.numel() for g in grads])
+            chunks = int(lib.dagnn_opt_chunks(numel, len(allp)))
+            sc = self._scratch
+            if sc is None or sc[0].device != dev or sc[0].numel() < chunks:
+                sc = self._scratch = (torch.empty(max(chunks, 1), dtype=torch.float32, device=dev),
+                                      torch.empty(2, dtype=torch.float32, device=dev))
+            for o in range(0, len(grads), cap):
+                part = grads[o:o + cap]
+                ptrs = (C.c_void_p * len(part))(*[g.data_ptr() for g in part])
+                nn_ = (C.c_int64 * len(part))(*[g.numel() for g in part])
+                engine.check(lib.dagnn_grad_norm(ptrs, nn_, len(part), sc[0].data_ptr(), sc[0].numel(), sc[1].data_ptr(),
+                                                 1 if o > 0 else 0, sc[1].data_ptr() + 4, st), "dagnn_grad_norm")
+            self.last_norm = sc[1][1]
+        k = 0
+        for group, ps in work:
+            b1, b2 = group["betas"]
+            gs = grads[k:k + len(ps)]
+            k += len(ps)
+            for p in ps:
+                state = self.state[p]
+                if not state:
+                    state["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            # (one step counter per group, as torch keeps them in lock-step; parameters that joined later start their own)
+            steps = {}
+            for p, g in zip(ps, gs):
+                state = self.state[p]
+                if state["step"].is_cuda:   # (a checkpoint written by torch's fused Adam keeps its counters on the device)
+                    state["step"] = state["step"].cpu()
+                state["step"] += 1
+                steps.setdefault(int(state["step"]), []).append((p, g, state))
+            for stepno, items in steps.items():
+                for o in range(0, len(items), cap):
+                    part = items[o:o + cap]
+                    arr = (OptTensor * len(part))()
+                    for j, (p, g, state) in enumerate(part):
+                        m, v = state["exp_avg"], state["exp_avg_sq"]
+                        if not (p.is_contiguous() and m.is_contiguous() and v.is_contiguous()):
+                            raise engine.DagnnHipError("ClipAdam needs contiguous parameters")
+                        arr[j].param, arr[j].grad, arr[j].exp_avg, arr[j].exp_avg_sq, arr[j].numel = \
+                            p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+                    engine.check(lib.dagnn_clip_adam(arr, len(part), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                     float(group["weight_decay"]), stepno, float(self.max_norm) if clip else 0.0,
+                                                     self._scratch[1].data_ptr() + 4 if clip else None, st), "dagnn_clip_adam")
+        return loss

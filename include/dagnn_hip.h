@@ -390,6 +390,8 @@ typedef struct dagnn_df_pack_job {
 } dagnn_df_pack_job;
 int dagnn_pack_dataflow_batch(const dagnn_df_pack_job* jobs /* host */, int njob, int H, void* stream);
 int dagnn_score_parts(float* h /* [N,ld_h] */, int ld_h, int H, const float* w_key /* [H] */, int64_t N, void* stream);
+/* ... of several cells (the same ld_h / H / N) in one launch: n <= DAGNN_MAX_PACK_JOBS host arrays of device pointers. */
+int dagnn_score_parts_batch(float* const* h, const float* const* w_key, int n, int ld_h, int H, int64_t N, void* stream);
 /* Introspection (tests, host-side mirror): byte offsets of the schedule workspace's arrays, 13 entries: [grp_of,
  * gdepth, gload, loff, gtab0, gtab1, lcnt0, lcnt1, glbase0, glbase1, grec0, grec1, total]. */
 int dagnn_dataflow_layout(int64_t N, int64_t B, int groups, int64_t* offsets13 /* host */);
@@ -872,6 +874,22 @@ int dagnn_encode_forward(const dagnn_encode_args* args /* host */, void* stream)
  * zero before the first call (the kernel leaves it zero).  Sums in a fixed order: bitwise reproducible. */
 int dagnn_seq_ce(const float* logits, int64_t ld, const int64_t* y, int B, int S, int V, float* dlogits, float* row_loss,
                  float* loss, unsigned* counter, void* stream);
+
+/* The tail of the reference's training step - `clip_grad_norm_(model.parameters(), clip)` + `optim.Adam.step()`
+ * (ogbg-code/main_pyg.py:63-65,179) - over a table of fp32 tensors (csrc/optim.hip).  dagnn_grad_norm: the 2-norm of up to
+ * DAGNN_MAX_OPT_TENSORS gradients (`partial`: scratch of dagnn_opt_chunks() floats; `accumulate` != 0 adds the tensors' sum of
+ * squares to *norm_sq from an earlier call - tables beyond the limit) as a device float, summed in a fixed order.
+ * dagnn_clip_adam: Adam's update (no amsgrad, L2 weight decay, bias-corrected moments; `step` = 1, 2, ... of this update) with
+ * the gradient scaled by min(1, max_norm / (*norm + 1e-6)) as it is read (max_norm <= 0: no clipping, norm may be NULL);
+ * gradients are not modified.  Nothing synchronises; every pointer is a borrowed device pointer. */
+#define DAGNN_MAX_OPT_TENSORS 48
+typedef struct { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; int64_t numel; } dagnn_opt_tensor;
+int64_t dagnn_opt_chunks(const int64_t* numel /* host */, int n);
+int dagnn_grad_norm(const float* const* grads /* host array of device pointers */, const int64_t* numel /* host */, int n,
+                    float* partial, int64_t partial_len, float* norm_sq /* device [1] */, int accumulate, float* norm /* device [1] */,
+                    void* stream);
+int dagnn_clip_adam(const dagnn_opt_tensor* tensors /* host */, int n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int64_t step, float max_norm, const float* norm /* device */, void* stream);
 
 /* Guard of the host side's derived-weight caches (dagnn_amd/core.py: ParamGuard; nothing in the reference corresponds - its
  * modules read their parameters on every call).  A fingerprint of up to DAGNN_MAX_FP_TENSORS fp32 / int32 tensors: 1024 words

@@ -719,6 +719,59 @@ def test_fused_sequence_loss_is_the_loss_loop(device):
         assert torch.isnan(seq_cross_entropy(views, bad))
 
 
+@pytest.mark.parametrize("max_norm,wd", [(0.25, 0.0), (None, 0.0), (1e6, 0.01)])
+def test_clip_adam_is_clip_grad_norm_plus_adam(device, max_norm, wd):
+    """`train.ClipAdam.step()` against `torch.nn.utils.clip_grad_norm_` + `torch.optim.Adam.step()` (main_pyg.py:63-65) over
+    four steps: parameters and both moments, the reported norm, the state_dict layout (a torch Adam loads it and continues),
+    gradients left untouched; tensors of odd sizes and views at unaligned offsets (how the heads' biases sit in their matrix)."""
+    from dagnn_amd.train import ClipAdam
+    g0 = torch.Generator().manual_seed(7)
+    flat = torch.randn(5 * 5002 + 3, generator=g0)
+    shapes = [(768, 256), (768,), (1, 512), (33,), (5002, 64), (1,)]
+    def make():
+        base = flat.clone().to(device)
+        ps = [torch.nn.Parameter(torch.randn(*sh, generator=torch.Generator().manual_seed(10 + i)).to(device)) for i, sh in enumerate(shapes)]
+        views = []
+        for i in range(5):   # five "bias" views of one buffer: offsets 5002 * 4 bytes apart (not 16-byte aligned)
+            p = torch.nn.Parameter(torch.empty(0, device=device))
+            p.data = base[i * 5002:(i + 1) * 5002]
+            views.append(p)
+        return ps + views
+    pa, pb = make(), make()
+    opt_a = torch.optim.Adam(pa, lr=1e-2, weight_decay=wd)
+    opt_b = ClipAdam(pb, lr=1e-2, weight_decay=wd, max_norm=max_norm)
+    for it in range(4):
+        gs = [torch.randn(p.shape, generator=torch.Generator().manual_seed(100 * it + i)).to(device) * (3.0 if it % 2 else 0.01) for i, p in enumerate(pa)]
+        for p, q, g in zip(pa, pb, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        if it == 2:
+            pa[3].grad = pb[3].grad = None   # a parameter without a gradient this step is skipped (its step counter too)
+        norm_a = torch.nn.utils.clip_grad_norm_(pa, max_norm) if max_norm else None
+        opt_a.step()
+        opt_b.step()
+        if max_norm:
+            assert abs(float(opt_b.last_norm) - float(norm_a)) <= 1e-5 * float(norm_a)
+        for q, g in zip(pb, gs):
+            if q.grad is not None:
+                assert torch.equal(q.grad, g)   # not scaled in place
+        for i, (p, q) in enumerate(zip(pa, pb)):
+            assert Hh.maxdiff(q, p) <= 2e-6 * max(1.0, float(p.abs().max())), (it, i)
+            if p in opt_a.state:
+                for k in ("exp_avg", "exp_avg_sq"):
+                    ref = opt_a.state[p][k]
+                    assert Hh.maxdiff(opt_b.state[q][k], ref) <= 2e-6 * max(1e-3, float(ref.abs().max())), (it, i, k)
+                assert float(opt_b.state[q]["step"]) == float(opt_a.state[p]["step"])
+    # the state travels: a torch Adam continues from ClipAdam's state_dict
+    opt_c = torch.optim.Adam(pb, lr=1e-2, weight_decay=wd)
+    opt_c.load_state_dict(opt_b.state_dict())
+    for p, q in zip(pa, pb):
+        p.grad = q.grad = torch.ones_like(p) * 1e-3
+    opt_a.step()
+    opt_c.step()
+    for i, (p, q) in enumerate(zip(pa, pb)):
+        assert Hh.maxdiff(q, p) <= 2e-6 * max(1.0, float(p.abs().max())), i
+
+
 def test_reserved_cus_change_the_schedule_not_the_gradients(device, monkeypatch):
     """`DAGNN_AMD_RESERVED_CUS` = 0 / 32 / 64 (what `engine.reserved_cus` derives from the gradient exchange's group and RCCL's
     channel count): a training pass sized for fewer CUs deals the graphs to fewer groups - another schedule, the same

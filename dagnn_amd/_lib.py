@@ -303,11 +303,13 @@ SYMBOLS = {
                                    C.c_void_p, C.c_int, C.POINTER(IpropLayer), C.c_int, C.c_void_p, C.c_void_p]),
     "dagnn_encode_forward": (C.c_int, [C.POINTER(EncodeArgs), C.c_void_p]),
     "dagnn_debug_occupy": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
-    "dagnn_seq_ce": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                               C.c_void_p, C.c_void_p]),
+    "dagnn_tn_product": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "dagnn_seq_ce": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_void_p]),
     "dagnn_opt_chunks": (C.c_int64, [C.c_void_p, C.c_int]),
     "dagnn_grad_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
-    "dagnn_clip_adam": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_float,
+    "dagnn_clip_adam": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_float,
                                   C.c_void_p, C.c_void_p]),
     "dagnn_score_parts_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "dagnn_param_fingerprint": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

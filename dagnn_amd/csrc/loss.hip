@@ -28,7 +28,7 @@ __device__ __forceinline__ float ce_wave_sum(float v) {
 }
 
 __global__ void __launch_bounds__(256) seq_ce_kernel(const float* __restrict__ logits, long long ld, const long long* __restrict__ y,
-                                                     int B, int S, int V, float* __restrict__ dlogits, float* __restrict__ row_loss,
+                                                     int B, int S, int V, float* __restrict__ dlogits, long long ld_d, float* __restrict__ row_loss,
                                                      float* __restrict__ loss, unsigned* __restrict__ counter) {
     __shared__ float red[4];
     __shared__ unsigned last;
@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) seq_ce_kernel(const float* __restrict__ l
     const bool ok = t >= 0 && t < V;
     if (dlogits) {
         const float scale = 1.0f / ((float)B * (float)S), inv = 1.0f / z;
-        float* __restrict__ d = dlogits + (long long)b * ld + (long long)s * V;
+        float* __restrict__ d = dlogits + (long long)b * ld_d + (long long)s * V;
         for (int j = tid; j < V; j += 256) d[j] = (__expf(x[j] - m) * inv - (j == t ? 1.0f : 0.0f)) * scale;
     }
     if (tid == 0) {
@@ -79,12 +79,14 @@ __global__ void __launch_bounds__(256) seq_ce_kernel(const float* __restrict__ l
 
 }  // namespace
 
-extern "C" int dagnn_seq_ce(const float* logits, int64_t ld, const int64_t* y, int B, int S, int V, float* dlogits, float* row_loss,
-                            float* loss, unsigned* counter, void* stream) {
-    if (!logits || !y || !row_loss || !loss || !counter || B <= 0 || S <= 0 || V <= 0 || ld < (int64_t)S * V) return DAGNN_EINVAL;
+extern "C" int dagnn_seq_ce(const float* logits, int64_t ld, const int64_t* y, int B, int S, int V, float* dlogits, int64_t ld_d,
+                            float* row_loss, float* loss, unsigned* counter, void* stream) {
+    if (!logits || !y || !row_loss || !loss || !counter || B <= 0 || S <= 0 || V <= 0 || ld < (int64_t)S * V ||
+        (dlogits && ld_d < (int64_t)S * V))
+        return DAGNN_EINVAL;
     if ((int64_t)B * S >= (1ll << 31)) return DAGNN_EINVAL;
     hipLaunchKernelGGL(seq_ce_kernel, dim3((unsigned)(B * S)), dim3(256), 0, (hipStream_t)stream, logits, (long long)ld,
-                       (const long long*)y, B, S, V, dlogits, row_loss, loss, counter);
+                       (const long long*)y, B, S, V, dlogits, (long long)ld_d, row_loss, loss, counter);
     DAGNN_CHECK_LAUNCH();
     return DAGNN_OK;
 }

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) grad_norm_finish_kernel(const float* __re
     }
 }
 
-__global__ void __launch_bounds__(256) clip_adam_kernel(OptTable T, float lr, float beta1, float beta2, float eps, float weight_decay,
+__global__ void __launch_bounds__(256) clip_adam_kernel(OptTable T, float lr, float omb1, float beta2, float omb2, float eps, float weight_decay,
                                                         float bias1, float bias2_sqrt, float max_norm, const float* __restrict__ norm) {
     const int t = opt_find(T, blockIdx.x);
     const long long base = (long long)(blockIdx.x - T.first[t]) * OPT_CHUNK;
@@ -92,8 +92,8 @@ __global__ void __launch_bounds__(256) clip_adam_kernel(OptTable T, float lr, fl
     auto upd = [&](float& pp, float gg, float& mm, float& vv) {
         gg *= coef;
         if (weight_decay != 0.f) gg = fmaf(weight_decay, pp, gg);
-        mm = fmaf(1.0f - beta1, gg - mm, mm);               // lerp(m, g, 1 - beta1)
-        vv = fmaf(1.0f - beta2, gg * gg, beta2 * vv);
+        mm = fmaf(omb1, gg - mm, mm);               // lerp(m, g, 1 - beta1)
+        vv = fmaf(omb2, gg * gg, beta2 * vv);       // (1 - beta in double on the host, as torch rounds them: 1.0f - 0.999f is 1.3e-5 off)
         const float denom = sqrtf(vv) / bias2_sqrt + eps;
         pp -= step_size * (mm / denom);
     };
@@ -146,7 +146,7 @@ extern "C" int dagnn_grad_norm(const float* const* grads, const int64_t* numel, 
     return DAGNN_OK;
 }
 
-extern "C" int dagnn_clip_adam(const dagnn_opt_tensor* tensors, int n, float lr, float beta1, float beta2, float eps, float weight_decay,
+extern "C" int dagnn_clip_adam(const dagnn_opt_tensor* tensors, int n, double lr, double beta1, double beta2, double eps, double weight_decay,
                                int64_t step, float max_norm, const float* norm, void* stream) {
     if (!tensors || n <= 0 || n > DAGNN_MAX_OPT_TENSORS || step < 1 || (max_norm > 0.f && !norm)) return DAGNN_EINVAL;
     OptTable T;
@@ -160,9 +160,10 @@ extern "C" int dagnn_clip_adam(const dagnn_opt_tensor* tensors, int n, float lr,
         c += (int)k;
     }
     T.first[n] = c; T.count = n;
-    const double b1 = 1.0 - pow((double)beta1, (double)step), b2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)c), dim3(256), 0, (hipStream_t)stream, T, lr, beta1, beta2, eps, weight_decay,
-                       (float)b1, (float)sqrt(b2), max_norm, norm);
+    // (hyper-parameters arrive as doubles and are rounded to fp32 where torch rounds them: 1 - beta AFTER the subtraction)
+    const double b1 = 1.0 - pow(beta1, (double)step), b2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)c), dim3(256), 0, (hipStream_t)stream, T, (float)lr, (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)b1, (float)sqrt(b2), max_norm, norm);
     DAGNN_CHECK_LAUNCH();
     return DAGNN_OK;
 }

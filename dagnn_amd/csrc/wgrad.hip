@@ -305,6 +305,30 @@ extern "C" int dagnn_wgrad_splits(int num_cus, int njob, int Hp, int K2max, int6
     return s;
 }
 
+// One transposed product with a SMALL reduction and a LARGE output (the vocabulary heads' weight gradient: 128 graphs reduced,
+// 25 010 x 1 024 out - the opposite regime of the cells' products): the same wave tiles, no split, written straight to `out`.
+extern "C" int dagnn_tn_product(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t N, int M, int K2, float* out,
+                                float* colsum, void* stream) {
+    if (!A || !B || !out || N <= 0 || M <= 0 || K2 <= 0 || (K2 % 2) || lda < M || (lda % 4) || ldb < K2 || (ldb % 2) ||
+        lda > 0x7fffffff || ldb > 0x7fffffff || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 7) || (((uintptr_t)out) & 7))
+        return DAGNN_EINVAL;
+    // (the last float4 of a row may reach past column M - 1: lda % 4 == 0 keeps it inside the row's pitch, its products are
+    // rows >= M of the output and never stored)
+    if ((int64_t)((M + 3) / 4 * 4) > lda) return DAGNN_EINVAL;
+    WgArgs S;
+    S.job[0].A = A; S.job[0].B = B; S.job[0].dW = out; S.job[0].db = colsum;
+    S.job[0].lda = (int)lda; S.job[0].ldb = (int)ldb; S.job[0].K2 = K2;
+    S.njob = 1; S.M = M; S.Hp = M; S.H = M; S.splits = 1; S.N = N; S.K2max = K2;
+    S.tiles_m = (M + WG_TM - 1) / WG_TM;
+    S.tiles_k = (K2 + WG_TK - 1) / WG_TK;
+    S.wgs_per = (S.tiles_m * S.tiles_k + WG_WAVES - 1) / WG_WAVES;
+    S.part = out;        // partial tile of split 0 of job 0 == the result
+    S.bpart = colsum;
+    hipLaunchKernelGGL(wgrad_partial_kernel, dim3((unsigned)S.wgs_per), dim3(64 * WG_WAVES), 0, (hipStream_t)stream, S);
+    DAGNN_CHECK_LAUNCH();
+    return DAGNN_OK;
+}
+
 extern "C" int dagnn_wgrad_run(const dagnn_wgrad_job* jobs, int njob, int64_t N, int Hp, int H, int splits, void* workspace,
                                size_t workspace_bytes, void* stream) {
     if (!jobs || njob <= 0 || njob > WG_MAX_JOBS || N < 0 || Hp <= 0 || H <= 0 || H > Hp || (Hp % 4) || splits <= 0 ||

@@ -125,11 +125,22 @@ class _HeadsLinear(torch.autograd.Function):
     def backward(ctx, g):
         (out,) = ctx.saved_tensors
         wcat, V, S = ctx.wcat, ctx.V, ctx.S
-        g = g.contiguous()
+        if g.stride(1) != 1:
+            g = g.contiguous()
         d_out = g @ wcat if ctx.needs_input_grad[0] else None
         if ctx.needs[1]:
-            dw = g.t() @ out            # [S V, D]: the S weight gradients, one product
-            db = g.sum(0)
+            D = out.shape[1]
+            if g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0 and D % 2 == 0 and out.is_contiguous() and g.dtype == torch.float32:
+                # (rows pitched to a multiple of 4 floats - what train.seq_cross_entropy hands back: csrc/wgrad.hip's own tiles
+                # for a product that reduces 128 rows into 25 010 x 1 024 outputs, bias sums on the way)
+                dw = torch.empty(S * V, D, dtype=torch.float32, device=g.device)
+                db = torch.empty(S * V, dtype=torch.float32, device=g.device)
+                engine.check(engine._lib.load().dagnn_tn_product(g.data_ptr(), g.stride(0), out.data_ptr(), out.stride(0), g.shape[0],
+                                                                S * V, D, dw.data_ptr(), db.data_ptr(), engine._stream(g)),
+                             "dagnn_tn_product")
+            else:
+                dw = g.t() @ out            # [S V, D]: the S weight gradients, one product
+                db = g.sum(0)
             gw, gb = list(dw.split(V, 0)), list(db.split(V, 0))
         else:
             gw, gb = [None] * S, [None] * S

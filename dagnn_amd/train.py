@@ -206,7 +206,8 @@ class _SeqCE(torch.autograd.Function):
         B = base.shape[0]
         dev = base.device
         need_grad = base.requires_grad
-        dl = torch.empty_like(base) if need_grad else None
+        # (d logits with rows pitched to a multiple of 4 floats: what the heads' weight-gradient product reads 16 bytes at a time)
+        dl = torch.empty(B, (S * V + 3) // 4 * 4, dtype=torch.float32, device=dev)[:, :S * V] if need_grad else None
         row = torch.empty(B * S, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         key = (dev.index, engine._stream(base))
@@ -214,7 +215,8 @@ class _SeqCE(torch.autograd.Function):
         if cnt is None:
             cnt = _CE_COUNTERS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
         engine.check(lib.dagnn_seq_ce(base.data_ptr(), base.stride(0), y.data_ptr(), B, S, V, None if dl is None else dl.data_ptr(),
-                                      row.data_ptr(), loss.data_ptr(), cnt.data_ptr(), engine._stream(base)), "dagnn_seq_ce")
+                                      0 if dl is None else dl.stride(0), row.data_ptr(), loss.data_ptr(), cnt.data_ptr(),
+                                      engine._stream(base)), "dagnn_seq_ce")
         ctx.dl = dl
         return loss[0]
 

@@ -866,14 +866,21 @@ typedef struct dagnn_encode_args {
 } dagnn_encode_args;
 int dagnn_encode_forward(const dagnn_encode_args* args /* host */, void* stream);
 
+/* out [M, K2] = A^T B with A [N, lda >= M rounded up to 4], B [N, ldb]: the reduction over N rows is SMALL, the output large -
+ * the S vocabulary heads' weight gradient d logits^T x pooled vectors (dagnn.py:212-215 under main_pyg.py:62), where the
+ * library GEMM's pick for 25 010 x 1 024 x 128 runs at a quarter of the matrix rate; colsum [M] (may be NULL) = column sums of
+ * A (the heads' bias gradient).  fp32 MFMA, fixed summation order.  lda % 4 == 0, ldb and K2 even, A 16-byte aligned. */
+int dagnn_tn_product(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t N, int M, int K2, float* out,
+                     float* colsum, void* stream);
+
 /* The TOK task's training loss and its gradient in one launch (csrc/loss.hip; replaces the caller-side loop of
  * ogbg-code/main_pyg.py:55-60: `loss += CrossEntropyLoss()(pred_list[i], y_arr[:, i])` over the S heads, `/ S`).
  * logits [B, ld >= S * V]: head s's V outputs of graph b at b * ld + s * V (how DAGNN lays its heads' outputs side by side);
- * y [B, S] int64 targets in [0, V) (no ignore_index: an out-of-range target makes the loss NaN); dlogits (same layout, may be
+ * y [B, S] int64 targets in [0, V) (no ignore_index: an out-of-range target makes the loss NaN); dlogits (same layout with its own row pitch, may be
  * NULL) receives d loss / d logits = (softmax - onehot) / (B S); row_loss [B * S] scratch; loss [1]; counter [1] device word,
  * zero before the first call (the kernel leaves it zero).  Sums in a fixed order: bitwise reproducible. */
-int dagnn_seq_ce(const float* logits, int64_t ld, const int64_t* y, int B, int S, int V, float* dlogits, float* row_loss,
-                 float* loss, unsigned* counter, void* stream);
+int dagnn_seq_ce(const float* logits, int64_t ld, const int64_t* y, int B, int S, int V, float* dlogits, int64_t ld_dlogits,
+                 float* row_loss, float* loss, unsigned* counter, void* stream);
 
 /* The tail of the reference's training step - `clip_grad_norm_(model.parameters(), clip)` + `optim.Adam.step()`
  * (ogbg-code/main_pyg.py:63-65,179) - over a table of fp32 tensors (csrc/optim.hip).  dagnn_grad_norm: the 2-norm of up to
@@ -888,8 +895,8 @@ int64_t dagnn_opt_chunks(const int64_t* numel /* host */, int n);
 int dagnn_grad_norm(const float* const* grads /* host array of device pointers */, const int64_t* numel /* host */, int n,
                     float* partial, int64_t partial_len, float* norm_sq /* device [1] */, int accumulate, float* norm /* device [1] */,
                     void* stream);
-int dagnn_clip_adam(const dagnn_opt_tensor* tensors /* host */, int n, float lr, float beta1, float beta2, float eps,
-                    float weight_decay, int64_t step, float max_norm, const float* norm /* device */, void* stream);
+int dagnn_clip_adam(const dagnn_opt_tensor* tensors /* host */, int n, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, int64_t step, float max_norm, const float* norm /* device */, void* stream);
 
 /* Guard of the host side's derived-weight caches (dagnn_amd/core.py: ParamGuard; nothing in the reference corresponds - its
  * modules read their parameters on every call).  A fingerprint of up to DAGNN_MAX_FP_TENSORS fp32 / int32 tensors: 1024 words

@@ -964,7 +964,7 @@ __device__ __forceinline__ void bd_compute(const BdArgs& S, const BdCell& C, int
     // the store variants are hoisted out of the loop).
     typedef int i4v __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) const volatile i4v* lds_i4p;
-    const lds_i4p rdy_p = (lds_i4p)(unsigned)(uintptr_t)lds.rdy;
+    const lds_i4p rdy_p = (lds_i4p)(uintptr_t)(unsigned)(uintptr_t)lds.rdy;   // (an LDS address is the low 32 bits of the generic pointer)
     static_assert(DF_NLS == 2 && BD_WPS == 4, "two streams, four ready flags each");
     const bool lane_st = (lane & 16) == 0;   // (lanes 16 away hold the same sums)
     int* const dn_or_dump = lane == 0 ? lds.dn + cw : lds.dump + lane;

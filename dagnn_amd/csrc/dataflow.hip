@@ -1067,7 +1067,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     // other lanes write into a dump area), the gates evaluated by every lane, the store variants hoisted out of the loop.
     typedef int i4v __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) const volatile i4v* lds_i4p;
-    const lds_i4p rdy_p = (lds_i4p)(unsigned)(uintptr_t)lds.rdy;
+    const lds_i4p rdy_p = (lds_i4p)(uintptr_t)(unsigned)(uintptr_t)lds.rdy;   // (an LDS address is the low 32 bits of the generic pointer)
     const bool lane_st = (lane & 16) == 0;   // (lanes 16 away hold the same sums)
     // done flag: lane 0 writes dn[st][cw], the others a word of their own in the dump area
     int* const dn_or_dump = lane == 0 ? lds.dn + cw : reinterpret_cast<int*>(lds.bias) + lane;
@@ -1139,8 +1139,9 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
                 float4 bv[NK4];
 #pragma unroll
                 for (int q = 0; q < NK4; ++q) bv[q] = *reinterpret_cast<const float4*>(a_seg + 4 * q);
-                __builtin_amdgcn_sched_barrier(0);   // (every read in flight before the first product: left alone the scheduler
-                                                     // sinks them between the products, two registers ahead of their use)
+                if (KPT <= 16) __builtin_amdgcn_sched_barrier(0);   // (every read in flight before the first product: left alone the
+                                                     // scheduler sinks them between the products, two registers ahead of their use -
+                                                     // which is what H = 320 needs: its 120 weight registers leave no room for 40 more)
 #ifdef DF_EXP_NOOPLD   // timing experiment: no operand reads from LDS
 #pragma unroll
                 for (int q = 0; q < NK4; ++q) bv[q] = make_float4(wr[q], wz[q], wn[q], aval);

@@ -714,7 +714,7 @@ def main():
             if ms_fwd > 0:
                 tf = flops / (ms_fwd * 1e-3) / 1e12
                 traffic, traffic_source = None, None
-                tname = "r05_pmc_traffic.json" if df else "pmc_traffic.json"
+                tname = "r06_pmc_traffic.json" if df else "pmc_traffic.json"
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if lock and os.path.exists(tpath):  # separate rocprofv3 --pmc passes of this command, see profiles/README.md
                     rec = json.load(open(tpath))
@@ -747,11 +747,22 @@ def main():
                     "forwards_timed": n_rec // calls_per_step, "recurrence_ms_per_forward": round(ms_fwd, 4),
                     "algorithmic_flops_per_forward": flops, "algorithmic_bytes_per_forward": byts,
                     "hbm_frac_of_8TBps": round(byts / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                    # the gather stage on its own ("achieved_GBps = D L (E + N) 4H / t_recurrence"): the loader
+                    # waves' stream of predecessor rows + the rows written, against the 8 TB/s HBM peak; `traffic_split` (when
+                    # the PMC file is current) sets the counters' read and write totals beside it
+                    "gather_GBps": round(D * L * (E + N) * 4.0 * H / (ms_fwd * 1e-3) / 1e9, 1),
+                    "gather_frac_of_8TBps": round(D * L * (E + N) * 4.0 * H / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                    "traffic_split": ({"fetch_bytes": rec.get("fetch_bytes_per_forward"), "write_bytes": rec.get("write_bytes_per_forward"),
+                                       "what": "FETCH_SIZE (doubled: MI355X_MICROARCH.md, HBM) = the loaders' polls of predecessor and "
+                                               "projection granules that miss the XCD's L2 + weights / records / gi0; WRITE_SIZE = state "
+                                               "rows (plain) + their granules + the [N, 3H] projection granules"}
+                                      if traffic is not None else None),
                     "us_per_topological_layer": round(ms_fwd * 1e3 / max(T + L - 1, 1), 3),
                     "schedule": "dataflow" if df else model.schedule,
-                    "note": "fp32 matrix peak (the path computes in fp32: 1e-4 after ~375 dependent steps); the kernel is "
-                            "bound by dependent-chain latency (one granule hand-off per topological layer of the deepest "
-                            "graph) and by its loader waves' trips to memory, not by HBM bandwidth (hbm_frac)",
+                    "note": "fp32 matrix peak (the path computes in fp32: 1e-4 after ~375 dependent steps); round 6: the kernel is "
+                            "bound by the instruction issue of its specialised waves (ONE compute wave per SIMD pays ~5 cycles per "
+                            "instruction around 96 products per 4-row block), then by dependent-chain latency (one granule "
+                            "hand-off per topological layer of the deepest graph) - not by HBM bandwidth (hbm_frac, gather_GBps)",
                 }
         if detail is not None:   # the instrumented pass: spans include their own event cost (~8 us a pair)
             dsum = detail.summary()

@@ -7,6 +7,19 @@
 
 #define DAGNN_WAVE 64
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: done once per device and kernel (a bit per device ordinal in a
+// process-wide atomic mask; a device beyond 63 sets it on every call).  Returns hipSuccess or the call's error.
+#include <atomic>
+static inline hipError_t dagnn_lds_attr_once(std::atomic<unsigned long long>& done, const void* fn, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 64;
+    const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && bit) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+
 // Fork / join of a side stream around a host-side launch loop, on two events the CALLER owns (the library creates and
 // destroys nothing).  The destructor is the single exit path: whatever return statement leaves the function, the
 // caller's stream is ordered behind the work already queued on the side stream (which still reads and writes buffers

@@ -561,13 +561,9 @@ extern "C" int dagnn_fat_debug_read(unsigned long long* out16, int reset) {
 int dagnn_fat_launch(const int32_t* plan, const PlanLayout& L, const Cell* cells, int ncell, int H, int ld_h, int R, int vid_mod,
                      unsigned epoch, float* scratch, int num_cus, hipStream_t st) {
     if (ncell <= 0 || ncell > DAGNN_MAX_CELLS || (H % 64) || !scratch) return DAGNN_EINVAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fat_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)FAT_LDS_ALONE) != hipSuccess)
-            return DAGNN_EHIP(hipGetLastError());
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0ull};
+    if (dagnn_lds_attr_once(attr_done, reinterpret_cast<const void*>(fat_layer_kernel), (int)FAT_LDS_ALONE) != hipSuccess)
+        return DAGNN_EHIP(hipGetLastError());
     FatArgs A;
     int off = 0, tiles = 0;
     A.tile_start[0] = 0;

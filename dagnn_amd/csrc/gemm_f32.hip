@@ -317,13 +317,9 @@ extern "C" int dagnn_gemm_nt_bias(const dagnn_gemm_group* groups, int num_groups
     static const bool k32_off = getenv("DAGNN_AMD_GEMM_K32") && getenv("DAGNN_AMD_GEMM_K32")[0] == '0';   // A/B knob
     if (vec && K % GK == 0 && !k32_off) {
         constexpr size_t lds = (size_t)2 * 2 * BM * GP * sizeof(float);   // 72 KB: two blocks per CU
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bias_k32_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return DAGNN_EHIP(hipGetLastError());
-            attr_set = true;
-        }
+        static std::atomic<unsigned long long> attr_done{0ull};
+        if (dagnn_lds_attr_once(attr_done, reinterpret_cast<const void*>(gemm_nt_bias_k32_kernel), (int)lds) != hipSuccess)
+            return DAGNN_EHIP(hipGetLastError());
         hipLaunchKernelGGL(gemm_nt_bias_k32_kernel, grid, dim3(256), lds, (hipStream_t)stream, G, M, Nc, K, lda, ldw, ldc,
                            tiles_m, tiles_n);
     } else if (vec)

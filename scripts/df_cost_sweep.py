@@ -11,7 +11,7 @@ for B, seed in ((128, 0), (128, 1), (128, 2), (128, 3), (64, 4), (256, 5), (512,
     b = synth.code2_batch(seed, B)
     b.x[:, 1] %= 10030
     row = []
-    for cost in (3, 4, 5, 6, 8, 12):
+    for cost in (2, 3, 4, 5, 6, 8, 12):
         engine.DF_COST_LAYER = cost
         engine.TIMER = engine.KernelTimer(only=("dataflow_run",))
         with torch.no_grad():

@@ -52,7 +52,7 @@ def main():
     # "auto": every forward of the command launches the recurrence kernel exactly once, whatever legs bench.py runs
     forwards = int(sum(fc[k] for k in fc if k.startswith(RECURRENCE))) if sys.argv[3] == "auto" else int(sys.argv[3])
     per = {}
-    rec_bytes = 0.0
+    rec_bytes = rec_fetch = rec_write = 0.0
     for k in sorted(ft, key=lambda k: -ft[k]):
         if not k.endswith("_kernel") and "_kernel<" not in k:
             continue
@@ -61,6 +61,8 @@ def main():
                   "WRITE_SIZE_KiB": round(w_kib, 1), "hbm_bytes_corrected": int((2 * f_kib + w_kib) * 1024)}
         if k.startswith(RECURRENCE):
             rec_bytes += (2 * f_kib + w_kib) * 1024
+            rec_fetch += 2 * f_kib * 1024
+            rec_write += w_kib * 1024
     out = {
         "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over `python bench.py "
                 "--steps 2 --warmup 1 --cpu-passes 0 --no-kernel-timer --train-steps 0 --other-configs 0` (%d forwards: the headline leg, the loader-side-plan leg and the separate-calls leg; the recurrence kernel is the same in all three). Counter "
@@ -71,6 +73,8 @@ def main():
         "recurrence_kernels": list(RECURRENCE),
         "kernel_sources_sha16": sources_sha16(),
         "recurrence_hbm_bytes_per_forward": int(rec_bytes),
+        "fetch_bytes_per_forward": int(rec_fetch),    # (FETCH_SIZE doubled)
+        "write_bytes_per_forward": int(rec_write),
     }
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "profiles", out_name), "w") as f:

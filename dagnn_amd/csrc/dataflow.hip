@@ -178,25 +178,15 @@ __device__ __forceinline__ float df_tanh(float x) { return 1.0f - 2.0f * __built
 
 // operand rows in LDS: the K dimension is split over 8 lanes (KP8 = H / 8 = 2 KPT values each); K-lane segment s
 // starts at s * (KP8 + 4): the 8 segments a half DPP row reads concurrently (ds_read_b128) fall on disjoint banks
-// The forward kernel's compute shape (the reverse sweep keeps DF_NCW = 4 of df_common.h):
-//   DFF_NCW = 4  one compute wave per SIMD, 8 hidden units each (3 H/8 resident weights per lane), K split over 8 lanes;
-//   DFF_NCW = 8  two compute waves per SIMD, 4 hidden units each (3 H/16 weights per lane), K split over 16 lanes - waves
-//                cw and cw + 4 share a SIMD (a workgroup's waves go to the SIMDs cyclically), so one wave's reduce / gate /
-//                store epilogue issues beside the other's MFMA burst; 16 waves per workgroup = 4 per SIMD at <= 128 VGPRs.
-#ifndef DFF_NCW_V
-#define DFF_NCW_V 4   // (8: measured in round 6, 1.50 against 1.33 ms on the headline batch, 9.15 against 8.26 at B = 1024: DESIGN 4a)
-#endif
-constexpr int DFF_NCW = DFF_NCW_V;
+// The forward kernel's compute shape: one compute wave per SIMD, 8 hidden units each (3 H/8 resident weights per lane), K split over
+// 8 lanes.  (Round 6 measured the other shape the register file allows - two compute waves per SIMD with 4 units each, K over 16
+// lanes, 16 waves per workgroup at <= 128 VGPRs: 1.50 against 1.33 ms on the headline batch; the complete kernel
+// path is scripts/experiments/dataflow_split_r06.patch.)
+constexpr int DFF_NCW = DF_NCW;
 constexpr int DFF_THREADS = 64 * (DFF_NCW + DF_NLW);
-constexpr int DFF_NKS = DFF_NCW == 8 ? 16 : 8;   // K slices = lanes a unit's dot product is spread over
-// K slice s of an operand row starts at s * seg (seg = K values per slice + padding), rows are `row` words apart: the 16 lanes a
-// ds_read_b128 serves per LDS cycle (4 K slices x 4 rows, MI355X_MICROARCH.md, LDS) fall on disjoint banks -
-//   8 slices:  seg = H/8 + 4, row = 8 seg + 8;   16 slices: seg / 4 odd, row / 4 = 4 (mod 16)
-template <int KPT> struct DfPad {
-    static constexpr int kp8 = 16 * KPT / DFF_NKS;   // K values per slice
-    static constexpr int seg = DFF_NKS == 8 ? kp8 + 4 : ((kp8 / 4) & 1 ? kp8 + 8 : kp8 + 4);
-    static constexpr int row = DFF_NKS == 8 ? 8 * seg + 8 : 16 * seg + 16;
-};
+// operand rows in LDS: the K dimension is split over 8 lanes (KP8 = H / 8 values each); K-lane segment s starts at
+// s * (KP8 + 4): the 8 segments a half DPP row reads concurrently (ds_read_b128) fall on disjoint banks
+template <int KPT> struct DfPad { static constexpr int kp8 = 2 * KPT; static constexpr int seg = kp8 + 4; static constexpr int row = 8 * seg + 8; };
 
 constexpr int DF_CSLEEP_N = 1;   // s_sleep argument (x 64 cycles) of the compute waves' look at the ready flags
 #ifndef DF_WSLEEP_V
@@ -242,7 +232,6 @@ __device__ __forceinline__ bool df_wait4(const int* f, int target, int* err, uns
     unsigned spins = 0;
     for (;;) {
         int m = min(min(df_flag_ld(f), df_flag_ld(f + 1)), min(df_flag_ld(f + 2), df_flag_ld(f + 3)));   // (every compute wave's flag)
-        if (DFF_NCW == 8) m = min(m, min(min(df_flag_ld(f + 4), df_flag_ld(f + 5)), min(df_flag_ld(f + 6), df_flag_ld(f + 7))));
         if (m >= target) return true;
         __builtin_amdgcn_s_sleep(DF_WSLEEP_N);
         if (++spins > 4 * limit) { __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
@@ -1244,192 +1233,6 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     else { if (aux_out) run(std::false_type(), std::true_type()); else run(std::false_type(), std::false_type()); }
 }
 
-// x + (x of the lane 32 away): v_permlane32_swap on two copies of x leaves the low half of the wave in both halves of one
-// and the high half in both halves of the other (inline asm for the reasons given at df_row_pair_sum)
-__device__ __forceinline__ float df_half_sum(float x) {
-    float a = x, b = x;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return a + b;
-}
-
-#ifndef DF_MB_V
-#define DF_MB_V 4
-#endif
-constexpr int DF_MB = DF_MB_V;   // blocks of ONE stream a compute wave takes per look at the ready flags (<= DF_NSLOT)
-static_assert(DF_MB >= 1 && DF_MB <= 4 && DF_MB <= DF_NSLOT, "");
-
-// ---- compute wave `cw` of the 8-wave form (DFF_NCW = 8): hidden units [4 cw, 4 cw + 4) of the slice.  Lane = (K slice
-// ks = lane >> 2 of H/16 values, x = lane & 3):
-//   A operand  W[unit 4 cw + x][k]   - 3 x H/16 resident weights per lane,   B operand  a[row x][k]  from LDS,
-//   D[i][x] (register i) += W[unit 4 cw + i][k] a[row x][k]   for the lane's K slice: 3 H/16 instructions per block.
-// The 16 K slices are summed by a reduce-scatter over lane bits 2, 3 (DPP row_shl/shr 4, then 8: one unit of the four stays)
-// and an all-reduce over bits 4, 5 (v_permlane16_swap, v_permlane32_swap): every lane (ks, x) ends with the three gate sums
-// of unit 4 cw + 2 (ks & 1) + ((ks >> 1) & 1) for row x - FOUR times over (ks >> 2 = 0..3).  That redundancy is what lets a wave
-// take up to DF_MB = 4 ready blocks of a stream per look at the flags: the products and the reduction run per block, then the
-// lanes with ks >> 2 = i take block i's sums and ONE pass over gates, flag and stores serves all of them (a block that is
-// ready has every input it needs, so consecutive ready blocks of a stream never depend on each other).
-template <int KPT, int KIND>
-__device__ __forceinline__ void df_compute_split(const DfArgs& S, const DfCell& C, int sl, int pair, const DfLds& lds, int cw) {
-    constexpr int H = 16 * KPT;
-    constexpr int SEG = DfPad<KPT>::seg, KP = DfPad<KPT>::kp8, NK4 = KP / 4;
-    constexpr int NCT = 64 * DFF_NCW;
-    static_assert(DFF_NKS == 16 || DFF_NCW != 8, "");
-    typedef DfSlot<KPT> Slot;
-    const int tc = threadIdx.x & (NCT - 1);   // position among the compute waves (they come first)
-    const int lane = tc & 63;
-    const int ks = lane >> 2, x = lane & 3;
-    const bool s0 = (ks & 1) != 0, s1 = (ks & 2) != 0;
-    const int rq = ks >> 2;                   // the block (of those taken per look) this lane evaluates the gates of
-    constexpr bool proj = KIND == DFK_PROJ;
-    constexpr bool gi_ring = KIND == DFK_REC0;
-    const int d = C.dir;
-    int nb[DF_NLS];
-#pragma unroll
-    for (int q = 0; q < DF_NLS; ++q) {
-        const int grp = df_stream_group(pair, q, S.groups);
-        nb[q] = grp >= 0 ? S.sched[S.gtab[d] + 2 * grp + 1] : 0;
-    }
-    float wr[KP], wz[KP], wn[KP];   // the lane's K slice of the r / z / n rows of unit 4 cw + x
-    {
-        const float4* wp = C.w + (int64_t)sl * (3 * NK4) * NCT + tc;
-#pragma unroll
-        for (int q = 0; q < NK4; ++q) {
-            const float4 x0 = wp[(0 * NK4 + q) * NCT], x1 = wp[(1 * NK4 + q) * NCT], x2 = wp[(2 * NK4 + q) * NCT];
-            wr[4 * q] = x0.x; wr[4 * q + 1] = x0.y; wr[4 * q + 2] = x0.z; wr[4 * q + 3] = x0.w;
-            wz[4 * q] = x1.x; wz[4 * q + 1] = x1.y; wz[4 * q + 2] = x1.z; wz[4 * q + 3] = x1.w;
-            wn[4 * q] = x2.x; wn[4 * q + 1] = x2.y; wn[4 * q + 2] = x2.z; wn[4 * q + 3] = x2.w;
-        }
-#pragma unroll
-        for (int k = 0; k < KP; ++k) asm volatile("" : "+v"(wr[k]), "+v"(wz[k]), "+v"(wn[k]));   // landed before the block loop
-    }
-    const int unit_l = 4 * cw + 2 * (ks & 1) + ((ks >> 1) & 1), unit = sl * DF_JS + unit_l;   // after the reduction
-    float b_r = C.bias[unit], b_z = C.bias[H + unit], b_n = C.bias[2 * H + unit];
-    asm volatile("" : "+v"(b_r), "+v"(b_z), "+v"(b_n));
-    const int apos = unit + (SEG - KP) * (unit / KP);   // LDS position of column `unit` of an operand row
-    const unsigned epoch = S.epoch, spin_limit = S.spin_limit;
-    int* const err = S.err;
-    float* const h_out = C.h_out;
-    float* const aux_out = C.aux_out;
-    gran_t* const g_out = C.g_out;
-    const bool local_st = !proj && lds.local[0] != 0;
-    const int ld_h = S.ld_h, gld = S.gld, pld = S.pld, num_nodes = S.N;
-    const int b_off = Slot::a_off + x * Slot::AP + ks * SEG;   // B operand of this lane inside a slot: row x, K slice ks
-    const int g_off = x * (3 * DF_JS) + unit_l;                // gate operands of (row x, unit) inside a block's gi rows
-    const unsigned rdy_a = (unsigned)(uintptr_t)lds.rdy;
-    static_assert(DF_NLS == 2 && DF_WPS == 4, "the look at the ready flags reads 2 x 4 words");
-
-    int done[DF_NLS] = {0, 0};
-    int left = nb[0] + nb[1], pref = 0;
-    while (left > 0) {
-        // smallest positive lead first (the latency-bound stream), ties alternate; ONE trip to LDS per look
-        typedef int i4v __attribute__((ext_vector_type(4)));
-        int st = 0, lead = 1;
-        unsigned spins = 0;
-        for (;;) {
-            i4v r0, r1;
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(r0), "=&v"(r1) : "v"(rdy_a) : "memory");
-            const int m0 = __builtin_amdgcn_readfirstlane(min(min(r0.x, r0.y), min(r0.z, r0.w)));
-            const int m1 = __builtin_amdgcn_readfirstlane(min(min(r1.x, r1.y), min(r1.z, r1.w)));
-            const int l0 = done[0] < nb[0] ? m0 - done[0] : 0, l1 = done[1] < nb[1] ? m1 - done[1] : 0;
-            if (l0 > 0 || l1 > 0) {
-                st = l0 <= 0 ? 1 : (l1 <= 0 ? 0 : (l0 != l1 ? (l0 < l1 ? 0 : 1) : pref));
-                lead = st ? l1 : l0;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(DF_CSLEEP_N);
-            bool give_up = false;
-            if (++spins > 4 * spin_limit) {   // the pass is lost; it must still end (node ids are bounded below)
-                __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                give_up = true;
-            }
-            if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = true;
-            if (give_up) { st = done[0] < nb[0] ? 0 : 1; lead = 1; break; }
-        }
-        st = __builtin_amdgcn_readfirstlane(st);
-        const int nbk = __builtin_amdgcn_readfirstlane(min(lead, DF_MB));
-        pref = st ^ 1;
-        const int b = st ? done[1] : done[0];
-        if (st) done[1] += nbk; else done[0] += nbk;
-        left -= nbk;
-        const float* const ring_st = lds.ring + st * (DF_NSLOT * Slot::words);
-        // this lane's own block of the look: node id, gate operands (requested now, used after the products; a lane whose
-        // block was not taken reads a slot that may be in flux and drops the words)
-        const int bq = b + rq;
-        const float* const sown = ring_st + ((unsigned)bq % DF_NSLOT) * Slot::words;
-        const int gv = reinterpret_cast<const int*>(sown + Slot::v_off)[x];
-        float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, aval = 0.f;
-        if (!proj) {
-            const float* gp = (gi_ring ? lds.giring + (st * DF_GIRING + (unsigned)bq % DF_GIRING) * (DF_RB * 3 * DF_JS) : sown + Slot::gi_off) + g_off;
-            gi_r = gp[0]; gi_z = gp[DF_JS]; gi_n = gp[2 * DF_JS];
-            aval = sown[Slot::a_off + x * Slot::AP + apos];
-        }
-        float g3[DF_MB][3];
-#pragma unroll
-        for (int i = 0; i < DF_MB; ++i) {
-            g3[i][0] = g3[i][1] = g3[i][2] = 0.f;
-            if (i < nbk) {   // (wave-uniform)
-                const float* a_seg = ring_st + ((unsigned)(b + i) % DF_NSLOT) * Slot::words + b_off;
-                float4 bv[NK4];
-#pragma unroll
-                for (int q = 0; q < NK4; ++q) bv[q] = *reinterpret_cast<const float4*>(a_seg + 4 * q);
-                f4v acc[3] = {(f4v){0.f, 0.f, 0.f, 0.f}, (f4v){0.f, 0.f, 0.f, 0.f}, (f4v){0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                for (int q = 0; q < NK4; ++q) {
-                    const float bqv[4] = {bv[q].x, bv[q].y, bv[q].z, bv[q].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q + e], bqv[e], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wz[4 * q + e], bqv[e], acc[1], 0, 0, 0);
-                        acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(wn[4 * q + e], bqv[e], acc[2], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    // (every DPP op outside the selects: inside a divergent branch its source lanes would be switched off)
-                    const float u0 = acc[a][0] + df_dpp<0x104>(acc[a][0]), u1 = acc[a][1] + df_dpp<0x104>(acc[a][1]);   // + the lane 4 up
-                    const float u2 = acc[a][2] + df_dpp<0x114>(acc[a][2]), u3 = acc[a][3] + df_dpp<0x114>(acc[a][3]);   // + the lane 4 down
-                    const float e0 = s0 ? u2 : u0, e1 = s0 ? u3 : u1;   // units (2, 3) | (0, 1)
-                    const float f0 = e0 + df_dpp<0x108>(e0), f1 = e1 + df_dpp<0x118>(e1);
-                    const float f = s1 ? f1 : f0;
-                    g3[i][a] = df_half_sum(df_row_pair_sum(f));
-                }
-            }
-        }
-        float g_r = g3[0][0], g_z = g3[0][1], g_n = g3[0][2];
-#pragma unroll
-        for (int i = 1; i < DF_MB; ++i) if (rq == i) { g_r = g3[i][0]; g_z = g3[i][1]; g_n = g3[i][2]; }
-        // (the bound on the node id also covers padding rows, id -1, and a slot that may hold anything once a wait has expired)
-        const bool live = rq < nbk && (unsigned)gv < (unsigned)num_nodes;
-        float hv = 0.f;
-        if (live && !proj) {
-            const float rg = df_sigm(g_r + b_r + gi_r);
-            const float zg = df_sigm(g_z + b_z + gi_z);
-            const float ng = df_tanh(fmaf(rg, g_n + b_n, gi_n));
-            hv = fmaf(zg, aval - ng, ng);   // n + z * (a - n)
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) df_flag_st(lds.dn + st * DFF_NCW + cw, b + nbk);   // this wave is done with the slots (LDS executes a wave's accesses in order)
-        if (live) {
-            if (proj) {   // input-side pre-activations of the upper cell: W_ih u + b_ih, gate-major
-                gran_t* po = g_out + (int64_t)gv * pld + unit;
-                __hip_atomic_store(po, gran_pack(epoch, g_r + b_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(po + H, gran_pack(epoch, g_z + b_z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(po + 2 * H, gran_pack(epoch, g_n + b_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                // hand-off store first (see df_compute), the plain state row behind it
-                if (local_st) g_out[(int64_t)gv * gld + unit] = gran_pack(epoch, hv);
-                else __hip_atomic_store(g_out + (int64_t)gv * gld + unit, gran_pack(epoch, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                h_out[(int64_t)gv * ld_h + unit] = hv;
-            }
-            if (aux_out) {   // (behind the hand-off stores: nobody waits for these)
-                float* ao = aux_out + (int64_t)gv * (3 * H) + unit;
-                ao[0] = g_r + b_r; ao[H] = g_z + b_z; ao[2 * H] = g_n + b_n;
-            }
-        }
-    }
-}
-
 template <int KPT>
 __global__ void __launch_bounds__(DFF_THREADS, DFF_THREADS / 256) dataflow_kernel(const int32_t* __restrict__ plan, DfArgs S) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1507,18 +1310,10 @@ __global__ void __launch_bounds__(DFF_THREADS, DFF_THREADS / 256) dataflow_kerne
     const int variant = C.variant;
     if (wave < DFF_NCW) {
         const int cw = wave;
-        if constexpr (DFF_NCW == 8) {
-            switch (variant >> 2) {
-                case DFK_REC0: df_compute_split<KPT, DFK_REC0>(S, C, sl, pair, lds, cw); break;
-                case DFK_RECP: df_compute_split<KPT, DFK_RECP>(S, C, sl, pair, lds, cw); break;
-                default: df_compute_split<KPT, DFK_PROJ>(S, C, sl, pair, lds, cw); break;
-            }
-        } else {
-            switch (variant >> 2) {
-                case DFK_REC0: df_compute<KPT, DFK_REC0>(S, C, sl, pair, lds, cw); break;
-                case DFK_RECP: df_compute<KPT, DFK_RECP>(S, C, sl, pair, lds, cw); break;
-                default: df_compute<KPT, DFK_PROJ>(S, C, sl, pair, lds, cw); break;
-            }
+        switch (variant >> 2) {
+            case DFK_REC0: df_compute<KPT, DFK_REC0>(S, C, sl, pair, lds, cw); break;
+            case DFK_RECP: df_compute<KPT, DFK_RECP>(S, C, sl, pair, lds, cw); break;
+            default: df_compute<KPT, DFK_PROJ>(S, C, sl, pair, lds, cw); break;
         }
     } else {
         const int set = (wave - DFF_NCW) / DF_WPS;
@@ -1550,23 +1345,20 @@ template <int KPT> size_t df_lds_bytes() {
     return (size_t)DF_NLS * (DF_NSLOT * DfSlot<KPT>::words + DF_GIRING * DF_RB * 3 * DF_JS + DF_RB * 8 * 16) * 4 + 128 + 3 * DF_JS * 4 + 128;
 }
 
-// Which element of W the idx-th float4 of a packed matrix holds.  Two layouts: the 4-compute-wave one (256 compute threads,
-// 8 units per wave, K over 8 lanes: the reverse sweep's transposed packs always, the forward kernel at H = 320) and the
-// 8-compute-wave one of df_compute_split (512 compute threads, 4 units per wave, K over 16 lanes: forward, H <= 256).
+// Which element of W the idx-th float4 of a packed matrix holds: thread tc = (compute wave tc >> 6, unit quad (tc >> 5) & 1, K slice
+// (tc >> 2) & 7, unit of the quad tc & 3) of the 256 compute threads.
 struct DfPackPos { int sl, g, k4, unit, ks, kp; };
 __device__ __forceinline__ DfPackPos df_pack_pos(int64_t idx, int H, bool transposed) {
-    const bool split = !transposed && H <= 256 && DFF_NCW == 8;
-    const int nct = split ? 512 : 256, nks = split ? 16 : 8;
+    (void)transposed;
     DfPackPos P;
-    P.kp = H / nks;
+    P.kp = H >> 3;
     const int nk4 = P.kp >> 2, nq = 3 * nk4;
-    const int tc = (int)(idx % nct);
-    const int64_t rest = idx / nct;
+    const int tc = (int)(idx & 255);
+    const int64_t rest = idx >> 8;
     const int q = (int)(rest % nq);
     P.sl = (int)(rest / nq);
     P.g = q / nk4; P.k4 = q - P.g * nk4;
-    if (split) { P.unit = P.sl * DF_JS + 4 * (tc >> 6) + (tc & 3); P.ks = (tc >> 2) & 15; }
-    else { P.unit = P.sl * DF_JS + 8 * (tc >> 6) + 4 * ((tc >> 5) & 1) + (tc & 3); P.ks = (tc >> 2) & 7; }
+    P.unit = P.sl * DF_JS + 8 * (tc >> 6) + 4 * ((tc >> 5) & 1) + (tc & 3); P.ks = (tc >> 2) & 7;
     return P;
 }
 

@@ -2,7 +2,7 @@
 # Matrix-core utilisation of every kernel that issues MFMAs today: ONE counter set (SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CU_CYCLES,
 # SQ_INSTS_VALU_MFMA_MOPS_F32, GRBM_GUI_ACTIVE), collected in separate `rocprofv3 --pmc` runs (no trace domains next to them)
 # of four workloads: headline forward + training steps, the reference's training shape (emb_dim 300), cfg 5, cfg 5 on the
-# tile kernel alone.  Folded per kernel into gpurun_out/<name>.json (copy to profiles/).   usage: scripts/pmc_mfma.sh r05_pmc_mfma
+# tile kernel alone.  Folded per kernel into gpurun_out/<name>.json (copy to profiles/).   usage: scripts/pmc_mfma.sh r06_pmc_mfma
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 NAME=${1:-r05_pmc_mfma}
 C="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE"

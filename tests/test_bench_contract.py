@@ -33,7 +33,7 @@ def _check_line(j, n_gpus, steps, warmup, with_cpu=True):
 
 
 @pytest.mark.parametrize("name", ["r01_final_bench.json.log", "r02_final_bench.json.log", "r03_final_bench.json.log",
-                                  "r04_final_bench.json.log", "r05_final_bench.json.log"])
+                                  "r04_final_bench.json.log", "r05_final_bench.json.log", "r06_final_bench.json.log"])
 def test_committed_round_line_keeps_the_contract(name):
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
@@ -53,7 +53,7 @@ def test_committed_round_line_keeps_the_contract(name):
         assert j["roofline"]["schedule"] == "dataflow" and j["roofline"]["frac"] > 0.15
         assert set(j["other_configs"]) >= {"cfg1_NA_B64_h128_L2_unidir", "cfg4_BN_B128_h256_L2_bidir", "cfg5_code2_B256_h512_L5_bidir"}
         assert j["training_step"]["kernels_ms_per_step"]["backward_run"] < 3.0
-    if name.startswith(("r04", "r05")):   # rounds 4-5: + the reference's own training shape, the full training step with clip_grad_norm
+    if name.startswith(("r04", "r05", "r06")):   # rounds 4-6: + the reference's own training shape, the full training step with clip_grad_norm
         rnd = name[:3]
         assert j["roofline"]["traffic_source"].startswith("profiles/%s_pmc_traffic.json" % rnd) and j["roofline"]["traffic"] > 0
         assert j["roofline"]["schedule"] == "dataflow" and j["roofline"]["frac"] > 0.18
@@ -61,7 +61,15 @@ def test_committed_round_line_keeps_the_contract(name):
                                            "ogb_tok_h300_L2_B160"}
         assert j["training_step"]["kernels_ms_per_step"]["backward_run"] < 2.0 and j["training_step"]["ms_per_step_median"] > 0
         assert j["loader_side_plan"]["ms_per_step"] < j["ms_per_step"]
-    if name.startswith("r05"):   # round 5: the line says how the front of the recurrence is built, and times the unfused / unfolded path beside it
+    if name.startswith("r06"):   # round 6: the leaner kernel, the gather stream's own figure, the training tail through the library's entries
+        r = j["roofline"]
+        assert r["frac"] > 0.22 and r["recurrence_ms_per_forward"] < 1.2
+        assert r["gather_GBps"] > 0 and abs(r["gather_frac_of_8TBps"] - r["gather_GBps"] / 8000.0) < 1e-3
+        assert r["traffic_split"]["fetch_bytes"] + r["traffic_split"]["write_bytes"] == r["traffic"]
+        assert "seq_cross_entropy" in j["training_step"]["loss"] and "ClipAdam" in j["training_step"]["optimizer"]
+        h300 = j["other_configs"]["ogb_tok_h300_L2_B160"]["roofline"]
+        assert h300["gflop_per_forward"] < h300["gflop_per_forward_padded"]   # priced on the model's own width
+    if name.startswith(("r05", "r06")):   # round 5: the line says how the front of the recurrence is built, and times the unfused / unfolded path beside it
         assert "dagnn_prepare" in j["config"]["front_of_recurrence"] and "folded" in j["config"]["front_of_recurrence"]
         assert j["separate_calls_no_folding"]["ms_per_step"] > j["ms_per_step"] > 0
         assert j["kernels_ms_per_step"]["prepare"] < 0.15

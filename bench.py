@@ -169,17 +169,25 @@ def training_leg(model, inputs, B, S, V, steps, warmup, world, device, barrier):
         opt.step()   # (ClipAdam: clip + update)
         return loss
 
+    # the warm-up steps run under the same instrumentation as the timed ones (HIP event pairs around the library calls, the
+    # exposed-collective events): torch creates its timing events lazily, and twelve hipEventCreate calls inside the FIRST timed
+    # step made it 6.2-6.4 ms against 4.8 for every later one (round 6: that was the step's whole "p90 = max" tail)
+    # ... and everything slow on the host (garbage collection, event objects) happens BEFORE the last warm-up steps, so that the
+    # device is idle for microseconds, not tens of milliseconds, between the synchronisation and the first timed step: after a
+    # long idle gap the first step ran at 6.3 ms, the second at 5.0, every later one at 4.8 (clocks ramping back up)
+    import gc
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    engine.TIMER = engine.KernelTimer()
     for i in range(warmup):
-        step(inputs[i])
-    torch.cuda.synchronize()
+        if i == max(warmup - 2, 0):
+            gc.collect()
+            gc.disable()   # a generation-2 collection in the middle of a 12 ms step is a 60-80 ms host stall (measured)
+        step(inputs[i], timed=True)
+    exposed.clear()
     timer = engine.KernelTimer()
     engine.TIMER = timer
     barrier()
     torch.cuda.synchronize()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    import gc
-    gc.collect()
-    gc.disable()   # a generation-2 collection in the middle of a 12 ms step is a 60-80 ms host stall (measured)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(warmup, warmup + steps):
@@ -421,7 +429,7 @@ def main():
     ap.add_argument("--other-configs", type=int, default=1,
                     help="1: also time BASELINE.json's other configurations briefly (cfg 1 NA, cfg 4 BN, cfg 5 wide/deep) "
                          "and report them under `other_configs` (never as `value`); 0 disables")
-    ap.add_argument("--train-steps", type=int, default=10,
+    ap.add_argument("--train-steps", type=int, default=20,
                     help="also time this many full training steps (fwd + bwd + optimizer) after the headline "
                          "forward measurement and report them as `training_step`; 0 disables the leg")
     ap.add_argument("--schedule", choices=["lockstep", "pergraph"], default=None,

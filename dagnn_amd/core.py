@@ -108,6 +108,22 @@ class ParamGuard(object):
                                                      err.data_ptr(), engine.ERR_PARAMS_MOVED, st), "dagnn_param_fingerprint")
 
 
+def guard_params(mod, err: Optional[torch.Tensor]) -> None:
+    """`ParamGuard.check` of module `mod`'s fp32 GPU parameters (evaluation passes of all three modules call this)."""
+    if mod.training or not engine.PARAM_GUARD or err is None:
+        return
+    g = mod.__dict__.get("_param_guard")
+    if g is None:
+        g = mod.__dict__["_param_guard"] = ParamGuard()
+        mod.__dict__["_param_list"] = [p for p in mod.parameters() if p.is_cuda and p.dtype == torch.float32]
+    g.check(mod.__dict__["_param_list"], err)
+
+
+def drop_guard(mod) -> None:
+    mod.__dict__.pop("_param_list", None)
+    mod.__dict__.pop("_param_guard", None)
+
+
 def built_marker(t):
     """(event, stream, seen) behind derived tensors just built on the current stream of `t`'s device - a pass on ANOTHER
     stream (`bench.py --streams k`, micro-batches in flight) must not read them before the kernels that made them are done."""

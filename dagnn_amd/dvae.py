@@ -288,16 +288,10 @@ class _DvaeDagnn(_DvaeBase):
 
     def train(self, mode: bool = True):
         """Mode switches drop the derived-weight caches (see core.DerivedCache)."""
-        for c in self.__dict__.get("_derived", {}).values():
-            c.invalidate()
-        # the `add` / `max` aggregators derive their weights on the cached view object (variants._derive keeps its
-        # DerivedCache on the module it is handed): fused optimizers and `.data` writes do not bump `_version`, so a
-        # train() / eval() switch must drop that cache too, exactly as DAGNN.train() does for its own
-        view = self.__dict__.get("_agg_view_obj")
-        if view is not None:
-            vc = view.__dict__.get("_variant_cache")
-            if vc is not None:
-                vc.invalidate()
+        # (the `add` / `max` aggregators derive their weights on the cached view object - variants._derive keeps its DerivedCache
+        # on the module it is handed: fused optimizers and `.data` writes do not bump `_version`, so a train() / eval() switch
+        # must drop that cache too, exactly as DAGNN.train() does for its own)
+        self.invalidate_caches()
         return super().train(mode)
 
     # ---- hooks of autograd.Recurrence
@@ -370,6 +364,30 @@ class _DvaeDagnn(_DvaeBase):
 
     def forward(self, G):
         """`dvae/dagnn.py:99-175` / `dvae/dagnn_bn.py:98-168`."""
+        out = self._forward(G)
+        if not self.training and engine.PARAM_GUARD:
+            # evaluation passes: the parameters behind the derived-weight caches still are what the caches were built from
+            # (core.ParamGuard; one small launch, reported like a device-side failure)
+            from .core import guard_params
+            p0 = next(self.parameters())
+            if p0.is_cuda:
+                guard_params(self, self._arena_for(p0).err)
+        return out
+
+    def invalidate_caches(self) -> None:
+        """Drop every tensor derived from the parameters (what `train()` / `eval()` do): call it after updating parameters in
+        evaluation mode through a path the version counters do not see (`.data`, a fused optimizer)."""
+        for c in self.__dict__.get("_derived", {}).values():
+            c.invalidate()
+        view = self.__dict__.get("_agg_view_obj")
+        if view is not None:
+            vc = view.__dict__.get("_variant_cache")
+            if vc is not None:
+                vc.invalidate()
+        from .core import drop_guard
+        drop_guard(self)
+
+    def _forward(self, G):
         if self.output_all and self.out_pool not in (K.P_MAX, K.P_MEAN, K.P_ADD):
             raise NotImplementedError("out_pool=%r over all nodes: the reference's own self-attention pooling of the "
                                       "D-VAE models references an undefined layer (dvae/dagnn.py:85-88)" % self.out_pool)

@@ -609,12 +609,8 @@ class DAGNN(nn.Module):
         (`core.ParamGuard`; a training-mode pass rebuilds everything anyway)."""
         if self.training or not engine.PARAM_GUARD:
             return
-        g = self.__dict__.get("_param_guard")
-        if g is None:
-            from .core import ParamGuard
-            g = self.__dict__["_param_guard"] = ParamGuard()
-            self.__dict__["_param_list"] = [p for p in self.parameters() if p.is_cuda and p.dtype == torch.float32]
-        g.check(self.__dict__["_param_list"], self._arena_for(x).err)
+        from .core import guard_params
+        guard_params(self, self._arena_for(x).err)
 
     def invalidate_caches(self) -> None:
         """Drop every tensor derived from the parameters (what `train()` / `eval()` do): call it after updating parameters in
@@ -623,11 +619,8 @@ class DAGNN(nn.Module):
                                                                       self.__dict__.get("_variant_cache")]:
             if c is not None:
                 c.invalidate()
-        g = self.__dict__.get("_param_guard")
-        if g is not None:
-            g.reset()
-        self.__dict__.pop("_param_list", None)
-        self.__dict__.pop("_param_guard", None)
+        from .core import drop_guard
+        drop_guard(self)
 
     def _head_storage(self):
         """The S vocabulary heads' weights and biases as ONE [S V, D] / [S V] pair: each head's parameter is (made) a VIEW of

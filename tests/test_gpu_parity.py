@@ -204,6 +204,23 @@ def test_parameter_writes_the_version_counters_miss_are_reported(device):
         model(b.clone().to(device))
         model(b.clone().to(device))
     model.check()
+    # the D-VAE encoders carry the same guard
+    meta, arr = Hh.load("bn_h256_bidir")
+    enc, _ = Hh.dvae_model(meta)
+    enc = enc.to(device)
+    with torch.no_grad():
+        enc(Hh.dvae_batch(arr, device))
+        enc(Hh.dvae_batch(arr, device))
+    enc.check()
+    next(p_ for n_, p_ in enc.named_parameters() if "weight_hh" in n_).data.mul_(1.5)
+    with torch.no_grad():
+        enc(Hh.dvae_batch(arr, device))
+    with pytest.raises(DagnnHipError, match="version counter"):
+        enc.check()
+    enc.invalidate_caches()
+    with torch.no_grad():
+        enc(Hh.dvae_batch(arr, device))
+    enc.check()
 
 
 def test_pack_whh(device):

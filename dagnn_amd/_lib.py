@@ -93,7 +93,8 @@ class FrontierArgs(C.Structure):
 
 class DataflowCell(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("w_hh", "w_ih", "b_hh", "b_ih", "w_key", "static_score", "edge_gain",
-                                          "vid_bias", "gi0", "h_out", "granules", "proj_granules", "gh_out", "gi_out")]
+                                          "vid_bias", "gi0", "h_out", "granules", "proj_granules", "gh_out", "gi_out",
+                                          "agg_edge_w", "agg_edge_b")] + [("agg", C.c_int)]
 
 
 class DataflowArgs(C.Structure):

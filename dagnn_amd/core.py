@@ -167,7 +167,8 @@ class CellParams(object):
     """Device-side, kernel-ready parameters of one (direction, stacked layer) cell."""
 
     __slots__ = ("w_ih", "b_ih", "w_hh_t", "b_hh", "w_key", "edge_gain", "vid_bias", "w_hh_pk", "w_ih_pk",
-                 "b_ih_dev", "Hp", "key_raw", "w_hh_raw", "w_hh_df", "w_ih_df", "w_hh_bt", "w_ih_bt", "df_ok", "gain_src", "fold", "built")
+                 "b_ih_dev", "Hp", "key_raw", "w_hh_raw", "w_hh_df", "w_ih_df", "w_hh_bt", "w_ih_bt", "df_ok", "gain_src", "fold", "built",
+                 "agg", "agg_w", "agg_b")   # (agg / agg_w / agg_b: plain aggregators on the dataflow kernel, variants.run_plain_dataflow)
 
 
 def pack_dataflow(cells, transposed_too: bool = False) -> None:

@@ -122,13 +122,16 @@ struct DfCell {
     const gran_t* g_in;   // projection: granules of the lower stacked layer's states
     float* aux_out;       // training passes: [N,3H] plain copy of the pre-activations this cell computes (recurrent: W_hh a +
                           // b_hh; projection: W_ih u + b_ih), or null
+    const float* agg_w;   // plain aggregators (`add` / `max`, dagnn.py:232-251): edge_encoder.weight [H, R] or null
+    const float* agg_b;   //                                                       edge_encoder.bias [H] or null
     int dir;
     int kind;
-    int variant;          // KIND * 4 + (RR == 2 ? 2 : 0) + EXTRA
+    int variant;          // AGG * 16 + KIND * 4 + (RR == 2 ? 2 : 0) + EXTRA
     int partner;          // recurrent: index of the projection cell that reads this cell's state rows, or -1
+    int agg;              // DAGNN_DF_AGG_*: 0 attention (the soft-max fold), 1 add, 2 max, 3 none (the aggregate is zero)
 };
 
-#define DF_MAX_KCELLS 24   // (24 x 112 bytes of cell table + the role table + the rest stay inside the 4 KB kernel-argument segment)
+#define DF_MAX_KCELLS 24   // (24 x 136 bytes of cell table + the role table + the rest stay inside the 4 KB kernel-argument segment)
 #define DF_MAX_WGS 320     // workgroups the XCD-aware placement table covers (one per CU)
 #define DF_IDLE_ROLE 0xffffu
 
@@ -249,7 +252,10 @@ __device__ __forceinline__ bool df_retry(unsigned& spins, int* err, unsigned lim
 }
 
 // ---- loader wave: row `lw` of every block of this group
-template <int KPT, int KIND, int RR, bool EXTRA>
+// PLAIN: the cell's aggregator is not an attention soft-max but `add` / `max` over the messages h_j + e_j, e_j =
+// edge_encoder(edge_attr_j) (AggConv, dagnn.py:232-251; C.agg picks the fold at run time; 3: no message lands on these rows -
+// the reference's shared AggConv in the reverse direction - and the aggregate is zero without a poll)
+template <int KPT, int KIND, int RR, bool EXTRA, bool PLAIN = false>
 __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, const DfArgs& S,
                                           const DfCell& C, int sl, int group, const DfLds& lds, int w, int set) {
     constexpr int H = 16 * KPT;
@@ -290,7 +296,22 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
     for (int q = 0; q < 4; ++q) {
         const int c = 64 * q + lane;
         cpos[q] = c + (SEG - KP8) * (c / KP8);
-        if (!proj && !(EXTRA && C.sscore) && q < NQ4) wk[q] = C.wkey[c];
+        if (!proj && !PLAIN && !(EXTRA && C.sscore) && q < NQ4) wk[q] = C.wkey[c];
+    }
+    // plain aggregators: the lane's columns of the edge encoder (two edge features at most: the host checks)
+    const int agg = PLAIN ? C.agg : 0;
+    const int Rp = (PLAIN && C.agg_w) ? S.R : 0;
+    float ew0[4] = {0.f, 0.f, 0.f, 0.f}, ew1[4] = {0.f, 0.f, 0.f, 0.f}, ebv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (PLAIN && C.agg_w) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 64 * q + lane;
+            if (q < NQ4) {
+                if (Rp >= 1) ew0[q] = C.agg_w[(int64_t)c * Rp];
+                if (Rp >= 2) ew1[q] = C.agg_w[(int64_t)c * Rp + 1];
+                ebv[q] = C.agg_b ? C.agg_b[c] : 0.f;
+            }
+        }
     }
     const bool prof_wave = DF_PROF && dbg != nullptr && (int)blockIdx.x == S.dbg_wg && w == 0 && lane == 0;
     bool prof = prof_wave;
@@ -445,7 +466,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
         };
         if (v >= 0) {
             const int eb = r0.y;
-            const int deg = proj ? 1 : r0.z - r0.y;   // a projection reads ONE row: the node's own state one layer down
+            const int deg = proj ? 1 : ((PLAIN && agg == 3) ? 0 : r0.z - r0.y);   // a projection reads ONE row: the node's own state one layer down
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             float m = -INFINITY, l = 0.f;
             // input-side pre-activations of the slice from the projection cell: 3 gates x 32 units, lanes 0..31
@@ -455,10 +476,26 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
             // in-edges in chunks of <= 4 (ids and features of the first chunk came with the record).  A node with more
             // than 4 in-edges takes two chunks per trip to memory (all of them finished long ago: the trips, not the
             // data, are what such a row waits for)
+            float ff0[4] = {0.f, 0.f, 0.f, 0.f}, ff1[4] = {0.f, 0.f, 0.f, 0.f};   // (PLAIN) the chunk's raw edge features
             auto chunk_ids = [&](int c0, int (&pj)[4], float (&fe)[4]) -> int {
                 const int nn = max(0, min(4, deg - c0));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { pj[e] = 0; fe[e] = 0.f; }
+                if (PLAIN && Rp > 0) {
+                    if (c0 == 0) {
+                        ff0[0] = __int_as_float(r2.x); ff0[1] = __int_as_float(r2.z); ff0[2] = __int_as_float(r3.x); ff0[3] = __int_as_float(r3.z);
+                        if (Rp >= 2) { ff1[0] = __int_as_float(r2.y); ff1[1] = __int_as_float(r2.w); ff1[2] = __int_as_float(r3.y); ff1[3] = __int_as_float(r3.w); }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ff0[e] = ff1[e] = 0.f;
+                            if (e < nn) {
+                                ff0[e] = eattr[(int64_t)(eb + c0 + e) * Rp];
+                                if (Rp >= 2) ff1[e] = eattr[(int64_t)(eb + c0 + e) * Rp + 1];
+                            }
+                        }
+                    }
+                }
                 if (proj) {
                     pj[0] = v;
                 } else if (c0 == 0) {
@@ -570,7 +607,18 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                     dbg[8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64(); dbg[8 * (int64_t)(DF_NLS * b + set) + 6] = polls;
                     if (DF_NLS * b + set >= 8) dbg[8 * (int64_t)(DF_NLS * b + set) + 7] = t_issue;   // when the poll that found the row was issued
                 }
-                if (deg == 1) {
+                if (PLAIN) {   // messages h_j + e_j, summed or maximised column by column (rows without a message stay zero)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (e < nn) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float mv = __uint_as_float((unsigned)A.x[e][q]) + fmaf(ff0[e], ew0[q], fmaf(ff1[e], ew1[q], ebv[q]));
+                                acc[q] = agg == 2 ? ((c0 == 0 && e == 0) ? mv : fmaxf(acc[q], mv)) : acc[q] + mv;
+                            }
+                        }
+                    }
+                } else if (deg == 1) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[q] = __uint_as_float((unsigned)A.x[0][q]);
                     l = 1.f;
@@ -580,7 +628,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                 c0 += 4;
             } while (c0 < deg);
             if (prof) { asm volatile("" :: "v"(acc[0]), "v"(acc[3]), "v"(l)); dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + set) + 4] = wall_clock64(); }   // fold done
-            if (deg > 1) {   // PyG softmax: exp(x - max) / (sum + 1e-16)
+            if (deg > 1 && !PLAIN) {   // PyG softmax: exp(x - max) / (sum + 1e-16)
                 const float inv = __builtin_amdgcn_rcpf(l + 1e-16f);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] *= inv;
@@ -1310,7 +1358,7 @@ __global__ void __launch_bounds__(DFF_THREADS, DFF_THREADS / 256) dataflow_kerne
     const int variant = C.variant;
     if (wave < DFF_NCW) {
         const int cw = wave;
-        switch (variant >> 2) {
+        switch ((variant >> 2) & 3) {
             case DFK_REC0: df_compute<KPT, DFK_REC0>(S, C, sl, pair, lds, cw); break;
             case DFK_RECP: df_compute<KPT, DFK_RECP>(S, C, sl, pair, lds, cw); break;
             default: df_compute<KPT, DFK_PROJ>(S, C, sl, pair, lds, cw); break;
@@ -1325,6 +1373,10 @@ __global__ void __launch_bounds__(DFF_THREADS, DFF_THREADS / 256) dataflow_kerne
             else if (variant == DFK_RECP * 4 + 2) { df_loader_fast<KPT, DFK_RECP>(plan, S, C, sl, grp, lds, w, set); }
             else if ((variant >> 2) == DFK_PROJ) { df_loader_fast<KPT, DFK_PROJ>(plan, S, C, sl, grp, lds, w, set); }
             else if constexpr (KPT <= 16) {
+                if (variant >= 16) {   // plain aggregators (add / max / none)
+                    if (((variant >> 2) & 3) == DFK_REC0) df_loader<KPT, DFK_REC0, -1, false, true>(plan, S, C, sl, grp, lds, w, set);
+                    else df_loader<KPT, DFK_RECP, -1, false, true>(plan, S, C, sl, grp, lds, w, set);
+                } else
                 switch (variant) {
                     DF_LOADER_CASE(DFK_REC0, 2, false) DF_LOADER_CASE(DFK_REC0, 2, true)
                     DF_LOADER_CASE(DFK_REC0, -1, false) DF_LOADER_CASE(DFK_REC0, -1, true)
@@ -1580,13 +1632,15 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
         if (!((dir_mask >> d) & 1)) continue;
         for (int i = 0; i < Ls; ++i) {
             const dagnn_dataflow_cell& c = a->cell[d][i];
-            if (!c.w_hh || !c.b_hh || (!c.w_key && !c.static_score) || !c.h_out || !c.granules) return DAGNN_EINVAL;
+            if (c.agg < 0 || c.agg > 3 || (c.agg != 0 && (pl->num_edge_feats > 2 || a->vid_mod > 0 || c.static_score))) return DAGNN_EINVAL;
+            if (!c.w_hh || !c.b_hh || (c.agg == 0 && !c.w_key && !c.static_score) || !c.h_out || !c.granules) return DAGNN_EINVAL;
             if (i == 0 ? !c.gi0 : (!c.w_ih || !c.b_ih || !c.proj_granules)) return DAGNN_EINVAL;
             if (nc + (i > 0 ? 2 : 1) > DF_MAX_KCELLS) return DAGNN_EINVAL;
             if (i > 0) {   // projection cell: W_ih x (states of layer i - 1) + b_ih
                 DfCell& P = S.cell[nc++];
                 P.w = (const float4*)c.w_ih; P.bias = c.b_ih;
                 P.wkey = nullptr; P.sscore = nullptr; P.gain = nullptr; P.vid = nullptr; P.gi0 = nullptr; P.p_in = nullptr;
+                P.agg_w = nullptr; P.agg_b = nullptr; P.agg = 0;
                 P.h_out = nullptr;
                 P.g_out = (gran_t*)c.proj_granules;
                 P.g_in = (const gran_t*)a->cell[d][i - 1].granules;
@@ -1609,6 +1663,8 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
             K.dir = d; K.kind = DF_RECURRENT;
             K.variant = (i == 0 ? DFK_REC0 : DFK_RECP) * 4 + ((K.gain && pl->num_edge_feats == 2) ? 2 : 0) + ((K.sscore || K.vid) ? 1 : 0);
             K.partner = -1;
+            K.agg = c.agg; K.agg_w = c.agg != 0 ? c.agg_edge_w : nullptr; K.agg_b = c.agg != 0 ? c.agg_edge_b : nullptr;
+            if (c.agg != 0) { K.variant = 16 * c.agg + (i == 0 ? DFK_REC0 : DFK_RECP) * 4; K.gain = nullptr; K.wkey = nullptr; }
         }
     }
     const DfLayout SL = df_layout_words(pl->N, pl->B, G);

@@ -83,6 +83,7 @@ BWD_TAIL_MAX_BLOCKS = _env_int("DAGNN_AMD_BWD_TAIL_MAX_BLOCKS", 4)
 # 2.302-2.312 against 2.3085 ms - nothing - and two processes sharing one GPU (the two-rank bench test) failed.
 PLAN_OVERLAP = _env_int("DAGNN_AMD_PLAN_OVERLAP", 0)              # 1: training passes launch plan / schedule on the arena's side stream next to encoder + input GEMM (model._plan_of); measured: 13 separate launches 1.64 -> 1.59 ms per forward, the fused pipeline (csrc/prepare.hip) gains nothing from it (fork + join cost what it hides: training step 5.42 against 5.32 ms)
 SIDE_PRIORITY = _env_int("DAGNN_AMD_SIDE_PRIORITY", 0)     # stream priority of an arena's side stream (-1: high)
+VARIANT_DATAFLOW = _env_int("DAGNN_AMD_VARIANT_DATAFLOW", 1)  # 1: evaluation passes of agg = add / max (GRU cells, no agg_x, H <= 256) run on the persistent dataflow kernel (a plain fold in its loader) instead of the per-layer variant launches
 PARAM_GUARD = _env_int("DAGNN_AMD_PARAM_GUARD", 1)            # 1: evaluation passes fingerprint the parameters behind the derived-weight caches (core.ParamGuard: one small launch per pass); a write the version counters missed is reported like a device-side failure
 ERR_PARAMS_MOVED = 0x10000                                       # bit of the arena's error word the guard sets
 FOLD_INPUT = _env_int("DAGNN_AMD_FOLD_INPUT", 1)              # 1: evaluation passes over an ASTNodeEncoder fold the embedding tables through W_ih of stacked layer 0 once per
@@ -678,6 +679,10 @@ def dataflow_args(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, 
                 fc.w_key = c.w_key.data_ptr()
             fc.edge_gain = _ptr(c.edge_gain) if plan.R > 0 else None
             fc.vid_bias = _ptr(c.vid_bias) if vid_mod > 0 else None
+            agg = getattr(c, "agg", 0)
+            if agg:   # a plain aggregator (add / max / none): no keys, no gains - the edge encoder itself
+                fc.agg, fc.agg_edge_w, fc.agg_edge_b = int(agg), _ptr(getattr(c, "agg_w", None)), _ptr(getattr(c, "agg_b", None))
+                fc.w_key = fc.static_score = fc.edge_gain = None
             fc.gi0 = gi0[d].data_ptr() if i == 0 else None
             fc.h_out = h[d][i].data_ptr()
             fc.granules = gran[(d, i)].data_ptr()

@@ -150,6 +150,8 @@ class _HeadsLinear(torch.autograd.Function):
 class DAGNN(nn.Module):
     """See module docstring.  Constructor mirrors `dagnn.py:18-112` argument for argument."""
 
+    _plain_dataflow_ok = True   # (variants.run_plain_dataflow: `add` / `max` of THIS class - one shared AggConv - on the dataflow kernel)
+
     def __init__(self, num_vocab, max_seq_len, emb_dim, hidden_dim, out_dim,
                  num_rels=2, w_edge_attr=True, num_layers=2, bidirectional=True, mapper_bias=True,
                  agg_x=False, agg=K.NA_ATTN_H, out_wx=True, out_pool_all=True, out_pool=K.P_MAX, encoder=None,
@@ -542,7 +544,7 @@ class DAGNN(nn.Module):
             G.x = self.encoder(G.x, G.node_depth.view(-1, ))
             if self.variant_backend == "torch" or (torch.is_grad_enabled()
                                                     and any(p.requires_grad for p in self.parameters())):
-                for c in (self._head_cache, self.__dict__.get("_variant_cache")):
+                for c in (self._head_cache, self.__dict__.get("_variant_cache"), self.__dict__.get("_plain_df_cache")):
                     if c is not None:
                         c.invalidate()
                 if self.variant_backend != "torch" and variants.hip_backward_supported(self, G):
@@ -616,7 +618,8 @@ class DAGNN(nn.Module):
         """Drop every tensor derived from the parameters (what `train()` / `eval()` do): call it after updating parameters in
         evaluation mode through a path the version counters do not see (`.data`, a fused optimizer)."""
         for c in list(self.__dict__.get("_derived", {}).values()) + [self.__dict__.get("_head_cache"),
-                                                                      self.__dict__.get("_variant_cache")]:
+                                                                      self.__dict__.get("_variant_cache"),
+                                                                      self.__dict__.get("_plain_df_cache")]:
             if c is not None:
                 c.invalidate()
         from .core import drop_guard

@@ -227,9 +227,79 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def run_plain_dataflow(mod, x: torch.Tensor, plan) -> Optional[List[List[Optional[torch.Tensor]]]]:
+    """`agg` = `add` / `max` with GRU cells on the persistent dataflow kernel (csrc/dataflow.hip: the generic loader folds the
+    messages h_j + edge_encoder(edge_attr_j) by sum or maximum instead of the attention soft-max; the GRU side is the
+    kernel's own).  The reference builds ONE AggConv for both directions (dagnn.py:74-75): in the reverse direction its
+    messages land on the successors, the frontier rows read zeros - those cells run with an empty aggregate and poll nothing.
+    Returns None where the kernel does not apply (the caller keeps the per-layer variant launches)."""
+    from .core import derive_cell, pack_dataflow
+    H, L = mod.hidden_dim, mod.num_layers
+    dirs = list(mod.dirs)
+    N, dev = x.shape[0], x.device
+    if not getattr(mod, "_plain_dataflow_ok", False) or not engine.VARIANT_DATAFLOW or not engine.DATAFLOW \
+            or mod.agg not in ("add", "max") or not mod.recurr or mod.agg_x \
+            or N == 0 or plan.R > 2 or mod.schedule != "lockstep":
+        return None
+    conv = mod.node_aggr_0[0]
+    wea = bool(getattr(conv, "wea", False))
+    if wea and plan.R == 0:
+        return None
+    shared_flow = getattr(mod, "shared_agg_flow", True)
+    srcs = [p for d in dirs for cell in getattr(mod, "cells_%d" % d) for p in cell.parameters()] + \
+        ([conv.edge_encoder.weight, conv.edge_encoder.bias] if wea else [])
+
+    def make():
+        out = {}
+        zkey = None
+        for d in dirs:
+            for i, cell in enumerate(getattr(mod, "cells_%d" % d)):
+                if zkey is None:
+                    zkey = torch.zeros(1, H, dtype=torch.float32, device=dev)   # (no keys: derive_cell's attention slots stay unused)
+                c = derive_cell(cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh, zkey, H, 0, i > 0, None, 0,
+                                schedule="lockstep", pack=False, stacked=L)
+                if c.Hp > 256 or not c.df_ok:
+                    return None
+                c.agg = 3 if (shared_flow and d == 1) else (1 if mod.agg == "add" else 2)
+                c.agg_w = c.agg_b = None
+                if wea and c.agg != 3:
+                    w = torch.zeros(c.Hp, plan.R, dtype=torch.float32, device=dev)
+                    w[:H] = conv.edge_encoder.weight.detach().float()
+                    b = torch.zeros(c.Hp, dtype=torch.float32, device=dev)
+                    b[:H] = conv.edge_encoder.bias.detach().float()
+                    c.agg_w, c.agg_b = w, b
+                out[(d, i)] = c
+        pack_dataflow(out.values())
+        return out
+
+    cache = mod.__dict__.setdefault("_plain_df_cache", DerivedCache())
+    cells = cache.get(srcs, make, fresh=mod.training)
+    if cells is None:
+        return None
+    Hp = cells[(dirs[0], 0)].Hp
+    groups = engine.dataflow_groups(dev, len(dirs), L, Hp, plan.B)
+    if groups <= 0 or N * 3 * Hp >= (1 << 31):
+        return None
+    arena = mod._arena_for(x)
+    arena.poll()
+    gi0 = engine.gemm_nt_bias([x] * len(dirs), [cells[(d, 0)].w_ih for d in dirs], [cells[(d, 0)].b_ih for d in dirs])
+    gi = [None, None]
+    for q, d in enumerate(dirs):
+        gi[d] = gi0[q]
+    ld = engine.frontier_ld(Hp)
+    h = [[torch.empty(N, ld, dtype=torch.float32, device=dev) if d in dirs else None for _ in range(L)] for d in range(2)]
+    plan.wait_ready()
+    engine.dataflow_run(plan, dirs, L, Hp, cells, gi, h, groups, arena=arena)
+    return [[h[d][i][:, :H] if h[d][i] is not None else None for i in range(L)] for d in range(2)]
+
+
 def run_hip(mod, G, x: torch.Tensor, plan) -> List[List[Optional[torch.Tensor]]]:
-    """h[d][i] ([N, hidden]) through `dagnn_variant_run` (csrc/variants.hip).  `plan`: engine.PlanHandle of the batch
-    (with the edge features when the model has an edge encoder)."""
+    """h[d][i] ([N, hidden]) through `dagnn_variant_run` (csrc/variants.hip) - or, for `add` / `max` with GRU cells, through the
+    persistent dataflow kernel (`run_plain_dataflow`).  `plan`: engine.PlanHandle of the batch (with the edge features when
+    the model has an edge encoder)."""
+    fast = run_plain_dataflow(mod, engine._dev(x.detach(), "node inputs", torch.float32), plan)
+    if fast is not None:
+        return fast
     N, H, L, E = x.shape[0], mod.hidden_dim, mod.num_layers, mod.emb_dim
     x = engine._dev(x.detach(), "node inputs", torch.float32)
     dev = x.device

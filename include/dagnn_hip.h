@@ -338,7 +338,18 @@ typedef struct dagnn_dataflow_cell {
     float* gh_out;          /* NULL, or [N,3H]: the hidden-side pre-activations W_hh a + b_hh of every node as the gates saw them */
     float* gi_out;          /* NULL, or [N,3H] (stacked layers > 0): the input-side pre-activations as plain floats - what a
                              * training pass keeps for its reverse sweep instead of recomputing both with GEMMs */
+    /* plain aggregators (AggConv `add` / `max`, ogbg-code/model/dagnn.py:232-251: messages h_j + edge_encoder(edge_attr_j)):
+     * agg = DAGNN_DF_AGG_ATTN (0, the soft-max above), _ADD, _MAX, or _NONE (no message lands on these rows - the reference's one
+     * shared AggConv in the reverse direction - the aggregate is zero).  agg_edge_w [H, num_edge_feats <= 2] / agg_edge_b [H]:
+     * the edge encoder in torch layout, or NULL (no edge features).  H <= 256; w_key / edge_gain / static_score are ignored. */
+    const float* agg_edge_w;
+    const float* agg_edge_b;
+    int agg;
 } dagnn_dataflow_cell;
+#define DAGNN_DF_AGG_ATTN 0
+#define DAGNN_DF_AGG_ADD 1
+#define DAGNN_DF_AGG_MAX 2
+#define DAGNN_DF_AGG_NONE 3
 
 typedef struct dagnn_dataflow_args {
     dagnn_dataflow_cell cell[DAGNN_MAX_DIRS][DAGNN_MAX_STACKED];

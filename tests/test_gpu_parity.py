@@ -1618,6 +1618,54 @@ def test_variant_forward_matches_reference_golden(device, name):
             assert Hh.maxdiff(h[rows], arr["h_%d_%d" % (d, i)]) < TOL
 
 
+@pytest.mark.parametrize("agg", ["add", "max"])
+def test_plain_aggregators_on_the_dataflow_kernel(device, agg, monkeypatch):
+    """`agg` = `add` / `max` (AggConv, dagnn.py:232-251) evaluation passes run on the persistent dataflow kernel - the generic
+    loader folds the messages h_j + edge_encoder(edge_attr_j) by sum / maximum, the reverse direction aggregates nothing (the
+    reference's shared module).  The reference fixture must come out of THAT path (the pass says which one it took), the
+    per-layer variant launches must agree with it on a headline-shaped batch, and the result is bitwise reproducible."""
+    from dagnn_amd import variants
+    name = "var_h64_" + agg
+    meta, arr = Hh.load(name)
+    model = Hh.code2_model(meta).to(device)
+    calls = []
+    real = variants.run_plain_dataflow
+    monkeypatch.setattr(variants, "run_plain_dataflow", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        G = Hh.code2_batch(arr, device)
+        out = model(G)
+    assert calls and len(out) == arr["pred"].shape[0]
+    for o, ref in zip(out, arr["pred"]):
+        assert Hh.maxdiff(o, ref) < TOL
+    rows = arr["rows"]
+    for d, hd in enumerate(G.h):
+        for i, h in enumerate(hd):
+            assert Hh.maxdiff(h[rows], arr["h_%d_%d" % (d, i)]) < TOL
+    monkeypatch.setattr(variants, "run_plain_dataflow", real)
+    # a wider model on a code2-like batch with fan-in beyond one chunk: both paths, and twice the same bits
+    from dagnn_amd import DAGNN, ASTNodeEncoder
+    enc = ASTNodeEncoder(128, 98, 10030, 20)
+    big = DAGNN(num_vocab=32, max_seq_len=3, emb_dim=128, hidden_dim=128, out_dim=None, encoder=enc, w_edge_attr=True, num_layers=2,
+                bidirectional=True, agg=agg, out_wx=False, out_pool_all=False, out_pool="max", dropout=0.0).eval()
+    seeded_fill(big, 77)
+    big = big.to(device)
+    b = synth.code2_batch(5, 48)
+    outs = {}
+    for flag in (1, 0, 1):
+        monkeypatch.setattr(engine, "VARIANT_DATAFLOW", flag)
+        with torch.no_grad():
+            Gb = b.clone().to(device)
+            o = torch.stack(big(Gb))
+            hs = [h.clone() for hd in Gb.h for h in hd]
+        big.check()
+        if flag in outs:
+            assert torch.equal(outs[flag][0], o)
+        outs[flag] = (o, hs)
+    assert Hh.maxdiff(outs[1][0], outs[0][0]) < TOL
+    for a_, b_ in zip(outs[1][1], outs[0][1]):
+        assert Hh.maxdiff(a_, b_) < TOL
+
+
 @pytest.mark.parametrize("name", Hh.GRAD_VAR)
 def test_variant_training_step_gradients_match_reference_golden(device, name, monkeypatch):
     """`gated_sum` (with / without mapper bias), `mattn_h` (L = 2 and 3), `add`, `max`, and `gated_sum` / `mattn_h` on the

@@ -102,7 +102,7 @@ class DataflowArgs(C.Structure):
                 ("H", C.c_int), ("ld_h", C.c_int), ("gld", C.c_int), ("pld", C.c_int), ("vid_mod", C.c_int), ("groups", C.c_int),
                 ("epoch", C.c_uint), ("schedule", C.c_void_p), ("err", C.c_void_p), ("debug_timing", C.c_void_p),
                 ("spin_limit", C.c_uint), ("debug_wg", C.c_int), ("num_cus", C.c_int), ("xcc_table", C.c_void_p),
-                ("plan_status", C.c_void_p), ("xcd_first", C.c_int)]
+                ("plan_status", C.c_void_p), ("xcd_first", C.c_int), ("stat_rows", C.c_int)]
 
 
 class TilesCell(C.Structure):
@@ -149,7 +149,8 @@ class BwdDataflowArgs(C.Structure):
     _fields_ = [("cell", (BwdDataflowCell * MAX_STACKED) * MAX_DIRS), ("num_stacked", C.c_int), ("dir_mask", C.c_int),
                 ("H", C.c_int), ("ld_h", C.c_int), ("ld_g", C.c_int), ("gld", C.c_int), ("groups", C.c_int),
                 ("epoch", C.c_uint), ("spin_limit", C.c_uint), ("schedule", C.c_void_p), ("records", C.c_void_p),
-                ("err", C.c_void_p), ("plan_status", C.c_void_p), ("num_cus", C.c_int), ("xcc_table", C.c_void_p), ("xcd_first", C.c_int)]
+                ("err", C.c_void_p), ("plan_status", C.c_void_p), ("num_cus", C.c_int), ("xcc_table", C.c_void_p), ("xcd_first", C.c_int),
+                ("stat_rows_written", C.c_int)]
 
 
 class GatherJob0(C.Structure):   # (dagnn_gather_job inside dagnn_encode_args; `GatherJob` below has the same layout)

@@ -373,6 +373,8 @@ def run_stack_lockstep(plan: engine.PlanHandle, x: torch.Tensor, cells: Dict[Tup
     elif groups > 0:
         pack_dataflow(cells.values(), transposed_too=keep is not None and bool(engine.BWD_DATAFLOW))
         preact = {} if (keep is not None and engine.BWD_DATAFLOW) else None
+        if preact is not None and engine.stat_rows_ok(dev, N, Hp, len(dirs), L, plan.B, groups):
+            preact["stat_rows"] = True
         engine.dataflow_run(plan, dirs, L, Hp, cells, gi, h, groups, vid_mod=vid_nodes, arena=arena,
                             static_score=static_score, score_parts=keep is not None, preact=preact, training=keep is not None)
         if keep is not None:

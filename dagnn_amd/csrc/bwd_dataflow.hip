@@ -40,7 +40,6 @@
 namespace {
 
 typedef float bf4 __attribute__((ext_vector_type(4)));
-constexpr int BD_NSTAT_C = 8;
 
 #ifndef BD_NSLOT_V
 #define BD_NSLOT_V 3
@@ -53,11 +52,11 @@ constexpr int BD_WPS = BD_WPS_V;     // loader waves per stream (4: one row of a
 constexpr int BD_RPW = DF_RB / BD_WPS;   // rows of a block per loader wave, one after the other
 constexpr int BD_NLW = DF_NLS * BD_WPS;
 constexpr int BD_THREADS = 64 * (DF_NCW + BD_NLW);
-constexpr int BD_SP = 256;           // pitch of a static row (floats): lane l holds columns {l, 64 + l, 128 + l, 192 + l} at [4l, 4l + 4)
+constexpr int BD_SP = DF_STAT_SP;    // pitch of a static row (floats): lane l holds columns {l, 64 + l, 128 + l, 192 + l} at [4l, 4l + 4)
 // H = 320 (round 4): a fifth column block {256 + l}.  The record of a (cell, node) is then part A = the eight 256-float rows as
 // before, part B = eight 64-float rows behind them (row r, lane l at 8 * 256 + 64 r + l): 10 KB instead of 8
-__host__ __device__ constexpr int bd_stat_floats(int H) { return BD_NSTAT_C * (H > 256 ? 320 : 256); }
-constexpr int BD_NSTAT = 8;          // static rows per (cell, node): Gext, h, c_r, c_z, c_nr, c_n, z, c_q
+__host__ __device__ constexpr int bd_stat_floats(int H) { return df_stat_floats(H); }
+constexpr int BD_NSTAT = DF_NSTAT;   // static rows per (cell, node): Gext, h, c_r, c_z, c_nr, c_n, z, c_q (df_common.h)
 constexpr int BD_RD = 6;             // a loader wave requests a record this many of its blocks ahead (ring: 8 entries)
 // a successor record (bd_records_kernel): 64 words = one DMA of a full wave
 //   [0..3] v, first / last CSR slot of v's row in direction 1 - d, 0     [4..7] first four successors   [8..11] their edge ids
@@ -70,7 +69,7 @@ constexpr int BD_RECW = 64;
 static_assert(BD_WPS_V == 4, "the workgroup shape: 4 compute + 2 x 4 loader waves (the 8-wave shape of round 4 is in scripts/experiments/)");
 constexpr int BD_SCAL_SL = 1;        // slice whose compute waves store sigma_v and the edge-feature sums (slice 0 stores q_v)
 enum { BD_DA = 0, BD_DU = 1 };
-enum { ST_GEXT = 0, ST_H = 1, ST_CR = 2, ST_CZ = 3, ST_CNR = 4, ST_CN = 5, ST_Z = 6, ST_CQ = 7 };
+enum { ST_GEXT = DF_ST_GEXT, ST_H = DF_ST_H, ST_CR = DF_ST_CR, ST_CZ = DF_ST_CZ, ST_CNR = DF_ST_CNR, ST_CN = DF_ST_CN, ST_Z = DF_ST_Z, ST_CQ = DF_ST_CQ };
 
 struct BdCell {            // (104 bytes: 30 kernel cells - 8 stacked layers, both directions - fit the kernel-argument segment)
     const float4* w;       // packed slices (dagnn_pack_dataflow of the gate-wise transposed matrix)
@@ -303,6 +302,22 @@ __global__ void __launch_bounds__(256) bd_stat_kernel(BdStatArgs A, int64_t N) {
 #pragma unroll
         for (int r = 0; r < BD_NSTAT; ++r) rec[BD_NSTAT * BD_SP + 64 * r + lane] = o[r][4];
     }
+}
+
+// ... and when the forward kernel's training epilogue wrote rows 1..7 already (dagnn_dataflow_args.stat_rows): row 0 only
+__global__ void __launch_bounds__(256) bd_gext_kernel(BdStatArgs A, int64_t N) {
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= N) return;
+    const BdStatCell& C = A.cell[blockIdx.y];
+    const int H = A.H;
+    const float* g = C.gext + v * A.ld_g;
+    float o[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) o[q] = 64 * q + lane < H ? g[64 * q + lane] : 0.f;
+    float* rec = C.stat + v * bd_stat_floats(H);
+    reinterpret_cast<float4*>(rec)[ST_GEXT * (BD_SP / 4) + lane] = make_float4(o[0], o[1], o[2], o[3]);
+    if (H > 256) rec[BD_NSTAT * BD_SP + 64 * ST_GEXT + lane] = o[4];
 }
 
 // ---------------------------------------------------------------- loader waves
@@ -1223,12 +1238,16 @@ extern "C" int dagnn_bwd_dataflow_prepare(const dagnn_plan* pl, const dagnn_bwd_
         if (!((dir_mask >> d) & 1)) continue;
         for (int i = 0; i < Ls; ++i) {
             const dagnn_bwd_dataflow_cell& c = a->cell[d][i];
-            if (!c.gi || !c.gh || !c.a || !c.b_hh || !c.h || !c.g_ext || !c.stat) return DAGNN_EINVAL;
+            if (!c.g_ext || !c.stat) return DAGNN_EINVAL;
+            if (!a->stat_rows_written && (!c.gi || !c.gh || !c.a || !c.b_hh || !c.h)) return DAGNN_EINVAL;
             BdStatCell& K = A.cell[A.ncell++];
             K.gi = c.gi; K.gh = c.gh; K.a = c.a; K.b_hh = c.b_hh; K.h = c.h; K.gext = c.g_ext; K.stat = c.stat;
         }
     }
-    hipLaunchKernelGGL(bd_stat_kernel, dim3((unsigned)((pl->N + 3) / 4), (unsigned)A.ncell), dim3(256), 0, st, A, pl->N);
+    if (a->stat_rows_written)   // (the forward pass of this step ran with dagnn_dataflow_args.stat_rows on these buffers)
+        hipLaunchKernelGGL(bd_gext_kernel, dim3((unsigned)((pl->N + 3) / 4), (unsigned)A.ncell), dim3(256), 0, st, A, pl->N);
+    else
+        hipLaunchKernelGGL(bd_stat_kernel, dim3((unsigned)((pl->N + 3) / 4), (unsigned)A.ncell), dim3(256), 0, st, A, pl->N);
     DAGNN_CHECK_LAUNCH();
     return DAGNN_OK;
 }

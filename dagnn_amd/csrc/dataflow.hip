@@ -153,6 +153,7 @@ struct DfArgs {
     // in that L2 (plain stores instead of write-through ones) only when it SEES all their readers there.
     gran_t* xcc_tab;
     int nroles;
+    int aux_stat;               // recurrent cells: aux_out is the reverse sweep's static-record buffer (rows 1..7 written here)
     unsigned short role[DF_MAX_WGS];
 };
 
@@ -1079,6 +1080,8 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     float b_r = C.bias[unit], b_z = C.bias[H + unit], b_n = C.bias[2 * H + unit];
     asm volatile("" : "+v"(b_r), "+v"(b_z), "+v"(b_n));   // landed before the loop (see the weights above)
     const int apos = unit + (SEG - KP8) * (unit / KP8);   // LDS position of column `unit` of an operand row
+    // byte position of column `unit` inside a row of the reverse sweep's static record (df_common.h)
+    const unsigned stat_col = unit >= 256 ? 4u * (DF_NSTAT * DF_STAT_SP + (unit - 256)) : 4u * (4 * (unit & 63) + (unit >> 6));
     const unsigned epoch = S.epoch, spin_limit = S.spin_limit;
     int* const err = S.err;
     float* const h_out = C.h_out;
@@ -1113,7 +1116,8 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     static_assert(DF_NLS == 2, "two streams per workgroup");
 
     auto run = [&](auto local_c, auto aux_c) {
-        constexpr bool LOCAL = decltype(local_c)::value, AUX = decltype(aux_c)::value;
+        constexpr bool LOCAL = decltype(local_c)::value;
+        constexpr int AUX = decltype(aux_c)::value;   // 0: none, 1: the pre-activations, 2: the reverse sweep's static rows
         int done0 = 0, done1 = 0, pref = 0;
         int m0 = 0, m1 = 0;   // blocks the streams' loaders had finished at the last look (wave-uniform)
         auto flags_min = [&](const i4v& r0, const i4v& r1) {   // DF_WPS flags per stream, stream-major
@@ -1236,14 +1240,14 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
             }
             if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 1] = wall_clock64();
             const float p_r = g3[0] + b_r, p_z = g3[1] + b_z, p_n = g3[2] + b_n;   // W a + b: the cell's pre-activations
-            float hv = 0.f;
+            float hv = 0.f, ng = 0.f;
             if (!proj) {   // (every lane: no branch around the gates)
 #ifdef DF_EXP_NOEPI
                 hv = p_r + gi_r + p_z + gi_z + p_n + gi_n + aval;
 #else
                 rg = df_sigm(p_r + gi_r);
                 zg = df_sigm(p_z + gi_z);
-                const float ng = df_tanh(fmaf(rg, p_n, gi_n));
+                ng = df_tanh(fmaf(rg, p_n, gi_n));
                 hv = fmaf(zg, aval - ng, ng);   // n + z * (a - n)
 #endif
             }
@@ -1269,16 +1273,42 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
                     else __hip_atomic_store(g_out + df_idx(gv, gld, unit), gran_pack(epoch, hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     h_out[df_idx(gv, ld_h, unit)] = hv;
                 }
-                if (AUX) {   // (behind the hand-off stores: nobody waits for these)
+                if (AUX == 1) {   // (behind the hand-off stores: nobody waits for these)
                     float* ao = aux_out + df_idx(gv, 3 * H, unit);
                     ao[0] = p_r; ao[H] = p_z; ao[2 * H] = p_n;
+                }
+                if (AUX == 2 && !proj) {
+                    // the reverse sweep's static rows of this node (csrc/bwd_dataflow.hip, bd_stat_kernel: the same terms in
+                    // the same order, from the gates this pass applied): the state and the six coefficient rows in the
+                    // record's lane order - column c at 4 (c % 64) + c / 64 of a 256-float row, columns 256.. (H = 320) in part
+                    // B.  The row of external gradients is the reverse pass's to fill.
+                    const float cn = (1.0f - zg) * (1.0f - ng * ng);
+                    const float cz = (aval - ng) * zg * (1.0f - zg);
+                    const float cr = cn * p_n * rg * (1.0f - rg);
+                    const float cnr = cn * rg;
+                    const float cq = zg * aval + cr * (p_r - b_r) + cz * (p_z - b_z) + cnr * (p_n - b_n);
+                    // (a uniform base and a 32-bit byte offset - the host checks N x record bytes < 2^32 -, row offsets as immediates)
+                    char* const rec = reinterpret_cast<char*>(aux_out) + ((unsigned)gv * (unsigned)(4 * df_stat_floats(H)) + stat_col);
+                    auto put = [&](auto rs_c) {
+                        constexpr int RS = 4 * decltype(rs_c)::value;
+                        *reinterpret_cast<float*>(rec + DF_ST_H * RS) = hv; *reinterpret_cast<float*>(rec + DF_ST_CR * RS) = cr;
+                        *reinterpret_cast<float*>(rec + DF_ST_CZ * RS) = cz; *reinterpret_cast<float*>(rec + DF_ST_CNR * RS) = cnr;
+                        *reinterpret_cast<float*>(rec + DF_ST_CN * RS) = cn; *reinterpret_cast<float*>(rec + DF_ST_Z * RS) = zg;
+                        *reinterpret_cast<float*>(rec + DF_ST_CQ * RS) = cq;
+                    };
+                    if (H > 256 && sl >= 256 / DF_JS) put(std::integral_constant<int, 64>());   // (wave-uniform)
+                    else put(std::integral_constant<int, DF_STAT_SP>());
                 }
             }
             if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 2] = wall_clock64();
         }
     };
-    if (local_st) { if (aux_out) run(std::true_type(), std::true_type()); else run(std::true_type(), std::false_type()); }
-    else { if (aux_out) run(std::false_type(), std::true_type()); else run(std::false_type(), std::false_type()); }
+    typedef std::integral_constant<int, 0> aux0;
+    typedef std::integral_constant<int, 1> aux1;
+    typedef std::integral_constant<int, 2> aux2;
+    if (!aux_out) { if (local_st) run(std::true_type(), aux0()); else run(std::false_type(), aux0()); }
+    else if (proj || !S.aux_stat) { if (local_st) run(std::true_type(), aux1()); else run(std::false_type(), aux1()); }
+    else { if (local_st) run(std::true_type(), aux2()); else run(std::false_type(), aux2()); }
 }
 
 template <int KPT>
@@ -1636,6 +1666,7 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
             if (!c.w_hh || !c.b_hh || (c.agg == 0 && !c.w_key && !c.static_score) || !c.h_out || !c.granules) return DAGNN_EINVAL;
             if (i == 0 ? !c.gi0 : (!c.w_ih || !c.b_ih || !c.proj_granules)) return DAGNN_EINVAL;
             if (nc + (i > 0 ? 2 : 1) > DF_MAX_KCELLS) return DAGNN_EINVAL;
+            if (a->stat_rows && (!c.gh_out || c.gi_out)) return DAGNN_EINVAL;
             if (i > 0) {   // projection cell: W_ih x (states of layer i - 1) + b_ih
                 DfCell& P = S.cell[nc++];
                 P.w = (const float4*)c.w_ih; P.bias = c.b_ih;
@@ -1673,6 +1704,7 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
     for (int d = 0; d < 2; ++d) { S.gtab[d] = SL.gtab[d]; S.grec[d] = SL.grec[d]; S.col[d] = L.col[d]; S.eattr[d] = L.eattr[d]; }
     S.spin_limit = a->spin_limit ? a->spin_limit : (1u << 22);
     S.N = (int)pl->N;
+    S.aux_stat = a->stat_rows ? 1 : 0;
     S.ncell = nc; S.H = H; S.ld_h = a->ld_h; S.gld = a->gld; S.pld = a->pld; S.R = pl->num_edge_feats;
     S.vid_mod = a->vid_mod > 0 ? a->vid_mod : 1;
     S.groups = G; S.epoch = a->epoch; S.err = (int*)a->err;

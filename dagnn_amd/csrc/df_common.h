@@ -193,4 +193,13 @@ __device__ __forceinline__ void df_assign_wave(const int32_t* items, const int32
     df_assign_chain(items, depth0, depth1, node_ptr, ws, S, B, G, c_layer, c_row, s_g, s_d, s_n, staged, count, (long long)node_ptr[B]);
 }
 
+// The reverse sweep's static record of a (cell, node) (csrc/bwd_dataflow.hip): eight rows - external gradient, state, the
+// five gate coefficients and c_q - of 256 floats in lane order (lane l holds columns {l, 64 + l, 128 + l, 192 + l} at
+// [4 l, 4 l + 4)); H = 320 adds part B behind them: eight 64-float rows of the columns 256 + l.  The forward kernel's training
+// epilogue (dataflow.hip) writes rows 1..7, the reverse pass's preparation row 0.
+constexpr int DF_NSTAT = 8;
+constexpr int DF_STAT_SP = 256;
+__host__ __device__ constexpr int df_stat_floats(int H) { return DF_NSTAT * (H > 256 ? 320 : 256); }
+enum { DF_ST_GEXT = 0, DF_ST_H = 1, DF_ST_CR = 2, DF_ST_CZ = 3, DF_ST_CNR = 4, DF_ST_CN = 5, DF_ST_Z = 6, DF_ST_CQ = 7 };
+
 }  // namespace

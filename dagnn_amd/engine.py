@@ -655,6 +655,20 @@ def dataflow_run(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, g
     arena.watch(plan, folded=True)
 
 
+def lib_static_floats(N: int, H: int) -> int:
+    return int(_lib.load().dagnn_bwd_dataflow_static_bytes_h(int(N), int(H))) // 4
+
+
+STAT_FWD = _env_int("DAGNN_AMD_STAT_FWD", 1)   # 1: a training pass's forward launch writes the reverse sweep's static rows itself
+
+
+def stat_rows_ok(device, N: int, H: int, num_dirs: int, L: int, B: int, groups: int) -> bool:
+    """Whether the forward dataflow launch of a training pass should write the reverse sweep's static rows (`stat_rows`):
+    the reverse pass will be `bwd_dataflow_sweep` on the same schedule, and a node's record is addressable with 32 bits."""
+    return bool(STAT_FWD) and groups > 0 and N > 0 and bwd_dataflow_groups(device, num_dirs, L, H, B) == groups and \
+        bwd_dataflow_fits(device, N, num_dirs * L) and lib_static_floats(N, H) * 4 < (1 << 32)
+
+
 def dataflow_args(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, gi0, h, groups: int, vid_mod: int = 0,
                   arena: Optional["GranuleArena"] = None, static_score=None, preact: Optional[dict] = None,
                   training: bool = False, args=None):
@@ -687,7 +701,14 @@ def dataflow_args(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, 
             fc.h_out = h[d][i].data_ptr()
             fc.granules = gran[(d, i)].data_ptr()
             fc.proj_granules = gran[("p", d, i)].data_ptr() if i > 0 else None
-            if preact is not None:
+            if preact is not None and preact.get("stat_rows"):
+                # the reverse sweep's static record of every node, rows 1..7 written by this launch (bwd_dataflow_sweep adds
+                # row 0); widths other than 256 / 320 leave the columns >= H to the fill
+                nfl = lib_static_floats(plan.N, H)
+                preact[("stat", d, i)] = (torch.empty if H in (256, 320) else torch.zeros)(nfl, dtype=torch.float32, device=plan.ws.device)
+                fc.gh_out = preact[("stat", d, i)].data_ptr()
+                args.stat_rows = 1
+            elif preact is not None:
                 preact[("gh", d, i)] = torch.empty(plan.N, 3 * H, dtype=torch.float32, device=plan.ws.device)
                 fc.gh_out = preact[("gh", d, i)].data_ptr()
                 if i > 0:
@@ -1341,7 +1362,10 @@ def bwd_dataflow_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, ce
         gh = {}
         gi = {(d, 0): gi0[d] for d in dirs}
         up = [(d, i) for d in dirs for i in range(1, L)]
-        if preact:   # the forward kernel kept the pre-activations of this pass (dataflow_run, `preact`)
+        stat_fwd = bool(preact) and all(("stat",) + k in preact for k in keys)   # the forward launch wrote rows 1..7 (`stat_rows`)
+        if stat_fwd:
+            gi = {}
+        elif preact and all(("gh",) + k in preact for k in keys):   # the forward kernel kept the pre-activations of this pass
             gh = {k: preact[("gh",) + k] for k in keys}
             gi.update({k: preact[("gi",) + k] for k in up})
         else:
@@ -1363,15 +1387,15 @@ def bwd_dataflow_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, ce
         for k in keys:
             d, i = k
             c, bc, o = cells[k], args.cell[d][i], out[k]
-            o["gi"], o["gh"] = gi[k], gh[k]
+            o["gi"], o["gh"] = gi.get(k), gh.get(k)
             if getattr(c, "w_hh_bt", None) is None:
                 c.w_hh_bt = pack_dataflow_transposed(c.w_hh_raw, H)
                 c.w_ih_bt = pack_dataflow_transposed(c.w_ih, H) if i > 0 else None
-            stat = torch.empty(stat_bytes // 4, **f32)
+            stat = preact[("stat",) + k] if stat_fwd else torch.empty(stat_bytes // 4, **f32)
             keep.append(stat)
             bc.w_hh_t, bc.w_ih_t = c.w_hh_bt.data_ptr(), _ptr(c.w_ih_bt)
             bc.w_key, bc.alpha = o["_wkey"].data_ptr(), o["alpha"].data_ptr()
-            bc.gi, bc.gh, bc.a, bc.b_hh = gi[k].data_ptr(), gh[k].data_ptr(), o["a"].data_ptr(), c.b_hh.data_ptr()
+            bc.gi, bc.gh, bc.a, bc.b_hh = _ptr(gi.get(k)), _ptr(gh.get(k)), o["a"].data_ptr(), c.b_hh.data_ptr()
             bc.h, bc.g_ext, bc.stat = h[d][i].data_ptr(), g_ext[d][i].data_ptr(), stat.data_ptr()
             bc.da_granules, bc.q_granules = gran[("da", d, i)].data_ptr(), gran[("q", d, i)].data_ptr()
             bc.dgi_granules = gran[("dgi", d, i)].data_ptr() if i > 0 else None
@@ -1381,6 +1405,7 @@ def bwd_dataflow_sweep(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, ce
         args.num_stacked, args.dir_mask, args.H = L, mask, H
         args.ld_h, args.ld_g, args.gld, args.groups = h[dirs[0]][0].shape[1], g_ext[dirs[0]][0].shape[1], H, int(groups)
         args.epoch, args.spin_limit = epoch, SPIN_LIMIT
+        args.stat_rows_written = 1 if stat_fwd else 0
         sched = plan.dataflow_schedule(groups)
         recs = torch.empty(lib.dagnn_bwd_dataflow_record_bytes(N) // 4, dtype=torch.int32, device=dev)
         keep.append(recs)

@@ -293,11 +293,12 @@ def run_plain_dataflow(mod, x: torch.Tensor, plan) -> Optional[List[List[Optiona
     return [[h[d][i][:, :H] if h[d][i] is not None else None for i in range(L)] for d in range(2)]
 
 
-def run_hip(mod, G, x: torch.Tensor, plan) -> List[List[Optional[torch.Tensor]]]:
+def run_hip(mod, G, x: torch.Tensor, plan, dataflow: bool = True) -> List[List[Optional[torch.Tensor]]]:
     """h[d][i] ([N, hidden]) through `dagnn_variant_run` (csrc/variants.hip) - or, for `add` / `max` with GRU cells, through the
-    persistent dataflow kernel (`run_plain_dataflow`).  `plan`: engine.PlanHandle of the batch (with the edge features when
-    the model has an edge encoder)."""
-    fast = run_plain_dataflow(mod, engine._dev(x.detach(), "node inputs", torch.float32), plan)
+    persistent dataflow kernel (`run_plain_dataflow`; `dataflow=False`: never - a training pass, whose reverse sweep reads
+    dense [N, hidden] state rows).  `plan`: engine.PlanHandle of the batch (with the edge features when the model has an edge
+    encoder)."""
+    fast = run_plain_dataflow(mod, engine._dev(x.detach(), "node inputs", torch.float32), plan) if dataflow else None
     if fast is not None:
         return fast
     N, H, L, E = x.shape[0], mod.hidden_dim, mod.num_layers, mod.emb_dim
@@ -616,7 +617,7 @@ class VariantRecurrence(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mod, G, plan, x, *params):
-        h = run_hip(mod, G, x, plan)
+        h = run_hip(mod, G, x, plan, dataflow=False)
         ctx.mod, ctx.plan, ctx.h = mod, plan, h
         ctx.save_for_backward(x, *params)
         return tuple(h[d][i] for d in mod.dirs for i in range(mod.num_layers))

@@ -376,6 +376,11 @@ typedef struct dagnn_dataflow_args {
     int xcd_first;          /* XCD-aware placement: the XCD the packing starts with (0..7).  Launches that run next to each other
                             * (micro-batches in flight on several streams, each sized for a part of the device) pass different
                             * values, otherwise all of them pack their workgroups onto the same first XCDs and take turns */
+    int stat_rows;          /* training passes whose reverse pass is dagnn_bwd_dataflow_run: nonzero = every cell's `gh_out` is that
+                            * cell's static-record buffer `stat` (dagnn_bwd_dataflow_static_bytes_h; zero-filled by the caller when
+                            * H is neither 256 nor 320) and the kernel writes the state and the six gate-coefficient rows of each
+                            * node's record instead of the pre-activations; `gi_out` must be NULL.  The reverse pass then only
+                            * adds the external-gradient row (dagnn_bwd_dataflow_args.stat_rows_written) */
 } dagnn_dataflow_args;
 
 int dagnn_dataflow_groups(int num_cus, int num_dirs, int num_stacked, int H, int64_t B);
@@ -559,7 +564,8 @@ int dagnn_backward_run(const dagnn_plan* plan /* host */, const dagnn_backward_a
 /* ------------------------------------------------------------------------------------------
  * The same reverse sweep as ONE persistent dataflow launch (csrc/bwd_dataflow.hip; H <= 256): the mirror image of
  * dagnn_dataflow_run on the same schedule workspace, replacing dagnn_backward_run's T + L - 1 launches.
- *   1. dagnn_backward_prepare (a, alpha) and the two pre-activation GEMMs (gi, gh) as before;
+ *   1. dagnn_backward_prepare (a, alpha) and the two pre-activation GEMMs (gi, gh) as before (no gi / gh when the forward
+ *      launch wrote the static rows itself: stat_rows / stat_rows_written);
  *   2. dagnn_bwd_dataflow_prepare: successor records in schedule order (`records`, dagnn_bwd_dataflow_record_bytes: 256 bytes
  *      per record - the node, its successor row, the first four successors with their edge features and the attention weight
  *      of every stacked layer, so `alpha` of step 1 must be final) and the per-(cell, node) static rows `stat` (dagnn_bwd_dataflow_static_bytes each): Gext, h and the GRU-backward
@@ -581,7 +587,8 @@ typedef struct dagnn_bwd_dataflow_cell {
     const float* b_hh;      /* prepare: [3H] */
     const float* h;         /* prepare: [N,ld_h] forward states */
     const float* g_ext;     /* prepare: [N,ld_g] gradient reaching h from outside the recurrence */
-    float* stat;            /* [N, 8 * 256] static rows: written by prepare, read by run */
+    float* stat;            /* [N, 8 * 256] static rows: written by prepare (or, all but the g_ext row, by the forward launch:
+                             * stat_rows_written), read by run */
     void* da_granules;      /* uint64 [N,gld] */
     void* q_granules;       /* uint64 [N] */
     void* dgi_granules;     /* uint64 [N,3 gld] (stacked layers > 0) */
@@ -603,6 +610,9 @@ typedef struct dagnn_bwd_dataflow_args {
     int num_cus;              /* XCD-aware placement, as in dagnn_dataflow_args (0 / NULL: off) */
     void* xcc_table;
     int xcd_first;            /* as in dagnn_dataflow_args */
+    int stat_rows_written;    /* nonzero: the forward launch of this step wrote rows 1..7 of every `stat` record
+                               * (dagnn_dataflow_args.stat_rows); prepare only scatters g_ext into row 0 and gi / gh / a / b_hh / h
+                               * of the cells are not read */
 } dagnn_bwd_dataflow_args;
 
 size_t dagnn_bwd_dataflow_record_bytes(int64_t N);

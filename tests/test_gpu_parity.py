@@ -820,6 +820,40 @@ def test_reserved_cus_change_the_schedule_not_the_gradients(device, monkeypatch)
     assert engine.reserved_cus_info(True) == (0, "no communicator")   # (a single process without torch.distributed)
 
 
+@pytest.mark.parametrize("H,L", [(256, 2), (128, 1), (320, 1)])
+def test_static_rows_from_the_forward_launch_feed_the_reverse_sweep(device, monkeypatch, H, L):
+    """`DAGNN_AMD_STAT_FWD` (engine.stat_rows_ok): the forward launch of a training pass writes the reverse sweep's static
+    record rows - state and gate coefficients (csrc/dataflow.hip, the AUX == 2 epilogue) - and `dagnn_bwd_dataflow_prepare`
+    only adds the external-gradient row.  The same loss; gradients within fp32 rounding of the ones from the records
+    `bd_stat_kernel` builds out of the kept pre-activations (it re-evaluates the gates with expf / tanhf, the forward
+    epilogue uses the gates it applied); the widths cover the zero-filled record (128), both parts of the 320 one."""
+    from dagnn_amd import _lib
+    lib = _lib.load()
+    model = _headline_model(H=H, L=L, V=32, seed=6).to(device)
+    b = synth.code2_batch(13, 96, 125)
+    y = torch.randint(0, 32, (96, 5), generator=torch.Generator().manual_seed(2)).to(device)
+    got, flags = {}, {}
+    orig = lib.dagnn_bwd_dataflow_prepare
+
+    class _Spy(object):
+        def __call__(self, plan, args, stream):
+            flags.setdefault(cur[0], []).append(int(args._obj.stat_rows_written))
+            return orig(plan, args, stream)
+    monkeypatch.setattr(lib, "dagnn_bwd_dataflow_prepare", _Spy(), raising=False)
+    cur = [None]
+    for flag in (0, 1):
+        cur[0] = flag
+        monkeypatch.setattr(engine, "STAT_FWD", flag)
+        loss, grads = _train_step(model, b.clone().to(device), y)
+        model.check()
+        got[flag] = (loss.clone(), {k: v.clone() for k, v in grads.items()})
+    assert flags[0] == [0] and flags[1] == [1], flags
+    assert torch.equal(got[0][0], got[1][0])
+    for k, g in got[1][1].items():
+        ref = got[0][1][k]
+        assert Hh.maxdiff(g, ref) <= 2e-5 * max(float(ref.abs().max()), 1e-3), k
+
+
 def _degenerate_batch(extra=()):
     """Single-node graphs, a chain, stars with a 200-way fan-in / fan-out, a graph with no edges, a duplicate edge
     (`extra`: more graphs behind them)."""

@@ -102,7 +102,7 @@ class DataflowArgs(C.Structure):
                 ("H", C.c_int), ("ld_h", C.c_int), ("gld", C.c_int), ("pld", C.c_int), ("vid_mod", C.c_int), ("groups", C.c_int),
                 ("epoch", C.c_uint), ("schedule", C.c_void_p), ("err", C.c_void_p), ("debug_timing", C.c_void_p),
                 ("spin_limit", C.c_uint), ("debug_wg", C.c_int), ("num_cus", C.c_int), ("xcc_table", C.c_void_p),
-                ("plan_status", C.c_void_p), ("xcd_first", C.c_int), ("stat_rows", C.c_int)]
+                ("plan_status", C.c_void_p), ("xcd_first", C.c_int), ("stat_rows", C.c_int), ("slices64", C.c_int)]
 
 
 class TilesCell(C.Structure):
@@ -258,6 +258,7 @@ SYMBOLS = {
                                           C.c_void_p, C.c_void_p]),
     "dagnn_dataflow_run": (C.c_int, [C.POINTER(Plan), C.POINTER(DataflowArgs), C.c_void_p]),
     "dagnn_dataflow_run_wide": (C.c_int, [C.POINTER(Plan), C.POINTER(DataflowArgs), C.c_void_p]),
+    "dagnn_dataflow_run_x": (C.c_int, [C.POINTER(Plan), C.POINTER(DataflowArgs), C.c_void_p]),
     "dagnn_tiles_launches": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dagnn_tiles_run": (C.c_int, [C.POINTER(Plan), C.POINTER(TilesArgs), C.c_void_p]),
     "dagnn_pack_dataflow": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -186,8 +186,23 @@ __device__ __forceinline__ float df_tanh(float x) { return 1.0f - 2.0f * __built
 // 8 lanes.  (Round 6 measured the other shape the register file allows - two compute waves per SIMD with 4 units each, K over 16
 // lanes, 16 waves per workgroup at <= 128 VGPRs: 1.50 against 1.33 ms on the headline batch; the complete kernel
 // path is scripts/experiments/dataflow_split_r06.patch.)
-constexpr int DFF_NCW = DF_NCW;
-constexpr int DFF_THREADS = 64 * (DFF_NCW + DF_NLW);
+// The slice shape of a translation unit (dataflow_x.hip sets the macros): DFF_JS hidden units per workgroup = 8 per compute wave,
+// DFF_NLS streams per workgroup, 12 waves in all.  The default - 32 units, 4 compute waves, 2 streams x 4 loader waves - is the
+// reverse sweep's shape too (df_common.h); the 64-unit shape has 8 compute waves (two per SIMD) and ONE stream of 4 loader waves.
+#ifndef DFF_JS_V
+#define DFF_JS_V DF_JS
+#endif
+#ifndef DFF_NLS_V
+#define DFF_NLS_V DF_NLS
+#endif
+constexpr int DFF_JS = DFF_JS_V;
+constexpr int DFF_NCW = DFF_JS / 8;
+constexpr int DFF_NLS = DFF_NLS_V;
+constexpr int DFF_NLW = DFF_JS == DF_JS ? DF_NLW : 12 - DFF_NCW;
+constexpr int DFF_WPS = DFF_NLW / DFF_NLS;      // loader waves per stream
+constexpr int DFF_RPW = DF_RB / DFF_WPS;        // rows of a block per loader wave (one after the other)
+constexpr int DFF_THREADS = 64 * (DFF_NCW + DFF_NLW);
+static_assert((DFF_NCW == 4 || DFF_NCW == 8) && DFF_NCW * 8 == DFF_JS && DFF_NLW % DFF_NLS == 0 && DF_RB % DFF_WPS == 0 && (DFF_NLS == 1 || DFF_NLS == 2), "workgroup shape");
 // operand rows in LDS: the K dimension is split over 8 lanes (KP8 = H / 8 values each); K-lane segment s starts at
 // s * (KP8 + 4): the 8 segments a half DPP row reads concurrently (ds_read_b128) fall on disjoint banks
 template <int KPT> struct DfPad { static constexpr int kp8 = 2 * KPT; static constexpr int seg = kp8 + 4; static constexpr int row = 8 * seg + 8; };
@@ -200,15 +215,17 @@ constexpr int DF_WSLEEP_N = DF_WSLEEP_V;   // ... of a loader's wait for its rin
 constexpr bool DF_LEAN_COMPUTE = true;   // (the 12-wave shape: the 2 x 4 ready flags are one trip to LDS; the 8-wave shape of H = 320 has 2 x 2)
 constexpr int DF_RD = 6;       // a loader wave requests a row record this many of ITS blocks ahead (record ring: 8 entries)
 constexpr int DF_GD = 2;       // a gi0 slice this many (its node id must have landed: DF_RD >= DF_GD + 2)
+constexpr int DF_GI_LANES = 3 * DFF_JS / 4;          // lanes of a gi0 slice's DMA: 16 bytes each, gate-major
 constexpr int DF_GIRING = DF_NSLOT + DF_GD + 2;   // blocks in a stream's gi0 ring: slots in use + prefetch distance + slack
 
 // group served by stream `set` of workgroup set `pair` (-1: none).  (Measured and dropped: the first set serving the
 // deepest graph's group alone, 9 groups on 5 sets - 2.15 ms against 1.93: what binds the pass is the sets'
 // throughput, not that one chain.)
 __device__ __host__ __forceinline__ int df_stream_group(int pair, int set, int groups) {
-    return df_group_of_stream(pair, set, groups);
+    const int g = DFF_NLS * pair + set;
+    return g < groups ? g : -1;
 }
-__host__ inline int df_sets_for(int groups) { return (groups + DF_NLS - 1) / DF_NLS; }
+__host__ inline int df_sets_for(int groups) { return (groups + DFF_NLS - 1) / DFF_NLS; }
 
 struct DfLds {
     float* ring;     // [NLS][NSLOT] slots: a ring per stream
@@ -217,7 +234,7 @@ struct DfLds {
     int* rdy;        // [NLS][WPS]  per loader wave: blocks it has finished (relaxed workgroup-scope atomics: plain ds_ accesses;
     int* dn;         // [NLS][NCW]  per stream and compute wave likewise   a volatile access here compiles to a FLAT load + vmcnt(0))
     int* local;      // [1] every reader of this cell's state rows runs on this workgroup's XCD (see DfArgs::role)
-    float* bias;     // [3][DF_JS] the slice's biases, gate-major (the thin-block path evaluates other units per lane than the
+    float* bias;     // [3][DFF_JS] the slice's biases, gate-major (the thin-block path evaluates other units per lane than the
                      // MFMA path, whose lanes keep their three biases in registers)
 };
 
@@ -225,7 +242,7 @@ template <int KPT> struct DfSlot {
     static constexpr int AP = DfPad<KPT>::row;
     static constexpr int a_off = 0;                       // [RB][AP]  operand rows (aggregates / lower-layer rows)
     static constexpr int gi_off = DF_RB * AP;             // [RB][96]  input-side pre-activations of the slice
-    static constexpr int v_off = gi_off + DF_RB * 3 * DF_JS;   // [RB] ints (16 B)
+    static constexpr int v_off = gi_off + DF_RB * 3 * DFF_JS;   // [RB] ints (16 B)
     static constexpr int words = v_off + 4;
 };
 
@@ -236,6 +253,7 @@ __device__ __forceinline__ bool df_wait4(const int* f, int target, int* err, uns
     unsigned spins = 0;
     for (;;) {
         int m = min(min(df_flag_ld(f), df_flag_ld(f + 1)), min(df_flag_ld(f + 2), df_flag_ld(f + 3)));   // (every compute wave's flag)
+        if (DFF_NCW == 8) m = min(m, min(min(df_flag_ld(f + 4), df_flag_ld(f + 5)), min(df_flag_ld(f + 6), df_flag_ld(f + 7))));
         if (m >= target) return true;
         __builtin_amdgcn_s_sleep(DF_WSLEEP_N);
         if (++spins > 4 * limit) { __hip_atomic_fetch_or(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
@@ -333,7 +351,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
     //    One statement per shape: NN rows x 4 loads (H < 256 repeats the last 512 bytes: same instruction count for
     //    every H), the projection slice or not, no / record / record + gi0 prefetch.
     struct Sweep { gran_t x[4][4]; gran_t xp[3]; };
-    const unsigned lane8 = 8u * lane, lane31x8 = 8u * (lane & 31);
+    const unsigned lane8 = 8u * lane, lane31x8 = 8u * (lane & (DFF_JS - 1));
     constexpr bool has_gi0 = KIND == DFK_REC0;
 #define DF_ROW_LD(e)                                                            \
     "global_load_dwordx2 %[x" #e "0], %[vo], %[b" #e "] offset:0 sc1\n\t"        \
@@ -350,7 +368,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
     "global_load_dwordx2 %[p0], %[vp], %[c0] offset:0 sc1\n\t"       \
     "global_load_dwordx2 %[p1], %[vp], %[c1] offset:0 sc1\n\t"       \
     "global_load_dwordx2 %[p2], %[vp], %[c2] offset:0 sc1\n\t"
-    // LDS-DMA: lane l of the first 16 (24) lanes moves 4 (16) bytes to M0 + 4 l (16 l); all lanes are active here
+    // LDS-DMA: lane l of the first 16 (3 JS / 4) lanes moves 4 (16) bytes to M0 + 4 l (16 l); all lanes are active here
 #define DF_DMA_0 "s_waitcnt vmcnt(0)"
 #define DF_DMA_1                                                                                   \
     "s_mov_b32 %[km], m0\n\ts_mov_b64 %[ke], exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %[rl]\n\t" \
@@ -359,7 +377,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
 #define DF_DMA_2                                                                                   \
     "s_mov_b32 %[km], m0\n\ts_mov_b64 %[ke], exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %[rl]\n\t" \
     "s_nop 0\n\tglobal_load_lds_dword %[ra], off\n\t"                                              \
-    "s_mov_b64 exec, 0xffffff\n\ts_mov_b32 m0, %[gl]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[ga], off\n\t" \
+    "s_bfm_b64 exec, %[gx], 0\n\ts_mov_b32 m0, %[gl]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[ga], off\n\t" \
     "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]\n\ts_waitcnt vmcnt(2)"
 #define DF_TRIP(n, p, d)                                                                                                   \
     asm volatile(DF_ROWS_##n DF_PROJ_##p DF_DMA_##d                                                                        \
@@ -370,13 +388,13 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                    [p0] "=v"(W.xp[0]), [p1] "=v"(W.xp[1]), [p2] "=v"(W.xp[2]), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra), [ga] "+v"(ga)  \
                  : [vo] "v"(lane8), [vp] "v"(lane31x8), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),            \
                    [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [rl] "s"(rl), [gl] "s"(gl),    \
-                   [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)                                                                \
+                   [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3), [gx] "n"(DF_GI_LANES)                                          \
                  : "memory")
 #define DF_CASE(n, p, d) case (n) * 6 + (p) * 3 + (d): DF_TRIP(n, p, d); break;
 #define DF_CASES(n) DF_CASE(n, 0, 0) DF_CASE(n, 0, 1) DF_CASE(n, 0, 2) DF_CASE(n, 1, 0) DF_CASE(n, 1, 1) DF_CASE(n, 1, 2)
 
-    // (a wave serves DF_RPW rows of every block, one after the other: `lw` and the ring addresses below follow the row)
-    int lw = w * DF_RPW;
+    // (a wave serves DFF_RPW rows of every block, one after the other: `lw` and the ring addresses below follow the row)
+    int lw = w * DFF_RPW;
     int* rec_ring;
     unsigned rec_ring_a, gi_ring_a;
     const int32_t* rec_w;
@@ -384,18 +402,18 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
         lw = row;
         rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
         rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
-        gi_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds.giring + (set * DF_GIRING * DF_RB + lw) * (3 * DF_JS)));
+        gi_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds.giring + (set * DF_GIRING * DF_RB + lw) * (3 * DFF_JS)));
         rec_w = recs + 16 * lw + (lane & 15);
     };
     set_row(lw);
     const int64_t wstride = 16 * DF_RB;   // words per block
-    const int gi_lane_off = ((lane % 24) >> 3) * H + sl * DF_JS + 4 * (lane & 7);
+    const int gi_lane_off = ((lane % DF_GI_LANES) / (DFF_JS / 4)) * H + sl * DFF_JS + 4 * (lane % (DFF_JS / 4));
     // addresses of the prefetch group: record of this wave's j-th block (past the end: the last block's again) -> ring
     // entry j & 7; gi0 slice of `node` -> gi ring entry blk % DF_GIRING, row lw
     auto rec_src = [&](int j) -> const void* { return rec_w + (int64_t)min(j, nblk - 1) * wstride; };
     auto rec_dst = [&](int j) -> unsigned { return rec_ring_a + (j & 7) * 64; };
     auto gi_src = [&](int node) -> const void* { return gi0 + (int64_t)max(node, 0) * 3 * H + gi_lane_off; };
-    auto gi_dst = [&](int blk) -> unsigned { return gi_ring_a + (blk % DF_GIRING) * (DF_RB * 3 * DF_JS * 4); };
+    auto gi_dst = [&](int blk) -> unsigned { return gi_ring_a + (blk % DF_GIRING) * (DF_RB * 3 * DFF_JS * 4); };
     auto glds4 = [&](const void* gsrc, unsigned lds_dst) {   // lane l: 4 bytes from gsrc -> LDS lds_dst + 4 l
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
@@ -407,10 +425,10 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
     };
     auto rec_dma = [&](int j) { if (lane < 16) glds4(rec_src(j), rec_dst(j)); };
-    auto gi_dma = [&](int blk, int node) { if (lane < 24) glds16(gi_src(node), gi_dst(blk)); };
+    auto gi_dma = [&](int blk, int node) { if (lane < DF_GI_LANES) glds16(gi_src(node), gi_dst(blk)); };
     if (nblk > 0) {   // prologue: records of this wave's rows of blocks 0..RD-1, gi0 slices of blocks 0..GD-1
-        for (int rr = 0; rr < DF_RPW; ++rr) {
-            set_row(w * DF_RPW + rr);
+        for (int rr = 0; rr < DFF_RPW; ++rr) {
+            set_row(w * DFF_RPW + rr);
 #pragma unroll
             for (int j = 0; j < DF_RD; ++j) rec_dma(j);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -427,8 +445,8 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
       const int j = b;
       bool slot_free = b < DF_NSLOT;   // the ring slot has been handed back (checked once per block, before the first write)
 #pragma unroll 1
-      for (int rr = 0; rr < DF_RPW; ++rr) {
-        if (DF_RPW > 1) { set_row(w * DF_RPW + rr); prof = prof_wave && rr == 0; }
+      for (int rr = 0; rr < DFF_RPW; ++rr) {
+        if (DFF_RPW > 1) { set_row(w * DFF_RPW + rr); prof = prof_wave && rr == 0; }
         const int cur = rec_ring[(j & 7) * 16 + (lane & 15)];
 #define DF_W(i) __builtin_amdgcn_readlane(cur, i)
         const int4 r0 = make_int4(DF_W(0), DF_W(1), DF_W(2), DF_W(3));
@@ -441,7 +459,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
         float* sbase = lds.ring + (set * DF_NSLOT + slot) * Slot::words;
         int* v_s = reinterpret_cast<int*>(sbase + Slot::v_off);
         const int v = r0.x;
-        if (prof) dbg[8 * (int64_t)(DF_NLS * b + set) + 4] = wall_clock64();
+        if (prof) dbg[8 * (int64_t)(DFF_NLS * b + set) + 4] = wall_clock64();
         unsigned polls = 0;
         constexpr int O1 = (NQ4 > 1 ? 1 : 0) * 512, O2 = (NQ4 > 2 ? 2 : NQ4 - 1) * 512, O3 = (NQ4 - 1) * 512;
         // one trip to memory: the rows pj[0..nn), the projection slice if `pp`, the prefetch group P(b) if `dma`
@@ -473,7 +491,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
             // input-side pre-activations of the slice from the projection cell: 3 gates x 32 units, lanes 0..31
             bool p_pending = KIND == DFK_RECP;
             float pv[3] = {0.f, 0.f, 0.f};
-            const gran_t* gp_in = p_pending ? p_in + (unsigned)v * (unsigned)pld + sl * DF_JS : g_src;   // wave-uniform (g_src: never loaded)
+            const gran_t* gp_in = p_pending ? p_in + (unsigned)v * (unsigned)pld + sl * DFF_JS : g_src;   // wave-uniform (g_src: never loaded)
             // in-edges in chunks of <= 4 (ids and features of the first chunk came with the record).  A node with more
             // than 4 in-edges takes two chunks per trip to memory (all of them finished long ago: the trips, not the
             // data, are what such a row waits for)
@@ -605,8 +623,8 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                     if ((rows_ok && !p_pending) || !df_retry(spins, err, spin_limit)) break;
                 }
                 if (prof && c0 == 0) {
-                    dbg[8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64(); dbg[8 * (int64_t)(DF_NLS * b + set) + 6] = polls;
-                    if (DF_NLS * b + set >= 8) dbg[8 * (int64_t)(DF_NLS * b + set) + 7] = t_issue;   // when the poll that found the row was issued
+                    dbg[8 * (int64_t)(DFF_NLS * b + set) + 5] = wall_clock64(); dbg[8 * (int64_t)(DFF_NLS * b + set) + 6] = polls;
+                    if (DFF_NLS * b + set >= 8) dbg[8 * (int64_t)(DFF_NLS * b + set) + 7] = t_issue;   // when the poll that found the row was issued
                 }
                 if (PLAIN) {   // messages h_j + e_j, summed or maximised column by column (rows without a message stay zero)
 #pragma unroll
@@ -628,7 +646,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                 }
                 c0 += 4;
             } while (c0 < deg);
-            if (prof) { asm volatile("" :: "v"(acc[0]), "v"(acc[3]), "v"(l)); dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + set) + 4] = wall_clock64(); }   // fold done
+            if (prof) { asm volatile("" :: "v"(acc[0]), "v"(acc[3]), "v"(l)); dbg[(1 << 19) + 8 * (int64_t)(DFF_NLS * b + set) + 4] = wall_clock64(); }   // fold done
             if (deg > 1 && !PLAIN) {   // PyG softmax: exp(x - max) / (sum + 1e-16)
                 const float inv = __builtin_amdgcn_rcpf(l + 1e-16f);
 #pragma unroll
@@ -638,9 +656,9 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
             float* a_row = sbase + Slot::a_off + lw * Slot::AP;
 #pragma unroll
             for (int q = 0; q < NQ4; ++q) a_row[cpos[q]] = acc[q];
-            if (KIND == DFK_RECP && lane < 32) {
+            if (KIND == DFK_RECP && lane < DFF_JS) {
 #pragma unroll
-                for (int g = 0; g < 3; ++g) sbase[Slot::gi_off + lw * (3 * DF_JS) + g * DF_JS + lane] = pv[g];
+                for (int g = 0; g < 3; ++g) sbase[Slot::gi_off + lw * (3 * DFF_JS) + g * DFF_JS + lane] = pv[g];
             }
         } else {
             const int none[4] = {0, 0, 0, 0};
@@ -649,10 +667,10 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
         }
         if (lane == 0) v_s[lw] = v;
       }
-        if (prof_wave) dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64();   // LDS writes issued
+        if (prof_wave) dbg[(1 << 19) + 8 * (int64_t)(DFF_NLS * b + set) + 5] = wall_clock64();   // LDS writes issued
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) df_flag_st(lds.rdy + set * DF_WPS + w, b + 1);
-        if (prof_wave) dbg[8 * (int64_t)(DF_NLS * b + set) + 3] = wall_clock64();
+        if (lane == 0) df_flag_st(lds.rdy + set * DFF_WPS + w, b + 1);
+        if (prof_wave) dbg[8 * (int64_t)(DFF_NLS * b + set) + 3] = wall_clock64();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of ours is in flight when the wave ends
 #undef DF_TRIP
@@ -681,7 +699,7 @@ struct DfSweep { gran_t x[4][5]; gran_t xp[3]; };   // (the fifth column block: 
                    [p0] "=v"(W.xp[0]), [p1] "=v"(W.xp[1]), [p2] "=v"(W.xp[2]), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra), [ga] "+v"(ga)  \
                  : [vo] "v"(lane8), [vp] "v"(lane31x8), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),            \
                    [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [rl] "s"(rl), [gl] "s"(gl),    \
-                   [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3)                                                                \
+                   [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3), [gx] "n"(DF_GI_LANES)                                          \
                  : "memory")
 // H = 320: five column blocks per lane
 #define DF_ROW_LD5(e) DF_ROW_LD(e) "global_load_dwordx2 %[x" #e "4], %[vo], %[b" #e "] offset:%[o4] sc1\n\t"
@@ -699,7 +717,7 @@ struct DfSweep { gran_t x[4][5]; gran_t xp[3]; };   // (the fifth column block: 
                    [p0] "=v"(W.xp[0]), [p1] "=v"(W.xp[1]), [p2] "=v"(W.xp[2]), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra), [ga] "+v"(ga)  \
                  : [vo] "v"(lane8), [vp] "v"(lane31x8), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),            \
                    [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [rl] "s"(rl), [gl] "s"(gl),    \
-                   [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3), [o4] "n"(2048)                                                \
+                   [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3), [o4] "n"(2048), [gx] "n"(DF_GI_LANES)                          \
                  : "memory")
 #define DF_IFC(n, p, d) if constexpr (NN == (n) && PP == (p) && DMA == (d)) { if constexpr (NQ4 == 5) { DF_TRIP5(n, p, d); } else { DF_TRIP(n, p, d); } } else
 #define DF_IFCS(n) DF_IFC(n, 0, 0) DF_IFC(n, 0, 1) DF_IFC(n, 0, 2) DF_IFC(n, 1, 0) DF_IFC(n, 1, 1) DF_IFC(n, 1, 2)
@@ -772,9 +790,9 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
         cpos[q] = c + (SEG - KP8) * (c / KP8);
         wk[q] = (!proj && q < NQ4) ? C.wkey[c] : 0.f;
     }
-    const unsigned lane8 = 8u * lane, lane31x8 = 8u * (lane & 31);
-    // (a wave serves DF_RPW rows of every block, one after the other: `lw` and the ring addresses follow the row)
-    int lw = w * DF_RPW;
+    const unsigned lane8 = 8u * lane, lane31x8 = 8u * (lane & (DFF_JS - 1));
+    // (a wave serves DFF_RPW rows of every block, one after the other: `lw` and the ring addresses follow the row)
+    int lw = w * DFF_RPW;
     int* rec_ring;
     unsigned rec_ring_a, gi_ring_a;
     const int32_t* rec_w;
@@ -782,16 +800,16 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
         lw = row;
         rec_ring = lds.rec + (set * DF_RB + lw) * (8 * 16);
         rec_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)rec_ring);
-        gi_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds.giring + (set * DF_GIRING * DF_RB + lw) * (3 * DF_JS)));
+        gi_ring_a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds.giring + (set * DF_GIRING * DF_RB + lw) * (3 * DFF_JS)));
         rec_w = recs + 16 * lw + (lane & 15);
     };
     set_row(lw);
     const int64_t wstride = 16 * DF_RB;
-    const int gi_lane_off = ((lane % 24) >> 3) * H + sl * DF_JS + 4 * (lane & 7);
+    const int gi_lane_off = ((lane % DF_GI_LANES) / (DFF_JS / 4)) * H + sl * DFF_JS + 4 * (lane % (DFF_JS / 4));
     auto rec_src = [&](int j) -> const void* { return rec_w + (int64_t)min(j, nblk - 1) * wstride; };
     auto rec_dst = [&](int j) -> unsigned { return rec_ring_a + (j & 7) * 64; };
     auto gi_src = [&](int node) -> const void* { return gi0 + (int64_t)max(node, 0) * 3 * H + gi_lane_off; };
-    auto gi_dst = [&](int blk) -> unsigned { return gi_ring_a + (blk % DF_GIRING) * (DF_RB * 3 * DF_JS * 4); };
+    auto gi_dst = [&](int blk) -> unsigned { return gi_ring_a + (blk % DF_GIRING) * (DF_RB * 3 * DFF_JS * 4); };
     if (nblk > 0) {   // prologue: records of blocks 0..RD-1, gi0 slices of blocks 0..GD-1
         auto glds4 = [&](const void* gsrc, unsigned lds_dst) {
             unsigned keep;
@@ -803,8 +821,8 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
         };
-        for (int rr = 0; rr < DF_RPW; ++rr) {
-            set_row(w * DF_RPW + rr);
+        for (int rr = 0; rr < DFF_RPW; ++rr) {
+            set_row(w * DFF_RPW + rr);
 #pragma unroll
             for (int j = 0; j < DF_RD; ++j) if (lane < 16) glds4(rec_src(j), rec_dst(j));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -812,7 +830,7 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
 #pragma unroll
                 for (int j = 0; j < DF_GD; ++j) {
                     const int node = __builtin_amdgcn_readfirstlane(rec_ring[j * 16]);
-                    if (lane < 24) glds16(gi_src(node), gi_dst(j));
+                    if (lane < DF_GI_LANES) glds16(gi_src(node), gi_dst(j));
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -829,9 +847,9 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
         // where rows are already waiting)
         if (b >= DF_NSLOT) df_wait4(dn, b - DF_NSLOT + 1, err, spin_limit);
 #pragma unroll 1
-      for (int rr = 0; rr < DF_RPW; ++rr) {
-        if (DF_RPW > 1) set_row(w * DF_RPW + rr);
-        if (prof) { dbg[8 * (int64_t)(DF_NLS * b + set) + 4] = wall_clock64(); polls = 0; }
+      for (int rr = 0; rr < DFF_RPW; ++rr) {
+        if (DFF_RPW > 1) set_row(w * DFF_RPW + rr);
+        if (prof) { dbg[8 * (int64_t)(DFF_NLS * b + set) + 4] = wall_clock64(); polls = 0; }
         const int cur = rec_ring[(b & 7) * 16 + (lane & 15)];
         const int v2 = has_gi0 ? __builtin_amdgcn_readfirstlane(rec_ring[((b + DF_GD) & 7) * 16]) : 0;   // node of block b + GD (landed long ago)
 #define DF_W(i) __builtin_amdgcn_readlane(cur, i)
@@ -851,7 +869,7 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
 #endif
             const int eb = DF_W(1);
             const int deg = proj ? 1 : DF_W(2) - eb;
-            if (PPK) T.c = p_in + (unsigned)v * pld + sl * DF_JS;
+            if (PPK) T.c = p_in + (unsigned)v * pld + sl * DFF_JS;
             // poll until every granule of the trip carries this pass's tag: first trip with the prefetch group behind it
             auto poll = [&](auto nn_c, auto dma_c) {
                 constexpr int NN = decltype(nn_c)::value, DM = decltype(dma_c)::value;
@@ -869,8 +887,8 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
                     } while (more && !df_landed<NN, PPK, NQ4>(A, epoch));
                 }
                 if (prof && DM != 0) {
-                    dbg[8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64(); dbg[8 * (int64_t)(DF_NLS * b + set) + 6] = polls;
-                    if (DF_NLS * b + set >= 8) dbg[8 * (int64_t)(DF_NLS * b + set) + 7] = t_issue;
+                    dbg[8 * (int64_t)(DFF_NLS * b + set) + 5] = wall_clock64(); dbg[8 * (int64_t)(DFF_NLS * b + set) + 6] = polls;
+                    if (DFF_NLS * b + set >= 8) dbg[8 * (int64_t)(DFF_NLS * b + set) + 7] = t_issue;
                 }
             };
 #define DF_ROWF(e, q) __uint_as_float((unsigned)A.x[e][q])
@@ -980,13 +998,13 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
                 for (int q = 0; q < NC; ++q) acc[q] *= inv;
             }
 #undef DF_ROWF
-            if (prof) { asm volatile("" :: "v"(acc[0]), "v"(acc[NC - 1])); dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + set) + 4] = wall_clock64(); }   // fold done
+            if (prof) { asm volatile("" :: "v"(acc[0]), "v"(acc[NC - 1])); dbg[(1 << 19) + 8 * (int64_t)(DFF_NLS * b + set) + 4] = wall_clock64(); }   // fold done
             float* a_row = sbase + Slot::a_off + lw * Slot::AP;
 #pragma unroll
             for (int q = 0; q < NQ4; ++q) a_row[cpos[q]] = acc[q];
             if (PPK) {   // input-side pre-activations of the slice: lanes l and l + 32 loaded the same granules (same words, same place)
 #pragma unroll
-                for (int g = 0; g < 3; ++g) sbase[Slot::gi_off + lw * (3 * DF_JS) + g * DF_JS + (lane & 31)] = __uint_as_float((unsigned)A.xp[g]);
+                for (int g = 0; g < 3; ++g) sbase[Slot::gi_off + lw * (3 * DFF_JS) + g * DFF_JS + (lane & (DFF_JS - 1))] = __uint_as_float((unsigned)A.xp[g]);
             }
         } else {
             df_trip<NQ4, H, 0, 0, DMA1>(A, T, lane8, lane31x8);   // an idle row keeps the cadence: P(b) out, P(b - 1) landed
@@ -994,13 +1012,14 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
 #undef DF_W
         reinterpret_cast<int*>(sbase + Slot::v_off)[lw] = v;   // (every lane: same word, same value - no lane-0 predicate)
       }
-        if (prof) dbg[(1 << 19) + 8 * (int64_t)(DF_NLS * b + set) + 5] = wall_clock64();   // LDS writes issued
+        if (prof) dbg[(1 << 19) + 8 * (int64_t)(DFF_NLS * b + set) + 5] = wall_clock64();   // LDS writes issued
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        df_flag_st(lds.rdy + set * DF_WPS + w, b + 1);
-        if (prof) dbg[8 * (int64_t)(DF_NLS * b + set) + 3] = wall_clock64();
+        df_flag_st(lds.rdy + set * DFF_WPS + w, b + 1);
+        if (prof) dbg[8 * (int64_t)(DFF_NLS * b + set) + 3] = wall_clock64();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of ours is in flight when the wave ends
 }
+
 #undef DF_TRIP
 #undef DF_TRIP5
 #undef DF_IFC
@@ -1050,15 +1069,16 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     constexpr bool gi_ring = KIND == DFK_REC0;
     const int d = C.dir;
     // the two streams of this workgroup: groups NLS * pair and NLS * pair + 1 (the second may not exist)
-    int nb[DF_NLS];   // blocks of the workgroup's streams (0: no such group)
+    int nb[DFF_NLS];   // blocks of the workgroup's streams (0: no such group)
 #pragma unroll
-    for (int q = 0; q < DF_NLS; ++q) {
+    for (int q = 0; q < DFF_NLS; ++q) {
         const int grp = df_stream_group(pair, q, S.groups);
         nb[q] = grp >= 0 ? S.sched[S.gtab[d] + 2 * grp + 1] : 0;
     }
     float wr[KP8], wz[KP8], wn[KP8];   // the lane's K slice of the r / z / n rows of its unit
     {
-        const float4* wp = C.w + (int64_t)sl * (3 * NK4) * 256 + tc;
+        // (the packed matrix is in 32-unit slices of 256 lanes: a 64-unit workgroup's compute waves 4..7 take the odd one)
+        const float4* wp = C.w + (int64_t)(sl * (DFF_JS / 32) + (cw >> 2)) * (3 * NK4) * 256 + tc;
 #pragma unroll
         for (int q = 0; q < NK4; ++q) {
             const float4 x0 = wp[(0 * NK4 + q) * 256], x1 = wp[(1 * NK4 + q) * 256], x2 = wp[(2 * NK4 + q) * 256];
@@ -1075,7 +1095,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     // (the activations are the MFMA's A operand, the weights its B operand: D register i = row i, lane x = unit x - the four lanes
     // of a quad store four consecutive units of one row, 32 contiguous bytes of granules; with the operands the other way round
     // every lane of a store went to another row: 32 eight-byte transactions per instruction, a quarter of the wave's time)
-    const int unit_l = 8 * cw + 4 * quad + x, unit = sl * DF_JS + unit_l;
+    const int unit_l = 8 * cw + 4 * quad + x, unit = sl * DFF_JS + unit_l;
     const int row_l = 2 * (ks & 1) + ((ks >> 1) & 1);
     float b_r = C.bias[unit], b_z = C.bias[H + unit], b_n = C.bias[2 * H + unit];
     asm volatile("" : "+v"(b_r), "+v"(b_z), "+v"(b_n));   // landed before the loop (see the weights above)
@@ -1112,24 +1132,24 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
     // done flag: lane 0 writes dn[st][cw], the others a word of their own in the dump area
     int* const dn_or_dump = lane == 0 ? lds.dn + cw : reinterpret_cast<int*>(lds.bias) + lane;
     const int dn_step = lane == 0 ? DFF_NCW : 0;   // (words between the two streams' flags)
-    const int nb0 = nb[0], nb1 = DF_NLS > 1 ? nb[DF_NLS - 1] : 0;
-    static_assert(DF_NLS == 2, "two streams per workgroup");
+    const int nb0 = nb[0], nb1 = DFF_NLS > 1 ? nb[DFF_NLS - 1] : 0;
+    static_assert(DFF_NLS == 2 || (DFF_NLS == 1 && DFF_WPS == 4), "two streams per workgroup, or one (its counters below stay zero)");
 
     auto run = [&](auto local_c, auto aux_c) {
         constexpr bool LOCAL = decltype(local_c)::value;
         constexpr int AUX = decltype(aux_c)::value;   // 0: none, 1: the pre-activations, 2: the reverse sweep's static rows
         int done0 = 0, done1 = 0, pref = 0;
         int m0 = 0, m1 = 0;   // blocks the streams' loaders had finished at the last look (wave-uniform)
-        auto flags_min = [&](const i4v& r0, const i4v& r1) {   // DF_WPS flags per stream, stream-major
-            if (DF_WPS == 4) {
+        auto flags_min = [&](const i4v& r0, const i4v& r1) {   // DFF_WPS flags per stream, stream-major
+            if (DFF_WPS == 4) {
                 m0 = __builtin_amdgcn_readfirstlane(min(min(r0.x, r0.y), min(r0.z, r0.w)));
-                m1 = __builtin_amdgcn_readfirstlane(min(min(r1.x, r1.y), min(r1.z, r1.w)));
+                if (DFF_NLS > 1) m1 = __builtin_amdgcn_readfirstlane(min(min(r1.x, r1.y), min(r1.z, r1.w)));
             } else {
                 m0 = __builtin_amdgcn_readfirstlane(min(r0.x, r0.y));
                 m1 = __builtin_amdgcn_readfirstlane(min(r0.z, r0.w));
             }
         };
-        static_assert(DF_WPS == 4 || DF_WPS == 2, "");
+        static_assert(DFF_WPS == 4 || DFF_WPS == 2, "");
         for (int left = nb0 + nb1; left > 0; --left) {
             int l0 = m0 - done0, l1 = m1 - done1;   // leads (>= 0: a loader stops at its stream's last block)
 #ifdef DF_EXP_NOLOOK   // timing experiment: no look at the ready flags (only meaningful with DF_EXP_NOLOAD)
@@ -1138,7 +1158,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
             if (l0 <= 0 && l1 <= 0) {   // nothing known to be ready: look until there is
                 unsigned spins = 0;
                 for (;;) {
-                    const i4v r0 = rdy_p[0], r1 = DF_WPS == 4 ? rdy_p[1] : r0;
+                    const i4v r0 = rdy_p[0], r1 = (DFF_WPS == 4 && DFF_NLS > 1) ? rdy_p[1] : r0;
                     flags_min(r0, r1);
                     l0 = m0 - done0; l1 = m1 - done1;
                     if (l0 > 0 || l1 > 0) break;
@@ -1162,15 +1182,15 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
             done1 += st;
             const float* sbase = lds.ring + (st * DF_NSLOT + (b & (DF_NSLOT - 1))) * Slot::words;
             static_assert((DF_NSLOT & (DF_NSLOT - 1)) == 0 && (DF_GIRING & (DF_GIRING - 1)) == 0, "ring sizes are powers of two");
-            if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 0] = wall_clock64();
+            if (prof) dbg[8 * (int64_t)(DFF_NLS * b + st) + 0] = wall_clock64();
             // every LDS read of the block leaves in one go: the row's node id, the gate operands, the operand rows (a dead
             // row's lanes read their slot's stale words and drop them)
             const int gv = reinterpret_cast<const int*>(sbase + Slot::v_off)[row_l];
             float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, aval = 0.f;
             if (!proj) {   // from the gi0 ring (stacked layer 0) or from the slot (projection granules)
-                const float* gp = (gi_ring ? lds.giring + (st * DF_GIRING + (b & (DF_GIRING - 1))) * (DF_RB * 3 * DF_JS) : sbase + Slot::gi_off) +
-                                  row_l * (3 * DF_JS) + unit_l;
-                gi_r = gp[0]; gi_z = gp[DF_JS]; gi_n = gp[2 * DF_JS];
+                const float* gp = (gi_ring ? lds.giring + (st * DF_GIRING + (b & (DF_GIRING - 1))) * (DF_RB * 3 * DFF_JS) : sbase + Slot::gi_off) +
+                                  row_l * (3 * DFF_JS) + unit_l;
+                gi_r = gp[0]; gi_z = gp[DFF_JS]; gi_n = gp[2 * DFF_JS];
                 aval = sbase[Slot::a_off + row_l * Slot::AP + apos];
             }
             float g3[3];
@@ -1224,7 +1244,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
 #ifndef DF_EXP_NOLOOK
                 {   // the look for the NEXT block: issued behind the last product, read at the top of the next iteration
                     __builtin_amdgcn_sched_barrier(0);
-                    const i4v r0 = rdy_p[0], r1 = DF_WPS == 4 ? rdy_p[1] : r0;
+                    const i4v r0 = rdy_p[0], r1 = (DFF_WPS == 4 && DFF_NLS > 1) ? rdy_p[1] : r0;
 #endif
 #ifdef DF_EXP_NOEPI   // timing experiment: no reduction, no gates
 #pragma unroll
@@ -1238,7 +1258,7 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
                 }
 #endif
             }
-            if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 1] = wall_clock64();
+            if (prof) dbg[8 * (int64_t)(DFF_NLS * b + st) + 1] = wall_clock64();
             const float p_r = g3[0] + b_r, p_z = g3[1] + b_z, p_n = g3[2] + b_n;   // W a + b: the cell's pre-activations
             float hv = 0.f, ng = 0.f;
             if (!proj) {   // (every lane: no branch around the gates)
@@ -1296,11 +1316,11 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
                         *reinterpret_cast<float*>(rec + DF_ST_CN * RS) = cn; *reinterpret_cast<float*>(rec + DF_ST_Z * RS) = zg;
                         *reinterpret_cast<float*>(rec + DF_ST_CQ * RS) = cq;
                     };
-                    if (H > 256 && sl >= 256 / DF_JS) put(std::integral_constant<int, 64>());   // (wave-uniform)
+                    if (H > 256 && sl >= 256 / DFF_JS) put(std::integral_constant<int, 64>());   // (wave-uniform)
                     else put(std::integral_constant<int, DF_STAT_SP>());
                 }
             }
-            if (prof) dbg[8 * (int64_t)(DF_NLS * b + st) + 2] = wall_clock64();
+            if (prof) dbg[8 * (int64_t)(DFF_NLS * b + st) + 2] = wall_clock64();
         }
     };
     typedef std::integral_constant<int, 0> aux0;
@@ -1315,7 +1335,7 @@ template <int KPT>
 __global__ void __launch_bounds__(DFF_THREADS, DFF_THREADS / 256) dataflow_kernel(const int32_t* __restrict__ plan, DfArgs S) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef DfSlot<KPT> Slot;
-    constexpr int NS = 16 * KPT / DF_JS;
+    constexpr int NS = 16 * KPT / DFF_JS;
     const int tid = threadIdx.x;
     if (S.status && S.status[0] != 0) {   // the batch violates the plan contract: the schedule is garbage - do not walk it
         if (tid == 0) __hip_atomic_fetch_or(S.err, 4 | ((S.status[0] & 0xff) << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1341,16 +1361,16 @@ __global__ void __launch_bounds__(DFF_THREADS, DFF_THREADS / 256) dataflow_kerne
     const DfCell& C = S.cell[c];
     DfLds lds;
     lds.ring = smem;
-    lds.giring = lds.ring + DF_NLS * DF_NSLOT * Slot::words;
-    lds.rec = reinterpret_cast<int*>(lds.giring + DF_NLS * DF_GIRING * DF_RB * 3 * DF_JS);
-    int* flags = lds.rec + DF_NLS * DF_RB * 8 * 16;
+    lds.giring = lds.ring + DFF_NLS * DF_NSLOT * Slot::words;
+    lds.rec = reinterpret_cast<int*>(lds.giring + DFF_NLS * DF_GIRING * DF_RB * 3 * DFF_JS);
+    int* flags = lds.rec + DFF_NLS * DF_RB * 8 * 16;
     lds.rdy = flags;
-    lds.dn = flags + DF_NLW;
-    lds.local = flags + DF_NLW + DF_NLS * DFF_NCW;
+    lds.dn = flags + DFF_NLW;
+    lds.local = flags + DFF_NLW + DFF_NLS * DFF_NCW;
     lds.bias = reinterpret_cast<float*>(flags + 32);
-    if (tid < DF_NLW + DF_NLS * DFF_NCW + 1) flags[tid] = 0;
-    static_assert(DF_NLW + DF_NLS * DFF_NCW + 1 <= 32, "flag words");
-    if (tid >= 64 && tid < 64 + 3 * DF_JS) lds.bias[tid - 64] = C.bias[((tid - 64) / DF_JS) * (16 * KPT) + sl * DF_JS + (tid - 64) % DF_JS];
+    if (tid < DFF_NLW + DFF_NLS * DFF_NCW + 1) flags[tid] = 0;
+    static_assert(DFF_NLW + DFF_NLS * DFF_NCW + 1 <= 32, "flag words");
+    if (tid >= 64 && tid < 64 + 3 * DFF_JS) lds.bias[tid - 64] = C.bias[((tid - 64) / DFF_JS) * (16 * KPT) + sl * DFF_JS + (tid - 64) % DFF_JS];
     if (S.nroles > 0 && wave == 0) {
         // where does this workgroup really run?  Publish it, and - recurrent cells - look where the readers of this cell's
         // state rows run: its own slices and the slices of the projection cell above it, same workgroup set
@@ -1394,9 +1414,9 @@ __global__ void __launch_bounds__(DFF_THREADS, DFF_THREADS / 256) dataflow_kerne
             default: df_compute<KPT, DFK_PROJ>(S, C, sl, pair, lds, cw); break;
         }
     } else {
-        const int set = (wave - DFF_NCW) / DF_WPS;
+        const int set = (wave - DFF_NCW) / DFF_WPS;
         const int grp = df_stream_group(pair, set, S.groups);
-        const int w = (wave - DFF_NCW) % DF_WPS;   // the row of its stream's blocks this wave serves
+        const int w = (wave - DFF_NCW) % DFF_WPS;   // the row of its stream's blocks this wave serves
         if (grp >= 0) {
 #define DF_LOADER_CASE(K, RR, EX) case (K) * 4 + ((RR) == 2 ? 2 : 0) + ((EX) ? 1 : 0): df_loader<KPT, K, RR, EX>(plan, S, C, sl, grp, lds, w, set); break;
             if (variant == DFK_REC0 * 4 + 2) { df_loader_fast<KPT, DFK_REC0>(plan, S, C, sl, grp, lds, w, set); }
@@ -1424,7 +1444,7 @@ __global__ void __launch_bounds__(DFF_THREADS, DFF_THREADS / 256) dataflow_kerne
 }
 
 template <int KPT> size_t df_lds_bytes() {
-    return (size_t)DF_NLS * (DF_NSLOT * DfSlot<KPT>::words + DF_GIRING * DF_RB * 3 * DF_JS + DF_RB * 8 * 16) * 4 + 128 + 3 * DF_JS * 4 + 128;
+    return (size_t)DFF_NLS * (DF_NSLOT * DfSlot<KPT>::words + DF_GIRING * DF_RB * 3 * DFF_JS + DF_RB * 8 * 16) * 4 + 128 + 3 * DFF_JS * 4 + 128;
 }
 
 // Which element of W the idx-th float4 of a packed matrix holds: thread tc = (compute wave tc >> 6, unit quad (tc >> 5) & 1, K slice
@@ -1515,8 +1535,8 @@ __global__ void __launch_bounds__(256) df_score_parts_kernel(DfScoreJobs J, int 
 
 }  // namespace
 
-#ifdef DF_WIDE_TU
-constexpr int DF_TU_MAX_H = 320;   // this translation unit: csrc/dataflow_w.hip, the 8-wave workgroup shape of H = 320
+#if defined(DF_WIDE_TU) || defined(DF_X_TU)
+constexpr int DF_TU_MAX_H = 320;   // this translation unit: csrc/dataflow_w.hip (H = 320) or csrc/dataflow_x.hip (64-unit slices, H = 256 / 320)
 #else
 constexpr int DF_TU_MAX_H = 256;
 extern "C" size_t dagnn_dataflow_bytes(int64_t N, int64_t B, int groups) {
@@ -1538,7 +1558,7 @@ extern "C" int dagnn_dataflow_groups(int num_cus, int num_dirs, int num_stacked,
         return 0;
     const int kcells = num_dirs * (2 * num_stacked - 1);   // one projection cell per stacked layer above the first
     if (kcells > DF_MAX_KCELLS) return 0;
-    int64_t g = (int64_t)DF_NLS * (num_cus / (kcells * (H / DF_JS)));   // NLS groups per workgroup set
+    int64_t g = (int64_t)DFF_NLS * (num_cus / (kcells * (H / DFF_JS)));   // NLS groups per workgroup set
     if (g > DF_MAX_GROUPS) g = DF_MAX_GROUPS;
     if (g > B) g = B;
     return (int)g;
@@ -1629,9 +1649,19 @@ extern "C" int dagnn_score_parts(float* h, int ld_h, int H, const float* w_key, 
     return dagnn_score_parts_batch(&h, &w_key, 1, ld_h, H, N, stream);
 }
 
-#endif   // !DF_WIDE_TU
+#endif   // !DF_WIDE_TU && !DF_X_TU
 
-#ifdef DF_WIDE_TU
+#if defined(DF_X_TU)
+extern "C" int dagnn_dataflow_run_x(const dagnn_plan* pl, const dagnn_dataflow_args* a, void* stream) {
+    if (!pl || !pl->data || !a || !a->schedule) return DAGNN_EINVAL;
+    if (a->H != 256 && a->H != 320) return DAGNN_EINVAL;
+    if (a->H > 256) {   // (the lean loaders only, as in dagnn_dataflow_run_wide)
+        if (pl->num_edge_feats != 2 || a->vid_mod > 0) return DAGNN_EINVAL;
+        for (int d = 0; d < 2; ++d)
+            for (int i = 0; i < a->num_stacked && i < DAGNN_MAX_STACKED; ++i)
+                if (((a->dir_mask >> d) & 1) && (a->cell[d][i].static_score || !a->cell[d][i].edge_gain || a->cell[d][i].agg != 0)) return DAGNN_EINVAL;
+    }
+#elif defined(DF_WIDE_TU)
 extern "C" int dagnn_dataflow_run_wide(const dagnn_plan* pl, const dagnn_dataflow_args* a, void* stream) {
     if (!pl || !pl->data || !a || !a->schedule) return DAGNN_EINVAL;
     if (a->H <= 256) return DAGNN_EINVAL;
@@ -1643,6 +1673,7 @@ extern "C" int dagnn_dataflow_run_wide(const dagnn_plan* pl, const dagnn_dataflo
 #else
 extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_args* a, void* stream) {
     if (!pl || !pl->data || !a || !a->schedule) return DAGNN_EINVAL;
+    if (a->slices64 && (a->H == 256 || a->H == 320)) return dagnn_dataflow_run_x(pl, a, stream);   // 64-unit slices: csrc/dataflow_x.hip
     if (a->H > 256) return dagnn_dataflow_run_wide(pl, a, stream);   // H = 320: csrc/dataflow_w.hip
 #endif
     const int H = a->H, Ls = a->num_stacked, dir_mask = a->dir_mask & 3, G = a->groups;
@@ -1712,14 +1743,14 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
     S.dbg_wg = a->debug_wg;
     S.status = (const int32_t*)a->plan_status;
     const int32_t* plan = (const int32_t*)pl->data;
-    unsigned grid = (unsigned)(df_sets_for(G) * nc * (H / DF_JS));
+    unsigned grid = (unsigned)(df_sets_for(G) * nc * (H / DFF_JS));
     // XCD-aware placement (optional: the caller names the CU count and lends a tagged table): units = a recurrent cell's
     // slices + the slices of the projection cell reading its rows; bins = the 8 XCDs (num_cus / 8 CUs each, one workgroup
     // per CU); largest units first, first fit; workgroup (slot k of XCD x) = k * 8 + x under the observed dispatch rule.
     // If the units do not fit, the linear mapping stays (and every hand-off store is write-through, as before).
     S.nroles = 0; S.xcc_tab = (gran_t*)a->xcc_table;
     if (a->num_cus >= 8 && a->num_cus <= DF_MAX_WGS && a->xcc_table && df_sets_for(G) < 64 && nc <= 31) {
-        const int NS = H / DF_JS, sets = df_sets_for(G), cap = a->num_cus / 8;
+        const int NS = H / DFF_JS, sets = df_sets_for(G), cap = a->num_cus / 8;
         int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const int xrot = (a->xcd_first % 8 + 8) % 8;   // bin x of the packing = XCD (x + xcd_first) mod 8
         for (int b = 0; b < DF_MAX_WGS; ++b) S.role[b] = DF_IDLE_ROLE;
@@ -1753,7 +1784,11 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
         if (ea != hipSuccess) return DAGNN_EHIP(ea);                                                                     \
         hipLaunchKernelGGL((dataflow_kernel<KPT>), dim3(grid), dim3(DFF_THREADS), df_lds_bytes<KPT>(), st, plan, S);      \
     } while (0)
-#ifdef DF_WIDE_TU
+#if defined(DF_X_TU)
+    // (a persistent kernel: every workgroup must be resident)
+    if (a->num_cus > 0 && (int64_t)grid > a->num_cus && S.nroles == 0) return DAGNN_EINVAL;
+    if (H == 320) DF_LAUNCH(20); else DF_LAUNCH(16);
+#elif defined(DF_WIDE_TU)
     DF_LAUNCH(20);
 #else
     switch (H / 16) {

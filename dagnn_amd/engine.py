@@ -727,9 +727,14 @@ def dataflow_args(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, 
         args.xcc_table = arena.xcc_table(plan.ws.device).data_ptr()
         args.xcd_first = arena.xcd_first
     args.plan_status = plan.status.data_ptr()
+    # 64-unit slices (csrc/dataflow_x.hip): the cell variants its pair loader exists for - two edge features, keys from the states
+    lean = plan.R == 2 and static_score is None and not vid_mod and \
+        all(getattr(cells[(d, i)], "edge_gain", None) is not None and not getattr(cells[(d, i)], "agg", 0) for d in dirs for i in range(L))
+    args.slices64 = 1 if (DF_SLICES64 and H in (256, 320) and lean) else 0
     return args
 
 
+DF_SLICES64 = _env_int("DAGNN_AMD_DF_SLICES64", 0)   # 1: 64 hidden units, 8 compute waves and one stream per workgroup (csrc/dataflow_x.hip)
 DF_WIDE = _env_int("DAGNN_AMD_DF_WIDE", 1)   # 1: hidden sizes 257..320 run 320 wide on the dataflow kernel's 8-wave shape (csrc/dataflow_w.hip)
 
 

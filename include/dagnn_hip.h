@@ -381,6 +381,10 @@ typedef struct dagnn_dataflow_args {
                             * H is neither 256 nor 320) and the kernel writes the state and the six gate-coefficient rows of each
                             * node's record instead of the pre-activations; `gi_out` must be NULL.  The reverse pass then only
                             * adds the external-gradient row (dagnn_bwd_dataflow_args.stat_rows_written) */
+    int slices64;           /* nonzero and H = 256 / 320: the workgroup shape of csrc/dataflow_x.hip - 64 hidden units, 8 compute
+                            * waves and one stream per workgroup, `groups` workgroup sets of (kernel cells x H / 64) workgroups
+                            * (the caller guarantees they fit the device: groups <= 2 * floor(CUs / (cells x H / 32)), what
+                            * dagnn_dataflow_groups returns).  Same schedule, same results */
 } dagnn_dataflow_args;
 
 int dagnn_dataflow_groups(int num_cus, int num_dirs, int num_stacked, int H, int64_t B);
@@ -393,6 +397,7 @@ int dagnn_dataflow_run(const dagnn_plan* plan /* host */, const dagnn_dataflow_a
  * key biases (anything else: DAGNN_EINVAL - the caller keeps such models on the other paths).  dagnn_dataflow_run forwards
  * H > 256 here; dagnn_dataflow_groups / dagnn_pack_dataflow accept H = 320. */
 int dagnn_dataflow_run_wide(const dagnn_plan* plan /* host */, const dagnn_dataflow_args* args /* host */, void* stream);
+int dagnn_dataflow_run_x(const dagnn_plan* plan /* host */, const dagnn_dataflow_args* args /* host */, void* stream);   /* slices64 */
 int dagnn_pack_dataflow(const float* w /* [3H,H] */, float* out /* 3H*H floats */, int H, void* stream);
 /* the same order of the gate-wise transposed matrix W'[g H + j][u] = W[g H + u][j] (reverse sweep, dagnn_bwd_dataflow_run) */
 int dagnn_pack_dataflow_transposed(const float* w /* [3H,H] */, float* out /* 3H*H floats */, int H, void* stream);

@@ -15,7 +15,7 @@ import re
 import sys
 from collections import defaultdict
 
-RECURRENCE = ("dataflow_kernel", "frontier_step_kernel", "frontier_tail_kernel", "frontier_mfma_kernel", "aggregate_rows_kernel")
+RECURRENCE = ("dataflow_kernel", "dataflow64_kernel", "frontier_step_kernel", "frontier_tail_kernel", "frontier_mfma_kernel", "aggregate_rows_kernel")
 
 
 def short(name):

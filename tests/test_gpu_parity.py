@@ -854,6 +854,45 @@ def test_static_rows_from_the_forward_launch_feed_the_reverse_sweep(device, monk
         assert Hh.maxdiff(g, ref) <= 2e-5 * max(float(ref.abs().max()), 1e-3), k
 
 
+@pytest.mark.parametrize("H,L", [(256, 2), (320, 1)])
+def test_sixty_four_unit_slices_are_the_same_pass(device, monkeypatch, H, L):
+    """`DAGNN_AMD_DF_SLICES64=1` (csrc/dataflow_x.hip): the forward dataflow kernel with 64 hidden units, 8 compute waves and one
+    stream per workgroup - the same schedule, packed weights and arithmetic, so logits, loss and every gradient of a training
+    step (its forward writes the reverse sweep's static rows from that shape) agree with the 32-unit shape to the last bit; the
+    entry point really ran."""
+    from dagnn_amd import _lib
+    lib = _lib.load()
+    model = _headline_model(H=H, L=L, V=32, seed=8).to(device)
+    b = synth.code2_batch(14, 96, 125)
+    y = torch.randint(0, 32, (96, 5), generator=torch.Generator().manual_seed(3)).to(device)
+    seen = []
+    orig = lib.dagnn_dataflow_run
+
+    class _Spy(object):
+        def __call__(self, plan, args, stream):
+            seen.append(int(args._obj.slices64))
+            return orig(plan, args, stream)
+    monkeypatch.setattr(lib, "dagnn_dataflow_run", _Spy(), raising=False)
+    got = {}
+    for flag in (0, 1):
+        monkeypatch.setattr(engine, "DF_SLICES64", flag)
+        model.eval()
+        with torch.no_grad():
+            logits = torch.stack(model(b.clone().to(device)))
+        model.check()
+        loss, grads = _train_step(model, b.clone().to(device), y)
+        model.check()
+        got[flag] = (logits.clone(), loss.clone(), {k: v.clone() for k, v in grads.items()})
+    assert 0 in seen and 1 in seen, seen
+    assert torch.equal(got[0][0], got[1][0])
+    assert torch.equal(got[0][1], got[1][1])
+    for k, g in got[1][2].items():
+        if "encoder." in k:   # (torch's embedding backward accumulates with atomics)
+            assert Hh.maxdiff(g, got[0][2][k]) <= 1e-6 * max(1.0, float(got[0][2][k].abs().max())), k
+        else:
+            assert torch.equal(g, got[0][2][k]), k
+
+
 def _degenerate_batch(extra=()):
     """Single-node graphs, a chain, stars with a 200-way fan-in / fan-out, a graph with no edges, a duplicate edge
     (`extra`: more graphs behind them)."""

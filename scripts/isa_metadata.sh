@@ -21,8 +21,8 @@ from collections import Counter
 c = Counter(m.group(1) for l in k for m in [re.match(r'\s*v_writelane_b32 (v\d+),', l)] if m)
 spill = c.most_common(1)[0][0] if c else None
 print("== dataflow_kernel<16>: where the spilled SGPRs (lanes of %s) are read or written, per top-level loop of the kernel" % spill)
-print("   (loops in code order: two start-up loops (placement handshake), the three lean loaders REC0 / RECP / PROJ, the twelve compute-loop instances, then the generic")
-print("    loader's variants, which no benchmarked configuration runs)")
+print("   (loops in code order: the placement handshake and the loader variants - lean REC0 / RECP / PROJ, then the generic ones -, and LAST the")
+print("    eighteen compute-loop instances: 3 cell kinds x {rows handed over in L2 / write-through} x {no extra output / pre-activations / static rows})")
 hdrs = [(i, re.match(r'^(\.LBB\d+_\d+):', l).group(1)) for i, l in enumerate(k) if '=>This Loop Header: Depth=1' in l]
 for i, name in hdrs:
     n, cur = 0, False

@@ -91,6 +91,35 @@ def test_host_only_entry_points_without_gpu():
     assert lib.dagnn_variant_run(ctypes.byref(plan), ctypes.byref(va), ptrs, nl, None) == -22   # plan without data
 
 
+def test_dataflow_argument_structs_carry_the_round6_fields():
+    """`dagnn_dataflow_args.stat_rows` (the forward launch of a training pass writes the reverse sweep's static rows into the
+    buffers passed as `gh_out`; `gi_out` must then be NULL) and `slices64`, `dagnn_bwd_dataflow_args.stat_rows_written`: the
+    ctypes mirrors end where the C structs end, and the one bad value each case plants is refused before any HIP call."""
+    lib = _lib.load()
+    plan = _lib.Plan(64, 0, 4, 3, 1, 2, 0)
+    a = _lib.DataflowArgs()
+    a.num_stacked, a.dir_mask, a.H, a.ld_h, a.gld, a.pld, a.groups, a.epoch = 2, 1, 64, 68, 68, 192, 1, 1
+    a.schedule, a.err = 64, 64
+    for i in range(2):
+        c = a.cell[0][i]
+        c.w_hh = c.b_hh = c.w_key = c.h_out = c.granules = c.edge_gain = 64
+    a.cell[0][0].gi0 = 64
+    a.cell[0][1].w_ih = a.cell[0][1].b_ih = a.cell[0][1].proj_granules = 64
+    a.stat_rows = 1
+    a.cell[0][0].gh_out = a.cell[0][1].gh_out = 64
+    a.cell[0][1].gi_out = 64                      # static rows AND kept pre-activations: refused
+    assert lib.dagnn_dataflow_run(ctypes.byref(plan), ctypes.byref(a), None) == -22
+    a.cell[0][1].gi_out, a.cell[0][1].gh_out = None, None   # a cell without its record buffer
+    assert lib.dagnn_dataflow_run(ctypes.byref(plan), ctypes.byref(a), None) == -22
+    a.cell[0][1].gh_out, a.slices64, a.H = 64, 1, 192       # the 64-unit shape exists for H = 256 / 320: other widths take the 32-unit one
+    a.cell[0][1].gi_out = 64
+    assert lib.dagnn_dataflow_run(ctypes.byref(plan), ctypes.byref(a), None) == -22
+    a.H = 128                                                # ... and its own entry point refuses them
+    assert lib.dagnn_dataflow_run_x(ctypes.byref(plan), ctypes.byref(a), None) == -22
+    assert _lib.DataflowArgs.slices64.offset == ctypes.sizeof(_lib.DataflowArgs) - 8 or _lib.DataflowArgs.slices64.offset == ctypes.sizeof(_lib.DataflowArgs) - 4
+    assert _lib.BwdDataflowArgs.stat_rows_written.offset >= _lib.BwdDataflowArgs.xcd_first.offset + 4
+
+
 def test_engine_refuses_cpu_tensors():
     from dagnn_amd import engine
     with pytest.raises(_lib.DagnnHipError):

@@ -108,6 +108,13 @@ constexpr bool DF_PROF = true;
 constexpr bool DF_PROF = false;
 #endif
 
+// A projection granule: the three input-side pre-activations of one unit of one node behind ONE tag - 16 bytes {tag, r, z, n},
+// stored and loaded as a whole (global_store_dwordx4 / global_load_dwordx4 on 16-byte aligned addresses, write-through stores).
+// The guide promises single-copy atomicity for 8 bytes; for an aligned 16 it was measured (scripts/ubench/tear16.hip: 1.4e10
+// observed value changes across XCDs without a torn read, against 1 % torn on the 8-bytes-off control).  Against three
+// 8-byte granules: a third less hand-off traffic, one load / store / tag check instead of three.
+typedef unsigned pgran_t __attribute__((ext_vector_type(4)));
+
 struct DfCell {
     const float4* w;      // packed slices (dagnn_pack_dataflow): W_hh (recurrent) or W_ih (projection)
     const float* bias;    // [3H] b_hh (recurrent; + b_ih folded by the projection) or b_ih (projection)
@@ -116,9 +123,9 @@ struct DfCell {
     const float* gain;    // [R] or null
     const float* vid;     // [vid_mod] or null
     const float* gi0;     // recurrent, stacked layer 0: [N,3H] input-side pre-activations, else null
-    const gran_t* p_in;   // recurrent, stacked layers > 0: [N,pld] granules of its projection cell, else null
+    const pgran_t* p_in;  // recurrent, stacked layers > 0: [N,pld] projection granules of its projection cell, else null
     float* h_out;         // recurrent: [N,ld_h]
-    gran_t* g_out;        // recurrent: [N,gld] granules of h_out; projection: [N,pld] granules of the pre-activations
+    gran_t* g_out;        // recurrent: [N,gld] granules of h_out; projection: [N,pld] projection granules (pgran_t) of the pre-activations
     const gran_t* g_in;   // projection: granules of the lower stacked layer's states
     float* aux_out;       // training passes: [N,3H] plain copy of the pre-activations this cell computes (recurrent: W_hh a +
                           // b_hh; projection: W_ih u + b_ih), or null
@@ -295,7 +302,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
     int* const err = S.err;
     const gran_t* const g_src = proj ? C.g_in : C.g_out;   // rows this cell reads: the lower layer's / its own states
     const int gld = S.gld, pld = S.pld;
-    const gran_t* const p_in = KIND == DFK_RECP ? C.p_in : nullptr;
+    const pgran_t* const p_in = KIND == DFK_RECP ? C.p_in : nullptr;
     const float* const gi0 = KIND == DFK_REC0 ? C.gi0 : nullptr;
     const float* const sscore = EXTRA ? C.sscore : nullptr;
     const float* const vid = EXTRA ? C.vid : nullptr;
@@ -350,8 +357,8 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
     //    wrong one - measured twice, a memory fault and a silent 0.5 error.
     //    One statement per shape: NN rows x 4 loads (H < 256 repeats the last 512 bytes: same instruction count for
     //    every H), the projection slice or not, no / record / record + gi0 prefetch.
-    struct Sweep { gran_t x[4][4]; gran_t xp[3]; };
-    const unsigned lane8 = 8u * lane, lane31x8 = 8u * (lane & (DFF_JS - 1));
+    struct Sweep { gran_t x[4][4]; pgran_t xp; };
+    const unsigned lane8 = 8u * lane, lanepx16 = 16u * (lane & (DFF_JS - 1));
     constexpr bool has_gi0 = KIND == DFK_REC0;
 #define DF_ROW_LD(e)                                                            \
     "global_load_dwordx2 %[x" #e "0], %[vo], %[b" #e "] offset:0 sc1\n\t"        \
@@ -364,10 +371,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
 #define DF_ROWS_3 DF_ROWS_2 DF_ROW_LD(2)
 #define DF_ROWS_4 DF_ROWS_3 DF_ROW_LD(3)
 #define DF_PROJ_0 ""
-#define DF_PROJ_1                                                   \
-    "global_load_dwordx2 %[p0], %[vp], %[c0] offset:0 sc1\n\t"       \
-    "global_load_dwordx2 %[p1], %[vp], %[c1] offset:0 sc1\n\t"       \
-    "global_load_dwordx2 %[p2], %[vp], %[c2] offset:0 sc1\n\t"
+#define DF_PROJ_1 "global_load_dwordx4 %[p0], %[vp], %[c0] offset:0 sc1\n\t"
     // LDS-DMA: lane l of the first 16 (3 JS / 4) lanes moves 4 (16) bytes to M0 + 4 l (16 l); all lanes are active here
 #define DF_DMA_0 "s_waitcnt vmcnt(0)"
 #define DF_DMA_1                                                                                   \
@@ -385,9 +389,9 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                    [x10] "=v"(W.x[1][0]), [x11] "=v"(W.x[1][1]), [x12] "=v"(W.x[1][2]), [x13] "=v"(W.x[1][3]),             \
                    [x20] "=v"(W.x[2][0]), [x21] "=v"(W.x[2][1]), [x22] "=v"(W.x[2][2]), [x23] "=v"(W.x[2][3]),             \
                    [x30] "=v"(W.x[3][0]), [x31] "=v"(W.x[3][1]), [x32] "=v"(W.x[3][2]), [x33] "=v"(W.x[3][3]),             \
-                   [p0] "=v"(W.xp[0]), [p1] "=v"(W.xp[1]), [p2] "=v"(W.xp[2]), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra), [ga] "+v"(ga)  \
-                 : [vo] "v"(lane8), [vp] "v"(lane31x8), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),            \
-                   [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [rl] "s"(rl), [gl] "s"(gl),    \
+                   [p0] "=v"(W.xp), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra), [ga] "+v"(ga)  \
+                 : [vo] "v"(lane8), [vp] "v"(lanepx16), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),            \
+                   [c0] "s"(c0p), [rl] "s"(rl), [gl] "s"(gl),    \
                    [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3), [gx] "n"(DF_GI_LANES)                                          \
                  : "memory")
 #define DF_CASE(n, p, d) case (n) * 6 + (p) * 3 + (d): DF_TRIP(n, p, d); break;
@@ -464,14 +468,14 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
         constexpr int O1 = (NQ4 > 1 ? 1 : 0) * 512, O2 = (NQ4 > 2 ? 2 : NQ4 - 1) * 512, O3 = (NQ4 - 1) * 512;
         // one trip to memory: the rows pj[0..nn), the projection slice if `pp`, the prefetch group P(b) if `dma`
         // (1: record, 2: record + gi0 slice); returns with every register it loaded valid
-        auto trip = [&](Sweep& W, int nn, bool pp, int dma, const int (&pj)[4], const gran_t* gp_in) {
+        auto trip = [&](Sweep& W, int nn, bool pp, int dma, const int (&pj)[4], const pgran_t* gp_in) {
             // wave-uniform row bases (unused slots: row 0, not loaded); N * gld granules fit 32 bits (host check): one
             // 32-bit multiply + a 64-bit add per row instead of the five-instruction 64-bit product
             const gran_t* b0 = g_src + (unsigned)pj[0] * (unsigned)gld;
             const gran_t* b1 = g_src + (unsigned)pj[1] * (unsigned)gld;
             const gran_t* b2 = g_src + (unsigned)pj[2] * (unsigned)gld;
             const gran_t* b3 = g_src + (unsigned)pj[3] * (unsigned)gld;
-            const gran_t* c0p = gp_in, * c1p = gp_in + H, * c2p = gp_in + 2 * H;
+            const pgran_t* c0p = gp_in;
             const void* ra = rec_src(j + DF_RD);
             const unsigned rl = rec_dst(j + DF_RD);
             const void* ga = has_gi0 ? gi_src(v2) : ra;
@@ -491,7 +495,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
             // input-side pre-activations of the slice from the projection cell: 3 gates x 32 units, lanes 0..31
             bool p_pending = KIND == DFK_RECP;
             float pv[3] = {0.f, 0.f, 0.f};
-            const gran_t* gp_in = p_pending ? p_in + (unsigned)v * (unsigned)pld + sl * DFF_JS : g_src;   // wave-uniform (g_src: never loaded)
+            const pgran_t* gp_in = p_pending ? p_in + (unsigned)v * (unsigned)pld + sl * DFF_JS : reinterpret_cast<const pgran_t*>(g_src);   // wave-uniform (g_src: never loaded)
             // in-edges in chunks of <= 4 (ids and features of the first chunk came with the record).  A node with more
             // than 4 in-edges takes two chunks per trip to memory (all of them finished long ago: the trips, not the
             // data, are what such a row waits for)
@@ -610,12 +614,8 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
                     dma = 0;
                     const bool rows_ok = arrived(A, nn);
                     if (p_pending) {
-                        bool okp = true;
-#pragma unroll
-                        for (int g = 0; g < 3; ++g) okp = okp && (unsigned)(A.xp[g] >> 32) == epoch;
-                        if (__all(okp)) {
-#pragma unroll
-                            for (int g = 0; g < 3; ++g) pv[g] = __uint_as_float((unsigned)A.xp[g]);
+                        if (__all(A.xp.x == epoch)) {
+                            pv[0] = __uint_as_float(A.xp.y); pv[1] = __uint_as_float(A.xp.z); pv[2] = __uint_as_float(A.xp.w);
                             p_pending = false;
                         }
                     }
@@ -662,7 +662,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
             }
         } else {
             const int none[4] = {0, 0, 0, 0};
-            trip(A, 0, false, has_gi0 ? 2 : 1, none, g_src);   // an idle row keeps the cadence: P(b) out, P(b - 1) landed
+            trip(A, 0, false, has_gi0 ? 2 : 1, none, reinterpret_cast<const pgran_t*>(g_src));   // an idle row keeps the cadence: P(b) out, P(b - 1) landed
             if (!slot_free) { df_wait4(dn, b - DF_NSLOT + 1, err, spin_limit); slot_free = true; }
         }
         if (lane == 0) v_s[lw] = v;
@@ -688,7 +688,7 @@ __device__ __forceinline__ void df_loader(const int32_t* __restrict__ plan, cons
 //     branch], the soft-max of a single chunk needs no running rescale, nothing is predicated per lane;
 //   * everything that does not depend on the polled rows happens BEFORE the poll (ring-slot wait, addresses, edge gains);
 //   * rows with more than 4 in-edges take the general chunk loop (online soft-max), as before.
-struct DfSweep { gran_t x[4][5]; gran_t xp[3]; };   // (the fifth column block: H = 320 only)
+struct DfSweep { gran_t x[4][5]; pgran_t xp; };   // (the fifth column block: H = 320 only)
 
 #define DF_TRIP(n, p, d)                                                                                                   \
     asm volatile(DF_ROWS_##n DF_PROJ_##p DF_DMA_##d                                                                        \
@@ -696,9 +696,9 @@ struct DfSweep { gran_t x[4][5]; gran_t xp[3]; };   // (the fifth column block: 
                    [x10] "=v"(W.x[1][0]), [x11] "=v"(W.x[1][1]), [x12] "=v"(W.x[1][2]), [x13] "=v"(W.x[1][3]),             \
                    [x20] "=v"(W.x[2][0]), [x21] "=v"(W.x[2][1]), [x22] "=v"(W.x[2][2]), [x23] "=v"(W.x[2][3]),             \
                    [x30] "=v"(W.x[3][0]), [x31] "=v"(W.x[3][1]), [x32] "=v"(W.x[3][2]), [x33] "=v"(W.x[3][3]),             \
-                   [p0] "=v"(W.xp[0]), [p1] "=v"(W.xp[1]), [p2] "=v"(W.xp[2]), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra), [ga] "+v"(ga)  \
-                 : [vo] "v"(lane8), [vp] "v"(lane31x8), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),            \
-                   [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [rl] "s"(rl), [gl] "s"(gl),    \
+                   [p0] "=v"(W.xp), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra), [ga] "+v"(ga)  \
+                 : [vo] "v"(lane8), [vp] "v"(lanepx16), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),            \
+                   [c0] "s"(c0p), [rl] "s"(rl), [gl] "s"(gl),    \
                    [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3), [gx] "n"(DF_GI_LANES)                                          \
                  : "memory")
 // H = 320: five column blocks per lane
@@ -714,9 +714,9 @@ struct DfSweep { gran_t x[4][5]; gran_t xp[3]; };   // (the fifth column block: 
                    [x10] "=v"(W.x[1][0]), [x11] "=v"(W.x[1][1]), [x12] "=v"(W.x[1][2]), [x13] "=v"(W.x[1][3]), [x14] "=v"(W.x[1][4]), \
                    [x20] "=v"(W.x[2][0]), [x21] "=v"(W.x[2][1]), [x22] "=v"(W.x[2][2]), [x23] "=v"(W.x[2][3]), [x24] "=v"(W.x[2][4]), \
                    [x30] "=v"(W.x[3][0]), [x31] "=v"(W.x[3][1]), [x32] "=v"(W.x[3][2]), [x33] "=v"(W.x[3][3]), [x34] "=v"(W.x[3][4]), \
-                   [p0] "=v"(W.xp[0]), [p1] "=v"(W.xp[1]), [p2] "=v"(W.xp[2]), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra), [ga] "+v"(ga)  \
-                 : [vo] "v"(lane8), [vp] "v"(lane31x8), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),            \
-                   [c0] "s"(c0p), [c1] "s"(c1p), [c2] "s"(c2p), [rl] "s"(rl), [gl] "s"(gl),    \
+                   [p0] "=v"(W.xp), [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec), [ra] "+v"(ra), [ga] "+v"(ga)  \
+                 : [vo] "v"(lane8), [vp] "v"(lanepx16), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3),            \
+                   [c0] "s"(c0p), [rl] "s"(rl), [gl] "s"(gl),    \
                    [o1] "n"(O1), [o2] "n"(O2), [o3] "n"(O3), [o4] "n"(2048), [gx] "n"(DF_GI_LANES)                          \
                  : "memory")
 #define DF_IFC(n, p, d) if constexpr (NN == (n) && PP == (p) && DMA == (d)) { if constexpr (NQ4 == 5) { DF_TRIP5(n, p, d); } else { DF_TRIP(n, p, d); } } else
@@ -724,7 +724,7 @@ struct DfSweep { gran_t x[4][5]; gran_t xp[3]; };   // (the fifth column block: 
 
 struct DfTripArgs {
     const gran_t* b[4];        // wave-uniform row bases
-    const gran_t* c;           // projection slice of the node (gate 0; the gates are H granules apart)
+    const pgran_t* c;          // projection slice of the node (its DFF_JS projection granules)
     const void* ra; unsigned rl;   // prefetch group: record (global source per lane, LDS destination)
     const void* ga; unsigned gl;   //                 gi0 slice
 };
@@ -732,10 +732,10 @@ struct DfTripArgs {
 // one trip to memory: NN rows (+ the projection slice) into W, the prefetch group behind them, the counted wait - ONE asm
 // statement of a static shape (see df_loader)
 template <int NQ4, int H, int NN, int PP, int DMA>
-__device__ __forceinline__ void df_trip(DfSweep& W, const DfTripArgs& T, unsigned lane8, unsigned lane31x8) {
+__device__ __forceinline__ void df_trip(DfSweep& W, const DfTripArgs& T, unsigned lane8, unsigned lanepx16) {
     constexpr int O1 = (NQ4 > 1 ? 1 : 0) * 512, O2 = (NQ4 > 2 ? 2 : NQ4 - 1) * 512, O3 = (NQ4 > 3 ? 3 : NQ4 - 1) * 512;
     const gran_t* b0 = T.b[0]; const gran_t* b1 = T.b[1]; const gran_t* b2 = T.b[2]; const gran_t* b3 = T.b[3];
-    const gran_t* c0p = T.c; const gran_t* c1p = T.c + H; const gran_t* c2p = T.c + 2 * H;
+    const pgran_t* c0p = T.c;
     const void* ra = T.ra; const unsigned rl = T.rl; const void* ga = T.ga; const unsigned gl = T.gl;
     unsigned keep_m0;
     unsigned long long keep_exec;
@@ -752,7 +752,7 @@ __device__ __forceinline__ bool df_landed(const DfSweep& W, unsigned epoch) {
         m = min(min(m, min((unsigned)(W.x[e][0] >> 32), (unsigned)(W.x[e][1] >> 32))), min((unsigned)(W.x[e][2] >> 32), (unsigned)(W.x[e][3] >> 32)));
         if (NQ4 == 5) m = min(m, (unsigned)(W.x[e][4] >> 32));
     }
-    if (PP) m = min(min(m, (unsigned)(W.xp[0] >> 32)), min((unsigned)(W.xp[1] >> 32), (unsigned)(W.xp[2] >> 32)));
+    if (PP) m = min(m, W.xp.x);
     return __builtin_amdgcn_uicmp(m, epoch, 33 /* ICMP_NE */) == 0ull;
 }
 
@@ -777,7 +777,7 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
     int* const err = S.err;
     const gran_t* const g_src = proj ? C.g_in : C.g_out;
     const unsigned gld = (unsigned)S.gld, pld = (unsigned)S.pld;
-    const gran_t* const p_in = KIND == DFK_RECP ? C.p_in : nullptr;
+    const pgran_t* const p_in = KIND == DFK_RECP ? C.p_in : nullptr;
     const float* const gi0 = has_gi0 ? C.gi0 : nullptr;
     const float gain0 = proj ? 0.f : C.gain[0], gain1 = proj ? 0.f : C.gain[1];
     int* const dn = lds.dn + set * DFF_NCW;
@@ -790,7 +790,7 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
         cpos[q] = c + (SEG - KP8) * (c / KP8);
         wk[q] = (!proj && q < NQ4) ? C.wkey[c] : 0.f;
     }
-    const unsigned lane8 = 8u * lane, lane31x8 = 8u * (lane & (DFF_JS - 1));
+    const unsigned lane8 = 8u * lane, lanepx16 = 16u * (lane & (DFF_JS - 1));
     // (a wave serves DFF_RPW rows of every block, one after the other: `lw` and the ring addresses follow the row)
     int lw = w * DFF_RPW;
     int* rec_ring;
@@ -858,7 +858,7 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
         DfTripArgs T;
         T.ra = rec_src(b + DF_RD); T.rl = rec_dst(b + DF_RD);
         T.ga = has_gi0 ? gi_src(v2) : T.ra; T.gl = gi_dst(b + DF_GD);
-        T.b[0] = T.b[1] = T.b[2] = T.b[3] = g_src; T.c = g_src;
+        T.b[0] = T.b[1] = T.b[2] = T.b[3] = g_src; T.c = reinterpret_cast<const pgran_t*>(g_src);
         float acc[NC];
 #pragma unroll
         for (int q = 0; q < NC; ++q) acc[q] = 0.f;
@@ -874,7 +874,7 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
             auto poll = [&](auto nn_c, auto dma_c) {
                 constexpr int NN = decltype(nn_c)::value, DM = decltype(dma_c)::value;
                 if (prof) { t_issue = wall_clock64(); ++polls; }
-                df_trip<NQ4, H, NN, PPK, DM>(A, T, lane8, lane31x8);
+                df_trip<NQ4, H, NN, PPK, DM>(A, T, lane8, lanepx16);
                 if (NN + PPK > 0 && !df_landed<NN, PPK, NQ4>(A, epoch)) {
                     unsigned spins = 0;
                     // (a lost pass leaves the loop BEHIND its trip: with a way out in front of it the rows of the previous trip
@@ -883,7 +883,7 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
                     do {
                         more = df_retry(spins, err, spin_limit);
                         if (prof) { t_issue = wall_clock64(); ++polls; }
-                        df_trip<NQ4, H, NN, PPK, 0>(A, T, lane8, lane31x8);
+                        df_trip<NQ4, H, NN, PPK, 0>(A, T, lane8, lanepx16);
                     } while (more && !df_landed<NN, PPK, NQ4>(A, epoch));
                 }
                 if (prof && DM != 0) {
@@ -1004,10 +1004,10 @@ __device__ __forceinline__ void df_loader_fast(const int32_t* __restrict__ plan,
             for (int q = 0; q < NQ4; ++q) a_row[cpos[q]] = acc[q];
             if (PPK) {   // input-side pre-activations of the slice: lanes l and l + 32 loaded the same granules (same words, same place)
 #pragma unroll
-                for (int g = 0; g < 3; ++g) sbase[Slot::gi_off + lw * (3 * DFF_JS) + g * DFF_JS + (lane & (DFF_JS - 1))] = __uint_as_float((unsigned)A.xp[g]);
+                for (int g = 0; g < 3; ++g) sbase[Slot::gi_off + lw * (3 * DFF_JS) + g * DFF_JS + (lane & (DFF_JS - 1))] = __uint_as_float(A.xp[1 + g]);
             }
         } else {
-            df_trip<NQ4, H, 0, 0, DMA1>(A, T, lane8, lane31x8);   // an idle row keeps the cadence: P(b) out, P(b - 1) landed
+            df_trip<NQ4, H, 0, 0, DMA1>(A, T, lane8, lanepx16);   // an idle row keeps the cadence: P(b) out, P(b - 1) landed
         }
 #undef DF_W
         reinterpret_cast<int*>(sbase + Slot::v_off)[lw] = v;   // (every lane: same word, same value - no lane-0 predicate)
@@ -1280,11 +1280,10 @@ __device__ __forceinline__ void df_compute(const DfArgs& S, const DfCell& C, int
             // (the bound on the node id also covers padding rows, id -1, and a slot that may hold anything once a wait has
             // expired: the pass is lost then, but it must not write outside its buffers)
             if (lane_st && (unsigned)gv < (unsigned)num_nodes) {
-                if (proj) {   // input-side pre-activations of the upper cell: W_ih u + b_ih, gate-major
-                    gran_t* po = g_out + df_idx(gv, pld, unit);
-                    __hip_atomic_store(po, gran_pack(epoch, p_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(po + H, gran_pack(epoch, p_z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(po + 2 * H, gran_pack(epoch, p_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (proj) {   // input-side pre-activations of the upper cell: W_ih u + b_ih - the unit's three gates behind one tag
+                    pgran_t* po = reinterpret_cast<pgran_t*>(g_out) + df_idx(gv, pld, unit);
+                    const pgran_t pv = {epoch, __float_as_uint(p_r), __float_as_uint(p_z), __float_as_uint(p_n)};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(po), "v"(pv) : "memory");
                 } else {
                     // hand-off store first (the consumers poll it): write-through (sc1: the line leaves this XCD's L2, any XCD's
                     // sc1 load finds it in memory), or - all readers are on this XCD - a plain 8-byte store that leaves the line in
@@ -1678,7 +1677,7 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
 #endif
     const int H = a->H, Ls = a->num_stacked, dir_mask = a->dir_mask & 3, G = a->groups;
     if (H <= 0 || (H % 64) || H > DF_TU_MAX_H || Ls <= 0 || Ls > DAGNN_MAX_STACKED || !dir_mask || a->ld_h < H || a->gld < H ||
-        (Ls > 1 && a->pld < 3 * H) || G < 1 || G > DF_MAX_GROUPS || a->epoch == 0 || !a->err)
+        (Ls > 1 && a->pld < H) || G < 1 || G > DF_MAX_GROUPS || a->epoch == 0 || !a->err)
         return DAGNN_EINVAL;
     if (pl->B == 0 || pl->N == 0) return DAGNN_OK;
     // row offsets inside the granule buffers are 32-bit in the kernel (granules: 8 bytes each)
@@ -1704,6 +1703,7 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
                 P.wkey = nullptr; P.sscore = nullptr; P.gain = nullptr; P.vid = nullptr; P.gi0 = nullptr; P.p_in = nullptr;
                 P.agg_w = nullptr; P.agg_b = nullptr; P.agg = 0;
                 P.h_out = nullptr;
+                if ((uintptr_t)c.proj_granules & 15) return DAGNN_EINVAL;
                 P.g_out = (gran_t*)c.proj_granules;
                 P.g_in = (const gran_t*)a->cell[d][i - 1].granules;
                 P.aux_out = c.gi_out;
@@ -1717,7 +1717,7 @@ extern "C" int dagnn_dataflow_run(const dagnn_plan* pl, const dagnn_dataflow_arg
             K.gain = pl->num_edge_feats > 0 ? c.edge_gain : nullptr;
             K.vid = a->vid_mod > 0 ? c.vid_bias : nullptr;
             K.gi0 = i == 0 ? c.gi0 : nullptr;
-            K.p_in = i > 0 ? (const gran_t*)c.proj_granules : nullptr;
+            K.p_in = i > 0 ? (const pgran_t*)c.proj_granules : nullptr;
             K.h_out = c.h_out;
             K.g_out = (gran_t*)c.granules;
             K.g_in = nullptr;

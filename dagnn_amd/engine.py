@@ -678,7 +678,8 @@ def dataflow_args(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, 
         args = DataflowArgs()
     gld = H + H // 16
     keys = [(d, i) for d in dirs for i in range(L)] + [("p", d, i) for d in dirs for i in range(1, L)]
-    gran, epoch, err = arena.get(keys, plan.N, gld, plan.ws.device, widths={k: 3 * H for k in keys if k[0] == "p"})
+    # (projection granules: 16 bytes {tag, r, z, n} per unit = 2 H words of 8 bytes per node)
+    gran, epoch, err = arena.get(keys, plan.N, gld, plan.ws.device, widths={k: 2 * H for k in keys if k[0] == "p"})
     mask = 0
     for d in dirs:
         mask |= 1 << d
@@ -715,7 +716,7 @@ def dataflow_args(plan: PlanHandle, dirs: Sequence[int], L: int, H: int, cells, 
                     preact[("gi", d, i)] = torch.empty(plan.N, 3 * H, dtype=torch.float32, device=plan.ws.device)
                     fc.gi_out = preact[("gi", d, i)].data_ptr()
     args.num_stacked, args.dir_mask, args.H, args.ld_h, args.gld = L, mask, H, h[dirs[0]][0].shape[1], gld
-    args.pld = 3 * H
+    args.pld = H   # (row pitch of the projection granules, in 16-byte granules)
     args.vid_mod, args.groups, args.epoch = int(vid_mod), int(groups), epoch
     sched = plan.dataflow_schedule(groups)
     args.schedule, args.err = sched.data_ptr(), err.data_ptr()

@@ -333,8 +333,9 @@ typedef struct dagnn_dataflow_cell {
     const float* gi0;       /* [N,3H] W_ih x + b_ih (stacked layer 0 only) */
     float* h_out;           /* [N,ld_h] */
     void* granules;         /* uint64 [N,gld] */
-    void* proj_granules;    /* stacked layers > 0: uint64 [N,pld] (pld >= 3H), the hand-off buffer of the cell's input-side
-                             * pre-activations W_ih u + b_ih (same zero-init / epoch contract as `granules`); else NULL */
+    void* proj_granules;    /* stacked layers > 0: 16-byte granules {tag, r, z, n} [N,pld] (pld >= H, 16-byte aligned), the hand-off
+                             * buffer of the cell's input-side pre-activations W_ih u + b_ih, one granule per unit (same
+                             * zero-init / epoch contract as `granules`); else NULL */
     float* gh_out;          /* NULL, or [N,3H]: the hidden-side pre-activations W_hh a + b_hh of every node as the gates saw them */
     float* gi_out;          /* NULL, or [N,3H] (stacked layers > 0): the input-side pre-activations as plain floats - what a
                              * training pass keeps for its reverse sweep instead of recomputing both with GEMMs */

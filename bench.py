@@ -763,7 +763,7 @@ def main():
                     "traffic_split": ({"fetch_bytes": rec.get("fetch_bytes_per_forward"), "write_bytes": rec.get("write_bytes_per_forward"),
                                        "what": "FETCH_SIZE (doubled: MI355X_MICROARCH.md, HBM) = the loaders' polls of predecessor and "
                                                "projection granules that miss the XCD's L2 + weights / records / gi0; WRITE_SIZE = state "
-                                               "rows (plain) + their granules + the [N, 3H] projection granules"}
+                                               "rows (plain) + their 8-byte granules + the [N, H] 16-byte projection granules {tag, r, z, n}"}
                                       if traffic is not None else None),
                     "us_per_topological_layer": round(ms_fwd * 1e3 / max(T + L - 1, 1), 3),
                     "schedule": "dataflow" if df else model.schedule,

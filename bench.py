@@ -577,6 +577,28 @@ def main():
                                "(attach_plan): no plan / schedule kernels inside the step",
                        "ms_per_step": round(float(tp) / args.steps * 1e3, 4),
                        "graphs_per_s": round(world * B * args.steps / float(tp), 1)}
+    # consecutive batches on TWO HIP streams (what `--streams 2` times as `value`): the plan / schedule / encoder launches, the heads and
+    # the host side of batch i + 1 run beside the recurrence of batch i; the all-resident recurrence launches themselves stay ordered
+    # device-wide (engine.persistent_launch).  Reported next to the headline - `value` stays one batch strictly after the other.
+    overlap_res = None
+    if args.streams == 1 and model.schedule == "lockstep" and rank == 0 and world == 1:
+        two = [torch.cuda.Stream(device) for _ in range(2)]
+        oin = fresh_inputs(master, args.warmup + args.steps)
+        with torch.no_grad():
+            for i in range(args.warmup):
+                with torch.cuda.stream(two[i % 2]):
+                    model(oin[i])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.warmup, args.warmup + args.steps):
+                with torch.cuda.stream(two[i % 2]):
+                    model(oin[i])
+            torch.cuda.synchronize()
+            to_ = time.perf_counter() - t0
+        model.check()
+        overlap_res = {"what": "the same K forward(G) calls issued alternately on two HIP streams (bench.py --streams 2): the front and the "
+                               "heads of one batch beside the recurrence of the other; never `value`",
+                       "ms_per_step": round(to_ / args.steps * 1e3, 4), "graphs_per_s": round(B * args.steps / to_, 1)}
     # the same forward on round 5's front of the recurrence: 13 plan / schedule launches, the encoder, the [N, emb] x [emb, 3H]
     # input GEMM of both directions - no fused pipeline, no tables folded through W_ih.  Reported next to the headline so that
     # what the folding and the fusion buy stays visible; never `value`.
@@ -787,6 +809,8 @@ def main():
             result["loader_side_plan"] = planned_res
         if front_res is not None:
             result["separate_calls_no_folding"] = front_res
+        if overlap_res is not None:
+            result["two_streams"] = overlap_res
         if strong_res is not None:
             result["strong_scaling"] = strong_res
         if multi_res is not None:
